@@ -1,0 +1,128 @@
+/* paillier_hip.h -- C ABI of the MI355X batched Paillier engine (libpaillier_hip.so).
+ *
+ * This is the drop-in boundary for the hot path of sachaservan/paillier: the reference has no FFI
+ * seam of its own; every hot-path call bottoms out in github.com/ncw/gmp
+ * (`Exp`, `Mul`+`Mod`, `ModInverse`).  Each entry point below replaces the per-ciphertext loop a
+ * Go caller would write around ONE exported reference method, for a whole batch, and cites that
+ * method.  INTEGRATION.md shows the cgo binding.
+ *
+ * Operand format (what Go can produce from gmp.Int.Bytes()): unsigned big-endian integers,
+ * ELEMENT-MAJOR with a fixed byte stride per element, left-padded with zero bytes.
+ * `mem` says where the buffers live: PGPU_MEM_HOST (copied by the library) or PGPU_MEM_DEVICE
+ * (HBM pointers on the context's device; nothing is copied).
+ *
+ * All functions return PGPU_OK (0) or a negative error; pgpu_last_error() gives the text.
+ * Every batch function launches HIP kernels on the context's stream and blocks until the
+ * results are in the output buffers.  There is no CPU fallback: without a gfx950 device,
+ * pgpu_ctx_create fails with PGPU_ERR_NO_DEVICE.
+ */
+#ifndef PAILLIER_HIP_H
+#define PAILLIER_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define PGPU_OK 0
+#define PGPU_ERR_INVALID (-1)       /* bad argument (size, level, null pointer, even modulus ...) */
+#define PGPU_ERR_NO_DEVICE (-2)     /* no HIP device / not gfx950 */
+#define PGPU_ERR_HIP (-3)           /* HIP runtime error (see pgpu_last_error) */
+#define PGPU_ERR_UNSUPPORTED (-4)   /* modulus width or level not built */
+#define PGPU_ERR_NOT_INVERTIBLE (-5)/* ModInverse of a non-unit (undefined in the reference) */
+#define PGPU_ERR_THRESHOLD (-6)     /* "Threshold not meet" / duplicate share ids (thresholdkey.go:77-89) */
+
+#define PGPU_MEM_HOST 0
+#define PGPU_MEM_DEVICE 1
+
+/* paillier.go:17-23 */
+#define PGPU_LEVEL_ONE 0
+#define PGPU_LEVEL_TWO 1
+
+/* pgpu_decrypt flags */
+#define PGPU_DECRYPT_DEFAULT 0      /* CRT over p^2, q^2 when (n, lambda) factor n, else generic */
+#define PGPU_DECRYPT_NO_CRT 1       /* the reference's formula verbatim: c^lambda mod n^(s+1), L, * lambda^-1 */
+
+/* per-lane status bits (int32 array, optional) */
+#define PGPU_LANE_OK 0
+#define PGPU_LANE_NONUNIT 1         /* gcd(c, n) != 1: lane was recomputed on the generic path */
+
+typedef struct pgpu_ctx pgpu_ctx;
+typedef struct pgpu_pubkey pgpu_pubkey;
+typedef struct pgpu_seckey pgpu_seckey;
+typedef struct pgpu_modulus pgpu_modulus;
+
+const char* pgpu_last_error(void);
+const char* pgpu_version(void);
+
+/* device = HIP device ordinal; stream = hipStream_t to launch on, or NULL for the default stream. */
+int pgpu_ctx_create(int device, void* stream, pgpu_ctx** out);
+void pgpu_ctx_destroy(pgpu_ctx* ctx);
+/* Timing of the dominant (modexp VM) kernel of the last batch call, measured with HIP events on
+ * the context's stream: milliseconds, number of launches, and 28-bit-limb multiply-adds executed. */
+int pgpu_ctx_last_profile(pgpu_ctx* ctx, double* vm_ms, int* vm_launches, double* vm_mads);
+
+/* ---- keys ---------------------------------------------------------------------------------- */
+
+/* PublicKey{N,G,H,K} (paillier.go:46-57).  H and K may be NULL/0 when alternative encryption is
+ * not used.  n^2, n^3 and all Montgomery constants are precomputed here, immutably (the reference
+ * caches them lazily and racily: paillier.go:72-90). */
+int pgpu_pubkey_create(pgpu_ctx* ctx, const uint8_t* n_be, size_t n_len, const uint8_t* g_be, size_t g_len,
+                       const uint8_t* h_be, size_t h_len, const uint8_t* k_be, size_t k_len, pgpu_pubkey** out);
+void pgpu_pubkey_destroy(pgpu_pubkey* pk);
+/* byte length of n^s (plaintexts) and n^(s+1) (ciphertexts) for the level: the natural strides */
+size_t pgpu_pubkey_plain_bytes(const pgpu_pubkey* pk, int level);
+size_t pgpu_pubkey_cipher_bytes(const pgpu_pubkey* pk, int level);
+
+/* SecretKey{PublicKey; Lambda} (paillier.go:60-63).  p and q are recovered from (n, lambda = phi(n))
+ * to enable CRT; if lambda is not phi(n) the generic path is used. */
+int pgpu_seckey_create(pgpu_ctx* ctx, const pgpu_pubkey* pk, const uint8_t* lambda_be, size_t lambda_len,
+                       pgpu_seckey** out);
+void pgpu_seckey_destroy(pgpu_seckey* sk);
+int pgpu_seckey_has_crt(const pgpu_seckey* sk);
+
+/* ---- Paillier batch operations --------------------------------------------------------------- */
+
+/* PublicKey.EncryptWithRAtLevel (paillier.go:206-218), for i in [0,batch):
+ *   c[i] = G^m[i] * r[i]^(n^s) mod n^(s+1)                                                        */
+int pgpu_encrypt_with_r(const pgpu_pubkey* pk, int level, size_t batch, const uint8_t* m, size_t m_stride,
+                        const uint8_t* r, size_t r_stride, uint8_t* c, size_t c_stride, int mem);
+
+/* SecretKey.Decrypt (paillier.go:292-303): m[i] = L_s(c[i]^lambda mod n^(s+1)) * lambda^-1 mod n^s.
+ * status (optional, host int32[batch]) receives PGPU_LANE_* bits. */
+int pgpu_decrypt(const pgpu_seckey* sk, int level, size_t batch, const uint8_t* c, size_t c_stride, uint8_t* m,
+                 size_t m_stride, int mem, int flags, int32_t* status);
+
+/* PublicKey.Add on two ciphertext vectors (operations.go:11-29 with two operands):
+ *   out[i] = a[i] * b[i] mod n^(s+1)                                                              */
+int pgpu_add(const pgpu_pubkey* pk, int level, size_t batch, const uint8_t* a, size_t a_stride, const uint8_t* b,
+             size_t b_stride, uint8_t* out, size_t out_stride, int mem);
+
+/* PublicKey.ConstMult (operations.go:58-64): out[i] = c[i]^k mod n^(s+1).
+ * k_stride == 0: one shared k of k_len bytes; otherwise k[i] at k + i*k_stride, k_len bytes each. */
+int pgpu_const_mult(const pgpu_pubkey* pk, int level, size_t batch, const uint8_t* c, size_t c_stride,
+                    const uint8_t* k, size_t k_len, size_t k_stride, uint8_t* out, size_t out_stride, int mem);
+
+/* ---- generic modular batch primitives (the gmp.Int seam: Exp / Mul+Mod) ------------------------ */
+
+/* Load an odd modulus (big-endian).  Precomputes -N^-1 mod 2^28, R mod N, R^2 mod N, R^3 mod N. */
+int pgpu_modulus_create(pgpu_ctx* ctx, const uint8_t* n_be, size_t n_len, pgpu_modulus** out);
+void pgpu_modulus_destroy(pgpu_modulus* mod);
+size_t pgpu_modulus_bytes(const pgpu_modulus* mod);
+
+/* gmp.Int.Exp(base, e, N) for a batch: out[i] = base[i]^e mod N (e == 0 -> 1).
+ * e_stride == 0: shared exponent; otherwise one exponent per element.  base may be >= N
+ * (up to twice the modulus width), as with mpz_powm. */
+int pgpu_modexp(const pgpu_modulus* mod, size_t batch, const uint8_t* base, size_t base_stride, size_t base_len,
+                const uint8_t* e, size_t e_len, size_t e_stride, uint8_t* out, size_t out_stride, int mem);
+
+/* new(gmp.Int).Mod(new(gmp.Int).Mul(a, b), N) for a batch. */
+int pgpu_modmul(const pgpu_modulus* mod, size_t batch, const uint8_t* a, size_t a_stride, size_t a_len,
+                const uint8_t* b, size_t b_stride, size_t b_len, uint8_t* out, size_t out_stride, int mem);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* PAILLIER_HIP_H */

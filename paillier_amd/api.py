@@ -1,0 +1,289 @@
+"""ctypes binding of include/paillier_hip.h, mirroring the reference's Go API for the hot path.
+
+Reference methods mirrored (file:line in /root/reference):
+  PublicKey.EncryptWithR / EncryptWithRAtLevel   paillier.go:185,206
+  SecretKey.Decrypt                              paillier.go:292
+  PublicKey.Add / ConstMult                      operations.go:11,58
+  gmp.Int.Exp / Mul+Mod                          (ncw/gmp seam)
+Batch variants take and return Python ints (tests) or raw fixed-stride big-endian buffers (bench).
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+from typing import List, Optional, Sequence
+
+import numpy as np
+
+ENC_LEVEL_ONE = 0
+ENC_LEVEL_TWO = 1
+MEM_HOST = 0
+MEM_DEVICE = 1
+DECRYPT_DEFAULT = 0
+DECRYPT_NO_CRT = 1
+
+
+class PaillierHipError(RuntimeError):
+    def __init__(self, code: int, msg: str):
+        super().__init__(f"[{code}] {msg}")
+        self.code = code
+
+
+def library_path() -> str:
+    return os.path.join(os.path.dirname(os.path.abspath(__file__)), "libpaillier_hip.so")
+
+
+_lib = None
+
+_u8p = C.POINTER(C.c_uint8)
+_vp = C.c_void_p
+_sz = C.c_size_t
+_int = C.c_int
+
+# name -> (restype, argtypes); every symbol include/paillier_hip.h declares
+SIGNATURES = {
+    "pgpu_last_error": (C.c_char_p, []),
+    "pgpu_version": (C.c_char_p, []),
+    "pgpu_ctx_create": (_int, [_int, _vp, C.POINTER(_vp)]),
+    "pgpu_ctx_destroy": (None, [_vp]),
+    "pgpu_ctx_last_profile": (_int, [_vp, C.POINTER(C.c_double), C.POINTER(_int), C.POINTER(C.c_double)]),
+    "pgpu_pubkey_create": (_int, [_vp, _vp, _sz, _vp, _sz, _vp, _sz, _vp, _sz, C.POINTER(_vp)]),
+    "pgpu_pubkey_destroy": (None, [_vp]),
+    "pgpu_pubkey_plain_bytes": (_sz, [_vp, _int]),
+    "pgpu_pubkey_cipher_bytes": (_sz, [_vp, _int]),
+    "pgpu_seckey_create": (_int, [_vp, _vp, _vp, _sz, C.POINTER(_vp)]),
+    "pgpu_seckey_destroy": (None, [_vp]),
+    "pgpu_seckey_has_crt": (_int, [_vp]),
+    "pgpu_encrypt_with_r": (_int, [_vp, _int, _sz, _vp, _sz, _vp, _sz, _vp, _sz, _int]),
+    "pgpu_decrypt": (_int, [_vp, _int, _sz, _vp, _sz, _vp, _sz, _int, _int, _vp]),
+    "pgpu_add": (_int, [_vp, _int, _sz, _vp, _sz, _vp, _sz, _vp, _sz, _int]),
+    "pgpu_const_mult": (_int, [_vp, _int, _sz, _vp, _sz, _vp, _sz, _sz, _vp, _sz, _int]),
+    "pgpu_modulus_create": (_int, [_vp, _vp, _sz, C.POINTER(_vp)]),
+    "pgpu_modulus_destroy": (None, [_vp]),
+    "pgpu_modulus_bytes": (_sz, [_vp]),
+    "pgpu_modexp": (_int, [_vp, _sz, _vp, _sz, _sz, _vp, _sz, _sz, _vp, _sz, _int]),
+    "pgpu_modmul": (_int, [_vp, _sz, _vp, _sz, _sz, _vp, _sz, _sz, _vp, _sz, _int]),
+}
+
+
+def load_library():
+    """Loads libpaillier_hip.so; raises if it has not been built (there is no fallback)."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    path = library_path()
+    if not os.path.exists(path):
+        raise PaillierHipError(-100, f"{path} not found: run `python -c 'import __graft_entry__ as g; g.build()'` first")
+    lib = C.CDLL(path)
+    for name, (res, args) in SIGNATURES.items():
+        fn = getattr(lib, name)
+        fn.restype = res
+        fn.argtypes = args
+    _lib = lib
+    return lib
+
+
+def _check(rc: int):
+    if rc != 0:
+        raise PaillierHipError(rc, load_library().pgpu_last_error().decode())
+
+
+def _be(v: int, n: Optional[int] = None) -> bytes:
+    if n is None:
+        n = max(1, (v.bit_length() + 7) // 8)
+    return int(v).to_bytes(n, "big")
+
+
+def ints_to_be(vals: Sequence[int], stride: int) -> np.ndarray:
+    """Python ints -> uint8[batch, stride], big-endian, left-padded (what Go's Bytes() + padding gives)."""
+    buf = b"".join(int(v).to_bytes(stride, "big") for v in vals)
+    return np.frombuffer(buf, dtype=np.uint8).reshape(len(vals), stride).copy()
+
+
+def be_to_ints(arr: np.ndarray) -> List[int]:
+    raw = arr.tobytes()
+    stride = arr.shape[1]
+    return [int.from_bytes(raw[i * stride:(i + 1) * stride], "big") for i in range(arr.shape[0])]
+
+
+def _ptr(a) -> int:
+    if isinstance(a, np.ndarray):
+        return a.ctypes.data
+    return int(a)  # raw device pointer (e.g. torch.Tensor.data_ptr())
+
+
+class Context:
+    """One device + stream.  `stream` is a hipStream_t handle (e.g. torch.cuda.current_stream().cuda_stream)."""
+
+    def __init__(self, device: int = 0, stream: Optional[int] = None):
+        self.lib = load_library()
+        h = _vp()
+        _check(self.lib.pgpu_ctx_create(device, _vp(stream or 0), C.byref(h)))
+        self.h = h
+        self.device = device
+
+    def last_profile(self):
+        ms, n, mads = C.c_double(), C.c_int(), C.c_double()
+        _check(self.lib.pgpu_ctx_last_profile(self.h, C.byref(ms), C.byref(n), C.byref(mads)))
+        return {"vm_ms": ms.value, "vm_launches": n.value, "vm_mads": mads.value}
+
+    def close(self):
+        if self.h:
+            self.lib.pgpu_ctx_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+class Modulus:
+    """The gmp.Int seam: batched Exp(x, e, N) and Mod(Mul(a, b), N)."""
+
+    def __init__(self, ctx: Context, n: int):
+        self.ctx, self.n = ctx, n
+        h = _vp()
+        b = _be(n)
+        _check(ctx.lib.pgpu_modulus_create(ctx.h, b, len(b), C.byref(h)))
+        self.h = h
+        self.nbytes = ctx.lib.pgpu_modulus_bytes(h)
+
+    def exp_batch(self, bases: Sequence[int], e, base_bytes: Optional[int] = None) -> List[int]:
+        """e: one int (shared exponent) or a sequence (one per base)."""
+        lib = self.ctx.lib
+        bl = base_bytes or self.nbytes
+        bb = ints_to_be(bases, bl)
+        out = np.zeros((len(bases), self.nbytes), dtype=np.uint8)
+        if isinstance(e, int):
+            eb = np.frombuffer(_be(e), dtype=np.uint8).copy()
+            el, es = eb.size, 0
+        else:
+            el = max(1, max((int(v).bit_length() + 7) // 8 for v in e))
+            eb = ints_to_be(e, el)
+            es = el
+        _check(lib.pgpu_modexp(self.h, len(bases), _ptr(bb), bl, bl, _ptr(eb), el, es, _ptr(out), self.nbytes, MEM_HOST))
+        return be_to_ints(out)
+
+    def mul_batch(self, a: Sequence[int], b: Sequence[int]) -> List[int]:
+        lib = self.ctx.lib
+        ab, bb = ints_to_be(a, self.nbytes), ints_to_be(b, self.nbytes)
+        out = np.zeros((len(a), self.nbytes), dtype=np.uint8)
+        _check(lib.pgpu_modmul(self.h, len(a), _ptr(ab), self.nbytes, self.nbytes, _ptr(bb), self.nbytes, self.nbytes,
+                               _ptr(out), self.nbytes, MEM_HOST))
+        return be_to_ints(out)
+
+    def __del__(self):
+        try:
+            if self.h:
+                self.ctx.lib.pgpu_modulus_destroy(self.h)
+                self.h = None
+        except Exception:
+            pass
+
+
+class PublicKey:
+    """paillier.go:46-57 PublicKey{N, G, H, K}; batch variants of the exported methods."""
+
+    def __init__(self, ctx: Context, N: int, G: Optional[int] = None, H: Optional[int] = None, K: Optional[int] = None):
+        self.ctx = ctx
+        self.N, self.G, self.H, self.K = N, (N + 1 if G is None else G), H, K
+        nb, gb = _be(N), _be(self.G)
+        hb = _be(H) if H else None
+        kb = _be(K) if K else None
+        h = _vp()
+        _check(ctx.lib.pgpu_pubkey_create(ctx.h, nb, len(nb), gb, len(gb), hb, len(hb) if hb else 0,
+                                          kb, len(kb) if kb else 0, C.byref(h)))
+        self.h = h
+
+    def plain_bytes(self, level: int = ENC_LEVEL_ONE) -> int:
+        return self.ctx.lib.pgpu_pubkey_plain_bytes(self.h, level)
+
+    def cipher_bytes(self, level: int = ENC_LEVEL_ONE) -> int:
+        return self.ctx.lib.pgpu_pubkey_cipher_bytes(self.h, level)
+
+    # -- raw-buffer forms (host numpy arrays or device pointers) -----------------------------------
+    def encrypt_with_r_raw(self, batch, m, m_stride, r, r_stride, c, c_stride, mem=MEM_HOST, level=ENC_LEVEL_ONE):
+        _check(self.ctx.lib.pgpu_encrypt_with_r(self.h, level, batch, _ptr(m), m_stride, _ptr(r), r_stride, _ptr(c),
+                                                c_stride, mem))
+
+    # -- int forms ----------------------------------------------------------------------------------
+    def EncryptWithRBatch(self, ms: Sequence[int], rs: Sequence[int], level: int = ENC_LEVEL_ONE) -> List[int]:
+        """paillier.go:206-218 for each (m, r)."""
+        pb, cb = self.plain_bytes(level), self.cipher_bytes(level)
+        mb, rb = ints_to_be(ms, pb), ints_to_be(rs, pb)
+        out = np.zeros((len(ms), cb), dtype=np.uint8)
+        self.encrypt_with_r_raw(len(ms), mb, pb, rb, pb, out, cb, MEM_HOST, level)
+        return be_to_ints(out)
+
+    def AddBatch(self, a: Sequence[int], b: Sequence[int], level: int = ENC_LEVEL_ONE) -> List[int]:
+        """operations.go:11-29 with two operands, element-wise over the batch."""
+        cb = self.cipher_bytes(level)
+        ab, bb = ints_to_be(a, cb), ints_to_be(b, cb)
+        out = np.zeros((len(a), cb), dtype=np.uint8)
+        _check(self.ctx.lib.pgpu_add(self.h, level, len(a), _ptr(ab), cb, _ptr(bb), cb, _ptr(out), cb, MEM_HOST))
+        return be_to_ints(out)
+
+    def ConstMultBatch(self, cts: Sequence[int], k, level: int = ENC_LEVEL_ONE) -> List[int]:
+        """operations.go:58-64; k is one int (shared) or one per ciphertext."""
+        cb = self.cipher_bytes(level)
+        cbuf = ints_to_be(cts, cb)
+        out = np.zeros((len(cts), cb), dtype=np.uint8)
+        if isinstance(k, int):
+            kb = np.frombuffer(_be(k), dtype=np.uint8).copy()
+            kl, ks = kb.size, 0
+        else:
+            kl = max(1, max((int(v).bit_length() + 7) // 8 for v in k))
+            kb = ints_to_be(k, kl)
+            ks = kl
+        _check(self.ctx.lib.pgpu_const_mult(self.h, level, len(cts), _ptr(cbuf), cb, _ptr(kb), kl, ks, _ptr(out), cb,
+                                            MEM_HOST))
+        return be_to_ints(out)
+
+    def __del__(self):
+        try:
+            if self.h:
+                self.ctx.lib.pgpu_pubkey_destroy(self.h)
+                self.h = None
+        except Exception:
+            pass
+
+
+class SecretKey:
+    """paillier.go:60-63 SecretKey{PublicKey; Lambda}."""
+
+    def __init__(self, ctx: Context, pk: PublicKey, Lambda: int):
+        self.ctx, self.pk, self.Lambda = ctx, pk, Lambda
+        lb = _be(Lambda)
+        h = _vp()
+        _check(ctx.lib.pgpu_seckey_create(ctx.h, pk.h, lb, len(lb), C.byref(h)))
+        self.h = h
+
+    @property
+    def has_crt(self) -> bool:
+        return bool(self.ctx.lib.pgpu_seckey_has_crt(self.h))
+
+    def decrypt_raw(self, batch, c, c_stride, m, m_stride, mem=MEM_HOST, level=ENC_LEVEL_ONE, flags=DECRYPT_DEFAULT,
+                    status: Optional[np.ndarray] = None):
+        _check(self.ctx.lib.pgpu_decrypt(self.h, level, batch, _ptr(c), c_stride, _ptr(m), m_stride, mem, flags,
+                                         _ptr(status) if status is not None else None))
+
+    def DecryptBatch(self, cts: Sequence[int], level: int = ENC_LEVEL_ONE, flags: int = DECRYPT_DEFAULT,
+                     return_status: bool = False):
+        """paillier.go:292-303 for each ciphertext."""
+        pb, cb = self.pk.plain_bytes(level), self.pk.cipher_bytes(level)
+        cbuf = ints_to_be(cts, cb)
+        out = np.zeros((len(cts), pb), dtype=np.uint8)
+        status = np.zeros(len(cts), dtype=np.int32)
+        self.decrypt_raw(len(cts), cbuf, cb, out, pb, MEM_HOST, level, flags, status)
+        res = be_to_ints(out)
+        return (res, status) if return_status else res
+
+    def __del__(self):
+        try:
+            if self.h:
+                self.ctx.lib.pgpu_seckey_destroy(self.h)
+                self.h = None
+        except Exception:
+            pass

@@ -1,0 +1,902 @@
+// capi.cpp -- C ABI (include/paillier_hip.h) of the batched Paillier engine: contexts, keys,
+// Montgomery constants, VM program generation and kernel orchestration.  Host code here runs once
+// per key or once per batch call; everything per ciphertext happens in kernels.hip on the GPU.
+#include <hip/hip_runtime.h>
+#include <stdarg.h>
+#include <stdio.h>
+#include <string.h>
+#include <memory>
+#include <string>
+#include <vector>
+
+#include "../../include/paillier_hip.h"
+#include "hostbig.hpp"
+#include "kernels.h"
+
+using hostbig::BigU;
+
+namespace {
+
+constexpr int LB = 28;
+thread_local std::string g_err;
+
+int fail(int code, const char* fmt, ...) {
+  char buf[512];
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(buf, sizeof buf, fmt, ap);
+  va_end(ap);
+  g_err = buf;
+  return code;
+}
+
+struct HipError { hipError_t e; const char* what; };
+#define HIPCHK(x)                                                      \
+  do {                                                                 \
+    hipError_t e_ = (x);                                               \
+    if (e_ != hipSuccess) throw HipError{e_, #x};                      \
+  } while (0)
+
+struct ApiError { int code; std::string msg; };
+[[noreturn]] void api_throw(int code, const std::string& m) { throw ApiError{code, m}; }
+
+size_t round_up(size_t v, size_t m) { return (v + m - 1) / m * m; }
+
+}  // namespace
+
+// ------------------------------------------------------------------------------------------------
+// Context: device, stream, workspace pool, profile events
+// ------------------------------------------------------------------------------------------------
+struct pgpu_ctx {
+  int device = 0;
+  hipStream_t stream = nullptr;
+  // workspace: list of chunks, bump allocated, reset per API call
+  struct Chunk { char* p; size_t cap; size_t used; };
+  std::vector<Chunk> chunks;
+  std::vector<std::vector<uint32_t>> host_keep;  // host buffers that async copies read from
+  // profile of the last call
+  struct Ev { hipEvent_t a, b; double mads; };
+  std::vector<Ev> evs;
+  size_t evs_used = 0;
+
+  void bind() { HIPCHK(hipSetDevice(device)); }
+
+  void reset_ws() {
+    if (chunks.size() > 1) {  // consolidate into one chunk of the total size
+      HIPCHK(hipStreamSynchronize(stream));
+      size_t total = 0;
+      for (auto& c : chunks) { total += c.cap; HIPCHK(hipFree(c.p)); }
+      chunks.clear();
+      Chunk c{nullptr, round_up(total, 1 << 20), 0};
+      HIPCHK(hipMalloc((void**)&c.p, c.cap));
+      chunks.push_back(c);
+    }
+    for (auto& c : chunks) c.used = 0;
+    host_keep.clear();
+    evs_used = 0;
+  }
+  void* ws(size_t bytes) {
+    bytes = round_up(bytes ? bytes : 1, 256);
+    for (auto& c : chunks)
+      if (c.cap - c.used >= bytes) { void* p = c.p + c.used; c.used += bytes; return p; }
+    Chunk c{nullptr, round_up(bytes, 64 << 20), bytes};
+    HIPCHK(hipMalloc((void**)&c.p, c.cap));
+    chunks.push_back(c);
+    return c.p;
+  }
+  template <class T> T* ws_t(size_t n) { return (T*)ws(n * sizeof(T)); }
+
+  uint32_t* upload_words(const std::vector<uint32_t>& v) {
+    host_keep.push_back(v);
+    uint32_t* d = ws_t<uint32_t>(v.size());
+    HIPCHK(hipMemcpyAsync(d, host_keep.back().data(), v.size() * 4, hipMemcpyHostToDevice, stream));
+    return d;
+  }
+  Ev& next_ev() {
+    if (evs_used == evs.size()) {
+      Ev e;
+      HIPCHK(hipEventCreate(&e.a));
+      HIPCHK(hipEventCreate(&e.b));
+      e.mads = 0;
+      evs.push_back(e);
+    }
+    return evs[evs_used++];
+  }
+  ~pgpu_ctx() {
+    for (auto& c : chunks) (void)hipFree(c.p);
+    for (auto& e : evs) { (void)hipEventDestroy(e.a); (void)hipEventDestroy(e.b); }
+  }
+};
+
+// ------------------------------------------------------------------------------------------------
+// Modulus context: Montgomery constants for one odd modulus on the device
+// ------------------------------------------------------------------------------------------------
+namespace {
+
+enum { C_R2 = 0, C_R3 = 1, C_ONE_M = 2, C_ONE = 3, C_USER = 4 };
+
+struct ModCtx {
+  pgpu_ctx* ctx = nullptr;
+  BigU N, R;
+  size_t nbits = 0, nbytes = 0;
+  int WL = 0, K = 0, WT = 0;
+  uint32_t n0inv = 0;
+  std::vector<BigU> consts;
+  uint32_t* d_nmod = nullptr;
+  uint32_t* d_consts = nullptr;
+  size_t d_consts_cap = 0;
+
+  static bool pick_shape(size_t bits, int& wl, int& k) {
+    struct S { int wl, k; } shapes[] = {{37, 1}, {55, 1}, {74, 1}, {55, 2}, {74, 2}, {55, 4}, {83, 4}};
+    for (auto s : shapes)
+      if (bits + 3 <= (size_t)LB * s.wl * s.k) { wl = s.wl; k = s.k; return true; }
+    return false;
+  }
+
+  void init(pgpu_ctx* c, const BigU& n) {
+    ctx = c;
+    N = n;
+    if (!N.is_odd() || N.bit_length() < 8) api_throw(PGPU_ERR_INVALID, "modulus must be odd and at least 8 bits");
+    nbits = N.bit_length();
+    nbytes = (nbits + 7) / 8;
+    if (!pick_shape(nbits, WL, K)) api_throw(PGPU_ERR_UNSUPPORTED, "modulus wider than 9293 bits is not built");
+    WT = WL * K;
+    R = hostbig::shl(BigU(1), (size_t)LB * WT);
+    uint32_t n0 = N.d[0], x = n0;  // Newton: x = n0^-1 mod 2^32
+    for (int i = 0; i < 6; ++i) x *= 2u - n0 * x;
+    n0inv = (0u - x) & ((1u << LB) - 1);
+    BigU r1 = R % N, r2 = hostbig::mulmod(r1, r1, N), r3 = hostbig::mulmod(r2, r1, N);
+    consts = {r2, r3, r1, BigU(1)};
+  }
+  int add_const(const BigU& v) {  // v < 2N (any value below R works as a Montgomery operand)
+    consts.push_back(v);
+    return (int)consts.size() - 1;
+  }
+  // Montgomery form of v
+  BigU to_mont(const BigU& v) const { return hostbig::mulmod(v % N, R % N, N); }
+  void upload() {
+    ctx->bind();
+    if (!d_nmod) HIPCHK(hipMalloc((void**)&d_nmod, (size_t)WT * 4));
+    std::vector<uint32_t> nl = N.to_limbs(LB, WT);
+    HIPCHK(hipMemcpy(d_nmod, nl.data(), nl.size() * 4, hipMemcpyHostToDevice));
+    if (consts.size() > d_consts_cap) {
+      if (d_consts) HIPCHK(hipFree(d_consts));
+      d_consts_cap = consts.size() + 8;
+      HIPCHK(hipMalloc((void**)&d_consts, d_consts_cap * WT * 4));
+    }
+    std::vector<uint32_t> all;
+    for (auto& c : consts) {
+      auto l = c.to_limbs(LB, WT);
+      all.insert(all.end(), l.begin(), l.end());
+    }
+    HIPCHK(hipMemcpy(d_consts, all.data(), all.size() * 4, hipMemcpyHostToDevice));
+  }
+  ~ModCtx() {
+    if (d_nmod) (void)hipFree(d_nmod);
+    if (d_consts) (void)hipFree(d_consts);
+  }
+};
+
+// device copy of an arbitrary constant as `w` canonical 28-bit limbs
+struct DevLimbs {
+  uint32_t* d = nullptr;
+  int w = 0;
+  void set(const BigU& v, int width) {
+    w = width;
+    auto l = v.to_limbs(LB, width);
+    if (!d) HIPCHK(hipMalloc((void**)&d, (size_t)width * 4));
+    HIPCHK(hipMemcpy(d, l.data(), l.size() * 4, hipMemcpyHostToDevice));
+  }
+  ~DevLimbs() { if (d) (void)hipFree(d); }
+};
+
+// ------------------------------------------------------------------------------------------------
+// VM programs
+// ------------------------------------------------------------------------------------------------
+struct Prog {
+  std::vector<uint32_t> w;
+  double montmuls = 0;
+  void op(uint32_t o, uint32_t arg = 0, uint32_t aux = 0) {
+    w.push_back(o | (aux << 8));
+    w.push_back(arg);
+    if (o == VM_SQR || o == VM_MUL || o == VM_MULC || o == VM_MULV) montmuls += 1;
+  }
+  void end() { op(VM_END); }
+};
+
+constexpr uint32_t NO_SLOT = 0xFFFFFFFFu;
+
+// x <- Montgomery form of the input held in slot lo (+ hi * R when hi != NO_SLOT); lazy, < 2N
+void emit_to_mont(Prog& p, uint32_t lo, uint32_t hi, uint32_t tmp) {
+  if (hi != NO_SLOT) {
+    p.op(VM_LOAD, hi);
+    p.op(VM_MULC, C_R3);   // hi * R^2
+    p.op(VM_STORE, tmp);
+    p.op(VM_LOAD, lo);
+    p.op(VM_MULC, C_R2);   // lo * R
+    p.op(VM_ADD, tmp);     // (hi R + lo) R, limbs <= 2^29 + 2
+    p.op(VM_MULC, C_ONE_M);  // * R * R^-1: renormalise (lazy < 2N)
+  } else {
+    p.op(VM_LOAD, lo);
+    p.op(VM_MULC, C_R2);
+  }
+}
+
+// Shared-exponent fixed-window (w = 5) modexp.  Table slots tab .. tab+31.
+// post_slot != NO_SLOT: the result is multiplied by mem[post_slot] (a plain residue), which also takes
+// it out of Montgomery form; otherwise it is multiplied by the constant 1.  Result (lazy, < 2N) -> out.
+void emit_modexp_shared(Prog& p, const BigU& e, uint32_t in_lo, uint32_t in_hi, uint32_t tmp, uint32_t out,
+                        uint32_t tab, uint32_t post_slot, bool skip_zero_digits) {
+  const int w = 5;
+  if (e.is_zero()) {  // gmp.Int.Exp: y <= 0 -> 1
+    if (post_slot != NO_SLOT) { p.op(VM_LOAD, post_slot); } else { p.op(VM_LOADC, C_ONE); }
+    p.op(VM_STORE, out);
+    return;
+  }
+  emit_to_mont(p, in_lo, in_hi, tmp);
+  const size_t ebits = e.bit_length();
+  const size_t nwin = (ebits + w - 1) / w;
+  auto digit = [&](size_t i_from_top) {
+    size_t lo_bit = (nwin - 1 - i_from_top) * w;
+    uint32_t d = 0;
+    for (int b = 0; b < w; ++b) d |= (uint32_t)e.bit(lo_bit + b) << b;
+    return d;
+  };
+  uint32_t maxd = 0;
+  for (size_t i = 0; i < nwin; ++i) maxd = std::max(maxd, digit(i));
+  p.op(VM_STORE, tab + 1);
+  p.op(VM_LOADC, C_ONE_M);
+  p.op(VM_STORE, tab + 0);
+  p.op(VM_LOAD, tab + 1);
+  for (uint32_t k = 2; k <= maxd; ++k) {
+    p.op(VM_MUL, tab + 1);
+    p.op(VM_STORE, tab + k);
+  }
+  p.op(VM_LOAD, tab + digit(0));
+  for (size_t i = 1; i < nwin; ++i) {
+    for (int s = 0; s < w; ++s) p.op(VM_SQR);
+    uint32_t d = digit(i);
+    if (d != 0 || !skip_zero_digits) p.op(VM_MUL, tab + d);
+  }
+  if (post_slot != NO_SLOT) p.op(VM_MUL, post_slot); else p.op(VM_MULC, C_ONE);
+  p.op(VM_STORE, out);
+}
+
+// Per-number exponent, fixed window w = 4 (7 windows per 28-bit exponent limb).  The exponent limbs are
+// the segment's `digits` array [we][nb].  Table slots tab .. tab+15.
+void emit_modexp_perlane(Prog& p, int we, uint32_t in_lo, uint32_t in_hi, uint32_t tmp, uint32_t out, uint32_t tab,
+                         uint32_t post_slot) {
+  emit_to_mont(p, in_lo, in_hi, tmp);
+  p.op(VM_STORE, tab + 1);
+  p.op(VM_LOADC, C_ONE_M);
+  p.op(VM_STORE, tab + 0);
+  p.op(VM_LOAD, tab + 1);
+  for (uint32_t k = 2; k < 16; ++k) {
+    p.op(VM_MUL, tab + 1);
+    p.op(VM_STORE, tab + k);
+  }
+  const int nwin = we * 7;
+  p.op(VM_LOADC, C_ONE_M);
+  for (int i = nwin - 1; i >= 0; --i) {
+    if (i != nwin - 1) for (int s = 0; s < 4; ++s) p.op(VM_SQR);
+    p.op(VM_MULV, (uint32_t)i, tab);
+  }
+  if (post_slot != NO_SLOT) p.op(VM_MUL, post_slot); else p.op(VM_MULC, C_ONE);
+  p.op(VM_STORE, out);
+}
+
+struct SegSpec {
+  const ModCtx* mc;
+  const Prog* prog;
+  uint32_t* mem;
+  const uint32_t* digits;
+};
+
+// launch one VM kernel with 1 or 2 segments of `nb` numbers each (same modulus shape)
+void run_vm(pgpu_ctx* ctx, size_t nb, const SegSpec& s0, const SegSpec* s1, bool profile) {
+  const ModCtx* mc = s0.mc;
+  if (s1 && (s1->mc->WL != mc->WL || s1->mc->K != mc->K)) api_throw(PGPU_ERR_INVALID, "segment shape mismatch");
+  VmArgs a;
+  memset(&a, 0, sizeof a);
+  const SegSpec* ss[2] = {&s0, s1};
+  double montmuls = 0;
+  for (int i = 0; i < 2; ++i) {
+    if (!ss[i]) continue;
+    VmSeg& g = a.seg[i];
+    g.prog = ctx->upload_words(ss[i]->prog->w);
+    g.nmod = ss[i]->mc->d_nmod;
+    g.consts = ss[i]->mc->d_consts;
+    g.mem = ss[i]->mem;
+    g.digits = ss[i]->digits;
+    g.n0inv = ss[i]->mc->n0inv;
+    g.nb = (uint32_t)nb;
+    montmuls += ss[i]->prog->montmuls;
+  }
+  const uint32_t blocks_per_seg = (uint32_t)(nb * mc->K / VM_BLOCK);
+  a.seg0_blocks = blocks_per_seg;
+  const uint32_t blocks = blocks_per_seg * (s1 ? 2 : 1);
+  pgpu_ctx::Ev* ev = nullptr;
+  if (profile) {
+    ev = &ctx->next_ev();
+    ev->mads = montmuls * 2.0 * mc->WT * mc->WT * (double)nb;  // v_mad_u64_u32 lane-ops executed
+    HIPCHK(hipEventRecord(ev->a, ctx->stream));
+  }
+  hipError_t e = launch_vm(mc->WL, mc->K, a, blocks, ctx->stream);
+  if (e != hipSuccess) throw HipError{e, "launch_vm"};
+  if (profile) HIPCHK(hipEventRecord(ev->b, ctx->stream));
+}
+
+// stage an operand buffer (host or device, big-endian element-major) and unpack it to `wt` limbs
+void unpack_operand(pgpu_ctx* ctx, const uint8_t* buf, size_t stride, size_t nbytes, size_t count, int mem,
+                    uint32_t* out, int wt, size_t nb) {
+  if (nbytes > stride) api_throw(PGPU_ERR_INVALID, "operand length exceeds its stride");
+  if (nbytes * 8 > (size_t)LB * wt + 7) api_throw(PGPU_ERR_INVALID, "operand wider than the modulus supports");
+  const uint8_t* d = buf;
+  if (mem == PGPU_MEM_HOST) {
+    uint8_t* st = (uint8_t*)ctx->ws(stride * count);
+    HIPCHK(hipMemcpyAsync(st, buf, stride * count, hipMemcpyHostToDevice, ctx->stream));
+    d = st;
+  }
+  // operands are right-aligned in their stride: the value is the last nbytes of each element
+  launch_unpack_be(d + (stride - nbytes), stride, nbytes, count, out, wt, nb, ctx->stream);
+}
+
+void pack_result(pgpu_ctx* ctx, const uint32_t* in, int wt, size_t nb, size_t count, uint8_t* out, size_t stride,
+                 size_t nbytes, int mem) {
+  if (nbytes > stride) api_throw(PGPU_ERR_INVALID, "result length exceeds its stride");
+  if (mem == PGPU_MEM_HOST) {
+    uint8_t* st = (uint8_t*)ctx->ws(stride * count);
+    HIPCHK(hipMemsetAsync(st, 0, stride * count, ctx->stream));
+    launch_pack_be(in, wt, nb, count, st + (stride - nbytes), stride, nbytes, ctx->stream);
+    HIPCHK(hipMemcpyAsync(out, st, stride * count, hipMemcpyDeviceToHost, ctx->stream));
+  } else {
+    if (stride != nbytes) HIPCHK(hipMemsetAsync(out, 0, stride * count, ctx->stream));
+    launch_pack_be(in, wt, nb, count, out + (stride - nbytes), stride, nbytes, ctx->stream);
+  }
+}
+
+template <class F> int guarded(F&& f) {
+  try {
+    f();
+    return PGPU_OK;
+  } catch (const HipError& e) {
+    return fail(PGPU_ERR_HIP, "HIP error: %s (%s)", hipGetErrorString(e.e), e.what);
+  } catch (const ApiError& e) {
+    return fail(e.code, "%s", e.msg.c_str());
+  } catch (const std::exception& e) {
+    return fail(PGPU_ERR_INVALID, "%s", e.what());
+  }
+}
+
+}  // namespace
+
+// ------------------------------------------------------------------------------------------------
+// Opaque handle types
+// ------------------------------------------------------------------------------------------------
+struct pgpu_modulus {
+  pgpu_ctx* ctx;
+  ModCtx mc;
+};
+
+struct pgpu_pubkey {
+  pgpu_ctx* ctx;
+  BigU N, G, H, Kk;
+  bool g_is_n_plus_1;
+  ModCtx mn, mn2;                 // moduli n, n^2  (level one)
+  std::unique_ptr<ModCtx> mn3;    // n^3 (level two), built when the width is supported
+  DevLimbs n_limbs;               // n as mn.WT limbs (multiplicand of the closed-form g^m)
+};
+
+struct pgpu_seckey {
+  pgpu_ctx* ctx;
+  const pgpu_pubkey* pk;
+  BigU lambda;
+  bool has_crt = false;
+  BigU p, q;
+  ModCtx mp, mq, mp2, mq2;       // moduli p, q, p^2, q^2
+  int c_hpR = -1, c_hqR = -1;    // constants: hp*R mod p in mp, hq*R mod q in mq
+  int c_pinvR = -1;              // p^-1 * R mod q in mq
+  DevLimbs pinv2k, qinv2k;       // p^-1 mod 2^(28 mp.WT), q^-1 mod 2^(28 mq.WT)
+  DevLimbs p_limbs;              // p as mp.WT limbs
+  // generic path (reference formula)
+  int c_muR = -1;                // lambda^-1 mod n, times R mod n, in pk->mn
+  DevLimbs ninv2k;               // n^-1 mod 2^(28 mn.WT)
+  DevLimbs n_minus_mu;           // (n - mu) mod n, the answer for c == 0 (L(-1) = -1)
+};
+
+// inverse of odd d modulo 2^bits
+static BigU inv_mod_pow2(const BigU& d, size_t bits) {
+  BigU m = hostbig::shl(BigU(1), bits), out;
+  if (!hostbig::modinv(d, m, out)) api_throw(PGPU_ERR_INVALID, "inverse mod 2^k of an even number");
+  return out;
+}
+
+extern "C" {
+
+const char* pgpu_last_error(void) { return g_err.c_str(); }
+const char* pgpu_version(void) { return "paillier_hip 0.1 (gfx950, radix-2^28 Montgomery VM)"; }
+
+int pgpu_ctx_create(int device, void* stream, pgpu_ctx** out) {
+  if (!out) return fail(PGPU_ERR_INVALID, "null out");
+  int n = 0;
+  if (hipGetDeviceCount(&n) != hipSuccess || n <= 0) return fail(PGPU_ERR_NO_DEVICE, "no HIP device: this library has no CPU path");
+  if (device < 0 || device >= n) return fail(PGPU_ERR_INVALID, "device %d out of range (have %d)", device, n);
+  hipDeviceProp_t prop;
+  if (hipGetDeviceProperties(&prop, device) != hipSuccess) return fail(PGPU_ERR_HIP, "hipGetDeviceProperties failed");
+  if (strncmp(prop.gcnArchName, "gfx950", 6) != 0)
+    return fail(PGPU_ERR_NO_DEVICE, "device %d is %s; the kernels are built for gfx950 only", device, prop.gcnArchName);
+  pgpu_ctx* c = new pgpu_ctx();
+  c->device = device;
+  c->stream = (hipStream_t)stream;
+  int rc = guarded([&] { c->bind(); });
+  if (rc != PGPU_OK) { delete c; return rc; }
+  *out = c;
+  return PGPU_OK;
+}
+
+void pgpu_ctx_destroy(pgpu_ctx* ctx) {
+  if (!ctx) return;
+  (void)hipSetDevice(ctx->device);
+  (void)hipStreamSynchronize(ctx->stream);
+  delete ctx;
+}
+
+int pgpu_ctx_last_profile(pgpu_ctx* ctx, double* vm_ms, int* vm_launches, double* vm_mads) {
+  if (!ctx) return fail(PGPU_ERR_INVALID, "null ctx");
+  return guarded([&] {
+    ctx->bind();
+    double ms = 0, mads = 0;
+    for (size_t i = 0; i < ctx->evs_used; ++i) {
+      HIPCHK(hipEventSynchronize(ctx->evs[i].b));
+      float t = 0;
+      HIPCHK(hipEventElapsedTime(&t, ctx->evs[i].a, ctx->evs[i].b));
+      ms += t;
+      mads += ctx->evs[i].mads;
+    }
+    if (vm_ms) *vm_ms = ms;
+    if (vm_launches) *vm_launches = (int)ctx->evs_used;
+    if (vm_mads) *vm_mads = mads;
+  });
+}
+
+// ---- generic modulus ----------------------------------------------------------------------------
+
+int pgpu_modulus_create(pgpu_ctx* ctx, const uint8_t* n_be, size_t n_len, pgpu_modulus** out) {
+  if (!ctx || !n_be || !out) return fail(PGPU_ERR_INVALID, "null argument");
+  std::unique_ptr<pgpu_modulus> m(new pgpu_modulus());
+  int rc = guarded([&] {
+    m->ctx = ctx;
+    m->mc.init(ctx, BigU::from_be(n_be, n_len));
+    m->mc.upload();
+  });
+  if (rc == PGPU_OK) *out = m.release();
+  return rc;
+}
+void pgpu_modulus_destroy(pgpu_modulus* mod) { delete mod; }
+size_t pgpu_modulus_bytes(const pgpu_modulus* mod) { return mod ? mod->mc.nbytes : 0; }
+
+}  // extern "C"
+
+namespace {
+
+// out[i] = base[i]^e mod N on an already-unpacked base array (slot layout described inline).
+// Returns the device array of canonical results (WT limbs, limb-major).
+// base_wide: the base occupies 2*WT limbs (slots 0 and 1).  post: optional plain multiplicand array.
+struct ModexpPlan {
+  size_t nb;
+  uint32_t* mem;     // slots: 0 in_lo, 1 in_hi, 2 tmp, 3 out, 4 post, 5.. table
+  uint32_t* out() const { return mem + 3 * slot_words; }
+  uint32_t* in() const { return mem; }
+  uint32_t* post() const { return mem + 4 * slot_words; }
+  size_t slot_words;
+};
+
+ModexpPlan modexp_alloc(pgpu_ctx* ctx, const ModCtx& mc, size_t nb, int table_slots) {
+  ModexpPlan pl;
+  pl.nb = nb;
+  pl.slot_words = (size_t)mc.WT * nb;
+  pl.mem = ctx->ws_t<uint32_t>(pl.slot_words * (size_t)(5 + table_slots));
+  return pl;
+}
+
+void modexp_shared_run(pgpu_ctx* ctx, const ModCtx& mc, const ModexpPlan& pl, const BigU& e, bool wide, bool use_post,
+                       bool skip_zero) {
+  Prog p;
+  emit_modexp_shared(p, e, 0, wide ? 1 : NO_SLOT, 2, 3, 5, use_post ? 4 : NO_SLOT, skip_zero);
+  p.end();
+  SegSpec s{&mc, &p, pl.mem, nullptr};
+  run_vm(ctx, pl.nb, s, nullptr, true);
+  launch_canon(pl.out(), mc.d_nmod, mc.WT, pl.nb, ctx->stream);
+}
+
+void modexp_perlane_run(pgpu_ctx* ctx, const ModCtx& mc, const ModexpPlan& pl, const uint32_t* exps, int we, bool wide,
+                        bool use_post) {
+  Prog p;
+  emit_modexp_perlane(p, we, 0, wide ? 1 : NO_SLOT, 2, 3, 5, use_post ? 4 : NO_SLOT);
+  p.end();
+  SegSpec s{&mc, &p, pl.mem, exps};
+  run_vm(ctx, pl.nb, s, nullptr, true);
+  launch_canon(pl.out(), mc.d_nmod, mc.WT, pl.nb, ctx->stream);
+}
+
+// x mod N for an array of `w_in` <= 2*WT limbs -> canonical WT limbs in `out`
+void reduce_mod(pgpu_ctx* ctx, const ModCtx& mc, const uint32_t* in, int w_in, uint32_t* out, size_t nb) {
+  // slots: 0 lo, 1 hi, 2 tmp, 3 out
+  size_t sw = (size_t)mc.WT * nb;
+  uint32_t* mem = ctx->ws_t<uint32_t>(sw * 4);
+  bool wide = w_in > mc.WT;
+  launch_copy_limbs(in, 0, std::min(w_in, mc.WT), mem, mc.WT, nb, ctx->stream);
+  if (wide) launch_copy_limbs(in, mc.WT, w_in - mc.WT, mem + sw, mc.WT, nb, ctx->stream);
+  Prog p;
+  emit_to_mont(p, 0, wide ? 1 : NO_SLOT, 2);
+  p.op(VM_MULC, C_ONE);
+  p.op(VM_STORE, 3);
+  p.end();
+  SegSpec s{&mc, &p, mem, nullptr};
+  run_vm(ctx, nb, s, nullptr, false);
+  launch_canon(mem + 3 * sw, mc.d_nmod, mc.WT, nb, ctx->stream);
+  HIPCHK(hipMemcpyAsync(out, mem + 3 * sw, sw * 4, hipMemcpyDeviceToDevice, ctx->stream));
+}
+
+void check_batch_args(const void* a, const void* b, size_t batch) {
+  if (!a || !b) api_throw(PGPU_ERR_INVALID, "null buffer");
+  if (batch == 0) api_throw(PGPU_ERR_INVALID, "empty batch");
+  if (batch > (1u << 26)) api_throw(PGPU_ERR_INVALID, "batch too large");
+}
+
+}  // namespace
+
+extern "C" {
+
+int pgpu_modexp(const pgpu_modulus* mod, size_t batch, const uint8_t* base, size_t base_stride, size_t base_len,
+                const uint8_t* e, size_t e_len, size_t e_stride, uint8_t* out, size_t out_stride, int mem) {
+  if (!mod) return fail(PGPU_ERR_INVALID, "null modulus");
+  pgpu_ctx* ctx = mod->ctx;
+  const ModCtx& mc = mod->mc;
+  return guarded([&] {
+    check_batch_args(base, out, batch);
+    if (!e) api_throw(PGPU_ERR_INVALID, "null exponent");
+    ctx->bind();
+    ctx->reset_ws();
+    const size_t nb = round_up(batch, VM_BLOCK);
+    const bool wide = base_len * 8 > (size_t)LB * mc.WT;
+    if (base_len * 8 > (size_t)2 * LB * mc.WT) api_throw(PGPU_ERR_INVALID, "base wider than twice the modulus width");
+    const bool perlane = e_stride != 0;
+    ModexpPlan pl = modexp_alloc(ctx, mc, nb, perlane ? 16 : 32);
+    unpack_operand(ctx, base, base_stride, base_len, batch, mem, pl.in(), wide ? 2 * mc.WT : mc.WT, nb);
+    if (!perlane) {
+      BigU ev = BigU::from_be(e, e_len);
+      modexp_shared_run(ctx, mc, pl, ev, wide, false, true);
+    } else {
+      int we = (int)((e_len * 8 + LB - 1) / LB);
+      if (we < 1) we = 1;
+      uint32_t* exps = ctx->ws_t<uint32_t>((size_t)we * nb);
+      unpack_operand(ctx, e, e_stride, e_len, batch, mem, exps, we, nb);
+      modexp_perlane_run(ctx, mc, pl, exps, we, wide, false);
+    }
+    pack_result(ctx, pl.out(), mc.WT, nb, batch, out, out_stride, mc.nbytes, mem);
+    HIPCHK(hipStreamSynchronize(ctx->stream));
+  });
+}
+
+int pgpu_modmul(const pgpu_modulus* mod, size_t batch, const uint8_t* a, size_t a_stride, size_t a_len,
+                const uint8_t* b, size_t b_stride, size_t b_len, uint8_t* out, size_t out_stride, int mem) {
+  if (!mod) return fail(PGPU_ERR_INVALID, "null modulus");
+  pgpu_ctx* ctx = mod->ctx;
+  const ModCtx& mc = mod->mc;
+  return guarded([&] {
+    check_batch_args(a, out, batch);
+    if (!b) api_throw(PGPU_ERR_INVALID, "null buffer");
+    if (a_len * 8 > (size_t)LB * mc.WT || b_len * 8 > (size_t)LB * mc.WT)
+      api_throw(PGPU_ERR_INVALID, "modmul operands must fit the modulus width");
+    ctx->bind();
+    ctx->reset_ws();
+    const size_t nb = round_up(batch, VM_BLOCK);
+    size_t sw = (size_t)mc.WT * nb;
+    uint32_t* memv = ctx->ws_t<uint32_t>(sw * 3);  // slots: 0 a, 1 b, 2 out
+    unpack_operand(ctx, a, a_stride, a_len, batch, mem, memv, mc.WT, nb);
+    unpack_operand(ctx, b, b_stride, b_len, batch, mem, memv + sw, mc.WT, nb);
+    Prog p;
+    p.op(VM_LOAD, 0);
+    p.op(VM_MULC, C_R2);
+    p.op(VM_MUL, 1);
+    p.op(VM_STORE, 2);
+    p.end();
+    SegSpec s{&mc, &p, memv, nullptr};
+    run_vm(ctx, nb, s, nullptr, true);
+    launch_canon(memv + 2 * sw, mc.d_nmod, mc.WT, nb, ctx->stream);
+    pack_result(ctx, memv + 2 * sw, mc.WT, nb, batch, out, out_stride, mc.nbytes, mem);
+    HIPCHK(hipStreamSynchronize(ctx->stream));
+  });
+}
+
+// ---- keys ---------------------------------------------------------------------------------------
+
+int pgpu_pubkey_create(pgpu_ctx* ctx, const uint8_t* n_be, size_t n_len, const uint8_t* g_be, size_t g_len,
+                       const uint8_t* h_be, size_t h_len, const uint8_t* k_be, size_t k_len, pgpu_pubkey** out) {
+  if (!ctx || !n_be || !g_be || !out) return fail(PGPU_ERR_INVALID, "null argument");
+  std::unique_ptr<pgpu_pubkey> pk(new pgpu_pubkey());
+  int rc = guarded([&] {
+    ctx->bind();
+    pk->ctx = ctx;
+    pk->N = BigU::from_be(n_be, n_len);
+    pk->G = BigU::from_be(g_be, g_len);
+    if (h_be) pk->H = BigU::from_be(h_be, h_len);
+    if (k_be) pk->Kk = BigU::from_be(k_be, k_len);
+    pk->g_is_n_plus_1 = (pk->G == pk->N + BigU(1));
+    BigU n2 = pk->N * pk->N;
+    pk->mn.init(ctx, pk->N);
+    pk->mn2.init(ctx, n2);
+    pk->mn.upload();
+    pk->mn2.upload();
+    int wl, k;
+    BigU n3 = n2 * pk->N;
+    if (ModCtx::pick_shape(n3.bit_length(), wl, k)) {
+      pk->mn3.reset(new ModCtx());
+      pk->mn3->init(ctx, n3);
+      pk->mn3->upload();
+    }
+    pk->n_limbs.set(pk->N, pk->mn.WT);
+  });
+  if (rc == PGPU_OK) *out = pk.release();
+  return rc;
+}
+void pgpu_pubkey_destroy(pgpu_pubkey* pk) { delete pk; }
+
+size_t pgpu_pubkey_plain_bytes(const pgpu_pubkey* pk, int level) {
+  if (!pk) return 0;
+  return level == PGPU_LEVEL_TWO ? pk->mn2.nbytes : pk->mn.nbytes;
+}
+size_t pgpu_pubkey_cipher_bytes(const pgpu_pubkey* pk, int level) {
+  if (!pk) return 0;
+  if (level == PGPU_LEVEL_TWO) return pk->mn3 ? pk->mn3->nbytes : 0;
+  return pk->mn2.nbytes;
+}
+
+int pgpu_seckey_create(pgpu_ctx* ctx, const pgpu_pubkey* pk, const uint8_t* lambda_be, size_t lambda_len,
+                       pgpu_seckey** out) {
+  if (!ctx || !pk || !lambda_be || !out) return fail(PGPU_ERR_INVALID, "null argument");
+  std::unique_ptr<pgpu_seckey> sk(new pgpu_seckey());
+  int rc = guarded([&] {
+    ctx->bind();
+    sk->ctx = ctx;
+    sk->pk = pk;
+    sk->lambda = BigU::from_be(lambda_be, lambda_len);
+    const BigU& n = pk->N;
+    if (sk->lambda.is_zero()) api_throw(PGPU_ERR_INVALID, "lambda is zero");
+    // generic-path constants (paillier.go:298: mu = lambda^-1 mod n)
+    BigU mu;
+    if (!hostbig::modinv(sk->lambda, n, mu)) api_throw(PGPU_ERR_NOT_INVERTIBLE, "lambda is not invertible mod n");
+    pgpu_pubkey* pkm = const_cast<pgpu_pubkey*>(pk);  // constants are appended to the key's tables once, here
+    sk->c_muR = pkm->mn.add_const(pkm->mn.to_mont(mu));
+    pkm->mn.upload();
+    sk->ninv2k.set(inv_mod_pow2(n, (size_t)LB * pk->mn.WT), pk->mn.WT);
+    sk->n_minus_mu.set((n - mu) % n, pk->mn.WT);
+    // recover p, q from n and lambda = (p-1)(q-1): p + q = n - lambda + 1
+    if (hostbig::cmp(n + BigU(1), sk->lambda) > 0) {
+      BigU s = n + BigU(1) - sk->lambda;
+      BigU s2 = s * s, n4 = hostbig::shl(n, 2);
+      if (hostbig::cmp(s2, n4) >= 0) {
+        BigU d = hostbig::isqrt(s2 - n4);
+        if (d * d == s2 - n4 && !((s + d).is_odd())) {
+          BigU p = hostbig::shr(s + d, 1), q = hostbig::shr(s - d, 1);
+          if (p * q == n && p.is_odd() && q.is_odd() && !(p == q) && !(q == BigU(1))) {
+            sk->p = p;
+            sk->q = q;
+            sk->has_crt = true;
+          }
+        }
+      }
+    }
+    if (sk->has_crt) {
+      const BigU &p = sk->p, &q = sk->q;
+      sk->mp.init(ctx, p);
+      sk->mq.init(ctx, q);
+      sk->mp2.init(ctx, p * p);
+      sk->mq2.init(ctx, q * q);
+      if (sk->mp.WL != sk->mq.WL || sk->mp.K != sk->mq.K || sk->mp2.WL != sk->mq2.WL || sk->mp2.K != sk->mq2.K) {
+        sk->has_crt = false;  // unbalanced primes: the two CRT halves would need different kernels
+      } else {
+        // hp = L_p((1+n)^(p-1) mod p^2)^-1 mod p = ((p-1) q)^-1 mod p, same for q
+        BigU hp, hq, pinv;
+        BigU p1q = hostbig::mulmod(p - BigU(1), q % p, p), q1p = hostbig::mulmod(q - BigU(1), p % q, q);
+        if (!hostbig::modinv(p1q, p, hp) || !hostbig::modinv(q1p, q, hq) || !hostbig::modinv(p % q, q, pinv))
+          api_throw(PGPU_ERR_INVALID, "CRT constants not invertible");
+        sk->c_hpR = sk->mp.add_const(sk->mp.to_mont(hp));
+        sk->c_hqR = sk->mq.add_const(sk->mq.to_mont(hq));
+        sk->c_pinvR = sk->mq.add_const(sk->mq.to_mont(pinv));
+        sk->mp.upload();
+        sk->mq.upload();
+        sk->mp2.upload();
+        sk->mq2.upload();
+        sk->pinv2k.set(inv_mod_pow2(p, (size_t)LB * sk->mp.WT), sk->mp.WT);
+        sk->qinv2k.set(inv_mod_pow2(q, (size_t)LB * sk->mq.WT), sk->mq.WT);
+        sk->p_limbs.set(p, sk->mp.WT);
+      }
+    }
+  });
+  if (rc == PGPU_OK) *out = sk.release();
+  return rc;
+}
+void pgpu_seckey_destroy(pgpu_seckey* sk) { delete sk; }
+int pgpu_seckey_has_crt(const pgpu_seckey* sk) { return sk && sk->has_crt; }
+
+}  // extern "C"
+
+// ------------------------------------------------------------------------------------------------
+// Paillier batch operations
+// ------------------------------------------------------------------------------------------------
+namespace {
+
+const ModCtx& cipher_mod(const pgpu_pubkey* pk, int level) {
+  if (level == PGPU_LEVEL_ONE) return pk->mn2;
+  if (level == PGPU_LEVEL_TWO) {
+    if (!pk->mn3) api_throw(PGPU_ERR_UNSUPPORTED, "n^3 is wider than the built kernels");
+    return *pk->mn3;
+  }
+  api_throw(PGPU_ERR_INVALID, "bad encryption level");
+}
+
+// Level-one decryption, CRT over p^2 and q^2.  c: device array of 2*WT2 limbs (WT2 = mp2.WT) per number.
+// Returns device array of mn.WT-limb plaintexts; status bits are OR-ed into d_status.
+uint32_t* decrypt1_crt(const pgpu_seckey* sk, const uint32_t* c_limbs, size_t nb, size_t count, int32_t* d_status) {
+  pgpu_ctx* ctx = sk->ctx;
+  const ModCtx &mp = sk->mp, &mq = sk->mq, &mp2 = sk->mp2, &mq2 = sk->mq2;
+  const int W2 = mp2.WT, W1 = mp.WT;
+  const size_t S2 = (size_t)W2 * nb, S1 = (size_t)W1 * nb;
+  // big VM memory: slots 0,1 = c (lo, hi); P: tmp 2, out 3, table 4..35; Q: tmp 36, out 37, table 38..69
+  uint32_t* mem = ctx->ws_t<uint32_t>(S2 * 70);
+  HIPCHK(hipMemcpyAsync(mem, c_limbs, S2 * 2 * 4, hipMemcpyDeviceToDevice, ctx->stream));
+  Prog pp, pq;
+  emit_modexp_shared(pp, sk->p - BigU(1), 0, 1, 2, 3, 4, NO_SLOT, false);
+  pp.end();
+  emit_modexp_shared(pq, sk->q - BigU(1), 0, 1, 36, 37, 38, NO_SLOT, false);
+  pq.end();
+  SegSpec sp{&mp2, &pp, mem, nullptr}, sq{&mq2, &pq, mem, nullptr};
+  run_vm(ctx, nb, sp, &sq, true);
+  uint32_t *up = mem + 3 * S2, *uq = mem + 37 * S2;
+  launch_canon(up, mp2.d_nmod, W2, nb, ctx->stream);
+  launch_canon(uq, mq2.d_nmod, W2, nb, ctx->stream);
+  // small memory: slots 0 Lp, 1 Lq, 2 mp, 3 mq, 4 B, 5 A, 6 h
+  uint32_t* m1 = ctx->ws_t<uint32_t>(S1 * 7);
+  launch_L_exact(up, W2, sk->pinv2k.d, mp.d_nmod, W1, m1 + 0 * S1, W1, nb, count, d_status, PGPU_LANE_NONUNIT, ctx->stream);
+  launch_L_exact(uq, W2, sk->qinv2k.d, mq.d_nmod, W1, m1 + 1 * S1, W1, nb, count, d_status, PGPU_LANE_NONUNIT, ctx->stream);
+  Prog a, b, c;
+  a.op(VM_LOAD, 0); a.op(VM_MULC, (uint32_t)sk->c_hpR); a.op(VM_STORE, 2); a.end();   // m_p = L_p * h_p mod p
+  b.op(VM_LOAD, 1); b.op(VM_MULC, (uint32_t)sk->c_hqR); b.op(VM_STORE, 3); b.end();   // m_q = L_q * h_q mod q
+  SegSpec sa{&mp, &a, m1, nullptr}, sb{&mq, &b, m1, nullptr};
+  run_vm(ctx, nb, sa, &sb, false);
+  c.op(VM_LOAD, 2); c.op(VM_MULC, (uint32_t)sk->c_pinvR); c.op(VM_STORE, 4);           // B = m_p * p^-1 mod q
+  c.op(VM_LOAD, 3); c.op(VM_MULC, (uint32_t)sk->c_pinvR); c.op(VM_STORE, 5);           // A = m_q * p^-1 mod q
+  c.end();
+  SegSpec sc{&mq, &c, m1, nullptr};
+  run_vm(ctx, nb, sc, nullptr, false);
+  launch_canon(m1 + 4 * S1, mq.d_nmod, W1, nb, ctx->stream);
+  launch_canon(m1 + 5 * S1, mq.d_nmod, W1, nb, ctx->stream);
+  launch_canon(m1 + 2 * S1, mp.d_nmod, W1, nb, ctx->stream);
+  launch_sub_mod(m1 + 5 * S1, m1 + 4 * S1, mq.d_nmod, m1 + 6 * S1, W1, nb, ctx->stream);  // h = A - B mod q
+  const int WN = sk->pk->mn.WT;
+  uint32_t* res = ctx->ws_t<uint32_t>((size_t)WN * nb);
+  // m = m_p + p * h
+  launch_mul_const_add(m1 + 6 * S1, W1, sk->p_limbs.d, W1, m1 + 2 * S1, W1, 0, res, WN, nb, ctx->stream);
+  return res;
+}
+
+}  // namespace
+
+extern "C" {
+
+int pgpu_decrypt(const pgpu_seckey* sk, int level, size_t batch, const uint8_t* c, size_t c_stride, uint8_t* m,
+                 size_t m_stride, int mem, int flags, int32_t* status) {
+  if (!sk) return fail(PGPU_ERR_INVALID, "null key");
+  pgpu_ctx* ctx = sk->ctx;
+  return guarded([&] {
+    check_batch_args(c, m, batch);
+    if (level != PGPU_LEVEL_ONE) api_throw(PGPU_ERR_UNSUPPORTED, "level-two decryption is not built yet");
+    ctx->bind();
+    ctx->reset_ws();
+    const size_t nb = round_up(batch, VM_BLOCK);
+    const pgpu_pubkey* pk = sk->pk;
+    const size_t cbytes = pk->mn2.nbytes;
+    if (c_stride < cbytes) api_throw(PGPU_ERR_INVALID, "ciphertext stride smaller than the byte length of n^2");
+    int32_t* d_status = ctx->ws_t<int32_t>(nb);
+    HIPCHK(hipMemsetAsync(d_status, 0, nb * 4, ctx->stream));
+    const bool crt = sk->has_crt && !(flags & PGPU_DECRYPT_NO_CRT);
+    if (!crt) api_throw(PGPU_ERR_UNSUPPORTED, "generic (non-CRT) decryption is not built yet");
+    const int W2 = sk->mp2.WT;
+    uint32_t* cl = ctx->ws_t<uint32_t>((size_t)2 * W2 * nb);
+    // the ciphertext is the last cbytes of each element (values >= n^2 are reduced implicitly by the Horner prologue)
+    unpack_operand(ctx, c, c_stride, cbytes, batch, mem, cl, 2 * W2, nb);
+    uint32_t* res = decrypt1_crt(sk, cl, nb, batch, d_status);
+    pack_result(ctx, res, pk->mn.WT, nb, batch, m, m_stride, pk->mn.nbytes, mem);
+    if (status) HIPCHK(hipMemcpyAsync(status, d_status, batch * 4, hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHK(hipStreamSynchronize(ctx->stream));
+  });
+}
+
+int pgpu_encrypt_with_r(const pgpu_pubkey* pk, int level, size_t batch, const uint8_t* m, size_t m_stride,
+                        const uint8_t* r, size_t r_stride, uint8_t* c, size_t c_stride, int mem) {
+  if (!pk) return fail(PGPU_ERR_INVALID, "null key");
+  pgpu_ctx* ctx = pk->ctx;
+  return guarded([&] {
+    check_batch_args(m, c, batch);
+    if (!r) api_throw(PGPU_ERR_INVALID, "null buffer");
+    if (level != PGPU_LEVEL_ONE) api_throw(PGPU_ERR_UNSUPPORTED, "level-two encryption is not built yet");
+    if (!pk->g_is_n_plus_1) api_throw(PGPU_ERR_UNSUPPORTED, "G != N+1 is not built yet");
+    ctx->bind();
+    ctx->reset_ws();
+    const size_t nb = round_up(batch, VM_BLOCK);
+    const ModCtx &mn = pk->mn, &mn2 = pk->mn2;
+    const size_t mlen = std::min(m_stride, mn.nbytes), rlen = std::min(r_stride, mn2.nbytes);
+    // m mod n (the generator 1+n has order n, so G^m = G^(m mod n))
+    uint32_t* ml = ctx->ws_t<uint32_t>((size_t)mn.WT * nb);
+    unpack_operand(ctx, m, m_stride, mlen, batch, mem, ml, mn.WT, nb);
+    uint32_t* mred = ctx->ws_t<uint32_t>((size_t)mn.WT * nb);
+    reduce_mod(ctx, mn, ml, mn.WT, mred, nb);
+    ModexpPlan pl = modexp_alloc(ctx, mn2, nb, 32);
+    // g^m = 1 + m n  (< n^2), written as the post-multiplicand
+    launch_mul_const_add(mred, mn.WT, pk->n_limbs.d, mn.WT, nullptr, 0, 1, pl.post(), mn2.WT, nb, ctx->stream);
+    unpack_operand(ctx, r, r_stride, rlen, batch, mem, pl.in(), mn2.WT, nb);
+    modexp_shared_run(ctx, mn2, pl, pk->N, false, true, true);  // r^n * g^m mod n^2 (n is public: zero windows skipped)
+    pack_result(ctx, pl.out(), mn2.WT, nb, batch, c, c_stride, mn2.nbytes, mem);
+    HIPCHK(hipStreamSynchronize(ctx->stream));
+  });
+}
+
+int pgpu_add(const pgpu_pubkey* pk, int level, size_t batch, const uint8_t* a, size_t a_stride, const uint8_t* b,
+             size_t b_stride, uint8_t* out, size_t out_stride, int mem) {
+  if (!pk) return fail(PGPU_ERR_INVALID, "null key");
+  pgpu_ctx* ctx = pk->ctx;
+  return guarded([&] {
+    check_batch_args(a, out, batch);
+    if (!b) api_throw(PGPU_ERR_INVALID, "null buffer");
+    const ModCtx& mc = cipher_mod(pk, level);
+    ctx->bind();
+    ctx->reset_ws();
+    const size_t nb = round_up(batch, VM_BLOCK);
+    size_t sw = (size_t)mc.WT * nb;
+    uint32_t* memv = ctx->ws_t<uint32_t>(sw * 3);
+    unpack_operand(ctx, a, a_stride, std::min(a_stride, mc.nbytes), batch, mem, memv, mc.WT, nb);
+    unpack_operand(ctx, b, b_stride, std::min(b_stride, mc.nbytes), batch, mem, memv + sw, mc.WT, nb);
+    Prog p;
+    p.op(VM_LOAD, 0);
+    p.op(VM_MULC, C_R2);
+    p.op(VM_MUL, 1);
+    p.op(VM_STORE, 2);
+    p.end();
+    SegSpec s{&mc, &p, memv, nullptr};
+    run_vm(ctx, nb, s, nullptr, true);
+    launch_canon(memv + 2 * sw, mc.d_nmod, mc.WT, nb, ctx->stream);
+    pack_result(ctx, memv + 2 * sw, mc.WT, nb, batch, out, out_stride, mc.nbytes, mem);
+    HIPCHK(hipStreamSynchronize(ctx->stream));
+  });
+}
+
+int pgpu_const_mult(const pgpu_pubkey* pk, int level, size_t batch, const uint8_t* c, size_t c_stride,
+                    const uint8_t* k, size_t k_len, size_t k_stride, uint8_t* out, size_t out_stride, int mem) {
+  if (!pk) return fail(PGPU_ERR_INVALID, "null key");
+  pgpu_ctx* ctx = pk->ctx;
+  return guarded([&] {
+    check_batch_args(c, out, batch);
+    if (!k) api_throw(PGPU_ERR_INVALID, "null exponent");
+    const ModCtx& mc = cipher_mod(pk, level);
+    ctx->bind();
+    ctx->reset_ws();
+    const size_t nb = round_up(batch, VM_BLOCK);
+    const bool perlane = k_stride != 0;
+    ModexpPlan pl = modexp_alloc(ctx, mc, nb, perlane ? 16 : 32);
+    unpack_operand(ctx, c, c_stride, std::min(c_stride, mc.nbytes), batch, mem, pl.in(), mc.WT, nb);
+    if (!perlane) {
+      modexp_shared_run(ctx, mc, pl, BigU::from_be(k, k_len), false, false, true);
+    } else {
+      int we = std::max<int>(1, (int)((k_len * 8 + LB - 1) / LB));
+      uint32_t* exps = ctx->ws_t<uint32_t>((size_t)we * nb);
+      unpack_operand(ctx, k, k_stride, k_len, batch, mem, exps, we, nb);
+      modexp_perlane_run(ctx, mc, pl, exps, we, false, false);
+    }
+    pack_result(ctx, pl.out(), mc.WT, nb, batch, out, out_stride, mc.nbytes, mem);
+    HIPCHK(hipStreamSynchronize(ctx->stream));
+  });
+}
+
+}  // extern "C"

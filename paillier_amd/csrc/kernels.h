@@ -1,0 +1,50 @@
+// kernels.h -- launch interface between capi.cpp (host orchestration) and kernels.hip.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+constexpr int VM_BLOCK = 256;
+
+// VM opcodes.  An instruction is two 32-bit words: w0 = op | (aux << 8), w1 = arg.
+enum VmOp : uint32_t {
+  VM_END = 0,
+  VM_LOAD = 1,    // x <- mem[arg]
+  VM_STORE = 2,   // mem[arg] <- x
+  VM_LOADC = 3,   // x <- consts[arg]            (uniform constant)
+  VM_SQR = 4,     // x <- x*x*R^-1
+  VM_MUL = 5,     // x <- x*mem[arg]*R^-1
+  VM_MULC = 6,    // x <- x*consts[arg]*R^-1
+  VM_MULV = 7,    // x <- x*mem[aux + digits[arg][g]]*R^-1   (per-number table index)
+  VM_ADD = 8,     // x <- x + mem[arg]            (lazy; must be followed by a MULC before SQR)
+  VM_SETOFF = 9,  // operand number offset for LOAD/STORE/MUL/ADD <- arg
+};
+
+struct VmSeg {
+  const uint32_t* prog;    // program words
+  const uint32_t* nmod;    // WT modulus limbs (canonical, zero padded)
+  const uint32_t* consts;  // [c][WT]
+  uint32_t* mem;           // [slot][WT][nb]
+  const uint32_t* digits;  // [step][nb]  (MULV)
+  uint32_t n0inv;          // -N^-1 mod 2^28
+  uint32_t nb;             // numbers in this segment (multiple of VM_BLOCK / K)
+};
+
+struct VmArgs {
+  VmSeg seg[2];
+  uint32_t seg0_blocks;  // blocks [0, seg0_blocks) run seg[0], the rest seg[1]
+};
+
+hipError_t launch_vm(int wl, int k, const VmArgs& a, uint32_t blocks, hipStream_t st);
+
+void launch_unpack_be(const uint8_t* in, size_t stride, size_t nbytes, size_t count, uint32_t* out, int wt, size_t nb, hipStream_t st);
+void launch_pack_be(const uint32_t* in, int wt, size_t nb, size_t count, uint8_t* out, size_t stride, size_t nbytes, hipStream_t st);
+void launch_canon(uint32_t* x, const uint32_t* nmod, int wt, size_t nb, hipStream_t st);
+void launch_mul_const_add(const uint32_t* a, int wa, const uint32_t* bconst, int wb, const uint32_t* addv, int wadd,
+                          uint32_t add_small, uint32_t* out, int wo, size_t nb, hipStream_t st);
+void launch_L_exact(const uint32_t* u, int wu, const uint32_t* dinv, const uint32_t* d, int wd, uint32_t* l, int wl,
+                    size_t nb, size_t count, int32_t* status, int32_t flag, hipStream_t st);
+void launch_sub_mod(const uint32_t* a, const uint32_t* b, const uint32_t* q, uint32_t* out, int w, size_t nb, hipStream_t st);
+void launch_copy_limbs(const uint32_t* in, int l0, int w, uint32_t* out, int wo, size_t nb, hipStream_t st);
+void launch_fill_const(const uint32_t* c, uint32_t* out, int wo, size_t nb, hipStream_t st);
+void launch_gather(const uint32_t* in, size_t nb_in, const uint32_t* idx, size_t n_idx, uint32_t* out, size_t nb_out, int w, hipStream_t st);
+void launch_scatter(const uint32_t* in, size_t nb_in, const uint32_t* idx, size_t n_idx, uint32_t* out, size_t nb_out, int w, hipStream_t st);

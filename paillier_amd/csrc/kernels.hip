@@ -1,0 +1,359 @@
+// kernels.hip -- gfx950 kernels of the batched Paillier engine.
+//
+//  vm_kernel<WL,K>   the hot kernel: a tiny wave-uniform "big-integer VM".  Every number of the
+//                    batch (one lane, or K adjacent lanes for wide moduli) keeps ONE value x in
+//                    VGPRs and executes the same host-generated program of Montgomery
+//                    operations (LOAD/STORE/SQR/MUL/...).  A shared-exponent modexp, a window
+//                    table build, a Horner reduction of a wide input, a per-lane-exponent modexp
+//                    are all just programs; control flow is uniform, so there is no divergence.
+//                    >= 99 % of a Paillier op is spent in its SQR/MUL (bigint28.h montmul).
+//  k_*               light element-wise helpers (format conversion, canonicalisation, the exact
+//                    division of L(), CRT recombination, g^m closed form).  One lane per number,
+//                    operands streamed from limb-major arrays in HBM (coalesced).
+//
+// Batch layout in HBM ("limb-major"): uint32_t a[WT][NB]; limb l of number g at a[l*NB + g],
+// 28-bit limbs (bigint28.h).  NB is the batch size padded to a multiple of 256.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include "bigint28.h"
+#include "kernels.h"
+
+using namespace pa28;
+
+// ------------------------------------------------------------------------------------------
+// VM kernel
+// ------------------------------------------------------------------------------------------
+template <int WL, int K>
+__global__ void __launch_bounds__(VM_BLOCK, (3 * WL + 24 <= 256) ? 2 : 1) vm_kernel(VmArgs args) {
+  constexpr int WT = WL * K;
+  constexpr int NPB = VM_BLOCK / K;  // numbers per block
+  extern __shared__ __attribute__((aligned(16))) uint32_t lds[];
+  uint32_t* s_n = lds;                    // WT modulus limbs
+  uint32_t* s_a = lds + ((WT + 3) & ~3);  // a-operand columns: [WT][NPB]
+
+  const int segi = blockIdx.x >= args.seg0_blocks ? 1 : 0;
+  const VmSeg sg = args.seg[segi];
+  const uint32_t blk = blockIdx.x - (segi ? args.seg0_blocks : 0u);
+  const int tid = threadIdx.x;
+  const int k = tid % K;
+  const int gl = tid / K;
+  const size_t nb = sg.nb;
+  const size_t g = (size_t)blk * NPB + gl;  // number index inside the segment (always < nb: nb is padded)
+  const uint32_t is_first = (k == 0) ? 0xFFFFFFFFu : 0u;
+  const uint32_t not_last = (k == K - 1) ? 0u : 0xFFFFFFFFu;
+
+  for (int j = tid; j < WT; j += VM_BLOCK) s_n[j] = sg.nmod[j];
+  __syncthreads();
+
+  uint32_t x[WL];
+#pragma unroll
+  for (int j = 0; j < WL; ++j) x[j] = 0;
+  size_t goff = 0;  // operand number offset (OP_SETOFF), used by tree products
+
+  const uint32_t* prog = sg.prog;
+  for (uint32_t pc = 0;; pc += 2) {
+    const uint32_t w0 = prog[pc];
+    const uint32_t arg = prog[pc + 1];
+    const uint32_t op = w0 & 0xFFu;
+    if (op == VM_END) break;
+    if (op == VM_SETOFF) { goff = arg; continue; }
+    if (op == VM_LOAD) {
+      const uint32_t* p = sg.mem + ((size_t)arg * WT + (size_t)k * WL) * nb + g + goff;
+#pragma unroll
+      for (int j = 0; j < WL; ++j) x[j] = p[(size_t)j * nb];
+      continue;
+    }
+    if (op == VM_LOADC) {
+      const uint32_t* p = sg.consts + (size_t)arg * WT + (size_t)k * WL;
+#pragma unroll
+      for (int j = 0; j < WL; ++j) x[j] = p[j];
+      continue;
+    }
+    if (op == VM_STORE) {
+      uint32_t* p = sg.mem + ((size_t)arg * WT + (size_t)k * WL) * nb + g + goff;
+#pragma unroll
+      for (int j = 0; j < WL; ++j) p[(size_t)j * nb] = x[j];
+      continue;
+    }
+    if (op == VM_ADD) {  // lazy limb-wise add; the program must renormalise with a MULC before squaring
+      const uint32_t* p = sg.mem + ((size_t)arg * WT + (size_t)k * WL) * nb + g + goff;
+#pragma unroll
+      for (int j = 0; j < WL; ++j) x[j] += p[(size_t)j * nb];
+      continue;
+    }
+    // ---- multiply family: stage the `a` operand into this number's LDS column, then montmul
+    uint32_t* col = s_a + (size_t)(k * WL) * NPB + gl;
+    if (op == VM_SQR) {
+#pragma unroll
+      for (int j = 0; j < WL; ++j) col[j * NPB] = x[j];
+    } else if (op == VM_MULC) {
+      const uint32_t* p = sg.consts + (size_t)arg * WT + (size_t)k * WL;
+#pragma unroll
+      for (int j = 0; j < WL; ++j) col[j * NPB] = p[j];
+    } else {
+      size_t slot = arg;
+      if (op == VM_MULV) slot = (size_t)(w0 >> 8) + sg.digits[(size_t)arg * nb + g];
+      const uint32_t* p = sg.mem + (slot * WT + (size_t)k * WL) * nb + g + goff;
+#pragma unroll
+      for (int j = 0; j < WL; ++j) col[j * NPB] = p[(size_t)j * nb];
+    }
+    montmul<WL, K>(x, s_a + gl, NPB, s_n + k * WL, sg.n0inv, is_first, not_last);
+  }
+}
+
+template <int WL, int K>
+static hipError_t launch_vm_t(const VmArgs& a, uint32_t blocks, hipStream_t st) {
+  constexpr int WT = WL * K;
+  const size_t lds = (size_t)(((WT + 3) & ~3) + WT * (VM_BLOCK / K)) * 4;
+  static bool attr_set = false;
+  if (!attr_set) {
+    hipError_t e = hipFuncSetAttribute((const void*)vm_kernel<WL, K>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e != hipSuccess) return e;
+    attr_set = true;
+  }
+  hipLaunchKernelGGL((vm_kernel<WL, K>), dim3(blocks), dim3(VM_BLOCK), lds, st, a);
+  return hipGetLastError();
+}
+
+hipError_t launch_vm(int wl, int k, const VmArgs& a, uint32_t blocks, hipStream_t st) {
+  if (wl == 37 && k == 1) return launch_vm_t<37, 1>(a, blocks, st);
+  if (wl == 55 && k == 1) return launch_vm_t<55, 1>(a, blocks, st);
+  if (wl == 74 && k == 1) return launch_vm_t<74, 1>(a, blocks, st);
+  if (wl == 55 && k == 2) return launch_vm_t<55, 2>(a, blocks, st);
+  if (wl == 74 && k == 2) return launch_vm_t<74, 2>(a, blocks, st);
+  if (wl == 55 && k == 4) return launch_vm_t<55, 4>(a, blocks, st);
+  if (wl == 83 && k == 4) return launch_vm_t<83, 4>(a, blocks, st);
+  return hipErrorInvalidValue;
+}
+
+// ------------------------------------------------------------------------------------------
+// Helper kernels (one lane per number; generic width)
+// ------------------------------------------------------------------------------------------
+
+// big-endian bytes, element-major with fixed stride  ->  28-bit limbs, limb-major.
+// Elements >= count are written as zero (padding lanes).
+__global__ void k_unpack_be(const uint8_t* __restrict__ in, size_t stride, size_t nbytes, size_t count,
+                            uint32_t* __restrict__ out, int wt, size_t nb) {
+  size_t g = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (g >= nb) return;
+  const uint8_t* p = in + g * stride;
+  for (int l = 0; l < wt; ++l) {
+    uint32_t v = 0;
+    if (g < count) {
+      // limb l covers bits [28 l, 28 l + 28): bytes (28 l)/8 .. from the little end
+      size_t bit = (size_t)l * LB;
+      size_t byte0 = bit / 8;
+      uint64_t acc = 0;
+      for (int b = 0; b < 5; ++b) {
+        size_t bi = byte0 + b;  // index from the least significant byte
+        if (bi < nbytes) acc |= (uint64_t)p[nbytes - 1 - bi] << (8 * b);
+      }
+      v = (uint32_t)(acc >> (bit % 8)) & LMASK;
+    }
+    out[(size_t)l * nb + g] = v;
+  }
+}
+
+// canonical 28-bit limbs (limb-major) -> big-endian bytes, fixed stride.  Bits above nbytes are dropped
+// (the caller guarantees the value fits).
+__global__ void k_pack_be(const uint32_t* __restrict__ in, int wt, size_t nb, size_t count,
+                          uint8_t* __restrict__ out, size_t stride, size_t nbytes) {
+  size_t g = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (g >= count) return;
+  uint8_t* p = out + g * stride;
+  for (size_t bi = 0; bi < nbytes; ++bi) {  // bi = index from the least significant byte
+    size_t bit = bi * 8;
+    int l = (int)(bit / LB);
+    int sh = (int)(bit % LB);
+    uint64_t v = 0;
+    if (l < wt) v = in[(size_t)l * nb + g];
+    if (l + 1 < wt) v |= (uint64_t)in[(size_t)(l + 1) * nb + g] << LB;
+    p[nbytes - 1 - bi] = (uint8_t)(v >> sh);
+  }
+}
+
+// Lazy limbs (any limb < 2^32, value < 3N) -> canonical residue in [0, N), in place.
+// Sequential carry, then up to two conditional subtractions of N.
+__global__ void k_canon(uint32_t* __restrict__ x, const uint32_t* __restrict__ nmod, int wt, size_t nb) {
+  size_t g = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (g >= nb) return;
+  uint64_t c = 0;
+  for (int l = 0; l < wt; ++l) {
+    c += x[(size_t)l * nb + g];
+    x[(size_t)l * nb + g] = (uint32_t)c & LMASK;
+    c >>= LB;
+  }
+  for (int rep = 0; rep < 2; ++rep) {
+    // compare x with N from the top
+    int ge = 1;
+    for (int l = wt - 1; l >= 0; --l) {
+      uint32_t a = x[(size_t)l * nb + g], b = nmod[l];
+      if (a != b) { ge = a > b; break; }
+    }
+    if (!ge) break;
+    int32_t br = 0;
+    for (int l = 0; l < wt; ++l) {
+      int32_t d = (int32_t)x[(size_t)l * nb + g] - (int32_t)nmod[l] - br;
+      br = d < 0;
+      x[(size_t)l * nb + g] = (uint32_t)(d + (br << LB)) & LMASK;
+    }
+  }
+}
+
+// out[wo] = (a[wa] * b_const[wb] + addend) mod 2^(28 wo), canonical in, canonical out.  b is wave-uniform.
+// Used for g^m = 1 + m*n and for m_p + p*h.
+__global__ void k_mul_const_add(const uint32_t* __restrict__ a, int wa, const uint32_t* __restrict__ bconst, int wb,
+                                const uint32_t* __restrict__ addv, int wadd, uint32_t add_small,
+                                uint32_t* __restrict__ out, int wo, size_t nb) {
+  size_t g = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (g >= nb) return;
+  uint64_t acc = add_small, carry_hi = 0;  // 128-bit column accumulator (acc + carry_hi * 2^64)
+  for (int c = 0; c < wo; ++c) {
+    int i0 = c - (wb - 1) > 0 ? c - (wb - 1) : 0;
+    int i1 = c < wa - 1 ? c : wa - 1;
+    for (int i = i0; i <= i1; ++i) {
+      uint64_t p = (uint64_t)a[(size_t)i * nb + g] * bconst[c - i];
+      acc += p;
+      carry_hi += acc < p;
+    }
+    if (addv && c < wadd) {
+      uint64_t v = addv[(size_t)c * nb + g];
+      acc += v;
+      carry_hi += acc < v;
+    }
+    out[(size_t)c * nb + g] = (uint32_t)acc & LMASK;
+    acc = (acc >> LB) | (carry_hi << (64 - LB));
+    carry_hi >>= LB;
+  }
+}
+
+// Paillier L function by exact division:  l = (u - 1) / d  where d (wd limbs, odd) divides u - 1.
+//   l = (u - 1) * dinv  mod 2^(28 wl),   dinv = d^-1 mod 2^(28 wl)  (uniform constant)
+// u is canonical (wu limbs).  The division is exact iff l * d + 1 == u; otherwise status |= flag
+// (the ciphertext was not a unit mod n: the caller re-runs that lane on the generic path).
+__global__ void k_L_exact(const uint32_t* __restrict__ u, int wu, const uint32_t* __restrict__ dinv,
+                          const uint32_t* __restrict__ d, int wd, uint32_t* __restrict__ l, int wl, size_t nb,
+                          size_t count, int32_t* __restrict__ status, int32_t flag) {
+  size_t g = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (g >= nb) return;
+  // pass 1: l = (u - 1) * dinv mod 2^(28 wl), column by column; (u-1) limbs are generated on the fly
+  // borrow chain for u - 1:
+  uint64_t acc = 0, hi = 0;
+  for (int c = 0; c < wl; ++c) {
+    // (u-1)[i] for i <= c
+    int32_t br = 1;
+    for (int i = 0; i <= c; ++i) {
+      int32_t ui = (i < wu) ? (int32_t)u[(size_t)i * nb + g] : 0;
+      int32_t v = ui - br;
+      br = v < 0;
+      uint32_t um1 = (uint32_t)(v + (br << LB)) & LMASK;
+      uint64_t p = (uint64_t)um1 * dinv[c - i];
+      acc += p;
+      hi += acc < p;
+    }
+    l[(size_t)c * nb + g] = (uint32_t)acc & LMASK;
+    acc = (acc >> LB) | (hi << (64 - LB));
+    hi >>= LB;
+  }
+  // pass 2: verify l * d + 1 == u over all wu limbs
+  int bad = 0;
+  acc = 1; hi = 0;
+  for (int c = 0; c < wu; ++c) {
+    int i0 = c - (wd - 1) > 0 ? c - (wd - 1) : 0;
+    int i1 = c < wl - 1 ? c : wl - 1;
+    for (int i = i0; i <= i1; ++i) {
+      uint64_t p = (uint64_t)l[(size_t)i * nb + g] * d[c - i];
+      acc += p;
+      hi += acc < p;
+    }
+    bad |= ((uint32_t)acc & LMASK) != u[(size_t)c * nb + g];
+    acc = (acc >> LB) | (hi << (64 - LB));
+    hi >>= LB;
+  }
+  bad |= (acc != 0) | (hi != 0);
+  if (bad && g < count) status[g] |= flag;
+}
+
+// out = (a - b) mod q for canonical a, b in [0, q): a - b + (a < b ? q : 0)
+__global__ void k_sub_mod(const uint32_t* __restrict__ a, const uint32_t* __restrict__ b,
+                          const uint32_t* __restrict__ q, uint32_t* __restrict__ out, int w, size_t nb) {
+  size_t g = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (g >= nb) return;
+  int32_t br = 0;
+  for (int l = 0; l < w; ++l) {
+    int32_t d = (int32_t)a[(size_t)l * nb + g] - (int32_t)b[(size_t)l * nb + g] - br;
+    br = d < 0;
+    out[(size_t)l * nb + g] = (uint32_t)(d + (br << LB)) & LMASK;
+  }
+  if (br) {
+    uint32_t c = 0;
+    for (int l = 0; l < w; ++l) {
+      uint32_t s = out[(size_t)l * nb + g] + q[l] + c;
+      out[(size_t)l * nb + g] = s & LMASK;
+      c = s >> LB;
+    }
+  }
+}
+
+// copy `w` limbs (zero-extending to wo) between limb-major arrays, optionally starting at source limb `l0`
+__global__ void k_copy_limbs(const uint32_t* __restrict__ in, int l0, int w, uint32_t* __restrict__ out, int wo, size_t nb) {
+  size_t g = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (g >= nb) return;
+  for (int l = 0; l < wo; ++l) out[(size_t)l * nb + g] = (l < w) ? in[(size_t)(l0 + l) * nb + g] : 0u;
+}
+
+// fill a limb-major array with a uniform constant (wo limbs)
+__global__ void k_fill_const(const uint32_t* __restrict__ c, uint32_t* __restrict__ out, int wo, size_t nb) {
+  size_t g = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (g >= nb) return;
+  for (int l = 0; l < wo; ++l) out[(size_t)l * nb + g] = c[l];
+}
+
+// gather / scatter of selected numbers (used to re-run flagged lanes on the generic path)
+__global__ void k_gather(const uint32_t* __restrict__ in, size_t nb_in, const uint32_t* __restrict__ idx, size_t n_idx,
+                         uint32_t* __restrict__ out, size_t nb_out, int w) {
+  size_t g = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (g >= nb_out) return;
+  for (int l = 0; l < w; ++l) out[(size_t)l * nb_out + g] = (g < n_idx) ? in[(size_t)l * nb_in + idx[g]] : 0u;
+}
+__global__ void k_scatter(const uint32_t* __restrict__ in, size_t nb_in, const uint32_t* __restrict__ idx, size_t n_idx,
+                          uint32_t* __restrict__ out, size_t nb_out, int w) {
+  size_t g = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (g >= n_idx) return;
+  for (int l = 0; l < w; ++l) out[(size_t)l * nb_out + idx[g]] = in[(size_t)l * nb_in + g];
+}
+
+#define HELPER_GRID(nb) dim3((unsigned)(((nb) + 255) / 256)), dim3(256)
+
+void launch_unpack_be(const uint8_t* in, size_t stride, size_t nbytes, size_t count, uint32_t* out, int wt, size_t nb, hipStream_t st) {
+  hipLaunchKernelGGL(k_unpack_be, HELPER_GRID(nb), 0, st, in, stride, nbytes, count, out, wt, nb);
+}
+void launch_pack_be(const uint32_t* in, int wt, size_t nb, size_t count, uint8_t* out, size_t stride, size_t nbytes, hipStream_t st) {
+  hipLaunchKernelGGL(k_pack_be, HELPER_GRID(count ? count : 1), 0, st, in, wt, nb, count, out, stride, nbytes);
+}
+void launch_canon(uint32_t* x, const uint32_t* nmod, int wt, size_t nb, hipStream_t st) {
+  hipLaunchKernelGGL(k_canon, HELPER_GRID(nb), 0, st, x, nmod, wt, nb);
+}
+void launch_mul_const_add(const uint32_t* a, int wa, const uint32_t* bconst, int wb, const uint32_t* addv, int wadd,
+                          uint32_t add_small, uint32_t* out, int wo, size_t nb, hipStream_t st) {
+  hipLaunchKernelGGL(k_mul_const_add, HELPER_GRID(nb), 0, st, a, wa, bconst, wb, addv, wadd, add_small, out, wo, nb);
+}
+void launch_L_exact(const uint32_t* u, int wu, const uint32_t* dinv, const uint32_t* d, int wd, uint32_t* l, int wl,
+                    size_t nb, size_t count, int32_t* status, int32_t flag, hipStream_t st) {
+  hipLaunchKernelGGL(k_L_exact, HELPER_GRID(nb), 0, st, u, wu, dinv, d, wd, l, wl, nb, count, status, flag);
+}
+void launch_sub_mod(const uint32_t* a, const uint32_t* b, const uint32_t* q, uint32_t* out, int w, size_t nb, hipStream_t st) {
+  hipLaunchKernelGGL(k_sub_mod, HELPER_GRID(nb), 0, st, a, b, q, out, w, nb);
+}
+void launch_copy_limbs(const uint32_t* in, int l0, int w, uint32_t* out, int wo, size_t nb, hipStream_t st) {
+  hipLaunchKernelGGL(k_copy_limbs, HELPER_GRID(nb), 0, st, in, l0, w, out, wo, nb);
+}
+void launch_fill_const(const uint32_t* c, uint32_t* out, int wo, size_t nb, hipStream_t st) {
+  hipLaunchKernelGGL(k_fill_const, HELPER_GRID(nb), 0, st, c, out, wo, nb);
+}
+void launch_gather(const uint32_t* in, size_t nb_in, const uint32_t* idx, size_t n_idx, uint32_t* out, size_t nb_out, int w, hipStream_t st) {
+  hipLaunchKernelGGL(k_gather, HELPER_GRID(nb_out), 0, st, in, nb_in, idx, n_idx, out, nb_out, w);
+}
+void launch_scatter(const uint32_t* in, size_t nb_in, const uint32_t* idx, size_t n_idx, uint32_t* out, size_t nb_out, int w, hipStream_t st) {
+  hipLaunchKernelGGL(k_scatter, HELPER_GRID(n_idx ? n_idx : 1), 0, st, in, nb_in, idx, n_idx, out, nb_out, w);
+}

@@ -1,0 +1,106 @@
+"""GPU parity tests: the HIP path, called through the C ABI (ctypes), against the CPU oracle on the same
+seeded inputs.  Bit-exact (integer work): every comparison is `==` on Python ints."""
+import random
+
+import pytest
+
+from oracle import paillier_oracle as po
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def ctx():
+    import paillier_amd as pa
+    return pa.Context(0)
+
+
+def rand_odd(bits, rng):
+    return rng.getrandbits(bits) | (1 << (bits - 1)) | 1
+
+
+# (modulus bits) -> kernel shape exercised: 1024 (37,1) 1536 (55,1) 2048 (74,1) 3072 (55,2) 4096 (74,2) 6144 (55,4)
+@pytest.mark.parametrize("bits", [1024, 1536, 2048, 3072, 4096, 6144, 521, 2069, 4141])
+def test_modmul_matches_python(ctx, bits):
+    import paillier_amd as pa
+    rng = random.Random(bits)
+    n = rand_odd(bits, rng)
+    mod = pa.Modulus(ctx, n)
+    a = [rng.randrange(n) for _ in range(300)] + [0, 1, n - 1, n - 1]
+    b = [rng.randrange(n) for _ in range(300)] + [5, n - 1, n - 1, 1]
+    got = mod.mul_batch(a, b)
+    assert got == [x * y % n for x, y in zip(a, b)]
+
+
+@pytest.mark.parametrize("bits", [1024, 2048, 3072, 4096, 6144])
+def test_modexp_shared_matches_python(ctx, bits):
+    import paillier_amd as pa
+    rng = random.Random(bits + 1)
+    n = rand_odd(bits, rng)
+    mod = pa.Modulus(ctx, n)
+    bases = [rng.randrange(n) for _ in range(70)] + [0, 1, n - 1]
+    for e in (rng.getrandbits(bits // 2), 0, 1, 2, 31, 32, rng.getrandbits(200) << 77):
+        got = mod.exp_batch(bases, e)
+        assert got == [po.gmp_exp(x, e, n) for x in bases], f"e={e:#x}"
+
+
+def test_modexp_wide_base(ctx):
+    """mpz_powm accepts base >= modulus; the VM reduces a double-width base with a Horner prologue."""
+    import paillier_amd as pa
+    rng = random.Random(5)
+    n = rand_odd(2048, rng)
+    mod = pa.Modulus(ctx, n)
+    bases = [rng.getrandbits(4096) for _ in range(40)] + [n, n * n - 1, (1 << 4096) - 1]
+    e = rng.getrandbits(300)
+    assert mod.exp_batch(bases, e, base_bytes=512) == [pow(x, e, n) for x in bases]
+
+
+@pytest.mark.parametrize("bits", [2048, 4096])
+def test_modexp_per_lane_exponent(ctx, bits):
+    import paillier_amd as pa
+    rng = random.Random(bits + 2)
+    n = rand_odd(bits, rng)
+    mod = pa.Modulus(ctx, n)
+    bases = [rng.randrange(n) for _ in range(66)]
+    exps = [rng.getrandbits(rng.choice([1, 17, 64, 300, 511])) for _ in bases]
+    exps[0], exps[1] = 0, 1
+    assert mod.exp_batch(bases, exps) == [po.gmp_exp(x, e, n) for x, e in zip(bases, exps)]
+
+
+@pytest.fixture(scope="module")
+def key1024():
+    sk, p, q = po.keygen_seeded(1024, 1)
+    return sk, p, q
+
+
+def test_config1_encrypt_decrypt_roundtrip_1024(ctx, key1024):
+    """BASELINE config 1: 1024-bit key, 256 EncryptWithR -> Decrypt round trips (paillier_test.go:52-63,158-173)."""
+    import paillier_amd as pa
+    sk_o, p, q = key1024
+    rng = random.Random(1)
+    pk = pa.PublicKey(ctx, sk_o.N, sk_o.G)
+    sk = pa.SecretKey(ctx, pk, sk_o.Lambda)
+    assert sk.has_crt
+    ms = [rng.randrange(sk_o.N) for _ in range(252)] + [0, 1, sk_o.N - 1, 12]
+    rs = [po.rand_unit(sk_o.N, rng) for _ in ms]
+    cts = pk.EncryptWithRBatch(ms, rs)
+    assert cts == [po.encrypt_with_r(sk_o, m, r).C for m, r in zip(ms, rs)]
+    got, status = sk.DecryptBatch(cts, return_status=True)
+    assert got == ms
+    assert got == [po.decrypt(sk_o, po.Ciphertext(c)) for c in cts[:8]] + ms[8:]
+    assert not status.any()
+
+
+def test_add_constmult_1024(ctx, key1024):
+    import paillier_amd as pa
+    sk_o, p, q = key1024
+    rng = random.Random(3)
+    pk = pa.PublicKey(ctx, sk_o.N, sk_o.G)
+    n2 = sk_o.N ** 2
+    a = [rng.randrange(n2) for _ in range(100)]
+    b = [rng.randrange(n2) for _ in range(100)]
+    assert pk.AddBatch(a, b) == [po.add(sk_o, po.Ciphertext(x), po.Ciphertext(y)).C for x, y in zip(a, b)]
+    k = 50 ** 50 % sk_o.N  # operations_test.go:174-185
+    assert pk.ConstMultBatch(a, k) == [po.const_mult(sk_o, po.Ciphertext(x), k).C for x in a]
+    ks = [rng.randrange(sk_o.N) for _ in a]
+    assert pk.ConstMultBatch(a[:40], ks[:40]) == [po.const_mult(sk_o, po.Ciphertext(x), kk).C for x, kk in zip(a, ks[:40])]
