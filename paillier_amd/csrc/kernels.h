@@ -14,7 +14,7 @@ enum VmOp : uint32_t {
   VM_SQR = 4,     // x <- x*x*R^-1
   VM_MUL = 5,     // x <- x*mem[arg]*R^-1
   VM_MULC = 6,    // x <- x*consts[arg]*R^-1
-  VM_MULV = 7,    // x <- x*mem[aux + digits[arg][g]]*R^-1   (per-number table index)
+  VM_MULV = 7,    // x <- x*mem[aux + window(arg) of this number's exponent]*R^-1  (4-bit windows, per-number gather)
   VM_ADD = 8,     // x <- x + mem[arg]            (lazy; must be followed by a MULC before SQR)
   VM_SETOFF = 9,  // operand number offset for LOAD/STORE/MUL/ADD <- arg
 };
@@ -24,7 +24,7 @@ struct VmSeg {
   const uint32_t* nmod;    // WT modulus limbs (canonical, zero padded)
   const uint32_t* consts;  // [c][WT]
   uint32_t* mem;           // [slot][WT][nb]
-  const uint32_t* digits;  // [step][nb]  (MULV)
+  const uint32_t* digits;  // per-number exponents as 28-bit limbs, limb-major [we][nb]  (MULV)
   uint32_t n0inv;          // -N^-1 mod 2^28
   uint32_t nb;             // numbers in this segment (multiple of VM_BLOCK / K)
 };

@@ -92,7 +92,12 @@ __global__ void __launch_bounds__(VM_BLOCK, (3 * WL + 24 <= 256) ? 2 : 1) vm_ker
       for (int j = 0; j < WL; ++j) col[j * NPB] = p[j];
     } else {
       size_t slot = arg;
-      if (op == VM_MULV) slot = (size_t)(w0 >> 8) + sg.digits[(size_t)arg * nb + g];
+      if (op == VM_MULV) {
+        // arg = index of a 4-bit window of this number's own exponent (7 windows per 28-bit limb);
+        // aux = first table slot.  The table index differs per number: a gather, not a branch.
+        const uint32_t elimb = sg.digits[(size_t)(arg / 7u) * nb + g];
+        slot = (size_t)(w0 >> 8) + ((elimb >> (4u * (arg % 7u))) & 15u);
+      }
       const uint32_t* p = sg.mem + (slot * WT + (size_t)k * WL) * nb + g + goff;
 #pragma unroll
       for (int j = 0; j < WL; ++j) col[j * NPB] = p[(size_t)j * nb];
