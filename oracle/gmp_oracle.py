@@ -1,0 +1,87 @@
+"""ctypes loader for oracle/_build/libgmp_oracle.so (CPU ORACLE -- test infrastructure / CPU baseline only).
+See oracle/gmp_oracle.c for what it restates.  Never imported by paillier_amd/."""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_PATH = os.path.join(_HERE, "_build", "libgmp_oracle.so")
+_lib = None
+
+
+def load():
+    global _lib
+    if _lib is None:
+        if not os.path.exists(_PATH):
+            subprocess.check_call(["make", "-s", "-C", _HERE])
+        _lib = C.CDLL(_PATH)
+        _lib.oracle_gmp_version.restype = C.c_char_p
+        for name in ("oracle_decrypt_batch", "oracle_encrypt_batch", "oracle_modexp_batch"):
+            getattr(_lib, name).restype = C.c_int
+    return _lib
+
+
+def _be(v):
+    return int(v).to_bytes(max(1, (int(v).bit_length() + 7) // 8), "big")
+
+
+def _p(a):
+    return C.c_void_p(a.ctypes.data)
+
+
+def decrypt_batch_raw(n, lam, c_buf: np.ndarray, m_stride: int, threads: int = 1):
+    """c_buf: uint8[batch, stride] big-endian.  Returns (uint8[batch, m_stride], threads_used)."""
+    lib = load()
+    nb, lb = _be(n), _be(lam)
+    out = np.zeros((c_buf.shape[0], m_stride), dtype=np.uint8)
+    used = lib.oracle_decrypt_batch(nb, C.c_size_t(len(nb)), lb, C.c_size_t(len(lb)), C.c_size_t(c_buf.shape[0]),
+                                    _p(c_buf), C.c_size_t(c_buf.shape[1]), _p(out), C.c_size_t(m_stride), threads)
+    return out, used
+
+
+def encrypt_batch_raw(n, g, m_buf: np.ndarray, r_buf: np.ndarray, c_stride: int, threads: int = 1):
+    lib = load()
+    nb, gb = _be(n), _be(g)
+    out = np.zeros((m_buf.shape[0], c_stride), dtype=np.uint8)
+    used = lib.oracle_encrypt_batch(nb, C.c_size_t(len(nb)), gb, C.c_size_t(len(gb)), C.c_size_t(m_buf.shape[0]),
+                                    _p(m_buf), C.c_size_t(m_buf.shape[1]), _p(r_buf), C.c_size_t(r_buf.shape[1]),
+                                    _p(out), C.c_size_t(c_stride), threads)
+    return out, used
+
+
+def modexp_batch_raw(mod, e, b_buf: np.ndarray, o_stride: int, threads: int = 1):
+    lib = load()
+    mb, eb = _be(mod), _be(e)
+    out = np.zeros((b_buf.shape[0], o_stride), dtype=np.uint8)
+    used = lib.oracle_modexp_batch(mb, C.c_size_t(len(mb)), eb, C.c_size_t(len(eb)), C.c_size_t(b_buf.shape[0]),
+                                   _p(b_buf), C.c_size_t(b_buf.shape[1]), _p(out), C.c_size_t(o_stride), threads)
+    return out, used
+
+
+def _ints_to_be(vals, stride):
+    return np.frombuffer(b"".join(int(v).to_bytes(stride, "big") for v in vals), dtype=np.uint8).reshape(len(vals), stride).copy()
+
+
+def _be_to_ints(arr):
+    raw, s = arr.tobytes(), arr.shape[1]
+    return [int.from_bytes(raw[i * s:(i + 1) * s], "big") for i in range(arr.shape[0])]
+
+
+def decrypt_batch(n, lam, cts, threads=1):
+    nb = (n.bit_length() + 7) // 8
+    out, _ = decrypt_batch_raw(n, lam, _ints_to_be(cts, 2 * nb), nb, threads)
+    return _be_to_ints(out)
+
+
+def encrypt_batch(n, g, ms, rs, threads=1):
+    nb = (n.bit_length() + 7) // 8
+    out, _ = encrypt_batch_raw(n, g, _ints_to_be(ms, nb), _ints_to_be(rs, nb), 2 * nb, threads)
+    return _be_to_ints(out)
+
+
+def modexp_batch(mod, e, bases, threads=1):
+    nb = (mod.bit_length() + 7) // 8
+    out, _ = modexp_batch_raw(mod, e, _ints_to_be(bases, nb), nb, threads)
+    return _be_to_ints(out)

@@ -766,6 +766,9 @@ uint32_t* decrypt1_crt(const pgpu_seckey* sk, const uint32_t* c_limbs, size_t nb
   b.op(VM_LOAD, 1); b.op(VM_MULC, (uint32_t)sk->c_hqR); b.op(VM_STORE, 3); b.end();   // m_q = L_q * h_q mod q
   SegSpec sa{&mp, &a, m1, nullptr}, sb{&mq, &b, m1, nullptr};
   run_vm(ctx, nb, sa, &sb, false);
+  // Garner needs ONE integer m_p in both places it is used (B below and the final sum): canonicalise it
+  // first.  (A lazy m_p in [p, 2p) here and a reduced one in the sum gave m - p on ~1e-4 of the lanes.)
+  launch_canon(m1 + 2 * S1, mp.d_nmod, W1, nb, ctx->stream);
   c.op(VM_LOAD, 2); c.op(VM_MULC, (uint32_t)sk->c_pinvR); c.op(VM_STORE, 4);           // B = m_p * p^-1 mod q
   c.op(VM_LOAD, 3); c.op(VM_MULC, (uint32_t)sk->c_pinvR); c.op(VM_STORE, 5);           // A = m_q * p^-1 mod q
   c.end();
@@ -773,7 +776,6 @@ uint32_t* decrypt1_crt(const pgpu_seckey* sk, const uint32_t* c_limbs, size_t nb
   run_vm(ctx, nb, sc, nullptr, false);
   launch_canon(m1 + 4 * S1, mq.d_nmod, W1, nb, ctx->stream);
   launch_canon(m1 + 5 * S1, mq.d_nmod, W1, nb, ctx->stream);
-  launch_canon(m1 + 2 * S1, mp.d_nmod, W1, nb, ctx->stream);
   launch_sub_mod(m1 + 5 * S1, m1 + 4 * S1, mq.d_nmod, m1 + 6 * S1, W1, nb, ctx->stream);  // h = A - B mod q
   const int WN = sk->pk->mn.WT;
   uint32_t* res = ctx->ws_t<uint32_t>((size_t)WN * nb);
