@@ -63,6 +63,11 @@ void pgpu_ctx_destroy(pgpu_ctx* ctx);
 /* Timing of the dominant (modexp VM) kernel of the last batch call, measured with HIP events on
  * the context's stream: milliseconds, number of launches, and 28-bit-limb multiply-adds executed. */
 int pgpu_ctx_last_profile(pgpu_ctx* ctx, double* vm_ms, int* vm_launches, double* vm_mads);
+/* Runtime switches.  "asm" (default 1): run the hand-scheduled gfx950 assembly VM kernels; 0 selects the
+ * hipcc-generated kernels of identical semantics (used by the parity tests to cross-check the two). */
+int pgpu_ctx_set_flag(pgpu_ctx* ctx, const char* name, int value);
+/* number of VM launches of the last batch call that ran the assembly kernel */
+int pgpu_ctx_last_vm_asm(pgpu_ctx* ctx);
 
 /* ---- keys ---------------------------------------------------------------------------------- */
 
@@ -121,6 +126,13 @@ int pgpu_modexp(const pgpu_modulus* mod, size_t batch, const uint8_t* base, size
 /* new(gmp.Int).Mod(new(gmp.Int).Mul(a, b), N) for a batch. */
 int pgpu_modmul(const pgpu_modulus* mod, size_t batch, const uint8_t* a, size_t a_stride, size_t a_len,
                 const uint8_t* b, size_t b_stride, size_t b_len, uint8_t* out, size_t out_stride, int mem);
+
+/* ---- test hook -------------------------------------------------------------------------------------- */
+/* Runs a raw VM program (kernels.h opcodes; pairs of words) on raw slot memory: host array of 28-bit limbs,
+ * limb-major [slot][WT][nb], nb a multiple of 256.  use_asm selects the assembly or the hipcc kernel.
+ * For tests only: lets the two implementations of the VM be compared opcode by opcode. */
+int pgpu_vm_debug_run(const pgpu_modulus* mod, const uint32_t* prog, size_t prog_words, uint32_t* mem_host,
+                      size_t nslots, size_t nb, int use_asm, int* wt_out);
 
 #ifdef __cplusplus
 }

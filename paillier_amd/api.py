@@ -47,6 +47,8 @@ SIGNATURES = {
     "pgpu_ctx_create": (_int, [_int, _vp, C.POINTER(_vp)]),
     "pgpu_ctx_destroy": (None, [_vp]),
     "pgpu_ctx_last_profile": (_int, [_vp, C.POINTER(C.c_double), C.POINTER(_int), C.POINTER(C.c_double)]),
+    "pgpu_ctx_set_flag": (_int, [_vp, C.c_char_p, _int]),
+    "pgpu_ctx_last_vm_asm": (_int, [_vp]),
     "pgpu_pubkey_create": (_int, [_vp, _vp, _sz, _vp, _sz, _vp, _sz, _vp, _sz, C.POINTER(_vp)]),
     "pgpu_pubkey_destroy": (None, [_vp]),
     "pgpu_pubkey_plain_bytes": (_sz, [_vp, _int]),
@@ -62,6 +64,7 @@ SIGNATURES = {
     "pgpu_modulus_destroy": (None, [_vp]),
     "pgpu_modulus_bytes": (_sz, [_vp]),
     "pgpu_modexp": (_int, [_vp, _sz, _vp, _sz, _sz, _vp, _sz, _sz, _vp, _sz, _int]),
+    "pgpu_vm_debug_run": (_int, [_vp, _vp, _sz, _vp, _sz, _sz, _int, C.POINTER(_int)]),
     "pgpu_modmul": (_int, [_vp, _sz, _vp, _sz, _sz, _vp, _sz, _sz, _vp, _sz, _int]),
 }
 
@@ -127,6 +130,12 @@ class Context:
         _check(self.lib.pgpu_ctx_last_profile(self.h, C.byref(ms), C.byref(n), C.byref(mads)))
         return {"vm_ms": ms.value, "vm_launches": n.value, "vm_mads": mads.value}
 
+    def set_flag(self, name: str, value: int):
+        _check(self.lib.pgpu_ctx_set_flag(self.h, name.encode(), value))
+
+    def last_vm_asm(self) -> int:
+        return self.lib.pgpu_ctx_last_vm_asm(self.h)
+
     def close(self):
         if self.h:
             self.lib.pgpu_ctx_destroy(self.h)
@@ -165,6 +174,14 @@ class Modulus:
             es = el
         _check(lib.pgpu_modexp(self.h, len(bases), _ptr(bb), bl, bl, _ptr(eb), el, es, _ptr(out), self.nbytes, MEM_HOST))
         return be_to_ints(out)
+
+    def vm_debug_run(self, prog_words: Sequence[int], mem: np.ndarray, nslots: int, nb: int, use_asm: bool) -> np.ndarray:
+        """Test hook (include/paillier_hip.h pgpu_vm_debug_run).  mem: uint32[nslots, WT, nb]; returns the memory after the run."""
+        pw = np.asarray(prog_words, dtype=np.uint32)
+        m = np.ascontiguousarray(mem, dtype=np.uint32).copy()
+        wt = C.c_int()
+        _check(self.ctx.lib.pgpu_vm_debug_run(self.h, _ptr(pw), pw.size, _ptr(m), nslots, nb, int(use_asm), C.byref(wt)))
+        return m
 
     def mul_batch(self, a: Sequence[int], b: Sequence[int]) -> List[int]:
         lib = self.ctx.lib

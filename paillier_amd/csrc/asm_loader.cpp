@@ -1,0 +1,46 @@
+// asm_loader.cpp -- loads the hand-scheduled VM kernels (gen_vm_asm.py -> *.hsaco, embedded by the build as
+// vm_asm_blobs.inc) with the HIP module API and launches them with the same VmArgs block as vm_kernel<>.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <string.h>
+#include <mutex>
+
+#include "kernels.h"
+
+namespace {
+struct Blob { int wl, k; const unsigned char* data; size_t size; const char* name; };
+#include "vm_asm_blobs.inc"   // defines: static const Blob kBlobs[]; static const int kNumBlobs;
+
+struct Loaded { hipModule_t mod = nullptr; hipFunction_t fn = nullptr; bool tried = false; };
+Loaded g_loaded[16];
+std::mutex g_mu;
+
+int find_blob(int wl, int k) {
+  for (int i = 0; i < kNumBlobs; ++i)
+    if (kBlobs[i].wl == wl && kBlobs[i].k == k) return i;
+  return -1;
+}
+}  // namespace
+
+bool vm_asm_available(int wl, int k) { return find_blob(wl, k) >= 0; }
+
+hipError_t launch_vm_asm(int wl, int k, const VmArgs& a, uint32_t blocks, hipStream_t st) {
+  int i = find_blob(wl, k);
+  if (i < 0) return hipErrorInvalidValue;
+  {
+    std::lock_guard<std::mutex> lk(g_mu);
+    Loaded& L = g_loaded[i];
+    if (!L.tried) {
+      L.tried = true;
+      hipError_t e = hipModuleLoadData(&L.mod, kBlobs[i].data);
+      if (e != hipSuccess) return e;
+      e = hipModuleGetFunction(&L.fn, L.mod, kBlobs[i].name);
+      if (e != hipSuccess) return e;
+    }
+    if (!L.fn) return hipErrorInvalidValue;
+  }
+  VmArgs args = a;
+  size_t size = sizeof(VmArgs);
+  void* extra[] = {HIP_LAUNCH_PARAM_BUFFER_POINTER, &args, HIP_LAUNCH_PARAM_BUFFER_SIZE, &size, HIP_LAUNCH_PARAM_END};
+  return hipModuleLaunchKernel(g_loaded[i].fn, blocks, 1, 1, VM_BLOCK, 1, 1, 0, st, nullptr, extra);
+}

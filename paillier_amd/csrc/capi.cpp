@@ -58,6 +58,8 @@ struct pgpu_ctx {
   struct Ev { hipEvent_t a, b; double mads; };
   std::vector<Ev> evs;
   size_t evs_used = 0;
+  bool use_asm = true;       // hand-scheduled VM kernels (pgpu_ctx_set_flag("asm", 0) selects the hipcc-generated ones)
+  int last_vm_asm = 0;       // number of VM launches of the last call that ran the assembly kernel
 
   void bind() { HIPCHK(hipSetDevice(device)); }
 
@@ -74,6 +76,7 @@ struct pgpu_ctx {
     for (auto& c : chunks) c.used = 0;
     host_keep.clear();
     evs_used = 0;
+    last_vm_asm = 0;
   }
   void* ws(size_t bytes) {
     bytes = round_up(bytes ? bytes : 1, 256);
@@ -196,7 +199,9 @@ struct DevLimbs {
 struct Prog {
   std::vector<uint32_t> w;
   double montmuls = 0;
+  bool asm_ok = true;  // only opcodes the assembly kernel implements
   void op(uint32_t o, uint32_t arg = 0, uint32_t aux = 0) {
+    if (o == VM_MULV || o == VM_SETOFF) asm_ok = false;
     w.push_back(o | (aux << 8));
     w.push_back(arg);
     if (o == VM_SQR || o == VM_MUL || o == VM_MULC || o == VM_MULV) montmuls += 1;
@@ -321,7 +326,11 @@ void run_vm(pgpu_ctx* ctx, size_t nb, const SegSpec& s0, const SegSpec* s1, bool
     ev->mads = montmuls * 2.0 * mc->WT * mc->WT * (double)nb;  // v_mad_u64_u32 lane-ops executed
     HIPCHK(hipEventRecord(ev->a, ctx->stream));
   }
-  hipError_t e = launch_vm(mc->WL, mc->K, a, blocks, ctx->stream);
+  bool use_asm = ctx->use_asm && vm_asm_available(mc->WL, mc->K) && s0.prog->asm_ok && (!s1 || s1->prog->asm_ok) &&
+                 (uint64_t)nb * mc->WT * 4 < (1ull << 32);
+  hipError_t e = use_asm ? launch_vm_asm(mc->WL, mc->K, a, blocks, ctx->stream)
+                         : launch_vm(mc->WL, mc->K, a, blocks, ctx->stream);
+  if (use_asm) ctx->last_vm_asm++;
   if (e != hipSuccess) throw HipError{e, "launch_vm"};
   if (profile) HIPCHK(hipEventRecord(ev->b, ctx->stream));
 }
@@ -440,6 +449,14 @@ void pgpu_ctx_destroy(pgpu_ctx* ctx) {
   (void)hipStreamSynchronize(ctx->stream);
   delete ctx;
 }
+
+int pgpu_ctx_set_flag(pgpu_ctx* ctx, const char* name, int value) {
+  if (!ctx || !name) return fail(PGPU_ERR_INVALID, "null argument");
+  if (strcmp(name, "asm") == 0) { ctx->use_asm = value != 0; return PGPU_OK; }
+  return fail(PGPU_ERR_INVALID, "unknown flag %s", name);
+}
+
+int pgpu_ctx_last_vm_asm(pgpu_ctx* ctx) { return ctx ? ctx->last_vm_asm : 0; }
 
 int pgpu_ctx_last_profile(pgpu_ctx* ctx, double* vm_ms, int* vm_launches, double* vm_mads) {
   if (!ctx) return fail(PGPU_ERR_INVALID, "null ctx");
@@ -575,6 +592,34 @@ int pgpu_modexp(const pgpu_modulus* mod, size_t batch, const uint8_t* base, size
       modexp_perlane_run(ctx, mc, pl, exps, we, wide, false);
     }
     pack_result(ctx, pl.out(), mc.WT, nb, batch, out, out_stride, mc.nbytes, mem);
+    HIPCHK(hipStreamSynchronize(ctx->stream));
+  });
+}
+
+/* Test hook: run a raw VM program on raw limb-major slot memory (host arrays of 28-bit limbs).
+ * mem_words = nslots * WT * nb uint32.  Used by tests/ to compare the assembly and hipcc kernels per opcode. */
+int pgpu_vm_debug_run(const pgpu_modulus* mod, const uint32_t* prog, size_t prog_words, uint32_t* mem_host,
+                      size_t nslots, size_t nb, int use_asm, int* wt_out) {
+  if (!mod || !prog || !mem_host) return fail(PGPU_ERR_INVALID, "null argument");
+  pgpu_ctx* ctx = mod->ctx;
+  const ModCtx& mc = mod->mc;
+  if (wt_out) *wt_out = mc.WT;
+  return guarded([&] {
+    if (nb % VM_BLOCK) api_throw(PGPU_ERR_INVALID, "nb must be a multiple of 256");
+    ctx->bind();
+    ctx->reset_ws();
+    size_t words = nslots * (size_t)mc.WT * nb;
+    uint32_t* d = ctx->ws_t<uint32_t>(words);
+    HIPCHK(hipMemcpyAsync(d, mem_host, words * 4, hipMemcpyHostToDevice, ctx->stream));
+    Prog p;
+    p.w.assign(prog, prog + prog_words);
+    p.asm_ok = true;
+    bool saved = ctx->use_asm;
+    ctx->use_asm = use_asm != 0;
+    SegSpec s{&mc, &p, d, nullptr};
+    try { run_vm(ctx, nb, s, nullptr, false); } catch (...) { ctx->use_asm = saved; throw; }
+    ctx->use_asm = saved;
+    HIPCHK(hipMemcpyAsync(mem_host, d, words * 4, hipMemcpyDeviceToHost, ctx->stream));
     HIPCHK(hipStreamSynchronize(ctx->stream));
   });
 }

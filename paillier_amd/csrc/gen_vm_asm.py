@@ -1,0 +1,562 @@
+#!/usr/bin/env python3
+"""gen_vm_asm.py -- emits the hand-scheduled gfx950 assembly of the big-integer VM kernel
+(`vm_asm_<WL>_<K>`), the hot kernel of the engine.
+
+Same contract as the compiler-generated `vm_kernel<WL,K>` in kernels.hip (same VmArgs kernarg block, same
+opcodes, same LDS/HBM layouts, bit-identical results); tests run both and compare.  Why assembly: the inner
+loop is 2*WL v_mad_u64_u32 per row and nothing else should issue.  hipcc's version of it carries an s_nop
+after every inline-asm multiply that feeds another one and waits for LDS on every modulus read (31 % of the
+multiply issue rate measured); here the row is one hand-ordered stream:
+
+  * pass A (t[j] += a_i*x[j]) runs DEPTH columns ahead of pass B (t[j-1] = t[j] + m*n[j]) so no multiply
+    waits on the one before it;
+  * K == 1: the modulus lives in SGPRs for the whole kernel (v_mad_u64_u32 takes an SGPR multiplicand), so a
+    row touches LDS once (the next a_i, prefetched a row ahead);
+  * K > 1: modulus limbs stream from LDS through rotating 4-limb buffers with counted lgkmcnt waits;
+  * accumulators t[] (2*WL VGPRs) and the operand x[] (WL VGPRs) never move: pass B writes column j's
+    result into column j-1's registers, which is the Montgomery shift.
+
+Register file budget (WL = 74): 148 (t) + 74 (x) + ~30 = 252 <= 256 architectural VGPRs -> 2 waves/SIMD.
+
+Supported opcodes: END LOAD STORE LOADC SQR MUL MULC ADD (programs using MULV / SETOFF run on the
+compiler-generated kernel).
+"""
+import sys
+
+LB = 28
+MASK = (1 << LB) - 1
+BLOCK = 256
+OPS = dict(END=0, LOAD=1, STORE=2, LOADC=3, SQR=4, MUL=5, MULC=6, MULV=7, ADD=8, SETOFF=9)
+
+
+class Gen:
+    def __init__(self, WL, K, depth=8):
+        assert K in (1, 2, 4)
+        self.WL, self.K, self.WT = WL, K, WL * K
+        self.NPB = BLOCK // K
+        self.WLp = (WL + 3) // 4 * 4
+        self.depth = depth
+        self.n_sgpr = (K == 1 and WL <= 74)
+        self.flush = (2 * self.WT + 1) > 255
+        self.flush_every = 48
+        self.lines = []
+        self.name = f"vm_asm_{WL}_{K}"
+        # ---- VGPR map: t[] pairs, x[], then scalars; pairs are even-aligned
+        self.vX = 2 * WL
+        e = 3 * WL
+        singles = ["ai", "ain", "m", "t1"]
+        for nm in singles:
+            setattr(self, "v_" + nm, e)
+            e += 1
+        e = (e + 1) // 2 * 2
+        self.v_y0 = e
+        e += 2
+        self.NBUF = 3
+        self.nbuf = []
+        if not self.n_sgpr:
+            for i in range(self.NBUF):
+                self.nbuf.append(e)
+                e += 4
+        for nm in ["goff", "aread", "awrite", "arow", "nbase", "isfirst", "notlast", "t2", "t3", "t4", "koff"]:
+            setattr(self, "v_" + nm, e)
+            e += 1
+        self.v_addr = self.v_arow  # row pointer (inside a product) and global offset (between products) never overlap
+        e = (e + 1) // 2 * 2
+        self.v_p0 = e  # 64-bit temp pair
+        e += 2
+        self.v_p1 = e  # 64-bit temp pair; doubles as the row carry c
+        self.v_c = e
+        e += 2
+        self.n_vgpr = e
+        assert e <= 256, f"VGPR budget exceeded: {e}"
+        # ---- SGPR map
+        self.s_N = 20  # K == 1: modulus limbs s[20 : 20+WL)
+        self.s_sbase = 94  # 64-bit scalar base for global accesses
+        self.s_t0, self.s_t1 = 96, 97
+        self.n_sgpr_count = 100
+        # ---- LDS layout
+        self.lds_n = 0
+        self.lds_a = (K * self.WLp * 4 + 15) // 16 * 16 if not self.n_sgpr else 0
+        self.lds_bytes = self.lds_a + (self.WT + 1) * self.NPB * 4
+
+    # ---- helpers
+    def e(self, s="", raw=False):
+        self.lines.append(s if raw or not s or s.endswith(":") else "  " + s)
+
+    def T(self, j):
+        return f"v[{2 * j}:{2 * j + 1}]"
+
+    def Tlo(self, j):
+        return f"v{2 * j}"
+
+    def Thi(self, j):
+        return f"v{2 * j + 1}"
+
+    def X(self, j):
+        return f"v{self.vX + j}"
+
+    def P(self, r):
+        return f"v[{r}:{r + 1}]"
+
+    def V(self, r):
+        return f"v{r}"
+
+    def mad(self, dst, a, b, c):
+        self.e(f"v_mad_u64_u32 {dst}, vcc, {a}, {b}, {c}")
+
+    # ---------------------------------------------------------------------------------------------
+    def prologue(self):
+        g = self
+        e = self.e
+        e(f'.amdgcn_target "amdgcn-amd-amdhsa--gfx950"')
+        e(".text")
+        e(f".globl {self.name}")
+        e(".p2align 8")
+        e(f".type {self.name},@function")
+        e(f"{self.name}:")
+        # s[0:1] kernarg, s2 workgroup id, v0 workitem id
+        e("s_load_dword s3, s[0:1], 0x60")  # seg0_blocks
+        e("s_waitcnt lgkmcnt(0)")
+        e("s_cmp_ge_u32 s2, s3")
+        e("s_cbranch_scc0 L_seg0")
+        e("s_sub_u32 s2, s2, s3")  # block index inside segment 1
+        e("s_add_u32 s0, s0, 48")
+        e("s_addc_u32 s1, s1, 0")
+        e("L_seg0:")
+        e("s_load_dwordx8 s[4:11], s[0:1], 0x0")   # prog, nmod, consts, mem
+        e("s_load_dwordx4 s[12:15], s[0:1], 0x20")  # digits, n0inv, nb
+        e("s_waitcnt lgkmcnt(0)")
+        e("s_lshl_b32 s3, s15, 2")  # s3 = nb*4 : byte stride between limb rows
+        # lane indices
+        K, WL, NPB = self.K, self.WL, self.NPB
+        sh = {1: 0, 2: 1, 4: 2}[K]
+        e(f"v_and_b32 v{g.v_t1}, {K - 1}, v0")          # k
+        e(f"v_lshrrev_b32 v{g.v_t2}, {sh}, v0")          # gl
+        # g = blk*NPB + gl ; goff = (k*WL*nb + g)*4
+        e(f"s_mul_i32 s{g.s_t0}, s2, {NPB}")
+        e(f"v_add_u32 v{g.v_t3}, s{g.s_t0}, v{g.v_t2}")   # g
+        e(f"s_mul_i32 s{g.s_t1}, s15, {WL}")              # WL*nb
+        e(f"v_mul_lo_u32 v{g.v_t4}, v{g.v_t1}, s{g.s_t1}")  # k*WL*nb
+        e(f"v_add_lshl_u32 v{g.v_goff}, v{g.v_t4}, v{g.v_t3}, 2")
+        # LDS addresses
+        e(f"v_lshlrev_b32 v{g.v_aread}, 2, v{g.v_t2}")
+        if self.lds_a:
+            e(f"v_add_u32 v{g.v_aread}, {self.lds_a}, v{g.v_aread}")
+        e(f"v_mul_u32_u24 v{g.v_t4}, {WL * NPB * 4}, v{g.v_t1}")
+        e(f"v_add_u32 v{g.v_awrite}, v{g.v_t4}, v{g.v_aread}")
+        e(f"v_mul_u32_u24 v{g.v_nbase}, {self.WLp * 4}, v{g.v_t1}")
+        e(f"v_mul_u32_u24 v{g.v_koff}, {WL * 4}, v{g.v_t1}")  # byte offset of this lane's slice inside a WT-limb constant
+        # masks
+        e(f"v_cmp_eq_u32 vcc, 0, v{g.v_t1}")
+        e("s_nop 1")
+        e(f"v_cndmask_b32 v{g.v_isfirst}, 0, -1, vcc")
+        e(f"v_cmp_ne_u32 vcc, {K - 1}, v{g.v_t1}")
+        e("s_nop 1")
+        e(f"v_cndmask_b32 v{g.v_notlast}, 0, -1, vcc")
+        if self.n_sgpr:
+            # modulus -> SGPRs s[20: 20+WL)
+            off, s = 0, self.s_N
+            rem = WL
+            while rem > 0:
+                for cnt in (16, 8, 4, 2, 1):
+                    align = 4 if cnt >= 4 else cnt
+                    if cnt <= rem and s % align == 0:
+                        if cnt == 1:
+                            e(f"s_load_dword s{s}, s[6:7], {hex(off)}")
+                        else:
+                            e(f"s_load_dwordx{cnt} s[{s}:{s + cnt - 1}], s[6:7], {hex(off)}")
+                        off += 4 * cnt
+                        s += cnt
+                        rem -= cnt
+                        break
+                else:
+                    raise RuntimeError("cannot tile the modulus into SGPR loads")
+            e("s_waitcnt lgkmcnt(0)")
+        else:
+            # modulus -> LDS, slice k at byte offset k*WLp*4 (16-byte aligned for ds_read_b128)
+            e(f"v_lshlrev_b32 v{g.v_t3}, 2, v0")                 # tid*4
+            e(f"v_cmp_gt_u32 vcc, {WL}, v0")
+            e("s_nop 1")
+            e("s_and_saveexec_b64 s[96:97], vcc")
+            for sgi in range(K):
+                e(f"global_load_dword v{g.v_p1}, v{g.v_t3}, s[6:7] offset:{sgi * WL * 4}")
+                e("s_waitcnt vmcnt(0)")
+                e(f"ds_write_b32 v{g.v_t3}, v{g.v_p1} offset:{sgi * self.WLp * 4}")
+            e("s_waitcnt lgkmcnt(0)")
+            e("s_mov_b64 exec, s[96:97]")
+            e("s_barrier")
+        # x = 0
+        for j in range(WL):
+            e(f"v_mov_b32 {self.X(j)}, 0")
+
+    # scalar base of a memory slot: s[sbase] = mem + arg * WT*nb*4
+    def slot_base(self):
+        g = self
+        e = self.e
+        e(f"s_mul_i32 s{g.s_t0}, s3, {self.WT}")            # WT*nb*4 (< 2^32, enforced by the host)
+        e(f"s_mul_hi_u32 s{g.s_sbase + 1}, s17, s{g.s_t0}")
+        e(f"s_mul_i32 s{g.s_sbase}, s17, s{g.s_t0}")
+        e(f"s_add_u32 s{g.s_sbase}, s{g.s_sbase}, s10")
+        e(f"s_addc_u32 s{g.s_sbase + 1}, s{g.s_sbase + 1}, s11")
+
+    def const_base(self):
+        g = self
+        e = self.e
+        e(f"s_mul_i32 s{g.s_t0}, s17, {self.WT * 4}")
+        e(f"s_add_u32 s{g.s_sbase}, s8, s{g.s_t0}")
+        e(f"s_addc_u32 s{g.s_sbase + 1}, s9, 0")
+
+    def load_slot_into(self, regs):
+        """regs[j] <- limb j of mem[slot] for this lane (slot base already in s[sbase])"""
+        g = self
+        e = self.e
+        e(f"v_mov_b32 v{g.v_addr}, v{g.v_goff}")
+        for j in range(self.WL):
+            e(f"global_load_dword {regs[j]}, v{g.v_addr}, s[{g.s_sbase}:{g.s_sbase + 1}]")
+            if j != self.WL - 1:
+                e(f"v_add_u32 v{g.v_addr}, s3, v{g.v_addr}")
+        e("s_waitcnt vmcnt(0)")
+
+    def load_const_into(self, regs):
+        g = self
+        for j in range(self.WL):
+            self.e(f"global_load_dword {regs[j]}, v{g.v_koff}, s[{g.s_sbase}:{g.s_sbase + 1}] offset:{4 * j}")
+        self.e("s_waitcnt vmcnt(0)")
+
+    def stage_to_lds(self, regs):
+        """a-operand column of this lane's slice <- regs"""
+        g = self
+        e = self.e
+        stride = self.NPB * 4
+        base_reg = g.v_awrite
+        cur_base_off = 0
+        for j in range(self.WL):
+            off = j * stride - cur_base_off
+            if off > 65535:
+                cur_base_off = j * stride
+                e(f"v_add_u32 v{g.v_t1}, {cur_base_off}, v{g.v_awrite}")
+                base_reg = g.v_t1
+                off = 0
+            e(f"ds_write_b32 v{base_reg}, {regs[j]} offset:{off}")
+        e("s_waitcnt lgkmcnt(0)")
+
+    # ---------------------------------------------------------------------------------------------
+    def dispatcher(self):
+        g = self
+        e = self.e
+        Xs = [self.X(j) for j in range(self.WL)]
+        St = [f"v{j}" for j in range(self.WL)]  # staging registers (the accumulators are dead between products)
+        e("L_next:")
+        e("s_load_dwordx2 s[16:17], s[4:5], 0x0")
+        e("s_add_u32 s4, s4, 8")
+        e("s_addc_u32 s5, s5, 0")
+        e("s_waitcnt lgkmcnt(0)")
+        e("s_and_b32 s18, s16, 0xff")
+        for nm in ("SQR", "MUL", "MULC", "LOAD", "STORE", "LOADC", "ADD"):
+            e(f"s_cmp_eq_u32 s18, {OPS[nm]}")
+            e(f"s_cbranch_scc1 L_{nm.lower()}")
+        e("s_endpgm")  # END (and anything unsupported: the host never sends those)
+
+        e("L_load:")
+        self.slot_base()
+        self.load_slot_into(Xs)
+        e("s_branch L_next")
+
+        e("L_loadc:")
+        self.const_base()
+        self.load_const_into(Xs)
+        e("s_branch L_next")
+
+        e("L_store:")
+        self.slot_base()
+        e(f"v_mov_b32 v{g.v_addr}, v{g.v_goff}")
+        for j in range(self.WL):
+            e(f"global_store_dword v{g.v_addr}, {Xs[j]}, s[{g.s_sbase}:{g.s_sbase + 1}]")
+            if j != self.WL - 1:
+                e(f"v_add_u32 v{g.v_addr}, s3, v{g.v_addr}")
+        e("s_waitcnt vmcnt(0)")
+        e("s_branch L_next")
+
+        e("L_add:")
+        self.slot_base()
+        self.load_slot_into(St)
+        for j in range(self.WL):
+            e(f"v_add_u32 {Xs[j]}, {Xs[j]}, {St[j]}")
+        e("s_branch L_next")
+
+        e("L_mul:")
+        self.slot_base()
+        self.load_slot_into(St)
+        self.stage_to_lds(St)
+        e("s_branch L_montmul")
+
+        e("L_mulc:")
+        self.const_base()
+        self.load_const_into(St)
+        self.stage_to_lds(St)
+        e("s_branch L_montmul")
+
+        e("L_sqr:")
+        self.stage_to_lds(Xs)
+        # falls through into the product
+
+    # ---------------------------------------------------------------------------------------------
+    def montmul(self):
+        g = self
+        e = self.e
+        WL, K, NPB = self.WL, self.K, self.NPB
+        rstride = NPB * 4
+        e("L_montmul:")
+        for j in range(WL if K > 1 else WL - 1):
+            e(f"v_mov_b32 {self.Tlo(j)}, 0")
+            e(f"v_mov_b32 {self.Thi(j)}, 0")
+        e(f"v_mov_b32 v{g.v_arow}, v{g.v_aread}")
+        e(f"ds_read_b32 v{g.v_ain}, v{g.v_arow}")
+        e(f"v_add_u32 v{g.v_arow}, {rstride}, v{g.v_arow}")
+        e(f"s_mov_b32 s19, 0")
+        e("L_row:")
+        # LDS queue model: list of destination tags in issue order
+        q = []
+
+        def wait_for(tag):
+            idx = max(i for i, t in enumerate(q) if t == tag)
+            after = len(q) - 1 - idx
+            e(f"s_waitcnt lgkmcnt({after})")
+            del q[: idx + 1]
+
+        e("s_waitcnt lgkmcnt(0)")
+        e(f"v_mov_b32 v{g.v_ai}, v{g.v_ain}")
+        e(f"ds_read_b32 v{g.v_ain}, v{g.v_arow}")
+        q.append("ain")
+        e(f"v_add_u32 v{g.v_arow}, {rstride}, v{g.v_arow}")
+        nchunks = (WL + 3) // 4
+        issued = 0
+        if not self.n_sgpr:
+            for cidx in range(min(g.NBUF, nchunks)):
+                e(f"ds_read_b128 v[{g.nbuf[cidx % g.NBUF]}:{g.nbuf[cidx % g.NBUF] + 3}], v{g.v_nbase} offset:{16 * cidx}")
+                q.append(("n", cidx))
+                issued += 1
+
+        def N(j):
+            if self.n_sgpr:
+                return f"s{g.s_N + j}"
+            return f"v{g.nbuf[(j // 4) % g.NBUF] + (j % 4)}"
+
+        ai = f"v{g.v_ai}"
+        m = f"v{g.v_m}"
+
+        def A(j):
+            if j == WL - 1 and K == 1:
+                self.mad(self.T(j), ai, self.X(j), "0")
+            else:
+                self.mad(self.T(j), ai, self.X(j), self.T(j))
+
+        state = {"issued": issued}
+
+        def B(j):
+            if not self.n_sgpr and j % 4 == 0:
+                wait_for(("n", j // 4))
+            if j == 0:
+                self.mad(self.P(g.v_y0), m, N(0), self.T(0))
+            elif j == 1:
+                self.mad(self.T(0), m, N(1), self.T(1))
+            else:
+                self.mad(self.T(j - 1), m, N(j), self.T(j))
+            if not self.n_sgpr and j % 4 == 3 and state["issued"] < nchunks:
+                cidx = state["issued"]
+                # buffer (cidx % 4) was last used by chunk cidx-4 < j//4: free
+                e(f"ds_read_b128 v[{g.nbuf[cidx % g.NBUF]}:{g.nbuf[cidx % g.NBUF] + 3}], v{g.v_nbase} offset:{16 * cidx}")
+                q.append(("n", cidx))
+                state["issued"] += 1
+
+        D = min(self.depth, WL)
+        for j in range(D):
+            A(j)
+            if j == 1 or (D == 1 and j == 0):
+                pass
+        # quotient digit
+        e(f"v_mul_lo_u32 {m}, {self.Tlo(0)}, s14")
+        e(f"v_and_b32 {m}, {hex(MASK)}, {m}")
+        if K > 1:
+            bc = {2: "[0,0,2,2]", 4: "[0,0,0,0]"}[K]
+            e("s_nop 1")
+            e(f"v_mov_b32_dpp {m}, {m} quad_perm:{bc} row_mask:0xf bank_mask:0xf")
+        nextA = D
+        for j in range(WL):
+            B(j)
+            if j == 0:
+                e(f"v_lshrrev_b64 {self.P(g.v_c)}, {LB}, {self.P(g.v_y0)}")
+                if K > 1:
+                    e(f"v_and_b32 v{g.v_c}, v{g.v_c}, v{g.v_isfirst}")
+                    e(f"v_and_b32 v{g.v_c + 1}, v{g.v_c + 1}, v{g.v_isfirst}")
+            if nextA < WL:
+                A(nextA)
+                nextA += 1
+            if j == 1:
+                e(f"v_lshl_add_u64 {self.T(0)}, {self.T(0)}, 0, {self.P(g.v_c)}")
+        if K > 1:
+            fn = {2: "[1,1,3,3]", 4: "[1,2,3,3]"}[K]
+            e(f"v_mov_b32_dpp {self.Tlo(WL - 1)}, v{g.v_y0} quad_perm:{fn} row_mask:0xf bank_mask:0xf")
+            e(f"v_mov_b32_dpp {self.Thi(WL - 1)}, v{g.v_y0 + 1} quad_perm:{fn} row_mask:0xf bank_mask:0xf")
+            e(f"v_and_b32 {self.Tlo(WL - 1)}, {self.Tlo(WL - 1)}, v{g.v_notlast}")
+            e(f"v_and_b32 {self.Thi(WL - 1)}, {self.Thi(WL - 1)}, v{g.v_notlast}")
+        e("s_add_u32 s19, s19, 1")
+        if self.flush:
+            self.flush_block()
+        e(f"s_cmp_lt_u32 s19, {self.WT}")
+        e("s_cbranch_scc1 L_row")
+        e("s_waitcnt lgkmcnt(0)")  # the dangling prefetch of row WT
+        if K == 1:
+            # the top column is re-created by A(WL-1) every row (src2 = 0); after the last shift it is logically 0
+            e(f"v_mov_b32 {self.Tlo(WL - 1)}, 0")
+            e(f"v_mov_b32 {self.Thi(WL - 1)}, 0")
+        self.normalize()
+        e("s_branch L_next")
+
+    def flush_block(self):
+        """every flush_every rows: push bits >= 2^28 of every accumulator one column up"""
+        g = self
+        e = self.e
+        WL, K = self.WL, self.K
+        # s19 already incremented: flush when s19 % flush_every == 0  (s19 = 48, 96, ...)
+        e(f"s_mul_hi_u32 s{g.s_t0}, s19, {((1 << 32) + self.flush_every - 1) // self.flush_every}")  # s19 / fe
+        e(f"s_mul_i32 s{g.s_t0}, s{g.s_t0}, {self.flush_every}")
+        e(f"s_cmp_lg_u32 s{g.s_t0}, s19")
+        e("s_cbranch_scc1 L_noflush")
+        top = WL - 1
+        if K > 1:
+            # top_c = (t[top] >> 28) & notlast ; t[top] &= (MASK | ~notlast)
+            e(f"v_lshrrev_b64 {self.P(g.v_p1)}, {LB}, {self.T(top)}")
+            e(f"v_and_b32 v{g.v_p1}, v{g.v_p1}, v{g.v_notlast}")
+            e(f"v_and_b32 v{g.v_p1 + 1}, v{g.v_p1 + 1}, v{g.v_notlast}")
+            e(f"v_not_b32 v{g.v_t1}, v{g.v_notlast}")
+            e(f"v_or_b32 v{g.v_t2}, {hex(MASK)}, v{g.v_t1}")
+            e(f"v_and_b32 {self.Tlo(top)}, {self.Tlo(top)}, v{g.v_t2}")
+            e(f"v_and_b32 {self.Thi(top)}, {self.Thi(top)}, v{g.v_t1}")
+        for j in range(WL - 2, -1, -1):
+            e(f"v_lshrrev_b64 {self.P(g.v_p0)}, {LB}, {self.T(j)}")
+            e(f"v_lshl_add_u64 {self.T(j + 1)}, {self.T(j + 1)}, 0, {self.P(g.v_p0)}")
+            e(f"v_and_b32 {self.Tlo(j)}, {hex(MASK)}, {self.Tlo(j)}")
+            e(f"v_mov_b32 {self.Thi(j)}, 0")
+        if K > 1:
+            fp = {2: "[0,0,2,2]", 4: "[0,0,1,2]"}[K]
+            e("s_nop 1")
+            e(f"v_mov_b32_dpp v{g.v_p0}, v{g.v_p1} quad_perm:{fp} row_mask:0xf bank_mask:0xf")
+            e(f"v_mov_b32_dpp v{g.v_p0 + 1}, v{g.v_p1 + 1} quad_perm:{fp} row_mask:0xf bank_mask:0xf")
+            e(f"v_not_b32 v{g.v_t1}, v{g.v_isfirst}")
+            e(f"v_and_b32 v{g.v_p0}, v{g.v_p0}, v{g.v_t1}")
+            e(f"v_and_b32 v{g.v_p0 + 1}, v{g.v_p0 + 1}, v{g.v_t1}")
+            e(f"v_lshl_add_u64 {self.T(0)}, {self.T(0)}, 0, {self.P(g.v_p0)}")
+        e("L_noflush:")
+
+    def normalize(self):
+        """x_j = ((lo_j + mid_{j-1} + hi_{j-2}) & M) + ((lo_{j-1} + mid_{j-2} + hi_{j-3}) >> 28)"""
+        g = self
+        e = self.e
+        WL, K = self.WL, self.K
+        M = hex(MASK)
+        # rolling registers: mid_prev (t1), hi_prev (t2), hi_prev2 (t3), s_prev (t4)
+        mid_p, hi_p, hi_p2, s_p = f"v{g.v_t1}", f"v{g.v_t2}", f"v{g.v_t3}", f"v{g.v_t4}"
+        if K > 1:
+            fp = {2: "[0,0,2,2]", 4: "[0,0,1,2]"}[K]
+            top, top2 = WL - 1, WL - 2
+            # incoming mid_{-1}, hi_{-1}, hi_{-2} from the previous lane's top columns
+            e(f"v_alignbit_b32 v{g.v_p0}, {self.Thi(top)}, {self.Tlo(top)}, {LB}")
+            e(f"v_and_b32 v{g.v_p0}, {M}, v{g.v_p0}")                       # mid_top
+            e(f"v_lshrrev_b32 v{g.v_p0 + 1}, {2 * LB - 32}, {self.Thi(top)}")     # hi_top
+            e(f"v_lshrrev_b32 v{g.v_p1}, {2 * LB - 32}, {self.Thi(top2)}")        # hi_top2
+            e(f"v_not_b32 v{g.v_p1 + 1}, v{g.v_isfirst}")
+            e("s_nop 1")
+            e(f"v_mov_b32_dpp {mid_p}, v{g.v_p0} quad_perm:{fp} row_mask:0xf bank_mask:0xf")
+            e(f"v_mov_b32_dpp {hi_p}, v{g.v_p0 + 1} quad_perm:{fp} row_mask:0xf bank_mask:0xf")
+            e(f"v_mov_b32_dpp {hi_p2}, v{g.v_p1} quad_perm:{fp} row_mask:0xf bank_mask:0xf")
+            e(f"v_and_b32 {mid_p}, {mid_p}, v{g.v_p1 + 1}")
+            e(f"v_and_b32 {hi_p}, {hi_p}, v{g.v_p1 + 1}")
+            e(f"v_and_b32 {hi_p2}, {hi_p2}, v{g.v_p1 + 1}")
+        else:
+            e(f"v_mov_b32 {mid_p}, 0")
+            e(f"v_mov_b32 {hi_p}, 0")
+            e(f"v_mov_b32 {hi_p2}, 0")
+        # pass 1: s_j into X(j) (x is dead after the rows)
+        for j in range(WL):
+            lo = f"v{g.v_p0}"
+            e(f"v_and_b32 {lo}, {M}, {self.Tlo(j)}")
+            e(f"v_add3_u32 {self.X(j)}, {lo}, {mid_p}, {hi_p2}")
+            # roll: hi_p2 <- hi_p ; hi_p <- hi_j ; mid_p <- mid_j
+            e(f"v_mov_b32 {hi_p2}, {hi_p}")
+            e(f"v_lshrrev_b32 {hi_p}, {2 * LB - 32}, {self.Thi(j)}")
+            e(f"v_alignbit_b32 {mid_p}, {self.Thi(j)}, {self.Tlo(j)}, {LB}")
+            e(f"v_and_b32 {mid_p}, {M}, {mid_p}")
+        # pass 2 (descending so s_{j-1} is still unmodified): x_j = (s_j & M) + (s_{j-1} >> 28)
+        if K > 1:
+            fp = {2: "[0,0,2,2]", 4: "[0,0,1,2]"}[K]
+            e(f"v_lshrrev_b32 v{g.v_p0}, {LB}, {self.X(WL - 1)}")
+            e(f"v_not_b32 v{g.v_p1 + 1}, v{g.v_isfirst}")
+            e("s_nop 1")
+            e(f"v_mov_b32_dpp {s_p}, v{g.v_p0} quad_perm:{fp} row_mask:0xf bank_mask:0xf")
+            e(f"v_and_b32 {s_p}, {s_p}, v{g.v_p1 + 1}")
+        for j in range(WL - 1, -1, -1):
+            if j >= 1:
+                e(f"v_lshrrev_b32 v{g.v_p0}, {LB}, {self.X(j - 1)}")
+                e(f"v_and_b32 {self.X(j)}, {M}, {self.X(j)}")
+                e(f"v_add_u32 {self.X(j)}, {self.X(j)}, v{g.v_p0}")
+            else:
+                e(f"v_and_b32 {self.X(0)}, {M}, {self.X(0)}")
+                if K > 1:
+                    e(f"v_add_u32 {self.X(0)}, {self.X(0)}, {s_p}")
+
+    def epilogue(self):
+        e = self.e
+        nm = self.name
+        e(".rodata")
+        e(".p2align 6")
+        e(f".amdhsa_kernel {nm}")
+        e(f"  .amdhsa_group_segment_fixed_size {self.lds_bytes}")
+        e("  .amdhsa_private_segment_fixed_size 0")
+        e("  .amdhsa_kernarg_size 104")
+        e("  .amdhsa_user_sgpr_kernarg_segment_ptr 1")
+        e("  .amdhsa_system_sgpr_workgroup_id_x 1")
+        e("  .amdhsa_system_vgpr_workitem_id 0")
+        e(f"  .amdhsa_next_free_vgpr {self.n_vgpr}")
+        e(f"  .amdhsa_next_free_sgpr {self.n_sgpr_count}")
+        e(f"  .amdhsa_accum_offset {(self.n_vgpr + 3) // 4 * 4}")
+        e("  .amdhsa_reserve_vcc 1")
+        e(".end_amdhsa_kernel")
+        e(".amdgpu_metadata", raw=True)
+        e("---", raw=True)
+        e("amdhsa.version: [1, 2]", raw=True)
+        e("amdhsa.kernels:", raw=True)
+        e(f"  - .name: {nm}", raw=True)
+        e(f"    .symbol: {nm}.kd", raw=True)
+        e("    .kernarg_segment_size: 104", raw=True)
+        e(f"    .group_segment_fixed_size: {self.lds_bytes}", raw=True)
+        e("    .private_segment_fixed_size: 0", raw=True)
+        e("    .kernarg_segment_align: 8", raw=True)
+        e("    .wavefront_size: 64", raw=True)
+        e(f"    .sgpr_count: {self.n_sgpr_count}", raw=True)
+        e(f"    .vgpr_count: {self.n_vgpr}", raw=True)
+        e("    .max_flat_workgroup_size: 256", raw=True)
+        e("    .args:", raw=True)
+        e("      - .size: 104", raw=True)
+        e("        .offset: 0", raw=True)
+        e("        .value_kind: by_value", raw=True)
+        e("...", raw=True)
+        e(".end_amdgpu_metadata", raw=True)
+
+    def generate(self):
+        self.prologue()
+        self.dispatcher()
+        self.montmul()
+        self.epilogue()
+        return "\n".join(self.lines) + "\n"
+
+
+SHAPES = [(74, 1), (37, 1), (55, 1), (55, 2), (74, 2), (55, 4)]
+
+if __name__ == "__main__":
+    out_dir = sys.argv[1] if len(sys.argv) > 1 else "."
+    for wl, k in SHAPES:
+        g = Gen(wl, k)
+        with open(f"{out_dir}/vm_asm_{wl}_{k}.s", "w") as f:
+            f.write(g.generate())
+        print(f"vm_asm_{wl}_{k}: vgpr={g.n_vgpr} lds={g.lds_bytes}")

@@ -104,3 +104,24 @@ def test_add_constmult_1024(ctx, key1024):
     assert pk.ConstMultBatch(a, k) == [po.const_mult(sk_o, po.Ciphertext(x), k).C for x in a]
     ks = [rng.randrange(sk_o.N) for _ in a]
     assert pk.ConstMultBatch(a[:40], ks[:40]) == [po.const_mult(sk_o, po.Ciphertext(x), kk).C for x, kk in zip(a, ks[:40])]
+
+
+@pytest.mark.parametrize("bits", [1024, 1536, 2048, 3072, 4096, 6144])
+def test_asm_kernel_matches_compiler_kernel(ctx, bits):
+    """The hand-scheduled assembly VM kernel and the hipcc-generated one must agree bit for bit (and with Python)."""
+    import paillier_amd as pa
+    rng = random.Random(bits + 7)
+    n = rand_odd(bits, rng)
+    mod = pa.Modulus(ctx, n)
+    bases = [rng.randrange(n) for _ in range(130)] + [0, 1, n - 1]
+    e = rng.getrandbits(160) | 1
+    try:
+        ctx.set_flag("asm", 1)
+        got_asm = mod.exp_batch(bases, e)
+        assert ctx.last_vm_asm() >= 1, "assembly kernel was not used"
+        ctx.set_flag("asm", 0)
+        got_cc = mod.exp_batch(bases, e)
+        assert ctx.last_vm_asm() == 0
+    finally:
+        ctx.set_flag("asm", 1)
+    assert got_asm == got_cc == [pow(b, e, n) for b in bases]
