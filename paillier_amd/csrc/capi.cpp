@@ -804,8 +804,11 @@ uint32_t* decrypt1_crt(const pgpu_seckey* sk, const uint32_t* c_limbs, size_t nb
   launch_canon(uq, mq2.d_nmod, W2, nb, ctx->stream);
   // small memory: slots 0 Lp, 1 Lq, 2 mp, 3 mq, 4 B, 5 A, 6 h
   uint32_t* m1 = ctx->ws_t<uint32_t>(S1 * 7);
-  launch_L_exact(up, W2, sk->pinv2k.d, mp.d_nmod, W1, m1 + 0 * S1, W1, nb, count, d_status, PGPU_LANE_NONUNIT, ctx->stream);
-  launch_L_exact(uq, W2, sk->qinv2k.d, mq.d_nmod, W1, m1 + 1 * S1, W1, nb, count, d_status, PGPU_LANE_NONUNIT, ctx->stream);
+  uint32_t* tb = ctx->ws_t<uint32_t>(S2);
+  launch_div_exact(up, W2, 1, nullptr, 0, tb, sk->pinv2k.d, mp.d_nmod, W1, m1 + 0 * S1, W1, nb, count, d_status,
+                   PGPU_LANE_NONUNIT, ctx->stream);
+  launch_div_exact(uq, W2, 1, nullptr, 0, tb, sk->qinv2k.d, mq.d_nmod, W1, m1 + 1 * S1, W1, nb, count, d_status,
+                   PGPU_LANE_NONUNIT, ctx->stream);
   Prog a, b, c;
   a.op(VM_LOAD, 0); a.op(VM_MULC, (uint32_t)sk->c_hpR); a.op(VM_STORE, 2); a.end();   // m_p = L_p * h_p mod p
   b.op(VM_LOAD, 1); b.op(VM_MULC, (uint32_t)sk->c_hqR); b.op(VM_STORE, 3); b.end();   // m_q = L_q * h_q mod q
@@ -829,6 +832,49 @@ uint32_t* decrypt1_crt(const pgpu_seckey* sk, const uint32_t* c_limbs, size_t nb
   return res;
 }
 
+
+// Level-one decryption by the reference's own formula (paillier.go:292-303), for ANY c (units or not):
+//   u = c^lambda mod n^2 ; ml = L(u) = Div(u - 1, n) (Euclidean: floor, and -1 for u = 0) ; m = ml * lambda^-1 mod n.
+// c: device array of mn2.WT limbs per number.  Returns device array of mn.WT-limb plaintexts.
+uint32_t* decrypt1_generic(const pgpu_seckey* sk, const uint32_t* c_limbs, size_t nb, size_t count) {
+  pgpu_ctx* ctx = sk->ctx;
+  const pgpu_pubkey* pk = sk->pk;
+  const ModCtx &mn = pk->mn, &mn2 = pk->mn2;
+  const int W1 = mn.WT, W2 = mn2.WT;
+  ModexpPlan pl = modexp_alloc(ctx, mn2, nb, 32);
+  HIPCHK(hipMemcpyAsync(pl.in(), c_limbs, (size_t)W2 * nb * 4, hipMemcpyDeviceToDevice, ctx->stream));
+  modexp_shared_run(ctx, mn2, pl, sk->lambda, false, false, false);  // u, canonical
+  int32_t* zf = ctx->ws_t<int32_t>(nb);
+  launch_is_zero(pl.out(), W2, nb, zf, ctx->stream);
+  // v = u - 1 (t of a division by 1 is not needed: reuse k_div_exact's first pass through a unit divisor is overkill;
+  // do it with the const-mul kernel: v = u * 1 + (2^(28 W2) - 1) mod 2^(28 W2) would wrap; use a dedicated pass below)
+  uint32_t* v = ctx->ws_t<uint32_t>((size_t)W2 * nb);
+  uint32_t* r = ctx->ws_t<uint32_t>((size_t)W1 * nb);
+  uint32_t* q = ctx->ws_t<uint32_t>((size_t)W1 * nb);
+  uint32_t* scratch_l = ctx->ws_t<uint32_t>((size_t)W1 * nb);
+  int32_t* st_dummy = ctx->ws_t<int32_t>(nb);
+  HIPCHK(hipMemsetAsync(st_dummy, 0, nb * 4, ctx->stream));
+  // k_div_exact's first pass writes t = u - 1 into tbuf = v (the quotient by n it also computes is discarded)
+  launch_div_exact(pl.out(), W2, 1, nullptr, 0, v, sk->ninv2k.d, mn.d_nmod, W1, scratch_l, W1, nb, count, st_dummy, 1,
+                   ctx->stream);
+  reduce_mod(ctx, mn, v, W2, r, nb);                                   // r = (u - 1) mod n
+  uint32_t* tb = ctx->ws_t<uint32_t>((size_t)W2 * nb);
+  launch_div_exact(v, W2, 0, r, W1, tb, sk->ninv2k.d, mn.d_nmod, W1, q, W1, nb, count, st_dummy, 2, ctx->stream);  // floor
+  size_t s1 = (size_t)W1 * nb;
+  uint32_t* m1 = ctx->ws_t<uint32_t>(s1 * 2);
+  HIPCHK(hipMemcpyAsync(m1, q, s1 * 4, hipMemcpyDeviceToDevice, ctx->stream));
+  Prog p;
+  p.op(VM_LOAD, 0);
+  p.op(VM_MULC, (uint32_t)sk->c_muR);   // ml * mu mod n
+  p.op(VM_STORE, 1);
+  p.end();
+  SegSpec sg{&mn, &p, m1, nullptr};
+  run_vm(ctx, nb, sg, nullptr, false);
+  launch_canon(m1 + s1, mn.d_nmod, W1, nb, ctx->stream);
+  launch_select_const(zf, sk->n_minus_mu.d, m1 + s1, W1, nb, ctx->stream);  // u = 0: L = -1 -> m = -mu mod n
+  return m1 + s1;
+}
+
 }  // namespace
 
 extern "C" {
@@ -849,14 +895,34 @@ int pgpu_decrypt(const pgpu_seckey* sk, int level, size_t batch, const uint8_t* 
     int32_t* d_status = ctx->ws_t<int32_t>(nb);
     HIPCHK(hipMemsetAsync(d_status, 0, nb * 4, ctx->stream));
     const bool crt = sk->has_crt && !(flags & PGPU_DECRYPT_NO_CRT);
-    if (!crt) api_throw(PGPU_ERR_UNSUPPORTED, "generic (non-CRT) decryption is not built yet");
-    const int W2 = sk->mp2.WT;
-    uint32_t* cl = ctx->ws_t<uint32_t>((size_t)2 * W2 * nb);
-    // the ciphertext is the last cbytes of each element (values >= n^2 are reduced implicitly by the Horner prologue)
-    unpack_operand(ctx, c, c_stride, cbytes, batch, mem, cl, 2 * W2, nb);
-    uint32_t* res = decrypt1_crt(sk, cl, nb, batch, d_status);
+    const int WC = pk->mn2.WT;  // == 2 * mp2.WT when CRT is available
+    if (crt && 2 * sk->mp2.WT != WC) api_throw(PGPU_ERR_UNSUPPORTED, "CRT and generic layouts disagree");
+    uint32_t* cl = ctx->ws_t<uint32_t>((size_t)WC * nb);
+    // the ciphertext is the last cbytes of each element (values >= n^2 are reduced implicitly)
+    unpack_operand(ctx, c, c_stride, cbytes, batch, mem, cl, WC, nb);
+    uint32_t* res;
+    std::vector<int32_t> hstat(batch, 0);
+    if (crt) {
+      res = decrypt1_crt(sk, cl, nb, batch, d_status);
+      HIPCHK(hipMemcpyAsync(hstat.data(), d_status, batch * 4, hipMemcpyDeviceToHost, ctx->stream));
+      HIPCHK(hipStreamSynchronize(ctx->stream));
+      std::vector<uint32_t> idx;
+      for (size_t i = 0; i < batch; ++i)
+        if (hstat[i] & PGPU_LANE_NONUNIT) idx.push_back((uint32_t)i);
+      if (!idx.empty()) {
+        // gcd(c, n) != 1 on these lanes: the CRT shortcut (L exact) does not apply; run the reference formula on them
+        const size_t nbg = round_up(idx.size(), VM_BLOCK);
+        uint32_t* d_idx = ctx->upload_words(idx);
+        uint32_t* cg = ctx->ws_t<uint32_t>((size_t)WC * nbg);
+        launch_gather(cl, nb, d_idx, idx.size(), cg, nbg, WC, ctx->stream);
+        uint32_t* rg = decrypt1_generic(sk, cg, nbg, idx.size());
+        launch_scatter(rg, nbg, d_idx, idx.size(), res, nb, pk->mn.WT, ctx->stream);
+      }
+    } else {
+      res = decrypt1_generic(sk, cl, nb, batch);
+    }
     pack_result(ctx, res, pk->mn.WT, nb, batch, m, m_stride, pk->mn.nbytes, mem);
-    if (status) HIPCHK(hipMemcpyAsync(status, d_status, batch * 4, hipMemcpyDeviceToHost, ctx->stream));
+    if (status) memcpy(status, hstat.data(), batch * 4);
     HIPCHK(hipStreamSynchronize(ctx->stream));
   });
 }

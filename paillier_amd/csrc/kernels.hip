@@ -232,27 +232,31 @@ __global__ void k_mul_const_add(const uint32_t* __restrict__ a, int wa, const ui
   }
 }
 
-// Paillier L function by exact division:  l = (u - 1) / d  where d (wd limbs, odd) divides u - 1.
-//   l = (u - 1) * dinv  mod 2^(28 wl),   dinv = d^-1 mod 2^(28 wl)  (uniform constant)
-// u is canonical (wu limbs).  The division is exact iff l * d + 1 == u; otherwise status |= flag
-// (the ciphertext was not a unit mod n: the caller re-runs that lane on the generic path).
-__global__ void k_L_exact(const uint32_t* __restrict__ u, int wu, const uint32_t* __restrict__ dinv,
-                          const uint32_t* __restrict__ d, int wd, uint32_t* __restrict__ l, int wl, size_t nb,
-                          size_t count, int32_t* __restrict__ status, int32_t flag) {
+// Exact division  l = t / d  with  t = u - sub_small - subv  (all canonical limb arrays, d odd, uniform):
+//   l = t * dinv  mod 2^(28 wl),   dinv = d^-1 mod 2^(28 wl)
+// The quotient is exact iff t >= 0 and l * d == t; otherwise status |= flag.
+// Used for Paillier's L(u) = (u - 1) / n  (u = 1 mod n for every unit c; a non-unit c fails the check and is
+// re-run on the generic path) and for floor((u-1)/n) = ((u-1) - ((u-1) mod n)) / n on the generic path.
+// tbuf: scratch limb-major array [wu][nb] that receives t.
+__global__ void k_div_exact(const uint32_t* __restrict__ u, int wu, uint32_t sub_small,
+                            const uint32_t* __restrict__ subv, int wsub, uint32_t* __restrict__ tbuf,
+                            const uint32_t* __restrict__ dinv, const uint32_t* __restrict__ d, int wd,
+                            uint32_t* __restrict__ l, int wl, size_t nb, size_t count, int32_t* __restrict__ status,
+                            int32_t flag) {
   size_t g = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (g >= nb) return;
-  // pass 1: l = (u - 1) * dinv mod 2^(28 wl), column by column; (u-1) limbs are generated on the fly
-  // borrow chain for u - 1:
+  int32_t br = 0;
+  for (int i = 0; i < wu; ++i) {
+    int32_t v = (int32_t)u[(size_t)i * nb + g] - br - (i == 0 ? (int32_t)sub_small : 0) -
+                ((subv && i < wsub) ? (int32_t)subv[(size_t)i * nb + g] : 0);
+    br = v < 0;
+    tbuf[(size_t)i * nb + g] = (uint32_t)(v + (br << LB)) & LMASK;
+  }
+  int bad = br;  // t < 0
   uint64_t acc = 0, hi = 0;
   for (int c = 0; c < wl; ++c) {
-    // (u-1)[i] for i <= c
-    int32_t br = 1;
     for (int i = 0; i <= c; ++i) {
-      int32_t ui = (i < wu) ? (int32_t)u[(size_t)i * nb + g] : 0;
-      int32_t v = ui - br;
-      br = v < 0;
-      uint32_t um1 = (uint32_t)(v + (br << LB)) & LMASK;
-      uint64_t p = (uint64_t)um1 * dinv[c - i];
+      uint64_t p = (uint64_t)(i < wu ? tbuf[(size_t)i * nb + g] : 0u) * dinv[c - i];
       acc += p;
       hi += acc < p;
     }
@@ -260,9 +264,7 @@ __global__ void k_L_exact(const uint32_t* __restrict__ u, int wu, const uint32_t
     acc = (acc >> LB) | (hi << (64 - LB));
     hi >>= LB;
   }
-  // pass 2: verify l * d + 1 == u over all wu limbs
-  int bad = 0;
-  acc = 1; hi = 0;
+  acc = 0; hi = 0;
   for (int c = 0; c < wu; ++c) {
     int i0 = c - (wd - 1) > 0 ? c - (wd - 1) : 0;
     int i1 = c < wl - 1 ? c : wl - 1;
@@ -271,12 +273,29 @@ __global__ void k_L_exact(const uint32_t* __restrict__ u, int wu, const uint32_t
       acc += p;
       hi += acc < p;
     }
-    bad |= ((uint32_t)acc & LMASK) != u[(size_t)c * nb + g];
+    bad |= ((uint32_t)acc & LMASK) != tbuf[(size_t)c * nb + g];
     acc = (acc >> LB) | (hi << (64 - LB));
     hi >>= LB;
   }
   bad |= (acc != 0) | (hi != 0);
   if (bad && g < count) status[g] |= flag;
+}
+
+// flags[g] = (x == 0)
+__global__ void k_is_zero(const uint32_t* __restrict__ x, int w, size_t nb, int32_t* __restrict__ flags) {
+  size_t g = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (g >= nb) return;
+  uint32_t o = 0;
+  for (int l = 0; l < w; ++l) o |= x[(size_t)l * nb + g];
+  flags[g] = o == 0;
+}
+
+// x <- c (uniform constant, w limbs) on the lanes whose flag is set
+__global__ void k_select_const(const int32_t* __restrict__ flags, const uint32_t* __restrict__ c, uint32_t* __restrict__ x,
+                               int w, size_t nb) {
+  size_t g = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (g >= nb || !flags[g]) return;
+  for (int l = 0; l < w; ++l) x[(size_t)l * nb + g] = c[l];
 }
 
 // out = (a - b) mod q for canonical a, b in [0, q): a - b + (a < b ? q : 0)
@@ -343,9 +362,17 @@ void launch_mul_const_add(const uint32_t* a, int wa, const uint32_t* bconst, int
                           uint32_t add_small, uint32_t* out, int wo, size_t nb, hipStream_t st) {
   hipLaunchKernelGGL(k_mul_const_add, HELPER_GRID(nb), 0, st, a, wa, bconst, wb, addv, wadd, add_small, out, wo, nb);
 }
-void launch_L_exact(const uint32_t* u, int wu, const uint32_t* dinv, const uint32_t* d, int wd, uint32_t* l, int wl,
-                    size_t nb, size_t count, int32_t* status, int32_t flag, hipStream_t st) {
-  hipLaunchKernelGGL(k_L_exact, HELPER_GRID(nb), 0, st, u, wu, dinv, d, wd, l, wl, nb, count, status, flag);
+void launch_div_exact(const uint32_t* u, int wu, uint32_t sub_small, const uint32_t* subv, int wsub, uint32_t* tbuf,
+                      const uint32_t* dinv, const uint32_t* d, int wd, uint32_t* l, int wl, size_t nb, size_t count,
+                      int32_t* status, int32_t flag, hipStream_t st) {
+  hipLaunchKernelGGL(k_div_exact, HELPER_GRID(nb), 0, st, u, wu, sub_small, subv, wsub, tbuf, dinv, d, wd, l, wl, nb, count,
+                     status, flag);
+}
+void launch_is_zero(const uint32_t* x, int w, size_t nb, int32_t* flags, hipStream_t st) {
+  hipLaunchKernelGGL(k_is_zero, HELPER_GRID(nb), 0, st, x, w, nb, flags);
+}
+void launch_select_const(const int32_t* flags, const uint32_t* c, uint32_t* x, int w, size_t nb, hipStream_t st) {
+  hipLaunchKernelGGL(k_select_const, HELPER_GRID(nb), 0, st, flags, c, x, w, nb);
 }
 void launch_sub_mod(const uint32_t* a, const uint32_t* b, const uint32_t* q, uint32_t* out, int w, size_t nb, hipStream_t st) {
   hipLaunchKernelGGL(k_sub_mod, HELPER_GRID(nb), 0, st, a, b, q, out, w, nb);
