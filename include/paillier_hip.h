@@ -105,6 +105,12 @@ int pgpu_decrypt(const pgpu_seckey* sk, int level, size_t batch, const uint8_t* 
 int pgpu_add(const pgpu_pubkey* pk, int level, size_t batch, const uint8_t* a, size_t a_stride, const uint8_t* b,
              size_t b_stride, uint8_t* out, size_t out_stride, int mem);
 
+/* PublicKey.Sub on two ciphertext vectors (operations.go:32-55 with two operands):
+ *   out[i] = a[i] * b[i]^-1 mod n^(s+1).  Returns PGPU_ERR_NOT_INVERTIBLE if some b[i] is not a unit
+ * (mpz_invert is undefined there and the reference does not check). */
+int pgpu_sub(const pgpu_pubkey* pk, int level, size_t batch, const uint8_t* a, size_t a_stride, const uint8_t* b,
+             size_t b_stride, uint8_t* out, size_t out_stride, int mem);
+
 /* PublicKey.ConstMult (operations.go:58-64): out[i] = c[i]^k mod n^(s+1).
  * k_stride == 0: one shared k of k_len bytes; otherwise k[i] at k + i*k_stride, k_len bytes each. */
 int pgpu_const_mult(const pgpu_pubkey* pk, int level, size_t batch, const uint8_t* c, size_t c_stride,
@@ -122,6 +128,12 @@ size_t pgpu_modulus_bytes(const pgpu_modulus* mod);
  * (up to twice the modulus width), as with mpz_powm. */
 int pgpu_modexp(const pgpu_modulus* mod, size_t batch, const uint8_t* base, size_t base_stride, size_t base_len,
                 const uint8_t* e, size_t e_len, size_t e_stride, uint8_t* out, size_t out_stride, int mem);
+
+/* gmp.Int.ModInverse(x, N) for a batch (Montgomery's trick as a parallel tree: 3 modular products per element and
+ * one host inversion per call).  x may be up to twice the modulus width.  PGPU_ERR_NOT_INVERTIBLE if any x[i] is
+ * not a unit. */
+int pgpu_modinv(const pgpu_modulus* mod, size_t batch, const uint8_t* x, size_t x_stride, size_t x_len, uint8_t* out,
+                size_t out_stride, int mem);
 
 /* new(gmp.Int).Mod(new(gmp.Int).Mul(a, b), N) for a batch. */
 int pgpu_modmul(const pgpu_modulus* mod, size_t batch, const uint8_t* a, size_t a_stride, size_t a_len,

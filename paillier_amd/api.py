@@ -59,12 +59,14 @@ SIGNATURES = {
     "pgpu_encrypt_with_r": (_int, [_vp, _int, _sz, _vp, _sz, _vp, _sz, _vp, _sz, _int]),
     "pgpu_decrypt": (_int, [_vp, _int, _sz, _vp, _sz, _vp, _sz, _int, _int, _vp]),
     "pgpu_add": (_int, [_vp, _int, _sz, _vp, _sz, _vp, _sz, _vp, _sz, _int]),
+    "pgpu_sub": (_int, [_vp, _int, _sz, _vp, _sz, _vp, _sz, _vp, _sz, _int]),
     "pgpu_const_mult": (_int, [_vp, _int, _sz, _vp, _sz, _vp, _sz, _sz, _vp, _sz, _int]),
     "pgpu_modulus_create": (_int, [_vp, _vp, _sz, C.POINTER(_vp)]),
     "pgpu_modulus_destroy": (None, [_vp]),
     "pgpu_modulus_bytes": (_sz, [_vp]),
     "pgpu_modexp": (_int, [_vp, _sz, _vp, _sz, _sz, _vp, _sz, _sz, _vp, _sz, _int]),
     "pgpu_vm_debug_run": (_int, [_vp, _vp, _sz, _vp, _sz, _sz, _int, C.POINTER(_int)]),
+    "pgpu_modinv": (_int, [_vp, _sz, _vp, _sz, _sz, _vp, _sz, _int]),
     "pgpu_modmul": (_int, [_vp, _sz, _vp, _sz, _sz, _vp, _sz, _sz, _vp, _sz, _int]),
 }
 
@@ -183,6 +185,13 @@ class Modulus:
         _check(self.ctx.lib.pgpu_vm_debug_run(self.h, _ptr(pw), pw.size, _ptr(m), nslots, nb, int(use_asm), C.byref(wt)))
         return m
 
+    def inv_batch(self, xs: Sequence[int]) -> List[int]:
+        """gmp.Int.ModInverse for each x."""
+        xb = ints_to_be(xs, self.nbytes)
+        out = np.zeros((len(xs), self.nbytes), dtype=np.uint8)
+        _check(self.ctx.lib.pgpu_modinv(self.h, len(xs), _ptr(xb), self.nbytes, self.nbytes, _ptr(out), self.nbytes, MEM_HOST))
+        return be_to_ints(out)
+
     def mul_batch(self, a: Sequence[int], b: Sequence[int]) -> List[int]:
         lib = self.ctx.lib
         ab, bb = ints_to_be(a, self.nbytes), ints_to_be(b, self.nbytes)
@@ -240,6 +249,14 @@ class PublicKey:
         ab, bb = ints_to_be(a, cb), ints_to_be(b, cb)
         out = np.zeros((len(a), cb), dtype=np.uint8)
         _check(self.ctx.lib.pgpu_add(self.h, level, len(a), _ptr(ab), cb, _ptr(bb), cb, _ptr(out), cb, MEM_HOST))
+        return be_to_ints(out)
+
+    def SubBatch(self, a: Sequence[int], b: Sequence[int], level: int = ENC_LEVEL_ONE) -> List[int]:
+        """operations.go:32-55 with two operands, element-wise: a[i] * b[i]^-1 mod n^(s+1)."""
+        cb = self.cipher_bytes(level)
+        ab, bb = ints_to_be(a, cb), ints_to_be(b, cb)
+        out = np.zeros((len(a), cb), dtype=np.uint8)
+        _check(self.ctx.lib.pgpu_sub(self.h, level, len(a), _ptr(ab), cb, _ptr(bb), cb, _ptr(out), cb, MEM_HOST))
         return be_to_ints(out)
 
     def ConstMultBatch(self, cts: Sequence[int], k, level: int = ENC_LEVEL_ONE) -> List[int]:

@@ -198,13 +198,14 @@ struct DevLimbs {
 // ------------------------------------------------------------------------------------------------
 struct Prog {
   std::vector<uint32_t> w;
-  double montmuls = 0;
+  double montmuls = 0, sqrs = 0;
   bool asm_ok = true;  // only opcodes the assembly kernel implements
   void op(uint32_t o, uint32_t arg = 0, uint32_t aux = 0) {
     if (o == VM_MULV || o == VM_SETOFF) asm_ok = false;
     w.push_back(o | (aux << 8));
     w.push_back(arg);
     if (o == VM_SQR || o == VM_MUL || o == VM_MULC || o == VM_MULV) montmuls += 1;
+    if (o == VM_SQR) sqrs += 1;
   }
   void end() { op(VM_END); }
 };
@@ -298,13 +299,13 @@ struct SegSpec {
 };
 
 // launch one VM kernel with 1 or 2 segments of `nb` numbers each (same modulus shape)
-void run_vm(pgpu_ctx* ctx, size_t nb, const SegSpec& s0, const SegSpec* s1, bool profile) {
+void run_vm(pgpu_ctx* ctx, size_t nb, const SegSpec& s0, const SegSpec* s1, bool profile, size_t launch_nb = 0) {
   const ModCtx* mc = s0.mc;
   if (s1 && (s1->mc->WL != mc->WL || s1->mc->K != mc->K)) api_throw(PGPU_ERR_INVALID, "segment shape mismatch");
   VmArgs a;
   memset(&a, 0, sizeof a);
   const SegSpec* ss[2] = {&s0, s1};
-  double montmuls = 0;
+  double montmuls = 0, sqrs = 0;
   for (int i = 0; i < 2; ++i) {
     if (!ss[i]) continue;
     VmSeg& g = a.seg[i];
@@ -316,18 +317,24 @@ void run_vm(pgpu_ctx* ctx, size_t nb, const SegSpec& s0, const SegSpec* s1, bool
     g.n0inv = ss[i]->mc->n0inv;
     g.nb = (uint32_t)nb;
     montmuls += ss[i]->prog->montmuls;
+    sqrs += ss[i]->prog->sqrs;
   }
-  const uint32_t blocks_per_seg = (uint32_t)(nb * mc->K / VM_BLOCK);
+  if (launch_nb == 0) launch_nb = nb;  // numbers actually launched (<= nb, the row stride of the arrays)
+  const uint32_t blocks_per_seg = (uint32_t)(launch_nb * mc->K / VM_BLOCK);
   a.seg0_blocks = blocks_per_seg;
   const uint32_t blocks = blocks_per_seg * (s1 ? 2 : 1);
+  const bool use_asm = ctx->use_asm && vm_asm_available(mc->WL, mc->K) && s0.prog->asm_ok && (!s1 || s1->prog->asm_ok) &&
+                       (uint64_t)nb * mc->WT * 4 < (1ull << 32);
   pgpu_ctx::Ev* ev = nullptr;
   if (profile) {
     ev = &ctx->next_ev();
-    ev->mads = montmuls * 2.0 * mc->WT * mc->WT * (double)nb;  // v_mad_u64_u32 lane-ops executed
+    // v_mad_u64_u32 lane-ops executed: 2 WT^2 per product; the assembly kernel's K == 1 squaring rows use the
+    // symmetry of the square: WL^2 (reduction) + WL(WL-1)/2 + WL (product)
+    const double full = 2.0 * mc->WT * mc->WT;
+    const double sq = (use_asm && mc->K == 1) ? (double)mc->WT * mc->WT + 0.5 * mc->WT * (mc->WT - 1) + mc->WT : full;
+    ev->mads = ((montmuls - sqrs) * full + sqrs * sq) * (double)launch_nb;
     HIPCHK(hipEventRecord(ev->a, ctx->stream));
   }
-  bool use_asm = ctx->use_asm && vm_asm_available(mc->WL, mc->K) && s0.prog->asm_ok && (!s1 || s1->prog->asm_ok) &&
-                 (uint64_t)nb * mc->WT * 4 < (1ull << 32);
   hipError_t e = use_asm ? launch_vm_asm(mc->WL, mc->K, a, blocks, ctx->stream)
                          : launch_vm(mc->WL, mc->K, a, blocks, ctx->stream);
   if (use_asm) ctx->last_vm_asm++;
@@ -555,6 +562,81 @@ void reduce_mod(pgpu_ctx* ctx, const ModCtx& mc, const uint32_t* in, int w_in, u
   HIPCHK(hipMemcpyAsync(out, mem + 3 * sw, sw * 4, hipMemcpyDeviceToDevice, ctx->stream));
 }
 
+// Batch modular inverse (gmp.Int.ModInverse for a whole batch) by Montgomery's trick arranged as a binary tree so that
+// every level is one data-parallel VM launch: products up the tree (pairs (i, i + half) via VM_SETOFF), ONE inversion
+// of the root on the host, inverses down the tree.  3 Montgomery products per element instead of a ~2*bits-step
+// extended Euclid per element.  x: canonical, stride nb, `count` valid.  Returns canonical inverses with stride nb.
+// A non-unit anywhere in the batch makes the root non-invertible -> PGPU_ERR_NOT_INVERTIBLE (mpz_invert is undefined
+// there, and the reference never checks).
+uint32_t* batch_inverse(pgpu_ctx* ctx, const ModCtx& mc, const uint32_t* x, size_t nb, size_t count) {
+  const int WT = mc.WT;
+  size_t nbt = VM_BLOCK;
+  int L = 8;
+  while (nbt < count) { nbt <<= 1; ++L; }
+  const size_t sw = (size_t)WT * nbt;
+  // slots: V_0..V_L, I0, I1, A, B, O
+  const uint32_t SV = 0, SI0 = (uint32_t)L + 1, SI1 = SI0 + 1, SA = SI0 + 2, SB = SI0 + 3, SO = SI0 + 4;
+  uint32_t* mem = ctx->ws_t<uint32_t>(sw * (size_t)(L + 6) + 8192);
+  HIPCHK(hipMemsetAsync(mem + sw * (size_t)(L + 6), 0, 8192 * 4, ctx->stream));
+  // V_0 = x (padding lanes = 1), to Montgomery form
+  launch_restride(x, nb, count, mc.d_consts + (size_t)C_ONE * WT, mem + SV * sw, nbt, WT, ctx->stream);
+  {
+    Prog p;
+    p.op(VM_LOAD, SV); p.op(VM_MULC, C_R2); p.op(VM_STORE, SV); p.end();
+    SegSpec sg{&mc, &p, mem, nullptr};
+    run_vm(ctx, nbt, sg, nullptr, false);
+  }
+  for (int k = 0; k < L; ++k) {  // V_{k+1}[i] = V_k[i] * V_k[i + half]
+    const size_t half = nbt >> (k + 1);
+    Prog p;
+    p.op(VM_LOAD, SV + k); p.op(VM_SETOFF, (uint32_t)half); p.op(VM_MUL, SV + k); p.op(VM_SETOFF, 0);
+    p.op(VM_STORE, SV + k + 1); p.end();
+    SegSpec sg{&mc, &p, mem, nullptr};
+    run_vm(ctx, nbt, sg, nullptr, false, std::max<size_t>(VM_BLOCK, half));
+  }
+  // root: out of Montgomery form, canonical, to the host
+  {
+    Prog p;
+    p.op(VM_LOAD, SV + L); p.op(VM_MULC, C_ONE); p.op(VM_STORE, SO); p.end();
+    SegSpec sg{&mc, &p, mem, nullptr};
+    run_vm(ctx, nbt, sg, nullptr, false, VM_BLOCK);
+    launch_canon(mem + SO * sw, mc.d_nmod, WT, nbt, ctx->stream);
+  }
+  std::vector<uint8_t> rb(mc.nbytes);
+  uint8_t* d_rb = (uint8_t*)ctx->ws(mc.nbytes);
+  launch_pack_be(mem + SO * sw, WT, nbt, 1, d_rb, mc.nbytes, mc.nbytes, ctx->stream);
+  HIPCHK(hipMemcpyAsync(rb.data(), d_rb, mc.nbytes, hipMemcpyDeviceToHost, ctx->stream));
+  HIPCHK(hipStreamSynchronize(ctx->stream));
+  BigU root = BigU::from_be(rb.data(), rb.size()), rinv;
+  if (!hostbig::modinv(root, mc.N, rinv))
+    api_throw(PGPU_ERR_NOT_INVERTIBLE, "ModInverse: an element of the batch is not invertible modulo the modulus");
+  uint32_t* d_rinv = ctx->upload_words(mc.to_mont(rinv).to_limbs(LB, WT));
+  // every lane of I0 <- root inverse (count = 0: all lanes take the fill value); only lane 0 is consumed
+  launch_restride(mem + SI0 * sw, nbt, 0, d_rinv, mem + SI0 * sw, nbt, WT, ctx->stream);
+  uint32_t cur = SI0, nxt = SI1;
+  for (int k = L - 1; k >= 0; --k) {
+    const size_t half = nbt >> (k + 1);
+    Prog p;
+    p.op(VM_LOAD, cur); p.op(VM_SETOFF, (uint32_t)half); p.op(VM_MUL, SV + k); p.op(VM_SETOFF, 0); p.op(VM_STORE, SA);
+    p.op(VM_LOAD, cur); p.op(VM_MUL, SV + k); p.op(VM_STORE, SB);
+    p.end();
+    SegSpec sg{&mc, &p, mem, nullptr};
+    run_vm(ctx, nbt, sg, nullptr, false, std::max<size_t>(VM_BLOCK, half));
+    launch_merge_halves(mem + SA * sw, mem + SB * sw, half, mem + nxt * sw, nbt, WT, ctx->stream);
+    std::swap(cur, nxt);
+  }
+  {
+    Prog p;
+    p.op(VM_LOAD, cur); p.op(VM_MULC, C_ONE); p.op(VM_STORE, SO); p.end();
+    SegSpec sg{&mc, &p, mem, nullptr};
+    run_vm(ctx, nbt, sg, nullptr, false);
+    launch_canon(mem + SO * sw, mc.d_nmod, WT, nbt, ctx->stream);
+  }
+  uint32_t* out = ctx->ws_t<uint32_t>((size_t)WT * nb);
+  launch_restride(mem + SO * sw, nbt, count, nullptr, out, nb, WT, ctx->stream);
+  return out;
+}
+
 void check_batch_args(const void* a, const void* b, size_t batch) {
   if (!a || !b) api_throw(PGPU_ERR_INVALID, "null buffer");
   if (batch == 0) api_throw(PGPU_ERR_INVALID, "empty batch");
@@ -620,6 +702,28 @@ int pgpu_vm_debug_run(const pgpu_modulus* mod, const uint32_t* prog, size_t prog
     try { run_vm(ctx, nb, s, nullptr, false); } catch (...) { ctx->use_asm = saved; throw; }
     ctx->use_asm = saved;
     HIPCHK(hipMemcpyAsync(mem_host, d, words * 4, hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHK(hipStreamSynchronize(ctx->stream));
+  });
+}
+
+int pgpu_modinv(const pgpu_modulus* mod, size_t batch, const uint8_t* x, size_t x_stride, size_t x_len, uint8_t* out,
+                size_t out_stride, int mem) {
+  if (!mod) return fail(PGPU_ERR_INVALID, "null modulus");
+  pgpu_ctx* ctx = mod->ctx;
+  const ModCtx& mc = mod->mc;
+  return guarded([&] {
+    check_batch_args(x, out, batch);
+    ctx->bind();
+    ctx->reset_ws();
+    const size_t nb = round_up(batch, VM_BLOCK);
+    const int w_in = (int)((x_len * 8 + LB - 1) / LB);
+    if (w_in > 2 * mc.WT) api_throw(PGPU_ERR_INVALID, "operand wider than twice the modulus width");
+    uint32_t* xl = ctx->ws_t<uint32_t>((size_t)std::max(w_in, mc.WT) * nb);
+    unpack_operand(ctx, x, x_stride, x_len, batch, mem, xl, std::max(w_in, mc.WT), nb);
+    uint32_t* xr = ctx->ws_t<uint32_t>((size_t)mc.WT * nb);
+    reduce_mod(ctx, mc, xl, std::max(w_in, mc.WT), xr, nb);
+    uint32_t* inv = batch_inverse(ctx, mc, xr, nb, batch);
+    pack_result(ctx, inv, mc.WT, nb, batch, out, out_stride, mc.nbytes, mem);
     HIPCHK(hipStreamSynchronize(ctx->stream));
   });
 }
@@ -977,6 +1081,36 @@ int pgpu_add(const pgpu_pubkey* pk, int level, size_t batch, const uint8_t* a, s
     p.op(VM_MUL, 1);
     p.op(VM_STORE, 2);
     p.end();
+    SegSpec s{&mc, &p, memv, nullptr};
+    run_vm(ctx, nb, s, nullptr, true);
+    launch_canon(memv + 2 * sw, mc.d_nmod, mc.WT, nb, ctx->stream);
+    pack_result(ctx, memv + 2 * sw, mc.WT, nb, batch, out, out_stride, mc.nbytes, mem);
+    HIPCHK(hipStreamSynchronize(ctx->stream));
+  });
+}
+
+int pgpu_sub(const pgpu_pubkey* pk, int level, size_t batch, const uint8_t* a, size_t a_stride, const uint8_t* b,
+             size_t b_stride, uint8_t* out, size_t out_stride, int mem) {
+  if (!pk) return fail(PGPU_ERR_INVALID, "null key");
+  pgpu_ctx* ctx = pk->ctx;
+  return guarded([&] {
+    check_batch_args(a, out, batch);
+    if (!b) api_throw(PGPU_ERR_INVALID, "null buffer");
+    const ModCtx& mc = cipher_mod(pk, level);
+    ctx->bind();
+    ctx->reset_ws();
+    const size_t nb = round_up(batch, VM_BLOCK);
+    size_t sw = (size_t)mc.WT * nb;
+    uint32_t* memv = ctx->ws_t<uint32_t>(sw * 3);  // slots: 0 a, 1 b^-1, 2 out
+    unpack_operand(ctx, a, a_stride, std::min(a_stride, mc.nbytes), batch, mem, memv, mc.WT, nb);
+    uint32_t* bl = ctx->ws_t<uint32_t>(sw);
+    unpack_operand(ctx, b, b_stride, std::min(b_stride, mc.nbytes), batch, mem, bl, mc.WT, nb);
+    uint32_t* br = ctx->ws_t<uint32_t>(sw);
+    reduce_mod(ctx, mc, bl, mc.WT, br, nb);
+    uint32_t* binv = batch_inverse(ctx, mc, br, nb, batch);   // operations.go:43  neg = ModInverse(c.C, ns1)
+    HIPCHK(hipMemcpyAsync(memv + sw, binv, sw * 4, hipMemcpyDeviceToDevice, ctx->stream));
+    Prog p;
+    p.op(VM_LOAD, 0); p.op(VM_MULC, C_R2); p.op(VM_MUL, 1); p.op(VM_STORE, 2); p.end();   // operations.go:44-47
     SegSpec s{&mc, &p, memv, nullptr};
     run_vm(ctx, nb, s, nullptr, true);
     launch_canon(memv + 2 * sw, mc.d_nmod, mc.WT, nb, ctx->stream);

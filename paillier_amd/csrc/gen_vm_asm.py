@@ -39,12 +39,13 @@ class Gen:
         self.n_sgpr = (K == 1 and WL <= 74)
         self.flush = (2 * self.WT + 1) > 255
         self.flush_every = 48
+        self.sq_rows = (K == 1)  # dedicated squaring rows (symmetric products computed once)
         self.lines = []
         self.name = f"vm_asm_{WL}_{K}"
         # ---- VGPR map: t[] pairs, x[], then scalars; pairs are even-aligned
         self.vX = 2 * WL
         e = 3 * WL
-        singles = ["ai", "ain", "m", "t1"]
+        singles = ["ai", "ain", "m", "t1"] + (["din", "drow"] if K == 1 else [])
         for nm in singles:
             setattr(self, "v_" + nm, e)
             e += 1
@@ -73,7 +74,7 @@ class Gen:
         self.s_N = 20  # K == 1: modulus limbs s[20 : 20+WL)
         self.s_sbase = 94  # 64-bit scalar base for global accesses
         self.s_t0, self.s_t1 = 96, 97
-        self.n_sgpr_count = 100
+        self.n_sgpr_count = 102
         # ---- LDS layout
         self.lds_n = 0
         self.lds_a = (K * self.WLp * 4 + 15) // 16 * 16 if not self.n_sgpr else 0
@@ -298,7 +299,7 @@ class Gen:
 
         e("L_sqr:")
         self.stage_to_lds(Xs)
-        # falls through into the product
+        e("s_branch L_montsq" if self.sq_rows else "s_branch L_montmul")
 
     # ---------------------------------------------------------------------------------------------
     def montmul(self):
@@ -410,6 +411,79 @@ class Gen:
             # the top column is re-created by A(WL-1) every row (src2 = 0); after the last shift it is logically 0
             e(f"v_mov_b32 {self.Tlo(WL - 1)}, 0")
             e(f"v_mov_b32 {self.Thi(WL - 1)}, 0")
+        self.normalize()
+        e("s_branch L_next")
+
+    # ---------------------------------------------------------------------------------------------
+    def montsq(self):
+        """x <- x*x*R^-1 for K == 1, using the symmetry of the square:
+             x^2 = sum_i x_i^2 2^(56 i) + 2 * sum_{i<j} x_i x_j 2^(28 (i+j)).
+        Row i adds the doubled off-diagonal products 2 x_i x_j only for j > i (a computed jump into the pass-A
+        table skips the first i+1 entries: every entry is one 8-byte v_mad_u64_u32).  The diagonal x_i^2 belongs to
+        column 2i; it is added when that column sits in accumulator 0, i.e. at row 2i (even rows; x_i re-read from
+        the LDS column), and for columns >= WT after the last row (static registers).  Column i is complete when
+        row i starts, so the quotient digit m is computed first and its latency hides behind pass A.
+        Multiplies per product: WL(WL-1)/2 + WL + WL^2 instead of 2 WL^2."""
+        g = self
+        e = self.e
+        WL, WT = self.WL, self.WT
+        assert self.K == 1 and self.n_sgpr
+        rstride = self.NPB * 4
+        ai2, m, din = f"v{g.v_ai}", f"v{g.v_m}", f"v{g.v_din}"
+        e("L_montsq:")
+        for j in range(WL):
+            e(f"v_mov_b32 {self.Tlo(j)}, 0")
+            e(f"v_mov_b32 {self.Thi(j)}, 0")
+        e(f"v_mov_b32 v{g.v_arow}, v{g.v_aread}")
+        e(f"v_mov_b32 v{g.v_drow}, v{g.v_aread}")
+        e(f"ds_read_b32 v{g.v_ain}, v{g.v_arow}")
+        e(f"ds_read_b32 {din}, v{g.v_drow}")
+        e(f"v_add_u32 v{g.v_arow}, {rstride}, v{g.v_arow}")
+        e(f"v_add_u32 v{g.v_drow}, {rstride}, v{g.v_drow}")
+        e("s_mov_b32 s19, 0")
+        e("L_rowsq:")
+        e("s_waitcnt lgkmcnt(0)")
+        e(f"v_lshlrev_b32 {ai2}, 1, v{g.v_ain}")          # 2 * x_i
+        e("s_bitcmp1_b32 s19, 0")
+        e("s_cbranch_scc1 L_sq_odd")
+        self.mad(self.T(0), din, din, self.T(0))          # diagonal x_(i/2)^2 into column i
+        e(f"ds_read_b32 {din}, v{g.v_drow}")
+        e(f"v_add_u32 v{g.v_drow}, {rstride}, v{g.v_drow}")
+        e("L_sq_odd:")
+        e(f"ds_read_b32 v{g.v_ain}, v{g.v_arow}")
+        e(f"v_add_u32 v{g.v_arow}, {rstride}, v{g.v_arow}")
+        e(f"v_mul_lo_u32 {m}, {self.Tlo(0)}, s14")
+        e(f"v_and_b32 {m}, {hex(MASK)}, {m}")
+        # computed jump: enter the pass-A table at entry i+1 (table starts at A_1)
+        e("s_getpc_b64 s[96:97]")
+        e("L_sq_ret:")
+        e("s_lshl_b32 s98, s19, 3")
+        e("s_add_u32 s96, s96, s98")
+        e("s_addc_u32 s97, s97, 0")
+        e("s_add_u32 s96, s96, L_sqA-L_sq_ret")
+        e("s_addc_u32 s97, s97, 0")
+        e("s_setpc_b64 s[96:97]")
+        e("L_sqA:")
+        for j in range(1, WL):
+            self.mad(self.T(j), ai2, self.X(j), self.T(j))
+        e("L_sqB:")
+        N = lambda j: f"s{g.s_N + j}"
+        self.mad(self.P(g.v_y0), m, N(0), self.T(0))
+        self.mad(self.T(0), m, N(1), self.T(1))
+        e(f"v_lshrrev_b64 {self.P(g.v_c)}, {LB}, {self.P(g.v_y0)}")
+        for j in range(2, WL):
+            self.mad(self.T(j - 1), m, N(j), self.T(j))
+            if j == 4 or (WL <= 4 and j == WL - 1):
+                e(f"v_lshl_add_u64 {self.T(0)}, {self.T(0)}, 0, {self.P(g.v_c)}")
+        e(f"v_mov_b32 {self.Tlo(WL - 1)}, 0")
+        e(f"v_mov_b32 {self.Thi(WL - 1)}, 0")
+        e("s_add_u32 s19, s19, 1")
+        e(f"s_cmp_lt_u32 s19, {WT}")
+        e("s_cbranch_scc1 L_rowsq")
+        e("s_waitcnt lgkmcnt(0)")
+        # diagonals of the columns >= WT: x_i^2 lands in accumulator 2i - WT
+        for i in range((WT + 1) // 2, WT):
+            self.mad(self.T(2 * i - WT), self.X(i), self.X(i), self.T(2 * i - WT))
         self.normalize()
         e("s_branch L_next")
 
@@ -547,6 +621,8 @@ class Gen:
         self.prologue()
         self.dispatcher()
         self.montmul()
+        if self.sq_rows:
+            self.montsq()
         self.epilogue()
         return "\n".join(self.lines) + "\n"
 

@@ -55,3 +55,6 @@ void launch_copy_limbs(const uint32_t* in, int l0, int w, uint32_t* out, int wo,
 void launch_fill_const(const uint32_t* c, uint32_t* out, int wo, size_t nb, hipStream_t st);
 void launch_gather(const uint32_t* in, size_t nb_in, const uint32_t* idx, size_t n_idx, uint32_t* out, size_t nb_out, int w, hipStream_t st);
 void launch_scatter(const uint32_t* in, size_t nb_in, const uint32_t* idx, size_t n_idx, uint32_t* out, size_t nb_out, int w, hipStream_t st);
+void launch_restride(const uint32_t* in, size_t nb_in, size_t count, const uint32_t* fill, uint32_t* out, size_t nb_out, int w,
+                     hipStream_t st);
+void launch_merge_halves(const uint32_t* lo, const uint32_t* hi, size_t half, uint32_t* out, size_t nb, int w, hipStream_t st);

@@ -347,6 +347,23 @@ __global__ void k_scatter(const uint32_t* __restrict__ in, size_t nb_in, const u
   for (int l = 0; l < w; ++l) out[(size_t)l * nb_out + idx[g]] = in[(size_t)l * nb_in + g];
 }
 
+// out[l][g] (stride nb_out) = g < count ? in[l][g] (stride nb_in) : fill[l]   (re-stride / pad a batch)
+__global__ void k_restride(const uint32_t* __restrict__ in, size_t nb_in, size_t count, const uint32_t* __restrict__ fill,
+                           uint32_t* __restrict__ out, size_t nb_out, int w) {
+  size_t g = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (g >= nb_out) return;
+  for (int l = 0; l < w; ++l) out[(size_t)l * nb_out + g] = (g < count) ? in[(size_t)l * nb_in + g] : (fill ? fill[l] : 0u);
+}
+
+// out[g] = g < half ? lo[g] : hi[g - half]   for g < 2*half   (all arrays limb-major with stride nb)
+__global__ void k_merge_halves(const uint32_t* __restrict__ lo, const uint32_t* __restrict__ hi, size_t half,
+                               uint32_t* __restrict__ out, size_t nb, int w) {
+  size_t g = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (g >= 2 * half) return;
+  const uint32_t* src = g < half ? lo + g : hi + (g - half);
+  for (int l = 0; l < w; ++l) out[(size_t)l * nb + g] = src[(size_t)l * nb];
+}
+
 #define HELPER_GRID(nb) dim3((unsigned)(((nb) + 255) / 256)), dim3(256)
 
 void launch_unpack_be(const uint8_t* in, size_t stride, size_t nbytes, size_t count, uint32_t* out, int wt, size_t nb, hipStream_t st) {
@@ -388,4 +405,11 @@ void launch_gather(const uint32_t* in, size_t nb_in, const uint32_t* idx, size_t
 }
 void launch_scatter(const uint32_t* in, size_t nb_in, const uint32_t* idx, size_t n_idx, uint32_t* out, size_t nb_out, int w, hipStream_t st) {
   hipLaunchKernelGGL(k_scatter, HELPER_GRID(n_idx ? n_idx : 1), 0, st, in, nb_in, idx, n_idx, out, nb_out, w);
+}
+void launch_restride(const uint32_t* in, size_t nb_in, size_t count, const uint32_t* fill, uint32_t* out, size_t nb_out, int w,
+                     hipStream_t st) {
+  hipLaunchKernelGGL(k_restride, HELPER_GRID(nb_out), 0, st, in, nb_in, count, fill, out, nb_out, w);
+}
+void launch_merge_halves(const uint32_t* lo, const uint32_t* hi, size_t half, uint32_t* out, size_t nb, int w, hipStream_t st) {
+  hipLaunchKernelGGL(k_merge_halves, HELPER_GRID(2 * half), 0, st, lo, hi, half, out, nb, w);
 }
