@@ -116,6 +116,22 @@ int pgpu_sub(const pgpu_pubkey* pk, int level, size_t batch, const uint8_t* a, s
 int pgpu_const_mult(const pgpu_pubkey* pk, int level, size_t batch, const uint8_t* c, size_t c_stride,
                     const uint8_t* k, size_t k_len, size_t k_stride, uint8_t* out, size_t out_stride, int mem);
 
+/* ---- threshold decryption (thresholdkey.go) ---------------------------------------------------------- */
+
+/* ThresholdSecretKey.PartialDecrypt (thresholdkey.go:192-201): out[i] = c[i]^(2 * l! * share) mod n^2,
+ * l = total_servers.  The share stays on the caller's side of the ABI (big-endian). */
+int pgpu_partial_decrypt(const pgpu_pubkey* pk, int total_servers, const uint8_t* share_be, size_t share_len, size_t batch,
+                         const uint8_t* c, size_t c_stride, uint8_t* out, size_t out_stride, int mem);
+
+/* ThresholdPublicKey.CombinePartialDecryptions (thresholdkey.go:149-161) for a batch of ciphertexts:
+ *   m[i] = L( prod_k partials[k][i]^(2 lambda_k) mod n^2 ) * (4 (l!)^2)^-1 mod n
+ * ids[k] = server id (1-based) of partials[k]; all partial buffers share `stride`.  Lagrange coefficients follow
+ * the reference's sequence of Euclidean divisions; negative exponents use a modular inverse as thresholdkey.go:132-138.
+ * PGPU_ERR_THRESHOLD when fewer than `threshold` shares or duplicate ids (thresholdkey.go:77-89). */
+int pgpu_combine_partial_decryptions(const pgpu_pubkey* pk, int total_servers, int threshold, int n_shares, const int* ids,
+                                     size_t batch, const uint8_t* const* partials, size_t stride, uint8_t* m,
+                                     size_t m_stride, int mem);
+
 /* ---- generic modular batch primitives (the gmp.Int seam: Exp / Mul+Mod) ------------------------ */
 
 /* Load an odd modulus (big-endian).  Precomputes -N^-1 mod 2^28, R mod N, R^2 mod N, R^3 mod N. */

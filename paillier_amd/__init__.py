@@ -12,6 +12,7 @@ from .api import (  # noqa: F401
     PaillierHipError,
     PublicKey,
     SecretKey,
+    ThresholdPublicKey,
     ENC_LEVEL_ONE,
     ENC_LEVEL_TWO,
     MEM_DEVICE,

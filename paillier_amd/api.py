@@ -60,6 +60,8 @@ SIGNATURES = {
     "pgpu_decrypt": (_int, [_vp, _int, _sz, _vp, _sz, _vp, _sz, _int, _int, _vp]),
     "pgpu_add": (_int, [_vp, _int, _sz, _vp, _sz, _vp, _sz, _vp, _sz, _int]),
     "pgpu_sub": (_int, [_vp, _int, _sz, _vp, _sz, _vp, _sz, _vp, _sz, _int]),
+    "pgpu_partial_decrypt": (_int, [_vp, _int, _vp, _sz, _sz, _vp, _sz, _vp, _sz, _int]),
+    "pgpu_combine_partial_decryptions": (_int, [_vp, _int, _int, _int, _vp, _sz, _vp, _sz, _vp, _sz, _int]),
     "pgpu_const_mult": (_int, [_vp, _int, _sz, _vp, _sz, _vp, _sz, _sz, _vp, _sz, _int]),
     "pgpu_modulus_create": (_int, [_vp, _vp, _sz, C.POINTER(_vp)]),
     "pgpu_modulus_destroy": (None, [_vp]),
@@ -282,6 +284,43 @@ class PublicKey:
                 self.h = None
         except Exception:
             pass
+
+
+class ThresholdPublicKey(PublicKey):
+    """thresholdkey.go:26-32 ThresholdPublicKey{PublicKey; TotalNumberOfDecryptionServers, Threshold, ...}."""
+
+    def __init__(self, ctx: Context, N: int, total: int, threshold: int, G: Optional[int] = None):
+        super().__init__(ctx, N, G)
+        self.TotalNumberOfDecryptionServers, self.Threshold = total, threshold
+
+    def partial_decrypt_raw(self, share: int, batch, c, c_stride, out, out_stride, mem=MEM_HOST):
+        sb = _be(share)
+        _check(self.ctx.lib.pgpu_partial_decrypt(self.h, self.TotalNumberOfDecryptionServers, sb, len(sb), batch, _ptr(c),
+                                                 c_stride, _ptr(out), out_stride, mem))
+
+    def combine_raw(self, ids: Sequence[int], batch, partial_ptrs: Sequence[int], stride, m, m_stride, mem=MEM_HOST):
+        n = len(ids)
+        ida = (C.c_int * n)(*ids)
+        pa_ = (C.c_void_p * n)(*partial_ptrs)
+        _check(self.ctx.lib.pgpu_combine_partial_decryptions(self.h, self.TotalNumberOfDecryptionServers, self.Threshold, n,
+                                                             ida, batch, pa_, stride, _ptr(m), m_stride, mem))
+
+    def PartialDecryptBatch(self, ID: int, share: int, cts: Sequence[int]):
+        """thresholdkey.go:192-201 for each ciphertext; returns (ID, [decryptions])."""
+        cb = self.cipher_bytes()
+        cbuf = ints_to_be(cts, cb)
+        out = np.zeros((len(cts), cb), dtype=np.uint8)
+        self.partial_decrypt_raw(share, len(cts), cbuf, cb, out, cb)
+        return ID, be_to_ints(out)
+
+    def CombinePartialDecryptionsBatch(self, shares) -> List[int]:
+        """thresholdkey.go:149-161; shares = [(ID, [decryption per ciphertext]), ...]."""
+        cb, pb = self.cipher_bytes(), self.plain_bytes()
+        bufs = [ints_to_be(d, cb) for _, d in shares]
+        batch = bufs[0].shape[0] if bufs else 0
+        out = np.zeros((max(batch, 1), pb), dtype=np.uint8)
+        self.combine_raw([i for i, _ in shares], batch, [b.ctypes.data for b in bufs], cb, out, pb)
+        return be_to_ints(out[:batch])
 
 
 class SecretKey:

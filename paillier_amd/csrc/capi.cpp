@@ -401,6 +401,8 @@ struct pgpu_pubkey {
   ModCtx mn, mn2;                 // moduli n, n^2  (level one)
   std::unique_ptr<ModCtx> mn3;    // n^3 (level two), built when the width is supported
   DevLimbs n_limbs;               // n as mn.WT limbs (multiplicand of the closed-form g^m)
+  DevLimbs ninv2k;                // n^-1 mod 2^(28 mn.WT): exact division by n (the L function)
+  std::vector<std::pair<int, int>> combine_consts;  // (total servers l, index of (4 (l!)^2)^-1 * R mod n in mn.consts)
 };
 
 struct pgpu_seckey {
@@ -416,7 +418,6 @@ struct pgpu_seckey {
   DevLimbs p_limbs;              // p as mp.WT limbs
   // generic path (reference formula)
   int c_muR = -1;                // lambda^-1 mod n, times R mod n, in pk->mn
-  DevLimbs ninv2k;               // n^-1 mod 2^(28 mn.WT)
   DevLimbs n_minus_mu;           // (n - mu) mod n, the answer for c == 0 (L(-1) = -1)
 };
 
@@ -786,6 +787,7 @@ int pgpu_pubkey_create(pgpu_ctx* ctx, const uint8_t* n_be, size_t n_len, const u
       pk->mn3->upload();
     }
     pk->n_limbs.set(pk->N, pk->mn.WT);
+    pk->ninv2k.set(inv_mod_pow2(pk->N, (size_t)LB * pk->mn.WT), pk->mn.WT);
   });
   if (rc == PGPU_OK) *out = pk.release();
   return rc;
@@ -819,7 +821,6 @@ int pgpu_seckey_create(pgpu_ctx* ctx, const pgpu_pubkey* pk, const uint8_t* lamb
     pgpu_pubkey* pkm = const_cast<pgpu_pubkey*>(pk);  // constants are appended to the key's tables once, here
     sk->c_muR = pkm->mn.add_const(pkm->mn.to_mont(mu));
     pkm->mn.upload();
-    sk->ninv2k.set(inv_mod_pow2(n, (size_t)LB * pk->mn.WT), pk->mn.WT);
     sk->n_minus_mu.set((n - mu) % n, pk->mn.WT);
     // recover p, q from n and lambda = (p-1)(q-1): p + q = n - lambda + 1
     if (hostbig::cmp(n + BigU(1), sk->lambda) > 0) {
@@ -937,46 +938,90 @@ uint32_t* decrypt1_crt(const pgpu_seckey* sk, const uint32_t* c_limbs, size_t nb
 }
 
 
-// Level-one decryption by the reference's own formula (paillier.go:292-303), for ANY c (units or not):
-//   u = c^lambda mod n^2 ; ml = L(u) = Div(u - 1, n) (Euclidean: floor, and -1 for u = 0) ; m = ml * lambda^-1 mod n.
-// c: device array of mn2.WT limbs per number.  Returns device array of mn.WT-limb plaintexts.
-uint32_t* decrypt1_generic(const pgpu_seckey* sk, const uint32_t* c_limbs, size_t nb, size_t count) {
-  pgpu_ctx* ctx = sk->ctx;
-  const pgpu_pubkey* pk = sk->pk;
+// m = L(u) * C mod n  with the reference's L(u, n) = Div(u - 1, n)  (paillier.go:436-440; Euclidean: floor for
+// u >= 1 and -1 for u = 0), for ANY canonical u < n^2.  floor((u-1)/n) = ((u-1) - ((u-1) mod n)) / n: one Montgomery
+// reduction mod n plus one exact division.  c_const = index of C*R mod n in pk->mn.consts; neg_const = (-C) mod n as
+// limbs (the u = 0 answer).  Returns mn.WT-limb canonical results.
+uint32_t* L_times_const(pgpu_ctx* ctx, const pgpu_pubkey* pk, const uint32_t* u, size_t nb, size_t count, int c_const,
+                        const uint32_t* neg_const) {
   const ModCtx &mn = pk->mn, &mn2 = pk->mn2;
   const int W1 = mn.WT, W2 = mn2.WT;
-  ModexpPlan pl = modexp_alloc(ctx, mn2, nb, 32);
-  HIPCHK(hipMemcpyAsync(pl.in(), c_limbs, (size_t)W2 * nb * 4, hipMemcpyDeviceToDevice, ctx->stream));
-  modexp_shared_run(ctx, mn2, pl, sk->lambda, false, false, false);  // u, canonical
   int32_t* zf = ctx->ws_t<int32_t>(nb);
-  launch_is_zero(pl.out(), W2, nb, zf, ctx->stream);
-  // v = u - 1 (t of a division by 1 is not needed: reuse k_div_exact's first pass through a unit divisor is overkill;
-  // do it with the const-mul kernel: v = u * 1 + (2^(28 W2) - 1) mod 2^(28 W2) would wrap; use a dedicated pass below)
+  launch_is_zero(u, W2, nb, zf, ctx->stream);
   uint32_t* v = ctx->ws_t<uint32_t>((size_t)W2 * nb);
   uint32_t* r = ctx->ws_t<uint32_t>((size_t)W1 * nb);
   uint32_t* q = ctx->ws_t<uint32_t>((size_t)W1 * nb);
   uint32_t* scratch_l = ctx->ws_t<uint32_t>((size_t)W1 * nb);
   int32_t* st_dummy = ctx->ws_t<int32_t>(nb);
   HIPCHK(hipMemsetAsync(st_dummy, 0, nb * 4, ctx->stream));
-  // k_div_exact's first pass writes t = u - 1 into tbuf = v (the quotient by n it also computes is discarded)
-  launch_div_exact(pl.out(), W2, 1, nullptr, 0, v, sk->ninv2k.d, mn.d_nmod, W1, scratch_l, W1, nb, count, st_dummy, 1,
-                   ctx->stream);
+  // first pass of k_div_exact leaves t = u - 1 in its scratch array (= v); its quotient is discarded here
+  launch_div_exact(u, W2, 1, nullptr, 0, v, pk->ninv2k.d, mn.d_nmod, W1, scratch_l, W1, nb, count, st_dummy, 1, ctx->stream);
   reduce_mod(ctx, mn, v, W2, r, nb);                                   // r = (u - 1) mod n
   uint32_t* tb = ctx->ws_t<uint32_t>((size_t)W2 * nb);
-  launch_div_exact(v, W2, 0, r, W1, tb, sk->ninv2k.d, mn.d_nmod, W1, q, W1, nb, count, st_dummy, 2, ctx->stream);  // floor
+  launch_div_exact(v, W2, 0, r, W1, tb, pk->ninv2k.d, mn.d_nmod, W1, q, W1, nb, count, st_dummy, 2, ctx->stream);  // floor
   size_t s1 = (size_t)W1 * nb;
   uint32_t* m1 = ctx->ws_t<uint32_t>(s1 * 2);
   HIPCHK(hipMemcpyAsync(m1, q, s1 * 4, hipMemcpyDeviceToDevice, ctx->stream));
   Prog p;
   p.op(VM_LOAD, 0);
-  p.op(VM_MULC, (uint32_t)sk->c_muR);   // ml * mu mod n
+  p.op(VM_MULC, (uint32_t)c_const);
   p.op(VM_STORE, 1);
   p.end();
   SegSpec sg{&mn, &p, m1, nullptr};
   run_vm(ctx, nb, sg, nullptr, false);
   launch_canon(m1 + s1, mn.d_nmod, W1, nb, ctx->stream);
-  launch_select_const(zf, sk->n_minus_mu.d, m1 + s1, W1, nb, ctx->stream);  // u = 0: L = -1 -> m = -mu mod n
+  launch_select_const(zf, neg_const, m1 + s1, W1, nb, ctx->stream);  // u = 0: L = -1
   return m1 + s1;
+}
+
+// Level-one decryption by the reference's own formula (paillier.go:292-303), for ANY c (units or not):
+//   u = c^lambda mod n^2 ; ml = L(u) ; m = ml * lambda^-1 mod n.
+// c: device array of mn2.WT limbs per number.  Returns device array of mn.WT-limb plaintexts.
+uint32_t* decrypt1_generic(const pgpu_seckey* sk, const uint32_t* c_limbs, size_t nb, size_t count) {
+  pgpu_ctx* ctx = sk->ctx;
+  const pgpu_pubkey* pk = sk->pk;
+  const ModCtx& mn2 = pk->mn2;
+  ModexpPlan pl = modexp_alloc(ctx, mn2, nb, 32);
+  HIPCHK(hipMemcpyAsync(pl.in(), c_limbs, (size_t)mn2.WT * nb * 4, hipMemcpyDeviceToDevice, ctx->stream));
+  modexp_shared_run(ctx, mn2, pl, sk->lambda, false, false, false);  // u, canonical (secret exponent: no window skipping)
+  return L_times_const(ctx, pk, pl.out(), nb, count, sk->c_muR, sk->n_minus_mu.d);
+}
+
+// ---- threshold decryption ------------------------------------------------------------------------------------
+
+// signed host integer for the Lagrange coefficients (thresholdkey.go:91-107)
+struct SBig { BigU mag; bool neg = false; };
+SBig smul_small(const SBig& a, long long k) {
+  SBig r;
+  r.mag = a.mag * BigU((uint64_t)(k < 0 ? -k : k));
+  r.neg = r.mag.is_zero() ? false : (a.neg != (k < 0));
+  return r;
+}
+// gmp.Int.Div: Euclidean division (remainder in [0, |d|))
+SBig sdiv_euclid(const SBig& n, long long d) {
+  BigU ad((uint64_t)(d < 0 ? -d : d)), q0, r0;
+  hostbig::divmod(n.mag, ad, q0, r0);
+  SBig q;
+  const bool dneg = d < 0;
+  if (!n.neg) { q.mag = q0; q.neg = dneg; }
+  else if (r0.is_zero()) { q.mag = q0; q.neg = !dneg; }
+  else { q.mag = q0 + BigU(1); q.neg = !dneg; }
+  if (q.mag.is_zero()) q.neg = false;
+  return q;
+}
+BigU factorial_big(int n) {
+  BigU r(1);
+  for (int i = 1; i <= n; ++i) r = r * BigU((uint64_t)i);
+  return r;
+}
+
+// x <- x^e for a small public exponent, square-and-multiply on the value held in slot `base` (Montgomery form).
+void emit_pow_small(Prog& p, const BigU& e, uint32_t base) {
+  // caller guarantees e >= 1 and x == mem[base] on entry
+  for (size_t i = e.bit_length() - 1; i-- > 0;) {
+    p.op(VM_SQR);
+    if (e.bit(i)) p.op(VM_MUL, base);
+  }
 }
 
 }  // namespace
@@ -1115,6 +1160,126 @@ int pgpu_sub(const pgpu_pubkey* pk, int level, size_t batch, const uint8_t* a, s
     run_vm(ctx, nb, s, nullptr, true);
     launch_canon(memv + 2 * sw, mc.d_nmod, mc.WT, nb, ctx->stream);
     pack_result(ctx, memv + 2 * sw, mc.WT, nb, batch, out, out_stride, mc.nbytes, mem);
+    HIPCHK(hipStreamSynchronize(ctx->stream));
+  });
+}
+
+int pgpu_partial_decrypt(const pgpu_pubkey* pk, int total_servers, const uint8_t* share_be, size_t share_len, size_t batch,
+                         const uint8_t* c, size_t c_stride, uint8_t* out, size_t out_stride, int mem) {
+  if (!pk || !share_be) return fail(PGPU_ERR_INVALID, "null argument");
+  pgpu_ctx* ctx = pk->ctx;
+  return guarded([&] {
+    check_batch_args(c, out, batch);
+    if (total_servers < 1) api_throw(PGPU_ERR_INVALID, "total_servers must be positive");
+    ctx->bind();
+    ctx->reset_ws();
+    const ModCtx& mc = pk->mn2;
+    const size_t nb = round_up(batch, VM_BLOCK);
+    // thresholdkey.go:195: exp = Share * (2 * delta), delta = l!
+    BigU e = BigU::from_be(share_be, share_len) * (BigU(2) * factorial_big(total_servers));
+    ModexpPlan pl = modexp_alloc(ctx, mc, nb, 32);
+    unpack_operand(ctx, c, c_stride, std::min(c_stride, mc.nbytes), batch, mem, pl.in(), mc.WT, nb);
+    modexp_shared_run(ctx, mc, pl, e, false, false, false);   // secret share: no window skipping
+    pack_result(ctx, pl.out(), mc.WT, nb, batch, out, out_stride, mc.nbytes, mem);
+    HIPCHK(hipStreamSynchronize(ctx->stream));
+  });
+}
+
+int pgpu_combine_partial_decryptions(const pgpu_pubkey* pk, int total_servers, int threshold, int n_shares, const int* ids,
+                                     size_t batch, const uint8_t* const* partials, size_t stride, uint8_t* m,
+                                     size_t m_stride, int mem) {
+  if (!pk || !ids || !partials) return fail(PGPU_ERR_INVALID, "null argument");
+  pgpu_ctx* ctx = pk->ctx;
+  return guarded([&] {
+    // thresholdkey.go:77-89 verifyPartialDecryptions
+    if (n_shares < threshold) api_throw(PGPU_ERR_THRESHOLD, "Threshold not meet");
+    for (int i = 0; i < n_shares; ++i)
+      for (int j = i + 1; j < n_shares; ++j)
+        if (ids[i] == ids[j]) api_throw(PGPU_ERR_THRESHOLD, "two shares has been created by the same server");
+    if (n_shares < 1 || total_servers < 1) api_throw(PGPU_ERR_INVALID, "bad share count");
+    check_batch_args(partials[0], m, batch);
+    ctx->bind();
+    ctx->reset_ws();
+    const ModCtx &mn = pk->mn, &mn2 = pk->mn2;
+    const size_t nb = round_up(batch, VM_BLOCK);
+    const size_t sw = (size_t)mn2.WT * nb;
+    const BigU delta = factorial_big(total_servers);
+    // Lagrange coefficients, in the reference's order of operations (thresholdkey.go:91-107)
+    std::vector<SBig> two_lambda(n_shares);
+    for (int i = 0; i < n_shares; ++i) {
+      SBig lam;
+      lam.mag = delta;
+      for (int j = 0; j < n_shares; ++j)
+        if (ids[j] != ids[i]) lam = sdiv_euclid(smul_small(lam, -(long long)ids[j]), (long long)ids[i] - ids[j]);
+      two_lambda[i] = smul_small(lam, 2);
+    }
+    // slots: 0..n-1 partials, n base, n+1 numerator, n+2 denominator
+    const uint32_t SB = (uint32_t)n_shares, SNUM = SB + 1, SDEN = SB + 2;
+    uint32_t* mem_v = ctx->ws_t<uint32_t>(sw * (size_t)(n_shares + 3));
+    for (int i = 0; i < n_shares; ++i) {
+      if (!partials[i]) api_throw(PGPU_ERR_INVALID, "null partial buffer");
+      unpack_operand(ctx, partials[i], stride, std::min(stride, mn2.nbytes), batch, mem, mem_v + (size_t)i * sw, mn2.WT, nb);
+    }
+    // numerator = prod over lambda_i >= 0 of c_i^(2 lambda_i); denominator = prod over lambda_i < 0 of c_i^|2 lambda_i|.
+    // (thresholdkey.go:132-138 inverts each negative factor separately; the product of inverses is the inverse of
+    //  the product, so one inversion per ciphertext gives the same canonical residue.)
+    Prog p;
+    bool have_den = false;
+    for (int pass = 0; pass < 2; ++pass) {
+      const uint32_t acc = pass == 0 ? SNUM : SDEN;
+      bool first = true;
+      for (int i = 0; i < n_shares; ++i) {
+        const SBig& e = two_lambda[i];
+        if ((pass == 1) != e.neg) continue;
+        if (e.mag.is_zero()) continue;  // Exp(x, 0) = 1: no contribution
+        p.op(VM_LOAD, (uint32_t)i);
+        p.op(VM_MULC, C_R2);
+        p.op(VM_STORE, SB);
+        emit_pow_small(p, e.mag, SB);
+        if (!first) p.op(VM_MUL, acc);
+        p.op(VM_STORE, acc);
+        first = false;
+        if (pass == 1) have_den = true;
+      }
+      if (first) { p.op(VM_LOADC, C_ONE_M); p.op(VM_STORE, acc); }
+    }
+    // leave Montgomery form: denominator -> canonical (to be inverted); numerator stays in Montgomery form
+    p.op(VM_LOAD, SDEN); p.op(VM_MULC, C_ONE); p.op(VM_STORE, SDEN);
+    p.end();
+    SegSpec sg{&mn2, &p, mem_v, nullptr};
+    run_vm(ctx, nb, sg, nullptr, true);
+    uint32_t* cprime = ctx->ws_t<uint32_t>(sw * 2);
+    if (have_den) {
+      launch_canon(mem_v + SDEN * sw, mn2.d_nmod, mn2.WT, nb, ctx->stream);
+      uint32_t* dinv = batch_inverse(ctx, mn2, mem_v + SDEN * sw, nb, batch);   // thresholdkey.go:135 ModInverse
+      HIPCHK(hipMemcpyAsync(mem_v + SDEN * sw, dinv, sw * 4, hipMemcpyDeviceToDevice, ctx->stream));
+    }
+    {
+      Prog q;   // cprime = numerator(Montgomery) * denominator^-1 (plain)  -> plain residue
+      q.op(VM_LOAD, SNUM);
+      if (have_den) q.op(VM_MUL, SDEN); else q.op(VM_MULC, C_ONE);
+      q.op(VM_STORE, SB);
+      q.end();
+      SegSpec sq{&mn2, &q, mem_v, nullptr};
+      run_vm(ctx, nb, sq, nullptr, false);
+      launch_canon(mem_v + SB * sw, mn2.d_nmod, mn2.WT, nb, ctx->stream);
+    }
+    (void)cprime;
+    // thresholdkey.go:143-146: L(cprime) * (4 delta^2)^-1 mod n   (combineSharesConstant, :63-66)
+    pgpu_pubkey* pkm = const_cast<pgpu_pubkey*>(pk);
+    int cidx = -1;
+    for (auto& pr : pkm->combine_consts) if (pr.first == total_servers) cidx = pr.second;
+    BigU cconst;
+    if (!hostbig::modinv((BigU(4) * delta * delta) % pk->N, pk->N, cconst))
+      api_throw(PGPU_ERR_NOT_INVERTIBLE, "4*delta^2 is not invertible mod n");
+    if (cidx < 0) {
+      cidx = pkm->mn.add_const(pkm->mn.to_mont(cconst));
+      pkm->mn.upload();
+      pkm->combine_consts.push_back({total_servers, cidx});
+    }
+    uint32_t* negc = ctx->upload_words(((pk->N - cconst) % pk->N).to_limbs(LB, mn.WT));
+    uint32_t* res = L_times_const(ctx, pk, mem_v + SB * sw, nb, batch, cidx, negc);
+    pack_result(ctx, res, mn.WT, nb, batch, m, m_stride, mn.nbytes, mem);
     HIPCHK(hipStreamSynchronize(ctx->stream));
   });
 }

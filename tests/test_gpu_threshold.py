@@ -1,0 +1,69 @@
+"""GPU parity for threshold decryption (thresholdkey.go): PartialDecrypt and CombinePartialDecryptions, against the
+reference's own toy KATs (run THROUGH the GPU path) and against the oracle on the committed safe-prime keys."""
+import itertools
+import json
+import os
+import random
+
+import pytest
+
+from oracle import paillier_oracle as po
+
+pytestmark = pytest.mark.gpu
+G = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+
+
+@pytest.fixture(scope="module")
+def ctx():
+    import paillier_amd as pa
+    return pa.Context(0)
+
+
+def test_reference_kats_on_gpu(ctx):
+    import paillier_amd as pa
+    # thresholdkey_test.go:58-74 TestDecrypt: N = 101*103, share 862, l = 10, c = 56 -> 40644522
+    tk = pa.ThresholdPublicKey(ctx, 101 * 103, total=10, threshold=1)
+    assert tk.PartialDecryptBatch(9, 862, [56]) == (9, [40644522])
+    # thresholdkey_test.go:267-281 TestDecryption: shares (1, 384111638639), (2, 235243761043), N = 637753, l = 2 -> 100
+    tk = pa.ThresholdPublicKey(ctx, 637753, total=2, threshold=2)
+    assert tk.CombinePartialDecryptionsBatch([(1, [384111638639]), (2, [235243761043])]) == [100]
+    # thresholdkey_test.go:151-166: threshold not met / duplicate ids
+    with pytest.raises(pa.PaillierHipError) as ei:
+        tk.CombinePartialDecryptionsBatch([(1, [384111638639])])
+    assert ei.value.code == -6
+    with pytest.raises(pa.PaillierHipError) as ei:
+        tk.CombinePartialDecryptionsBatch([(1, [384111638639]), (1, [235243761043])])
+    assert ei.value.code == -6
+
+
+@pytest.mark.parametrize("bits", ["512", "2048"])
+def test_partial_decrypt_and_combine_all_subsets(ctx, bits):
+    """BASELINE config 4 shape: l = 5, t = 3.  Every 3-subset has at least one negative Lagrange coefficient."""
+    import paillier_amd as pa
+    k = json.load(open(os.path.join(G, "keys.json")))["threshold"][bits]
+    n, total, thr = int(k["n"], 16), k["total"], k["threshold"]
+    shares = [int(s, 16) for s in k["shares"]]
+    v, vks = int(k["v"], 16), [int(x, 16) for x in k["vks"]]
+    tsks = [po.ThresholdSecretKey(N=n, G=n + 1, TotalNumberOfDecryptionServers=total, Threshold=thr, VerificationKey=v,
+                                  VerificationKeys=vks, ID=i + 1, Share=shares[i]) for i in range(total)]
+    rng = random.Random(int(bits))
+    ms = [0, 1, n - 1] + [rng.randrange(n) for _ in range(9)]
+    cts = [po.encrypt_with_r(tsks[0], m, po.rand_unit(n, rng)).C for m in ms]
+    tk = pa.ThresholdPublicKey(ctx, n, total=total, threshold=thr)
+    parts = {}
+    for t in tsks:
+        ID, dec = tk.PartialDecryptBatch(t.ID, t.Share, cts)
+        assert dec == [po.partial_decrypt(t, c).Decryption for c in cts]
+        parts[ID] = dec
+    subsets = list(itertools.combinations(range(1, total + 1), thr)) + [(5, 3, 1), (2, 4, 1, 5), (1, 2, 3, 4, 5)]
+    for ids in subsets:
+        got = tk.CombinePartialDecryptionsBatch([(i, parts[i]) for i in ids])
+        assert got == ms, f"subset {ids}"
+        want = [po.combine_partial_decryptions(tsks[0], [po.PartialDecryption(i, parts[i][j]) for i in ids])
+                for j in range(3)]
+        assert got[:3] == want
+    # tampered share: still must equal what the reference computes on the same (wrong) inputs
+    bad = [(1, parts[1]), (3, [x ^ 5 for x in parts[3]]), (4, parts[4])]
+    got = tk.CombinePartialDecryptionsBatch(bad)
+    want = [po.combine_partial_decryptions(tsks[0], [po.PartialDecryption(i, d[j]) for i, d in bad]) for j in range(len(ms))]
+    assert got == want
