@@ -402,6 +402,10 @@ struct pgpu_pubkey {
   std::unique_ptr<ModCtx> mn3;    // n^3 (level two), built when the width is supported
   DevLimbs n_limbs;               // n as mn.WT limbs (multiplicand of the closed-form g^m)
   DevLimbs ninv2k;                // n^-1 mod 2^(28 mn.WT): exact division by n (the L function)
+  DevLimbs ninv2k_2;              // n^-1 mod 2^(28 mn2.WT): quotients up to n^2 (level two)
+  DevLimbs n2_limbs;              // n^2 as mn2.WT limbs
+  int c_inv2R = -1;               // 2^-1 * R mod n in mn.consts        (binomial of the level-two g^m)
+  int c_ninv2R_2 = -1;            // n * 2^-1 * R mod n^2 in mn2.consts (Damgard-Jurik recovery, paillier.go:326-331)
   std::vector<std::pair<int, int>> combine_consts;  // (total servers l, index of (4 (l!)^2)^-1 * R mod n in mn.consts)
 };
 
@@ -419,6 +423,7 @@ struct pgpu_seckey {
   // generic path (reference formula)
   int c_muR = -1;                // lambda^-1 mod n, times R mod n, in pk->mn
   DevLimbs n_minus_mu;           // (n - mu) mod n, the answer for c == 0 (L(-1) = -1)
+  int c_mu2R = -1;               // lambda^-1 mod n^2, times R mod n^2, in pk->mn2 (level two)
 };
 
 // inverse of odd d modulo 2^bits
@@ -788,6 +793,14 @@ int pgpu_pubkey_create(pgpu_ctx* ctx, const uint8_t* n_be, size_t n_len, const u
     }
     pk->n_limbs.set(pk->N, pk->mn.WT);
     pk->ninv2k.set(inv_mod_pow2(pk->N, (size_t)LB * pk->mn.WT), pk->mn.WT);
+    pk->ninv2k_2.set(inv_mod_pow2(pk->N, (size_t)LB * pk->mn2.WT), pk->mn2.WT);
+    pk->n2_limbs.set(n2, pk->mn2.WT);
+    BigU inv2 = hostbig::shr(pk->N + BigU(1), 1);                       // 2^-1 mod n
+    BigU inv2_n2 = hostbig::shr(n2 + BigU(1), 1);                       // 2^-1 mod n^2
+    pk->c_inv2R = pk->mn.add_const(pk->mn.to_mont(inv2));
+    pk->c_ninv2R_2 = pk->mn2.add_const(pk->mn2.to_mont(hostbig::mulmod(pk->N, inv2_n2, n2)));
+    pk->mn.upload();
+    pk->mn2.upload();
   });
   if (rc == PGPU_OK) *out = pk.release();
   return rc;
@@ -822,6 +835,13 @@ int pgpu_seckey_create(pgpu_ctx* ctx, const pgpu_pubkey* pk, const uint8_t* lamb
     sk->c_muR = pkm->mn.add_const(pkm->mn.to_mont(mu));
     pkm->mn.upload();
     sk->n_minus_mu.set((n - mu) % n, pk->mn.WT);
+    {
+      BigU mu2, n2v = n * n;
+      if (hostbig::modinv(sk->lambda, n2v, mu2)) {
+        sk->c_mu2R = pkm->mn2.add_const(pkm->mn2.to_mont(mu2));
+        pkm->mn2.upload();
+      }
+    }
     // recover p, q from n and lambda = (p-1)(q-1): p + q = n - lambda + 1
     if (hostbig::cmp(n + BigU(1), sk->lambda) > 0) {
       BigU s = n + BigU(1) - sk->lambda;
@@ -938,27 +958,44 @@ uint32_t* decrypt1_crt(const pgpu_seckey* sk, const uint32_t* c_limbs, size_t nb
 }
 
 
-// m = L(u) * C mod n  with the reference's L(u, n) = Div(u - 1, n)  (paillier.go:436-440; Euclidean: floor for
-// u >= 1 and -1 for u = 0), for ANY canonical u < n^2.  floor((u-1)/n) = ((u-1) - ((u-1) mod n)) / n: one Montgomery
-// reduction mod n plus one exact division.  c_const = index of C*R mod n in pk->mn.consts; neg_const = (-C) mod n as
-// limbs (the u = 0 answer).  Returns mn.WT-limb canonical results.
-uint32_t* L_times_const(pgpu_ctx* ctx, const pgpu_pubkey* pk, const uint32_t* u, size_t nb, size_t count, int c_const,
-                        const uint32_t* neg_const) {
+// The reference's L(u, n) = Div(u - 1, n) (paillier.go:436-440; Euclidean: floor for u >= 1 and -1 for u = 0) for a
+// canonical u of `wu` limbs: floor((u-1)/n) = ((u-1) - ((u-1) mod n)) / n -- Montgomery reductions mod n plus one
+// exact division.  Returns the quotient (wq limbs: mn.WT for u < n^2, mn2.WT for u < n^3); zf[g] = (u == 0), for which
+// the caller substitutes the value that stands for -1.
+uint32_t* L_floor(pgpu_ctx* ctx, const pgpu_pubkey* pk, const uint32_t* u, int wu, size_t nb, size_t count, int wq,
+                  int32_t* zf) {
   const ModCtx &mn = pk->mn, &mn2 = pk->mn2;
   const int W1 = mn.WT, W2 = mn2.WT;
-  int32_t* zf = ctx->ws_t<int32_t>(nb);
-  launch_is_zero(u, W2, nb, zf, ctx->stream);
-  uint32_t* v = ctx->ws_t<uint32_t>((size_t)W2 * nb);
+  launch_is_zero(u, wu, nb, zf, ctx->stream);
+  uint32_t* v = ctx->ws_t<uint32_t>((size_t)wu * nb);
+  launch_sub_one(u, v, wu, nb, ctx->stream);
   uint32_t* r = ctx->ws_t<uint32_t>((size_t)W1 * nb);
-  uint32_t* q = ctx->ws_t<uint32_t>((size_t)W1 * nb);
-  uint32_t* scratch_l = ctx->ws_t<uint32_t>((size_t)W1 * nb);
+  if (wu <= 2 * W1) {
+    reduce_mod(ctx, mn, v, wu, r, nb);
+  } else {
+    if (wu > 2 * W2) api_throw(PGPU_ERR_UNSUPPORTED, "L_floor operand too wide");
+    uint32_t* r2 = ctx->ws_t<uint32_t>((size_t)W2 * nb);
+    reduce_mod(ctx, mn2, v, wu, r2, nb);     // (u-1) mod n^2
+    reduce_mod(ctx, mn, r2, W2, r, nb);      // ... mod n
+  }
+  uint32_t* q = ctx->ws_t<uint32_t>((size_t)wq * nb);
+  uint32_t* tb = ctx->ws_t<uint32_t>((size_t)wu * nb);
   int32_t* st_dummy = ctx->ws_t<int32_t>(nb);
   HIPCHK(hipMemsetAsync(st_dummy, 0, nb * 4, ctx->stream));
-  // first pass of k_div_exact leaves t = u - 1 in its scratch array (= v); its quotient is discarded here
-  launch_div_exact(u, W2, 1, nullptr, 0, v, pk->ninv2k.d, mn.d_nmod, W1, scratch_l, W1, nb, count, st_dummy, 1, ctx->stream);
-  reduce_mod(ctx, mn, v, W2, r, nb);                                   // r = (u - 1) mod n
-  uint32_t* tb = ctx->ws_t<uint32_t>((size_t)W2 * nb);
-  launch_div_exact(v, W2, 0, r, W1, tb, pk->ninv2k.d, mn.d_nmod, W1, q, W1, nb, count, st_dummy, 2, ctx->stream);  // floor
+  const uint32_t* dinv = (wq == W1) ? pk->ninv2k.d : pk->ninv2k_2.d;
+  if (wq != W1 && wq != W2) api_throw(PGPU_ERR_INVALID, "L_floor quotient width");
+  launch_div_exact(v, wu, 0, r, W1, tb, dinv, mn.d_nmod, W1, q, wq, nb, count, st_dummy, 2, ctx->stream);
+  return q;
+}
+
+// m = L(u) * C mod n for canonical u < n^2.  c_const = index of C*R mod n in pk->mn.consts; neg_const = (-C) mod n as
+// limbs (the u = 0 answer: L = -1).  Returns mn.WT-limb canonical results.
+uint32_t* L_times_const(pgpu_ctx* ctx, const pgpu_pubkey* pk, const uint32_t* u, size_t nb, size_t count, int c_const,
+                        const uint32_t* neg_const) {
+  const ModCtx& mn = pk->mn;
+  const int W1 = mn.WT;
+  int32_t* zf = ctx->ws_t<int32_t>(nb);
+  uint32_t* q = L_floor(ctx, pk, u, pk->mn2.WT, nb, count, W1, zf);
   size_t s1 = (size_t)W1 * nb;
   uint32_t* m1 = ctx->ws_t<uint32_t>(s1 * 2);
   HIPCHK(hipMemcpyAsync(m1, q, s1 * 4, hipMemcpyDeviceToDevice, ctx->stream));
@@ -985,6 +1022,61 @@ uint32_t* decrypt1_generic(const pgpu_seckey* sk, const uint32_t* c_limbs, size_
   HIPCHK(hipMemcpyAsync(pl.in(), c_limbs, (size_t)mn2.WT * nb * 4, hipMemcpyDeviceToDevice, ctx->stream));
   modexp_shared_run(ctx, mn2, pl, sk->lambda, false, false, false);  // u, canonical (secret exponent: no window skipping)
   return L_times_const(ctx, pk, pl.out(), nb, count, sk->c_muR, sk->n_minus_mu.d);
+}
+
+// Level-two (Damgard-Jurik s = 2) decryption by the reference's formula (paillier.go:292-340):
+//   a = c^lambda mod n^3
+//   i1 = L(a mod n^2)                                   (recoveryAlgorithm j = 1)
+//   i  = (L(a) - (|i1| (i1 - 1) mod n^2) * n * 2^-1) mod n^2      (j = 2, k = 2; |i1| from SetBytes(i.Bytes()), :320)
+//   m  = i * lambda^-1 mod n^2
+// c: device array of mn3.WT limbs.  Returns mn2.WT-limb canonical plaintexts.
+uint32_t* decrypt2_generic(const pgpu_seckey* sk, const uint32_t* c_limbs, size_t nb, size_t count) {
+  pgpu_ctx* ctx = sk->ctx;
+  const pgpu_pubkey* pk = sk->pk;
+  if (!pk->mn3 || sk->c_mu2R < 0) api_throw(PGPU_ERR_UNSUPPORTED, "level two is not available for this key");
+  const ModCtx &mn = pk->mn, &mn2 = pk->mn2, &mn3 = *pk->mn3;
+  const int W1 = mn.WT, W2 = mn2.WT, W3 = mn3.WT;
+  ModexpPlan pl = modexp_alloc(ctx, mn3, nb, 32);
+  HIPCHK(hipMemcpyAsync(pl.in(), c_limbs, (size_t)W3 * nb * 4, hipMemcpyDeviceToDevice, ctx->stream));
+  modexp_shared_run(ctx, mn3, pl, sk->lambda, false, false, false);
+  const uint32_t* a = pl.out();
+  // j = 1
+  uint32_t* a2 = ctx->ws_t<uint32_t>((size_t)W2 * nb);
+  reduce_mod(ctx, mn2, a, W3, a2, nb);
+  int32_t* z1 = ctx->ws_t<int32_t>(nb);
+  uint32_t* i1 = L_floor(ctx, pk, a2, W2, nb, count, W1, z1);
+  // j = 2
+  int32_t* z2 = ctx->ws_t<int32_t>(nb);
+  uint32_t* t1 = L_floor(ctx, pk, a, W3, nb, count, W2, z2);
+  const size_t s2 = (size_t)W2 * nb;
+  uint32_t* n2m1 = ctx->upload_words((mn2.N - BigU(1)).to_limbs(LB, W2));
+  uint32_t* n2m2 = ctx->upload_words((mn2.N - BigU(2)).to_limbs(LB, W2));
+  uint32_t* one2 = ctx->upload_words(BigU(1).to_limbs(LB, W2));
+  launch_select_const(z2, n2m1, t1, W2, nb, ctx->stream);                  // L(0) = -1  ->  n^2 - 1 (mod n^2)
+  // slots (mod n^2): 0 |i1|, 1 (i1 - 1) mod n^2, 2 X*n/2, 3 i, 4 m
+  uint32_t* mv = ctx->ws_t<uint32_t>(s2 * 5);
+  launch_copy_limbs(i1, 0, W1, mv, W2, nb, ctx->stream);                     // zero-extend
+  launch_select_const(z1, one2, mv, W2, nb, ctx->stream);                    // i1 = -1: |i1| = 1
+  uint32_t* ones = ctx->ws_t<uint32_t>(s2);
+  launch_fill_const(one2, ones, W2, nb, ctx->stream);
+  launch_copy_limbs(i1, 0, W1, mv + 3 * s2, W2, nb, ctx->stream);
+  launch_sub_mod(mv + 3 * s2, ones, mn2.d_nmod, mv + s2, W2, nb, ctx->stream);   // (i1 - 1) mod n^2
+  launch_select_const(z1, n2m2, mv + s2, W2, nb, ctx->stream);               // i1 = -1: i1 - 1 = -2
+  Prog p;
+  p.op(VM_LOAD, 0); p.op(VM_MULC, C_R2); p.op(VM_MUL, 1);                    // X = |i1| (i1-1) mod n^2 (plain)
+  p.op(VM_MULC, (uint32_t)pk->c_ninv2R_2);                                   // X * n * 2^-1 mod n^2
+  p.op(VM_STORE, 2);
+  p.end();
+  SegSpec sg{&mn2, &p, mv, nullptr};
+  run_vm(ctx, nb, sg, nullptr, false);
+  launch_canon(mv + 2 * s2, mn2.d_nmod, W2, nb, ctx->stream);
+  launch_sub_mod(t1, mv + 2 * s2, mn2.d_nmod, mv + 3 * s2, W2, nb, ctx->stream);  // i
+  Prog q;
+  q.op(VM_LOAD, 3); q.op(VM_MULC, (uint32_t)sk->c_mu2R); q.op(VM_STORE, 4); q.end();
+  SegSpec sq{&mn2, &q, mv, nullptr};
+  run_vm(ctx, nb, sq, nullptr, false);
+  launch_canon(mv + 4 * s2, mn2.d_nmod, W2, nb, ctx->stream);
+  return mv + 4 * s2;
 }
 
 // ---- threshold decryption ------------------------------------------------------------------------------------
@@ -1034,11 +1126,22 @@ int pgpu_decrypt(const pgpu_seckey* sk, int level, size_t batch, const uint8_t* 
   pgpu_ctx* ctx = sk->ctx;
   return guarded([&] {
     check_batch_args(c, m, batch);
-    if (level != PGPU_LEVEL_ONE) api_throw(PGPU_ERR_UNSUPPORTED, "level-two decryption is not built yet");
     ctx->bind();
     ctx->reset_ws();
     const size_t nb = round_up(batch, VM_BLOCK);
     const pgpu_pubkey* pk = sk->pk;
+    if (level == PGPU_LEVEL_TWO) {
+      const ModCtx& mn3 = cipher_mod(pk, level);
+      if (c_stride < mn3.nbytes) api_throw(PGPU_ERR_INVALID, "ciphertext stride smaller than the byte length of n^3");
+      uint32_t* cl3 = ctx->ws_t<uint32_t>((size_t)mn3.WT * nb);
+      unpack_operand(ctx, c, c_stride, mn3.nbytes, batch, mem, cl3, mn3.WT, nb);
+      uint32_t* r2 = decrypt2_generic(sk, cl3, nb, batch);
+      pack_result(ctx, r2, pk->mn2.WT, nb, batch, m, m_stride, pk->mn2.nbytes, mem);
+      if (status) memset(status, 0, batch * 4);
+      HIPCHK(hipStreamSynchronize(ctx->stream));
+      return;
+    }
+    if (level != PGPU_LEVEL_ONE) api_throw(PGPU_ERR_INVALID, "bad encryption level");
     const size_t cbytes = pk->mn2.nbytes;
     if (c_stride < cbytes) api_throw(PGPU_ERR_INVALID, "ciphertext stride smaller than the byte length of n^2");
     int32_t* d_status = ctx->ws_t<int32_t>(nb);
@@ -1083,11 +1186,43 @@ int pgpu_encrypt_with_r(const pgpu_pubkey* pk, int level, size_t batch, const ui
   return guarded([&] {
     check_batch_args(m, c, batch);
     if (!r) api_throw(PGPU_ERR_INVALID, "null buffer");
-    if (level != PGPU_LEVEL_ONE) api_throw(PGPU_ERR_UNSUPPORTED, "level-two encryption is not built yet");
     if (!pk->g_is_n_plus_1) api_throw(PGPU_ERR_UNSUPPORTED, "G != N+1 is not built yet");
     ctx->bind();
     ctx->reset_ws();
     const size_t nb = round_up(batch, VM_BLOCK);
+    if (level == PGPU_LEVEL_TWO) {
+      // c = (1+n)^m * r^(n^2) mod n^3,  (1+n)^m = 1 + m n + C(m,2) n^2 (mod n^3), m taken mod n^2
+      const ModCtx &mn = pk->mn, &mn2 = pk->mn2, &mn3 = cipher_mod(pk, level);
+      const int W1 = mn.WT, W2 = mn2.WT, W3 = mn3.WT;
+      const size_t mlen = std::min(m_stride, mn2.nbytes), rlen = std::min(r_stride, mn3.nbytes);
+      uint32_t* ml = ctx->ws_t<uint32_t>((size_t)W2 * nb);
+      unpack_operand(ctx, m, m_stride, mlen, batch, mem, ml, W2, nb);
+      uint32_t* mred = ctx->ws_t<uint32_t>((size_t)W2 * nb);
+      reduce_mod(ctx, mn2, ml, W2, mred, nb);
+      // t = C(m,2) mod n = (m mod n) ((m-1) mod n) 2^-1 mod n
+      const size_t s1 = (size_t)W1 * nb;
+      uint32_t* mv = ctx->ws_t<uint32_t>(s1 * 4);   // slots: 0 m0, 1 (m0-1) mod n, 2 t, 3 ones
+      reduce_mod(ctx, mn, mred, W2, mv, nb);
+      launch_fill_const(mn.d_consts + (size_t)C_ONE * W1, mv + 3 * s1, W1, nb, ctx->stream);
+      launch_sub_mod(mv, mv + 3 * s1, mn.d_nmod, mv + s1, W1, nb, ctx->stream);
+      Prog pt;
+      pt.op(VM_LOAD, 0); pt.op(VM_MULC, C_R2); pt.op(VM_MUL, 1); pt.op(VM_MULC, (uint32_t)pk->c_inv2R); pt.op(VM_STORE, 2);
+      pt.end();
+      SegSpec st{&mn, &pt, mv, nullptr};
+      run_vm(ctx, nb, st, nullptr, false);
+      launch_canon(mv + 2 * s1, mn.d_nmod, W1, nb, ctx->stream);
+      ModexpPlan pl = modexp_alloc(ctx, mn3, nb, 32);
+      uint32_t* tmpa = ctx->ws_t<uint32_t>((size_t)W3 * nb);
+      launch_mul_const_add(mred, W2, pk->n_limbs.d, W1, nullptr, 0, 1, tmpa, W3, nb, ctx->stream);            // 1 + m n
+      launch_mul_const_add(mv + 2 * s1, W1, pk->n2_limbs.d, W2, tmpa, W3, 0, pl.post(), W3, nb, ctx->stream);  // + t n^2
+      launch_canon(pl.post(), mn3.d_nmod, W3, nb, ctx->stream);                                              // mod n^3
+      unpack_operand(ctx, r, r_stride, rlen, batch, mem, pl.in(), W3, nb);
+      modexp_shared_run(ctx, mn3, pl, mn2.N, false, true, true);   // r^(n^2) * g^m mod n^3
+      pack_result(ctx, pl.out(), W3, nb, batch, c, c_stride, mn3.nbytes, mem);
+      HIPCHK(hipStreamSynchronize(ctx->stream));
+      return;
+    }
+    if (level != PGPU_LEVEL_ONE) api_throw(PGPU_ERR_INVALID, "bad encryption level");
     const ModCtx &mn = pk->mn, &mn2 = pk->mn2;
     const size_t mlen = std::min(m_stride, mn.nbytes), rlen = std::min(r_stride, mn2.nbytes);
     // m mod n (the generator 1+n has order n, so G^m = G^(m mod n))

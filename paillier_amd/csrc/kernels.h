@@ -58,3 +58,4 @@ void launch_scatter(const uint32_t* in, size_t nb_in, const uint32_t* idx, size_
 void launch_restride(const uint32_t* in, size_t nb_in, size_t count, const uint32_t* fill, uint32_t* out, size_t nb_out, int w,
                      hipStream_t st);
 void launch_merge_halves(const uint32_t* lo, const uint32_t* hi, size_t half, uint32_t* out, size_t nb, int w, hipStream_t st);
+void launch_sub_one(const uint32_t* x, uint32_t* out, int w, size_t nb, hipStream_t st);

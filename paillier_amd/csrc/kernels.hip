@@ -281,6 +281,18 @@ __global__ void k_div_exact(const uint32_t* __restrict__ u, int wu, uint32_t sub
   if (bad && g < count) status[g] |= flag;
 }
 
+// out = x - 1 (w limbs); x == 0 wraps to all-ones limbs (callers flag that lane separately)
+__global__ void k_sub_one(const uint32_t* __restrict__ x, uint32_t* __restrict__ out, int w, size_t nb) {
+  size_t g = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (g >= nb) return;
+  int32_t br = 1;
+  for (int l = 0; l < w; ++l) {
+    int32_t v = (int32_t)x[(size_t)l * nb + g] - br;
+    br = v < 0;
+    out[(size_t)l * nb + g] = (uint32_t)(v + (br << LB)) & LMASK;
+  }
+}
+
 // flags[g] = (x == 0)
 __global__ void k_is_zero(const uint32_t* __restrict__ x, int w, size_t nb, int32_t* __restrict__ flags) {
   size_t g = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -412,4 +424,7 @@ void launch_restride(const uint32_t* in, size_t nb_in, size_t count, const uint3
 }
 void launch_merge_halves(const uint32_t* lo, const uint32_t* hi, size_t half, uint32_t* out, size_t nb, int w, hipStream_t st) {
   hipLaunchKernelGGL(k_merge_halves, HELPER_GRID(2 * half), 0, st, lo, hi, half, out, nb, w);
+}
+void launch_sub_one(const uint32_t* x, uint32_t* out, int w, size_t nb, hipStream_t st) {
+  hipLaunchKernelGGL(k_sub_one, HELPER_GRID(nb), 0, st, x, out, w, nb);
 }

@@ -1,0 +1,65 @@
+"""GPU parity for the generalized (Damgard-Jurik s = 2) scheme: level-two EncryptWithR / Decrypt and nested
+encryption (paillier.go:199-203,206-218,292-372), against the oracle.  n^3 of a 1024-bit key runs on the 2-lane
+kernel shape, n^3 of a 2048-bit key on the 4-lane shape."""
+import json
+import os
+import random
+
+import pytest
+
+from oracle import paillier_oracle as po
+
+pytestmark = pytest.mark.gpu
+G = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+
+
+@pytest.fixture(scope="module")
+def ctx():
+    import paillier_amd as pa
+    return pa.Context(0)
+
+
+@pytest.mark.parametrize("bits", ["1024", "2048"])
+def test_level_two_encrypt_decrypt(ctx, bits):
+    import paillier_amd as pa
+    from paillier_amd import ENC_LEVEL_TWO
+    k = json.load(open(os.path.join(G, "keys.json")))["paillier"][bits]
+    p, q = int(k["p"], 16), int(k["q"], 16)
+    n, lam = p * q, (p - 1) * (q - 1)
+    n2, n3 = n * n, n ** 3
+    sk_o = po.SecretKey(N=n, G=n + 1, Lambda=lam)
+    pk = pa.PublicKey(ctx, n, n + 1)
+    sk = pa.SecretKey(ctx, pk, lam)
+    rng = random.Random(int(bits) + 2)
+    ms = [0, 1, 2, n - 1, n, n + 1, n2 - 1] + [rng.randrange(n2) for _ in range(9)]
+    rs = [po.rand_unit(n, rng) for _ in ms]
+    cts = pk.EncryptWithRBatch(ms, rs, level=ENC_LEVEL_TWO)
+    assert cts == [po.encrypt_with_r_at_level(sk_o, m, r, po.ENC_LEVEL_TWO).C for m, r in zip(ms, rs)]
+    assert sk.DecryptBatch(cts, level=ENC_LEVEL_TWO) == ms
+    # arbitrary elements of Z_{n^3}: must equal the reference's recovery algorithm on the same input
+    weird = [rng.randrange(n3) for _ in range(4)] + [n3 - 1, 1, p, n, n2, 0, 5 * n2]
+    got = sk.DecryptBatch(weird, level=ENC_LEVEL_TWO)
+    assert got == [po.decrypt(sk_o, po.Ciphertext(c, po.ENC_LEVEL_TWO)) for c in weird]
+
+
+def test_nested_encrypt_decrypt(ctx):
+    """paillier_test.go:65-87: NestedEncrypt = level-one encryption encrypted again at level two."""
+    import paillier_amd as pa
+    from paillier_amd import ENC_LEVEL_ONE, ENC_LEVEL_TWO
+    sk_o, p, q = po.keygen_seeded(1024, 1)
+    n = sk_o.N
+    pk = pa.PublicKey(ctx, n, n + 1)
+    sk = pa.SecretKey(ctx, pk, sk_o.Lambda)
+    rng = random.Random(77)
+    ms = [rng.randrange(n) for _ in range(20)]
+    inner = pk.EncryptWithRBatch(ms, [po.rand_unit(n, rng) for _ in ms], level=ENC_LEVEL_ONE)
+    outer = pk.EncryptWithRBatch(inner, [po.rand_unit(n, rng) for _ in ms], level=ENC_LEVEL_TWO)
+    layer = sk.DecryptBatch(outer, level=ENC_LEVEL_TWO)        # DecryptNestedCiphertextLayer
+    assert layer == inner
+    assert sk.DecryptBatch(layer, level=ENC_LEVEL_ONE) == ms   # NestedDecrypt
+    assert [po.nested_decrypt(sk_o, po.Ciphertext(c, po.ENC_LEVEL_TWO)) for c in outer[:3]] == ms[:3]
+    # NestedAdd (operations.go:121-127): ConstMult of a level-two ciphertext by a level-one ciphertext value
+    other = pk.EncryptWithRBatch([5] * 3, [po.rand_unit(n, rng) for _ in range(3)])
+    summed = pk.ConstMultBatch(outer[:3], other, level=ENC_LEVEL_TWO)
+    assert summed == [po.nested_add(sk_o, po.Ciphertext(a, po.ENC_LEVEL_TWO), po.Ciphertext(b)).C
+                      for a, b in zip(outer[:3], other)]
