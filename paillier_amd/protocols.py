@@ -1,0 +1,198 @@
+"""Batch forms of the reference's proof protocols, orchestrated on the host over the GPU batch primitives.
+
+Every modular exponentiation, product and inverse below runs on the GPU through the C ABI (`Modulus.exp_batch`,
+`mul_batch`, `inv_batch`, `PublicKey.*Batch`, `SecretKey.DecryptBatch`); the host does what the reference does outside
+gmp: SHA-256 over `Bytes()` of the transcript, the unreduced integers that only feed the hash, and control flow.
+
+Reference functions mirrored (file:line in /root/reference):
+  ExtractRandonness                       operations.go:75-91
+  NestedRandomize (randomness supplied)   operations.go:96-118
+  PartialDecryptionWithZKP / VerifyProof  thresholdkey.go:225-311
+  ProveDDLEQ / VerifyDDLEQProof           ddleq.go:27-153
+  RandomOracleDigest / RandomOracleBit    random_oracle.go:10-32
+"""
+from __future__ import annotations
+
+import hashlib
+from dataclasses import dataclass
+from typing import List, Optional, Sequence
+
+from .api import ENC_LEVEL_ONE, ENC_LEVEL_TWO, Context, Modulus, PublicKey, SecretKey, ThresholdPublicKey
+
+
+def _bytes(x: int) -> bytes:
+    """gmp.Int.Bytes(): minimal big-endian magnitude, empty for zero."""
+    x = abs(int(x))
+    return x.to_bytes((x.bit_length() + 7) // 8, "big")
+
+
+def random_oracle_digest(*values: int) -> bytes:
+    """random_oracle.go:20-32 -- the FIRST argument is skipped (:24-26)."""
+    return hashlib.sha256(b"".join(_bytes(v) for v in values[1:])).digest()
+
+
+def random_oracle_bit(*values: int) -> bool:
+    """random_oracle.go:10-16."""
+    return int.from_bytes(random_oracle_digest(*values), "big") % 2 == 1
+
+
+def _factorial(n: int) -> int:
+    r = 1
+    for i in range(1, n + 1):
+        r *= i
+    return r
+
+
+class _Mods:
+    """Moduli n, n^2, n^3 of a key on one context (cached on the key object)."""
+
+    def __init__(self, ctx: Context, n: int):
+        self.n, self.n2, self.n3 = n, n * n, n ** 3
+        self.m1, self.m2, self.m3 = Modulus(ctx, n), Modulus(ctx, n * n), Modulus(ctx, n ** 3)
+
+
+def _mods(key) -> _Mods:
+    m = getattr(key, "_mods", None)
+    if m is None:
+        m = _Mods(key.ctx, key.N)
+        key._mods = m
+    return m
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# operations.go
+# ---------------------------------------------------------------------------------------------------------------
+
+def extract_randomness_batch(sk: SecretKey, cts: Sequence[int], level: int = ENC_LEVEL_ONE) -> List[int]:
+    """operations.go:75-91 for each ciphertext."""
+    pk, mods = sk.pk, _mods(sk.pk)
+    n = pk.N
+    ns, ns1, mod1 = (n, mods.n2, mods.m2) if level == ENC_LEVEL_ONE else (mods.n2, mods.n3, mods.m3)
+    ns_inv = pow(ns, -1, sk.Lambda)                       # ModInverse(ns, Lambda): one scalar per key
+    v = sk.DecryptBatch(cts, level=level)
+    gv = mod1.exp_batch([pk.G] * len(cts), v)             # G^v mod n^(s+1), per-ciphertext exponent
+    gv_inv = mod1.inv_batch(gv)
+    z = mod1.mul_batch(gv_inv, list(cts))
+    if level == ENC_LEVEL_TWO:                            # z < n^3: bring it below n^2 before the exponentiation mod n
+        z = mods.m2.exp_batch(z, 1, base_bytes=2 * mods.m2.nbytes)
+    return mods.m1.exp_batch(z, ns_inv, base_bytes=2 * mods.m1.nbytes)
+
+
+def nested_randomize_with_ab_batch(pk: PublicKey, cts: Sequence[int], a_s: Sequence[int], b_s: Sequence[int]) -> List[int]:
+    """operations.go:96-118 with the draws (a, b) supplied: ct^(a^n mod n^2) * b^(n^2) mod n^3."""
+    mods = _mods(pk)
+    an = mods.m2.exp_batch(list(a_s), mods.n)
+    bn2 = mods.m3.exp_batch(list(b_s), mods.n2)
+    r = mods.m3.exp_batch(list(cts), an)
+    return mods.m3.mul_batch(r, bn2)
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# thresholdkey.go: share-decryption proofs
+# ---------------------------------------------------------------------------------------------------------------
+
+@dataclass
+class PartialDecryptionZKP:
+    ID: int
+    Decryption: int
+    E: int
+    Z: int
+    C: int
+
+
+def partial_decryption_with_zkp_batch(tk: ThresholdPublicKey, ID: int, share: int, verification_key: int,
+                                      cts: Sequence[int], rs: Sequence[int]) -> List[PartialDecryptionZKP]:
+    """thresholdkey.go:225-257 for each ciphertext, with the random r (< n^2, :233) supplied."""
+    mods = _mods(tk)
+    delta = _factorial(tk.TotalNumberOfDecryptionServers)
+    _, dec = tk.PartialDecryptBatch(ID, share, cts)
+    c4m = tk.ConstMultBatch(list(cts), 4)                              # Exp(c^4, r, n^2) = (c^4 mod n^2)^r
+    a = mods.m2.exp_batch(c4m, list(rs))
+    b = mods.m2.exp_batch([verification_key] * len(cts), list(rs))
+    out = []
+    for c, d, ai, bi, r in zip(cts, dec, a, b, rs):
+        c4, ci2 = c ** 4, d ** 2                                       # unreduced: only the hash sees them (:241,248)
+        e = int.from_bytes(hashlib.sha256(_bytes(ai) + _bytes(bi) + _bytes(c4) + _bytes(ci2)).digest(), "big")
+        out.append(PartialDecryptionZKP(ID, d, e, r + e * delta * share, c))   # computeZ :313-317
+    return out
+
+
+def verify_proof_batch(tk: ThresholdPublicKey, verification_key: int, verification_keys: Sequence[int],
+                       proofs: Sequence[PartialDecryptionZKP]) -> List[bool]:
+    """thresholdkey.go:278-311 for each proof."""
+    mods = _mods(tk)
+    cs, ds = [p.C for p in proofs], [p.Decryption for p in proofs]
+    zs, es = [p.Z for p in proofs], [p.E for p in proofs]
+    c4m = tk.ConstMultBatch(cs, 4)
+    a1 = mods.m2.exp_batch(c4m, zs)
+    a2 = mods.m2.inv_batch(mods.m2.exp_batch(mods.m2.mul_batch(ds, ds), es))
+    a = mods.m2.mul_batch(a1, a2)
+    b1 = mods.m2.exp_batch([verification_key] * len(proofs), zs)
+    b2 = mods.m2.inv_batch(mods.m2.exp_batch([verification_keys[p.ID - 1] for p in proofs], es))
+    b = mods.m2.mul_batch(b1, b2)
+    ok = []
+    for p, ai, bi in zip(proofs, a, b):
+        h = hashlib.sha256(_bytes(ai) + _bytes(bi) + _bytes(p.C ** 4) + _bytes(p.Decryption ** 2)).digest()
+        ok.append(p.E == int.from_bytes(h, "big"))
+    return ok
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# ddleq.go
+# ---------------------------------------------------------------------------------------------------------------
+
+@dataclass
+class DDLEQProofInstance:
+    X: int
+    Y: int
+    Alpha: int
+    E: int
+    F: int
+
+
+class DDLEQPanic(Exception):
+    """ddleq.go:68 panics when the statement is false."""
+
+
+def prove_ddleq_instances(sk: SecretKey, ct1s: Sequence[int], ct2s: Sequence[int], a_s: Sequence[int], b_s: Sequence[int],
+                          xs: Sequence[int], ys: Sequence[int]) -> List[DDLEQProofInstance]:
+    """ddleq.go:55-127 for a batch of (statement, instance) pairs with the draws (x, y) supplied."""
+    pk, mods = sk.pk, _mods(sk.pk)
+    m2, m3, n, n2 = mods.m2, mods.m3, mods.n, mods.n2
+    B = len(ct1s)
+    an = m2.exp_batch(list(a_s), n)
+    sanity = m3.mul_batch(m3.exp_batch(list(ct1s), an), m3.exp_batch(list(b_s), n2))
+    if sanity != list(ct2s):
+        raise DDLEQPanic("cannot prove re-encryption because inputs are wrong")
+    xn = m2.exp_batch(list(xs), n)
+    yn2 = m3.exp_batch(list(ys), n2)
+    alpha = m3.mul_batch(m3.exp_batch(list(ct1s), xn), yn2)
+    chal = [random_oracle_bit(c1, c2, x, y, al) for c1, c2, x, y, al in zip(ct1s, ct2s, xs, ys, alpha)]
+    e, f = list(xs), list(ys)
+    idx = [i for i in range(B) if chal[i]]
+    if idx:
+        sel = lambda v: [v[i] for i in idx]
+        ainv = m2.inv_batch(sel(a_s))
+        e_sel = m2.mul_batch(sel(xs), ainv)
+        s = extract_randomness_batch(sk, sel(ct1s), level=ENC_LEVEL_TWO)
+        en = m2.exp_batch(e_sel, n)
+        c = m3.exp_batch(s, sel(an))
+        c = m3.mul_batch(c, sel(b_s))
+        c = m3.inv_batch(m3.exp_batch(c, en))
+        c = m3.mul_batch(c, m3.exp_batch(s, sel(xn)))
+        f_sel = m3.mul_batch(sel(ys), c)
+        for j, i in enumerate(idx):
+            e[i], f[i] = e_sel[j], f_sel[j]
+    return [DDLEQProofInstance(xs[i], ys[i], alpha[i], e[i], f[i]) for i in range(B)]
+
+
+def verify_ddleq_instances(pk: PublicKey, ct1s: Sequence[int], ct2s: Sequence[int],
+                           proofs: Sequence[DDLEQProofInstance]) -> List[bool]:
+    """ddleq.go:129-153 for a batch of (statement, instance) pairs."""
+    mods = _mods(pk)
+    chal = [random_oracle_bit(c1, c2, p.X, p.Y, p.Alpha) for c1, c2, p in zip(ct1s, ct2s, proofs)]
+    check = [c2 if ch else c1 for c1, c2, ch in zip(ct1s, ct2s, chal)]
+    en = mods.m2.exp_batch([p.E for p in proofs], mods.n)
+    fn2 = mods.m3.exp_batch([p.F for p in proofs], mods.n2)
+    got = mods.m3.mul_batch(mods.m3.exp_batch(check, en), fn2)
+    return [g == p.Alpha for g, p in zip(got, proofs)]

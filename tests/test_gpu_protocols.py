@@ -1,0 +1,116 @@
+"""GPU parity for the proof protocols: ExtractRandonness, NestedRandomize, the share-decryption ZKP
+(thresholdkey.go:225-311) and DDLEQ (ddleq.go), against the oracle with the random draws supplied."""
+import json
+import os
+import random
+
+import pytest
+
+from oracle import paillier_oracle as po
+
+pytestmark = pytest.mark.gpu
+G = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+
+
+@pytest.fixture(scope="module")
+def ctx():
+    import paillier_amd as pa
+    return pa.Context(0)
+
+
+def test_extract_randomness_both_levels(ctx):
+    """operations_test.go:130-163: chosen r = i^2."""
+    import paillier_amd as pa
+    from paillier_amd import protocols as pr
+    sk_o, p, q = po.keygen_seeded(1024, 1)
+    n = sk_o.N
+    pk = pa.PublicKey(ctx, n, n + 1)
+    sk = pa.SecretKey(ctx, pk, sk_o.Lambda)
+    rng = random.Random(5)
+    rs = [(i * i) % n or 1 for i in range(2, 14)]
+    ms = [rng.randrange(n) for _ in rs]
+    for level, olevel in ((pa.ENC_LEVEL_ONE, po.ENC_LEVEL_ONE), (pa.ENC_LEVEL_TWO, po.ENC_LEVEL_TWO)):
+        cts = pk.EncryptWithRBatch(ms, rs, level=level)
+        got = pr.extract_randomness_batch(sk, cts, level=level)
+        assert got == [po.extract_randomness(sk_o, po.Ciphertext(c, olevel)) for c in cts]
+        if level == pa.ENC_LEVEL_ONE:
+            assert got == rs
+
+
+def test_share_decryption_zkp(ctx):
+    import paillier_amd as pa
+    from paillier_amd import protocols as pr
+    k = json.load(open(os.path.join(G, "keys.json")))["threshold"]["512"]
+    n, total, thr = int(k["n"], 16), k["total"], k["threshold"]
+    shares = [int(s, 16) for s in k["shares"]]
+    v, vks = int(k["v"], 16), [int(x, 16) for x in k["vks"]]
+    tsk = po.ThresholdSecretKey(N=n, G=n + 1, TotalNumberOfDecryptionServers=total, Threshold=thr, VerificationKey=v,
+                                VerificationKeys=vks, ID=3, Share=shares[2])
+    rng = random.Random(9)
+    cts = [po.encrypt_with_r(tsk, rng.randrange(n), po.rand_unit(n, rng)).C for _ in range(12)]
+    rs = [rng.randrange(n * n) for _ in cts]
+    tk = pa.ThresholdPublicKey(ctx, n, total=total, threshold=thr)
+    proofs = pr.partial_decryption_with_zkp_batch(tk, 3, shares[2], v, cts, rs)
+    for pf, c, r in zip(proofs, cts, rs):
+        ref = po.partial_decryption_with_zkp_r(tsk, c, r)
+        assert (pf.Decryption, pf.E, pf.Z) == (ref.Decryption, ref.E, ref.Z)
+    assert pr.verify_proof_batch(tk, v, vks, proofs) == [True] * len(proofs)
+    # tampering (thresholdkey_test.go:283-292,385-393): wrong E, wrong ID, wrong ciphertext
+    proofs[0].E += 1
+    proofs[1].ID = 4
+    proofs[2].C = cts[3]
+    bad = pr.verify_proof_batch(tk, v, vks, proofs)
+    assert bad[:3] == [False, False, False] and all(bad[3:])
+    for pf, ok in zip(proofs[:4], bad[:4]):
+        ref = po.PartialDecryptionZKP(ID=pf.ID, Decryption=pf.Decryption, Key=po.threshold_public_key_of(tsk), E=pf.E,
+                                      Z=pf.Z, C=pf.C)
+        assert po.verify_proof(ref) == ok
+
+
+def test_ddleq_prove_verify(ctx):
+    """ddleq_test.go:9-72 at a 256-bit key with the draws supplied: completeness, soundness, transcript parity."""
+    import paillier_amd as pa
+    from paillier_amd import protocols as pr
+    sk_o, p, q = po.keygen_seeded(256, 3)
+    n = sk_o.N
+    pk = pa.PublicKey(ctx, n, n + 1)
+    sk = pa.SecretKey(ctx, pk, sk_o.Lambda)
+    rng = random.Random(21)
+    B = 24
+    ms = [rng.randrange(n) for _ in range(B)]
+    inner = [po.encrypt_with_r(sk_o, m, po.rand_unit(n, rng)).C for m in ms]
+    ct1 = [po.encrypt_with_r_at_level(sk_o, c, po.rand_unit(n, rng), po.ENC_LEVEL_TWO).C for c in inner]
+    a_s = [po.rand_unit(n, rng) for _ in range(B)]
+    b_s = [po.rand_unit(n, rng) for _ in range(B)]
+    ct2 = pr.nested_randomize_with_ab_batch(pk, ct1, a_s, b_s)
+    assert ct2 == [po.nested_randomize_with_ab(sk_o, po.Ciphertext(c, po.ENC_LEVEL_TWO), a, b).C
+                   for c, a, b in zip(ct1, a_s, b_s)]
+    xs = [po.rand_unit(n, rng) for _ in range(B)]
+    ys = [po.rand_unit(n, rng) for _ in range(B)]
+    proofs = pr.prove_ddleq_instances(sk, ct1, ct2, a_s, b_s, xs, ys)
+    bits = []
+    for i, pf in enumerate(proofs):
+        ref = po.prove_ddleq_instance_xy(sk_o, po.Ciphertext(ct1[i], po.ENC_LEVEL_TWO), po.Ciphertext(ct2[i], po.ENC_LEVEL_TWO),
+                                         a_s[i], b_s[i], xs[i], ys[i])
+        assert (pf.X, pf.Y, pf.Alpha, pf.E, pf.F) == (ref.X, ref.Y, ref.Alpha, ref.E, ref.F)
+        bits.append(pf.E != pf.X or pf.F != pf.Y)
+    assert any(bits) and not all(bits), "both challenge bits must occur in the sample"
+    assert pr.verify_ddleq_instances(pk, ct1, ct2, proofs) == [True] * B
+    # soundness check of ddleq_test.go:40-72: a different ct2 must not verify
+    wrong = ct2[1:] + ct2[:1]
+    res = pr.verify_ddleq_instances(pk, ct1, wrong, proofs)
+    want = [po.verify_ddleq_proof_instance(sk_o, po.Ciphertext(c1, po.ENC_LEVEL_TWO), po.Ciphertext(c2, po.ENC_LEVEL_TWO),
+                                           po.DDLEQProofInstance(pf.X, pf.Y, pf.Alpha, pf.E, pf.F))
+            for c1, c2, pf in zip(ct1, wrong, proofs)]
+    assert res == want and not all(res)
+    # a false statement makes the prover panic (ddleq.go:68)
+    with pytest.raises(pr.DDLEQPanic):
+        pr.prove_ddleq_instances(sk, ct1[:2], wrong[:2], a_s[:2], b_s[:2], xs[:2], ys[:2])
+
+
+def test_random_oracle_quirks():
+    from paillier_amd import protocols as pr
+    assert pr.random_oracle_digest(1, 2, 3) == pr.random_oracle_digest(999, 2, 3)        # arg 0 is skipped
+    assert pr.random_oracle_digest(1, 0, 3) == pr.random_oracle_digest(1, 3)             # zero contributes no bytes
+    assert pr.random_oracle_digest(5, 2, 3) == po.random_oracle_digest(5, 2, 3)
+    assert pr.random_oracle_bit(7, 2 ** 300 + 5, 11) == po.random_oracle_bit(7, 2 ** 300 + 5, 11)
