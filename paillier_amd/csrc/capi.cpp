@@ -200,8 +200,10 @@ struct Prog {
   std::vector<uint32_t> w;
   double montmuls = 0, sqrs = 0;
   bool asm_ok = true;  // only opcodes the assembly kernel implements
+  bool has_mulv = false;
   void op(uint32_t o, uint32_t arg = 0, uint32_t aux = 0) {
-    if (o == VM_MULV || o == VM_SETOFF) asm_ok = false;
+    if (o == VM_SETOFF) asm_ok = false;
+    if (o == VM_MULV) has_mulv = true;
     w.push_back(o | (aux << 8));
     w.push_back(arg);
     if (o == VM_SQR || o == VM_MUL || o == VM_MULC || o == VM_MULV) montmuls += 1;
@@ -324,7 +326,7 @@ void run_vm(pgpu_ctx* ctx, size_t nb, const SegSpec& s0, const SegSpec* s1, bool
   a.seg0_blocks = blocks_per_seg;
   const uint32_t blocks = blocks_per_seg * (s1 ? 2 : 1);
   const bool use_asm = ctx->use_asm && vm_asm_available(mc->WL, mc->K) && s0.prog->asm_ok && (!s1 || s1->prog->asm_ok) &&
-                       (uint64_t)nb * mc->WT * 4 < (1ull << 32);
+                       (uint64_t)nb * mc->WT * 4 * ((s0.prog->has_mulv || (s1 && s1->prog->has_mulv)) ? 17 : 1) < (1ull << 32);
   pgpu_ctx::Ev* ev = nullptr;
   if (profile) {
     ev = &ctx->next_ev();

@@ -160,3 +160,23 @@ def test_sub_1024(ctx, key1024):
     got = pk.SubBatch(c1, c2)
     assert got == [po.sub(sk_o, po.Ciphertext(a), po.Ciphertext(b)).C for a, b in zip(c1, c2)]
     assert sk.DecryptBatch(got) == [(a - b) % sk_o.N for a, b in zip(ms1, ms2)]  # operations_test.go:52-70
+
+
+@pytest.mark.parametrize("bits", [1024, 2048, 3072, 4096, 6144])
+def test_asm_kernel_per_number_exponent(ctx, bits):
+    """VM_MULV (per-number 4-bit windows, table gather) in the assembly kernel vs the hipcc kernel vs Python."""
+    import paillier_amd as pa
+    rng = random.Random(bits + 9)
+    n = rand_odd(bits, rng)
+    mod = pa.Modulus(ctx, n)
+    bases = [rng.randrange(n) for _ in range(200)]
+    exps = [rng.getrandbits(rng.choice([3, 28, 29, 57, 200])) for _ in bases]
+    try:
+        ctx.set_flag("asm", 1)
+        got_asm = mod.exp_batch(bases, exps)
+        assert ctx.last_vm_asm() >= 1, "assembly kernel was not used"
+        ctx.set_flag("asm", 0)
+        got_cc = mod.exp_batch(bases, exps)
+    finally:
+        ctx.set_flag("asm", 1)
+    assert got_asm == got_cc == [po.gmp_exp(b, e, n) for b, e in zip(bases, exps)]

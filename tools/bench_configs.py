@@ -1,0 +1,113 @@
+#!/usr/bin/env python3
+"""Throughput of the other BASELINE.json configs on ONE GPU (bench.py stays the headline Decrypt-2048 line).
+Prints one JSON line per config.  Every config ends with a parity check against the oracle on a sample."""
+import json, os, sys, time, random
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import numpy as np
+import torch
+import paillier_amd as pa
+from paillier_amd.api import MEM_DEVICE, ints_to_be, be_to_ints
+from paillier_amd import protocols as pr
+from oracle import paillier_oracle as po
+
+K = json.load(open(os.path.join(ROOT, "tests/golden/keys.json")))
+dev = torch.device("cuda", 0)
+ctx = pa.Context(0, torch.cuda.current_stream().cuda_stream)
+which = sys.argv[1:] or ["encrypt2048", "decrypt3072", "threshold2048", "ddleq2048"]
+
+
+def rand_below(n, count, nbytes, rng):
+    raw = rng.integers(0, 256, size=(count, nbytes), dtype=np.uint8)
+    top = n >> (8 * (nbytes - 1))
+    raw[:, 0] %= np.uint8(top) if top < 256 else np.uint8(255)
+    return raw
+
+
+def timed(fn, reps=3):
+    fn(); torch.cuda.synchronize()
+    t = time.perf_counter()
+    for _ in range(reps):
+        fn()
+    torch.cuda.synchronize()
+    return (time.perf_counter() - t) / reps
+
+
+def key(bits):
+    k = K["paillier"][str(bits)]
+    p, q = int(k["p"], 16), int(k["q"], 16)
+    return p * q, (p - 1) * (q - 1)
+
+
+if "encrypt2048" in which:   # BASELINE config 2
+    n, lam = key(2048)
+    pk = pa.PublicKey(ctx, n); B = 65536; rng = np.random.default_rng(2)
+    m = torch.from_numpy(rand_below(n, B, 256, rng)).to(dev); r_h = rand_below(n, B, 256, rng); r_h[:, -1] |= 1
+    r = torch.from_numpy(r_h).to(dev); c = torch.zeros((B, 512), dtype=torch.uint8, device=dev)
+    dt = timed(lambda: pk.encrypt_with_r_raw(B, m.data_ptr(), 256, r.data_ptr(), 256, c.data_ptr(), 512, MEM_DEVICE))
+    prof = ctx.last_profile()
+    mi, ri, ci = be_to_ints(m[:3].cpu().numpy()), be_to_ints(r[:3].cpu().numpy()), be_to_ints(c[:3].cpu().numpy())
+    sk_o = po.SecretKey(N=n, G=n + 1, Lambda=lam)
+    assert ci == [po.encrypt_with_r(sk_o, a, b).C for a, b in zip(mi, ri)]
+    print(json.dumps({"config": "Batch 65536 Encrypt, 2048-bit n (r^n * g^m mod n^2)", "value": B / dt, "unit": "encryptions/s",
+                      "ms_per_batch": dt * 1e3, "vm_ms": prof["vm_ms"], "executed_Tmad_per_s": prof["vm_mads"] / prof["vm_ms"] / 1e9,
+                      "parity": "3 lanes vs oracle"}), flush=True)
+
+if "decrypt3072" in which:   # BASELINE config 3
+    n, lam = key(3072)
+    pk = pa.PublicKey(ctx, n); sk = pa.SecretKey(ctx, pk, lam); B = 65536; rng = np.random.default_rng(3)
+    m_h = rand_below(n, B, 384, rng); r_h = rand_below(n, B, 384, rng); r_h[:, -1] |= 1
+    m = torch.from_numpy(m_h).to(dev); r = torch.from_numpy(r_h).to(dev)
+    c = torch.zeros((B, 768), dtype=torch.uint8, device=dev); out = torch.zeros((B, 384), dtype=torch.uint8, device=dev)
+    pk.encrypt_with_r_raw(B, m.data_ptr(), 384, r.data_ptr(), 384, c.data_ptr(), 768, MEM_DEVICE)
+    enc = ctx.last_profile()
+    dt = timed(lambda: sk.decrypt_raw(B, c.data_ptr(), 768, out.data_ptr(), 384, MEM_DEVICE))
+    prof = ctx.last_profile()
+    assert torch.equal(out, m), "round trip failed"
+    sk_o = po.SecretKey(N=n, G=n + 1, Lambda=lam)
+    assert be_to_ints(out[:2].cpu().numpy()) == [po.decrypt(sk_o, po.Ciphertext(x)) for x in be_to_ints(c[:2].cpu().numpy())]
+    print(json.dumps({"config": "Batch 65536 Decrypt, 3072-bit n (CRT over p^2,q^2)", "value": B / dt, "unit": "decryptions/s",
+                      "ms_per_batch": dt * 1e3, "vm_ms": prof["vm_ms"], "executed_Tmad_per_s": prof["vm_mads"] / prof["vm_ms"] / 1e9,
+                      "encrypt3072_per_s": B / (enc["vm_ms"] * 1e-3), "parity": "65536-lane round trip + 2 lanes vs oracle"}), flush=True)
+
+if "threshold2048" in which:  # BASELINE config 4, single-GPU part: 3 x PartialDecrypt + Combine for 16384 ciphertexts
+    k = K["threshold"]["2048"]; n = int(k["n"], 16); shares = [int(s, 16) for s in k["shares"]]
+    tk = pa.ThresholdPublicKey(ctx, n, total=5, threshold=3); B = 16384; rng = np.random.default_rng(4)
+    m_h = rand_below(n, B, 256, rng); r_h = rand_below(n, B, 256, rng); r_h[:, -1] |= 1
+    m = torch.from_numpy(m_h).to(dev); r = torch.from_numpy(r_h).to(dev)
+    c = torch.zeros((B, 512), dtype=torch.uint8, device=dev); out = torch.zeros((B, 256), dtype=torch.uint8, device=dev)
+    tk.encrypt_with_r_raw(B, m.data_ptr(), 256, r.data_ptr(), 256, c.data_ptr(), 512, MEM_DEVICE)
+    ids = [1, 3, 5]
+    parts = [torch.zeros((B, 512), dtype=torch.uint8, device=dev) for _ in ids]
+    def run():
+        for i, pbuf in zip(ids, parts):
+            tk.partial_decrypt_raw(shares[i - 1], B, c.data_ptr(), 512, pbuf.data_ptr(), 512, MEM_DEVICE)
+        tk.combine_raw(ids, B, [pbuf.data_ptr() for pbuf in parts], 512, out.data_ptr(), 256, MEM_DEVICE)
+    dt = timed(run, reps=2)
+    assert torch.equal(out, m), "threshold round trip failed"
+    t0 = time.perf_counter(); tk.partial_decrypt_raw(shares[0], B, c.data_ptr(), 512, parts[0].data_ptr(), 512, MEM_DEVICE); torch.cuda.synchronize()
+    t_pd = time.perf_counter() - t0
+    t0 = time.perf_counter(); tk.combine_raw(ids, B, [pbuf.data_ptr() for pbuf in parts], 512, out.data_ptr(), 256, MEM_DEVICE); torch.cuda.synchronize()
+    t_cb = time.perf_counter() - t0
+    print(json.dumps({"config": "Threshold (t=3,l=5) 3 x PartialDecrypt + Combine, 2048-bit, 16384 ciphertexts, servers {1,3,5}",
+                      "value": B / dt, "unit": "threshold decryptions/s", "ms_per_batch": dt * 1e3,
+                      "partial_decrypt_per_s": B / t_pd, "combine_per_s": B / t_cb, "parity": "16384-lane round trip"}), flush=True)
+
+if "ddleq2048" in which:  # BASELINE config 5 (per-instance throughput, secpar = 1)
+    n, lam = key(2048)
+    pk = pa.PublicKey(ctx, n); sk = pa.SecretKey(ctx, pk, lam); B = 512; rng = random.Random(5)
+    sk_o = po.SecretKey(N=n, G=n + 1, Lambda=lam)
+    ms = [rng.randrange(n) for _ in range(B)]
+    inner = pk.EncryptWithRBatch(ms, [rng.randrange(1, n) | 1 for _ in ms])
+    ct1 = pk.EncryptWithRBatch(inner, [rng.randrange(1, n) | 1 for _ in ms], level=pa.ENC_LEVEL_TWO)
+    a_s = [rng.randrange(1, n) | 1 for _ in ms]; b_s = [rng.randrange(1, n) | 1 for _ in ms]
+    ct2 = pr.nested_randomize_with_ab_batch(pk, ct1, a_s, b_s)
+    xs = [rng.randrange(1, n) | 1 for _ in ms]; ys = [rng.randrange(1, n) | 1 for _ in ms]
+    t0 = time.perf_counter(); proofs = pr.prove_ddleq_instances(sk, ct1, ct2, a_s, b_s, xs, ys); t_p = time.perf_counter() - t0
+    t0 = time.perf_counter(); ok = pr.verify_ddleq_instances(pk, ct1, ct2, proofs); t_v = time.perf_counter() - t0
+    assert all(ok)
+    ref = po.prove_ddleq_instance_xy(sk_o, po.Ciphertext(ct1[0], 1), po.Ciphertext(ct2[0], 1), a_s[0], b_s[0], xs[0], ys[0])
+    assert (proofs[0].Alpha, proofs[0].E, proofs[0].F) == (ref.Alpha, ref.E, ref.F)
+    print(json.dumps({"config": f"DDLEQ 2048-bit, {B} instances (secpar=1 each), int-list API incl. host packing",
+                      "prove_instances_per_s": B / t_p, "verify_instances_per_s": B / t_v,
+                      "parity": "all verify; instance 0 vs oracle"}), flush=True)
