@@ -322,10 +322,19 @@ void run_vm(pgpu_ctx* ctx, size_t nb, const SegSpec& s0, const SegSpec* s1, bool
     sqrs += ss[i]->prog->sqrs;
   }
   if (launch_nb == 0) launch_nb = nb;  // numbers actually launched (<= nb, the row stride of the arrays)
-  const uint32_t blocks_per_seg = (uint32_t)(launch_nb * mc->K / VM_BLOCK);
+  // Occupancy-aware shape: the same WT limbs can be sliced over more lanes (WL/2 x 2K).  One lane per slice keeps
+  // the multiply count but fills the chip when the batch is small; K == 1 additionally has the cheaper squaring rows,
+  // so the smallest K that still gives every SIMD two waves (1024 SIMDs x 2 x 64 lanes) wins.
+  int WL = mc->WL, K = mc->K;
+  {
+    const size_t lanes_wanted = 1024 * 2 * 64;
+    const size_t segs = s1 ? 2 : 1;
+    while (launch_nb * K * segs < lanes_wanted && K < 4 && WL % 2 == 0 && WL / 2 >= 37) { WL /= 2; K *= 2; }
+  }
+  const uint32_t blocks_per_seg = (uint32_t)(launch_nb * K / VM_BLOCK);
   a.seg0_blocks = blocks_per_seg;
   const uint32_t blocks = blocks_per_seg * (s1 ? 2 : 1);
-  const bool use_asm = ctx->use_asm && vm_asm_available(mc->WL, mc->K) && s0.prog->asm_ok && (!s1 || s1->prog->asm_ok) &&
+  const bool use_asm = ctx->use_asm && vm_asm_available(WL, K) && s0.prog->asm_ok && (!s1 || s1->prog->asm_ok) &&
                        (uint64_t)nb * mc->WT * 4 * ((s0.prog->has_mulv || (s1 && s1->prog->has_mulv)) ? 17 : 1) < (1ull << 32);
   pgpu_ctx::Ev* ev = nullptr;
   if (profile) {
@@ -333,12 +342,11 @@ void run_vm(pgpu_ctx* ctx, size_t nb, const SegSpec& s0, const SegSpec* s1, bool
     // v_mad_u64_u32 lane-ops executed: 2 WT^2 per product; the assembly kernel's K == 1 squaring rows use the
     // symmetry of the square: WL^2 (reduction) + WL(WL-1)/2 + WL (product)
     const double full = 2.0 * mc->WT * mc->WT;
-    const double sq = (use_asm && mc->K == 1) ? (double)mc->WT * mc->WT + 0.5 * mc->WT * (mc->WT - 1) + mc->WT : full;
+    const double sq = (use_asm && K == 1) ? (double)mc->WT * mc->WT + 0.5 * mc->WT * (mc->WT - 1) + mc->WT : full;
     ev->mads = ((montmuls - sqrs) * full + sqrs * sq) * (double)launch_nb;
     HIPCHK(hipEventRecord(ev->a, ctx->stream));
   }
-  hipError_t e = use_asm ? launch_vm_asm(mc->WL, mc->K, a, blocks, ctx->stream)
-                         : launch_vm(mc->WL, mc->K, a, blocks, ctx->stream);
+  hipError_t e = use_asm ? launch_vm_asm(WL, K, a, blocks, ctx->stream) : launch_vm(WL, K, a, blocks, ctx->stream);
   if (use_asm) ctx->last_vm_asm++;
   if (e != hipSuccess) throw HipError{e, "launch_vm"};
   if (profile) HIPCHK(hipEventRecord(ev->b, ctx->stream));

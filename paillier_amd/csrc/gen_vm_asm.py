@@ -661,7 +661,7 @@ class Gen:
         return "\n".join(self.lines) + "\n"
 
 
-SHAPES = [(74, 1), (37, 1), (55, 1), (55, 2), (74, 2), (55, 4)]
+SHAPES = [(74, 1), (37, 1), (55, 1), (55, 2), (74, 2), (55, 4), (37, 2), (37, 4)]
 
 if __name__ == "__main__":
     out_dir = sys.argv[1] if len(sys.argv) > 1 else "."

@@ -6,7 +6,7 @@ import numpy as np
 import paillier_amd as pa
 from model28 import to_limbs, from_limbs, MASK
 END, LOAD, STORE, LOADC, SQR, MUL, MULC, MULV, ADD = 0, 1, 2, 3, 4, 5, 6, 7, 8
-shapes = {1024: (37, 1), 1536: (55, 1), 2048: (74, 1), 3072: (55, 2), 4096: (74, 2), 6144: (55, 4)}
+shapes = {1024: (37, 1), 1536: (55, 1), 2048: (74, 1), 3072: (55, 2), 4096: (74, 2), 6144: (55, 4)}  # WT = wl*k; small nb -> run_vm re-slices 74->37x2, 148->37x4
 ctx = pa.Context(0)
 bits_list = [int(x) for x in sys.argv[1:]] or [1024]
 for bits in bits_list:
