@@ -95,6 +95,13 @@ int pgpu_seckey_has_crt(const pgpu_seckey* sk);
 int pgpu_encrypt_with_r(const pgpu_pubkey* pk, int level, size_t batch, const uint8_t* m, size_t m_stride,
                         const uint8_t* r, size_t r_stride, uint8_t* c, size_t c_stride, int mem);
 
+/* PublicKey.AltEncryptWithRAtLevel (paillier.go:221-238): c[i] = G^m[i] * h_s^(r[i] mod K) mod n^(s+1), with
+ * h_1 = (N-H)^N mod N^2, h_2 = (N^2-H)^(N^2) mod N^3 (paillier.go:416-434).  h_s is shared by the batch, so the engine
+ * uses a fixed-base comb table (no squarings).  The reference overwrites the caller's r with r mod K; pass r_reduced
+ * (same stride as r, may be NULL) to receive it.  Requires H and K (a power of two) in the public key. */
+int pgpu_alt_encrypt_with_r(const pgpu_pubkey* pk, int level, size_t batch, const uint8_t* m, size_t m_stride,
+                            const uint8_t* r, size_t r_stride, uint8_t* c, size_t c_stride, uint8_t* r_reduced, int mem);
+
 /* SecretKey.Decrypt (paillier.go:292-303): m[i] = L_s(c[i]^lambda mod n^(s+1)) * lambda^-1 mod n^s.
  * status (optional, host int32[batch]) receives PGPU_LANE_* bits. */
 int pgpu_decrypt(const pgpu_seckey* sk, int level, size_t batch, const uint8_t* c, size_t c_stride, uint8_t* m,

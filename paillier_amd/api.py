@@ -57,6 +57,7 @@ SIGNATURES = {
     "pgpu_seckey_destroy": (None, [_vp]),
     "pgpu_seckey_has_crt": (_int, [_vp]),
     "pgpu_encrypt_with_r": (_int, [_vp, _int, _sz, _vp, _sz, _vp, _sz, _vp, _sz, _int]),
+    "pgpu_alt_encrypt_with_r": (_int, [_vp, _int, _sz, _vp, _sz, _vp, _sz, _vp, _sz, _vp, _int]),
     "pgpu_decrypt": (_int, [_vp, _int, _sz, _vp, _sz, _vp, _sz, _int, _int, _vp]),
     "pgpu_add": (_int, [_vp, _int, _sz, _vp, _sz, _vp, _sz, _vp, _sz, _int]),
     "pgpu_sub": (_int, [_vp, _int, _sz, _vp, _sz, _vp, _sz, _vp, _sz, _int]),
@@ -245,6 +246,17 @@ class PublicKey:
         self.encrypt_with_r_raw(len(ms), mb, pb, rb, pb, out, cb, MEM_HOST, level)
         return be_to_ints(out)
 
+    def AltEncryptWithRBatch(self, ms: Sequence[int], rs: Sequence[int], level: int = ENC_LEVEL_ONE):
+        """paillier.go:221-238 for each (m, r); returns (ciphertexts, r mod K) -- the reference overwrites r in place."""
+        pb, cb = self.plain_bytes(level), self.cipher_bytes(level)
+        rb_len = max(1, max((int(r).bit_length() + 7) // 8 for r in rs))
+        mb, rb = ints_to_be(ms, pb), ints_to_be(rs, rb_len)
+        out = np.zeros((len(ms), cb), dtype=np.uint8)
+        rred = np.zeros((len(ms), rb_len), dtype=np.uint8)
+        _check(self.ctx.lib.pgpu_alt_encrypt_with_r(self.h, level, len(ms), _ptr(mb), pb, _ptr(rb), rb_len, _ptr(out), cb,
+                                                    _ptr(rred), MEM_HOST))
+        return be_to_ints(out), be_to_ints(rred)
+
     def AddBatch(self, a: Sequence[int], b: Sequence[int], level: int = ENC_LEVEL_ONE) -> List[int]:
         """operations.go:11-29 with two operands, element-wise over the batch."""
         cb = self.cipher_bytes(level)
@@ -276,6 +288,17 @@ class PublicKey:
         _check(self.ctx.lib.pgpu_const_mult(self.h, level, len(cts), _ptr(cbuf), cb, _ptr(kb), kl, ks, _ptr(out), cb,
                                             MEM_HOST))
         return be_to_ints(out)
+
+    def NestedAddBatch(self, ct1s: Sequence[int], ct2s: Sequence[int]) -> List[int]:
+        """operations.go:121-127: level-two ciphertext ^ (level-one ciphertext value)."""
+        return self.ConstMultBatch(ct1s, list(ct2s), level=ENC_LEVEL_TWO)
+
+    def NestedSubBatch(self, ct1s: Sequence[int], ct2s: Sequence[int]) -> List[int]:
+        """operations.go:130-140: ConstMult(ct1, ModInverse(ct2.C, n^2)) at level two."""
+        m2 = getattr(self, "_mod_n2", None)
+        if m2 is None:
+            m2 = self._mod_n2 = Modulus(self.ctx, self.N * self.N)
+        return self.ConstMultBatch(ct1s, m2.inv_batch(list(ct2s)), level=ENC_LEVEL_TWO)
 
     def __del__(self):
         try:

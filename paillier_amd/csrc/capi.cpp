@@ -206,7 +206,7 @@ struct Prog {
     if (o == VM_MULV) has_mulv = true;
     w.push_back(o | (aux << 8));
     w.push_back(arg);
-    if (o == VM_SQR || o == VM_MUL || o == VM_MULC || o == VM_MULV) montmuls += 1;
+    if (o == VM_SQR || o == VM_MUL || o == VM_MULC || o == VM_MULV || o == VM_MULCV) montmuls += 1;
     if (o == VM_SQR) sqrs += 1;
   }
   void end() { op(VM_END); }
@@ -416,6 +416,7 @@ struct pgpu_pubkey {
   DevLimbs n2_limbs;              // n^2 as mn2.WT limbs
   int c_inv2R = -1;               // 2^-1 * R mod n in mn.consts        (binomial of the level-two g^m)
   int c_ninv2R_2 = -1;            // n * 2^-1 * R mod n^2 in mn2.consts (Damgard-Jurik recovery, paillier.go:326-331)
+  struct AltTab { bool built = false; int base = 0; int nwin = 0; size_t kbits = 0; } alt[2];  // fixed-base comb tables of h_s
   std::vector<std::pair<int, int>> combine_consts;  // (total servers l, index of (4 (l!)^2)^-1 * R mod n in mn.consts)
 };
 
@@ -1189,6 +1190,98 @@ int pgpu_decrypt(const pgpu_seckey* sk, int level, size_t batch, const uint8_t* 
   });
 }
 
+}  // extern "C"
+
+namespace {
+
+// post <- G^m mod n^(s+1) for G = n + 1 (closed form; paillier.go:213 with the generator the reference always uses):
+//   s = 1: 1 + (m mod n) n                       s = 2: 1 + m n + C(m,2) n^2 (mod n^3), m taken mod n^2
+// `post` has cipher_mod(level).WT limbs per number.
+void build_gm(pgpu_ctx* ctx, const pgpu_pubkey* pk, int level, const uint8_t* m, size_t m_stride, size_t batch, int mem,
+              size_t nb, uint32_t* post) {
+  const ModCtx &mn = pk->mn, &mn2 = pk->mn2;
+  const int W1 = mn.WT, W2 = mn2.WT;
+  if (!pk->g_is_n_plus_1) {
+    // a caller-supplied generator (PublicKey.G is an exported field): the literal Exp(G, m, n^(s+1)) of paillier.go:213,
+    // one exponent per ciphertext, uniform base
+    const ModCtx& mc = (level == PGPU_LEVEL_ONE) ? mn2 : *pk->mn3;
+    const size_t mlen = m_stride;
+    const int we = std::max<int>(1, (int)((mlen * 8 + LB - 1) / LB));
+    uint32_t* exps = ctx->ws_t<uint32_t>((size_t)we * nb);
+    unpack_operand(ctx, m, m_stride, mlen, batch, mem, exps, we, nb);
+    ModexpPlan pl = modexp_alloc(ctx, mc, nb, 16);
+    uint32_t* gl = ctx->upload_words((pk->G % mc.N).to_limbs(LB, mc.WT));
+    launch_fill_const(gl, pl.in(), mc.WT, nb, ctx->stream);
+    modexp_perlane_run(ctx, mc, pl, exps, we, false, false);
+    HIPCHK(hipMemcpyAsync(post, pl.out(), (size_t)mc.WT * nb * 4, hipMemcpyDeviceToDevice, ctx->stream));
+    return;
+  }
+  if (level == PGPU_LEVEL_ONE) {
+    const size_t mlen = std::min(m_stride, mn.nbytes);
+    uint32_t* ml = ctx->ws_t<uint32_t>((size_t)W1 * nb);
+    unpack_operand(ctx, m, m_stride, mlen, batch, mem, ml, W1, nb);
+    uint32_t* mred = ctx->ws_t<uint32_t>((size_t)W1 * nb);
+    reduce_mod(ctx, mn, ml, W1, mred, nb);   // the generator 1+n has order n: G^m = G^(m mod n)
+    launch_mul_const_add(mred, W1, pk->n_limbs.d, W1, nullptr, 0, 1, post, W2, nb, ctx->stream);
+    return;
+  }
+  const ModCtx& mn3 = *pk->mn3;
+  const int W3 = mn3.WT;
+  const size_t mlen = std::min(m_stride, mn2.nbytes);
+  uint32_t* ml = ctx->ws_t<uint32_t>((size_t)W2 * nb);
+  unpack_operand(ctx, m, m_stride, mlen, batch, mem, ml, W2, nb);
+  uint32_t* mred = ctx->ws_t<uint32_t>((size_t)W2 * nb);
+  reduce_mod(ctx, mn2, ml, W2, mred, nb);
+  // t = C(m,2) mod n = (m mod n) ((m-1) mod n) 2^-1 mod n
+  const size_t s1 = (size_t)W1 * nb;
+  uint32_t* mv = ctx->ws_t<uint32_t>(s1 * 4);   // slots: 0 m0, 1 (m0-1) mod n, 2 t, 3 ones
+  reduce_mod(ctx, mn, mred, W2, mv, nb);
+  launch_fill_const(mn.d_consts + (size_t)C_ONE * W1, mv + 3 * s1, W1, nb, ctx->stream);
+  launch_sub_mod(mv, mv + 3 * s1, mn.d_nmod, mv + s1, W1, nb, ctx->stream);
+  Prog pt;
+  pt.op(VM_LOAD, 0); pt.op(VM_MULC, C_R2); pt.op(VM_MUL, 1); pt.op(VM_MULC, (uint32_t)pk->c_inv2R); pt.op(VM_STORE, 2);
+  pt.end();
+  SegSpec st{&mn, &pt, mv, nullptr};
+  run_vm(ctx, nb, st, nullptr, false);
+  launch_canon(mv + 2 * s1, mn.d_nmod, W1, nb, ctx->stream);
+  uint32_t* tmpa = ctx->ws_t<uint32_t>((size_t)W3 * nb);
+  launch_mul_const_add(mred, W2, pk->n_limbs.d, W1, nullptr, 0, 1, tmpa, W3, nb, ctx->stream);            // 1 + m n
+  launch_mul_const_add(mv + 2 * s1, W1, pk->n2_limbs.d, W2, tmpa, W3, 0, post, W3, nb, ctx->stream);      // + t n^2
+  launch_canon(post, mn3.d_nmod, W3, nb, ctx->stream);                                                   // mod n^3
+}
+
+// Fixed-base comb table of h_s for AltEncrypt (paillier.go:416-434: h_1 = (N-H)^N mod N^2, h_2 = (N^2-H)^(N^2) mod N^3):
+// entries h^(d 16^i) (Montgomery form), i < ceil(log2(K)/4), d < 16, appended to the ciphertext modulus' constants.
+void ensure_alt_table(pgpu_pubkey* pk, int level) {
+  pgpu_pubkey::AltTab& t = pk->alt[level];
+  if (t.built) return;
+  if (pk->H.is_zero() || pk->Kk.is_zero()) api_throw(PGPU_ERR_INVALID, "alternative encryption needs H and K in the public key");
+  const size_t kbits = pk->Kk.bit_length() - 1;
+  if (!(hostbig::shl(BigU(1), kbits) == pk->Kk)) api_throw(PGPU_ERR_UNSUPPORTED, "K must be a power of two (KeyGen: 2^(secparam/2))");
+  ModCtx& mc = (level == PGPU_LEVEL_ONE) ? pk->mn2 : *pk->mn3;
+  const BigU ns = (level == PGPU_LEVEL_ONE) ? pk->N : pk->mn2.N;
+  if (hostbig::cmp(ns, pk->H) <= 0) api_throw(PGPU_ERR_INVALID, "H must be smaller than n^s");
+  BigU base = hostbig::powmod(ns - pk->H, ns, mc.N);
+  t.kbits = kbits;
+  t.nwin = (int)((kbits + 3) / 4);
+  t.base = (int)mc.consts.size();
+  const BigU rmod = mc.R % mc.N;
+  for (int i = 0; i < t.nwin; ++i) {
+    BigU cur(1);
+    for (int d = 0; d < 16; ++d) {
+      mc.consts.push_back(hostbig::mulmod(cur, rmod, mc.N));   // Montgomery form of base^d
+      cur = hostbig::mulmod(cur, base, mc.N);
+    }
+    base = cur;  // base^16
+  }
+  mc.upload();
+  t.built = true;
+}
+
+}  // namespace
+
+extern "C" {
+
 int pgpu_encrypt_with_r(const pgpu_pubkey* pk, int level, size_t batch, const uint8_t* m, size_t m_stride,
                         const uint8_t* r, size_t r_stride, uint8_t* c, size_t c_stride, int mem) {
   if (!pk) return fail(PGPU_ERR_INVALID, "null key");
@@ -1196,56 +1289,64 @@ int pgpu_encrypt_with_r(const pgpu_pubkey* pk, int level, size_t batch, const ui
   return guarded([&] {
     check_batch_args(m, c, batch);
     if (!r) api_throw(PGPU_ERR_INVALID, "null buffer");
-    if (!pk->g_is_n_plus_1) api_throw(PGPU_ERR_UNSUPPORTED, "G != N+1 is not built yet");
+    if (level != PGPU_LEVEL_ONE && level != PGPU_LEVEL_TWO) api_throw(PGPU_ERR_INVALID, "bad encryption level");
+    const ModCtx& mc = cipher_mod(pk, level);
     ctx->bind();
     ctx->reset_ws();
     const size_t nb = round_up(batch, VM_BLOCK);
-    if (level == PGPU_LEVEL_TWO) {
-      // c = (1+n)^m * r^(n^2) mod n^3,  (1+n)^m = 1 + m n + C(m,2) n^2 (mod n^3), m taken mod n^2
-      const ModCtx &mn = pk->mn, &mn2 = pk->mn2, &mn3 = cipher_mod(pk, level);
-      const int W1 = mn.WT, W2 = mn2.WT, W3 = mn3.WT;
-      const size_t mlen = std::min(m_stride, mn2.nbytes), rlen = std::min(r_stride, mn3.nbytes);
-      uint32_t* ml = ctx->ws_t<uint32_t>((size_t)W2 * nb);
-      unpack_operand(ctx, m, m_stride, mlen, batch, mem, ml, W2, nb);
-      uint32_t* mred = ctx->ws_t<uint32_t>((size_t)W2 * nb);
-      reduce_mod(ctx, mn2, ml, W2, mred, nb);
-      // t = C(m,2) mod n = (m mod n) ((m-1) mod n) 2^-1 mod n
-      const size_t s1 = (size_t)W1 * nb;
-      uint32_t* mv = ctx->ws_t<uint32_t>(s1 * 4);   // slots: 0 m0, 1 (m0-1) mod n, 2 t, 3 ones
-      reduce_mod(ctx, mn, mred, W2, mv, nb);
-      launch_fill_const(mn.d_consts + (size_t)C_ONE * W1, mv + 3 * s1, W1, nb, ctx->stream);
-      launch_sub_mod(mv, mv + 3 * s1, mn.d_nmod, mv + s1, W1, nb, ctx->stream);
-      Prog pt;
-      pt.op(VM_LOAD, 0); pt.op(VM_MULC, C_R2); pt.op(VM_MUL, 1); pt.op(VM_MULC, (uint32_t)pk->c_inv2R); pt.op(VM_STORE, 2);
-      pt.end();
-      SegSpec st{&mn, &pt, mv, nullptr};
-      run_vm(ctx, nb, st, nullptr, false);
-      launch_canon(mv + 2 * s1, mn.d_nmod, W1, nb, ctx->stream);
-      ModexpPlan pl = modexp_alloc(ctx, mn3, nb, 32);
-      uint32_t* tmpa = ctx->ws_t<uint32_t>((size_t)W3 * nb);
-      launch_mul_const_add(mred, W2, pk->n_limbs.d, W1, nullptr, 0, 1, tmpa, W3, nb, ctx->stream);            // 1 + m n
-      launch_mul_const_add(mv + 2 * s1, W1, pk->n2_limbs.d, W2, tmpa, W3, 0, pl.post(), W3, nb, ctx->stream);  // + t n^2
-      launch_canon(pl.post(), mn3.d_nmod, W3, nb, ctx->stream);                                              // mod n^3
-      unpack_operand(ctx, r, r_stride, rlen, batch, mem, pl.in(), W3, nb);
-      modexp_shared_run(ctx, mn3, pl, mn2.N, false, true, true);   // r^(n^2) * g^m mod n^3
-      pack_result(ctx, pl.out(), W3, nb, batch, c, c_stride, mn3.nbytes, mem);
-      HIPCHK(hipStreamSynchronize(ctx->stream));
-      return;
+    ModexpPlan pl = modexp_alloc(ctx, mc, nb, 32);
+    build_gm(ctx, pk, level, m, m_stride, batch, mem, nb, pl.post());
+    unpack_operand(ctx, r, r_stride, std::min(r_stride, mc.nbytes), batch, mem, pl.in(), mc.WT, nb);
+    const BigU& ns = (level == PGPU_LEVEL_ONE) ? pk->N : pk->mn2.N;
+    modexp_shared_run(ctx, mc, pl, ns, false, true, true);  // r^(n^s) * g^m mod n^(s+1)  (public exponent: zero windows skipped)
+    pack_result(ctx, pl.out(), mc.WT, nb, batch, c, c_stride, mc.nbytes, mem);
+    HIPCHK(hipStreamSynchronize(ctx->stream));
+  });
+}
+
+int pgpu_alt_encrypt_with_r(const pgpu_pubkey* pk, int level, size_t batch, const uint8_t* m, size_t m_stride,
+                            const uint8_t* r, size_t r_stride, uint8_t* c, size_t c_stride, uint8_t* r_reduced, int mem) {
+  if (!pk) return fail(PGPU_ERR_INVALID, "null key");
+  pgpu_ctx* ctx = pk->ctx;
+  return guarded([&] {
+    check_batch_args(m, c, batch);
+    if (!r) api_throw(PGPU_ERR_INVALID, "null buffer");
+    if (level != PGPU_LEVEL_ONE && level != PGPU_LEVEL_TWO) api_throw(PGPU_ERR_INVALID, "bad encryption level");
+    const ModCtx& mc = cipher_mod(pk, level);
+    ctx->bind();
+    ensure_alt_table(const_cast<pgpu_pubkey*>(pk), level);
+    const pgpu_pubkey::AltTab& t = pk->alt[level];
+    ctx->reset_ws();
+    const size_t nb = round_up(batch, VM_BLOCK);
+    const size_t sw = (size_t)mc.WT * nb;
+    uint32_t* memv = ctx->ws_t<uint32_t>(sw * 2);   // slots: 0 g^m (post), 1 out
+    build_gm(ctx, pk, level, m, m_stride, batch, mem, nb, memv);
+    // r mod K: K = 2^kbits, so the low kbits of r (paillier.go:228, which also overwrites the caller's r)
+    const int we = (int)((t.kbits + LB - 1) / LB);
+    const size_t rbytes = std::min(r_stride, (t.kbits + 7) / 8);
+    uint32_t* exps = ctx->ws_t<uint32_t>((size_t)std::max(we, 1) * nb);
+    {
+      // unpack only the low ceil(kbits/8) bytes of each r, then clear the bits above kbits
+      const uint8_t* d = r;
+      if (mem == PGPU_MEM_HOST) {
+        uint8_t* stg = (uint8_t*)ctx->ws(r_stride * batch);
+        HIPCHK(hipMemcpyAsync(stg, r, r_stride * batch, hipMemcpyHostToDevice, ctx->stream));
+        d = stg;
+      }
+      launch_unpack_be(d + (r_stride - rbytes), r_stride, rbytes, batch, exps, we, nb, ctx->stream);
+      launch_mask_bits(exps, we, nb, t.kbits, ctx->stream);
     }
-    if (level != PGPU_LEVEL_ONE) api_throw(PGPU_ERR_INVALID, "bad encryption level");
-    const ModCtx &mn = pk->mn, &mn2 = pk->mn2;
-    const size_t mlen = std::min(m_stride, mn.nbytes), rlen = std::min(r_stride, mn2.nbytes);
-    // m mod n (the generator 1+n has order n, so G^m = G^(m mod n))
-    uint32_t* ml = ctx->ws_t<uint32_t>((size_t)mn.WT * nb);
-    unpack_operand(ctx, m, m_stride, mlen, batch, mem, ml, mn.WT, nb);
-    uint32_t* mred = ctx->ws_t<uint32_t>((size_t)mn.WT * nb);
-    reduce_mod(ctx, mn, ml, mn.WT, mred, nb);
-    ModexpPlan pl = modexp_alloc(ctx, mn2, nb, 32);
-    // g^m = 1 + m n  (< n^2), written as the post-multiplicand
-    launch_mul_const_add(mred, mn.WT, pk->n_limbs.d, mn.WT, nullptr, 0, 1, pl.post(), mn2.WT, nb, ctx->stream);
-    unpack_operand(ctx, r, r_stride, rlen, batch, mem, pl.in(), mn2.WT, nb);
-    modexp_shared_run(ctx, mn2, pl, pk->N, false, true, true);  // r^n * g^m mod n^2 (n is public: zero windows skipped)
-    pack_result(ctx, pl.out(), mn2.WT, nb, batch, c, c_stride, mn2.nbytes, mem);
+    Prog p;
+    p.op(VM_LOADC, C_ONE_M);
+    for (int i = 0; i < t.nwin; ++i) p.op(VM_MULCV, (uint32_t)i, (uint32_t)t.base);
+    p.op(VM_MUL, 0);      // * g^m (plain) -> leaves Montgomery form
+    p.op(VM_STORE, 1);
+    p.end();
+    SegSpec sg{&mc, &p, memv, exps};
+    run_vm(ctx, nb, sg, nullptr, true);
+    launch_canon(memv + sw, mc.d_nmod, mc.WT, nb, ctx->stream);
+    pack_result(ctx, memv + sw, mc.WT, nb, batch, c, c_stride, mc.nbytes, mem);
+    if (r_reduced) pack_result(ctx, exps, we, nb, batch, r_reduced, r_stride, std::min(r_stride, (size_t)((t.kbits + 7) / 8)), mem);
     HIPCHK(hipStreamSynchronize(ctx->stream));
   });
 }

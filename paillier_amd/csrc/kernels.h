@@ -17,6 +17,7 @@ enum VmOp : uint32_t {
   VM_MULV = 7,    // x <- x*mem[aux + window(arg) of this number's exponent]*R^-1  (4-bit windows, per-number gather)
   VM_ADD = 8,     // x <- x + mem[arg]            (lazy; must be followed by a MULC before SQR)
   VM_SETOFF = 9,  // operand number offset for LOAD/STORE/MUL/ADD <- arg
+  VM_MULCV = 10,  // x <- x*consts[aux + 16*arg + window(arg) of this number's exponent]*R^-1  (fixed-base comb table)
 };
 
 struct VmSeg {
@@ -59,3 +60,4 @@ void launch_restride(const uint32_t* in, size_t nb_in, size_t count, const uint3
                      hipStream_t st);
 void launch_merge_halves(const uint32_t* lo, const uint32_t* hi, size_t half, uint32_t* out, size_t nb, int w, hipStream_t st);
 void launch_sub_one(const uint32_t* x, uint32_t* out, int w, size_t nb, hipStream_t st);
+void launch_mask_bits(uint32_t* x, int w, size_t nb, size_t bits, hipStream_t st);

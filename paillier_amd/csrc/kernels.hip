@@ -90,6 +90,13 @@ __global__ void __launch_bounds__(VM_BLOCK, (3 * WL + 24 <= 256) ? 2 : 1) vm_ker
       const uint32_t* p = sg.consts + (size_t)arg * WT + (size_t)k * WL;
 #pragma unroll
       for (int j = 0; j < WL; ++j) col[j * NPB] = p[j];
+    } else if (op == VM_MULCV) {
+      // fixed-base comb: table entry (window arg, digit of this number's exponent) of a table shared by the batch
+      const uint32_t elimb = sg.digits[(size_t)(arg / 7u) * nb + g];
+      const uint32_t digit = (elimb >> (4u * (arg % 7u))) & 15u;
+      const uint32_t* p = sg.consts + ((size_t)(w0 >> 8) + 16u * arg + digit) * WT + (size_t)k * WL;
+#pragma unroll
+      for (int j = 0; j < WL; ++j) col[j * NPB] = p[j];
     } else {
       size_t slot = arg;
       if (op == VM_MULV) {
@@ -295,6 +302,17 @@ __global__ void k_sub_one(const uint32_t* __restrict__ x, uint32_t* __restrict__
   }
 }
 
+// clear every bit >= `bits` of a w-limb number (r mod 2^bits)
+__global__ void k_mask_bits(uint32_t* __restrict__ x, int w, size_t nb, size_t bits) {
+  size_t g = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (g >= nb) return;
+  for (int l = 0; l < w; ++l) {
+    size_t lo = (size_t)l * LB;
+    uint32_t m = lo >= bits ? 0u : (bits - lo >= (size_t)LB ? LMASK : ((1u << (bits - lo)) - 1u));
+    x[(size_t)l * nb + g] &= m;
+  }
+}
+
 // flags[g] = (x == 0)
 __global__ void k_is_zero(const uint32_t* __restrict__ x, int w, size_t nb, int32_t* __restrict__ flags) {
   size_t g = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -429,4 +447,7 @@ void launch_merge_halves(const uint32_t* lo, const uint32_t* hi, size_t half, ui
 }
 void launch_sub_one(const uint32_t* x, uint32_t* out, int w, size_t nb, hipStream_t st) {
   hipLaunchKernelGGL(k_sub_one, HELPER_GRID(nb), 0, st, x, out, w, nb);
+}
+void launch_mask_bits(uint32_t* x, int w, size_t nb, size_t bits, hipStream_t st) {
+  hipLaunchKernelGGL(k_mask_bits, HELPER_GRID(nb), 0, st, x, w, nb, bits);
 }

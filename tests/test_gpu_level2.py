@@ -63,3 +63,46 @@ def test_nested_encrypt_decrypt(ctx):
     summed = pk.ConstMultBatch(outer[:3], other, level=ENC_LEVEL_TWO)
     assert summed == [po.nested_add(sk_o, po.Ciphertext(a, po.ENC_LEVEL_TWO), po.Ciphertext(b)).C
                       for a, b in zip(outer[:3], other)]
+
+
+@pytest.mark.parametrize("level", [0, 1])
+def test_alt_encrypt_fixed_base_comb(ctx, level):
+    """AltEncryptWithRAtLevel (paillier.go:221-238): c = G^m * h_s^(r mod K); the engine evaluates h_s^r with a
+    fixed-base comb table.  r is deliberately wider than K so that the reference's in-place r.Mod(r, K) matters."""
+    import paillier_amd as pa
+    sk_o, p, q = po.keygen_seeded(1024, 1)
+    n = sk_o.N
+    pk = pa.PublicKey(ctx, n, n + 1, H=sk_o.H, K=sk_o.K)
+    sk = pa.SecretKey(ctx, pk, sk_o.Lambda)
+    rng = random.Random(31 + level)
+    nsq = n if level == 0 else n * n
+    ms = [0, 1, nsq - 1] + [rng.randrange(nsq) for _ in range(17)]
+    rs = [rng.randrange(n) for _ in ms]
+    rs[0], rs[1], rs[2] = 0, sk_o.K, sk_o.K - 1
+    cts, rred = pk.AltEncryptWithRBatch(ms, rs, level=level)
+    want = [po.alt_encrypt_with_r_at_level(sk_o, m, r, level) for m, r in zip(ms, rs)]
+    assert cts == [w[0].C for w in want]
+    assert rred == [w[1] for w in want]
+    assert sk.DecryptBatch(cts, level=level) == ms
+
+
+def test_generator_other_than_n_plus_1_and_nested_sub(ctx):
+    """PublicKey.G is an exported field (paillier.go:48): with G != N+1 the engine must evaluate the literal
+    Exp(G, m, n^2).  Also NestedSub (operations.go:130-140)."""
+    import paillier_amd as pa
+    sk_o, p, q = po.keygen_seeded(1024, 1)
+    n = sk_o.N
+    rng = random.Random(8)
+    g = (1 + n) * pow(rng.randrange(2, n), n, n * n) % (n * n)          # another valid generator, not n + 1
+    pk_o = po.PublicKey(N=n, G=g)
+    pk = pa.PublicKey(ctx, n, g)
+    ms = [0, 1, n - 1] + [rng.randrange(n) for _ in range(7)]
+    rs = [po.rand_unit(n, rng) for _ in ms]
+    assert pk.EncryptWithRBatch(ms, rs) == [po.encrypt_with_r(pk_o, m, r).C for m, r in zip(ms, rs)]
+    # NestedSub on the standard generator
+    pk1 = pa.PublicKey(ctx, n, n + 1)
+    inner = [po.encrypt_with_r(sk_o, m, r).C for m, r in zip(ms[:4], rs[:4])]
+    outer = [po.encrypt_with_r_at_level(sk_o, c, r, po.ENC_LEVEL_TWO).C for c, r in zip(inner, rs[4:8])]
+    other = [po.encrypt_with_r(sk_o, 3, r).C for r in rs[:4]]
+    assert pk1.NestedSubBatch(outer, other) == [
+        po.nested_sub(sk_o, po.Ciphertext(a, po.ENC_LEVEL_TWO), po.Ciphertext(b)).C for a, b in zip(outer, other)]
