@@ -37,6 +37,7 @@ class Gen:
         self.WLp = (WL + 3) // 4 * 4
         self.depth = depth
         self.n_sgpr = (K == 1 and WL <= 74)
+        self.n_vreg = (K > 1 and WL <= 55)   # K > 1 with spare registers: the lane's modulus slice stays in VGPRs
         self.flush = (2 * self.WT + 1) > 255
         self.flush_every = 48
         self.sq_rows = (K == 1)  # dedicated squaring rows (symmetric products computed once)
@@ -54,7 +55,11 @@ class Gen:
         e += 2
         self.NBUF = 3
         self.nbuf = []
-        if not self.n_sgpr:
+        self.v_N = None
+        if self.n_vreg:
+            self.v_N = e
+            e += WL
+        elif not self.n_sgpr:
             for i in range(self.NBUF):
                 self.nbuf.append(e)
                 e += 4
@@ -186,6 +191,14 @@ class Gen:
             e("s_waitcnt lgkmcnt(0)")
             e("s_mov_b64 exec, s[96:97]")
             e("s_barrier")
+            if self.n_vreg:
+                for j in range(0, WL, 4):
+                    cnt = min(4, WL - j)
+                    if cnt == 4:
+                        pass
+                for j in range(WL):
+                    e(f"ds_read_b32 v{g.v_N + j}, v{g.v_nbase} offset:{4 * j}")
+                e("s_waitcnt lgkmcnt(0)")
         # x = 0
         for j in range(WL):
             e(f"v_mov_b32 {self.X(j)}, 0")
@@ -398,7 +411,7 @@ class Gen:
         e(f"v_add_u32 v{g.v_arow}, {rstride}, v{g.v_arow}")
         nchunks = (WL + 3) // 4
         issued = 0
-        if not self.n_sgpr:
+        if not self.n_sgpr and not self.n_vreg:
             for cidx in range(min(g.NBUF, nchunks)):
                 e(f"ds_read_b128 v[{g.nbuf[cidx % g.NBUF]}:{g.nbuf[cidx % g.NBUF] + 3}], v{g.v_nbase} offset:{16 * cidx}")
                 q.append(("n", cidx))
@@ -407,6 +420,8 @@ class Gen:
         def N(j):
             if self.n_sgpr:
                 return f"s{g.s_N + j}"
+            if self.n_vreg:
+                return f"v{g.v_N + j}"
             return f"v{g.nbuf[(j // 4) % g.NBUF] + (j % 4)}"
 
         ai = f"v{g.v_ai}"
@@ -421,7 +436,7 @@ class Gen:
         state = {"issued": issued}
 
         def B(j):
-            if not self.n_sgpr and j % 4 == 0:
+            if not self.n_sgpr and not self.n_vreg and j % 4 == 0:
                 wait_for(("n", j // 4))
             if j == 0:
                 self.mad(self.P(g.v_y0), m, N(0), self.T(0))
@@ -429,7 +444,7 @@ class Gen:
                 self.mad(self.T(0), m, N(1), self.T(1))
             else:
                 self.mad(self.T(j - 1), m, N(j), self.T(j))
-            if not self.n_sgpr and j % 4 == 3 and state["issued"] < nchunks:
+            if not self.n_sgpr and not self.n_vreg and j % 4 == 3 and state["issued"] < nchunks:
                 cidx = state["issued"]
                 # buffer (cidx % 4) was last used by chunk cidx-4 < j//4: free
                 e(f"ds_read_b128 v[{g.nbuf[cidx % g.NBUF]}:{g.nbuf[cidx % g.NBUF] + 3}], v{g.v_nbase} offset:{16 * cidx}")
@@ -595,6 +610,20 @@ class Gen:
         e = self.e
         WL, K = self.WL, self.K
         M = hex(MASK)
+        if K == 1:
+            # One lane owns the whole number: plain sequential carry, 3 instructions per limb (64-bit add, mask, 64-bit
+            # shift) and fully canonical limbs.  Dependent VALU issue costs the same as independent issue on gfx950
+            # (profiles/r01_valu_rates.txt, "1 dependent chain"), so the chain is not a latency problem.
+            c = self.P(g.v_c)
+            e(f"v_and_b32 {self.X(0)}, {M}, {self.Tlo(0)}")
+            e(f"v_lshrrev_b64 {c}, {LB}, {self.T(0)}")
+            for j in range(1, WL):
+                e(f"v_lshl_add_u64 {self.T(j)}, {self.T(j)}, 0, {c}")
+                e(f"v_and_b32 {self.X(j)}, {M}, {self.Tlo(j)}")
+                if j < WL - 1:
+                    e(f"v_lshrrev_b64 {c}, {LB}, {self.T(j)}")
+            return
+        # K > 1: carry-save style normalisation (no chain across the lanes of a number)
         # rolling registers: mid_prev (t1), hi_prev (t2), hi_prev2 (t3), s_prev (t4)
         mid_p, hi_p, hi_p2, s_p = f"v{g.v_t1}", f"v{g.v_t2}", f"v{g.v_t3}", f"v{g.v_t4}"
         if K > 1:
