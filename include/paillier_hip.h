@@ -139,6 +139,22 @@ int pgpu_combine_partial_decryptions(const pgpu_pubkey* pk, int total_servers, i
                                      size_t batch, const uint8_t* const* partials, size_t stride, uint8_t* m,
                                      size_t m_stride, int mem);
 
+/* ---- proofs (ddleq.go, random_oracle.go) ----------------------------------------------------------- */
+
+/* RandomOracleDigest-style transcripts on the device: digests[i] = SHA-256( Bytes(parts[0][i]) || ... ) where Bytes is
+ * gmp.Int.Bytes() (minimal big-endian, zero -> empty; random_oracle.go:20-32, thresholdkey.go:319-326).  The caller
+ * passes exactly the integers that are hashed (i.e. WITHOUT the skipped first argument of RandomOracleDigest).
+ * parts[k] is a fixed-stride big-endian buffer with strides[k] bytes per element; digests = 32 bytes per element. */
+int pgpu_random_oracle_digest(pgpu_ctx* ctx, int nparts, const uint8_t* const* parts, const size_t* strides, size_t batch,
+                              uint8_t* digests, int mem);
+
+/* PublicKey.verifyDDLEQProofInstance for a batch of (statement, instance) pairs (ddleq.go:129-153), entirely on the
+ * device: Fiat-Shamir bit = LSB(SHA-256(ct2||X||Y||Alpha)), check = bit ? ct2 : ct1,
+ * ok[i] = (check^(E^n mod n^2) * F^(n^2) mod n^3 == Alpha).  ct/alpha strides = byte length of n^3.  ok: host int32[batch]. */
+int pgpu_ddleq_verify(const pgpu_pubkey* pk, size_t batch, const uint8_t* ct1, const uint8_t* ct2, size_t ct_stride,
+                      const uint8_t* x, const uint8_t* y, size_t xy_stride, const uint8_t* alpha, size_t alpha_stride,
+                      const uint8_t* e, size_t e_stride, const uint8_t* f, size_t f_stride, int32_t* ok, int mem);
+
 /* ---- generic modular batch primitives (the gmp.Int seam: Exp / Mul+Mod) ------------------------ */
 
 /* Load an odd modulus (big-endian).  Precomputes -N^-1 mod 2^28, R mod N, R^2 mod N, R^3 mod N. */

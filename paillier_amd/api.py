@@ -63,6 +63,8 @@ SIGNATURES = {
     "pgpu_sub": (_int, [_vp, _int, _sz, _vp, _sz, _vp, _sz, _vp, _sz, _int]),
     "pgpu_partial_decrypt": (_int, [_vp, _int, _vp, _sz, _sz, _vp, _sz, _vp, _sz, _int]),
     "pgpu_combine_partial_decryptions": (_int, [_vp, _int, _int, _int, _vp, _sz, _vp, _sz, _vp, _sz, _int]),
+    "pgpu_random_oracle_digest": (_int, [_vp, _int, _vp, _vp, _sz, _vp, _int]),
+    "pgpu_ddleq_verify": (_int, [_vp, _sz, _vp, _vp, _sz, _vp, _vp, _sz, _vp, _sz, _vp, _sz, _vp, _sz, _vp, _int]),
     "pgpu_const_mult": (_int, [_vp, _int, _sz, _vp, _sz, _vp, _sz, _sz, _vp, _sz, _int]),
     "pgpu_modulus_create": (_int, [_vp, _vp, _sz, C.POINTER(_vp)]),
     "pgpu_modulus_destroy": (None, [_vp]),
@@ -140,6 +142,18 @@ class Context:
 
     def last_vm_asm(self) -> int:
         return self.lib.pgpu_ctx_last_vm_asm(self.h)
+
+    def random_oracle_digest_batch(self, columns: Sequence[Sequence[int]]) -> List[bytes]:
+        """SHA-256(Bytes(col0[i]) || Bytes(col1[i]) || ...) on the device, one digest per row i."""
+        n = len(columns)
+        batch = len(columns[0])
+        strides = [max(1, max((int(v).bit_length() + 7) // 8 for v in col)) for col in columns]
+        bufs = [ints_to_be(col, st) for col, st in zip(columns, strides)]
+        ptrs = (C.c_void_p * n)(*[b.ctypes.data for b in bufs])
+        sts = (C.c_size_t * n)(*strides)
+        out = np.zeros((batch, 32), dtype=np.uint8)
+        _check(self.lib.pgpu_random_oracle_digest(self.h, n, ptrs, sts, batch, _ptr(out), MEM_HOST))
+        return [out[i].tobytes() for i in range(batch)]
 
     def close(self):
         if self.h:
@@ -288,6 +302,17 @@ class PublicKey:
         _check(self.ctx.lib.pgpu_const_mult(self.h, level, len(cts), _ptr(cbuf), cb, _ptr(kb), kl, ks, _ptr(out), cb,
                                             MEM_HOST))
         return be_to_ints(out)
+
+    def VerifyDDLEQInstancesBatch(self, ct1s, ct2s, xs, ys, alphas, es, fs) -> List[bool]:
+        """ddleq.go:129-153 for a batch of (statement, instance) pairs, on the device (hash included)."""
+        cb3, pb1, pb2 = self.cipher_bytes(ENC_LEVEL_TWO), self.plain_bytes(ENC_LEVEL_ONE), self.plain_bytes(ENC_LEVEL_TWO)
+        B = len(ct1s)
+        bufs = [ints_to_be(ct1s, cb3), ints_to_be(ct2s, cb3), ints_to_be(xs, pb1), ints_to_be(ys, pb1), ints_to_be(alphas, cb3),
+                ints_to_be(es, pb2), ints_to_be(fs, cb3)]
+        ok = np.zeros(B, dtype=np.int32)
+        _check(self.ctx.lib.pgpu_ddleq_verify(self.h, B, _ptr(bufs[0]), _ptr(bufs[1]), cb3, _ptr(bufs[2]), _ptr(bufs[3]), pb1,
+                                              _ptr(bufs[4]), cb3, _ptr(bufs[5]), pb2, _ptr(bufs[6]), cb3, _ptr(ok), MEM_HOST))
+        return [bool(v) for v in ok]
 
     def NestedAddBatch(self, ct1s: Sequence[int], ct2s: Sequence[int]) -> List[int]:
         """operations.go:121-127: level-two ciphertext ^ (level-one ciphertext value)."""

@@ -1530,6 +1530,96 @@ int pgpu_combine_partial_decryptions(const pgpu_pubkey* pk, int total_servers, i
   });
 }
 
+int pgpu_random_oracle_digest(pgpu_ctx* ctx, int nparts, const uint8_t* const* parts, const size_t* strides, size_t batch,
+                              uint8_t* digests, int mem) {
+  if (!ctx || !parts || !strides || !digests) return fail(PGPU_ERR_INVALID, "null argument");
+  return guarded([&] {
+    if (nparts < 0 || nparts > 6) api_throw(PGPU_ERR_INVALID, "0..6 transcript parts");
+    if (batch == 0) api_throw(PGPU_ERR_INVALID, "empty batch");
+    ctx->bind();
+    ctx->reset_ws();
+    const size_t nb = round_up(batch, VM_BLOCK);
+    const uint32_t* dp[6];
+    int dw[6];
+    for (int i = 0; i < nparts; ++i) {
+      if (!parts[i]) api_throw(PGPU_ERR_INVALID, "null part");
+      dw[i] = std::max<int>(1, (int)((strides[i] * 8 + LB - 1) / LB));
+      uint32_t* l = ctx->ws_t<uint32_t>((size_t)dw[i] * nb);
+      unpack_operand(ctx, parts[i], strides[i], strides[i], batch, mem, l, dw[i], nb);
+      dp[i] = l;
+    }
+    uint32_t* dg = ctx->ws_t<uint32_t>(8 * nb);
+    launch_sha256_transcript(dp, dw, nparts, nb, batch, dg, nullptr, ctx->stream);
+    // digests: 32 bytes each, big-endian words
+    std::vector<uint32_t> h(8 * nb);
+    HIPCHK(hipMemcpyAsync(h.data(), dg, 8 * nb * 4, hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHK(hipStreamSynchronize(ctx->stream));
+    std::vector<uint8_t> outb(32 * batch);
+    for (size_t g = 0; g < batch; ++g)
+      for (int i = 0; i < 8; ++i) {
+        uint32_t v = h[(size_t)i * nb + g];
+        outb[g * 32 + 4 * i + 0] = (uint8_t)(v >> 24); outb[g * 32 + 4 * i + 1] = (uint8_t)(v >> 16);
+        outb[g * 32 + 4 * i + 2] = (uint8_t)(v >> 8);  outb[g * 32 + 4 * i + 3] = (uint8_t)v;
+      }
+    if (mem == PGPU_MEM_HOST) memcpy(digests, outb.data(), outb.size());
+    else HIPCHK(hipMemcpy(digests, outb.data(), outb.size(), hipMemcpyHostToDevice));
+  });
+}
+
+int pgpu_ddleq_verify(const pgpu_pubkey* pk, size_t batch, const uint8_t* ct1, const uint8_t* ct2, size_t ct_stride,
+                      const uint8_t* x, const uint8_t* y, size_t xy_stride, const uint8_t* alpha, size_t alpha_stride,
+                      const uint8_t* e, size_t e_stride, const uint8_t* f, size_t f_stride, int32_t* ok, int mem) {
+  if (!pk || !ct1 || !ct2 || !x || !y || !alpha || !e || !f || !ok) return fail(PGPU_ERR_INVALID, "null argument");
+  pgpu_ctx* ctx = pk->ctx;
+  return guarded([&] {
+    if (batch == 0) api_throw(PGPU_ERR_INVALID, "empty batch");
+    if (!pk->mn3) api_throw(PGPU_ERR_UNSUPPORTED, "n^3 is wider than the built kernels");
+    ctx->bind();
+    ctx->reset_ws();
+    const ModCtx &mn2 = pk->mn2, &mn3 = *pk->mn3;
+    const int W2 = mn2.WT, W3 = mn3.WT;
+    const size_t nb = round_up(batch, VM_BLOCK);
+    auto wof = [](size_t stride) { return std::max<int>(1, (int)((stride * 8 + LB - 1) / LB)); };
+    // transcript operands exactly as given (ddleq.go:136: RandomOracleBit(ct1, ct2, X, Y, Alpha); ct1 is skipped by
+    // random_oracle.go:24-26)
+    const int wc = std::max(wof(ct_stride), W3), wxy = wof(xy_stride), wa = std::max(wof(alpha_stride), W3);
+    uint32_t* c1 = ctx->ws_t<uint32_t>((size_t)wc * nb);
+    uint32_t* c2 = ctx->ws_t<uint32_t>((size_t)wc * nb);
+    uint32_t* xl = ctx->ws_t<uint32_t>((size_t)wxy * nb);
+    uint32_t* yl = ctx->ws_t<uint32_t>((size_t)wxy * nb);
+    uint32_t* al = ctx->ws_t<uint32_t>((size_t)wa * nb);
+    unpack_operand(ctx, ct1, ct_stride, ct_stride, batch, mem, c1, wc, nb);
+    unpack_operand(ctx, ct2, ct_stride, ct_stride, batch, mem, c2, wc, nb);
+    unpack_operand(ctx, x, xy_stride, xy_stride, batch, mem, xl, wxy, nb);
+    unpack_operand(ctx, y, xy_stride, xy_stride, batch, mem, yl, wxy, nb);
+    unpack_operand(ctx, alpha, alpha_stride, alpha_stride, batch, mem, al, wa, nb);
+    int32_t* chal = ctx->ws_t<int32_t>(nb);
+    HIPCHK(hipMemsetAsync(chal, 0, nb * 4, ctx->stream));
+    const uint32_t* parts[4] = {c2, xl, yl, al};
+    const int widths[4] = {wc, wxy, wxy, wa};
+    launch_sha256_transcript(parts, widths, 4, nb, batch, nullptr, chal, ctx->stream);
+    if (wc != W3) api_throw(PGPU_ERR_INVALID, "ciphertext stride must be the byte length of n^3");
+    // en = E^n mod n^2 ; fn2 = F^(n^2) mod n^3                                   (ddleq.go:143-144)
+    ModexpPlan pe = modexp_alloc(ctx, mn2, nb, 32);
+    unpack_operand(ctx, e, e_stride, std::min(e_stride, 2 * mn2.nbytes), batch, mem, pe.in(), 2 * W2, nb);
+    modexp_shared_run(ctx, mn2, pe, pk->N, true, false, true);
+    ModexpPlan pf = modexp_alloc(ctx, mn3, nb, 32);
+    if (f_stride * 8 > (size_t)LB * W3 + 7) api_throw(PGPU_ERR_INVALID, "F wider than n^3");
+    unpack_operand(ctx, f, f_stride, f_stride, batch, mem, pf.in(), W3, nb);
+    modexp_shared_run(ctx, mn3, pf, mn2.N, false, false, true);
+    // check = chalBit ? ct2 : ct1 ; check^en * fn2 mod n^3 == alpha              (ddleq.go:138-152)
+    ModexpPlan pc = modexp_alloc(ctx, mn3, nb, 16);
+    launch_select(chal, c2, c1, pc.in(), W3, nb, ctx->stream);
+    HIPCHK(hipMemcpyAsync(pc.post(), pf.out(), (size_t)W3 * nb * 4, hipMemcpyDeviceToDevice, ctx->stream));
+    modexp_perlane_run(ctx, mn3, pc, pe.out(), W2, false, true);
+    int32_t* d_ok = ctx->ws_t<int32_t>(nb);
+    if (wa != W3) api_throw(PGPU_ERR_INVALID, "alpha stride must be the byte length of n^3");
+    launch_equal(pc.out(), al, W3, nb, batch, d_ok, ctx->stream);
+    HIPCHK(hipMemcpyAsync(ok, d_ok, batch * 4, hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHK(hipStreamSynchronize(ctx->stream));
+  });
+}
+
 int pgpu_const_mult(const pgpu_pubkey* pk, int level, size_t batch, const uint8_t* c, size_t c_stride,
                     const uint8_t* k, size_t k_len, size_t k_stride, uint8_t* out, size_t out_stride, int mem) {
   if (!pk) return fail(PGPU_ERR_INVALID, "null key");

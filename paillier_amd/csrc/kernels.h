@@ -61,3 +61,8 @@ void launch_restride(const uint32_t* in, size_t nb_in, size_t count, const uint3
 void launch_merge_halves(const uint32_t* lo, const uint32_t* hi, size_t half, uint32_t* out, size_t nb, int w, hipStream_t st);
 void launch_sub_one(const uint32_t* x, uint32_t* out, int w, size_t nb, hipStream_t st);
 void launch_mask_bits(uint32_t* x, int w, size_t nb, size_t bits, hipStream_t st);
+// SHA-256 over the concatenated minimal big-endian bytes of up to 6 canonical limb-major numbers per lane
+void launch_sha256_transcript(const uint32_t* const* parts, const int* widths, int nparts, size_t nb, size_t count,
+                              uint32_t* digest_out, int32_t* bit_out, hipStream_t st);
+void launch_equal(const uint32_t* a, const uint32_t* b, int w, size_t nb, size_t count, int32_t* ok, hipStream_t st);
+void launch_select(const int32_t* flags, const uint32_t* a, const uint32_t* b, uint32_t* out, int w, size_t nb, hipStream_t st);

@@ -396,6 +396,129 @@ __global__ void k_merge_halves(const uint32_t* __restrict__ lo, const uint32_t* 
   for (int l = 0; l < w; ++l) out[(size_t)l * nb + g] = src[(size_t)l * nb];
 }
 
+// ------------------------------------------------------------------------------------------
+// SHA-256 of a transcript of big integers, one lane per transcript (random_oracle.go:20-32, thresholdkey.go:319-326):
+// the message is the concatenation of gmp.Int.Bytes() of each part -- minimal big-endian, NO length prefix, zero
+// contributes no bytes.  Parts are canonical 28-bit-limb numbers in limb-major arrays.
+// ------------------------------------------------------------------------------------------
+struct ShaPart { const uint32_t* p; int w; };
+struct ShaArgs { ShaPart part[6]; int nparts; };
+
+__device__ __forceinline__ uint32_t rotr32(uint32_t x, int n) { return (x >> n) | (x << (32 - n)); }
+
+__constant__ uint32_t kSha256K[64] = {
+    0x428a2f98, 0x71374491, 0xb5c0fbcf, 0xe9b5dba5, 0x3956c25b, 0x59f111f1, 0x923f82a4, 0xab1c5ed5, 0xd807aa98, 0x12835b01,
+    0x243185be, 0x550c7dc3, 0x72be5d74, 0x80deb1fe, 0x9bdc06a7, 0xc19bf174, 0xe49b69c1, 0xefbe4786, 0x0fc19dc6, 0x240ca1cc,
+    0x2de92c6f, 0x4a7484aa, 0x5cb0a9dc, 0x76f988da, 0x983e5152, 0xa831c66d, 0xb00327c8, 0xbf597fc7, 0xc6e00bf3, 0xd5a79147,
+    0x06ca6351, 0x14292967, 0x27b70a85, 0x2e1b2138, 0x4d2c6dfc, 0x53380d13, 0x650a7354, 0x766a0abb, 0x81c2c92e, 0x92722c85,
+    0xa2bfe8a1, 0xa81a664b, 0xc24b8b70, 0xc76c51a3, 0xd192e819, 0xd6990624, 0xf40e3585, 0x106aa070, 0x19a4c116, 0x1e376c08,
+    0x2748774c, 0x34b0bcb5, 0x391c0cb3, 0x4ed8aa4a, 0x5b9cca4f, 0x682e6ff3, 0x748f82ee, 0x78a5636f, 0x84c87814, 0x8cc70208,
+    0x90befffa, 0xa4506ceb, 0xbef9a3f7, 0xc67178f2};
+
+struct Sha256 {
+  uint32_t h[8];
+  uint32_t w[16];
+  uint32_t fill;      // bytes in the current block
+  uint64_t total;     // message bytes
+  __device__ void init() {
+    h[0] = 0x6a09e667; h[1] = 0xbb67ae85; h[2] = 0x3c6ef372; h[3] = 0xa54ff53a;
+    h[4] = 0x510e527f; h[5] = 0x9b05688c; h[6] = 0x1f83d9ab; h[7] = 0x5be0cd19;
+    fill = 0; total = 0;
+    for (int i = 0; i < 16; ++i) w[i] = 0;
+  }
+  __device__ void block() {
+    uint32_t a = h[0], b = h[1], c = h[2], d = h[3], e = h[4], f = h[5], g = h[6], hh = h[7];
+    uint32_t ws[16];
+    for (int i = 0; i < 16; ++i) ws[i] = w[i];
+    for (int i = 0; i < 64; ++i) {
+      uint32_t wi;
+      if (i < 16) wi = ws[i];
+      else {
+        uint32_t w15 = ws[(i + 1) & 15], w2 = ws[(i + 14) & 15];
+        uint32_t s0 = rotr32(w15, 7) ^ rotr32(w15, 18) ^ (w15 >> 3);
+        uint32_t s1 = rotr32(w2, 17) ^ rotr32(w2, 19) ^ (w2 >> 10);
+        wi = ws[i & 15] + s0 + ws[(i + 9) & 15] + s1;
+        ws[i & 15] = wi;
+      }
+      uint32_t S1 = rotr32(e, 6) ^ rotr32(e, 11) ^ rotr32(e, 25);
+      uint32_t ch = (e & f) ^ (~e & g);
+      uint32_t t1 = hh + S1 + ch + kSha256K[i] + wi;
+      uint32_t S0 = rotr32(a, 2) ^ rotr32(a, 13) ^ rotr32(a, 22);
+      uint32_t mj = (a & b) ^ (a & c) ^ (b & c);
+      uint32_t t2 = S0 + mj;
+      hh = g; g = f; f = e; e = d + t1; d = c; c = b; b = a; a = t1 + t2;
+    }
+    h[0] += a; h[1] += b; h[2] += c; h[3] += d; h[4] += e; h[5] += f; h[6] += g; h[7] += hh;
+    for (int i = 0; i < 16; ++i) w[i] = 0;
+    fill = 0;
+  }
+  __device__ void put(uint8_t byte) {
+    w[fill >> 2] |= (uint32_t)byte << (24 - 8 * (fill & 3));
+    ++fill; ++total;
+    if (fill == 64) block();
+  }
+  __device__ void finish() {
+    uint64_t bits = total * 8;
+    put(0x80); --total;
+    if (fill > 56) { while (fill != 0) { put(0); --total; } }
+    while (fill < 56) { put(0); --total; }
+    w[14] = (uint32_t)(bits >> 32);
+    w[15] = (uint32_t)bits;
+    block();
+  }
+};
+
+// digest_out: uint32[8][nb] limb-major (word i of number g at [i*nb + g]); bit_out (optional): low bit of the digest
+// read as a big-endian integer (RandomOracleBit, random_oracle.go:10-16)
+__global__ void k_sha256_transcript(ShaArgs a, size_t nb, size_t count, uint32_t* __restrict__ digest_out,
+                                    int32_t* __restrict__ bit_out) {
+  size_t g = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (g >= count) return;
+  Sha256 s;
+  s.init();
+  for (int pi = 0; pi < a.nparts; ++pi) {
+    const uint32_t* p = a.part[pi].p;
+    const int w = a.part[pi].w;
+    // find the most significant non-zero byte
+    long top = -1;
+    for (int l = w - 1; l >= 0; --l) {
+      uint32_t v = p[(size_t)l * nb + g];
+      if (v) { top = (long)l * LB + (31 - __clz(v)); break; }
+    }
+    if (top < 0) continue;                       // zero: Bytes() is empty
+    for (long byte = top / 8; byte >= 0; --byte) {
+      long bit = byte * 8;
+      int l = (int)(bit / LB), sh = (int)(bit % LB);
+      uint64_t v = p[(size_t)l * nb + g];
+      if (l + 1 < w) v |= (uint64_t)p[(size_t)(l + 1) * nb + g] << LB;
+      s.put((uint8_t)(v >> sh));
+    }
+  }
+  s.finish();
+  if (digest_out)
+    for (int i = 0; i < 8; ++i) digest_out[(size_t)i * nb + g] = s.h[i];
+  if (bit_out) bit_out[g] = (int32_t)(s.h[7] & 1u);
+}
+
+// ok[g] = (a == b) limb-wise (canonical numbers)
+__global__ void k_equal(const uint32_t* __restrict__ a, const uint32_t* __restrict__ b, int w, size_t nb, size_t count,
+                        int32_t* __restrict__ ok) {
+  size_t g = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (g >= count) return;
+  uint32_t d = 0;
+  for (int l = 0; l < w; ++l) d |= a[(size_t)l * nb + g] ^ b[(size_t)l * nb + g];
+  ok[g] = d == 0;
+}
+
+// out <- flags[g] ? a : b   (w limbs)
+__global__ void k_select(const int32_t* __restrict__ flags, const uint32_t* __restrict__ a, const uint32_t* __restrict__ b,
+                         uint32_t* __restrict__ out, int w, size_t nb) {
+  size_t g = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (g >= nb) return;
+  const uint32_t* src = flags[g] ? a : b;
+  for (int l = 0; l < w; ++l) out[(size_t)l * nb + g] = src[(size_t)l * nb + g];
+}
+
 #define HELPER_GRID(nb) dim3((unsigned)(((nb) + 255) / 256)), dim3(256)
 
 void launch_unpack_be(const uint8_t* in, size_t stride, size_t nbytes, size_t count, uint32_t* out, int wt, size_t nb, hipStream_t st) {
@@ -450,4 +573,17 @@ void launch_sub_one(const uint32_t* x, uint32_t* out, int w, size_t nb, hipStrea
 }
 void launch_mask_bits(uint32_t* x, int w, size_t nb, size_t bits, hipStream_t st) {
   hipLaunchKernelGGL(k_mask_bits, HELPER_GRID(nb), 0, st, x, w, nb, bits);
+}
+void launch_sha256_transcript(const uint32_t* const* parts, const int* widths, int nparts, size_t nb, size_t count,
+                              uint32_t* digest_out, int32_t* bit_out, hipStream_t st) {
+  ShaArgs a;
+  a.nparts = nparts;
+  for (int i = 0; i < nparts && i < 6; ++i) { a.part[i].p = parts[i]; a.part[i].w = widths[i]; }
+  hipLaunchKernelGGL(k_sha256_transcript, dim3((unsigned)((count + 63) / 64)), dim3(64), 0, st, a, nb, count, digest_out, bit_out);
+}
+void launch_equal(const uint32_t* a, const uint32_t* b, int w, size_t nb, size_t count, int32_t* ok, hipStream_t st) {
+  hipLaunchKernelGGL(k_equal, HELPER_GRID(count ? count : 1), 0, st, a, b, w, nb, count, ok);
+}
+void launch_select(const int32_t* flags, const uint32_t* a, const uint32_t* b, uint32_t* out, int w, size_t nb, hipStream_t st) {
+  hipLaunchKernelGGL(k_select, HELPER_GRID(nb), 0, st, flags, a, b, out, w, nb);
 }

@@ -114,3 +114,50 @@ def test_random_oracle_quirks():
     assert pr.random_oracle_digest(1, 0, 3) == pr.random_oracle_digest(1, 3)             # zero contributes no bytes
     assert pr.random_oracle_digest(5, 2, 3) == po.random_oracle_digest(5, 2, 3)
     assert pr.random_oracle_bit(7, 2 ** 300 + 5, 11) == po.random_oracle_bit(7, 2 ** 300 + 5, 11)
+
+
+def test_device_sha256_transcripts(ctx):
+    """SHA-256 over gmp.Int.Bytes() concatenations on the device vs hashlib: every length class around the 55/56/64-byte
+    padding boundaries, zero parts (empty bytes), multi-block messages."""
+    import hashlib
+    rng = random.Random(3)
+    def by(x):
+        return x.to_bytes((x.bit_length() + 7) // 8, "big")
+    col0, col1, col2 = [], [], []
+    for nbytes in list(range(0, 70)) + [119, 120, 127, 128, 129, 255, 256, 700]:
+        a = rng.getrandbits(8 * nbytes) | (1 << (8 * nbytes - 1)) if nbytes else 0
+        col0.append(a)
+        col1.append(rng.choice([0, 1, 255, 256, rng.getrandbits(300)]))
+        col2.append(rng.getrandbits(rng.choice([1, 8, 9, 2047, 6144])))
+    got = ctx.random_oracle_digest_batch([col0, col1, col2])
+    want = [hashlib.sha256(by(a) + by(b) + by(c)).digest() for a, b, c in zip(col0, col1, col2)]
+    assert got == want
+
+
+def test_ddleq_verify_on_device(ctx):
+    """pgpu_ddleq_verify (hash + three modexps per instance on the device) vs the oracle, valid and invalid proofs."""
+    import paillier_amd as pa
+    sk_o, p, q = po.keygen_seeded(256, 3)
+    n = sk_o.N
+    pk = pa.PublicKey(ctx, n, n + 1)
+    rng = random.Random(22)
+    B = 40
+    ct1 = [po.encrypt_with_r_at_level(sk_o, po.encrypt_with_r(sk_o, rng.randrange(n), po.rand_unit(n, rng)).C,
+                                      po.rand_unit(n, rng), po.ENC_LEVEL_TWO).C for _ in range(B)]
+    a_s = [po.rand_unit(n, rng) for _ in range(B)]
+    b_s = [po.rand_unit(n, rng) for _ in range(B)]
+    ct2 = [po.nested_randomize_with_ab(sk_o, po.Ciphertext(c, po.ENC_LEVEL_TWO), a, b).C for c, a, b in zip(ct1, a_s, b_s)]
+    proofs = [po.prove_ddleq_instance_xy(sk_o, po.Ciphertext(c1, 1), po.Ciphertext(c2, 1), a, b, po.rand_unit(n, rng),
+                                         po.rand_unit(n, rng)) for c1, c2, a, b in zip(ct1, ct2, a_s, b_s)]
+    args = lambda c2s, prs: (ct1, c2s, [p.X for p in prs], [p.Y for p in prs], [p.Alpha for p in prs], [p.E for p in prs],
+                             [p.F for p in prs])
+    assert pk.VerifyDDLEQInstancesBatch(*args(ct2, proofs)) == [True] * B
+    wrong = ct2[1:] + ct2[:1]
+    got = pk.VerifyDDLEQInstancesBatch(*args(wrong, proofs))
+    want = [po.verify_ddleq_proof_instance(sk_o, po.Ciphertext(c1, 1), po.Ciphertext(c2, 1), pf)
+            for c1, c2, pf in zip(ct1, wrong, proofs)]
+    assert got == want and not all(got)
+    proofs[0].F += 1
+    proofs[1].E = (proofs[1].E + 1) % (n * n)
+    got = pk.VerifyDDLEQInstancesBatch(*args(ct2, proofs))
+    assert got[:2] == [False, False] and all(got[2:])
