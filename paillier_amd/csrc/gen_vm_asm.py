@@ -388,8 +388,7 @@ class Gen:
         rstride = NPB * 4
         e("L_montmul:")
         for j in range(WL if K > 1 else WL - 1):
-            e(f"v_mov_b32 {self.Tlo(j)}, 0")
-            e(f"v_mov_b32 {self.Thi(j)}, 0")
+            e(f"v_mov_b64 {self.T(j)}, 0")
         e(f"v_mov_b32 v{g.v_arow}, v{g.v_aread}")
         e(f"ds_read_b32 v{g.v_ain}, v{g.v_arow}")
         e(f"v_add_u32 v{g.v_arow}, {rstride}, v{g.v_arow}")
@@ -490,8 +489,7 @@ class Gen:
         e("s_waitcnt lgkmcnt(0)")  # the dangling prefetch of row WT
         if K == 1:
             # the top column is re-created by A(WL-1) every row (src2 = 0); after the last shift it is logically 0
-            e(f"v_mov_b32 {self.Tlo(WL - 1)}, 0")
-            e(f"v_mov_b32 {self.Thi(WL - 1)}, 0")
+            e(f"v_mov_b64 {self.T(WL - 1)}, 0")
         self.normalize()
         e("s_branch L_next")
 
@@ -513,8 +511,7 @@ class Gen:
         ai2, m, din = f"v{g.v_ai}", f"v{g.v_m}", f"v{g.v_din}"
         e("L_montsq:")
         for j in range(WL):
-            e(f"v_mov_b32 {self.Tlo(j)}, 0")
-            e(f"v_mov_b32 {self.Thi(j)}, 0")
+            e(f"v_mov_b64 {self.T(j)}, 0")
         e(f"v_mov_b32 v{g.v_arow}, v{g.v_aread}")
         e(f"v_mov_b32 v{g.v_drow}, v{g.v_aread}")
         e(f"ds_read_b32 v{g.v_ain}, v{g.v_arow}")
@@ -524,7 +521,7 @@ class Gen:
         e("s_mov_b32 s19, 0")
         e("L_rowsq:")
         e("s_waitcnt lgkmcnt(0)")
-        e(f"v_lshlrev_b32 {ai2}, 1, v{g.v_ain}")          # 2 * x_i
+        e(f"v_add_u32 {ai2}, v{g.v_ain}, v{g.v_ain}")        # 2 * x_i
         e("s_bitcmp1_b32 s19, 0")
         e("s_cbranch_scc1 L_sq_odd")
         self.mad(self.T(0), din, din, self.T(0))          # diagonal x_(i/2)^2 into column i
@@ -556,8 +553,7 @@ class Gen:
             self.mad(self.T(j - 1), m, N(j), self.T(j))
             if j == 4 or (WL <= 4 and j == WL - 1):
                 e(f"v_lshl_add_u64 {self.T(0)}, {self.T(0)}, 0, {self.P(g.v_c)}")
-        e(f"v_mov_b32 {self.Tlo(WL - 1)}, 0")
-        e(f"v_mov_b32 {self.Thi(WL - 1)}, 0")
+        e(f"v_mov_b64 {self.T(WL - 1)}, 0")
         e("s_add_u32 s19, s19, 1")
         e(f"s_cmp_lt_u32 s19, {WT}")
         e("s_cbranch_scc1 L_rowsq")

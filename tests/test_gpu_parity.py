@@ -180,3 +180,38 @@ def test_asm_kernel_per_number_exponent(ctx, bits):
     finally:
         ctx.set_flag("asm", 1)
     assert got_asm == got_cc == [po.gmp_exp(b, e, n) for b, e in zip(bases, exps)]
+
+
+@pytest.mark.parametrize("count", [1, 255, 257, 1000])
+def test_ragged_batch_sizes(ctx, key1024, count):
+    """Batches that are not multiples of the 256-lane block (padding lanes must never leak into results)."""
+    import paillier_amd as pa
+    sk_o, p, q = key1024
+    n = sk_o.N
+    rng = random.Random(count)
+    pk = pa.PublicKey(ctx, n, n + 1)
+    sk = pa.SecretKey(ctx, pk, sk_o.Lambda)
+    ms = [rng.randrange(n) for _ in range(count)]
+    rs = [po.rand_unit(n, rng) for _ in range(count)]
+    cts = pk.EncryptWithRBatch(ms, rs)
+    assert cts[:2] == [po.encrypt_with_r(sk_o, m, r).C for m, r in zip(ms[:2], rs[:2])]
+    assert cts[-1] == po.encrypt_with_r(sk_o, ms[-1], rs[-1]).C
+    assert sk.DecryptBatch(cts) == ms
+    doubled = pk.AddBatch(cts, cts)
+    assert sk.DecryptBatch(doubled) == [(2 * m) % n for m in ms]
+    assert pk.SubBatch(doubled, cts) == cts
+    assert sk.DecryptBatch(pk.ConstMultBatch(cts, 3)) == [(3 * m) % n for m in ms]
+
+
+def test_empty_and_bad_arguments(ctx, key1024):
+    import numpy as np
+    import paillier_amd as pa
+    sk_o, p, q = key1024
+    pk = pa.PublicKey(ctx, sk_o.N, sk_o.N + 1)
+    with pytest.raises(pa.PaillierHipError):     # empty batch
+        pk.encrypt_with_r_raw(0, np.zeros((1, 128), np.uint8), 128, np.zeros((1, 128), np.uint8), 128,
+                              np.zeros((1, 256), np.uint8), 256)
+    with pytest.raises(pa.PaillierHipError):     # even modulus
+        pa.Modulus(ctx, 1 << 1024)
+    with pytest.raises(pa.PaillierHipError):     # modulus wider than the built kernels
+        pa.Modulus(ctx, (1 << 12000) + 1)
