@@ -139,6 +139,22 @@ int pgpu_combine_partial_decryptions(const pgpu_pubkey* pk, int total_servers, i
                                      size_t batch, const uint8_t* const* partials, size_t stride, uint8_t* m,
                                      size_t m_stride, int mem);
 
+/* ---- share-decryption proofs (thresholdkey.go:225-326) ------------------------------------------------- */
+
+/* ThresholdSecretKey.PartialDecryptionWithZKP for a batch, with the random r (< n^2, thresholdkey.go:233) supplied:
+ *   dec[i] = c[i]^(2 l! s) ; a = (c^4)^r, b = V^r mod n^2 ; E = SHA-256(a || b || c^4 || dec^2) (unreduced powers) ;
+ *   Z = r + E l! s.   e_out: 32 bytes per proof; z_out: z_stride bytes per proof.  V^r uses a fixed-base comb table. */
+int pgpu_share_zkp_prove(const pgpu_pubkey* pk, int total_servers, const uint8_t* share_be, size_t share_len,
+                         const uint8_t* vkey_be, size_t vkey_len, size_t batch, const uint8_t* c, size_t c_stride,
+                         const uint8_t* r, size_t r_stride, uint8_t* dec, size_t dec_stride, uint8_t* e_out, uint8_t* z_out,
+                         size_t z_stride, int mem);
+
+/* PartialDecryptionZKP.VerifyProof for a batch of proofs of ONE server (thresholdkey.go:278-311):
+ *   ok[i] = ( E == SHA-256( (c^4)^Z (dec^2)^-E || V^Z v_i^-E || c^4 || dec^2 ) ),  v_i = VerificationKeys[ID-1]. */
+int pgpu_share_zkp_verify(const pgpu_pubkey* pk, const uint8_t* vkey_be, size_t vkey_len, const uint8_t* vi_be, size_t vi_len,
+                          size_t batch, const uint8_t* c, size_t c_stride, const uint8_t* dec, size_t dec_stride,
+                          const uint8_t* e, const uint8_t* z, size_t z_stride, int32_t* ok, int mem);
+
 /* ---- proofs (ddleq.go, random_oracle.go) ----------------------------------------------------------- */
 
 /* RandomOracleDigest-style transcripts on the device: digests[i] = SHA-256( Bytes(parts[0][i]) || ... ) where Bytes is

@@ -65,6 +65,8 @@ SIGNATURES = {
     "pgpu_combine_partial_decryptions": (_int, [_vp, _int, _int, _int, _vp, _sz, _vp, _sz, _vp, _sz, _int]),
     "pgpu_random_oracle_digest": (_int, [_vp, _int, _vp, _vp, _sz, _vp, _int]),
     "pgpu_ddleq_verify": (_int, [_vp, _sz, _vp, _vp, _sz, _vp, _vp, _sz, _vp, _sz, _vp, _sz, _vp, _sz, _vp, _int]),
+    "pgpu_share_zkp_prove": (_int, [_vp, _int, _vp, _sz, _vp, _sz, _sz, _vp, _sz, _vp, _sz, _vp, _sz, _vp, _vp, _sz, _int]),
+    "pgpu_share_zkp_verify": (_int, [_vp, _vp, _sz, _vp, _sz, _sz, _vp, _sz, _vp, _sz, _vp, _vp, _sz, _vp, _int]),
     "pgpu_const_mult": (_int, [_vp, _int, _sz, _vp, _sz, _vp, _sz, _sz, _vp, _sz, _int]),
     "pgpu_modulus_create": (_int, [_vp, _vp, _sz, C.POINTER(_vp)]),
     "pgpu_modulus_destroy": (None, [_vp]),
@@ -352,6 +354,32 @@ class ThresholdPublicKey(PublicKey):
         pa_ = (C.c_void_p * n)(*partial_ptrs)
         _check(self.ctx.lib.pgpu_combine_partial_decryptions(self.h, self.TotalNumberOfDecryptionServers, self.Threshold, n,
                                                              ida, batch, pa_, stride, _ptr(m), m_stride, mem))
+
+    def PartialDecryptionWithZKPBatch(self, ID: int, share: int, verification_key: int, cts: Sequence[int], rs: Sequence[int]):
+        """thresholdkey.go:225-257 with r supplied, entirely on the device.  Returns (decryptions, Es, Zs)."""
+        cb = self.cipher_bytes()
+        zb = cb + 48
+        B = len(cts)
+        cbuf, rbuf = ints_to_be(cts, cb), ints_to_be(rs, cb)
+        dec = np.zeros((B, cb), np.uint8)
+        eo = np.zeros((B, 32), np.uint8)
+        zo = np.zeros((B, zb), np.uint8)
+        sb, vb = _be(share), _be(verification_key)
+        _check(self.ctx.lib.pgpu_share_zkp_prove(self.h, self.TotalNumberOfDecryptionServers, sb, len(sb), vb, len(vb), B,
+                                                 _ptr(cbuf), cb, _ptr(rbuf), cb, _ptr(dec), cb, _ptr(eo), _ptr(zo), zb, MEM_HOST))
+        return be_to_ints(dec), be_to_ints(eo), be_to_ints(zo)
+
+    def VerifyProofBatch(self, verification_key: int, vi: int, cts, decs, es, zs) -> List[bool]:
+        """thresholdkey.go:278-311 for a batch of proofs of one server (vi = VerificationKeys[ID-1]), on the device."""
+        cb = self.cipher_bytes()
+        zb = max(cb + 48, max((int(z).bit_length() + 7) // 8 for z in zs))
+        B = len(cts)
+        bufs = [ints_to_be(cts, cb), ints_to_be(decs, cb), ints_to_be(es, 32), ints_to_be(zs, zb)]
+        ok = np.zeros(B, np.int32)
+        vb, ib = _be(verification_key), _be(vi)
+        _check(self.ctx.lib.pgpu_share_zkp_verify(self.h, vb, len(vb), ib, len(ib), B, _ptr(bufs[0]), cb, _ptr(bufs[1]), cb,
+                                                  _ptr(bufs[2]), _ptr(bufs[3]), zb, _ptr(ok), MEM_HOST))
+        return [bool(v) for v in ok]
 
     def PartialDecryptBatch(self, ID: int, share: int, cts: Sequence[int]):
         """thresholdkey.go:192-201 for each ciphertext; returns (ID, [decryptions])."""

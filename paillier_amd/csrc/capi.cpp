@@ -422,6 +422,8 @@ struct pgpu_pubkey {
   int c_inv2R = -1;               // 2^-1 * R mod n in mn.consts        (binomial of the level-two g^m)
   int c_ninv2R_2 = -1;            // n * 2^-1 * R mod n^2 in mn2.consts (Damgard-Jurik recovery, paillier.go:326-331)
   struct AltTab { bool built = false; int base = 0; int nwin = 0; size_t kbits = 0; } alt[2];  // fixed-base comb tables of h_s
+  struct FixedBase { BigU base; int idx; int nwin; };
+  std::vector<FixedBase> fixed_bases;   // comb tables of other fixed bases mod n^2 (verification keys)
   std::vector<std::pair<int, int>> combine_consts;  // (total servers l, index of (4 (l!)^2)^-1 * R mod n in mn.consts)
 };
 
@@ -1620,6 +1622,230 @@ int pgpu_ddleq_verify(const pgpu_pubkey* pk, size_t batch, const uint8_t* ct1, c
     int32_t* d_ok = ctx->ws_t<int32_t>(nb);
     if (wa != W3) api_throw(PGPU_ERR_INVALID, "alpha stride must be the byte length of n^3");
     launch_equal(pc.out(), al, W3, nb, batch, d_ok, ctx->stream);
+    HIPCHK(hipMemcpyAsync(ok, d_ok, batch * 4, hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHK(hipStreamSynchronize(ctx->stream));
+  });
+}
+
+}  // extern "C"
+
+namespace {
+
+// fixed-base comb table of `base` modulo n^2 covering exponents of up to `ebits` bits; returns (first const index, windows)
+const pgpu_pubkey::FixedBase& ensure_fixed_base(pgpu_pubkey* pk, const BigU& base_in, size_t ebits) {
+  ModCtx& mc = pk->mn2;
+  BigU base = base_in % mc.N;
+  const int nwin = (int)((ebits + 3) / 4);
+  for (auto& f : pk->fixed_bases)
+    if (f.base == base && f.nwin >= nwin) return f;
+  pgpu_pubkey::FixedBase f;
+  f.base = base;
+  f.nwin = nwin;
+  f.idx = (int)mc.consts.size();
+  const BigU rmod = mc.R % mc.N;
+  BigU b = base;
+  for (int i = 0; i < nwin; ++i) {
+    BigU cur(1);
+    for (int d = 0; d < 16; ++d) {
+      mc.consts.push_back(hostbig::mulmod(cur, rmod, mc.N));
+      cur = hostbig::mulmod(cur, b, mc.N);
+    }
+    b = cur;
+  }
+  mc.upload();
+  pk->fixed_bases.push_back(f);
+  return pk->fixed_bases.back();
+}
+
+// x^e mod n^2 for a uniform base with a comb table and per-number exponents (limb-major [we][nb]); result canonical in `out`
+void comb_pow(pgpu_ctx* ctx, const ModCtx& mc, const pgpu_pubkey::FixedBase& fb, const uint32_t* exps, int we, size_t nb,
+              uint32_t* out) {
+  const int nwin = std::min(fb.nwin, we * 7);
+  size_t sw = (size_t)mc.WT * nb;
+  uint32_t* memv = ctx->ws_t<uint32_t>(sw);
+  Prog p;
+  p.op(VM_LOADC, C_ONE_M);
+  for (int i = 0; i < nwin; ++i) p.op(VM_MULCV, (uint32_t)i, (uint32_t)fb.idx);
+  p.op(VM_MULC, C_ONE);
+  p.op(VM_STORE, 0);
+  p.end();
+  SegSpec sg{&mc, &p, memv, exps};
+  run_vm(ctx, nb, sg, nullptr, true);
+  launch_canon(memv, mc.d_nmod, mc.WT, nb, ctx->stream);
+  HIPCHK(hipMemcpyAsync(out, memv, sw * 4, hipMemcpyDeviceToDevice, ctx->stream));
+}
+
+// out = base[i]^(e[i]) mod N, per-number base (WT limbs) and per-number exponent (we limbs); canonical
+void perlane_pow(pgpu_ctx* ctx, const ModCtx& mc, const uint32_t* base, const uint32_t* exps, int we, size_t nb, uint32_t* out) {
+  ModexpPlan pl = modexp_alloc(ctx, mc, nb, 16);
+  HIPCHK(hipMemcpyAsync(pl.in(), base, (size_t)mc.WT * nb * 4, hipMemcpyDeviceToDevice, ctx->stream));
+  modexp_perlane_run(ctx, mc, pl, exps, we, false, false);
+  HIPCHK(hipMemcpyAsync(out, pl.out(), (size_t)mc.WT * nb * 4, hipMemcpyDeviceToDevice, ctx->stream));
+}
+
+// out = a * b mod N (canonical operands, WT limbs)
+void modmul_arrays(pgpu_ctx* ctx, const ModCtx& mc, const uint32_t* a, const uint32_t* b, size_t nb, uint32_t* out) {
+  size_t sw = (size_t)mc.WT * nb;
+  uint32_t* memv = ctx->ws_t<uint32_t>(sw * 3);
+  HIPCHK(hipMemcpyAsync(memv, a, sw * 4, hipMemcpyDeviceToDevice, ctx->stream));
+  HIPCHK(hipMemcpyAsync(memv + sw, b, sw * 4, hipMemcpyDeviceToDevice, ctx->stream));
+  Prog p;
+  p.op(VM_LOAD, 0); p.op(VM_MULC, C_R2); p.op(VM_MUL, 1); p.op(VM_STORE, 2); p.end();
+  SegSpec sg{&mc, &p, memv, nullptr};
+  run_vm(ctx, nb, sg, nullptr, false);
+  launch_canon(memv + 2 * sw, mc.d_nmod, mc.WT, nb, ctx->stream);
+  HIPCHK(hipMemcpyAsync(out, memv + 2 * sw, sw * 4, hipMemcpyDeviceToDevice, ctx->stream));
+}
+
+// Shared part of prove and verify: the Fiat-Shamir hash E = SHA-256(a || b || c^4 || c_i^2) over UNREDUCED c^4, c_i^2
+// (thresholdkey.go:241,248,319-326).  c, ci: canonical W2-limb arrays as given by the caller.  Returns digest words [8][nb].
+uint32_t* zkp_hash(pgpu_ctx* ctx, int W2, const uint32_t* a, const uint32_t* b, const uint32_t* c, const uint32_t* ci, size_t nb,
+                   size_t count) {
+  uint32_t* c2 = ctx->ws_t<uint32_t>((size_t)2 * W2 * nb);
+  uint32_t* c4 = ctx->ws_t<uint32_t>((size_t)4 * W2 * nb);
+  uint32_t* ci2 = ctx->ws_t<uint32_t>((size_t)2 * W2 * nb);
+  launch_mul_plain(c, W2, c, W2, c2, nb, ctx->stream);
+  launch_mul_plain(c2, 2 * W2, c2, 2 * W2, c4, nb, ctx->stream);
+  launch_mul_plain(ci, W2, ci, W2, ci2, nb, ctx->stream);
+  const uint32_t* parts[4] = {a, b, c4, ci2};
+  const int widths[4] = {W2, W2, 4 * W2, 2 * W2};
+  uint32_t* dg = ctx->ws_t<uint32_t>(8 * nb);
+  launch_sha256_transcript(parts, widths, 4, nb, count, dg, nullptr, ctx->stream);
+  return dg;
+}
+
+}  // namespace
+
+extern "C" {
+
+int pgpu_share_zkp_prove(const pgpu_pubkey* pk, int total_servers, const uint8_t* share_be, size_t share_len,
+                         const uint8_t* vkey_be, size_t vkey_len, size_t batch, const uint8_t* c, size_t c_stride,
+                         const uint8_t* r, size_t r_stride, uint8_t* dec, size_t dec_stride, uint8_t* e_out, uint8_t* z_out,
+                         size_t z_stride, int mem) {
+  if (!pk || !share_be || !vkey_be || !c || !r || !dec || !e_out || !z_out) return fail(PGPU_ERR_INVALID, "null argument");
+  pgpu_ctx* ctx = pk->ctx;
+  return guarded([&] {
+    if (batch == 0) api_throw(PGPU_ERR_INVALID, "empty batch");
+    ctx->bind();
+    const ModCtx& mc = pk->mn2;
+    const int W2 = mc.WT;
+    const BigU share = BigU::from_be(share_be, share_len), delta = factorial_big(total_servers);
+    const pgpu_pubkey::FixedBase fb = ensure_fixed_base(const_cast<pgpu_pubkey*>(pk), BigU::from_be(vkey_be, vkey_len), mc.nbits + 384);
+    ctx->reset_ws();
+    const size_t nb = round_up(batch, VM_BLOCK);
+    const size_t sw = (size_t)W2 * nb;
+    if (c_stride != mc.nbytes) api_throw(PGPU_ERR_INVALID, "ciphertext stride must be the byte length of n^2");
+    uint32_t* cl = ctx->ws_t<uint32_t>(sw);
+    unpack_operand(ctx, c, c_stride, c_stride, batch, mem, cl, W2, nb);
+    // Decryption = c^(2 delta s_i) mod n^2                                   (thresholdkey.go:229,192-201)
+    ModexpPlan pd = modexp_alloc(ctx, mc, nb, 32);
+    HIPCHK(hipMemcpyAsync(pd.in(), cl, sw * 4, hipMemcpyDeviceToDevice, ctx->stream));
+    modexp_shared_run(ctx, mc, pd, share * (BigU(2) * delta), false, false, false);
+    // r, a = (c^4)^r mod n^2, b = V^r mod n^2                                (thresholdkey.go:241-245)
+    const int wr = std::max<int>(1, (int)((r_stride * 8 + LB - 1) / LB));
+    uint32_t* rl = ctx->ws_t<uint32_t>((size_t)wr * nb);
+    unpack_operand(ctx, r, r_stride, r_stride, batch, mem, rl, wr, nb);
+    uint32_t* c4m = ctx->ws_t<uint32_t>(sw);
+    {
+      uint32_t* memv = ctx->ws_t<uint32_t>(sw * 2);
+      HIPCHK(hipMemcpyAsync(memv, cl, sw * 4, hipMemcpyDeviceToDevice, ctx->stream));
+      Prog p;
+      p.op(VM_LOAD, 0); p.op(VM_MULC, C_R2); p.op(VM_SQR); p.op(VM_SQR); p.op(VM_MULC, C_ONE); p.op(VM_STORE, 1); p.end();
+      SegSpec sg{&mc, &p, memv, nullptr};
+      run_vm(ctx, nb, sg, nullptr, false);
+      launch_canon(memv + sw, mc.d_nmod, W2, nb, ctx->stream);
+      HIPCHK(hipMemcpyAsync(c4m, memv + sw, sw * 4, hipMemcpyDeviceToDevice, ctx->stream));
+    }
+    uint32_t* a = ctx->ws_t<uint32_t>(sw);
+    uint32_t* b = ctx->ws_t<uint32_t>(sw);
+    perlane_pow(ctx, mc, c4m, rl, wr, nb, a);
+    comb_pow(ctx, mc, fb, rl, wr, nb, b);
+    uint32_t* dg = zkp_hash(ctx, W2, a, b, cl, pd.out(), nb, batch);
+    // E and Z = r + E * delta * s_i (plain integers, thresholdkey.go:313-317)
+    uint32_t* el = ctx->ws_t<uint32_t>(10 * nb);
+    launch_digest_to_limbs(dg, el, nb, ctx->stream);
+    const BigU ds = delta * share;
+    const int wds = std::max<int>(1, (int)((ds.bit_length() + LB - 1) / LB));
+    const int wz = std::max(wr, wds + 10) + 1;
+    if (z_stride * 8 < (size_t)LB * wz && z_stride * 8 < std::max((size_t)r_stride * 8, ds.bit_length() + 256) + 1)
+      api_throw(PGPU_ERR_INVALID, "z stride too small for r + E*delta*share");
+    uint32_t* d_ds = ctx->upload_words(ds.to_limbs(LB, wds));
+    uint32_t* zl = ctx->ws_t<uint32_t>((size_t)wz * nb);
+    launch_mul_const_add(el, 10, d_ds, wds, rl, wr, 0, zl, wz, nb, ctx->stream);
+    pack_result(ctx, pd.out(), W2, nb, batch, dec, dec_stride, mc.nbytes, mem);
+    pack_result(ctx, zl, wz, nb, batch, z_out, z_stride, std::min(z_stride, (size_t)((LB * wz + 7) / 8)), mem);
+    // E as 32 big-endian bytes
+    uint32_t* e10 = el;
+    pack_result(ctx, e10, 10, nb, batch, e_out, 32, 32, mem);
+    HIPCHK(hipStreamSynchronize(ctx->stream));
+  });
+}
+
+int pgpu_share_zkp_verify(const pgpu_pubkey* pk, const uint8_t* vkey_be, size_t vkey_len, const uint8_t* vi_be, size_t vi_len,
+                          size_t batch, const uint8_t* c, size_t c_stride, const uint8_t* dec, size_t dec_stride,
+                          const uint8_t* e, const uint8_t* z, size_t z_stride, int32_t* ok, int mem) {
+  if (!pk || !vkey_be || !vi_be || !c || !dec || !e || !z || !ok) return fail(PGPU_ERR_INVALID, "null argument");
+  pgpu_ctx* ctx = pk->ctx;
+  return guarded([&] {
+    if (batch == 0) api_throw(PGPU_ERR_INVALID, "empty batch");
+    ctx->bind();
+    const ModCtx& mc = pk->mn2;
+    const int W2 = mc.WT;
+    pgpu_pubkey* pkm = const_cast<pgpu_pubkey*>(pk);
+    const size_t zbits = z_stride * 8;
+    const pgpu_pubkey::FixedBase fbV = ensure_fixed_base(pkm, BigU::from_be(vkey_be, vkey_len), zbits);
+    const pgpu_pubkey::FixedBase fbI = ensure_fixed_base(pkm, BigU::from_be(vi_be, vi_len), 256);
+    ctx->reset_ws();
+    const size_t nb = round_up(batch, VM_BLOCK);
+    const size_t sw = (size_t)W2 * nb;
+    if (c_stride != mc.nbytes || dec_stride != mc.nbytes) api_throw(PGPU_ERR_INVALID, "c / decryption stride must be the byte length of n^2");
+    uint32_t* cl = ctx->ws_t<uint32_t>(sw);
+    uint32_t* dl = ctx->ws_t<uint32_t>(sw);
+    unpack_operand(ctx, c, c_stride, c_stride, batch, mem, cl, W2, nb);
+    unpack_operand(ctx, dec, dec_stride, dec_stride, batch, mem, dl, W2, nb);
+    const int wz = std::max<int>(1, (int)((z_stride * 8 + LB - 1) / LB));
+    uint32_t* zl = ctx->ws_t<uint32_t>((size_t)wz * nb);
+    unpack_operand(ctx, z, z_stride, z_stride, batch, mem, zl, wz, nb);
+    uint32_t* el = ctx->ws_t<uint32_t>(10 * nb);
+    unpack_operand(ctx, e, 32, 32, batch, mem, el, 10, nb);
+    // c^4 mod n^2 and c_i^2 mod n^2 in one program (two numbers per lane would need two x registers: two programs)
+    uint32_t* c4m = ctx->ws_t<uint32_t>(sw);
+    uint32_t* d2m = ctx->ws_t<uint32_t>(sw);
+    {
+      uint32_t* memv = ctx->ws_t<uint32_t>(sw * 4);
+      HIPCHK(hipMemcpyAsync(memv, cl, sw * 4, hipMemcpyDeviceToDevice, ctx->stream));
+      HIPCHK(hipMemcpyAsync(memv + sw, dl, sw * 4, hipMemcpyDeviceToDevice, ctx->stream));
+      Prog p;
+      p.op(VM_LOAD, 0); p.op(VM_MULC, C_R2); p.op(VM_SQR); p.op(VM_SQR); p.op(VM_MULC, C_ONE); p.op(VM_STORE, 2);
+      p.op(VM_LOAD, 1); p.op(VM_MULC, C_R2); p.op(VM_SQR); p.op(VM_MULC, C_ONE); p.op(VM_STORE, 3);
+      p.end();
+      SegSpec sg{&mc, &p, memv, nullptr};
+      run_vm(ctx, nb, sg, nullptr, false);
+      launch_canon(memv + 2 * sw, mc.d_nmod, W2, nb, ctx->stream);
+      launch_canon(memv + 3 * sw, mc.d_nmod, W2, nb, ctx->stream);
+      HIPCHK(hipMemcpyAsync(c4m, memv + 2 * sw, sw * 4, hipMemcpyDeviceToDevice, ctx->stream));
+      HIPCHK(hipMemcpyAsync(d2m, memv + 3 * sw, sw * 4, hipMemcpyDeviceToDevice, ctx->stream));
+    }
+    // a = (c^4)^Z * ((c_i^2)^E)^-1,  b = V^Z * (v_i^E)^-1  mod n^2          (thresholdkey.go:294-311)
+    uint32_t* a1 = ctx->ws_t<uint32_t>(sw);
+    uint32_t* a2 = ctx->ws_t<uint32_t>(sw);
+    uint32_t* b1 = ctx->ws_t<uint32_t>(sw);
+    uint32_t* b2 = ctx->ws_t<uint32_t>(sw);
+    perlane_pow(ctx, mc, c4m, zl, wz, nb, a1);
+    perlane_pow(ctx, mc, d2m, el, 10, nb, a2);
+    comb_pow(ctx, mc, fbV, zl, wz, nb, b1);
+    comb_pow(ctx, mc, fbI, el, 10, nb, b2);
+    uint32_t* a2i = batch_inverse(ctx, mc, a2, nb, batch);
+    uint32_t* av = ctx->ws_t<uint32_t>(sw);
+    modmul_arrays(ctx, mc, a1, a2i, nb, av);
+    uint32_t* b2i = batch_inverse(ctx, mc, b2, nb, batch);
+    uint32_t* bv = ctx->ws_t<uint32_t>(sw);
+    modmul_arrays(ctx, mc, b1, b2i, nb, bv);
+    uint32_t* dg = zkp_hash(ctx, W2, av, bv, cl, dl, nb, batch);
+    uint32_t* e2 = ctx->ws_t<uint32_t>(10 * nb);
+    launch_digest_to_limbs(dg, e2, nb, ctx->stream);
+    int32_t* d_ok = ctx->ws_t<int32_t>(nb);
+    launch_equal(e2, el, 10, nb, batch, d_ok, ctx->stream);
     HIPCHK(hipMemcpyAsync(ok, d_ok, batch * 4, hipMemcpyDeviceToHost, ctx->stream));
     HIPCHK(hipStreamSynchronize(ctx->stream));
   });

@@ -66,3 +66,5 @@ void launch_sha256_transcript(const uint32_t* const* parts, const int* widths, i
                               uint32_t* digest_out, int32_t* bit_out, hipStream_t st);
 void launch_equal(const uint32_t* a, const uint32_t* b, int w, size_t nb, size_t count, int32_t* ok, hipStream_t st);
 void launch_select(const int32_t* flags, const uint32_t* a, const uint32_t* b, uint32_t* out, int w, size_t nb, hipStream_t st);
+void launch_mul_plain(const uint32_t* a, int wa, const uint32_t* b, int wb, uint32_t* out, size_t nb, hipStream_t st);
+void launch_digest_to_limbs(const uint32_t* dg, uint32_t* out, size_t nb, hipStream_t st);

@@ -313,6 +313,43 @@ __global__ void k_mask_bits(uint32_t* __restrict__ x, int w, size_t nb, size_t b
   }
 }
 
+// out[wa+wb] = a[wa] * b[wb] as plain integers (canonical limbs in, canonical limbs out); both operands per-number.
+// Used only for the unreduced c^4 and c_i^2 that feed the Fiat-Shamir hash (thresholdkey.go:241,248).
+__global__ void k_mul_plain(const uint32_t* __restrict__ a, int wa, const uint32_t* __restrict__ b, int wb,
+                            uint32_t* __restrict__ out, size_t nb) {
+  size_t g = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (g >= nb) return;
+  uint64_t acc = 0, hi = 0;
+  const int wo = wa + wb;
+  for (int c = 0; c < wo; ++c) {
+    int i0 = c - (wb - 1) > 0 ? c - (wb - 1) : 0;
+    int i1 = c < wa - 1 ? c : wa - 1;
+    for (int i = i0; i <= i1; ++i) {
+      uint64_t p = (uint64_t)a[(size_t)i * nb + g] * b[(size_t)(c - i) * nb + g];
+      acc += p;
+      hi += acc < p;
+    }
+    out[(size_t)c * nb + g] = (uint32_t)acc & LMASK;
+    acc = (acc >> LB) | (hi << (64 - LB));
+    hi >>= LB;
+  }
+}
+
+// 32-byte big-endian digests (uint32 words, limb-major [8][nb]) -> 10 canonical 28-bit limbs (the integer E)
+__global__ void k_digest_to_limbs(const uint32_t* __restrict__ dg, uint32_t* __restrict__ out, size_t nb) {
+  size_t g = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (g >= nb) return;
+  // value = sum_i word[i] * 2^(32 (7 - i))
+  for (int l = 0; l < 10; ++l) {
+    int bit = l * LB;
+    int w = bit / 32, sh = bit % 32;               // little-endian word index
+    uint64_t v = 0;
+    if (w < 8) v = dg[(size_t)(7 - w) * nb + g];
+    if (w + 1 < 8) v |= (uint64_t)dg[(size_t)(7 - (w + 1)) * nb + g] << 32;
+    out[(size_t)l * nb + g] = (uint32_t)(v >> sh) & LMASK;
+  }
+}
+
 // flags[g] = (x == 0)
 __global__ void k_is_zero(const uint32_t* __restrict__ x, int w, size_t nb, int32_t* __restrict__ flags) {
   size_t g = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -586,4 +623,10 @@ void launch_equal(const uint32_t* a, const uint32_t* b, int w, size_t nb, size_t
 }
 void launch_select(const int32_t* flags, const uint32_t* a, const uint32_t* b, uint32_t* out, int w, size_t nb, hipStream_t st) {
   hipLaunchKernelGGL(k_select, HELPER_GRID(nb), 0, st, flags, a, b, out, w, nb);
+}
+void launch_mul_plain(const uint32_t* a, int wa, const uint32_t* b, int wb, uint32_t* out, size_t nb, hipStream_t st) {
+  hipLaunchKernelGGL(k_mul_plain, HELPER_GRID(nb), 0, st, a, wa, b, wb, out, nb);
+}
+void launch_digest_to_limbs(const uint32_t* dg, uint32_t* out, size_t nb, hipStream_t st) {
+  hipLaunchKernelGGL(k_digest_to_limbs, HELPER_GRID(nb), 0, st, dg, out, nb);
 }

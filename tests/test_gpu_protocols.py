@@ -161,3 +161,37 @@ def test_ddleq_verify_on_device(ctx):
     proofs[1].E = (proofs[1].E + 1) % (n * n)
     got = pk.VerifyDDLEQInstancesBatch(*args(ct2, proofs))
     assert got[:2] == [False, False] and all(got[2:])
+
+
+@pytest.mark.parametrize("bits", ["512", "2048"])
+def test_share_zkp_device_resident(ctx, bits):
+    """pgpu_share_zkp_prove / _verify (thresholdkey.go:225-311) fully on the device -- comb table for V^r, device SHA-256 over
+    the unreduced c^4 and c_i^2 -- against the oracle: same (Decryption, E, Z), acceptance, and rejection of tampering."""
+    import paillier_amd as pa
+    k = json.load(open(os.path.join(G, "keys.json")))["threshold"][bits]
+    n, total, thr = int(k["n"], 16), k["total"], k["threshold"]
+    shares = [int(s, 16) for s in k["shares"]]
+    v, vks = int(k["v"], 16), [int(x, 16) for x in k["vks"]]
+    sid = 2
+    tsk = po.ThresholdSecretKey(N=n, G=n + 1, TotalNumberOfDecryptionServers=total, Threshold=thr, VerificationKey=v,
+                                VerificationKeys=vks, ID=sid, Share=shares[sid - 1])
+    rng = random.Random(int(bits) + 5)
+    B = 10
+    cts = [po.encrypt_with_r(tsk, rng.randrange(n), po.rand_unit(n, rng)).C for _ in range(B)]
+    rs = [rng.randrange(n * n) for _ in cts]
+    rs[0] = 0
+    tk = pa.ThresholdPublicKey(ctx, n, total=total, threshold=thr)
+    dec, es, zs = tk.PartialDecryptionWithZKPBatch(sid, shares[sid - 1], v, cts, rs)
+    refs = [po.partial_decryption_with_zkp_r(tsk, c, r) for c, r in zip(cts, rs)]
+    assert dec == [p.Decryption for p in refs]
+    assert es == [p.E for p in refs]
+    assert zs == [p.Z for p in refs]
+    assert tk.VerifyProofBatch(v, vks[sid - 1], cts, dec, es, zs) == [True] * B
+    es2, zs2, cts2 = list(es), list(zs), list(cts)
+    es2[0] ^= 1
+    zs2[1] += 1
+    cts2[2] = cts[3]
+    got = tk.VerifyProofBatch(v, vks[sid - 1], cts2, dec, es2, zs2)
+    assert got[:3] == [False, False, False] and all(got[3:])
+    # wrong verification key (another server's): thresholdkey_test.go:294-327 expects rejection
+    assert tk.VerifyProofBatch(v, vks[sid % total], cts, dec, es, zs) == [False] * B
