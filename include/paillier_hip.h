@@ -171,6 +171,14 @@ int pgpu_ddleq_verify(const pgpu_pubkey* pk, size_t batch, const uint8_t* ct1, c
                       const uint8_t* x, const uint8_t* y, size_t xy_stride, const uint8_t* alpha, size_t alpha_stride,
                       const uint8_t* e, size_t e_stride, const uint8_t* f, size_t f_stride, int32_t* ok, int mem);
 
+/* SecretKey.proveDDLEQInstance for a batch of (statement, instance) pairs (ddleq.go:55-127) with the random draws x, y
+ * supplied: sanity check (a false statement returns PGPU_ERR_INVALID where the reference panics), Alpha, Fiat-Shamir
+ * bit on the device, and for bit = 1 the response (E, F) through the level-two ExtractRandonness (operations.go:75-91).
+ * ct strides = byte length of n^3 (also used for alpha and f_out); a, b, x, y share n_stride; e_stride >= bytes of n^2. */
+int pgpu_ddleq_prove(const pgpu_seckey* sk, size_t batch, const uint8_t* ct1, const uint8_t* ct2, size_t ct_stride,
+                     const uint8_t* a, const uint8_t* b, const uint8_t* x, const uint8_t* y, size_t n_stride, uint8_t* alpha,
+                     uint8_t* e_out, size_t e_stride, uint8_t* f_out, int mem);
+
 /* ---- generic modular batch primitives (the gmp.Int seam: Exp / Mul+Mod) ------------------------ */
 
 /* Load an odd modulus (big-endian).  Precomputes -N^-1 mod 2^28, R mod N, R^2 mod N, R^3 mod N. */

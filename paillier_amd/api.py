@@ -67,6 +67,7 @@ SIGNATURES = {
     "pgpu_ddleq_verify": (_int, [_vp, _sz, _vp, _vp, _sz, _vp, _vp, _sz, _vp, _sz, _vp, _sz, _vp, _sz, _vp, _int]),
     "pgpu_share_zkp_prove": (_int, [_vp, _int, _vp, _sz, _vp, _sz, _sz, _vp, _sz, _vp, _sz, _vp, _sz, _vp, _vp, _sz, _int]),
     "pgpu_share_zkp_verify": (_int, [_vp, _vp, _sz, _vp, _sz, _sz, _vp, _sz, _vp, _sz, _vp, _vp, _sz, _vp, _int]),
+    "pgpu_ddleq_prove": (_int, [_vp, _sz, _vp, _vp, _sz, _vp, _vp, _vp, _vp, _sz, _vp, _vp, _sz, _vp, _int]),
     "pgpu_const_mult": (_int, [_vp, _int, _sz, _vp, _sz, _vp, _sz, _sz, _vp, _sz, _int]),
     "pgpu_modulus_create": (_int, [_vp, _vp, _sz, C.POINTER(_vp)]),
     "pgpu_modulus_destroy": (None, [_vp]),
@@ -417,6 +418,18 @@ class SecretKey:
                     status: Optional[np.ndarray] = None):
         _check(self.ctx.lib.pgpu_decrypt(self.h, level, batch, _ptr(c), c_stride, _ptr(m), m_stride, mem, flags,
                                          _ptr(status) if status is not None else None))
+
+    def ProveDDLEQInstancesBatch(self, ct1s, ct2s, a_s, b_s, xs, ys):
+        """ddleq.go:55-127 for a batch with the draws supplied, on the device.  Returns (alphas, es, fs)."""
+        pk = self.pk
+        cb3, pb1, pb2 = pk.cipher_bytes(ENC_LEVEL_TWO), pk.plain_bytes(ENC_LEVEL_ONE), pk.plain_bytes(ENC_LEVEL_TWO)
+        B = len(ct1s)
+        bufs = [ints_to_be(ct1s, cb3), ints_to_be(ct2s, cb3), ints_to_be(a_s, pb1), ints_to_be(b_s, pb1), ints_to_be(xs, pb1),
+                ints_to_be(ys, pb1)]
+        al, eo, fo = np.zeros((B, cb3), np.uint8), np.zeros((B, pb2), np.uint8), np.zeros((B, cb3), np.uint8)
+        _check(self.ctx.lib.pgpu_ddleq_prove(self.h, B, _ptr(bufs[0]), _ptr(bufs[1]), cb3, _ptr(bufs[2]), _ptr(bufs[3]),
+                                             _ptr(bufs[4]), _ptr(bufs[5]), pb1, _ptr(al), _ptr(eo), pb2, _ptr(fo), MEM_HOST))
+        return be_to_ints(al), be_to_ints(eo), be_to_ints(fo)
 
     def DecryptBatch(self, cts: Sequence[int], level: int = ENC_LEVEL_ONE, flags: int = DECRYPT_DEFAULT,
                      return_status: bool = False):

@@ -1201,6 +1201,28 @@ int pgpu_decrypt(const pgpu_seckey* sk, int level, size_t batch, const uint8_t* 
 
 namespace {
 
+// post <- (1+n)^m mod n^3 = 1 + m n + C(m,2) n^2 (mod n^3) for canonical m < n^2 (mn2.WT limbs)
+void gm2_from_reduced(pgpu_ctx* ctx, const pgpu_pubkey* pk, const uint32_t* mred, size_t nb, uint32_t* post) {
+  const ModCtx &mn = pk->mn, &mn2 = pk->mn2, &mn3 = *pk->mn3;
+  const int W1 = mn.WT, W2 = mn2.WT, W3 = mn3.WT;
+  // t = C(m,2) mod n = (m mod n) ((m-1) mod n) 2^-1 mod n
+  const size_t s1 = (size_t)W1 * nb;
+  uint32_t* mv = ctx->ws_t<uint32_t>(s1 * 4);   // slots: 0 m0, 1 (m0-1) mod n, 2 t, 3 ones
+  reduce_mod(ctx, mn, mred, W2, mv, nb);
+  launch_fill_const(mn.d_consts + (size_t)C_ONE * W1, mv + 3 * s1, W1, nb, ctx->stream);
+  launch_sub_mod(mv, mv + 3 * s1, mn.d_nmod, mv + s1, W1, nb, ctx->stream);
+  Prog pt;
+  pt.op(VM_LOAD, 0); pt.op(VM_MULC, C_R2); pt.op(VM_MUL, 1); pt.op(VM_MULC, (uint32_t)pk->c_inv2R); pt.op(VM_STORE, 2);
+  pt.end();
+  SegSpec st{&mn, &pt, mv, nullptr};
+  run_vm(ctx, nb, st, nullptr, false);
+  launch_canon(mv + 2 * s1, mn.d_nmod, W1, nb, ctx->stream);
+  uint32_t* tmpa = ctx->ws_t<uint32_t>((size_t)W3 * nb);
+  launch_mul_const_add(mred, W2, pk->n_limbs.d, W1, nullptr, 0, 1, tmpa, W3, nb, ctx->stream);            // 1 + m n
+  launch_mul_const_add(mv + 2 * s1, W1, pk->n2_limbs.d, W2, tmpa, W3, 0, post, W3, nb, ctx->stream);      // + t n^2
+  launch_canon(post, mn3.d_nmod, W3, nb, ctx->stream);                                                   // mod n^3
+}
+
 // post <- G^m mod n^(s+1) for G = n + 1 (closed form; paillier.go:213 with the generator the reference always uses):
 //   s = 1: 1 + (m mod n) n                       s = 2: 1 + m n + C(m,2) n^2 (mod n^3), m taken mod n^2
 // `post` has cipher_mod(level).WT limbs per number.
@@ -1232,29 +1254,12 @@ void build_gm(pgpu_ctx* ctx, const pgpu_pubkey* pk, int level, const uint8_t* m,
     launch_mul_const_add(mred, W1, pk->n_limbs.d, W1, nullptr, 0, 1, post, W2, nb, ctx->stream);
     return;
   }
-  const ModCtx& mn3 = *pk->mn3;
-  const int W3 = mn3.WT;
   const size_t mlen = std::min(m_stride, mn2.nbytes);
   uint32_t* ml = ctx->ws_t<uint32_t>((size_t)W2 * nb);
   unpack_operand(ctx, m, m_stride, mlen, batch, mem, ml, W2, nb);
   uint32_t* mred = ctx->ws_t<uint32_t>((size_t)W2 * nb);
   reduce_mod(ctx, mn2, ml, W2, mred, nb);
-  // t = C(m,2) mod n = (m mod n) ((m-1) mod n) 2^-1 mod n
-  const size_t s1 = (size_t)W1 * nb;
-  uint32_t* mv = ctx->ws_t<uint32_t>(s1 * 4);   // slots: 0 m0, 1 (m0-1) mod n, 2 t, 3 ones
-  reduce_mod(ctx, mn, mred, W2, mv, nb);
-  launch_fill_const(mn.d_consts + (size_t)C_ONE * W1, mv + 3 * s1, W1, nb, ctx->stream);
-  launch_sub_mod(mv, mv + 3 * s1, mn.d_nmod, mv + s1, W1, nb, ctx->stream);
-  Prog pt;
-  pt.op(VM_LOAD, 0); pt.op(VM_MULC, C_R2); pt.op(VM_MUL, 1); pt.op(VM_MULC, (uint32_t)pk->c_inv2R); pt.op(VM_STORE, 2);
-  pt.end();
-  SegSpec st{&mn, &pt, mv, nullptr};
-  run_vm(ctx, nb, st, nullptr, false);
-  launch_canon(mv + 2 * s1, mn.d_nmod, W1, nb, ctx->stream);
-  uint32_t* tmpa = ctx->ws_t<uint32_t>((size_t)W3 * nb);
-  launch_mul_const_add(mred, W2, pk->n_limbs.d, W1, nullptr, 0, 1, tmpa, W3, nb, ctx->stream);            // 1 + m n
-  launch_mul_const_add(mv + 2 * s1, W1, pk->n2_limbs.d, W2, tmpa, W3, 0, post, W3, nb, ctx->stream);      // + t n^2
-  launch_canon(post, mn3.d_nmod, W3, nb, ctx->stream);                                                   // mod n^3
+  gm2_from_reduced(ctx, pk, mred, nb, post);
 }
 
 // Fixed-base comb table of h_s for AltEncrypt (paillier.go:416-434: h_1 = (N-H)^N mod N^2, h_2 = (N^2-H)^(N^2) mod N^3):
@@ -1715,6 +1720,154 @@ uint32_t* zkp_hash(pgpu_ctx* ctx, int W2, const uint32_t* a, const uint32_t* b, 
 }
 
 }  // namespace
+
+namespace {
+
+// out = base^e mod N for a shared exponent; base: `wb` limbs (<= 2 WT); canonical result
+void shared_pow(pgpu_ctx* ctx, const ModCtx& mc, const uint32_t* base, int wb, const BigU& e, size_t nb, uint32_t* out) {
+  ModexpPlan pl = modexp_alloc(ctx, mc, nb, 32);
+  const bool wide = wb > mc.WT;
+  launch_copy_limbs(base, 0, std::min(wb, mc.WT), pl.in(), mc.WT, nb, ctx->stream);
+  if (wide) launch_copy_limbs(base, mc.WT, wb - mc.WT, pl.in() + pl.slot_words, mc.WT, nb, ctx->stream);
+  modexp_shared_run(ctx, mc, pl, e, wide, false, true);
+  HIPCHK(hipMemcpyAsync(out, pl.out(), (size_t)mc.WT * nb * 4, hipMemcpyDeviceToDevice, ctx->stream));
+}
+
+uint32_t* zext(pgpu_ctx* ctx, const uint32_t* in, int w, int wo, size_t nb) {
+  uint32_t* o = ctx->ws_t<uint32_t>((size_t)wo * nb);
+  launch_copy_limbs(in, 0, w, o, wo, nb, ctx->stream);
+  return o;
+}
+
+}  // namespace
+
+extern "C" {
+
+int pgpu_ddleq_prove(const pgpu_seckey* sk, size_t batch, const uint8_t* ct1, const uint8_t* ct2, size_t ct_stride,
+                     const uint8_t* a, const uint8_t* b, const uint8_t* x, const uint8_t* y, size_t n_stride, uint8_t* alpha,
+                     uint8_t* e_out, size_t e_stride, uint8_t* f_out, int mem) {
+  if (!sk || !ct1 || !ct2 || !a || !b || !x || !y || !alpha || !e_out || !f_out) return fail(PGPU_ERR_INVALID, "null argument");
+  pgpu_ctx* ctx = sk->ctx;
+  const pgpu_pubkey* pk = sk->pk;
+  return guarded([&] {
+    if (batch == 0) api_throw(PGPU_ERR_INVALID, "empty batch");
+    if (!pk->mn3 || sk->c_mu2R < 0) api_throw(PGPU_ERR_UNSUPPORTED, "level two is not available for this key");
+    if (!pk->g_is_n_plus_1) api_throw(PGPU_ERR_UNSUPPORTED, "DDLEQ prover assumes G = N+1");
+    ctx->bind();
+    ctx->reset_ws();
+    const ModCtx &mn = pk->mn, &mn2 = pk->mn2, &mn3 = *pk->mn3;
+    const int W1 = mn.WT, W2 = mn2.WT, W3 = mn3.WT;
+    const size_t nb = round_up(batch, VM_BLOCK);
+    if (ct_stride != mn3.nbytes) api_throw(PGPU_ERR_INVALID, "ciphertext stride must be the byte length of n^3");
+    if (n_stride * 8 > (size_t)LB * W1 + 7) api_throw(PGPU_ERR_INVALID, "a, b, x, y must fit the width of n");
+    auto up = [&](const uint8_t* buf, size_t stride, int w) {
+      uint32_t* l = ctx->ws_t<uint32_t>((size_t)w * nb);
+      unpack_operand(ctx, buf, stride, stride, batch, mem, l, w, nb);
+      return l;
+    };
+    uint32_t *c1 = up(ct1, ct_stride, W3), *c2 = up(ct2, ct_stride, W3);
+    uint32_t *al = up(a, n_stride, W1), *bl = up(b, n_stride, W1), *xl = up(x, n_stride, W1), *yl = up(y, n_stride, W1);
+    const BigU &N = pk->N, &N2 = mn2.N;
+    // ---- sanity check (ddleq.go:62-69): ct1^(a^n mod n^2) * b^(n^2) mod n^3 == ct2, else the reference panics
+    uint32_t* an = ctx->ws_t<uint32_t>((size_t)W2 * nb);
+    shared_pow(ctx, mn2, al, W1, N, nb, an);
+    uint32_t* bn2 = ctx->ws_t<uint32_t>((size_t)W3 * nb);
+    shared_pow(ctx, mn3, bl, W1, N2, nb, bn2);
+    uint32_t* t3 = ctx->ws_t<uint32_t>((size_t)W3 * nb);
+    perlane_pow(ctx, mn3, c1, an, W2, nb, t3);
+    uint32_t* san = ctx->ws_t<uint32_t>((size_t)W3 * nb);
+    modmul_arrays(ctx, mn3, t3, bn2, nb, san);
+    int32_t* d_ok = ctx->ws_t<int32_t>(nb);
+    launch_equal(san, c2, W3, nb, batch, d_ok, ctx->stream);
+    std::vector<int32_t> hok(batch);
+    HIPCHK(hipMemcpyAsync(hok.data(), d_ok, batch * 4, hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHK(hipStreamSynchronize(ctx->stream));
+    for (size_t i = 0; i < batch; ++i)
+      if (!hok[i]) api_throw(PGPU_ERR_INVALID, "cannot prove re-encryption because inputs are wrong");
+    // ---- alpha = ct1^(x^n) * y^(n^2) mod n^3 (ddleq.go:81-87)
+    uint32_t* xn = ctx->ws_t<uint32_t>((size_t)W2 * nb);
+    shared_pow(ctx, mn2, xl, W1, N, nb, xn);
+    uint32_t* yn2 = ctx->ws_t<uint32_t>((size_t)W3 * nb);
+    shared_pow(ctx, mn3, yl, W1, N2, nb, yn2);
+    perlane_pow(ctx, mn3, c1, xn, W2, nb, t3);
+    uint32_t* alp = ctx->ws_t<uint32_t>((size_t)W3 * nb);
+    modmul_arrays(ctx, mn3, t3, yn2, nb, alp);
+    // ---- challenge bit = LSB SHA-256(ct2 || x || y || alpha)  (ddleq.go:91; ct1 is skipped by the oracle)
+    int32_t* chal = ctx->ws_t<int32_t>(nb);
+    HIPCHK(hipMemsetAsync(chal, 0, nb * 4, ctx->stream));
+    const uint32_t* parts[4] = {c2, xl, yl, alp};
+    const int widths[4] = {W3, W1, W1, W3};
+    launch_sha256_transcript(parts, widths, 4, nb, batch, nullptr, chal, ctx->stream);
+    std::vector<int32_t> hch(batch);
+    HIPCHK(hipMemcpyAsync(hch.data(), chal, batch * 4, hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHK(hipStreamSynchronize(ctx->stream));
+    // default outputs: e = x, f = y (chalBit false)
+    uint32_t* eo = zext(ctx, xl, W1, W2, nb);
+    uint32_t* fo = zext(ctx, yl, W1, W3, nb);
+    std::vector<uint32_t> idx;
+    for (size_t i = 0; i < batch; ++i) if (hch[i]) idx.push_back((uint32_t)i);
+    if (!idx.empty()) {
+      const size_t cnt = idx.size(), nbg = round_up(cnt, VM_BLOCK);
+      uint32_t* d_idx = ctx->upload_words(idx);
+      auto gat = [&](const uint32_t* in, int w) {
+        uint32_t* o = ctx->ws_t<uint32_t>((size_t)w * nbg);
+        launch_gather(in, nb, d_idx, cnt, o, nbg, w, ctx->stream);
+        return o;
+      };
+      uint32_t *ga = gat(al, W1), *gb = gat(bl, W1), *gx = gat(xl, W1), *gy = gat(yl, W1), *gc1 = gat(c1, W3), *gan = gat(an, W2),
+               *gxn = gat(xn, W2);
+      // padding lanes of the compacted batch must be invertible: fill a with 1 there
+      launch_restride(ga, nbg, cnt, mn.d_consts + (size_t)C_ONE * W1, ga, nbg, W1, ctx->stream);
+      // e = x * a^-1 mod n^2 (ddleq.go:94-99)
+      uint32_t* a2 = zext(ctx, ga, W1, W2, nbg);
+      uint32_t* ainv = batch_inverse(ctx, mn2, a2, nbg, cnt);
+      uint32_t* x2 = zext(ctx, gx, W1, W2, nbg);
+      uint32_t* ge = ctx->ws_t<uint32_t>((size_t)W2 * nbg);
+      modmul_arrays(ctx, mn2, x2, ainv, nbg, ge);
+      // s = ExtractRandonness(ct1) at level two (operations.go:75-91)
+      BigU ns_inv;
+      if (!hostbig::modinv(N2 % sk->lambda, sk->lambda, ns_inv)) api_throw(PGPU_ERR_NOT_INVERTIBLE, "n^2 is not invertible mod lambda");
+      uint32_t* v = decrypt2_generic(sk, gc1, nbg, cnt);                       // Decrypt(ct1): W2 limbs
+      uint32_t* gv = ctx->ws_t<uint32_t>((size_t)W3 * nbg);
+      gm2_from_reduced(ctx, pk, v, nbg, gv);                                   // G^v mod n^3
+      launch_restride(gv, nbg, cnt, mn3.d_consts + (size_t)C_ONE * W3, gv, nbg, W3, ctx->stream);
+      uint32_t* gvi = batch_inverse(ctx, mn3, gv, nbg, cnt);
+      uint32_t* z = ctx->ws_t<uint32_t>((size_t)W3 * nbg);
+      modmul_arrays(ctx, mn3, gvi, gc1, nbg, z);
+      uint32_t* z2 = ctx->ws_t<uint32_t>((size_t)W2 * nbg);
+      reduce_mod(ctx, mn2, z, W3, z2, nbg);
+      uint32_t* sres = ctx->ws_t<uint32_t>((size_t)W1 * nbg);
+      shared_pow(ctx, mn, z2, W2, ns_inv, nbg, sres);                          // z^nsInv mod n
+      uint32_t* s3 = zext(ctx, sres, W1, W3, nbg);
+      // c = ((s^an * b)^en)^-1 * s^xn ; f = y * c mod n^3   (ddleq.go:103-114)
+      uint32_t* en = ctx->ws_t<uint32_t>((size_t)W2 * nbg);
+      shared_pow(ctx, mn2, ge, W2, N, nbg, en);
+      uint32_t* cc = ctx->ws_t<uint32_t>((size_t)W3 * nbg);
+      perlane_pow(ctx, mn3, s3, gan, W2, nbg, cc);
+      uint32_t* b3 = zext(ctx, gb, W1, W3, nbg);
+      uint32_t* cb = ctx->ws_t<uint32_t>((size_t)W3 * nbg);
+      modmul_arrays(ctx, mn3, cc, b3, nbg, cb);
+      perlane_pow(ctx, mn3, cb, en, W2, nbg, cc);
+      launch_restride(cc, nbg, cnt, mn3.d_consts + (size_t)C_ONE * W3, cc, nbg, W3, ctx->stream);
+      uint32_t* ci = batch_inverse(ctx, mn3, cc, nbg, cnt);
+      uint32_t* sx = ctx->ws_t<uint32_t>((size_t)W3 * nbg);
+      perlane_pow(ctx, mn3, s3, gxn, W2, nbg, sx);
+      uint32_t* c5 = ctx->ws_t<uint32_t>((size_t)W3 * nbg);
+      modmul_arrays(ctx, mn3, ci, sx, nbg, c5);
+      uint32_t* y3 = zext(ctx, gy, W1, W3, nbg);
+      uint32_t* gf = ctx->ws_t<uint32_t>((size_t)W3 * nbg);
+      modmul_arrays(ctx, mn3, y3, c5, nbg, gf);
+      launch_scatter(ge, nbg, d_idx, cnt, eo, nb, W2, ctx->stream);
+      launch_scatter(gf, nbg, d_idx, cnt, fo, nb, W3, ctx->stream);
+    }
+    pack_result(ctx, alp, W3, nb, batch, alpha, ct_stride, mn3.nbytes, mem);
+    pack_result(ctx, eo, W2, nb, batch, e_out, e_stride, std::min(e_stride, mn2.nbytes), mem);
+    pack_result(ctx, fo, W3, nb, batch, f_out, ct_stride, mn3.nbytes, mem);
+    HIPCHK(hipStreamSynchronize(ctx->stream));
+  });
+}
+
+}  // extern "C"
 
 extern "C" {
 

@@ -195,3 +195,33 @@ def test_share_zkp_device_resident(ctx, bits):
     assert got[:3] == [False, False, False] and all(got[3:])
     # wrong verification key (another server's): thresholdkey_test.go:294-327 expects rejection
     assert tk.VerifyProofBatch(v, vks[sid % total], cts, dec, es, zs) == [False] * B
+
+
+def test_ddleq_prove_on_device(ctx):
+    """pgpu_ddleq_prove (sanity check, Alpha, device Fiat-Shamir bit, level-two ExtractRandonness response) vs the oracle."""
+    import paillier_amd as pa
+    sk_o, p, q = po.keygen_seeded(256, 3)
+    n = sk_o.N
+    pk = pa.PublicKey(ctx, n, n + 1)
+    sk = pa.SecretKey(ctx, pk, sk_o.Lambda)
+    rng = random.Random(23)
+    B = 30
+    ct1 = [po.encrypt_with_r_at_level(sk_o, po.encrypt_with_r(sk_o, rng.randrange(n), po.rand_unit(n, rng)).C,
+                                      po.rand_unit(n, rng), po.ENC_LEVEL_TWO).C for _ in range(B)]
+    a_s = [po.rand_unit(n, rng) for _ in range(B)]
+    b_s = [po.rand_unit(n, rng) for _ in range(B)]
+    ct2 = [po.nested_randomize_with_ab(sk_o, po.Ciphertext(c, 1), a, b).C for c, a, b in zip(ct1, a_s, b_s)]
+    xs = [po.rand_unit(n, rng) for _ in range(B)]
+    ys = [po.rand_unit(n, rng) for _ in range(B)]
+    al, es, fs = sk.ProveDDLEQInstancesBatch(ct1, ct2, a_s, b_s, xs, ys)
+    refs = [po.prove_ddleq_instance_xy(sk_o, po.Ciphertext(c1, 1), po.Ciphertext(c2, 1), a, b, x, y)
+            for c1, c2, a, b, x, y in zip(ct1, ct2, a_s, b_s, xs, ys)]
+    assert al == [r.Alpha for r in refs]
+    assert es == [r.E for r in refs]
+    assert fs == [r.F for r in refs]
+    bits = [r.E != r.X for r in refs]
+    assert any(bits) and not all(bits)
+    assert pk.VerifyDDLEQInstancesBatch(ct1, ct2, xs, ys, al, es, fs) == [True] * B
+    with pytest.raises(pa.PaillierHipError) as ei:     # ddleq.go:68 panics on a false statement
+        sk.ProveDDLEQInstancesBatch(ct1[:3], ct2[1:4], a_s[:3], b_s[:3], xs[:3], ys[:3])
+    assert "cannot prove re-encryption" in str(ei.value)
