@@ -528,44 +528,61 @@ class Gen:
         e(f"v_add_u32 v{g.v_arow}, {rstride}, v{g.v_arow}")
         e(f"v_add_u32 v{g.v_drow}, {rstride}, v{g.v_drow}")
         e("s_mov_b32 s19, 0")
+        N = lambda j: f"s{g.s_N + j}"
+
+        def row_body(tag, parity):
+            """one squaring row; parity: 0 even (diagonal), 1 odd, None decide at run time (odd WT shapes)"""
+            e("s_waitcnt lgkmcnt(0)")
+            e(f"v_add_u32 {ai2}, v{g.v_ain}, v{g.v_ain}")        # 2 * x_i
+            if parity is None:
+                e("s_bitcmp1_b32 s19, 0")
+                e(f"s_cbranch_scc1 L_sq_odd{tag}")
+            if parity in (0, None):
+                self.mad(self.T(0), din, din, self.T(0))          # diagonal x_(i/2)^2 into column i
+                e(f"ds_read_b32 {din}, v{g.v_drow}")
+                e(f"v_add_u32 v{g.v_drow}, {rstride}, v{g.v_drow}")
+            if parity is None:
+                e(f"L_sq_odd{tag}:")
+            e(f"ds_read_b32 v{g.v_ain}, v{g.v_arow}")
+            e(f"v_add_u32 v{g.v_arow}, {rstride}, v{g.v_arow}")
+            e(f"v_mul_lo_u32 {m}, {self.Tlo(0)}, s14")
+            e(f"v_and_b32 {m}, {hex(MASK)}, {m}")
+            # computed jump: enter the pass-A table at entry i+1 (table starts at A_1)
+            e("s_getpc_b64 s[96:97]")
+            e(f"L_sq_ret{tag}:")
+            if parity == 1:
+                e("s_lshl_b32 s98, s19, 3")
+                e("s_add_u32 s98, s98, 8")                        # this body handles row s19 + 1
+            else:
+                e("s_lshl_b32 s98, s19, 3")
+            e("s_add_u32 s96, s96, s98")
+            e("s_addc_u32 s97, s97, 0")
+            e(f"s_add_u32 s96, s96, L_sqA{tag}-L_sq_ret{tag}")
+            e("s_addc_u32 s97, s97, 0")
+            e("s_setpc_b64 s[96:97]")
+            self.align8()
+            e(f"L_sqA{tag}:")
+            for j in range(1, WL):
+                self.mad(self.T(j), ai2, self.X(j), self.T(j))
+            self.mad(self.P(g.v_y0), m, N(0), self.T(0))
+            self.mad(self.T(0), m, N(1), self.T(1))
+            e(f"v_lshrrev_b64 {self.P(g.v_c)}, {LB}, {self.P(g.v_y0)}")
+            for j in range(2, WL):
+                self.mad(self.T(j - 1), m, N(j), self.T(j))
+                if j == 4 or (WL <= 4 and j == WL - 1):
+                    e(f"v_lshl_add_u64 {self.T(0)}, {self.T(0)}, 0, {self.P(g.v_c)}")
+            e(f"v_mov_b64 {self.T(WL - 1)}, 0")
+
         e(".p2align 6")
         e("L_rowsq:")
-        e("s_waitcnt lgkmcnt(0)")
-        e(f"v_add_u32 {ai2}, v{g.v_ain}, v{g.v_ain}")        # 2 * x_i
-        e("s_bitcmp1_b32 s19, 0")
-        e("s_cbranch_scc1 L_sq_odd")
-        self.mad(self.T(0), din, din, self.T(0))          # diagonal x_(i/2)^2 into column i
-        e(f"ds_read_b32 {din}, v{g.v_drow}")
-        e(f"v_add_u32 v{g.v_drow}, {rstride}, v{g.v_drow}")
-        e("L_sq_odd:")
-        e(f"ds_read_b32 v{g.v_ain}, v{g.v_arow}")
-        e(f"v_add_u32 v{g.v_arow}, {rstride}, v{g.v_arow}")
-        e(f"v_mul_lo_u32 {m}, {self.Tlo(0)}, s14")
-        e(f"v_and_b32 {m}, {hex(MASK)}, {m}")
-        # computed jump: enter the pass-A table at entry i+1 (table starts at A_1)
-        e("s_getpc_b64 s[96:97]")
-        e("L_sq_ret:")
-        e("s_lshl_b32 s98, s19, 3")
-        e("s_add_u32 s96, s96, s98")
-        e("s_addc_u32 s97, s97, 0")
-        e("s_add_u32 s96, s96, L_sqA-L_sq_ret")
-        e("s_addc_u32 s97, s97, 0")
-        e("s_setpc_b64 s[96:97]")
-        self.align8()
-        e("L_sqA:")
-        for j in range(1, WL):
-            self.mad(self.T(j), ai2, self.X(j), self.T(j))
-        e("L_sqB:")
-        N = lambda j: f"s{g.s_N + j}"
-        self.mad(self.P(g.v_y0), m, N(0), self.T(0))
-        self.mad(self.T(0), m, N(1), self.T(1))
-        e(f"v_lshrrev_b64 {self.P(g.v_c)}, {LB}, {self.P(g.v_y0)}")
-        for j in range(2, WL):
-            self.mad(self.T(j - 1), m, N(j), self.T(j))
-            if j == 4 or (WL <= 4 and j == WL - 1):
-                e(f"v_lshl_add_u64 {self.T(0)}, {self.T(0)}, 0, {self.P(g.v_c)}")
-        e(f"v_mov_b64 {self.T(WL - 1)}, 0")
-        e("s_add_u32 s19, s19, 1")
+        if WT % 2 == 0:
+            # even and odd rows as two bodies: no parity branch, half the back edges (taken branches cost fetch bubbles)
+            row_body("_e", 0)
+            row_body("_o", 1)
+            e("s_add_u32 s19, s19, 2")
+        else:
+            row_body("", None)
+            e("s_add_u32 s19, s19, 1")
         e(f"s_cmp_lt_u32 s19, {WT}")
         e("s_cbranch_scc1 L_rowsq")
         e("s_waitcnt lgkmcnt(0)")

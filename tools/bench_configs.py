@@ -139,9 +139,19 @@ if "ddleq2048" in which:  # BASELINE config 5 (per-instance throughput, secpar =
         assert rc == 0, ctx.lib.pgpu_last_error()
     t_vd = timed(vrun, reps=2)
     assert okh.all()
+    # device-resident prover through the C ABI
+    da, db = tb(a_s, pb1), tb(b_s, pb1)
+    oa = torch.zeros((B, cb3), dtype=torch.uint8, device=dev); oe = torch.zeros((B, pb2), dtype=torch.uint8, device=dev)
+    of = torch.zeros((B, cb3), dtype=torch.uint8, device=dev)
+    def prun():
+        rc = ctx.lib.pgpu_ddleq_prove(sk.h, B, d[0].data_ptr(), d[1].data_ptr(), cb3, da.data_ptr(), db.data_ptr(), d[2].data_ptr(),
+                                      d[3].data_ptr(), pb1, oa.data_ptr(), oe.data_ptr(), pb2, of.data_ptr(), MEM_DEVICE)
+        assert rc == 0, ctx.lib.pgpu_last_error()
+    t_pd = timed(prun, reps=1)
+    assert torch.equal(oa, d[4]) and torch.equal(oe, d[5]) and torch.equal(of, d[6]), "device prover differs from the host-orchestrated one"
     ref = po.prove_ddleq_instance_xy(sk_o, po.Ciphertext(ct1[0], 1), po.Ciphertext(ct2[0], 1), a_s[0], b_s[0], xs[0], ys[0])
     assert (proofs[0].Alpha, proofs[0].E, proofs[0].F) == (ref.Alpha, ref.E, ref.F)
     print(json.dumps({"config": f"DDLEQ 2048-bit, {B} instances (secpar=1 each), int-list API incl. host packing",
                       "prove_instances_per_s": B / t_p, "verify_instances_per_s_host_orchestrated": B / t_v,
-                      "verify_instances_per_s_device_resident": B / t_vd,
+                      "verify_instances_per_s_device_resident": B / t_vd, "prove_instances_per_s_device_resident": B / t_pd,
                       "parity": "all verify; instance 0 vs oracle"}), flush=True)
