@@ -1792,7 +1792,7 @@ int pgpu_ddleq_prove(const pgpu_seckey* sk, size_t batch, const uint8_t* ct1, co
     perlane_pow(ctx, mn3, c1, xn, W2, nb, t3);
     uint32_t* alp = ctx->ws_t<uint32_t>((size_t)W3 * nb);
     modmul_arrays(ctx, mn3, t3, yn2, nb, alp);
-    // ---- challenge bit = LSB SHA-256(ct2 || x || y || alpha)  (ddleq.go:91; ct1 is skipped by the oracle)
+    // ---- challenge bit = LSB SHA-256(ct2 || x || y || alpha)  (ddleq.go:91; ct1 is skipped: random_oracle.go:24-26)
     int32_t* chal = ctx->ws_t<int32_t>(nb);
     HIPCHK(hipMemsetAsync(chal, 0, nb * 4, ctx->stream));
     const uint32_t* parts[4] = {c2, xl, yl, alp};

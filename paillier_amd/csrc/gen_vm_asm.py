@@ -42,6 +42,7 @@ class Gen:
         self.flush_every = 48
         self.sq_rows = (K == 1)  # dedicated squaring rows (symmetric products computed once)
         self.lines = []
+        self.deferred = []
         self.name = f"vm_asm_{WL}_{K}"
         # ---- VGPR map: t[] pairs, x[], then scalars; pairs are even-aligned
         self.vX = 2 * WL
@@ -399,98 +400,110 @@ class Gen:
         e(f"ds_read_b32 v{g.v_ain}, v{g.v_arow}")
         e(f"v_add_u32 v{g.v_arow}, {rstride}, v{g.v_arow}")
         e(f"s_mov_b32 s19, 0")
+        unroll2 = (self.WT % 2 == 0)
+
+        def gen_row(v_ai_cur, v_ai_next, swap_by_mov):
+            """one generic row; a_i is in v_ai_next on entry (prefetched).  swap_by_mov: copy it into v_ai_cur first
+            (single-body loop); otherwise the two bodies of the unrolled loop simply alternate the two registers."""
+            q = []
+
+            def wait_for(tag):
+                idx = max(i for i, t in enumerate(q) if t == tag)
+                after = len(q) - 1 - idx
+                e(f"s_waitcnt lgkmcnt({after})")
+                del q[: idx + 1]
+
+            e("s_waitcnt lgkmcnt(0)")
+            if swap_by_mov:
+                e(f"v_mov_b32 v{v_ai_cur}, v{v_ai_next}")
+                ai_reg, pre_reg = v_ai_cur, v_ai_next
+            else:
+                ai_reg, pre_reg = v_ai_next, v_ai_cur      # use the prefetched register directly; prefetch into the other
+            e(f"ds_read_b32 v{pre_reg}, v{g.v_arow}")
+            q.append("ain")
+            e(f"v_add_u32 v{g.v_arow}, {rstride}, v{g.v_arow}")
+            nchunks = (WL + 3) // 4
+            issued = 0
+            if not self.n_sgpr and not self.n_vreg:
+                for cidx in range(min(g.NBUF, nchunks)):
+                    e(f"ds_read_b128 v[{g.nbuf[cidx % g.NBUF]}:{g.nbuf[cidx % g.NBUF] + 3}], v{g.v_nbase} offset:{16 * cidx}")
+                    q.append(("n", cidx))
+                    issued += 1
+
+            def N(j):
+                if self.n_sgpr:
+                    return f"s{g.s_N + j}"
+                if self.n_vreg:
+                    return f"v{g.v_N + j}"
+                return f"v{g.nbuf[(j // 4) % g.NBUF] + (j % 4)}"
+
+            ai = f"v{ai_reg}"
+            m = f"v{g.v_m}"
+
+            def A(j):
+                if j == WL - 1 and K == 1:
+                    self.mad(self.T(j), ai, self.X(j), "0")
+                else:
+                    self.mad(self.T(j), ai, self.X(j), self.T(j))
+
+            state = {"issued": issued}
+
+            def B(j):
+                if not self.n_sgpr and not self.n_vreg and j % 4 == 0:
+                    wait_for(("n", j // 4))
+                if j == 0:
+                    self.mad(self.P(g.v_y0), m, N(0), self.T(0))
+                elif j == 1:
+                    self.mad(self.T(0), m, N(1), self.T(1))
+                else:
+                    self.mad(self.T(j - 1), m, N(j), self.T(j))
+                if not self.n_sgpr and not self.n_vreg and j % 4 == 3 and state["issued"] < nchunks:
+                    cidx = state["issued"]
+                    e(f"ds_read_b128 v[{g.nbuf[cidx % g.NBUF]}:{g.nbuf[cidx % g.NBUF] + 3}], v{g.v_nbase} offset:{16 * cidx}")
+                    q.append(("n", cidx))
+                    state["issued"] += 1
+
+            D = min(self.depth, WL)
+            self.align8()
+            for j in range(D):
+                A(j)
+            e(f"v_mul_lo_u32 {m}, {self.Tlo(0)}, s14")
+            e(f"v_and_b32 {m}, {hex(MASK)}, {m}")
+            if K > 1:
+                bc = {2: "[0,0,2,2]", 4: "[0,0,0,0]"}[K]
+                e("s_nop 1")
+                e(f"v_mov_b32_dpp {m}, {m} quad_perm:{bc} row_mask:0xf bank_mask:0xf")
+                self.align8()
+            nextA = D
+            for j in range(WL):
+                B(j)
+                if j == 0:
+                    e(f"v_lshrrev_b64 {self.P(g.v_c)}, {LB}, {self.P(g.v_y0)}")
+                    if K > 1:
+                        e(f"v_and_b32 v{g.v_c}, v{g.v_c}, v{g.v_isfirst}")
+                        e(f"v_and_b32 v{g.v_c + 1}, v{g.v_c + 1}, v{g.v_isfirst}")
+                if nextA < WL:
+                    A(nextA)
+                    nextA += 1
+                if j == 1:
+                    e(f"v_lshl_add_u64 {self.T(0)}, {self.T(0)}, 0, {self.P(g.v_c)}")
+            if K > 1:
+                fn = {2: "[1,1,3,3]", 4: "[1,2,3,3]"}[K]
+                e(f"v_mov_b32_dpp {self.Tlo(WL - 1)}, v{g.v_y0} quad_perm:{fn} row_mask:0xf bank_mask:0xf")
+                e(f"v_mov_b32_dpp {self.Thi(WL - 1)}, v{g.v_y0 + 1} quad_perm:{fn} row_mask:0xf bank_mask:0xf")
+                e(f"v_and_b32 {self.Tlo(WL - 1)}, {self.Tlo(WL - 1)}, v{g.v_notlast}")
+                e(f"v_and_b32 {self.Thi(WL - 1)}, {self.Thi(WL - 1)}, v{g.v_notlast}")
+
         e(".p2align 6")
         e("L_row:")
-        # LDS queue model: list of destination tags in issue order
-        q = []
-
-        def wait_for(tag):
-            idx = max(i for i, t in enumerate(q) if t == tag)
-            after = len(q) - 1 - idx
-            e(f"s_waitcnt lgkmcnt({after})")
-            del q[: idx + 1]
-
-        e("s_waitcnt lgkmcnt(0)")
-        e(f"v_mov_b32 v{g.v_ai}, v{g.v_ain}")
-        e(f"ds_read_b32 v{g.v_ain}, v{g.v_arow}")
-        q.append("ain")
-        e(f"v_add_u32 v{g.v_arow}, {rstride}, v{g.v_arow}")
-        nchunks = (WL + 3) // 4
-        issued = 0
-        if not self.n_sgpr and not self.n_vreg:
-            for cidx in range(min(g.NBUF, nchunks)):
-                e(f"ds_read_b128 v[{g.nbuf[cidx % g.NBUF]}:{g.nbuf[cidx % g.NBUF] + 3}], v{g.v_nbase} offset:{16 * cidx}")
-                q.append(("n", cidx))
-                issued += 1
-
-        def N(j):
-            if self.n_sgpr:
-                return f"s{g.s_N + j}"
-            if self.n_vreg:
-                return f"v{g.v_N + j}"
-            return f"v{g.nbuf[(j // 4) % g.NBUF] + (j % 4)}"
-
-        ai = f"v{g.v_ai}"
-        m = f"v{g.v_m}"
-
-        def A(j):
-            if j == WL - 1 and K == 1:
-                self.mad(self.T(j), ai, self.X(j), "0")
-            else:
-                self.mad(self.T(j), ai, self.X(j), self.T(j))
-
-        state = {"issued": issued}
-
-        def B(j):
-            if not self.n_sgpr and not self.n_vreg and j % 4 == 0:
-                wait_for(("n", j // 4))
-            if j == 0:
-                self.mad(self.P(g.v_y0), m, N(0), self.T(0))
-            elif j == 1:
-                self.mad(self.T(0), m, N(1), self.T(1))
-            else:
-                self.mad(self.T(j - 1), m, N(j), self.T(j))
-            if not self.n_sgpr and not self.n_vreg and j % 4 == 3 and state["issued"] < nchunks:
-                cidx = state["issued"]
-                # buffer (cidx % 4) was last used by chunk cidx-4 < j//4: free
-                e(f"ds_read_b128 v[{g.nbuf[cidx % g.NBUF]}:{g.nbuf[cidx % g.NBUF] + 3}], v{g.v_nbase} offset:{16 * cidx}")
-                q.append(("n", cidx))
-                state["issued"] += 1
-
-        D = min(self.depth, WL)
-        self.align8()
-        for j in range(D):
-            A(j)
-            if j == 1 or (D == 1 and j == 0):
-                pass
-        # quotient digit
-        e(f"v_mul_lo_u32 {m}, {self.Tlo(0)}, s14")
-        e(f"v_and_b32 {m}, {hex(MASK)}, {m}")
-        if K > 1:
-            bc = {2: "[0,0,2,2]", 4: "[0,0,0,0]"}[K]
-            e("s_nop 1")
-            e(f"v_mov_b32_dpp {m}, {m} quad_perm:{bc} row_mask:0xf bank_mask:0xf")
-            self.align8()
-        nextA = D
-        for j in range(WL):
-            B(j)
-            if j == 0:
-                e(f"v_lshrrev_b64 {self.P(g.v_c)}, {LB}, {self.P(g.v_y0)}")
-                if K > 1:
-                    e(f"v_and_b32 v{g.v_c}, v{g.v_c}, v{g.v_isfirst}")
-                    e(f"v_and_b32 v{g.v_c + 1}, v{g.v_c + 1}, v{g.v_isfirst}")
-            if nextA < WL:
-                A(nextA)
-                nextA += 1
-            if j == 1:
-                e(f"v_lshl_add_u64 {self.T(0)}, {self.T(0)}, 0, {self.P(g.v_c)}")
-        if K > 1:
-            fn = {2: "[1,1,3,3]", 4: "[1,2,3,3]"}[K]
-            e(f"v_mov_b32_dpp {self.Tlo(WL - 1)}, v{g.v_y0} quad_perm:{fn} row_mask:0xf bank_mask:0xf")
-            e(f"v_mov_b32_dpp {self.Thi(WL - 1)}, v{g.v_y0 + 1} quad_perm:{fn} row_mask:0xf bank_mask:0xf")
-            e(f"v_and_b32 {self.Tlo(WL - 1)}, {self.Tlo(WL - 1)}, v{g.v_notlast}")
-            e(f"v_and_b32 {self.Thi(WL - 1)}, {self.Thi(WL - 1)}, v{g.v_notlast}")
-        e("s_add_u32 s19, s19, 1")
+        if unroll2:
+            # two row bodies alternate the a_i registers (no copy) and halve the taken back edges
+            gen_row(g.v_ai, g.v_ain, False)
+            gen_row(g.v_ain, g.v_ai, False)
+            e("s_add_u32 s19, s19, 2")
+        else:
+            gen_row(g.v_ai, g.v_ain, True)
+            e("s_add_u32 s19, s19, 1")
         if self.flush:
             self.flush_block()
         e(f"s_cmp_lt_u32 s19, {self.WT}")
@@ -501,6 +514,8 @@ class Gen:
             e(f"v_mov_b64 {self.T(WL - 1)}, 0")
         self.normalize()
         e("s_branch L_next")
+        self.lines.extend(self.deferred)
+        self.deferred = []
 
     # ---------------------------------------------------------------------------------------------
     def montsq(self):
@@ -601,7 +616,11 @@ class Gen:
         e(f"s_mul_hi_u32 s{g.s_t0}, s19, {((1 << 32) + self.flush_every - 1) // self.flush_every}")  # s19 / fe
         e(f"s_mul_i32 s{g.s_t0}, s{g.s_t0}, {self.flush_every}")
         e(f"s_cmp_lg_u32 s{g.s_t0}, s19")
-        e("s_cbranch_scc1 L_noflush")
+        e("s_cbranch_scc0 L_doflush")      # rare; the common path falls through (a taken branch costs a fetch bubble)
+        e("L_noflush:")
+        main = self.lines
+        self.lines = self.deferred          # the flush body is emitted out of line, after the product
+        e("L_doflush:")
         top = WL - 1
         if K > 1:
             # top_c = (t[top] >> 28) & notlast ; t[top] &= (MASK | ~notlast)
@@ -626,7 +645,8 @@ class Gen:
             e(f"v_and_b32 v{g.v_p0}, v{g.v_p0}, v{g.v_t1}")
             e(f"v_and_b32 v{g.v_p0 + 1}, v{g.v_p0 + 1}, v{g.v_t1}")
             e(f"v_lshl_add_u64 {self.T(0)}, {self.T(0)}, 0, {self.P(g.v_p0)}")
-        e("L_noflush:")
+        e("s_branch L_noflush")
+        self.lines = main
 
     def normalize(self):
         """x_j = ((lo_j + mid_{j-1} + hi_{j-2}) & M) + ((lo_{j-1} + mid_{j-2} + hi_{j-3}) >> 28)"""
