@@ -140,7 +140,7 @@ def main():
     alg_bytes = cb + pb  # read c (n^2 bytes) + write m (n bytes)
     roofline = {
         "bound": "valu",  # integer multiply issue (v_mad_u64_u32); neither HBM nor MFMA binds
-        "kernel": "vm_kernel<74,1> (CRT modexp over p^2 and q^2)" if args.bits == 2048 else "vm_kernel",
+        "kernel": "vm_asm_74_1 (CRT modexp over p^2 and q^2, both halves in one launch)" if args.bits == 2048 else "vm_asm (CRT modexp over p^2 and q^2)",
         "achieved": achieved / 1e12,
         "peak": PEAK_MAD_PER_S / 1e12,
         "unit": "Tmul32/s",

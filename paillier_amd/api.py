@@ -263,6 +263,30 @@ class PublicKey:
         self.encrypt_with_r_raw(len(ms), mb, pb, rb, pb, out, cb, MEM_HOST, level)
         return be_to_ints(out)
 
+    # -- forms that draw their own randomness on the host, as the reference does with crypto/rand -----------------
+    def random_units(self, count: int) -> List[int]:
+        """utils.go:36-49 GetRandomNumberInMultiplicativeGroup: uniform r in [0, n) with r != 0 and gcd(r, n) = 1."""
+        import math
+        import secrets
+        out = []
+        while len(out) < count:
+            r = secrets.randbelow(self.N)
+            if r != 0 and math.gcd(r, self.N) == 1:
+                out.append(r)
+        return out
+
+    def EncryptBatch(self, ms: Sequence[int], level: int = ENC_LEVEL_ONE) -> List[int]:
+        """paillier.go:192-194,258-269 EncryptAtLevel for each m (fresh r per ciphertext from the host CSPRNG)."""
+        return self.EncryptWithRBatch(ms, self.random_units(len(ms)), level)
+
+    def NestedEncryptBatch(self, ms: Sequence[int]) -> List[int]:
+        """paillier.go:199-203: level-one encryption, then level-two encryption of the ciphertext value."""
+        return self.EncryptBatch(self.EncryptBatch(ms, ENC_LEVEL_ONE), ENC_LEVEL_TWO)
+
+    def RandomizeBatch(self, cts: Sequence[int], level: int = ENC_LEVEL_ONE) -> List[int]:
+        """operations.go:67-69: Add(ct, Encrypt(0))."""
+        return self.AddBatch(cts, self.EncryptBatch([0] * len(cts), level), level)
+
     def AltEncryptWithRBatch(self, ms: Sequence[int], rs: Sequence[int], level: int = ENC_LEVEL_ONE):
         """paillier.go:221-238 for each (m, r); returns (ciphertexts, r mod K) -- the reference overwrites r in place."""
         pb, cb = self.plain_bytes(level), self.cipher_bytes(level)
@@ -418,6 +442,16 @@ class SecretKey:
                     status: Optional[np.ndarray] = None):
         _check(self.ctx.lib.pgpu_decrypt(self.h, level, batch, _ptr(c), c_stride, _ptr(m), m_stride, mem, flags,
                                          _ptr(status) if status is not None else None))
+
+    def NestedDecryptBatch(self, cts: Sequence[int]) -> List[int]:
+        """paillier.go:344-355: peel the level-two layer, then decrypt at level one (0 stays 0: the reference's edge case)."""
+        layer = self.DecryptBatch(cts, level=ENC_LEVEL_TWO)
+        nz = [i for i, v in enumerate(layer) if v != 0]
+        out = [0] * len(layer)
+        if nz:
+            for i, v in zip(nz, self.DecryptBatch([layer[i] for i in nz], level=ENC_LEVEL_ONE)):
+                out[i] = v
+        return out
 
     def ProveDDLEQInstancesBatch(self, ct1s, ct2s, a_s, b_s, xs, ys):
         """ddleq.go:55-127 for a batch with the draws supplied, on the device.  Returns (alphas, es, fs)."""

@@ -243,6 +243,41 @@ void emit_modexp_shared(Prog& p, const BigU& e, uint32_t in_lo, uint32_t in_hi, 
     return;
   }
   emit_to_mont(p, in_lo, in_hi, tmp);
+  if (skip_zero_digits && e.bit_length() >= 64) {
+    // PUBLIC exponent (n, n^2, ...): sliding window over odd powers -- the operation sequence depends on the exponent's
+    // bits, which is fine for public values and never used for lambda, p-1 or key shares.
+    // table slot tab+k holds x^(2k+1); slot tab+31 holds x^2 during the build (sw <= 5 uses at most 16 odd powers)
+    const int sw = 5;
+    const uint32_t nodd = 1u << (sw - 1);
+    p.op(VM_STORE, tab + 0);          // x^1
+    p.op(VM_SQR);
+    p.op(VM_STORE, tab + 31);         // x^2
+    p.op(VM_LOAD, tab + 0);
+    for (uint32_t k = 1; k < nodd; ++k) {
+      p.op(VM_MUL, tab + 31);
+      p.op(VM_STORE, tab + k);        // x^(2k+1)
+    }
+    long i = (long)e.bit_length() - 1;
+    bool first = true;
+    while (i >= 0) {
+      if (!e.bit((size_t)i)) { p.op(VM_SQR); --i; continue; }
+      long l = std::max<long>(i - sw + 1, 0);
+      while (!e.bit((size_t)l)) ++l;                    // window [l, i] ends in a one bit
+      uint32_t val = 0;
+      for (long b = i; b >= l; --b) val = (val << 1) | (uint32_t)e.bit((size_t)b);
+      if (first) {
+        p.op(VM_LOAD, tab + (val >> 1));
+        first = false;
+      } else {
+        for (long b = i; b >= l; --b) p.op(VM_SQR);
+        p.op(VM_MUL, tab + (val >> 1));
+      }
+      i = l - 1;
+    }
+    if (post_slot != NO_SLOT) p.op(VM_MUL, post_slot); else p.op(VM_MULC, C_ONE);
+    p.op(VM_STORE, out);
+    return;
+  }
   const size_t ebits = e.bit_length();
   const size_t nwin = (ebits + w - 1) / w;
   auto digit = [&](size_t i_from_top) {

@@ -106,3 +106,22 @@ def test_generator_other_than_n_plus_1_and_nested_sub(ctx):
     other = [po.encrypt_with_r(sk_o, 3, r).C for r in rs[:4]]
     assert pk1.NestedSubBatch(outer, other) == [
         po.nested_sub(sk_o, po.Ciphertext(a, po.ENC_LEVEL_TWO), po.Ciphertext(b)).C for a, b in zip(outer, other)]
+
+
+def test_host_randomness_forms(ctx):
+    """Encrypt / NestedEncrypt / Randomize draw r on the host (as the reference does with crypto/rand); results are checked
+    by decryption, the property the reference's own randomized tests check (paillier_test.go:52-87, operations_test.go:92-110)."""
+    import paillier_amd as pa
+    sk_o, p, q = po.keygen_seeded(1024, 1)
+    n = sk_o.N
+    pk = pa.PublicKey(ctx, n, n + 1)
+    sk = pa.SecretKey(ctx, pk, sk_o.Lambda)
+    rng = random.Random(4)
+    ms = [rng.randrange(n) for _ in range(30)] + [0, 1]
+    cts = pk.EncryptBatch(ms)
+    assert sk.DecryptBatch(cts) == ms and len(set(cts)) == len(cts)
+    rer = pk.RandomizeBatch(cts)
+    assert rer != cts and sk.DecryptBatch(rer) == ms
+    nested = pk.NestedEncryptBatch(ms)
+    assert sk.NestedDecryptBatch(nested) == ms
+    assert sk.NestedDecryptBatch(nested[:2]) == [po.nested_decrypt(sk_o, po.Ciphertext(c, po.ENC_LEVEL_TWO)) for c in nested[:2]]
