@@ -196,3 +196,59 @@ def verify_ddleq_instances(pk: PublicKey, ct1s: Sequence[int], ct2s: Sequence[in
     fn2 = mods.m3.exp_batch([p.F for p in proofs], mods.n2)
     got = mods.m3.mul_batch(mods.m3.exp_batch(check, en), fn2)
     return [g == p.Alpha for g, p in zip(got, proofs)]
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# whole-protocol forms with the reference's signatures (randomness drawn on the host, as crypto/rand does there)
+# ---------------------------------------------------------------------------------------------------------------
+
+def prove_ddleq(sk: SecretKey, secpar: int, ct1: int, ct2: int, a: int, b: int) -> List[DDLEQProofInstance]:
+    """ddleq.go:27-40 ProveDDLEQ: `secpar` independent instances for ONE statement, proved as one device batch."""
+    xs, ys = sk.pk.random_units(secpar), sk.pk.random_units(secpar)
+    al, es, fs = sk.ProveDDLEQInstancesBatch([ct1] * secpar, [ct2] * secpar, [a] * secpar, [b] * secpar, xs, ys)
+    return [DDLEQProofInstance(x, y, A, e, f) for x, y, A, e, f in zip(xs, ys, al, es, fs)]
+
+
+def verify_ddleq_proof(pk: PublicKey, ct1: int, ct2: int, proof: Sequence[DDLEQProofInstance]) -> bool:
+    """ddleq.go:44-53 VerifyDDLEQProof: every instance must verify."""
+    k = len(proof)
+    if k == 0:
+        return True
+    return all(pk.VerifyDDLEQInstancesBatch([ct1] * k, [ct2] * k, [p.X for p in proof], [p.Y for p in proof],
+                                            [p.Alpha for p in proof], [p.E for p in proof], [p.F for p in proof]))
+
+
+def combine_partial_decryptions_zkp(tk: ThresholdPublicKey, verification_key: int, verification_keys: Sequence[int],
+                                    shares: Sequence[Sequence[PartialDecryptionZKP]]) -> List[int]:
+    """thresholdkey.go:164-172 CombinePartialDecryptionsZKP for a batch of ciphertexts.  shares[k] = the proofs of server k
+    (one per ciphertext, same ciphertext order).  A server whose proof fails for a ciphertext is dropped FOR THAT ciphertext,
+    as the reference drops it; ciphertexts are regrouped by their surviving server set and combined per group."""
+    B = len(shares[0])
+    valid = []
+    for srv in shares:
+        sid = srv[0].ID
+        valid.append(tk.VerifyProofBatch(verification_key, verification_keys[sid - 1], [p.C for p in srv],
+                                         [p.Decryption for p in srv], [p.E for p in srv], [p.Z for p in srv]))
+    groups = {}
+    for i in range(B):
+        key = tuple(k for k in range(len(shares)) if valid[k][i])
+        groups.setdefault(key, []).append(i)
+    out: List[Optional[int]] = [None] * B
+    for key, idxs in groups.items():
+        sub = [(shares[k][0].ID, [shares[k][i].Decryption for i in idxs]) for k in key]
+        res = tk.CombinePartialDecryptionsBatch(sub)      # raises PaillierHipError(-6) when fewer than Threshold survive
+        for i, v in zip(idxs, res):
+            out[i] = v
+    return out  # type: ignore[return-value]
+
+
+def verify_decryption(tk: ThresholdPublicKey, verification_key: int, verification_keys: Sequence[int], encrypted: Sequence[int],
+                      decrypted: Sequence[int], shares: Sequence[Sequence[PartialDecryptionZKP]]) -> None:
+    """thresholdkey.go:175-189 VerifyDecryption for a batch; raises ValueError with the reference's messages."""
+    for srv in shares:
+        for p, c in zip(srv, encrypted):
+            if p.C != c:
+                raise ValueError("The encrypted message is not the same than the one in the shares")
+    res = combine_partial_decryptions_zkp(tk, verification_key, verification_keys, shares)
+    if list(res) != list(decrypted):
+        raise ValueError("The decrypted message is not the same than the one in the shares")

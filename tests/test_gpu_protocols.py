@@ -225,3 +225,48 @@ def test_ddleq_prove_on_device(ctx):
     with pytest.raises(pa.PaillierHipError) as ei:     # ddleq.go:68 panics on a false statement
         sk.ProveDDLEQInstancesBatch(ct1[:3], ct2[1:4], a_s[:3], b_s[:3], xs[:3], ys[:3])
     assert "cannot prove re-encryption" in str(ei.value)
+
+
+def test_whole_protocol_forms(ctx):
+    """ProveDDLEQ / VerifyDDLEQProof with host-drawn randomness (ddleq_test.go:9-72) and CombinePartialDecryptionsZKP /
+    VerifyDecryption (thresholdkey_test.go:294-394): completeness, and a cheating server being dropped."""
+    import paillier_amd as pa
+    from paillier_amd import protocols as pr
+    # DDLEQ, secpar = 10 as in the reference's tests
+    sk_o, p, q = po.keygen_seeded(256, 3)
+    n = sk_o.N
+    pk = pa.PublicKey(ctx, n, n + 1)
+    sk = pa.SecretKey(ctx, pk, sk_o.Lambda)
+    rng = random.Random(41)
+    ct1 = pk.NestedEncryptBatch([1234])[0]
+    a, b = po.rand_unit(n, rng), po.rand_unit(n, rng)
+    ct2 = pr.nested_randomize_with_ab_batch(pk, [ct1], [a], [b])[0]
+    proof = pr.prove_ddleq(sk, 10, ct1, ct2, a, b)
+    assert pr.verify_ddleq_proof(pk, ct1, ct2, proof)
+    assert po.verify_ddleq_proof(sk_o, po.Ciphertext(ct1, 1), po.Ciphertext(ct2, 1),
+                                 [po.DDLEQProofInstance(i.X, i.Y, i.Alpha, i.E, i.F) for i in proof])
+    other = pr.nested_randomize_with_ab_batch(pk, [pk.NestedEncryptBatch([1235])[0]], [a], [b])[0]
+    assert not pr.verify_ddleq_proof(pk, ct1, other, proof)
+    # threshold with proofs
+    k = json.load(open(os.path.join(G, "keys.json")))["threshold"]["512"]
+    tn, total, thr = int(k["n"], 16), k["total"], k["threshold"]
+    shares = [int(s, 16) for s in k["shares"]]
+    v, vks = int(k["v"], 16), [int(x, 16) for x in k["vks"]]
+    tk = pa.ThresholdPublicKey(ctx, tn, total=total, threshold=thr)
+    ms = [rng.randrange(tn) for _ in range(6)]
+    cts = tk.EncryptBatch(ms)
+    def proofs_of(sid):
+        rs = [rng.randrange(tn * tn) for _ in cts]
+        d, es, zs = tk.PartialDecryptionWithZKPBatch(sid, shares[sid - 1], v, cts, rs)
+        return [pr.PartialDecryptionZKP(sid, di, ei, zi, ci) for di, ei, zi, ci in zip(d, es, zs, cts)]
+    srv = [proofs_of(s) for s in (1, 2, 4, 5)]
+    assert pr.combine_partial_decryptions_zkp(tk, v, vks, srv) == ms
+    pr.verify_decryption(tk, v, vks, cts, ms, srv)
+    srv[1][3].Decryption ^= 2          # server 2 cheats on ciphertext 3: dropped there, the other three still reach t = 3
+    assert pr.combine_partial_decryptions_zkp(tk, v, vks, srv) == ms
+    srv[0][3].Z += 1                   # a second bad proof on the same ciphertext: only 2 < t shares survive
+    with pytest.raises(pa.PaillierHipError) as ei:
+        pr.combine_partial_decryptions_zkp(tk, v, vks, srv)
+    assert ei.value.code == -6
+    with pytest.raises(ValueError):
+        pr.verify_decryption(tk, v, vks, cts[::-1], ms, [proofs_of(1), proofs_of(2), proofs_of(3)])
