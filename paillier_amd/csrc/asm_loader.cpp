@@ -12,7 +12,8 @@ struct Blob { int wl, k; const unsigned char* data; size_t size; const char* nam
 #include "vm_asm_blobs.inc"   // defines: static const Blob kBlobs[]; static const int kNumBlobs;
 
 struct Loaded { hipModule_t mod = nullptr; hipFunction_t fn = nullptr; bool tried = false; };
-Loaded g_loaded[16];
+constexpr int kMaxDevices = 16;
+Loaded g_loaded[16][kMaxDevices];   // a hipModule belongs to one device: load per (shape, device)
 std::mutex g_mu;
 
 int find_blob(int wl, int k) {
@@ -27,9 +28,13 @@ bool vm_asm_available(int wl, int k) { return find_blob(wl, k) >= 0; }
 hipError_t launch_vm_asm(int wl, int k, const VmArgs& a, uint32_t blocks, hipStream_t st) {
   int i = find_blob(wl, k);
   if (i < 0) return hipErrorInvalidValue;
+  int dev = 0;
+  hipError_t de = hipGetDevice(&dev);
+  if (de != hipSuccess) return de;
+  if (dev < 0 || dev >= kMaxDevices) return hipErrorInvalidDevice;
   {
     std::lock_guard<std::mutex> lk(g_mu);
-    Loaded& L = g_loaded[i];
+    Loaded& L = g_loaded[i][dev];
     if (!L.tried) {
       L.tried = true;
       hipError_t e = hipModuleLoadData(&L.mod, kBlobs[i].data);
@@ -42,5 +47,5 @@ hipError_t launch_vm_asm(int wl, int k, const VmArgs& a, uint32_t blocks, hipStr
   VmArgs args = a;
   size_t size = sizeof(VmArgs);
   void* extra[] = {HIP_LAUNCH_PARAM_BUFFER_POINTER, &args, HIP_LAUNCH_PARAM_BUFFER_SIZE, &size, HIP_LAUNCH_PARAM_END};
-  return hipModuleLaunchKernel(g_loaded[i].fn, blocks, 1, 1, VM_BLOCK, 1, 1, 0, st, nullptr, extra);
+  return hipModuleLaunchKernel(g_loaded[i][dev].fn, blocks, 1, 1, VM_BLOCK, 1, 1, 0, st, nullptr, extra);
 }

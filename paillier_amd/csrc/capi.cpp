@@ -140,7 +140,7 @@ struct ModCtx {
   void init(pgpu_ctx* c, const BigU& n) {
     ctx = c;
     N = n;
-    if (!N.is_odd() || N.bit_length() < 8) api_throw(PGPU_ERR_INVALID, "modulus must be odd and at least 8 bits");
+    if (!N.is_odd() || N.bit_length() < 2) api_throw(PGPU_ERR_INVALID, "modulus must be odd and at least 3");
     nbits = N.bit_length();
     nbytes = (nbits + 7) / 8;
     if (!pick_shape(nbits, WL, K)) api_throw(PGPU_ERR_UNSUPPORTED, "modulus wider than 9293 bits is not built");

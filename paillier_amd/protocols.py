@@ -252,3 +252,11 @@ def verify_decryption(tk: ThresholdPublicKey, verification_key: int, verificatio
     res = combine_partial_decryptions_zkp(tk, verification_key, verification_keys, shares)
     if list(res) != list(decrypted):
         raise ValueError("The decrypted message is not the same than the one in the shares")
+
+
+def create_verification_keys(tk: ThresholdPublicKey, v: int, shares: Sequence[int]) -> List[int]:
+    """thresholdkey_generator.go:246-254 createVerificationKeys: v_i = v^(l! * s_i) mod n^2 for every server, as one batch
+    with per-server exponents (the modexp-heavy part of threshold key generation; l = 100 in the
+    reference's tests)."""
+    delta = _factorial(tk.TotalNumberOfDecryptionServers)
+    return _mods(tk).m2.exp_batch([v] * len(shares), [s * delta for s in shares])

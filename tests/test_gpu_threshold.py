@@ -67,3 +67,19 @@ def test_partial_decrypt_and_combine_all_subsets(ctx, bits):
     got = tk.CombinePartialDecryptionsBatch(bad)
     want = [po.combine_partial_decryptions(tsks[0], [po.PartialDecryption(i, d[j]) for i, d in bad]) for j in range(len(ms))]
     assert got == want
+
+
+def test_create_verification_keys_kat_and_large(ctx):
+    """thresholdkey_generator_test.go:314-324 through the GPU (v = 54, n^2 = 101^2, l = 10, shares (12, 90, 103) -> (6162, 304,
+    2728)), and a 100-server key as in thresholdkey_test.go:329-355."""
+    import paillier_amd as pa
+    from paillier_amd import protocols as pr
+    tk = pa.ThresholdPublicKey(ctx, 101, total=10, threshold=1)
+    assert pr.create_verification_keys(tk, 54, [12, 90, 103]) == [6162, 304, 2728]
+    k = json.load(open(os.path.join(G, "keys.json")))["threshold"]["512"]
+    n = int(k["n"], 16)
+    tk = pa.ThresholdPublicKey(ctx, n, total=100, threshold=75)
+    rng = random.Random(100)
+    shares = [rng.randrange(n * n) for _ in range(100)]
+    v = int(k["v"], 16)
+    assert pr.create_verification_keys(tk, v, shares) == po.tkg_create_verification_keys(v, n * n, 100, shares)
