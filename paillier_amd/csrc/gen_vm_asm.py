@@ -41,13 +41,18 @@ class Gen:
         self.flush = (2 * self.WT + 1) > 255
         self.flush_every = 48
         self.sq_rows = (K == 1)  # dedicated squaring rows (symmetric products computed once)
+        # multi-lane squaring (last-slice rows use the triangular skip): pays for K == 2 (-12.5 % multiplies; measured
+        # +7.8 % on Decrypt-3072); for K == 4 the saving (6 %) is eaten by the per-row multiplier preparation (measured -7 %
+        # on the 16k threshold batch), so those shapes keep the generic unrolled rows
+        self.sq_rows_k = (K == 2 and WL <= 55)
         self.lines = []
         self.deferred = []
         self.name = f"vm_asm_{WL}_{K}"
         # ---- VGPR map: t[] pairs, x[], then scalars; pairs are even-aligned
         self.vX = 2 * WL
         e = 3 * WL
-        singles = ["ai", "ain", "m", "t1"] + (["din", "drow"] if K == 1 else [])
+        singles = ["ai", "ain", "m", "t1"] + (["din", "drow"] if K == 1 else []) + \
+                  (["k", "sh", "mk", "mult", "km2", "islast"] if (K == 2 and WL <= 55) else [])
         for nm in singles:
             setattr(self, "v_" + nm, e)
             e += 1
@@ -166,6 +171,12 @@ class Gen:
         e(f"v_cmp_ne_u32 vcc, {K - 1}, v{g.v_t1}")
         e("s_nop 1")
         e(f"v_cndmask_b32 v{g.v_notlast}, 0, -1, vcc")
+        if self.sq_rows_k:
+            e(f"v_mov_b32 v{g.v_k}, v{g.v_t1}")
+            e(f"v_not_b32 v{g.v_islast}, v{g.v_notlast}")
+            e(f"v_cmp_eq_u32 vcc, {K - 2}, v{g.v_t1}")
+            e("s_nop 1")
+            e(f"v_cndmask_b32 v{g.v_km2}, 0, -1, vcc")
         if self.n_sgpr:
             # modulus -> SGPRs s[20: 20+WL)
             off, s = 0, self.s_N
@@ -385,9 +396,107 @@ class Gen:
 
         e("L_sqr:")
         self.stage_to_lds(Xs)
-        e("s_branch L_montsq" if self.sq_rows else "s_branch L_montmul")
+        e("s_branch L_montsq" if (self.sq_rows or self.sq_rows_k) else "s_branch L_montmul")
 
     # ---------------------------------------------------------------------------------------------
+    def gen_row(self, v_ai_cur, v_ai_next, swap_by_mov, mult_prep=None):
+        """one generic row; a_i is in v_ai_next on entry (prefetched).  swap_by_mov: copy it into v_ai_cur first
+        (single-body loop); otherwise the two bodies of the unrolled loop simply alternate the two registers."""
+        g = self
+        e = self.e
+        WL, K, NPB = self.WL, self.K, self.NPB
+        rstride = NPB * 4
+        q = []
+
+        def wait_for(tag):
+            idx = max(i for i, t in enumerate(q) if t == tag)
+            after = len(q) - 1 - idx
+            e(f"s_waitcnt lgkmcnt({after})")
+            del q[: idx + 1]
+
+        e("s_waitcnt lgkmcnt(0)")
+        if swap_by_mov:
+            e(f"v_mov_b32 v{v_ai_cur}, v{v_ai_next}")
+            ai_reg, pre_reg = v_ai_cur, v_ai_next
+        else:
+            ai_reg, pre_reg = v_ai_next, v_ai_cur      # use the prefetched register directly; prefetch into the other
+        e(f"ds_read_b32 v{pre_reg}, v{g.v_arow}")
+        q.append("ain")
+        e(f"v_add_u32 v{g.v_arow}, {rstride}, v{g.v_arow}")
+        nchunks = (WL + 3) // 4
+        issued = 0
+        if not self.n_sgpr and not self.n_vreg:
+            for cidx in range(min(g.NBUF, nchunks)):
+                e(f"ds_read_b128 v[{g.nbuf[cidx % g.NBUF]}:{g.nbuf[cidx % g.NBUF] + 3}], v{g.v_nbase} offset:{16 * cidx}")
+                q.append(("n", cidx))
+                issued += 1
+
+        def N(j):
+            if self.n_sgpr:
+                return f"s{g.s_N + j}"
+            if self.n_vreg:
+                return f"v{g.v_N + j}"
+            return f"v{g.nbuf[(j // 4) % g.NBUF] + (j % 4)}"
+
+        ai = f"v{ai_reg}"
+        if mult_prep is not None:
+            ai = mult_prep(ai)           # per-lane multiplier derived from a_i (multi-lane squaring)
+        m = f"v{g.v_m}"
+
+        def A(j):
+            if j == WL - 1 and K == 1:
+                self.mad(self.T(j), ai, self.X(j), "0")
+            else:
+                self.mad(self.T(j), ai, self.X(j), self.T(j))
+
+        state = {"issued": issued}
+
+        def B(j):
+            if not self.n_sgpr and not self.n_vreg and j % 4 == 0:
+                wait_for(("n", j // 4))
+            if j == 0:
+                self.mad(self.P(g.v_y0), m, N(0), self.T(0))
+            elif j == 1:
+                self.mad(self.T(0), m, N(1), self.T(1))
+            else:
+                self.mad(self.T(j - 1), m, N(j), self.T(j))
+            if not self.n_sgpr and not self.n_vreg and j % 4 == 3 and state["issued"] < nchunks:
+                cidx = state["issued"]
+                e(f"ds_read_b128 v[{g.nbuf[cidx % g.NBUF]}:{g.nbuf[cidx % g.NBUF] + 3}], v{g.v_nbase} offset:{16 * cidx}")
+                q.append(("n", cidx))
+                state["issued"] += 1
+
+        D = min(self.depth, WL)
+        self.align8()
+        for j in range(D):
+            A(j)
+        e(f"v_mul_lo_u32 {m}, {self.Tlo(0)}, s14")
+        e(f"v_and_b32 {m}, {hex(MASK)}, {m}")
+        if K > 1:
+            bc = {2: "[0,0,2,2]", 4: "[0,0,0,0]"}[K]
+            e("s_nop 1")
+            e(f"v_mov_b32_dpp {m}, {m} quad_perm:{bc} row_mask:0xf bank_mask:0xf")
+            self.align8()
+        nextA = D
+        for j in range(WL):
+            B(j)
+            if j == 0:
+                e(f"v_lshrrev_b64 {self.P(g.v_c)}, {LB}, {self.P(g.v_y0)}")
+                if K > 1:
+                    e(f"v_and_b32 v{g.v_c}, v{g.v_c}, v{g.v_isfirst}")
+                    e(f"v_and_b32 v{g.v_c + 1}, v{g.v_c + 1}, v{g.v_isfirst}")
+            if nextA < WL:
+                A(nextA)
+                nextA += 1
+            if j == 1:
+                e(f"v_lshl_add_u64 {self.T(0)}, {self.T(0)}, 0, {self.P(g.v_c)}")
+        if K > 1:
+            fn = {2: "[1,1,3,3]", 4: "[1,2,3,3]"}[K]
+            e(f"v_mov_b32_dpp {self.Tlo(WL - 1)}, v{g.v_y0} quad_perm:{fn} row_mask:0xf bank_mask:0xf")
+            e(f"v_mov_b32_dpp {self.Thi(WL - 1)}, v{g.v_y0 + 1} quad_perm:{fn} row_mask:0xf bank_mask:0xf")
+            e(f"v_and_b32 {self.Tlo(WL - 1)}, {self.Tlo(WL - 1)}, v{g.v_notlast}")
+            e(f"v_and_b32 {self.Thi(WL - 1)}, {self.Thi(WL - 1)}, v{g.v_notlast}")
+
     def montmul(self):
         g = self
         e = self.e
@@ -402,107 +511,15 @@ class Gen:
         e(f"s_mov_b32 s19, 0")
         unroll2 = (self.WT % 2 == 0)
 
-        def gen_row(v_ai_cur, v_ai_next, swap_by_mov):
-            """one generic row; a_i is in v_ai_next on entry (prefetched).  swap_by_mov: copy it into v_ai_cur first
-            (single-body loop); otherwise the two bodies of the unrolled loop simply alternate the two registers."""
-            q = []
-
-            def wait_for(tag):
-                idx = max(i for i, t in enumerate(q) if t == tag)
-                after = len(q) - 1 - idx
-                e(f"s_waitcnt lgkmcnt({after})")
-                del q[: idx + 1]
-
-            e("s_waitcnt lgkmcnt(0)")
-            if swap_by_mov:
-                e(f"v_mov_b32 v{v_ai_cur}, v{v_ai_next}")
-                ai_reg, pre_reg = v_ai_cur, v_ai_next
-            else:
-                ai_reg, pre_reg = v_ai_next, v_ai_cur      # use the prefetched register directly; prefetch into the other
-            e(f"ds_read_b32 v{pre_reg}, v{g.v_arow}")
-            q.append("ain")
-            e(f"v_add_u32 v{g.v_arow}, {rstride}, v{g.v_arow}")
-            nchunks = (WL + 3) // 4
-            issued = 0
-            if not self.n_sgpr and not self.n_vreg:
-                for cidx in range(min(g.NBUF, nchunks)):
-                    e(f"ds_read_b128 v[{g.nbuf[cidx % g.NBUF]}:{g.nbuf[cidx % g.NBUF] + 3}], v{g.v_nbase} offset:{16 * cidx}")
-                    q.append(("n", cidx))
-                    issued += 1
-
-            def N(j):
-                if self.n_sgpr:
-                    return f"s{g.s_N + j}"
-                if self.n_vreg:
-                    return f"v{g.v_N + j}"
-                return f"v{g.nbuf[(j // 4) % g.NBUF] + (j % 4)}"
-
-            ai = f"v{ai_reg}"
-            m = f"v{g.v_m}"
-
-            def A(j):
-                if j == WL - 1 and K == 1:
-                    self.mad(self.T(j), ai, self.X(j), "0")
-                else:
-                    self.mad(self.T(j), ai, self.X(j), self.T(j))
-
-            state = {"issued": issued}
-
-            def B(j):
-                if not self.n_sgpr and not self.n_vreg and j % 4 == 0:
-                    wait_for(("n", j // 4))
-                if j == 0:
-                    self.mad(self.P(g.v_y0), m, N(0), self.T(0))
-                elif j == 1:
-                    self.mad(self.T(0), m, N(1), self.T(1))
-                else:
-                    self.mad(self.T(j - 1), m, N(j), self.T(j))
-                if not self.n_sgpr and not self.n_vreg and j % 4 == 3 and state["issued"] < nchunks:
-                    cidx = state["issued"]
-                    e(f"ds_read_b128 v[{g.nbuf[cidx % g.NBUF]}:{g.nbuf[cidx % g.NBUF] + 3}], v{g.v_nbase} offset:{16 * cidx}")
-                    q.append(("n", cidx))
-                    state["issued"] += 1
-
-            D = min(self.depth, WL)
-            self.align8()
-            for j in range(D):
-                A(j)
-            e(f"v_mul_lo_u32 {m}, {self.Tlo(0)}, s14")
-            e(f"v_and_b32 {m}, {hex(MASK)}, {m}")
-            if K > 1:
-                bc = {2: "[0,0,2,2]", 4: "[0,0,0,0]"}[K]
-                e("s_nop 1")
-                e(f"v_mov_b32_dpp {m}, {m} quad_perm:{bc} row_mask:0xf bank_mask:0xf")
-                self.align8()
-            nextA = D
-            for j in range(WL):
-                B(j)
-                if j == 0:
-                    e(f"v_lshrrev_b64 {self.P(g.v_c)}, {LB}, {self.P(g.v_y0)}")
-                    if K > 1:
-                        e(f"v_and_b32 v{g.v_c}, v{g.v_c}, v{g.v_isfirst}")
-                        e(f"v_and_b32 v{g.v_c + 1}, v{g.v_c + 1}, v{g.v_isfirst}")
-                if nextA < WL:
-                    A(nextA)
-                    nextA += 1
-                if j == 1:
-                    e(f"v_lshl_add_u64 {self.T(0)}, {self.T(0)}, 0, {self.P(g.v_c)}")
-            if K > 1:
-                fn = {2: "[1,1,3,3]", 4: "[1,2,3,3]"}[K]
-                e(f"v_mov_b32_dpp {self.Tlo(WL - 1)}, v{g.v_y0} quad_perm:{fn} row_mask:0xf bank_mask:0xf")
-                e(f"v_mov_b32_dpp {self.Thi(WL - 1)}, v{g.v_y0 + 1} quad_perm:{fn} row_mask:0xf bank_mask:0xf")
-                e(f"v_and_b32 {self.Tlo(WL - 1)}, {self.Tlo(WL - 1)}, v{g.v_notlast}")
-                e(f"v_and_b32 {self.Thi(WL - 1)}, {self.Thi(WL - 1)}, v{g.v_notlast}")
-
         e(".p2align 6")
         e("L_row:")
         if unroll2:
             # two row bodies alternate the a_i registers (no copy) and halve the taken back edges
-            gen_row(g.v_ai, g.v_ain, False)
-            gen_row(g.v_ain, g.v_ai, False)
+            self.gen_row(g.v_ai, g.v_ain, False)
+            self.gen_row(g.v_ain, g.v_ai, False)
             e("s_add_u32 s19, s19, 2")
         else:
-            gen_row(g.v_ai, g.v_ain, True)
+            self.gen_row(g.v_ai, g.v_ain, True)
             e("s_add_u32 s19, s19, 1")
         if self.flush:
             self.flush_block()
@@ -607,7 +624,116 @@ class Gen:
         self.normalize()
         e("s_branch L_next")
 
-    def flush_block(self):
+    # ---------------------------------------------------------------------------------------------
+    def montsq_k(self):
+        """x <- x*x*R^-1 for K > 1 lanes per number (modulus slice in VGPRs), using the symmetry of the square at slice
+        granularity.  Slice b of lane b holds x^(b).  For the rows whose multiplier a_i comes from slice a:
+          lane b == a : plain products a_i * x^(a)_j          (the (a,a) block as an ordinary product)
+          lane b >  a : doubled products 2 a_i * x^(b)_j      (each cross block computed once)
+          lane b <  a : multiplier 0                           (its cross blocks were done in earlier rows)
+        and for a == K-1 (the last slice) every other lane is idle, so those rows use the triangular form of the K == 1
+        kernel: a computed jump skips the entries j <= i' and the diagonal x_i^2 -- whose column 2i is >= WT -- is added
+        after the last row.  A-pass entries: (K - 1/2) WL^2 per lane instead of K WL^2."""
+        g = self
+        e = self.e
+        WL, K, WT = self.WL, self.K, self.WT
+        assert self.n_vreg
+        rstride = self.NPB * 4
+        m = f"v{g.v_m}"
+        N = lambda j: f"v{g.v_N + j}"
+        e("L_montsq:")
+        for j in range(WL):
+            e(f"v_mov_b64 {self.T(j)}, 0")
+        e(f"v_mov_b32 v{g.v_arow}, v{g.v_aread}")
+        e(f"ds_read_b32 v{g.v_ain}, v{g.v_arow}")
+        e(f"v_add_u32 v{g.v_arow}, {rstride}, v{g.v_arow}")
+        e("s_mov_b32 s19, 0")
+
+        def prep(ai):
+            e(f"v_lshlrev_b32 v{g.v_mult}, v{g.v_sh}, {ai}")
+            e(f"v_and_b32 v{g.v_mult}, v{g.v_mult}, v{g.v_mk}")
+            return f"v{g.v_mult}"
+
+        for a in range(K - 1):
+            # per-lane shift / mask for the rows of slice a
+            e(f"v_cmp_lt_u32 vcc, {a}, v{g.v_k}")          # k > a
+            e("s_nop 1")
+            e(f"v_cndmask_b32 v{g.v_sh}, 0, 1, vcc")
+            e(f"v_cmp_le_u32 vcc, {a}, v{g.v_k}")          # k >= a
+            e("s_nop 1")
+            e(f"v_cndmask_b32 v{g.v_mk}, 0, -1, vcc")
+            e(".p2align 6")
+            e(f"L_sqk_{a}:")
+            self.gen_row(g.v_ai, g.v_ain, True, mult_prep=prep)
+            e("s_add_u32 s19, s19, 1")
+            if self.flush:
+                self.flush_block(tag=f"_k{a}")
+            e(f"s_cmp_lt_u32 s19, {(a + 1) * WL}")
+            e(f"s_cbranch_scc1 L_sqk_{a}")
+        # ---- rows of the last slice: triangular
+        ai2 = f"v{g.v_mult}"
+        e(".p2align 6")
+        e("L_sqk_last:")
+        e("s_waitcnt lgkmcnt(0)")
+        e(f"v_add_u32 {ai2}, v{g.v_ain}, v{g.v_ain}")
+        e(f"v_and_b32 {ai2}, {ai2}, v{g.v_islast}")
+        e(f"ds_read_b32 v{g.v_ain}, v{g.v_arow}")
+        e(f"v_add_u32 v{g.v_arow}, {rstride}, v{g.v_arow}")
+        e(f"v_mul_lo_u32 {m}, {self.Tlo(0)}, s14")
+        e(f"v_and_b32 {m}, {hex(MASK)}, {m}")
+        bc = {2: "[0,0,2,2]", 4: "[0,0,0,0]"}[K]
+        e("s_nop 1")
+        e(f"v_mov_b32_dpp {m}, {m} quad_perm:{bc} row_mask:0xf bank_mask:0xf")
+        e("s_getpc_b64 s[96:97]")
+        e("L_sqk_ret:")
+        e(f"s_sub_u32 s98, s19, {(K - 1) * WL}")            # i' = row index inside the last slice
+        e("s_lshl_b32 s98, s98, 3")
+        e("s_add_u32 s96, s96, s98")
+        e("s_addc_u32 s97, s97, 0")
+        e("s_add_u32 s96, s96, L_sqkA-L_sqk_ret")
+        e("s_addc_u32 s97, s97, 0")
+        e("s_setpc_b64 s[96:97]")
+        self.align8()
+        e("L_sqkA:")
+        for j in range(1, WL):
+            self.mad(self.T(j), ai2, self.X(j), self.T(j))
+        self.mad(self.P(g.v_y0), m, N(0), self.T(0))
+        self.mad(self.T(0), m, N(1), self.T(1))
+        e(f"v_lshrrev_b64 {self.P(g.v_c)}, {LB}, {self.P(g.v_y0)}")
+        e(f"v_and_b32 v{g.v_c}, v{g.v_c}, v{g.v_isfirst}")
+        e(f"v_and_b32 v{g.v_c + 1}, v{g.v_c + 1}, v{g.v_isfirst}")
+        for j in range(2, WL):
+            self.mad(self.T(j - 1), m, N(j), self.T(j))
+            if j == 4 or (WL <= 4 and j == WL - 1):
+                e(f"v_lshl_add_u64 {self.T(0)}, {self.T(0)}, 0, {self.P(g.v_c)}")
+        fn = {2: "[1,1,3,3]", 4: "[1,2,3,3]"}[K]
+        e(f"v_mov_b32_dpp {self.Tlo(WL - 1)}, v{g.v_y0} quad_perm:{fn} row_mask:0xf bank_mask:0xf")
+        e(f"v_mov_b32_dpp {self.Thi(WL - 1)}, v{g.v_y0 + 1} quad_perm:{fn} row_mask:0xf bank_mask:0xf")
+        e(f"v_and_b32 {self.Tlo(WL - 1)}, {self.Tlo(WL - 1)}, v{g.v_notlast}")
+        e(f"v_and_b32 {self.Thi(WL - 1)}, {self.Thi(WL - 1)}, v{g.v_notlast}")
+        e("s_add_u32 s19, s19, 1")
+        if self.flush:
+            self.flush_block(tag="_klast")
+        e(f"s_cmp_lt_u32 s19, {WT}")
+        e("s_cbranch_scc1 L_sqk_last")
+        e("s_waitcnt lgkmcnt(0)")
+        # ---- diagonals of the last slice: x_i^2 (i = (K-1) WL + i') belongs to column 2i, final position 2i - WT
+        for ip in range(WL):
+            pos = (K - 2) * WL + 2 * ip
+            lane, local = pos // WL, pos % WL
+            if lane == K - 1:
+                e(f"v_and_b32 v{g.v_t1}, {self.X(ip)}, v{g.v_islast}")
+            else:
+                assert lane == K - 2
+                e(f"v_mov_b32_dpp v{g.v_t1}, {self.X(ip)} quad_perm:{fn} row_mask:0xf bank_mask:0xf")
+                e(f"v_and_b32 v{g.v_t1}, v{g.v_t1}, v{g.v_km2}")
+            self.mad(self.T(local), f"v{g.v_t1}", f"v{g.v_t1}", self.T(local))
+        self.normalize()
+        e("s_branch L_next")
+        self.lines.extend(self.deferred)
+        self.deferred = []
+
+    def flush_block(self, tag=""):
         """every flush_every rows: push bits >= 2^28 of every accumulator one column up"""
         g = self
         e = self.e
@@ -616,11 +742,11 @@ class Gen:
         e(f"s_mul_hi_u32 s{g.s_t0}, s19, {((1 << 32) + self.flush_every - 1) // self.flush_every}")  # s19 / fe
         e(f"s_mul_i32 s{g.s_t0}, s{g.s_t0}, {self.flush_every}")
         e(f"s_cmp_lg_u32 s{g.s_t0}, s19")
-        e("s_cbranch_scc0 L_doflush")      # rare; the common path falls through (a taken branch costs a fetch bubble)
-        e("L_noflush:")
+        e(f"s_cbranch_scc0 L_doflush{tag}")      # rare; the common path falls through (a taken branch costs a fetch bubble)
+        e(f"L_noflush{tag}:")
         main = self.lines
         self.lines = self.deferred          # the flush body is emitted out of line, after the product
-        e("L_doflush:")
+        e(f"L_doflush{tag}:")
         top = WL - 1
         if K > 1:
             # top_c = (t[top] >> 28) & notlast ; t[top] &= (MASK | ~notlast)
@@ -645,7 +771,7 @@ class Gen:
             e(f"v_and_b32 v{g.v_p0}, v{g.v_p0}, v{g.v_t1}")
             e(f"v_and_b32 v{g.v_p0 + 1}, v{g.v_p0 + 1}, v{g.v_t1}")
             e(f"v_lshl_add_u64 {self.T(0)}, {self.T(0)}, 0, {self.P(g.v_p0)}")
-        e("s_branch L_noflush")
+        e(f"s_branch L_noflush{tag}")
         self.lines = main
 
     def normalize(self):
@@ -762,6 +888,8 @@ class Gen:
         self.montmul()
         if self.sq_rows:
             self.montsq()
+        if self.sq_rows_k:
+            self.montsq_k()
         self.epilogue()
         return "\n".join(self.lines) + "\n"
 
