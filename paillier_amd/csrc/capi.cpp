@@ -1200,8 +1200,11 @@ int pgpu_decrypt(const pgpu_seckey* sk, int level, size_t batch, const uint8_t* 
     int32_t* d_status = ctx->ws_t<int32_t>(nb);
     HIPCHK(hipMemsetAsync(d_status, 0, nb * 4, ctx->stream));
     const bool crt = sk->has_crt && !(flags & PGPU_DECRYPT_NO_CRT);
-    const int WC = pk->mn2.WT;  // == 2 * mp2.WT when CRT is available
-    if (crt && 2 * sk->mp2.WT != WC) api_throw(PGPU_ERR_UNSUPPORTED, "CRT and generic layouts disagree");
+    // CRT consumes c as two chunks of WT(p^2) limbs (c = lo + hi * R_p); WT(n^2) <= 2 WT(p^2) always, with equality for
+    // real key sizes and strict inequality for toy keys where every modulus gets the minimum shape: zero-extend.
+    const int WG = pk->mn2.WT;
+    const int WC = crt ? 2 * sk->mp2.WT : WG;
+    if (WC < WG) api_throw(PGPU_ERR_UNSUPPORTED, "CRT and generic layouts disagree");
     uint32_t* cl = ctx->ws_t<uint32_t>((size_t)WC * nb);
     // the ciphertext is the last cbytes of each element (values >= n^2 are reduced implicitly)
     unpack_operand(ctx, c, c_stride, cbytes, batch, mem, cl, WC, nb);
@@ -1218,8 +1221,8 @@ int pgpu_decrypt(const pgpu_seckey* sk, int level, size_t batch, const uint8_t* 
         // gcd(c, n) != 1 on these lanes: the CRT shortcut (L exact) does not apply; run the reference formula on them
         const size_t nbg = round_up(idx.size(), VM_BLOCK);
         uint32_t* d_idx = ctx->upload_words(idx);
-        uint32_t* cg = ctx->ws_t<uint32_t>((size_t)WC * nbg);
-        launch_gather(cl, nb, d_idx, idx.size(), cg, nbg, WC, ctx->stream);
+        uint32_t* cg = ctx->ws_t<uint32_t>((size_t)WG * nbg);
+        launch_gather(cl, nb, d_idx, idx.size(), cg, nbg, WG, ctx->stream);   // the low WT(n^2) limbs hold all of c
         uint32_t* rg = decrypt1_generic(sk, cg, nbg, idx.size());
         launch_scatter(rg, nbg, d_idx, idx.size(), res, nb, pk->mn.WT, ctx->stream);
       }

@@ -215,3 +215,28 @@ def test_empty_and_bad_arguments(ctx, key1024):
         pa.Modulus(ctx, 1 << 1024)
     with pytest.raises(pa.PaillierHipError):     # modulus wider than the built kernels
         pa.Modulus(ctx, (1 << 12000) + 1)
+
+
+@pytest.mark.parametrize("bits", [64, 128, 256])
+def test_fresh_small_keys_properties(ctx, bits):
+    """The reference's randomised tests draw a fresh 64-bit key per iteration (paillier_test.go:52-138,
+    operations_test.go:11-128): round trips and homomorphic identities for several fresh small keys, both levels."""
+    import paillier_amd as pa
+    for it in range(6):
+        sk_o, p, q = po.keygen_seeded(bits, 1000 * bits + it)
+        n = sk_o.N
+        rng = random.Random(it)
+        pk = pa.PublicKey(ctx, n, n + 1)
+        sk = pa.SecretKey(ctx, pk, sk_o.Lambda)
+        ms = [rng.randrange(n) for _ in range(9)] + [0, n - 1]
+        rs = [po.rand_unit(n, rng) for _ in ms]
+        cts = pk.EncryptWithRBatch(ms, rs)
+        assert cts == [po.encrypt_with_r(sk_o, m, r).C for m, r in zip(ms, rs)]
+        assert sk.DecryptBatch(cts) == ms
+        assert sk.DecryptBatch(pk.AddBatch(cts, cts[::-1])) == [(a + b) % n for a, b in zip(ms, ms[::-1])]
+        assert sk.DecryptBatch(pk.SubBatch(cts, cts[::-1])) == [(a - b) % n for a, b in zip(ms, ms[::-1])]
+        k = rng.randrange(n)
+        assert sk.DecryptBatch(pk.ConstMultBatch(cts, k)) == [m * k % n for m in ms]
+        c2 = pk.EncryptWithRBatch(cts, rs, level=pa.ENC_LEVEL_TWO)            # nested (paillier_test.go:65-87)
+        assert c2 == [po.encrypt_with_r_at_level(sk_o, c, r, po.ENC_LEVEL_TWO).C for c, r in zip(cts, rs)]
+        assert sk.NestedDecryptBatch(c2) == ms
