@@ -153,7 +153,7 @@ def main():
         # HBM bytes per launch from the PMC passes of this same command (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate
         # runs, 2 x FETCH_SIZE gfx950 correction): profiles/r01_bench_pmc_summary.txt.  It is the per-lane window table
         # (written once, ~240 entry reads per modexp), not re-reads of the inputs.  Only known for the default workload.
-        "traffic": 1.02e10 if (args.bits == 2048 and B == 65536) else None,
+        "traffic": 1.022e10 if (args.bits == 2048 and B == 65536) else None,
         "hbm": {"achieved": alg_bytes * B / (vm_ms_avg * 1e-3) / 1e9, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                 "frac": alg_bytes * B / (vm_ms_avg * 1e-3) / 1e9 / HBM_PEAK_GBPS, "alg_bytes_per_decrypt": alg_bytes},
     }

@@ -382,7 +382,10 @@ void run_vm(pgpu_ctx* ctx, size_t nb, const SegSpec& s0, const SegSpec* s1, bool
     // v_mad_u64_u32 lane-ops executed: 2 WT^2 per product; the assembly kernel's K == 1 squaring rows use the
     // symmetry of the square: WL^2 (reduction) + WL(WL-1)/2 + WL (product)
     const double full = 2.0 * mc->WT * mc->WT;
-    const double sq = (use_asm && K == 1) ? (double)mc->WT * mc->WT + 0.5 * mc->WT * (mc->WT - 1) + mc->WT : full;
+    // squaring rows: K == 1 triangular (WT^2 + WT(WT-1)/2 + WT); K == 2 slice-level symmetry (product part 1.5 WL^2 per lane)
+    double sq = full;
+    if (use_asm && K == 1) sq = (double)mc->WT * mc->WT + 0.5 * mc->WT * (mc->WT - 1) + mc->WT;
+    else if (use_asm && K == 2 && WL <= 55) sq = (double)mc->WT * mc->WT * (2.0 - 1.0 / (2 * K)) + WL;
     ev->mads = ((montmuls - sqrs) * full + sqrs * sq) * (double)launch_nb;
     HIPCHK(hipEventRecord(ev->a, ctx->stream));
   }
