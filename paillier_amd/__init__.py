@@ -13,6 +13,9 @@ from .api import (  # noqa: F401
     PublicKey,
     SecretKey,
     ThresholdPublicKey,
+    DECRYPT_DEFAULT,
+    DECRYPT_NO_CRT,
+    LANE_NONUNIT,
     ENC_LEVEL_ONE,
     ENC_LEVEL_TWO,
     MEM_DEVICE,

@@ -21,6 +21,7 @@ MEM_HOST = 0
 MEM_DEVICE = 1
 DECRYPT_DEFAULT = 0
 DECRYPT_NO_CRT = 1
+LANE_NONUNIT = 1
 
 
 class PaillierHipError(RuntimeError):

@@ -480,6 +480,16 @@ struct pgpu_seckey {
   int c_muR = -1;                // lambda^-1 mod n, times R mod n, in pk->mn
   DevLimbs n_minus_mu;           // (n - mu) mod n, the answer for c == 0 (L(-1) = -1)
   int c_mu2R = -1;               // lambda^-1 mod n^2, times R mod n^2, in pk->mn2 (level two)
+  // level-two CRT over p^3 and q^3
+  bool has_crt2 = false;
+  ModCtx mp3, mq3;
+  int c_qinv_p = -1, c_pinv_q = -1;      // q^-1 mod p in mp, p^-1 mod q in mq, stored plain (x*R (x) c = x*c)
+  int c_inv2R_p = -1, c_inv2R_q = -1;    // 2^-1 * R
+  int c_q2R = -1, c_p2R = -1;            // q^2 * R mod p^2 in mp2, p^2 * R mod q^2 in mq2
+  int c_hp2R = -1, c_hq2R = -1;          // (q (p-1))^-1 * R mod p^2 in mp2, (p (q-1))^-1 * R mod q^2 in mq2
+  int c_p2invR = -1;                     // (p^2)^-1 * R mod q^2 in mq2
+  DevLimbs pinv2k_2, qinv2k_2;           // p^-1 mod 2^(28 mp2.WT), q^-1 mod 2^(28 mq2.WT)
+  DevLimbs q_limbs, p2_limbs;            // q as mq.WT limbs, p^2 as mp2.WT limbs
 };
 
 // inverse of odd d modulo 2^bits
@@ -938,6 +948,38 @@ int pgpu_seckey_create(pgpu_ctx* ctx, const pgpu_pubkey* pk, const uint8_t* lamb
         sk->pinv2k.set(inv_mod_pow2(p, (size_t)LB * sk->mp.WT), sk->mp.WT);
         sk->qinv2k.set(inv_mod_pow2(q, (size_t)LB * sk->mq.WT), sk->mq.WT);
         sk->p_limbs.set(p, sk->mp.WT);
+        if (pk->mn3 && sk->c_mu2R >= 0) {
+          const BigU p2 = p * p, q2 = q * q;
+          sk->mp3.init(ctx, p2 * p);
+          sk->mq3.init(ctx, q2 * q);
+          BigU qinv, pinvq, inv2p, inv2q, hp2, hq2, p2inv;
+          const BigU two(2);
+          if (sk->mp3.WL == sk->mq3.WL && sk->mp3.K == sk->mq3.K && hostbig::modinv(q % p, p, qinv) &&
+              hostbig::modinv(p % q, q, pinvq) && hostbig::modinv(two, p, inv2p) && hostbig::modinv(two, q, inv2q) &&
+              hostbig::modinv(hostbig::mulmod(q % p2, p - BigU(1), p2), p2, hp2) &&
+              hostbig::modinv(hostbig::mulmod(p % q2, q - BigU(1), q2), q2, hq2) && hostbig::modinv(p2 % q2, q2, p2inv)) {
+            sk->c_qinv_p = sk->mp.add_const(qinv);
+            sk->c_pinv_q = sk->mq.add_const(pinvq);
+            sk->c_inv2R_p = sk->mp.add_const(sk->mp.to_mont(inv2p));
+            sk->c_inv2R_q = sk->mq.add_const(sk->mq.to_mont(inv2q));
+            sk->c_q2R = sk->mp2.add_const(sk->mp2.to_mont(q2));
+            sk->c_p2R = sk->mq2.add_const(sk->mq2.to_mont(p2));
+            sk->c_hp2R = sk->mp2.add_const(sk->mp2.to_mont(hp2));
+            sk->c_hq2R = sk->mq2.add_const(sk->mq2.to_mont(hq2));
+            sk->c_p2invR = sk->mq2.add_const(sk->mq2.to_mont(p2inv));
+            sk->mp.upload();
+            sk->mq.upload();
+            sk->mp2.upload();
+            sk->mq2.upload();
+            sk->mp3.upload();
+            sk->mq3.upload();
+            sk->pinv2k_2.set(inv_mod_pow2(p, (size_t)LB * sk->mp2.WT), sk->mp2.WT);
+            sk->qinv2k_2.set(inv_mod_pow2(q, (size_t)LB * sk->mq2.WT), sk->mq2.WT);
+            sk->q_limbs.set(q, sk->mq.WT);
+            sk->p2_limbs.set(p2, sk->mp2.WT);
+            sk->has_crt2 = true;
+          }
+        }
       }
     }
   });
@@ -1135,6 +1177,139 @@ uint32_t* decrypt2_generic(const pgpu_seckey* sk, const uint32_t* c_limbs, size_
   return mv + 4 * s2;
 }
 
+// Level-two decryption, CRT over p^3 and q^3 (the level-one idea of decrypt1_crt carried to s = 2).  For a unit c =
+// (1+n)^m r^(n^2) mod n^3:  u_p = c^(p-1) mod p^3 = (1+n)^x with x = m (p-1) mod p^2 (r^(n^2 (p-1)) = 1: the group has
+// order p^2 (p-1)), and (1+n)^x = 1 + x n + C(x,2) n^2 (mod p^3) because p^3 | n^3.  So with L_p(u) = (u-1)/p (exact):
+//   L_p = x q + C(x,2) q^2 p  (mod p^2)   =>   x1 = L_p q^-1 mod p,   x = (L_p - C(x1,2) p q^2) q^-1  mod p^2
+// (C(x,2) p mod p^2 depends on x mod p only), m mod p^2 = x (p-1)^-1, likewise mod q^2, then Garner.  Two 1.5k-bit-wide
+// exponentiations with half-length exponents instead of one three times as wide: ~4x fewer limb products than
+// paillier.go:292-340 and the same integers out.  c: device array of 2*mp3.WT limbs per number.  Returns mn2.WT-limb
+// plaintexts; lanes where a division is not exact (c not a unit) get PGPU_LANE_NONUNIT and are redone by the caller.
+uint32_t* decrypt2_crt(const pgpu_seckey* sk, const uint32_t* c_limbs, size_t nb, size_t count, int32_t* d_status) {
+  pgpu_ctx* ctx = sk->ctx;
+  const ModCtx &mp = sk->mp, &mq = sk->mq, &mp2 = sk->mp2, &mq2 = sk->mq2, &mp3 = sk->mp3, &mq3 = sk->mq3;
+  const int W1 = mp.WT, W2 = mp2.WT, W3 = mp3.WT;
+  const size_t S1 = (size_t)W1 * nb, S2 = (size_t)W2 * nb, S3 = (size_t)W3 * nb;
+  uint32_t* mem = ctx->ws_t<uint32_t>(S3 * 70);   // same slot plan as decrypt1_crt
+  HIPCHK(hipMemcpyAsync(mem, c_limbs, S3 * 2 * 4, hipMemcpyDeviceToDevice, ctx->stream));
+  {
+    Prog pp, pq;
+    emit_modexp_shared(pp, sk->p - BigU(1), 0, 1, 2, 3, 4, NO_SLOT, false);
+    pp.end();
+    emit_modexp_shared(pq, sk->q - BigU(1), 0, 1, 36, 37, 38, NO_SLOT, false);
+    pq.end();
+    SegSpec sp{&mp3, &pp, mem, nullptr}, sq{&mq3, &pq, mem, nullptr};
+    run_vm(ctx, nb, sp, &sq, true);
+  }
+  uint32_t *up = mem + 3 * S3, *uq = mem + 37 * S3;
+  launch_canon(up, mp3.d_nmod, W3, nb, ctx->stream);
+  launch_canon(uq, mq3.d_nmod, W3, nb, ctx->stream);
+  // m2 (W2-limb slots): per side s in {0 (p), 1 (q)}: 5s+0 L, 5s+1 t*prime, 5s+2 w, 5s+3 L - w, 5s+4 m mod prime^2;
+  // then 10 B, 11 A, 12 h
+  uint32_t* m2 = ctx->ws_t<uint32_t>(S2 * 13);
+  uint32_t* tb = ctx->ws_t<uint32_t>(S3);
+  launch_div_exact(up, W3, 1, nullptr, 0, tb, sk->pinv2k_2.d, mp.d_nmod, W1, m2 + 0 * S2, W2, nb, count, d_status,
+                   PGPU_LANE_NONUNIT, ctx->stream);
+  launch_div_exact(uq, W3, 1, nullptr, 0, tb, sk->qinv2k_2.d, mq.d_nmod, W1, m2 + 5 * S2, W2, nb, count, d_status,
+                   PGPU_LANE_NONUNIT, ctx->stream);
+  // m1 (W1-limb slots): per side 6s+0 L lo, 6s+1 L hi, 6s+2 tmp, 6s+3 x1, 6s+4 x1 - 1, 6s+5 t; 12 = ones
+  uint32_t* m1 = ctx->ws_t<uint32_t>(S1 * 13);
+  const int whi = std::min(W2 - W1, W1);   // L < prime^2 < 2^(56 W1): limbs above 2 W1 are zero
+  for (int s = 0; s < 2; ++s) {
+    const uint32_t* L = m2 + (size_t)(5 * s) * S2;
+    launch_copy_limbs(L, 0, W1, m1 + (size_t)(6 * s) * S1, W1, nb, ctx->stream);
+    launch_copy_limbs(L, W1, whi, m1 + (size_t)(6 * s + 1) * S1, W1, nb, ctx->stream);
+  }
+  {
+    Prog a, b;                                                             // x1 = L * other^-1 mod prime
+    emit_to_mont(a, 0, 1, 2); a.op(VM_MULC, (uint32_t)sk->c_qinv_p); a.op(VM_STORE, 3); a.end();
+    emit_to_mont(b, 6, 7, 8); b.op(VM_MULC, (uint32_t)sk->c_pinv_q); b.op(VM_STORE, 9); b.end();
+    SegSpec sa{&mp, &a, m1, nullptr}, sb{&mq, &b, m1, nullptr};
+    run_vm(ctx, nb, sa, &sb, false);
+  }
+  launch_canon(m1 + 3 * S1, mp.d_nmod, W1, nb, ctx->stream);
+  launch_canon(m1 + 9 * S1, mq.d_nmod, W1, nb, ctx->stream);
+  launch_fill_const(mp.d_consts + (size_t)C_ONE * W1, m1 + 12 * S1, W1, nb, ctx->stream);
+  launch_sub_mod(m1 + 3 * S1, m1 + 12 * S1, mp.d_nmod, m1 + 4 * S1, W1, nb, ctx->stream);
+  launch_sub_mod(m1 + 9 * S1, m1 + 12 * S1, mq.d_nmod, m1 + 10 * S1, W1, nb, ctx->stream);
+  {
+    Prog a, b;                                                             // t = x1 (x1 - 1) / 2 mod prime
+    a.op(VM_LOAD, 3); a.op(VM_MULC, C_R2); a.op(VM_MUL, 4); a.op(VM_MULC, (uint32_t)sk->c_inv2R_p); a.op(VM_STORE, 5); a.end();
+    b.op(VM_LOAD, 9); b.op(VM_MULC, C_R2); b.op(VM_MUL, 10); b.op(VM_MULC, (uint32_t)sk->c_inv2R_q); b.op(VM_STORE, 11); b.end();
+    SegSpec sa{&mp, &a, m1, nullptr}, sb{&mq, &b, m1, nullptr};
+    run_vm(ctx, nb, sa, &sb, false);
+  }
+  launch_canon(m1 + 5 * S1, mp.d_nmod, W1, nb, ctx->stream);
+  launch_canon(m1 + 11 * S1, mq.d_nmod, W1, nb, ctx->stream);
+  launch_mul_const_add(m1 + 5 * S1, W1, sk->p_limbs.d, W1, nullptr, 0, 0, m2 + 1 * S2, W2, nb, ctx->stream);   // t p < p^2
+  launch_mul_const_add(m1 + 11 * S1, W1, sk->q_limbs.d, W1, nullptr, 0, 0, m2 + 6 * S2, W2, nb, ctx->stream);
+  {
+    Prog a, b;                                                             // w = t prime other^2 mod prime^2
+    a.op(VM_LOAD, 1); a.op(VM_MULC, (uint32_t)sk->c_q2R); a.op(VM_STORE, 2); a.end();
+    b.op(VM_LOAD, 6); b.op(VM_MULC, (uint32_t)sk->c_p2R); b.op(VM_STORE, 7); b.end();
+    SegSpec sa{&mp2, &a, m2, nullptr}, sb{&mq2, &b, m2, nullptr};
+    run_vm(ctx, nb, sa, &sb, false);
+  }
+  launch_canon(m2 + 2 * S2, mp2.d_nmod, W2, nb, ctx->stream);
+  launch_canon(m2 + 7 * S2, mq2.d_nmod, W2, nb, ctx->stream);
+  launch_sub_mod(m2 + 0 * S2, m2 + 2 * S2, mp2.d_nmod, m2 + 3 * S2, W2, nb, ctx->stream);
+  launch_sub_mod(m2 + 5 * S2, m2 + 7 * S2, mq2.d_nmod, m2 + 8 * S2, W2, nb, ctx->stream);
+  {
+    Prog a, b;                                                             // m mod prime^2 = (L - w) (other (prime-1))^-1
+    a.op(VM_LOAD, 3); a.op(VM_MULC, (uint32_t)sk->c_hp2R); a.op(VM_STORE, 4); a.end();
+    b.op(VM_LOAD, 8); b.op(VM_MULC, (uint32_t)sk->c_hq2R); b.op(VM_STORE, 9); b.end();
+    SegSpec sa{&mp2, &a, m2, nullptr}, sb{&mq2, &b, m2, nullptr};
+    run_vm(ctx, nb, sa, &sb, false);
+  }
+  launch_canon(m2 + 4 * S2, mp2.d_nmod, W2, nb, ctx->stream);   // ONE integer m_p2 for both uses below (see decrypt1_crt)
+  {
+    Prog c;                                                                // Garner in Z_{q^2}
+    c.op(VM_LOAD, 4); c.op(VM_MULC, (uint32_t)sk->c_p2invR); c.op(VM_STORE, 10);
+    c.op(VM_LOAD, 9); c.op(VM_MULC, (uint32_t)sk->c_p2invR); c.op(VM_STORE, 11);
+    c.end();
+    SegSpec sc{&mq2, &c, m2, nullptr};
+    run_vm(ctx, nb, sc, nullptr, false);
+  }
+  launch_canon(m2 + 10 * S2, mq2.d_nmod, W2, nb, ctx->stream);
+  launch_canon(m2 + 11 * S2, mq2.d_nmod, W2, nb, ctx->stream);
+  launch_sub_mod(m2 + 11 * S2, m2 + 10 * S2, mq2.d_nmod, m2 + 12 * S2, W2, nb, ctx->stream);   // h = (m_q2 - m_p2) / p^2 mod q^2
+  const int WN = sk->pk->mn2.WT;
+  uint32_t* res = ctx->ws_t<uint32_t>((size_t)WN * nb);
+  launch_mul_const_add(m2 + 12 * S2, W2, sk->p2_limbs.d, W2, m2 + 4 * S2, W2, 0, res, WN, nb, ctx->stream);   // m_p2 + p^2 h
+  return res;
+}
+
+// Level-two decryption of `count` ciphertexts held as wc limbs each (wc = 2*mp3.WT when crt, else mn3.WT): CRT first,
+// then the reference formula on the lanes whose ciphertext turned out not to be a unit.  hstat (host, `count` entries,
+// may be null) receives the per-lane status.  Synchronises the stream when crt is set.
+uint32_t* decrypt2_units_or_generic(const pgpu_seckey* sk, const uint32_t* cl3, int wc, size_t nb, size_t count, bool crt,
+                                    int32_t* hstat) {
+  pgpu_ctx* ctx = sk->ctx;
+  const pgpu_pubkey* pk = sk->pk;
+  if (!crt) return decrypt2_generic(sk, cl3, nb, count);
+  const int W3 = pk->mn3->WT, W2 = pk->mn2.WT;
+  int32_t* d_status = ctx->ws_t<int32_t>(nb);
+  HIPCHK(hipMemsetAsync(d_status, 0, nb * 4, ctx->stream));
+  uint32_t* res = decrypt2_crt(sk, cl3, nb, count, d_status);
+  std::vector<int32_t> st(count);
+  HIPCHK(hipMemcpyAsync(st.data(), d_status, count * 4, hipMemcpyDeviceToHost, ctx->stream));
+  HIPCHK(hipStreamSynchronize(ctx->stream));
+  std::vector<uint32_t> idx;
+  for (size_t i = 0; i < count; ++i)
+    if (st[i] & PGPU_LANE_NONUNIT) idx.push_back((uint32_t)i);
+  if (!idx.empty()) {
+    const size_t nbg = round_up(idx.size(), VM_BLOCK);
+    uint32_t* d_idx = ctx->upload_words(idx);
+    uint32_t* cg = ctx->ws_t<uint32_t>((size_t)W3 * nbg);
+    launch_gather(cl3, nb, d_idx, idx.size(), cg, nbg, W3, ctx->stream);   // the low WT(n^3) limbs hold all of c
+    uint32_t* rg = decrypt2_generic(sk, cg, nbg, idx.size());
+    launch_scatter(rg, nbg, d_idx, idx.size(), res, nb, W2, ctx->stream);
+  }
+  if (hstat) memcpy(hstat, st.data(), count * 4);
+  (void)wc;
+  return res;
+}
+
 // ---- threshold decryption ------------------------------------------------------------------------------------
 
 // signed host integer for the Lagrange coefficients (thresholdkey.go:91-107)
@@ -1189,11 +1364,14 @@ int pgpu_decrypt(const pgpu_seckey* sk, int level, size_t batch, const uint8_t* 
     if (level == PGPU_LEVEL_TWO) {
       const ModCtx& mn3 = cipher_mod(pk, level);
       if (c_stride < mn3.nbytes) api_throw(PGPU_ERR_INVALID, "ciphertext stride smaller than the byte length of n^3");
-      uint32_t* cl3 = ctx->ws_t<uint32_t>((size_t)mn3.WT * nb);
-      unpack_operand(ctx, c, c_stride, mn3.nbytes, batch, mem, cl3, mn3.WT, nb);
-      uint32_t* r2 = decrypt2_generic(sk, cl3, nb, batch);
+      const bool crt2 = sk->has_crt2 && !(flags & PGPU_DECRYPT_NO_CRT) && 2 * sk->mp3.WT >= mn3.WT;
+      const int WC3 = crt2 ? 2 * sk->mp3.WT : mn3.WT;
+      uint32_t* cl3 = ctx->ws_t<uint32_t>((size_t)WC3 * nb);
+      unpack_operand(ctx, c, c_stride, mn3.nbytes, batch, mem, cl3, WC3, nb);
+      std::vector<int32_t> hstat2(batch, 0);
+      uint32_t* r2 = decrypt2_units_or_generic(sk, cl3, WC3, nb, batch, crt2, hstat2.data());
       pack_result(ctx, r2, pk->mn2.WT, nb, batch, m, m_stride, pk->mn2.nbytes, mem);
-      if (status) memset(status, 0, batch * 4);
+      if (status) memcpy(status, hstat2.data(), batch * 4);
       HIPCHK(hipStreamSynchronize(ctx->stream));
       return;
     }
@@ -1868,7 +2046,10 @@ int pgpu_ddleq_prove(const pgpu_seckey* sk, size_t batch, const uint8_t* ct1, co
       // s = ExtractRandonness(ct1) at level two (operations.go:75-91)
       BigU ns_inv;
       if (!hostbig::modinv(N2 % sk->lambda, sk->lambda, ns_inv)) api_throw(PGPU_ERR_NOT_INVERTIBLE, "n^2 is not invertible mod lambda");
-      uint32_t* v = decrypt2_generic(sk, gc1, nbg, cnt);                       // Decrypt(ct1): W2 limbs
+      const bool crt2 = sk->has_crt2 && 2 * sk->mp3.WT >= W3;
+      const int WC3 = crt2 ? 2 * sk->mp3.WT : W3;
+      uint32_t* v = decrypt2_units_or_generic(sk, crt2 ? zext(ctx, gc1, W3, WC3, nbg) : gc1, WC3, nbg, cnt, crt2,
+                                              nullptr);                        // Decrypt(ct1): W2 limbs
       uint32_t* gv = ctx->ws_t<uint32_t>((size_t)W3 * nbg);
       gm2_from_reduced(ctx, pk, v, nbg, gv);                                   // G^v mod n^3
       launch_restride(gv, nbg, cnt, mn3.d_consts + (size_t)C_ONE * W3, gv, nbg, W3, ctx->stream);

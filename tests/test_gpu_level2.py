@@ -38,8 +38,15 @@ def test_level_two_encrypt_decrypt(ctx, bits):
     assert sk.DecryptBatch(cts, level=ENC_LEVEL_TWO) == ms
     # arbitrary elements of Z_{n^3}: must equal the reference's recovery algorithm on the same input
     weird = [rng.randrange(n3) for _ in range(4)] + [n3 - 1, 1, p, n, n2, 0, 5 * n2]
-    got = sk.DecryptBatch(weird, level=ENC_LEVEL_TWO)
-    assert got == [po.decrypt(sk_o, po.Ciphertext(c, po.ENC_LEVEL_TWO)) for c in weird]
+    got, st = sk.DecryptBatch(weird, level=ENC_LEVEL_TWO, return_status=True)
+    want = [po.decrypt(sk_o, po.Ciphertext(c, po.ENC_LEVEL_TWO)) for c in weird]
+    assert got == want
+    # the default path is CRT over p^3, q^3 with the non-units redone by the reference formula; both must agree with it
+    from math import gcd
+    assert [bool(s & pa.LANE_NONUNIT) for s in st] == [gcd(c, n) != 1 for c in weird]
+    assert sk.DecryptBatch(weird, level=ENC_LEVEL_TWO, flags=pa.DECRYPT_NO_CRT) == want
+    many = [rng.randrange(n3) for _ in range(300)]
+    assert sk.DecryptBatch(many, level=ENC_LEVEL_TWO) == sk.DecryptBatch(many, level=ENC_LEVEL_TWO, flags=pa.DECRYPT_NO_CRT)
 
 
 def test_nested_encrypt_decrypt(ctx):

@@ -91,6 +91,26 @@ if "decrypt3072" in which:   # BASELINE config 3
                       "ms_per_batch": dt * 1e3, "vm_ms": prof["vm_ms"], "executed_Tmad_per_s": prof["vm_mads"] / prof["vm_ms"] / 1e9,
                       "encrypt3072_per_s": B / (enc["vm_ms"] * 1e-3), "parity": "65536-lane round trip + 2 lanes vs oracle"}), flush=True)
 
+if "decrypt2048_l2" in which:   # level two (Damgard-Jurik s = 2, paillier.go:292-340): CRT over p^3, q^3 vs the reference formula
+    n, lam = key(2048)
+    pk = pa.PublicKey(ctx, n); sk = pa.SecretKey(ctx, pk, lam); B = 32768; rng = np.random.default_rng(7)
+    m_h = rand_below(n * n, B, 512, rng); r_h = rand_below(n, B, 256, rng); r_h[:, -1] |= 1
+    m = torch.from_numpy(m_h).to(dev); r = torch.from_numpy(r_h).to(dev)
+    c = torch.zeros((B, 768), dtype=torch.uint8, device=dev); out = torch.zeros((B, 512), dtype=torch.uint8, device=dev)
+    pk.encrypt_with_r_raw(B, m.data_ptr(), 512, r.data_ptr(), 256, c.data_ptr(), 768, MEM_DEVICE, level=1)
+    enc = ctx.last_profile()
+    dt = timed(lambda: sk.decrypt_raw(B, c.data_ptr(), 768, out.data_ptr(), 512, MEM_DEVICE, level=1))
+    prof = ctx.last_profile()
+    assert torch.equal(out, m), "level-two round trip failed"
+    dt_ref = timed(lambda: sk.decrypt_raw(B, c.data_ptr(), 768, out.data_ptr(), 512, MEM_DEVICE, level=1, flags=pa.DECRYPT_NO_CRT), reps=1)
+    assert torch.equal(out, m), "level-two round trip (reference formula) failed"
+    sk_o = po.SecretKey(N=n, G=n + 1, Lambda=lam)
+    assert be_to_ints(out[:2].cpu().numpy()) == [po.decrypt(sk_o, po.Ciphertext(x, po.ENC_LEVEL_TWO)) for x in be_to_ints(c[:2].cpu().numpy())]
+    print(json.dumps({"config": "Batch 32768 level-two Decrypt, 2048-bit n (CRT over p^3,q^3)", "value": B / dt, "unit": "decryptions/s",
+                      "ms_per_batch": dt * 1e3, "vm_ms": prof["vm_ms"], "executed_Tmad_per_s": prof["vm_mads"] / prof["vm_ms"] / 1e9,
+                      "reference_formula_per_s": B / dt_ref, "encrypt_l2_per_s": B / (enc["vm_ms"] * 1e-3),
+                      "parity": "32768-lane round trip (both paths) + 2 lanes vs oracle"}), flush=True)
+
 if "threshold2048" in which:  # BASELINE config 4, single-GPU part: 3 x PartialDecrypt + Combine for 16384 ciphertexts
     k = K["threshold"]["2048"]; n = int(k["n"], 16); shares = [int(s, 16) for s in k["shares"]]
     tk = pa.ThresholdPublicKey(ctx, n, total=5, threshold=3); B = 16384; rng = np.random.default_rng(4)
