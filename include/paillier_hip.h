@@ -42,7 +42,7 @@ extern "C" {
 #define PGPU_LEVEL_TWO 1
 
 /* pgpu_decrypt flags */
-#define PGPU_DECRYPT_DEFAULT 0      /* CRT over p^2, q^2 when (n, lambda) factor n, else generic */
+#define PGPU_DECRYPT_DEFAULT 0      /* CRT over p^(s+1), q^(s+1) when (n, lambda) factor n, else generic */
 #define PGPU_DECRYPT_NO_CRT 1       /* the reference's formula verbatim: c^lambda mod n^(s+1), L, * lambda^-1 */
 
 /* per-lane status bits (int32 array, optional) */
