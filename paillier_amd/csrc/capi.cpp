@@ -369,7 +369,8 @@ void run_vm(pgpu_ctx* ctx, size_t nb, const SegSpec& s0, const SegSpec* s1, bool
     while (launch_nb * K * segs < lanes_wanted && K < 4 && WL % 2 == 0 && WL / 2 >= 37) { WL /= 2; K *= 2; }
     // 148 limbs (n^2 of a 2048-bit key): the 4-lane slicing keeps the modulus slice in registers (no LDS streaming)
     // and measured 6 % faster than (74,2) even at full occupancy
-    if (WL == 74 && K == 2) { WL = 37; K = 4; }
+    static const bool w74 = [] { const char* e = getenv("PGPU_W74"); return e ? atoi(e) != 0 : true; }();
+    if (WL == 74 && K == 2 && !(w74 && ctx->use_asm)) { WL = 37; K = 4; }
   }
   const uint32_t blocks_per_seg = (uint32_t)(launch_nb * K / VM_BLOCK);
   a.seg0_blocks = blocks_per_seg;

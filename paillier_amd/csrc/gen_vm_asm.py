@@ -894,12 +894,381 @@ class Gen:
         return "\n".join(self.lines) + "\n"
 
 
+class GenW(Gen):
+    """Wave-sliced shape: the S = `K` slices of WL limbs of one number live in the SAME lane of S different waves of
+    the workgroup (wave w: slice w % S of number group w / S), not in neighbouring lanes of one wave.  Every wave then
+    runs the single-lane row (modulus slice in SGPRs, triangular squaring possible) and the slices talk through LDS:
+
+      * the quotient digit m_i is computed by the bottom wave (slice 0) and published in a 2-slot ring;
+      * the shifted-out column of an upper wave (its low 28 bits; the rest is carried inside the wave) is published in a
+        2-slot ring and added by the wave below two rows later -- the upper wave runs about one row behind, nobody waits
+        in steady state;
+      * after the last row the final carry travels upwards once.
+
+    Every word carries a 4-bit tag (valid | op parity | row/2 mod 4) next to its 28-bit payload, so a reader sees at
+    once whether the word it read is the one it needs; a mismatch takes an out-of-line bounded spin.  Producer/consumer
+    order (m_r is written after lo_{r-2} was verified; lo_i is written after m_i was verified) makes 2 slots enough.
+    One s_barrier per product (after the a-operand column is staged) orders the column writes.
+    """
+
+    def __init__(self, WL, S, depth=8):
+        assert S == 2, "two wave slices for now"
+        Gen.__init__(self, WL, 1, depth)
+        self.S = S
+        self.K = 1                      # register map and row code of the single-lane shape
+        self.Kabi = S                   # what the host calls K (numbers per block = 256 / S)
+        self.WT = WL * S
+        self.NPB = BLOCK // S
+        self.name = f"vm_asm_{WL}_{S}"
+        self.flush = False
+        assert 3 * WL + 3 <= 255, "a column lives WL rows and takes <= 3 product units per row"
+        self.sq_rows = False
+        self.sq_rows_k = False
+        # LDS: rings first, then the a-operand column [WT + 1][NPB]
+        row = self.NPB * 4
+        self.lds_m = 0                  # m ring: 2 slots
+        self.lds_lo = 2 * row           # lo ring: 2 slots
+        self.lds_cy = 4 * row           # final carry: 2 words
+        self.lds_a = 6 * row
+        self.lds_bytes = self.lds_a + (self.WT + 1) * row
+        # extra VGPRs (the K == 1 map leaves room: nbase / isfirst / notlast are unused)
+        self.v_ring = self.v_nbase      # gl * 4
+        self.v_raw = self.v_isfirst     # word read from a ring
+        self.v_lo = self.v_p0           # pair (payload, 0): v_p0 + 1 is kept 0 inside a product
+        # SGPRs
+        self.s_slice, self.s_dead, self.s_lim = 0, 1, 15
+        self.s_exp, self.s_exp2, self.s_par = 99, 100, 101
+        self.s_cnt = 16
+        self.SPIN_LIMIT = 200000
+        self.uid = 0
+
+    # ---- tag helpers ------------------------------------------------------------------------------------------
+    def set_exp(self):
+        """s_exp = tag word of rows (s19, s19+1); s_exp2 = tag word of rows (s19+2, s19+3)"""
+        g, e = self, self.e
+        e(f"s_lshl_b32 s{g.s_exp}, s19, 27")               # (s19 >> 1) << 28
+        e(f"s_and_b32 s{g.s_exp}, s{g.s_exp}, 0x30000000")
+        e(f"s_add_u32 s{g.s_exp2}, s{g.s_exp}, 0x10000000")
+        e(f"s_and_b32 s{g.s_exp2}, s{g.s_exp2}, 0x30000000")
+        e(f"s_or_b32 s{g.s_exp}, s{g.s_exp}, s{g.s_par}")
+        e(f"s_or_b32 s{g.s_exp2}, s{g.s_exp2}, s{g.s_par}")
+
+    def check(self, dst, off, exp):
+        """dst <- payload of v_raw if its tag equals `exp`; else spin (bounded) re-reading LDS word v_ring + off"""
+        g, e = self, self.e
+        self.uid += 1
+        u = self.uid
+        e(f"v_xor_b32 {dst}, s{exp}, v{g.v_raw}")
+        e(f"v_cmp_le_u32 vcc, s{g.s_lim}, {dst}")
+        e("s_nop 0")
+        e(f"s_cbranch_vccnz L_slow{u}")
+        e(f"L_ok{u}:")
+        main = self.lines
+        self.lines = self.deferred
+        e(f"L_slow{u}:")
+        e(f"s_cmp_lg_u32 s{g.s_dead}, 0")
+        e(f"s_cbranch_scc1 L_ok{u}")
+        e(f"s_mov_b32 s{g.s_cnt}, 0")
+        e(f"L_spin{u}:")
+        e("s_sleep 1")
+        e(f"ds_read_b32 v{g.v_raw}, v{g.v_ring} offset:{off}")
+        e("s_waitcnt lgkmcnt(0)")
+        e(f"v_xor_b32 {dst}, s{exp}, v{g.v_raw}")
+        e(f"v_cmp_le_u32 vcc, s{g.s_lim}, {dst}")
+        e("s_nop 0")
+        e(f"s_cbranch_vccz L_ok{u}")
+        e(f"s_add_u32 s{g.s_cnt}, s{g.s_cnt}, 1")
+        e(f"s_cmp_lt_u32 s{g.s_cnt}, {g.SPIN_LIMIT}")
+        e(f"s_cbranch_scc1 L_spin{u}")
+        e(f"s_mov_b32 s{g.s_dead}, 1")                   # partner never answered: stop waiting for the rest of the kernel
+        e(f"s_branch L_ok{u}")
+        self.lines = main
+
+    # ---- prologue ---------------------------------------------------------------------------------------------
+    def prologue(self):
+        g, e = self, self.e
+        WL, NPB, S = self.WL, self.NPB, self.S
+        e(f'.amdgcn_target "amdgcn-amd-amdhsa--gfx950"')
+        e(".text")
+        e(f".globl {self.name}")
+        e(".p2align 8")
+        e(f".type {self.name},@function")
+        e(f"{self.name}:")
+        e("s_load_dword s3, s[0:1], 0x60")
+        e("s_waitcnt lgkmcnt(0)")
+        e("s_cmp_ge_u32 s2, s3")
+        e("s_cbranch_scc0 L_seg0")
+        e("s_sub_u32 s2, s2, s3")
+        e("s_add_u32 s0, s0, 48")
+        e("s_addc_u32 s1, s1, 0")
+        e("L_seg0:")
+        e("s_load_dwordx8 s[4:11], s[0:1], 0x0")
+        e("s_load_dwordx4 s[12:15], s[0:1], 0x20")
+        e("s_waitcnt lgkmcnt(0)")
+        e("s_lshl_b32 s3, s15, 2")                                   # nb*4
+        # wave -> (slice, group); s0/s1 are free from here on
+        e(f"v_lshrrev_b32 v{g.v_t1}, 6, v0")
+        e("s_nop 1")
+        e(f"v_readfirstlane_b32 s{g.s_t0}, v{g.v_t1}")               # wave id
+        e(f"s_and_b32 s{g.s_slice}, s{g.s_t0}, {S - 1}")
+        e(f"s_lshr_b32 s{g.s_t0}, s{g.s_t0}, {S.bit_length() - 1}")   # group
+        e(f"s_lshl_b32 s{g.s_t0}, s{g.s_t0}, 6")
+        e(f"v_and_b32 v{g.v_t2}, 63, v0")
+        e(f"v_add_u32 v{g.v_t2}, s{g.s_t0}, v{g.v_t2}")              # gl = group*64 + lane
+        e(f"s_mul_i32 s{g.s_t0}, s2, {NPB}")
+        e(f"v_add_u32 v{g.v_t3}, s{g.s_t0}, v{g.v_t2}")              # g
+        e(f"s_mul_i32 s{g.s_t1}, s15, {WL}")
+        e(f"s_mul_i32 s{g.s_t1}, s{g.s_t1}, s{g.s_slice}")           # slice*WL*nb
+        e(f"v_add_u32 v{g.v_t4}, s{g.s_t1}, v{g.v_t3}")
+        e(f"v_lshlrev_b32 v{g.v_goff}, 2, v{g.v_t4}")
+        e(f"v_lshlrev_b32 v{g.v_ring}, 2, v{g.v_t2}")                # gl*4
+        e(f"v_add_u32 v{g.v_aread}, {self.lds_a}, v{g.v_ring}")
+        e(f"s_mul_i32 s{g.s_t0}, s{g.s_slice}, {WL * NPB * 4}")
+        e(f"v_add_u32 v{g.v_awrite}, s{g.s_t0}, v{g.v_aread}")
+        e(f"s_mul_i32 s{g.s_t0}, s{g.s_slice}, {WL * 4}")
+        e(f"v_mov_b32 v{g.v_koff}, s{g.s_t0}")
+        # this wave's modulus slice -> SGPRs
+        e(f"s_add_u32 s6, s6, s{g.s_t0}")
+        e("s_addc_u32 s7, s7, 0")
+        off, s, rem = 0, self.s_N, WL
+        while rem > 0:
+            for cnt in (16, 8, 4, 2, 1):
+                align = 4 if cnt >= 4 else cnt
+                if cnt <= rem and s % align == 0:
+                    if cnt == 1:
+                        e(f"s_load_dword s{s}, s[6:7], {hex(off)}")
+                    else:
+                        e(f"s_load_dwordx{cnt} s[{s}:{s + cnt - 1}], s[6:7], {hex(off)}")
+                    off += 4 * cnt
+                    s += cnt
+                    rem -= cnt
+                    break
+            else:
+                raise RuntimeError("cannot tile the modulus into SGPR loads")
+        e("s_waitcnt lgkmcnt(0)")
+        e(f"s_mov_b32 s{g.s_lim}, 0x10000000")
+        e(f"s_mov_b32 s{g.s_dead}, 0")
+        e(f"s_mov_b32 s{g.s_par}, 0x80000000")                       # valid | parity 0
+        # rings: m and carry words invalid (tag 0); lo ring pre-loaded with lo_{-2} = lo_{-1} = 0 for the first product
+        e(f"v_mov_b32 v{g.v_t1}, 0")
+        e(f"v_mov_b32 v{g.v_t3}, s{g.s_par}")
+        row = NPB * 4
+        for k in range(2):
+            e(f"ds_write_b32 v{g.v_ring}, v{g.v_t1} offset:{self.lds_m + k * row}")
+            e(f"ds_write_b32 v{g.v_ring}, v{g.v_t1} offset:{self.lds_cy + k * row}")
+            e(f"ds_write_b32 v{g.v_ring}, v{g.v_t3} offset:{self.lds_lo + k * row}")
+        e("s_waitcnt lgkmcnt(0)")
+        e("s_barrier")
+        for j in range(WL):
+            e(f"v_mov_b32 {self.X(j)}, 0")
+
+    # ---- one row --------------------------------------------------------------------------------------------
+    def row_bottom(self, ai_reg, pre_reg, b, full=True, mult=None, a_from=0):
+        """slice 0.  b: row parity (ring slot).  The a_i for this row is in ai_reg; the next one is prefetched into
+        pre_reg.  v_raw holds the ring word lo_{r-2} (read issued a row earlier)."""
+        g, e = self, self.e
+        WL = self.WL
+        row = self.NPB * 4
+        N = lambda j: f"s{g.s_N + j}"
+        m = f"v{g.v_m}"
+        e("s_waitcnt lgkmcnt(0)")
+        self.check(f"v{g.v_lo}", self.lds_lo + b * row, g.s_exp)
+        e(f"v_lshl_add_u64 {self.T(WL - 2)}, {self.T(WL - 2)}, 0, {self.P(g.v_lo)}")
+        e(f"ds_read_b32 v{pre_reg}, v{g.v_arow}")
+        e(f"v_add_u32 v{g.v_arow}, {row}, v{g.v_arow}")
+        e(f"ds_read_b32 v{g.v_raw}, v{g.v_ring} offset:{self.lds_lo + (1 - b) * row}")    # lo_{r-1}, needed next row
+        ai = f"v{ai_reg}"
+        if mult is not None:
+            ai = mult(ai)
+        self.align8()
+        if full:
+            self.mad(self.T(0), ai, self.X(0), self.T(0))
+        e(f"v_mul_lo_u32 {m}, {self.Tlo(0)}, s14")
+        e(f"v_and_b32 {m}, {hex(MASK)}, {m}")
+        e(f"v_or_b32 v{g.v_t1}, s{g.s_exp}, {m}")
+        e(f"ds_write_b32 v{g.v_ring}, v{g.v_t1} offset:{self.lds_m + b * row}")
+        if full:
+            self.align8()
+            for j in range(1, WL):
+                if j == WL - 1:
+                    self.mad(self.T(j), ai, self.X(j), "0")
+                else:
+                    self.mad(self.T(j), ai, self.X(j), self.T(j))
+        self.align8()
+        self.mad(self.P(g.v_y0), m, N(0), self.T(0))
+        self.mad(self.T(0), m, N(1), self.T(1))
+        e(f"v_lshrrev_b64 {self.P(g.v_c)}, {LB}, {self.P(g.v_y0)}")
+        for j in range(2, WL):
+            self.mad(self.T(j - 1), m, N(j), self.T(j))
+            if j == 4:
+                e(f"v_lshl_add_u64 {self.T(0)}, {self.T(0)}, 0, {self.P(g.v_c)}")
+        if not full:
+            e(f"v_mov_b64 {self.T(WL - 1)}, 0")
+
+    def row_top(self, ai_reg, pre_reg, b, full=True):
+        g, e = self, self.e
+        WL = self.WL
+        row = self.NPB * 4
+        N = lambda j: f"s{g.s_N + j}"
+        m = f"v{g.v_m}"
+        e("s_waitcnt lgkmcnt(0)")
+        e(f"ds_read_b32 v{pre_reg}, v{g.v_arow}")
+        e(f"v_add_u32 v{g.v_arow}, {row}, v{g.v_arow}")
+        e(f"ds_read_b32 v{g.v_raw}, v{g.v_ring} offset:{self.lds_m + b * row}")           # m_i
+        ai = f"v{ai_reg}"
+        self.align8()
+        for j in range(WL):
+            if j == WL - 1:
+                self.mad(self.T(j), ai, self.X(j), "0")
+            else:
+                self.mad(self.T(j), ai, self.X(j), self.T(j))
+        e("s_waitcnt lgkmcnt(0)")
+        self.check(m, self.lds_m + b * row, g.s_exp)
+        self.align8()
+        self.mad(self.P(g.v_y0), m, N(0), self.T(0))
+        self.mad(self.T(0), m, N(1), self.T(1))
+        e(f"v_and_b32 v{g.v_t1}, {hex(MASK)}, v{g.v_y0}")
+        e(f"v_or_b32 v{g.v_t1}, s{g.s_exp2}, v{g.v_t1}")
+        e(f"ds_write_b32 v{g.v_ring}, v{g.v_t1} offset:{self.lds_lo + b * row}")          # lo_i
+        e(f"v_lshrrev_b64 {self.P(g.v_c)}, {LB}, {self.P(g.v_y0)}")
+        self.align8()
+        for j in range(2, WL):
+            self.mad(self.T(j - 1), m, N(j), self.T(j))
+            if j == 4:
+                e(f"v_lshl_add_u64 {self.T(0)}, {self.T(0)}, 0, {self.P(g.v_c)}")
+
+    # ---- product ----------------------------------------------------------------------------------------------
+    def product_entry(self):
+        """common head of a product: the a column is staged; order it, clear the accumulators, flip the parity"""
+        g, e = self, self.e
+        WL = self.WL
+        row = self.NPB * 4
+        e("s_barrier")
+        for j in range(WL - 1):
+            e(f"v_mov_b64 {self.T(j)}, 0")
+        e(f"v_mov_b32 v{g.v_lo + 1}, 0")
+        e(f"v_mov_b32 v{g.v_arow}, v{g.v_aread}")
+        e(f"ds_read_b32 v{g.v_ain}, v{g.v_arow}")
+        e(f"v_add_u32 v{g.v_arow}, {row}, v{g.v_arow}")
+        e("s_mov_b32 s19, 0")
+
+    def finish_bottom(self):
+        """after the last row: the two outstanding lo words, sequential carry, final carry up"""
+        g, e = self, self.e
+        WL = self.WL
+        row = self.NPB * 4
+        M = hex(MASK)
+        self.set_exp()
+        e("s_waitcnt lgkmcnt(0)")                         # v_raw = lo_{WT-2} (read issued in the last row), dangling a prefetch
+        self.check(f"v{g.v_lo}", self.lds_lo + 0 * row, g.s_exp)
+        e(f"v_lshl_add_u64 {self.T(WL - 2)}, {self.T(WL - 2)}, 0, {self.P(g.v_lo)}")
+        e(f"ds_read_b32 v{g.v_raw}, v{g.v_ring} offset:{self.lds_lo + 1 * row}")
+        e("s_waitcnt lgkmcnt(0)")
+        self.check(f"v{g.v_lo}", self.lds_lo + 1 * row, g.s_exp)
+        e(f"v_mov_b32 {self.Tlo(WL - 1)}, v{g.v_lo}")
+        e(f"v_mov_b32 {self.Thi(WL - 1)}, 0")
+        c = self.P(g.v_c)
+        e(f"v_and_b32 {self.X(0)}, {M}, {self.Tlo(0)}")
+        e(f"v_lshrrev_b64 {c}, {LB}, {self.T(0)}")
+        for j in range(1, WL):
+            e(f"v_lshl_add_u64 {self.T(j)}, {self.T(j)}, 0, {c}")
+            e(f"v_and_b32 {self.X(j)}, {M}, {self.Tlo(j)}")
+            e(f"v_lshrrev_b64 {c}, {LB}, {self.T(j)}")
+        # carry (< 2^37) -> two tagged words
+        e(f"v_and_b32 v{g.v_t1}, {M}, v{g.v_c}")
+        e(f"v_or_b32 v{g.v_t1}, s{g.s_par}, v{g.v_t1}")
+        e(f"v_lshrrev_b64 {c}, {LB}, {c}")
+        e(f"v_or_b32 v{g.v_t2}, s{g.s_par}, v{g.v_c}")
+        e(f"ds_write_b32 v{g.v_ring}, v{g.v_t1} offset:{self.lds_cy}")
+        e(f"ds_write_b32 v{g.v_ring}, v{g.v_t2} offset:{self.lds_cy + row}")
+        e(f"s_xor_b32 s{g.s_par}, s{g.s_par}, 0x40000000")
+        e("s_branch L_next")
+
+    def finish_top(self):
+        g, e = self, self.e
+        WL = self.WL
+        row = self.NPB * 4
+        M = hex(MASK)
+        e("s_waitcnt lgkmcnt(0)")
+        e(f"v_mov_b64 {self.T(WL - 1)}, 0")
+        e(f"ds_read_b32 v{g.v_raw}, v{g.v_ring} offset:{self.lds_cy}")
+        e("s_waitcnt lgkmcnt(0)")
+        self.check(f"v{g.v_lo}", self.lds_cy, g.s_par)
+        e(f"v_lshl_add_u64 {self.T(0)}, {self.T(0)}, 0, {self.P(g.v_lo)}")
+        e(f"ds_read_b32 v{g.v_raw}, v{g.v_ring} offset:{self.lds_cy + row}")
+        e("s_waitcnt lgkmcnt(0)")
+        self.check(f"v{g.v_lo}", self.lds_cy + row, g.s_par)
+        e(f"v_lshl_add_u64 {self.T(1)}, {self.T(1)}, 0, {self.P(g.v_lo)}")
+        # the bottom wave is past its last lo word: pre-load lo_{-2} = lo_{-1} = 0 of the next product
+        e(f"s_xor_b32 s{g.s_par}, s{g.s_par}, 0x40000000")
+        e(f"v_mov_b32 v{g.v_t1}, s{g.s_par}")
+        e(f"ds_write_b32 v{g.v_ring}, v{g.v_t1} offset:{self.lds_lo}")
+        e(f"ds_write_b32 v{g.v_ring}, v{g.v_t1} offset:{self.lds_lo + row}")
+        c = self.P(g.v_c)
+        e(f"v_and_b32 {self.X(0)}, {M}, {self.Tlo(0)}")
+        e(f"v_lshrrev_b64 {c}, {LB}, {self.T(0)}")
+        for j in range(1, WL):
+            e(f"v_lshl_add_u64 {self.T(j)}, {self.T(j)}, 0, {c}")
+            e(f"v_and_b32 {self.X(j)}, {M}, {self.Tlo(j)}")
+            if j < WL - 1:
+                e(f"v_lshrrev_b64 {c}, {LB}, {self.T(j)}")
+        e("s_waitcnt lgkmcnt(0)")
+        e("s_branch L_next")
+
+    def montmul(self):
+        g, e = self, self.e
+        WT = self.WT
+        row = self.NPB * 4
+        assert WT % 2 == 0
+        e("L_montmul:")
+        self.product_entry()
+        e(f"s_cmp_eq_u32 s{g.s_slice}, 0")
+        e("s_cbranch_scc0 L_mm_top")
+        # ---------------- bottom wave
+        e(f"ds_read_b32 v{g.v_raw}, v{g.v_ring} offset:{self.lds_lo}")        # lo_{-2}
+        e(".p2align 6")
+        e("L_rowb:")
+        self.set_exp()
+        self.row_bottom(g.v_ain, g.v_ai, 0)
+        self.row_bottom(g.v_ai, g.v_ain, 1)
+        e("s_add_u32 s19, s19, 2")
+        e(f"s_cmp_lt_u32 s19, {WT}")
+        e("s_cbranch_scc1 L_rowb")
+        self.finish_bottom()
+        # ---------------- top wave
+        e(".p2align 6")
+        e("L_mm_top:")
+        e("L_rowt:")
+        self.set_exp()
+        self.row_top(g.v_ain, g.v_ai, 0)
+        self.row_top(g.v_ai, g.v_ain, 1)
+        e("s_add_u32 s19, s19, 2")
+        e(f"s_cmp_lt_u32 s19, {WT}")
+        e("s_cbranch_scc1 L_rowt")
+        self.finish_top()
+        self.lines.extend(self.deferred)
+        self.deferred = []
+
+    def generate(self):
+        self.prologue()
+        self.dispatcher()
+        self.montmul()
+        self.epilogue()
+        return "\n".join(self.lines) + "\n"
+
+
 SHAPES = [(74, 1), (37, 1), (55, 1), (55, 2), (74, 2), (55, 4), (37, 2), (37, 4)]
+WAVE_SLICED = {(74, 2)}     # shapes whose slices live in different waves (GenW) instead of neighbouring lanes (Gen)
+
+
+def make_gen(wl, k):
+    return GenW(wl, k) if (wl, k) in WAVE_SLICED else Gen(wl, k)
+
 
 if __name__ == "__main__":
     out_dir = sys.argv[1] if len(sys.argv) > 1 else "."
     for wl, k in SHAPES:
-        g = Gen(wl, k)
+        g = make_gen(wl, k)
         with open(f"{out_dir}/vm_asm_{wl}_{k}.s", "w") as f:
             f.write(g.generate())
         print(f"vm_asm_{wl}_{k}: vgpr={g.n_vgpr} lds={g.lds_bytes}")
