@@ -64,7 +64,9 @@ void pgpu_ctx_destroy(pgpu_ctx* ctx);
  * the context's stream: milliseconds, number of launches, and 28-bit-limb multiply-adds executed. */
 int pgpu_ctx_last_profile(pgpu_ctx* ctx, double* vm_ms, int* vm_launches, double* vm_mads);
 /* Runtime switches.  "asm" (default 1): run the hand-scheduled gfx950 assembly VM kernels; 0 selects the
- * hipcc-generated kernels of identical semantics (used by the parity tests to cross-check the two). */
+ * hipcc-generated kernels of identical semantics (used by the parity tests to cross-check the two).
+ * "lanes_wanted" (default 0 = fill the chip): the lane count below which a batch is re-sliced over more lanes per
+ * number; 1 keeps every modulus on its natural kernel shape whatever the batch size (tests). */
 int pgpu_ctx_set_flag(pgpu_ctx* ctx, const char* name, int value);
 /* number of VM launches of the last batch call that ran the assembly kernel */
 int pgpu_ctx_last_vm_asm(pgpu_ctx* ctx);

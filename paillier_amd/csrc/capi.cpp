@@ -61,6 +61,7 @@ struct pgpu_ctx {
   size_t evs_used = 0;
   bool use_asm = true;       // hand-scheduled VM kernels (pgpu_ctx_set_flag("asm", 0) selects the hipcc-generated ones)
   int last_vm_asm = 0;       // number of VM launches of the last call that ran the assembly kernel
+  size_t lanes_wanted = 0;   // 0: default occupancy target; tests set 1 to run every modulus at its natural shape
 
   void bind() { HIPCHK(hipSetDevice(device)); }
 
@@ -364,7 +365,7 @@ void run_vm(pgpu_ctx* ctx, size_t nb, const SegSpec& s0, const SegSpec* s1, bool
   int WL = mc->WL, K = mc->K;
   {
     static const size_t lanes_env = [] { const char* e = getenv("PGPU_LANES_WANTED"); return e ? (size_t)atoll(e) : (size_t)0; }();
-    const size_t lanes_wanted = lanes_env ? lanes_env : (size_t)1024 * 2 * 64;  // env override: tuning experiments only
+    const size_t lanes_wanted = ctx->lanes_wanted ? ctx->lanes_wanted : lanes_env ? lanes_env : (size_t)1024 * 2 * 64;
     const size_t segs = s1 ? 2 : 1;
     while (launch_nb * K * segs < lanes_wanted && K < 4 && WL % 2 == 0 && WL / 2 >= 37) { WL /= 2; K *= 2; }
     // 148 limbs (n^2 of a 2048-bit key): the 4-lane slicing keeps the modulus slice in registers (no LDS streaming)
@@ -387,6 +388,7 @@ void run_vm(pgpu_ctx* ctx, size_t nb, const SegSpec& s0, const SegSpec* s1, bool
     double sq = full;
     if (use_asm && K == 1) sq = (double)mc->WT * mc->WT + 0.5 * mc->WT * (mc->WT - 1) + mc->WT;
     else if (use_asm && K == 2 && WL <= 55) sq = (double)mc->WT * mc->WT * (2.0 - 1.0 / (2 * K)) + WL;
+    else if (use_asm && K == 2 && WL == 74) sq = 2.0 * WL * WL + WL + 2.0 * mc->WT * WL;   // wave-sliced: every product once
     ev->mads = ((montmuls - sqrs) * full + sqrs * sq) * (double)launch_nb;
     HIPCHK(hipEventRecord(ev->a, ctx->stream));
   }
@@ -533,6 +535,7 @@ void pgpu_ctx_destroy(pgpu_ctx* ctx) {
 int pgpu_ctx_set_flag(pgpu_ctx* ctx, const char* name, int value) {
   if (!ctx || !name) return fail(PGPU_ERR_INVALID, "null argument");
   if (strcmp(name, "asm") == 0) { ctx->use_asm = value != 0; return PGPU_OK; }
+  if (strcmp(name, "lanes_wanted") == 0) { ctx->lanes_wanted = value > 0 ? (size_t)value : 0; return PGPU_OK; }
   return fail(PGPU_ERR_INVALID, "unknown flag %s", name);
 }
 

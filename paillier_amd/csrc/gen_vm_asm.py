@@ -396,7 +396,7 @@ class Gen:
 
         e("L_sqr:")
         self.stage_to_lds(Xs)
-        e("s_branch L_montsq" if (self.sq_rows or self.sq_rows_k) else "s_branch L_montmul")
+        e("s_branch L_montsq" if (self.sq_rows or self.sq_rows_k or getattr(self, "sq_rows_w", False)) else "s_branch L_montmul")
 
     # ---------------------------------------------------------------------------------------------
     def gen_row(self, v_ai_cur, v_ai_next, swap_by_mov, mult_prep=None):
@@ -924,6 +924,7 @@ class GenW(Gen):
         assert 3 * WL + 3 <= 255, "a column lives WL rows and takes <= 3 product units per row"
         self.sq_rows = False
         self.sq_rows_k = False
+        self.sq_rows_w = True           # symmetric squaring split over the two waves (montsq below)
         # LDS: rings first, then the a-operand column [WT + 1][NPB]
         row = self.NPB * 4
         self.lds_m = 0                  # m ring: 2 slots
@@ -1184,13 +1185,14 @@ class GenW(Gen):
         e(f"s_xor_b32 s{g.s_par}, s{g.s_par}, 0x40000000")
         e("s_branch L_next")
 
-    def finish_top(self):
+    def finish_top(self, top_zeroed=False):
         g, e = self, self.e
         WL = self.WL
         row = self.NPB * 4
         M = hex(MASK)
         e("s_waitcnt lgkmcnt(0)")
-        e(f"v_mov_b64 {self.T(WL - 1)}, 0")
+        if not top_zeroed:
+            e(f"v_mov_b64 {self.T(WL - 1)}, 0")
         e(f"ds_read_b32 v{g.v_raw}, v{g.v_ring} offset:{self.lds_cy}")
         e("s_waitcnt lgkmcnt(0)")
         self.check(f"v{g.v_lo}", self.lds_cy, g.s_par)
@@ -1249,10 +1251,189 @@ class GenW(Gen):
         self.lines.extend(self.deferred)
         self.deferred = []
 
+    # ---- squaring ---------------------------------------------------------------------------------------------
+    def jump_into(self, tag, table, ret, idx_code):
+        """computed jump: enter `table` (8-byte entries) at entry index left in s98 by idx_code()"""
+        e = self.e
+        e("s_getpc_b64 s[96:97]")
+        e(f"{ret}:")
+        idx_code()
+        e("s_lshl_b32 s98, s98, 3")
+        e("s_add_u32 s96, s96, s98")
+        e("s_addc_u32 s97, s97, 0")
+        e(f"s_add_u32 s96, s96, {table}-{ret}")
+        e("s_addc_u32 s97, s97, 0")
+        e("s_setpc_b64 s[96:97]")
+
+    def b_stream(self, publish_lo=None):
+        """pass B with the shift; publish_lo: (slot offset) for the top wave"""
+        g, e = self, self.e
+        WL = self.WL
+        N = lambda j: f"s{g.s_N + j}"
+        m = f"v{g.v_m}"
+        self.mad(self.P(g.v_y0), m, N(0), self.T(0))
+        self.mad(self.T(0), m, N(1), self.T(1))
+        if publish_lo is not None:
+            e(f"v_and_b32 v{g.v_t1}, {hex(MASK)}, v{g.v_y0}")
+            e(f"v_or_b32 v{g.v_t1}, s{g.s_exp2}, v{g.v_t1}")
+            e(f"ds_write_b32 v{g.v_ring}, v{g.v_t1} offset:{publish_lo}")
+        e(f"v_lshrrev_b64 {self.P(g.v_c)}, {LB}, {self.P(g.v_y0)}")
+        if publish_lo is not None:
+            self.align8()
+        for j in range(2, WL):
+            self.mad(self.T(j - 1), m, N(j), self.T(j))
+            if j == 4:
+                e(f"v_lshl_add_u64 {self.T(0)}, {self.T(0)}, 0, {self.P(g.v_c)}")
+        e(f"v_mov_b64 {self.T(WL - 1)}, 0")
+
+    def sq_row_bottom(self, p):
+        """symmetric squaring row of slice 0 (row r = s19 + p).  a_r (any limb of x) times the lo slice, doubled, for the
+        columns c > r mod WL; the diagonal x_(r/2)^2 on even rows; see montsq()."""
+        g, e = self, self.e
+        WL = self.WL
+        row = self.NPB * 4
+        m, ai2, din = f"v{g.v_m}", f"v{g.v_ai}", f"v{g.v_din}"
+        e("s_waitcnt lgkmcnt(0)")
+        self.check(f"v{g.v_lo}", self.lds_lo + p * row, g.s_exp)
+        e(f"v_lshl_add_u64 {self.T(WL - 2)}, {self.T(WL - 2)}, 0, {self.P(g.v_lo)}")
+        e(f"v_add_u32 {ai2}, v{g.v_ain}, v{g.v_ain}")
+        if p == 0:
+            self.mad(self.T(0), din, din, self.T(0))
+            e(f"ds_read_b32 {din}, v{g.v_drow}")
+            e(f"v_add_u32 v{g.v_drow}, {row}, v{g.v_drow}")
+        e(f"ds_read_b32 v{g.v_ain}, v{g.v_arow}")
+        e(f"v_add_u32 v{g.v_arow}, {row}, v{g.v_arow}")
+        e(f"ds_read_b32 v{g.v_raw}, v{g.v_ring} offset:{self.lds_lo + (1 - p) * row}")
+        e(f"v_mul_lo_u32 {m}, {self.Tlo(0)}, s14")
+        e(f"v_and_b32 {m}, {hex(MASK)}, {m}")
+        e(f"v_or_b32 v{g.v_t1}, s{g.s_exp}, {m}")
+        e(f"ds_write_b32 v{g.v_ring}, v{g.v_t1} offset:{self.lds_m + p * row}")
+        tag = f"_sb{p}"
+
+        def idx():
+            if p:
+                e("s_add_u32 s98, s19, 1")
+            else:
+                e("s_mov_b32 s98, s19")
+            e(f"s_sub_u32 s17, s98, {WL}")            # (s96/s97 hold the pc here; s17 is free inside a product)
+            e(f"s_cmp_ge_u32 s98, {WL}")
+            e("s_cselect_b32 s98, s17, s98")
+
+        self.jump_into(tag, f"L_sqA{tag}", f"L_sqr{tag}", idx)
+        self.align8()
+        e(f"L_sqA{tag}:")
+        for j in range(1, WL):
+            self.mad(self.T(j), ai2, self.X(j), self.T(j))
+        self.b_stream()
+
+    def sq_row_top(self, p, hi_rows):
+        """symmetric squaring row of slice 1.  Rows r < WL (a_r = lo limb r): doubled products with hi[c], c >= r.
+        Rows r >= WL (a_r = hi limb i' = r - WL): doubled products with hi[c], c > i', and on even rows the diagonal
+        hi[(r - WL)/2]^2 into column 0."""
+        g, e = self, self.e
+        WL = self.WL
+        row = self.NPB * 4
+        m, ai2, din = f"v{g.v_m}", f"v{g.v_ai}", f"v{g.v_din}"
+        e("s_waitcnt lgkmcnt(0)")
+        e(f"v_add_u32 {ai2}, v{g.v_ain}, v{g.v_ain}")
+        if hi_rows and p == 0:
+            self.mad(self.T(0), din, din, self.T(0))
+            e(f"ds_read_b32 {din}, v{g.v_drow}")
+            e(f"v_add_u32 v{g.v_drow}, {row}, v{g.v_drow}")
+        e(f"ds_read_b32 v{g.v_ain}, v{g.v_arow}")
+        e(f"v_add_u32 v{g.v_arow}, {row}, v{g.v_arow}")
+        e(f"ds_read_b32 v{g.v_raw}, v{g.v_ring} offset:{self.lds_m + p * row}")
+        tag = f"_st{int(hi_rows)}{p}"
+
+        def idx():
+            if hi_rows:
+                e(f"s_sub_u32 s98, s19, {WL - 1 - p}")       # (r - WL) + 1
+            elif p:
+                e("s_add_u32 s98, s19, 1")
+            else:
+                e("s_mov_b32 s98, s19")
+
+        self.jump_into(tag, f"L_sqA{tag}", f"L_sqr{tag}", idx)
+        self.align8()
+        e(f"L_sqA{tag}:")
+        for j in range(WL):
+            self.mad(self.T(j), ai2, self.X(j), self.T(j))
+        e("s_waitcnt lgkmcnt(0)")
+        self.check(m, self.lds_m + p * row, g.s_exp)
+        self.align8()
+        self.b_stream(publish_lo=self.lds_lo + p * row)
+
+    def montsq(self):
+        """x <- x*x*R^-1 with x = lo + hi B^WL split over the two waves, every product x_i x_j (i < j) computed once:
+             both in lo          bottom wave, row i          (columns c = j > i)
+             both in hi          top wave,    row WL + i'    (columns c = j' > i')
+             i in lo, j in hi    top wave at row i when j' >= i;  bottom wave at row WL + j' when j' < i
+           so every row of either wave is a triangular row (a computed jump skips the leading table entries) and the two
+           waves carry the same number of multiplies in every row -- they stay in lock step.  Diagonals x_k^2 join column
+           2k when it is accumulator 0 of the wave that holds it (bottom: rows 2k; top: rows WL + 2k'), the rest (top
+           wave, k' >= WL/2) after the last row from the static registers."""
+        g, e = self, self.e
+        WL, WT = self.WL, self.WT
+        row = self.NPB * 4
+        assert WL % 2 == 0
+        e("L_montsq:")
+        e("s_barrier")
+        for j in range(WL):
+            e(f"v_mov_b64 {self.T(j)}, 0")
+        e(f"v_mov_b32 v{g.v_lo + 1}, 0")
+        e(f"v_mov_b32 v{g.v_arow}, v{g.v_aread}")
+        e(f"ds_read_b32 v{g.v_ain}, v{g.v_arow}")
+        e(f"v_add_u32 v{g.v_arow}, {row}, v{g.v_arow}")
+        e("s_mov_b32 s19, 0")
+        e(f"s_cmp_eq_u32 s{g.s_slice}, 0")
+        e("s_cbranch_scc0 L_sq_top")
+        # ---------------- bottom wave
+        e(f"v_mov_b32 v{g.v_drow}, v{g.v_aread}")
+        e(f"ds_read_b32 v{g.v_din}, v{g.v_drow}")
+        e(f"v_add_u32 v{g.v_drow}, {row}, v{g.v_drow}")
+        e(f"ds_read_b32 v{g.v_raw}, v{g.v_ring} offset:{self.lds_lo}")
+        e(".p2align 6")
+        e("L_sqb:")
+        self.set_exp()
+        self.sq_row_bottom(0)
+        self.sq_row_bottom(1)
+        e("s_add_u32 s19, s19, 2")
+        e(f"s_cmp_lt_u32 s19, {WT}")
+        e("s_cbranch_scc1 L_sqb")
+        self.finish_bottom()
+        # ---------------- top wave
+        e(".p2align 6")
+        e("L_sq_top:")
+        e("L_sqt0:")
+        self.set_exp()
+        self.sq_row_top(0, False)
+        self.sq_row_top(1, False)
+        e("s_add_u32 s19, s19, 2")
+        e(f"s_cmp_lt_u32 s19, {WL}")
+        e("s_cbranch_scc1 L_sqt0")
+        e(f"v_add_u32 v{g.v_drow}, {WL * row}, v{g.v_aread}")
+        e(f"ds_read_b32 v{g.v_din}, v{g.v_drow}")
+        e(f"v_add_u32 v{g.v_drow}, {row}, v{g.v_drow}")
+        e(".p2align 6")
+        e("L_sqt1:")
+        self.set_exp()
+        self.sq_row_top(0, True)
+        self.sq_row_top(1, True)
+        e("s_add_u32 s19, s19, 2")
+        e(f"s_cmp_lt_u32 s19, {WT}")
+        e("s_cbranch_scc1 L_sqt1")
+        e("s_waitcnt lgkmcnt(0)")
+        for k in range(WL // 2, WL):
+            self.mad(self.T(2 * k - WL), self.X(k), self.X(k), self.T(2 * k - WL))
+        self.finish_top(top_zeroed=True)
+        self.lines.extend(self.deferred)
+        self.deferred = []
+
     def generate(self):
         self.prologue()
         self.dispatcher()
         self.montmul()
+        self.montsq()
         self.epilogue()
         return "\n".join(self.lines) + "\n"
 

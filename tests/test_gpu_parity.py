@@ -240,3 +240,30 @@ def test_fresh_small_keys_properties(ctx, bits):
         c2 = pk.EncryptWithRBatch(cts, rs, level=pa.ENC_LEVEL_TWO)            # nested (paillier_test.go:65-87)
         assert c2 == [po.encrypt_with_r_at_level(sk_o, c, r, po.ENC_LEVEL_TWO).C for c, r in zip(cts, rs)]
         assert sk.NestedDecryptBatch(c2) == ms
+
+
+@pytest.mark.parametrize("bits", [4096])
+def test_wave_sliced_kernel(ctx, bits):
+    """Moduli of 148 limbs run on the wave-sliced kernel (slices of a number in different waves, LDS rings between them)
+    when the batch is large; force that shape for a small batch and check products, squarings (symmetric schedule),
+    shared-exponent and per-number-exponent ladders against Python and against the compiler-generated kernel."""
+    import paillier_amd as pa
+    rng = random.Random(bits + 99)
+    n = rand_odd(bits, rng)
+    mod = pa.Modulus(ctx, n)
+    xs = [rng.randrange(n) for _ in range(380)] + [0, 1, n - 1, n - 2]
+    ys = [rng.randrange(n) for _ in xs]
+    e = rng.getrandbits(300) | 1
+    es = [rng.getrandbits(200) for _ in xs]
+    try:
+        ctx.set_flag("lanes_wanted", 1)
+        assert mod.mul_batch(xs, ys) == [a * b % n for a, b in zip(xs, ys)]
+        assert ctx.last_vm_asm() >= 1
+        got = mod.exp_batch(xs, e)
+        assert got == [pow(a, e, n) for a in xs]
+        assert mod.exp_batch(xs, es) == [pow(a, k, n) for a, k in zip(xs, es)]
+        ctx.set_flag("asm", 0)
+        assert mod.exp_batch(xs, e) == got
+    finally:
+        ctx.set_flag("asm", 1)
+        ctx.set_flag("lanes_wanted", 0)

@@ -11,7 +11,9 @@ K = json.load(open(os.path.join(ROOT, "tests/golden/keys.json")))
 ctx = pa.Context(0)
 B = int(sys.argv[1]) if len(sys.argv) > 1 else 20000
 rng = random.Random(99)
-for bits in (1024, 2048):
+for bits, natural in ((1024, 0), (2048, 0), (2048, 1)):
+    # natural = 1: every modulus on its natural kernel shape (n^2 of the 2048-bit key: the wave-sliced 148-limb kernel)
+    ctx.set_flag("lanes_wanted", natural)
     k = K["paillier"][str(bits)]
     p, q = int(k["p"], 16), int(k["q"], 16)
     n, lam = p * q, (p - 1) * (q - 1)
@@ -38,7 +40,8 @@ for bits in (1024, 2048):
     m2 = [rng.randrange(n2) for _ in range(B2)]
     c2 = pk.EncryptWithRBatch(m2, rs[:B2], level=1)
     assert sk.DecryptBatch(c2, level=1) == m2, "L2 round trip"
-    print(f"{bits}-bit key: {B} samples ok ({time.time() - t:.1f}s)", flush=True)
+    print(f"{bits}-bit key{' (natural shapes)' if natural else ''}: {B} samples ok ({time.time() - t:.1f}s)", flush=True)
+ctx.set_flag("lanes_wanted", 0)
 k = K["threshold"]["2048"]
 n = int(k["n"], 16); shares = [int(s, 16) for s in k["shares"]]
 tk = pa.ThresholdPublicKey(ctx, n, total=5, threshold=3)
