@@ -359,17 +359,19 @@ void run_vm(pgpu_ctx* ctx, size_t nb, const SegSpec& s0, const SegSpec* s1, bool
     sqrs += ss[i]->prog->sqrs;
   }
   if (launch_nb == 0) launch_nb = nb;  // numbers actually launched (<= nb, the row stride of the arrays)
-  // Occupancy-aware shape: the same WT limbs can be sliced over more lanes (WL/2 x 2K).  One lane per slice keeps
-  // the multiply count but fills the chip when the batch is small; K == 1 additionally has the cheaper squaring rows,
-  // so the smallest K that still gives every SIMD two waves (1024 SIMDs x 2 x 64 lanes) wins.
+  // Occupancy-aware shape: the same WT limbs can be sliced over more lanes (WL/2 x 2K).  One lane per slice keeps the
+  // multiply count but fills the chip when the batch is small.  The natural shape has the cheapest squarings (K == 1:
+  // triangular rows; the wave-sliced 2-slice kernels: every limb product once), and a single wave per SIMD already
+  // issues at ~88 % of the two-wave rate, so it wins from one wave per SIMD (1024 SIMDs x 64 lanes) upwards; below that
+  // the finer slicing wins (tools/occupancy_sweep.py: Decrypt-2048 at 32768: 1.24 M/s natural vs 1.01 M/s re-sliced; at
+  // 16384: 0.63 vs 0.88 M/s; Encrypt-2048 at 32768: 295 k vs 271 k; at 16384: 148 k vs 251 k).
   int WL = mc->WL, K = mc->K;
   {
     static const size_t lanes_env = [] { const char* e = getenv("PGPU_LANES_WANTED"); return e ? (size_t)atoll(e) : (size_t)0; }();
-    const size_t lanes_wanted = ctx->lanes_wanted ? ctx->lanes_wanted : lanes_env ? lanes_env : (size_t)1024 * 2 * 64;
+    const size_t lanes_wanted = ctx->lanes_wanted ? ctx->lanes_wanted : lanes_env ? lanes_env : (size_t)1024 * 64;
     const size_t segs = s1 ? 2 : 1;
     while (launch_nb * K * segs < lanes_wanted && K < 4 && WL % 2 == 0 && WL / 2 >= 37) { WL /= 2; K *= 2; }
-    // 148 limbs (n^2 of a 2048-bit key): the 4-lane slicing keeps the modulus slice in registers (no LDS streaming)
-    // and measured 6 % faster than (74,2) even at full occupancy
+    // PGPU_W74=0 (experiments): the 4-lane slicing instead of the wave-sliced 148-limb kernel
     static const bool w74 = [] { const char* e = getenv("PGPU_W74"); return e ? atoi(e) != 0 : true; }();
     if (WL == 74 && K == 2 && !(w74 && ctx->use_asm)) { WL = 37; K = 4; }
   }
@@ -387,8 +389,8 @@ void run_vm(pgpu_ctx* ctx, size_t nb, const SegSpec& s0, const SegSpec* s1, bool
     // squaring rows: K == 1 triangular (WT^2 + WT(WT-1)/2 + WT); K == 2 slice-level symmetry (product part 1.5 WL^2 per lane)
     double sq = full;
     if (use_asm && K == 1) sq = (double)mc->WT * mc->WT + 0.5 * mc->WT * (mc->WT - 1) + mc->WT;
-    else if (use_asm && K == 2 && WL <= 55) sq = (double)mc->WT * mc->WT * (2.0 - 1.0 / (2 * K)) + WL;
-    else if (use_asm && K == 2 && WL == 74) sq = 2.0 * WL * WL + WL + 2.0 * mc->WT * WL;   // wave-sliced: every product once
+    else if (use_asm && K == 2 && WL >= 55) sq = 2.0 * WL * WL + WL + 2.0 * mc->WT * WL;   // wave-sliced: every product once
+    else if (use_asm && K == 2) sq = (double)mc->WT * mc->WT * (2.0 - 1.0 / (2 * K)) + WL;
     ev->mads = ((montmuls - sqrs) * full + sqrs * sq) * (double)launch_nb;
     HIPCHK(hipEventRecord(ev->a, ctx->stream));
   }

@@ -1326,32 +1326,37 @@ class GenW(Gen):
             self.mad(self.T(j), ai2, self.X(j), self.T(j))
         self.b_stream()
 
-    def sq_row_top(self, p, hi_rows):
-        """symmetric squaring row of slice 1.  Rows r < WL (a_r = lo limb r): doubled products with hi[c], c >= r.
-        Rows r >= WL (a_r = hi limb i' = r - WL): doubled products with hi[c], c > i', and on even rows the diagonal
-        hi[(r - WL)/2]^2 into column 0."""
+    def sq_row_top(self, p):
+        """symmetric squaring row of slice 1 (row r = s19 + p).  Rows r < WL (a_r = lo limb r): doubled products with
+        hi[c], c >= r.  Rows r >= WL (a_r = hi limb i' = r - WL): doubled products with hi[c], c > i', and when r - WL is
+        even the diagonal hi[(r - WL)/2]^2 into column 0 (the diagonal register holds 0 until row WL)."""
         g, e = self, self.e
         WL = self.WL
         row = self.NPB * 4
         m, ai2, din = f"v{g.v_m}", f"v{g.v_ai}", f"v{g.v_din}"
+        tag = f"_st{p}"
         e("s_waitcnt lgkmcnt(0)")
         e(f"v_add_u32 {ai2}, v{g.v_ain}, v{g.v_ain}")
-        if hi_rows and p == 0:
+        if p == (WL & 1):
             self.mad(self.T(0), din, din, self.T(0))
+            # next diagonal operand (for row r + 2) once r + 2 >= WL
+            e(f"s_cmp_lt_u32 s19, {WL - 2 - p}")
+            e(f"s_cbranch_scc1 L_nodin{tag}")
             e(f"ds_read_b32 {din}, v{g.v_drow}")
             e(f"v_add_u32 v{g.v_drow}, {row}, v{g.v_drow}")
+            e(f"L_nodin{tag}:")
         e(f"ds_read_b32 v{g.v_ain}, v{g.v_arow}")
         e(f"v_add_u32 v{g.v_arow}, {row}, v{g.v_arow}")
         e(f"ds_read_b32 v{g.v_raw}, v{g.v_ring} offset:{self.lds_m + p * row}")
-        tag = f"_st{int(hi_rows)}{p}"
 
         def idx():
-            if hi_rows:
-                e(f"s_sub_u32 s98, s19, {WL - 1 - p}")       # (r - WL) + 1
-            elif p:
+            if p:
                 e("s_add_u32 s98, s19, 1")
             else:
                 e("s_mov_b32 s98, s19")
+            e(f"s_sub_u32 s17, s98, {WL - 1}")          # rows >= WL enter at i' + 1
+            e(f"s_cmp_ge_u32 s98, {WL}")
+            e("s_cselect_b32 s98, s17, s98")
 
         self.jump_into(tag, f"L_sqA{tag}", f"L_sqr{tag}", idx)
         self.align8()
@@ -1375,7 +1380,6 @@ class GenW(Gen):
         g, e = self, self.e
         WL, WT = self.WL, self.WT
         row = self.NPB * 4
-        assert WL % 2 == 0
         e("L_montsq:")
         e("s_barrier")
         for j in range(WL):
@@ -1404,26 +1408,18 @@ class GenW(Gen):
         # ---------------- top wave
         e(".p2align 6")
         e("L_sq_top:")
-        e("L_sqt0:")
-        self.set_exp()
-        self.sq_row_top(0, False)
-        self.sq_row_top(1, False)
-        e("s_add_u32 s19, s19, 2")
-        e(f"s_cmp_lt_u32 s19, {WL}")
-        e("s_cbranch_scc1 L_sqt0")
-        e(f"v_add_u32 v{g.v_drow}, {WL * row}, v{g.v_aread}")
-        e(f"ds_read_b32 v{g.v_din}, v{g.v_drow}")
-        e(f"v_add_u32 v{g.v_drow}, {row}, v{g.v_drow}")
+        e(f"v_add_u32 v{g.v_drow}, {WL * row}, v{g.v_aread}")      # diagonal operands: limbs WL, WL+1, ...
+        e(f"v_mov_b32 v{g.v_din}, 0")
         e(".p2align 6")
-        e("L_sqt1:")
+        e("L_sqt:")
         self.set_exp()
-        self.sq_row_top(0, True)
-        self.sq_row_top(1, True)
+        self.sq_row_top(0)
+        self.sq_row_top(1)
         e("s_add_u32 s19, s19, 2")
         e(f"s_cmp_lt_u32 s19, {WT}")
-        e("s_cbranch_scc1 L_sqt1")
+        e("s_cbranch_scc1 L_sqt")
         e("s_waitcnt lgkmcnt(0)")
-        for k in range(WL // 2, WL):
+        for k in range((WL + 1) // 2, WL):
             self.mad(self.T(2 * k - WL), self.X(k), self.X(k), self.T(2 * k - WL))
         self.finish_top(top_zeroed=True)
         self.lines.extend(self.deferred)
@@ -1439,7 +1435,7 @@ class GenW(Gen):
 
 
 SHAPES = [(74, 1), (37, 1), (55, 1), (55, 2), (74, 2), (55, 4), (37, 2), (37, 4)]
-WAVE_SLICED = {(74, 2)}     # shapes whose slices live in different waves (GenW) instead of neighbouring lanes (Gen)
+WAVE_SLICED = {(74, 2), (55, 2)}     # shapes whose slices live in different waves (GenW) instead of neighbouring lanes (Gen)
 
 
 def make_gen(wl, k):

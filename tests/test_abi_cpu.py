@@ -65,11 +65,21 @@ def test_asm_generator_model():
     sys.path.insert(0, os.path.join(ROOT, "paillier_amd", "csrc"))
     import gen_vm_asm
     for wl, k in gen_vm_asm.SHAPES:
-        g = gen_vm_asm.Gen(wl, k)
+        g = gen_vm_asm.make_gen(wl, k)
         text = g.generate()
+        assert g.n_vgpr <= 256
+        if (wl, k) in gen_vm_asm.WAVE_SLICED:
+            # slices in different waves: each wave's product loop is two rows of 2*WL multiplies; the squaring rows of both
+            # waves are triangular tables of WL-1 / WL entries behind a computed jump, plus WL reduction multiplies
+            for lbl in ("L_rowb", "L_rowt"):
+                row = text.split(lbl + ":")[1].split("s_cbranch_scc1 " + lbl)[0]
+                assert row.count("v_mad_u64_u32") == 2 * wl * 2
+            sq = text.split("L_sqb:")[1].split("s_cbranch_scc1 L_sqb")[0]
+            assert sq.count("v_mad_u64_u32") == 2 * (wl - 1) + 2 * wl + 1          # two rows + one diagonal
+            assert g.lds_bytes * 2 <= 160 * 1024, "two workgroups per CU must fit in LDS"
+            continue
         row = text.split("L_row:")[1].split("s_cbranch_scc1 L_row")[0]
         if "L_noflush" in row:
             row = row.split("s_add_u32 s19, s19, 1")[0]
         bodies = 2 if (wl * k) % 2 == 0 else 1       # the row loop is unrolled by two when the limb count is even
         assert row.count("v_mad_u64_u32") == 2 * wl * bodies
-        assert g.n_vgpr <= 256
