@@ -579,18 +579,11 @@ class Gen:
             e(f"v_add_u32 v{g.v_arow}, {rstride}, v{g.v_arow}")
             e(f"v_mul_lo_u32 {m}, {self.Tlo(0)}, s14")
             e(f"v_and_b32 {m}, {hex(MASK)}, {m}")
-            # computed jump: enter the pass-A table at entry i+1 (table starts at A_1)
-            e("s_getpc_b64 s[96:97]")
-            e(f"L_sq_ret{tag}:")
-            if parity == 1:
-                e("s_lshl_b32 s98, s19, 3")
-                e("s_add_u32 s98, s98, 8")                        # this body handles row s19 + 1
-            else:
-                e("s_lshl_b32 s98, s19, 3")
-            e("s_add_u32 s96, s96, s98")
-            e("s_addc_u32 s97, s97, 0")
-            e(f"s_add_u32 s96, s96, L_sqA{tag}-L_sq_ret{tag}")
-            e("s_addc_u32 s97, s97, 0")
+            # computed jump: enter the pass-A table at entry i+1 (table starts at A_1).  s[6:7] = address of L_sq_base
+            # (taken once per product), s18 = 8 * s19
+            e(f"s_add_u32 s98, s18, L_sqA{tag}-L_sq_base{'+8' if parity == 1 else ''}")   # odd body: row s19 + 1
+            e("s_add_u32 s96, s6, s98")
+            e("s_addc_u32 s97, s7, 0")
             e("s_setpc_b64 s[96:97]")
             self.align8()
             e(f"L_sqA{tag}:")
@@ -605,6 +598,9 @@ class Gen:
                     e(f"v_lshl_add_u64 {self.T(0)}, {self.T(0)}, 0, {self.P(g.v_c)}")
             e(f"v_mov_b64 {self.T(WL - 1)}, 0")
 
+        e("s_getpc_b64 s[6:7]")      # s6/s7 (modulus pointer) are dead after the prologue
+        e("L_sq_base:")
+        e("s_mov_b32 s18, 0")
         e(".p2align 6")
         e("L_rowsq:")
         if WT % 2 == 0:
@@ -612,9 +608,11 @@ class Gen:
             row_body("_e", 0)
             row_body("_o", 1)
             e("s_add_u32 s19, s19, 2")
+            e("s_add_u32 s18, s18, 16")
         else:
             row_body("", None)
             e("s_add_u32 s19, s19, 1")
+            e("s_add_u32 s18, s18, 8")
         e(f"s_cmp_lt_u32 s19, {WT}")
         e("s_cbranch_scc1 L_rowsq")
         e("s_waitcnt lgkmcnt(0)")
@@ -944,15 +942,16 @@ class GenW(Gen):
         self.uid = 0
 
     # ---- tag helpers ------------------------------------------------------------------------------------------
-    def set_exp(self):
-        """s_exp = tag word of rows (s19, s19+1); s_exp2 = tag word of rows (s19+2, s19+3)"""
+    def set_exp(self, both=True):
+        """s_exp = tag word of rows (s19, s19+1); s_exp2 = tag word of rows (s19+2, s19+3) (top wave only)"""
         g, e = self, self.e
         e(f"s_lshl_b32 s{g.s_exp}, s19, 27")               # (s19 >> 1) << 28
         e(f"s_and_b32 s{g.s_exp}, s{g.s_exp}, 0x30000000")
-        e(f"s_add_u32 s{g.s_exp2}, s{g.s_exp}, 0x10000000")
-        e(f"s_and_b32 s{g.s_exp2}, s{g.s_exp2}, 0x30000000")
+        if both:
+            e(f"s_add_u32 s{g.s_exp2}, s{g.s_exp}, 0x10000000")
+            e(f"s_and_b32 s{g.s_exp2}, s{g.s_exp2}, 0x30000000")
+            e(f"s_or_b32 s{g.s_exp2}, s{g.s_exp2}, s{g.s_par}")
         e(f"s_or_b32 s{g.s_exp}, s{g.s_exp}, s{g.s_par}")
-        e(f"s_or_b32 s{g.s_exp2}, s{g.s_exp2}, s{g.s_par}")
 
     def check(self, dst, off, exp):
         """dst <- payload of v_raw if its tag equals `exp`; else spin (bounded) re-reading LDS word v_ring + off"""
@@ -961,7 +960,6 @@ class GenW(Gen):
         u = self.uid
         e(f"v_xor_b32 {dst}, s{exp}, v{g.v_raw}")
         e(f"v_cmp_le_u32 vcc, s{g.s_lim}, {dst}")
-        e("s_nop 0")
         e(f"s_cbranch_vccnz L_slow{u}")
         e(f"L_ok{u}:")
         main = self.lines
@@ -976,7 +974,6 @@ class GenW(Gen):
         e("s_waitcnt lgkmcnt(0)")
         e(f"v_xor_b32 {dst}, s{exp}, v{g.v_raw}")
         e(f"v_cmp_le_u32 vcc, s{g.s_lim}, {dst}")
-        e("s_nop 0")
         e(f"s_cbranch_vccz L_ok{u}")
         e(f"s_add_u32 s{g.s_cnt}, s{g.s_cnt}, 1")
         e(f"s_cmp_lt_u32 s{g.s_cnt}, {g.SPIN_LIMIT}")
@@ -1230,7 +1227,7 @@ class GenW(Gen):
         e(f"ds_read_b32 v{g.v_raw}, v{g.v_ring} offset:{self.lds_lo}")        # lo_{-2}
         e(".p2align 6")
         e("L_rowb:")
-        self.set_exp()
+        self.set_exp(both=False)
         self.row_bottom(g.v_ain, g.v_ai, 0)
         self.row_bottom(g.v_ai, g.v_ain, 1)
         e("s_add_u32 s19, s19, 2")
@@ -1252,18 +1249,38 @@ class GenW(Gen):
         self.deferred = []
 
     # ---- squaring ---------------------------------------------------------------------------------------------
-    def jump_into(self, tag, table, ret, idx_code):
-        """computed jump: enter `table` (8-byte entries) at entry index left in s98 by idx_code()"""
+    def jump_base(self, label):
+        """once per product and wave role: s[6:7] = address of `label` (s6/s7 are free after the prologue); the running
+        table offset 8*idx(row s19) lives in s18"""
         e = self.e
-        e("s_getpc_b64 s[96:97]")
-        e(f"{ret}:")
-        idx_code()
-        e("s_lshl_b32 s98, s98, 3")
-        e("s_add_u32 s96, s96, s98")
-        e("s_addc_u32 s97, s97, 0")
-        e(f"s_add_u32 s96, s96, {table}-{ret}")
-        e("s_addc_u32 s97, s97, 0")
+        e("s_getpc_b64 s[6:7]")
+        e(f"{label}:")
+
+    def jump_into(self, p, table, base, reset):
+        """computed jump of row s19 + p into `table` (8-byte entries) at entry idx(row): idx grows by one per row and is
+        set to `reset` at row WL.  s18 = 8*idx(s19) on entry of body 0; body 1 leaves 8*idx(s19 + 1) in s17."""
+        e = self.e
+        WL = self.WL
+        if p == 0:
+            src = "s18"
+        else:
+            e("s_add_u32 s17, s18, 8")
+            if WL % 2 == 1:
+                e(f"s_cmp_eq_u32 s19, {WL - 1}")
+                e(f"s_cselect_b32 s17, {8 * reset}, s17")
+            src = "s17"
+        e(f"s_add_u32 s98, {src}, {table}-{base}")
+        e("s_add_u32 s96, s6, s98")
+        e("s_addc_u32 s97, s7, 0")
         e("s_setpc_b64 s[96:97]")
+
+    def jump_next(self, reset):
+        """after `s_add_u32 s19, s19, 2`: s18 = 8*idx of the new row s19"""
+        e = self.e
+        e("s_add_u32 s18, s17, 8")
+        if self.WL % 2 == 0:
+            e(f"s_cmp_eq_u32 s19, {self.WL}")
+            e(f"s_cselect_b32 s18, {8 * reset}, s18")
 
     def b_stream(self, publish_lo=None):
         """pass B with the shift; publish_lo: (slot offset) for the top wave"""
@@ -1309,17 +1326,7 @@ class GenW(Gen):
         e(f"v_or_b32 v{g.v_t1}, s{g.s_exp}, {m}")
         e(f"ds_write_b32 v{g.v_ring}, v{g.v_t1} offset:{self.lds_m + p * row}")
         tag = f"_sb{p}"
-
-        def idx():
-            if p:
-                e("s_add_u32 s98, s19, 1")
-            else:
-                e("s_mov_b32 s98, s19")
-            e(f"s_sub_u32 s17, s98, {WL}")            # (s96/s97 hold the pc here; s17 is free inside a product)
-            e(f"s_cmp_ge_u32 s98, {WL}")
-            e("s_cselect_b32 s98, s17, s98")
-
-        self.jump_into(tag, f"L_sqA{tag}", f"L_sqr{tag}", idx)
+        self.jump_into(p, f"L_sqA{tag}", "L_sqbase_b", 0)
         self.align8()
         e(f"L_sqA{tag}:")
         for j in range(1, WL):
@@ -1349,16 +1356,7 @@ class GenW(Gen):
         e(f"v_add_u32 v{g.v_arow}, {row}, v{g.v_arow}")
         e(f"ds_read_b32 v{g.v_raw}, v{g.v_ring} offset:{self.lds_m + p * row}")
 
-        def idx():
-            if p:
-                e("s_add_u32 s98, s19, 1")
-            else:
-                e("s_mov_b32 s98, s19")
-            e(f"s_sub_u32 s17, s98, {WL - 1}")          # rows >= WL enter at i' + 1
-            e(f"s_cmp_ge_u32 s98, {WL}")
-            e("s_cselect_b32 s98, s17, s98")
-
-        self.jump_into(tag, f"L_sqA{tag}", f"L_sqr{tag}", idx)
+        self.jump_into(p, f"L_sqA{tag}", "L_sqbase_t", 1)
         self.align8()
         e(f"L_sqA{tag}:")
         for j in range(WL):
@@ -1396,12 +1394,15 @@ class GenW(Gen):
         e(f"ds_read_b32 v{g.v_din}, v{g.v_drow}")
         e(f"v_add_u32 v{g.v_drow}, {row}, v{g.v_drow}")
         e(f"ds_read_b32 v{g.v_raw}, v{g.v_ring} offset:{self.lds_lo}")
+        self.jump_base("L_sqbase_b")
+        e("s_mov_b32 s18, 0")
         e(".p2align 6")
         e("L_sqb:")
-        self.set_exp()
+        self.set_exp(both=False)
         self.sq_row_bottom(0)
         self.sq_row_bottom(1)
         e("s_add_u32 s19, s19, 2")
+        self.jump_next(0)
         e(f"s_cmp_lt_u32 s19, {WT}")
         e("s_cbranch_scc1 L_sqb")
         self.finish_bottom()
@@ -1410,12 +1411,15 @@ class GenW(Gen):
         e("L_sq_top:")
         e(f"v_add_u32 v{g.v_drow}, {WL * row}, v{g.v_aread}")      # diagonal operands: limbs WL, WL+1, ...
         e(f"v_mov_b32 v{g.v_din}, 0")
+        self.jump_base("L_sqbase_t")
+        e("s_mov_b32 s18, 0")
         e(".p2align 6")
         e("L_sqt:")
         self.set_exp()
         self.sq_row_top(0)
         self.sq_row_top(1)
         e("s_add_u32 s19, s19, 2")
+        self.jump_next(1)
         e(f"s_cmp_lt_u32 s19, {WT}")
         e("s_cbranch_scc1 L_sqt")
         e("s_waitcnt lgkmcnt(0)")
