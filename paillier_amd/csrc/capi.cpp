@@ -245,17 +245,18 @@ void emit_modexp_shared(Prog& p, const BigU& e, uint32_t in_lo, uint32_t in_hi, 
   }
   emit_to_mont(p, in_lo, in_hi, tmp);
   if (skip_zero_digits && e.bit_length() >= 64) {
-    // PUBLIC exponent (n, n^2, ...): sliding window over odd powers -- the operation sequence depends on the exponent's
-    // bits, which is fine for public values and never used for lambda, p-1 or key shares.
-    // table slot tab+k holds x^(2k+1); slot tab+31 holds x^2 during the build (sw <= 5 uses at most 16 odd powers)
-    const int sw = 5;
+    // Sliding window over odd powers: ~bits/(sw+1) products instead of bits/w, half the table.  The operation sequence
+    // depends on the exponent's bits -- on the KEY, never on the ciphertexts: every lane of every batch under one key
+    // runs the same program, so kernel time carries no per-ciphertext signal (what mpz_powm, the reference's own
+    // backend, does too).  Table slot tab+k holds x^(2k+1); x^2 sits in `tmp` during the build (free after the entry).
+    const int sw = e.bit_length() >= 700 ? 6 : 5;        // 2^(sw-1) + bits/(sw+1) products: 6 wins from ~700 bits
     const uint32_t nodd = 1u << (sw - 1);
     p.op(VM_STORE, tab + 0);          // x^1
     p.op(VM_SQR);
-    p.op(VM_STORE, tab + 31);         // x^2
+    p.op(VM_STORE, tmp);              // x^2
     p.op(VM_LOAD, tab + 0);
     for (uint32_t k = 1; k < nodd; ++k) {
-      p.op(VM_MUL, tab + 31);
+      p.op(VM_MUL, tmp);
       p.op(VM_STORE, tab + k);        // x^(2k+1)
     }
     long i = (long)e.bit_length() - 1;
@@ -1022,9 +1023,9 @@ uint32_t* decrypt1_crt(const pgpu_seckey* sk, const uint32_t* c_limbs, size_t nb
   uint32_t* mem = ctx->ws_t<uint32_t>(S2 * 70);
   HIPCHK(hipMemcpyAsync(mem, c_limbs, S2 * 2 * 4, hipMemcpyDeviceToDevice, ctx->stream));
   Prog pp, pq;
-  emit_modexp_shared(pp, sk->p - BigU(1), 0, 1, 2, 3, 4, NO_SLOT, false);
+  emit_modexp_shared(pp, sk->p - BigU(1), 0, 1, 2, 3, 4, NO_SLOT, true);
   pp.end();
-  emit_modexp_shared(pq, sk->q - BigU(1), 0, 1, 36, 37, 38, NO_SLOT, false);
+  emit_modexp_shared(pq, sk->q - BigU(1), 0, 1, 36, 37, 38, NO_SLOT, true);
   pq.end();
   SegSpec sp{&mp2, &pp, mem, nullptr}, sq{&mq2, &pq, mem, nullptr};
   run_vm(ctx, nb, sp, &sq, true);
@@ -1124,7 +1125,7 @@ uint32_t* decrypt1_generic(const pgpu_seckey* sk, const uint32_t* c_limbs, size_
   const ModCtx& mn2 = pk->mn2;
   ModexpPlan pl = modexp_alloc(ctx, mn2, nb, 32);
   HIPCHK(hipMemcpyAsync(pl.in(), c_limbs, (size_t)mn2.WT * nb * 4, hipMemcpyDeviceToDevice, ctx->stream));
-  modexp_shared_run(ctx, mn2, pl, sk->lambda, false, false, false);  // u, canonical (secret exponent: no window skipping)
+  modexp_shared_run(ctx, mn2, pl, sk->lambda, false, false, true);   // u, canonical
   return L_times_const(ctx, pk, pl.out(), nb, count, sk->c_muR, sk->n_minus_mu.d);
 }
 
@@ -1142,7 +1143,7 @@ uint32_t* decrypt2_generic(const pgpu_seckey* sk, const uint32_t* c_limbs, size_
   const int W1 = mn.WT, W2 = mn2.WT, W3 = mn3.WT;
   ModexpPlan pl = modexp_alloc(ctx, mn3, nb, 32);
   HIPCHK(hipMemcpyAsync(pl.in(), c_limbs, (size_t)W3 * nb * 4, hipMemcpyDeviceToDevice, ctx->stream));
-  modexp_shared_run(ctx, mn3, pl, sk->lambda, false, false, false);
+  modexp_shared_run(ctx, mn3, pl, sk->lambda, false, false, true);
   const uint32_t* a = pl.out();
   // j = 1
   uint32_t* a2 = ctx->ws_t<uint32_t>((size_t)W2 * nb);
@@ -1200,9 +1201,9 @@ uint32_t* decrypt2_crt(const pgpu_seckey* sk, const uint32_t* c_limbs, size_t nb
   HIPCHK(hipMemcpyAsync(mem, c_limbs, S3 * 2 * 4, hipMemcpyDeviceToDevice, ctx->stream));
   {
     Prog pp, pq;
-    emit_modexp_shared(pp, sk->p - BigU(1), 0, 1, 2, 3, 4, NO_SLOT, false);
+    emit_modexp_shared(pp, sk->p - BigU(1), 0, 1, 2, 3, 4, NO_SLOT, true);
     pp.end();
-    emit_modexp_shared(pq, sk->q - BigU(1), 0, 1, 36, 37, 38, NO_SLOT, false);
+    emit_modexp_shared(pq, sk->q - BigU(1), 0, 1, 36, 37, 38, NO_SLOT, true);
     pq.end();
     SegSpec sp{&mp3, &pp, mem, nullptr}, sq{&mq3, &pq, mem, nullptr};
     run_vm(ctx, nb, sp, &sq, true);
@@ -1662,7 +1663,7 @@ int pgpu_partial_decrypt(const pgpu_pubkey* pk, int total_servers, const uint8_t
     BigU e = BigU::from_be(share_be, share_len) * (BigU(2) * factorial_big(total_servers));
     ModexpPlan pl = modexp_alloc(ctx, mc, nb, 32);
     unpack_operand(ctx, c, c_stride, std::min(c_stride, mc.nbytes), batch, mem, pl.in(), mc.WT, nb);
-    modexp_shared_run(ctx, mc, pl, e, false, false, false);   // secret share: no window skipping
+    modexp_shared_run(ctx, mc, pl, e, false, false, true);
     pack_result(ctx, pl.out(), mc.WT, nb, batch, out, out_stride, mc.nbytes, mem);
     HIPCHK(hipStreamSynchronize(ctx->stream));
   });
@@ -2121,7 +2122,7 @@ int pgpu_share_zkp_prove(const pgpu_pubkey* pk, int total_servers, const uint8_t
     // Decryption = c^(2 delta s_i) mod n^2                                   (thresholdkey.go:229,192-201)
     ModexpPlan pd = modexp_alloc(ctx, mc, nb, 32);
     HIPCHK(hipMemcpyAsync(pd.in(), cl, sw * 4, hipMemcpyDeviceToDevice, ctx->stream));
-    modexp_shared_run(ctx, mc, pd, share * (BigU(2) * delta), false, false, false);
+    modexp_shared_run(ctx, mc, pd, share * (BigU(2) * delta), false, false, true);
     // r, a = (c^4)^r mod n^2, b = V^r mod n^2                                (thresholdkey.go:241-245)
     const int wr = std::max<int>(1, (int)((r_stride * 8 + LB - 1) / LB));
     uint32_t* rl = ctx->ws_t<uint32_t>((size_t)wr * nb);
