@@ -27,6 +27,7 @@ sys.path.insert(0, ROOT)
 # theoretical figure (the stricter denominator).
 PEAK_MAD_PER_S = 256 * 4 * 64 / 4 * 2.4e9
 HBM_PEAK_GBPS = 8000.0
+TRAFFIC_DEFAULT = None   # HBM bytes per launch of the dominant kernel for the default workload (PMC passes, profiles/)
 
 
 def alg_mul32_per_modexp(mod_bits: int, exp_bits: int, w: int = 5) -> float:
@@ -133,27 +134,33 @@ def main():
     vm_ms_avg = sum(vm_ms) / len(vm_ms)
     value = world * B * args.steps / elapsed
     half = args.bits // 2
-    alg_mul32 = 2 * alg_mul32_per_modexp(args.bits, half)  # CRT: two modexps, modulus p^2 (bits), exponent p-1 (bits/2)
+    # SURVEY.md §8(d) unit (schoolbook CIOS on 32-bit words, fixed 5-bit window): kept for reference.  The engine needs
+    # fewer multiplies than that (squaring symmetry, sliding windows and -- for 2048-bit keys -- residues modulo p^2 as two
+    # base-p digits: 3.5 instead of 6 half-width products per squaring), so a rate in SURVEY units can exceed the issue
+    # peak.  The roofline therefore prices the kernel in the multiplies its own algorithm needs: 28-bit limb products,
+    # counted per VM opcode by the library (squarings H(H-1)/2 + H + 3H^2, products 5H^2 on the pair kernel).
+    alg_mul32 = 2 * alg_mul32_per_modexp(args.bits, half)
     alg_mul32_noncrt = alg_mul32_per_modexp(2 * args.bits, args.bits)
-    achieved = alg_mul32 * B / (vm_ms_avg * 1e-3)
-    executed = prof["vm_mads"] / (vm_ms_avg * 1e-3)
+    alg_mads = prof["vm_mads"] / B                     # 28-bit multiply-adds the ladder programs need per decryption
+    achieved = prof["vm_mads"] / (vm_ms_avg * 1e-3)
     alg_bytes = cb + pb  # read c (n^2 bytes) + write m (n bytes)
+    kernel = {2048: "vm_asm_37_16 (pair kernel: x^(p-1) mod p^2 and x^(q-1) mod q^2 ladders, both halves in one launch)",
+              1024: "vm_asm_37_1 (CRT modexp over p^2 and q^2)", 3072: "vm_asm_55_2 (CRT modexp over p^2 and q^2, wave-sliced)"}[args.bits]
     roofline = {
         "bound": "valu",  # integer multiply issue (v_mad_u64_u32); neither HBM nor MFMA binds
-        "kernel": "vm_asm_74_1 (CRT modexp over p^2 and q^2, both halves in one launch)" if args.bits == 2048 else "vm_asm (CRT modexp over p^2 and q^2)",
+        "kernel": kernel,
         "achieved": achieved / 1e12,
         "peak": PEAK_MAD_PER_S / 1e12,
-        "unit": "Tmul32/s",
+        "unit": "Tmad28/s",
         "frac": achieved / PEAK_MAD_PER_S,
-        "executed_mad28_per_s_T": executed / 1e12,
-        "executed_frac": executed / PEAK_MAD_PER_S,
         "kernel_ms_per_launch": vm_ms_avg,
-        "alg_mul32_per_decrypt_crt": alg_mul32,
-        "alg_mul32_per_decrypt_noncrt": alg_mul32_noncrt,
+        "alg_mad28_per_decrypt": alg_mads,
+        "survey_unit": {"alg_mul32_per_decrypt_crt": alg_mul32, "alg_mul32_per_decrypt_noncrt": alg_mul32_noncrt,
+                        "rate_Tmul32_per_s": alg_mul32 * B / (vm_ms_avg * 1e-3) / 1e12},
         # HBM bytes per launch from the PMC passes of this same command (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate
         # runs, 2 x FETCH_SIZE gfx950 correction): profiles/r01_bench_pmc_summary.txt.  It is the per-lane window table
-        # (written once, ~240 entry reads per modexp), not re-reads of the inputs.  Only known for the default workload.
-        "traffic": 1.022e10 if (args.bits == 2048 and B == 65536) else None,
+        # (written once, one entry read per window product), not re-reads of the inputs.  Only known for the default workload.
+        "traffic": TRAFFIC_DEFAULT if (args.bits == 2048 and B == 65536) else None,
         "hbm": {"achieved": alg_bytes * B / (vm_ms_avg * 1e-3) / 1e9, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                 "frac": alg_bytes * B / (vm_ms_avg * 1e-3) / 1e9 / HBM_PEAK_GBPS, "alg_bytes_per_decrypt": alg_bytes},
     }

@@ -65,6 +65,8 @@ void pgpu_ctx_destroy(pgpu_ctx* ctx);
 int pgpu_ctx_last_profile(pgpu_ctx* ctx, double* vm_ms, int* vm_launches, double* vm_mads);
 /* Runtime switches.  "asm" (default 1): run the hand-scheduled gfx950 assembly VM kernels; 0 selects the
  * hipcc-generated kernels of identical semantics (used by the parity tests to cross-check the two).
+ * "pair" (default 1): run the Decrypt ladders modulo p^2 / q^2 on the pair kernel (two base-p digits per residue); 0
+ * keeps them on the ordinary 2H-limb kernel.
  * "lanes_wanted" (default 0 = fill the chip): the lane count below which a batch is re-sliced over more lanes per
  * number; 1 keeps every modulus on its natural kernel shape whatever the batch size (tests). */
 int pgpu_ctx_set_flag(pgpu_ctx* ctx, const char* name, int value);
@@ -210,6 +212,12 @@ int pgpu_modmul(const pgpu_modulus* mod, size_t batch, const uint8_t* a, size_t 
  * For tests only: lets the two implementations of the VM be compared opcode by opcode. */
 int pgpu_vm_debug_run(const pgpu_modulus* mod, const uint32_t* prog, size_t prog_words, uint32_t* mem_host,
                       size_t nslots, size_t nb, int use_asm, int* wt_out);
+
+/* Same for the pair kernel (residues modulo p^2 as two base-p digits, the Decrypt ladder of 2048-bit keys): slots are
+ * [2H][nb] limb arrays (digit a0 in limbs 0..H-1, a1 in limbs H..2H-1), SQR / MUL are the pair operations.
+ * consts_out (optional, 2H words) receives the kernel's constants p | Cadj, h_out the digit width H. */
+int pgpu_pair_debug_run(pgpu_ctx* ctx, const uint8_t* p_be, size_t p_len, const uint32_t* prog, size_t prog_words,
+                        uint32_t* mem_host, size_t nslots, size_t nb, uint32_t* consts_out, int* h_out);
 
 #ifdef __cplusplus
 }

@@ -61,6 +61,7 @@ struct pgpu_ctx {
   size_t evs_used = 0;
   bool use_asm = true;       // hand-scheduled VM kernels (pgpu_ctx_set_flag("asm", 0) selects the hipcc-generated ones)
   int last_vm_asm = 0;       // number of VM launches of the last call that ran the assembly kernel
+  bool use_pair = true;      // Decrypt ladders mod p^2 on the pair kernel (pgpu_ctx_set_flag("pair", 0): the 2H-limb kernel)
   size_t lanes_wanted = 0;   // 0: default occupancy target; tests set 1 to run every modulus at its natural shape
 
   void bind() { HIPCHK(hipSetDevice(device)); }
@@ -236,14 +237,15 @@ void emit_to_mont(Prog& p, uint32_t lo, uint32_t hi, uint32_t tmp) {
 // post_slot != NO_SLOT: the result is multiplied by mem[post_slot] (a plain residue), which also takes
 // it out of Montgomery form; otherwise it is multiplied by the constant 1.  Result (lazy, < 2N) -> out.
 void emit_modexp_shared(Prog& p, const BigU& e, uint32_t in_lo, uint32_t in_hi, uint32_t tmp, uint32_t out,
-                        uint32_t tab, uint32_t post_slot, bool skip_zero_digits) {
+                        uint32_t tab, uint32_t post_slot, bool skip_zero_digits, bool raw = false) {
   const int w = 5;
+  if (raw && (e.bit_length() < 64 || !skip_zero_digits)) api_throw(PGPU_ERR_INVALID, "raw ladder needs the sliding-window form");
   if (e.is_zero()) {  // gmp.Int.Exp: y <= 0 -> 1
     if (post_slot != NO_SLOT) { p.op(VM_LOAD, post_slot); } else { p.op(VM_LOADC, C_ONE); }
     p.op(VM_STORE, out);
     return;
   }
-  emit_to_mont(p, in_lo, in_hi, tmp);
+  if (raw) p.op(VM_LOAD, in_lo); else emit_to_mont(p, in_lo, in_hi, tmp);
   if (skip_zero_digits && e.bit_length() >= 64) {
     // Sliding window over odd powers: ~bits/(sw+1) products instead of bits/w, half the table.  The operation sequence
     // depends on the exponent's bits -- on the KEY, never on the ciphertexts: every lane of every batch under one key
@@ -276,7 +278,7 @@ void emit_modexp_shared(Prog& p, const BigU& e, uint32_t in_lo, uint32_t in_hi, 
       }
       i = l - 1;
     }
-    if (post_slot != NO_SLOT) p.op(VM_MUL, post_slot); else p.op(VM_MULC, C_ONE);
+    if (!raw) { if (post_slot != NO_SLOT) p.op(VM_MUL, post_slot); else p.op(VM_MULC, C_ONE); }
     p.op(VM_STORE, out);
     return;
   }
@@ -336,6 +338,11 @@ struct SegSpec {
   const Prog* prog;
   uint32_t* mem;
   const uint32_t* digits;
+  // pair kernel (N = p^2 as two base-p digits, gen_vm_asm.py GenP): `pair` = device array p | Cadj (H limbs each),
+  // pair_n0inv = -p^-1 mod 2^28, pair_h = H.  mc stays the 2H-limb modulus p^2 (slot size, accounting).
+  const uint32_t* pair = nullptr;
+  uint32_t pair_n0inv = 0;
+  int pair_h = 0;
 };
 
 // launch one VM kernel with 1 or 2 segments of `nb` numbers each (same modulus shape)
@@ -350,11 +357,11 @@ void run_vm(pgpu_ctx* ctx, size_t nb, const SegSpec& s0, const SegSpec* s1, bool
     if (!ss[i]) continue;
     VmSeg& g = a.seg[i];
     g.prog = ctx->upload_words(ss[i]->prog->w);
-    g.nmod = ss[i]->mc->d_nmod;
+    g.nmod = ss[i]->pair ? const_cast<uint32_t*>(ss[i]->pair) : ss[i]->mc->d_nmod;
     g.consts = ss[i]->mc->d_consts;
     g.mem = ss[i]->mem;
     g.digits = ss[i]->digits;
-    g.n0inv = ss[i]->mc->n0inv;
+    g.n0inv = ss[i]->pair ? ss[i]->pair_n0inv : ss[i]->mc->n0inv;
     g.nb = (uint32_t)nb;
     montmuls += ss[i]->prog->montmuls;
     sqrs += ss[i]->prog->sqrs;
@@ -367,7 +374,12 @@ void run_vm(pgpu_ctx* ctx, size_t nb, const SegSpec& s0, const SegSpec* s1, bool
   // the finer slicing wins (tools/occupancy_sweep.py: Decrypt-2048 at 32768: 1.24 M/s natural vs 1.01 M/s re-sliced; at
   // 16384: 0.63 vs 0.88 M/s; Encrypt-2048 at 32768: 295 k vs 271 k; at 16384: 148 k vs 251 k).
   int WL = mc->WL, K = mc->K;
-  {
+  const bool pair = s0.pair != nullptr;
+  if (s1 && pair != (s1->pair != nullptr)) api_throw(PGPU_ERR_INVALID, "segment kind mismatch");
+  if (pair) {
+    WL = s0.pair_h;
+    K = 16;   // tag of the pair kernel: one lane per number, 2H-limb values
+  } else {
     static const size_t lanes_env = [] { const char* e = getenv("PGPU_LANES_WANTED"); return e ? (size_t)atoll(e) : (size_t)0; }();
     const size_t lanes_wanted = ctx->lanes_wanted ? ctx->lanes_wanted : lanes_env ? lanes_env : (size_t)1024 * 64;
     const size_t segs = s1 ? 2 : 1;
@@ -376,7 +388,7 @@ void run_vm(pgpu_ctx* ctx, size_t nb, const SegSpec& s0, const SegSpec* s1, bool
     static const bool w74 = [] { const char* e = getenv("PGPU_W74"); return e ? atoi(e) != 0 : true; }();
     if (WL == 74 && K == 2 && !(w74 && ctx->use_asm)) { WL = 37; K = 4; }
   }
-  const uint32_t blocks_per_seg = (uint32_t)(launch_nb * K / VM_BLOCK);
+  const uint32_t blocks_per_seg = (uint32_t)(launch_nb * (pair ? 1 : K) / VM_BLOCK);
   a.seg0_blocks = blocks_per_seg;
   const uint32_t blocks = blocks_per_seg * (s1 ? 2 : 1);
   const bool use_asm = ctx->use_asm && vm_asm_available(WL, K) && s0.prog->asm_ok && (!s1 || s1->prog->asm_ok) &&
@@ -389,12 +401,19 @@ void run_vm(pgpu_ctx* ctx, size_t nb, const SegSpec& s0, const SegSpec* s1, bool
     const double full = 2.0 * mc->WT * mc->WT;
     // squaring rows: K == 1 triangular (WT^2 + WT(WT-1)/2 + WT); K == 2 slice-level symmetry (product part 1.5 WL^2 per lane)
     double sq = full;
+    double mulp = full;
+    if (pair) {   // five / three-and-a-half half-width products (see GenP)
+      const double H = WL;
+      mulp = 5.0 * H * H;
+      sq = 3.0 * H * H + 0.5 * H * (H - 1) + H;
+    } else
     if (use_asm && K == 1) sq = (double)mc->WT * mc->WT + 0.5 * mc->WT * (mc->WT - 1) + mc->WT;
     else if (use_asm && K == 2 && WL >= 55) sq = 2.0 * WL * WL + WL + 2.0 * mc->WT * WL;   // wave-sliced: every product once
     else if (use_asm && K == 2) sq = (double)mc->WT * mc->WT * (2.0 - 1.0 / (2 * K)) + WL;
-    ev->mads = ((montmuls - sqrs) * full + sqrs * sq) * (double)launch_nb;
+    ev->mads = ((montmuls - sqrs) * mulp + sqrs * sq) * (double)launch_nb;
     HIPCHK(hipEventRecord(ev->a, ctx->stream));
   }
+  if (pair && !use_asm) api_throw(PGPU_ERR_UNSUPPORTED, "the pair kernel exists in assembly only");
   hipError_t e = use_asm ? launch_vm_asm(WL, K, a, blocks, ctx->stream) : launch_vm(WL, K, a, blocks, ctx->stream);
   if (use_asm) ctx->last_vm_asm++;
   if (e != hipSuccess) throw HipError{e, "launch_vm"};
@@ -486,6 +505,11 @@ struct pgpu_seckey {
   int c_muR = -1;                // lambda^-1 mod n, times R mod n, in pk->mn
   DevLimbs n_minus_mu;           // (n - mu) mod n, the answer for c == 0 (L(-1) = -1)
   int c_mu2R = -1;               // lambda^-1 mod n^2, times R mod n^2, in pk->mn2 (level two)
+  // pair kernel for the p^2 / q^2 ladders (GenP): p | Cadj limb arrays, R_H mod p^2 as a plain constant of mp2 / mq2
+  bool has_pair = false;
+  DevLimbs pair_p, pair_q;
+  int c_rh_p2 = -1, c_rh_q2 = -1;
+  DevLimbs q_limbs1;               // q as mq.WT limbs (p_limbs is above)
   // level-two CRT over p^3 and q^3
   bool has_crt2 = false;
   ModCtx mp3, mq3;
@@ -497,6 +521,19 @@ struct pgpu_seckey {
   DevLimbs pinv2k_2, qinv2k_2;           // p^-1 mod 2^(28 mp2.WT), q^-1 mod 2^(28 mq2.WT)
   DevLimbs q_limbs, p2_limbs;            // q as mq.WT limbs, p^2 as mp2.WT limbs
 };
+
+// Constants of the pair kernel for a prime of H limbs: its limbs, then Cadj -- the multiple of the prime whose limbs
+// 0..H-1 can all be taken from [2^28, 2^29), so that Cadj - m is limb-wise non-negative for every quotient m < 2^(28 H).
+static std::vector<uint32_t> make_pair_consts(const BigU& pr, int H) {
+  BigU D;
+  for (int j = 0; j < H; ++j) D = D + hostbig::shl(BigU(1), (size_t)LB * j + LB);
+  BigU kq, kr;
+  hostbig::divmod(D, pr, kq, kr);
+  BigU E = (kq + BigU(1)) * pr - D;          // 0 < E <= prime < 2^(28 H)
+  std::vector<uint32_t> v = pr.to_limbs(LB, H), el = E.to_limbs(LB, H);
+  for (int j = 0; j < H; ++j) v.push_back(el[j] + (1u << LB));
+  return v;
+}
 
 // inverse of odd d modulo 2^bits
 static BigU inv_mod_pow2(const BigU& d, size_t bits) {
@@ -538,6 +575,7 @@ void pgpu_ctx_destroy(pgpu_ctx* ctx) {
 int pgpu_ctx_set_flag(pgpu_ctx* ctx, const char* name, int value) {
   if (!ctx || !name) return fail(PGPU_ERR_INVALID, "null argument");
   if (strcmp(name, "asm") == 0) { ctx->use_asm = value != 0; return PGPU_OK; }
+  if (strcmp(name, "pair") == 0) { ctx->use_pair = value != 0; return PGPU_OK; }
   if (strcmp(name, "lanes_wanted") == 0) { ctx->lanes_wanted = value > 0 ? (size_t)value : 0; return PGPU_OK; }
   return fail(PGPU_ERR_INVALID, "unknown flag %s", name);
 }
@@ -785,6 +823,42 @@ int pgpu_vm_debug_run(const pgpu_modulus* mod, const uint32_t* prog, size_t prog
   });
 }
 
+int pgpu_pair_debug_run(pgpu_ctx* ctx, const uint8_t* p_be, size_t p_len, const uint32_t* prog, size_t prog_words,
+                        uint32_t* mem_host, size_t nslots, size_t nb, uint32_t* consts_out, int* h_out) {
+  if (!ctx || !p_be || !prog || !mem_host) return fail(PGPU_ERR_INVALID, "null argument");
+  return guarded([&] {
+    if (nb % VM_BLOCK) api_throw(PGPU_ERR_INVALID, "nb must be a multiple of 256");
+    ctx->bind();
+    ctx->reset_ws();
+    const BigU pr = BigU::from_be(p_be, p_len);
+    ModCtx mp, mp2;
+    mp.init(ctx, pr);
+    mp2.init(ctx, pr * pr);
+    if (mp.K != 1 || mp2.K != 1 || mp2.WT != 2 * mp.WT || !vm_asm_available(mp.WT, 16))
+      api_throw(PGPU_ERR_UNSUPPORTED, "no pair kernel for this prime width");
+    mp2.upload();
+    const int H = mp.WT;
+    if (h_out) *h_out = H;
+    std::vector<uint32_t> pc = make_pair_consts(pr, H);
+    if (consts_out) memcpy(consts_out, pc.data(), pc.size() * 4);
+    uint32_t* d_pc = ctx->upload_words(pc);
+    size_t words = nslots * (size_t)mp2.WT * nb;
+    uint32_t* d = ctx->ws_t<uint32_t>(words);
+    HIPCHK(hipMemcpyAsync(d, mem_host, words * 4, hipMemcpyHostToDevice, ctx->stream));
+    Prog p;
+    p.w.assign(prog, prog + prog_words);
+    p.asm_ok = true;
+    SegSpec s{&mp2, &p, d, nullptr};
+    s.pair = d_pc; s.pair_n0inv = mp.n0inv; s.pair_h = H;
+    bool saved = ctx->use_asm;
+    ctx->use_asm = true;
+    try { run_vm(ctx, nb, s, nullptr, false); } catch (...) { ctx->use_asm = saved; throw; }
+    ctx->use_asm = saved;
+    HIPCHK(hipMemcpyAsync(mem_host, d, words * 4, hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHK(hipStreamSynchronize(ctx->stream));
+  });
+}
+
 int pgpu_modinv(const pgpu_modulus* mod, size_t batch, const uint8_t* x, size_t x_stride, size_t x_len, uint8_t* out,
                 size_t out_stride, int mem) {
   if (!mod) return fail(PGPU_ERR_INVALID, "null modulus");
@@ -955,6 +1029,25 @@ int pgpu_seckey_create(pgpu_ctx* ctx, const pgpu_pubkey* pk, const uint8_t* lamb
         sk->pinv2k.set(inv_mod_pow2(p, (size_t)LB * sk->mp.WT), sk->mp.WT);
         sk->qinv2k.set(inv_mod_pow2(q, (size_t)LB * sk->mq.WT), sk->mq.WT);
         sk->p_limbs.set(p, sk->mp.WT);
+        sk->q_limbs1.set(q, sk->mq.WT);
+        if (sk->mp.K == 1 && sk->mp2.K == 1 && sk->mp2.WT == 2 * sk->mp.WT && vm_asm_available(sk->mp.WT, 16)) {
+          const int H = sk->mp.WT;
+          auto pair_consts = [&](const BigU& pr) { return make_pair_consts(pr, H); };
+          std::vector<uint32_t> vp = pair_consts(p), vq = pair_consts(q);
+          auto put = [&](DevLimbs& d, const std::vector<uint32_t>& v) {
+            d.w = (int)v.size();
+            HIPCHK(hipMalloc((void**)&d.d, v.size() * 4));
+            HIPCHK(hipMemcpy(d.d, v.data(), v.size() * 4, hipMemcpyHostToDevice));
+          };
+          put(sk->pair_p, vp);
+          put(sk->pair_q, vq);
+          const BigU RH = hostbig::shl(BigU(1), (size_t)LB * H);
+          sk->c_rh_p2 = sk->mp2.add_const(RH % sk->mp2.N);
+          sk->c_rh_q2 = sk->mq2.add_const(RH % sk->mq2.N);
+          sk->mp2.upload();
+          sk->mq2.upload();
+          sk->has_pair = true;
+        }
         if (pk->mn3 && sk->c_mu2R >= 0) {
           const BigU p2 = p * p, q2 = q * q;
           sk->mp3.init(ctx, p2 * p);
@@ -1022,14 +1115,64 @@ uint32_t* decrypt1_crt(const pgpu_seckey* sk, const uint32_t* c_limbs, size_t nb
   // big VM memory: slots 0,1 = c (lo, hi); P: tmp 2, out 3, table 4..35; Q: tmp 36, out 37, table 38..69
   uint32_t* mem = ctx->ws_t<uint32_t>(S2 * 70);
   HIPCHK(hipMemcpyAsync(mem, c_limbs, S2 * 2 * 4, hipMemcpyDeviceToDevice, ctx->stream));
-  Prog pp, pq;
-  emit_modexp_shared(pp, sk->p - BigU(1), 0, 1, 2, 3, 4, NO_SLOT, true);
-  pp.end();
-  emit_modexp_shared(pq, sk->q - BigU(1), 0, 1, 36, 37, 38, NO_SLOT, true);
-  pq.end();
-  SegSpec sp{&mp2, &pp, mem, nullptr}, sq{&mq2, &pq, mem, nullptr};
-  run_vm(ctx, nb, sp, &sq, true);
   uint32_t *up = mem + 3 * S2, *uq = mem + 37 * S2;
+  if (sk->has_pair && ctx->use_asm && ctx->use_pair) {
+    // The ladder runs on the pair kernel (residues mod p^2 as two base-p digits: 58 % of the multiplies of a squaring).
+    // (1) X = c R_H mod p^2 on the ordinary kernel, canonical
+    {
+      Prog a, b;
+      emit_to_mont(a, 0, 1, 2);  a.op(VM_MULC, (uint32_t)sk->c_rh_p2); a.op(VM_STORE, 3);  a.end();
+      emit_to_mont(b, 0, 1, 36); b.op(VM_MULC, (uint32_t)sk->c_rh_q2); b.op(VM_STORE, 37); b.end();
+      SegSpec sa{&mp2, &a, mem, nullptr}, sb{&mq2, &b, mem, nullptr};
+      run_vm(ctx, nb, sa, &sb, false);
+      launch_canon(up, mp2.d_nmod, W2, nb, ctx->stream);
+      launch_canon(uq, mq2.d_nmod, W2, nb, ctx->stream);
+    }
+    // (2) digits X = X0 + X1 prime  ->  slots 2 / 36 (X0 in limbs 0..H-1, X1 in limbs H..2H-1)
+    {
+      uint32_t* x0 = ctx->ws_t<uint32_t>(S1 * 2);
+      uint32_t* tbx = ctx->ws_t<uint32_t>(S2);
+      int32_t* st_dummy = ctx->ws_t<int32_t>(nb);
+      HIPCHK(hipMemsetAsync(st_dummy, 0, nb * 4, ctx->stream));
+      reduce_mod(ctx, mp, up, W2, x0, nb);
+      reduce_mod(ctx, mq, uq, W2, x0 + S1, nb);
+      uint32_t *dp = mem + 2 * S2, *dq = mem + 36 * S2;
+      launch_div_exact(up, W2, 0, x0, W1, tbx, sk->pinv2k.d, mp.d_nmod, W1, dp + S1, W1, nb, count, st_dummy, 2, ctx->stream);
+      launch_div_exact(uq, W2, 0, x0 + S1, W1, tbx, sk->qinv2k.d, mq.d_nmod, W1, dq + S1, W1, nb, count, st_dummy, 2, ctx->stream);
+      HIPCHK(hipMemcpyAsync(dp, x0, S1 * 4, hipMemcpyDeviceToDevice, ctx->stream));
+      HIPCHK(hipMemcpyAsync(dq, x0 + S1, S1 * 4, hipMemcpyDeviceToDevice, ctx->stream));
+    }
+    // (3) the ladder: x^(prime - 1) in pair form
+    {
+      Prog pp, pq;
+      emit_modexp_shared(pp, sk->p - BigU(1), 2, NO_SLOT, 2, 3, 4, NO_SLOT, true, true);
+      pp.end();
+      emit_modexp_shared(pq, sk->q - BigU(1), 36, NO_SLOT, 36, 37, 38, NO_SLOT, true, true);
+      pq.end();
+      SegSpec sp{&mp2, &pp, mem, nullptr}, sq{&mq2, &pq, mem, nullptr};
+      sp.pair = sk->pair_p.d; sp.pair_n0inv = mp.n0inv; sp.pair_h = W1;
+      sq.pair = sk->pair_q.d; sq.pair_n0inv = mq.n0inv; sq.pair_h = W1;
+      run_vm(ctx, nb, sp, &sq, true);
+    }
+    // (4) back: F~ = F0 + F1 prime (an integer = F R_H mod p^2, lazy), then F = F~ R_H^-1 on the ordinary kernel
+    {
+      launch_mul_const_add(up + S1, W1, sk->p_limbs.d, W1, up, W1, 0, mem + 2 * S2, W2, nb, ctx->stream);
+      launch_mul_const_add(uq + S1, W1, sk->q_limbs1.d, W1, uq, W1, 0, mem + 36 * S2, W2, nb, ctx->stream);
+      Prog a, b;
+      a.op(VM_LOAD, 2);  a.op(VM_MULC, (uint32_t)sk->c_rh_p2); a.op(VM_STORE, 3);  a.end();
+      b.op(VM_LOAD, 36); b.op(VM_MULC, (uint32_t)sk->c_rh_q2); b.op(VM_STORE, 37); b.end();
+      SegSpec sa{&mp2, &a, mem, nullptr}, sb{&mq2, &b, mem, nullptr};
+      run_vm(ctx, nb, sa, &sb, false);
+    }
+  } else {
+    Prog pp, pq;
+    emit_modexp_shared(pp, sk->p - BigU(1), 0, 1, 2, 3, 4, NO_SLOT, true);
+    pp.end();
+    emit_modexp_shared(pq, sk->q - BigU(1), 0, 1, 36, 37, 38, NO_SLOT, true);
+    pq.end();
+    SegSpec sp{&mp2, &pp, mem, nullptr}, sq{&mq2, &pq, mem, nullptr};
+    run_vm(ctx, nb, sp, &sq, true);
+  }
   launch_canon(up, mp2.d_nmod, W2, nb, ctx->stream);
   launch_canon(uq, mq2.d_nmod, W2, nb, ctx->stream);
   // small memory: slots 0 Lp, 1 Lq, 2 mp, 3 mq, 4 B, 5 A, 6 h

@@ -1438,11 +1438,213 @@ class GenW(Gen):
         return "\n".join(self.lines) + "\n"
 
 
-SHAPES = [(74, 1), (37, 1), (55, 1), (55, 2), (74, 2), (55, 4), (37, 2), (37, 4)]
+class GenP(Gen):
+    """Pair kernel for moduli N = p^2 (Paillier's CRT halves): a residue y mod p^2 is kept as two base-p digits
+    y~ = y R mod p^2 = a0 + a1 p   (R = 2^(28 H), H = limbs of p; a0, a1 lazily reduced mod p)
+    and a product costs five half-width limb products instead of eight:
+        a0 b0 = t R - m p            (Montgomery step mod p; m = the quotient digits it computes anyway)
+        c0 = t,   c1 = (a0 b1 + a1 b0 + Cadj - m) R^-1 mod p      (one more Montgomery step mod p)
+    because a1 b1 p^2 vanishes and the reduction modulo p^2 splits into two reductions modulo p.  Cadj is a multiple of p
+    whose limbs all exceed 2^28, so Cadj - m is limb-wise non-negative (no borrows in the lazy accumulators).
+    A squaring needs H(H-1)/2 + H + 3 H^2 multiplies instead of (2H)(2H-1)/2 + 2H + 4 H^2: 58 %.
+    Same VM contract as vm_asm_74_1 (74-limb values: a0 in limbs 0..H-1, a1 in limbs H..2H-1); SQR and MUL are the pair
+    operations; `nmod` points at p (H limbs) followed by Cadj (H limbs), `n0inv` belongs to p.
+    Phase 1 (a0 b0 and its reduction) is fully unrolled: static column renaming instead of the register shift, the
+    triangular rows of a squaring need no computed jump, and each quotient digit lands in its own register."""
+
+    def __init__(self, H=37):
+        Gen.__init__(self, 2 * H, 1)
+        assert H % 2 == 1 and 6 * H <= 224
+        self.H = H
+        self.name = f"vm_asm_{H}_16"
+        self.sq_rows = True
+        self.vM = 2 * H            # quotient digits of phase 1, as Cadj_i - m_i
+        self.vA = 3 * H            # new a0 of a MUL (the old one is still an operand of phase 2)
+
+    def X0(self, j):
+        return self.X(j)
+
+    def X1(self, j):
+        return self.X(self.H + j)
+
+    def Pm(self, j):
+        return f"s{self.s_N + j}"
+
+    def Cd(self, j):
+        return f"s{self.s_N + self.H + j}"
+
+    # ---- phase 1: c0 = a0 * b0 * R^-1 mod p, quotient digits captured -------------------------------------------
+    def phase1(self, sq, dest):
+        g, e = self, self.e
+        H = self.H
+        row = self.NPB * 4
+        m = f"v{g.v_m}"
+        fresh = set(range(H))
+
+        def acc(pos, a, b):
+            c = pos % H
+            if c in fresh:
+                fresh.discard(c)
+                self.mad(self.T(c), a, b, "0")
+            else:
+                self.mad(self.T(c), a, b, self.T(c))
+
+        if not sq:
+            e(f"ds_read_b32 v{g.v_ain}, v{g.v_aread}")
+        regs = [g.v_ain, g.v_ai]
+        for i in range(H):
+            if sq:
+                ai = self.X0(i)
+                e(f"v_add_u32 v{g.v_ai}, {ai}, {ai}")
+                self.align8()
+                acc(2 * i, ai, ai)
+                for j in range(i + 1, H):
+                    acc(i + j, f"v{g.v_ai}", self.X0(j))
+            else:
+                cur, nxt = regs[i % 2], regs[(i + 1) % 2]
+                e("s_waitcnt lgkmcnt(0)")
+                if i + 1 < H:
+                    e(f"ds_read_b32 v{nxt}, v{g.v_aread} offset:{(i + 1) * row}")
+                self.align8()
+                for j in range(H):
+                    acc(i + j, f"v{cur}", self.X0(j))
+            c0 = i % H
+            assert c0 not in fresh
+            e(f"v_mul_lo_u32 {m}, {self.Tlo(c0)}, s14")
+            e(f"v_and_b32 {m}, {hex(MASK)}, {m}")
+            e(f"v_sub_u32 v{g.vM + i}, {self.Cd(i)}, {m}")
+            self.align8()
+            for j in range(H):
+                acc(i + j, m, self.Pm(j))
+            e(f"v_lshrrev_b64 {self.P(g.v_c)}, {LB}, {self.T(c0)}")
+            e(f"v_lshl_add_u64 {self.T((i + 1) % H)}, {self.T((i + 1) % H)}, 0, {self.P(g.v_c)}")
+            fresh.add(c0)
+        # columns H .. 2H-1 hold c0; the one just retired is position 2H-1... no: position H-1 was retired, i.e. column
+        # (H-1) % H is free and position 2H-1 was never opened unless written above
+        live = {}
+        for pos in range(H, 2 * H):
+            c = pos % H
+            if c in fresh:
+                e(f"v_mov_b64 {self.T(c)}, 0")
+                fresh.discard(c)
+            live[pos] = c
+        # sequential carry into dest[0..H-1]
+        M = hex(MASK)
+        cpair = self.P(g.v_c)
+        first = True
+        for k, pos in enumerate(range(H, 2 * H)):
+            c = live[pos]
+            if not first:
+                e(f"v_lshl_add_u64 {self.T(c)}, {self.T(c)}, 0, {cpair}")
+            first = False
+            e(f"v_and_b32 {dest(k)}, {M}, {self.Tlo(c)}")
+            if k < H - 1:
+                e(f"v_lshrrev_b64 {cpair}, {LB}, {self.T(c)}")
+
+    # ---- phase 2: c1 = (cross + Cadj - m) R^-1 mod p ---------------------------------------------------------------
+    def phase2_row(self, sq, cur, nxt, cur1, nxt1, first):
+        """one row, register-shift style (T(j-1) <- T(j) + m' p_j).  sq: multiplier 2 a0_i times a1; else b0_i times a1
+        plus b1_i times a0.  cur/nxt: a_i registers (this row / prefetch); cur1/nxt1: the b1 stream of a MUL."""
+        g, e = self, self.e
+        H = self.H
+        row = self.NPB * 4
+        m = f"v{g.v_m}"
+        e("s_waitcnt lgkmcnt(0)")
+        e(f"ds_read_b32 v{nxt}, v{g.v_arow}")
+        if not sq:
+            e(f"ds_read_b32 v{nxt1}, v{g.v_arow} offset:{H * row}")
+        e(f"v_add_u32 v{g.v_arow}, {row}, v{g.v_arow}")
+        if sq:
+            e(f"v_add_u32 v{cur}, v{cur}, v{cur}")
+        a = f"v{cur}"
+        self.align8()
+        for j in range(H):
+            if j == H - 1 and not first:
+                self.mad(self.T(j), a, self.X1(j), "0")
+            else:
+                self.mad(self.T(j), a, self.X1(j), self.T(j))
+        if not sq:
+            for j in range(H):
+                self.mad(self.T(j), f"v{cur1}", self.X0(j), self.T(j))
+        e(f"v_mul_lo_u32 {m}, {self.Tlo(0)}, s14")
+        e(f"v_and_b32 {m}, {hex(MASK)}, {m}")
+        self.align8()
+        self.mad(self.P(g.v_y0), m, self.Pm(0), self.T(0))
+        self.mad(self.T(0), m, self.Pm(1), self.T(1))
+        e(f"v_lshrrev_b64 {self.P(g.v_c)}, {LB}, {self.P(g.v_y0)}")
+        for j in range(2, H):
+            self.mad(self.T(j - 1), m, self.Pm(j), self.T(j))
+            if j == 4:
+                e(f"v_lshl_add_u64 {self.T(0)}, {self.T(0)}, 0, {self.P(g.v_c)}")
+
+    def phase2(self, sq, tag):
+        g, e = self, self.e
+        H = self.H
+        row = self.NPB * 4
+        for j in range(H):
+            e(f"v_mov_b32 {self.Tlo(j)}, v{g.vM + j}")
+            e(f"v_mov_b32 {self.Thi(j)}, 0")
+        e(f"v_mov_b32 v{g.v_arow}, v{g.v_aread}")
+        e(f"ds_read_b32 v{g.v_ain}, v{g.v_arow}")
+        if not sq:
+            e(f"ds_read_b32 v{g.v_t2}, v{g.v_arow} offset:{H * row}")
+        e(f"v_add_u32 v{g.v_arow}, {row}, v{g.v_arow}")
+        # row 0 keeps the initial value of the top column; then (H-1)/2 iterations of two rows
+        self.phase2_row(sq, g.v_ain, g.v_ai, g.v_t2, g.v_t3, True)
+        e("s_mov_b32 s19, 1")
+        e(".p2align 6")
+        e(f"L_p2{tag}:")
+        self.phase2_row(sq, g.v_ai, g.v_ain, g.v_t3, g.v_t2, False)
+        self.phase2_row(sq, g.v_ain, g.v_ai, g.v_t2, g.v_t3, False)
+        e("s_add_u32 s19, s19, 2")
+        e(f"s_cmp_lt_u32 s19, {H}")
+        e(f"s_cbranch_scc1 L_p2{tag}")
+        e("s_waitcnt lgkmcnt(0)")
+        e(f"v_mov_b64 {self.T(H - 1)}, 0")
+        M = hex(MASK)
+        c = self.P(g.v_c)
+        e(f"v_and_b32 {self.X1(0)}, {M}, {self.Tlo(0)}")
+        e(f"v_lshrrev_b64 {c}, {LB}, {self.T(0)}")
+        for j in range(1, H):
+            e(f"v_lshl_add_u64 {self.T(j)}, {self.T(j)}, 0, {c}")
+            e(f"v_and_b32 {self.X1(j)}, {M}, {self.Tlo(j)}")
+            if j < H - 1:
+                e(f"v_lshrrev_b64 {c}, {LB}, {self.T(j)}")
+
+    def montsq(self):
+        e = self.e
+        e("L_montsq:")
+        self.phase1(True, self.X0)        # phase 2 reads a0 from the LDS column, so the new a0 can replace the old one now
+        self.phase2(True, "s")
+        e("s_branch L_next")
+
+    def montmul(self):
+        g, e = self, self.e
+        H = self.H
+        e("L_montmul:")
+        self.phase1(False, lambda k: f"v{g.vA + k}")
+        self.phase2(False, "m")
+        for j in range(H):
+            e(f"v_mov_b32 {self.X0(j)}, v{g.vA + j}")
+        e("s_branch L_next")
+
+    def generate(self):
+        self.prologue()
+        self.dispatcher()
+        self.montmul()
+        self.montsq()
+        self.epilogue()
+        return "\n".join(self.lines) + "\n"
+
+
+SHAPES = [(74, 1), (37, 1), (55, 1), (55, 2), (74, 2), (55, 4), (37, 2), (37, 4), (37, 16)]
+PAIR = {(37, 16)}           # (H, 16): the pair kernel for N = p^2 with H-limb p (GenP); 16 is a tag, not a lane count
 WAVE_SLICED = {(74, 2), (55, 2)}     # shapes whose slices live in different waves (GenW) instead of neighbouring lanes (Gen)
 
 
 def make_gen(wl, k):
+    if (wl, k) in PAIR:
+        return GenP(wl)
     return GenW(wl, k) if (wl, k) in WAVE_SLICED else Gen(wl, k)
 
 

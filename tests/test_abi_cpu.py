@@ -68,6 +68,18 @@ def test_asm_generator_model():
         g = gen_vm_asm.make_gen(wl, k)
         text = g.generate()
         assert g.n_vgpr <= 256
+        if (wl, k) in gen_vm_asm.PAIR:
+            # pair kernel: H(H-1)/2 + H + H^2 multiplies in the unrolled phase 1 of a squaring, 2 H^2 in phase 1 of a product,
+            # phase-2 rows of 2H (squaring) and 3H (product) multiplies, one peeled row + a two-row loop body each
+            H = wl
+            sq = text.split("L_montsq:")[1]
+            p1 = sq.split("L_p2s:")[0]
+            assert p1.count("v_mad_u64_u32") == H * (H - 1) // 2 + H + H * H + 2 * H        # + the peeled phase-2 row
+            assert sq.split("L_p2s:")[1].split("s_cbranch_scc1 L_p2s")[0].count("v_mad_u64_u32") == 2 * 2 * H
+            mm = text.split("L_montmul:")[1].split("L_montsq:")[0]
+            assert mm.split("L_p2m:")[0].count("v_mad_u64_u32") == 2 * H * H + 3 * H
+            assert mm.split("L_p2m:")[1].split("s_cbranch_scc1 L_p2m")[0].count("v_mad_u64_u32") == 2 * 3 * H
+            continue
         if (wl, k) in gen_vm_asm.WAVE_SLICED:
             # slices in different waves: each wave's product loop is two rows of 2*WL multiplies; the squaring rows of both
             # waves are triangular tables of WL-1 / WL entries behind a computed jump, plus WL reduction multiplies

@@ -1,0 +1,125 @@
+"""GPU parity for the pair kernel (gen_vm_asm.py GenP): residues modulo p^2 kept as two base-p digits
+y R mod p^2 = a0 + a1 p, product = two Montgomery steps modulo p.  Every digit the kernel produces is an exact integer
+function of its inputs, so the comparison with the Python restatement below is bit for bit; a whole ladder is then checked
+against pow(); and Decrypt (which runs its ladders on this kernel for 2048-bit keys) must not depend on the "pair" switch."""
+import json
+import os
+import random
+
+import numpy as np
+import pytest
+
+from model28 import to_limbs, from_limbs
+
+pytestmark = pytest.mark.gpu
+G = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+END, LOAD, STORE, SQR, MUL = 0, 1, 2, 4, 5
+LB = 28
+
+
+@pytest.fixture(scope="module")
+def ctx():
+    import paillier_amd as pa
+    return pa.Context(0)
+
+
+def pair_model(p, H, cadj):
+    R = 1 << (LB * H)
+    nneg = (-pow(p, -1, R)) % R
+
+    def mont(u):
+        m = (u * nneg) % R
+        return (u + m * p) // R, m
+
+    def pmul(a, b):
+        t, m = mont(a[0] * b[0])
+        c1, _ = mont(a[0] * b[1] + a[1] * b[0] + cadj - m)
+        return (t, c1)
+    return pmul, R
+
+
+def test_pair_products_match_the_integer_model(ctx):
+    k = json.load(open(os.path.join(G, "keys.json")))["paillier"]["2048"]
+    p = int(k["p"], 16)
+    rng = random.Random(20)
+    nb, nslots = 256, 6
+    H = 37
+    mem = np.zeros((nslots, 2 * H, nb), dtype=np.uint32)
+    vals = {}
+    for s in (0, 1):
+        for g in range(nb):
+            hi = 2 * p if g % 3 else p            # lazy digits up to 2p as well as canonical ones
+            a = (rng.randrange(hi), rng.randrange(hi))
+            if g == 0:
+                a = (0, 0)
+            if g == 1:
+                a = (p - 1, p - 1)
+            vals[s, g] = a
+            mem[s, :H, g] = to_limbs(a[0], H)
+            mem[s, H:, g] = to_limbs(a[1], H)
+    prog = [LOAD, 0, SQR, 0, STORE, 2, LOAD, 0, MUL, 1, STORE, 3, SQR, 0, SQR, 0, MUL, 0, STORE, 4, END, 0]
+    out, consts, h = ctx.pair_debug_run(p, prog, mem, nslots, nb)
+    assert h == H and from_limbs(consts[:H]) == p
+    cadj = from_limbs(consts[H:])
+    assert cadj % p == 0 and all((1 << LB) <= int(c) < (2 << LB) for c in consts[H:])
+    pmul, R = pair_model(p, H, cadj)
+    for g in range(nb):
+        x, y = vals[0, g], vals[1, g]
+        sq = pmul(x, x)
+        xy = pmul(x, y)
+        t = pmul(xy, xy)
+        t = pmul(t, t)
+        t = pmul(t, x)
+        for slot, want in ((2, sq), (3, xy), (4, t)):
+            got = (from_limbs(out[slot, :H, g]), from_limbs(out[slot, H:, g]))
+            assert got == want, (g, slot)
+            assert all(int(v) < (1 << LB) for v in out[slot, :, g])
+
+
+def test_pair_ladder_is_a_modexp(ctx):
+    k = json.load(open(os.path.join(G, "keys.json")))["paillier"]["2048"]
+    q = int(k["q"], 16)
+    H, nb, nslots = 37, 256, 3
+    rng = random.Random(21)
+    R = 1 << (LB * H)
+    q2 = q * q
+    ys = [rng.randrange(q2) for _ in range(nb)]
+    mem = np.zeros((nslots, 2 * H, nb), dtype=np.uint32)
+    for g, y in enumerate(ys):
+        yt = y * R % q2
+        mem[0, :H, g] = to_limbs(yt % q, H)
+        mem[0, H:, g] = to_limbs(yt // q, H)
+    e = rng.getrandbits(90) | (1 << 89)
+    prog = [LOAD, 0]
+    for bit in bin(e)[3:]:
+        prog += [SQR, 0]
+        if bit == "1":
+            prog += [MUL, 0]
+    prog += [STORE, 1, END, 0]
+    out, _, _ = ctx.pair_debug_run(q, prog, mem, nslots, nb)
+    rinv = pow(R, -1, q2)
+    for g, y in enumerate(ys):
+        got = (from_limbs(out[1, :H, g]) + from_limbs(out[1, H:, g]) * q) * rinv % q2
+        assert got == pow(y, e, q2), g
+
+
+def test_decrypt_does_not_depend_on_the_pair_switch(ctx):
+    import paillier_amd as pa
+    from oracle import paillier_oracle as po
+    k = json.load(open(os.path.join(G, "keys.json")))["paillier"]["2048"]
+    p, q = int(k["p"], 16), int(k["q"], 16)
+    n, lam = p * q, (p - 1) * (q - 1)
+    pk = pa.PublicKey(ctx, n, n + 1)
+    sk = pa.SecretKey(ctx, pk, lam)
+    sk_o = po.SecretKey(N=n, G=n + 1, Lambda=lam)
+    rng = random.Random(22)
+    cts = [rng.randrange(n * n) for _ in range(700)] + [0, 1, p, q, n, n * n - 1, p * p, 5 * q]
+    try:
+        ctx.set_flag("pair", 1)
+        with_pair = sk.DecryptBatch(cts)
+        ctx.set_flag("pair", 0)
+        without = sk.DecryptBatch(cts)
+    finally:
+        ctx.set_flag("pair", 1)
+    assert with_pair == without
+    assert with_pair[:40] + with_pair[-8:] == [po.decrypt(sk_o, po.Ciphertext(c)) for c in cts[:40] + cts[-8:]]
