@@ -1132,13 +1132,11 @@ uint32_t* decrypt1_crt(const pgpu_seckey* sk, const uint32_t* c_limbs, size_t nb
     {
       uint32_t* x0 = ctx->ws_t<uint32_t>(S1 * 2);
       uint32_t* tbx = ctx->ws_t<uint32_t>(S2);
-      int32_t* st_dummy = ctx->ws_t<int32_t>(nb);
-      HIPCHK(hipMemsetAsync(st_dummy, 0, nb * 4, ctx->stream));
       reduce_mod(ctx, mp, up, W2, x0, nb);
       reduce_mod(ctx, mq, uq, W2, x0 + S1, nb);
       uint32_t *dp = mem + 2 * S2, *dq = mem + 36 * S2;
-      launch_div_exact(up, W2, 0, x0, W1, tbx, sk->pinv2k.d, mp.d_nmod, W1, dp + S1, W1, nb, count, st_dummy, 2, ctx->stream);
-      launch_div_exact(uq, W2, 0, x0 + S1, W1, tbx, sk->qinv2k.d, mq.d_nmod, W1, dq + S1, W1, nb, count, st_dummy, 2, ctx->stream);
+      launch_div_exact(up, W2, 0, x0, W1, tbx, sk->pinv2k.d, mp.d_nmod, W1, dp + S1, W1, nb, count, nullptr, 0, ctx->stream);
+      launch_div_exact(uq, W2, 0, x0 + S1, W1, tbx, sk->qinv2k.d, mq.d_nmod, W1, dq + S1, W1, nb, count, nullptr, 0, ctx->stream);
       HIPCHK(hipMemcpyAsync(dp, x0, S1 * 4, hipMemcpyDeviceToDevice, ctx->stream));
       HIPCHK(hipMemcpyAsync(dq, x0 + S1, S1 * 4, hipMemcpyDeviceToDevice, ctx->stream));
     }

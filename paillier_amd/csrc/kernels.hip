@@ -290,6 +290,74 @@ __global__ void k_div_exact(const uint32_t* __restrict__ u, int wu, uint32_t sub
   if (bad && g < count) status[g] |= flag;
 }
 
+// Register-resident versions of the two helpers on the Decrypt-2048 path (fixed widths, fully unrolled: the operand
+// lives in VGPRs instead of being re-read from memory for every limb product).  A column of <= 64 products of
+// 28-bit limbs plus the incoming carry stays below 2^63, so one 64-bit accumulator per column is enough.
+template <int WU, int WL, int WD, bool CHECK>
+__global__ void __launch_bounds__(256) k_div_exact_t(const uint32_t* __restrict__ u, uint32_t sub_small,
+                                                     const uint32_t* __restrict__ subv,
+                                                     const uint32_t* __restrict__ dinv, const uint32_t* __restrict__ d,
+                                                     uint32_t* __restrict__ l, size_t nb, size_t count,
+                                                     int32_t* __restrict__ status, int32_t flag) {
+  static_assert(WL <= 64 && WD <= 64, "single 64-bit column accumulator");
+  size_t g = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (g >= nb) return;
+  uint32_t t[WU];
+  int32_t br = 0;
+#pragma unroll
+  for (int i = 0; i < WU; ++i) {
+    int32_t v = (int32_t)u[(size_t)i * nb + g] - br - (i == 0 ? (int32_t)sub_small : 0) -
+                ((subv && i < WL) ? (int32_t)subv[(size_t)i * nb + g] : 0);
+    br = v < 0;
+    t[i] = (uint32_t)(v + (br << LB)) & LMASK;
+  }
+  int bad = br;
+  uint32_t q[WL];
+  uint64_t acc = 0;
+#pragma unroll
+  for (int c = 0; c < WL; ++c) {
+#pragma unroll
+    for (int i = 0; i <= c; ++i) acc += (uint64_t)t[i] * dinv[c - i];
+    q[c] = (uint32_t)acc & LMASK;
+    acc >>= LB;
+  }
+#pragma unroll
+  for (int c = 0; c < WL; ++c) l[(size_t)c * nb + g] = q[c];
+  if (CHECK) {
+    acc = 0;
+#pragma unroll
+    for (int c = 0; c < WU; ++c) {
+#pragma unroll
+      for (int i = (c - (WD - 1) > 0 ? c - (WD - 1) : 0); i <= (c < WL - 1 ? c : WL - 1); ++i) acc += (uint64_t)q[i] * d[c - i];
+      bad |= ((uint32_t)acc & LMASK) != t[c];
+      acc >>= LB;
+    }
+    bad |= acc != 0;
+    if (bad && g < count) status[g] |= flag;
+  }
+}
+
+template <int WA, int WB, int WO>
+__global__ void __launch_bounds__(256) k_mul_const_add_t(const uint32_t* __restrict__ a, const uint32_t* __restrict__ bconst,
+                                                         const uint32_t* __restrict__ addv, int wadd, uint32_t add_small,
+                                                         uint32_t* __restrict__ out, size_t nb) {
+  static_assert(WA <= 64 && WB <= 64, "single 64-bit column accumulator");
+  size_t g = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (g >= nb) return;
+  uint32_t x[WA];
+#pragma unroll
+  for (int i = 0; i < WA; ++i) x[i] = a[(size_t)i * nb + g];
+  uint64_t acc = add_small;
+#pragma unroll
+  for (int c = 0; c < WO; ++c) {
+#pragma unroll
+    for (int i = (c - (WB - 1) > 0 ? c - (WB - 1) : 0); i <= (c < WA - 1 ? c : WA - 1); ++i) acc += (uint64_t)x[i] * bconst[c - i];
+    if (addv && c < wadd) acc += addv[(size_t)c * nb + g];
+    out[(size_t)c * nb + g] = (uint32_t)acc & LMASK;
+    acc >>= LB;
+  }
+}
+
 // out = x - 1 (w limbs); x == 0 wraps to all-ones limbs (callers flag that lane separately)
 __global__ void k_sub_one(const uint32_t* __restrict__ x, uint32_t* __restrict__ out, int w, size_t nb) {
   size_t g = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -569,11 +637,30 @@ void launch_canon(uint32_t* x, const uint32_t* nmod, int wt, size_t nb, hipStrea
 }
 void launch_mul_const_add(const uint32_t* a, int wa, const uint32_t* bconst, int wb, const uint32_t* addv, int wadd,
                           uint32_t add_small, uint32_t* out, int wo, size_t nb, hipStream_t st) {
+  if (wa == 37 && wb == 37 && wo == 74 && (!addv || wadd <= 74)) {
+    hipLaunchKernelGGL((k_mul_const_add_t<37, 37, 74>), HELPER_GRID(nb), 0, st, a, bconst, addv, wadd, add_small, out, nb);
+    return;
+  }
   hipLaunchKernelGGL(k_mul_const_add, HELPER_GRID(nb), 0, st, a, wa, bconst, wb, addv, wadd, add_small, out, wo, nb);
 }
 void launch_div_exact(const uint32_t* u, int wu, uint32_t sub_small, const uint32_t* subv, int wsub, uint32_t* tbuf,
                       const uint32_t* dinv, const uint32_t* d, int wd, uint32_t* l, int wl, size_t nb, size_t count,
                       int32_t* status, int32_t flag, hipStream_t st) {
+  // status == nullptr: the caller knows the division is exact (digit split): no check
+  if (wu == 74 && wl == 37 && wd == 37 && (!subv || wsub == 37)) {
+    if (status)
+      hipLaunchKernelGGL((k_div_exact_t<74, 37, 37, true>), HELPER_GRID(nb), 0, st, u, sub_small, subv, dinv, d, l, nb, count,
+                         status, flag);
+    else
+      hipLaunchKernelGGL((k_div_exact_t<74, 37, 37, false>), HELPER_GRID(nb), 0, st, u, sub_small, subv, dinv, d, l, nb, count,
+                         status, flag);
+    return;
+  }
+  if (!status) {   // generic widths: run the check against a scratch word nobody reads (count = 0 masks every lane)
+    hipLaunchKernelGGL(k_div_exact, HELPER_GRID(nb), 0, st, u, wu, sub_small, subv, wsub, tbuf, dinv, d, wd, l, wl, nb,
+                       (size_t)0, (int32_t*)tbuf, 0);
+    return;
+  }
   hipLaunchKernelGGL(k_div_exact, HELPER_GRID(nb), 0, st, u, wu, sub_small, subv, wsub, tbuf, dinv, d, wd, l, wl, nb, count,
                      status, flag);
 }
