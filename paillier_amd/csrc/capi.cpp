@@ -67,7 +67,10 @@ struct pgpu_ctx {
   void bind() { HIPCHK(hipSetDevice(device)); }
 
   void reset_ws() {
-    if (chunks.size() > 1) {  // consolidate into one chunk of the total size
+    // Chunks are kept across calls (the same call sequence lands in the same chunks again: no allocation in steady
+    // state).  Only a long tail of chunks is consolidated: that costs a device synchronisation and a large hipMalloc
+    // (~100 ms), which must not land in a caller's second call.
+    if (chunks.size() > 8) {
       HIPCHK(hipStreamSynchronize(stream));
       size_t total = 0;
       for (auto& c : chunks) { total += c.cap; HIPCHK(hipFree(c.p)); }
