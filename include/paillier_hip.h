@@ -215,8 +215,10 @@ int pgpu_vm_debug_run(const pgpu_modulus* mod, const uint32_t* prog, size_t prog
 
 /* Same for the pair kernel (residues modulo p^2 as two base-p digits, the Decrypt ladder of 2048-bit keys): slots are
  * [2H][nb] limb arrays (digit a0 in limbs 0..H-1, a1 in limbs H..2H-1), SQR / MUL are the pair operations.
+ * lanes = 1: the one-lane kernel for N = p^2 with a 37-limb prime (Decrypt); lanes = 2: the two-lane kernel for N = n^2 with
+ * a 74-limb public n (Encrypt, PartialDecrypt, ...; any odd n).
  * consts_out (optional, 2H words) receives the kernel's constants p | Cadj, h_out the digit width H. */
-int pgpu_pair_debug_run(pgpu_ctx* ctx, const uint8_t* p_be, size_t p_len, const uint32_t* prog, size_t prog_words,
+int pgpu_pair_debug_run(pgpu_ctx* ctx, const uint8_t* p_be, size_t p_len, int lanes, const uint32_t* prog, size_t prog_words,
                         uint32_t* mem_host, size_t nslots, size_t nb, uint32_t* consts_out, int* h_out);
 
 #ifdef __cplusplus

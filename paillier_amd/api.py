@@ -75,7 +75,7 @@ SIGNATURES = {
     "pgpu_modulus_bytes": (_sz, [_vp]),
     "pgpu_modexp": (_int, [_vp, _sz, _vp, _sz, _sz, _vp, _sz, _sz, _vp, _sz, _int]),
     "pgpu_vm_debug_run": (_int, [_vp, _vp, _sz, _vp, _sz, _sz, _int, C.POINTER(_int)]),
-    "pgpu_pair_debug_run": (_int, [_vp, _vp, _sz, _vp, _sz, _vp, _sz, _sz, _vp, C.POINTER(_int)]),
+    "pgpu_pair_debug_run": (_int, [_vp, _vp, _sz, _int, _vp, _sz, _vp, _sz, _sz, _vp, C.POINTER(_int)]),
     "pgpu_modinv": (_int, [_vp, _sz, _vp, _sz, _sz, _vp, _sz, _int]),
     "pgpu_modmul": (_int, [_vp, _sz, _vp, _sz, _sz, _vp, _sz, _sz, _vp, _sz, _int]),
 }
@@ -145,14 +145,14 @@ class Context:
     def set_flag(self, name: str, value: int):
         _check(self.lib.pgpu_ctx_set_flag(self.h, name.encode(), value))
 
-    def pair_debug_run(self, prime: int, prog_words: Sequence[int], mem: np.ndarray, nslots: int, nb: int):
+    def pair_debug_run(self, prime: int, prog_words: Sequence[int], mem: np.ndarray, nslots: int, nb: int, lanes: int = 1):
         """Test hook (pgpu_pair_debug_run).  mem: uint32[nslots, 2H, nb].  Returns (memory after the run, constants p|Cadj, H)."""
         pw = np.asarray(prog_words, dtype=np.uint32)
         m = np.ascontiguousarray(mem, dtype=np.uint32).copy()
         pb = np.frombuffer(_be(prime), dtype=np.uint8).copy()
         consts = np.zeros(m.shape[1], dtype=np.uint32)
         h = C.c_int()
-        _check(self.lib.pgpu_pair_debug_run(self.h, _ptr(pb), pb.size, _ptr(pw), pw.size, _ptr(m), nslots, nb, _ptr(consts),
+        _check(self.lib.pgpu_pair_debug_run(self.h, _ptr(pb), pb.size, lanes, _ptr(pw), pw.size, _ptr(m), nslots, nb, _ptr(consts),
                                             C.byref(h)))
         return m, consts, h.value
 

@@ -124,8 +124,19 @@ namespace {
 
 enum { C_R2 = 0, C_R3 = 1, C_ONE_M = 2, C_ONE = 3, C_USER = 4 };
 
+struct ModCtx;
+// A modulus N = n^2 whose root n is known can run its shared-exponent ladders on the two-lane pair kernel (GenQ).
+struct PairInfo {
+  const ModCtx* root = nullptr;       // n
+  const uint32_t* consts = nullptr;   // device: n | Cadj (H limbs each) + one word of padding
+  int c_rh = -1;                      // index of R_H mod n^2 (plain) in the consts of n^2
+  const uint32_t* dinv = nullptr;     // n^-1 mod 2^(28 H)
+  const uint32_t* n_limbs = nullptr;  // n as H limbs
+};
+
 struct ModCtx {
   pgpu_ctx* ctx = nullptr;
+  PairInfo pairn;
   BigU N, R;
   size_t nbits = 0, nbytes = 0;
   int WL = 0, K = 0, WT = 0;
@@ -346,6 +357,7 @@ struct SegSpec {
   const uint32_t* pair = nullptr;
   uint32_t pair_n0inv = 0;
   int pair_h = 0;
+  int pair_lanes = 1;   // 1: GenP (one lane holds both digits); 2: GenQ (one digit per lane)
 };
 
 // launch one VM kernel with 1 or 2 segments of `nb` numbers each (same modulus shape)
@@ -381,7 +393,7 @@ void run_vm(pgpu_ctx* ctx, size_t nb, const SegSpec& s0, const SegSpec* s1, bool
   if (s1 && pair != (s1->pair != nullptr)) api_throw(PGPU_ERR_INVALID, "segment kind mismatch");
   if (pair) {
     WL = s0.pair_h;
-    K = 16;   // tag of the pair kernel: one lane per number, 2H-limb values
+    K = s0.pair_lanes == 2 ? 32 : 16;   // tags of the pair kernels, not lane counts
   } else {
     static const size_t lanes_env = [] { const char* e = getenv("PGPU_LANES_WANTED"); return e ? (size_t)atoll(e) : (size_t)0; }();
     const size_t lanes_wanted = ctx->lanes_wanted ? ctx->lanes_wanted : lanes_env ? lanes_env : (size_t)1024 * 64;
@@ -391,7 +403,7 @@ void run_vm(pgpu_ctx* ctx, size_t nb, const SegSpec& s0, const SegSpec* s1, bool
     static const bool w74 = [] { const char* e = getenv("PGPU_W74"); return e ? atoi(e) != 0 : true; }();
     if (WL == 74 && K == 2 && !(w74 && ctx->use_asm)) { WL = 37; K = 4; }
   }
-  const uint32_t blocks_per_seg = (uint32_t)(launch_nb * (pair ? 1 : K) / VM_BLOCK);
+  const uint32_t blocks_per_seg = (uint32_t)(launch_nb * (pair ? s0.pair_lanes : K) / VM_BLOCK);
   a.seg0_blocks = blocks_per_seg;
   const uint32_t blocks = blocks_per_seg * (s1 ? 2 : 1);
   const bool use_asm = ctx->use_asm && vm_asm_available(WL, K) && s0.prog->asm_ok && (!s1 || s1->prog->asm_ok) &&
@@ -405,7 +417,11 @@ void run_vm(pgpu_ctx* ctx, size_t nb, const SegSpec& s0, const SegSpec* s1, bool
     // squaring rows: K == 1 triangular (WT^2 + WT(WT-1)/2 + WT); K == 2 slice-level symmetry (product part 1.5 WL^2 per lane)
     double sq = full;
     double mulp = full;
-    if (pair) {   // five / three-and-a-half half-width products (see GenP)
+    if (pair && s0.pair_lanes == 2) {   // GenQ: one / two Montgomery passes modulo n in both lanes
+      const double H = WL;
+      mulp = 8.0 * H * H;
+      sq = 4.0 * H * H;
+    } else if (pair) {   // five / three-and-a-half half-width products (see GenP)
       const double H = WL;
       mulp = 5.0 * H * H;
       sq = 3.0 * H * H + 0.5 * H * (H - 1) + H;
@@ -490,6 +506,7 @@ struct pgpu_pubkey {
   struct AltTab { bool built = false; int base = 0; int nwin = 0; size_t kbits = 0; } alt[2];  // fixed-base comb tables of h_s
   struct FixedBase { BigU base; int idx; int nwin; };
   std::vector<FixedBase> fixed_bases;   // comb tables of other fixed bases mod n^2 (verification keys)
+  DevLimbs pairn_consts;          // n | Cadj | pad for the two-lane pair kernel (mn2.pairn points here)
   std::vector<std::pair<int, int>> combine_consts;  // (total servers l, index of (4 (l!)^2)^-1 * R mod n in mn.consts)
 };
 
@@ -643,8 +660,60 @@ ModexpPlan modexp_alloc(pgpu_ctx* ctx, const ModCtx& mc, size_t nb, int table_sl
   return pl;
 }
 
+void reduce_mod(pgpu_ctx* ctx, const ModCtx& mc, const uint32_t* in, int w_in, uint32_t* out, size_t nb);
+
+// pl.in() (canonical, < N) ^ e [* pl.post()] mod N = n^2 on the two-lane pair kernel; result lazy in pl.out()
+void modexp_shared_pair(pgpu_ctx* ctx, const ModCtx& mc, const ModexpPlan& pl, const BigU& e, bool use_post) {
+  const PairInfo& pi = mc.pairn;
+  const ModCtx& mn = *pi.root;
+  const int H = mn.WT, W2 = mc.WT;
+  const size_t nb = pl.nb, S1 = (size_t)H * nb, SW = pl.slot_words;
+  uint32_t* mem = pl.mem;
+  // (1) X = x R_H mod n^2, canonical, in slot 3
+  {
+    Prog a;
+    a.op(VM_LOAD, 0); a.op(VM_MULC, C_R2); a.op(VM_MULC, (uint32_t)pi.c_rh); a.op(VM_STORE, 3); a.end();
+    SegSpec sa{&mc, &a, mem, nullptr};
+    run_vm(ctx, nb, sa, nullptr, false);
+    launch_canon(mem + 3 * SW, mc.d_nmod, W2, nb, ctx->stream);
+  }
+  // (2) digits X = X0 + X1 n -> slot 2
+  {
+    uint32_t* x0 = ctx->ws_t<uint32_t>(S1);
+    uint32_t* tb = ctx->ws_t<uint32_t>(SW);
+    reduce_mod(ctx, mn, mem + 3 * SW, W2, x0, nb);
+    launch_div_exact(mem + 3 * SW, W2, 0, x0, H, tb, pi.dinv, mn.d_nmod, H, mem + 2 * SW + S1, H, nb, nb, nullptr, 0, ctx->stream);
+    HIPCHK(hipMemcpyAsync(mem + 2 * SW, x0, S1 * 4, hipMemcpyDeviceToDevice, ctx->stream));
+  }
+  // (3) the ladder in pair form
+  {
+    Prog p;
+    emit_modexp_shared(p, e, 2, NO_SLOT, 2, 3, 5, NO_SLOT, true, true);
+    p.end();
+    SegSpec sp{&mc, &p, mem, nullptr};
+    sp.pair = pi.consts; sp.pair_n0inv = mn.n0inv; sp.pair_h = H; sp.pair_lanes = 2;
+    run_vm(ctx, nb, sp, nullptr, true);
+  }
+  // (4) F~ = F0 + F1 n, out of pair and Montgomery form, times the plain residue in the post slot
+  {
+    launch_mul_const_add(mem + 3 * SW + S1, H, pi.n_limbs, H, mem + 3 * SW, H, 0, mem + 2 * SW, W2, nb, ctx->stream);
+    Prog a;
+    a.op(VM_LOAD, 2); a.op(VM_MULC, (uint32_t)pi.c_rh);
+    if (use_post) { a.op(VM_MULC, C_R2); a.op(VM_MUL, 4); }
+    a.op(VM_STORE, 3); a.end();
+    SegSpec sa{&mc, &a, mem, nullptr};
+    run_vm(ctx, nb, sa, nullptr, false);
+  }
+}
+
 void modexp_shared_run(pgpu_ctx* ctx, const ModCtx& mc, const ModexpPlan& pl, const BigU& e, bool wide, bool use_post,
                        bool skip_zero) {
+  if (mc.pairn.root && ctx->use_asm && ctx->use_pair && !wide && skip_zero && e.bit_length() >= 256 &&
+      pl.nb * 2 >= (ctx->lanes_wanted ? ctx->lanes_wanted : (size_t)1024 * 64)) {
+    modexp_shared_pair(ctx, mc, pl, e, use_post);
+    launch_canon(pl.out(), mc.d_nmod, mc.WT, pl.nb, ctx->stream);
+    return;
+  }
   Prog p;
   emit_modexp_shared(p, e, 0, wide ? 1 : NO_SLOT, 2, 3, 5, use_post ? 4 : NO_SLOT, skip_zero);
   p.end();
@@ -826,7 +895,7 @@ int pgpu_vm_debug_run(const pgpu_modulus* mod, const uint32_t* prog, size_t prog
   });
 }
 
-int pgpu_pair_debug_run(pgpu_ctx* ctx, const uint8_t* p_be, size_t p_len, const uint32_t* prog, size_t prog_words,
+int pgpu_pair_debug_run(pgpu_ctx* ctx, const uint8_t* p_be, size_t p_len, int lanes, const uint32_t* prog, size_t prog_words,
                         uint32_t* mem_host, size_t nslots, size_t nb, uint32_t* consts_out, int* h_out) {
   if (!ctx || !p_be || !prog || !mem_host) return fail(PGPU_ERR_INVALID, "null argument");
   return guarded([&] {
@@ -837,13 +906,15 @@ int pgpu_pair_debug_run(pgpu_ctx* ctx, const uint8_t* p_be, size_t p_len, const 
     ModCtx mp, mp2;
     mp.init(ctx, pr);
     mp2.init(ctx, pr * pr);
-    if (mp.K != 1 || mp2.K != 1 || mp2.WT != 2 * mp.WT || !vm_asm_available(mp.WT, 16))
-      api_throw(PGPU_ERR_UNSUPPORTED, "no pair kernel for this prime width");
+    if (lanes != 1 && lanes != 2) api_throw(PGPU_ERR_INVALID, "lanes must be 1 or 2");
+    if (mp.K != 1 || mp2.WT != 2 * mp.WT || !vm_asm_available(mp.WT, lanes == 2 ? 32 : 16))
+      api_throw(PGPU_ERR_UNSUPPORTED, "no pair kernel for this width");
     mp2.upload();
     const int H = mp.WT;
     if (h_out) *h_out = H;
     std::vector<uint32_t> pc = make_pair_consts(pr, H);
     if (consts_out) memcpy(consts_out, pc.data(), pc.size() * 4);
+    pc.push_back(0);
     uint32_t* d_pc = ctx->upload_words(pc);
     size_t words = nslots * (size_t)mp2.WT * nb;
     uint32_t* d = ctx->ws_t<uint32_t>(words);
@@ -852,7 +923,7 @@ int pgpu_pair_debug_run(pgpu_ctx* ctx, const uint8_t* p_be, size_t p_len, const 
     p.w.assign(prog, prog + prog_words);
     p.asm_ok = true;
     SegSpec s{&mp2, &p, d, nullptr};
-    s.pair = d_pc; s.pair_n0inv = mp.n0inv; s.pair_h = H;
+    s.pair = d_pc; s.pair_n0inv = mp.n0inv; s.pair_h = H; s.pair_lanes = lanes;
     bool saved = ctx->use_asm;
     ctx->use_asm = true;
     try { run_vm(ctx, nb, s, nullptr, false); } catch (...) { ctx->use_asm = saved; throw; }
@@ -949,6 +1020,20 @@ int pgpu_pubkey_create(pgpu_ctx* ctx, const uint8_t* n_be, size_t n_len, const u
     BigU inv2_n2 = hostbig::shr(n2 + BigU(1), 1);                       // 2^-1 mod n^2
     pk->c_inv2R = pk->mn.add_const(pk->mn.to_mont(inv2));
     pk->c_ninv2R_2 = pk->mn2.add_const(pk->mn2.to_mont(hostbig::mulmod(pk->N, inv2_n2, n2)));
+    if (pk->mn.K == 1 && pk->mn2.WT == 2 * pk->mn.WT && vm_asm_available(pk->mn.WT, 32)) {
+      const int H = pk->mn.WT;
+      std::vector<uint32_t> pc = make_pair_consts(pk->N, H);
+      pc.push_back(0);   // the kernel prefetches one word past Cadj
+      pk->pairn_consts.w = (int)pc.size();
+      HIPCHK(hipMalloc((void**)&pk->pairn_consts.d, pc.size() * 4));
+      HIPCHK(hipMemcpy(pk->pairn_consts.d, pc.data(), pc.size() * 4, hipMemcpyHostToDevice));
+      PairInfo& pi = pk->mn2.pairn;
+      pi.root = &pk->mn;
+      pi.consts = pk->pairn_consts.d;
+      pi.c_rh = pk->mn2.add_const(hostbig::shl(BigU(1), (size_t)LB * H) % n2);
+      pi.dinv = pk->ninv2k.d;
+      pi.n_limbs = pk->n_limbs.d;
+    }
     pk->mn.upload();
     pk->mn2.upload();
   });

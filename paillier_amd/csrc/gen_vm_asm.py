@@ -1637,14 +1637,258 @@ class GenP(Gen):
         return "\n".join(self.lines) + "\n"
 
 
-SHAPES = [(74, 1), (37, 1), (55, 1), (55, 2), (74, 2), (55, 4), (37, 2), (37, 4), (37, 16)]
+class GenQ(Gen):
+    """In-wave pair kernel for moduli N = n^2 with n PUBLIC (Encrypt, ConstMult, PartialDecrypt, proofs): the residue
+    y R mod n^2 = a0 + a1 n (R = 2^(28 H), H = limbs of n) lives in two neighbouring lanes -- lane 0 holds a0, lane 1
+    holds a1 -- and both lanes run the single-lane Montgomery row modulo n (n in SGPRs, the same for both lanes):
+        lane 0:  t  = a0 b0 R^-1                     quotient digits m_i
+        lane 1:  c1 = (a1 b0 [+ ...] + Cadj - m) R^-1     m_i arrives by DPP in the row that needs it (column 0 of row i)
+    A squaring is ONE pass (lane 0: a0 a0, lane 1: 2 a0 a1): 2 H^2 multiplies per lane instead of 3 H^2 for the
+    symmetric 2H-limb squaring split over two waves.  A product needs a second pass for a0 b1 (lane 0; its result
+    crosses to lane 1 through the LDS rows the multiplier b1 occupied): 4 H^2 per lane, what the 2H-limb product costs.
+    Slot layout = the two-lane layout of every other K = 2 shape: limbs 0..H-1 = a0, H..2H-1 = a1.
+    `nmod` points at n (H limbs) followed by Cadj (H limbs, streamed one word per row by scalar loads)."""
+
+    def __init__(self, H=74):
+        Gen.__init__(self, H, 2)
+        assert H % 2 == 0 and 3 * H + 3 <= 255
+        self.H = H
+        self.name = f"vm_asm_{H}_32"
+        self.n_sgpr = True
+        self.n_vreg = False
+        self.flush = False
+        self.sq_rows = True
+        self.sq_rows_k = False
+        self.lds_a = 0
+        self.lds_bytes = (self.WT + 1) * self.NPB * 4
+        # VGPR map of the single-lane shape plus the lane link
+        self.vX = 2 * H
+        e = 3 * H
+        for nm in ["ai", "ain", "m", "t1", "sh", "l1mask"]:
+            setattr(self, "v_" + nm, e)
+            e += 1
+        e = (e + 1) // 2 * 2
+        self.v_y0 = e
+        e += 2
+        self.v_d = e          # pair (adjustment, 0)
+        e += 2
+        for nm in ["goff", "aread", "awrite", "arow", "nbase", "isfirst", "notlast", "t2", "t3", "t4", "koff"]:
+            setattr(self, "v_" + nm, e)
+            e += 1
+        self.v_addr = self.v_arow
+        e = (e + 1) // 2 * 2
+        self.v_p0 = e
+        e += 2
+        self.v_p1 = e
+        self.v_c = e
+        e += 2
+        self.n_vgpr = e
+        assert e <= 256, e
+        self.s_cadj, self.s_cadj_n, self.s_coff = 99, 100, 101
+
+    def prologue(self):
+        # the K = 2 lane mapping of the base class, with the modulus (H limbs, shared by both lanes) in SGPRs
+        g, e = self, self.e
+        H, NPB = self.H, self.NPB
+        e(f'.amdgcn_target "amdgcn-amd-amdhsa--gfx950"')
+        e(".text")
+        e(f".globl {self.name}")
+        e(".p2align 8")
+        e(f".type {self.name},@function")
+        e(f"{self.name}:")
+        e("s_load_dword s3, s[0:1], 0x60")
+        e("s_waitcnt lgkmcnt(0)")
+        e("s_cmp_ge_u32 s2, s3")
+        e("s_cbranch_scc0 L_seg0")
+        e("s_sub_u32 s2, s2, s3")
+        e("s_add_u32 s0, s0, 48")
+        e("s_addc_u32 s1, s1, 0")
+        e("L_seg0:")
+        e("s_load_dwordx8 s[4:11], s[0:1], 0x0")
+        e("s_load_dwordx4 s[12:15], s[0:1], 0x20")
+        e("s_waitcnt lgkmcnt(0)")
+        e("s_lshl_b32 s3, s15, 2")
+        e(f"v_and_b32 v{g.v_t1}, 1, v0")                 # k
+        e(f"v_lshrrev_b32 v{g.v_t2}, 1, v0")             # gl
+        e(f"s_mul_i32 s{g.s_t0}, s2, {NPB}")
+        e(f"v_add_u32 v{g.v_t3}, s{g.s_t0}, v{g.v_t2}")  # g
+        e(f"s_mul_i32 s{g.s_t1}, s15, {H}")
+        e(f"v_mul_lo_u32 v{g.v_t4}, v{g.v_t1}, s{g.s_t1}")
+        e(f"v_add_lshl_u32 v{g.v_goff}, v{g.v_t4}, v{g.v_t3}, 2")
+        e(f"v_lshlrev_b32 v{g.v_aread}, 2, v{g.v_t2}")
+        e(f"v_mul_u32_u24 v{g.v_t4}, {H * NPB * 4}, v{g.v_t1}")
+        e(f"v_add_u32 v{g.v_awrite}, v{g.v_t4}, v{g.v_aread}")
+        e(f"v_mul_u32_u24 v{g.v_koff}, {H * 4}, v{g.v_t1}")
+        e(f"v_cmp_eq_u32 vcc, 0, v{g.v_t1}")
+        e("s_nop 1")
+        e(f"v_cndmask_b32 v{g.v_isfirst}, 0, -1, vcc")
+        e(f"v_not_b32 v{g.v_l1mask}, v{g.v_isfirst}")
+        off, s, rem = 0, self.s_N, H
+        while rem > 0:
+            for cnt in (16, 8, 4, 2, 1):
+                align = 4 if cnt >= 4 else cnt
+                if cnt <= rem and s % align == 0:
+                    if cnt == 1:
+                        e(f"s_load_dword s{s}, s[6:7], {hex(off)}")
+                    else:
+                        e(f"s_load_dwordx{cnt} s[{s}:{s + cnt - 1}], s[6:7], {hex(off)}")
+                    off += 4 * cnt
+                    s += cnt
+                    rem -= cnt
+                    break
+            else:
+                raise RuntimeError("cannot tile the modulus into SGPR loads")
+        e("s_waitcnt lgkmcnt(0)")
+        e(f"s_add_u32 s6, s6, {4 * H}")                  # s[6:7] -> Cadj
+        e("s_addc_u32 s7, s7, 0")
+        for j in range(H):
+            e(f"v_mov_b32 {self.X(j)}, 0")
+
+    def row(self, cur, nxt, aoff, link, use_sh, first):
+        """one Montgomery row modulo n in both lanes.  cur/nxt: multiplier registers (this row / prefetch); aoff: byte
+        offset of the multiplier stream inside the a column; link: lane 1 takes Cadj_i - m_i(lane 0) into column 0."""
+        g, e = self, self.e
+        H = self.H
+        row = self.NPB * 4
+        N = lambda j: f"s{g.s_N + j}"
+        m = f"v{g.v_m}"
+        e("s_waitcnt lgkmcnt(0)")
+        e(f"ds_read_b32 v{nxt}, v{g.v_arow} offset:{aoff}")
+        e(f"v_add_u32 v{g.v_arow}, {row}, v{g.v_arow}")
+        if link:
+            e(f"s_mov_b32 s{g.s_cadj}, s{g.s_cadj_n}")
+            e(f"s_add_u32 s{g.s_coff}, s{g.s_coff}, 4")
+            e(f"s_load_dword s{g.s_cadj_n}, s[6:7], s{g.s_coff}")
+        a = f"v{cur}"
+        if use_sh:
+            e(f"v_lshlrev_b32 v{cur}, v{g.v_sh}, v{cur}")
+        self.align8()
+        for j in range(H):
+            if j == H - 1:
+                self.mad(self.T(j), a, self.X(j), "0")
+            else:
+                self.mad(self.T(j), a, self.X(j), self.T(j))
+        e(f"v_mul_lo_u32 {m}, {self.Tlo(0)}, s14")
+        e(f"v_and_b32 {m}, {hex(MASK)}, {m}")
+        if link:
+            e("s_nop 1")
+            e(f"v_mov_b32_dpp v{g.v_d}, {m} quad_perm:[0,0,2,2] row_mask:0xf bank_mask:0xf")
+            e(f"v_sub_u32 v{g.v_d}, s{g.s_cadj}, v{g.v_d}")
+            e(f"v_and_b32 v{g.v_d}, v{g.v_d}, v{g.v_l1mask}")
+            e(f"v_lshl_add_u64 {self.T(0)}, {self.T(0)}, 0, {self.P(g.v_d)}")
+            e(f"v_mul_lo_u32 {m}, {self.Tlo(0)}, s14")
+            e(f"v_and_b32 {m}, {hex(MASK)}, {m}")
+        self.align8()
+        self.mad(self.P(g.v_y0), m, N(0), self.T(0))
+        self.mad(self.T(0), m, N(1), self.T(1))
+        e(f"v_lshrrev_b64 {self.P(g.v_c)}, {LB}, {self.P(g.v_y0)}")
+        for j in range(2, H):
+            self.mad(self.T(j - 1), m, N(j), self.T(j))
+            if j == 4:
+                e(f"v_lshl_add_u64 {self.T(0)}, {self.T(0)}, 0, {self.P(g.v_c)}")
+
+    def passes(self, tag, aoff, link, use_sh):
+        """H rows: T <- (multiplier stream at aoff) * X * R^-1 (+ the lane link)"""
+        g, e = self, self.e
+        H = self.H
+        row = self.NPB * 4
+        for j in range(H - 1):
+            e(f"v_mov_b64 {self.T(j)}, 0")
+        e(f"v_mov_b32 v{g.v_d + 1}, 0")
+        e(f"v_mov_b32 v{g.v_arow}, v{g.v_aread}")
+        e(f"ds_read_b32 v{g.v_ain}, v{g.v_arow} offset:{aoff}")
+        e(f"v_add_u32 v{g.v_arow}, {row}, v{g.v_arow}")
+        if link:
+            e(f"s_mov_b32 s{g.s_coff}, 0")
+            e(f"s_load_dword s{g.s_cadj_n}, s[6:7], 0x0")
+        e("s_mov_b32 s19, 0")
+        e(".p2align 6")
+        e(f"L_q{tag}:")
+        self.row(g.v_ain, g.v_ai, aoff, link, use_sh, False)
+        self.row(g.v_ai, g.v_ain, aoff, link, use_sh, False)
+        e("s_add_u32 s19, s19, 2")
+        e(f"s_cmp_lt_u32 s19, {H}")
+        e(f"s_cbranch_scc1 L_q{tag}")
+        e("s_waitcnt lgkmcnt(0)")
+        e(f"v_mov_b64 {self.T(H - 1)}, 0")
+
+    def normalize_to(self, dest):
+        """sequential carry (every lane owns a whole H-limb digit); dest(j, reg_lo) emits the store of limb j"""
+        g, e = self, self.e
+        H = self.H
+        M = hex(MASK)
+        c = self.P(g.v_c)
+        for j in range(H):
+            if j:
+                e(f"v_lshl_add_u64 {self.T(j)}, {self.T(j)}, 0, {c}")
+            dest(j)
+            if j < H - 1:
+                e(f"v_lshrrev_b64 {c}, {LB}, {self.T(j)}")
+
+    def montsq(self):
+        g, e = self, self.e
+        M = hex(MASK)
+        e("L_montsq:")
+        e(f"v_and_b32 v{g.v_sh}, 1, v{g.v_l1mask}")           # lane 1 doubles its multiplier: 2 a0 a1
+        self.passes("s", 0, True, True)
+        self.normalize_to(lambda j: e(f"v_and_b32 {self.X(j)}, {M}, {self.Tlo(j)}"))
+        e("s_branch L_next")
+
+    def montmul(self):
+        g, e = self, self.e
+        H = self.H
+        M = hex(MASK)
+        row = self.NPB * 4
+        e("L_montmul:")
+        # pass 1: lane 0: r2 = a0 b1 R^-1 (multiplier rows H..2H-1); lane 1 runs along, its result is dropped
+        self.passes("m1", H * row, False, False)
+        e(f"v_add_u32 v{g.v_t4}, {H * row}, v{g.v_aread}")       # rows H.. of the a column (offsets must stay below 64 KB)
+        e("s_mov_b64 s[96:97], exec")
+        e("s_mov_b32 s98, 0x55555555")
+        e("s_mov_b32 exec_lo, s98")
+        e("s_mov_b32 exec_hi, s98")
+
+        def to_lds(j):
+            e(f"v_and_b32 v{g.v_t1}, {M}, {self.Tlo(j)}")
+            e(f"ds_write_b32 v{g.v_t4}, v{g.v_t1} offset:{j * row}")
+        self.normalize_to(to_lds)
+        e("s_mov_b64 exec, s[96:97]")
+        # pass 2: lane 0: t = a0 b0 R^-1; lane 1: r1 = (a1 b0 + Cadj - m) R^-1
+        self.passes("m2", 0, True, False)
+        self.normalize_to(lambda j: e(f"v_and_b32 {self.X(j)}, {M}, {self.Tlo(j)}"))
+        # lane 1: c1 = r1 + r2 (limbs < 2^29: a lazy multiplicand)
+        e("s_mov_b32 s98, 0xaaaaaaaa")
+        e("s_mov_b32 exec_lo, s98")
+        e("s_mov_b32 exec_hi, s98")
+        St = [f"v{j}" for j in range(H)]
+        for j in range(H):
+            e(f"ds_read_b32 {St[j]}, v{g.v_t4} offset:{j * row}")
+        e("s_waitcnt lgkmcnt(0)")
+        for j in range(H):
+            e(f"v_add_u32 {self.X(j)}, {self.X(j)}, {St[j]}")
+        e("s_mov_b64 exec, s[96:97]")
+        e("s_branch L_next")
+
+    def generate(self):
+        self.prologue()
+        self.dispatcher()
+        self.montmul()
+        self.montsq()
+        self.epilogue()
+        return "\n".join(self.lines) + "\n"
+
+
+SHAPES = [(74, 1), (37, 1), (55, 1), (55, 2), (74, 2), (55, 4), (37, 2), (37, 4), (37, 16), (74, 32)]
 PAIR = {(37, 16)}           # (H, 16): the pair kernel for N = p^2 with H-limb p (GenP); 16 is a tag, not a lane count
+PAIR2 = {(74, 32)}          # (H, 32): the two-lane pair kernel for N = n^2 with H-limb n (GenQ)
 WAVE_SLICED = {(74, 2), (55, 2)}     # shapes whose slices live in different waves (GenW) instead of neighbouring lanes (Gen)
 
 
 def make_gen(wl, k):
     if (wl, k) in PAIR:
         return GenP(wl)
+    if (wl, k) in PAIR2:
+        return GenQ(wl)
     return GenW(wl, k) if (wl, k) in WAVE_SLICED else Gen(wl, k)
 
 

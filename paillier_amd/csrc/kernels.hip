@@ -291,15 +291,16 @@ __global__ void k_div_exact(const uint32_t* __restrict__ u, int wu, uint32_t sub
 }
 
 // Register-resident versions of the two helpers on the Decrypt-2048 path (fixed widths, fully unrolled: the operand
-// lives in VGPRs instead of being re-read from memory for every limb product).  A column of <= 64 products of
-// 28-bit limbs plus the incoming carry stays below 2^63, so one 64-bit accumulator per column is enough.
+// lives in VGPRs instead of being re-read from memory for every limb product).  A column of <= 128 products of
+// canonical 28-bit limbs (or 74 products with one lazy 29-bit operand) plus the incoming carry stays below 2^64, so
+// one 64-bit accumulator per column is enough.
 template <int WU, int WL, int WD, bool CHECK>
 __global__ void __launch_bounds__(256) k_div_exact_t(const uint32_t* __restrict__ u, uint32_t sub_small,
                                                      const uint32_t* __restrict__ subv,
                                                      const uint32_t* __restrict__ dinv, const uint32_t* __restrict__ d,
                                                      uint32_t* __restrict__ l, size_t nb, size_t count,
                                                      int32_t* __restrict__ status, int32_t flag) {
-  static_assert(WL <= 64 && WD <= 64, "single 64-bit column accumulator");
+  static_assert(WL <= 128 && WD <= 128, "single 64-bit column accumulator: <= 128 products of canonical limbs");
   size_t g = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (g >= nb) return;
   uint32_t t[WU];
@@ -341,7 +342,7 @@ template <int WA, int WB, int WO>
 __global__ void __launch_bounds__(256) k_mul_const_add_t(const uint32_t* __restrict__ a, const uint32_t* __restrict__ bconst,
                                                          const uint32_t* __restrict__ addv, int wadd, uint32_t add_small,
                                                          uint32_t* __restrict__ out, size_t nb) {
-  static_assert(WA <= 64 && WB <= 64, "single 64-bit column accumulator");
+  static_assert(WA <= 74 && WB <= 74, "single 64-bit column accumulator: 74 products of a 29-bit by a 28-bit limb stay below 2^64");
   size_t g = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (g >= nb) return;
   uint32_t x[WA];
@@ -641,6 +642,10 @@ void launch_mul_const_add(const uint32_t* a, int wa, const uint32_t* bconst, int
     hipLaunchKernelGGL((k_mul_const_add_t<37, 37, 74>), HELPER_GRID(nb), 0, st, a, bconst, addv, wadd, add_small, out, nb);
     return;
   }
+  if (wa == 74 && wb == 74 && wo == 148 && (!addv || wadd <= 148)) {
+    hipLaunchKernelGGL((k_mul_const_add_t<74, 74, 148>), HELPER_GRID(nb), 0, st, a, bconst, addv, wadd, add_small, out, nb);
+    return;
+  }
   hipLaunchKernelGGL(k_mul_const_add, HELPER_GRID(nb), 0, st, a, wa, bconst, wb, addv, wadd, add_small, out, wo, nb);
 }
 void launch_div_exact(const uint32_t* u, int wu, uint32_t sub_small, const uint32_t* subv, int wsub, uint32_t* tbuf,
@@ -654,6 +659,11 @@ void launch_div_exact(const uint32_t* u, int wu, uint32_t sub_small, const uint3
     else
       hipLaunchKernelGGL((k_div_exact_t<74, 37, 37, false>), HELPER_GRID(nb), 0, st, u, sub_small, subv, dinv, d, l, nb, count,
                          status, flag);
+    return;
+  }
+  if (wu == 148 && wl == 74 && wd == 74 && !status && (!subv || wsub == 74)) {
+    hipLaunchKernelGGL((k_div_exact_t<148, 74, 74, false>), HELPER_GRID(nb), 0, st, u, sub_small, subv, dinv, d, l, nb, count,
+                       status, flag);
     return;
   }
   if (!status) {   // generic widths: run the check against a scratch word nobody reads (count = 0 masks every lane)

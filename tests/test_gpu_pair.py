@@ -123,3 +123,64 @@ def test_decrypt_does_not_depend_on_the_pair_switch(ctx):
         ctx.set_flag("pair", 1)
     assert with_pair == without
     assert with_pair[:40] + with_pair[-8:] == [po.decrypt(sk_o, po.Ciphertext(c)) for c in cts[:40] + cts[-8:]]
+
+
+def test_two_lane_pair_kernel_matches_the_integer_model(ctx):
+    """GenQ: N = n^2 with a public 74-limb n, digit a0 in lane 0 and a1 in lane 1.  A product adds the two partial results
+    r1 + r2 limb-wise (a lazy digit below 4n), so digits are compared as integers."""
+    k = json.load(open(os.path.join(G, "keys.json")))["paillier"]["2048"]
+    n = int(k["p"], 16) * int(k["q"], 16)
+    rng = random.Random(23)
+    nb, nslots, H = 256, 6, 74
+    mem = np.zeros((nslots, 2 * H, nb), dtype=np.uint32)
+    vals = {}
+    for s in (0, 1):
+        for g in range(nb):
+            hi = 2 * n if g % 3 else n
+            a = (rng.randrange(hi), rng.randrange(hi))
+            if g == 0:
+                a = (0, 0)
+            if g == 1:
+                a = (n - 1, n - 1)
+            vals[s, g] = a
+            mem[s, :H, g] = to_limbs(a[0], H)
+            mem[s, H:, g] = to_limbs(a[1], H)
+    prog = [LOAD, 0, SQR, 0, STORE, 2, LOAD, 0, MUL, 1, STORE, 3, SQR, 0, SQR, 0, MUL, 0, STORE, 4, END, 0]
+    out, consts, h = ctx.pair_debug_run(n, prog, mem, nslots, nb, lanes=2)
+    assert h == H and from_limbs(consts[:H]) == n
+    cadj = from_limbs(consts[H:])
+    assert cadj % n == 0
+    R = 1 << (LB * H)
+    nneg = (-pow(n, -1, R)) % R
+
+    def mont(u):
+        m = (u * nneg) % R
+        return (u + m * n) // R, m
+
+    def psq(a):
+        t, m = mont(a[0] * a[0])
+        return (t, mont(2 * a[0] * a[1] + cadj - m)[0])
+
+    def pmul(a, b):      # x = a (registers), b = the slot operand: r2 = a0 b1, then t = a0 b0 and r1 = a1 b0 + Cadj - m
+        r2, _ = mont(a[0] * b[1])
+        t, m = mont(a[0] * b[0])
+        r1, _ = mont(a[1] * b[0] + cadj - m)
+        return (t, r1 + r2)
+
+    for g in range(nb):
+        x, y = vals[0, g], vals[1, g]
+        sq = psq(x)
+        xy = pmul(x, y)
+        t = psq(psq(xy))
+        t = pmul(t, x)
+        for slot, want in ((2, sq), (3, xy), (4, t)):
+            got = (from_limbs(out[slot, :H, g]), from_limbs(out[slot, H:, g]))
+            assert got == want, (g, slot)
+    # and the value represented is the product modulo n^2
+    n2 = n * n
+    rinv = pow(R, -1, n2)
+    for g in (2, 3, 200):
+        x, y = vals[0, g], vals[1, g]
+        xv, yv = (x[0] + x[1] * n) % n2, (y[0] + y[1] * n) % n2
+        got = (from_limbs(out[3, :H, g]) + from_limbs(out[3, H:, g]) * n) % n2
+        assert got == xv * yv * rinv % n2
