@@ -527,6 +527,7 @@ struct pgpu_seckey {
   int c_mu2R = -1;               // lambda^-1 mod n^2, times R mod n^2, in pk->mn2 (level two)
   // pair kernel for the p^2 / q^2 ladders (GenP): p | Cadj limb arrays, R_H mod p^2 as a plain constant of mp2 / mq2
   bool has_pair = false;
+  int pair_lanes = 1;              // 1: GenP (both digits in one lane, 37-limb primes); 2: GenQ (one digit per lane: 55 / 74 limbs)
   DevLimbs pair_p, pair_q;
   int c_rh_p2 = -1, c_rh_q2 = -1;
   DevLimbs q_limbs1;               // q as mq.WT limbs (p_limbs is above)
@@ -1118,10 +1119,14 @@ int pgpu_seckey_create(pgpu_ctx* ctx, const pgpu_pubkey* pk, const uint8_t* lamb
         sk->qinv2k.set(inv_mod_pow2(q, (size_t)LB * sk->mq.WT), sk->mq.WT);
         sk->p_limbs.set(p, sk->mp.WT);
         sk->q_limbs1.set(q, sk->mq.WT);
-        if (sk->mp.K == 1 && sk->mp2.K == 1 && sk->mp2.WT == 2 * sk->mp.WT && vm_asm_available(sk->mp.WT, 16)) {
+        const int pair_tag = vm_asm_available(sk->mp.WT, 16) && sk->mp2.K == 1 ? 16 : 32;
+        if (sk->mp.K == 1 && sk->mp2.WT == 2 * sk->mp.WT && vm_asm_available(sk->mp.WT, pair_tag)) {
+          sk->pair_lanes = pair_tag == 16 ? 1 : 2;
           const int H = sk->mp.WT;
           auto pair_consts = [&](const BigU& pr) { return make_pair_consts(pr, H); };
           std::vector<uint32_t> vp = pair_consts(p), vq = pair_consts(q);
+          vp.push_back(0);   // the two-lane kernel prefetches one word past Cadj
+          vq.push_back(0);
           auto put = [&](DevLimbs& d, const std::vector<uint32_t>& v) {
             d.w = (int)v.size();
             HIPCHK(hipMalloc((void**)&d.d, v.size() * 4));
@@ -1204,7 +1209,9 @@ uint32_t* decrypt1_crt(const pgpu_seckey* sk, const uint32_t* c_limbs, size_t nb
   uint32_t* mem = ctx->ws_t<uint32_t>(S2 * 70);
   HIPCHK(hipMemcpyAsync(mem, c_limbs, S2 * 2 * 4, hipMemcpyDeviceToDevice, ctx->stream));
   uint32_t *up = mem + 3 * S2, *uq = mem + 37 * S2;
-  if (sk->has_pair && ctx->use_asm && ctx->use_pair) {
+  // (the two-lane kernel needs 2 lanes x 2 halves per ciphertext to fill the chip; below that the finer slicings win)
+  if (sk->has_pair && ctx->use_asm && ctx->use_pair &&
+      (sk->pair_lanes == 1 || nb * 4 >= (ctx->lanes_wanted ? ctx->lanes_wanted : (size_t)1024 * 64))) {
     // The ladder runs on the pair kernel (residues mod p^2 as two base-p digits: 58 % of the multiplies of a squaring).
     // (1) X = c R_H mod p^2 on the ordinary kernel, canonical
     {
@@ -1236,8 +1243,8 @@ uint32_t* decrypt1_crt(const pgpu_seckey* sk, const uint32_t* c_limbs, size_t nb
       emit_modexp_shared(pq, sk->q - BigU(1), 36, NO_SLOT, 36, 37, 38, NO_SLOT, true, true);
       pq.end();
       SegSpec sp{&mp2, &pp, mem, nullptr}, sq{&mq2, &pq, mem, nullptr};
-      sp.pair = sk->pair_p.d; sp.pair_n0inv = mp.n0inv; sp.pair_h = W1;
-      sq.pair = sk->pair_q.d; sq.pair_n0inv = mq.n0inv; sq.pair_h = W1;
+      sp.pair = sk->pair_p.d; sp.pair_n0inv = mp.n0inv; sp.pair_h = W1; sp.pair_lanes = sk->pair_lanes;
+      sq.pair = sk->pair_q.d; sq.pair_n0inv = mq.n0inv; sq.pair_h = W1; sq.pair_lanes = sk->pair_lanes;
       run_vm(ctx, nb, sp, &sq, true);
     }
     // (4) back: F~ = F0 + F1 prime (an integer = F R_H mod p^2, lazy), then F = F~ R_H^-1 on the ordinary kernel

@@ -1651,7 +1651,7 @@ class GenQ(Gen):
 
     def __init__(self, H=74):
         Gen.__init__(self, H, 2)
-        assert H % 2 == 0 and 3 * H + 3 <= 255
+        assert 3 * H + 3 <= 255
         self.H = H
         self.name = f"vm_asm_{H}_32"
         self.n_sgpr = True
@@ -1801,11 +1801,18 @@ class GenQ(Gen):
         if link:
             e(f"s_mov_b32 s{g.s_coff}, 0")
             e(f"s_load_dword s{g.s_cadj_n}, s[6:7], 0x0")
-        e("s_mov_b32 s19, 0")
+        if H % 2:
+            # odd row count: one peeled row, then the two-row loop with the multiplier registers swapped
+            self.row(g.v_ain, g.v_ai, aoff, link, use_sh, False)
+            e("s_mov_b32 s19, 1")
+            ra, rb = g.v_ai, g.v_ain
+        else:
+            e("s_mov_b32 s19, 0")
+            ra, rb = g.v_ain, g.v_ai
         e(".p2align 6")
         e(f"L_q{tag}:")
-        self.row(g.v_ain, g.v_ai, aoff, link, use_sh, False)
-        self.row(g.v_ai, g.v_ain, aoff, link, use_sh, False)
+        self.row(ra, rb, aoff, link, use_sh, False)
+        self.row(rb, ra, aoff, link, use_sh, False)
         e("s_add_u32 s19, s19, 2")
         e(f"s_cmp_lt_u32 s19, {H}")
         e(f"s_cbranch_scc1 L_q{tag}")
@@ -1878,9 +1885,9 @@ class GenQ(Gen):
         return "\n".join(self.lines) + "\n"
 
 
-SHAPES = [(74, 1), (37, 1), (55, 1), (55, 2), (74, 2), (55, 4), (37, 2), (37, 4), (37, 16), (74, 32)]
+SHAPES = [(74, 1), (37, 1), (55, 1), (55, 2), (74, 2), (55, 4), (37, 2), (37, 4), (37, 16), (74, 32), (55, 32)]
 PAIR = {(37, 16)}           # (H, 16): the pair kernel for N = p^2 with H-limb p (GenP); 16 is a tag, not a lane count
-PAIR2 = {(74, 32)}          # (H, 32): the two-lane pair kernel for N = n^2 with H-limb n (GenQ)
+PAIR2 = {(74, 32), (55, 32)}          # (H, 32): the two-lane pair kernel for N = n^2 with H-limb n (GenQ)
 WAVE_SLICED = {(74, 2), (55, 2)}     # shapes whose slices live in different waves (GenW) instead of neighbouring lanes (Gen)
 
 

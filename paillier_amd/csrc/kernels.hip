@@ -642,6 +642,10 @@ void launch_mul_const_add(const uint32_t* a, int wa, const uint32_t* bconst, int
     hipLaunchKernelGGL((k_mul_const_add_t<37, 37, 74>), HELPER_GRID(nb), 0, st, a, bconst, addv, wadd, add_small, out, nb);
     return;
   }
+  if (wa == 55 && wb == 55 && wo == 110 && (!addv || wadd <= 110)) {
+    hipLaunchKernelGGL((k_mul_const_add_t<55, 55, 110>), HELPER_GRID(nb), 0, st, a, bconst, addv, wadd, add_small, out, nb);
+    return;
+  }
   if (wa == 74 && wb == 74 && wo == 148 && (!addv || wadd <= 148)) {
     hipLaunchKernelGGL((k_mul_const_add_t<74, 74, 148>), HELPER_GRID(nb), 0, st, a, bconst, addv, wadd, add_small, out, nb);
     return;
@@ -661,9 +665,22 @@ void launch_div_exact(const uint32_t* u, int wu, uint32_t sub_small, const uint3
                          status, flag);
     return;
   }
-  if (wu == 148 && wl == 74 && wd == 74 && !status && (!subv || wsub == 74)) {
-    hipLaunchKernelGGL((k_div_exact_t<148, 74, 74, false>), HELPER_GRID(nb), 0, st, u, sub_small, subv, dinv, d, l, nb, count,
-                       status, flag);
+  if (wu == 148 && wl == 74 && wd == 74 && (!subv || wsub == 74)) {
+    if (status)
+      hipLaunchKernelGGL((k_div_exact_t<148, 74, 74, true>), HELPER_GRID(nb), 0, st, u, sub_small, subv, dinv, d, l, nb, count,
+                         status, flag);
+    else
+      hipLaunchKernelGGL((k_div_exact_t<148, 74, 74, false>), HELPER_GRID(nb), 0, st, u, sub_small, subv, dinv, d, l, nb, count,
+                         status, flag);
+    return;
+  }
+  if (wu == 110 && wl == 55 && wd == 55 && (!subv || wsub == 55)) {
+    if (status)
+      hipLaunchKernelGGL((k_div_exact_t<110, 55, 55, true>), HELPER_GRID(nb), 0, st, u, sub_small, subv, dinv, d, l, nb, count,
+                         status, flag);
+    else
+      hipLaunchKernelGGL((k_div_exact_t<110, 55, 55, false>), HELPER_GRID(nb), 0, st, u, sub_small, subv, dinv, d, l, nb, count,
+                         status, flag);
     return;
   }
   if (!status) {   // generic widths: run the check against a scratch word nobody reads (count = 0 masks every lane)

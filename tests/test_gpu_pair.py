@@ -184,3 +184,29 @@ def test_two_lane_pair_kernel_matches_the_integer_model(ctx):
         xv, yv = (x[0] + x[1] * n) % n2, (y[0] + y[1] * n) % n2
         got = (from_limbs(out[3, :H, g]) + from_limbs(out[3, H:, g]) * n) % n2
         assert got == xv * yv * rinv % n2
+
+
+def test_decrypt_3072_on_the_two_lane_pair_kernel(ctx):
+    """3072-bit keys: the CRT ladders modulo p^2, q^2 (55-limb primes) run on the two-lane pair kernel when the batch
+    fills the chip; force it for a small batch and compare with the ordinary kernels and the oracle."""
+    import paillier_amd as pa
+    from oracle import paillier_oracle as po
+    k = json.load(open(os.path.join(G, "keys.json")))["paillier"]["3072"]
+    p, q = int(k["p"], 16), int(k["q"], 16)
+    n, lam = p * q, (p - 1) * (q - 1)
+    pk = pa.PublicKey(ctx, n, n + 1)
+    sk = pa.SecretKey(ctx, pk, lam)
+    sk_o = po.SecretKey(N=n, G=n + 1, Lambda=lam)
+    rng = random.Random(24)
+    cts = [rng.randrange(n * n) for _ in range(300)] + [0, 1, p, q, n, n * n - 1]
+    try:
+        ctx.set_flag("lanes_wanted", 1)
+        ctx.set_flag("pair", 1)
+        with_pair = sk.DecryptBatch(cts)
+        ctx.set_flag("pair", 0)
+        without = sk.DecryptBatch(cts)
+    finally:
+        ctx.set_flag("pair", 1)
+        ctx.set_flag("lanes_wanted", 0)
+    assert with_pair == without
+    assert with_pair[:20] + with_pair[-6:] == [po.decrypt(sk_o, po.Ciphertext(c)) for c in cts[:20] + cts[-6:]]
