@@ -527,6 +527,7 @@ struct pgpu_seckey {
   int c_mu2R = -1;               // lambda^-1 mod n^2, times R mod n^2, in pk->mn2 (level two)
   // pair kernel for the p^2 / q^2 ladders (GenP): p | Cadj limb arrays, R_H mod p^2 as a plain constant of mp2 / mq2
   bool has_pair = false;
+  bool pair_small2 = false;        // 37-limb primes: below one wave per SIMD the two-lane kernel fills the chip better
   int pair_lanes = 1;              // 1: GenP (both digits in one lane, 37-limb primes); 2: GenQ (one digit per lane: 55 / 74 limbs)
   DevLimbs pair_p, pair_q;
   int c_rh_p2 = -1, c_rh_q2 = -1;
@@ -1122,6 +1123,7 @@ int pgpu_seckey_create(pgpu_ctx* ctx, const pgpu_pubkey* pk, const uint8_t* lamb
         const int pair_tag = vm_asm_available(sk->mp.WT, 16) && sk->mp2.K == 1 ? 16 : 32;
         if (sk->mp.K == 1 && sk->mp2.WT == 2 * sk->mp.WT && vm_asm_available(sk->mp.WT, pair_tag)) {
           sk->pair_lanes = pair_tag == 16 ? 1 : 2;
+          sk->pair_small2 = sk->pair_lanes == 1 && vm_asm_available(sk->mp.WT, 32);   // two-lane variant for small batches
           const int H = sk->mp.WT;
           auto pair_consts = [&](const BigU& pr) { return make_pair_consts(pr, H); };
           std::vector<uint32_t> vp = pair_consts(p), vq = pair_consts(q);
@@ -1210,8 +1212,13 @@ uint32_t* decrypt1_crt(const pgpu_seckey* sk, const uint32_t* c_limbs, size_t nb
   HIPCHK(hipMemcpyAsync(mem, c_limbs, S2 * 2 * 4, hipMemcpyDeviceToDevice, ctx->stream));
   uint32_t *up = mem + 3 * S2, *uq = mem + 37 * S2;
   // (the two-lane kernel needs 2 lanes x 2 halves per ciphertext to fill the chip; below that the finer slicings win)
-  if (sk->has_pair && ctx->use_asm && ctx->use_pair &&
-      (sk->pair_lanes == 1 || nb * 4 >= (ctx->lanes_wanted ? ctx->lanes_wanted : (size_t)1024 * 64))) {
+  const size_t lanes_target = ctx->lanes_wanted ? ctx->lanes_wanted : (size_t)1024 * 64;
+  // one lane per number (GenP) from one wave per SIMD upwards; two lanes per number (GenQ) from there down to one wave
+  // per SIMD again; below that the ordinary kernels with their finer slicings
+  const int pair_lanes_now = (sk->pair_lanes == 1 && sk->pair_small2 && nb * 2 < lanes_target) ? 2 : sk->pair_lanes;
+  // (a two-lane digit pass is 2 H^2 multiplies per lane: shorter than any slicing of the 2H-limb kernels for H <= 55, so it
+  // also wins when the batch is latency-bound; for H = 74 the 4-lane slicing has the same length and fills the chip better)
+  if (sk->has_pair && ctx->use_asm && ctx->use_pair && (pair_lanes_now == 1 || W1 <= 55 || nb * 4 >= lanes_target)) {
     // The ladder runs on the pair kernel (residues mod p^2 as two base-p digits: 58 % of the multiplies of a squaring).
     // (1) X = c R_H mod p^2 on the ordinary kernel, canonical
     {
@@ -1243,8 +1250,8 @@ uint32_t* decrypt1_crt(const pgpu_seckey* sk, const uint32_t* c_limbs, size_t nb
       emit_modexp_shared(pq, sk->q - BigU(1), 36, NO_SLOT, 36, 37, 38, NO_SLOT, true, true);
       pq.end();
       SegSpec sp{&mp2, &pp, mem, nullptr}, sq{&mq2, &pq, mem, nullptr};
-      sp.pair = sk->pair_p.d; sp.pair_n0inv = mp.n0inv; sp.pair_h = W1; sp.pair_lanes = sk->pair_lanes;
-      sq.pair = sk->pair_q.d; sq.pair_n0inv = mq.n0inv; sq.pair_h = W1; sq.pair_lanes = sk->pair_lanes;
+      sp.pair = sk->pair_p.d; sp.pair_n0inv = mp.n0inv; sp.pair_h = W1; sp.pair_lanes = pair_lanes_now;
+      sq.pair = sk->pair_q.d; sq.pair_n0inv = mq.n0inv; sq.pair_h = W1; sq.pair_lanes = pair_lanes_now;
       run_vm(ctx, nb, sp, &sq, true);
     }
     // (4) back: F~ = F0 + F1 prime (an integer = F R_H mod p^2, lazy), then F = F~ R_H^-1 on the ordinary kernel

@@ -20,6 +20,12 @@ Register file budget (WL = 74): 148 (t) + 74 (x) + ~30 = 252 <= 256 architectura
 
 Supported opcodes: END LOAD STORE LOADC SQR MUL MULC MULV ADD (programs using SETOFF run on the
 compiler-generated kernel).
+
+Four generators share the VM contract (kernarg block, opcodes, slot layout):
+  Gen    lanes of one wave hold the K slices of a number (K = 1, 2, 4)
+  GenW   the two slices live in the same lane of two waves; LDS rings between them; symmetric squaring
+  GenP   N = p^2, p known, 37 limbs: a residue is two base-p digits in ONE lane; a product is two Montgomery steps mod p
+  GenQ   N = n^2 (or p^2), root known: the two digits in TWO neighbouring lanes, quotient digits by DPP
 """
 import sys
 
@@ -1885,9 +1891,9 @@ class GenQ(Gen):
         return "\n".join(self.lines) + "\n"
 
 
-SHAPES = [(74, 1), (37, 1), (55, 1), (55, 2), (74, 2), (55, 4), (37, 2), (37, 4), (37, 16), (74, 32), (55, 32)]
+SHAPES = [(74, 1), (37, 1), (55, 1), (55, 2), (74, 2), (55, 4), (37, 2), (37, 4), (37, 16), (74, 32), (55, 32), (37, 32)]
 PAIR = {(37, 16)}           # (H, 16): the pair kernel for N = p^2 with H-limb p (GenP); 16 is a tag, not a lane count
-PAIR2 = {(74, 32), (55, 32)}          # (H, 32): the two-lane pair kernel for N = n^2 with H-limb n (GenQ)
+PAIR2 = {(74, 32), (55, 32), (37, 32)}          # (H, 32): the two-lane pair kernel for N = n^2 with H-limb n (GenQ)
 WAVE_SLICED = {(74, 2), (55, 2)}     # shapes whose slices live in different waves (GenW) instead of neighbouring lanes (Gen)
 
 
