@@ -357,7 +357,7 @@ struct SegSpec {
   const uint32_t* pair = nullptr;
   uint32_t pair_n0inv = 0;
   int pair_h = 0;
-  int pair_lanes = 1;   // 1: GenP (one lane holds both digits); 2: GenQ (one digit per lane)
+  int pair_lanes = 1;   // 1: GenP (one lane holds both digits); 2: GenQ (one digit per lane); 4: GenQ4 (two lanes per digit)
 };
 
 // launch one VM kernel with 1 or 2 segments of `nb` numbers each (same modulus shape)
@@ -392,8 +392,8 @@ void run_vm(pgpu_ctx* ctx, size_t nb, const SegSpec& s0, const SegSpec* s1, bool
   const bool pair = s0.pair != nullptr;
   if (s1 && pair != (s1->pair != nullptr)) api_throw(PGPU_ERR_INVALID, "segment kind mismatch");
   if (pair) {
-    WL = s0.pair_h;
-    K = s0.pair_lanes == 2 ? 32 : 16;   // tags of the pair kernels, not lane counts
+    WL = s0.pair_lanes == 4 ? s0.pair_h / 2 : s0.pair_h;
+    K = s0.pair_lanes == 4 ? 64 : s0.pair_lanes == 2 ? 32 : 16;   // tags of the pair kernels, not lane counts
   } else {
     static const size_t lanes_env = [] { const char* e = getenv("PGPU_LANES_WANTED"); return e ? (size_t)atoll(e) : (size_t)0; }();
     const size_t lanes_wanted = ctx->lanes_wanted ? ctx->lanes_wanted : lanes_env ? lanes_env : (size_t)1024 * 64;
@@ -417,8 +417,8 @@ void run_vm(pgpu_ctx* ctx, size_t nb, const SegSpec& s0, const SegSpec* s1, bool
     // squaring rows: K == 1 triangular (WT^2 + WT(WT-1)/2 + WT); K == 2 slice-level symmetry (product part 1.5 WL^2 per lane)
     double sq = full;
     double mulp = full;
-    if (pair && s0.pair_lanes == 2) {   // GenQ: one / two Montgomery passes modulo n in both lanes
-      const double H = WL;
+    if (pair && s0.pair_lanes >= 2) {   // GenQ / GenQ4: one / two Montgomery passes modulo n in every digit lane
+      const double H = s0.pair_h;
       mulp = 8.0 * H * H;
       sq = 4.0 * H * H;
     } else if (pair) {   // five / three-and-a-half half-width products (see GenP)
@@ -665,7 +665,7 @@ ModexpPlan modexp_alloc(pgpu_ctx* ctx, const ModCtx& mc, size_t nb, int table_sl
 void reduce_mod(pgpu_ctx* ctx, const ModCtx& mc, const uint32_t* in, int w_in, uint32_t* out, size_t nb);
 
 // pl.in() (canonical, < N) ^ e [* pl.post()] mod N = n^2 on the two-lane pair kernel; result lazy in pl.out()
-void modexp_shared_pair(pgpu_ctx* ctx, const ModCtx& mc, const ModexpPlan& pl, const BigU& e, bool use_post) {
+void modexp_shared_pair(pgpu_ctx* ctx, const ModCtx& mc, const ModexpPlan& pl, const BigU& e, bool use_post, int lanes) {
   const PairInfo& pi = mc.pairn;
   const ModCtx& mn = *pi.root;
   const int H = mn.WT, W2 = mc.WT;
@@ -693,7 +693,7 @@ void modexp_shared_pair(pgpu_ctx* ctx, const ModCtx& mc, const ModexpPlan& pl, c
     emit_modexp_shared(p, e, 2, NO_SLOT, 2, 3, 5, NO_SLOT, true, true);
     p.end();
     SegSpec sp{&mc, &p, mem, nullptr};
-    sp.pair = pi.consts; sp.pair_n0inv = mn.n0inv; sp.pair_h = H; sp.pair_lanes = 2;
+    sp.pair = pi.consts; sp.pair_n0inv = mn.n0inv; sp.pair_h = H; sp.pair_lanes = lanes;
     run_vm(ctx, nb, sp, nullptr, true);
   }
   // (4) F~ = F0 + F1 n, out of pair and Montgomery form, times the plain residue in the post slot
@@ -710,9 +710,12 @@ void modexp_shared_pair(pgpu_ctx* ctx, const ModCtx& mc, const ModexpPlan& pl, c
 
 void modexp_shared_run(pgpu_ctx* ctx, const ModCtx& mc, const ModexpPlan& pl, const BigU& e, bool wide, bool use_post,
                        bool skip_zero) {
+  // two lanes per number from one wave per SIMD upwards; below that four (each digit over two lanes: a squaring is half as
+  // long as on the 4-lane 2H-limb kernel, which is what counts when the ladder's latency is the run time)
+  const bool two = pl.nb * 2 >= (ctx->lanes_wanted ? ctx->lanes_wanted : (size_t)1024 * 64);
   if (mc.pairn.root && ctx->use_asm && ctx->use_pair && !wide && skip_zero && e.bit_length() >= 256 &&
-      pl.nb * 2 >= (ctx->lanes_wanted ? ctx->lanes_wanted : (size_t)1024 * 64)) {
-    modexp_shared_pair(ctx, mc, pl, e, use_post);
+      (two || (mc.pairn.root->WT % 2 == 0 && vm_asm_available(mc.pairn.root->WT / 2, 64)))) {
+    modexp_shared_pair(ctx, mc, pl, e, use_post, two ? 2 : 4);
     launch_canon(pl.out(), mc.d_nmod, mc.WT, pl.nb, ctx->stream);
     return;
   }
@@ -908,8 +911,9 @@ int pgpu_pair_debug_run(pgpu_ctx* ctx, const uint8_t* p_be, size_t p_len, int la
     ModCtx mp, mp2;
     mp.init(ctx, pr);
     mp2.init(ctx, pr * pr);
-    if (lanes != 1 && lanes != 2) api_throw(PGPU_ERR_INVALID, "lanes must be 1 or 2");
-    if (mp.K != 1 || mp2.WT != 2 * mp.WT || !vm_asm_available(mp.WT, lanes == 2 ? 32 : 16))
+    if (lanes != 1 && lanes != 2 && lanes != 4) api_throw(PGPU_ERR_INVALID, "lanes must be 1, 2 or 4");
+    if (mp.K != 1 || mp2.WT != 2 * mp.WT ||
+        !(lanes == 4 ? (mp.WT % 2 == 0 && vm_asm_available(mp.WT / 2, 64)) : vm_asm_available(mp.WT, lanes == 2 ? 32 : 16)))
       api_throw(PGPU_ERR_UNSUPPORTED, "no pair kernel for this width");
     mp2.upload();
     const int H = mp.WT;

@@ -1891,8 +1891,249 @@ class GenQ(Gen):
         return "\n".join(self.lines) + "\n"
 
 
-SHAPES = [(74, 1), (37, 1), (55, 1), (55, 2), (74, 2), (55, 4), (37, 2), (37, 4), (37, 16), (74, 32), (55, 32), (37, 32)]
+class GenQ4(Gen):
+    """The two-lane pair kernel with every digit sliced over two lanes: 4 lanes per number (lanes 0,1 = the two 37-limb
+    slices of a0, lanes 2,3 = those of a1 -- the slot layout of the (37,4) shape).  Inside a digit the two slices work as
+    in the two-lane shapes of Gen (quotient digit broadcast and boundary column by DPP, modulus slice in VGPRs); between
+    the digits the link of GenQ (lane 2 takes Cadj_i - m_i from lane 0 in row i).  A squaring is 74 rows of 74 multiplies
+    per lane -- half of the (37,4) kernel's 148 rows -- which is what counts when a batch is too small to fill the chip
+    and the ladder's latency is the run time."""
+
+    def __init__(self, WL=37):
+        Gen.__init__(self, WL, 2)
+        assert self.n_vreg and not self.flush
+        self.H = 2 * WL                 # limbs of a digit
+        self.WTslot = 4 * WL            # limbs of a slot
+        self.WT = self.WTslot           # what the dispatcher's slot / constant addressing uses
+        self.NPB = BLOCK // 4
+        self.name = f"vm_asm_{WL}_64"
+        self.sq_rows = True
+        self.sq_rows_k = False
+        # extra registers after the base map
+        e = self.n_vgpr
+        self.v_sh, self.v_l2mask = e, e + 1
+        e += 2
+        e = (e + 1) // 2 * 2
+        self.v_d = e                    # pair (adjustment, 0)
+        e += 2
+        self.vR2 = e                    # pass-1 result of a product (digit a0 b1), 37 limbs
+        e += WL
+        self.n_vgpr = e
+        assert e <= 256, e
+        self._xb = self.vX
+        self.s_cadj, self.s_cadj_n, self.s_coff = 99, 100, 101
+        self.lds_bytes = self.lds_a + (self.WTslot + 1) * self.NPB * 4
+
+    def X(self, j):
+        return f"v{self._xb + j}"
+
+    # slot / constant addressing uses the 4-lane slot width
+    def slot_base(self):
+        g, e = self, self.e
+        e(f"s_mul_i32 s{g.s_t0}, s3, {self.WTslot}")
+        e(f"s_mul_hi_u32 s{g.s_sbase + 1}, s17, s{g.s_t0}")
+        e(f"s_mul_i32 s{g.s_sbase}, s17, s{g.s_t0}")
+        e(f"s_add_u32 s{g.s_sbase}, s{g.s_sbase}, s10")
+        e(f"s_addc_u32 s{g.s_sbase + 1}, s{g.s_sbase + 1}, s11")
+
+    def const_base(self):
+        g, e = self, self.e
+        e(f"s_mul_i32 s{g.s_t0}, s17, {self.WTslot * 4}")
+        e(f"s_add_u32 s{g.s_sbase}, s8, s{g.s_t0}")
+        e(f"s_addc_u32 s{g.s_sbase + 1}, s9, 0")
+
+    def prologue(self):
+        g, e = self, self.e
+        WL, NPB = self.WL, self.NPB
+        e(f'.amdgcn_target "amdgcn-amd-amdhsa--gfx950"')
+        e(".text")
+        e(f".globl {self.name}")
+        e(".p2align 8")
+        e(f".type {self.name},@function")
+        e(f"{self.name}:")
+        e("s_load_dword s3, s[0:1], 0x60")
+        e("s_waitcnt lgkmcnt(0)")
+        e("s_cmp_ge_u32 s2, s3")
+        e("s_cbranch_scc0 L_seg0")
+        e("s_sub_u32 s2, s2, s3")
+        e("s_add_u32 s0, s0, 48")
+        e("s_addc_u32 s1, s1, 0")
+        e("L_seg0:")
+        e("s_load_dwordx8 s[4:11], s[0:1], 0x0")
+        e("s_load_dwordx4 s[12:15], s[0:1], 0x20")
+        e("s_waitcnt lgkmcnt(0)")
+        e("s_lshl_b32 s3, s15, 2")
+        e(f"v_and_b32 v{g.v_t1}, 3, v0")                  # k4 = 2 d + s
+        e(f"v_lshrrev_b32 v{g.v_t2}, 2, v0")              # gl
+        e(f"s_mul_i32 s{g.s_t0}, s2, {NPB}")
+        e(f"v_add_u32 v{g.v_t3}, s{g.s_t0}, v{g.v_t2}")   # g
+        e(f"s_mul_i32 s{g.s_t1}, s15, {WL}")
+        e(f"v_mul_lo_u32 v{g.v_t4}, v{g.v_t1}, s{g.s_t1}")
+        e(f"v_add_lshl_u32 v{g.v_goff}, v{g.v_t4}, v{g.v_t3}, 2")
+        e(f"v_lshlrev_b32 v{g.v_aread}, 2, v{g.v_t2}")
+        e(f"v_add_u32 v{g.v_aread}, {self.lds_a}, v{g.v_aread}")
+        e(f"v_mul_u32_u24 v{g.v_t4}, {WL * NPB * 4}, v{g.v_t1}")
+        e(f"v_add_u32 v{g.v_awrite}, v{g.v_t4}, v{g.v_aread}")
+        e(f"v_mul_u32_u24 v{g.v_koff}, {WL * 4}, v{g.v_t1}")
+        e(f"v_and_b32 v{g.v_t4}, 1, v{g.v_t1}")           # s
+        e(f"v_mul_u32_u24 v{g.v_nbase}, {self.WLp * 4}, v{g.v_t4}")
+        e(f"v_lshrrev_b32 v{g.v_sh}, 1, v{g.v_t1}")       # d (kept; a squaring uses it as the multiplier shift)
+        e(f"v_cmp_eq_u32 vcc, 0, v{g.v_t4}")
+        e("s_nop 1")
+        e(f"v_cndmask_b32 v{g.v_isfirst}, 0, -1, vcc")
+        e(f"v_mov_b32 v{g.v_notlast}, v{g.v_isfirst}")     # two slices per digit: slice 0 is the first and the not-last one
+        e(f"v_cmp_eq_u32 vcc, 2, v{g.v_t1}")
+        e("s_nop 1")
+        e(f"v_cndmask_b32 v{g.v_l2mask}, 0, -1, vcc")
+        # modulus n (2 slices) -> LDS -> this lane's slice in VGPRs
+        e(f"v_lshlrev_b32 v{g.v_t3}, 2, v0")
+        e(f"v_cmp_gt_u32 vcc, {WL}, v0")
+        e("s_nop 1")
+        e("s_and_saveexec_b64 s[96:97], vcc")
+        for sgi in range(2):
+            e(f"global_load_dword v{g.v_p1}, v{g.v_t3}, s[6:7] offset:{sgi * WL * 4}")
+            e("s_waitcnt vmcnt(0)")
+            e(f"ds_write_b32 v{g.v_t3}, v{g.v_p1} offset:{sgi * self.WLp * 4}")
+        e("s_waitcnt lgkmcnt(0)")
+        e("s_mov_b64 exec, s[96:97]")
+        e("s_barrier")
+        for j in range(WL):
+            e(f"ds_read_b32 v{g.v_N + j}, v{g.v_nbase} offset:{4 * j}")
+        e("s_waitcnt lgkmcnt(0)")
+        e(f"s_add_u32 s6, s6, {4 * self.H}")              # s[6:7] -> Cadj
+        e("s_addc_u32 s7, s7, 0")
+        for j in range(WL):
+            e(f"v_mov_b32 {self.X(j)}, 0")
+
+    def row(self, cur, nxt, aoff, link, use_sh):
+        g, e = self, self.e
+        WL = self.WL
+        row = self.NPB * 4
+        N = lambda j: f"v{g.v_N + j}"
+        m = f"v{g.v_m}"
+        e("s_waitcnt lgkmcnt(0)")
+        e(f"ds_read_b32 v{nxt}, v{g.v_arow} offset:{aoff}")
+        e(f"v_add_u32 v{g.v_arow}, {row}, v{g.v_arow}")
+        if link:
+            e(f"s_mov_b32 s{g.s_cadj}, s{g.s_cadj_n}")
+            e(f"s_add_u32 s{g.s_coff}, s{g.s_coff}, 4")
+            e(f"s_load_dword s{g.s_cadj_n}, s[6:7], s{g.s_coff}")
+        if use_sh:
+            e(f"v_lshlrev_b32 v{cur}, v{g.v_sh}, v{cur}")
+        a = f"v{cur}"
+        self.align8()
+        for j in range(WL):
+            self.mad(self.T(j), a, self.X(j), self.T(j))
+        e(f"v_mul_lo_u32 {m}, {self.Tlo(0)}, s14")
+        e(f"v_and_b32 {m}, {hex(MASK)}, {m}")
+        e("s_nop 1")
+        if link:
+            e(f"v_mov_b32_dpp v{g.v_d}, {m} quad_perm:[0,1,0,3] row_mask:0xf bank_mask:0xf")
+            e(f"v_sub_u32 v{g.v_d}, s{g.s_cadj}, v{g.v_d}")
+            e(f"v_and_b32 v{g.v_d}, v{g.v_d}, v{g.v_l2mask}")
+            e(f"v_lshl_add_u64 {self.T(0)}, {self.T(0)}, 0, {self.P(g.v_d)}")
+            e(f"v_mul_lo_u32 {m}, {self.Tlo(0)}, s14")
+            e(f"v_and_b32 {m}, {hex(MASK)}, {m}")
+            e("s_nop 1")
+        e(f"v_mov_b32_dpp {m}, {m} quad_perm:[0,0,2,2] row_mask:0xf bank_mask:0xf")
+        self.align8()
+        self.mad(self.P(g.v_y0), m, N(0), self.T(0))
+        self.mad(self.T(0), m, N(1), self.T(1))
+        e(f"v_lshrrev_b64 {self.P(g.v_c)}, {LB}, {self.P(g.v_y0)}")
+        e(f"v_and_b32 v{g.v_c}, v{g.v_c}, v{g.v_isfirst}")
+        e(f"v_and_b32 v{g.v_c + 1}, v{g.v_c + 1}, v{g.v_isfirst}")
+        for j in range(2, WL):
+            self.mad(self.T(j - 1), m, N(j), self.T(j))
+            if j == 4:
+                e(f"v_lshl_add_u64 {self.T(0)}, {self.T(0)}, 0, {self.P(g.v_c)}")
+        e(f"v_mov_b32_dpp {self.Tlo(WL - 1)}, v{g.v_y0} quad_perm:[1,1,3,3] row_mask:0xf bank_mask:0xf")
+        e(f"v_mov_b32_dpp {self.Thi(WL - 1)}, v{g.v_y0 + 1} quad_perm:[1,1,3,3] row_mask:0xf bank_mask:0xf")
+        e(f"v_and_b32 {self.Tlo(WL - 1)}, {self.Tlo(WL - 1)}, v{g.v_notlast}")
+        e(f"v_and_b32 {self.Thi(WL - 1)}, {self.Thi(WL - 1)}, v{g.v_notlast}")
+
+    def passes(self, tag, aoff, link, use_sh):
+        g, e = self, self.e
+        WL, H = self.WL, self.H
+        row = self.NPB * 4
+        for j in range(WL):
+            e(f"v_mov_b64 {self.T(j)}, 0")
+        e(f"v_mov_b32 v{g.v_d + 1}, 0")
+        e(f"v_mov_b32 v{g.v_arow}, v{g.v_aread}")
+        e(f"ds_read_b32 v{g.v_ain}, v{g.v_arow} offset:{aoff}")
+        e(f"v_add_u32 v{g.v_arow}, {row}, v{g.v_arow}")
+        if link:
+            e(f"s_mov_b32 s{g.s_coff}, 0")
+            e(f"s_load_dword s{g.s_cadj_n}, s[6:7], 0x0")
+        e("s_mov_b32 s19, 0")
+        e(".p2align 6")
+        e(f"L_q{tag}:")
+        self.row(g.v_ain, g.v_ai, aoff, link, use_sh)
+        self.row(g.v_ai, g.v_ain, aoff, link, use_sh)
+        e("s_add_u32 s19, s19, 2")
+        e(f"s_cmp_lt_u32 s19, {H}")
+        e(f"s_cbranch_scc1 L_q{tag}")
+        e("s_waitcnt lgkmcnt(0)")
+
+    def montsq(self):
+        g, e = self, self.e
+        e("L_montsq:")
+        self.passes("s", 0, True, True)
+        self.normalize()
+        e("s_branch L_next")
+
+    def montmul(self):
+        g, e = self, self.e
+        WL, H = self.WL, self.H
+        row = self.NPB * 4
+        e("L_montmul:")
+        # pass 1: digit lanes 0,1: r2 = a0 b1 R^-1 (multiplier rows H..2H-1); lanes 2,3 run along, result dropped
+        self.passes("m1", H * row, False, False)
+        self._xb = self.vR2
+        self.normalize()
+        self._xb = self.vX
+        # lanes of digit 0 park r2 in the LDS rows that held b1: row H + 37 s + j
+
+        def park_addr():
+            e(f"v_not_b32 v{g.v_t4}, v{g.v_isfirst}")                   # -1 for slice 1
+            e(f"v_and_b32 v{g.v_t4}, {WL * row}, v{g.v_t4}")
+            e(f"v_add_u32 v{g.v_t4}, v{g.v_t4}, v{g.v_aread}")
+            e(f"v_add_u32 v{g.v_t4}, {H * row}, v{g.v_t4}")
+        park_addr()
+        e("s_mov_b64 s[96:97], exec")
+        e("s_mov_b32 s98, 0x33333333")
+        e("s_mov_b32 exec_lo, s98")
+        e("s_mov_b32 exec_hi, s98")
+        for j in range(WL):
+            e(f"ds_write_b32 v{g.v_t4}, v{g.vR2 + j} offset:{j * row}")
+        e("s_mov_b64 exec, s[96:97]")
+        # pass 2: digit 0: t = a0 b0 R^-1; digit 1: r1 = (a1 b0 + Cadj - m) R^-1
+        self.passes("m2", 0, True, False)
+        self.normalize()
+        park_addr()                     # (normalize() uses the scratch registers)
+        e("s_mov_b32 s98, 0xcccccccc")
+        e("s_mov_b32 exec_lo, s98")
+        e("s_mov_b32 exec_hi, s98")
+        St = [f"v{j}" for j in range(WL)]
+        for j in range(WL):
+            e(f"ds_read_b32 {St[j]}, v{g.v_t4} offset:{j * row}")
+        e("s_waitcnt lgkmcnt(0)")
+        for j in range(WL):
+            e(f"v_add_u32 {self.X(j)}, {self.X(j)}, {St[j]}")
+        e("s_mov_b64 exec, s[96:97]")
+        e("s_branch L_next")
+
+    def generate(self):
+        self.prologue()
+        self.dispatcher()
+        self.montmul()
+        self.montsq()
+        self.epilogue()
+        return "\n".join(self.lines) + "\n"
+
+
+SHAPES = [(74, 1), (37, 1), (55, 1), (55, 2), (74, 2), (55, 4), (37, 2), (37, 4), (37, 16), (74, 32), (55, 32), (37, 32), (37, 64)]
 PAIR = {(37, 16)}           # (H, 16): the pair kernel for N = p^2 with H-limb p (GenP); 16 is a tag, not a lane count
+PAIR4 = {(37, 64)}          # (WL, 64): GenQ4, the two digits of GenQ(2 WL) sliced over two lanes each
 PAIR2 = {(74, 32), (55, 32), (37, 32)}          # (H, 32): the two-lane pair kernel for N = n^2 with H-limb n (GenQ)
 WAVE_SLICED = {(74, 2), (55, 2)}     # shapes whose slices live in different waves (GenW) instead of neighbouring lanes (Gen)
 
@@ -1902,6 +2143,8 @@ def make_gen(wl, k):
         return GenP(wl)
     if (wl, k) in PAIR2:
         return GenQ(wl)
+    if (wl, k) in PAIR4:
+        return GenQ4(wl)
     return GenW(wl, k) if (wl, k) in WAVE_SLICED else Gen(wl, k)
 
 

@@ -80,6 +80,11 @@ def test_asm_generator_model():
             assert mm.split("L_p2m:")[0].count("v_mad_u64_u32") == 2 * H * H + 3 * H
             assert mm.split("L_p2m:")[1].split("s_cbranch_scc1 L_p2m")[0].count("v_mad_u64_u32") == 2 * 3 * H
             continue
+        if (wl, k) in gen_vm_asm.PAIR4:
+            for lbl, where in (("L_qs", "L_montsq:"), ("L_qm1", "L_montmul:"), ("L_qm2", "L_montmul:")):
+                body = text.split(where)[1].split(lbl + ":")[1].split("s_cbranch_scc1 " + lbl)[0]
+                assert body.count("v_mad_u64_u32") == 2 * 2 * wl          # two rows of 2 WL multiplies per lane
+            continue
         if (wl, k) in gen_vm_asm.PAIR2:
             # two-lane pair kernel: every pass is a loop of two single-lane rows of 2H multiplies; a squaring has one pass,
             # a product two

@@ -125,9 +125,11 @@ def test_decrypt_does_not_depend_on_the_pair_switch(ctx):
     assert with_pair[:40] + with_pair[-8:] == [po.decrypt(sk_o, po.Ciphertext(c)) for c in cts[:40] + cts[-8:]]
 
 
-def test_two_lane_pair_kernel_matches_the_integer_model(ctx):
-    """GenQ: N = n^2 with a public 74-limb n, digit a0 in lane 0 and a1 in lane 1.  A product adds the two partial results
-    r1 + r2 limb-wise (a lazy digit below 4n), so digits are compared as integers."""
+@pytest.mark.parametrize("lanes", [2, 4])
+def test_two_lane_pair_kernel_matches_the_integer_model(ctx, lanes):
+    """GenQ (lanes = 2): N = n^2 with a public 74-limb n, digit a0 in lane 0 and a1 in lane 1; GenQ4 (lanes = 4): every
+    digit sliced over two lanes.  A product adds the two partial results r1 + r2 limb-wise (a lazy digit below 4n), so
+    digits are compared as integers."""
     k = json.load(open(os.path.join(G, "keys.json")))["paillier"]["2048"]
     n = int(k["p"], 16) * int(k["q"], 16)
     rng = random.Random(23)
@@ -146,7 +148,7 @@ def test_two_lane_pair_kernel_matches_the_integer_model(ctx):
             mem[s, :H, g] = to_limbs(a[0], H)
             mem[s, H:, g] = to_limbs(a[1], H)
     prog = [LOAD, 0, SQR, 0, STORE, 2, LOAD, 0, MUL, 1, STORE, 3, SQR, 0, SQR, 0, MUL, 0, STORE, 4, END, 0]
-    out, consts, h = ctx.pair_debug_run(n, prog, mem, nslots, nb, lanes=2)
+    out, consts, h = ctx.pair_debug_run(n, prog, mem, nslots, nb, lanes=lanes)
     assert h == H and from_limbs(consts[:H]) == n
     cadj = from_limbs(consts[H:])
     assert cadj % n == 0
