@@ -175,6 +175,21 @@ __global__ void k_pack_be(const uint32_t* __restrict__ in, int wt, size_t nb, si
   size_t g = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (g >= count) return;
   uint8_t* p = out + g * stride;
+  if (((nbytes | stride | (size_t)(uintptr_t)out) & 3) == 0) {
+    // whole 32-bit words: word w (from the most significant end) holds bits [8 (nbytes - 4 - 4 w), +32) of the number
+    uint32_t* pw = (uint32_t*)p;
+    const size_t nw = nbytes / 4;
+    for (size_t w = 0; w < nw; ++w) {
+      size_t bit = 8 * (nbytes - 4 - 4 * w);
+      int l = (int)(bit / LB), sh = (int)(bit % LB);
+      uint64_t v = 0;
+      if (l < wt) v = in[(size_t)l * nb + g];
+      if (l + 1 < wt) v |= (uint64_t)in[(size_t)(l + 1) * nb + g] << LB;
+      if (l + 2 < wt && sh + 32 > 2 * LB) v |= (uint64_t)in[(size_t)(l + 2) * nb + g] << (2 * LB);
+      pw[w] = __builtin_bswap32((uint32_t)(v >> sh));
+    }
+    return;
+  }
   for (size_t bi = 0; bi < nbytes; ++bi) {  // bi = index from the least significant byte
     size_t bit = bi * 8;
     int l = (int)(bit / LB);
