@@ -145,7 +145,8 @@ def main():
     achieved = prof["vm_mads"] / (vm_ms_avg * 1e-3)
     alg_bytes = cb + pb  # read c (n^2 bytes) + write m (n bytes)
     kernel = {2048: "vm_asm_37_16 (pair kernel: x^(p-1) mod p^2 and x^(q-1) mod q^2 ladders, both halves in one launch)",
-              1024: "vm_asm_37_1 (CRT modexp over p^2 and q^2)", 3072: "vm_asm_55_2 (CRT modexp over p^2 and q^2, wave-sliced)"}[args.bits]
+              1024: "vm_asm_37_1 (CRT modexp over p^2 and q^2)",
+              3072: "vm_asm_55_32 (two-lane pair kernel: ladders modulo p^2 and q^2, both halves in one launch)"}[args.bits]
     roofline = {
         "bound": "valu",  # integer multiply issue (v_mad_u64_u32); neither HBM nor MFMA binds
         "kernel": kernel,
