@@ -401,7 +401,8 @@ class Gen:
         e("s_branch L_montmul")
 
         e("L_sqr:")
-        self.stage_to_lds(Xs)
+        if not getattr(self, "sq_self_staged", False):
+            self.stage_to_lds(Xs)
         e("s_branch L_montsq" if (self.sq_rows or self.sq_rows_k or getattr(self, "sq_rows_w", False)) else "s_branch L_montmul")
 
     # ---------------------------------------------------------------------------------------------
@@ -1464,7 +1465,8 @@ class GenP(Gen):
         self.H = H
         self.name = f"vm_asm_{H}_16"
         self.sq_rows = True
-        self.vM = 2 * H            # quotient digits of phase 1, as Cadj_i - m_i
+        self.sq_self_staged = True # a squaring writes its (doubled) multipliers to the LDS column itself, row by row
+        self.vM = 2 * H            # quotient digits m_i of phase 1 (phase 2 starts from Cadj_i - m_i)
         self.vA = 3 * H            # new a0 of a MUL (the old one is still an operand of phase 2)
 
     def X0(self, j):
@@ -1502,6 +1504,7 @@ class GenP(Gen):
             if sq:
                 ai = self.X0(i)
                 e(f"v_add_u32 v{g.v_ai}, {ai}, {ai}")
+                e(f"ds_write_b32 v{g.v_awrite}, v{g.v_ai} offset:{i * row}")     # phase 2 multiplies by 2 a0_i
                 self.align8()
                 acc(2 * i, ai, ai)
                 for j in range(i + 1, H):
@@ -1516,12 +1519,12 @@ class GenP(Gen):
                     acc(i + j, f"v{cur}", self.X0(j))
             c0 = i % H
             assert c0 not in fresh
-            e(f"v_mul_lo_u32 {m}, {self.Tlo(c0)}, s14")
-            e(f"v_and_b32 {m}, {hex(MASK)}, {m}")
-            e(f"v_sub_u32 v{g.vM + i}, {self.Cd(i)}, {m}")
+            mi = f"v{g.vM + i}"                      # the quotient digit stays in its own register for phase 2
+            e(f"v_mul_lo_u32 {mi}, {self.Tlo(c0)}, s14")
+            e(f"v_and_b32 {mi}, {hex(MASK)}, {mi}")
             self.align8()
             for j in range(H):
-                acc(i + j, m, self.Pm(j))
+                acc(i + j, mi, self.Pm(j))
             e(f"v_lshrrev_b64 {self.P(g.v_c)}, {LB}, {self.T(c0)}")
             e(f"v_lshl_add_u64 {self.T((i + 1) % H)}, {self.T((i + 1) % H)}, 0, {self.P(g.v_c)}")
             fresh.add(c0)
@@ -1548,7 +1551,7 @@ class GenP(Gen):
                 e(f"v_lshrrev_b64 {cpair}, {LB}, {self.T(c)}")
 
     # ---- phase 2: c1 = (cross + Cadj - m) R^-1 mod p ---------------------------------------------------------------
-    def phase2_row(self, sq, cur, nxt, cur1, nxt1, first):
+    def phase2_row(self, sq, cur, nxt, cur1, nxt1, first, roff=0, bump=None):
         """one row, register-shift style (T(j-1) <- T(j) + m' p_j).  sq: multiplier 2 a0_i times a1; else b0_i times a1
         plus b1_i times a0.  cur/nxt: a_i registers (this row / prefetch); cur1/nxt1: the b1 stream of a MUL."""
         g, e = self, self.e
@@ -1556,13 +1559,12 @@ class GenP(Gen):
         row = self.NPB * 4
         m = f"v{g.v_m}"
         e("s_waitcnt lgkmcnt(0)")
-        e(f"ds_read_b32 v{nxt}, v{g.v_arow}")
+        e(f"ds_read_b32 v{nxt}, v{g.v_arow} offset:{roff}")
         if not sq:
-            e(f"ds_read_b32 v{nxt1}, v{g.v_arow} offset:{H * row}")
-        e(f"v_add_u32 v{g.v_arow}, {row}, v{g.v_arow}")
-        if sq:
-            e(f"v_add_u32 v{cur}, v{cur}, v{cur}")
-        a = f"v{cur}"
+            e(f"ds_read_b32 v{nxt1}, v{g.v_arow} offset:{H * row + roff}")
+        if bump:
+            e(f"v_add_u32 v{g.v_arow}, {bump}, v{g.v_arow}")
+        a = f"v{cur}"                                   # a squaring reads 2 a0_i: phase 1 stored it doubled
         self.align8()
         for j in range(H):
             if j == H - 1 and not first:
@@ -1588,7 +1590,7 @@ class GenP(Gen):
         H = self.H
         row = self.NPB * 4
         for j in range(H):
-            e(f"v_mov_b32 {self.Tlo(j)}, v{g.vM + j}")
+            e(f"v_sub_u32 {self.Tlo(j)}, {self.Cd(j)}, v{g.vM + j}")     # Cadj_j - m_j >= 0 limb by limb
             e(f"v_mov_b32 {self.Thi(j)}, 0")
         e(f"v_mov_b32 v{g.v_arow}, v{g.v_aread}")
         e(f"ds_read_b32 v{g.v_ain}, v{g.v_arow}")
@@ -1596,12 +1598,12 @@ class GenP(Gen):
             e(f"ds_read_b32 v{g.v_t2}, v{g.v_arow} offset:{H * row}")
         e(f"v_add_u32 v{g.v_arow}, {row}, v{g.v_arow}")
         # row 0 keeps the initial value of the top column; then (H-1)/2 iterations of two rows
-        self.phase2_row(sq, g.v_ain, g.v_ai, g.v_t2, g.v_t3, True)
+        self.phase2_row(sq, g.v_ain, g.v_ai, g.v_t2, g.v_t3, True, 0, row)
         e("s_mov_b32 s19, 1")
         e(".p2align 6")
         e(f"L_p2{tag}:")
-        self.phase2_row(sq, g.v_ai, g.v_ain, g.v_t3, g.v_t2, False)
-        self.phase2_row(sq, g.v_ain, g.v_ai, g.v_t2, g.v_t3, False)
+        self.phase2_row(sq, g.v_ai, g.v_ain, g.v_t3, g.v_t2, False, 0, None)
+        self.phase2_row(sq, g.v_ain, g.v_ai, g.v_t2, g.v_t3, False, row, 2 * row)
         e("s_add_u32 s19, s19, 2")
         e(f"s_cmp_lt_u32 s19, {H}")
         e(f"s_cbranch_scc1 L_p2{tag}")
