@@ -347,6 +347,50 @@ void emit_modexp_perlane(Prog& p, int we, uint32_t in_lo, uint32_t in_hi, uint32
   p.op(VM_STORE, out);
 }
 
+// x^(per-number exponent) * y^(shared exponent e) with ONE chain of squarings (interleaved / "Shamir" exponentiation):
+// x's 4-bit fixed windows (MULV on the table tab1[0..15]) and y's sliding windows over odd powers (tab2[0..31], w = 6) hang
+// off the same accumulator.  Costs max(bits) squarings instead of the sum: what check^(E^n) * F^(n^2) of the DDLEQ
+// verifier (ddleq.go:143-152) and alpha = ct1^(x^n) * y^(n^2) of the prover (ddleq.go:81-87) need.
+// x in slot in1, y in slot in2 (plain residues); result (plain, lazy) -> out.
+void emit_modexp_dual(Prog& p, int we, const BigU& e, uint32_t in1, uint32_t in2, uint32_t tmp, uint32_t out, uint32_t tab1,
+                      uint32_t tab2) {
+  // tables
+  emit_to_mont(p, in1, NO_SLOT, tmp);
+  p.op(VM_STORE, tab1 + 1);
+  p.op(VM_LOADC, C_ONE_M);
+  p.op(VM_STORE, tab1 + 0);
+  p.op(VM_LOAD, tab1 + 1);
+  for (uint32_t k = 2; k < 16; ++k) { p.op(VM_MUL, tab1 + 1); p.op(VM_STORE, tab1 + k); }
+  const int sw = 6;
+  const uint32_t nodd = 1u << (sw - 1);
+  emit_to_mont(p, in2, NO_SLOT, tmp);
+  p.op(VM_STORE, tab2 + 0);
+  p.op(VM_SQR);
+  p.op(VM_STORE, tmp);
+  p.op(VM_LOAD, tab2 + 0);
+  for (uint32_t k = 1; k < nodd; ++k) { p.op(VM_MUL, tmp); p.op(VM_STORE, tab2 + k); }
+  // sliding windows of e: mul_at[l] = table index to multiply in after the squaring of bit l (the window's lowest bit)
+  const long nbits = std::max<long>((long)we * LB, (long)e.bit_length());
+  std::vector<int> mul_at((size_t)nbits, -1);
+  for (long i = (long)e.bit_length() - 1; i >= 0;) {
+    if (!e.bit((size_t)i)) { --i; continue; }
+    long l = std::max<long>(i - sw + 1, 0);
+    while (!e.bit((size_t)l)) ++l;
+    uint32_t val = 0;
+    for (long b = i; b >= l; --b) val = (val << 1) | (uint32_t)e.bit((size_t)b);
+    mul_at[(size_t)l] = (int)(val >> 1);
+    i = l - 1;
+  }
+  p.op(VM_LOADC, C_ONE_M);
+  for (long b = nbits - 1; b >= 0; --b) {
+    if (b != nbits - 1) p.op(VM_SQR);
+    if (b % 4 == 0 && b / 4 < (long)we * 7) p.op(VM_MULV, (uint32_t)(b / 4), tab1);
+    if (mul_at[(size_t)b] >= 0) p.op(VM_MUL, tab2 + (uint32_t)mul_at[(size_t)b]);
+  }
+  p.op(VM_MULC, C_ONE);
+  p.op(VM_STORE, out);
+}
+
 struct SegSpec {
   const ModCtx* mc;
   const Prog* prog;
@@ -2098,15 +2142,20 @@ int pgpu_ddleq_verify(const pgpu_pubkey* pk, size_t batch, const uint8_t* ct1, c
     ModexpPlan pe = modexp_alloc(ctx, mn2, nb, 32);
     unpack_operand(ctx, e, e_stride, std::min(e_stride, 2 * mn2.nbytes), batch, mem, pe.in(), 2 * W2, nb);
     modexp_shared_run(ctx, mn2, pe, pk->N, true, false, true);
-    ModexpPlan pf = modexp_alloc(ctx, mn3, nb, 32);
+    // check = chalBit ? ct2 : ct1 ; check^en * F^(n^2) mod n^3 == alpha           (ddleq.go:138-152)
+    // one interleaved ladder: the squarings of check^en and of F^(n^2) are shared (emit_modexp_dual)
     if (f_stride * 8 > (size_t)LB * W3 + 7) api_throw(PGPU_ERR_INVALID, "F wider than n^3");
-    unpack_operand(ctx, f, f_stride, f_stride, batch, mem, pf.in(), W3, nb);
-    modexp_shared_run(ctx, mn3, pf, mn2.N, false, false, true);
-    // check = chalBit ? ct2 : ct1 ; check^en * fn2 mod n^3 == alpha              (ddleq.go:138-152)
-    ModexpPlan pc = modexp_alloc(ctx, mn3, nb, 16);
+    ModexpPlan pc = modexp_alloc(ctx, mn3, nb, 48);       // slots: 0 check, 1 F, 2 tmp, 3 out, 5..20 / 21..52 the two tables
     launch_select(chal, c2, c1, pc.in(), W3, nb, ctx->stream);
-    HIPCHK(hipMemcpyAsync(pc.post(), pf.out(), (size_t)W3 * nb * 4, hipMemcpyDeviceToDevice, ctx->stream));
-    modexp_perlane_run(ctx, mn3, pc, pe.out(), W2, false, true);
+    unpack_operand(ctx, f, f_stride, f_stride, batch, mem, pc.in() + pc.slot_words, W3, nb);
+    {
+      Prog pd;
+      emit_modexp_dual(pd, W2, mn2.N, 0, 1, 2, 3, 5, 21);
+      pd.end();
+      SegSpec sd{&mn3, &pd, pc.mem, pe.out()};
+      run_vm(ctx, nb, sd, nullptr, true);
+      launch_canon(pc.out(), mn3.d_nmod, W3, nb, ctx->stream);
+    }
     int32_t* d_ok = ctx->ws_t<int32_t>(nb);
     if (wa != W3) api_throw(PGPU_ERR_INVALID, "alpha stride must be the byte length of n^3");
     launch_equal(pc.out(), al, W3, nb, batch, d_ok, ctx->stream);
@@ -2220,44 +2269,53 @@ void shared_pow(pgpu_ctx* ctx, const ModCtx& mc, const uint32_t* base, int wb, c
 // width, the same exponent -- in one two-segment launch, then Garner.  2.6x fewer limb products than the ladder modulo
 // n^3, the same canonical residue.  Per-number exponents (exps: we limbs each) or one shared exponent (*e).
 void pow_n3_crt(const pgpu_seckey* sk, const uint32_t* base, int wb, const uint32_t* exps, int we, const BigU* e, size_t nb,
-                uint32_t* out) {
+                uint32_t* out, const uint32_t* base2 = nullptr, int wb2 = 0) {
+  // base2 != nullptr: out = base^(per-number exps) * base2^(*e), one interleaved ladder per half (emit_modexp_dual)
   pgpu_ctx* ctx = sk->ctx;
   const ModCtx &mp3 = sk->mp3, &mq3 = sk->mq3;
   const int W = mp3.WT, W3 = sk->pk->mn3->WT;
   const size_t S = (size_t)W * nb;
-  // slots: P: in 0, tmp 2, out 3, table 4..35;  Q: in 36, tmp 38, out 39, table 40..71;  72 A, 73 B, 74 h
-  uint32_t* mem = ctx->ws_t<uint32_t>(S * 75);
+  // slots: P: in 0, in2 1, tmp 2, out 3, tables 4..51;  Q: the same + QO;  A, B, h after them
+  const uint32_t QO = 56, SA = 112, SB = 113, SH = 114;
+  uint32_t* mem = ctx->ws_t<uint32_t>(S * 115);
   reduce_mod(ctx, mp3, base, wb, mem + 0 * S, nb);
-  reduce_mod(ctx, mq3, base, wb, mem + 36 * S, nb);
+  reduce_mod(ctx, mq3, base, wb, mem + (size_t)QO * S, nb);
+  if (base2) {
+    reduce_mod(ctx, mp3, base2, wb2, mem + 1 * S, nb);
+    reduce_mod(ctx, mq3, base2, wb2, mem + (size_t)(QO + 1) * S, nb);
+  }
   {
     Prog pp, pq;
-    if (exps) {
+    if (base2) {
+      emit_modexp_dual(pp, we, *e, 0, 1, 2, 3, 4, 20);
+      emit_modexp_dual(pq, we, *e, QO, QO + 1, QO + 2, QO + 3, QO + 4, QO + 20);
+    } else if (exps) {
       emit_modexp_perlane(pp, we, 0, NO_SLOT, 2, 3, 4, NO_SLOT);
-      emit_modexp_perlane(pq, we, 36, NO_SLOT, 38, 39, 40, NO_SLOT);
+      emit_modexp_perlane(pq, we, QO, NO_SLOT, QO + 2, QO + 3, QO + 4, NO_SLOT);
     } else {
       emit_modexp_shared(pp, *e, 0, NO_SLOT, 2, 3, 4, NO_SLOT, true);
-      emit_modexp_shared(pq, *e, 36, NO_SLOT, 38, 39, 40, NO_SLOT, true);
+      emit_modexp_shared(pq, *e, QO, NO_SLOT, QO + 2, QO + 3, QO + 4, NO_SLOT, true);
     }
     pp.end();
     pq.end();
     SegSpec sp{&mp3, &pp, mem, exps}, sq{&mq3, &pq, mem, exps};
     run_vm(ctx, nb, sp, &sq, true);
   }
-  uint32_t *xp = mem + 3 * S, *xq = mem + 39 * S;
+  uint32_t *xp = mem + 3 * S, *xq = mem + (size_t)(QO + 3) * S;
   launch_canon(xp, mp3.d_nmod, W, nb, ctx->stream);     // ONE integer x_p for both uses below
   launch_canon(xq, mq3.d_nmod, W, nb, ctx->stream);
   {
     Prog c;
-    c.op(VM_LOAD, 3);  c.op(VM_MULC, (uint32_t)sk->c_p3invR); c.op(VM_STORE, 73);
-    c.op(VM_LOAD, 39); c.op(VM_MULC, (uint32_t)sk->c_p3invR); c.op(VM_STORE, 72);
+    c.op(VM_LOAD, 3);      c.op(VM_MULC, (uint32_t)sk->c_p3invR); c.op(VM_STORE, SB);
+    c.op(VM_LOAD, QO + 3); c.op(VM_MULC, (uint32_t)sk->c_p3invR); c.op(VM_STORE, SA);
     c.end();
     SegSpec sc{&mq3, &c, mem, nullptr};
     run_vm(ctx, nb, sc, nullptr, false);
   }
-  launch_canon(mem + 72 * S, mq3.d_nmod, W, nb, ctx->stream);
-  launch_canon(mem + 73 * S, mq3.d_nmod, W, nb, ctx->stream);
-  launch_sub_mod(mem + 72 * S, mem + 73 * S, mq3.d_nmod, mem + 74 * S, W, nb, ctx->stream);    // h = (x_q - x_p) / p^3 mod q^3
-  launch_mul_const_add(mem + 74 * S, W, sk->p3_limbs.d, W, xp, W, 0, out, W3, nb, ctx->stream);   // x_p + p^3 h
+  launch_canon(mem + (size_t)SA * S, mq3.d_nmod, W, nb, ctx->stream);
+  launch_canon(mem + (size_t)SB * S, mq3.d_nmod, W, nb, ctx->stream);
+  launch_sub_mod(mem + (size_t)SA * S, mem + (size_t)SB * S, mq3.d_nmod, mem + (size_t)SH * S, W, nb, ctx->stream);  // h = (x_q - x_p) / p^3 mod q^3
+  launch_mul_const_add(mem + (size_t)SH * S, W, sk->p3_limbs.d, W, xp, W, 0, out, W3, nb, ctx->stream);              // x_p + p^3 h
 }
 
 uint32_t* zext(pgpu_ctx* ctx, const uint32_t* in, int w, int wo, size_t nb) {
@@ -2309,11 +2367,15 @@ int pgpu_ddleq_prove(const pgpu_seckey* sk, size_t batch, const uint8_t* ct1, co
     uint32_t* an = ctx->ws_t<uint32_t>((size_t)W2 * nb);
     shared_pow(ctx, mn2, al, W1, N, nb, an);
     uint32_t* bn2 = ctx->ws_t<uint32_t>((size_t)W3 * nb);
-    shared3(bl, W1, N2, nb, bn2);
     uint32_t* t3 = ctx->ws_t<uint32_t>((size_t)W3 * nb);
-    perlane3(c1, an, W2, nb, t3);
     uint32_t* san = ctx->ws_t<uint32_t>((size_t)W3 * nb);
-    modmul_arrays(ctx, mn3, t3, bn2, nb, san);
+    if (crt3) {
+      pow_n3_crt(sk, c1, W3, an, W2, &N2, nb, san, bl, W1);          // ct1^(a^n) * b^(n^2): one interleaved ladder per half
+    } else {
+      shared3(bl, W1, N2, nb, bn2);
+      perlane3(c1, an, W2, nb, t3);
+      modmul_arrays(ctx, mn3, t3, bn2, nb, san);
+    }
     int32_t* d_ok = ctx->ws_t<int32_t>(nb);
     launch_equal(san, c2, W3, nb, batch, d_ok, ctx->stream);
     std::vector<int32_t> hok(batch);
@@ -2325,10 +2387,15 @@ int pgpu_ddleq_prove(const pgpu_seckey* sk, size_t batch, const uint8_t* ct1, co
     uint32_t* xn = ctx->ws_t<uint32_t>((size_t)W2 * nb);
     shared_pow(ctx, mn2, xl, W1, N, nb, xn);
     uint32_t* yn2 = ctx->ws_t<uint32_t>((size_t)W3 * nb);
-    shared3(yl, W1, N2, nb, yn2);
-    perlane3(c1, xn, W2, nb, t3);
     uint32_t* alp = ctx->ws_t<uint32_t>((size_t)W3 * nb);
-    modmul_arrays(ctx, mn3, t3, yn2, nb, alp);
+    if (crt3) {
+      pow_n3_crt(sk, c1, W3, xn, W2, &N2, nb, alp, yl, W1);
+      // y^(n^2) alone is needed again below only for chalBit = 1 instances, where f is built from other terms: not here
+    } else {
+      shared3(yl, W1, N2, nb, yn2);
+      perlane3(c1, xn, W2, nb, t3);
+      modmul_arrays(ctx, mn3, t3, yn2, nb, alp);
+    }
     // ---- challenge bit = LSB SHA-256(ct2 || x || y || alpha)  (ddleq.go:91; ct1 is skipped: random_oracle.go:24-26)
     int32_t* chal = ctx->ws_t<int32_t>(nb);
     HIPCHK(hipMemsetAsync(chal, 0, nb * 4, ctx->stream));
