@@ -130,6 +130,7 @@ struct PairInfo {
   const ModCtx* root = nullptr;       // n
   const uint32_t* consts = nullptr;   // device: n | Cadj (H limbs each) + one word of padding
   int c_rh = -1;                      // index of R_H mod n^2 (plain) in the consts of n^2
+  int c_one_pair = -1;                // index of the pair form of 1 (the digits of R_H mod n^2) in the consts of n^2
   const uint32_t* dinv = nullptr;     // n^-1 mod 2^(28 H)
   const uint32_t* n_limbs = nullptr;  // n as H limbs
 };
@@ -326,11 +327,14 @@ void emit_modexp_shared(Prog& p, const BigU& e, uint32_t in_lo, uint32_t in_hi, 
 
 // Per-number exponent, fixed window w = 4 (7 windows per 28-bit exponent limb).  The exponent limbs are
 // the segment's `digits` array [we][nb].  Table slots tab .. tab+15.
+// raw_one >= 0: the value in slot in_lo is already in the kernel's working form (pair kernels), raw_one is the constant
+// holding 1 in that form; no entry, no exit.
 void emit_modexp_perlane(Prog& p, int we, uint32_t in_lo, uint32_t in_hi, uint32_t tmp, uint32_t out, uint32_t tab,
-                         uint32_t post_slot) {
-  emit_to_mont(p, in_lo, in_hi, tmp);
+                         uint32_t post_slot, int raw_one = -1) {
+  const uint32_t one = raw_one >= 0 ? (uint32_t)raw_one : (uint32_t)C_ONE_M;
+  if (raw_one >= 0) p.op(VM_LOAD, in_lo); else emit_to_mont(p, in_lo, in_hi, tmp);
   p.op(VM_STORE, tab + 1);
-  p.op(VM_LOADC, C_ONE_M);
+  p.op(VM_LOADC, one);
   p.op(VM_STORE, tab + 0);
   p.op(VM_LOAD, tab + 1);
   for (uint32_t k = 2; k < 16; ++k) {
@@ -338,12 +342,12 @@ void emit_modexp_perlane(Prog& p, int we, uint32_t in_lo, uint32_t in_hi, uint32
     p.op(VM_STORE, tab + k);
   }
   const int nwin = we * 7;
-  p.op(VM_LOADC, C_ONE_M);
+  p.op(VM_LOADC, one);
   for (int i = nwin - 1; i >= 0; --i) {
     if (i != nwin - 1) for (int s = 0; s < 4; ++s) p.op(VM_SQR);
     p.op(VM_MULV, (uint32_t)i, tab);
   }
-  if (post_slot != NO_SLOT) p.op(VM_MUL, post_slot); else p.op(VM_MULC, C_ONE);
+  if (raw_one < 0) { if (post_slot != NO_SLOT) p.op(VM_MUL, post_slot); else p.op(VM_MULC, C_ONE); }
   p.op(VM_STORE, out);
 }
 
@@ -711,7 +715,8 @@ ModexpPlan modexp_alloc(pgpu_ctx* ctx, const ModCtx& mc, size_t nb, int table_sl
 void reduce_mod(pgpu_ctx* ctx, const ModCtx& mc, const uint32_t* in, int w_in, uint32_t* out, size_t nb);
 
 // pl.in() (canonical, < N) ^ e [* pl.post()] mod N = n^2 on the two-lane pair kernel; result lazy in pl.out()
-void modexp_shared_pair(pgpu_ctx* ctx, const ModCtx& mc, const ModexpPlan& pl, const BigU& e, bool use_post, int lanes) {
+void modexp_pair(pgpu_ctx* ctx, const ModCtx& mc, const ModexpPlan& pl, const BigU* e, const uint32_t* exps, int we,
+                 bool use_post, int lanes) {
   const PairInfo& pi = mc.pairn;
   const ModCtx& mn = *pi.root;
   const int H = mn.WT, W2 = mc.WT;
@@ -736,9 +741,10 @@ void modexp_shared_pair(pgpu_ctx* ctx, const ModCtx& mc, const ModexpPlan& pl, c
   // (3) the ladder in pair form
   {
     Prog p;
-    emit_modexp_shared(p, e, 2, NO_SLOT, 2, 3, 5, NO_SLOT, true, true);
+    if (exps) emit_modexp_perlane(p, we, 2, NO_SLOT, 2, 3, 5, NO_SLOT, pi.c_one_pair);
+    else emit_modexp_shared(p, *e, 2, NO_SLOT, 2, 3, 5, NO_SLOT, true, true);
     p.end();
-    SegSpec sp{&mc, &p, mem, nullptr};
+    SegSpec sp{&mc, &p, mem, exps};
     sp.pair = pi.consts; sp.pair_n0inv = mn.n0inv; sp.pair_h = H; sp.pair_lanes = lanes;
     run_vm(ctx, nb, sp, nullptr, true);
   }
@@ -761,7 +767,7 @@ void modexp_shared_run(pgpu_ctx* ctx, const ModCtx& mc, const ModexpPlan& pl, co
   const bool two = pl.nb * 2 >= (ctx->lanes_wanted ? ctx->lanes_wanted : (size_t)1024 * 64);
   if (mc.pairn.root && ctx->use_asm && ctx->use_pair && !wide && skip_zero && e.bit_length() >= 256 &&
       (two || (mc.pairn.root->WT % 2 == 0 && vm_asm_available(mc.pairn.root->WT / 2, 64)))) {
-    modexp_shared_pair(ctx, mc, pl, e, use_post, two ? 2 : 4);
+    modexp_pair(ctx, mc, pl, &e, nullptr, 0, use_post, two ? 2 : 4);
     launch_canon(pl.out(), mc.d_nmod, mc.WT, pl.nb, ctx->stream);
     return;
   }
@@ -775,6 +781,16 @@ void modexp_shared_run(pgpu_ctx* ctx, const ModCtx& mc, const ModexpPlan& pl, co
 
 void modexp_perlane_run(pgpu_ctx* ctx, const ModCtx& mc, const ModexpPlan& pl, const uint32_t* exps, int we, bool wide,
                         bool use_post) {
+  {
+    const bool two = pl.nb * 2 >= (ctx->lanes_wanted ? ctx->lanes_wanted : (size_t)1024 * 64);
+    const uint64_t table_bytes = (uint64_t)pl.nb * mc.WT * 4 * 17;      // MULV gathers with 32-bit offsets
+    if (mc.pairn.root && mc.pairn.c_one_pair >= 0 && ctx->use_asm && ctx->use_pair && !wide && we >= 10 &&
+        table_bytes < (1ull << 32) && (two || (mc.pairn.root->WT % 2 == 0 && vm_asm_available(mc.pairn.root->WT / 2, 64)))) {
+      modexp_pair(ctx, mc, pl, nullptr, exps, we, use_post, two ? 2 : 4);
+      launch_canon(pl.out(), mc.d_nmod, mc.WT, pl.nb, ctx->stream);
+      return;
+    }
+  }
   Prog p;
   emit_modexp_perlane(p, we, 0, wide ? 1 : NO_SLOT, 2, 3, 5, use_post ? 4 : NO_SLOT);
   p.end();
@@ -1082,7 +1098,13 @@ int pgpu_pubkey_create(pgpu_ctx* ctx, const uint8_t* n_be, size_t n_len, const u
       PairInfo& pi = pk->mn2.pairn;
       pi.root = &pk->mn;
       pi.consts = pk->pairn_consts.d;
-      pi.c_rh = pk->mn2.add_const(hostbig::shl(BigU(1), (size_t)LB * H) % n2);
+      const BigU rh = hostbig::shl(BigU(1), (size_t)LB * H) % n2;
+      pi.c_rh = pk->mn2.add_const(rh);
+      {
+        BigU d1, d0;
+        hostbig::divmod(rh, pk->N, d1, d0);                       // R_H mod n^2 = d0 + d1 n
+        pi.c_one_pair = pk->mn2.add_const(d0 + hostbig::shl(d1, (size_t)LB * H));   // limbs 0..H-1 = d0, H..2H-1 = d1
+      }
       pi.dinv = pk->ninv2k.d;
       pi.n_limbs = pk->n_limbs.d;
     }

@@ -212,3 +212,28 @@ def test_decrypt_3072_on_the_two_lane_pair_kernel(ctx):
         ctx.set_flag("lanes_wanted", 0)
     assert with_pair == without
     assert with_pair[:20] + with_pair[-6:] == [po.decrypt(sk_o, po.Ciphertext(c)) for c in cts[:20] + cts[-6:]]
+
+
+@pytest.mark.parametrize("force_two_lanes", [0, 1])
+def test_const_mult_per_ciphertext_on_the_pair_kernels(ctx, force_two_lanes):
+    """ConstMult with one k per ciphertext (operations.go:58-64 element-wise; NestedAdd's shape) is a per-number-exponent
+    ladder modulo n^2: table gathers (MULV) on the pair kernels -- the four-lane one for a small batch, the two-lane one
+    when forced -- must agree with the ordinary kernels and with Python."""
+    import paillier_amd as pa
+    k = json.load(open(os.path.join(G, "keys.json")))["paillier"]["2048"]
+    n = int(k["p"], 16) * int(k["q"], 16)
+    n2 = n * n
+    pk = pa.PublicKey(ctx, n, n + 1)
+    rng = random.Random(25 + force_two_lanes)
+    cs = [rng.randrange(n2) for _ in range(260)] + [0, 1, n2 - 1]
+    ks = [rng.randrange(n) for _ in cs[:-2]] + [0, 1]
+    try:
+        ctx.set_flag("lanes_wanted", 1 if force_two_lanes else 0)
+        ctx.set_flag("pair", 1)
+        got = pk.ConstMultBatch(cs, ks)
+        ctx.set_flag("pair", 0)
+        ref = pk.ConstMultBatch(cs, ks)
+    finally:
+        ctx.set_flag("pair", 1)
+        ctx.set_flag("lanes_wanted", 0)
+    assert got == ref == [pow(c, kk, n2) for c, kk in zip(cs, ks)]
