@@ -27,7 +27,7 @@ sys.path.insert(0, ROOT)
 # theoretical figure (the stricter denominator).
 PEAK_MAD_PER_S = 256 * 4 * 64 / 4 * 2.4e9
 HBM_PEAK_GBPS = 8000.0
-TRAFFIC_DEFAULT = 7.99e9   # HBM bytes per launch of the dominant kernel for the default workload (PMC passes, profiles/)
+TRAFFIC_DEFAULT = 8.0e9   # HBM bytes per launch of the dominant kernel for the default workload (PMC passes, profiles/)
 
 
 def alg_mul32_per_modexp(mod_bits: int, exp_bits: int, w: int = 5) -> float:
