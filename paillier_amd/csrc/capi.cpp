@@ -579,6 +579,8 @@ struct pgpu_seckey {
   int pair_lanes = 1;              // 1: GenP (both digits in one lane, 37-limb primes); 2: GenQ (one digit per lane: 55 / 74 limbs)
   DevLimbs pair_p, pair_q;
   int c_rh_p2 = -1, c_rh_q2 = -1;
+  int c_pk_p2[4] = {-1, -1, -1, -1}, c_pk_q2[4] = {-1, -1, -1, -1};   // pair forms of R_H^(k+2): chunk k of c enters the ladder
+  int c_onep_p2 = -1, c_onep_q2 = -1;                                 // pair form of 1 (normalises a lazy pair)
   DevLimbs q_limbs1;               // q as mq.WT limbs (p_limbs is above)
   // level-two CRT over p^3 and q^3
   bool has_crt2 = false;
@@ -1211,6 +1213,22 @@ int pgpu_seckey_create(pgpu_ctx* ctx, const pgpu_pubkey* pk, const uint8_t* lamb
           const BigU RH = hostbig::shl(BigU(1), (size_t)LB * H);
           sk->c_rh_p2 = sk->mp2.add_const(RH % sk->mp2.N);
           sk->c_rh_q2 = sk->mq2.add_const(RH % sk->mq2.N);
+          auto pair_const = [&](ModCtx& m2, const BigU& pr, const BigU& v) {     // digits of v mod prime^2 as [d0 | d1]
+            BigU d1, d0;
+            hostbig::divmod(v % m2.N, pr, d1, d0);
+            return m2.add_const(d0 + hostbig::shl(d1, (size_t)LB * H));
+          };
+          {
+            BigU rp = RH % sk->mp2.N, rq = RH % sk->mq2.N, ap = rp, aq = rq;     // R_H^1
+            sk->c_onep_p2 = pair_const(sk->mp2, p, ap);
+            sk->c_onep_q2 = pair_const(sk->mq2, q, aq);
+            for (int k2 = 0; k2 < 4; ++k2) {
+              ap = hostbig::mulmod(ap, rp, sk->mp2.N);                            // R_H^(k2+2)
+              aq = hostbig::mulmod(aq, rq, sk->mq2.N);
+              sk->c_pk_p2[k2] = pair_const(sk->mp2, p, ap);
+              sk->c_pk_q2[k2] = pair_const(sk->mq2, q, aq);
+            }
+          }
           sk->mp2.upload();
           sk->mq2.upload();
           sk->has_pair = true;
@@ -1287,8 +1305,9 @@ uint32_t* decrypt1_crt(const pgpu_seckey* sk, const uint32_t* c_limbs, size_t nb
   const ModCtx &mp = sk->mp, &mq = sk->mq, &mp2 = sk->mp2, &mq2 = sk->mq2;
   const int W2 = mp2.WT, W1 = mp.WT;
   const size_t S2 = (size_t)W2 * nb, S1 = (size_t)W1 * nb;
-  // big VM memory: slots 0,1 = c (lo, hi); P: tmp 2, out 3, table 4..35; Q: tmp 36, out 37, table 38..69
-  uint32_t* mem = ctx->ws_t<uint32_t>(S2 * 70);
+  // big VM memory: slots 0,1 = c (lo, hi); P: tmp 2, out 3, table 4..35; Q: tmp 36, out 37, table 38..69; 70..73 chunks of c
+  uint32_t* mem = ctx->ws_t<uint32_t>(S2 * 74);
+  bool pair_done = false;
   HIPCHK(hipMemcpyAsync(mem, c_limbs, S2 * 2 * 4, hipMemcpyDeviceToDevice, ctx->stream));
   uint32_t *up = mem + 3 * S2, *uq = mem + 37 * S2;
   // (the two-lane kernel needs 2 lanes x 2 halves per ciphertext to fill the chip; below that the finer slicings win)
@@ -1299,50 +1318,37 @@ uint32_t* decrypt1_crt(const pgpu_seckey* sk, const uint32_t* c_limbs, size_t nb
   // (a two-lane digit pass is 2 H^2 multiplies per lane: shorter than any slicing of the 2H-limb kernels for H <= 55, so it
   // also wins when the batch is latency-bound; for H = 74 the 4-lane slicing has the same length and fills the chip better)
   if (sk->has_pair && ctx->use_asm && ctx->use_pair && (pair_lanes_now == 1 || W1 <= 55 || nb * 4 >= lanes_target)) {
-    // The ladder runs on the pair kernel (residues mod p^2 as two base-p digits: 58 % of the multiplies of a squaring).
-    // (1) X = c R_H mod p^2 on the ordinary kernel, canonical
+    // The whole ladder runs on the pair kernel (residues mod p^2 as two base-p digits: 58 % of the multiplies of a
+    // squaring), entry and exit included:
+    //   entry  c = sum_k c_k R_H^k (four H-limb chunks): the pair (c_k, 0) times the pair form of R_H^(k+2) is c_k R_H^k in
+    //          pair form; the lazy sums are normalised by a product with the pair form of 1;
+    //   exit   one product with the pair (1, 0): digit 0 becomes F mod p (= 1 for every unit) and digit 1 becomes
+    //          (F1 + Cadj - m'') R^-1 = (F - 1)/p mod p = L_p -- Paillier's L function falls out of the last Montgomery step.
+    pair_done = true;
+    const uint32_t CH = 70;
+    for (int k2 = 0; k2 < 4; ++k2)
+      launch_copy_limbs(c_limbs, k2 * W1, W1, mem + (size_t)(CH + k2) * S2, W2, nb, ctx->stream);
     {
-      Prog a, b;
-      emit_to_mont(a, 0, 1, 2);  a.op(VM_MULC, (uint32_t)sk->c_rh_p2); a.op(VM_STORE, 3);  a.end();
-      emit_to_mont(b, 0, 1, 36); b.op(VM_MULC, (uint32_t)sk->c_rh_q2); b.op(VM_STORE, 37); b.end();
-      SegSpec sa{&mp2, &a, mem, nullptr}, sb{&mq2, &b, mem, nullptr};
-      run_vm(ctx, nb, sa, &sb, false);
-      launch_canon(up, mp2.d_nmod, W2, nb, ctx->stream);
-      launch_canon(uq, mq2.d_nmod, W2, nb, ctx->stream);
-    }
-    // (2) digits X = X0 + X1 prime  ->  slots 2 / 36 (X0 in limbs 0..H-1, X1 in limbs H..2H-1)
-    {
-      uint32_t* x0 = ctx->ws_t<uint32_t>(S1 * 2);
-      uint32_t* tbx = ctx->ws_t<uint32_t>(S2);
-      reduce_mod(ctx, mp, up, W2, x0, nb);
-      reduce_mod(ctx, mq, uq, W2, x0 + S1, nb);
-      uint32_t *dp = mem + 2 * S2, *dq = mem + 36 * S2;
-      launch_div_exact(up, W2, 0, x0, W1, tbx, sk->pinv2k.d, mp.d_nmod, W1, dp + S1, W1, nb, count, nullptr, 0, ctx->stream);
-      launch_div_exact(uq, W2, 0, x0 + S1, W1, tbx, sk->qinv2k.d, mq.d_nmod, W1, dq + S1, W1, nb, count, nullptr, 0, ctx->stream);
-      HIPCHK(hipMemcpyAsync(dp, x0, S1 * 4, hipMemcpyDeviceToDevice, ctx->stream));
-      HIPCHK(hipMemcpyAsync(dq, x0 + S1, S1 * 4, hipMemcpyDeviceToDevice, ctx->stream));
-    }
-    // (3) the ladder: x^(prime - 1) in pair form
-    {
+      auto entry = [&](Prog& pr, const int* ck, int onep, uint32_t acc) {
+        pr.op(VM_LOAD, CH); pr.op(VM_MULC, (uint32_t)ck[0]); pr.op(VM_STORE, acc);
+        for (uint32_t k2 = 1; k2 < 4; ++k2) {
+          pr.op(VM_LOAD, CH + k2); pr.op(VM_MULC, (uint32_t)ck[k2]); pr.op(VM_ADD, acc);
+          pr.op(VM_MULC, (uint32_t)onep); pr.op(VM_STORE, acc);
+        }
+      };
       Prog pp, pq;
+      entry(pp, sk->c_pk_p2, sk->c_onep_p2, 2);
       emit_modexp_shared(pp, sk->p - BigU(1), 2, NO_SLOT, 2, 3, 4, NO_SLOT, true, true);
+      pp.op(VM_LOAD, 3); pp.op(VM_MULC, C_ONE); pp.op(VM_STORE, 3);
       pp.end();
+      entry(pq, sk->c_pk_q2, sk->c_onep_q2, 36);
       emit_modexp_shared(pq, sk->q - BigU(1), 36, NO_SLOT, 36, 37, 38, NO_SLOT, true, true);
+      pq.op(VM_LOAD, 37); pq.op(VM_MULC, C_ONE); pq.op(VM_STORE, 37);
       pq.end();
       SegSpec sp{&mp2, &pp, mem, nullptr}, sq{&mq2, &pq, mem, nullptr};
       sp.pair = sk->pair_p.d; sp.pair_n0inv = mp.n0inv; sp.pair_h = W1; sp.pair_lanes = pair_lanes_now;
       sq.pair = sk->pair_q.d; sq.pair_n0inv = mq.n0inv; sq.pair_h = W1; sq.pair_lanes = pair_lanes_now;
       run_vm(ctx, nb, sp, &sq, true);
-    }
-    // (4) back: F~ = F0 + F1 prime (an integer = F R_H mod p^2, lazy), then F = F~ R_H^-1 on the ordinary kernel
-    {
-      launch_mul_const_add(up + S1, W1, sk->p_limbs.d, W1, up, W1, 0, mem + 2 * S2, W2, nb, ctx->stream);
-      launch_mul_const_add(uq + S1, W1, sk->q_limbs1.d, W1, uq, W1, 0, mem + 36 * S2, W2, nb, ctx->stream);
-      Prog a, b;
-      a.op(VM_LOAD, 2);  a.op(VM_MULC, (uint32_t)sk->c_rh_p2); a.op(VM_STORE, 3);  a.end();
-      b.op(VM_LOAD, 36); b.op(VM_MULC, (uint32_t)sk->c_rh_q2); b.op(VM_STORE, 37); b.end();
-      SegSpec sa{&mp2, &a, mem, nullptr}, sb{&mq2, &b, mem, nullptr};
-      run_vm(ctx, nb, sa, &sb, false);
     }
   } else {
     Prog pp, pq;
@@ -1353,15 +1359,25 @@ uint32_t* decrypt1_crt(const pgpu_seckey* sk, const uint32_t* c_limbs, size_t nb
     SegSpec sp{&mp2, &pp, mem, nullptr}, sq{&mq2, &pq, mem, nullptr};
     run_vm(ctx, nb, sp, &sq, true);
   }
-  launch_canon(up, mp2.d_nmod, W2, nb, ctx->stream);
-  launch_canon(uq, mq2.d_nmod, W2, nb, ctx->stream);
   // small memory: slots 0 Lp, 1 Lq, 2 mp, 3 mq, 4 B, 5 A, 6 h
   uint32_t* m1 = ctx->ws_t<uint32_t>(S1 * 7);
-  uint32_t* tb = ctx->ws_t<uint32_t>(S2);
-  launch_div_exact(up, W2, 1, nullptr, 0, tb, sk->pinv2k.d, mp.d_nmod, W1, m1 + 0 * S1, W1, nb, count, d_status,
-                   PGPU_LANE_NONUNIT, ctx->stream);
-  launch_div_exact(uq, W2, 1, nullptr, 0, tb, sk->qinv2k.d, mq.d_nmod, W1, m1 + 1 * S1, W1, nb, count, d_status,
-                   PGPU_LANE_NONUNIT, ctx->stream);
+  if (pair_done) {
+    // out slots hold (F mod prime | L): a unit has first digit exactly 1; L is lazy below 2 prime
+    launch_flag_not_one(up, W1, nb, count, d_status, PGPU_LANE_NONUNIT, ctx->stream);
+    launch_flag_not_one(uq, W1, nb, count, d_status, PGPU_LANE_NONUNIT, ctx->stream);
+    launch_canon(up + S1, mp.d_nmod, W1, nb, ctx->stream);
+    launch_canon(uq + S1, mq.d_nmod, W1, nb, ctx->stream);
+    HIPCHK(hipMemcpyAsync(m1 + 0 * S1, up + S1, S1 * 4, hipMemcpyDeviceToDevice, ctx->stream));
+    HIPCHK(hipMemcpyAsync(m1 + 1 * S1, uq + S1, S1 * 4, hipMemcpyDeviceToDevice, ctx->stream));
+  } else {
+    launch_canon(up, mp2.d_nmod, W2, nb, ctx->stream);
+    launch_canon(uq, mq2.d_nmod, W2, nb, ctx->stream);
+    uint32_t* tb = ctx->ws_t<uint32_t>(S2);
+    launch_div_exact(up, W2, 1, nullptr, 0, tb, sk->pinv2k.d, mp.d_nmod, W1, m1 + 0 * S1, W1, nb, count, d_status,
+                     PGPU_LANE_NONUNIT, ctx->stream);
+    launch_div_exact(uq, W2, 1, nullptr, 0, tb, sk->qinv2k.d, mq.d_nmod, W1, m1 + 1 * S1, W1, nb, count, d_status,
+                     PGPU_LANE_NONUNIT, ctx->stream);
+  }
   Prog a, b, c;
   a.op(VM_LOAD, 0); a.op(VM_MULC, (uint32_t)sk->c_hpR); a.op(VM_STORE, 2); a.end();   // m_p = L_p * h_p mod p
   b.op(VM_LOAD, 1); b.op(VM_MULC, (uint32_t)sk->c_hqR); b.op(VM_STORE, 3); b.end();   // m_q = L_q * h_q mod q

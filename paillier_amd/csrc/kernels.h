@@ -49,6 +49,7 @@ void launch_mul_const_add(const uint32_t* a, int wa, const uint32_t* bconst, int
 void launch_div_exact(const uint32_t* u, int wu, uint32_t sub_small, const uint32_t* subv, int wsub, uint32_t* tbuf,
                       const uint32_t* dinv, const uint32_t* d, int wd, uint32_t* l, int wl, size_t nb, size_t count,
                       int32_t* status, int32_t flag, hipStream_t st);
+void launch_flag_not_one(const uint32_t* x, int w, size_t nb, size_t count, int32_t* status, int32_t flag, hipStream_t st);
 void launch_is_zero(const uint32_t* x, int w, size_t nb, int32_t* flags, hipStream_t st);
 void launch_select_const(const int32_t* flags, const uint32_t* c, uint32_t* x, int w, size_t nb, hipStream_t st);
 void launch_sub_mod(const uint32_t* a, const uint32_t* b, const uint32_t* q, uint32_t* out, int w, size_t nb, hipStream_t st);

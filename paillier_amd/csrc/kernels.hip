@@ -443,6 +443,17 @@ __global__ void k_is_zero(const uint32_t* __restrict__ x, int w, size_t nb, int3
   flags[g] = o == 0;
 }
 
+// status[g] |= flag where the w-limb number x is not exactly 1 (canonical limbs).  Used on the first digit of
+// x^(p-1) in pair form: it is 1 for every unit and 0 or p for a multiple of p.
+__global__ void k_flag_not_one(const uint32_t* __restrict__ x, int w, size_t nb, size_t count, int32_t* __restrict__ status,
+                               int32_t flag) {
+  size_t g = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (g >= count) return;
+  uint32_t o = x[g] ^ 1u;
+  for (int l = 1; l < w; ++l) o |= x[(size_t)l * nb + g];
+  if (o) status[g] |= flag;
+}
+
 // x <- c (uniform constant, w limbs) on the lanes whose flag is set
 __global__ void k_select_const(const int32_t* __restrict__ flags, const uint32_t* __restrict__ c, uint32_t* __restrict__ x,
                                int w, size_t nb) {
@@ -705,6 +716,9 @@ void launch_div_exact(const uint32_t* u, int wu, uint32_t sub_small, const uint3
   }
   hipLaunchKernelGGL(k_div_exact, HELPER_GRID(nb), 0, st, u, wu, sub_small, subv, wsub, tbuf, dinv, d, wd, l, wl, nb, count,
                      status, flag);
+}
+void launch_flag_not_one(const uint32_t* x, int w, size_t nb, size_t count, int32_t* status, int32_t flag, hipStream_t st) {
+  hipLaunchKernelGGL(k_flag_not_one, HELPER_GRID(nb), 0, st, x, w, nb, count, status, flag);
 }
 void launch_is_zero(const uint32_t* x, int w, size_t nb, int32_t* flags, hipStream_t st) {
   hipLaunchKernelGGL(k_is_zero, HELPER_GRID(nb), 0, st, x, w, nb, flags);
