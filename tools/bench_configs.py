@@ -14,7 +14,7 @@ from oracle import paillier_oracle as po
 K = json.load(open(os.path.join(ROOT, "tests/golden/keys.json")))
 dev = torch.device("cuda", 0)
 ctx = pa.Context(0, torch.cuda.current_stream().cuda_stream)
-which = sys.argv[1:] or ["encrypt2048", "altencrypt2048", "decrypt3072", "threshold2048", "ddleq2048"]
+which = sys.argv[1:] or ["encrypt2048", "altencrypt2048", "decrypt3072", "threshold2048", "zkp2048", "ddleq2048"]
 
 
 def rand_below(n, count, nbytes, rng):
@@ -133,6 +133,34 @@ if "threshold2048" in which:  # BASELINE config 4, single-GPU part: 3 x PartialD
     print(json.dumps({"config": "Threshold (t=3,l=5) 3 x PartialDecrypt + Combine, 2048-bit, 16384 ciphertexts, servers {1,3,5}",
                       "value": B / dt, "unit": "threshold decryptions/s", "ms_per_batch": dt * 1e3,
                       "partial_decrypt_per_s": B / t_pd, "combine_per_s": B / t_cb, "parity": "16384-lane round trip"}), flush=True)
+
+if "zkp2048" in which:   # PartialDecryptionWithZKP (r supplied) and VerifyProof (thresholdkey.go:225-311), device-resident, raw buffers
+    import ctypes as C
+    k = K["threshold"]["2048"]; n = int(k["n"], 16); shares = [int(s, 16) for s in k["shares"]]
+    v, vks = int(k["v"], 16), [int(x, 16) for x in k["vks"]]
+    tk = pa.ThresholdPublicKey(ctx, n, total=5, threshold=3); B = 16384; rng = np.random.default_rng(8); sid = 2
+    m_h = rand_below(n, B, 256, rng); r_h = rand_below(n, B, 256, rng); r_h[:, -1] |= 1
+    c_d = torch.zeros((B, 512), dtype=torch.uint8, device=dev)
+    tk.encrypt_with_r_raw(B, torch.from_numpy(m_h).to(dev).data_ptr(), 256, torch.from_numpy(r_h).to(dev).data_ptr(), 256, c_d.data_ptr(), 512, MEM_DEVICE)
+    c_h = c_d.cpu().numpy(); rz = rand_below(n * n, B, 512, rng)
+    dec = np.zeros((B, 512), np.uint8); eo = np.zeros((B, 32), np.uint8); zb = 512 + 48; zo = np.zeros((B, zb), np.uint8)
+    from paillier_amd.api import _be, _ptr, MEM_HOST
+    sb, vb, ib = _be(shares[sid - 1]), _be(v), _be(vks[sid - 1])
+    def prove():
+        rc = ctx.lib.pgpu_share_zkp_prove(tk.h, 5, sb, len(sb), vb, len(vb), B, _ptr(c_h), 512, _ptr(rz), 512, _ptr(dec), 512, _ptr(eo), _ptr(zo), zb, MEM_HOST)
+        assert rc == 0, ctx.lib.pgpu_last_error()
+    dtp = timed(prove, reps=2)
+    ok = np.zeros(B, np.int32)
+    def verify():
+        rc = ctx.lib.pgpu_share_zkp_verify(tk.h, vb, len(vb), ib, len(ib), B, _ptr(c_h), 512, _ptr(dec), 512, _ptr(eo), _ptr(zo), zb, _ptr(ok), MEM_HOST)
+        assert rc == 0, ctx.lib.pgpu_last_error()
+    dtv = timed(verify, reps=2)
+    assert ok.all(), "a valid share proof was rejected"
+    tsk = po.ThresholdSecretKey(N=n, G=n + 1, TotalNumberOfDecryptionServers=5, Threshold=3, VerificationKey=v, VerificationKeys=vks, ID=sid, Share=shares[sid - 1])
+    ref = po.partial_decryption_with_zkp_r(tsk, be_to_ints(c_h[:1])[0], be_to_ints(rz[:1])[0])
+    assert (be_to_ints(dec[:1])[0], be_to_ints(eo[:1])[0], be_to_ints(zo[:1])[0]) == (ref.Decryption, ref.E, ref.Z)
+    print(json.dumps({"config": "Share-decryption ZKP, 2048-bit, 16384 ciphertexts, one server, host buffers", "prove_per_s": B / dtp,
+                      "verify_per_s": B / dtv, "parity": "all 16384 proofs verify; proof 0 vs oracle"}), flush=True)
 
 if "ddleq2048" in which:  # BASELINE config 5 (per-instance throughput, secpar = 1)
     n, lam = key(2048)
