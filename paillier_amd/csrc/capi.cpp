@@ -2178,8 +2178,11 @@ int pgpu_ddleq_verify(const pgpu_pubkey* pk, size_t batch, const uint8_t* ct1, c
     if (wc != W3) api_throw(PGPU_ERR_INVALID, "ciphertext stride must be the byte length of n^3");
     // en = E^n mod n^2 ; fn2 = F^(n^2) mod n^3                                   (ddleq.go:143-144)
     ModexpPlan pe = modexp_alloc(ctx, mn2, nb, 32);
-    unpack_operand(ctx, e, e_stride, std::min(e_stride, 2 * mn2.nbytes), batch, mem, pe.in(), 2 * W2, nb);
-    modexp_shared_run(ctx, mn2, pe, pk->N, true, false, true);
+    // E is a residue modulo n^2 in every honest proof (ddleq.go:94-99); a wider field (up to twice the width) is reduced
+    // by the ordinary kernel's two-chunk entry, the usual width takes the pair-kernel path
+    const bool ewide = e_stride * 8 > (size_t)LB * W2;
+    unpack_operand(ctx, e, e_stride, std::min(e_stride, 2 * mn2.nbytes), batch, mem, pe.in(), ewide ? 2 * W2 : W2, nb);
+    modexp_shared_run(ctx, mn2, pe, pk->N, ewide, false, true);
     // check = chalBit ? ct2 : ct1 ; check^en * F^(n^2) mod n^3 == alpha           (ddleq.go:138-152)
     // one interleaved ladder: the squarings of check^en and of F^(n^2) are shared (emit_modexp_dual)
     if (f_stride * 8 > (size_t)LB * W3 + 7) api_throw(PGPU_ERR_INVALID, "F wider than n^3");
