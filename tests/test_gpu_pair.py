@@ -103,7 +103,9 @@ def test_pair_ladder_is_a_modexp(ctx):
         assert got == pow(y, e, q2), g
 
 
-def test_decrypt_does_not_depend_on_the_pair_switch(ctx):
+@pytest.mark.parametrize("one_lane", [0, 1])
+def test_decrypt_does_not_depend_on_the_pair_switch(ctx, one_lane):
+    """one_lane = 1 forces the one-lane kernel (GenP, what a full batch runs); 0 leaves the small-batch choice (two lanes)."""
     import paillier_amd as pa
     from oracle import paillier_oracle as po
     k = json.load(open(os.path.join(G, "keys.json")))["paillier"]["2048"]
@@ -115,13 +117,17 @@ def test_decrypt_does_not_depend_on_the_pair_switch(ctx):
     rng = random.Random(22)
     cts = [rng.randrange(n * n) for _ in range(700)] + [0, 1, p, q, n, n * n - 1, p * p, 5 * q]
     try:
+        ctx.set_flag("lanes_wanted", 1 if one_lane else 0)
         ctx.set_flag("pair", 1)
-        with_pair = sk.DecryptBatch(cts)
+        with_pair, st = sk.DecryptBatch(cts, return_status=True)
         ctx.set_flag("pair", 0)
-        without = sk.DecryptBatch(cts)
+        without, st0 = sk.DecryptBatch(cts, return_status=True)
     finally:
         ctx.set_flag("pair", 1)
-    assert with_pair == without
+        ctx.set_flag("lanes_wanted", 0)
+    assert with_pair == without and list(st) == list(st0)
+    from math import gcd
+    assert [bool(v & pa.LANE_NONUNIT) for v in st] == [gcd(c, n) != 1 for c in cts]
     assert with_pair[:40] + with_pair[-8:] == [po.decrypt(sk_o, po.Ciphertext(c)) for c in cts[:40] + cts[-8:]]
 
 
