@@ -1871,7 +1871,9 @@ class GenQ(Gen):
         # pass 2: lane 0: t = a0 b0 R^-1; lane 1: r1 = (a1 b0 + Cadj - m) R^-1
         self.passes("m2", 0, True, False)
         self.normalize_to(lambda j: e(f"v_and_b32 {self.X(j)}, {M}, {self.Tlo(j)}"))
-        # lane 1: c1 = r1 + r2 (limbs < 2^29: a lazy multiplicand)
+        # lane 1: c1 = r1 + r2, limbs made canonical again (the top limb keeps the excess: c1 < 4n).  A lazy 29-bit limb would
+        # be harmless for typical values, but a doubled multiplier times a 29-bit multiplicand over 74 rows can exceed the 64-bit
+        # column in the worst case; 28-bit limbs keep every column below 223 product units.
         e("s_mov_b32 s98, 0xaaaaaaaa")
         e("s_mov_b32 exec_lo, s98")
         e("s_mov_b32 exec_hi, s98")
@@ -1880,7 +1882,13 @@ class GenQ(Gen):
             e(f"ds_read_b32 {St[j]}, v{g.v_t4} offset:{j * row}")
         e("s_waitcnt lgkmcnt(0)")
         for j in range(H):
-            e(f"v_add_u32 {self.X(j)}, {self.X(j)}, {St[j]}")
+            if j:
+                e(f"v_add3_u32 {self.X(j)}, {self.X(j)}, {St[j]}, v{g.v_t1}")
+            else:
+                e(f"v_add_u32 {self.X(j)}, {self.X(j)}, {St[j]}")
+            if j < H - 1:
+                e(f"v_lshrrev_b32 v{g.v_t1}, {LB}, {self.X(j)}")
+                e(f"v_and_b32 {self.X(j)}, {M}, {self.X(j)}")
         e("s_mov_b64 exec, s[96:97]")
         e("s_branch L_next")
 
@@ -1913,8 +1921,8 @@ class GenQ4(Gen):
         self.sq_rows_k = False
         # extra registers after the base map
         e = self.n_vgpr
-        self.v_sh, self.v_l2mask = e, e + 1
-        e += 2
+        self.v_sh, self.v_l2mask, self.v_l3mask = e, e + 1, e + 2
+        e += 3
         e = (e + 1) // 2 * 2
         self.v_d = e                    # pair (adjustment, 0)
         e += 2
@@ -1987,6 +1995,9 @@ class GenQ4(Gen):
         e(f"v_cmp_eq_u32 vcc, 2, v{g.v_t1}")
         e("s_nop 1")
         e(f"v_cndmask_b32 v{g.v_l2mask}, 0, -1, vcc")
+        e(f"v_cmp_eq_u32 vcc, 3, v{g.v_t1}")
+        e("s_nop 1")
+        e(f"v_cndmask_b32 v{g.v_l3mask}, 0, -1, vcc")
         # modulus n (2 slices) -> LDS -> this lane's slice in VGPRs
         e(f"v_lshlrev_b32 v{g.v_t3}, 2, v0")
         e(f"v_cmp_gt_u32 vcc, {WL}, v0")
@@ -2119,9 +2130,29 @@ class GenQ4(Gen):
         for j in range(WL):
             e(f"ds_read_b32 {St[j]}, v{g.v_t4} offset:{j * row}")
         e("s_waitcnt lgkmcnt(0)")
+        # c1 = r1 + r2 with the limbs brought back below 2^28 + 4 (carry-save: x_j = (s_j & M) + (s_{j-1} >> 28); the carry out of a
+        # slice's top limb enters limb 0 of the next slice by DPP; the digit's top limb keeps its excess) -- see GenQ.montmul
+        M = hex(MASK)
         for j in range(WL):
             e(f"v_add_u32 {self.X(j)}, {self.X(j)}, {St[j]}")
+        # carries, from the top down so that every s_{j-1} is still unmodified when it is read
+        e(f"v_lshrrev_b32 v{g.v_t2}, {LB}, {self.X(WL - 1)}")                   # carry out of this slice's top limb
+        e(f"v_and_b32 v{g.v_t2}, v{g.v_t2}, v{g.v_isfirst}")                    # only slice 0 passes it on ...
+        e(f"v_not_b32 v{g.v_t3}, v{g.v_isfirst}")
+        e(f"v_or_b32 v{g.v_t3}, {M}, v{g.v_t3}")                                # ... and only slice 0 masks its top limb
+        for j in range(WL - 1, 0, -1):
+            e(f"v_lshrrev_b32 v{g.v_t1}, {LB}, {self.X(j - 1)}")
+            if j == WL - 1:
+                e(f"v_and_b32 {self.X(j)}, {self.X(j)}, v{g.v_t3}")
+            else:
+                e(f"v_and_b32 {self.X(j)}, {M}, {self.X(j)}")
+            e(f"v_add_u32 {self.X(j)}, {self.X(j)}, v{g.v_t1}")
+        e(f"v_and_b32 {self.X(0)}, {M}, {self.X(0)}")
         e("s_mov_b64 exec, s[96:97]")
+        e("s_nop 1")
+        e(f"v_mov_b32_dpp v{g.v_t1}, v{g.v_t2} quad_perm:[0,0,2,2] row_mask:0xf bank_mask:0xf")   # lane 3 <- lane 2 (and 1 <- 0: zero)
+        e(f"v_and_b32 v{g.v_t1}, v{g.v_t1}, v{g.v_l3mask}")
+        e(f"v_add_u32 {self.X(0)}, {self.X(0)}, v{g.v_t1}")
         e("s_branch L_next")
 
     def generate(self):
