@@ -157,7 +157,9 @@ def main():
         "kernel_ms_per_launch": vm_ms_avg,
         "alg_mad28_per_decrypt": alg_mads,
         "survey_unit": {"alg_mul32_per_decrypt_crt": alg_mul32, "alg_mul32_per_decrypt_noncrt": alg_mul32_noncrt,
-                        "rate_Tmul32_per_s": alg_mul32 * B / (vm_ms_avg * 1e-3) / 1e12},
+                        "rate_Tmul32_per_s": alg_mul32 * B / (vm_ms_avg * 1e-3) / 1e12,
+                        "frac_of_issue_peak": alg_mul32 * B / (vm_ms_avg * 1e-3) / PEAK_MAD_PER_S,
+                        "note": "above 1: the engine's algorithm needs fewer multiplies than the schoolbook count of SURVEY 8(d)"},
         # HBM bytes per launch from the PMC passes of this same command (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate
         # runs, 2 x FETCH_SIZE gfx950 correction): profiles/r01_bench_pmc_summary.txt.  It is the per-lane window table
         # (written once, one entry read per window product), not re-reads of the inputs.  Only known for the default workload.
