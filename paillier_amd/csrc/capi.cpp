@@ -1730,8 +1730,9 @@ int pgpu_decrypt(const pgpu_seckey* sk, int level, size_t batch, const uint8_t* 
     // CRT consumes c as two chunks of WT(p^2) limbs (c = lo + hi * R_p); WT(n^2) <= 2 WT(p^2) always, with equality for
     // real key sizes and strict inequality for toy keys where every modulus gets the minimum shape: zero-extend.
     const int WG = pk->mn2.WT;
-    const int WC = crt ? 2 * sk->mp2.WT : WG;
-    if (WC < WG) api_throw(PGPU_ERR_UNSUPPORTED, "CRT and generic layouts disagree");
+    // (and for 4096-bit keys n^2 takes a wider kernel shape than two chunks of p^2: the unpacked array then has the
+    // generic width, CRT reads its first 2 WT(p^2) limb rows -- everything above bit 8192 is zero)
+    const int WC = crt ? std::max(2 * sk->mp2.WT, WG) : WG;
     uint32_t* cl = ctx->ws_t<uint32_t>((size_t)WC * nb);
     // the ciphertext is the last cbytes of each element (values >= n^2 are reduced implicitly)
     unpack_operand(ctx, c, c_stride, cbytes, batch, mem, cl, WC, nb);

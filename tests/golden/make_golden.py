@@ -20,7 +20,26 @@ def hx(v):
     return format(int(v), "x")
 
 
+def extra_4096():
+    """A 4096-bit key (2048-bit primes: 74-limb CRT halves, the two-lane pair kernel's widest use) with a few Decrypt
+    vectors, in a file of its own so that the older fixtures stay byte-identical."""
+    sk, p, q = po.keygen_seeded(4096, 4096)
+    rng = random.Random(4196)
+    n, n2 = sk.N, sk.N ** 2
+    ms = [0, 1, n - 1] + [rng.randrange(n) for _ in range(5)]
+    rs = [po.rand_unit(n, rng) for _ in ms]
+    cts = [po.encrypt_with_r(sk, m, r).C for m, r in zip(ms, rs)]
+    weird = [0, p, 7 * q, n, n2 - 1] + [rng.randrange(n2) for _ in range(3)]
+    out = {"p": hx(p), "q": hx(q), "n": hx(n), "lambda": hx(sk.Lambda), "m": [hx(m) for m in ms], "r": [hx(r) for r in rs],
+           "c": [hx(c) for c in cts], "weird_c": [hx(c) for c in weird],
+           "weird_m": [hx(po.decrypt(sk, po.Ciphertext(c))) for c in weird]}
+    with open(os.path.join(HERE, "key4096.json"), "w") as f:
+        json.dump(out, f, indent=0, sort_keys=True)
+
+
 def main():
+    if len(sys.argv) > 1 and sys.argv[1] == "4096":
+        return extra_4096()
     keys = {}
     for bits in (1024, 2048, 3072):
         sk, p, q = po.keygen_seeded(bits, bits)

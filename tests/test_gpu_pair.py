@@ -243,3 +243,33 @@ def test_const_mult_per_ciphertext_on_the_pair_kernels(ctx, force_two_lanes):
         ctx.set_flag("pair", 1)
         ctx.set_flag("lanes_wanted", 0)
     assert got == ref == [pow(c, kk, n2) for c, kk in zip(cs, ks)]
+
+
+@pytest.mark.parametrize("force_pair", [0, 1])
+def test_decrypt_4096_bit_key(ctx, force_pair):
+    """4096-bit keys: CRT halves modulo p^2, q^2 with 74-limb primes (148-limb moduli).  Golden vectors from the oracle
+    (tests/golden/key4096.json, written by make_golden.py 4096); with force_pair the ladders run on the two-lane pair kernel
+    even for this small batch."""
+    import paillier_amd as pa
+    k = json.load(open(os.path.join(G, "key4096.json")))
+    p, q = int(k["p"], 16), int(k["q"], 16)
+    n, lam = p * q, int(k["lambda"], 16)
+    pk = pa.PublicKey(ctx, n, n + 1)
+    sk = pa.SecretKey(ctx, pk, lam)
+    assert sk.has_crt
+    ms, rs, cs = ([int(x, 16) for x in k[key]] for key in ("m", "r", "c"))
+    wc, wm = ([int(x, 16) for x in k[key]] for key in ("weird_c", "weird_m"))
+    try:
+        ctx.set_flag("lanes_wanted", 1 if force_pair else 0)
+        assert pk.EncryptWithRBatch(ms, rs) == cs
+        assert sk.DecryptBatch(cs) == ms
+        got, st = sk.DecryptBatch(wc, return_status=True)
+        assert got == wm
+        from math import gcd
+        assert [bool(v & pa.LANE_NONUNIT) for v in st] == [gcd(c, n) != 1 for c in wc]
+        rng = random.Random(26)
+        many = [rng.randrange(n * n) for _ in range(200)]
+        a = sk.DecryptBatch(many)
+        assert a == sk.DecryptBatch(many, flags=pa.DECRYPT_NO_CRT)
+    finally:
+        ctx.set_flag("lanes_wanted", 0)
