@@ -30,3 +30,18 @@ def test_modexp_cross():
     bases = [rng.randrange(n) for _ in range(5)] + [0, 1]
     for e in (0, 1, rng.getrandbits(700)):
         assert go.modexp_batch(n, e, bases) == [po.gmp_exp(b, e, n) for b in bases]
+
+
+def test_key4096_vectors_against_libgmp():
+    """tests/golden/key4096.json was written by the Python oracle; libgmp (the reference's own backend) must reproduce its
+    ciphertexts and plaintexts for the units (for non-units libgmp's mpz_invert-free path is the same formula: compare too)."""
+    import json
+    import os
+    k = json.load(open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "key4096.json")))
+    n, lam = int(k["n"], 16), int(k["lambda"], 16)
+    assert n == int(k["p"], 16) * int(k["q"], 16) and n.bit_length() == 4096
+    ms, rs, cs = ([int(x, 16) for x in k[key]] for key in ("m", "r", "c"))
+    assert go.encrypt_batch(n, n + 1, ms, rs) == cs
+    assert go.decrypt_batch(n, lam, cs) == ms
+    wc, wm = ([int(x, 16) for x in k[key]] for key in ("weird_c", "weird_m"))
+    assert go.decrypt_batch(n, lam, wc) == wm
