@@ -148,7 +148,7 @@ struct ModCtx {
   size_t d_consts_cap = 0;
 
   static bool pick_shape(size_t bits, int& wl, int& k) {
-    struct S { int wl, k; } shapes[] = {{37, 1}, {55, 1}, {74, 1}, {55, 2}, {74, 2}, {55, 4}, {83, 4}};
+    struct S { int wl, k; } shapes[] = {{37, 1}, {55, 1}, {74, 1}, {55, 2}, {74, 2}, {55, 4}, {74, 4}, {83, 4}};
     for (auto s : shapes)
       if (bits + 3 <= (size_t)LB * s.wl * s.k) { wl = s.wl; k = s.k; return true; }
     return false;

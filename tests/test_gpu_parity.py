@@ -106,7 +106,7 @@ def test_add_constmult_1024(ctx, key1024):
     assert pk.ConstMultBatch(a[:40], ks[:40]) == [po.const_mult(sk_o, po.Ciphertext(x), kk).C for x, kk in zip(a, ks[:40])]
 
 
-@pytest.mark.parametrize("bits", [1024, 1536, 2048, 3072, 4096, 6144])
+@pytest.mark.parametrize("bits", [1024, 1536, 2048, 3072, 4096, 6144, 8192])
 def test_asm_kernel_matches_compiler_kernel(ctx, bits):
     """The hand-scheduled assembly VM kernel and the hipcc-generated one must agree bit for bit (and with Python)."""
     import paillier_amd as pa
