@@ -48,6 +48,8 @@ extern "C" {
 /* per-lane status bits (int32 array, optional) */
 #define PGPU_LANE_OK 0
 #define PGPU_LANE_NONUNIT 1         /* gcd(c, n) != 1: lane was recomputed on the generic path */
+#define PGPU_LANE_NOT_INVERTIBLE 2  /* a ModInverse operand of this lane is not a unit: its result is 0 (mpz_invert leaves
+                                     * the reference's result undefined there); the other lanes are unaffected */
 
 typedef struct pgpu_ctx pgpu_ctx;
 typedef struct pgpu_pubkey pgpu_pubkey;
@@ -117,10 +119,23 @@ int pgpu_add(const pgpu_pubkey* pk, int level, size_t batch, const uint8_t* a, s
              size_t b_stride, uint8_t* out, size_t out_stride, int mem);
 
 /* PublicKey.Sub on two ciphertext vectors (operations.go:32-55 with two operands):
- *   out[i] = a[i] * b[i]^-1 mod n^(s+1).  Returns PGPU_ERR_NOT_INVERTIBLE if some b[i] is not a unit
- * (mpz_invert is undefined there and the reference does not check). */
+ *   out[i] = a[i] * b[i]^-1 mod n^(s+1).
+ * A b[i] that is not a unit has no inverse (mpz_invert leaves the reference's result undefined and the reference does not
+ * check): that lane's result is 0 and status[i] = PGPU_LANE_NOT_INVERTIBLE, every other lane is computed normally.
+ * status: optional host int32[batch]; when it is NULL such a lane makes the call return PGPU_ERR_NOT_INVERTIBLE (after
+ * the outputs have been written). */
 int pgpu_sub(const pgpu_pubkey* pk, int level, size_t batch, const uint8_t* a, size_t a_stride, const uint8_t* b,
-             size_t b_stride, uint8_t* out, size_t out_stride, int mem);
+             size_t b_stride, uint8_t* out, size_t out_stride, int mem, int32_t* status);
+
+/* The variadic forms PublicKey.Add(cts...) / Sub(cts...) (operations.go:11,32), element-wise over a batch: ops[k] is the
+ * buffer of the k-th argument (all with the same stride), n_ops >= 1.
+ *   add: out[i] = prod_k ops[k][i] mod n^(s+1)   (the accumulator starts at 1: a single operand comes back reduced)
+ *   sub: out[i] = ops[0][i] * prod_{k>=1} ops[k][i]^-1 mod n^(s+1); with ONE operand the reference returns cts[0].C
+ *        unreduced (operations.go:34): the bytes are copied through unchanged. */
+int pgpu_add_many(const pgpu_pubkey* pk, int level, int n_ops, size_t batch, const uint8_t* const* ops, size_t stride,
+                  uint8_t* out, size_t out_stride, int mem);
+int pgpu_sub_many(const pgpu_pubkey* pk, int level, int n_ops, size_t batch, const uint8_t* const* ops, size_t stride,
+                  uint8_t* out, size_t out_stride, int mem, int32_t* status);
 
 /* PublicKey.ConstMult (operations.go:58-64): out[i] = c[i]^k mod n^(s+1).
  * k_stride == 0: one shared k of k_len bytes; otherwise k[i] at k + i*k_stride, k_len bytes each. */
@@ -138,10 +153,13 @@ int pgpu_partial_decrypt(const pgpu_pubkey* pk, int total_servers, const uint8_t
  *   m[i] = L( prod_k partials[k][i]^(2 lambda_k) mod n^2 ) * (4 (l!)^2)^-1 mod n
  * ids[k] = server id (1-based) of partials[k]; all partial buffers share `stride`.  Lagrange coefficients follow
  * the reference's sequence of Euclidean divisions; negative exponents use a modular inverse as thresholdkey.go:132-138.
- * PGPU_ERR_THRESHOLD when fewer than `threshold` shares or duplicate ids (thresholdkey.go:77-89). */
+ * PGPU_ERR_THRESHOLD when fewer than `threshold` shares or duplicate ids (thresholdkey.go:77-89).
+ * status (optional host int32[batch]): PGPU_LANE_NOT_INVERTIBLE where a share with a negative coefficient is not a unit
+ * modulo n^2 (its m[i] is then computed with 0 for the missing inverse); NULL turns such a lane into the return code
+ * PGPU_ERR_NOT_INVERTIBLE, as for pgpu_sub. */
 int pgpu_combine_partial_decryptions(const pgpu_pubkey* pk, int total_servers, int threshold, int n_shares, const int* ids,
                                      size_t batch, const uint8_t* const* partials, size_t stride, uint8_t* m,
-                                     size_t m_stride, int mem);
+                                     size_t m_stride, int mem, int32_t* status);
 
 /* ---- share-decryption proofs (thresholdkey.go:225-326) ------------------------------------------------- */
 
@@ -154,7 +172,9 @@ int pgpu_share_zkp_prove(const pgpu_pubkey* pk, int total_servers, const uint8_t
                          size_t z_stride, int mem);
 
 /* PartialDecryptionZKP.VerifyProof for a batch of proofs of ONE server (thresholdkey.go:278-311):
- *   ok[i] = ( E == SHA-256( (c^4)^Z (dec^2)^-E || V^Z v_i^-E || c^4 || dec^2 ) ),  v_i = VerificationKeys[ID-1]. */
+ *   ok[i] = ( E == SHA-256( (c^4)^Z (dec^2)^-E || V^Z v_i^-E || c^4 || dec^2 ) ),  v_i = VerificationKeys[ID-1].
+ * A proof whose Decryption is not a unit modulo n^2 (e.g. 0, or a multiple of a prime factor) is rejected (ok[i] = 0)
+ * without affecting the other proofs of the batch.  z_stride <= byte length of n^2 + 96. */
 int pgpu_share_zkp_verify(const pgpu_pubkey* pk, const uint8_t* vkey_be, size_t vkey_len, const uint8_t* vi_be, size_t vi_len,
                           size_t batch, const uint8_t* c, size_t c_stride, const uint8_t* dec, size_t dec_stride,
                           const uint8_t* e, const uint8_t* z, size_t z_stride, int32_t* ok, int mem);
@@ -197,10 +217,12 @@ int pgpu_modexp(const pgpu_modulus* mod, size_t batch, const uint8_t* base, size
                 const uint8_t* e, size_t e_len, size_t e_stride, uint8_t* out, size_t out_stride, int mem);
 
 /* gmp.Int.ModInverse(x, N) for a batch (Montgomery's trick as a parallel tree: 3 modular products per element and
- * one host inversion per call).  x may be up to twice the modulus width.  PGPU_ERR_NOT_INVERTIBLE if any x[i] is
- * not a unit. */
+ * one host inversion per call).  x may be up to twice the modulus width.  Non-units: out[i] = 0 and
+ * status[i] = PGPU_LANE_NOT_INVERTIBLE (status: optional host int32[batch]; NULL: PGPU_ERR_NOT_INVERTIBLE is returned after
+ * the invertible lanes have been written).  The non-units are found by a per-lane binary GCD on the device, run only when
+ * the single inversion of the tree fails. */
 int pgpu_modinv(const pgpu_modulus* mod, size_t batch, const uint8_t* x, size_t x_stride, size_t x_len, uint8_t* out,
-                size_t out_stride, int mem);
+                size_t out_stride, int mem, int32_t* status);
 
 /* new(gmp.Int).Mod(new(gmp.Int).Mul(a, b), N) for a batch. */
 int pgpu_modmul(const pgpu_modulus* mod, size_t batch, const uint8_t* a, size_t a_stride, size_t a_len,

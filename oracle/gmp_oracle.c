@@ -17,6 +17,7 @@
 #include <gmp.h>
 #include <stddef.h>
 #include <stdint.h>
+#include <stdlib.h>
 #include <string.h>
 #ifdef _OPENMP
 #include <omp.h>
@@ -168,6 +169,276 @@ int oracle_modexp_batch(const uint8_t* mod_be, size_t mod_len, const uint8_t* e_
   }
   mpz_clears(n, e, NULL);
   return used;
+}
+
+
+/* ---- Decrypt with CRT: the second CPU-baseline line BASELINE.md section 3 promises ("the same harness with CRT, so
+ * that the GPU's algorithmic advantage and its hardware advantage are separable").  NOT the reference's algorithm
+ * (paillier.go:292-303 has no CRT; SecretKey does not even keep p, q): the textbook Paillier CRT decryption
+ *   m_p = L_p(c^(p-1) mod p^2) h_p mod p, h_p = ((p-1) q)^-1 mod p, likewise q, Garner.
+ * Equal to decrypt1 for every unit c (tests/test_oracle_cross.py). */
+int oracle_decrypt_crt_batch(const uint8_t* p_be, size_t p_len, const uint8_t* q_be, size_t q_len, size_t batch,
+                             const uint8_t* c, size_t c_stride, uint8_t* m_out, size_t m_stride, int threads) {
+  mpz_t p, q, p2, q2, p1, q1, hp, hq, pinv, t;
+  mpz_inits(p, q, p2, q2, p1, q1, hp, hq, pinv, t, NULL);
+  imp(p, p_be, p_len);
+  imp(q, q_be, q_len);
+  mpz_mul(p2, p, p);
+  mpz_mul(q2, q, q);
+  mpz_sub_ui(p1, p, 1);
+  mpz_sub_ui(q1, q, 1);
+  mpz_mul(t, p1, q); mpz_mod(t, t, p); mpz_invert(hp, t, p);
+  mpz_mul(t, q1, p); mpz_mod(t, t, q); mpz_invert(hq, t, q);
+  mpz_invert(pinv, p, q);
+  int used = 1;
+#ifdef _OPENMP
+  if (threads > 0) omp_set_num_threads(threads);
+#pragma omp parallel
+#endif
+  {
+#ifdef _OPENMP
+#pragma omp single
+    used = omp_get_num_threads();
+#endif
+    mpz_t ci, up, uq, mp, mq, h;
+    mpz_inits(ci, up, uq, mp, mq, h, NULL);
+#ifdef _OPENMP
+#pragma omp for schedule(dynamic, 4)
+#endif
+    for (long i = 0; i < (long)batch; ++i) {
+      imp(ci, c + (size_t)i * c_stride, c_stride);
+      mpz_powm(up, ci, p1, p2);
+      mpz_powm(uq, ci, q1, q2);
+      mpz_sub_ui(up, up, 1); mpz_fdiv_q(up, up, p); mpz_mul(mp, up, hp); mpz_mod(mp, mp, p);
+      mpz_sub_ui(uq, uq, 1); mpz_fdiv_q(uq, uq, q); mpz_mul(mq, uq, hq); mpz_mod(mq, mq, q);
+      mpz_sub(h, mq, mp); mpz_mul(h, h, pinv); mpz_mod(h, h, q);
+      mpz_mul(h, h, p); mpz_add(h, h, mp);
+      expo(h, m_out + (size_t)i * m_stride, m_stride);
+    }
+    mpz_clears(ci, up, uq, mp, mq, h, NULL);
+  }
+  mpz_clears(p, q, p2, q2, p1, q1, hp, hq, pinv, t, NULL);
+  return used;
+}
+
+/* ---- SHA-256 (FIPS 180-4), for the Fiat-Shamir transcripts of random_oracle.go / thresholdkey.go:319-326 ---- */
+typedef struct { uint32_t h[8]; uint8_t buf[64]; size_t fill; uint64_t total; } sha256_t;
+static const uint32_t SK[64] = {
+  0x428a2f98,0x71374491,0xb5c0fbcf,0xe9b5dba5,0x3956c25b,0x59f111f1,0x923f82a4,0xab1c5ed5,0xd807aa98,0x12835b01,0x243185be,
+  0x550c7dc3,0x72be5d74,0x80deb1fe,0x9bdc06a7,0xc19bf174,0xe49b69c1,0xefbe4786,0x0fc19dc6,0x240ca1cc,0x2de92c6f,0x4a7484aa,
+  0x5cb0a9dc,0x76f988da,0x983e5152,0xa831c66d,0xb00327c8,0xbf597fc7,0xc6e00bf3,0xd5a79147,0x06ca6351,0x14292967,0x27b70a85,
+  0x2e1b2138,0x4d2c6dfc,0x53380d13,0x650a7354,0x766a0abb,0x81c2c92e,0x92722c85,0xa2bfe8a1,0xa81a664b,0xc24b8b70,0xc76c51a3,
+  0xd192e819,0xd6990624,0xf40e3585,0x106aa070,0x19a4c116,0x1e376c08,0x2748774c,0x34b0bcb5,0x391c0cb3,0x4ed8aa4a,0x5b9cca4f,
+  0x682e6ff3,0x748f82ee,0x78a5636f,0x84c87814,0x8cc70208,0x90befffa,0xa4506ceb,0xbef9a3f7,0xc67178f2};
+#define ROR(x, n) (((x) >> (n)) | ((x) << (32 - (n))))
+static void sha256_block(sha256_t* s, const uint8_t* b) {
+  uint32_t w[64], a[8];
+  for (int i = 0; i < 16; ++i) w[i] = (uint32_t)b[4 * i] << 24 | (uint32_t)b[4 * i + 1] << 16 | (uint32_t)b[4 * i + 2] << 8 | b[4 * i + 3];
+  for (int i = 16; i < 64; ++i) {
+    uint32_t s0 = ROR(w[i - 15], 7) ^ ROR(w[i - 15], 18) ^ (w[i - 15] >> 3), s1 = ROR(w[i - 2], 17) ^ ROR(w[i - 2], 19) ^ (w[i - 2] >> 10);
+    w[i] = w[i - 16] + s0 + w[i - 7] + s1;
+  }
+  memcpy(a, s->h, sizeof a);
+  for (int i = 0; i < 64; ++i) {
+    uint32_t S1 = ROR(a[4], 6) ^ ROR(a[4], 11) ^ ROR(a[4], 25), ch = (a[4] & a[5]) ^ (~a[4] & a[6]);
+    uint32_t t1 = a[7] + S1 + ch + SK[i] + w[i];
+    uint32_t S0 = ROR(a[0], 2) ^ ROR(a[0], 13) ^ ROR(a[0], 22), mj = (a[0] & a[1]) ^ (a[0] & a[2]) ^ (a[1] & a[2]);
+    uint32_t t2 = S0 + mj;
+    a[7] = a[6]; a[6] = a[5]; a[5] = a[4]; a[4] = a[3] + t1; a[3] = a[2]; a[2] = a[1]; a[1] = a[0]; a[0] = t1 + t2;
+  }
+  for (int i = 0; i < 8; ++i) s->h[i] += a[i];
+}
+static void sha256_init(sha256_t* s) {
+  static const uint32_t iv[8] = {0x6a09e667,0xbb67ae85,0x3c6ef372,0xa54ff53a,0x510e527f,0x9b05688c,0x1f83d9ab,0x5be0cd19};
+  memcpy(s->h, iv, sizeof iv);
+  s->fill = 0; s->total = 0;
+}
+static void sha256_update(sha256_t* s, const uint8_t* d, size_t n) {
+  s->total += n;
+  while (n) {
+    size_t k = 64 - s->fill; if (k > n) k = n;
+    memcpy(s->buf + s->fill, d, k); s->fill += k; d += k; n -= k;
+    if (s->fill == 64) { sha256_block(s, s->buf); s->fill = 0; }
+  }
+}
+static void sha256_final(sha256_t* s, uint8_t out[32]) {
+  uint64_t bits = s->total * 8;
+  uint8_t pad = 0x80;
+  sha256_update(s, &pad, 1);
+  pad = 0;
+  while (s->fill != 56) sha256_update(s, &pad, 1);
+  uint8_t l[8];
+  for (int i = 0; i < 8; ++i) l[i] = (uint8_t)(bits >> (56 - 8 * i));
+  sha256_update(s, l, 8);
+  for (int i = 0; i < 8; ++i) { out[4 * i] = s->h[i] >> 24; out[4 * i + 1] = s->h[i] >> 16; out[4 * i + 2] = s->h[i] >> 8; out[4 * i + 3] = s->h[i]; }
+}
+/* h.Write(x.Bytes()): minimal big-endian magnitude, nothing for zero */
+static void sha256_mpz(sha256_t* s, const mpz_t z) {
+  if (mpz_sgn(z) == 0) return;
+  size_t cnt = (mpz_sizeinbase(z, 2) + 7) / 8;
+  uint8_t stack[1024], *b = cnt <= sizeof stack ? stack : (uint8_t*)malloc(cnt);
+  mpz_export(b, NULL, 1, 1, 1, 0, z);
+  sha256_update(s, b, cnt);
+  if (b != stack) free(b);
+}
+
+/* random_oracle.go:10-32 RandomOracleBit(ct1, ct2, x, y, alpha): argument 0 (ct1) is skipped */
+static int ro_bit4(const mpz_t ct2, const mpz_t x, const mpz_t y, const mpz_t alpha) {
+  sha256_t s;
+  uint8_t d[32];
+  sha256_init(&s);
+  sha256_mpz(&s, ct2); sha256_mpz(&s, x); sha256_mpz(&s, y); sha256_mpz(&s, alpha);
+  sha256_final(&s, d);
+  return d[31] & 1;   /* big.Int(SetBytes(res)) mod 2 */
+}
+
+/* ddleq.go:129-153 verifyDDLEQProofInstance for a batch of (statement, instance) pairs.  Strides: ct/alpha/f = s3 bytes,
+ * x/y = s1, e = s2.  ok_out[i] = 1/0. */
+int oracle_ddleq_verify_batch(const uint8_t* n_be, size_t n_len, size_t batch, const uint8_t* ct1, const uint8_t* ct2, size_t s3,
+                              const uint8_t* x, const uint8_t* y, size_t s1, const uint8_t* alpha, const uint8_t* e, size_t s2,
+                              const uint8_t* f, int32_t* ok_out, int threads) {
+  mpz_t n, n2, n3;
+  mpz_inits(n, n2, n3, NULL);
+  imp(n, n_be, n_len);
+  mpz_mul(n2, n, n);
+  mpz_mul(n3, n2, n);
+  int used = 1;
+#ifdef _OPENMP
+  if (threads > 0) omp_set_num_threads(threads);
+#pragma omp parallel
+#endif
+  {
+#ifdef _OPENMP
+#pragma omp single
+    used = omp_get_num_threads();
+#endif
+    mpz_t c1, c2, xi, yi, al, ei, fi, en, fn2, chk;
+    mpz_inits(c1, c2, xi, yi, al, ei, fi, en, fn2, chk, NULL);
+#ifdef _OPENMP
+#pragma omp for schedule(dynamic, 1)
+#endif
+    for (long i = 0; i < (long)batch; ++i) {
+      imp(c1, ct1 + (size_t)i * s3, s3); imp(c2, ct2 + (size_t)i * s3, s3);
+      imp(xi, x + (size_t)i * s1, s1); imp(yi, y + (size_t)i * s1, s1);
+      imp(al, alpha + (size_t)i * s3, s3); imp(ei, e + (size_t)i * s2, s2); imp(fi, f + (size_t)i * s3, s3);
+      int bit = ro_bit4(c2, xi, yi, al);            /* :136 */
+      mpz_set(chk, bit ? c2 : c1);                  /* :138-141 */
+      gmp_exp(en, ei, n, n2);                       /* :143 */
+      gmp_exp(fn2, fi, n2, n3);                     /* :144 */
+      gmp_exp(chk, chk, en, n3);                    /* :146 */
+      mpz_mul(chk, chk, fn2);                       /* :147-148 */
+      mpz_mod(chk, chk, n3);
+      ok_out[i] = mpz_cmp(al, chk) == 0;
+    }
+    mpz_clears(c1, c2, xi, yi, al, ei, fi, en, fn2, chk, NULL);
+  }
+  mpz_clears(n, n2, n3, NULL);
+  return used;
+}
+
+/* paillier.go:308-340 recoveryAlgorithm for s = 2 (statement for statement) and :292-303 Decrypt at level two */
+static void decrypt2(mpz_t m, const mpz_t c, const mpz_t n, const mpz_t n2, const mpz_t n3, const mpz_t lambda) {
+  mpz_t a, i, t1, t2, amod, kf, mu;
+  mpz_inits(a, i, t1, t2, amod, kf, mu, NULL);
+  gmp_exp(a, c, lambda, n3);                         /* :296 */
+  /* j = 1: nj = n, nj1 = n^2 */
+  mpz_mod(amod, a, n2);
+  L_fn(i, amod, n);                                  /* i = t1 (no inner loop for j = 1) */
+  /* j = 2: nj = n^2, nj1 = n^3 */
+  mpz_mod(amod, a, n3);
+  L_fn(t1, amod, n);
+  mpz_abs(t2, i);                                    /* :320 SetBytes(i.Bytes()): magnitude */
+  mpz_sub_ui(i, i, 1);                               /* :323 (k = 2) */
+  mpz_mul(t2, t2, i); mpz_mod(t2, t2, n2);           /* :324-325 */
+  mpz_mul(t2, t2, n);                                /* :326  nk = n^(k-1) = n */
+  mpz_set_ui(kf, 2); mpz_invert(kf, kf, n2);         /* :327-328  (k!)^-1 mod nj */
+  mpz_mul(t2, t2, kf);                               /* :329 */
+  mpz_sub(t2, t1, t2);                               /* :330 */
+  mpz_mod(t1, t2, n2);                               /* :331 */
+  /* i = t1 */
+  mpz_invert(mu, lambda, n2);                        /* :298 */
+  mpz_mul(m, t1, mu);
+  mpz_mod(m, m, n2);
+  mpz_clears(a, i, t1, t2, amod, kf, mu, NULL);
+}
+
+/* ddleq.go:55-127 proveDDLEQInstance with the draws x, y supplied (G = n + 1 as KeyGen sets it), for a batch of
+ * (statement, instance) pairs.  Returns -1 if a statement fails the sanity check (the reference panics, :68).
+ * Strides: ct1/ct2/alpha_out/f_out = s3, a/b/x/y = s1, e_out = s2. */
+int oracle_ddleq_prove_batch(const uint8_t* n_be, size_t n_len, const uint8_t* lambda_be, size_t l_len, size_t batch,
+                             const uint8_t* ct1, const uint8_t* ct2, size_t s3, const uint8_t* a, const uint8_t* b, const uint8_t* x,
+                             const uint8_t* y, size_t s1, uint8_t* alpha_out, uint8_t* e_out, size_t s2, uint8_t* f_out,
+                             int32_t* bit_out, int threads) {
+  mpz_t n, n2, n3, lambda, g, nsinv;
+  mpz_inits(n, n2, n3, lambda, g, nsinv, NULL);
+  imp(n, n_be, n_len);
+  imp(lambda, lambda_be, l_len);
+  mpz_mul(n2, n, n);
+  mpz_mul(n3, n2, n);
+  mpz_add_ui(g, n, 1);
+  int bad = 0;
+#ifdef _OPENMP
+  if (threads > 0) omp_set_num_threads(threads);
+#pragma omp parallel
+#endif
+  {
+    mpz_t c1, c2, ai, bi, xi, yi, an, xn, yn2, al, t, e, f, s, v, gv, z, en, cc, ainv, nsi;
+    mpz_inits(c1, c2, ai, bi, xi, yi, an, xn, yn2, al, t, e, f, s, v, gv, z, en, cc, ainv, nsi, NULL);
+#ifdef _OPENMP
+#pragma omp for schedule(dynamic, 1)
+#endif
+    for (long i = 0; i < (long)batch; ++i) {
+      imp(c1, ct1 + (size_t)i * s3, s3); imp(c2, ct2 + (size_t)i * s3, s3);
+      imp(ai, a + (size_t)i * s1, s1); imp(bi, b + (size_t)i * s1, s1);
+      imp(xi, x + (size_t)i * s1, s1); imp(yi, y + (size_t)i * s1, s1);
+      gmp_exp(an, ai, n, n2);                        /* :62 */
+      gmp_exp(t, c1, an, n3);
+      gmp_exp(cc, bi, n2, n3);                       /* :63 */
+      mpz_mul(t, t, cc); mpz_mod(t, t, n3);          /* :64-65 */
+      if (mpz_cmp(t, c2) != 0) {                     /* :67-69 panic */
+#ifdef _OPENMP
+#pragma omp atomic write
+#endif
+        bad = 1;
+        continue;
+      }
+      gmp_exp(xn, xi, n, n2);                        /* :81 */
+      gmp_exp(yn2, yi, n2, n3);                      /* :82 */
+      gmp_exp(al, c1, xn, n3);                       /* :85 */
+      mpz_mul(al, al, yn2); mpz_mod(al, al, n3);     /* :86-87 */
+      int bit = ro_bit4(c2, xi, yi, al);             /* :91 */
+      mpz_set(e, xi);
+      mpz_set(f, yi);
+      if (bit) {
+        mpz_invert(ainv, ai, n2);                    /* :96 */
+        mpz_mul(e, e, ainv); mpz_mod(e, e, n2);      /* :97-98 */
+        /* s = ExtractRandonness(ct1), level two (operations.go:75-91) */
+        mpz_invert(nsi, n2, lambda);                 /* :80 */
+        decrypt2(v, c1, n, n2, n3, lambda);          /* :82 */
+        gmp_exp(gv, g, v, n3);                       /* :83 */
+        mpz_invert(gv, gv, n3);                      /* :84 */
+        mpz_mul(z, gv, c1); mpz_mod(z, z, n3);       /* :85-86 */
+        gmp_exp(s, z, nsi, n);                       /* :88 */
+        gmp_exp(an, ai, n, n2);                      /* ddleq.go:104 */
+        gmp_exp(en, e, n, n2);                       /* :105 */
+        gmp_exp(cc, s, an, n3);                      /* :107 */
+        mpz_mul(cc, cc, bi);                         /* :108 (not reduced) */
+        gmp_exp(cc, cc, en, n3);                     /* :109 */
+        mpz_invert(cc, cc, n3);                      /* :110 */
+        gmp_exp(t, s, xn, n3);
+        mpz_mul(cc, cc, t);                          /* :112 */
+        mpz_mul(f, f, cc);                           /* :113 */
+        mpz_mod(f, f, n3);                           /* :114 */
+      }
+      expo(al, alpha_out + (size_t)i * s3, s3);
+      expo(e, e_out + (size_t)i * s2, s2);
+      expo(f, f_out + (size_t)i * s3, s3);
+      if (bit_out) bit_out[i] = bit;
+    }
+    mpz_clears(c1, c2, ai, bi, xi, yi, an, xn, yn2, al, t, e, f, s, v, gv, z, en, cc, ainv, nsi, NULL);
+  }
+  mpz_clears(n, n2, n3, lambda, g, nsinv, NULL);
+  return bad ? -1 : 0;
 }
 
 const char* oracle_gmp_version(void) { return gmp_version; }

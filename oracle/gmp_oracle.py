@@ -18,7 +18,8 @@ def load():
             subprocess.check_call(["make", "-s", "-C", _HERE])
         _lib = C.CDLL(_PATH)
         _lib.oracle_gmp_version.restype = C.c_char_p
-        for name in ("oracle_decrypt_batch", "oracle_encrypt_batch", "oracle_modexp_batch"):
+        for name in ("oracle_decrypt_batch", "oracle_encrypt_batch", "oracle_modexp_batch", "oracle_decrypt_crt_batch",
+                     "oracle_ddleq_verify_batch", "oracle_ddleq_prove_batch"):
             getattr(_lib, name).restype = C.c_int
     return _lib
 
@@ -85,3 +86,47 @@ def modexp_batch(mod, e, bases, threads=1):
     nb = (mod.bit_length() + 7) // 8
     out, _ = modexp_batch_raw(mod, e, _ints_to_be(bases, nb), nb, threads)
     return _be_to_ints(out)
+
+
+def decrypt_crt_batch_raw(p, q, c_buf: np.ndarray, m_stride: int, threads: int = 1):
+    """Textbook CRT decryption on libgmp (second CPU-baseline line; not the reference's algorithm)."""
+    lib = load()
+    pb, qb = _be(p), _be(q)
+    out = np.zeros((c_buf.shape[0], m_stride), dtype=np.uint8)
+    used = lib.oracle_decrypt_crt_batch(pb, C.c_size_t(len(pb)), qb, C.c_size_t(len(qb)), C.c_size_t(c_buf.shape[0]),
+                                        _p(c_buf), C.c_size_t(c_buf.shape[1]), _p(out), C.c_size_t(m_stride), threads)
+    return out, used
+
+
+def ddleq_verify_batch(n, ct1s, ct2s, xs, ys, alphas, es, fs, threads=1):
+    """ddleq.go:129-153 on libgmp (+ SHA-256 in C) for a batch of (statement, instance) pairs -> list of bool."""
+    lib = load()
+    s1 = (n.bit_length() + 7) // 8
+    s2, s3 = ((n * n).bit_length() + 7) // 8, ((n ** 3).bit_length() + 7) // 8
+    B = len(ct1s)
+    bufs = [_ints_to_be(ct1s, s3), _ints_to_be(ct2s, s3), _ints_to_be(xs, s1), _ints_to_be(ys, s1), _ints_to_be(alphas, s3),
+            _ints_to_be(es, s2), _ints_to_be(fs, s3)]
+    ok = np.zeros(B, dtype=np.int32)
+    nb = _be(n)
+    lib.oracle_ddleq_verify_batch(nb, C.c_size_t(len(nb)), C.c_size_t(B), _p(bufs[0]), _p(bufs[1]), C.c_size_t(s3), _p(bufs[2]),
+                                  _p(bufs[3]), C.c_size_t(s1), _p(bufs[4]), _p(bufs[5]), C.c_size_t(s2), _p(bufs[6]), _p(ok), threads)
+    return [bool(v) for v in ok]
+
+
+def ddleq_prove_batch(n, lam, ct1s, ct2s, a_s, b_s, xs, ys, threads=1):
+    """ddleq.go:55-127 with (x, y) supplied, on libgmp -> (alphas, es, fs, challenge bits); raises on a false statement."""
+    lib = load()
+    s1 = (n.bit_length() + 7) // 8
+    s2, s3 = ((n * n).bit_length() + 7) // 8, ((n ** 3).bit_length() + 7) // 8
+    B = len(ct1s)
+    bufs = [_ints_to_be(ct1s, s3), _ints_to_be(ct2s, s3), _ints_to_be(a_s, s1), _ints_to_be(b_s, s1), _ints_to_be(xs, s1),
+            _ints_to_be(ys, s1)]
+    al, eo, fo = np.zeros((B, s3), np.uint8), np.zeros((B, s2), np.uint8), np.zeros((B, s3), np.uint8)
+    bits = np.zeros(B, dtype=np.int32)
+    nb, lb = _be(n), _be(lam)
+    rc = lib.oracle_ddleq_prove_batch(nb, C.c_size_t(len(nb)), lb, C.c_size_t(len(lb)), C.c_size_t(B), _p(bufs[0]), _p(bufs[1]),
+                                      C.c_size_t(s3), _p(bufs[2]), _p(bufs[3]), _p(bufs[4]), _p(bufs[5]), C.c_size_t(s1), _p(al),
+                                      _p(eo), C.c_size_t(s2), _p(fo), _p(bits), threads)
+    if rc != 0:
+        raise RuntimeError("cannot prove re-encryption because inputs are wrong")
+    return _be_to_ints(al), _be_to_ints(eo), _be_to_ints(fo), [int(v) for v in bits]

@@ -22,6 +22,7 @@ MEM_DEVICE = 1
 DECRYPT_DEFAULT = 0
 DECRYPT_NO_CRT = 1
 LANE_NONUNIT = 1
+LANE_NOT_INVERTIBLE = 2
 
 
 class PaillierHipError(RuntimeError):
@@ -61,9 +62,11 @@ SIGNATURES = {
     "pgpu_alt_encrypt_with_r": (_int, [_vp, _int, _sz, _vp, _sz, _vp, _sz, _vp, _sz, _vp, _int]),
     "pgpu_decrypt": (_int, [_vp, _int, _sz, _vp, _sz, _vp, _sz, _int, _int, _vp]),
     "pgpu_add": (_int, [_vp, _int, _sz, _vp, _sz, _vp, _sz, _vp, _sz, _int]),
-    "pgpu_sub": (_int, [_vp, _int, _sz, _vp, _sz, _vp, _sz, _vp, _sz, _int]),
+    "pgpu_sub": (_int, [_vp, _int, _sz, _vp, _sz, _vp, _sz, _vp, _sz, _int, _vp]),
+    "pgpu_add_many": (_int, [_vp, _int, _int, _sz, _vp, _sz, _vp, _sz, _int]),
+    "pgpu_sub_many": (_int, [_vp, _int, _int, _sz, _vp, _sz, _vp, _sz, _int, _vp]),
     "pgpu_partial_decrypt": (_int, [_vp, _int, _vp, _sz, _sz, _vp, _sz, _vp, _sz, _int]),
-    "pgpu_combine_partial_decryptions": (_int, [_vp, _int, _int, _int, _vp, _sz, _vp, _sz, _vp, _sz, _int]),
+    "pgpu_combine_partial_decryptions": (_int, [_vp, _int, _int, _int, _vp, _sz, _vp, _sz, _vp, _sz, _int, _vp]),
     "pgpu_random_oracle_digest": (_int, [_vp, _int, _vp, _vp, _sz, _vp, _int]),
     "pgpu_ddleq_verify": (_int, [_vp, _sz, _vp, _vp, _sz, _vp, _vp, _sz, _vp, _sz, _vp, _sz, _vp, _sz, _vp, _int]),
     "pgpu_share_zkp_prove": (_int, [_vp, _int, _vp, _sz, _vp, _sz, _sz, _vp, _sz, _vp, _sz, _vp, _sz, _vp, _vp, _sz, _int]),
@@ -76,7 +79,7 @@ SIGNATURES = {
     "pgpu_modexp": (_int, [_vp, _sz, _vp, _sz, _sz, _vp, _sz, _sz, _vp, _sz, _int]),
     "pgpu_vm_debug_run": (_int, [_vp, _vp, _sz, _vp, _sz, _sz, _int, C.POINTER(_int)]),
     "pgpu_pair_debug_run": (_int, [_vp, _vp, _sz, _int, _vp, _sz, _vp, _sz, _sz, _vp, C.POINTER(_int)]),
-    "pgpu_modinv": (_int, [_vp, _sz, _vp, _sz, _sz, _vp, _sz, _int]),
+    "pgpu_modinv": (_int, [_vp, _sz, _vp, _sz, _sz, _vp, _sz, _int, _vp]),
     "pgpu_modmul": (_int, [_vp, _sz, _vp, _sz, _sz, _vp, _sz, _sz, _vp, _sz, _int]),
 }
 
@@ -218,12 +221,15 @@ class Modulus:
         _check(self.ctx.lib.pgpu_vm_debug_run(self.h, _ptr(pw), pw.size, _ptr(m), nslots, nb, int(use_asm), C.byref(wt)))
         return m
 
-    def inv_batch(self, xs: Sequence[int]) -> List[int]:
-        """gmp.Int.ModInverse for each x."""
+    def inv_batch(self, xs: Sequence[int], return_status: bool = False):
+        """gmp.Int.ModInverse for each x.  Non-units raise PaillierHipError(-5) unless return_status is set, in which case
+        they come back as 0 with status LANE_NOT_INVERTIBLE (the other lanes are computed either way)."""
         xb = ints_to_be(xs, self.nbytes)
         out = np.zeros((len(xs), self.nbytes), dtype=np.uint8)
-        _check(self.ctx.lib.pgpu_modinv(self.h, len(xs), _ptr(xb), self.nbytes, self.nbytes, _ptr(out), self.nbytes, MEM_HOST))
-        return be_to_ints(out)
+        status = np.zeros(len(xs), dtype=np.int32) if return_status else None
+        _check(self.ctx.lib.pgpu_modinv(self.h, len(xs), _ptr(xb), self.nbytes, self.nbytes, _ptr(out), self.nbytes, MEM_HOST,
+                                        _ptr(status) if return_status else None))
+        return (be_to_ints(out), status) if return_status else be_to_ints(out)
 
     def mul_batch(self, a: Sequence[int], b: Sequence[int]) -> List[int]:
         lib = self.ctx.lib
@@ -298,7 +304,7 @@ class PublicKey:
 
     def RandomizeBatch(self, cts: Sequence[int], level: int = ENC_LEVEL_ONE) -> List[int]:
         """operations.go:67-69: Add(ct, Encrypt(0))."""
-        return self.AddBatch(cts, self.EncryptBatch([0] * len(cts), level), level)
+        return self.AddBatch(cts, self.EncryptBatch([0] * len(cts), level), level=level)
 
     def AltEncryptWithRBatch(self, ms: Sequence[int], rs: Sequence[int], level: int = ENC_LEVEL_ONE):
         """paillier.go:221-238 for each (m, r); returns (ciphertexts, r mod K) -- the reference overwrites r in place."""
@@ -311,21 +317,31 @@ class PublicKey:
                                                     _ptr(rred), MEM_HOST))
         return be_to_ints(out), be_to_ints(rred)
 
-    def AddBatch(self, a: Sequence[int], b: Sequence[int], level: int = ENC_LEVEL_ONE) -> List[int]:
-        """operations.go:11-29 with two operands, element-wise over the batch."""
+    def AddBatch(self, *cts: Sequence[int], level: int = ENC_LEVEL_ONE) -> List[int]:
+        """operations.go:11-29 Add(cts...), element-wise over the batch: every positional argument is one operand vector."""
         cb = self.cipher_bytes(level)
-        ab, bb = ints_to_be(a, cb), ints_to_be(b, cb)
-        out = np.zeros((len(a), cb), dtype=np.uint8)
-        _check(self.ctx.lib.pgpu_add(self.h, level, len(a), _ptr(ab), cb, _ptr(bb), cb, _ptr(out), cb, MEM_HOST))
+        st = max(cb, max((int(v).bit_length() + 7) // 8 for op in cts for v in op))
+        bufs = [ints_to_be(op, st) for op in cts]
+        ptrs = (C.c_void_p * len(bufs))(*[b.ctypes.data for b in bufs])
+        B = len(cts[0])
+        out = np.zeros((B, cb), dtype=np.uint8)
+        _check(self.ctx.lib.pgpu_add_many(self.h, level, len(bufs), B, ptrs, st, _ptr(out), cb, MEM_HOST))
         return be_to_ints(out)
 
-    def SubBatch(self, a: Sequence[int], b: Sequence[int], level: int = ENC_LEVEL_ONE) -> List[int]:
-        """operations.go:32-55 with two operands, element-wise: a[i] * b[i]^-1 mod n^(s+1)."""
+    def SubBatch(self, *cts: Sequence[int], level: int = ENC_LEVEL_ONE, return_status: bool = False):
+        """operations.go:32-55 Sub(cts...), element-wise: cts[0][i] * prod_{k>=1} cts[k][i]^-1 mod n^(s+1).  A single operand
+        is returned unreduced, as the reference does.  A subtrahend that is not a unit raises PaillierHipError(-5) unless
+        return_status is set (then that lane is 0 with LANE_NOT_INVERTIBLE and the others are computed)."""
         cb = self.cipher_bytes(level)
-        ab, bb = ints_to_be(a, cb), ints_to_be(b, cb)
-        out = np.zeros((len(a), cb), dtype=np.uint8)
-        _check(self.ctx.lib.pgpu_sub(self.h, level, len(a), _ptr(ab), cb, _ptr(bb), cb, _ptr(out), cb, MEM_HOST))
-        return be_to_ints(out)
+        st = max(cb, max((int(v).bit_length() + 7) // 8 for op in cts for v in op))
+        bufs = [ints_to_be(op, st) for op in cts]
+        ptrs = (C.c_void_p * len(bufs))(*[b.ctypes.data for b in bufs])
+        B = len(cts[0])
+        out = np.zeros((B, st if len(cts) == 1 else cb), dtype=np.uint8)
+        status = np.zeros(B, dtype=np.int32) if return_status else None
+        _check(self.ctx.lib.pgpu_sub_many(self.h, level, len(bufs), B, ptrs, st, _ptr(out), out.shape[1], MEM_HOST,
+                                          _ptr(status) if return_status else None))
+        return (be_to_ints(out), status) if return_status else be_to_ints(out)
 
     def ConstMultBatch(self, cts: Sequence[int], k, level: int = ENC_LEVEL_ONE) -> List[int]:
         """operations.go:58-64; k is one int (shared) or one per ciphertext."""
@@ -386,12 +402,14 @@ class ThresholdPublicKey(PublicKey):
         _check(self.ctx.lib.pgpu_partial_decrypt(self.h, self.TotalNumberOfDecryptionServers, sb, len(sb), batch, _ptr(c),
                                                  c_stride, _ptr(out), out_stride, mem))
 
-    def combine_raw(self, ids: Sequence[int], batch, partial_ptrs: Sequence[int], stride, m, m_stride, mem=MEM_HOST):
+    def combine_raw(self, ids: Sequence[int], batch, partial_ptrs: Sequence[int], stride, m, m_stride, mem=MEM_HOST,
+                    status: Optional[np.ndarray] = None):
         n = len(ids)
         ida = (C.c_int * n)(*ids)
         pa_ = (C.c_void_p * n)(*partial_ptrs)
         _check(self.ctx.lib.pgpu_combine_partial_decryptions(self.h, self.TotalNumberOfDecryptionServers, self.Threshold, n,
-                                                             ida, batch, pa_, stride, _ptr(m), m_stride, mem))
+                                                             ida, batch, pa_, stride, _ptr(m), m_stride, mem,
+                                                             _ptr(status) if status is not None else None))
 
     def PartialDecryptionWithZKPBatch(self, ID: int, share: int, verification_key: int, cts: Sequence[int], rs: Sequence[int]):
         """thresholdkey.go:225-257 with r supplied, entirely on the device.  Returns (decryptions, Es, Zs)."""
@@ -427,14 +445,16 @@ class ThresholdPublicKey(PublicKey):
         self.partial_decrypt_raw(share, len(cts), cbuf, cb, out, cb)
         return ID, be_to_ints(out)
 
-    def CombinePartialDecryptionsBatch(self, shares) -> List[int]:
+    def CombinePartialDecryptionsBatch(self, shares, return_status: bool = False):
         """thresholdkey.go:149-161; shares = [(ID, [decryption per ciphertext]), ...]."""
         cb, pb = self.cipher_bytes(), self.plain_bytes()
         bufs = [ints_to_be(d, cb) for _, d in shares]
         batch = bufs[0].shape[0] if bufs else 0
         out = np.zeros((max(batch, 1), pb), dtype=np.uint8)
-        self.combine_raw([i for i, _ in shares], batch, [b.ctypes.data for b in bufs], cb, out, pb)
-        return be_to_ints(out[:batch])
+        status = np.zeros(max(batch, 1), dtype=np.int32) if return_status else None
+        self.combine_raw([i for i, _ in shares], batch, [b.ctypes.data for b in bufs], cb, out, pb, status=status)
+        res = be_to_ints(out[:batch])
+        return (res, status[:batch]) if return_status else res
 
 
 class SecretKey:

@@ -11,9 +11,11 @@ namespace {
 struct Blob { int wl, k; const unsigned char* data; size_t size; const char* name; };
 #include "vm_asm_blobs.inc"   // defines: static const Blob kBlobs[]; static const int kNumBlobs;
 
-struct Loaded { hipModule_t mod = nullptr; hipFunction_t fn = nullptr; bool tried = false; };
+struct Loaded { hipModule_t mod = nullptr; hipFunction_t fn = nullptr; bool tried = false; hipError_t err = hipSuccess; };
 constexpr int kMaxDevices = 16;
-Loaded g_loaded[16][kMaxDevices];   // a hipModule belongs to one device: load per (shape, device)
+constexpr int kMaxBlobs = 64;
+static_assert(kNumBlobs <= kMaxBlobs, "g_loaded is indexed by blob: raise kMaxBlobs when gen_vm_asm.SHAPES grows");
+Loaded g_loaded[kMaxBlobs][kMaxDevices];   // a hipModule belongs to one device: load per (shape, device)
 std::mutex g_mu;
 
 int find_blob(int wl, int k) {
@@ -38,11 +40,10 @@ hipError_t launch_vm_asm(int wl, int k, const VmArgs& a, uint32_t blocks, hipStr
     if (!L.tried) {
       L.tried = true;
       hipError_t e = hipModuleLoadData(&L.mod, kBlobs[i].data);
-      if (e != hipSuccess) return e;
-      e = hipModuleGetFunction(&L.fn, L.mod, kBlobs[i].name);
-      if (e != hipSuccess) return e;
+      if (e == hipSuccess) e = hipModuleGetFunction(&L.fn, L.mod, kBlobs[i].name);
+      if (e != hipSuccess) { L.fn = nullptr; L.err = e; }
     }
-    if (!L.fn) return hipErrorInvalidValue;
+    if (!L.fn) return L.err != hipSuccess ? L.err : hipErrorInvalidValue;   // the first load error, every time
   }
   VmArgs args = a;
   size_t size = sizeof(VmArgs);

@@ -43,6 +43,13 @@ struct ApiError { int code; std::string msg; };
 
 size_t round_up(size_t v, size_t m) { return (v + m - 1) / m * m; }
 
+// overwrite key material before its storage is released (not elided: volatile stores)
+void wipe(void* p, size_t n) {
+  volatile unsigned char* v = (volatile unsigned char*)p;
+  while (n--) *v++ = 0;
+}
+template <class T> void wipe_vec(std::vector<T>& v) { if (!v.empty()) wipe(v.data(), v.size() * sizeof(T)); }
+
 }  // namespace
 
 // ------------------------------------------------------------------------------------------------
@@ -80,6 +87,7 @@ struct pgpu_ctx {
       chunks.push_back(c);
     }
     for (auto& c : chunks) c.used = 0;
+    for (auto& h : host_keep) wipe_vec(h);   // ladder programs encode secret exponents (p - 1, q - 1, shares)
     host_keep.clear();
     evs_used = 0;
     last_vm_asm = 0;
@@ -111,7 +119,14 @@ struct pgpu_ctx {
     }
     return evs[evs_used++];
   }
+  // zero the workspace (intermediate values of the last call, ladder programs of secret exponents)
+  void wipe_ws() {
+    for (auto& c : chunks) (void)hipMemsetAsync(c.p, 0, c.cap, stream);
+    (void)hipStreamSynchronize(stream);
+    for (auto& h : host_keep) wipe_vec(h);
+  }
   ~pgpu_ctx() {
+    wipe_ws();
     for (auto& c : chunks) (void)hipFree(c.p);
     for (auto& e : evs) { (void)hipEventDestroy(e.a); (void)hipEventDestroy(e.b); }
   }
@@ -192,9 +207,11 @@ struct ModCtx {
     }
     HIPCHK(hipMemcpy(d_consts, all.data(), all.size() * 4, hipMemcpyHostToDevice));
   }
-  ~ModCtx() {
-    if (d_nmod) (void)hipFree(d_nmod);
-    if (d_consts) (void)hipFree(d_consts);
+  ~ModCtx() {   // a modulus may be secret (p, q and their powers): nothing of it outlives the handle
+    if (d_nmod) { (void)hipMemset(d_nmod, 0, (size_t)WT * 4); (void)hipFree(d_nmod); }
+    if (d_consts) { (void)hipMemset(d_consts, 0, d_consts_cap * WT * 4); (void)hipFree(d_consts); }
+    wipe_vec(N.d);
+    for (auto& c : consts) wipe_vec(c.d);
   }
 };
 
@@ -208,7 +225,7 @@ struct DevLimbs {
     if (!d) HIPCHK(hipMalloc((void**)&d, (size_t)width * 4));
     HIPCHK(hipMemcpy(d, l.data(), l.size() * 4, hipMemcpyHostToDevice));
   }
-  ~DevLimbs() { if (d) (void)hipFree(d); }
+  ~DevLimbs() { if (d) { (void)hipMemset(d, 0, (size_t)w * 4); (void)hipFree(d); } }
 };
 
 // ------------------------------------------------------------------------------------------------
@@ -570,9 +587,12 @@ struct pgpu_seckey {
   DevLimbs pinv2k, qinv2k;       // p^-1 mod 2^(28 mp.WT), q^-1 mod 2^(28 mq.WT)
   DevLimbs p_limbs;              // p as mp.WT limbs
   // generic path (reference formula)
-  int c_muR = -1;                // lambda^-1 mod n, times R mod n, in pk->mn
+  ModCtx smn, smn2;              // the key's own constant tables for n and n^2: secret-derived constants never enter the
+                                 // (shared, longer-lived) public key's tables
+  int c_muR = -1;                // lambda^-1 mod n, times R mod n, in smn
   DevLimbs n_minus_mu;           // (n - mu) mod n, the answer for c == 0 (L(-1) = -1)
-  int c_mu2R = -1;               // lambda^-1 mod n^2, times R mod n^2, in pk->mn2 (level two)
+  int c_mu2R = -1;               // lambda^-1 mod n^2, times R mod n^2, in smn2 (level two)
+  ~pgpu_seckey() { wipe_vec(lambda.d); wipe_vec(p.d); wipe_vec(q.d); }
   // pair kernel for the p^2 / q^2 ladders (GenP): p | Cadj limb arrays, R_H mod p^2 as a plain constant of mp2 / mq2
   bool has_pair = false;
   bool pair_small2 = false;        // 37-limb primes: below one wave per SIMD the two-lane kernel fills the chip better
@@ -820,22 +840,54 @@ void reduce_mod(pgpu_ctx* ctx, const ModCtx& mc, const uint32_t* in, int w_in, u
   HIPCHK(hipMemcpyAsync(out, mem + 3 * sw, sw * 4, hipMemcpyDeviceToDevice, ctx->stream));
 }
 
+// Stage an operand that is read modulo N, whatever its stride.  Up to the width of the modulus the bytes go straight into
+// WT limbs (a Montgomery operand may be any value below R; `canonical` additionally reduces it below N).  A wider stride
+// is unpacked whole and reduced chunk by chunk (Horner over WT-limb chunks), so that no leading byte is silently
+// dropped: the reference's Exp / Mul+Mod reduce any value correctly.
+void unpack_mod(pgpu_ctx* ctx, const ModCtx& mc, const uint8_t* buf, size_t stride, size_t count, int mem, uint32_t* out,
+                size_t nb, bool canonical = false) {
+  const int WT = mc.WT;
+  if (stride * 8 <= (size_t)LB * WT) {
+    if (!canonical) { unpack_operand(ctx, buf, stride, stride, count, mem, out, WT, nb); return; }
+    uint32_t* raw = ctx->ws_t<uint32_t>((size_t)WT * nb);
+    unpack_operand(ctx, buf, stride, stride, count, mem, raw, WT, nb);
+    reduce_mod(ctx, mc, raw, WT, out, nb);
+    return;
+  }
+  const int w_in = (int)((stride * 8 + LB - 1) / LB);
+  uint32_t* wide = ctx->ws_t<uint32_t>((size_t)w_in * nb);
+  unpack_operand(ctx, buf, stride, stride, count, mem, wide, w_in, nb);
+  if (w_in <= 2 * WT) { reduce_mod(ctx, mc, wide, w_in, out, nb); return; }
+  const size_t sw = (size_t)WT * nb;
+  const int nchunks = (w_in + WT - 1) / WT;
+  uint32_t* arr = ctx->ws_t<uint32_t>(2 * sw);   // [chunk | running remainder]: the value chunk + rem * 2^(28 WT)
+  launch_copy_limbs(wide, (nchunks - 1) * WT, w_in - (nchunks - 1) * WT, arr + sw, WT, nb, ctx->stream);
+  for (int k = nchunks - 2; k >= 0; --k) {
+    launch_copy_limbs(wide, k * WT, WT, arr, WT, nb, ctx->stream);
+    reduce_mod(ctx, mc, arr, 2 * WT, k ? arr + sw : out, nb);
+  }
+}
+
 // Batch modular inverse (gmp.Int.ModInverse for a whole batch) by Montgomery's trick arranged as a binary tree so that
-// every level is one data-parallel VM launch: products up the tree (pairs (i, i + half) via VM_SETOFF), ONE inversion
-// of the root on the host, inverses down the tree.  3 Montgomery products per element instead of a ~2*bits-step
-// extended Euclid per element.  x: canonical, stride nb, `count` valid.  Returns canonical inverses with stride nb.
-// A non-unit anywhere in the batch makes the root non-invertible -> PGPU_ERR_NOT_INVERTIBLE (mpz_invert is undefined
-// there, and the reference never checks).
-uint32_t* batch_inverse(pgpu_ctx* ctx, const ModCtx& mc, const uint32_t* x, size_t nb, size_t count) {
+// every level is one data-parallel VM launch: products up the tree (number i with number i + half: the upper half of a
+// level is copied next to the lower half, so the programs are plain LOAD / MUL / STORE and run on the assembly kernels),
+// ONE inversion of the root on the host, inverses down the tree.  3 Montgomery products per element instead of a
+// ~2*bits-step extended Euclid per element.  x: canonical, stride nb, `count` valid.  Returns canonical inverses with
+// stride nb, or nullptr when the root is not invertible (some element is not a unit).
+uint32_t* tree_inverse(pgpu_ctx* ctx, const ModCtx& mc, const uint32_t* x, size_t nb, size_t count) {
   const int WT = mc.WT;
   size_t nbt = VM_BLOCK;
   int L = 8;
   while (nbt < count) { nbt <<= 1; ++L; }
   const size_t sw = (size_t)WT * nbt;
-  // slots: V_0..V_L, I0, I1, A, B, O
-  const uint32_t SV = 0, SI0 = (uint32_t)L + 1, SI1 = SI0 + 1, SA = SI0 + 2, SB = SI0 + 3, SO = SI0 + 4;
-  uint32_t* mem = ctx->ws_t<uint32_t>(sw * (size_t)(L + 6) + 8192);
-  HIPCHK(hipMemsetAsync(mem + sw * (size_t)(L + 6), 0, 8192 * 4, ctx->stream));
+  // slots: V_0..V_L, U (upper half of the current level, moved down), I0, I1, A, B, O
+  const uint32_t SV = 0, SU = (uint32_t)L + 1, SI0 = SU + 1, SI1 = SI0 + 1, SA = SI0 + 2, SB = SI0 + 3, SO = SI0 + 4;
+  uint32_t* mem = ctx->ws_t<uint32_t>(sw * (size_t)(L + 7));
+  HIPCHK(hipMemsetAsync(mem + (size_t)SU * sw, 0, sw * 4, ctx->stream));
+  auto upper_half = [&](int k, size_t half) {   // U[i] <- V_k[i + half], i < half
+    HIPCHK(hipMemcpy2DAsync(mem + (size_t)SU * sw, nbt * 4, mem + (size_t)(SV + k) * sw + half, nbt * 4, half * 4, (size_t)WT,
+                            hipMemcpyDeviceToDevice, ctx->stream));
+  };
   // V_0 = x (padding lanes = 1), to Montgomery form
   launch_restride(x, nb, count, mc.d_consts + (size_t)C_ONE * WT, mem + SV * sw, nbt, WT, ctx->stream);
   {
@@ -846,9 +898,9 @@ uint32_t* batch_inverse(pgpu_ctx* ctx, const ModCtx& mc, const uint32_t* x, size
   }
   for (int k = 0; k < L; ++k) {  // V_{k+1}[i] = V_k[i] * V_k[i + half]
     const size_t half = nbt >> (k + 1);
+    upper_half(k, half);
     Prog p;
-    p.op(VM_LOAD, SV + k); p.op(VM_SETOFF, (uint32_t)half); p.op(VM_MUL, SV + k); p.op(VM_SETOFF, 0);
-    p.op(VM_STORE, SV + k + 1); p.end();
+    p.op(VM_LOAD, SV + k); p.op(VM_MUL, SU); p.op(VM_STORE, SV + k + 1); p.end();
     SegSpec sg{&mc, &p, mem, nullptr};
     run_vm(ctx, nbt, sg, nullptr, false, std::max<size_t>(VM_BLOCK, half));
   }
@@ -866,17 +918,17 @@ uint32_t* batch_inverse(pgpu_ctx* ctx, const ModCtx& mc, const uint32_t* x, size
   HIPCHK(hipMemcpyAsync(rb.data(), d_rb, mc.nbytes, hipMemcpyDeviceToHost, ctx->stream));
   HIPCHK(hipStreamSynchronize(ctx->stream));
   BigU root = BigU::from_be(rb.data(), rb.size()), rinv;
-  if (!hostbig::modinv(root, mc.N, rinv))
-    api_throw(PGPU_ERR_NOT_INVERTIBLE, "ModInverse: an element of the batch is not invertible modulo the modulus");
+  if (!hostbig::modinv(root, mc.N, rinv)) return nullptr;
   uint32_t* d_rinv = ctx->upload_words(mc.to_mont(rinv).to_limbs(LB, WT));
   // every lane of I0 <- root inverse (count = 0: all lanes take the fill value); only lane 0 is consumed
   launch_restride(mem + SI0 * sw, nbt, 0, d_rinv, mem + SI0 * sw, nbt, WT, ctx->stream);
   uint32_t cur = SI0, nxt = SI1;
   for (int k = L - 1; k >= 0; --k) {
     const size_t half = nbt >> (k + 1);
+    upper_half(k, half);
     Prog p;
-    p.op(VM_LOAD, cur); p.op(VM_SETOFF, (uint32_t)half); p.op(VM_MUL, SV + k); p.op(VM_SETOFF, 0); p.op(VM_STORE, SA);
-    p.op(VM_LOAD, cur); p.op(VM_MUL, SV + k); p.op(VM_STORE, SB);
+    p.op(VM_LOAD, cur); p.op(VM_MUL, SU); p.op(VM_STORE, SA);         // inverse of V_k[i]        = I_{k+1}[i] V_k[i + half]
+    p.op(VM_LOAD, cur); p.op(VM_MUL, SV + k); p.op(VM_STORE, SB);     // inverse of V_k[i + half] = I_{k+1}[i] V_k[i]
     p.end();
     SegSpec sg{&mc, &p, mem, nullptr};
     run_vm(ctx, nbt, sg, nullptr, false, std::max<size_t>(VM_BLOCK, half));
@@ -894,6 +946,56 @@ uint32_t* batch_inverse(pgpu_ctx* ctx, const ModCtx& mc, const uint32_t* x, size
   launch_restride(mem + SO * sw, nbt, count, nullptr, out, nb, WT, ctx->stream);
   return out;
 }
+
+// gmp.Int.ModInverse for a batch.  d_bad (device int32[nb], may be null) receives 1 on the lanes that are not units and 0
+// elsewhere; those lanes get the result 0 (mpz_invert leaves its result undefined there and the reference never checks).
+// One hostile element must not cost the honest ones their answers: when the tree's root cannot be inverted, a per-lane
+// binary GCD finds the non-units, 1 is substituted for them and the tree runs again.  With d_bad == nullptr a non-unit
+// throws PGPU_ERR_NOT_INVERTIBLE (callers for which a non-unit means the whole call is meaningless).
+uint32_t* batch_inverse(pgpu_ctx* ctx, const ModCtx& mc, const uint32_t* x, size_t nb, size_t count, int32_t* d_bad = nullptr,
+                        bool* any_bad = nullptr) {
+  if (any_bad) *any_bad = false;
+  if (d_bad) HIPCHK(hipMemsetAsync(d_bad, 0, nb * 4, ctx->stream));
+  uint32_t* out = tree_inverse(ctx, mc, x, nb, count);
+  if (out) return out;
+  if (!d_bad) api_throw(PGPU_ERR_NOT_INVERTIBLE, "ModInverse: an element of the batch is not invertible modulo the modulus");
+  const size_t sw = (size_t)mc.WT * nb;
+  uint32_t* work = ctx->ws_t<uint32_t>(2 * sw);
+  launch_unit_flags(x, mc.d_nmod, mc.WT, nb, count, work, d_bad, ctx->stream);
+  uint32_t* x1 = ctx->ws_t<uint32_t>(sw);
+  HIPCHK(hipMemcpyAsync(x1, x, sw * 4, hipMemcpyDeviceToDevice, ctx->stream));
+  launch_select_const(d_bad, mc.d_consts + (size_t)C_ONE * mc.WT, x1, mc.WT, nb, ctx->stream);
+  out = tree_inverse(ctx, mc, x1, nb, count);
+  if (!out) api_throw(PGPU_ERR_NOT_INVERTIBLE, "ModInverse: internal error (non-unit survived the unit test)");
+  uint32_t* zero = ctx->ws_t<uint32_t>((size_t)mc.WT);
+  HIPCHK(hipMemsetAsync(zero, 0, (size_t)mc.WT * 4, ctx->stream));
+  launch_select_const(d_bad, zero, out, mc.WT, nb, ctx->stream);
+  if (any_bad) *any_bad = true;
+  return out;
+}
+
+// After a batch_inverse with per-lane flags: OR PGPU_LANE_NOT_INVERTIBLE into the caller's status array, or -- when the caller
+// passed none -- report the failure through the return code once the outputs have been written (finish_bad_lanes()).
+struct BadLanes {
+  bool any = false;
+  std::vector<int32_t> host;
+  void collect(pgpu_ctx* ctx, const int32_t* d_bad, size_t batch, bool any_bad) {
+    if (!any_bad) return;
+    any = true;
+    host.resize(batch);
+    HIPCHK(hipMemcpyAsync(host.data(), d_bad, batch * 4, hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHK(hipStreamSynchronize(ctx->stream));
+  }
+  void finish(int32_t* status, size_t batch) const {
+    if (status) {
+      for (size_t i = 0; i < batch; ++i) status[i] = (any && host[i]) ? PGPU_LANE_NOT_INVERTIBLE : PGPU_LANE_OK;
+      return;
+    }
+    if (any)
+      api_throw(PGPU_ERR_NOT_INVERTIBLE, "ModInverse of a non-unit: the invertible lanes were computed, the others are zero "
+                                         "(pass a status array to get them per lane)");
+  }
+};
 
 void check_batch_args(const void* a, const void* b, size_t batch) {
   if (!a || !b) api_throw(PGPU_ERR_INVALID, "null buffer");
@@ -1004,7 +1106,7 @@ int pgpu_pair_debug_run(pgpu_ctx* ctx, const uint8_t* p_be, size_t p_len, int la
 }
 
 int pgpu_modinv(const pgpu_modulus* mod, size_t batch, const uint8_t* x, size_t x_stride, size_t x_len, uint8_t* out,
-                size_t out_stride, int mem) {
+                size_t out_stride, int mem, int32_t* status) {
   if (!mod) return fail(PGPU_ERR_INVALID, "null modulus");
   pgpu_ctx* ctx = mod->ctx;
   const ModCtx& mc = mod->mc;
@@ -1019,9 +1121,14 @@ int pgpu_modinv(const pgpu_modulus* mod, size_t batch, const uint8_t* x, size_t 
     unpack_operand(ctx, x, x_stride, x_len, batch, mem, xl, std::max(w_in, mc.WT), nb);
     uint32_t* xr = ctx->ws_t<uint32_t>((size_t)mc.WT * nb);
     reduce_mod(ctx, mc, xl, std::max(w_in, mc.WT), xr, nb);
-    uint32_t* inv = batch_inverse(ctx, mc, xr, nb, batch);
+    int32_t* d_bad = ctx->ws_t<int32_t>(nb);
+    bool any_bad = false;
+    uint32_t* inv = batch_inverse(ctx, mc, xr, nb, batch, d_bad, &any_bad);
+    BadLanes bl;
+    bl.collect(ctx, d_bad, batch, any_bad);
     pack_result(ctx, inv, mc.WT, nb, batch, out, out_stride, mc.nbytes, mem);
     HIPCHK(hipStreamSynchronize(ctx->stream));
+    bl.finish(status, batch);
   });
 }
 
@@ -1131,6 +1238,7 @@ size_t pgpu_pubkey_cipher_bytes(const pgpu_pubkey* pk, int level) {
 int pgpu_seckey_create(pgpu_ctx* ctx, const pgpu_pubkey* pk, const uint8_t* lambda_be, size_t lambda_len,
                        pgpu_seckey** out) {
   if (!ctx || !pk || !lambda_be || !out) return fail(PGPU_ERR_INVALID, "null argument");
+  if (ctx != pk->ctx) return fail(PGPU_ERR_INVALID, "the secret key must live on its public key's context (device pointers are shared)");
   std::unique_ptr<pgpu_seckey> sk(new pgpu_seckey());
   int rc = guarded([&] {
     ctx->bind();
@@ -1142,16 +1250,15 @@ int pgpu_seckey_create(pgpu_ctx* ctx, const pgpu_pubkey* pk, const uint8_t* lamb
     // generic-path constants (paillier.go:298: mu = lambda^-1 mod n)
     BigU mu;
     if (!hostbig::modinv(sk->lambda, n, mu)) api_throw(PGPU_ERR_NOT_INVERTIBLE, "lambda is not invertible mod n");
-    pgpu_pubkey* pkm = const_cast<pgpu_pubkey*>(pk);  // constants are appended to the key's tables once, here
-    sk->c_muR = pkm->mn.add_const(pkm->mn.to_mont(mu));
-    pkm->mn.upload();
+    sk->smn.init(ctx, n);
+    sk->smn2.init(ctx, n * n);
+    sk->c_muR = sk->smn.add_const(sk->smn.to_mont(mu));
+    sk->smn.upload();
     sk->n_minus_mu.set((n - mu) % n, pk->mn.WT);
     {
       BigU mu2, n2v = n * n;
-      if (hostbig::modinv(sk->lambda, n2v, mu2)) {
-        sk->c_mu2R = pkm->mn2.add_const(pkm->mn2.to_mont(mu2));
-        pkm->mn2.upload();
-      }
+      if (hostbig::modinv(sk->lambda, n2v, mu2)) sk->c_mu2R = sk->smn2.add_const(sk->smn2.to_mont(mu2));
+      sk->smn2.upload();
     }
     // recover p, q from n and lambda = (p-1)(q-1): p + q = n - lambda + 1
     if (hostbig::cmp(n + BigU(1), sk->lambda) > 0) {
@@ -1279,7 +1386,12 @@ int pgpu_seckey_create(pgpu_ctx* ctx, const pgpu_pubkey* pk, const uint8_t* lamb
   if (rc == PGPU_OK) *out = sk.release();
   return rc;
 }
-void pgpu_seckey_destroy(pgpu_seckey* sk) { delete sk; }
+void pgpu_seckey_destroy(pgpu_seckey* sk) {
+  if (!sk) return;
+  (void)hipSetDevice(sk->ctx->device);
+  sk->ctx->wipe_ws();   // the workspace may still hold this key's ladder programs and intermediate residues
+  delete sk;
+}
 int pgpu_seckey_has_crt(const pgpu_seckey* sk) { return sk && sk->has_crt; }
 
 }  // extern "C"
@@ -1434,9 +1546,8 @@ uint32_t* L_floor(pgpu_ctx* ctx, const pgpu_pubkey* pk, const uint32_t* u, int w
 
 // m = L(u) * C mod n for canonical u < n^2.  c_const = index of C*R mod n in pk->mn.consts; neg_const = (-C) mod n as
 // limbs (the u = 0 answer: L = -1).  Returns mn.WT-limb canonical results.
-uint32_t* L_times_const(pgpu_ctx* ctx, const pgpu_pubkey* pk, const uint32_t* u, size_t nb, size_t count, int c_const,
-                        const uint32_t* neg_const) {
-  const ModCtx& mn = pk->mn;
+uint32_t* L_times_const(pgpu_ctx* ctx, const pgpu_pubkey* pk, const uint32_t* u, size_t nb, size_t count, const ModCtx& mn,
+                        int c_const, const uint32_t* neg_const) {
   const int W1 = mn.WT;
   int32_t* zf = ctx->ws_t<int32_t>(nb);
   uint32_t* q = L_floor(ctx, pk, u, pk->mn2.WT, nb, count, W1, zf);
@@ -1465,7 +1576,7 @@ uint32_t* decrypt1_generic(const pgpu_seckey* sk, const uint32_t* c_limbs, size_
   ModexpPlan pl = modexp_alloc(ctx, mn2, nb, 32);
   HIPCHK(hipMemcpyAsync(pl.in(), c_limbs, (size_t)mn2.WT * nb * 4, hipMemcpyDeviceToDevice, ctx->stream));
   modexp_shared_run(ctx, mn2, pl, sk->lambda, false, false, true);   // u, canonical
-  return L_times_const(ctx, pk, pl.out(), nb, count, sk->c_muR, sk->n_minus_mu.d);
+  return L_times_const(ctx, pk, pl.out(), nb, count, sk->smn, sk->c_muR, sk->n_minus_mu.d);
 }
 
 // Level-two (Damgard-Jurik s = 2) decryption by the reference's formula (paillier.go:292-340):
@@ -1517,7 +1628,7 @@ uint32_t* decrypt2_generic(const pgpu_seckey* sk, const uint32_t* c_limbs, size_
   launch_sub_mod(t1, mv + 2 * s2, mn2.d_nmod, mv + 3 * s2, W2, nb, ctx->stream);  // i
   Prog q;
   q.op(VM_LOAD, 3); q.op(VM_MULC, (uint32_t)sk->c_mu2R); q.op(VM_STORE, 4); q.end();
-  SegSpec sq{&mn2, &q, mv, nullptr};
+  SegSpec sq{&sk->smn2, &q, mv, nullptr};
   run_vm(ctx, nb, sq, nullptr, false);
   launch_canon(mv + 4 * s2, mn2.d_nmod, W2, nb, ctx->stream);
   return mv + 4 * s2;
@@ -1812,19 +1923,13 @@ void build_gm(pgpu_ctx* ctx, const pgpu_pubkey* pk, int level, const uint8_t* m,
     return;
   }
   if (level == PGPU_LEVEL_ONE) {
-    const size_t mlen = std::min(m_stride, mn.nbytes);
-    uint32_t* ml = ctx->ws_t<uint32_t>((size_t)W1 * nb);
-    unpack_operand(ctx, m, m_stride, mlen, batch, mem, ml, W1, nb);
     uint32_t* mred = ctx->ws_t<uint32_t>((size_t)W1 * nb);
-    reduce_mod(ctx, mn, ml, W1, mred, nb);   // the generator 1+n has order n: G^m = G^(m mod n)
+    unpack_mod(ctx, mn, m, m_stride, batch, mem, mred, nb, true);   // the generator 1+n has order n: G^m = G^(m mod n)
     launch_mul_const_add(mred, W1, pk->n_limbs.d, W1, nullptr, 0, 1, post, W2, nb, ctx->stream);
     return;
   }
-  const size_t mlen = std::min(m_stride, mn2.nbytes);
-  uint32_t* ml = ctx->ws_t<uint32_t>((size_t)W2 * nb);
-  unpack_operand(ctx, m, m_stride, mlen, batch, mem, ml, W2, nb);
   uint32_t* mred = ctx->ws_t<uint32_t>((size_t)W2 * nb);
-  reduce_mod(ctx, mn2, ml, W2, mred, nb);
+  unpack_mod(ctx, mn2, m, m_stride, batch, mem, mred, nb, true);   // 1+n has order n^2 modulo n^3
   gm2_from_reduced(ctx, pk, mred, nb, post);
 }
 
@@ -1874,7 +1979,7 @@ int pgpu_encrypt_with_r(const pgpu_pubkey* pk, int level, size_t batch, const ui
     const size_t nb = round_up(batch, VM_BLOCK);
     ModexpPlan pl = modexp_alloc(ctx, mc, nb, 32);
     build_gm(ctx, pk, level, m, m_stride, batch, mem, nb, pl.post());
-    unpack_operand(ctx, r, r_stride, std::min(r_stride, mc.nbytes), batch, mem, pl.in(), mc.WT, nb);
+    unpack_mod(ctx, mc, r, r_stride, batch, mem, pl.in(), nb);
     const BigU& ns = (level == PGPU_LEVEL_ONE) ? pk->N : pk->mn2.N;
     modexp_shared_run(ctx, mc, pl, ns, false, true, true);  // r^(n^s) * g^m mod n^(s+1)  (public exponent: zero windows skipped)
     pack_result(ctx, pl.out(), mc.WT, nb, batch, c, c_stride, mc.nbytes, mem);
@@ -1929,63 +2034,116 @@ int pgpu_alt_encrypt_with_r(const pgpu_pubkey* pk, int level, size_t batch, cons
   });
 }
 
-int pgpu_add(const pgpu_pubkey* pk, int level, size_t batch, const uint8_t* a, size_t a_stride, const uint8_t* b,
-             size_t b_stride, uint8_t* out, size_t out_stride, int mem) {
-  if (!pk) return fail(PGPU_ERR_INVALID, "null key");
+int pgpu_add_many(const pgpu_pubkey* pk, int level, int n_ops, size_t batch, const uint8_t* const* ops, size_t stride,
+                  uint8_t* out, size_t out_stride, int mem) {
+  if (!pk || !ops) return fail(PGPU_ERR_INVALID, "null argument");
   pgpu_ctx* ctx = pk->ctx;
   return guarded([&] {
-    check_batch_args(a, out, batch);
-    if (!b) api_throw(PGPU_ERR_INVALID, "null buffer");
+    if (n_ops < 1) api_throw(PGPU_ERR_INVALID, "Add needs at least one operand (the reference indexes cts[0])");
+    check_batch_args(ops[0], out, batch);
     const ModCtx& mc = cipher_mod(pk, level);
     ctx->bind();
     ctx->reset_ws();
     const size_t nb = round_up(batch, VM_BLOCK);
-    size_t sw = (size_t)mc.WT * nb;
-    uint32_t* memv = ctx->ws_t<uint32_t>(sw * 3);
-    unpack_operand(ctx, a, a_stride, std::min(a_stride, mc.nbytes), batch, mem, memv, mc.WT, nb);
-    unpack_operand(ctx, b, b_stride, std::min(b_stride, mc.nbytes), batch, mem, memv + sw, mc.WT, nb);
+    const size_t sw = (size_t)mc.WT * nb;
+    uint32_t* memv = ctx->ws_t<uint32_t>(sw * (size_t)(n_ops + 1));
+    for (int k = 0; k < n_ops; ++k) {
+      if (!ops[k]) api_throw(PGPU_ERR_INVALID, "null operand buffer");
+      unpack_mod(ctx, mc, ops[k], stride, batch, mem, memv + (size_t)k * sw, nb);
+    }
+    // operations.go:12-22: accumulator = 1; accumulator = accumulator * c mod n^(s+1) for every operand
     Prog p;
     p.op(VM_LOAD, 0);
-    p.op(VM_MULC, C_R2);
-    p.op(VM_MUL, 1);
-    p.op(VM_STORE, 2);
+    for (int k = 1; k < n_ops; ++k) { p.op(VM_MULC, C_R2); p.op(VM_MUL, (uint32_t)k); }
+    if (n_ops == 1) { p.op(VM_MULC, C_R2); p.op(VM_MULC, C_ONE); }   // 1 * c mod n^(s+1): a single operand comes back reduced
+    p.op(VM_STORE, (uint32_t)n_ops);
     p.end();
-    SegSpec s{&mc, &p, memv, nullptr};
-    run_vm(ctx, nb, s, nullptr, true);
-    launch_canon(memv + 2 * sw, mc.d_nmod, mc.WT, nb, ctx->stream);
-    pack_result(ctx, memv + 2 * sw, mc.WT, nb, batch, out, out_stride, mc.nbytes, mem);
+    SegSpec sg{&mc, &p, memv, nullptr};
+    run_vm(ctx, nb, sg, nullptr, true);
+    launch_canon(memv + (size_t)n_ops * sw, mc.d_nmod, mc.WT, nb, ctx->stream);
+    pack_result(ctx, memv + (size_t)n_ops * sw, mc.WT, nb, batch, out, out_stride, mc.nbytes, mem);
     HIPCHK(hipStreamSynchronize(ctx->stream));
   });
 }
 
-int pgpu_sub(const pgpu_pubkey* pk, int level, size_t batch, const uint8_t* a, size_t a_stride, const uint8_t* b,
+int pgpu_add(const pgpu_pubkey* pk, int level, size_t batch, const uint8_t* a, size_t a_stride, const uint8_t* b,
              size_t b_stride, uint8_t* out, size_t out_stride, int mem) {
-  if (!pk) return fail(PGPU_ERR_INVALID, "null key");
+  if (a_stride != b_stride) return fail(PGPU_ERR_INVALID, "pgpu_add: both operands must share one stride");
+  const uint8_t* ops[2] = {a, b};
+  return pgpu_add_many(pk, level, 2, batch, ops, a_stride, out, out_stride, mem);
+}
+
+int pgpu_sub_many(const pgpu_pubkey* pk, int level, int n_ops, size_t batch, const uint8_t* const* ops, size_t stride,
+                  uint8_t* out, size_t out_stride, int mem, int32_t* status) {
+  if (!pk || !ops) return fail(PGPU_ERR_INVALID, "null argument");
   pgpu_ctx* ctx = pk->ctx;
   return guarded([&] {
-    check_batch_args(a, out, batch);
-    if (!b) api_throw(PGPU_ERR_INVALID, "null buffer");
+    if (n_ops < 1) api_throw(PGPU_ERR_INVALID, "Sub needs at least one operand (the reference indexes cts[0])");
+    check_batch_args(ops[0], out, batch);
     const ModCtx& mc = cipher_mod(pk, level);
     ctx->bind();
     ctx->reset_ws();
+    if (n_ops == 1) {
+      // operations.go:34-47: accumulator := cts[0].C and the loop body never runs -- the operand comes back UNREDUCED
+      if (out_stride < stride) api_throw(PGPU_ERR_INVALID, "single-operand Sub returns its operand: out_stride < stride");
+      if (mem == PGPU_MEM_HOST) {
+        for (size_t i = 0; i < batch; ++i) {
+          memset(out + i * out_stride, 0, out_stride - stride);
+          memcpy(out + i * out_stride + (out_stride - stride), ops[0] + i * stride, stride);
+        }
+      } else {
+        HIPCHK(hipMemsetAsync(out, 0, out_stride * batch, ctx->stream));
+        HIPCHK(hipMemcpy2DAsync(out + (out_stride - stride), out_stride, ops[0], stride, stride, batch, hipMemcpyDeviceToDevice,
+                                ctx->stream));
+        HIPCHK(hipStreamSynchronize(ctx->stream));
+      }
+      if (status) memset(status, 0, batch * sizeof(int32_t));
+      return;
+    }
     const size_t nb = round_up(batch, VM_BLOCK);
-    size_t sw = (size_t)mc.WT * nb;
-    uint32_t* memv = ctx->ws_t<uint32_t>(sw * 3);  // slots: 0 a, 1 b^-1, 2 out
-    unpack_operand(ctx, a, a_stride, std::min(a_stride, mc.nbytes), batch, mem, memv, mc.WT, nb);
-    uint32_t* bl = ctx->ws_t<uint32_t>(sw);
-    unpack_operand(ctx, b, b_stride, std::min(b_stride, mc.nbytes), batch, mem, bl, mc.WT, nb);
-    uint32_t* br = ctx->ws_t<uint32_t>(sw);
-    reduce_mod(ctx, mc, bl, mc.WT, br, nb);
-    uint32_t* binv = batch_inverse(ctx, mc, br, nb, batch);   // operations.go:43  neg = ModInverse(c.C, ns1)
-    HIPCHK(hipMemcpyAsync(memv + sw, binv, sw * 4, hipMemcpyDeviceToDevice, ctx->stream));
+    const size_t sw = (size_t)mc.WT * nb;
+    // slots: 0 minuend, 1..n-1 subtrahends, n denominator / its inverse, n+1 out
+    const uint32_t SD = (uint32_t)n_ops, SO = SD + 1;
+    uint32_t* memv = ctx->ws_t<uint32_t>(sw * (size_t)(n_ops + 2));
+    for (int k = 0; k < n_ops; ++k) {
+      if (!ops[k]) api_throw(PGPU_ERR_INVALID, "null operand buffer");
+      unpack_mod(ctx, mc, ops[k], stride, batch, mem, memv + (size_t)k * sw, nb);
+    }
+    // operations.go:43-47 inverts every subtrahend and multiplies the inverses in; the product of the inverses is the
+    // inverse of the product, so ONE inversion per ciphertext gives the same canonical residue
+    {
+      Prog p;
+      p.op(VM_LOAD, 1);
+      for (int k = 2; k < n_ops; ++k) { p.op(VM_MULC, C_R2); p.op(VM_MUL, (uint32_t)k); }
+      p.op(VM_MULC, C_R2); p.op(VM_MULC, C_ONE);      // reduce below 2N whatever the operand was
+      p.op(VM_STORE, SD);
+      p.end();
+      SegSpec sg{&mc, &p, memv, nullptr};
+      run_vm(ctx, nb, sg, nullptr, false);
+      launch_canon(memv + (size_t)SD * sw, mc.d_nmod, mc.WT, nb, ctx->stream);
+    }
+    int32_t* d_bad = ctx->ws_t<int32_t>(nb);
+    bool any_bad = false;
+    uint32_t* dinv = batch_inverse(ctx, mc, memv + (size_t)SD * sw, nb, batch, d_bad, &any_bad);   // operations.go:43 ModInverse
+    BadLanes bl;
+    bl.collect(ctx, d_bad, batch, any_bad);
+    HIPCHK(hipMemcpyAsync(memv + (size_t)SD * sw, dinv, sw * 4, hipMemcpyDeviceToDevice, ctx->stream));
     Prog p;
-    p.op(VM_LOAD, 0); p.op(VM_MULC, C_R2); p.op(VM_MUL, 1); p.op(VM_STORE, 2); p.end();   // operations.go:44-47
-    SegSpec s{&mc, &p, memv, nullptr};
-    run_vm(ctx, nb, s, nullptr, true);
-    launch_canon(memv + 2 * sw, mc.d_nmod, mc.WT, nb, ctx->stream);
-    pack_result(ctx, memv + 2 * sw, mc.WT, nb, batch, out, out_stride, mc.nbytes, mem);
+    p.op(VM_LOAD, 0); p.op(VM_MULC, C_R2); p.op(VM_MUL, SD); p.op(VM_STORE, SO); p.end();   // operations.go:44-47
+    SegSpec s2{&mc, &p, memv, nullptr};
+    run_vm(ctx, nb, s2, nullptr, true);
+    launch_canon(memv + (size_t)SO * sw, mc.d_nmod, mc.WT, nb, ctx->stream);
+    pack_result(ctx, memv + (size_t)SO * sw, mc.WT, nb, batch, out, out_stride, mc.nbytes, mem);
     HIPCHK(hipStreamSynchronize(ctx->stream));
+    bl.finish(status, batch);
   });
+}
+
+int pgpu_sub(const pgpu_pubkey* pk, int level, size_t batch, const uint8_t* a, size_t a_stride, const uint8_t* b,
+             size_t b_stride, uint8_t* out, size_t out_stride, int mem, int32_t* status) {
+  if (a_stride != b_stride) return fail(PGPU_ERR_INVALID, "pgpu_sub: both operands must share one stride");
+  const uint8_t* ops[2] = {a, b};
+  return pgpu_sub_many(pk, level, 2, batch, ops, a_stride, out, out_stride, mem, status);
 }
 
 int pgpu_partial_decrypt(const pgpu_pubkey* pk, int total_servers, const uint8_t* share_be, size_t share_len, size_t batch,
@@ -2002,7 +2160,7 @@ int pgpu_partial_decrypt(const pgpu_pubkey* pk, int total_servers, const uint8_t
     // thresholdkey.go:195: exp = Share * (2 * delta), delta = l!
     BigU e = BigU::from_be(share_be, share_len) * (BigU(2) * factorial_big(total_servers));
     ModexpPlan pl = modexp_alloc(ctx, mc, nb, 32);
-    unpack_operand(ctx, c, c_stride, std::min(c_stride, mc.nbytes), batch, mem, pl.in(), mc.WT, nb);
+    unpack_mod(ctx, mc, c, c_stride, batch, mem, pl.in(), nb);
     modexp_shared_run(ctx, mc, pl, e, false, false, true);
     pack_result(ctx, pl.out(), mc.WT, nb, batch, out, out_stride, mc.nbytes, mem);
     HIPCHK(hipStreamSynchronize(ctx->stream));
@@ -2011,7 +2169,7 @@ int pgpu_partial_decrypt(const pgpu_pubkey* pk, int total_servers, const uint8_t
 
 int pgpu_combine_partial_decryptions(const pgpu_pubkey* pk, int total_servers, int threshold, int n_shares, const int* ids,
                                      size_t batch, const uint8_t* const* partials, size_t stride, uint8_t* m,
-                                     size_t m_stride, int mem) {
+                                     size_t m_stride, int mem, int32_t* status) {
   if (!pk || !ids || !partials) return fail(PGPU_ERR_INVALID, "null argument");
   pgpu_ctx* ctx = pk->ctx;
   return guarded([&] {
@@ -2042,7 +2200,7 @@ int pgpu_combine_partial_decryptions(const pgpu_pubkey* pk, int total_servers, i
     uint32_t* mem_v = ctx->ws_t<uint32_t>(sw * (size_t)(n_shares + 3));
     for (int i = 0; i < n_shares; ++i) {
       if (!partials[i]) api_throw(PGPU_ERR_INVALID, "null partial buffer");
-      unpack_operand(ctx, partials[i], stride, std::min(stride, mn2.nbytes), batch, mem, mem_v + (size_t)i * sw, mn2.WT, nb);
+      unpack_mod(ctx, mn2, partials[i], stride, batch, mem, mem_v + (size_t)i * sw, nb);
     }
     // numerator = prod over lambda_i >= 0 of c_i^(2 lambda_i); denominator = prod over lambda_i < 0 of c_i^|2 lambda_i|.
     // (thresholdkey.go:132-138 inverts each negative factor separately; the product of inverses is the inverse of
@@ -2072,10 +2230,13 @@ int pgpu_combine_partial_decryptions(const pgpu_pubkey* pk, int total_servers, i
     p.end();
     SegSpec sg{&mn2, &p, mem_v, nullptr};
     run_vm(ctx, nb, sg, nullptr, true);
-    uint32_t* cprime = ctx->ws_t<uint32_t>(sw * 2);
+    BadLanes bl;
     if (have_den) {
       launch_canon(mem_v + SDEN * sw, mn2.d_nmod, mn2.WT, nb, ctx->stream);
-      uint32_t* dinv = batch_inverse(ctx, mn2, mem_v + SDEN * sw, nb, batch);   // thresholdkey.go:135 ModInverse
+      int32_t* d_bad = ctx->ws_t<int32_t>(nb);
+      bool any_bad = false;
+      uint32_t* dinv = batch_inverse(ctx, mn2, mem_v + SDEN * sw, nb, batch, d_bad, &any_bad);   // thresholdkey.go:135 ModInverse
+      bl.collect(ctx, d_bad, batch, any_bad);
       HIPCHK(hipMemcpyAsync(mem_v + SDEN * sw, dinv, sw * 4, hipMemcpyDeviceToDevice, ctx->stream));
     }
     {
@@ -2088,7 +2249,6 @@ int pgpu_combine_partial_decryptions(const pgpu_pubkey* pk, int total_servers, i
       run_vm(ctx, nb, sq, nullptr, false);
       launch_canon(mem_v + SB * sw, mn2.d_nmod, mn2.WT, nb, ctx->stream);
     }
-    (void)cprime;
     // thresholdkey.go:143-146: L(cprime) * (4 delta^2)^-1 mod n   (combineSharesConstant, :63-66)
     pgpu_pubkey* pkm = const_cast<pgpu_pubkey*>(pk);
     int cidx = -1;
@@ -2102,9 +2262,10 @@ int pgpu_combine_partial_decryptions(const pgpu_pubkey* pk, int total_servers, i
       pkm->combine_consts.push_back({total_servers, cidx});
     }
     uint32_t* negc = ctx->upload_words(((pk->N - cconst) % pk->N).to_limbs(LB, mn.WT));
-    uint32_t* res = L_times_const(ctx, pk, mem_v + SB * sw, nb, batch, cidx, negc);
+    uint32_t* res = L_times_const(ctx, pk, mem_v + SB * sw, nb, batch, pk->mn, cidx, negc);
     pack_result(ctx, res, mn.WT, nb, batch, m, m_stride, mn.nbytes, mem);
     HIPCHK(hipStreamSynchronize(ctx->stream));
+    bl.finish(status, batch);   // a share that is not a unit modulo n^2 (mpz_invert undefined in the reference): flagged per lane
   });
 }
 
@@ -2239,6 +2400,7 @@ const pgpu_pubkey::FixedBase& ensure_fixed_base(pgpu_pubkey* pk, const BigU& bas
 // x^e mod n^2 for a uniform base with a comb table and per-number exponents (limb-major [we][nb]); result canonical in `out`
 void comb_pow(pgpu_ctx* ctx, const ModCtx& mc, const pgpu_pubkey::FixedBase& fb, const uint32_t* exps, int we, size_t nb,
               uint32_t* out) {
+  if (we * 7 > fb.nwin + 6) api_throw(PGPU_ERR_INVALID, "fixed-base table narrower than the exponent");   // callers size the table
   const int nwin = std::min(fb.nwin, we * 7);
   size_t sw = (size_t)mc.WT * nb;
   uint32_t* memv = ctx->ws_t<uint32_t>(sw);
@@ -2532,7 +2694,9 @@ int pgpu_share_zkp_prove(const pgpu_pubkey* pk, int total_servers, const uint8_t
     const ModCtx& mc = pk->mn2;
     const int W2 = mc.WT;
     const BigU share = BigU::from_be(share_be, share_len), delta = factorial_big(total_servers);
-    const pgpu_pubkey::FixedBase fb = ensure_fixed_base(const_cast<pgpu_pubkey*>(pk), BigU::from_be(vkey_be, vkey_len), mc.nbits + 384);
+    if (r_stride > mc.nbytes + 96) api_throw(PGPU_ERR_INVALID, "r stride larger than the byte length of n^2 plus 96 (r < n^2, thresholdkey.go:233)");
+    const pgpu_pubkey::FixedBase fb = ensure_fixed_base(const_cast<pgpu_pubkey*>(pk), BigU::from_be(vkey_be, vkey_len),
+                                                        std::max(mc.nbits + 384, r_stride * 8));
     ctx->reset_ws();
     const size_t nb = round_up(batch, VM_BLOCK);
     const size_t sw = (size_t)W2 * nb;
@@ -2594,7 +2758,10 @@ int pgpu_share_zkp_verify(const pgpu_pubkey* pk, const uint8_t* vkey_be, size_t 
     const ModCtx& mc = pk->mn2;
     const int W2 = mc.WT;
     pgpu_pubkey* pkm = const_cast<pgpu_pubkey*>(pk);
-    const size_t zbits = z_stride * 8;
+    // Z = r + E * l! * s_i with r < n^2, E < 2^256, s_i < n^2: at most ~n^2 bits + 256 + log2(l!) bits.  The stride sizes a
+    // table that is kept with the key: bound it (an unbounded caller-chosen stride would grow the key without limit).
+    if (z_stride > mc.nbytes + 96) api_throw(PGPU_ERR_INVALID, "z stride larger than the byte length of n^2 plus 96");
+    const size_t zbits = std::max(z_stride * 8, mc.nbits + 384);
     const pgpu_pubkey::FixedBase fbV = ensure_fixed_base(pkm, BigU::from_be(vkey_be, vkey_len), zbits);
     const pgpu_pubkey::FixedBase fbI = ensure_fixed_base(pkm, BigU::from_be(vi_be, vi_len), 256);
     ctx->reset_ws();
@@ -2637,10 +2804,14 @@ int pgpu_share_zkp_verify(const pgpu_pubkey* pk, const uint8_t* vkey_be, size_t 
     perlane_pow(ctx, mc, d2m, el, 10, nb, a2);
     comb_pow(ctx, mc, fbV, zl, wz, nb, b1);
     comb_pow(ctx, mc, fbI, el, 10, nb, b2);
-    uint32_t* a2i = batch_inverse(ctx, mc, a2, nb, batch);
+    // A proof whose Decryption (or v_i) is not a unit has no inverse: mpz_invert leaves the reference's a2 / b2 undefined
+    // and the hash comparison fails; here such a lane is rejected (ok = 0) without disturbing the other proofs.
+    int32_t* bad_a = ctx->ws_t<int32_t>(nb);
+    int32_t* bad_b = ctx->ws_t<int32_t>(nb);
+    uint32_t* a2i = batch_inverse(ctx, mc, a2, nb, batch, bad_a);
     uint32_t* av = ctx->ws_t<uint32_t>(sw);
     modmul_arrays(ctx, mc, a1, a2i, nb, av);
-    uint32_t* b2i = batch_inverse(ctx, mc, b2, nb, batch);
+    uint32_t* b2i = batch_inverse(ctx, mc, b2, nb, batch, bad_b);
     uint32_t* bv = ctx->ws_t<uint32_t>(sw);
     modmul_arrays(ctx, mc, b1, b2i, nb, bv);
     uint32_t* dg = zkp_hash(ctx, W2, av, bv, cl, dl, nb, batch);
@@ -2648,6 +2819,8 @@ int pgpu_share_zkp_verify(const pgpu_pubkey* pk, const uint8_t* vkey_be, size_t 
     launch_digest_to_limbs(dg, e2, nb, ctx->stream);
     int32_t* d_ok = ctx->ws_t<int32_t>(nb);
     launch_equal(e2, el, 10, nb, batch, d_ok, ctx->stream);
+    launch_clear_where(bad_a, batch, d_ok, ctx->stream);
+    launch_clear_where(bad_b, batch, d_ok, ctx->stream);
     HIPCHK(hipMemcpyAsync(ok, d_ok, batch * 4, hipMemcpyDeviceToHost, ctx->stream));
     HIPCHK(hipStreamSynchronize(ctx->stream));
   });
@@ -2666,7 +2839,7 @@ int pgpu_const_mult(const pgpu_pubkey* pk, int level, size_t batch, const uint8_
     const size_t nb = round_up(batch, VM_BLOCK);
     const bool perlane = k_stride != 0;
     ModexpPlan pl = modexp_alloc(ctx, mc, nb, perlane ? 16 : 32);
-    unpack_operand(ctx, c, c_stride, std::min(c_stride, mc.nbytes), batch, mem, pl.in(), mc.WT, nb);
+    unpack_mod(ctx, mc, c, c_stride, batch, mem, pl.in(), nb);
     if (!perlane) {
       modexp_shared_run(ctx, mc, pl, BigU::from_be(k, k_len), false, false, true);
     } else {

@@ -69,3 +69,8 @@ void launch_equal(const uint32_t* a, const uint32_t* b, int w, size_t nb, size_t
 void launch_select(const int32_t* flags, const uint32_t* a, const uint32_t* b, uint32_t* out, int w, size_t nb, hipStream_t st);
 void launch_mul_plain(const uint32_t* a, int wa, const uint32_t* b, int wb, uint32_t* out, size_t nb, hipStream_t st);
 void launch_digest_to_limbs(const uint32_t* dg, uint32_t* out, size_t nb, hipStream_t st);
+// slow path of batch_inverse: flags[g] = gcd(x[g], N) != 1 (binary GCD per lane; work = 2*w*nb words of scratch)
+void launch_unit_flags(const uint32_t* x, const uint32_t* nmod, int w, size_t nb, size_t count, uint32_t* work, int32_t* flags,
+                       hipStream_t st);
+void launch_or_flags(const int32_t* flags, size_t count, int32_t* status, int32_t flag, hipStream_t st);
+void launch_clear_where(const int32_t* flags, size_t count, int32_t* ok, hipStream_t st);

@@ -117,11 +117,11 @@ template <int WL, int K>
 static hipError_t launch_vm_t(const VmArgs& a, uint32_t blocks, hipStream_t st) {
   constexpr int WT = WL * K;
   const size_t lds = (size_t)(((WT + 3) & ~3) + WT * (VM_BLOCK / K)) * 4;
-  static bool attr_set = false;
-  if (!attr_set) {
+  // the attribute is per device: set it before every launch (a cheap host-side call) rather than caching one flag per
+  // template instantiation, which would leave a second GPU of the same process without it
+  if (lds > 48 * 1024) {
     hipError_t e = hipFuncSetAttribute((const void*)vm_kernel<WL, K>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) return e;
-    attr_set = true;
   }
   hipLaunchKernelGGL((vm_kernel<WL, K>), dim3(blocks), dim3(VM_BLOCK), lds, st, a);
   return hipGetLastError();
@@ -652,6 +652,79 @@ __global__ void k_select(const int32_t* __restrict__ flags, const uint32_t* __re
   for (int l = 0; l < w; ++l) out[(size_t)l * nb + g] = src[(size_t)l * nb + g];
 }
 
+
+// flags[g] = (gcd(x, N) != 1) for canonical x and the odd modulus N: a per-lane binary GCD on limb-major work arrays
+// (work: [2][w][nb]).  SLOW PATH ONLY -- it runs when the one inversion of batch_inverse's product tree fails, i.e. when
+// some element of the batch is not a unit (hostile or malformed input), to find out WHICH lanes those are; mpz_invert
+// gives the reference the same information per call.  O(bits) iterations of O(w) limb operations per lane, divergent.
+__global__ void k_unit_flags(const uint32_t* __restrict__ x, const uint32_t* __restrict__ nmod, int w, size_t nb, size_t count,
+                             uint32_t* __restrict__ work, int32_t* __restrict__ flags) {
+  size_t g = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (g >= nb) return;
+  if (g >= count) { flags[g] = 0; return; }
+  uint32_t* A = work + g;
+  uint32_t* B = work + (size_t)w * nb + g;
+  int la = 0, lb = 0;
+  for (int l = 0; l < w; ++l) {
+    const uint32_t v = x[(size_t)l * nb + g], m = nmod[l];
+    A[(size_t)l * nb] = v;
+    B[(size_t)l * nb] = m;
+    if (v) la = l + 1;
+    if (m) lb = l + 1;
+  }
+  // invariant: B is odd.  gcd(A, B) is preserved by A >>= 1 (A even) and by (A, B) <- (|A - B|, min(A, B)).
+  while (la > 0) {
+    const uint32_t a0 = A[0];
+    if (a0 == 0) {                               // a whole zero limb: shift right by 28 bits
+      for (int l = 0; l + 1 < la; ++l) A[(size_t)l * nb] = A[(size_t)(l + 1) * nb];
+      A[(size_t)(la - 1) * nb] = 0;
+      --la;
+      continue;
+    }
+    const int s = __builtin_ctz(a0);
+    if (s) {
+      uint32_t cur = a0;
+      for (int l = 0; l < la; ++l) {
+        const uint32_t nxt = (l + 1 < la) ? A[(size_t)(l + 1) * nb] : 0u;
+        A[(size_t)l * nb] = ((cur >> s) | (nxt << (LB - s))) & LMASK;
+        cur = nxt;
+      }
+      if (A[(size_t)(la - 1) * nb] == 0) --la;
+    }
+    int cmp = la - lb;
+    if (cmp == 0)
+      for (int l = la - 1; l >= 0; --l) {
+        const uint32_t av = A[(size_t)l * nb], bv = B[(size_t)l * nb];
+        if (av != bv) { cmp = av > bv ? 1 : -1; break; }
+      }
+    if (cmp == 0) break;                         // A == B: the gcd is B
+    if (cmp < 0) {
+      uint32_t* t = A; A = B; B = t;
+      const int tl = la; la = lb; lb = tl;
+    }
+    int32_t br = 0;                              // A -= B  (A > B, both odd: the difference is even)
+    for (int l = 0; l < la; ++l) {
+      const int32_t d = (int32_t)A[(size_t)l * nb] - (l < lb ? (int32_t)B[(size_t)l * nb] : 0) - br;
+      br = d < 0;
+      A[(size_t)l * nb] = (uint32_t)(d + (br << LB)) & LMASK;
+    }
+    while (la > 0 && A[(size_t)(la - 1) * nb] == 0) --la;
+  }
+  flags[g] = !(lb == 1 && B[0] == 1u);
+}
+
+// status[g] |= flag where flags[g] != 0 (g < count)
+__global__ void k_or_flags(const int32_t* __restrict__ flags, size_t count, int32_t* __restrict__ status, int32_t flag) {
+  size_t g = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (g < count && flags[g]) status[g] |= flag;
+}
+
+// ok[g] = 0 where flags[g] != 0
+__global__ void k_clear_where(const int32_t* __restrict__ flags, size_t count, int32_t* __restrict__ ok) {
+  size_t g = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (g < count && flags[g]) ok[g] = 0;
+}
+
 #define HELPER_GRID(nb) dim3((unsigned)(((nb) + 255) / 256)), dim3(256)
 
 void launch_unpack_be(const uint8_t* in, size_t stride, size_t nbytes, size_t count, uint32_t* out, int wt, size_t nb, hipStream_t st) {
@@ -773,4 +846,14 @@ void launch_mul_plain(const uint32_t* a, int wa, const uint32_t* b, int wb, uint
 }
 void launch_digest_to_limbs(const uint32_t* dg, uint32_t* out, size_t nb, hipStream_t st) {
   hipLaunchKernelGGL(k_digest_to_limbs, HELPER_GRID(nb), 0, st, dg, out, nb);
+}
+void launch_unit_flags(const uint32_t* x, const uint32_t* nmod, int w, size_t nb, size_t count, uint32_t* work, int32_t* flags,
+                       hipStream_t st) {
+  hipLaunchKernelGGL(k_unit_flags, dim3((unsigned)((nb + 63) / 64)), dim3(64), 0, st, x, nmod, w, nb, count, work, flags);
+}
+void launch_or_flags(const int32_t* flags, size_t count, int32_t* status, int32_t flag, hipStream_t st) {
+  hipLaunchKernelGGL(k_or_flags, HELPER_GRID(count ? count : 1), 0, st, flags, count, status, flag);
+}
+void launch_clear_where(const int32_t* flags, size_t count, int32_t* ok, hipStream_t st) {
+  hipLaunchKernelGGL(k_clear_where, HELPER_GRID(count ? count : 1), 0, st, flags, count, ok);
 }

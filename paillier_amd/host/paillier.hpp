@@ -128,7 +128,8 @@ class PublicKey {  // paillier.go:46-57
     for (auto& c : b) bs.push_back(c.C);
     auto pa = pack(as, cb), pb = pack(bs, cb);
     std::vector<uint8_t> out(a.size() * cb);
-    check((sub ? pgpu_sub : pgpu_add)(h_, level, a.size(), pa.data(), cb, pb.data(), cb, out.data(), cb, PGPU_MEM_HOST));
+    check(sub ? pgpu_sub(h_, level, a.size(), pa.data(), cb, pb.data(), cb, out.data(), cb, PGPU_MEM_HOST, nullptr)
+              : pgpu_add(h_, level, a.size(), pa.data(), cb, pb.data(), cb, out.data(), cb, PGPU_MEM_HOST));
     std::vector<Ciphertext> res;
     for (auto& v : unpack(out, cb)) res.push_back({v, level});
     return res;
@@ -185,7 +186,7 @@ class ThresholdPublicKey : public PublicKey {  // thresholdkey.go:26-32
     size_t batch = shares.empty() ? 0 : shares[0].Decryption.size();
     std::vector<uint8_t> out(batch * pb);
     check(pgpu_combine_partial_decryptions(h_, TotalNumberOfDecryptionServers, Threshold, (int)shares.size(), ids.data(), batch,
-                                           ptrs.data(), cb, out.data(), pb, PGPU_MEM_HOST));
+                                           ptrs.data(), cb, out.data(), pb, PGPU_MEM_HOST, nullptr));
     return unpack(out, pb);
   }
 };

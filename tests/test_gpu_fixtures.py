@@ -1,0 +1,179 @@
+"""GPU parity against the committed fixtures of the proof / threshold / level-two paths at the BASELINE key size
+(tests/golden/proofs.json: 2048-bit keys, written by make_golden.py from the Python-int oracle and re-derived by the
+libgmp oracle in tests/test_golden_proofs.py).  Nothing here is computed by an oracle at test time: the HIP path, through
+the C ABI, against committed numbers.
+
+BASELINE config 5 (DDLEQ, 2048 bits) runs at its real size: 64 (statement, instance) pairs, so n^3 is 6144 bits and the
+prover takes pow_n3_crt over p^3 / q^3 with the interleaved ladders, the verifier the 6144-bit interleaved ladder."""
+import hashlib
+import json
+import os
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+G = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+
+
+def load(name):
+    with open(os.path.join(G, name)) as f:
+        return json.load(f)
+
+
+def H(xs):
+    return [int(x, 16) for x in xs]
+
+
+@pytest.fixture(scope="module")
+def ctx():
+    import paillier_amd as pa
+    return pa.Context(0)
+
+
+@pytest.fixture(scope="module")
+def keys(ctx):
+    import paillier_amd as pa
+    k = load("keys.json")["paillier"]["2048"]
+    n, lam = int(k["n"], 16), int(k["lambda"], 16)
+    pk = pa.PublicKey(ctx, n, n + 1)
+    return pk, pa.SecretKey(ctx, pk, lam)
+
+
+def test_ddleq_2048_prove_and_verify(ctx, keys):
+    """pgpu_ddleq_prove / pgpu_ddleq_verify (ddleq.go:55-153) on 64 instances of 4 statements, both challenge bits."""
+    pk, sk = keys
+    d = load("proofs.json")["ddleq"]
+    st = [{k: int(v, 16) for k, v in s.items()} for s in d["statements"]]
+    ins = d["instances"]
+    col = lambda key: [st[i["s"]][key] for i in ins]
+    xs, ys = H(i["x"] for i in ins), H(i["y"] for i in ins)
+    al, es, fs = sk.ProveDDLEQInstancesBatch(col("ct1"), col("ct2"), col("a"), col("b"), xs, ys)
+    assert ctx.last_vm_asm() > 0
+    dg = [hashlib.sha256(a.to_bytes(768, "big") + e.to_bytes(512, "big") + f.to_bytes(768, "big")).hexdigest()
+          for a, e, f in zip(al, es, fs)]
+    assert dg == [i["digest"] for i in ins]
+    for i, rec in enumerate(ins[:16]):
+        assert (al[i], es[i], fs[i]) == (int(rec["alpha"], 16), int(rec["e"], 16), int(rec["f"], 16))
+    bits = [int(e != x or f != y) for e, f, x, y in zip(es, fs, xs, ys)]
+    assert bits == [i["bit"] for i in ins] and 0 < sum(bits) < 64
+    assert pk.VerifyDDLEQInstancesBatch(col("ct1"), col("ct2"), xs, ys, al, es, fs) == [True] * 64
+    wrong = [st[(i["s"] + 1) % 4]["ct2"] for i in ins]
+    got = pk.VerifyDDLEQInstancesBatch(col("ct1"), wrong, xs, ys, al, es, fs)
+    assert got == [bool(i["verify_wrong_ct2"]) for i in ins] and not all(got)
+    # tampered responses are rejected
+    es2, fs2 = list(es), list(fs)
+    es2[0] ^= 1
+    fs2[1] ^= 1
+    got = pk.VerifyDDLEQInstancesBatch(col("ct1"), col("ct2"), xs, ys, al, es2, fs2)
+    assert got[:2] == [False, False] and all(got[2:])
+    # a false statement: the reference panics (ddleq.go:68)
+    import paillier_amd as pa
+    with pytest.raises(pa.PaillierHipError) as ei:
+        sk.ProveDDLEQInstancesBatch(col("ct1")[:4], wrong[:4], col("a")[:4], col("b")[:4], xs[:4], ys[:4])
+    assert "cannot prove re-encryption" in str(ei.value)
+
+
+def test_ddleq_2048_kernels_off(ctx, keys):
+    """The same fixture with the assembly / pair kernels switched off (hipcc VM kernels, ladders modulo n^3 instead of
+    p^3, q^3): every implementation of the path must land on the committed numbers."""
+    pk, sk = keys
+    d = load("proofs.json")["ddleq"]
+    st = [{k: int(v, 16) for k, v in s.items()} for s in d["statements"]]
+    ins = d["instances"][:16]
+    col = lambda key: [st[i["s"]][key] for i in ins]
+    xs, ys = H(i["x"] for i in ins), H(i["y"] for i in ins)
+    ctx.set_flag("pair", 0)
+    try:
+        al, es, fs = sk.ProveDDLEQInstancesBatch(col("ct1"), col("ct2"), col("a"), col("b"), xs, ys)
+    finally:
+        ctx.set_flag("pair", 1)
+    assert (al, es, fs) == (H(i["alpha"] for i in ins), H(i["e"] for i in ins), H(i["f"] for i in ins))
+    ctx.set_flag("asm", 0)
+    try:
+        assert pk.VerifyDDLEQInstancesBatch(col("ct1"), col("ct2"), xs, ys, al, es, fs) == [True] * len(ins)
+    finally:
+        ctx.set_flag("asm", 1)
+
+
+def test_encrypt_2048_on_the_full_batch_kernel(ctx, keys):
+    """EncryptWithR at 2048 bits with lanes_wanted = 1: the batch keeps the kernel shape a 65 536-ciphertext batch uses
+    (vm_asm_74_32, the two-lane pair kernel) instead of the small-batch re-slicing, and is compared with the committed c."""
+    pk, sk = keys
+    e = load("vectors.json")["2048"]["encrypt"]
+    ctx.set_flag("lanes_wanted", 1)
+    try:
+        assert pk.EncryptWithRBatch(H(e["m"]), H(e["r"])) == H(e["c"])
+        assert ctx.last_vm_asm() > 0
+        d = load("vectors.json")["2048"]["decrypt"]
+        assert sk.DecryptBatch(H(d["c"])) == H(d["m"])
+        l2 = load("proofs.json")["level2"]
+        import paillier_amd as pa
+        assert pk.EncryptWithRBatch(H(l2["m"]), H(l2["r"]), level=pa.ENC_LEVEL_TWO) == H(l2["c"])
+    finally:
+        ctx.set_flag("lanes_wanted", 0)
+
+
+def test_sub_and_level_two(ctx, keys):
+    import paillier_amd as pa
+    pk, sk = keys
+    P = load("proofs.json")
+    s = P["sub"]
+    assert pk.SubBatch(H(s["l1"]["a"]), H(s["l1"]["b"])) == H(s["l1"]["out"])
+    assert pk.SubBatch(H(s["l2"]["a"]), H(s["l2"]["b"]), level=pa.ENC_LEVEL_TWO) == H(s["l2"]["out"])
+    a3, s3 = s["add3"], s["sub3"]
+    assert pk.AddBatch(H(a3["a"]), H(a3["b"]), H(a3["c"])) == H(a3["out"])          # operations.go:11 variadic
+    assert pk.SubBatch(H(s3["a"]), H(s3["b"]), H(s3["c"])) == H(s3["out"])          # operations.go:32 variadic
+    one = s["sub1_unreduced"]
+    assert pk.SubBatch([int(one["a"], 16)]) == [int(one["out"], 16)]                # single operand: returned as is
+    l2 = P["level2"]
+    cts = pk.EncryptWithRBatch(H(l2["m"]), H(l2["r"]), level=pa.ENC_LEVEL_TWO)
+    assert cts == H(l2["c"])
+    assert sk.DecryptBatch(cts, level=pa.ENC_LEVEL_TWO) == H(l2["m"])
+    assert sk.DecryptBatch(H(l2["weird_c"]), level=pa.ENC_LEVEL_TWO) == H(l2["weird_m"])
+    assert sk.DecryptBatch(H(l2["weird_c"]), level=pa.ENC_LEVEL_TWO, flags=pa.DECRYPT_NO_CRT) == H(l2["weird_m"])
+
+
+def test_random_oracle_digest_fixture(ctx):
+    """RandomOracleDigest (random_oracle.go:20-32) on the device: the caller drops argument 0, zero arguments are empty."""
+    rows = load("proofs.json")["random_oracle"]
+    for row in rows:
+        args = H(row["args"])[1:]
+        if not args:
+            continue
+        got = ctx.random_oracle_digest_batch([[a] * 3 for a in args])
+        assert [g.hex() for g in got] == [row["digest"]] * 3
+        assert got[0][-1] & 1 == row["bit"]
+
+
+def test_threshold_fixture(ctx):
+    import paillier_amd as pa
+    P = load("proofs.json")
+    t = load("keys.json")["threshold"]["2048"]
+    tn, total, thr = int(t["n"], 16), t["total"], t["threshold"]
+    shares, v, vks = H(t["shares"]), int(t["v"], 16), H(t["vks"])
+    tk = pa.ThresholdPublicKey(ctx, tn, total=total, threshold=thr)
+    th = P["threshold"]
+    cs, parts = H(th["c"]), [H(r) for r in th["partials"]]
+    for i in range(total):
+        assert tk.PartialDecryptBatch(i + 1, shares[i], cs) == (i + 1, parts[i])
+    for c in th["combine"]:
+        assert tk.CombinePartialDecryptionsBatch([(i, parts[i - 1]) for i in c["ids"]]) == H(c["m"]), c["ids"]
+    tam = th["tampered"]
+    bad = [(i, [x ^ tam["xor_server3"] for x in parts[i - 1]] if i == 3 else parts[i - 1]) for i in tam["ids"]]
+    assert tk.CombinePartialDecryptionsBatch(bad) == H(tam["m"])
+    z = P["share_zkp"]
+    sid, recs = z["server"], z["proofs"]
+    cts, rs = H(r["c"] for r in recs), H(r["r"] for r in recs)
+    dec, es, zs = tk.PartialDecryptionWithZKPBatch(sid, shares[sid - 1], v, cts, rs)
+    assert dec == H(r["dec"] for r in recs)
+    assert es == H(r["e"] for r in recs)
+    assert zs == H(r["z"] for r in recs)
+    assert tk.VerifyProofBatch(v, vks[sid - 1], cts, dec, es, zs) == [True] * len(recs)
+    # the two hashed residues of the verifier (thresholdkey.go:294-311), recomputed from GPU primitives
+    m2 = pa.Modulus(ctx, tn * tn)
+    c4 = tk.ConstMultBatch(cts, 4)
+    a = m2.mul_batch(m2.exp_batch(c4, zs), m2.inv_batch(m2.exp_batch(m2.mul_batch(dec, dec), es)))
+    assert a == H(r["verify_a"] for r in recs)
+    digests = ctx.random_oracle_digest_batch([H(r["a"] for r in recs), H(r["b"] for r in recs), H(r["c4"] for r in recs),
+                                              H(r["ci2"] for r in recs)])
+    assert [int.from_bytes(g, "big") for g in digests] == es
