@@ -7,6 +7,8 @@
 #include <stdlib.h>
 #include <string.h>
 #include <memory>
+#include <mutex>
+#include <set>
 #include <string>
 #include <vector>
 
@@ -636,6 +638,15 @@ static BigU inv_mod_pow2(const BigU& d, size_t bits) {
   return out;
 }
 
+// Contexts that are alive: a key handle may outlive its context (garbage-collected bindings destroy in any order), so
+// nothing dereferences a key's context pointer on the way out without looking here first.
+static std::mutex g_live_mu;
+static std::set<pgpu_ctx*> g_live_ctx;
+static bool ctx_alive(pgpu_ctx* c) {
+  std::lock_guard<std::mutex> lk(g_live_mu);
+  return g_live_ctx.count(c) != 0;
+}
+
 extern "C" {
 
 const char* pgpu_last_error(void) { return g_err.c_str(); }
@@ -655,12 +666,14 @@ int pgpu_ctx_create(int device, void* stream, pgpu_ctx** out) {
   c->stream = (hipStream_t)stream;
   int rc = guarded([&] { c->bind(); });
   if (rc != PGPU_OK) { delete c; return rc; }
+  { std::lock_guard<std::mutex> lk(g_live_mu); g_live_ctx.insert(c); }
   *out = c;
   return PGPU_OK;
 }
 
 void pgpu_ctx_destroy(pgpu_ctx* ctx) {
   if (!ctx) return;
+  { std::lock_guard<std::mutex> lk(g_live_mu); g_live_ctx.erase(ctx); }
   (void)hipSetDevice(ctx->device);
   (void)hipStreamSynchronize(ctx->stream);
   delete ctx;
@@ -1388,8 +1401,10 @@ int pgpu_seckey_create(pgpu_ctx* ctx, const pgpu_pubkey* pk, const uint8_t* lamb
 }
 void pgpu_seckey_destroy(pgpu_seckey* sk) {
   if (!sk) return;
-  (void)hipSetDevice(sk->ctx->device);
-  sk->ctx->wipe_ws();   // the workspace may still hold this key's ladder programs and intermediate residues
+  if (ctx_alive(sk->ctx)) {   // (a context destroyed earlier wiped its workspace itself)
+    (void)hipSetDevice(sk->ctx->device);
+    sk->ctx->wipe_ws();       // the workspace may still hold this key's ladder programs and intermediate residues
+  }
   delete sk;
 }
 int pgpu_seckey_has_crt(const pgpu_seckey* sk) { return sk && sk->has_crt; }

@@ -124,7 +124,8 @@ def test_wide_strides_are_reduced_not_truncated(ctx):
         k = rng.randrange(n)
         kb = np.frombuffer(k.to_bytes(128, "big"), dtype=np.uint8).copy()
         out = np.zeros((6, cb), dtype=np.uint8)
-        rc = ctx.lib.pgpu_const_mult(pk.h, 0, 6, _ptr(ints_to_be(big, st)), st, _ptr(kb), 128, 0, _ptr(out), cb, MEM_HOST)
+        cbuf = ints_to_be(big, st)           # (keep the array alive across the call: _ptr() only takes its address)
+        rc = ctx.lib.pgpu_const_mult(pk.h, 0, 6, _ptr(cbuf), st, _ptr(kb), 128, 0, _ptr(out), cb, MEM_HOST)
         assert rc == 0
         assert be_to_ints(out) == [pow(c, k, n2) for c in big]
         assert pk.AddBatch(big, big[::-1]) == [a * b % n2 for a, b in zip(big, big[::-1])]
