@@ -1,21 +1,25 @@
 #!/usr/bin/env python3
-"""bench.py -- headline benchmark: 2048-bit Paillier decryptions/s on N MI355X (BASELINE.json `metric`).
+"""bench.py -- headline benchmark: 2048-bit Paillier decryptions/s on N MI355X (BASELINE.json `metric`), plus the other
+four BASELINE configs as `extra_configs` of the same JSON line.
 
-One "step" = one pass of the hot path (SecretKey.Decrypt, paillier.go:292-303, for a whole batch) over one
-batch of synthetic ciphertexts that are already resident in HBM (big-endian, element-major: the C-ABI operand
-format).  The timed region contains everything a caller pays per batch: unpack -> CRT modexp over p^2 and
-q^2 (the VM kernel) -> L / CRT recombination -> pack.  Results are checked bit-exactly after the timed
-region (decrypt(encrypt(m, r)) == m for the full batch, plus an oracle spot check on rank 0).
+One "step" = one pass of the hot path (SecretKey.Decrypt, paillier.go:292-303, for a whole batch) over one batch of
+synthetic ciphertexts that are already resident in HBM (big-endian, element-major: the C-ABI operand format).  The timed
+region contains everything a caller pays per batch: unpack -> CRT modexp over p^2 and q^2 (the VM kernel) -> L / CRT
+recombination -> pack.  Results are checked bit-exactly after the timed region (decrypt(encrypt(m, r)) == m for the full
+batch on every rank, plus sample checks on rank 0 in the CPU leg).
 
-N > 1: launched by torch.distributed.run, one rank per GPU.  Ciphertext batches shard with no data-path
-collective (scaling = weak: every rank decrypts its own `--batch`); RCCL is used for the barrier and the
-MAX-over-ranks time only.
+N > 1: `python bench.py --gpus N` starts its own N ranks (torch.distributed.run, one process per GPU, RCCL) unless it is
+already running under a launcher (WORLD_SIZE set).  Ciphertext batches shard with no data-path collective (scaling = weak:
+every rank decrypts its own `--batch`); RCCL carries the barrier, the MAX-over-ranks time and -- in the threshold extra
+config -- the one real exchange of the domain: the all-gather of the partial decryptions before the local combine.
 
 Prints ONE JSON line on rank 0.
 """
 import argparse
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -27,7 +31,6 @@ sys.path.insert(0, ROOT)
 # theoretical figure (the stricter denominator).
 PEAK_MAD_PER_S = 256 * 4 * 64 / 4 * 2.4e9
 HBM_PEAK_GBPS = 8000.0
-TRAFFIC_DEFAULT = 8.0e9   # HBM bytes per launch of the dominant kernel for the default workload (PMC passes, profiles/)
 
 
 def alg_mul32_per_modexp(mod_bits: int, exp_bits: int, w: int = 5) -> float:
@@ -35,6 +38,102 @@ def alg_mul32_per_modexp(mod_bits: int, exp_bits: int, w: int = 5) -> float:
     e + ceil(e/w) + 2^w - 2 + 2 Montgomery products."""
     W = mod_bits // 32
     return (exp_bits + -(-exp_bits // w) + (1 << w)) * (2 * W * W + W)
+
+
+def free_port() -> int:
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def self_launch(args) -> int:
+    """`python bench.py --gpus N` outside a launcher: start N ranks as a CHILD process (torch.distributed.run, one rank per
+    GPU) before this process has made any GPU call, and hand back its exit code."""
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
+           "--master-addr", "127.0.0.1", "--master-port", str(free_port()), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    return subprocess.call(cmd, env=env)
+
+
+def measure_traffic_pmc(bits: int, batch: int, timeout_s: float = 150.0):
+    """HBM bytes per launch of the dominant kernel, measured for THIS run's workload: two child processes of this same
+    command under `rocprofv3 --pmc` (FETCH_SIZE and WRITE_SIZE need a pass each: MI355X_MICROARCH.md "rocprofv3 PMC slots";
+    no tracing domain is combined with --pmc), started before this process touches the GPU.  gfx950 correction of that
+    guide: FETCH_SIZE counts half the bytes of wide coalesced reads -> 2 x FETCH_SIZE + WRITE_SIZE (both in KB).
+    Returns (bytes or None, note)."""
+    import csv
+    import glob
+    import shutil
+    import tempfile
+    if shutil.which("rocprofv3") is None:
+        return None, "rocprofv3 not on PATH"
+    if any("rocprof" in os.environ.get(k, "").lower() for k in ("LD_PRELOAD", "ROCP_TOOL_LIBRARIES", "HSA_TOOLS_LIB")):
+        return None, "already running under a profiler"
+    out = {}
+    tmp = tempfile.mkdtemp(prefix="bench_pmc_", dir="/tmp")
+    env = dict(os.environ, TMPDIR="/tmp")
+    try:
+        for counter in ("FETCH_SIZE", "WRITE_SIZE"):
+            d = os.path.join(tmp, counter)
+            cmd = ["rocprofv3", "--pmc", counter, "--output-format", "csv", "-d", d, "-o", "p", "--", sys.executable,
+                   os.path.abspath(__file__), "--gpus", "1", "--steps", "1", "--warmup", "1", "--bits", str(bits), "--batch",
+                   str(batch), "--headline-only"]
+            r = subprocess.run(cmd, cwd="/tmp", env=env, stdout=subprocess.PIPE, stderr=subprocess.PIPE, timeout=timeout_s)
+            if r.returncode != 0:
+                return None, f"rocprofv3 --pmc {counter} failed (rc {r.returncode})"
+            kern = None
+            for line in r.stdout.decode(errors="ignore").splitlines():
+                if line.startswith("{"):
+                    kern = json.loads(line)["roofline"]["kernel_name"]
+            per = {}
+            for f in glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True):
+                for row in csv.DictReader(open(f)):
+                    if kern and row["Kernel_Name"].startswith(kern) and row["Counter_Name"] == counter:
+                        per[row["Dispatch_Id"]] = per.get(row["Dispatch_Id"], 0.0) + float(row["Counter_Value"])
+            if not per:
+                return None, f"no {counter} rows for kernel {kern}"
+            vals = sorted(per.values())
+            out[counter] = vals[len(vals) // 2]          # median over the launches of the dominant kernel (KB)
+        return (2.0 * out["FETCH_SIZE"] + out["WRITE_SIZE"]) * 1024.0, (
+            "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, one child pass each of this command; 2 x FETCH_SIZE + WRITE_SIZE "
+            "(gfx950 half-count correction), median per launch of the dominant kernel")
+    except Exception as e:  # noqa: BLE001 -- the measurement is optional; the bench line is not
+        return None, f"PMC pass failed: {type(e).__name__}: {e}"
+    finally:
+        shutil.rmtree(tmp, ignore_errors=True)
+
+
+def host_cpu_info():
+    """CPU model / sockets / cores / threads of the host and what this process may use of it."""
+    info = {"model": None, "sockets": None, "physical_cores": None, "logical_cpus": os.cpu_count()}
+    try:
+        phys, socks = set(), set()
+        pid = cid = None
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("model name") and info["model"] is None:
+                info["model"] = line.split(":", 1)[1].strip()
+            elif line.startswith("physical id"):
+                pid = line.split(":")[1].strip()
+                socks.add(pid)
+            elif line.startswith("core id"):
+                cid = line.split(":")[1].strip()
+                phys.add((pid, cid))
+        info["sockets"], info["physical_cores"] = len(socks) or None, len(phys) or None
+    except OSError:
+        pass
+    usable = len(os.sched_getaffinity(0))
+    try:   # cgroup v2 CPU quota of the box's share
+        q, per = open("/sys/fs/cgroup/cpu.max").read().split()
+        if q != "max":
+            info["cgroup_cpu_quota"] = float(q) / float(per)
+            usable = min(usable, max(1, int(float(q) / float(per))))
+    except (OSError, ValueError):
+        pass
+    info["usable_cpus"] = usable
+    return info
 
 
 def main():
@@ -46,30 +145,54 @@ def main():
     ap.add_argument("--bits", type=int, default=2048, choices=[1024, 2048, 3072])
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="CPU-baseline budget (wall seconds)")
+    ap.add_argument("--no-extra", action="store_true", help="skip the extra_configs (BASELINE configs 2-5)")
+    ap.add_argument("--no-traffic", action="store_true", help="skip the rocprofv3 PMC child passes (roofline.traffic = null)")
+    ap.add_argument("--headline-only", action="store_true", help="(internal: PMC child pass) headline only, no CPU leg")
+    ap.add_argument("--extra-steps", type=int, default=2)
     args = ap.parse_args()
+    if args.headline_only:
+        args.no_cpu_baseline = args.no_extra = args.no_traffic = True
 
-    import numpy as np
-    import torch
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        sys.exit(self_launch(args))          # nothing has touched the GPU yet
 
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus:
-        print(f"[bench] WORLD_SIZE={world} != --gpus {args.gpus}; using WORLD_SIZE", file=sys.stderr)
+        print(f"[bench] WORLD_SIZE={world} but --gpus {args.gpus}: refusing to report a mislabelled run", file=sys.stderr)
+        sys.exit(2)
+
+    traffic, traffic_note = None, "not measured (--no-traffic / N > 1)"
+    if world == 1 and not args.no_traffic:
+        traffic, traffic_note = measure_traffic_pmc(args.bits, args.batch)   # child processes; before any GPU call here
+
+    import numpy as np
+    import torch
+
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
+    dist = None
     if world > 1:
         import torch.distributed as dist
         dist.init_process_group("nccl", device_id=dev)
+        if dist.get_world_size() != args.gpus:
+            print(f"[bench] process group has {dist.get_world_size()} ranks, --gpus {args.gpus}", file=sys.stderr)
+            sys.exit(2)
 
     import paillier_amd as pa
     from paillier_amd.api import MEM_DEVICE
+    from paillier_amd import dist as pdist
 
     with open(os.path.join(ROOT, "tests", "golden", "keys.json")) as f:
-        k = json.load(f)["paillier"][str(args.bits)]
-    p, q = int(k["p"], 16), int(k["q"], 16)
-    n, lam = p * q, (p - 1) * (q - 1)
+        KEYS = json.load(f)
 
+    def paillier_key(bits):
+        k = KEYS["paillier"][str(bits)]
+        p, q = int(k["p"], 16), int(k["q"], 16)
+        return p, q, p * q, (p - 1) * (q - 1)
+
+    p, q, n, lam = paillier_key(args.bits)
     ctx = pa.Context(local_rank, torch.cuda.current_stream().cuda_stream)
     pk = pa.PublicKey(ctx, n, n + 1)
     sk = pa.SecretKey(ctx, pk, lam)
@@ -77,15 +200,24 @@ def main():
     B = args.batch
     pb, cb = pk.plain_bytes(), pk.cipher_bytes()
 
+    def rand_below(modulus, count, nbytes, rng):
+        """uniform-ish values below `modulus` as big-endian rows: top byte strictly below the modulus' top byte"""
+        raw = rng.integers(0, 256, size=(count, nbytes), dtype=np.uint8)
+        top = modulus >> (8 * (nbytes - 1))
+        raw[:, 0] %= np.uint8(min(max(top, 1), 255))
+        return raw
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    # ---- headline: Decrypt ---------------------------------------------------------------------------------------
     # synthetic inputs: uniform m in [0, n) and r in Z_n^* from a seeded PRNG (seed differs per rank);
     # ciphertexts are produced by the engine's own Encrypt (setup, untimed).
     rng = np.random.default_rng(1234 + rank)
-    def rand_below_n(count):
-        raw = rng.integers(0, 256, size=(count, pb), dtype=np.uint8)
-        raw[:, 0] %= np.uint8(n >> (8 * (pb - 1)))  # top byte strictly below n's top byte => value < n
-        return raw
-    m_host = rand_below_n(B)
-    r_host = rand_below_n(B)
+    m_host = rand_below(n, B, pb, rng)
+    r_host = rand_below(n, B, pb, rng)
     r_host[:, -1] |= 1
     m_dev = torch.from_numpy(m_host).to(dev)
     r_dev = torch.from_numpy(r_host).to(dev)
@@ -96,11 +228,6 @@ def main():
 
     def step():
         sk.decrypt_raw(B, c_dev.data_ptr(), cb, out_dev.data_ptr(), pb, MEM_DEVICE)
-
-    def barrier():
-        if world > 1:
-            dist.barrier()
-        torch.cuda.synchronize()
 
     for _ in range(args.warmup):
         step()
@@ -117,6 +244,7 @@ def main():
         tt = torch.tensor([elapsed], dtype=torch.float64, device=dev)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         elapsed = float(tt.item())
+    prof = ctx.last_profile()
 
     # parity at full size: round trip is the identity on every lane, on every rank
     ok = bool(torch.equal(out_dev, m_dev))
@@ -124,13 +252,187 @@ def main():
         bad = int((out_dev != m_dev).any(dim=1).sum().item())
         raise SystemExit(f"[bench] rank {rank}: PARITY FAILURE: {bad} of {B} decryptions differ from the plaintexts")
 
+    # ---- extra configs (BASELINE.json configs 2-5), same process, same rules: inputs resident in HBM, HIP-event kernel
+    # time, executed multiply-adds from the library's per-opcode count, full-batch round-trip parity where one exists ------
+    extras, checks = [], {}
+
+    def timed(fn, steps):
+        fn()
+        torch.cuda.synchronize()
+        ms, mads, kern = [], 0.0, ""
+        t = time.perf_counter()
+        for _ in range(steps):
+            mads, vms, kern = fn()
+            ms.append(vms)
+        torch.cuda.synchronize()
+        return (time.perf_counter() - t) / steps, sum(ms) / len(ms), mads, kern
+
+    def one_call(fn):
+        """run one C-ABI call and return (mads, vm_ms, kernel) of it"""
+        fn()
+        pr_ = ctx.last_profile()
+        return pr_["vm_mads"], pr_["vm_ms"], pr_["kernel"]
+
+    def entry(name, workload, unit, count, dt, vms, mads, kern, parity):
+        return {"config": name, "workload": workload, "value": count / dt, "unit": unit, "ms_per_batch": dt * 1e3,
+                "kernel": kern, "kernel_ms_per_batch": vms, "executed_mad28": mads,
+                "frac": (mads / (vms * 1e-3) / PEAK_MAD_PER_S) if vms else None, "parity": parity}
+
+    if not args.no_extra and world == 1:
+        ES = args.extra_steps
+        # config 2: Batch 65536 Encrypt, 2048-bit
+        p2, q2, n2k, lam2 = paillier_key(2048)
+        pk2 = pk if args.bits == 2048 else pa.PublicKey(ctx, n2k, n2k + 1)
+        sk2 = sk if args.bits == 2048 else pa.SecretKey(ctx, pk2, lam2)
+        BE = 65536
+        rg = np.random.default_rng(2)
+        em_h, er_h = rand_below(n2k, BE, 256, rg), rand_below(n2k, BE, 256, rg)
+        er_h[:, -1] |= 1
+        em, er = torch.from_numpy(em_h).to(dev), torch.from_numpy(er_h).to(dev)
+        ec = torch.zeros((BE, 512), dtype=torch.uint8, device=dev)
+        eo = torch.zeros((BE, 256), dtype=torch.uint8, device=dev)
+        dt, vms, mads, kern = timed(lambda: one_call(lambda: pk2.encrypt_with_r_raw(
+            BE, em.data_ptr(), 256, er.data_ptr(), 256, ec.data_ptr(), 512, MEM_DEVICE)), ES)
+        sk2.decrypt_raw(BE, ec.data_ptr(), 512, eo.data_ptr(), 256, MEM_DEVICE)
+        assert torch.equal(eo, em), "[bench] Encrypt-2048: Decrypt(Encrypt(m, r)) != m"
+        extras.append(entry("encrypt_2048", "Batch 65536 EncryptWithR, 2048-bit n, level 1 (r^n * (1+n)^m mod n^2)",
+                            "encryptions/s", BE, dt, vms, mads, kern, "65536-lane decrypt round trip"))
+        checks["encrypt_2048"] = (n2k, em_h[:64], er_h[:64], ec[:64].cpu().numpy())
+
+        # config 3: Batch 65536 Decrypt, 3072-bit
+        p3, q3, n3k, lam3 = paillier_key(3072)
+        pk3 = pa.PublicKey(ctx, n3k, n3k + 1)
+        sk3 = pa.SecretKey(ctx, pk3, lam3)
+        rg = np.random.default_rng(3)
+        dm_h, dr_h = rand_below(n3k, BE, 384, rg), rand_below(n3k, BE, 384, rg)
+        dr_h[:, -1] |= 1
+        dm, dr = torch.from_numpy(dm_h).to(dev), torch.from_numpy(dr_h).to(dev)
+        dc = torch.zeros((BE, 768), dtype=torch.uint8, device=dev)
+        do = torch.zeros((BE, 384), dtype=torch.uint8, device=dev)
+        pk3.encrypt_with_r_raw(BE, dm.data_ptr(), 384, dr.data_ptr(), 384, dc.data_ptr(), 768, MEM_DEVICE)
+        dt, vms, mads, kern = timed(lambda: one_call(lambda: sk3.decrypt_raw(
+            BE, dc.data_ptr(), 768, do.data_ptr(), 384, MEM_DEVICE)), ES)
+        assert torch.equal(do, dm), "[bench] Decrypt-3072 round trip failed"
+        extras.append(entry("decrypt_3072", "Batch 65536 Decrypt, 3072-bit n, level 1, CRT over p^2, q^2", "decryptions/s",
+                            BE, dt, vms, mads, kern, "65536-lane round trip"))
+        checks["decrypt_3072"] = (n3k, lam3, dc[:32].cpu().numpy(), do[:32].cpu().numpy())
+        del pk3, sk3, dm, dr, dc, do
+
+        # config 5: DDLEQ prove / verify, 2048-bit, 16384 (statement, instance) pairs, secpar = 1 each
+        BD = 16384
+        rg = np.random.default_rng(5)
+        cb3, pb2 = pk2.cipher_bytes(1), pk2.plain_bytes(1)
+        tb = lambda a: torch.from_numpy(a).to(dev)
+        def unit():
+            a = rand_below(n2k, BD, 256, rg)
+            a[:, -1] |= 1
+            return a
+        dmsg, r1, r2, da_h, db_h, dx_h, dy_h = rand_below(n2k, BD, 256, rg), unit(), unit(), unit(), unit(), unit(), unit()
+        inner = torch.zeros((BD, 512), dtype=torch.uint8, device=dev)
+        ct1 = torch.zeros((BD, cb3), dtype=torch.uint8, device=dev)
+        pk2.encrypt_with_r_raw(BD, tb(dmsg).data_ptr(), 256, tb(r1).data_ptr(), 256, inner.data_ptr(), 512, MEM_DEVICE)
+        pk2.encrypt_with_r_raw(BD, inner.data_ptr(), 512, tb(r2).data_ptr(), 256, ct1.data_ptr(), cb3, MEM_DEVICE, level=1)
+        # ct2 = NestedRandomize(ct1; a, b) = ct1^(a^n mod n^2) * b^(n^2) mod n^3  (operations.go:96-118)
+        m2, m3 = pa.Modulus(ctx, n2k * n2k), pa.Modulus(ctx, n2k ** 3)
+        da, db, dx, dy = tb(da_h), tb(db_h), tb(dx_h), tb(dy_h)
+        an = torch.zeros((BD, pb2), dtype=torch.uint8, device=dev)
+        t3 = torch.zeros((BD, cb3), dtype=torch.uint8, device=dev)
+        bn2 = torch.zeros((BD, cb3), dtype=torch.uint8, device=dev)
+        ct2 = torch.zeros((BD, cb3), dtype=torch.uint8, device=dev)
+        nbe, n2be = n2k.to_bytes(256, "big"), (n2k * n2k).to_bytes(512, "big")
+        m2.exp_raw(BD, da.data_ptr(), 256, nbe, 256, 0, an.data_ptr(), pb2, MEM_DEVICE)
+        m3.exp_raw(BD, ct1.data_ptr(), cb3, an.data_ptr(), pb2, pb2, t3.data_ptr(), cb3, MEM_DEVICE)
+        m3.exp_raw(BD, db.data_ptr(), 256, n2be, 512, 0, bn2.data_ptr(), cb3, MEM_DEVICE)
+        m3.mul_raw(BD, t3.data_ptr(), cb3, bn2.data_ptr(), cb3, ct2.data_ptr(), cb3, MEM_DEVICE)
+        al = torch.zeros((BD, cb3), dtype=torch.uint8, device=dev)
+        pe = torch.zeros((BD, pb2), dtype=torch.uint8, device=dev)
+        pf = torch.zeros((BD, cb3), dtype=torch.uint8, device=dev)
+        okh = np.zeros(BD, dtype=np.int32)
+        dt, vms, mads, kern = timed(lambda: one_call(lambda: sk2.ddleq_prove_raw(
+            BD, ct1.data_ptr(), ct2.data_ptr(), da.data_ptr(), db.data_ptr(), dx.data_ptr(), dy.data_ptr(), al.data_ptr(),
+            pe.data_ptr(), pf.data_ptr(), MEM_DEVICE)), 1)
+        extras.append(entry("ddleq_prove_2048", "16384 DDLEQ instances (secpar = 1 each), 2048-bit n: sanity check, Alpha, "
+                            "Fiat-Shamir bit, response through level-two ExtractRandonness (ddleq.go:55-127)",
+                            "instances/s", BD, dt, vms, mads, kern, "every proof verifies (below)"))
+        dt, vms, mads, kern = timed(lambda: one_call(lambda: pk2.ddleq_verify_raw(
+            BD, ct1.data_ptr(), ct2.data_ptr(), dx.data_ptr(), dy.data_ptr(), al.data_ptr(), pe.data_ptr(), pf.data_ptr(), okh,
+            MEM_DEVICE)), ES)
+        assert okh.all(), "[bench] DDLEQ: a proof made by the prover was rejected by the verifier"
+        extras.append(entry("ddleq_verify_2048", "16384 DDLEQ instances, 2048-bit n: hash bit + check^(E^n) * F^(n^2) mod n^3 "
+                            "(ddleq.go:129-153)", "instances/s", BD, dt, vms, mads, kern, "16384 of 16384 accepted"))
+        S = 8
+        checks["ddleq_2048"] = (n2k, lam2, [x[:S].cpu().numpy() for x in (ct1, ct2, da, db, dx, dy, al, pe, pf)])
+        del inner, ct1, ct2, an, t3, bn2, al, pe, pf, m2, m3
+
+    # config 4: threshold decryption (t = 3, l = 5), 16384 ciphertexts per step over the `world` ranks -- strong scaling:
+    # (server, ciphertext) units sharded over the ranks, all-gather of the 512-byte partials (RCCL), local combine
+    if not args.no_extra:
+        kt = KEYS["threshold"]["2048"]
+        tn, shares = int(kt["n"], 16), [int(s, 16) for s in kt["shares"]]
+        ids = [1, 3, 5]                       # every 3-subset of 5 has a negative Lagrange coefficient
+        tk = pa.ThresholdPublicKey(ctx, tn, total=5, threshold=3)
+        BT = 16384
+        rg = np.random.default_rng(4)         # the same ciphertexts on every rank (inputs are public)
+        tm_h, tr_h = rand_below(tn, BT, 256, rg), rand_below(tn, BT, 256, rg)
+        tr_h[:, -1] |= 1
+        tm, tr = torch.from_numpy(tm_h).to(dev), torch.from_numpy(tr_h).to(dev)
+        tc = torch.zeros((BT, 512), dtype=torch.uint8, device=dev)
+        tk.encrypt_with_r_raw(BT, tm.data_ptr(), 256, tr.data_ptr(), 256, tc.data_ptr(), 512, MEM_DEVICE)
+        acc = {"mads": 0.0, "ms": 0.0, "kern": "", "best": 0.0}
+
+        def note():
+            pr_ = ctx.last_profile()
+            acc["mads"] += pr_["vm_mads"]
+            acc["ms"] += pr_["vm_ms"]
+            if pr_["vm_mads"] > acc["best"]:
+                acc["best"], acc["kern"] = pr_["vm_mads"], pr_["kernel"]
+
+        def partial_fn(s, rows):
+            o = torch.empty((rows.shape[0], 512), dtype=torch.uint8, device=dev)
+            tk.partial_decrypt_raw(shares[ids[s] - 1], rows.shape[0], rows.data_ptr(), 512, o.data_ptr(), 512, MEM_DEVICE)
+            note()
+            return o
+
+        def combine_fn(parts):
+            o = torch.empty((parts[0].shape[0], 256), dtype=torch.uint8, device=dev)
+            tk.combine_raw(ids, parts[0].shape[0], [x.data_ptr() for x in parts], 512, o.data_ptr(), 256, MEM_DEVICE)
+            note()
+            return o
+
+        def tstep():
+            return pdist.threshold_decrypt_sharded(tc, len(ids), rank, world, partial_fn, combine_fn)
+
+        tstep()
+        barrier()
+        acc.update(mads=0.0, ms=0.0, best=0.0)
+        t = time.perf_counter()
+        for _ in range(args.extra_steps):
+            tout, (sb, se) = tstep()
+        barrier()
+        tel = pdist.max_over_ranks(time.perf_counter() - t, dev)
+        tok = torch.tensor([1 if (tout is None or torch.equal(tout, tm[sb:se])) else 0], dtype=torch.int32, device=dev)
+        if world > 1:
+            dist.all_reduce(tok, op=dist.ReduceOp.MIN)
+        if not int(tok.item()):
+            raise SystemExit("[bench] threshold decryption: Combine(PartialDecrypt x 3) != m on some rank")
+        e = entry("threshold_2048", f"t=3 of l=5, servers {ids}, 16384 ciphertexts per step, 2048-bit safe-prime key: 3 x "
+                  f"PartialDecrypt + CombinePartialDecryptions; (server, ciphertext) units sharded over {world} rank(s), "
+                  f"all-gather of the partials" + (" over RCCL" if world > 1 else " (single rank: no exchange)") +
+                  ", local combine", "threshold decryptions/s", BT, tel / args.extra_steps,
+                  acc["ms"] / args.extra_steps, acc["mads"] / args.extra_steps, acc["kern"],
+                  "all 16384 plaintexts recovered on every rank")
+        e.update({"scaling": "strong", "n_gpus": world, "exchange_bytes_per_step": len(ids) * BT * 512 if world > 1 else 0,
+                  "kernel_ms_note": "rank 0's share of the step"})
+        extras.append(e)
+        if world == 1:
+            checks["threshold_2048"] = (tn, shares, ids, tc[:4].cpu().numpy(), tm_h[:4])
+
     if rank != 0:
         if world > 1:
             dist.barrier()
             dist.destroy_process_group()
         return
 
-    prof = ctx.last_profile()
     vm_ms_avg = sum(vm_ms) / len(vm_ms)
     value = world * B * args.steps / elapsed
     half = args.bits // 2
@@ -144,12 +446,13 @@ def main():
     alg_mads = prof["vm_mads"] / B                     # 28-bit multiply-adds the ladder programs need per decryption
     achieved = prof["vm_mads"] / (vm_ms_avg * 1e-3)
     alg_bytes = cb + pb  # read c (n^2 bytes) + write m (n bytes)
-    kernel = {2048: "vm_asm_37_16 (pair kernel: x^(p-1) mod p^2 and x^(q-1) mod q^2 ladders, both halves in one launch)",
-              1024: "vm_asm_37_1 (CRT modexp over p^2 and q^2)",
-              3072: "vm_asm_55_32 (two-lane pair kernel: ladders modulo p^2 and q^2, both halves in one launch)"}[args.bits]
+    what = {2048: "pair kernel: x^(p-1) mod p^2 and x^(q-1) mod q^2 ladders, both halves in one launch",
+            1024: "CRT modexp over p^2 and q^2",
+            3072: "two-lane pair kernel: ladders modulo p^2 and q^2, both halves in one launch"}[args.bits]
     roofline = {
         "bound": "valu",  # integer multiply issue (v_mad_u64_u32); neither HBM nor MFMA binds
-        "kernel": kernel,
+        "kernel": f"{prof['kernel']} ({what})",
+        "kernel_name": prof["kernel"],
         "achieved": achieved / 1e12,
         "peak": PEAK_MAD_PER_S / 1e12,
         "unit": "Tmad28/s",
@@ -160,34 +463,95 @@ def main():
                         "rate_Tmul32_per_s": alg_mul32 * B / (vm_ms_avg * 1e-3) / 1e12,
                         "frac_of_issue_peak": alg_mul32 * B / (vm_ms_avg * 1e-3) / PEAK_MAD_PER_S,
                         "note": "above 1: the engine's algorithm needs fewer multiplies than the schoolbook count of SURVEY 8(d)"},
-        # HBM bytes per launch from the PMC passes of this same command (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate
-        # runs, 2 x FETCH_SIZE gfx950 correction): profiles/r01_bench_pmc_summary.txt.  It is the per-lane window table
-        # (written once, one entry read per window product), not re-reads of the inputs.  Only known for the default workload.
-        "traffic": TRAFFIC_DEFAULT if (args.bits == 2048 and B == 65536) else None,
+        # HBM bytes per launch of the dominant kernel from PMC counters (see measure_traffic_pmc): the per-lane window table
+        # (written once, one entry read per window product), not re-reads of the inputs
+        "traffic": traffic,
+        "traffic_source": traffic_note,
         "hbm": {"achieved": alg_bytes * B / (vm_ms_avg * 1e-3) / 1e9, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
-                "frac": alg_bytes * B / (vm_ms_avg * 1e-3) / 1e9 / HBM_PEAK_GBPS, "alg_bytes_per_decrypt": alg_bytes},
+                "frac": alg_bytes * B / (vm_ms_avg * 1e-3) / 1e9 / HBM_PEAK_GBPS, "alg_bytes_per_decrypt": alg_bytes,
+                "traffic_GBps": (traffic / (vm_ms_avg * 1e-3) / 1e9) if traffic else None},
     }
 
     cpu_baseline = None
     if world == 1 and not args.no_cpu_baseline:
-        from oracle import gmp_oracle as go  # CPU baseline leg: the libgmp restatement of paillier.go:292-303
-        threads = min(16, os.cpu_count() or 1)
-        c_host = c_dev[:4096].cpu().numpy()
+        # CPU leg: the libgmp restatement of the reference's call sequence, timed on this box's host cores, and -- with the
+        # same library -- the sample checks of the extra configs.  (The reference itself is Go on github.com/ncw/gmp -> libgmp
+        # and cannot be built here: no Go toolchain, dependency not vendored; kind = "port".)
+        from oracle import gmp_oracle as go
+        host = host_cpu_info()
+        threads = host["usable_cpus"]
+        if host["physical_cores"] and threads > host["physical_cores"]:
+            threads = host["physical_cores"]          # mpz_powm saturates a core's multiplier: SMT siblings add nothing
+        c_host = c_dev.cpu().numpy()
+        go.decrypt_batch_raw(n, lam, c_host[:8], pb, threads=1)          # warm-up: library load, page faults, caches
         t = time.perf_counter()
-        out1, _ = go.decrypt_batch_raw(n, lam, c_host[:32], pb, threads=1)
+        out1, _ = go.decrypt_batch_raw(n, lam, c_host[8:40], pb, threads=1)
         per_op = (time.perf_counter() - t) / 32
-        sample = int(max(64, min(4096, args.cpu_seconds * threads / per_op)))
+        go.decrypt_batch_raw(n, lam, c_host[:4 * threads], pb, threads=threads)   # warm the thread pool
+        sample = int(max(64, min(B, args.cpu_seconds * threads / per_op)))
         t = time.perf_counter()
         outc, used = go.decrypt_batch_raw(n, lam, c_host[:sample], pb, threads=threads)
         dt = time.perf_counter() - t
         assert (outc == m_host[:sample]).all(), "CPU baseline disagrees with the plaintexts"
         assert (out_dev[:sample].cpu().numpy() == outc).all(), "GPU result differs from the libgmp oracle"
+        scrt = min(B, 4 * sample)
+        t = time.perf_counter()
+        outk, _ = go.decrypt_crt_batch_raw(p, q, c_host[:scrt], pb, threads=threads)
+        dtk = time.perf_counter() - t
+        assert (outk == m_host[:scrt]).all(), "CRT CPU baseline disagrees with the plaintexts"
         cpu_baseline = {
-            "value": sample / dt, "unit": "decryptions/s", "cores": int(used), "kind": "port",
+            "value": sample / dt, "unit": "decryptions/s", "cores": int(used),
+            "kind": "port",
+            "kind_note": "libgmp restatement of the reference's call sequence; the reference (Go + github.com/ncw/gmp) cannot be "
+                         "built in this image: no Go toolchain, dependency not vendored",
             "single_thread_value": 1.0 / per_op,
+            "crt_value": scrt / dtk, "crt_note": f"the same harness with textbook CRT over p^2, q^2 (not the reference's "
+                                                 f"algorithm), {scrt} ciphertexts, {used} threads",
+            "host": host,
             "sample": f"{sample} of the same {args.bits}-bit ciphertexts; libgmp {go.load().oracle_gmp_version().decode()} "
-                      f"mpz_powm call sequence of paillier.go:292-303 (no CRT, lambda^-1 per call), {used} OpenMP threads",
+                      f"mpz_powm call sequence of paillier.go:292-303 (no CRT, lambda^-1 per call), {used} OpenMP threads "
+                      f"(after a warm-up; single-thread figure from 32 calls after 8 warm-up calls)",
         }
+        # sample checks of the extra configs against the same libgmp oracle (+ the Python-int oracle for Combine)
+        by = {e["config"]: e for e in extras}
+        if "encrypt_2048" in checks:
+            nn, mh, rh, ch = checks["encrypt_2048"]
+            t = time.perf_counter()
+            want, u = go.encrypt_batch_raw(nn, nn + 1, mh, rh, 512, threads=threads)
+            by["encrypt_2048"].update({"parity": by["encrypt_2048"]["parity"] + "; 64 ciphertexts == libgmp oracle",
+                                       "cpu_per_s": 64 / (time.perf_counter() - t), "cpu_threads": int(u)})
+            assert (want == ch).all(), "[bench] Encrypt-2048 differs from the libgmp oracle"
+        if "decrypt_3072" in checks:
+            nn, ll, ch, mh = checks["decrypt_3072"]
+            t = time.perf_counter()
+            want, u = go.decrypt_batch_raw(nn, ll, ch, 384, threads=threads)
+            by["decrypt_3072"].update({"parity": by["decrypt_3072"]["parity"] + "; 32 plaintexts == libgmp oracle",
+                                       "cpu_per_s": 32 / (time.perf_counter() - t), "cpu_threads": int(u)})
+            assert (want == mh).all(), "[bench] Decrypt-3072 differs from the libgmp oracle"
+        if "ddleq_2048" in checks:
+            from paillier_amd.api import be_to_ints
+            nn, ll, arrs = checks["ddleq_2048"]
+            c1, c2, a_, b_, x_, y_, al_, e_, f_ = [be_to_ints(a) for a in arrs]
+            t = time.perf_counter()
+            wal, wes, wfs, bits = go.ddleq_prove_batch(nn, ll, c1, c2, a_, b_, x_, y_, threads=threads)
+            tp = time.perf_counter() - t
+            assert (wal, wes, wfs) == (al_, e_, f_), "[bench] DDLEQ prover differs from the libgmp oracle"
+            t = time.perf_counter()
+            assert all(go.ddleq_verify_batch(nn, c1, c2, x_, y_, al_, e_, f_, threads=threads))
+            tv = time.perf_counter() - t
+            by["ddleq_prove_2048"].update({"parity": f"{len(c1)} proofs (challenge bits {bits}) == libgmp oracle; all 16384 verify",
+                                           "cpu_per_s": len(c1) / tp, "cpu_threads": min(threads, len(c1))})
+            by["ddleq_verify_2048"].update({"parity": by["ddleq_verify_2048"]["parity"] + f"; {len(c1)} verdicts == libgmp oracle",
+                                            "cpu_per_s": len(c1) / tv, "cpu_threads": min(threads, len(c1))})
+        if "threshold_2048" in checks:
+            from oracle import paillier_oracle as po
+            from paillier_amd.api import be_to_ints
+            tn_, sh, ids_, ch, mh = checks["threshold_2048"]
+            tsks = [po.ThresholdSecretKey(N=tn_, G=tn_ + 1, TotalNumberOfDecryptionServers=5, Threshold=3, ID=i, Share=sh[i - 1])
+                    for i in ids_]
+            got = [po.combine_partial_decryptions(tsks[0], [po.partial_decrypt(ts, c) for ts in tsks]) for c in be_to_ints(ch)]
+            assert got == be_to_ints(mh), "[bench] threshold decryption differs from the oracle"
+            by["threshold_2048"]["parity"] += "; 4 ciphertexts: oracle PartialDecrypt x 3 + Combine == m"
 
     line = {
         "metric": f"paillier_{args.bits}bit_decryptions_per_s",
@@ -205,10 +569,12 @@ def main():
         "bit_exact": ok,
         "config": {"workload": f"Batch {B} Decrypt per GPU, {args.bits}-bit n, level 1, CRT over p^2,q^2; inputs resident "
                                f"in HBM as big-endian element-major bytes",
-                   "batch_per_gpu": B, "key_bits": args.bits, "parallelism": f"batch-sharded x{world}, no data-path collective"},
+                   "batch_per_gpu": B, "key_bits": args.bits, "parallelism": f"batch-sharded x{world}, no data-path collective",
+                   "world_size": world},
         "roofline": roofline,
         "cpu_baseline": cpu_baseline,
         "encrypt_setup": {"vm_ms": enc_prof["vm_ms"], "encryptions_per_s": B / (enc_prof["vm_ms"] * 1e-3)},
+        "extra_configs": extras,
     }
     print(json.dumps(line), flush=True)
     if world > 1:

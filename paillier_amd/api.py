@@ -51,6 +51,7 @@ SIGNATURES = {
     "pgpu_ctx_last_profile": (_int, [_vp, C.POINTER(C.c_double), C.POINTER(_int), C.POINTER(C.c_double)]),
     "pgpu_ctx_set_flag": (_int, [_vp, C.c_char_p, _int]),
     "pgpu_ctx_last_vm_asm": (_int, [_vp]),
+    "pgpu_ctx_last_kernel": (C.c_char_p, [_vp]),
     "pgpu_pubkey_create": (_int, [_vp, _vp, _sz, _vp, _sz, _vp, _sz, _vp, _sz, C.POINTER(_vp)]),
     "pgpu_pubkey_destroy": (None, [_vp]),
     "pgpu_pubkey_plain_bytes": (_sz, [_vp, _int]),
@@ -143,7 +144,8 @@ class Context:
     def last_profile(self):
         ms, n, mads = C.c_double(), C.c_int(), C.c_double()
         _check(self.lib.pgpu_ctx_last_profile(self.h, C.byref(ms), C.byref(n), C.byref(mads)))
-        return {"vm_ms": ms.value, "vm_launches": n.value, "vm_mads": mads.value}
+        return {"vm_ms": ms.value, "vm_launches": n.value, "vm_mads": mads.value,
+                "kernel": self.lib.pgpu_ctx_last_kernel(self.h).decode()}
 
     def set_flag(self, name: str, value: int):
         _check(self.lib.pgpu_ctx_set_flag(self.h, name.encode(), value))
@@ -212,6 +214,16 @@ class Modulus:
             es = el
         _check(lib.pgpu_modexp(self.h, len(bases), _ptr(bb), bl, bl, _ptr(eb), el, es, _ptr(out), self.nbytes, MEM_HOST))
         return be_to_ints(out)
+
+    def exp_raw(self, batch, base, base_stride, e, e_len, e_stride, out, out_stride, mem=MEM_HOST):
+        """pgpu_modexp on raw big-endian buffers (numpy arrays or device pointers); e_stride = 0: one shared exponent
+        (e is then a bytes-like of e_len bytes on the HOST)."""
+        _check(self.ctx.lib.pgpu_modexp(self.h, batch, _ptr(base), base_stride, base_stride, e if isinstance(e, bytes) else _ptr(e),
+                                        e_len, e_stride, _ptr(out), out_stride, mem))
+
+    def mul_raw(self, batch, a, a_stride, b, b_stride, out, out_stride, mem=MEM_HOST):
+        _check(self.ctx.lib.pgpu_modmul(self.h, batch, _ptr(a), a_stride, a_stride, _ptr(b), b_stride, b_stride, _ptr(out),
+                                        out_stride, mem))
 
     def vm_debug_run(self, prog_words: Sequence[int], mem: np.ndarray, nslots: int, nb: int, use_asm: bool) -> np.ndarray:
         """Test hook (include/paillier_hip.h pgpu_vm_debug_run).  mem: uint32[nslots, WT, nb]; returns the memory after the run."""
@@ -370,6 +382,13 @@ class PublicKey:
                                               _ptr(bufs[4]), cb3, _ptr(bufs[5]), pb2, _ptr(bufs[6]), cb3, _ptr(ok), MEM_HOST))
         return [bool(v) for v in ok]
 
+    def ddleq_verify_raw(self, batch, ct1, ct2, x, y, alpha, e, f, ok: np.ndarray, mem=MEM_HOST):
+        """pgpu_ddleq_verify on raw buffers with the natural strides (ct/alpha/f: bytes of n^3; x, y: bytes of n; e: bytes of
+        n^2); ok: host int32[batch]."""
+        cb3, pb1, pb2 = self.cipher_bytes(ENC_LEVEL_TWO), self.plain_bytes(ENC_LEVEL_ONE), self.plain_bytes(ENC_LEVEL_TWO)
+        _check(self.ctx.lib.pgpu_ddleq_verify(self.h, batch, _ptr(ct1), _ptr(ct2), cb3, _ptr(x), _ptr(y), pb1, _ptr(alpha), cb3,
+                                              _ptr(e), pb2, _ptr(f), cb3, _ptr(ok), mem))
+
     def NestedAddBatch(self, ct1s: Sequence[int], ct2s: Sequence[int]) -> List[int]:
         """operations.go:121-127: level-two ciphertext ^ (level-one ciphertext value)."""
         return self.ConstMultBatch(ct1s, list(ct2s), level=ENC_LEVEL_TWO)
@@ -475,6 +494,13 @@ class SecretKey:
                     status: Optional[np.ndarray] = None):
         _check(self.ctx.lib.pgpu_decrypt(self.h, level, batch, _ptr(c), c_stride, _ptr(m), m_stride, mem, flags,
                                          _ptr(status) if status is not None else None))
+
+    def ddleq_prove_raw(self, batch, ct1, ct2, a, b, x, y, alpha, e, f, mem=MEM_HOST):
+        """pgpu_ddleq_prove on raw buffers with the natural strides (see PublicKey.ddleq_verify_raw)."""
+        pk = self.pk
+        cb3, pb1, pb2 = pk.cipher_bytes(ENC_LEVEL_TWO), pk.plain_bytes(ENC_LEVEL_ONE), pk.plain_bytes(ENC_LEVEL_TWO)
+        _check(self.ctx.lib.pgpu_ddleq_prove(self.h, batch, _ptr(ct1), _ptr(ct2), cb3, _ptr(a), _ptr(b), _ptr(x), _ptr(y), pb1,
+                                             _ptr(alpha), _ptr(e), pb2, _ptr(f), mem))
 
     def NestedDecryptBatch(self, cts: Sequence[int]) -> List[int]:
         """paillier.go:344-355: peel the level-two layer, then decrypt at level one (0 stays 0: the reference's edge case)."""

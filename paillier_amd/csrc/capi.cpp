@@ -65,7 +65,7 @@ struct pgpu_ctx {
   std::vector<Chunk> chunks;
   std::vector<std::vector<uint32_t>> host_keep;  // host buffers that async copies read from
   // profile of the last call
-  struct Ev { hipEvent_t a, b; double mads; };
+  struct Ev { hipEvent_t a, b; double mads; char name[32]; };
   std::vector<Ev> evs;
   size_t evs_used = 0;
   bool use_asm = true;       // hand-scheduled VM kernels (pgpu_ctx_set_flag("asm", 0) selects the hipcc-generated ones)
@@ -117,6 +117,7 @@ struct pgpu_ctx {
       HIPCHK(hipEventCreate(&e.a));
       HIPCHK(hipEventCreate(&e.b));
       e.mads = 0;
+      e.name[0] = 0;
       evs.push_back(e);
     }
     return evs[evs_used++];
@@ -500,6 +501,7 @@ void run_vm(pgpu_ctx* ctx, size_t nb, const SegSpec& s0, const SegSpec* s1, bool
     HIPCHK(hipEventRecord(ev->a, ctx->stream));
   }
   if (pair && !use_asm) api_throw(PGPU_ERR_UNSUPPORTED, "the pair kernel exists in assembly only");
+  if (ev) snprintf(ev->name, sizeof ev->name, use_asm ? "vm_asm_%d_%d" : "vm_kernel<%d,%d>", WL, K);
   hipError_t e = use_asm ? launch_vm_asm(WL, K, a, blocks, ctx->stream) : launch_vm(WL, K, a, blocks, ctx->stream);
   if (use_asm) ctx->last_vm_asm++;
   if (e != hipSuccess) throw HipError{e, "launch_vm"};
@@ -688,6 +690,14 @@ int pgpu_ctx_set_flag(pgpu_ctx* ctx, const char* name, int value) {
 }
 
 int pgpu_ctx_last_vm_asm(pgpu_ctx* ctx) { return ctx ? ctx->last_vm_asm : 0; }
+
+const char* pgpu_ctx_last_kernel(pgpu_ctx* ctx) {
+  if (!ctx) return "";
+  const pgpu_ctx::Ev* best = nullptr;
+  for (size_t i = 0; i < ctx->evs_used; ++i)
+    if (!best || ctx->evs[i].mads > best->mads) best = &ctx->evs[i];
+  return best ? best->name : "";
+}
 
 int pgpu_ctx_last_profile(pgpu_ctx* ctx, double* vm_ms, int* vm_launches, double* vm_mads) {
   if (!ctx) return fail(PGPU_ERR_INVALID, "null ctx");

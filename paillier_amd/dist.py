@@ -44,3 +44,42 @@ def all_gather_bytes(local, world: int):
     out = torch.empty((world * local.shape[0],) + tuple(local.shape[1:]), dtype=local.dtype, device=local.device)
     dist.all_gather_into_tensor(out, local)  # concatenation along dim 0 (the layout both RCCL and gloo accept)
     return out.view((world,) + tuple(local.shape))
+
+
+def threshold_decrypt_sharded(c, n_servers: int, rank: int, world: int, partial_fn, combine_fn, pad_rows: bool = True):
+    """Threshold decryption of B ciphertexts with the work sharded over `world` ranks and ONE exchange step
+    (thresholdkey.go:149-201: every server's PartialDecrypt, then CombinePartialDecryptions).
+
+    Work units are (server, ciphertext) pairs, server-major: unit u = s * B + i.  Rank r computes the partial decryptions
+    of its contiguous unit range (so it touches at most two servers' shares -- shares are not replicated everywhere), the
+    fixed-stride partials are all-gathered (RCCL over xGMI with one GPU per rank; big-integer modular products are not a
+    collective reduction op: gather + local combine kernel), then every rank combines its own ciphertext slice.
+
+      c            uint8 tensor [B, cipher_bytes] (same on every rank: ciphertexts are public), on the device the
+                   collective backend moves (cuda for nccl, cpu for gloo)
+      partial_fn   (server_index, c_rows) -> uint8 tensor [len(c_rows), cipher_bytes]      PartialDecrypt of one server
+      combine_fn   ([rows of server 0, rows of server 1, ...]) -> uint8 tensor [rows, plain_bytes]   Combine
+    Returns (plaintext rows of this rank's ciphertext slice, (begin, end) of that slice).
+    """
+    import torch
+    B, cbytes = int(c.shape[0]), int(c.shape[1])
+    units = n_servers * B
+    ub, ue = shard_slice(units, rank, world)
+    per = -(-units // world) if pad_rows else (ue - ub)      # all-gather needs equal shapes
+    local = torch.zeros((max(per, 1), cbytes), dtype=torch.uint8, device=c.device)
+    u = ub
+    while u < ue:
+        s, i0 = divmod(u, B)
+        cnt = min(ue - u, B - i0)
+        local[u - ub:u - ub + cnt] = partial_fn(s, c[i0:i0 + cnt])
+        u += cnt
+    g = all_gather_bytes(local, world).reshape(world * max(per, 1), cbytes)
+    parts = torch.empty((units, cbytes), dtype=torch.uint8, device=c.device)
+    for q in range(world):          # un-pad: rank q's units sit at rows [q*per, q*per + len_q)
+        qb, qe = shard_slice(units, q, world)
+        parts[qb:qe] = g[q * max(per, 1):q * max(per, 1) + (qe - qb)]
+    parts = parts.view(n_servers, B, cbytes)
+    cb, ce = shard_slice(B, rank, world)
+    if ce == cb:
+        return None, (cb, ce)
+    return combine_fn([parts[s, cb:ce].contiguous() for s in range(n_servers)]), (cb, ce)

@@ -69,3 +69,96 @@ def test_shard_slice_properties():
             assert all(sl[i][1] == sl[i + 1][0] for i in range(world - 1))
             sizes = [e - b for b, e in sl]
             assert max(sizes) - min(sizes) <= 1
+
+
+# ---- threshold decryption across ranks: PartialDecrypt -> exchange -> Combine (thresholdkey.go:149-201) -----------------
+
+def _threshold_inputs(count):
+    import json
+    import random
+    from oracle import paillier_oracle as po
+    k = json.load(open(os.path.join(ROOT, "tests", "golden", "keys.json")))["threshold"]["512"]
+    n, shares = int(k["n"], 16), [int(s, 16) for s in k["shares"]]
+    rng = random.Random(77)
+    pk = po.PublicKey(N=n, G=n + 1)
+    ms = [0, n - 1] + [rng.randrange(n) for _ in range(count - 2)]
+    cts = [po.encrypt_with_r(pk, m, po.rand_unit(n, rng)).C for m in ms]
+    return n, shares, ms, cts
+
+
+def _threshold_worker(rank, world, port, ids, count, use_gpu, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    import numpy as np
+    from paillier_amd import dist as pd
+    from oracle import paillier_oracle as po
+    n, shares, ms, cts = _threshold_inputs(count)
+    cb, pb = 128, 64
+    to_rows = lambda vals, st: torch.from_numpy(np.frombuffer(b"".join(int(v).to_bytes(st, "big") for v in vals),
+                                                              dtype=np.uint8).reshape(len(vals), st).copy())
+    to_ints = lambda t: [int.from_bytes(bytes(r.tolist()), "big") for r in t]
+    c = to_rows(cts, cb)
+    if use_gpu:   # the product path through the C ABI (host buffers; both ranks share GPU 0 in this rehearsal)
+        import paillier_amd as pa
+        ctx = pa.Context(0)
+        tk = pa.ThresholdPublicKey(ctx, n, total=5, threshold=3)
+
+        def partial_fn(s, rows):
+            rows = rows.contiguous().numpy()
+            out = np.zeros((rows.shape[0], cb), dtype=np.uint8)
+            tk.partial_decrypt_raw(shares[ids[s] - 1], rows.shape[0], rows, cb, out, cb)
+            return torch.from_numpy(out)
+
+        def combine_fn(parts):
+            arrs = [x.contiguous().numpy() for x in parts]
+            out = np.zeros((arrs[0].shape[0], pb), dtype=np.uint8)
+            tk.combine_raw(ids, arrs[0].shape[0], [a.ctypes.data for a in arrs], cb, out, pb)
+            return torch.from_numpy(out)
+    else:         # CPU rehearsal of the exchange logic: the oracle plays the kernels
+        tsk = {i: po.ThresholdSecretKey(N=n, G=n + 1, TotalNumberOfDecryptionServers=5, Threshold=3, ID=i, Share=shares[i - 1])
+               for i in ids}
+
+        def partial_fn(s, rows):
+            return to_rows([po.partial_decrypt(tsk[ids[s]], x).Decryption for x in to_ints(rows)], cb)
+
+        def combine_fn(parts):
+            cols = [to_ints(x) for x in parts]
+            return to_rows([po.combine_partial_decryptions(tsk[ids[0]], [po.PartialDecryption(i, col[j]) for i, col in zip(ids, cols)])
+                            for j in range(len(cols[0]))], pb)
+    out, (b, e) = pd.threshold_decrypt_sharded(c, len(ids), rank, world, partial_fn, combine_fn)
+    q.put((rank, b, e, to_ints(out) if out is not None else []))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def _run_threshold(world, ids, count, use_gpu):
+    port = _free_port()
+    ctxm = mp.get_context("spawn")
+    q = ctxm.Queue()
+    procs = [ctxm.Process(target=_threshold_worker, args=(r, world, port, ids, count, use_gpu, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = sorted(q.get(timeout=300) for _ in range(world))
+    for p in procs:
+        p.join(timeout=120)
+        assert p.exitcode == 0
+    n, shares, ms, cts = _threshold_inputs(count)
+    got = []
+    for rank, b, e, vals in res:
+        assert b == len(got)          # contiguous ciphertext slices in rank order
+        got += vals
+    assert got == ms
+
+
+@pytest.mark.parametrize("ids,count", [([1, 2, 3], 7), ([1, 3, 5], 10)])
+def test_threshold_partial_exchange_combine_two_ranks_cpu(ids, count):
+    """world_size 2, gloo: each rank computes the partial decryptions of its (server, ciphertext) units, the partials are
+    all-gathered, each rank combines its ciphertext slice; the plaintexts come back.  7 ciphertexts x 3 servers = 21 units
+    over 2 ranks: a rank's range straddles two servers and the last rank is padded."""
+    _run_threshold(2, ids, count, use_gpu=False)
+
+
+@pytest.mark.gpu
+def test_threshold_partial_exchange_combine_two_ranks_gpu():
+    """The same flow with the HIP path doing PartialDecrypt and Combine (two gloo ranks sharing GPU 0)."""
+    _run_threshold(2, [1, 3, 5], 9, use_gpu=True)
