@@ -71,6 +71,7 @@ struct pgpu_ctx {
   bool use_asm = true;       // hand-scheduled VM kernels (pgpu_ctx_set_flag("asm", 0) selects the hipcc-generated ones)
   int last_vm_asm = 0;       // number of VM launches of the last call that ran the assembly kernel
   bool use_pair = true;      // Decrypt ladders mod p^2 on the pair kernel (pgpu_ctx_set_flag("pair", 0): the 2H-limb kernel)
+  bool use_triple = true;    // ladders modulo n^3 on the three-digit kernel (pgpu_ctx_set_flag("triple", 0): the 3H-limb kernels)
   size_t lanes_wanted = 0;   // 0: default occupancy target; tests set 1 to run every modulus at its natural shape
 
   void bind() { HIPCHK(hipSetDevice(device)); }
@@ -153,9 +154,25 @@ struct PairInfo {
   const uint32_t* n_limbs = nullptr;  // n as H limbs
 };
 
+// A modulus N = n^3 whose root n is known can run its ladders on the three-digit kernel (GenQ3): residues as
+// a0 + a1 n + a2 n^2 in the lanes of a quad.
+struct TripleInfo {
+  const ModCtx* root = nullptr;       // n
+  const ModCtx* mid = nullptr;        // n^2 (digit split)
+  const uint32_t* kconsts = nullptr;  // device: n (padded to an even count) | (C1_i, C2_i) pairs | two words of padding
+  const uint32_t* tconsts = nullptr;  // device: constants in digit form, [c][3H]; entry 0 = the digit form of 1
+  int c_rh = -1;                      // in the consts of n^3: R_H mod n^3 (plain): entry into the digit form
+  int c_exit = -1;                    // in the consts of n^3: R R_H^-1 mod n^3 (plain): exit from it
+  const uint32_t* dinv1 = nullptr;    // n^-1 mod 2^(28 WT(n))
+  const uint32_t* dinv2 = nullptr;    // n^-1 mod 2^(28 WT(n^2))
+  const uint32_t* n_limbs = nullptr;  // n   as WT(n) limbs
+  const uint32_t* n2_limbs = nullptr; // n^2 as WT(n^2) limbs
+};
+
 struct ModCtx {
   pgpu_ctx* ctx = nullptr;
   PairInfo pairn;
+  TripleInfo triple;
   BigU N, R;
   size_t nbits = 0, nbytes = 0;
   int WL = 0, K = 0, WT = 0;
@@ -377,17 +394,20 @@ void emit_modexp_perlane(Prog& p, int we, uint32_t in_lo, uint32_t in_hi, uint32
 // verifier (ddleq.go:143-152) and alpha = ct1^(x^n) * y^(n^2) of the prover (ddleq.go:81-87) need.
 // x in slot in1, y in slot in2 (plain residues); result (plain, lazy) -> out.
 void emit_modexp_dual(Prog& p, int we, const BigU& e, uint32_t in1, uint32_t in2, uint32_t tmp, uint32_t out, uint32_t tab1,
-                      uint32_t tab2) {
+                      uint32_t tab2, int raw_one = -1) {
+  // raw_one >= 0: in1 / in2 are already in the kernel's working form (digit kernels), raw_one = the constant holding 1 in
+  // that form; no entry, no exit
+  const uint32_t one_m = raw_one >= 0 ? (uint32_t)raw_one : (uint32_t)C_ONE_M;
   // tables
-  emit_to_mont(p, in1, NO_SLOT, tmp);
+  if (raw_one >= 0) p.op(VM_LOAD, in1); else emit_to_mont(p, in1, NO_SLOT, tmp);
   p.op(VM_STORE, tab1 + 1);
-  p.op(VM_LOADC, C_ONE_M);
+  p.op(VM_LOADC, one_m);
   p.op(VM_STORE, tab1 + 0);
   p.op(VM_LOAD, tab1 + 1);
   for (uint32_t k = 2; k < 16; ++k) { p.op(VM_MUL, tab1 + 1); p.op(VM_STORE, tab1 + k); }
   const int sw = 6;
   const uint32_t nodd = 1u << (sw - 1);
-  emit_to_mont(p, in2, NO_SLOT, tmp);
+  if (raw_one >= 0) p.op(VM_LOAD, in2); else emit_to_mont(p, in2, NO_SLOT, tmp);
   p.op(VM_STORE, tab2 + 0);
   p.op(VM_SQR);
   p.op(VM_STORE, tmp);
@@ -405,13 +425,13 @@ void emit_modexp_dual(Prog& p, int we, const BigU& e, uint32_t in1, uint32_t in2
     mul_at[(size_t)l] = (int)(val >> 1);
     i = l - 1;
   }
-  p.op(VM_LOADC, C_ONE_M);
+  p.op(VM_LOADC, one_m);
   for (long b = nbits - 1; b >= 0; --b) {
     if (b != nbits - 1) p.op(VM_SQR);
     if (b % 4 == 0 && b / 4 < (long)we * 7) p.op(VM_MULV, (uint32_t)(b / 4), tab1);
     if (mul_at[(size_t)b] >= 0) p.op(VM_MUL, tab2 + (uint32_t)mul_at[(size_t)b]);
   }
-  p.op(VM_MULC, C_ONE);
+  if (raw_one < 0) p.op(VM_MULC, C_ONE);
   p.op(VM_STORE, out);
 }
 
@@ -425,7 +445,9 @@ struct SegSpec {
   const uint32_t* pair = nullptr;
   uint32_t pair_n0inv = 0;
   int pair_h = 0;
-  int pair_lanes = 1;   // 1: GenP (one lane holds both digits); 2: GenQ (one digit per lane); 4: GenQ4 (two lanes per digit)
+  int pair_lanes = 1;   // 1: GenP (one lane holds both digits); 2: GenQ (one digit per lane); 4: GenQ4 (two lanes per digit);
+                        // 3: GenQ3 (three digits modulo n^3 in a quad; `tconsts` = its constant table, slots are 3H limbs)
+  const uint32_t* tconsts = nullptr;
 };
 
 // launch one VM kernel with 1 or 2 segments of `nb` numbers each (same modulus shape)
@@ -441,7 +463,7 @@ void run_vm(pgpu_ctx* ctx, size_t nb, const SegSpec& s0, const SegSpec* s1, bool
     VmSeg& g = a.seg[i];
     g.prog = ctx->upload_words(ss[i]->prog->w);
     g.nmod = ss[i]->pair ? const_cast<uint32_t*>(ss[i]->pair) : ss[i]->mc->d_nmod;
-    g.consts = ss[i]->mc->d_consts;
+    g.consts = ss[i]->tconsts ? const_cast<uint32_t*>(ss[i]->tconsts) : ss[i]->mc->d_consts;
     g.mem = ss[i]->mem;
     g.digits = ss[i]->digits;
     g.n0inv = ss[i]->pair ? ss[i]->pair_n0inv : ss[i]->mc->n0inv;
@@ -461,7 +483,7 @@ void run_vm(pgpu_ctx* ctx, size_t nb, const SegSpec& s0, const SegSpec* s1, bool
   if (s1 && pair != (s1->pair != nullptr)) api_throw(PGPU_ERR_INVALID, "segment kind mismatch");
   if (pair) {
     WL = s0.pair_lanes == 4 ? s0.pair_h / 2 : s0.pair_h;
-    K = s0.pair_lanes == 4 ? 64 : s0.pair_lanes == 2 ? 32 : 16;   // tags of the pair kernels, not lane counts
+    K = s0.pair_lanes == 4 ? 64 : s0.pair_lanes == 3 ? 48 : s0.pair_lanes == 2 ? 32 : 16;   // tags of the pair kernels, not lane counts
   } else {
     static const size_t lanes_env = [] { const char* e = getenv("PGPU_LANES_WANTED"); return e ? (size_t)atoll(e) : (size_t)0; }();
     const size_t lanes_wanted = ctx->lanes_wanted ? ctx->lanes_wanted : lanes_env ? lanes_env : (size_t)1024 * 64;
@@ -471,7 +493,7 @@ void run_vm(pgpu_ctx* ctx, size_t nb, const SegSpec& s0, const SegSpec* s1, bool
     static const bool w74 = [] { const char* e = getenv("PGPU_W74"); return e ? atoi(e) != 0 : true; }();
     if (WL == 74 && K == 2 && !(w74 && ctx->use_asm)) { WL = 37; K = 4; }
   }
-  const uint32_t blocks_per_seg = (uint32_t)(launch_nb * (pair ? s0.pair_lanes : K) / VM_BLOCK);
+  const uint32_t blocks_per_seg = (uint32_t)(launch_nb * (pair ? (s0.pair_lanes == 3 ? 4 : s0.pair_lanes) : K) / VM_BLOCK);
   a.seg0_blocks = blocks_per_seg;
   const uint32_t blocks = blocks_per_seg * (s1 ? 2 : 1);
   const bool use_asm = ctx->use_asm && vm_asm_available(WL, K) && s0.prog->asm_ok && (!s1 || s1->prog->asm_ok) &&
@@ -485,7 +507,11 @@ void run_vm(pgpu_ctx* ctx, size_t nb, const SegSpec& s0, const SegSpec* s1, bool
     // squaring rows: K == 1 triangular (WT^2 + WT(WT-1)/2 + WT); K == 2 slice-level symmetry (product part 1.5 WL^2 per lane)
     double sq = full;
     double mulp = full;
-    if (pair && s0.pair_lanes >= 2) {   // GenQ / GenQ4: one / two Montgomery passes modulo n in every digit lane
+    if (pair && s0.pair_lanes == 3) {   // GenQ3: a squaring is one pass in four lanes, a product 6 blocks (its second pass runs two lanes)
+      const double H = s0.pair_h;
+      mulp = 12.0 * H * H;
+      sq = 8.0 * H * H;
+    } else if (pair && s0.pair_lanes >= 2) {   // GenQ / GenQ4: one / two Montgomery passes modulo n in every digit lane
       const double H = s0.pair_h;
       mulp = 8.0 * H * H;
       sq = 4.0 * H * H;
@@ -576,6 +602,8 @@ struct pgpu_pubkey {
   struct FixedBase { BigU base; int idx; int nwin; };
   std::vector<FixedBase> fixed_bases;   // comb tables of other fixed bases mod n^2 (verification keys)
   DevLimbs pairn_consts;          // n | Cadj | pad for the two-lane pair kernel (mn2.pairn points here)
+  DevLimbs triple_kconsts;        // n | (C1_i, C2_i) pairs | pad for the three-digit kernel (mn3->triple points here)
+  DevLimbs triple_tconsts;        // its constants in digit form
   std::vector<std::pair<int, int>> combine_consts;  // (total servers l, index of (4 (l!)^2)^-1 * R mod n in mn.consts)
 };
 
@@ -633,6 +661,30 @@ static std::vector<uint32_t> make_pair_consts(const BigU& pr, int H) {
   return v;
 }
 
+// Constants of the three-digit kernel for the root n (H limbs): n padded to an even number of words, then the pairs
+// (C1_i, C2_i), then two words of padding (the kernel prefetches one pair past the end).  C1 = k1 n is make_pair_consts'
+// Cadj (every limb in [2^28, 2^29)); C2 = -k1 (mod n) shifted into the same limb range: the -C1 n that the first link
+// leaves in digit one is -k1 n^2, which C2 cancels in digit two.
+static std::vector<uint32_t> make_triple_kconsts(const BigU& n, int H) {
+  const int npad = (H + 1) / 2 * 2;
+  std::vector<uint32_t> pc = make_pair_consts(n, H);                 // n | C1
+  BigU D;
+  for (int j = 0; j < H; ++j) D = D + hostbig::shl(BigU(1), (size_t)LB * j + LB);
+  BigU c1 = BigU::from_limbs(pc.data() + H, LB, (size_t)H), k1, rem;
+  c1.trim();
+  hostbig::divmod(c1, n, k1, rem);
+  if (!rem.is_zero()) api_throw(PGPU_ERR_INVALID, "internal: C1 is not a multiple of n");
+  const BigU e2 = (n - ((k1 + D) % n)) % n;                            // C2 = D + e2 = -k1 (mod n)
+  const std::vector<uint32_t> e2l = e2.to_limbs(LB, (size_t)H);
+  std::vector<uint32_t> kc((size_t)npad + 2 * H + 2, 0);
+  for (int j = 0; j < H; ++j) {
+    kc[j] = pc[j];
+    kc[(size_t)npad + 2 * j] = pc[H + j];
+    kc[(size_t)npad + 2 * j + 1] = e2l[j] + (1u << LB);
+  }
+  return kc;
+}
+
 // inverse of odd d modulo 2^bits
 static BigU inv_mod_pow2(const BigU& d, size_t bits) {
   BigU m = hostbig::shl(BigU(1), bits), out;
@@ -685,6 +737,7 @@ int pgpu_ctx_set_flag(pgpu_ctx* ctx, const char* name, int value) {
   if (!ctx || !name) return fail(PGPU_ERR_INVALID, "null argument");
   if (strcmp(name, "asm") == 0) { ctx->use_asm = value != 0; return PGPU_OK; }
   if (strcmp(name, "pair") == 0) { ctx->use_pair = value != 0; return PGPU_OK; }
+  if (strcmp(name, "triple") == 0) { ctx->use_triple = value != 0; return PGPU_OK; }
   if (strcmp(name, "lanes_wanted") == 0) { ctx->lanes_wanted = value > 0 ? (size_t)value : 0; return PGPU_OK; }
   return fail(PGPU_ERR_INVALID, "unknown flag %s", name);
 }
@@ -805,10 +858,110 @@ void modexp_pair(pgpu_ctx* ctx, const ModCtx& mc, const ModexpPlan& pl, const Bi
   }
 }
 
+// ---- three-digit form for moduli n^3 (GenQ3) ---------------------------------------------------------------------
+// Slots of the digit kernel are 3H limbs (a0 | a1 | a2), H = WT(n); the generic kernels' slots of n^3 have WT(n^3) limbs.
+struct TriplePlan {
+  uint32_t* mem;        // [slot][3H][nb]
+  size_t slot_words;    // 3H * nb
+  size_t nb;
+  int H;
+  uint32_t* slot(uint32_t i) const { return mem + (size_t)i * slot_words; }
+};
+
+bool triple_usable(pgpu_ctx* ctx, const ModCtx& mc) {
+  static const bool env_on = [] { const char* e = getenv("PGPU_TRIPLE"); return e ? atoi(e) != 0 : true; }();
+  return env_on && mc.triple.root && ctx->use_asm && ctx->use_pair && ctx->use_triple;
+}
+
+TriplePlan triple_alloc(pgpu_ctx* ctx, const ModCtx& mc, size_t nb, int slots) {
+  TriplePlan tp;
+  tp.H = mc.triple.root->WT;
+  tp.nb = nb;
+  tp.slot_words = (size_t)3 * tp.H * nb;
+  tp.mem = ctx->ws_t<uint32_t>(tp.slot_words * (size_t)slots);
+  return tp;
+}
+
+// canonical residue x (WT(n^3) limbs, stride nb) -> digit form of x R_H mod n^3 in slot `slot`
+void triple_enter(pgpu_ctx* ctx, const ModCtx& mc, const uint32_t* x, const TriplePlan& tp, uint32_t slot) {
+  const TripleInfo& ti = mc.triple;
+  const ModCtx &mn = *ti.root, &mn2 = *ti.mid;
+  const int H = tp.H, W2 = mn2.WT, W3 = mc.WT;
+  const size_t nb = tp.nb, S1 = (size_t)H * nb, S2 = (size_t)W2 * nb, S3 = (size_t)W3 * nb;
+  uint32_t* gm = ctx->ws_t<uint32_t>(S3 * 2);       // generic slots: 0 x, 1 X = x R_H mod n^3 (canonical)
+  HIPCHK(hipMemcpyAsync(gm, x, S3 * 4, hipMemcpyDeviceToDevice, ctx->stream));
+  {
+    Prog a;
+    a.op(VM_LOAD, 0); a.op(VM_MULC, C_R2); a.op(VM_MULC, (uint32_t)ti.c_rh); a.op(VM_STORE, 1); a.end();
+    SegSpec sa{&mc, &a, gm, nullptr};
+    run_vm(ctx, nb, sa, nullptr, false);
+    launch_canon(gm + S3, mc.d_nmod, W3, nb, ctx->stream);
+  }
+  uint32_t* X = gm + S3;
+  uint32_t* d = tp.slot(slot);
+  uint32_t* r2 = ctx->ws_t<uint32_t>(S2);
+  uint32_t* Y = ctx->ws_t<uint32_t>(S2);
+  uint32_t* tb = ctx->ws_t<uint32_t>(S3);
+  reduce_mod(ctx, mn2, X, W3, r2, nb);              // X mod n^2
+  reduce_mod(ctx, mn, r2, W2, d, nb);               // X0 = X mod n
+  launch_div_exact(X, W3, 0, d, H, tb, ti.dinv2, mn.d_nmod, H, Y, W2, nb, nb, nullptr, 0, ctx->stream);        // Y = (X - X0) / n < n^2
+  reduce_mod(ctx, mn, Y, W2, d + S1, nb);           // X1 = Y mod n
+  launch_div_exact(Y, W2, 0, d + S1, H, tb, ti.dinv1, mn.d_nmod, H, d + 2 * S1, H, nb, nb, nullptr, 0, ctx->stream);   // X2
+}
+
+// digit form in slot `slot` (value F R_H) -> canonical F [* post] mod n^3 in `out` (WT(n^3) limbs); post: plain residue
+void triple_exit(pgpu_ctx* ctx, const ModCtx& mc, const TriplePlan& tp, uint32_t slot, uint32_t* out, const uint32_t* post) {
+  const TripleInfo& ti = mc.triple;
+  const ModCtx& mn2 = *ti.mid;
+  const int H = tp.H, W2 = mn2.WT, W3 = mc.WT;
+  const size_t nb = tp.nb, S1 = (size_t)H * nb, S3 = (size_t)W3 * nb;
+  const uint32_t* d = tp.slot(slot);
+  uint32_t* t = ctx->ws_t<uint32_t>((size_t)W2 * nb);
+  uint32_t* gm = ctx->ws_t<uint32_t>(S3 * 3);       // generic slots: 0 F~, 1 post, 2 out
+  launch_mul_const_add(d + S1, H, ti.n_limbs, H, d, H, 0, t, W2, nb, ctx->stream);              // F0 + F1 n
+  launch_mul_const_add(d + 2 * S1, H, ti.n2_limbs, W2, t, W2, 0, gm, W3, nb, ctx->stream);      // + F2 n^2  (< 2^(28 WT(n^3)))
+  Prog a;
+  a.op(VM_LOAD, 0); a.op(VM_MULC, (uint32_t)ti.c_exit);
+  if (post) {
+    HIPCHK(hipMemcpyAsync(gm + S3, post, S3 * 4, hipMemcpyDeviceToDevice, ctx->stream));
+    a.op(VM_MULC, C_R2); a.op(VM_MUL, 1);
+  }
+  a.op(VM_STORE, 2); a.end();
+  SegSpec sa{&mc, &a, gm, nullptr};
+  run_vm(ctx, nb, sa, nullptr, false);
+  launch_canon(gm + 2 * S3, mc.d_nmod, W3, nb, ctx->stream);
+  HIPCHK(hipMemcpyAsync(out, gm + 2 * S3, S3 * 4, hipMemcpyDeviceToDevice, ctx->stream));
+}
+
+void triple_run(pgpu_ctx* ctx, const ModCtx& mc, const TriplePlan& tp, const Prog& p, const uint32_t* exps) {
+  const TripleInfo& ti = mc.triple;
+  SegSpec sp{&mc, &p, tp.mem, exps};
+  sp.pair = ti.kconsts; sp.pair_n0inv = ti.root->n0inv; sp.pair_h = tp.H; sp.pair_lanes = 3; sp.tconsts = ti.tconsts;
+  run_vm(ctx, tp.nb, sp, nullptr, true);
+}
+
+// pl.in() (canonical, < n^3) ^ e [* pl.post()] mod n^3 on the three-digit kernel; canonical result in pl.out()
+void modexp_triple(pgpu_ctx* ctx, const ModCtx& mc, const ModexpPlan& pl, const BigU* e, const uint32_t* exps, int we,
+                   bool use_post) {
+  // digit slots: 0 in, 1 (unused), 2 tmp, 3 out, 5.. table
+  TriplePlan tp = triple_alloc(ctx, mc, pl.nb, 5 + 32);
+  triple_enter(ctx, mc, pl.in(), tp, 0);
+  Prog p;
+  if (exps) emit_modexp_perlane(p, we, 0, NO_SLOT, 2, 3, 5, NO_SLOT, 0);
+  else emit_modexp_shared(p, *e, 0, NO_SLOT, 2, 3, 5, NO_SLOT, true, true);
+  p.end();
+  triple_run(ctx, mc, tp, p, exps);
+  triple_exit(ctx, mc, tp, 3, pl.out(), use_post ? pl.post() : nullptr);
+}
+
 void modexp_shared_run(pgpu_ctx* ctx, const ModCtx& mc, const ModexpPlan& pl, const BigU& e, bool wide, bool use_post,
                        bool skip_zero) {
   // two lanes per number from one wave per SIMD upwards; below that four (each digit over two lanes: a squaring is half as
   // long as on the 4-lane 2H-limb kernel, which is what counts when the ladder's latency is the run time)
+  if (triple_usable(ctx, mc) && !wide && skip_zero && e.bit_length() >= 256) {
+    modexp_triple(ctx, mc, pl, &e, nullptr, 0, use_post);
+    return;
+  }
   const bool two = pl.nb * 2 >= (ctx->lanes_wanted ? ctx->lanes_wanted : (size_t)1024 * 64);
   if (mc.pairn.root && ctx->use_asm && ctx->use_pair && !wide && skip_zero && e.bit_length() >= 256 &&
       (two || (mc.pairn.root->WT % 2 == 0 && vm_asm_available(mc.pairn.root->WT / 2, 64)))) {
@@ -826,6 +979,10 @@ void modexp_shared_run(pgpu_ctx* ctx, const ModCtx& mc, const ModexpPlan& pl, co
 
 void modexp_perlane_run(pgpu_ctx* ctx, const ModCtx& mc, const ModexpPlan& pl, const uint32_t* exps, int we, bool wide,
                         bool use_post) {
+  if (triple_usable(ctx, mc) && !wide && we >= 10 && (uint64_t)pl.nb * (mc.WT + 4) * 4 * 17 < (1ull << 32)) {
+    modexp_triple(ctx, mc, pl, nullptr, exps, we, use_post);
+    return;
+  }
   {
     const bool two = pl.nb * 2 >= (ctx->lanes_wanted ? ctx->lanes_wanted : (size_t)1024 * 64);
     const uint64_t table_bytes = (uint64_t)pl.nb * mc.WT * 4 * 17;      // MULV gathers with 32-bit offsets
@@ -1100,7 +1257,35 @@ int pgpu_pair_debug_run(pgpu_ctx* ctx, const uint8_t* p_be, size_t p_len, int la
     ModCtx mp, mp2;
     mp.init(ctx, pr);
     mp2.init(ctx, pr * pr);
-    if (lanes != 1 && lanes != 2 && lanes != 4) api_throw(PGPU_ERR_INVALID, "lanes must be 1, 2 or 4");
+    if (lanes == 3) {
+      // three-digit kernel: slots are [3H][nb] (a0 | a1 | a2), the root is `p_be`; constants: one entry, the zero-extended
+      // digits given in consts_out on entry are NOT used -- the test passes constants as slots
+      if (mp.K != 1 || !vm_asm_available(mp.WT, 48)) api_throw(PGPU_ERR_UNSUPPORTED, "no three-digit kernel for this width");
+      const int H = mp.WT;
+      if (h_out) *h_out = H;
+      ModCtx mp3;
+      mp3.init(ctx, pr * pr * pr);
+      mp3.upload();
+      std::vector<uint32_t> kc = make_triple_kconsts(pr, H);
+      if (consts_out) memcpy(consts_out, kc.data(), std::min(kc.size(), (size_t)3 * H) * 4);
+      uint32_t* d_kc = ctx->upload_words(kc);
+      size_t words = nslots * (size_t)3 * H * nb;
+      uint32_t* d = ctx->ws_t<uint32_t>(words);
+      HIPCHK(hipMemcpyAsync(d, mem_host, words * 4, hipMemcpyHostToDevice, ctx->stream));
+      Prog p;
+      p.w.assign(prog, prog + prog_words);
+      p.asm_ok = true;
+      SegSpec s{&mp3, &p, d, nullptr};
+      s.pair = d_kc; s.pair_n0inv = mp.n0inv; s.pair_h = H; s.pair_lanes = 3; s.tconsts = d;   // constant c = slot c
+      bool saved = ctx->use_asm;
+      ctx->use_asm = true;
+      try { run_vm(ctx, nb, s, nullptr, false); } catch (...) { ctx->use_asm = saved; throw; }
+      ctx->use_asm = saved;
+      HIPCHK(hipMemcpyAsync(mem_host, d, words * 4, hipMemcpyDeviceToHost, ctx->stream));
+      HIPCHK(hipStreamSynchronize(ctx->stream));
+      return;
+    }
+    if (lanes != 1 && lanes != 2 && lanes != 4) api_throw(PGPU_ERR_INVALID, "lanes must be 1, 2, 3 or 4");
     if (mp.K != 1 || mp2.WT != 2 * mp.WT ||
         !(lanes == 4 ? (mp.WT % 2 == 0 && vm_asm_available(mp.WT / 2, 64)) : vm_asm_available(mp.WT, lanes == 2 ? 32 : 16)))
       api_throw(PGPU_ERR_UNSUPPORTED, "no pair kernel for this width");
@@ -1239,6 +1424,41 @@ int pgpu_pubkey_create(pgpu_ctx* ctx, const uint8_t* n_be, size_t n_len, const u
       }
       pi.dinv = pk->ninv2k.d;
       pi.n_limbs = pk->n_limbs.d;
+    }
+    if (pk->mn3 && pk->mn.K == 1 && vm_asm_available(pk->mn.WT, 48) && (size_t)LB * pk->mn3->WT >= n3.bit_length() + 3) {
+      const int H = pk->mn.WT;
+      ModCtx& m3 = *pk->mn3;
+      const std::vector<uint32_t> kc = make_triple_kconsts(pk->N, H);
+      pk->triple_kconsts.w = (int)kc.size();
+      HIPCHK(hipMalloc((void**)&pk->triple_kconsts.d, kc.size() * 4));
+      HIPCHK(hipMemcpy(pk->triple_kconsts.d, kc.data(), kc.size() * 4, hipMemcpyHostToDevice));
+      // digit form of 1: the digits of R_H mod n^3
+      const BigU RH = hostbig::shl(BigU(1), (size_t)LB * H);
+      BigU rh = RH % n3, q1, d0, d2, d1;
+      hostbig::divmod(rh, pk->N, q1, d0);
+      hostbig::divmod(q1, pk->N, d2, d1);
+      std::vector<uint32_t> tc;
+      for (const BigU* dg : {&d0, &d1, &d2}) {
+        auto l = dg->to_limbs(LB, (size_t)H);
+        tc.insert(tc.end(), l.begin(), l.end());
+      }
+      pk->triple_tconsts.w = (int)tc.size();
+      HIPCHK(hipMalloc((void**)&pk->triple_tconsts.d, tc.size() * 4));
+      HIPCHK(hipMemcpy(pk->triple_tconsts.d, tc.data(), tc.size() * 4, hipMemcpyHostToDevice));
+      TripleInfo& ti = m3.triple;
+      ti.mid = &pk->mn2;
+      ti.kconsts = pk->triple_kconsts.d;
+      ti.tconsts = pk->triple_tconsts.d;
+      ti.c_rh = m3.add_const(rh);
+      BigU rhinv;
+      if (!hostbig::modinv(rh, n3, rhinv)) api_throw(PGPU_ERR_INVALID, "internal: R_H is not invertible modulo n^3");
+      ti.c_exit = m3.add_const(hostbig::mulmod(m3.R % n3, rhinv, n3));
+      ti.dinv1 = pk->ninv2k.d;
+      ti.dinv2 = pk->ninv2k_2.d;
+      ti.n_limbs = pk->n_limbs.d;
+      ti.n2_limbs = pk->n2_limbs.d;
+      ti.root = &pk->mn;
+      m3.upload();
     }
     pk->mn.upload();
     pk->mn2.upload();
@@ -2373,10 +2593,21 @@ int pgpu_ddleq_verify(const pgpu_pubkey* pk, size_t batch, const uint8_t* ct1, c
     // check = chalBit ? ct2 : ct1 ; check^en * F^(n^2) mod n^3 == alpha           (ddleq.go:138-152)
     // one interleaved ladder: the squarings of check^en and of F^(n^2) are shared (emit_modexp_dual)
     if (f_stride * 8 > (size_t)LB * W3 + 7) api_throw(PGPU_ERR_INVALID, "F wider than n^3");
-    ModexpPlan pc = modexp_alloc(ctx, mn3, nb, 48);       // slots: 0 check, 1 F, 2 tmp, 3 out, 5..20 / 21..52 the two tables
+    const bool use3 = triple_usable(ctx, mn3) && (uint64_t)nb * (W3 + 4) * 4 * 17 < (1ull << 32);
+    ModexpPlan pc = modexp_alloc(ctx, mn3, nb, use3 ? 0 : 48);   // slots: 0 check, 1 F, 2 tmp, 3 out, 5..20 / 21..52 the two tables
     launch_select(chal, c2, c1, pc.in(), W3, nb, ctx->stream);
     unpack_operand(ctx, f, f_stride, f_stride, batch, mem, pc.in() + pc.slot_words, W3, nb);
-    {
+    if (use3) {
+      // the same interleaved ladder on the three-digit kernel: residues modulo n^3 as a0 + a1 n + a2 n^2
+      TriplePlan tp = triple_alloc(ctx, mn3, nb, 5 + 48);
+      triple_enter(ctx, mn3, pc.in(), tp, 0);
+      triple_enter(ctx, mn3, pc.in() + pc.slot_words, tp, 1);
+      Prog pd;
+      emit_modexp_dual(pd, W2, mn2.N, 0, 1, 2, 3, 5, 21, 0);
+      pd.end();
+      triple_run(ctx, mn3, tp, pd, pe.out());
+      triple_exit(ctx, mn3, tp, 3, pc.out(), nullptr);
+    } else {
       Prog pd;
       emit_modexp_dual(pd, W2, mn2.N, 0, 1, 2, 3, 5, 21);
       pd.end();

@@ -261,10 +261,15 @@ class Gen:
             self.e(f"global_load_dword {regs[j]}, v{g.v_koff}, s[{g.s_sbase}:{g.s_sbase + 1}] offset:{4 * j}")
         self.e("s_waitcnt vmcnt(0)")
 
+    def mask_digit_lanes(self, on):
+        """hook: kernels with helper lanes (GenQ3) restrict stores / LDS staging to the lanes that own a digit"""
+        pass
+
     def stage_to_lds(self, regs):
         """a-operand column of this lane's slice <- regs"""
         g = self
         e = self.e
+        self.mask_digit_lanes(True)
         stride = self.NPB * 4
         base_reg = g.v_awrite
         cur_base_off = 0
@@ -277,6 +282,7 @@ class Gen:
                 off = 0
             e(f"ds_write_b32 v{base_reg}, {regs[j]} offset:{off}")
         e("s_waitcnt lgkmcnt(0)")
+        self.mask_digit_lanes(False)
 
     # ---------------------------------------------------------------------------------------------
     def dispatcher(self):
@@ -307,12 +313,14 @@ class Gen:
 
         e("L_store:")
         self.slot_base()
+        self.mask_digit_lanes(True)
         e(f"v_mov_b32 v{g.v_addr}, v{g.v_goff}")
         for j in range(self.WL):
             e(f"global_store_dword v{g.v_addr}, {Xs[j]}, s[{g.s_sbase}:{g.s_sbase + 1}]")
             if j != self.WL - 1:
                 e(f"v_add_u32 v{g.v_addr}, s3, v{g.v_addr}")
         e("s_waitcnt vmcnt(0)")
+        self.mask_digit_lanes(False)
         e("s_branch L_next")
 
         e("L_add:")
@@ -2164,11 +2172,317 @@ class GenQ4(Gen):
         return "\n".join(self.lines) + "\n"
 
 
-SHAPES = [(74, 1), (37, 1), (55, 1), (55, 2), (74, 2), (55, 4), (74, 4), (37, 2), (37, 4), (37, 16), (74, 32), (55, 32), (37, 32), (37, 64)]
+class GenQ3(Gen):
+    """Three-digit kernel for moduli N = n^3 with n PUBLIC (level-two Encrypt / ConstMult / NestedRandomize, the DDLEQ
+    equations): the residue y R mod n^3 = a0 + a1 n + a2 n^2 (R = 2^(28 H), H = limbs of n, digits lazily reduced mod n)
+    lives in the lanes of a quad -- lane d holds digit a_d, lane 3 is a helper -- and all four lanes run the single-lane
+    Montgomery row modulo n (n in SGPRs) on their own block a_i * b_j of the product
+        y z = B00 + (B10 + B01) n + (B20 + B11 + B02) n^2   (mod n^3),    B_ij = a_i b_j.
+    A block is reduced on its own; what makes the digits exact modulo n^3 (not just modulo n) is that the QUOTIENT DIGITS
+    of a block's reduction are subtracted from a block of the next digit in the same row -- one DPP move per hop, as in
+    GenQ:   B00 -> m00 -> (B10 - m00 + C1) -> m10 -> (B20 - m10 + C2),      (B01) -> m01 -> (B11 - m01 + C1),
+    with C1 = k1 n a multiple of n whose limbs all exceed 2^28 (so the seeds stay limb-wise non-negative) and C2 = -k1 mod n
+    of the same shape (the -C1 n of digit one reappears as -k1 n^2 in digit two).
+      squaring  ONE pass of H rows: lane 0 a0 a0 | lane 1 2 a0 a1 | lane 2 2 a0 a2 | lane 3 a1 a1 (-> added to digit 2):
+                8 H^2 multiplies per number where the 4-lane 3H-limb kernel needs 18 H^2;
+      product   two passes: (a0 b0 | a1 b0 | a2 b0 | a0 b2), then (a0 b1 | a1 b1) with lanes 2, 3 masked off: 12 H^2
+                multiplies in 16 H^2 issue slots, against 18 H^2.
+    Multiplier streams come from the LDS column of the staged operand (each lane its own row offset), multiplicand
+    vectors are the lanes' own digits (lane 3 copies the one it needs by DPP).  No inter-wave traffic, no barriers.
+    Slot layout: 3H limbs -- a0 | a1 | a2.  `nmod` points at n (H limbs, padded to an even count) followed by the
+    interleaved pairs (C1_i, C2_i), streamed one pair per row by scalar loads."""
+
+    def __init__(self, H=74):
+        Gen.__init__(self, H, 4)
+        assert 3 * H + 3 <= 255
+        self.H = H
+        self.name = f"vm_asm_{H}_48"
+        self.WT = 3 * H                 # slot / constant width used by the dispatcher's addressing
+        self.NPB = 64
+        self.n_sgpr = True
+        self.n_vreg = False
+        self.flush = False
+        self.sq_rows = True
+        self.sq_rows_k = False
+        self.lds_a = 0
+        self.lds_bytes = (3 * H + 1) * self.NPB * 4
+        self.vX = 2 * H
+        e = 3 * H
+        for nm in ["ai", "ain", "m", "t1", "sh", "l1mask", "l2mask", "l12mask", "l3mask"]:
+            setattr(self, "v_" + nm, e)
+            e += 1
+        e = (e + 1) // 2 * 2
+        self.v_y0 = e
+        e += 2
+        self.v_d = e          # pair (adjustment, 0)
+        e += 2
+        for nm in ["goff", "aread", "awrite", "arow", "t2", "t3", "t4", "koff"]:
+            setattr(self, "v_" + nm, e)
+            e += 1
+        self.v_addr = self.v_arow
+        e = (e + 1) // 2 * 2
+        self.v_p0 = e
+        e += 2
+        self.v_p1 = e
+        self.v_c = e
+        e += 2
+        self.n_vgpr = e
+        assert e <= 256, e
+        self.s_coff = 99
+        self.npad = (H + 1) // 2 * 2    # n occupies an even number of words so that the pairs are 8-byte aligned
+
+    def set_exec(self, mask4):
+        """exec <- the lanes of every quad selected by the 4-bit mask"""
+        w = sum(mask4 << (4 * i) for i in range(8))
+        self.e(f"s_mov_b32 exec_lo, {hex(w)}")
+        self.e(f"s_mov_b32 exec_hi, {hex(w)}")
+
+    def mask_digit_lanes(self, on):
+        if on:
+            self.set_exec(0x7)
+        else:
+            self.e("s_mov_b64 exec, -1")
+
+    def prologue(self):
+        g, e = self, self.e
+        H, NPB = self.H, self.NPB
+        e(f'.amdgcn_target "amdgcn-amd-amdhsa--gfx950"')
+        e(".text")
+        e(f".globl {self.name}")
+        e(".p2align 8")
+        e(f".type {self.name},@function")
+        e(f"{self.name}:")
+        e("s_load_dword s3, s[0:1], 0x60")
+        e("s_waitcnt lgkmcnt(0)")
+        e("s_cmp_ge_u32 s2, s3")
+        e("s_cbranch_scc0 L_seg0")
+        e("s_sub_u32 s2, s2, s3")
+        e("s_add_u32 s0, s0, 48")
+        e("s_addc_u32 s1, s1, 0")
+        e("L_seg0:")
+        e("s_load_dwordx8 s[4:11], s[0:1], 0x0")
+        e("s_load_dwordx4 s[12:15], s[0:1], 0x20")
+        e("s_waitcnt lgkmcnt(0)")
+        e("s_lshl_b32 s3, s15, 2")
+        e(f"v_and_b32 v{g.v_t1}, 3, v0")                  # k: 0..2 digit lanes, 3 helper
+        e(f"v_lshrrev_b32 v{g.v_t2}, 2, v0")              # gl
+        e(f"s_mul_i32 s{g.s_t0}, s2, {NPB}")
+        e(f"v_add_u32 v{g.v_t3}, s{g.s_t0}, v{g.v_t2}")   # g
+        e(f"v_min_u32 v{g.v_t4}, 2, v{g.v_t1}")           # the helper lane aliases digit 2 for addressing (its stores are masked)
+        e(f"s_mul_i32 s{g.s_t1}, s15, {H}")
+        e(f"v_mul_lo_u32 v{g.v_koff}, v{g.v_t4}, s{g.s_t1}")
+        e(f"v_add_lshl_u32 v{g.v_goff}, v{g.v_koff}, v{g.v_t3}, 2")
+        e(f"v_lshlrev_b32 v{g.v_aread}, 2, v{g.v_t2}")
+        e(f"v_mul_u32_u24 v{g.v_awrite}, {H * NPB * 4}, v{g.v_t4}")
+        e(f"v_add_u32 v{g.v_awrite}, v{g.v_awrite}, v{g.v_aread}")
+        e(f"v_mul_u32_u24 v{g.v_koff}, {H * 4}, v{g.v_t4}")
+        for lane, reg in ((1, g.v_l1mask), (2, g.v_l2mask), (3, g.v_l3mask)):
+            e(f"v_cmp_eq_u32 vcc, {lane}, v{g.v_t1}")
+            e("s_nop 1")
+            e(f"v_cndmask_b32 v{reg}, 0, -1, vcc")
+        e(f"v_or_b32 v{g.v_l12mask}, v{g.v_l1mask}, v{g.v_l2mask}")
+        off, s, rem = 0, self.s_N, H
+        while rem > 0:
+            for cnt in (16, 8, 4, 2, 1):
+                align = 4 if cnt >= 4 else cnt
+                if cnt <= rem and s % align == 0:
+                    if cnt == 1:
+                        e(f"s_load_dword s{s}, s[6:7], {hex(off)}")
+                    else:
+                        e(f"s_load_dwordx{cnt} s[{s}:{s + cnt - 1}], s[6:7], {hex(off)}")
+                    off += 4 * cnt
+                    s += cnt
+                    rem -= cnt
+                    break
+            else:
+                raise RuntimeError("cannot tile the modulus into SGPR loads")
+        e("s_waitcnt lgkmcnt(0)")
+        e(f"s_add_u32 s6, s6, {4 * self.npad}")           # s[6:7] -> the (C1_i, C2_i) pairs
+        e("s_addc_u32 s7, s7, 0")
+        for j in range(H):
+            e(f"v_mov_b32 {self.X(j)}, 0")
+
+    def row(self, cur, nxt, link2, use_sh):
+        """one Montgomery row modulo n in every active lane; s[0:1] <- this row's (C1_i, C2_i); hop 1: lane 1 takes
+        C1_i - m(lane 0) into column 0; hop 2 (link2): lane 2 takes C2_i - m(lane 1)"""
+        g, e = self, self.e
+        H = self.H
+        row = self.NPB * 4
+        N = lambda j: f"s{g.s_N + j}"
+        m = f"v{g.v_m}"
+        e("s_waitcnt lgkmcnt(0)")
+        e(f"ds_read_b32 v{nxt}, v{g.v_arow}")
+        e(f"v_add_u32 v{g.v_arow}, {row}, v{g.v_arow}")
+        e("s_mov_b64 s[0:1], s[100:101]")
+        e(f"s_add_u32 s{g.s_coff}, s{g.s_coff}, 8")
+        e(f"s_load_dwordx2 s[100:101], s[6:7], s{g.s_coff}")
+        a = f"v{cur}"
+        if use_sh:
+            e(f"v_lshlrev_b32 v{cur}, v{g.v_sh}, v{cur}")
+        self.align8()
+        for j in range(H):
+            if j == H - 1:
+                self.mad(self.T(j), a, self.X(j), "0")
+            else:
+                self.mad(self.T(j), a, self.X(j), self.T(j))
+        e(f"v_mul_lo_u32 {m}, {self.Tlo(0)}, s14")
+        e(f"v_and_b32 {m}, {hex(MASK)}, {m}")
+        for hop, (cs, mask) in enumerate((("s0", g.v_l1mask), ("s1", g.v_l2mask))):
+            if hop == 1 and not link2:
+                break
+            e("s_nop 1")
+            e(f"v_mov_b32_dpp v{g.v_d}, {m} quad_perm:[0,0,1,2] row_mask:0xf bank_mask:0xf")
+            e(f"v_sub_u32 v{g.v_d}, {cs}, v{g.v_d}")
+            e(f"v_and_b32 v{g.v_d}, v{g.v_d}, v{mask}")
+            e(f"v_lshl_add_u64 {self.T(0)}, {self.T(0)}, 0, {self.P(g.v_d)}")
+            e(f"v_mul_lo_u32 {m}, {self.Tlo(0)}, s14")
+            e(f"v_and_b32 {m}, {hex(MASK)}, {m}")
+        self.align8()
+        self.mad(self.P(g.v_y0), m, N(0), self.T(0))
+        self.mad(self.T(0), m, N(1), self.T(1))
+        e(f"v_lshrrev_b64 {self.P(g.v_c)}, {LB}, {self.P(g.v_y0)}")
+        for j in range(2, H):
+            self.mad(self.T(j - 1), m, N(j), self.T(j))
+            if j == 4:
+                e(f"v_lshl_add_u64 {self.T(0)}, {self.T(0)}, 0, {self.P(g.v_c)}")
+
+    def passes(self, tag, off012, off3, link2, use_sh):
+        """H rows: T <- (multiplier stream) * X * R^-1 with the quotient links.  off012 / off3: first row of the stream
+        read by the digit lanes / by the helper lane."""
+        g, e = self, self.e
+        H = self.H
+        row = self.NPB * 4
+        for j in range(H - 1):
+            e(f"v_mov_b64 {self.T(j)}, 0")
+        e(f"v_mov_b32 v{g.v_d + 1}, 0")
+        e(f"v_and_b32 v{g.v_t1}, {(off3 - off012) * row}, v{g.v_l3mask}")
+        e(f"v_add_u32 v{g.v_arow}, v{g.v_aread}, v{g.v_t1}")
+        if off012:
+            e(f"v_add_u32 v{g.v_arow}, {off012 * row}, v{g.v_arow}")
+        e(f"ds_read_b32 v{g.v_ain}, v{g.v_arow}")
+        e(f"v_add_u32 v{g.v_arow}, {row}, v{g.v_arow}")
+        e(f"s_mov_b32 s{g.s_coff}, 0")
+        e("s_load_dwordx2 s[100:101], s[6:7], 0x0")
+        if H % 2:
+            self.row(g.v_ain, g.v_ai, link2, use_sh)
+            e("s_mov_b32 s19, 1")
+            ra, rb = g.v_ai, g.v_ain
+        else:
+            e("s_mov_b32 s19, 0")
+            ra, rb = g.v_ain, g.v_ai
+        e(".p2align 6")
+        e(f"L_q{tag}:")
+        self.row(ra, rb, link2, use_sh)
+        self.row(rb, ra, link2, use_sh)
+        e("s_add_u32 s19, s19, 2")
+        e(f"s_cmp_lt_u32 s19, {H}")
+        e(f"s_cbranch_scc1 L_q{tag}")
+        e("s_waitcnt lgkmcnt(0)")
+        e(f"v_mov_b64 {self.T(H - 1)}, 0")
+
+    def carry_T(self):
+        """sequential carry through the accumulators: canonical limb j ends up in Tlo(j) (the top limb keeps its excess)"""
+        g, e = self, self.e
+        H = self.H
+        c = self.P(g.v_c)
+        for j in range(H):
+            if j:
+                e(f"v_lshl_add_u64 {self.T(j)}, {self.T(j)}, 0, {c}")
+            if j < H - 1:
+                e(f"v_lshrrev_b64 {c}, {LB}, {self.T(j)}")
+                e(f"v_and_b32 {self.Tlo(j)}, {hex(MASK)}, {self.Tlo(j)}")
+
+    def carry_X(self):
+        """lazy limbs (sums of up to three canonical limbs) -> canonical again; the top limb keeps the excess"""
+        g, e = self, self.e
+        H = self.H
+        for j in range(H):
+            if j:
+                e(f"v_add_u32 {self.X(j)}, {self.X(j)}, v{g.v_t1}")
+            if j < H - 1:
+                e(f"v_lshrrev_b32 v{g.v_t1}, {LB}, {self.X(j)}")
+                e(f"v_and_b32 {self.X(j)}, {hex(MASK)}, {self.X(j)}")
+
+    def montsq(self):
+        g, e = self, self.e
+        H = self.H
+        e("L_montsq:")
+        e("s_nop 1")
+        for j in range(H):                                   # helper lane <- a1 (lanes 0..2 keep their own digit)
+            e(f"v_mov_b32_dpp {self.X(j)}, {self.X(j)} quad_perm:[0,1,2,1] row_mask:0xf bank_mask:0xf")
+        e(f"v_and_b32 v{g.v_sh}, 1, v{g.v_l12mask}")          # lanes 1, 2 double the multiplier: 2 a0 a1, 2 a0 a2
+        self.passes("s", 0, H, True, True)
+        self.carry_T()
+        for j in range(H):
+            e(f"v_mov_b32 {self.X(j)}, {self.Tlo(j)}")
+        e("s_nop 1")
+        for j in range(H):                                   # digit 2 += a1 a1 R^-1 (helper lane)
+            e(f"v_mov_b32_dpp v{g.v_t2}, {self.X(j)} quad_perm:[0,1,3,3] row_mask:0xf bank_mask:0xf")
+            e(f"v_and_b32 v{g.v_t2}, v{g.v_t2}, v{g.v_l2mask}")
+            e(f"v_add_u32 {self.X(j)}, {self.X(j)}, v{g.v_t2}")
+        self.carry_X()
+        e("s_branch L_next")
+
+    def montmul(self):
+        g, e = self, self.e
+        H = self.H
+        row = self.NPB * 4
+        e("L_montmul:")
+        e("s_nop 1")
+        for j in range(H):                                   # helper lane <- a0
+            e(f"v_mov_b32_dpp {self.X(j)}, {self.X(j)} quad_perm:[0,1,2,0] row_mask:0xf bank_mask:0xf")
+        # pass 1: stream b0 in the digit lanes (a0 b0 -> a1 b0 -> a2 b0 chained), stream b2 in the helper lane (a0 b2)
+        self.passes("m1", 0, 2 * H, True, False)
+        self.carry_T()
+        # lanes 0, 1 still need their digits as multiplicands: park their results in the LDS rows of the streams that are
+        # finished (lane 0: rows of b0, lane 1: rows of b2); lanes 2, 3 are done and keep theirs in X
+        e(f"v_and_b32 v{g.v_t4}, {2 * H * row}, v{g.v_l1mask}")
+        e(f"v_add_u32 v{g.v_t4}, v{g.v_t4}, v{g.v_aread}")
+        self.set_exec(0x3)
+        for j in range(H):
+            e(f"ds_write_b32 v{g.v_t4}, {self.Tlo(j)} offset:{j * row}")
+        self.set_exec(0xc)
+        for j in range(H):
+            e(f"v_mov_b32 {self.X(j)}, {self.Tlo(j)}")
+        # pass 2: stream b1 in lanes 0, 1 (a0 b1 -> a1 b1 chained); lanes 2, 3 masked off
+        self.set_exec(0x3)
+        self.passes("m2", H, H, False, False)
+        self.carry_T()
+        e("s_mov_b64 exec, -1")
+        # c0 = t00 | c1 = t10 + t01 | c2 = t20 + t02 + t11
+        e("s_nop 1")
+        St = [f"v{g.vX - 1 - j}" for j in range(0)]          # (no staging registers needed)
+        for j in range(H):
+            e(f"v_mov_b32_dpp v{g.v_t2}, {self.Tlo(j)} quad_perm:[0,0,1,3] row_mask:0xf bank_mask:0xf")   # lane 1 <- t01, lane 2 <- t11
+            e(f"v_mov_b32_dpp v{g.v_t3}, {self.X(j)} quad_perm:[0,1,3,3] row_mask:0xf bank_mask:0xf")     # lane 2 <- t02
+            e(f"v_and_b32 v{g.v_t2}, v{g.v_t2}, v{g.v_l12mask}")
+            e(f"v_and_b32 v{g.v_t3}, v{g.v_t3}, v{g.v_l2mask}")
+            e(f"v_add_u32 {self.Thi(j)}, v{g.v_t2}, v{g.v_t3}")           # the cross-lane part of limb j, kept in the dead half of T(j)
+        self.set_exec(0x3)
+        for j in range(H):
+            e(f"ds_read_b32 {self.X(j)}, v{g.v_t4} offset:{j * row}")    # lanes 0, 1: the parked t00 / t10
+        e("s_waitcnt lgkmcnt(0)")
+        e("s_mov_b64 exec, -1")
+        for j in range(H):
+            e(f"v_add_u32 {self.X(j)}, {self.X(j)}, {self.Thi(j)}")
+        self.carry_X()
+        e("s_branch L_next")
+
+    def generate(self):
+        self.prologue()
+        self.dispatcher()
+        self.montmul()
+        self.montsq()
+        self.epilogue()
+        return "\n".join(self.lines) + "\n"
+
+
+SHAPES = [(74, 1), (37, 1), (55, 1), (55, 2), (74, 2), (55, 4), (74, 4), (37, 2), (37, 4), (37, 16), (74, 32), (55, 32), (37, 32), (37, 64), (74, 48), (37, 48)]
 PAIR = {(37, 16)}           # (H, 16): the pair kernel for N = p^2 with H-limb p (GenP); 16 is a tag, not a lane count
 PAIR4 = {(37, 64)}          # (WL, 64): GenQ4, the two digits of GenQ(2 WL) sliced over two lanes each
 PAIR2 = {(74, 32), (55, 32), (37, 32)}          # (H, 32): the two-lane pair kernel for N = n^2 with H-limb n (GenQ)
 WAVE_SLICED = {(74, 2), (55, 2)}     # shapes whose slices live in different waves (GenW) instead of neighbouring lanes (Gen)
+TRIPLE = {(74, 48), (37, 48)}        # (H, 48): GenQ3, residues modulo n^3 as three base-n digits in the lanes of a quad
 
 
 def make_gen(wl, k):
@@ -2178,6 +2492,8 @@ def make_gen(wl, k):
         return GenQ(wl)
     if (wl, k) in PAIR4:
         return GenQ4(wl)
+    if (wl, k) in TRIPLE:
+        return GenQ3(wl)
     return GenW(wl, k) if (wl, k) in WAVE_SLICED else Gen(wl, k)
 
 
