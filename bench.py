@@ -318,6 +318,22 @@ def main():
         checks["decrypt_3072"] = (n3k, lam3, dc[:32].cpu().numpy(), do[:32].cpu().numpy())
         del pk3, sk3, dm, dr, dc, do
 
+        # level-two (Damgard-Jurik s = 2) EncryptWithR, 16384 ciphertexts: r^(n^2) (1+n)^m mod n^3 on the three-digit kernel
+        BL = 16384
+        rg = np.random.default_rng(6)
+        lm_h, lr_h = rand_below(n2k * n2k, BL, 512, rg), rand_below(n2k, BL, 256, rg)
+        lr_h[:, -1] |= 1
+        lm, lr = torch.from_numpy(lm_h).to(dev), torch.from_numpy(lr_h).to(dev)
+        lc = torch.zeros((BL, 768), dtype=torch.uint8, device=dev)
+        lo = torch.zeros((BL, 512), dtype=torch.uint8, device=dev)
+        dt, vms, mads, kern = timed(lambda: one_call(lambda: pk2.encrypt_with_r_raw(
+            BL, lm.data_ptr(), 512, lr.data_ptr(), 256, lc.data_ptr(), 768, MEM_DEVICE, level=1)), ES)
+        sk2.decrypt_raw(BL, lc.data_ptr(), 768, lo.data_ptr(), 512, MEM_DEVICE, level=1)
+        assert torch.equal(lo, lm), "[bench] level-two Encrypt: Decrypt(Encrypt(m, r)) != m"
+        extras.append(entry("encrypt_l2_2048", "Batch 16384 level-two EncryptWithR, 2048-bit n (r^(n^2) * (1+n)^m mod n^3)",
+                            "encryptions/s", BL, dt, vms, mads, kern, "16384-lane level-two decrypt round trip"))
+        del lm, lr, lc, lo
+
         # config 5: DDLEQ prove / verify, 2048-bit, 16384 (statement, instance) pairs, secpar = 1 each
         BD = 16384
         rg = np.random.default_rng(5)
@@ -399,8 +415,19 @@ def main():
             note()
             return o
 
+        def units_fn(server_index, rows):
+            # this rank's (server, ciphertext) units in one launch: per-unit exponents (pgpu_partial_decrypt_indexed)
+            o = torch.empty((rows.shape[0], 512), dtype=torch.uint8, device=dev)
+            rows = rows.contiguous()
+            tk.partial_decrypt_indexed_raw([shares[i - 1] for i in ids], server_index, rows.shape[0], rows.data_ptr(), 512,
+                                           o.data_ptr(), 512, MEM_DEVICE)
+            note()
+            return o
+
         def tstep():
-            return pdist.threshold_decrypt_sharded(tc, len(ids), rank, world, partial_fn, combine_fn)
+            # one launch per rank once a rank's share of a server falls below what fills the chip on its own
+            return pdist.threshold_decrypt_sharded(tc, len(ids), rank, world, partial_fn, combine_fn,
+                                                   units_fn=units_fn if (len(ids) * BT) // world < 32768 else None)
 
         tstep()
         barrier()

@@ -59,7 +59,11 @@ typedef struct pgpu_modulus pgpu_modulus;
 const char* pgpu_last_error(void);
 const char* pgpu_version(void);
 
-/* device = HIP device ordinal; stream = hipStream_t to launch on, or NULL for the default stream. */
+/* device = HIP device ordinal; stream = hipStream_t to launch on, NULL for the default stream, or PGPU_STREAM_NEW for a
+ * non-blocking stream that the context creates and owns.  A context is thread-compatible (one call at a time); batches too
+ * small to fill the GPU (a few thousand ciphertexts: the run time is the latency of one ladder) are overlapped by issuing
+ * them from several host threads on several contexts with streams of their own -- the kernels then share the chip. */
+#define PGPU_STREAM_NEW ((void*)(intptr_t)-1)
 int pgpu_ctx_create(int device, void* stream, pgpu_ctx** out);
 void pgpu_ctx_destroy(pgpu_ctx* ctx);
 /* Timing of the dominant (modexp VM) kernel of the last batch call, measured with HIP events on
@@ -151,6 +155,14 @@ int pgpu_const_mult(const pgpu_pubkey* pk, int level, size_t batch, const uint8_
  * l = total_servers.  The share stays on the caller's side of the ABI (big-endian). */
 int pgpu_partial_decrypt(const pgpu_pubkey* pk, int total_servers, const uint8_t* share_be, size_t share_len, size_t batch,
                          const uint8_t* c, size_t c_stride, uint8_t* out, size_t out_stride, int mem);
+
+/* ThresholdSecretKey.PartialDecrypt for a batch of (share, ciphertext) UNITS: out[i] = c[i]^(2 * l! * shares[share_index[i]])
+ * mod n^2.  One launch serves the units of several decryption servers (or any mix of them): the exponents become per-unit
+ * operands of the ladder.  This is what a shard of a threshold batch looks like -- e.g. 16 384 ciphertexts x 3 servers over
+ * 8 GPUs = 6 144 units per GPU: per server they could not fill the chip.  share_index: host int32[batch]. */
+int pgpu_partial_decrypt_indexed(const pgpu_pubkey* pk, int total_servers, int n_shares, const uint8_t* const* shares_be,
+                                 const size_t* share_lens, size_t batch, const uint8_t* c, size_t c_stride,
+                                 const int32_t* share_index, uint8_t* out, size_t out_stride, int mem);
 
 /* ThresholdPublicKey.CombinePartialDecryptions (thresholdkey.go:149-161) for a batch of ciphertexts:
  *   m[i] = L( prod_k partials[k][i]^(2 lambda_k) mod n^2 ) * (4 (l!)^2)^-1 mod n

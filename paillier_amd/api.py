@@ -67,6 +67,7 @@ SIGNATURES = {
     "pgpu_add_many": (_int, [_vp, _int, _int, _sz, _vp, _sz, _vp, _sz, _int]),
     "pgpu_sub_many": (_int, [_vp, _int, _int, _sz, _vp, _sz, _vp, _sz, _int, _vp]),
     "pgpu_partial_decrypt": (_int, [_vp, _int, _vp, _sz, _sz, _vp, _sz, _vp, _sz, _int]),
+    "pgpu_partial_decrypt_indexed": (_int, [_vp, _int, _int, _vp, _vp, _sz, _vp, _sz, _vp, _vp, _sz, _int]),
     "pgpu_combine_partial_decryptions": (_int, [_vp, _int, _int, _int, _vp, _sz, _vp, _sz, _vp, _sz, _int, _vp]),
     "pgpu_random_oracle_digest": (_int, [_vp, _int, _vp, _vp, _sz, _vp, _int]),
     "pgpu_ddleq_verify": (_int, [_vp, _sz, _vp, _vp, _sz, _vp, _vp, _sz, _vp, _sz, _vp, _sz, _vp, _sz, _vp, _int]),
@@ -134,10 +135,12 @@ def _ptr(a) -> int:
 class Context:
     """One device + stream.  `stream` is a hipStream_t handle (e.g. torch.cuda.current_stream().cuda_stream)."""
 
-    def __init__(self, device: int = 0, stream: Optional[int] = None):
+    def __init__(self, device: int = 0, stream: Optional[int] = None, own_stream: bool = False):
+        """own_stream: the context creates a non-blocking stream of its own (PGPU_STREAM_NEW) -- for overlapping small
+        batches issued from several host threads (paillier_amd.concurrent)."""
         self.lib = load_library()
         h = _vp()
-        _check(self.lib.pgpu_ctx_create(device, _vp(stream or 0), C.byref(h)))
+        _check(self.lib.pgpu_ctx_create(device, _vp(-1 if own_stream else (stream or 0)), C.byref(h)))
         self.h = h
         self.device = device
 
@@ -420,6 +423,16 @@ class ThresholdPublicKey(PublicKey):
         sb = _be(share)
         _check(self.ctx.lib.pgpu_partial_decrypt(self.h, self.TotalNumberOfDecryptionServers, sb, len(sb), batch, _ptr(c),
                                                  c_stride, _ptr(out), out_stride, mem))
+
+    def partial_decrypt_indexed_raw(self, shares: Sequence[int], share_index: np.ndarray, batch, c, c_stride, out, out_stride,
+                                    mem=MEM_HOST):
+        """pgpu_partial_decrypt_indexed: unit i uses shares[share_index[i]] (share_index: host int32[batch])."""
+        bs = [_be(s_) for s_ in shares]
+        arr = (C.c_char_p * len(bs))(*bs)
+        lens = (C.c_size_t * len(bs))(*[len(b) for b in bs])
+        si = np.ascontiguousarray(share_index, dtype=np.int32)
+        _check(self.ctx.lib.pgpu_partial_decrypt_indexed(self.h, self.TotalNumberOfDecryptionServers, len(bs), arr, lens, batch,
+                                                         _ptr(c), c_stride, _ptr(si), _ptr(out), out_stride, mem))
 
     def combine_raw(self, ids: Sequence[int], batch, partial_ptrs: Sequence[int], stride, m, m_stride, mem=MEM_HOST,
                     status: Optional[np.ndarray] = None):

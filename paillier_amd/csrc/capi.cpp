@@ -60,6 +60,7 @@ template <class T> void wipe_vec(std::vector<T>& v) { if (!v.empty()) wipe(v.dat
 struct pgpu_ctx {
   int device = 0;
   hipStream_t stream = nullptr;
+  bool own_stream = false;   // created by pgpu_ctx_create(device, PGPU_STREAM_NEW): destroyed with the context
   // workspace: list of chunks, bump allocated, reset per API call
   struct Chunk { char* p; size_t cap; size_t used; };
   std::vector<Chunk> chunks;
@@ -133,6 +134,7 @@ struct pgpu_ctx {
     wipe_ws();
     for (auto& c : chunks) (void)hipFree(c.p);
     for (auto& e : evs) { (void)hipEventDestroy(e.a); (void)hipEventDestroy(e.b); }
+    if (own_stream) (void)hipStreamDestroy(stream);
   }
 };
 
@@ -718,7 +720,14 @@ int pgpu_ctx_create(int device, void* stream, pgpu_ctx** out) {
   pgpu_ctx* c = new pgpu_ctx();
   c->device = device;
   c->stream = (hipStream_t)stream;
-  int rc = guarded([&] { c->bind(); });
+  int rc = guarded([&] {
+    c->bind();
+    if (stream == PGPU_STREAM_NEW) {
+      c->stream = nullptr;
+      HIPCHK(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
+      c->own_stream = true;
+    }
+  });
   if (rc != PGPU_OK) { delete c; return rc; }
   { std::lock_guard<std::mutex> lk(g_live_mu); g_live_ctx.insert(c); }
   *out = c;
@@ -2407,6 +2416,51 @@ int pgpu_partial_decrypt(const pgpu_pubkey* pk, int total_servers, const uint8_t
     ModexpPlan pl = modexp_alloc(ctx, mc, nb, 32);
     unpack_mod(ctx, mc, c, c_stride, batch, mem, pl.in(), nb);
     modexp_shared_run(ctx, mc, pl, e, false, false, true);
+    pack_result(ctx, pl.out(), mc.WT, nb, batch, out, out_stride, mc.nbytes, mem);
+    HIPCHK(hipStreamSynchronize(ctx->stream));
+  });
+}
+
+int pgpu_partial_decrypt_indexed(const pgpu_pubkey* pk, int total_servers, int n_shares, const uint8_t* const* shares_be,
+                                 const size_t* share_lens, size_t batch, const uint8_t* c, size_t c_stride,
+                                 const int32_t* share_index, uint8_t* out, size_t out_stride, int mem) {
+  if (!pk || !shares_be || !share_lens || !share_index) return fail(PGPU_ERR_INVALID, "null argument");
+  pgpu_ctx* ctx = pk->ctx;
+  return guarded([&] {
+    check_batch_args(c, out, batch);
+    if (total_servers < 1 || n_shares < 1 || n_shares > 4096) api_throw(PGPU_ERR_INVALID, "bad share count");
+    for (size_t i = 0; i < batch; ++i)
+      if (share_index[i] < 0 || share_index[i] >= n_shares) api_throw(PGPU_ERR_INVALID, "share index out of range");
+    ctx->bind();
+    ctx->reset_ws();
+    const ModCtx& mc = pk->mn2;
+    const size_t nb = round_up(batch, VM_BLOCK);
+    // thresholdkey.go:195: exp = Share * (2 * delta) for every share; the ladder takes them as per-number exponents, so the
+    // units of SEVERAL servers share one launch (a few thousand ciphertexts per server cannot fill the chip on their own)
+    const BigU two_delta = BigU(2) * factorial_big(total_servers);
+    std::vector<BigU> exps_big;
+    size_t ebits = 1;
+    for (int k = 0; k < n_shares; ++k) {
+      if (!shares_be[k]) api_throw(PGPU_ERR_INVALID, "null share");
+      exps_big.push_back(BigU::from_be(shares_be[k], share_lens[k]) * two_delta);
+      ebits = std::max(ebits, exps_big.back().bit_length());
+    }
+    const int we = (int)((ebits + LB - 1) / LB);
+    std::vector<uint32_t> table;
+    for (auto& e : exps_big) {
+      auto l = e.to_limbs(LB, (size_t)we);
+      table.insert(table.end(), l.begin(), l.end());
+      wipe_vec(e.d);
+    }
+    uint32_t* d_table = ctx->upload_words(table);
+    wipe_vec(table);
+    std::vector<uint32_t> idx(share_index, share_index + batch);
+    const int32_t* d_idx = (const int32_t*)ctx->upload_words(idx);
+    uint32_t* exps = ctx->ws_t<uint32_t>((size_t)we * nb);
+    launch_gather_rows(d_table, we, d_idx, batch, exps, nb, ctx->stream);
+    ModexpPlan pl = modexp_alloc(ctx, mc, nb, 16);
+    unpack_mod(ctx, mc, c, c_stride, batch, mem, pl.in(), nb);
+    modexp_perlane_run(ctx, mc, pl, exps, we, false, false);
     pack_result(ctx, pl.out(), mc.WT, nb, batch, out, out_stride, mc.nbytes, mem);
     HIPCHK(hipStreamSynchronize(ctx->stream));
   });

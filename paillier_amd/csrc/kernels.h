@@ -74,3 +74,5 @@ void launch_unit_flags(const uint32_t* x, const uint32_t* nmod, int w, size_t nb
                        hipStream_t st);
 void launch_or_flags(const int32_t* flags, size_t count, int32_t* status, int32_t flag, hipStream_t st);
 void launch_clear_where(const int32_t* flags, size_t count, int32_t* ok, hipStream_t st);
+// out[l][g] = table[idx[g]][l] (g < count; padding lanes take row 0)
+void launch_gather_rows(const uint32_t* table, int w, const int32_t* idx, size_t count, uint32_t* out, size_t nb, hipStream_t st);

@@ -713,6 +713,15 @@ __global__ void k_unit_flags(const uint32_t* __restrict__ x, const uint32_t* __r
   flags[g] = !(lb == 1 && B[0] == 1u);
 }
 
+// out[l][g] = table[idx[g]][l]: per-number exponent limbs from a small table of exponents (one row per key share)
+__global__ void k_gather_rows(const uint32_t* __restrict__ table, int w, const int32_t* __restrict__ idx, size_t count,
+                              uint32_t* __restrict__ out, size_t nb) {
+  size_t g = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (g >= nb) return;
+  const uint32_t* row = table + (size_t)(g < count ? idx[g] : 0) * w;
+  for (int l = 0; l < w; ++l) out[(size_t)l * nb + g] = row[l];
+}
+
 // status[g] |= flag where flags[g] != 0 (g < count)
 __global__ void k_or_flags(const int32_t* __restrict__ flags, size_t count, int32_t* __restrict__ status, int32_t flag) {
   size_t g = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -856,4 +865,7 @@ void launch_or_flags(const int32_t* flags, size_t count, int32_t* status, int32_
 }
 void launch_clear_where(const int32_t* flags, size_t count, int32_t* ok, hipStream_t st) {
   hipLaunchKernelGGL(k_clear_where, HELPER_GRID(count ? count : 1), 0, st, flags, count, ok);
+}
+void launch_gather_rows(const uint32_t* table, int w, const int32_t* idx, size_t count, uint32_t* out, size_t nb, hipStream_t st) {
+  hipLaunchKernelGGL(k_gather_rows, HELPER_GRID(nb), 0, st, table, w, idx, count, out, nb);
 }

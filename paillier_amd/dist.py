@@ -46,7 +46,8 @@ def all_gather_bytes(local, world: int):
     return out.view((world,) + tuple(local.shape))
 
 
-def threshold_decrypt_sharded(c, n_servers: int, rank: int, world: int, partial_fn, combine_fn, pad_rows: bool = True):
+def threshold_decrypt_sharded(c, n_servers: int, rank: int, world: int, partial_fn, combine_fn, pad_rows: bool = True,
+                              units_fn=None):
     """Threshold decryption of B ciphertexts with the work sharded over `world` ranks and ONE exchange step
     (thresholdkey.go:149-201: every server's PartialDecrypt, then CombinePartialDecryptions).
 
@@ -59,6 +60,9 @@ def threshold_decrypt_sharded(c, n_servers: int, rank: int, world: int, partial_
                    collective backend moves (cuda for nccl, cpu for gloo)
       partial_fn   (server_index, c_rows) -> uint8 tensor [len(c_rows), cipher_bytes]      PartialDecrypt of one server
       combine_fn   ([rows of server 0, rows of server 1, ...]) -> uint8 tensor [rows, plain_bytes]   Combine
+      units_fn     optional: (server_index int32 numpy [units], c_rows [units, cipher_bytes]) -> uint8 tensor [units,
+                   cipher_bytes]: this rank's units in ONE call (pgpu_partial_decrypt_indexed) instead of one partial_fn
+                   call per server -- a shard of a few thousand units fills the GPU only when its servers share a launch
     Returns (plaintext rows of this rank's ciphertext slice, (begin, end) of that slice).
     """
     import torch
@@ -67,12 +71,18 @@ def threshold_decrypt_sharded(c, n_servers: int, rank: int, world: int, partial_
     ub, ue = shard_slice(units, rank, world)
     per = -(-units // world) if pad_rows else (ue - ub)      # all-gather needs equal shapes
     local = torch.zeros((max(per, 1), cbytes), dtype=torch.uint8, device=c.device)
-    u = ub
-    while u < ue:
-        s, i0 = divmod(u, B)
-        cnt = min(ue - u, B - i0)
-        local[u - ub:u - ub + cnt] = partial_fn(s, c[i0:i0 + cnt])
-        u += cnt
+    if units_fn is not None and ue > ub:
+        import numpy as np
+        us = np.arange(ub, ue, dtype=np.int64)
+        rows = c[torch.from_numpy(us % B).to(c.device)]
+        local[:ue - ub] = units_fn((us // B).astype(np.int32), rows)
+    else:
+        u = ub
+        while u < ue:
+            s, i0 = divmod(u, B)
+            cnt = min(ue - u, B - i0)
+            local[u - ub:u - ub + cnt] = partial_fn(s, c[i0:i0 + cnt])
+            u += cnt
     g = all_gather_bytes(local, world).reshape(world * max(per, 1), cbytes)
     parts = torch.empty((units, cbytes), dtype=torch.uint8, device=c.device)
     for q in range(world):          # un-pad: rank q's units sit at rows [q*per, q*per + len_q)

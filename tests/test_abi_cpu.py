@@ -85,6 +85,15 @@ def test_asm_generator_model():
                 body = text.split(where)[1].split(lbl + ":")[1].split("s_cbranch_scc1 " + lbl)[0]
                 assert body.count("v_mad_u64_u32") == 2 * 2 * wl          # two rows of 2 WL multiplies per lane
             continue
+        if (wl, k) in gen_vm_asm.TRIPLE:
+            # three-digit kernel: every pass is a loop of two single-lane rows of 2H multiplies (a squaring: one pass in four
+            # lanes; a product: two passes, the second in two lanes); two quotient links per row in the linked passes
+            for lbl, where, hops in (("L_qs", "L_montsq:", 2), ("L_qm1", "L_montmul:", 2), ("L_qm2", "L_montmul:", 1)):
+                body = text.split(where)[1].split(lbl + ":")[1].split("s_cbranch_scc1 " + lbl)[0]
+                assert body.count("v_mad_u64_u32") == 2 * 2 * wl
+                assert body.count("quad_perm:[0,0,1,2]") == 2 * hops
+            assert g.lds_bytes * 2 <= 160 * 1024
+            continue
         if (wl, k) in gen_vm_asm.PAIR2:
             # two-lane pair kernel: every pass is a loop of two single-lane rows of 2H multiplies; a squaring has one pass,
             # a product two

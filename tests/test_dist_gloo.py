@@ -125,7 +125,14 @@ def _threshold_worker(rank, world, port, ids, count, use_gpu, q):
             cols = [to_ints(x) for x in parts]
             return to_rows([po.combine_partial_decryptions(tsk[ids[0]], [po.PartialDecryption(i, col[j]) for i, col in zip(ids, cols)])
                             for j in range(len(cols[0]))], pb)
-    out, (b, e) = pd.threshold_decrypt_sharded(c, len(ids), rank, world, partial_fn, combine_fn)
+    units_fn = None
+    if use_gpu:   # the one-launch form of a rank's units (pgpu_partial_decrypt_indexed)
+        def units_fn(server_index, rows):
+            rows = rows.contiguous().numpy()
+            out = np.zeros((rows.shape[0], cb), dtype=np.uint8)
+            tk.partial_decrypt_indexed_raw([shares[i - 1] for i in ids], server_index, rows.shape[0], rows, cb, out, cb)
+            return torch.from_numpy(out)
+    out, (b, e) = pd.threshold_decrypt_sharded(c, len(ids), rank, world, partial_fn, combine_fn, units_fn=units_fn)
     q.put((rank, b, e, to_ints(out) if out is not None else []))
     dist.barrier()
     dist.destroy_process_group()

@@ -83,3 +83,35 @@ def test_create_verification_keys_kat_and_large(ctx):
     shares = [rng.randrange(n * n) for _ in range(100)]
     v = int(k["v"], 16)
     assert pr.create_verification_keys(tk, v, shares) == po.tkg_create_verification_keys(v, n * n, 100, shares)
+
+
+@pytest.mark.parametrize("bits", ["512", "2048"])
+def test_partial_decrypt_indexed_units(ctx, bits):
+    """pgpu_partial_decrypt_indexed: (share, ciphertext) units of several servers in ONE launch (per-unit exponents) must
+    equal the per-server PartialDecrypt, i.e. the committed partials / the oracle."""
+    import numpy as np
+    import paillier_amd as pa
+    from paillier_amd.api import be_to_ints, ints_to_be
+    k = json.load(open(os.path.join(G, "keys.json")))["threshold"][bits]
+    n, total, thr = int(k["n"], 16), k["total"], k["threshold"]
+    shares = [int(s, 16) for s in k["shares"]]
+    tk = pa.ThresholdPublicKey(ctx, n, total=total, threshold=thr)
+    rng = random.Random(int(bits) + 3)
+    pkk = po.PublicKey(N=n, G=n + 1)
+    cts = [po.encrypt_with_r(pkk, rng.randrange(n), po.rand_unit(n, rng)).C for _ in range(7)]
+    units = [(s, i) for s in (0, 2, 4, 1) for i in range(len(cts))][3:]          # ragged: starts in the middle of a server
+    cb = tk.cipher_bytes()
+    rows = ints_to_be([cts[i] for _, i in units], cb)
+    out = np.zeros((len(units), cb), dtype=np.uint8)
+    tk.partial_decrypt_indexed_raw(shares, np.array([s for s, _ in units], dtype=np.int32), len(units), rows, cb, out, cb)
+    want = {s: tk.PartialDecryptBatch(s + 1, shares[s], cts)[1] for s in (0, 1, 2, 4)}
+    assert be_to_ints(out) == [want[s][i] for s, i in units]
+    tsk = po.ThresholdSecretKey(N=n, G=n + 1, TotalNumberOfDecryptionServers=total, Threshold=thr, ID=3, Share=shares[2])
+    assert want[2][:2] == [po.partial_decrypt(tsk, c).Decryption for c in cts[:2]]
+    if bits == "2048":
+        th = json.load(open(os.path.join(G, "proofs.json")))["threshold"]
+        cs = [int(x, 16) for x in th["c"]]
+        rows = ints_to_be(cs * 5, cb)
+        out = np.zeros((len(cs) * 5, cb), dtype=np.uint8)
+        tk.partial_decrypt_indexed_raw(shares, np.repeat(np.arange(5, dtype=np.int32), len(cs)), len(cs) * 5, rows, cb, out, cb)
+        assert be_to_ints(out) == [int(x, 16) for row in th["partials"] for x in row]
