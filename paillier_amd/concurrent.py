@@ -19,8 +19,14 @@ from .api import Context
 class Lanes:
     """`width` contexts on one device, each with its own stream, and a thread pool to drive them."""
 
-    def __init__(self, device: int = 0, width: int = 4):
+    def __init__(self, device: int = 0, width: int = 4, partition_cus: bool = True):
+        """partition_cus: lane k's stream is confined to the k-th of `width` slices of the device's compute units, so that the
+        lanes' kernels run side by side instead of piling up on the same CUs (measured: three concurrent 2048-ciphertext
+        PartialDecrypt calls take 1.8x the time of one without the partition)."""
         self.contexts: List[Context] = [Context(device, own_stream=True) for _ in range(width)]
+        if partition_cus and width > 1:
+            for k, cx in enumerate(self.contexts):
+                cx.set_flag("cu_partition", (width << 16) | k)
         self.pool = ThreadPoolExecutor(max_workers=width)
         self.state: List[dict] = [{} for _ in range(width)]      # per-lane cache for key handles etc.
 

@@ -748,6 +748,28 @@ int pgpu_ctx_set_flag(pgpu_ctx* ctx, const char* name, int value) {
   if (strcmp(name, "pair") == 0) { ctx->use_pair = value != 0; return PGPU_OK; }
   if (strcmp(name, "triple") == 0) { ctx->use_triple = value != 0; return PGPU_OK; }
   if (strcmp(name, "lanes_wanted") == 0) { ctx->lanes_wanted = value > 0 ? (size_t)value : 0; return PGPU_OK; }
+  if (strcmp(name, "cu_partition") == 0) {
+    // value = (parts << 16) | part: confine this context's (own) stream to the part-th of `parts` equal slices of the
+    // device's compute units.  Kernels of concurrently running contexts otherwise pile up on the same CUs (the dispatcher
+    // starts every kernel's workgroups from the same place) and slow each other down instead of using the idle ones.
+    if (!ctx->own_stream) return fail(PGPU_ERR_INVALID, "cu_partition needs a context created with PGPU_STREAM_NEW");
+    const int parts = value >> 16, part = value & 0xffff;
+    if (parts < 1 || part >= parts) return fail(PGPU_ERR_INVALID, "cu_partition: part out of range");
+    return guarded([&] {
+      ctx->bind();
+      hipDeviceProp_t prop;
+      HIPCHK(hipGetDeviceProperties(&prop, ctx->device));
+      const int ncu = prop.multiProcessorCount;
+      std::vector<uint32_t> mask((size_t)(ncu + 31) / 32, 0);
+      const int lo = (int)((long)ncu * part / parts), hi = (int)((long)ncu * (part + 1) / parts);
+      for (int i = lo; i < hi; ++i) mask[(size_t)i / 32] |= 1u << (i % 32);
+      HIPCHK(hipStreamSynchronize(ctx->stream));
+      hipStream_t ns = nullptr;
+      HIPCHK(hipExtStreamCreateWithCUMask(&ns, (uint32_t)mask.size(), mask.data()));
+      HIPCHK(hipStreamDestroy(ctx->stream));
+      ctx->stream = ns;
+    });
+  }
   return fail(PGPU_ERR_INVALID, "unknown flag %s", name);
 }
 

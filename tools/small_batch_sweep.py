@@ -51,8 +51,8 @@ for B in [int(x) for x in (sys.argv[1:] or [512, 1024, 2048, 4096, 8192, 16384, 
 # ---- the same small batches overlapped: `width` independent PartialDecrypt calls (e.g. the servers of a threshold
 # decryption) on contexts with streams of their own, driven from host threads (paillier_amd.concurrent.Lanes)
 from paillier_amd.concurrent import Lanes
-for width in (3, 8):
-    lanes = Lanes(0, width)
+for width, part in ((3, False), (3, True), (8, True)):
+    lanes = Lanes(0, width, partition_cus=part)
     bufs = [torch.zeros((4096, 512), dtype=torch.uint8, device=dev) for _ in range(width)]
 
     def call(cx, st, item):
@@ -70,6 +70,17 @@ for width in (3, 8):
             lanes.map(call, items)
         torch.cuda.synchronize()
         dt = (time.perf_counter() - t) / 3
-        print(json.dumps({"op": "partial_decrypt_2048_overlapped", "calls_in_flight": width, "batch_per_call": B, "ms": dt * 1e3,
+        print(json.dumps({"op": "partial_decrypt_2048_overlapped", "calls_in_flight": width, "cu_partition": part, "batch_per_call": B, "ms": dt * 1e3,
                           "us_per_ct": dt / (B * width) * 1e6, "per_s": B * width / dt}), flush=True)
     lanes.close()
+
+# ---- the units of three servers in ONE launch (pgpu_partial_decrypt_indexed: per-unit exponents)
+for B in (2048, 4096, 16384):
+    S = 3
+    rows = c[:B].repeat(S, 1).contiguous()
+    idx = np.repeat(np.arange(S, dtype=np.int32), B)
+    o = torch.zeros((S * B, 512), dtype=torch.uint8, device=dev)
+    dt = timed(lambda: tk.partial_decrypt_indexed_raw(shares[:S], idx, S * B, rows.data_ptr(), 512, o.data_ptr(), 512, MEM_DEVICE))
+    pr = ctx.last_profile()
+    print(json.dumps({"op": "partial_decrypt_2048_indexed", "servers": S, "ciphertexts": B, "ms": dt * 1e3,
+                      "us_per_unit": dt / (S * B) * 1e6, "units_per_s": S * B / dt, "kernel": pr["kernel"]}), flush=True)
