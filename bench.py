@@ -297,7 +297,19 @@ def main():
         assert torch.equal(eo, em), "[bench] Encrypt-2048: Decrypt(Encrypt(m, r)) != m"
         extras.append(entry("encrypt_2048", "Batch 65536 EncryptWithR, 2048-bit n, level 1 (r^n * (1+n)^m mod n^2)",
                             "encryptions/s", BE, dt, vms, mads, kern, "65536-lane decrypt round trip"))
+        # the same batch with the library drawing r itself (PublicKey.Encrypt, paillier.go:258-269): getrandom(2) on host
+        # threads + rejection below n, gcd test on the device
+        ec2 = torch.zeros((BE, 512), dtype=torch.uint8, device=dev)
+        t = time.perf_counter()
+        for _ in range(ES):
+            pk2.encrypt_raw(BE, em.data_ptr(), 256, ec2.data_ptr(), 512, None, 0, MEM_DEVICE)
+        torch.cuda.synchronize()
+        dt_rng = (time.perf_counter() - t) / ES
+        sk2.decrypt_raw(BE, ec2.data_ptr(), 512, eo.data_ptr(), 256, MEM_DEVICE)
+        assert torch.equal(eo, em), "[bench] Encrypt (library randomness): Decrypt(Encrypt(m)) != m"
+        extras[-1].update({"encrypt_with_library_randomness_per_s": BE / dt_rng, "fraction_of_with_r": dt / dt_rng})
         checks["encrypt_2048"] = (n2k, em_h[:64], er_h[:64], ec[:64].cpu().numpy())
+        del ec2
 
         # config 3: Batch 65536 Decrypt, 3072-bit
         p3, q3, n3k, lam3 = paillier_key(3072)

@@ -1,0 +1,188 @@
+// gpu.go -- cgo binding of libpaillier_hip.so (include/paillier_hip.h) for package paillier.
+//
+// Drop this file and batch.go next to paillier.go / operations.go / thresholdkey.go / ddleq.go of
+// sachaservan/paillier: they ADD batch variants of the exported methods and leave every existing type and signature
+// untouched (the scalar methods keep running on github.com/ncw/gmp).  Build with cgo:
+//
+//	CGO_CFLAGS="-I<repo>/include" CGO_LDFLAGS="-L<repo>/paillier_amd -lpaillier_hip" go build
+//
+// NOT compiled in the build image of this repository (no Go toolchain, ncw/gmp not vendored); the C entry points are
+// exercised, with the same calling convention -- caller-owned flat big-endian buffers, int status -- by
+// tests/c/test_cabi.c, tests/cpp/test_host_mirror.cpp and the ctypes mirror paillier_amd/api.py.
+//
+// Operand format at the boundary: what gmp.Int.Bytes() gives, left-padded with zeros to a fixed stride, element-major.
+// cgo rule: no Go pointer is retained by C after a call returns; every buffer below is a Go slice passed for the duration
+// of one blocking call.
+package paillier
+
+/*
+#cgo LDFLAGS: -lpaillier_hip
+#include <stdint.h>
+#include <stdlib.h>
+#include "paillier_hip.h"
+*/
+import "C"
+
+import (
+	"errors"
+	"fmt"
+	"unsafe"
+
+	gmp "github.com/ncw/gmp"
+)
+
+// GPU is one device context (one HIP stream).  Thread-compatible: one batch call at a time per GPU value; use several
+// (NewGPUOwnStream) for concurrent small batches.
+type GPU struct{ ctx *C.pgpu_ctx }
+
+// GPUError carries the C ABI's status code (PGPU_ERR_*).
+type GPUError struct {
+	Code int
+	Msg  string
+}
+
+func (e *GPUError) Error() string { return fmt.Sprintf("paillier_hip [%d]: %s", e.Code, e.Msg) }
+
+func status(rc C.int) error {
+	if rc == C.PGPU_OK {
+		return nil
+	}
+	return &GPUError{int(rc), C.GoString(C.pgpu_last_error())}
+}
+
+// NewGPU opens HIP device `device` on the default stream.
+func NewGPU(device int) (*GPU, error) {
+	var ctx *C.pgpu_ctx
+	if err := status(C.pgpu_ctx_create(C.int(device), nil, &ctx)); err != nil {
+		return nil, err
+	}
+	return &GPU{ctx}, nil
+}
+
+// NewGPUOwnStream opens a context with a stream of its own; part/parts confine it to one slice of the compute units
+// (parts == 0: the whole device) so that several contexts run small batches side by side.
+func NewGPUOwnStream(device, part, parts int) (*GPU, error) {
+	var ctx *C.pgpu_ctx
+	if err := status(C.pgpu_ctx_create(C.int(device), unsafe.Pointer(^uintptr(0)), &ctx)); err != nil {
+		return nil, err
+	}
+	g := &GPU{ctx}
+	if parts > 1 {
+		name := C.CString("cu_partition")
+		defer C.free(unsafe.Pointer(name))
+		if err := status(C.pgpu_ctx_set_flag(ctx, name, C.int(parts<<16|part))); err != nil {
+			g.Close()
+			return nil, err
+		}
+	}
+	return g, nil
+}
+
+func (g *GPU) Close() {
+	if g.ctx != nil {
+		C.pgpu_ctx_destroy(g.ctx)
+		g.ctx = nil
+	}
+}
+
+// ---- packing -------------------------------------------------------------------------------------------------------
+
+func pack(xs []*gmp.Int, stride int) []byte {
+	buf := make([]byte, len(xs)*stride)
+	for i, x := range xs {
+		b := x.Bytes() // minimal big-endian magnitude
+		if len(b) > stride {
+			panic("paillier: operand wider than its stride")
+		}
+		copy(buf[(i+1)*stride-len(b):(i+1)*stride], b)
+	}
+	return buf
+}
+
+func unpack(buf []byte, stride int) []*gmp.Int {
+	out := make([]*gmp.Int, len(buf)/stride)
+	for i := range out {
+		out[i] = new(gmp.Int).SetBytes(buf[i*stride : (i+1)*stride])
+	}
+	return out
+}
+
+func maxLen(xs []*gmp.Int, atLeast int) int {
+	n := atLeast
+	for _, x := range xs {
+		if l := len(x.Bytes()); l > n {
+			n = l
+		}
+	}
+	return n
+}
+
+func p8(b []byte) *C.uint8_t {
+	if len(b) == 0 {
+		return nil
+	}
+	return (*C.uint8_t)(unsafe.Pointer(&b[0]))
+}
+
+func bytesOf(x *gmp.Int) []byte {
+	b := x.Bytes()
+	if len(b) == 0 {
+		return []byte{0}
+	}
+	return b
+}
+
+// ---- key handles ---------------------------------------------------------------------------------------------------
+
+// GPUPublicKey is the device-side image of a PublicKey (n^2, n^3 and all Montgomery constants precomputed once).
+type GPUPublicKey struct {
+	g  *GPU
+	pk *PublicKey
+	h  *C.pgpu_pubkey
+}
+
+// Upload precomputes the key on the device (paillier.go:46-57 fields N, G, H, K).
+func (g *GPU) Upload(pk *PublicKey) (*GPUPublicKey, error) {
+	n, gg := bytesOf(pk.N), bytesOf(pk.G)
+	var hb, kb []byte
+	if pk.H != nil {
+		hb = bytesOf(pk.H)
+	}
+	if pk.K != nil {
+		kb = bytesOf(pk.K)
+	}
+	var h *C.pgpu_pubkey
+	rc := C.pgpu_pubkey_create(g.ctx, p8(n), C.size_t(len(n)), p8(gg), C.size_t(len(gg)), p8(hb), C.size_t(len(hb)), p8(kb),
+		C.size_t(len(kb)), &h)
+	if err := status(rc); err != nil {
+		return nil, err
+	}
+	return &GPUPublicKey{g, pk, h}, nil
+}
+
+func (k *GPUPublicKey) Close() { C.pgpu_pubkey_destroy(k.h); k.h = nil }
+
+func (k *GPUPublicKey) plainBytes(level EncryptionLevel) int {
+	return int(C.pgpu_pubkey_plain_bytes(k.h, C.int(level)))
+}
+func (k *GPUPublicKey) cipherBytes(level EncryptionLevel) int {
+	return int(C.pgpu_pubkey_cipher_bytes(k.h, C.int(level)))
+}
+
+// GPUSecretKey is the device-side image of a SecretKey: p and q are recovered from (n, lambda = phi(n)) for CRT.
+type GPUSecretKey struct {
+	pub *GPUPublicKey
+	sk  *SecretKey
+	h   *C.pgpu_seckey
+}
+
+func (k *GPUPublicKey) UploadSecret(sk *SecretKey) (*GPUSecretKey, error) {
+	l := bytesOf(sk.Lambda)
+	var h *C.pgpu_seckey
+	if err := status(C.pgpu_seckey_create(k.g.ctx, k.h, p8(l), C.size_t(len(l)), &h)); err != nil {
+		return nil, err
+	}
+	return &GPUSecretKey{k, sk, h}, nil
+}
+
+func (s *GPUSecretKey) Close() { C.pgpu_seckey_destroy(s.h); s.h = nil }

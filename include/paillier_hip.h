@@ -108,6 +108,16 @@ int pgpu_seckey_has_crt(const pgpu_seckey* sk);
 int pgpu_encrypt_with_r(const pgpu_pubkey* pk, int level, size_t batch, const uint8_t* m, size_t m_stride,
                         const uint8_t* r, size_t r_stride, uint8_t* c, size_t c_stride, int mem);
 
+/* PublicKey.EncryptAtLevel (paillier.go:258-269) for a batch: for every message a fresh r uniform in Z_n^* is drawn from the
+ * operating system's CSPRNG (getrandom(2)) the way utils.go:26-49 does it -- crypto/rand.Int's rejection sampling below n,
+ * redrawn while r = 0 or gcd(r, n) != 1 (the gcd test runs on the device for the whole batch) -- then c[i] as
+ * pgpu_encrypt_with_r.  r_out (optional, r_stride bytes per element, in `mem`) receives the randomness used. */
+int pgpu_encrypt(const pgpu_pubkey* pk, int level, size_t batch, const uint8_t* m, size_t m_stride, uint8_t* c, size_t c_stride,
+                 uint8_t* r_out, size_t r_stride, int mem);
+
+/* GetRandomNumberInMultiplicativeGroup (utils.go:36-49) for a batch: r_out[i] uniform in Z_n^* (see pgpu_encrypt). */
+int pgpu_random_units(const pgpu_pubkey* pk, size_t batch, uint8_t* r_out, size_t r_stride, int mem);
+
 /* PublicKey.AltEncryptWithRAtLevel (paillier.go:221-238): c[i] = G^m[i] * h_s^(r[i] mod K) mod n^(s+1), with
  * h_1 = (N-H)^N mod N^2, h_2 = (N^2-H)^(N^2) mod N^3 (paillier.go:416-434).  h_s is shared by the batch, so the engine
  * uses a fixed-base comb table (no squarings).  The reference overwrites the caller's r with r mod K; pass r_reduced

@@ -60,6 +60,8 @@ SIGNATURES = {
     "pgpu_seckey_destroy": (None, [_vp]),
     "pgpu_seckey_has_crt": (_int, [_vp]),
     "pgpu_encrypt_with_r": (_int, [_vp, _int, _sz, _vp, _sz, _vp, _sz, _vp, _sz, _int]),
+    "pgpu_encrypt": (_int, [_vp, _int, _sz, _vp, _sz, _vp, _sz, _vp, _sz, _int]),
+    "pgpu_random_units": (_int, [_vp, _sz, _vp, _sz, _int]),
     "pgpu_alt_encrypt_with_r": (_int, [_vp, _int, _sz, _vp, _sz, _vp, _sz, _vp, _sz, _vp, _int]),
     "pgpu_decrypt": (_int, [_vp, _int, _sz, _vp, _sz, _vp, _sz, _int, _int, _vp]),
     "pgpu_add": (_int, [_vp, _int, _sz, _vp, _sz, _vp, _sz, _vp, _sz, _int]),
@@ -299,19 +301,26 @@ class PublicKey:
 
     # -- forms that draw their own randomness on the host, as the reference does with crypto/rand -----------------
     def random_units(self, count: int) -> List[int]:
-        """utils.go:36-49 GetRandomNumberInMultiplicativeGroup: uniform r in [0, n) with r != 0 and gcd(r, n) = 1."""
-        import math
-        import secrets
-        out = []
-        while len(out) < count:
-            r = secrets.randbelow(self.N)
-            if r != 0 and math.gcd(r, self.N) == 1:
-                out.append(r)
-        return out
+        """utils.go:36-49 GetRandomNumberInMultiplicativeGroup for a batch (pgpu_random_units): uniform r in [0, n) with
+        r != 0 and gcd(r, n) = 1; bytes from getrandom(2), rejection as crypto/rand.Int, gcd test on the device."""
+        pb = self.plain_bytes()
+        out = np.zeros((count, pb), dtype=np.uint8)
+        _check(self.ctx.lib.pgpu_random_units(self.h, count, _ptr(out), pb, MEM_HOST))
+        return be_to_ints(out)
 
-    def EncryptBatch(self, ms: Sequence[int], level: int = ENC_LEVEL_ONE) -> List[int]:
-        """paillier.go:192-194,258-269 EncryptAtLevel for each m (fresh r per ciphertext from the host CSPRNG)."""
-        return self.EncryptWithRBatch(ms, self.random_units(len(ms)), level)
+    def encrypt_raw(self, batch, m, m_stride, c, c_stride, r_out=None, r_stride=0, mem=MEM_HOST, level=ENC_LEVEL_ONE):
+        """pgpu_encrypt: the library draws r (see random_units); r_out optionally receives it."""
+        _check(self.ctx.lib.pgpu_encrypt(self.h, level, batch, _ptr(m), m_stride, _ptr(c), c_stride,
+                                         _ptr(r_out) if r_out is not None else None, r_stride, mem))
+
+    def EncryptBatch(self, ms: Sequence[int], level: int = ENC_LEVEL_ONE, return_r: bool = False):
+        """paillier.go:192-194,258-269 EncryptAtLevel for each m (fresh r per ciphertext from the OS CSPRNG)."""
+        pb, cb, rb = self.plain_bytes(level), self.cipher_bytes(level), self.plain_bytes()
+        mb = ints_to_be(ms, pb)
+        out = np.zeros((len(ms), cb), dtype=np.uint8)
+        rr = np.zeros((len(ms), rb), dtype=np.uint8) if return_r else None
+        self.encrypt_raw(len(ms), mb, pb, out, cb, rr, rb, MEM_HOST, level)
+        return (be_to_ints(out), be_to_ints(rr)) if return_r else be_to_ints(out)
 
     def NestedEncryptBatch(self, ms: Sequence[int]) -> List[int]:
         """paillier.go:199-203: level-one encryption, then level-two encryption of the ciphertext value."""

@@ -9,6 +9,8 @@
 #include <memory>
 #include <mutex>
 #include <set>
+#include <sys/random.h>
+#include <thread>
 #include <string>
 #include <vector>
 
@@ -2241,6 +2243,23 @@ void ensure_alt_table(pgpu_pubkey* pk, int level) {
 
 extern "C" {
 
+// c = G^m * r^(n^s) mod n^(s+1) with r given as canonical limbs on the device (r_limbs: mc.WT limbs, stride nb) or as a
+// byte buffer (r, r_stride, in `mem`)
+static void encrypt_core(const pgpu_pubkey* pk, int level, size_t batch, const uint8_t* m, size_t m_stride, const uint8_t* r,
+                         size_t r_stride, const uint32_t* r_limbs, uint8_t* c, size_t c_stride, int mem) {
+  pgpu_ctx* ctx = pk->ctx;
+  const ModCtx& mc = cipher_mod(pk, level);
+  const size_t nb = round_up(batch, VM_BLOCK);
+  ModexpPlan pl = modexp_alloc(ctx, mc, nb, 32);
+  build_gm(ctx, pk, level, m, m_stride, batch, mem, nb, pl.post());
+  if (r_limbs) HIPCHK(hipMemcpyAsync(pl.in(), r_limbs, (size_t)mc.WT * nb * 4, hipMemcpyDeviceToDevice, ctx->stream));
+  else unpack_mod(ctx, mc, r, r_stride, batch, mem, pl.in(), nb);
+  const BigU& ns = (level == PGPU_LEVEL_ONE) ? pk->N : pk->mn2.N;
+  modexp_shared_run(ctx, mc, pl, ns, false, true, true);  // r^(n^s) * g^m mod n^(s+1)  (public exponent: zero windows skipped)
+  pack_result(ctx, pl.out(), mc.WT, nb, batch, c, c_stride, mc.nbytes, mem);
+  HIPCHK(hipStreamSynchronize(ctx->stream));
+}
+
 int pgpu_encrypt_with_r(const pgpu_pubkey* pk, int level, size_t batch, const uint8_t* m, size_t m_stride,
                         const uint8_t* r, size_t r_stride, uint8_t* c, size_t c_stride, int mem) {
   if (!pk) return fail(PGPU_ERR_INVALID, "null key");
@@ -2249,17 +2268,134 @@ int pgpu_encrypt_with_r(const pgpu_pubkey* pk, int level, size_t batch, const ui
     check_batch_args(m, c, batch);
     if (!r) api_throw(PGPU_ERR_INVALID, "null buffer");
     if (level != PGPU_LEVEL_ONE && level != PGPU_LEVEL_TWO) api_throw(PGPU_ERR_INVALID, "bad encryption level");
-    const ModCtx& mc = cipher_mod(pk, level);
+    ctx->bind();
+    ctx->reset_ws();
+    encrypt_core(pk, level, batch, m, m_stride, r, r_stride, nullptr, c, c_stride, mem);
+  });
+}
+
+// ---- randomness (utils.go:26-49) --------------------------------------------------------------------------------------
+// GetRandomNumber = crypto/rand.Int(rand.Reader, n): k = ceil(bitlen(n)/8) bytes from the operating system's CSPRNG, the
+// excess bits of the first byte cleared, accepted when the value is below n -- uniform on [0, n) by rejection.
+// GetRandomNumberInMultiplicativeGroup redraws while r = 0 or gcd(r, n) != 1.  Here: getrandom(2) on several host threads
+// into one byte matrix (the draws and the r < n rejection are a few ms per 65 536 elements), and the unit test for the whole
+// batch on the device -- the batch-inverse tree modulo n: if its single inversion succeeds every r is a unit (the
+// overwhelmingly likely case: a non-unit would reveal a factor of n); if not, the per-lane GCD kernel names the lanes to
+// redraw.  Randomness never comes from anywhere but the OS.
+static void os_random(uint8_t* p, size_t n) {
+  while (n) {
+    ssize_t got = getrandom(p, std::min<size_t>(n, 1u << 20), 0);
+    if (got < 0) {
+      if (errno == EINTR) continue;
+      api_throw(PGPU_ERR_INVALID, "getrandom failed");
+    }
+    p += got;
+    n -= (size_t)got;
+  }
+}
+
+static void draw_below(const std::vector<uint8_t>& n_be, uint8_t top_mask, uint8_t* out, size_t count, const uint32_t* only,
+                       size_t n_only) {
+  const size_t k = n_be.size();
+  auto fill = [&](size_t lo, size_t hi) {
+    std::vector<uint8_t> pool;
+    size_t pos = 0;
+    for (size_t j = lo; j < hi; ++j) {
+      uint8_t* r = out + (only ? (size_t)only[j] : j) * k;
+      for (;;) {
+        if (pos + k > pool.size()) { pool.resize(std::max<size_t>(k * 256, k)); os_random(pool.data(), pool.size()); pos = 0; }
+        memcpy(r, pool.data() + pos, k);
+        pos += k;
+        r[0] &= top_mask;
+        bool zero = true;
+        for (size_t b = 0; b < k; ++b) if (r[b]) { zero = false; break; }
+        if (!zero && memcmp(r, n_be.data(), k) < 0) break;      // 0 < r < n
+      }
+    }
+    wipe_vec(pool);
+  };
+  const size_t total = only ? n_only : count;
+  const size_t nthreads = std::max<size_t>(1, std::min<size_t>({(size_t)8, (size_t)std::thread::hardware_concurrency(), total / 2048 + 1}));
+  if (nthreads == 1) { fill(0, total); return; }
+  std::vector<std::thread> th;
+  std::vector<std::string> errs(nthreads);
+  for (size_t t = 0; t < nthreads; ++t)
+    th.emplace_back([&, t] {
+      try { fill(total * t / nthreads, total * (t + 1) / nthreads); } catch (const ApiError& e) { errs[t] = e.msg; }
+    });
+  for (auto& t : th) t.join();
+  for (auto& e : errs) if (!e.empty()) api_throw(PGPU_ERR_INVALID, e);
+}
+
+// `count` uniform elements of Z_n^* as canonical limbs on the device (mn.WT limbs, stride nb); host_out (optional): the
+// same values as big-endian bytes, k = byte length of n per element
+static uint32_t* random_units_device(const pgpu_pubkey* pk, size_t count, size_t nb, std::vector<uint8_t>* host_out) {
+  pgpu_ctx* ctx = pk->ctx;
+  const ModCtx& mn = pk->mn;
+  std::vector<uint8_t> n_be = pk->N.to_be_min();
+  const size_t k = n_be.size();
+  const int excess = (int)(k * 8 - pk->N.bit_length());
+  const uint8_t top_mask = (uint8_t)(0xFFu >> excess);
+  std::vector<uint8_t> buf(count * k);
+  draw_below(n_be, top_mask, buf.data(), count, nullptr, 0);
+  uint32_t* limbs = ctx->ws_t<uint32_t>((size_t)mn.WT * nb);
+  uint8_t* stage = (uint8_t*)ctx->ws(count * k);
+  int32_t* d_bad = ctx->ws_t<int32_t>(nb);
+  for (int round = 0; round < 64; ++round) {
+    HIPCHK(hipMemcpyAsync(stage, buf.data(), count * k, hipMemcpyHostToDevice, ctx->stream));
+    launch_unpack_be(stage, k, k, count, limbs, mn.WT, nb, ctx->stream);
+    // padding lanes: 1 (a unit), so that the tree sees units only
+    launch_restride(limbs, nb, count, mn.d_consts + (size_t)C_ONE * mn.WT, limbs, nb, mn.WT, ctx->stream);
+    bool any_bad = false;
+    (void)batch_inverse(ctx, mn, limbs, nb, count, d_bad, &any_bad);
+    if (!any_bad) break;
+    std::vector<int32_t> bad(count);
+    HIPCHK(hipMemcpyAsync(bad.data(), d_bad, count * 4, hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHK(hipStreamSynchronize(ctx->stream));
+    std::vector<uint32_t> redo;
+    for (size_t i = 0; i < count; ++i) if (bad[i]) redo.push_back((uint32_t)i);
+    if (redo.empty()) break;
+    draw_below(n_be, top_mask, buf.data(), count, redo.data(), redo.size());     // utils.go:46: draw again
+    if (round == 63) api_throw(PGPU_ERR_INVALID, "could not draw units modulo n (is n a product of tiny primes?)");
+  }
+  if (host_out) *host_out = buf;
+  wipe_vec(buf);
+  return limbs;
+}
+
+int pgpu_random_units(const pgpu_pubkey* pk, size_t batch, uint8_t* r_out, size_t r_stride, int mem) {
+  if (!pk || !r_out) return fail(PGPU_ERR_INVALID, "null argument");
+  pgpu_ctx* ctx = pk->ctx;
+  return guarded([&] {
+    if (batch == 0) api_throw(PGPU_ERR_INVALID, "empty batch");
     ctx->bind();
     ctx->reset_ws();
     const size_t nb = round_up(batch, VM_BLOCK);
-    ModexpPlan pl = modexp_alloc(ctx, mc, nb, 32);
-    build_gm(ctx, pk, level, m, m_stride, batch, mem, nb, pl.post());
-    unpack_mod(ctx, mc, r, r_stride, batch, mem, pl.in(), nb);
-    const BigU& ns = (level == PGPU_LEVEL_ONE) ? pk->N : pk->mn2.N;
-    modexp_shared_run(ctx, mc, pl, ns, false, true, true);  // r^(n^s) * g^m mod n^(s+1)  (public exponent: zero windows skipped)
-    pack_result(ctx, pl.out(), mc.WT, nb, batch, c, c_stride, mc.nbytes, mem);
+    uint32_t* limbs = random_units_device(pk, batch, nb, nullptr);
+    pack_result(ctx, limbs, pk->mn.WT, nb, batch, r_out, r_stride, pk->mn.nbytes, mem);
     HIPCHK(hipStreamSynchronize(ctx->stream));
+  });
+}
+
+int pgpu_encrypt(const pgpu_pubkey* pk, int level, size_t batch, const uint8_t* m, size_t m_stride, uint8_t* c, size_t c_stride,
+                 uint8_t* r_out, size_t r_stride, int mem) {
+  if (!pk) return fail(PGPU_ERR_INVALID, "null key");
+  pgpu_ctx* ctx = pk->ctx;
+  return guarded([&] {
+    check_batch_args(m, c, batch);
+    if (level != PGPU_LEVEL_ONE && level != PGPU_LEVEL_TWO) api_throw(PGPU_ERR_INVALID, "bad encryption level");
+    ctx->bind();
+    ctx->reset_ws();
+    const ModCtx& mc = cipher_mod(pk, level);
+    const size_t nb = round_up(batch, VM_BLOCK);
+    uint32_t* r1 = random_units_device(pk, batch, nb, nullptr);          // paillier.go:263: r in Z_n^* for either level
+    if (r_out) pack_result(ctx, r1, pk->mn.WT, nb, batch, r_out, r_stride, pk->mn.nbytes, mem);
+    uint32_t* rw = r1;
+    if (mc.WT != pk->mn.WT) {                                            // zero-extend to the width of n^(s+1)
+      rw = ctx->ws_t<uint32_t>((size_t)mc.WT * nb);
+      launch_copy_limbs(r1, 0, pk->mn.WT, rw, mc.WT, nb, ctx->stream);
+    }
+    encrypt_core(pk, level, batch, m, m_stride, nullptr, 0, rw, c, c_stride, mem);
   });
 }
 
