@@ -1,0 +1,265 @@
+/* test_cabi.c -- the drop-in boundary exercised the way cgo would call it: plain C99, caller-owned flat big-endian buffers,
+ * int status codes, no C++ and no Python in between.  Calls EVERY pgpu_* batch entry point of include/paillier_hip.h at
+ * least once and checks results against vectors the pytest driver (tests/test_gpu_c_abi.py) exports from the committed
+ * fixtures (the JSON files under tests/golden) as "key hex hex ..." lines.
+ *
+ *   gcc -std=c99 -pedantic -Wall -Werror tests/c/test_cabi.c -Iinclude -Lpaillier_amd -lpaillier_hip -o test_cabi
+ */
+#include <stdint.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+
+#include "paillier_hip.h"
+
+#define MAXV 128
+typedef struct { char key[32]; int n; char* hex[MAXV]; } entry_t;
+static entry_t g_ent[64];
+static int g_nent = 0;
+
+static int fail_line = 0;
+#define CHECK(cond) do { if (!(cond)) { fprintf(stderr, "FAILED %s:%d: %s  [%s]\n", __FILE__, __LINE__, #cond, pgpu_last_error()); fail_line = __LINE__; return 1; } } while (0)
+#define OK(call) CHECK((call) == PGPU_OK)
+
+static void load(const char* path) {
+  FILE* f = fopen(path, "r");
+  static char line[1 << 20];
+  if (!f) { perror(path); exit(2); }
+  while (fgets(line, sizeof line, f)) {
+    char* tok = strtok(line, " \n");
+    entry_t* e;
+    if (!tok) continue;
+    e = &g_ent[g_nent++];
+    strncpy(e->key, tok, sizeof e->key - 1);
+    e->n = 0;
+    while ((tok = strtok(NULL, " \n")) != NULL && e->n < MAXV) {
+      e->hex[e->n] = (char*)malloc(strlen(tok) + 1);
+      strcpy(e->hex[e->n++], tok);
+    }
+  }
+  fclose(f);
+}
+
+static const entry_t* get(const char* key) {
+  int i;
+  for (i = 0; i < g_nent; ++i) if (strcmp(g_ent[i].key, key) == 0) return &g_ent[i];
+  fprintf(stderr, "missing vector %s\n", key);
+  exit(2);
+}
+
+static int hexval(char c) { return c <= '9' ? c - '0' : (c | 32) - 'a' + 10; }
+
+/* hex -> big-endian bytes right-aligned in `stride` bytes (what Go builds from gmp.Int.Bytes()) */
+static void put(const char* hex, uint8_t* out, size_t stride) {
+  size_t len = strlen(hex), i;
+  memset(out, 0, stride);
+  for (i = 0; i < len; ++i) {
+    size_t nib = len - 1 - i;              /* nibble significance */
+    if (nib / 2 >= stride) { fprintf(stderr, "value wider than its stride\n"); exit(2); }
+    out[stride - 1 - nib / 2] |= (uint8_t)(hexval(hex[i]) << (4 * (nib % 2)));
+  }
+}
+
+static uint8_t* pack(const entry_t* e, size_t stride) {
+  uint8_t* b = (uint8_t*)calloc((size_t)e->n, stride);
+  int i;
+  for (i = 0; i < e->n; ++i) put(e->hex[i], b + (size_t)i * stride, stride);
+  return b;
+}
+
+static int same(const uint8_t* got, const entry_t* want, size_t stride) {
+  uint8_t* w = pack(want, stride);
+  int r = memcmp(got, w, (size_t)want->n * stride) == 0;
+  free(w);
+  return r;
+}
+
+static size_t bytes_of(const char* hex) { return (strlen(hex) + 1) / 2; }
+
+int main(int argc, char** argv) {
+  pgpu_ctx* ctx = NULL;
+  pgpu_pubkey *pk = NULL, *tpk = NULL;
+  pgpu_seckey* sk = NULL;
+  pgpu_modulus* mod = NULL;
+  uint8_t nb[512], gb[512], lb[512], tnb[512];
+  size_t nl, ll, pb, cb, cb3, pb2, B;
+  uint8_t *m, *r, *c, *out, *a, *b, *k0;
+  int32_t st[MAXV];
+  double ms, mads;
+  int launches;
+  const entry_t* e;
+
+  if (argc < 2) { fprintf(stderr, "usage: test_cabi vectors.txt\n"); return 2; }
+  load(argv[1]);
+  printf("%s\n", pgpu_version());
+  OK(pgpu_ctx_create(0, NULL, &ctx));
+  CHECK(pgpu_ctx_set_flag(ctx, "asm", 1) == PGPU_OK && pgpu_ctx_set_flag(ctx, "no-such-flag", 1) == PGPU_ERR_INVALID);
+
+  /* ---- keys */
+  nl = bytes_of(get("n")->hex[0]); put(get("n")->hex[0], nb, nl);
+  put(get("g")->hex[0], gb, nl);
+  ll = bytes_of(get("lambda")->hex[0]); put(get("lambda")->hex[0], lb, ll);
+  OK(pgpu_pubkey_create(ctx, nb, nl, gb, nl, NULL, 0, NULL, 0, &pk));
+  OK(pgpu_seckey_create(ctx, pk, lb, ll, &sk));
+  CHECK(pgpu_seckey_has_crt(sk) == 1);
+  pb = pgpu_pubkey_plain_bytes(pk, PGPU_LEVEL_ONE); cb = pgpu_pubkey_cipher_bytes(pk, PGPU_LEVEL_ONE);
+  pb2 = pgpu_pubkey_plain_bytes(pk, PGPU_LEVEL_TWO); cb3 = pgpu_pubkey_cipher_bytes(pk, PGPU_LEVEL_TWO);
+  CHECK(pb == nl && cb == 2 * nl && pb2 == 2 * nl && cb3 == 3 * nl);
+
+  /* ---- EncryptWithR / Decrypt (paillier.go:206-218,292-303) */
+  e = get("enc_m"); B = (size_t)e->n;
+  m = pack(e, pb); r = pack(get("enc_r"), pb); c = (uint8_t*)calloc(B, cb); out = (uint8_t*)calloc(B, cb3);
+  OK(pgpu_encrypt_with_r(pk, PGPU_LEVEL_ONE, B, m, pb, r, pb, c, cb, PGPU_MEM_HOST));
+  CHECK(same(c, get("enc_c"), cb));
+  OK(pgpu_ctx_last_profile(ctx, &ms, &launches, &mads));
+  CHECK(launches >= 1 && mads > 0 && strncmp(pgpu_ctx_last_kernel(ctx), "vm_", 3) == 0 && pgpu_ctx_last_vm_asm(ctx) >= 1);
+  OK(pgpu_decrypt(sk, PGPU_LEVEL_ONE, B, c, cb, out, pb, PGPU_MEM_HOST, PGPU_DECRYPT_DEFAULT, st));
+  CHECK(memcmp(out, m, B * pb) == 0 && st[0] == PGPU_LANE_OK);
+  free(c);
+  e = get("dec_c");
+  c = pack(e, cb);
+  OK(pgpu_decrypt(sk, PGPU_LEVEL_ONE, (size_t)e->n, c, cb, out, pb, PGPU_MEM_HOST, PGPU_DECRYPT_DEFAULT, st));
+  CHECK(same(out, get("dec_m"), pb) && st[8] == PGPU_LANE_NONUNIT);         /* vector 8 is c = 0 */
+  OK(pgpu_decrypt(sk, PGPU_LEVEL_ONE, (size_t)e->n, c, cb, out, pb, PGPU_MEM_HOST, PGPU_DECRYPT_NO_CRT, NULL));
+  CHECK(same(out, get("dec_m"), pb));
+  free(c);
+
+  /* ---- Encrypt with library randomness: Decrypt(Encrypt(m)) == m and c == EncryptWithR(m, r_out) */
+  c = (uint8_t*)calloc(B, cb);
+  { uint8_t* rr = (uint8_t*)calloc(B, pb); uint8_t* c2 = (uint8_t*)calloc(B, cb);
+    OK(pgpu_encrypt(pk, PGPU_LEVEL_ONE, B, m, pb, c, cb, rr, pb, PGPU_MEM_HOST));
+    OK(pgpu_encrypt_with_r(pk, PGPU_LEVEL_ONE, B, m, pb, rr, pb, c2, cb, PGPU_MEM_HOST));
+    CHECK(memcmp(c, c2, B * cb) == 0);
+    OK(pgpu_random_units(pk, B, rr, pb, PGPU_MEM_HOST));
+    free(rr); free(c2); }
+  OK(pgpu_decrypt(sk, PGPU_LEVEL_ONE, B, c, cb, out, pb, PGPU_MEM_HOST, 0, NULL));
+  CHECK(memcmp(out, m, B * pb) == 0);
+  free(c);
+
+  /* ---- Add / Sub / ConstMult (operations.go:11-64) */
+  e = get("add_a"); B = (size_t)e->n;
+  a = pack(e, cb); b = pack(get("add_b"), cb);
+  OK(pgpu_add(pk, PGPU_LEVEL_ONE, B, a, cb, b, cb, out, cb, PGPU_MEM_HOST));
+  CHECK(same(out, get("add_out"), cb));
+  { const uint8_t* ops[3]; uint8_t* t = (uint8_t*)calloc(B, cb);
+    ops[0] = a; ops[1] = b; ops[2] = b;
+    OK(pgpu_add_many(pk, PGPU_LEVEL_ONE, 3, B, ops, cb, t, cb, PGPU_MEM_HOST));          /* a b b */
+    ops[0] = t; ops[1] = b;
+    OK(pgpu_sub_many(pk, PGPU_LEVEL_ONE, 2, B, ops, cb, t, cb, PGPU_MEM_HOST, st));      /* / b  */
+    CHECK(same(t, get("add_out"), cb) && st[0] == PGPU_LANE_OK);
+    OK(pgpu_sub(pk, PGPU_LEVEL_ONE, B, t, cb, b, cb, t, cb, PGPU_MEM_HOST, NULL));        /* / b  = a mod n^2 */
+    OK(pgpu_add_many(pk, PGPU_LEVEL_ONE, 1, B, (const uint8_t* const*)&a, cb, out, cb, PGPU_MEM_HOST));
+    CHECK(memcmp(t, out, B * cb) == 0);
+    free(t); }
+  k0 = (uint8_t*)calloc(1, pb); put(get("cm_k0")->hex[0], k0, pb);
+  OK(pgpu_const_mult(pk, PGPU_LEVEL_ONE, B, a, cb, k0, pb, 0, out, cb, PGPU_MEM_HOST));
+  CHECK(same(out, get("cm_out"), cb));
+
+  /* ---- the gmp.Int seam: Exp / Mul+Mod / ModInverse */
+  { uint8_t n2b[1024]; const entry_t* n2 = get("n2"); size_t n2l = bytes_of(n2->hex[0]); uint8_t* inv = (uint8_t*)calloc(B, cb);
+    put(n2->hex[0], n2b, n2l);
+    OK(pgpu_modulus_create(ctx, n2b, n2l, &mod));
+    CHECK(pgpu_modulus_bytes(mod) == cb);
+    OK(pgpu_modexp(mod, B, a, cb, cb, k0, pb, 0, out, cb, PGPU_MEM_HOST));
+    CHECK(same(out, get("cm_out"), cb));
+    OK(pgpu_modmul(mod, B, a, cb, cb, b, cb, cb, out, cb, PGPU_MEM_HOST));
+    CHECK(same(out, get("add_out"), cb));
+    OK(pgpu_modinv(mod, B, b, cb, cb, inv, cb, PGPU_MEM_HOST, st));
+    OK(pgpu_modmul(mod, B, out, cb, cb, inv, cb, cb, out, cb, PGPU_MEM_HOST));             /* a b b^-1 = a mod n^2 */
+    OK(pgpu_add_many(pk, PGPU_LEVEL_ONE, 1, B, (const uint8_t* const*)&a, cb, inv, cb, PGPU_MEM_HOST));
+    CHECK(memcmp(out, inv, B * cb) == 0 && st[0] == PGPU_LANE_OK);
+    free(inv); }
+
+  /* ---- level two and AltEncrypt */
+  { const entry_t* l2m = get("l2_m"); size_t n2 = (size_t)l2m->n; uint8_t* mm = pack(l2m, pb2); uint8_t* rr = pack(get("l2_r"), pb);
+    uint8_t* cc = (uint8_t*)calloc(n2, cb3);
+    OK(pgpu_encrypt_with_r(pk, PGPU_LEVEL_TWO, n2, mm, pb2, rr, pb, cc, cb3, PGPU_MEM_HOST));
+    CHECK(same(cc, get("l2_c"), cb3));
+    OK(pgpu_decrypt(sk, PGPU_LEVEL_TWO, n2, cc, cb3, out, pb2, PGPU_MEM_HOST, 0, NULL));
+    CHECK(memcmp(out, mm, n2 * pb2) == 0);
+    free(mm); free(rr); free(cc); }
+  { pgpu_pubkey* apk = NULL; uint8_t hb[512], kb[512]; size_t hl = bytes_of(get("h")->hex[0]), kl = bytes_of(get("k")->hex[0]);
+    uint8_t* cc = (uint8_t*)calloc(B, cb); uint8_t* red = (uint8_t*)calloc(B, pb);
+    put(get("h")->hex[0], hb, hl); put(get("k")->hex[0], kb, kl);
+    OK(pgpu_pubkey_create(ctx, nb, nl, gb, nl, hb, hl, kb, kl, &apk));
+    OK(pgpu_alt_encrypt_with_r(apk, PGPU_LEVEL_ONE, B, m, pb, r, pb, cc, cb, red, PGPU_MEM_HOST));
+    OK(pgpu_decrypt(sk, PGPU_LEVEL_ONE, B, cc, cb, out, pb, PGPU_MEM_HOST, 0, NULL));      /* same n: decrypts under sk */
+    CHECK(memcmp(out, m, B * pb) == 0);
+    pgpu_pubkey_destroy(apk); free(cc); free(red); }
+
+  /* ---- threshold decryption (thresholdkey.go:149-201): committed partials and plaintexts */
+  { const entry_t* tc = get("t_c"); size_t nt = (size_t)tc->n, tl = bytes_of(get("t_n")->hex[0]), tcb = 2 * tl;
+    uint8_t* cc = pack(tc, tcb); uint8_t* parts[3]; const uint8_t* cparts[3]; int ids[3] = {1, 3, 5}; int s;
+    uint8_t shb[3][1024]; const uint8_t* shp[3]; size_t shl[3]; int32_t idx[MAXV]; uint8_t* un; uint8_t* uo;
+    put(get("t_n")->hex[0], tnb, tl);
+    { uint8_t tg[512]; memcpy(tg, tnb, tl); tg[tl - 1] += 1;                                /* G = N + 1 (n is odd) */
+      OK(pgpu_pubkey_create(ctx, tnb, tl, tg, tl, NULL, 0, NULL, 0, &tpk)); }
+    for (s = 0; s < 3; ++s) {
+      const char* sh = get("t_shares")->hex[ids[s] - 1];
+      char key[16];
+      shl[s] = bytes_of(sh); put(sh, shb[s], shl[s]); shp[s] = shb[s];
+      parts[s] = (uint8_t*)calloc(nt, tcb); cparts[s] = parts[s];
+      OK(pgpu_partial_decrypt(tpk, 5, shb[s], shl[s], nt, cc, tcb, parts[s], tcb, PGPU_MEM_HOST));
+      sprintf(key, "t_part%d", ids[s]);
+      CHECK(same(parts[s], get(key), tcb));
+    }
+    OK(pgpu_combine_partial_decryptions(tpk, 5, 3, 3, ids, nt, cparts, tcb, out, tl, PGPU_MEM_HOST, st));
+    CHECK(same(out, get("t_m"), tl) && st[0] == PGPU_LANE_OK);
+    CHECK(pgpu_combine_partial_decryptions(tpk, 5, 3, 2, ids, nt, cparts, tcb, out, tl, PGPU_MEM_HOST, NULL) == PGPU_ERR_THRESHOLD);
+    /* the units of the three servers in one launch */
+    un = (uint8_t*)calloc(3 * nt, tcb); uo = (uint8_t*)calloc(3 * nt, tcb);
+    for (s = 0; s < 3; ++s) { size_t i; for (i = 0; i < nt; ++i) { memcpy(un + (s * nt + i) * tcb, cc + i * tcb, tcb); idx[s * nt + i] = s; } }
+    OK(pgpu_partial_decrypt_indexed(tpk, 5, 3, shp, shl, 3 * nt, un, tcb, idx, uo, tcb, PGPU_MEM_HOST));
+    for (s = 0; s < 3; ++s) CHECK(memcmp(uo + (size_t)s * nt * tcb, parts[s], nt * tcb) == 0);
+    /* share-decryption proof: prove with the committed r, compare (dec, E, Z), verify */
+    { const entry_t* zc = get("z_c"); size_t nz = (size_t)zc->n, zs = tcb + 48; uint8_t* zcb = pack(zc, tcb); uint8_t* zr = pack(get("z_r"), tcb);
+      uint8_t* dec = (uint8_t*)calloc(nz, tcb); uint8_t* ee = (uint8_t*)calloc(nz, 32); uint8_t* zz = (uint8_t*)calloc(nz, zs);
+      uint8_t vb[1024], vib[1024], s2[1024]; size_t vl = bytes_of(get("t_v")->hex[0]), vil = bytes_of(get("t_vks")->hex[1]);
+      size_t s2l = bytes_of(get("t_shares")->hex[1]);
+      put(get("t_v")->hex[0], vb, vl); put(get("t_vks")->hex[1], vib, vil); put(get("t_shares")->hex[1], s2, s2l);
+      OK(pgpu_share_zkp_prove(tpk, 5, s2, s2l, vb, vl, nz, zcb, tcb, zr, tcb, dec, tcb, ee, zz, zs, PGPU_MEM_HOST));
+      CHECK(same(dec, get("z_dec"), tcb) && same(ee, get("z_e"), 32) && same(zz, get("z_z"), zs));
+      OK(pgpu_share_zkp_verify(tpk, vb, vl, vib, vil, nz, zcb, tcb, dec, tcb, ee, zz, zs, st, PGPU_MEM_HOST));
+      { size_t i; for (i = 0; i < nz; ++i) CHECK(st[i] == 1); }
+      ee[31] ^= 1;
+      OK(pgpu_share_zkp_verify(tpk, vb, vl, vib, vil, nz, zcb, tcb, dec, tcb, ee, zz, zs, st, PGPU_MEM_HOST));
+      CHECK(st[0] == 0 && st[1] == 1);
+      /* the transcript hash on its own: E = SHA-256(a || b || c^4 || ci^2) of the committed integers */
+      { const uint8_t* hp[4]; size_t hs[4]; uint8_t dg[32 * MAXV]; uint8_t* h0 = pack(get("z_a"), tcb); uint8_t* h1 = pack(get("z_b"), tcb);
+        uint8_t* h2 = pack(get("z_c4"), 4 * tcb); uint8_t* h3 = pack(get("z_ci2"), 2 * tcb);
+        hp[0] = h0; hp[1] = h1; hp[2] = h2; hp[3] = h3; hs[0] = tcb; hs[1] = tcb; hs[2] = 4 * tcb; hs[3] = 2 * tcb;
+        OK(pgpu_random_oracle_digest(ctx, 4, hp, hs, nz, dg, PGPU_MEM_HOST));
+        CHECK(same(dg, get("z_e"), 32));
+        free(h0); free(h1); free(h2); free(h3); }
+      free(zcb); free(zr); free(dec); free(ee); free(zz); }
+    free(cc); free(un); free(uo); for (s = 0; s < 3; ++s) free(parts[s]); }
+
+  /* ---- DDLEQ (ddleq.go:55-153): prove with the committed (x, y), compare, verify */
+  { const entry_t* d1 = get("d_ct1"); size_t nd = (size_t)d1->n, i;
+    uint8_t *c1 = pack(d1, cb3), *c2 = pack(get("d_ct2"), cb3), *da = pack(get("d_a"), pb), *db = pack(get("d_b"), pb),
+            *dx = pack(get("d_x"), pb), *dy = pack(get("d_y"), pb);
+    uint8_t *al = (uint8_t*)calloc(nd, cb3), *ee = (uint8_t*)calloc(nd, pb2), *ff = (uint8_t*)calloc(nd, cb3);
+    OK(pgpu_ddleq_prove(sk, nd, c1, c2, cb3, da, db, dx, dy, pb, al, ee, pb2, ff, PGPU_MEM_HOST));
+    CHECK(same(al, get("d_alpha"), cb3) && same(ee, get("d_e"), pb2) && same(ff, get("d_f"), cb3));
+    OK(pgpu_ddleq_verify(pk, nd, c1, c2, cb3, dx, dy, pb, al, cb3, ee, pb2, ff, cb3, st, PGPU_MEM_HOST));
+    for (i = 0; i < nd; ++i) CHECK(st[i] == 1);
+    ff[5] ^= 1;
+    OK(pgpu_ddleq_verify(pk, nd, c1, c2, cb3, dx, dy, pb, al, cb3, ee, pb2, ff, cb3, st, PGPU_MEM_HOST));
+    CHECK(st[0] == 0 && st[1] == 1);
+    CHECK(pgpu_ddleq_prove(sk, 2, c1, c2 + cb3, cb3, da, db, dx, dy, pb, al, ee, pb2, ff, PGPU_MEM_HOST) == PGPU_ERR_INVALID);   /* false statement */
+    free(c1); free(c2); free(da); free(db); free(dx); free(dy); free(al); free(ee); free(ff); }
+
+  /* ---- error conventions */
+  CHECK(pgpu_encrypt_with_r(pk, 7, B, m, pb, r, pb, out, cb, PGPU_MEM_HOST) == PGPU_ERR_INVALID);
+  CHECK(pgpu_encrypt_with_r(NULL, 0, B, m, pb, r, pb, out, cb, PGPU_MEM_HOST) == PGPU_ERR_INVALID);
+  { uint8_t even[4] = {0, 0, 1, 0}; pgpu_modulus* bad = NULL; CHECK(pgpu_modulus_create(ctx, even, 4, &bad) == PGPU_ERR_INVALID); }
+
+  pgpu_modulus_destroy(mod);
+  pgpu_seckey_destroy(sk);
+  pgpu_pubkey_destroy(pk);
+  pgpu_pubkey_destroy(tpk);
+  pgpu_ctx_destroy(ctx);
+  free(m); free(r); free(out); free(a); free(b); free(k0);
+  printf("c abi ok\n");
+  return 0;
+}
