@@ -2990,6 +2990,18 @@ void pow_n3_crt(const pgpu_seckey* sk, const uint32_t* base, int wb, const uint3
   launch_mul_const_add(mem + (size_t)SH * S, W, sk->p3_limbs.d, W, xp, W, 0, out, W3, nb, ctx->stream);              // x_p + p^3 h
 }
 
+// [w][nb] arrays a, b  ->  one [w][2 nb] array (a's numbers first): two independent batches share one launch
+uint32_t* concat2(pgpu_ctx* ctx, const uint32_t* a, const uint32_t* b, int w, size_t nb) {
+  uint32_t* o = ctx->ws_t<uint32_t>((size_t)w * 2 * nb);
+  HIPCHK(hipMemcpy2DAsync(o, 2 * nb * 4, a, nb * 4, nb * 4, (size_t)w, hipMemcpyDeviceToDevice, ctx->stream));
+  HIPCHK(hipMemcpy2DAsync(o + nb, 2 * nb * 4, b, nb * 4, nb * 4, (size_t)w, hipMemcpyDeviceToDevice, ctx->stream));
+  return o;
+}
+// half `which` (0 / 1) of a [w][2 nb] array -> [w][nb]
+void split2(pgpu_ctx* ctx, const uint32_t* in, int which, int w, size_t nb, uint32_t* out) {
+  HIPCHK(hipMemcpy2DAsync(out, nb * 4, in + (size_t)which * nb, 2 * nb * 4, nb * 4, (size_t)w, hipMemcpyDeviceToDevice, ctx->stream));
+}
+
 uint32_t* zext(pgpu_ctx* ctx, const uint32_t* in, int w, int wo, size_t nb) {
   uint32_t* o = ctx->ws_t<uint32_t>((size_t)wo * nb);
   launch_copy_limbs(in, 0, w, o, wo, nb, ctx->stream);
@@ -3036,13 +3048,31 @@ int pgpu_ddleq_prove(const pgpu_seckey* sk, size_t batch, const uint8_t* ct1, co
     uint32_t *al = up(a, n_stride, W1), *bl = up(b, n_stride, W1), *xl = up(x, n_stride, W1), *yl = up(y, n_stride, W1);
     const BigU &N = pk->N, &N2 = mn2.N;
     // ---- sanity check (ddleq.go:62-69): ct1^(a^n mod n^2) * b^(n^2) mod n^3 == ct2, else the reference panics
+    // Independent exponentiations of the same shape share a launch (twice the numbers: the chip is filled better and, for
+    // the half-size batches of the response, a latency-bound launch is saved outright): a^n | x^n, then the sanity value and
+    // alpha -- ct1^(a^n) b^(n^2) | ct1^(x^n) y^(n^2) -- and further down s^(a^n) | s^(x^n).
     uint32_t* an = ctx->ws_t<uint32_t>((size_t)W2 * nb);
-    shared_pow(ctx, mn2, al, W1, N, nb, an);
+    uint32_t* xn = ctx->ws_t<uint32_t>((size_t)W2 * nb);
+    {
+      uint32_t* ax = concat2(ctx, al, xl, W1, nb);
+      uint32_t* axn = ctx->ws_t<uint32_t>((size_t)W2 * 2 * nb);
+      shared_pow(ctx, mn2, ax, W1, N, 2 * nb, axn);
+      split2(ctx, axn, 0, W2, nb, an);
+      split2(ctx, axn, 1, W2, nb, xn);
+    }
     uint32_t* bn2 = ctx->ws_t<uint32_t>((size_t)W3 * nb);
     uint32_t* t3 = ctx->ws_t<uint32_t>((size_t)W3 * nb);
     uint32_t* san = ctx->ws_t<uint32_t>((size_t)W3 * nb);
+    uint32_t* alp = ctx->ws_t<uint32_t>((size_t)W3 * nb);
     if (crt3) {
-      pow_n3_crt(sk, c1, W3, an, W2, &N2, nb, san, bl, W1);          // ct1^(a^n) * b^(n^2): one interleaved ladder per half
+      // ct1^(a^n) * b^(n^2) and ct1^(x^n) * y^(n^2): one interleaved ladder per number and CRT half, both batches in one launch
+      uint32_t* cc2 = concat2(ctx, c1, c1, W3, nb);
+      uint32_t* ee2 = concat2(ctx, an, xn, W2, nb);
+      uint32_t* by2 = concat2(ctx, bl, yl, W1, nb);
+      uint32_t* o2 = ctx->ws_t<uint32_t>((size_t)W3 * 2 * nb);
+      pow_n3_crt(sk, cc2, W3, ee2, W2, &N2, 2 * nb, o2, by2, W1);
+      split2(ctx, o2, 0, W3, nb, san);
+      split2(ctx, o2, 1, W3, nb, alp);
     } else {
       shared3(bl, W1, N2, nb, bn2);
       perlane3(c1, an, W2, nb, t3);
@@ -3055,15 +3085,9 @@ int pgpu_ddleq_prove(const pgpu_seckey* sk, size_t batch, const uint8_t* ct1, co
     HIPCHK(hipStreamSynchronize(ctx->stream));
     for (size_t i = 0; i < batch; ++i)
       if (!hok[i]) api_throw(PGPU_ERR_INVALID, "cannot prove re-encryption because inputs are wrong");
-    // ---- alpha = ct1^(x^n) * y^(n^2) mod n^3 (ddleq.go:81-87)
-    uint32_t* xn = ctx->ws_t<uint32_t>((size_t)W2 * nb);
-    shared_pow(ctx, mn2, xl, W1, N, nb, xn);
+    // ---- alpha = ct1^(x^n) * y^(n^2) mod n^3 (ddleq.go:81-87); with CRT it came out of the launch above
     uint32_t* yn2 = ctx->ws_t<uint32_t>((size_t)W3 * nb);
-    uint32_t* alp = ctx->ws_t<uint32_t>((size_t)W3 * nb);
-    if (crt3) {
-      pow_n3_crt(sk, c1, W3, xn, W2, &N2, nb, alp, yl, W1);
-      // y^(n^2) alone is needed again below only for chalBit = 1 instances, where f is built from other terms: not here
-    } else {
+    if (!crt3) {
       shared3(yl, W1, N2, nb, yn2);
       perlane3(c1, xn, W2, nb, t3);
       modmul_arrays(ctx, mn3, t3, yn2, nb, alp);
@@ -3122,15 +3146,22 @@ int pgpu_ddleq_prove(const pgpu_seckey* sk, size_t batch, const uint8_t* ct1, co
       uint32_t* en = ctx->ws_t<uint32_t>((size_t)W2 * nbg);
       shared_pow(ctx, mn2, ge, W2, N, nbg, en);
       uint32_t* cc = ctx->ws_t<uint32_t>((size_t)W3 * nbg);
-      perlane3(s3, gan, W2, nbg, cc);
+      uint32_t* sx = ctx->ws_t<uint32_t>((size_t)W3 * nbg);
+      {
+        // s^(a^n) and s^(x^n) (ddleq.go:107,112): same base, independent exponents -> one launch
+        uint32_t* ss2 = concat2(ctx, s3, s3, W3, nbg);
+        uint32_t* ee2 = concat2(ctx, gan, gxn, W2, nbg);
+        uint32_t* o2 = ctx->ws_t<uint32_t>((size_t)W3 * 2 * nbg);
+        perlane3(ss2, ee2, W2, 2 * nbg, o2);
+        split2(ctx, o2, 0, W3, nbg, cc);
+        split2(ctx, o2, 1, W3, nbg, sx);
+      }
       uint32_t* b3 = zext(ctx, gb, W1, W3, nbg);
       uint32_t* cb = ctx->ws_t<uint32_t>((size_t)W3 * nbg);
       modmul_arrays(ctx, mn3, cc, b3, nbg, cb);
       perlane3(cb, en, W2, nbg, cc);
       launch_restride(cc, nbg, cnt, mn3.d_consts + (size_t)C_ONE * W3, cc, nbg, W3, ctx->stream);
       uint32_t* ci = batch_inverse(ctx, mn3, cc, nbg, cnt);
-      uint32_t* sx = ctx->ws_t<uint32_t>((size_t)W3 * nbg);
-      perlane3(s3, gxn, W2, nbg, sx);
       uint32_t* c5 = ctx->ws_t<uint32_t>((size_t)W3 * nbg);
       modmul_arrays(ctx, mn3, ci, sx, nbg, c5);
       uint32_t* y3 = zext(ctx, gy, W1, W3, nbg);

@@ -2319,24 +2319,35 @@ class GenQ3(Gen):
         a = f"v{cur}"
         if use_sh:
             e(f"v_lshlrev_b32 v{cur}, v{g.v_sh}, v{cur}")
-        self.align8()
-        for j in range(H):
-            if j == H - 1:
-                self.mad(self.T(j), a, self.X(j), "0")
-            else:
-                self.mad(self.T(j), a, self.X(j), self.T(j))
-        e(f"v_mul_lo_u32 {m}, {self.Tlo(0)}, s14")
-        e(f"v_and_b32 {m}, {hex(MASK)}, {m}")
+        # Column 0 is complete after the FIRST multiply of pass A (only a * x_0 lands in it), so the quotient digit and the
+        # two link hops (each a chain of dependent instructions: multiply, mask, DPP move, subtract, mask, 64-bit add) are
+        # started right away and their steps are spread between the remaining multiplies of pass A: no s_nop for the DPP
+        # hazard, and at one wave per SIMD -- a 16 384-number batch -- nothing waits on a result that is still in flight.
+        chain = [f"v_mul_lo_u32 {m}, {self.Tlo(0)}, s14", f"v_and_b32 {m}, {hex(MASK)}, {m}"]
         for hop, (cs, mask) in enumerate((("s0", g.v_l1mask), ("s1", g.v_l2mask))):
             if hop == 1 and not link2:
                 break
-            e("s_nop 1")
-            e(f"v_mov_b32_dpp v{g.v_d}, {m} quad_perm:[0,0,1,2] row_mask:0xf bank_mask:0xf")
-            e(f"v_sub_u32 v{g.v_d}, {cs}, v{g.v_d}")
-            e(f"v_and_b32 v{g.v_d}, v{g.v_d}, v{mask}")
-            e(f"v_lshl_add_u64 {self.T(0)}, {self.T(0)}, 0, {self.P(g.v_d)}")
-            e(f"v_mul_lo_u32 {m}, {self.Tlo(0)}, s14")
-            e(f"v_and_b32 {m}, {hex(MASK)}, {m}")
+            chain += [f"v_mov_b32_dpp v{g.v_d}, {m} quad_perm:[0,0,1,2] row_mask:0xf bank_mask:0xf",
+                      f"v_sub_u32 v{g.v_d}, {cs}, v{g.v_d}",
+                      f"v_and_b32 v{g.v_d}, v{g.v_d}, v{mask}",
+                      f"v_lshl_add_u64 {self.T(0)}, {self.T(0)}, 0, {self.P(g.v_d)}",
+                      f"v_mul_lo_u32 {m}, {self.Tlo(0)}, s14",
+                      f"v_and_b32 {m}, {hex(MASK)}, {m}"]
+        gap = min(3, (H - 1) // len(chain))                # multiplies between two steps of the chain (>= 2 covers the DPP hazard)
+        assert gap >= 2, "pass A is too short to hide the link chain"
+        self.align8()
+        self.mad(self.T(0), a, self.X(0), self.T(0))
+        j = 1
+        for step in chain:
+            for _ in range(gap):
+                self.mad(self.T(j), a, self.X(j), "0" if j == H - 1 else self.T(j))
+                j += 1
+            e(step)
+            if step.startswith("v_mov_b32_dpp") or step.startswith("v_and") or step.startswith("v_sub"):
+                self.align8()
+        while j < H:
+            self.mad(self.T(j), a, self.X(j), "0" if j == H - 1 else self.T(j))
+            j += 1
         self.align8()
         self.mad(self.P(g.v_y0), m, N(0), self.T(0))
         self.mad(self.T(0), m, N(1), self.T(1))
