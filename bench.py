@@ -149,6 +149,9 @@ def main():
     ap.add_argument("--no-traffic", action="store_true", help="skip the rocprofv3 PMC child passes (roofline.traffic = null)")
     ap.add_argument("--headline-only", action="store_true", help="(internal: PMC child pass) headline only, no CPU leg")
     ap.add_argument("--extra-steps", type=int, default=2)
+    ap.add_argument("--rehearse-one-gpu", action="store_true",
+                    help="N > 1 ranks that all use GPU 0 and exchange over gloo: rehearses the multi-rank code path (self-launch, "
+                         "sharding, the threshold exchange, the reductions) on a one-GPU box; not a measurement")
     args = ap.parse_args()
     if args.headline_only:
         args.no_cpu_baseline = args.no_extra = args.no_traffic = True
@@ -170,12 +173,17 @@ def main():
     import numpy as np
     import torch
 
+    if args.rehearse_one_gpu:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     dist = None
     if world > 1:
         import torch.distributed as dist
-        dist.init_process_group("nccl", device_id=dev)
+        if args.rehearse_one_gpu:
+            dist.init_process_group("gloo")
+        else:
+            dist.init_process_group("nccl", device_id=dev)
         if dist.get_world_size() != args.gpus:
             print(f"[bench] process group has {dist.get_world_size()} ranks, --gpus {args.gpus}", file=sys.stderr)
             sys.exit(2)
@@ -240,10 +248,7 @@ def main():
     barrier()
     t1 = time.perf_counter()
     elapsed = t1 - t0
-    if world > 1:
-        tt = torch.tensor([elapsed], dtype=torch.float64, device=dev)
-        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
-        elapsed = float(tt.item())
+    elapsed = pdist.max_over_ranks(elapsed, dev)
     prof = ctx.last_profile()
 
     # parity at full size: round trip is the identity on every lane, on every rank
@@ -449,14 +454,13 @@ def main():
             tout, (sb, se) = tstep()
         barrier()
         tel = pdist.max_over_ranks(time.perf_counter() - t, dev)
-        tok = torch.tensor([1 if (tout is None or torch.equal(tout, tm[sb:se])) else 0], dtype=torch.int32, device=dev)
-        if world > 1:
-            dist.all_reduce(tok, op=dist.ReduceOp.MIN)
-        if not int(tok.item()):
+        tok = pdist.min_over_ranks(1 if (tout is None or torch.equal(tout, tm[sb:se])) else 0, dev)
+        if not tok:
             raise SystemExit("[bench] threshold decryption: Combine(PartialDecrypt x 3) != m on some rank")
         e = entry("threshold_2048", f"t=3 of l=5, servers {ids}, 16384 ciphertexts per step, 2048-bit safe-prime key: 3 x "
                   f"PartialDecrypt + CombinePartialDecryptions; (server, ciphertext) units sharded over {world} rank(s), "
-                  f"all-gather of the partials" + (" over RCCL" if world > 1 else " (single rank: no exchange)") +
+                  f"all-gather of the partials" + ((" over gloo (rehearsal)" if args.rehearse_one_gpu else " over RCCL") if world > 1
+                                                  else " (single rank: no exchange)") +
                   ", local combine", "threshold decryptions/s", BT, tel / args.extra_steps,
                   acc["ms"] / args.extra_steps, acc["mads"] / args.extra_steps, acc["kern"],
                   "all 16384 plaintexts recovered on every rank")
@@ -604,7 +608,7 @@ def main():
         "scaling": "weak",
         "vs_baseline": None,
         "dtype": "u32 (28-bit limbs, 64-bit accumulators)",
-        "data": "synthetic",
+        "data": "synthetic" + (" (REHEARSAL: all ranks on one GPU, gloo; not a measurement)" if args.rehearse_one_gpu else ""),
         "bit_exact": ok,
         "config": {"workload": f"Batch {B} Decrypt per GPU, {args.bits}-bit n, level 1, CRT over p^2,q^2; inputs resident "
                                f"in HBM as big-endian element-major bytes",

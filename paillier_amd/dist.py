@@ -29,9 +29,24 @@ def max_over_ranks(value: float, device=None) -> float:
     import torch.distributed as dist
     if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
         return value
+    if dist.get_backend() == "gloo":
+        device = None                      # rehearsals over gloo reduce on the host
     t = torch.tensor([value], dtype=torch.float64, device=device)
     dist.all_reduce(t, op=dist.ReduceOp.MAX)
     return float(t.item())
+
+
+def min_over_ranks(flag: int, device=None) -> int:
+    """MIN all-reduce of a host integer (parity flags: 1 = this rank's results are right)."""
+    import torch
+    import torch.distributed as dist
+    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
+        return int(flag)
+    if dist.get_backend() == "gloo":
+        device = None
+    t = torch.tensor([int(flag)], dtype=torch.int32, device=device)
+    dist.all_reduce(t, op=dist.ReduceOp.MIN)
+    return int(t.item())
 
 
 def all_gather_bytes(local, world: int):
@@ -41,9 +56,12 @@ def all_gather_bytes(local, world: int):
     if world == 1:
         return local.unsqueeze(0)
     local = local.contiguous()
+    dev = local.device
+    if dist.get_backend() == "gloo" and local.is_cuda:
+        local = local.cpu()                # rehearsal of the exchange with several ranks on ONE GPU: through host memory
     out = torch.empty((world * local.shape[0],) + tuple(local.shape[1:]), dtype=local.dtype, device=local.device)
     dist.all_gather_into_tensor(out, local)  # concatenation along dim 0 (the layout both RCCL and gloo accept)
-    return out.view((world,) + tuple(local.shape))
+    return out.view((world,) + tuple(local.shape)).to(dev)
 
 
 def threshold_decrypt_sharded(c, n_servers: int, rank: int, world: int, partial_fn, combine_fn, pad_rows: bool = True,
