@@ -650,6 +650,8 @@ struct pgpu_seckey {
   DevLimbs p3_limbs;                     // p^3 as mp3.WT limbs
   DevLimbs pinv2k_2, qinv2k_2;           // p^-1 mod 2^(28 mp2.WT), q^-1 mod 2^(28 mq2.WT)
   DevLimbs q_limbs, p2_limbs;            // q as mq.WT limbs, p^2 as mp2.WT limbs
+  DevLimbs q2_limbs;                     // q^2 as mq2.WT limbs
+  DevLimbs tkc_p, ttc_p, tkc_q, ttc_q;   // three-digit kernel constants for the ladders modulo p^3 and q^3 (mp3 / mq3 .triple)
 };
 
 // Constants of the pair kernel for a prime of H limbs: its limbs, then Cadj -- the multiple of the prime whose limbs
@@ -687,6 +689,46 @@ static std::vector<uint32_t> make_triple_kconsts(const BigU& n, int H) {
     kc[(size_t)npad + 2 * j + 1] = e2l[j] + (1u << LB);
   }
   return kc;
+}
+
+// Attach the three-digit form to the modulus m3 = root^3: kernel constants, the digit form of 1, entry / exit constants.
+// kc / tc own the device arrays; the exact-division inverses and the limb arrays of root and root^2 belong to the caller.
+static void setup_triple(ModCtx& m3, const ModCtx& root, const ModCtx& mid, DevLimbs& kc_dev, DevLimbs& tc_dev, const uint32_t* dinv1,
+                         const uint32_t* dinv2, const uint32_t* n_limbs, const uint32_t* n2_limbs) {
+  const int H = root.WT;
+  const BigU& n = root.N;
+  const BigU& n3 = m3.N;
+  const std::vector<uint32_t> kc = make_triple_kconsts(n, H);
+  kc_dev.w = (int)kc.size();
+  HIPCHK(hipMalloc((void**)&kc_dev.d, kc.size() * 4));
+  HIPCHK(hipMemcpy(kc_dev.d, kc.data(), kc.size() * 4, hipMemcpyHostToDevice));
+  // digit form of 1: the digits of R_H mod root^3
+  const BigU RH = hostbig::shl(BigU(1), (size_t)LB * H);
+  BigU rh = RH % n3, q1, d0, d2, d1;
+  hostbig::divmod(rh, n, q1, d0);
+  hostbig::divmod(q1, n, d2, d1);
+  std::vector<uint32_t> tc;
+  for (const BigU* dg : {&d0, &d1, &d2}) {
+    auto l = dg->to_limbs(LB, (size_t)H);
+    tc.insert(tc.end(), l.begin(), l.end());
+  }
+  tc_dev.w = (int)tc.size();
+  HIPCHK(hipMalloc((void**)&tc_dev.d, tc.size() * 4));
+  HIPCHK(hipMemcpy(tc_dev.d, tc.data(), tc.size() * 4, hipMemcpyHostToDevice));
+  TripleInfo& ti = m3.triple;
+  ti.mid = &mid;
+  ti.kconsts = kc_dev.d;
+  ti.tconsts = tc_dev.d;
+  ti.c_rh = m3.add_const(rh);
+  BigU rhinv;
+  if (!hostbig::modinv(rh, n3, rhinv)) api_throw(PGPU_ERR_INVALID, "internal: R_H is not invertible modulo the cube");
+  ti.c_exit = m3.add_const(hostbig::mulmod(m3.R % n3, rhinv, n3));
+  ti.dinv1 = dinv1;
+  ti.dinv2 = dinv2;
+  ti.n_limbs = n_limbs;
+  ti.n2_limbs = n2_limbs;
+  ti.root = &root;
+  m3.upload();
 }
 
 // inverse of odd d modulo 2^bits
@@ -1459,39 +1501,8 @@ int pgpu_pubkey_create(pgpu_ctx* ctx, const uint8_t* n_be, size_t n_len, const u
       pi.n_limbs = pk->n_limbs.d;
     }
     if (pk->mn3 && pk->mn.K == 1 && vm_asm_available(pk->mn.WT, 48) && (size_t)LB * pk->mn3->WT >= n3.bit_length() + 3) {
-      const int H = pk->mn.WT;
-      ModCtx& m3 = *pk->mn3;
-      const std::vector<uint32_t> kc = make_triple_kconsts(pk->N, H);
-      pk->triple_kconsts.w = (int)kc.size();
-      HIPCHK(hipMalloc((void**)&pk->triple_kconsts.d, kc.size() * 4));
-      HIPCHK(hipMemcpy(pk->triple_kconsts.d, kc.data(), kc.size() * 4, hipMemcpyHostToDevice));
-      // digit form of 1: the digits of R_H mod n^3
-      const BigU RH = hostbig::shl(BigU(1), (size_t)LB * H);
-      BigU rh = RH % n3, q1, d0, d2, d1;
-      hostbig::divmod(rh, pk->N, q1, d0);
-      hostbig::divmod(q1, pk->N, d2, d1);
-      std::vector<uint32_t> tc;
-      for (const BigU* dg : {&d0, &d1, &d2}) {
-        auto l = dg->to_limbs(LB, (size_t)H);
-        tc.insert(tc.end(), l.begin(), l.end());
-      }
-      pk->triple_tconsts.w = (int)tc.size();
-      HIPCHK(hipMalloc((void**)&pk->triple_tconsts.d, tc.size() * 4));
-      HIPCHK(hipMemcpy(pk->triple_tconsts.d, tc.data(), tc.size() * 4, hipMemcpyHostToDevice));
-      TripleInfo& ti = m3.triple;
-      ti.mid = &pk->mn2;
-      ti.kconsts = pk->triple_kconsts.d;
-      ti.tconsts = pk->triple_tconsts.d;
-      ti.c_rh = m3.add_const(rh);
-      BigU rhinv;
-      if (!hostbig::modinv(rh, n3, rhinv)) api_throw(PGPU_ERR_INVALID, "internal: R_H is not invertible modulo n^3");
-      ti.c_exit = m3.add_const(hostbig::mulmod(m3.R % n3, rhinv, n3));
-      ti.dinv1 = pk->ninv2k.d;
-      ti.dinv2 = pk->ninv2k_2.d;
-      ti.n_limbs = pk->n_limbs.d;
-      ti.n2_limbs = pk->n2_limbs.d;
-      ti.root = &pk->mn;
-      m3.upload();
+      setup_triple(*pk->mn3, pk->mn, pk->mn2, pk->triple_kconsts, pk->triple_tconsts, pk->ninv2k.d, pk->ninv2k_2.d, pk->n_limbs.d,
+                   pk->n2_limbs.d);
     }
     pk->mn.upload();
     pk->mn2.upload();
@@ -1653,7 +1664,14 @@ int pgpu_seckey_create(pgpu_ctx* ctx, const pgpu_pubkey* pk, const uint8_t* lamb
             sk->qinv2k_2.set(inv_mod_pow2(q, (size_t)LB * sk->mq2.WT), sk->mq2.WT);
             sk->q_limbs.set(q, sk->mq.WT);
             sk->p2_limbs.set(p2, sk->mp2.WT);
+            sk->q2_limbs.set(q2, sk->mq2.WT);
             sk->has_crt2 = true;
+            // ladders modulo p^3 / q^3 (the DDLEQ prover, level-two CRT) in three-digit form: digits modulo the prime
+            if (sk->mp.K == 1 && sk->mq.K == 1 && sk->mp.WT == sk->mq.WT && vm_asm_available(sk->mp.WT, 48) &&
+                (size_t)LB * sk->mp3.WT >= sk->mp3.nbits + 3 && (size_t)LB * sk->mq3.WT >= sk->mq3.nbits + 3) {
+              setup_triple(sk->mp3, sk->mp, sk->mp2, sk->tkc_p, sk->ttc_p, sk->pinv2k.d, sk->pinv2k_2.d, sk->p_limbs.d, sk->p2_limbs.d);
+              setup_triple(sk->mq3, sk->mq, sk->mq2, sk->tkc_q, sk->ttc_q, sk->qinv2k.d, sk->qinv2k_2.d, sk->q_limbs.d, sk->q2_limbs.d);
+            }
           }
         }
       }
@@ -2947,6 +2965,45 @@ void pow_n3_crt(const pgpu_seckey* sk, const uint32_t* base, int wb, const uint3
   const ModCtx &mp3 = sk->mp3, &mq3 = sk->mq3;
   const int W = mp3.WT, W3 = sk->pk->mn3->WT;
   const size_t S = (size_t)W * nb;
+  if (triple_usable(ctx, mp3) && triple_usable(ctx, mq3) && (uint64_t)nb * (W + 4) * 4 * 17 < (1ull << 32)) {
+    // both halves on the three-digit kernel (digits modulo p and q, 37 limbs for 2048-bit keys): a squaring is 37 rows
+    // where the wave-sliced 110-limb kernel has 110 -- what counts for the half-size, latency-bound batches of the response
+    const int nslots = base2 ? 5 + 48 : exps ? 5 + 16 : 5 + 32;
+    TriplePlan tp = triple_alloc(ctx, mp3, nb, nslots), tq = triple_alloc(ctx, mq3, nb, nslots);
+    uint32_t* g = ctx->ws_t<uint32_t>(S * 6);       // generic slots (W limbs): 0 x_p, 1 x_q, 2 A, 3 B, 4 h, 5 scratch
+    for (int half = 0; half < 2; ++half) {
+      const ModCtx& m3 = half ? mq3 : mp3;
+      const TriplePlan& t = half ? tq : tp;
+      reduce_mod(ctx, m3, base, wb, g + 5 * S, nb);
+      triple_enter(ctx, m3, g + 5 * S, t, 0);
+      if (base2) {
+        reduce_mod(ctx, m3, base2, wb2, g + 5 * S, nb);
+        triple_enter(ctx, m3, g + 5 * S, t, 1);
+      }
+    }
+    Prog pp;
+    if (base2) emit_modexp_dual(pp, we, *e, 0, 1, 2, 3, 5, 21, 0);
+    else if (exps) emit_modexp_perlane(pp, we, 0, NO_SLOT, 2, 3, 5, NO_SLOT, 0);
+    else emit_modexp_shared(pp, *e, 0, NO_SLOT, 2, 3, 5, NO_SLOT, true, true);
+    pp.end();
+    SegSpec sp{&mp3, &pp, tp.mem, exps}, sq{&mq3, &pp, tq.mem, exps};
+    sp.pair = mp3.triple.kconsts; sp.pair_n0inv = sk->mp.n0inv; sp.pair_h = tp.H; sp.pair_lanes = 3; sp.tconsts = mp3.triple.tconsts;
+    sq.pair = mq3.triple.kconsts; sq.pair_n0inv = sk->mq.n0inv; sq.pair_h = tq.H; sq.pair_lanes = 3; sq.tconsts = mq3.triple.tconsts;
+    run_vm(ctx, nb, sp, &sq, true);
+    triple_exit(ctx, mp3, tp, 3, g + 0 * S, nullptr);     // x_p, canonical
+    triple_exit(ctx, mq3, tq, 3, g + 1 * S, nullptr);     // x_q
+    Prog c;
+    c.op(VM_LOAD, 0); c.op(VM_MULC, (uint32_t)sk->c_p3invR); c.op(VM_STORE, 3);
+    c.op(VM_LOAD, 1); c.op(VM_MULC, (uint32_t)sk->c_p3invR); c.op(VM_STORE, 2);
+    c.end();
+    SegSpec sc{&mq3, &c, g, nullptr};
+    run_vm(ctx, nb, sc, nullptr, false);
+    launch_canon(g + 2 * S, mq3.d_nmod, W, nb, ctx->stream);
+    launch_canon(g + 3 * S, mq3.d_nmod, W, nb, ctx->stream);
+    launch_sub_mod(g + 2 * S, g + 3 * S, mq3.d_nmod, g + 4 * S, W, nb, ctx->stream);                  // h = (x_q - x_p) / p^3 mod q^3
+    launch_mul_const_add(g + 4 * S, W, sk->p3_limbs.d, W, g, W, 0, out, W3, nb, ctx->stream);          // x_p + p^3 h
+    return;
+  }
   // slots: P: in 0, in2 1, tmp 2, out 3, tables 4..51;  Q: the same + QO;  A, B, h after them
   const uint32_t QO = 56, SA = 112, SB = 113, SH = 114;
   uint32_t* mem = ctx->ws_t<uint32_t>(S * 115);
