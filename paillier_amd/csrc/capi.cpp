@@ -1943,9 +1943,31 @@ uint32_t* decrypt2_crt(const pgpu_seckey* sk, const uint32_t* c_limbs, size_t nb
   const ModCtx &mp = sk->mp, &mq = sk->mq, &mp2 = sk->mp2, &mq2 = sk->mq2, &mp3 = sk->mp3, &mq3 = sk->mq3;
   const int W1 = mp.WT, W2 = mp2.WT, W3 = mp3.WT;
   const size_t S1 = (size_t)W1 * nb, S2 = (size_t)W2 * nb, S3 = (size_t)W3 * nb;
-  uint32_t* mem = ctx->ws_t<uint32_t>(S3 * 70);   // same slot plan as decrypt1_crt
-  HIPCHK(hipMemcpyAsync(mem, c_limbs, S3 * 2 * 4, hipMemcpyDeviceToDevice, ctx->stream));
-  {
+  uint32_t *up, *uq;
+  if (triple_usable(ctx, mp3) && triple_usable(ctx, mq3)) {
+    // c^(p-1) mod p^3 and c^(q-1) mod q^3 on the three-digit kernel (digits modulo the prime), both halves in one launch
+    TriplePlan tp = triple_alloc(ctx, mp3, nb, 5 + 32), tq = triple_alloc(ctx, mq3, nb, 5 + 32);
+    uint32_t* g = ctx->ws_t<uint32_t>(S3 * 3);
+    reduce_mod(ctx, mp3, c_limbs, 2 * W3, g + 2 * S3, nb);
+    triple_enter(ctx, mp3, g + 2 * S3, tp, 0);
+    reduce_mod(ctx, mq3, c_limbs, 2 * W3, g + 2 * S3, nb);
+    triple_enter(ctx, mq3, g + 2 * S3, tq, 0);
+    Prog pp, pq;
+    emit_modexp_shared(pp, sk->p - BigU(1), 0, NO_SLOT, 2, 3, 5, NO_SLOT, true, true);
+    pp.end();
+    emit_modexp_shared(pq, sk->q - BigU(1), 0, NO_SLOT, 2, 3, 5, NO_SLOT, true, true);
+    pq.end();
+    SegSpec sp{&mp3, &pp, tp.mem, nullptr}, sq{&mq3, &pq, tq.mem, nullptr};
+    sp.pair = mp3.triple.kconsts; sp.pair_n0inv = mp.n0inv; sp.pair_h = tp.H; sp.pair_lanes = 3; sp.tconsts = mp3.triple.tconsts;
+    sq.pair = mq3.triple.kconsts; sq.pair_n0inv = mq.n0inv; sq.pair_h = tq.H; sq.pair_lanes = 3; sq.tconsts = mq3.triple.tconsts;
+    run_vm(ctx, nb, sp, &sq, true);
+    up = g;
+    uq = g + S3;
+    triple_exit(ctx, mp3, tp, 3, up, nullptr);
+    triple_exit(ctx, mq3, tq, 3, uq, nullptr);
+  } else {
+    uint32_t* mem = ctx->ws_t<uint32_t>(S3 * 70);   // same slot plan as decrypt1_crt
+    HIPCHK(hipMemcpyAsync(mem, c_limbs, S3 * 2 * 4, hipMemcpyDeviceToDevice, ctx->stream));
     Prog pp, pq;
     emit_modexp_shared(pp, sk->p - BigU(1), 0, 1, 2, 3, 4, NO_SLOT, true);
     pp.end();
@@ -1953,10 +1975,11 @@ uint32_t* decrypt2_crt(const pgpu_seckey* sk, const uint32_t* c_limbs, size_t nb
     pq.end();
     SegSpec sp{&mp3, &pp, mem, nullptr}, sq{&mq3, &pq, mem, nullptr};
     run_vm(ctx, nb, sp, &sq, true);
+    up = mem + 3 * S3;
+    uq = mem + 37 * S3;
+    launch_canon(up, mp3.d_nmod, W3, nb, ctx->stream);
+    launch_canon(uq, mq3.d_nmod, W3, nb, ctx->stream);
   }
-  uint32_t *up = mem + 3 * S3, *uq = mem + 37 * S3;
-  launch_canon(up, mp3.d_nmod, W3, nb, ctx->stream);
-  launch_canon(uq, mq3.d_nmod, W3, nb, ctx->stream);
   // m2 (W2-limb slots): per side s in {0 (p), 1 (q)}: 5s+0 L, 5s+1 t*prime, 5s+2 w, 5s+3 L - w, 5s+4 m mod prime^2;
   // then 10 B, 11 A, 12 h
   uint32_t* m2 = ctx->ws_t<uint32_t>(S2 * 13);
