@@ -1944,7 +1944,8 @@ uint32_t* decrypt2_crt(const pgpu_seckey* sk, const uint32_t* c_limbs, size_t nb
   const int W1 = mp.WT, W2 = mp2.WT, W3 = mp3.WT;
   const size_t S1 = (size_t)W1 * nb, S2 = (size_t)W2 * nb, S3 = (size_t)W3 * nb;
   uint32_t *up, *uq;
-  if (triple_usable(ctx, mp3) && triple_usable(ctx, mq3)) {
+  if (triple_usable(ctx, mp3) && triple_usable(ctx, mq3) && (sk->p - BigU(1)).bit_length() >= 64 &&
+      (sk->q - BigU(1)).bit_length() >= 64) {       // (the raw ladder is the sliding-window form: toy keys keep the generic kernel)
     // c^(p-1) mod p^3 and c^(q-1) mod q^3 on the three-digit kernel (digits modulo the prime), both halves in one launch
     TriplePlan tp = triple_alloc(ctx, mp3, nb, 5 + 32), tq = triple_alloc(ctx, mq3, nb, 5 + 32);
     uint32_t* g = ctx->ws_t<uint32_t>(S3 * 3);
@@ -2988,7 +2989,8 @@ void pow_n3_crt(const pgpu_seckey* sk, const uint32_t* base, int wb, const uint3
   const ModCtx &mp3 = sk->mp3, &mq3 = sk->mq3;
   const int W = mp3.WT, W3 = sk->pk->mn3->WT;
   const size_t S = (size_t)W * nb;
-  if (triple_usable(ctx, mp3) && triple_usable(ctx, mq3) && (uint64_t)nb * (W + 4) * 4 * 17 < (1ull << 32)) {
+  if (triple_usable(ctx, mp3) && triple_usable(ctx, mq3) && (uint64_t)nb * (W + 4) * 4 * 17 < (1ull << 32) &&
+      (exps || base2 || e->bit_length() >= 64)) {
     // both halves on the three-digit kernel (digits modulo p and q, 37 limbs for 2048-bit keys): a squaring is 37 rows
     // where the wave-sliced 110-limb kernel has 110 -- what counts for the half-size, latency-bound batches of the response
     const int nslots = base2 ? 5 + 48 : exps ? 5 + 16 : 5 + 32;
