@@ -262,10 +262,10 @@ struct Prog {
   bool has_mulv = false;
   void op(uint32_t o, uint32_t arg = 0, uint32_t aux = 0) {
     if (o == VM_SETOFF) asm_ok = false;
-    if (o == VM_MULV) has_mulv = true;
+    if (o == VM_MULV || o == VM_MULV5) has_mulv = true;
     w.push_back(o | (aux << 8));
     w.push_back(arg);
-    if (o == VM_SQR || o == VM_MUL || o == VM_MULC || o == VM_MULV || o == VM_MULCV) montmuls += 1;
+    if (o == VM_SQR || o == VM_MUL || o == VM_MULC || o == VM_MULV || o == VM_MULCV || o == VM_MULV5) montmuls += 1;
     if (o == VM_SQR) sqrs += 1;
   }
   void end() { op(VM_END); }
@@ -370,23 +370,27 @@ void emit_modexp_shared(Prog& p, const BigU& e, uint32_t in_lo, uint32_t in_hi, 
 // the segment's `digits` array [we][nb].  Table slots tab .. tab+15.
 // raw_one >= 0: the value in slot in_lo is already in the kernel's working form (pair kernels), raw_one is the constant
 // holding 1 in that form; no entry, no exit.
+// w5: 5-bit windows (VM_MULV5; the segment's `digits` must be the repacked 25-bit words: windows5_of()); table tab .. tab+31.
+// Pays where a product costs two squarings (the digit kernels): 4 096-bit exponents take 820 + 30 products instead of
+// 1 024 + 14.
 void emit_modexp_perlane(Prog& p, int we, uint32_t in_lo, uint32_t in_hi, uint32_t tmp, uint32_t out, uint32_t tab,
-                         uint32_t post_slot, int raw_one = -1) {
+                         uint32_t post_slot, int raw_one = -1, bool w5 = false) {
   const uint32_t one = raw_one >= 0 ? (uint32_t)raw_one : (uint32_t)C_ONE_M;
+  const int wb = w5 ? 5 : 4;
   if (raw_one >= 0) p.op(VM_LOAD, in_lo); else emit_to_mont(p, in_lo, in_hi, tmp);
   p.op(VM_STORE, tab + 1);
   p.op(VM_LOADC, one);
   p.op(VM_STORE, tab + 0);
   p.op(VM_LOAD, tab + 1);
-  for (uint32_t k = 2; k < 16; ++k) {
+  for (uint32_t k = 2; k < (1u << wb); ++k) {
     p.op(VM_MUL, tab + 1);
     p.op(VM_STORE, tab + k);
   }
-  const int nwin = we * 7;
+  const int nwin = w5 ? (we * LB + 4) / 5 : we * 7;
   p.op(VM_LOADC, one);
   for (int i = nwin - 1; i >= 0; --i) {
-    if (i != nwin - 1) for (int s = 0; s < 4; ++s) p.op(VM_SQR);
-    p.op(VM_MULV, (uint32_t)i, tab);
+    if (i != nwin - 1) for (int s = 0; s < wb; ++s) p.op(VM_SQR);
+    p.op(w5 ? VM_MULV5 : VM_MULV, (uint32_t)i, tab);
   }
   if (raw_one < 0) { if (post_slot != NO_SLOT) p.op(VM_MUL, post_slot); else p.op(VM_MULC, C_ONE); }
   p.op(VM_STORE, out);
@@ -398,7 +402,7 @@ void emit_modexp_perlane(Prog& p, int we, uint32_t in_lo, uint32_t in_hi, uint32
 // verifier (ddleq.go:143-152) and alpha = ct1^(x^n) * y^(n^2) of the prover (ddleq.go:81-87) need.
 // x in slot in1, y in slot in2 (plain residues); result (plain, lazy) -> out.
 void emit_modexp_dual(Prog& p, int we, const BigU& e, uint32_t in1, uint32_t in2, uint32_t tmp, uint32_t out, uint32_t tab1,
-                      uint32_t tab2, int raw_one = -1) {
+                      uint32_t tab2, int raw_one = -1, bool w5 = false) {
   // raw_one >= 0: in1 / in2 are already in the kernel's working form (digit kernels), raw_one = the constant holding 1 in
   // that form; no entry, no exit
   const uint32_t one_m = raw_one >= 0 ? (uint32_t)raw_one : (uint32_t)C_ONE_M;
@@ -408,7 +412,7 @@ void emit_modexp_dual(Prog& p, int we, const BigU& e, uint32_t in1, uint32_t in2
   p.op(VM_LOADC, one_m);
   p.op(VM_STORE, tab1 + 0);
   p.op(VM_LOAD, tab1 + 1);
-  for (uint32_t k = 2; k < 16; ++k) { p.op(VM_MUL, tab1 + 1); p.op(VM_STORE, tab1 + k); }
+  for (uint32_t k = 2; k < (w5 ? 32u : 16u); ++k) { p.op(VM_MUL, tab1 + 1); p.op(VM_STORE, tab1 + k); }
   const int sw = 6;
   const uint32_t nodd = 1u << (sw - 1);
   if (raw_one >= 0) p.op(VM_LOAD, in2); else emit_to_mont(p, in2, NO_SLOT, tmp);
@@ -432,7 +436,8 @@ void emit_modexp_dual(Prog& p, int we, const BigU& e, uint32_t in1, uint32_t in2
   p.op(VM_LOADC, one_m);
   for (long b = nbits - 1; b >= 0; --b) {
     if (b != nbits - 1) p.op(VM_SQR);
-    if (b % 4 == 0 && b / 4 < (long)we * 7) p.op(VM_MULV, (uint32_t)(b / 4), tab1);
+    if (!w5 && b % 4 == 0 && b / 4 < (long)we * 7) p.op(VM_MULV, (uint32_t)(b / 4), tab1);
+    if (w5 && b % 5 == 0 && b / 5 < ((long)we * LB + 4) / 5) p.op(VM_MULV5, (uint32_t)(b / 5), tab1);
     if (mul_at[(size_t)b] >= 0) p.op(VM_MUL, tab2 + (uint32_t)mul_at[(size_t)b]);
   }
   if (raw_one < 0) p.op(VM_MULC, C_ONE);
@@ -943,6 +948,14 @@ struct TriplePlan {
   uint32_t* slot(uint32_t i) const { return mem + (size_t)i * slot_words; }
 };
 
+// per-number exponents (28-bit limbs, [we][nb]) -> the 25-bit words VM_MULV5 reads (5 windows of 5 bits each)
+const uint32_t* windows5_of(pgpu_ctx* ctx, const uint32_t* exps, int we, size_t nb) {
+  const int we5 = (we * LB + 24) / 25;
+  uint32_t* out = ctx->ws_t<uint32_t>((size_t)we5 * nb);
+  launch_repack_windows5(exps, we, out, we5, nb, ctx->stream);
+  return out;
+}
+
 bool triple_usable(pgpu_ctx* ctx, const ModCtx& mc) {
   static const bool env_on = [] { const char* e = getenv("PGPU_TRIPLE"); return e ? atoi(e) != 0 : true; }();
   return env_on && mc.triple.root && ctx->use_asm && ctx->use_pair && ctx->use_triple;
@@ -1018,12 +1031,17 @@ void triple_run(pgpu_ctx* ctx, const ModCtx& mc, const TriplePlan& tp, const Pro
 // pl.in() (canonical, < n^3) ^ e [* pl.post()] mod n^3 on the three-digit kernel; canonical result in pl.out()
 void modexp_triple(pgpu_ctx* ctx, const ModCtx& mc, const ModexpPlan& pl, const BigU* e, const uint32_t* exps, int we,
                    bool use_post) {
-  // digit slots: 0 in, 1 (unused), 2 tmp, 3 out, 5.. table
+  // digit slots: 0 in, 1 (unused), 2 tmp, 3 out, 5.. table (32 entries: sliding windows of a shared exponent, or the 5-bit
+  // windows of per-number exponents -- a product costs two squarings here, so the wider window pays)
   TriplePlan tp = triple_alloc(ctx, mc, pl.nb, 5 + 32);
   triple_enter(ctx, mc, pl.in(), tp, 0);
   Prog p;
-  if (exps) emit_modexp_perlane(p, we, 0, NO_SLOT, 2, 3, 5, NO_SLOT, 0);
-  else emit_modexp_shared(p, *e, 0, NO_SLOT, 2, 3, 5, NO_SLOT, true, true);
+  if (exps) {
+    emit_modexp_perlane(p, we, 0, NO_SLOT, 2, 3, 5, NO_SLOT, 0, true);
+    exps = windows5_of(ctx, exps, we, pl.nb);
+  } else {
+    emit_modexp_shared(p, *e, 0, NO_SLOT, 2, 3, 5, NO_SLOT, true, true);
+  }
   p.end();
   triple_run(ctx, mc, tp, p, exps);
   triple_exit(ctx, mc, tp, 3, pl.out(), use_post ? pl.post() : nullptr);
@@ -1054,7 +1072,7 @@ void modexp_shared_run(pgpu_ctx* ctx, const ModCtx& mc, const ModexpPlan& pl, co
 
 void modexp_perlane_run(pgpu_ctx* ctx, const ModCtx& mc, const ModexpPlan& pl, const uint32_t* exps, int we, bool wide,
                         bool use_post) {
-  if (triple_usable(ctx, mc) && !wide && we >= 10 && (uint64_t)pl.nb * (mc.WT + 4) * 4 * 17 < (1ull << 32)) {
+  if (triple_usable(ctx, mc) && !wide && we >= 10 && (uint64_t)pl.nb * (mc.WT + 4) * 4 * 33 < (1ull << 32)) {
     modexp_triple(ctx, mc, pl, nullptr, exps, we, use_post);
     return;
   }
@@ -2847,19 +2865,19 @@ int pgpu_ddleq_verify(const pgpu_pubkey* pk, size_t batch, const uint8_t* ct1, c
     // check = chalBit ? ct2 : ct1 ; check^en * F^(n^2) mod n^3 == alpha           (ddleq.go:138-152)
     // one interleaved ladder: the squarings of check^en and of F^(n^2) are shared (emit_modexp_dual)
     if (f_stride * 8 > (size_t)LB * W3 + 7) api_throw(PGPU_ERR_INVALID, "F wider than n^3");
-    const bool use3 = triple_usable(ctx, mn3) && (uint64_t)nb * (W3 + 4) * 4 * 17 < (1ull << 32);
+    const bool use3 = triple_usable(ctx, mn3) && (uint64_t)nb * (W3 + 4) * 4 * 33 < (1ull << 32);
     ModexpPlan pc = modexp_alloc(ctx, mn3, nb, use3 ? 0 : 48);   // slots: 0 check, 1 F, 2 tmp, 3 out, 5..20 / 21..52 the two tables
     launch_select(chal, c2, c1, pc.in(), W3, nb, ctx->stream);
     unpack_operand(ctx, f, f_stride, f_stride, batch, mem, pc.in() + pc.slot_words, W3, nb);
     if (use3) {
       // the same interleaved ladder on the three-digit kernel: residues modulo n^3 as a0 + a1 n + a2 n^2
-      TriplePlan tp = triple_alloc(ctx, mn3, nb, 5 + 48);
+      TriplePlan tp = triple_alloc(ctx, mn3, nb, 5 + 64);      // slots: 0 check, 1 F, 2 tmp, 3 out, 5..36 / 37..68 the tables
       triple_enter(ctx, mn3, pc.in(), tp, 0);
       triple_enter(ctx, mn3, pc.in() + pc.slot_words, tp, 1);
       Prog pd;
-      emit_modexp_dual(pd, W2, mn2.N, 0, 1, 2, 3, 5, 21, 0);
+      emit_modexp_dual(pd, W2, mn2.N, 0, 1, 2, 3, 5, 37, 0, true);     // 5-bit windows of E^n
       pd.end();
-      triple_run(ctx, mn3, tp, pd, pe.out());
+      triple_run(ctx, mn3, tp, pd, windows5_of(ctx, pe.out(), W2, nb));
       triple_exit(ctx, mn3, tp, 3, pc.out(), nullptr);
     } else {
       Prog pd;
@@ -2989,11 +3007,11 @@ void pow_n3_crt(const pgpu_seckey* sk, const uint32_t* base, int wb, const uint3
   const ModCtx &mp3 = sk->mp3, &mq3 = sk->mq3;
   const int W = mp3.WT, W3 = sk->pk->mn3->WT;
   const size_t S = (size_t)W * nb;
-  if (triple_usable(ctx, mp3) && triple_usable(ctx, mq3) && (uint64_t)nb * (W + 4) * 4 * 17 < (1ull << 32) &&
+  if (triple_usable(ctx, mp3) && triple_usable(ctx, mq3) && (uint64_t)nb * (W + 4) * 4 * 33 < (1ull << 32) &&
       (exps || base2 || e->bit_length() >= 64)) {
     // both halves on the three-digit kernel (digits modulo p and q, 37 limbs for 2048-bit keys): a squaring is 37 rows
     // where the wave-sliced 110-limb kernel has 110 -- what counts for the half-size, latency-bound batches of the response
-    const int nslots = base2 ? 5 + 48 : exps ? 5 + 16 : 5 + 32;
+    const int nslots = base2 ? 5 + 64 : 5 + 32;
     TriplePlan tp = triple_alloc(ctx, mp3, nb, nslots), tq = triple_alloc(ctx, mq3, nb, nslots);
     uint32_t* g = ctx->ws_t<uint32_t>(S * 6);       // generic slots (W limbs): 0 x_p, 1 x_q, 2 A, 3 B, 4 h, 5 scratch
     for (int half = 0; half < 2; ++half) {
@@ -3007,10 +3025,11 @@ void pow_n3_crt(const pgpu_seckey* sk, const uint32_t* base, int wb, const uint3
       }
     }
     Prog pp;
-    if (base2) emit_modexp_dual(pp, we, *e, 0, 1, 2, 3, 5, 21, 0);
-    else if (exps) emit_modexp_perlane(pp, we, 0, NO_SLOT, 2, 3, 5, NO_SLOT, 0);
+    if (base2) emit_modexp_dual(pp, we, *e, 0, 1, 2, 3, 5, 37, 0, true);
+    else if (exps) emit_modexp_perlane(pp, we, 0, NO_SLOT, 2, 3, 5, NO_SLOT, 0, true);
     else emit_modexp_shared(pp, *e, 0, NO_SLOT, 2, 3, 5, NO_SLOT, true, true);
     pp.end();
+    if (exps) exps = windows5_of(ctx, exps, we, nb);                       // 5-bit windows of the per-number exponents
     SegSpec sp{&mp3, &pp, tp.mem, exps}, sq{&mq3, &pp, tq.mem, exps};
     sp.pair = mp3.triple.kconsts; sp.pair_n0inv = sk->mp.n0inv; sp.pair_h = tp.H; sp.pair_lanes = 3; sp.tconsts = mp3.triple.tconsts;
     sq.pair = mq3.triple.kconsts; sq.pair_n0inv = sk->mq.n0inv; sq.pair_h = tq.H; sq.pair_lanes = 3; sq.tconsts = mq3.triple.tconsts;

@@ -32,7 +32,7 @@ import sys
 LB = 28
 MASK = (1 << LB) - 1
 BLOCK = 256
-OPS = dict(END=0, LOAD=1, STORE=2, LOADC=3, SQR=4, MUL=5, MULC=6, MULV=7, ADD=8, SETOFF=9, MULCV=10)
+OPS = dict(END=0, LOAD=1, STORE=2, LOADC=3, SQR=4, MUL=5, MULC=6, MULV=7, ADD=8, SETOFF=9, MULCV=10, MULV5=11)
 
 
 class Gen:
@@ -296,7 +296,7 @@ class Gen:
         e("s_addc_u32 s5, s5, 0")
         e("s_waitcnt lgkmcnt(0)")
         e("s_and_b32 s18, s16, 0xff")
-        for nm in ("SQR", "MUL", "MULC", "MULV", "MULCV", "LOAD", "STORE", "LOADC", "ADD"):
+        for nm in ("SQR", "MUL", "MULC", "MULV", "MULV5", "MULCV", "LOAD", "STORE", "LOADC", "ADD"):
             e(f"s_cmp_eq_u32 s18, {OPS[nm]}")
             e(f"s_cbranch_scc1 L_{nm.lower()}")
         e("s_endpgm")  # END (and anything unsupported: the host never sends those)
@@ -336,39 +336,41 @@ class Gen:
         self.stage_to_lds(St)
         e("s_branch L_montmul")
 
-        e("L_mulv:")
-        # per-number table index: window `arg` (4 bits, 7 per 28-bit limb) of this number's own exponent;
-        # table slot = aux + digit.  Uniform control flow, per-lane gather address.
-        e(f"s_mul_hi_u32 s{g.s_t1}, s17, {((1 << 32) + 6) // 7}")          # q = arg / 7
-        e(f"s_mul_i32 s98, s{g.s_t1}, 7")
-        e("s_sub_u32 s98, s17, s98")                                       # r = arg % 7
-        e("s_lshl_b32 s98, s98, 2")                                        # shift = 4 r
-        e(f"s_mul_hi_u32 s{g.s_sbase + 1}, s{g.s_t1}, s3")                 # digits + q * nb*4
-        e(f"s_mul_i32 s{g.s_sbase}, s{g.s_t1}, s3")
-        e(f"s_add_u32 s{g.s_sbase}, s{g.s_sbase}, s12")
-        e(f"s_addc_u32 s{g.s_sbase + 1}, s{g.s_sbase + 1}, s13")
-        e(f"v_subrev_u32 v{g.v_t2}, {self.lds_a}, v{g.v_aread}")           # gl*4
-        e(f"s_mul_i32 s{g.s_t0}, s2, {self.NPB * 4}")
-        e(f"v_add_u32 v{g.v_t2}, s{g.s_t0}, v{g.v_t2}")                    # g*4
-        e(f"global_load_dword v{g.v_t3}, v{g.v_t2}, s[{g.s_sbase}:{g.s_sbase + 1}]")
-        e("s_waitcnt vmcnt(0)")
-        e(f"v_lshrrev_b32 v{g.v_t3}, s98, v{g.v_t3}")
-        e(f"v_and_b32 v{g.v_t3}, 15, v{g.v_t3}")                           # digit
-        e(f"s_mul_i32 s{g.s_t0}, s3, {self.WT}")                           # slot stride in bytes
-        e(f"v_mul_lo_u32 v{g.v_t3}, v{g.v_t3}, s{g.s_t0}")                  # digit * stride (host guarantees < 2^32)
-        e("s_lshr_b32 s17, s16, 8")                                        # aux = first table slot
-        e(f"s_mul_hi_u32 s{g.s_sbase + 1}, s17, s{g.s_t0}")
-        e(f"s_mul_i32 s{g.s_sbase}, s17, s{g.s_t0}")
-        e(f"s_add_u32 s{g.s_sbase}, s{g.s_sbase}, s10")
-        e(f"s_addc_u32 s{g.s_sbase + 1}, s{g.s_sbase + 1}, s11")
-        e(f"v_add_u32 v{g.v_addr}, v{g.v_t3}, v{g.v_goff}")
-        for j in range(self.WL):
-            e(f"global_load_dword {St[j]}, v{g.v_addr}, s[{g.s_sbase}:{g.s_sbase + 1}]")
-            if j != self.WL - 1:
-                e(f"v_add_u32 v{g.v_addr}, s3, v{g.v_addr}")
-        e("s_waitcnt vmcnt(0)")
-        self.stage_to_lds(St)
-        e("s_branch L_montmul")
+        for lbl, per_word, wbits in (("L_mulv", 7, 4), ("L_mulv5", 5, 5)):
+            # per-number table index: window `arg` of this number's own exponent -- 4 bits, 7 per 28-bit limb (MULV), or 5
+            # bits, 5 per 25-bit word of the repacked exponent (MULV5); table slot = aux + digit.  Uniform control flow,
+            # per-lane gather address.
+            e(f"{lbl}:")
+            e(f"s_mul_hi_u32 s{g.s_t1}, s17, {((1 << 32) + per_word - 1) // per_word}")   # q = arg / per_word
+            e(f"s_mul_i32 s98, s{g.s_t1}, {per_word}")
+            e("s_sub_u32 s98, s17, s98")                                       # r = arg % per_word
+            e(f"s_mul_i32 s98, s98, {wbits}")                                  # shift = wbits * r
+            e(f"s_mul_hi_u32 s{g.s_sbase + 1}, s{g.s_t1}, s3")                 # digits + q * nb*4
+            e(f"s_mul_i32 s{g.s_sbase}, s{g.s_t1}, s3")
+            e(f"s_add_u32 s{g.s_sbase}, s{g.s_sbase}, s12")
+            e(f"s_addc_u32 s{g.s_sbase + 1}, s{g.s_sbase + 1}, s13")
+            e(f"v_subrev_u32 v{g.v_t2}, {self.lds_a}, v{g.v_aread}")           # gl*4
+            e(f"s_mul_i32 s{g.s_t0}, s2, {self.NPB * 4}")
+            e(f"v_add_u32 v{g.v_t2}, s{g.s_t0}, v{g.v_t2}")                    # g*4
+            e(f"global_load_dword v{g.v_t3}, v{g.v_t2}, s[{g.s_sbase}:{g.s_sbase + 1}]")
+            e("s_waitcnt vmcnt(0)")
+            e(f"v_lshrrev_b32 v{g.v_t3}, s98, v{g.v_t3}")
+            e(f"v_and_b32 v{g.v_t3}, {(1 << wbits) - 1}, v{g.v_t3}")           # digit
+            e(f"s_mul_i32 s{g.s_t0}, s3, {self.WT}")                           # slot stride in bytes
+            e(f"v_mul_lo_u32 v{g.v_t3}, v{g.v_t3}, s{g.s_t0}")                  # digit * stride (host guarantees < 2^32)
+            e("s_lshr_b32 s17, s16, 8")                                        # aux = first table slot
+            e(f"s_mul_hi_u32 s{g.s_sbase + 1}, s17, s{g.s_t0}")
+            e(f"s_mul_i32 s{g.s_sbase}, s17, s{g.s_t0}")
+            e(f"s_add_u32 s{g.s_sbase}, s{g.s_sbase}, s10")
+            e(f"s_addc_u32 s{g.s_sbase + 1}, s{g.s_sbase + 1}, s11")
+            e(f"v_add_u32 v{g.v_addr}, v{g.v_t3}, v{g.v_goff}")
+            for j in range(self.WL):
+                e(f"global_load_dword {St[j]}, v{g.v_addr}, s[{g.s_sbase}:{g.s_sbase + 1}]")
+                if j != self.WL - 1:
+                    e(f"v_add_u32 v{g.v_addr}, s3, v{g.v_addr}")
+            e("s_waitcnt vmcnt(0)")
+            self.stage_to_lds(St)
+            e("s_branch L_montmul")
 
         e("L_mulcv:")
         # fixed-base comb: a <- consts[aux + 16*arg + digit], digit = 4-bit window `arg` of this number's exponent

@@ -18,6 +18,7 @@ enum VmOp : uint32_t {
   VM_ADD = 8,     // x <- x + mem[arg]            (lazy; must be followed by a MULC before SQR)
   VM_SETOFF = 9,  // operand number offset for LOAD/STORE/MUL/ADD <- arg
   VM_MULCV = 10,  // x <- x*consts[aux + 16*arg + window(arg) of this number's exponent]*R^-1  (fixed-base comb table)
+  VM_MULV5 = 11,  // MULV with 5-bit windows: `digits` holds the exponents repacked as 25-bit words (5 windows each), 32-entry table
 };
 
 struct VmSeg {
@@ -76,3 +77,5 @@ void launch_or_flags(const int32_t* flags, size_t count, int32_t* status, int32_
 void launch_clear_where(const int32_t* flags, size_t count, int32_t* ok, hipStream_t st);
 // out[l][g] = table[idx[g]][l] (g < count; padding lanes take row 0)
 void launch_gather_rows(const uint32_t* table, int w, const int32_t* idx, size_t count, uint32_t* out, size_t nb, hipStream_t st);
+// per-number exponents as 28-bit limbs [we][nb] -> 25-bit words [we5][nb] (5 windows of 5 bits per word), for VM_MULV5
+void launch_repack_windows5(const uint32_t* in, int we, uint32_t* out, int we5, size_t nb, hipStream_t st);

@@ -104,6 +104,10 @@ __global__ void __launch_bounds__(VM_BLOCK, (3 * WL + 24 <= 256) ? 2 : 1) vm_ker
         // aux = first table slot.  The table index differs per number: a gather, not a branch.
         const uint32_t elimb = sg.digits[(size_t)(arg / 7u) * nb + g];
         slot = (size_t)(w0 >> 8) + ((elimb >> (4u * (arg % 7u))) & 15u);
+      } else if (op == VM_MULV5) {
+        // 5-bit windows of the exponent repacked as 25-bit words (5 windows per word); 32-entry table
+        const uint32_t eword = sg.digits[(size_t)(arg / 5u) * nb + g];
+        slot = (size_t)(w0 >> 8) + ((eword >> (5u * (arg % 5u))) & 31u);
       }
       const uint32_t* p = sg.mem + (slot * WT + (size_t)k * WL) * nb + g + goff;
 #pragma unroll
@@ -722,6 +726,18 @@ __global__ void k_gather_rows(const uint32_t* __restrict__ table, int w, const i
   for (int l = 0; l < w; ++l) out[(size_t)l * nb + g] = row[l];
 }
 
+// exponent limbs (28 bits) -> 25-bit words: word k = bits [25 k, 25 k + 25) of the number
+__global__ void k_repack_windows5(const uint32_t* __restrict__ in, int we, uint32_t* __restrict__ out, int we5, size_t nb) {
+  size_t g = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (g >= nb) return;
+  for (int k = 0; k < we5; ++k) {
+    const int bit = 25 * k, l = bit / LB, sh = bit % LB;
+    uint64_t v = l < we ? in[(size_t)l * nb + g] : 0u;
+    if (l + 1 < we) v |= (uint64_t)in[(size_t)(l + 1) * nb + g] << LB;
+    out[(size_t)k * nb + g] = (uint32_t)(v >> sh) & ((1u << 25) - 1u);
+  }
+}
+
 // status[g] |= flag where flags[g] != 0 (g < count)
 __global__ void k_or_flags(const int32_t* __restrict__ flags, size_t count, int32_t* __restrict__ status, int32_t flag) {
   size_t g = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -868,4 +884,7 @@ void launch_clear_where(const int32_t* flags, size_t count, int32_t* ok, hipStre
 }
 void launch_gather_rows(const uint32_t* table, int w, const int32_t* idx, size_t count, uint32_t* out, size_t nb, hipStream_t st) {
   hipLaunchKernelGGL(k_gather_rows, HELPER_GRID(nb), 0, st, table, w, idx, count, out, nb);
+}
+void launch_repack_windows5(const uint32_t* in, int we, uint32_t* out, int we5, size_t nb, hipStream_t st) {
+  hipLaunchKernelGGL(k_repack_windows5, HELPER_GRID(nb), 0, st, in, we, out, we5, nb);
 }
