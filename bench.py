@@ -441,10 +441,19 @@ def main():
             note()
             return o
 
+        def servers_fn(rows):
+            # one rank holding all t shares: the servers' ladders pair up in two-segment launches (pgpu_partial_decrypt_multi)
+            outs = [torch.empty((rows.shape[0], 512), dtype=torch.uint8, device=dev) for _ in ids]
+            tk.partial_decrypt_multi_raw([shares[i - 1] for i in ids], rows.shape[0], rows.data_ptr(), 512,
+                                         [o.data_ptr() for o in outs], 512, MEM_DEVICE)
+            note()
+            return outs
+
         def tstep():
             # one launch per rank once a rank's share of a server falls below what fills the chip on its own
             return pdist.threshold_decrypt_sharded(tc, len(ids), rank, world, partial_fn, combine_fn,
-                                                   units_fn=units_fn if (len(ids) * BT) // world < 32768 else None)
+                                                   units_fn=units_fn if (len(ids) * BT) // world < 32768 else None,
+                                                   servers_fn=servers_fn)
 
         tstep()
         barrier()

@@ -166,6 +166,14 @@ int pgpu_const_mult(const pgpu_pubkey* pk, int level, size_t batch, const uint8_
 int pgpu_partial_decrypt(const pgpu_pubkey* pk, int total_servers, const uint8_t* share_be, size_t share_len, size_t batch,
                          const uint8_t* c, size_t c_stride, uint8_t* out, size_t out_stride, int mem);
 
+/* ThresholdSecretKey.PartialDecrypt of ONE ciphertext batch by SEVERAL servers (a process that holds more than one share:
+ * the shape of the reference's own BenchmarkThresholdDecrypt, thresholdkey_test.go:396-427): outs[k][i] = c[i]^(2 * l! * shares[k]).
+ * The entry conversion of the ciphertexts is done once and the ladders of two servers share a launch, so that a batch which
+ * alone would leave the chip half empty runs on the efficient two-lane kernel. */
+int pgpu_partial_decrypt_multi(const pgpu_pubkey* pk, int total_servers, int n_shares, const uint8_t* const* shares_be,
+                               const size_t* share_lens, size_t batch, const uint8_t* c, size_t c_stride, uint8_t* const* outs,
+                               size_t out_stride, int mem);
+
 /* ThresholdSecretKey.PartialDecrypt for a batch of (share, ciphertext) UNITS: out[i] = c[i]^(2 * l! * shares[share_index[i]])
  * mod n^2.  One launch serves the units of several decryption servers (or any mix of them): the exponents become per-unit
  * operands of the ladder.  This is what a shard of a threshold batch looks like -- e.g. 16 384 ciphertexts x 3 servers over

@@ -69,6 +69,7 @@ SIGNATURES = {
     "pgpu_add_many": (_int, [_vp, _int, _int, _sz, _vp, _sz, _vp, _sz, _int]),
     "pgpu_sub_many": (_int, [_vp, _int, _int, _sz, _vp, _sz, _vp, _sz, _int, _vp]),
     "pgpu_partial_decrypt": (_int, [_vp, _int, _vp, _sz, _sz, _vp, _sz, _vp, _sz, _int]),
+    "pgpu_partial_decrypt_multi": (_int, [_vp, _int, _int, _vp, _vp, _sz, _vp, _sz, _vp, _sz, _int]),
     "pgpu_partial_decrypt_indexed": (_int, [_vp, _int, _int, _vp, _vp, _sz, _vp, _sz, _vp, _vp, _sz, _int]),
     "pgpu_combine_partial_decryptions": (_int, [_vp, _int, _int, _int, _vp, _sz, _vp, _sz, _vp, _sz, _int, _vp]),
     "pgpu_random_oracle_digest": (_int, [_vp, _int, _vp, _vp, _sz, _vp, _int]),
@@ -432,6 +433,15 @@ class ThresholdPublicKey(PublicKey):
         sb = _be(share)
         _check(self.ctx.lib.pgpu_partial_decrypt(self.h, self.TotalNumberOfDecryptionServers, sb, len(sb), batch, _ptr(c),
                                                  c_stride, _ptr(out), out_stride, mem))
+
+    def partial_decrypt_multi_raw(self, shares: Sequence[int], batch, c, c_stride, outs: Sequence, out_stride, mem=MEM_HOST):
+        """pgpu_partial_decrypt_multi: the same ciphertext batch under several shares; outs[k] receives server k's partials."""
+        bs = [_be(s_) for s_ in shares]
+        arr = (C.c_char_p * len(bs))(*bs)
+        lens = (C.c_size_t * len(bs))(*[len(b) for b in bs])
+        op = (C.c_void_p * len(bs))(*[_ptr(o) for o in outs])
+        _check(self.ctx.lib.pgpu_partial_decrypt_multi(self.h, self.TotalNumberOfDecryptionServers, len(bs), arr, lens, batch,
+                                                       _ptr(c), c_stride, op, out_stride, mem))
 
     def partial_decrypt_indexed_raw(self, shares: Sequence[int], share_index: np.ndarray, batch, c, c_stride, out, out_stride,
                                     mem=MEM_HOST):

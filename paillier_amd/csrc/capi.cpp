@@ -2639,6 +2639,90 @@ int pgpu_partial_decrypt(const pgpu_pubkey* pk, int total_servers, const uint8_t
   });
 }
 
+int pgpu_partial_decrypt_multi(const pgpu_pubkey* pk, int total_servers, int n_shares, const uint8_t* const* shares_be,
+                               const size_t* share_lens, size_t batch, const uint8_t* c, size_t c_stride, uint8_t* const* outs,
+                               size_t out_stride, int mem) {
+  if (!pk || !shares_be || !share_lens || !outs) return fail(PGPU_ERR_INVALID, "null argument");
+  pgpu_ctx* ctx = pk->ctx;
+  return guarded([&] {
+    if (n_shares < 1 || n_shares > 256 || total_servers < 1) api_throw(PGPU_ERR_INVALID, "bad share count");
+    check_batch_args(c, outs[0], batch);
+    ctx->bind();
+    ctx->reset_ws();
+    const ModCtx& mc = pk->mn2;
+    const size_t nb = round_up(batch, VM_BLOCK);
+    const BigU two_delta = BigU(2) * factorial_big(total_servers);
+    std::vector<BigU> es;
+    for (int k = 0; k < n_shares; ++k) {
+      if (!shares_be[k] || !outs[k]) api_throw(PGPU_ERR_INVALID, "null share / output buffer");
+      es.push_back(BigU::from_be(shares_be[k], share_lens[k]) * two_delta);       // thresholdkey.go:195
+    }
+    const PairInfo& pi = mc.pairn;
+    const bool pair_ok = pi.root && ctx->use_asm && ctx->use_pair;
+    bool all_long = true;
+    for (auto& e : es) all_long = all_long && e.bit_length() >= 256;
+    if (!pair_ok || !all_long) {                                   // no pair kernel for this key: server after server
+      for (int k = 0; k < n_shares; ++k) {
+        ModexpPlan pl = modexp_alloc(ctx, mc, nb, 32);
+        unpack_mod(ctx, mc, c, c_stride, batch, mem, pl.in(), nb);
+        modexp_shared_run(ctx, mc, pl, es[k], false, false, true);
+        pack_result(ctx, pl.out(), mc.WT, nb, batch, outs[k], out_stride, mc.nbytes, mem);
+      }
+      HIPCHK(hipStreamSynchronize(ctx->stream));
+      return;
+    }
+    // Every server raises the SAME ciphertexts to its own exponent: the entry into the pair form is done once, and the
+    // ladders of two servers share a launch (two program segments) -- 2 x 16 384 numbers fill the chip with the two-lane
+    // kernel, where one server's 16 384 alone need the less efficient four-lane slicing.
+    const ModCtx& mn = *pi.root;
+    const int H = mn.WT, W2 = mc.WT;
+    const size_t S1 = (size_t)H * nb, SW = (size_t)W2 * nb;
+    uint32_t* ent = ctx->ws_t<uint32_t>(SW * 4);          // generic slots: 0 x, 1 -, 2 digits (X0 | X1), 3 X
+    unpack_mod(ctx, mc, c, c_stride, batch, mem, ent, nb);
+    {
+      Prog a;
+      a.op(VM_LOAD, 0); a.op(VM_MULC, C_R2); a.op(VM_MULC, (uint32_t)pi.c_rh); a.op(VM_STORE, 3); a.end();
+      SegSpec sa{&mc, &a, ent, nullptr};
+      run_vm(ctx, nb, sa, nullptr, false);
+      launch_canon(ent + 3 * SW, mc.d_nmod, W2, nb, ctx->stream);
+      uint32_t* x0 = ctx->ws_t<uint32_t>(S1);
+      uint32_t* tb = ctx->ws_t<uint32_t>(SW);
+      reduce_mod(ctx, mn, ent + 3 * SW, W2, x0, nb);
+      launch_div_exact(ent + 3 * SW, W2, 0, x0, H, tb, pi.dinv, mn.d_nmod, H, ent + 2 * SW + S1, H, nb, nb, nullptr, 0, ctx->stream);
+      HIPCHK(hipMemcpyAsync(ent + 2 * SW, x0, S1 * 4, hipMemcpyDeviceToDevice, ctx->stream));
+    }
+    const size_t lanes_target = ctx->lanes_wanted ? ctx->lanes_wanted : (size_t)1024 * 64;
+    for (int k = 0; k < n_shares; k += 2) {
+      const int segs = (k + 1 < n_shares) ? 2 : 1;
+      const int lanes = ((size_t)segs * nb * 2 >= lanes_target || !(H % 2 == 0 && vm_asm_available(H / 2, 64))) ? 2 : 4;
+      uint32_t* pm[2];
+      Prog pr[2];
+      SegSpec sg[2];
+      for (int j = 0; j < segs; ++j) {
+        pm[j] = ctx->ws_t<uint32_t>(SW * (size_t)(5 + 32));        // pair slots: 2 in, 3 out, 5.. table
+        HIPCHK(hipMemcpyAsync(pm[j] + 2 * SW, ent + 2 * SW, SW * 4, hipMemcpyDeviceToDevice, ctx->stream));
+        emit_modexp_shared(pr[j], es[k + j], 2, NO_SLOT, 2, 3, 5, NO_SLOT, true, true);
+        pr[j].end();
+        sg[j] = SegSpec{&mc, &pr[j], pm[j], nullptr};
+        sg[j].pair = pi.consts; sg[j].pair_n0inv = mn.n0inv; sg[j].pair_h = H; sg[j].pair_lanes = lanes;
+      }
+      run_vm(ctx, nb, sg[0], segs == 2 ? &sg[1] : nullptr, true);
+      for (int j = 0; j < segs; ++j) {
+        // F~ = F0 + F1 n, out of pair and Montgomery form
+        launch_mul_const_add(pm[j] + 3 * SW + S1, H, pi.n_limbs, H, pm[j] + 3 * SW, H, 0, pm[j] + 2 * SW, W2, nb, ctx->stream);
+        Prog a;
+        a.op(VM_LOAD, 2); a.op(VM_MULC, (uint32_t)pi.c_rh); a.op(VM_STORE, 3); a.end();
+        SegSpec sa{&mc, &a, pm[j], nullptr};
+        run_vm(ctx, nb, sa, nullptr, false);
+        launch_canon(pm[j] + 3 * SW, mc.d_nmod, W2, nb, ctx->stream);
+        pack_result(ctx, pm[j] + 3 * SW, W2, nb, batch, outs[k + j], out_stride, mc.nbytes, mem);
+      }
+    }
+    for (auto& e : es) wipe_vec(e.d);
+    HIPCHK(hipStreamSynchronize(ctx->stream));
+  });
+}
+
 int pgpu_partial_decrypt_indexed(const pgpu_pubkey* pk, int total_servers, int n_shares, const uint8_t* const* shares_be,
                                  const size_t* share_lens, size_t batch, const uint8_t* c, size_t c_stride,
                                  const int32_t* share_index, uint8_t* out, size_t out_stride, int mem) {

@@ -65,7 +65,7 @@ def all_gather_bytes(local, world: int):
 
 
 def threshold_decrypt_sharded(c, n_servers: int, rank: int, world: int, partial_fn, combine_fn, pad_rows: bool = True,
-                              units_fn=None):
+                              units_fn=None, servers_fn=None):
     """Threshold decryption of B ciphertexts with the work sharded over `world` ranks and ONE exchange step
     (thresholdkey.go:149-201: every server's PartialDecrypt, then CombinePartialDecryptions).
 
@@ -81,6 +81,8 @@ def threshold_decrypt_sharded(c, n_servers: int, rank: int, world: int, partial_
       units_fn     optional: (server_index int32 numpy [units], c_rows [units, cipher_bytes]) -> uint8 tensor [units,
                    cipher_bytes]: this rank's units in ONE call (pgpu_partial_decrypt_indexed) instead of one partial_fn
                    call per server -- a shard of a few thousand units fills the GPU only when its servers share a launch
+      servers_fn   optional, used when ONE rank holds every share (world == 1): (c) -> [rows of server 0, rows of server 1, ...]
+                   for the whole batch in one call (pgpu_partial_decrypt_multi: two servers' ladders per launch)
     Returns (plaintext rows of this rank's ciphertext slice, (begin, end) of that slice).
     """
     import torch
@@ -89,7 +91,10 @@ def threshold_decrypt_sharded(c, n_servers: int, rank: int, world: int, partial_
     ub, ue = shard_slice(units, rank, world)
     per = -(-units // world) if pad_rows else (ue - ub)      # all-gather needs equal shapes
     local = torch.zeros((max(per, 1), cbytes), dtype=torch.uint8, device=c.device)
-    if units_fn is not None and ue > ub:
+    if servers_fn is not None and world == 1:
+        for s_, rows in enumerate(servers_fn(c)):
+            local[s_ * B:(s_ + 1) * B] = rows
+    elif units_fn is not None and ue > ub:
         import numpy as np
         us = np.arange(ub, ue, dtype=np.int64)
         rows = c[torch.from_numpy(us % B).to(c.device)]

@@ -115,3 +115,35 @@ def test_partial_decrypt_indexed_units(ctx, bits):
         out = np.zeros((len(cs) * 5, cb), dtype=np.uint8)
         tk.partial_decrypt_indexed_raw(shares, np.repeat(np.arange(5, dtype=np.int32), len(cs)), len(cs) * 5, rows, cb, out, cb)
         assert be_to_ints(out) == [int(x, 16) for row in th["partials"] for x in row]
+
+
+@pytest.mark.parametrize("bits", ["512", "2048"])
+def test_partial_decrypt_multi_servers(ctx, bits):
+    """pgpu_partial_decrypt_multi: one ciphertext batch under all five shares (pairs of servers share a launch, the odd one
+    runs alone) must equal the per-server PartialDecrypt / the committed partials; also with the pair kernels switched off."""
+    import numpy as np
+    import paillier_amd as pa
+    from paillier_amd.api import be_to_ints, ints_to_be
+    k = json.load(open(os.path.join(G, "keys.json")))["threshold"][bits]
+    n, total, thr = int(k["n"], 16), k["total"], k["threshold"]
+    shares = [int(s, 16) for s in k["shares"]]
+    tk = pa.ThresholdPublicKey(ctx, n, total=total, threshold=thr)
+    cb = tk.cipher_bytes()
+    if bits == "2048":
+        th = json.load(open(os.path.join(G, "proofs.json")))["threshold"]
+        cts = [int(x, 16) for x in th["c"]]
+        want = [[int(x, 16) for x in row] for row in th["partials"]]
+    else:
+        rng = random.Random(12)
+        pkk = po.PublicKey(N=n, G=n + 1)
+        cts = [po.encrypt_with_r(pkk, rng.randrange(n), po.rand_unit(n, rng)).C for _ in range(9)]
+        want = [tk.PartialDecryptBatch(i + 1, shares[i], cts)[1] for i in range(total)]
+    rows = ints_to_be(cts, cb)
+    for flag in (1, 0):
+        ctx.set_flag("pair", flag)
+        try:
+            outs = [np.zeros((len(cts), cb), dtype=np.uint8) for _ in shares]
+            tk.partial_decrypt_multi_raw(shares, len(cts), rows, cb, outs, cb)
+            assert [be_to_ints(o) for o in outs] == want
+        finally:
+            ctx.set_flag("pair", 1)
