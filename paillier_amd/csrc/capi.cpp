@@ -459,15 +459,17 @@ struct SegSpec {
   const uint32_t* tconsts = nullptr;
 };
 
-// launch one VM kernel with 1 or 2 segments of `nb` numbers each (same modulus shape)
-void run_vm(pgpu_ctx* ctx, size_t nb, const SegSpec& s0, const SegSpec* s1, bool profile, size_t launch_nb = 0) {
+// launch one VM kernel with 1 to 3 segments of `nb` numbers each (same modulus shape; s2 only together with s1)
+void run_vm(pgpu_ctx* ctx, size_t nb, const SegSpec& s0, const SegSpec* s1, bool profile, size_t launch_nb = 0,
+            const SegSpec* s2 = nullptr) {
   const ModCtx* mc = s0.mc;
   if (s1 && (s1->mc->WL != mc->WL || s1->mc->K != mc->K)) api_throw(PGPU_ERR_INVALID, "segment shape mismatch");
+  if (s2 && (!s1 || s2->mc->WL != mc->WL || s2->mc->K != mc->K)) api_throw(PGPU_ERR_INVALID, "segment shape mismatch");
   VmArgs a;
   memset(&a, 0, sizeof a);
-  const SegSpec* ss[2] = {&s0, s1};
+  const SegSpec* ss[3] = {&s0, s1, s2};
   double montmuls = 0, sqrs = 0;
-  for (int i = 0; i < 2; ++i) {
+  for (int i = 0; i < 3; ++i) {
     if (!ss[i]) continue;
     VmSeg& g = a.seg[i];
     g.prog = ctx->upload_words(ss[i]->prog->w);
@@ -490,13 +492,14 @@ void run_vm(pgpu_ctx* ctx, size_t nb, const SegSpec& s0, const SegSpec* s1, bool
   int WL = mc->WL, K = mc->K;
   const bool pair = s0.pair != nullptr;
   if (s1 && pair != (s1->pair != nullptr)) api_throw(PGPU_ERR_INVALID, "segment kind mismatch");
+  if (s2 && pair != (s2->pair != nullptr)) api_throw(PGPU_ERR_INVALID, "segment kind mismatch");
   if (pair) {
     WL = s0.pair_lanes == 4 ? s0.pair_h / 2 : s0.pair_h;
     K = s0.pair_lanes == 4 ? 64 : s0.pair_lanes == 3 ? 48 : s0.pair_lanes == 2 ? 32 : 16;   // tags of the pair kernels, not lane counts
   } else {
     static const size_t lanes_env = [] { const char* e = getenv("PGPU_LANES_WANTED"); return e ? (size_t)atoll(e) : (size_t)0; }();
     const size_t lanes_wanted = ctx->lanes_wanted ? ctx->lanes_wanted : lanes_env ? lanes_env : (size_t)1024 * 64;
-    const size_t segs = s1 ? 2 : 1;
+    const size_t segs = s2 ? 3 : s1 ? 2 : 1;
     while (launch_nb * K * segs < lanes_wanted && K < 4 && WL % 2 == 0 && WL / 2 >= 37) { WL /= 2; K *= 2; }
     // PGPU_W74=0 (experiments): the 4-lane slicing instead of the wave-sliced 148-limb kernel
     static const bool w74 = [] { const char* e = getenv("PGPU_W74"); return e ? atoi(e) != 0 : true; }();
@@ -504,9 +507,11 @@ void run_vm(pgpu_ctx* ctx, size_t nb, const SegSpec& s0, const SegSpec* s1, bool
   }
   const uint32_t blocks_per_seg = (uint32_t)(launch_nb * (pair ? (s0.pair_lanes == 3 ? 4 : s0.pair_lanes) : K) / VM_BLOCK);
   a.seg0_blocks = blocks_per_seg;
-  const uint32_t blocks = blocks_per_seg * (s1 ? 2 : 1);
+  a.seg1_blocks = blocks_per_seg;
+  const uint32_t blocks = blocks_per_seg * (s2 ? 3 : s1 ? 2 : 1);
   const bool use_asm = ctx->use_asm && vm_asm_available(WL, K) && s0.prog->asm_ok && (!s1 || s1->prog->asm_ok) &&
-                       (uint64_t)nb * mc->WT * 4 * ((s0.prog->has_mulv || (s1 && s1->prog->has_mulv)) ? 17 : 1) < (1ull << 32);
+                       (!s2 || s2->prog->asm_ok) &&
+                       (uint64_t)nb * mc->WT * 4 * ((s0.prog->has_mulv || (s1 && s1->prog->has_mulv) || (s2 && s2->prog->has_mulv)) ? 17 : 1) < (1ull << 32);
   pgpu_ctx::Ev* ev = nullptr;
   if (profile) {
     ev = &ctx->next_ev();
@@ -2692,12 +2697,16 @@ int pgpu_partial_decrypt_multi(const pgpu_pubkey* pk, int total_servers, int n_s
       HIPCHK(hipMemcpyAsync(ent + 2 * SW, x0, S1 * 4, hipMemcpyDeviceToDevice, ctx->stream));
     }
     const size_t lanes_target = ctx->lanes_wanted ? ctx->lanes_wanted : (size_t)1024 * 64;
-    for (int k = 0; k < n_shares; k += 2) {
-      const int segs = (k + 1 < n_shares) ? 2 : 1;
+    for (int k = 0; k < n_shares;) {
+      // two servers per launch: 2 x 16 384 numbers x 2 lanes are exactly one wave per SIMD.  (Three segments -- the kernels
+      // take up to three -- would be 1.5 waves per SIMD: the SIMDs that got two waves take as long as a full second wave,
+      // measured 236 ms against 122 + 76 ms for a pair plus a single.)
+      const int left = n_shares - k;
+      const int segs = std::min(left, 2);
       const int lanes = ((size_t)segs * nb * 2 >= lanes_target || !(H % 2 == 0 && vm_asm_available(H / 2, 64))) ? 2 : 4;
-      uint32_t* pm[2];
-      Prog pr[2];
-      SegSpec sg[2];
+      uint32_t* pm[3];
+      Prog pr[3];
+      SegSpec sg[3];
       for (int j = 0; j < segs; ++j) {
         pm[j] = ctx->ws_t<uint32_t>(SW * (size_t)(5 + 32));        // pair slots: 2 in, 3 out, 5.. table
         HIPCHK(hipMemcpyAsync(pm[j] + 2 * SW, ent + 2 * SW, SW * 4, hipMemcpyDeviceToDevice, ctx->stream));
@@ -2706,7 +2715,7 @@ int pgpu_partial_decrypt_multi(const pgpu_pubkey* pk, int total_servers, int n_s
         sg[j] = SegSpec{&mc, &pr[j], pm[j], nullptr};
         sg[j].pair = pi.consts; sg[j].pair_n0inv = mn.n0inv; sg[j].pair_h = H; sg[j].pair_lanes = lanes;
       }
-      run_vm(ctx, nb, sg[0], segs == 2 ? &sg[1] : nullptr, true);
+      run_vm(ctx, nb, sg[0], segs >= 2 ? &sg[1] : nullptr, true, 0, segs == 3 ? &sg[2] : nullptr);
       for (int j = 0; j < segs; ++j) {
         // F~ = F0 + F1 n, out of pair and Montgomery form
         launch_mul_const_add(pm[j] + 3 * SW + S1, H, pi.n_limbs, H, pm[j] + 3 * SW, H, 0, pm[j] + 2 * SW, W2, nb, ctx->stream);
@@ -2717,6 +2726,7 @@ int pgpu_partial_decrypt_multi(const pgpu_pubkey* pk, int total_servers, int n_s
         launch_canon(pm[j] + 3 * SW, mc.d_nmod, W2, nb, ctx->stream);
         pack_result(ctx, pm[j] + 3 * SW, W2, nb, batch, outs[k + j], out_stride, mc.nbytes, mem);
       }
+      k += segs;
     }
     for (auto& e : es) wipe_vec(e.d);
     HIPCHK(hipStreamSynchronize(ctx->stream));

@@ -128,6 +128,24 @@ class Gen:
     def mad(self, dst, a, b, c):
         self.e(f"v_mad_u64_u32 {dst}, vcc, {a}, {b}, {c}")
 
+    def select_segment(self):
+        """Up to three program segments per launch (VmArgs: seg[3], then seg0_blocks, seg1_blocks): blocks [0, b0) run segment
+        0, [b0, b0 + b1) segment 1, the rest segment 2.  Leaves s[0:1] at this block's VmSeg and s2 = block index inside it."""
+        e = self.e
+        e(f"s_load_dwordx2 s[4:5], s[0:1], {hex(3 * 48)}")     # seg0_blocks, seg1_blocks
+        e("s_waitcnt lgkmcnt(0)")
+        e("s_cmp_ge_u32 s2, s4")
+        e("s_cbranch_scc0 L_seg0")
+        e("s_sub_u32 s2, s2, s4")                               # block index inside segment 1 (or beyond)
+        e("s_add_u32 s0, s0, 48")
+        e("s_addc_u32 s1, s1, 0")
+        e("s_cmp_ge_u32 s2, s5")
+        e("s_cbranch_scc0 L_seg0")
+        e("s_sub_u32 s2, s2, s5")                               # block index inside segment 2
+        e("s_add_u32 s0, s0, 48")
+        e("s_addc_u32 s1, s1, 0")
+        e("L_seg0:")
+
     # ---------------------------------------------------------------------------------------------
     def prologue(self):
         g = self
@@ -139,14 +157,7 @@ class Gen:
         e(f".type {self.name},@function")
         e(f"{self.name}:")
         # s[0:1] kernarg, s2 workgroup id, v0 workitem id
-        e("s_load_dword s3, s[0:1], 0x60")  # seg0_blocks
-        e("s_waitcnt lgkmcnt(0)")
-        e("s_cmp_ge_u32 s2, s3")
-        e("s_cbranch_scc0 L_seg0")
-        e("s_sub_u32 s2, s2, s3")  # block index inside segment 1
-        e("s_add_u32 s0, s0, 48")
-        e("s_addc_u32 s1, s1, 0")
-        e("L_seg0:")
+        self.select_segment()
         e("s_load_dwordx8 s[4:11], s[0:1], 0x0")   # prog, nmod, consts, mem
         e("s_load_dwordx4 s[12:15], s[0:1], 0x20")  # digits, n0inv, nb
         e("s_waitcnt lgkmcnt(0)")
@@ -867,7 +878,7 @@ class Gen:
         e(f".amdhsa_kernel {nm}")
         e(f"  .amdhsa_group_segment_fixed_size {self.lds_bytes}")
         e("  .amdhsa_private_segment_fixed_size 0")
-        e("  .amdhsa_kernarg_size 104")
+        e("  .amdhsa_kernarg_size 152")
         e("  .amdhsa_user_sgpr_kernarg_segment_ptr 1")
         e("  .amdhsa_system_sgpr_workgroup_id_x 1")
         e("  .amdhsa_system_vgpr_workitem_id 0")
@@ -882,7 +893,7 @@ class Gen:
         e("amdhsa.kernels:", raw=True)
         e(f"  - .name: {nm}", raw=True)
         e(f"    .symbol: {nm}.kd", raw=True)
-        e("    .kernarg_segment_size: 104", raw=True)
+        e("    .kernarg_segment_size: 152", raw=True)
         e(f"    .group_segment_fixed_size: {self.lds_bytes}", raw=True)
         e("    .private_segment_fixed_size: 0", raw=True)
         e("    .kernarg_segment_align: 8", raw=True)
@@ -891,7 +902,7 @@ class Gen:
         e(f"    .vgpr_count: {self.n_vgpr}", raw=True)
         e("    .max_flat_workgroup_size: 256", raw=True)
         e("    .args:", raw=True)
-        e("      - .size: 104", raw=True)
+        e("      - .size: 152", raw=True)
         e("        .offset: 0", raw=True)
         e("        .value_kind: by_value", raw=True)
         e("...", raw=True)
@@ -1009,14 +1020,7 @@ class GenW(Gen):
         e(".p2align 8")
         e(f".type {self.name},@function")
         e(f"{self.name}:")
-        e("s_load_dword s3, s[0:1], 0x60")
-        e("s_waitcnt lgkmcnt(0)")
-        e("s_cmp_ge_u32 s2, s3")
-        e("s_cbranch_scc0 L_seg0")
-        e("s_sub_u32 s2, s2, s3")
-        e("s_add_u32 s0, s0, 48")
-        e("s_addc_u32 s1, s1, 0")
-        e("L_seg0:")
+        self.select_segment()
         e("s_load_dwordx8 s[4:11], s[0:1], 0x0")
         e("s_load_dwordx4 s[12:15], s[0:1], 0x20")
         e("s_waitcnt lgkmcnt(0)")
@@ -1714,14 +1718,7 @@ class GenQ(Gen):
         e(".p2align 8")
         e(f".type {self.name},@function")
         e(f"{self.name}:")
-        e("s_load_dword s3, s[0:1], 0x60")
-        e("s_waitcnt lgkmcnt(0)")
-        e("s_cmp_ge_u32 s2, s3")
-        e("s_cbranch_scc0 L_seg0")
-        e("s_sub_u32 s2, s2, s3")
-        e("s_add_u32 s0, s0, 48")
-        e("s_addc_u32 s1, s1, 0")
-        e("L_seg0:")
+        self.select_segment()
         e("s_load_dwordx8 s[4:11], s[0:1], 0x0")
         e("s_load_dwordx4 s[12:15], s[0:1], 0x20")
         e("s_waitcnt lgkmcnt(0)")
@@ -1971,14 +1968,7 @@ class GenQ4(Gen):
         e(".p2align 8")
         e(f".type {self.name},@function")
         e(f"{self.name}:")
-        e("s_load_dword s3, s[0:1], 0x60")
-        e("s_waitcnt lgkmcnt(0)")
-        e("s_cmp_ge_u32 s2, s3")
-        e("s_cbranch_scc0 L_seg0")
-        e("s_sub_u32 s2, s2, s3")
-        e("s_add_u32 s0, s0, 48")
-        e("s_addc_u32 s1, s1, 0")
-        e("L_seg0:")
+        self.select_segment()
         e("s_load_dwordx8 s[4:11], s[0:1], 0x0")
         e("s_load_dwordx4 s[12:15], s[0:1], 0x20")
         e("s_waitcnt lgkmcnt(0)")
@@ -2254,14 +2244,7 @@ class GenQ3(Gen):
         e(".p2align 8")
         e(f".type {self.name},@function")
         e(f"{self.name}:")
-        e("s_load_dword s3, s[0:1], 0x60")
-        e("s_waitcnt lgkmcnt(0)")
-        e("s_cmp_ge_u32 s2, s3")
-        e("s_cbranch_scc0 L_seg0")
-        e("s_sub_u32 s2, s2, s3")
-        e("s_add_u32 s0, s0, 48")
-        e("s_addc_u32 s1, s1, 0")
-        e("L_seg0:")
+        self.select_segment()
         e("s_load_dwordx8 s[4:11], s[0:1], 0x0")
         e("s_load_dwordx4 s[12:15], s[0:1], 0x20")
         e("s_waitcnt lgkmcnt(0)")

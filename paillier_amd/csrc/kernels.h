@@ -32,15 +32,16 @@ struct VmSeg {
 };
 
 struct VmArgs {
-  VmSeg seg[2];
-  uint32_t seg0_blocks;  // blocks [0, seg0_blocks) run seg[0], the rest seg[1]
+  VmSeg seg[3];
+  uint32_t seg0_blocks;  // blocks [0, seg0_blocks) run seg[0],
+  uint32_t seg1_blocks;  // the next seg1_blocks run seg[1], the rest seg[2]
 };
 
 hipError_t launch_vm(int wl, int k, const VmArgs& a, uint32_t blocks, hipStream_t st);
 // hand-scheduled assembly versions (asm_loader.cpp); same arguments, bit-identical results
 bool vm_asm_available(int wl, int k);
 hipError_t launch_vm_asm(int wl, int k, const VmArgs& a, uint32_t blocks, hipStream_t st);
-static_assert(sizeof(VmArgs) == 104, "VmArgs layout is hard-coded in gen_vm_asm.py");
+static_assert(sizeof(VmArgs) == 152, "VmArgs layout is hard-coded in gen_vm_asm.py (select_segment)");
 
 void launch_unpack_be(const uint8_t* in, size_t stride, size_t nbytes, size_t count, uint32_t* out, int wt, size_t nb, hipStream_t st);
 void launch_pack_be(const uint32_t* in, int wt, size_t nb, size_t count, uint8_t* out, size_t stride, size_t nbytes, hipStream_t st);

@@ -31,9 +31,9 @@ __global__ void __launch_bounds__(VM_BLOCK, (3 * WL + 24 <= 256) ? 2 : 1) vm_ker
   uint32_t* s_n = lds;                    // WT modulus limbs
   uint32_t* s_a = lds + ((WT + 3) & ~3);  // a-operand columns: [WT][NPB]
 
-  const int segi = blockIdx.x >= args.seg0_blocks ? 1 : 0;
+  const int segi = blockIdx.x < args.seg0_blocks ? 0 : (blockIdx.x - args.seg0_blocks < args.seg1_blocks ? 1 : 2);
   const VmSeg sg = args.seg[segi];
-  const uint32_t blk = blockIdx.x - (segi ? args.seg0_blocks : 0u);
+  const uint32_t blk = blockIdx.x - (segi >= 1 ? args.seg0_blocks : 0u) - (segi == 2 ? args.seg1_blocks : 0u);
   const int tid = threadIdx.x;
   const int k = tid % K;
   const int gl = tid / K;
