@@ -281,6 +281,24 @@ func (s *GPUSecretKey) ProveDDLEQBatch(ct1, ct2 []*Ciphertext, a, b, x, y []*gmp
 	return out, nil
 }
 
+// NestedRandomizeWithABBatch: PublicKey.NestedRandomize (operations.go:96-118) with the draws a[i], b[i] supplied (draw them
+// with GetRandomNumberInMultiplicativeGroup, as the reference does, to keep its distribution).
+func (k *GPUPublicKey) NestedRandomizeWithABBatch(ct []*Ciphertext, a, b []*gmp.Int) ([]*Ciphertext, error) {
+	c3, p1 := k.cipherBytes(EncLevelTwo), k.plainBytes(EncLevelOne)
+	for _, c := range ct {
+		if c.Level != EncLevelTwo {
+			panic("can only homomorphically randomize doubly encrypted values") // operations.go:98
+		}
+	}
+	cb, ab, bb, out := pack(cvals(ct), c3), pack(a, p1), pack(b, p1), make([]byte, len(ct)*c3)
+	rc := C.pgpu_nested_randomize_with_ab(k.h, C.size_t(len(ct)), p8(cb), C.size_t(c3), p8(ab), p8(bb), C.size_t(p1), p8(out),
+		C.size_t(c3), C.PGPU_MEM_HOST)
+	if err := status(rc); err != nil {
+		return nil, err
+	}
+	return cts(unpack(out, c3), EncLevelTwo, RegularEncryption), nil
+}
+
 // VerifyDDLEQBatch: PublicKey.verifyDDLEQProofInstance (ddleq.go:129-153) for every (statement, instance) pair;
 // VerifyDDLEQProof (ddleq.go:44-53) is the conjunction over one statement's instances.
 func (k *GPUPublicKey) VerifyDDLEQBatch(ct1, ct2 []*Ciphertext, proofs []*DDLEQProofInstance) ([]bool, error) {

@@ -221,6 +221,11 @@ int pgpu_share_zkp_verify(const pgpu_pubkey* pk, const uint8_t* vkey_be, size_t 
 int pgpu_random_oracle_digest(pgpu_ctx* ctx, int nparts, const uint8_t* const* parts, const size_t* strides, size_t batch,
                               uint8_t* digests, int mem);
 
+/* PublicKey.NestedRandomize (operations.go:96-118) with the two random draws a, b in Z_n^* supplied:
+ *   out[i] = ct[i]^(a[i]^n mod n^2) * b[i]^(n^2) mod n^3      (ct: level-two ciphertexts; one interleaved ladder per ciphertext) */
+int pgpu_nested_randomize_with_ab(const pgpu_pubkey* pk, size_t batch, const uint8_t* ct, size_t ct_stride, const uint8_t* a,
+                                  const uint8_t* b, size_t ab_stride, uint8_t* out, size_t out_stride, int mem);
+
 /* PublicKey.verifyDDLEQProofInstance for a batch of (statement, instance) pairs (ddleq.go:129-153), entirely on the
  * device: Fiat-Shamir bit = LSB(SHA-256(ct2||X||Y||Alpha)), check = bit ? ct2 : ct1,
  * ok[i] = (check^(E^n mod n^2) * F^(n^2) mod n^3 == Alpha).  ct/alpha strides = byte length of n^3.  ok: host int32[batch]. */

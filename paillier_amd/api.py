@@ -73,6 +73,7 @@ SIGNATURES = {
     "pgpu_partial_decrypt_indexed": (_int, [_vp, _int, _int, _vp, _vp, _sz, _vp, _sz, _vp, _vp, _sz, _int]),
     "pgpu_combine_partial_decryptions": (_int, [_vp, _int, _int, _int, _vp, _sz, _vp, _sz, _vp, _sz, _int, _vp]),
     "pgpu_random_oracle_digest": (_int, [_vp, _int, _vp, _vp, _sz, _vp, _int]),
+    "pgpu_nested_randomize_with_ab": (_int, [_vp, _sz, _vp, _sz, _vp, _vp, _sz, _vp, _sz, _int]),
     "pgpu_ddleq_verify": (_int, [_vp, _sz, _vp, _vp, _sz, _vp, _vp, _sz, _vp, _sz, _vp, _sz, _vp, _sz, _vp, _int]),
     "pgpu_share_zkp_prove": (_int, [_vp, _int, _vp, _sz, _vp, _sz, _sz, _vp, _sz, _vp, _sz, _vp, _sz, _vp, _vp, _sz, _int]),
     "pgpu_share_zkp_verify": (_int, [_vp, _vp, _sz, _vp, _sz, _sz, _vp, _sz, _vp, _sz, _vp, _vp, _sz, _vp, _int]),
@@ -401,6 +402,24 @@ class PublicKey:
         cb3, pb1, pb2 = self.cipher_bytes(ENC_LEVEL_TWO), self.plain_bytes(ENC_LEVEL_ONE), self.plain_bytes(ENC_LEVEL_TWO)
         _check(self.ctx.lib.pgpu_ddleq_verify(self.h, batch, _ptr(ct1), _ptr(ct2), cb3, _ptr(x), _ptr(y), pb1, _ptr(alpha), cb3,
                                               _ptr(e), pb2, _ptr(f), cb3, _ptr(ok), mem))
+
+    def nested_randomize_with_ab_raw(self, batch, ct, a, b, out, mem=MEM_HOST):
+        """pgpu_nested_randomize_with_ab with the natural strides (ct / out: bytes of n^3; a, b: bytes of n)."""
+        cb3, pb1 = self.cipher_bytes(ENC_LEVEL_TWO), self.plain_bytes(ENC_LEVEL_ONE)
+        _check(self.ctx.lib.pgpu_nested_randomize_with_ab(self.h, batch, _ptr(ct), cb3, _ptr(a), _ptr(b), pb1, _ptr(out), cb3, mem))
+
+    def NestedRandomizeWithABBatch(self, cts: Sequence[int], a_s: Sequence[int], b_s: Sequence[int]) -> List[int]:
+        """operations.go:96-118 for each ciphertext with the draws (a, b) supplied, on the device."""
+        cb3, pb1 = self.cipher_bytes(ENC_LEVEL_TWO), self.plain_bytes(ENC_LEVEL_ONE)
+        bufs = [ints_to_be(cts, cb3), ints_to_be(a_s, pb1), ints_to_be(b_s, pb1)]
+        out = np.zeros((len(cts), cb3), dtype=np.uint8)
+        self.nested_randomize_with_ab_raw(len(cts), bufs[0], bufs[1], bufs[2], out)
+        return be_to_ints(out)
+
+    def NestedRandomizeBatch(self, cts: Sequence[int]):
+        """operations.go:96-118 NestedRandomize: draws a, b in Z_n^* (library CSPRNG) and returns (ciphertexts, a, b)."""
+        a_s, b_s = self.random_units(len(cts)), self.random_units(len(cts))
+        return self.NestedRandomizeWithABBatch(cts, a_s, b_s), a_s, b_s
 
     def NestedAddBatch(self, ct1s: Sequence[int], ct2s: Sequence[int]) -> List[int]:
         """operations.go:121-127: level-two ciphertext ^ (level-one ciphertext value)."""

@@ -2916,6 +2916,70 @@ int pgpu_random_oracle_digest(pgpu_ctx* ctx, int nparts, const uint8_t* const* p
   });
 }
 
+}  // extern "C"
+
+namespace {
+// x^(per-number exponent, W2 limbs) * y^(n^2) mod n^3 as ONE interleaved ladder (emit_modexp_dual): the verifier's
+// check^(E^n) * F^(n^2) (ddleq.go:143-152) and NestedRandomize's ct^(a^n) * b^(n^2) (operations.go:108-114).
+// x, y: W3-limb arrays (any value below R); returns the canonical result (W3 limbs, stride nb).
+uint32_t* dual_pow_n3(pgpu_ctx* ctx, const pgpu_pubkey* pk, const uint32_t* x, const uint32_t* exps, const uint32_t* y, size_t nb) {
+  const ModCtx &mn2 = pk->mn2, &mn3 = *pk->mn3;
+  const int W2 = mn2.WT, W3 = mn3.WT;
+  const bool use3 = triple_usable(ctx, mn3) && (uint64_t)nb * (W3 + 4) * 4 * 33 < (1ull << 32);
+  ModexpPlan pc = modexp_alloc(ctx, mn3, nb, use3 ? 0 : 48);   // slots: 0 x, 1 y, 2 tmp, 3 out, 5..20 / 21..52 the two tables
+  HIPCHK(hipMemcpyAsync(pc.in(), x, pc.slot_words * 4, hipMemcpyDeviceToDevice, ctx->stream));
+  HIPCHK(hipMemcpyAsync(pc.in() + pc.slot_words, y, pc.slot_words * 4, hipMemcpyDeviceToDevice, ctx->stream));
+  if (use3) {
+    // the interleaved ladder on the three-digit kernel: residues modulo n^3 as a0 + a1 n + a2 n^2
+    TriplePlan tp = triple_alloc(ctx, mn3, nb, 5 + 64);        // slots: 0 x, 1 y, 2 tmp, 3 out, 5..36 / 37..68 the tables
+    triple_enter(ctx, mn3, pc.in(), tp, 0);
+    triple_enter(ctx, mn3, pc.in() + pc.slot_words, tp, 1);
+    Prog pd;
+    emit_modexp_dual(pd, W2, mn2.N, 0, 1, 2, 3, 5, 37, 0, true);       // 5-bit windows of the per-number exponent
+    pd.end();
+    triple_run(ctx, mn3, tp, pd, windows5_of(ctx, exps, W2, nb));
+    triple_exit(ctx, mn3, tp, 3, pc.out(), nullptr);
+  } else {
+    Prog pd;
+    emit_modexp_dual(pd, W2, mn2.N, 0, 1, 2, 3, 5, 21);
+    pd.end();
+    SegSpec sd{&mn3, &pd, pc.mem, exps};
+    run_vm(ctx, nb, sd, nullptr, true);
+    launch_canon(pc.out(), mn3.d_nmod, W3, nb, ctx->stream);
+  }
+  return pc.out();
+}
+}  // namespace
+
+extern "C" {
+
+int pgpu_nested_randomize_with_ab(const pgpu_pubkey* pk, size_t batch, const uint8_t* ct, size_t ct_stride, const uint8_t* a,
+                                  const uint8_t* b, size_t ab_stride, uint8_t* out, size_t out_stride, int mem) {
+  if (!pk || !ct || !a || !b || !out) return fail(PGPU_ERR_INVALID, "null argument");
+  pgpu_ctx* ctx = pk->ctx;
+  return guarded([&] {
+    if (batch == 0) api_throw(PGPU_ERR_INVALID, "empty batch");
+    if (!pk->mn3) api_throw(PGPU_ERR_UNSUPPORTED, "n^3 is wider than the built kernels");
+    ctx->bind();
+    ctx->reset_ws();
+    const ModCtx &mn2 = pk->mn2, &mn3 = *pk->mn3;
+    const int W2 = mn2.WT, W3 = mn3.WT;
+    const size_t nb = round_up(batch, VM_BLOCK);
+    // an = a^n mod n^2 (operations.go:108); r = ct^an * b^(n^2) mod n^3 (:109-114)
+    ModexpPlan pa_ = modexp_alloc(ctx, mn2, nb, 32);
+    unpack_mod(ctx, mn2, a, ab_stride, batch, mem, pa_.in(), nb);
+    modexp_shared_run(ctx, mn2, pa_, pk->N, false, false, true);
+    uint32_t* x = ctx->ws_t<uint32_t>((size_t)W3 * nb);
+    uint32_t* y = ctx->ws_t<uint32_t>((size_t)W3 * nb);
+    unpack_mod(ctx, mn3, ct, ct_stride, batch, mem, x, nb);
+    unpack_mod(ctx, mn3, b, ab_stride, batch, mem, y, nb);
+    uint32_t* res = dual_pow_n3(ctx, pk, x, pa_.out(), y, nb);
+    pack_result(ctx, res, W3, nb, batch, out, out_stride, mn3.nbytes, mem);
+    HIPCHK(hipStreamSynchronize(ctx->stream));
+    (void)W2;
+  });
+}
+
 int pgpu_ddleq_verify(const pgpu_pubkey* pk, size_t batch, const uint8_t* ct1, const uint8_t* ct2, size_t ct_stride,
                       const uint8_t* x, const uint8_t* y, size_t xy_stride, const uint8_t* alpha, size_t alpha_stride,
                       const uint8_t* e, size_t e_stride, const uint8_t* f, size_t f_stride, int32_t* ok, int mem) {
@@ -2959,31 +3023,14 @@ int pgpu_ddleq_verify(const pgpu_pubkey* pk, size_t batch, const uint8_t* ct1, c
     // check = chalBit ? ct2 : ct1 ; check^en * F^(n^2) mod n^3 == alpha           (ddleq.go:138-152)
     // one interleaved ladder: the squarings of check^en and of F^(n^2) are shared (emit_modexp_dual)
     if (f_stride * 8 > (size_t)LB * W3 + 7) api_throw(PGPU_ERR_INVALID, "F wider than n^3");
-    const bool use3 = triple_usable(ctx, mn3) && (uint64_t)nb * (W3 + 4) * 4 * 33 < (1ull << 32);
-    ModexpPlan pc = modexp_alloc(ctx, mn3, nb, use3 ? 0 : 48);   // slots: 0 check, 1 F, 2 tmp, 3 out, 5..20 / 21..52 the two tables
-    launch_select(chal, c2, c1, pc.in(), W3, nb, ctx->stream);
-    unpack_operand(ctx, f, f_stride, f_stride, batch, mem, pc.in() + pc.slot_words, W3, nb);
-    if (use3) {
-      // the same interleaved ladder on the three-digit kernel: residues modulo n^3 as a0 + a1 n + a2 n^2
-      TriplePlan tp = triple_alloc(ctx, mn3, nb, 5 + 64);      // slots: 0 check, 1 F, 2 tmp, 3 out, 5..36 / 37..68 the tables
-      triple_enter(ctx, mn3, pc.in(), tp, 0);
-      triple_enter(ctx, mn3, pc.in() + pc.slot_words, tp, 1);
-      Prog pd;
-      emit_modexp_dual(pd, W2, mn2.N, 0, 1, 2, 3, 5, 37, 0, true);     // 5-bit windows of E^n
-      pd.end();
-      triple_run(ctx, mn3, tp, pd, windows5_of(ctx, pe.out(), W2, nb));
-      triple_exit(ctx, mn3, tp, 3, pc.out(), nullptr);
-    } else {
-      Prog pd;
-      emit_modexp_dual(pd, W2, mn2.N, 0, 1, 2, 3, 5, 21);
-      pd.end();
-      SegSpec sd{&mn3, &pd, pc.mem, pe.out()};
-      run_vm(ctx, nb, sd, nullptr, true);
-      launch_canon(pc.out(), mn3.d_nmod, W3, nb, ctx->stream);
-    }
+    uint32_t* chk = ctx->ws_t<uint32_t>((size_t)W3 * nb);
+    uint32_t* fl = ctx->ws_t<uint32_t>((size_t)W3 * nb);
+    launch_select(chal, c2, c1, chk, W3, nb, ctx->stream);
+    unpack_operand(ctx, f, f_stride, f_stride, batch, mem, fl, W3, nb);
+    uint32_t* got = dual_pow_n3(ctx, pk, chk, pe.out(), fl, nb);
     int32_t* d_ok = ctx->ws_t<int32_t>(nb);
     if (wa != W3) api_throw(PGPU_ERR_INVALID, "alpha stride must be the byte length of n^3");
-    launch_equal(pc.out(), al, W3, nb, batch, d_ok, ctx->stream);
+    launch_equal(got, al, W3, nb, batch, d_ok, ctx->stream);
     HIPCHK(hipMemcpyAsync(ok, d_ok, batch * 4, hipMemcpyDeviceToHost, ctx->stream));
     HIPCHK(hipStreamSynchronize(ctx->stream));
   });

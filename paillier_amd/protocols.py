@@ -79,12 +79,9 @@ def extract_randomness_batch(sk: SecretKey, cts: Sequence[int], level: int = ENC
 
 
 def nested_randomize_with_ab_batch(pk: PublicKey, cts: Sequence[int], a_s: Sequence[int], b_s: Sequence[int]) -> List[int]:
-    """operations.go:96-118 with the draws (a, b) supplied: ct^(a^n mod n^2) * b^(n^2) mod n^3."""
-    mods = _mods(pk)
-    an = mods.m2.exp_batch(list(a_s), mods.n)
-    bn2 = mods.m3.exp_batch(list(b_s), mods.n2)
-    r = mods.m3.exp_batch(list(cts), an)
-    return mods.m3.mul_batch(r, bn2)
+    """operations.go:96-118 with the draws (a, b) supplied: ct^(a^n mod n^2) * b^(n^2) mod n^3 (one interleaved ladder per
+    ciphertext on the device: pgpu_nested_randomize_with_ab)."""
+    return pk.NestedRandomizeWithABBatch(list(cts), list(a_s), list(b_s))
 
 
 # ---------------------------------------------------------------------------------------------------------------

@@ -239,6 +239,8 @@ int main(int argc, char** argv) {
     uint8_t *c1 = pack(d1, cb3), *c2 = pack(get("d_ct2"), cb3), *da = pack(get("d_a"), pb), *db = pack(get("d_b"), pb),
             *dx = pack(get("d_x"), pb), *dy = pack(get("d_y"), pb);
     uint8_t *al = (uint8_t*)calloc(nd, cb3), *ee = (uint8_t*)calloc(nd, pb2), *ff = (uint8_t*)calloc(nd, cb3);
+    OK(pgpu_nested_randomize_with_ab(pk, nd, c1, cb3, da, db, pb, al, cb3, PGPU_MEM_HOST));     /* operations.go:96-118 */
+    CHECK(memcmp(al, c2, nd * cb3) == 0);
     OK(pgpu_ddleq_prove(sk, nd, c1, c2, cb3, da, db, dx, dy, pb, al, ee, pb2, ff, PGPU_MEM_HOST));
     CHECK(same(al, get("d_alpha"), cb3) && same(ee, get("d_e"), pb2) && same(ff, get("d_f"), cb3));
     OK(pgpu_ddleq_verify(pk, nd, c1, c2, cb3, dx, dy, pb, al, cb3, ee, pb2, ff, cb3, st, PGPU_MEM_HOST));
