@@ -358,11 +358,39 @@ __global__ void __launch_bounds__(256) k_div_exact_t(const uint32_t* __restrict_
   }
 }
 
+// Exact division without the check, quotient narrower than the dividend (the digit split of the three-digit form:
+// (X - X0) / n with X of WU limbs, the quotient known to fit WL limbs): l = t * dinv mod 2^(28 WL) needs t[0 .. WL) only.
+template <int WU, int WL, int WS>
+__global__ void __launch_bounds__(256) k_div_exact_nc(const uint32_t* __restrict__ u, uint32_t sub_small,
+                                                      const uint32_t* __restrict__ subv, const uint32_t* __restrict__ dinv,
+                                                      uint32_t* __restrict__ l, size_t nb) {
+  static_assert(WL <= 255 && WL <= WU, "a column of <= 255 products of canonical limbs fits the 64-bit accumulator");
+  size_t g = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (g >= nb) return;
+  uint32_t t[WL];
+  int32_t br = 0;
+#pragma unroll
+  for (int i = 0; i < WL; ++i) {
+    int32_t v = (int32_t)u[(size_t)i * nb + g] - br - (i == 0 ? (int32_t)sub_small : 0) -
+                ((subv && i < WS) ? (int32_t)subv[(size_t)i * nb + g] : 0);
+    br = v < 0;
+    t[i] = (uint32_t)(v + (br << LB)) & LMASK;
+  }
+  uint64_t acc = 0;
+#pragma unroll
+  for (int c = 0; c < WL; ++c) {
+#pragma unroll
+    for (int i = 0; i <= c; ++i) acc += (uint64_t)t[i] * dinv[c - i];
+    l[(size_t)c * nb + g] = (uint32_t)acc & LMASK;
+    acc >>= LB;
+  }
+}
+
 template <int WA, int WB, int WO>
 __global__ void __launch_bounds__(256) k_mul_const_add_t(const uint32_t* __restrict__ a, const uint32_t* __restrict__ bconst,
                                                          const uint32_t* __restrict__ addv, int wadd, uint32_t add_small,
                                                          uint32_t* __restrict__ out, size_t nb) {
-  static_assert(WA <= 74 && WB <= 74, "single 64-bit column accumulator: 74 products of a 29-bit by a 28-bit limb stay below 2^64");
+  static_assert(WA <= 74 && WB <= 74, "single 64-bit column accumulator: <= 74 products of a 29-bit by a 28-bit limb stay below 2^64");
   size_t g = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (g >= nb) return;
   uint32_t x[WA];
@@ -376,6 +404,43 @@ __global__ void __launch_bounds__(256) k_mul_const_add_t(const uint32_t* __restr
     if (addv && c < wadd) acc += addv[(size_t)c * nb + g];
     out[(size_t)c * nb + g] = (uint32_t)acc & LMASK;
     acc >>= LB;
+  }
+}
+
+// Runtime-width version for the wide products: one wave per block, the per-number operand staged limb-major in LDS
+// ([wa][64], conflict-free) next to the uniform constant (broadcast reads).  Two-word column accumulator as in
+// k_mul_const_add, so any widths are safe.
+__global__ void __launch_bounds__(64) k_mul_const_add_lds(const uint32_t* __restrict__ a, int wa, const uint32_t* __restrict__ bconst,
+                                                         int wb, const uint32_t* __restrict__ addv, int wadd, uint32_t add_small,
+                                                         uint32_t* __restrict__ out, int wo, size_t nb) {
+  extern __shared__ uint32_t mca_lds[];
+  uint32_t* xs = mca_lds;
+  uint32_t* bs = mca_lds + (size_t)wa * 64;
+  const int lane = threadIdx.x;
+  const size_t g = (size_t)blockIdx.x * 64 + lane;
+  for (int i = lane; i < wb; i += 64) bs[i] = bconst[i];
+  if (g < nb)
+    for (int i = 0; i < wa; ++i) xs[i * 64 + lane] = a[(size_t)i * nb + g];
+  __syncthreads();
+  if (g >= nb) return;
+  uint64_t acc = add_small, hi = 0;
+  for (int c = 0; c < wo; ++c) {
+    const int i0 = c - (wb - 1) > 0 ? c - (wb - 1) : 0;
+    const int i1 = c < wa - 1 ? c : wa - 1;
+#pragma unroll 4
+    for (int i = i0; i <= i1; ++i) {
+      uint64_t p = (uint64_t)xs[i * 64 + lane] * bs[c - i];
+      acc += p;
+      hi += acc < p;
+    }
+    if (addv && c < wadd) {
+      uint64_t v = addv[(size_t)c * nb + g];
+      acc += v;
+      hi += acc < v;
+    }
+    out[(size_t)c * nb + g] = (uint32_t)acc & LMASK;
+    acc = (acc >> LB) | (hi << (64 - LB));
+    hi >>= LB;
   }
 }
 
@@ -750,7 +815,9 @@ __global__ void k_clear_where(const int32_t* __restrict__ flags, size_t count, i
   if (g < count && flags[g]) ok[g] = 0;
 }
 
-#define HELPER_GRID(nb) dim3((unsigned)(((nb) + 255) / 256)), dim3(256)
+// one wave per block: the helpers are latency-bound at the batch sizes of the level-two / threshold paths (16384 lanes =
+// 256 one-wave blocks = every CU), and bandwidth-bound ones lose nothing
+#define HELPER_GRID(nb) dim3((unsigned)(((nb) + 63) / 64)), dim3(64)
 
 void launch_unpack_be(const uint8_t* in, size_t stride, size_t nbytes, size_t count, uint32_t* out, int wt, size_t nb, hipStream_t st) {
   hipLaunchKernelGGL(k_unpack_be, HELPER_GRID(nb), 0, st, in, stride, nbytes, count, out, wt, nb);
@@ -773,6 +840,14 @@ void launch_mul_const_add(const uint32_t* a, int wa, const uint32_t* bconst, int
   }
   if (wa == 74 && wb == 74 && wo == 148 && (!addv || wadd <= 148)) {
     hipLaunchKernelGGL((k_mul_const_add_t<74, 74, 148>), HELPER_GRID(nb), 0, st, a, bconst, addv, wadd, add_small, out, nb);
+    return;
+  }
+  // wide products (the three-digit form's exit F2 n^2 + ..., the closed form of (1+n)^m mod n^3): too long to unroll
+  // into registers, so the operand is staged in LDS and the block is one wave (a 16384-lane batch still covers 256 CUs)
+  if ((size_t)wa * 64 * 4 + (size_t)wb * 4 <= 60 * 1024) {
+    size_t lds = (size_t)wa * 64 * 4 + (size_t)wb * 4;
+    hipLaunchKernelGGL(k_mul_const_add_lds, dim3((unsigned)((nb + 63) / 64)), dim3(64), lds, st, a, wa, bconst, wb, addv, wadd,
+                       add_small, out, wo, nb);
     return;
   }
   hipLaunchKernelGGL(k_mul_const_add, HELPER_GRID(nb), 0, st, a, wa, bconst, wb, addv, wadd, add_small, out, wo, nb);
@@ -806,6 +881,14 @@ void launch_div_exact(const uint32_t* u, int wu, uint32_t sub_small, const uint3
     else
       hipLaunchKernelGGL((k_div_exact_t<110, 55, 55, false>), HELPER_GRID(nb), 0, st, u, sub_small, subv, dinv, d, l, nb, count,
                          status, flag);
+    return;
+  }
+  if (!status && subv && wu == 220 && wl == 148 && wsub == 74) {     // digit split of the three-digit form, 2048-bit keys
+    hipLaunchKernelGGL((k_div_exact_nc<220, 148, 74>), HELPER_GRID(nb), 0, st, u, sub_small, subv, dinv, l, nb);
+    return;
+  }
+  if (!status && subv && wu == 110 && wl == 74 && wsub == 37) {      // 1024-bit keys, and the halves modulo p^3 of 2048-bit keys
+    hipLaunchKernelGGL((k_div_exact_nc<110, 74, 37>), HELPER_GRID(nb), 0, st, u, sub_small, subv, dinv, l, nb);
     return;
   }
   if (!status) {   // generic widths: run the check against a scratch word nobody reads (count = 0 masks every lane)
