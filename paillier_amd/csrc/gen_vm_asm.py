@@ -2287,9 +2287,10 @@ class GenQ3(Gen):
         for j in range(H):
             e(f"v_mov_b32 {self.X(j)}, 0")
 
-    def row(self, cur, nxt, link2, use_sh):
+    def row(self, cur, nxt, link2, use_sh, first=False):
         """one Montgomery row modulo n in every active lane; s[0:1] <- this row's (C1_i, C2_i); hop 1: lane 1 takes
-        C1_i - m(lane 0) into column 0; hop 2 (link2): lane 2 takes C2_i - m(lane 1)"""
+        C1_i - m(lane 0) into column 0; hop 2 (link2): lane 2 takes C2_i - m(lane 1).  first: the accumulators are not
+        read (row 0 of a pass: no zeroing of T beforehand)"""
         g, e = self, self.e
         H = self.H
         row = self.NPB * 4
@@ -2321,17 +2322,18 @@ class GenQ3(Gen):
         gap = min(3, (H - 1) // len(chain))                # multiplies between two steps of the chain (>= 2 covers the DPP hazard)
         assert gap >= 2, "pass A is too short to hide the link chain"
         self.align8()
-        self.mad(self.T(0), a, self.X(0), self.T(0))
+        addend = lambda j: "0" if (first or j == H - 1) else self.T(j)
+        self.mad(self.T(0), a, self.X(0), addend(0))
         j = 1
         for step in chain:
             for _ in range(gap):
-                self.mad(self.T(j), a, self.X(j), "0" if j == H - 1 else self.T(j))
+                self.mad(self.T(j), a, self.X(j), addend(j))
                 j += 1
             e(step)
             if step.startswith("v_mov_b32_dpp") or step.startswith("v_and") or step.startswith("v_sub"):
                 self.align8()
         while j < H:
-            self.mad(self.T(j), a, self.X(j), "0" if j == H - 1 else self.T(j))
+            self.mad(self.T(j), a, self.X(j), addend(j))
             j += 1
         self.align8()
         self.mad(self.P(g.v_y0), m, N(0), self.T(0))
@@ -2348,8 +2350,6 @@ class GenQ3(Gen):
         g, e = self, self.e
         H = self.H
         row = self.NPB * 4
-        for j in range(H - 1):
-            e(f"v_mov_b64 {self.T(j)}, 0")
         e(f"v_mov_b32 v{g.v_d + 1}, 0")
         e(f"v_and_b32 v{g.v_t1}, {(off3 - off012) * row}, v{g.v_l3mask}")
         e(f"v_add_u32 v{g.v_arow}, v{g.v_aread}, v{g.v_t1}")
@@ -2359,12 +2359,13 @@ class GenQ3(Gen):
         e(f"v_add_u32 v{g.v_arow}, {row}, v{g.v_arow}")
         e(f"s_mov_b32 s{g.s_coff}, 0")
         e("s_load_dwordx2 s[100:101], s[6:7], 0x0")
+        self.row(g.v_ain, g.v_ai, link2, use_sh, first=True)       # row 0 starts the accumulators: T is never zeroed
         if H % 2:
-            self.row(g.v_ain, g.v_ai, link2, use_sh)
             e("s_mov_b32 s19, 1")
             ra, rb = g.v_ai, g.v_ain
         else:
-            e("s_mov_b32 s19, 0")
+            self.row(g.v_ai, g.v_ain, link2, use_sh)
+            e("s_mov_b32 s19, 2")
             ra, rb = g.v_ain, g.v_ai
         e(".p2align 6")
         e(f"L_q{tag}:")
@@ -2376,25 +2377,34 @@ class GenQ3(Gen):
         e("s_waitcnt lgkmcnt(0)")
         e(f"v_mov_b64 {self.T(H - 1)}, 0")
 
-    def carry_T(self):
-        """sequential carry through the accumulators: canonical limb j ends up in Tlo(j) (the top limb keeps its excess)"""
+    def carry_T(self, to_x=False):
+        """sequential carry through the accumulators: canonical limb j ends up in Tlo(j) (to_x: in X(j), the multiplicand
+        being dead by then); the top limb keeps its excess"""
         g, e = self, self.e
         H = self.H
         c = self.P(g.v_c)
         for j in range(H):
             if j:
                 e(f"v_lshl_add_u64 {self.T(j)}, {self.T(j)}, 0, {c}")
+            dst = self.X(j) if to_x else self.Tlo(j)
             if j < H - 1:
                 e(f"v_lshrrev_b64 {c}, {LB}, {self.T(j)}")
-                e(f"v_and_b32 {self.Tlo(j)}, {hex(MASK)}, {self.Tlo(j)}")
+                e(f"v_and_b32 {dst}, {hex(MASK)}, {self.Tlo(j)}")
+            elif to_x:
+                e(f"v_mov_b32 {dst}, {self.Tlo(j)}")
 
-    def carry_X(self):
-        """lazy limbs (sums of up to three canonical limbs) -> canonical again; the top limb keeps the excess"""
+    def carry_X(self, extra=None):
+        """lazy limbs (sums of up to three canonical limbs) -> canonical again; the top limb keeps the excess.
+        extra(j): a register added to limb j on the way (saves the separate addition)"""
         g, e = self, self.e
         H = self.H
         for j in range(H):
-            if j:
+            if j and extra:
+                e(f"v_add3_u32 {self.X(j)}, {self.X(j)}, {extra(j)}, v{g.v_t1}")
+            elif j:
                 e(f"v_add_u32 {self.X(j)}, {self.X(j)}, v{g.v_t1}")
+            elif extra:
+                e(f"v_add_u32 {self.X(j)}, {self.X(j)}, {extra(j)}")
             if j < H - 1:
                 e(f"v_lshrrev_b32 v{g.v_t1}, {LB}, {self.X(j)}")
                 e(f"v_and_b32 {self.X(j)}, {hex(MASK)}, {self.X(j)}")
@@ -2408,15 +2418,15 @@ class GenQ3(Gen):
             e(f"v_mov_b32_dpp {self.X(j)}, {self.X(j)} quad_perm:[0,1,2,1] row_mask:0xf bank_mask:0xf")
         e(f"v_and_b32 v{g.v_sh}, 1, v{g.v_l12mask}")          # lanes 1, 2 double the multiplier: 2 a0 a1, 2 a0 a2
         self.passes("s", 0, H, True, True)
-        self.carry_T()
+        self.carry_T(to_x=True)
+        # digit 2 += a1 a1 R^-1 (helper lane): one DPP addition per limb with only lanes 2, 3 enabled (the source lane of a
+        # DPP operand has to be active; what the helper lane computes for itself is never read)
+        self.set_exec(0xc)
+        e("s_nop 4")
         for j in range(H):
-            e(f"v_mov_b32 {self.X(j)}, {self.Tlo(j)}")
-        e("s_nop 1")
-        for j in range(H):                                   # digit 2 += a1 a1 R^-1 (helper lane)
-            e(f"v_mov_b32_dpp v{g.v_t2}, {self.X(j)} quad_perm:[0,1,3,3] row_mask:0xf bank_mask:0xf")
-            e(f"v_and_b32 v{g.v_t2}, v{g.v_t2}, v{g.v_l2mask}")
-            e(f"v_add_u32 {self.X(j)}, {self.X(j)}, v{g.v_t2}")
-        self.carry_X()
+            e(f"v_add_u32_dpp {self.X(j)}, {self.X(j)}, {self.X(j)} quad_perm:[0,1,3,3] row_mask:0xf bank_mask:0xf")
+        self.carry_X()                                       # lanes 0, 1 are canonical already and stay as they are
+        e("s_mov_b64 exec, -1")
         e("s_branch L_next")
 
     def montmul(self):
@@ -2431,37 +2441,31 @@ class GenQ3(Gen):
         self.passes("m1", 0, 2 * H, True, False)
         self.carry_T()
         # lanes 0, 1 still need their digits as multiplicands: park their results in the LDS rows of the streams that are
-        # finished (lane 0: rows of b0, lane 1: rows of b2); lanes 2, 3 are done and keep theirs in X
+        # finished (lane 0: rows of b0, lane 1: rows of b2); lanes 2, 3 are done: pass 2 runs with them masked off, so
+        # their results simply stay in Tlo
         e(f"v_and_b32 v{g.v_t4}, {2 * H * row}, v{g.v_l1mask}")
         e(f"v_add_u32 v{g.v_t4}, v{g.v_t4}, v{g.v_aread}")
         self.set_exec(0x3)
         for j in range(H):
             e(f"ds_write_b32 v{g.v_t4}, {self.Tlo(j)} offset:{j * row}")
-        self.set_exec(0xc)
-        for j in range(H):
-            e(f"v_mov_b32 {self.X(j)}, {self.Tlo(j)}")
-        # pass 2: stream b1 in lanes 0, 1 (a0 b1 -> a1 b1 chained); lanes 2, 3 masked off
-        self.set_exec(0x3)
+        # pass 2: stream b1 in lanes 0, 1 (a0 b1 -> a1 b1 chained)
         self.passes("m2", H, H, False, False)
         self.carry_T()
-        e("s_mov_b64 exec, -1")
         # c0 = t00 | c1 = t10 + t01 | c2 = t20 + t02 + t11
-        e("s_nop 1")
-        St = [f"v{g.vX - 1 - j}" for j in range(0)]          # (no staging registers needed)
-        for j in range(H):
-            e(f"v_mov_b32_dpp v{g.v_t2}, {self.Tlo(j)} quad_perm:[0,0,1,3] row_mask:0xf bank_mask:0xf")   # lane 1 <- t01, lane 2 <- t11
-            e(f"v_mov_b32_dpp v{g.v_t3}, {self.X(j)} quad_perm:[0,1,3,3] row_mask:0xf bank_mask:0xf")     # lane 2 <- t02
-            e(f"v_and_b32 v{g.v_t2}, v{g.v_t2}, v{g.v_l12mask}")
-            e(f"v_and_b32 v{g.v_t3}, v{g.v_t3}, v{g.v_l2mask}")
-            e(f"v_add_u32 {self.Thi(j)}, v{g.v_t2}, v{g.v_t3}")           # the cross-lane part of limb j, kept in the dead half of T(j)
-        self.set_exec(0x3)
         for j in range(H):
             e(f"ds_read_b32 {self.X(j)}, v{g.v_t4} offset:{j * row}")    # lanes 0, 1: the parked t00 / t10
-        e("s_waitcnt lgkmcnt(0)")
         e("s_mov_b64 exec, -1")
-        for j in range(H):
-            e(f"v_add_u32 {self.X(j)}, {self.X(j)}, {self.Thi(j)}")
-        self.carry_X()
+        e("s_nop 4")
+        for j in range(H):    # lane 1 <- t01, lane 2 <- t11, kept in the dead half of T(j)
+            e(f"v_mov_b32_dpp {self.Thi(j)}, {self.Tlo(j)} quad_perm:[0,0,1,3] row_mask:0xf bank_mask:0xf")
+        e("s_waitcnt lgkmcnt(0)")
+        self.set_exec(0xc)
+        e("s_nop 4")
+        for j in range(H):    # lane 2 <- t20 + t02 (the helper lane's own sum is never read)
+            e(f"v_add_u32_dpp {self.X(j)}, {self.Tlo(j)}, {self.Tlo(j)} quad_perm:[0,1,3,3] row_mask:0xf bank_mask:0xf")
+        self.set_exec(0x6)    # lane 0 (t00) is canonical and final
+        self.carry_X(extra=lambda j: self.Thi(j))
+        e("s_mov_b64 exec, -1")
         e("s_branch L_next")
 
     def generate(self):
