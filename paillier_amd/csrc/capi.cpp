@@ -260,12 +260,16 @@ struct Prog {
   double montmuls = 0, sqrs = 0;
   bool asm_ok = true;  // only opcodes the assembly kernel implements
   bool has_mulv = false;
+  uint32_t gather_slots = 1;  // slots a per-number gather spans (table entries + 1): its offsets are 32-bit in the assembly kernels
   void op(uint32_t o, uint32_t arg = 0, uint32_t aux = 0) {
     if (o == VM_SETOFF) asm_ok = false;
-    if (o == VM_MULV || o == VM_MULV5) has_mulv = true;
+    if (o == VM_MULV || o == VM_MULV5 || o == VM_MULV7) {
+      has_mulv = true;
+      gather_slots = std::max<uint32_t>(gather_slots, o == VM_MULV ? 17u : o == VM_MULV5 ? 33u : 129u);
+    }
     w.push_back(o | (aux << 8));
     w.push_back(arg);
-    if (o == VM_SQR || o == VM_MUL || o == VM_MULC || o == VM_MULV || o == VM_MULCV || o == VM_MULV5) montmuls += 1;
+    if (o == VM_SQR || o == VM_MUL || o == VM_MULC || o == VM_MULV || o == VM_MULCV || o == VM_MULV5 || o == VM_MULV7) montmuls += 1;
     if (o == VM_SQR) sqrs += 1;
   }
   void end() { op(VM_END); }
@@ -370,50 +374,57 @@ void emit_modexp_shared(Prog& p, const BigU& e, uint32_t in_lo, uint32_t in_hi, 
 // the segment's `digits` array [we][nb].  Table slots tab .. tab+15.
 // raw_one >= 0: the value in slot in_lo is already in the kernel's working form (pair kernels), raw_one is the constant
 // holding 1 in that form; no entry, no exit.
-// w5: 5-bit windows (VM_MULV5; the segment's `digits` must be the repacked 25-bit words: windows5_of()); table tab .. tab+31.
-// Pays where a product costs two squarings (the digit kernels): 4 096-bit exponents take 820 + 30 products instead of
-// 1 024 + 14.
-void emit_modexp_perlane(Prog& p, int we, uint32_t in_lo, uint32_t in_hi, uint32_t tmp, uint32_t out, uint32_t tab,
-                         uint32_t post_slot, int raw_one = -1, bool w5 = false) {
-  const uint32_t one = raw_one >= 0 ? (uint32_t)raw_one : (uint32_t)C_ONE_M;
-  const int wb = w5 ? 5 : 4;
-  if (raw_one >= 0) p.op(VM_LOAD, in_lo); else emit_to_mont(p, in_lo, in_hi, tmp);
+// wb: window bits.  4: VM_MULV (7 windows per limb), table tab .. tab+15.  5: VM_MULV5 (the segment's `digits` must be the
+// repacked 25-bit words: windows5_of()), 32 entries.  7: VM_MULV7 (4 windows per limb, no repacking), 128 entries.
+// The wide windows pay where a product costs two squarings (the digit kernels): a 4 096-bit exponent takes 586 products
+// and a 63 + 63 table at 7 bits, 820 + 30 at 5, 1 024 + 14 at 4.
+static int perlane_windows(int we, int wb) { return wb == 4 ? we * 7 : wb == 5 ? (we * LB + 4) / 5 : we * 4; }
+static VmOp perlane_op(int wb) { return wb == 4 ? VM_MULV : wb == 5 ? VM_MULV5 : VM_MULV7; }
+// table of x^0 .. x^(2^wb - 1) from x in the accumulator; the wide tables square for their even entries (a squaring
+// is half a product on the digit kernels)
+static void emit_power_table(Prog& p, uint32_t tab, uint32_t one, int wb) {
   p.op(VM_STORE, tab + 1);
   p.op(VM_LOADC, one);
   p.op(VM_STORE, tab + 0);
   p.op(VM_LOAD, tab + 1);
   for (uint32_t k = 2; k < (1u << wb); ++k) {
-    p.op(VM_MUL, tab + 1);
+    if (wb >= 5 && k % 2 == 0) { p.op(VM_LOAD, tab + k / 2); p.op(VM_SQR); }
+    else p.op(VM_MUL, tab + 1);
     p.op(VM_STORE, tab + k);
   }
-  const int nwin = w5 ? (we * LB + 4) / 5 : we * 7;
+}
+
+void emit_modexp_perlane(Prog& p, int we, uint32_t in_lo, uint32_t in_hi, uint32_t tmp, uint32_t out, uint32_t tab,
+                         uint32_t post_slot, int raw_one = -1, int wb = 4) {
+  const uint32_t one = raw_one >= 0 ? (uint32_t)raw_one : (uint32_t)C_ONE_M;
+  if (raw_one >= 0) p.op(VM_LOAD, in_lo); else emit_to_mont(p, in_lo, in_hi, tmp);
+  emit_power_table(p, tab, one, wb);
+  const int nwin = perlane_windows(we, wb);
   p.op(VM_LOADC, one);
   for (int i = nwin - 1; i >= 0; --i) {
     if (i != nwin - 1) for (int s = 0; s < wb; ++s) p.op(VM_SQR);
-    p.op(w5 ? VM_MULV5 : VM_MULV, (uint32_t)i, tab);
+    p.op(perlane_op(wb), (uint32_t)i, tab);
   }
   if (raw_one < 0) { if (post_slot != NO_SLOT) p.op(VM_MUL, post_slot); else p.op(VM_MULC, C_ONE); }
   p.op(VM_STORE, out);
 }
 
 // x^(per-number exponent) * y^(shared exponent e) with ONE chain of squarings (interleaved / "Shamir" exponentiation):
-// x's 4-bit fixed windows (MULV on the table tab1[0..15]) and y's sliding windows over odd powers (tab2[0..31], w = 6) hang
-// off the same accumulator.  Costs max(bits) squarings instead of the sum: what check^(E^n) * F^(n^2) of the DDLEQ
-// verifier (ddleq.go:143-152) and alpha = ct1^(x^n) * y^(n^2) of the prover (ddleq.go:81-87) need.
+// x's fixed windows (wb bits: MULV / MULV5 / MULV7 on the table tab1[0 .. 2^wb - 1]) and y's sliding windows over odd powers
+// (tab2[0 .. 2^(sw-1) - 1]; sw = 6, or 7 next to 7-bit windows) hang off the same accumulator.  Costs max(bits) squarings
+// instead of the sum: what check^(E^n) * F^(n^2) of the DDLEQ verifier (ddleq.go:143-152) and alpha = ct1^(x^n) * y^(n^2)
+// of the prover (ddleq.go:81-87) need.
 // x in slot in1, y in slot in2 (plain residues); result (plain, lazy) -> out.
+static int dual_sliding_bits(int wb) { return wb == 7 ? 7 : 6; }
 void emit_modexp_dual(Prog& p, int we, const BigU& e, uint32_t in1, uint32_t in2, uint32_t tmp, uint32_t out, uint32_t tab1,
-                      uint32_t tab2, int raw_one = -1, bool w5 = false) {
+                      uint32_t tab2, int raw_one = -1, int wb = 4) {
   // raw_one >= 0: in1 / in2 are already in the kernel's working form (digit kernels), raw_one = the constant holding 1 in
   // that form; no entry, no exit
   const uint32_t one_m = raw_one >= 0 ? (uint32_t)raw_one : (uint32_t)C_ONE_M;
   // tables
   if (raw_one >= 0) p.op(VM_LOAD, in1); else emit_to_mont(p, in1, NO_SLOT, tmp);
-  p.op(VM_STORE, tab1 + 1);
-  p.op(VM_LOADC, one_m);
-  p.op(VM_STORE, tab1 + 0);
-  p.op(VM_LOAD, tab1 + 1);
-  for (uint32_t k = 2; k < (w5 ? 32u : 16u); ++k) { p.op(VM_MUL, tab1 + 1); p.op(VM_STORE, tab1 + k); }
-  const int sw = 6;
+  emit_power_table(p, tab1, one_m, wb);
+  const int sw = dual_sliding_bits(wb);
   const uint32_t nodd = 1u << (sw - 1);
   if (raw_one >= 0) p.op(VM_LOAD, in2); else emit_to_mont(p, in2, NO_SLOT, tmp);
   p.op(VM_STORE, tab2 + 0);
@@ -433,11 +444,11 @@ void emit_modexp_dual(Prog& p, int we, const BigU& e, uint32_t in1, uint32_t in2
     mul_at[(size_t)l] = (int)(val >> 1);
     i = l - 1;
   }
+  const long nwin = perlane_windows(we, wb);
   p.op(VM_LOADC, one_m);
   for (long b = nbits - 1; b >= 0; --b) {
     if (b != nbits - 1) p.op(VM_SQR);
-    if (!w5 && b % 4 == 0 && b / 4 < (long)we * 7) p.op(VM_MULV, (uint32_t)(b / 4), tab1);
-    if (w5 && b % 5 == 0 && b / 5 < ((long)we * LB + 4) / 5) p.op(VM_MULV5, (uint32_t)(b / 5), tab1);
+    if (b % wb == 0 && b / wb < nwin) p.op(perlane_op(wb), (uint32_t)(b / wb), tab1);
     if (mul_at[(size_t)b] >= 0) p.op(VM_MUL, tab2 + (uint32_t)mul_at[(size_t)b]);
   }
   if (raw_one < 0) p.op(VM_MULC, C_ONE);
@@ -511,7 +522,8 @@ void run_vm(pgpu_ctx* ctx, size_t nb, const SegSpec& s0, const SegSpec* s1, bool
   const uint32_t blocks = blocks_per_seg * (s2 ? 3 : s1 ? 2 : 1);
   const bool use_asm = ctx->use_asm && vm_asm_available(WL, K) && s0.prog->asm_ok && (!s1 || s1->prog->asm_ok) &&
                        (!s2 || s2->prog->asm_ok) &&
-                       (uint64_t)nb * mc->WT * 4 * ((s0.prog->has_mulv || (s1 && s1->prog->has_mulv) || (s2 && s2->prog->has_mulv)) ? 17 : 1) < (1ull << 32);
+                       (uint64_t)nb * (s0.pair_lanes == 3 ? 3 * s0.pair_h : mc->WT) * 4 *
+                               std::max(s0.prog->gather_slots, std::max(s1 ? s1->prog->gather_slots : 1u, s2 ? s2->prog->gather_slots : 1u)) < (1ull << 32);
   pgpu_ctx::Ev* ev = nullptr;
   if (profile) {
     ev = &ctx->next_ev();
@@ -961,6 +973,14 @@ const uint32_t* windows5_of(pgpu_ctx* ctx, const uint32_t* exps, int we, size_t 
   return out;
 }
 
+// window bits for per-number exponents on the three-digit kernel: 7 while the 128-entry table stays within the kernel's
+// 32-bit gather offsets (nb <= 32768 at 2048-bit keys), else 5
+int triple_window_bits(size_t nb, int H) { return (uint64_t)nb * 3 * H * 4 * 129 < (1ull << 32) ? 7 : 5; }
+const uint32_t* windows5_of(pgpu_ctx* ctx, const uint32_t* exps, int we, size_t nb);
+const uint32_t* triple_windows(pgpu_ctx* ctx, const uint32_t* exps, int we, size_t nb, int wb) {
+  return wb == 5 ? windows5_of(ctx, exps, we, nb) : exps;
+}
+
 bool triple_usable(pgpu_ctx* ctx, const ModCtx& mc) {
   static const bool env_on = [] { const char* e = getenv("PGPU_TRIPLE"); return e ? atoi(e) != 0 : true; }();
   return env_on && mc.triple.root && ctx->use_asm && ctx->use_pair && ctx->use_triple;
@@ -1038,12 +1058,13 @@ void modexp_triple(pgpu_ctx* ctx, const ModCtx& mc, const ModexpPlan& pl, const 
                    bool use_post) {
   // digit slots: 0 in, 1 (unused), 2 tmp, 3 out, 5.. table (32 entries: sliding windows of a shared exponent, or the 5-bit
   // windows of per-number exponents -- a product costs two squarings here, so the wider window pays)
-  TriplePlan tp = triple_alloc(ctx, mc, pl.nb, 5 + 32);
+  const int wb = exps ? triple_window_bits(pl.nb, mc.triple.root->WT) : 5;
+  TriplePlan tp = triple_alloc(ctx, mc, pl.nb, 5 + (1 << wb));
   triple_enter(ctx, mc, pl.in(), tp, 0);
   Prog p;
   if (exps) {
-    emit_modexp_perlane(p, we, 0, NO_SLOT, 2, 3, 5, NO_SLOT, 0, true);
-    exps = windows5_of(ctx, exps, we, pl.nb);
+    emit_modexp_perlane(p, we, 0, NO_SLOT, 2, 3, 5, NO_SLOT, 0, wb);
+    exps = triple_windows(ctx, exps, we, pl.nb, wb);
   } else {
     emit_modexp_shared(p, *e, 0, NO_SLOT, 2, 3, 5, NO_SLOT, true, true);
   }
@@ -2931,13 +2952,15 @@ uint32_t* dual_pow_n3(pgpu_ctx* ctx, const pgpu_pubkey* pk, const uint32_t* x, c
   HIPCHK(hipMemcpyAsync(pc.in() + pc.slot_words, y, pc.slot_words * 4, hipMemcpyDeviceToDevice, ctx->stream));
   if (use3) {
     // the interleaved ladder on the three-digit kernel: residues modulo n^3 as a0 + a1 n + a2 n^2
-    TriplePlan tp = triple_alloc(ctx, mn3, nb, 5 + 64);        // slots: 0 x, 1 y, 2 tmp, 3 out, 5..36 / 37..68 the tables
+    const int wb = triple_window_bits(nb, mn3.triple.root->WT);       // 7-bit (or 5-bit) windows of the per-number exponent
+    const uint32_t tab2 = 5 + (1u << wb);
+    TriplePlan tp = triple_alloc(ctx, mn3, nb, (int)tab2 + (1 << (dual_sliding_bits(wb) - 1)));   // slots: 0 x, 1 y, 2 tmp, 3 out, 5.. / tab2.. the tables
     triple_enter(ctx, mn3, pc.in(), tp, 0);
     triple_enter(ctx, mn3, pc.in() + pc.slot_words, tp, 1);
     Prog pd;
-    emit_modexp_dual(pd, W2, mn2.N, 0, 1, 2, 3, 5, 37, 0, true);       // 5-bit windows of the per-number exponent
+    emit_modexp_dual(pd, W2, mn2.N, 0, 1, 2, 3, 5, tab2, 0, wb);
     pd.end();
-    triple_run(ctx, mn3, tp, pd, windows5_of(ctx, exps, W2, nb));
+    triple_run(ctx, mn3, tp, pd, triple_windows(ctx, exps, W2, nb, wb));
     triple_exit(ctx, mn3, tp, 3, pc.out(), nullptr);
   } else {
     Prog pd;
@@ -3152,7 +3175,9 @@ void pow_n3_crt(const pgpu_seckey* sk, const uint32_t* base, int wb, const uint3
       (exps || base2 || e->bit_length() >= 64)) {
     // both halves on the three-digit kernel (digits modulo p and q, 37 limbs for 2048-bit keys): a squaring is 37 rows
     // where the wave-sliced 110-limb kernel has 110 -- what counts for the half-size, latency-bound batches of the response
-    const int nslots = base2 ? 5 + 64 : 5 + 32;
+    const int win = exps ? triple_window_bits(nb, mp3.triple.root->WT) : 5;
+    const uint32_t tab2 = 5 + (1u << win);
+    const int nslots = base2 ? (int)tab2 + (1 << (dual_sliding_bits(win) - 1)) : 5 + (1 << win);
     TriplePlan tp = triple_alloc(ctx, mp3, nb, nslots), tq = triple_alloc(ctx, mq3, nb, nslots);
     uint32_t* g = ctx->ws_t<uint32_t>(S * 6);       // generic slots (W limbs): 0 x_p, 1 x_q, 2 A, 3 B, 4 h, 5 scratch
     for (int half = 0; half < 2; ++half) {
@@ -3166,11 +3191,11 @@ void pow_n3_crt(const pgpu_seckey* sk, const uint32_t* base, int wb, const uint3
       }
     }
     Prog pp;
-    if (base2) emit_modexp_dual(pp, we, *e, 0, 1, 2, 3, 5, 37, 0, true);
-    else if (exps) emit_modexp_perlane(pp, we, 0, NO_SLOT, 2, 3, 5, NO_SLOT, 0, true);
+    if (base2) emit_modexp_dual(pp, we, *e, 0, 1, 2, 3, 5, tab2, 0, win);
+    else if (exps) emit_modexp_perlane(pp, we, 0, NO_SLOT, 2, 3, 5, NO_SLOT, 0, win);
     else emit_modexp_shared(pp, *e, 0, NO_SLOT, 2, 3, 5, NO_SLOT, true, true);
     pp.end();
-    if (exps) exps = windows5_of(ctx, exps, we, nb);                       // 5-bit windows of the per-number exponents
+    if (exps) exps = triple_windows(ctx, exps, we, nb, win);
     SegSpec sp{&mp3, &pp, tp.mem, exps}, sq{&mq3, &pp, tq.mem, exps};
     sp.pair = mp3.triple.kconsts; sp.pair_n0inv = sk->mp.n0inv; sp.pair_h = tp.H; sp.pair_lanes = 3; sp.tconsts = mp3.triple.tconsts;
     sq.pair = mq3.triple.kconsts; sq.pair_n0inv = sk->mq.n0inv; sq.pair_h = tq.H; sq.pair_lanes = 3; sq.tconsts = mq3.triple.tconsts;

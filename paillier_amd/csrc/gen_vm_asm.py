@@ -32,7 +32,7 @@ import sys
 LB = 28
 MASK = (1 << LB) - 1
 BLOCK = 256
-OPS = dict(END=0, LOAD=1, STORE=2, LOADC=3, SQR=4, MUL=5, MULC=6, MULV=7, ADD=8, SETOFF=9, MULCV=10, MULV5=11)
+OPS = dict(END=0, LOAD=1, STORE=2, LOADC=3, SQR=4, MUL=5, MULC=6, MULV=7, ADD=8, SETOFF=9, MULCV=10, MULV5=11, MULV7=12)
 
 
 class Gen:
@@ -307,7 +307,7 @@ class Gen:
         e("s_addc_u32 s5, s5, 0")
         e("s_waitcnt lgkmcnt(0)")
         e("s_and_b32 s18, s16, 0xff")
-        for nm in ("SQR", "MUL", "MULC", "MULV", "MULV5", "MULCV", "LOAD", "STORE", "LOADC", "ADD"):
+        for nm in ("SQR", "MUL", "MULC", "MULV", "MULV5", "MULV7", "MULCV", "LOAD", "STORE", "LOADC", "ADD"):
             e(f"s_cmp_eq_u32 s18, {OPS[nm]}")
             e(f"s_cbranch_scc1 L_{nm.lower()}")
         e("s_endpgm")  # END (and anything unsupported: the host never sends those)
@@ -347,9 +347,9 @@ class Gen:
         self.stage_to_lds(St)
         e("s_branch L_montmul")
 
-        for lbl, per_word, wbits in (("L_mulv", 7, 4), ("L_mulv5", 5, 5)):
+        for lbl, per_word, wbits in (("L_mulv", 7, 4), ("L_mulv5", 5, 5), ("L_mulv7", 4, 7)):
             # per-number table index: window `arg` of this number's own exponent -- 4 bits, 7 per 28-bit limb (MULV), or 5
-            # bits, 5 per 25-bit word of the repacked exponent (MULV5); table slot = aux + digit.  Uniform control flow,
+            # bits, 5 per 25-bit word of the repacked exponent (MULV5), or 7 bits, 4 per limb (MULV7); table slot = aux + digit.  Uniform control flow,
             # per-lane gather address.
             e(f"{lbl}:")
             e(f"s_mul_hi_u32 s{g.s_t1}, s17, {((1 << 32) + per_word - 1) // per_word}")   # q = arg / per_word

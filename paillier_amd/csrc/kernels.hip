@@ -108,6 +108,10 @@ __global__ void __launch_bounds__(VM_BLOCK, (3 * WL + 24 <= 256) ? 2 : 1) vm_ker
         // 5-bit windows of the exponent repacked as 25-bit words (5 windows per word); 32-entry table
         const uint32_t eword = sg.digits[(size_t)(arg / 5u) * nb + g];
         slot = (size_t)(w0 >> 8) + ((eword >> (5u * (arg % 5u))) & 31u);
+      } else if (op == VM_MULV7) {
+        // 7-bit windows, 4 per 28-bit limb; 128-entry table
+        const uint32_t elimb = sg.digits[(size_t)(arg / 4u) * nb + g];
+        slot = (size_t)(w0 >> 8) + ((elimb >> (7u * (arg % 4u))) & 127u);
       }
       const uint32_t* p = sg.mem + (slot * WT + (size_t)k * WL) * nb + g + goff;
 #pragma unroll
