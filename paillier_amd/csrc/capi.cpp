@@ -260,9 +260,11 @@ struct Prog {
   double montmuls = 0, sqrs = 0;
   bool asm_ok = true;  // only opcodes the assembly kernel implements
   bool has_mulv = false;
+  bool nm_tables = false;     // VM_MULV7 / VM_STORET: among the assembly kernels only the three-digit ones implement them
   uint32_t gather_slots = 1;  // slots a per-number gather spans (table entries + 1): its offsets are 32-bit in the assembly kernels
   void op(uint32_t o, uint32_t arg = 0, uint32_t aux = 0) {
     if (o == VM_SETOFF) asm_ok = false;
+    if (o == VM_MULV7 || o == VM_STORET) nm_tables = true;
     if (o == VM_MULV || o == VM_MULV5 || o == VM_MULV7) {
       has_mulv = true;
       gather_slots = std::max<uint32_t>(gather_slots, o == VM_MULV ? 17u : o == VM_MULV5 ? 33u : 129u);
@@ -381,8 +383,26 @@ void emit_modexp_shared(Prog& p, const BigU& e, uint32_t in_lo, uint32_t in_hi, 
 static int perlane_windows(int we, int wb) { return wb == 4 ? we * 7 : wb == 5 ? (we * LB + 4) / 5 : we * 4; }
 static VmOp perlane_op(int wb) { return wb == 4 ? VM_MULV : wb == 5 ? VM_MULV5 : VM_MULV7; }
 // table of x^0 .. x^(2^wb - 1) from x in the accumulator; the wide tables square for their even entries (a squaring
-// is half a product on the digit kernels)
+// is half a product on the digit kernels).  The 7-bit table is gathered per number, so its 128 slots are number-major
+// (VM_STORET / VM_MULV7); the entries the build itself reads back (x and the ones that get squared) are kept limb-major as
+// well, in the 64 slots after the table.
+static int perlane_table_slots(int wb) { return wb == 7 ? 128 + 64 : 1 << wb; }
 static void emit_power_table(Prog& p, uint32_t tab, uint32_t one, int wb) {
+  if (wb == 7) {
+    const uint32_t scr = tab + 128;
+    p.op(VM_STORET, tab + 1);
+    p.op(VM_STORE, scr + 1);
+    p.op(VM_LOADC, one);
+    p.op(VM_STORET, tab + 0);
+    p.op(VM_LOAD, scr + 1);
+    for (uint32_t k = 2; k < 128; ++k) {
+      if (k % 2 == 0) { p.op(VM_LOAD, scr + k / 2); p.op(VM_SQR); }
+      else p.op(VM_MUL, scr + 1);
+      p.op(VM_STORET, tab + k);
+      if (k < 64) p.op(VM_STORE, scr + k);
+    }
+    return;
+  }
   p.op(VM_STORE, tab + 1);
   p.op(VM_LOADC, one);
   p.op(VM_STORE, tab + 0);
@@ -520,8 +540,9 @@ void run_vm(pgpu_ctx* ctx, size_t nb, const SegSpec& s0, const SegSpec* s1, bool
   a.seg0_blocks = blocks_per_seg;
   a.seg1_blocks = blocks_per_seg;
   const uint32_t blocks = blocks_per_seg * (s2 ? 3 : s1 ? 2 : 1);
+  const bool nm_tables = s0.prog->nm_tables || (s1 && s1->prog->nm_tables) || (s2 && s2->prog->nm_tables);
   const bool use_asm = ctx->use_asm && vm_asm_available(WL, K) && s0.prog->asm_ok && (!s1 || s1->prog->asm_ok) &&
-                       (!s2 || s2->prog->asm_ok) &&
+                       (!s2 || s2->prog->asm_ok) && (!nm_tables || (pair && s0.pair_lanes == 3)) &&
                        (uint64_t)nb * (s0.pair_lanes == 3 ? 3 * s0.pair_h : mc->WT) * 4 *
                                std::max(s0.prog->gather_slots, std::max(s1 ? s1->prog->gather_slots : 1u, s2 ? s2->prog->gather_slots : 1u)) < (1ull << 32);
   pgpu_ctx::Ev* ev = nullptr;
@@ -1059,7 +1080,7 @@ void modexp_triple(pgpu_ctx* ctx, const ModCtx& mc, const ModexpPlan& pl, const 
   // digit slots: 0 in, 1 (unused), 2 tmp, 3 out, 5.. table (32 entries: sliding windows of a shared exponent, or the 5-bit
   // windows of per-number exponents -- a product costs two squarings here, so the wider window pays)
   const int wb = exps ? triple_window_bits(pl.nb, mc.triple.root->WT) : 5;
-  TriplePlan tp = triple_alloc(ctx, mc, pl.nb, 5 + (1 << wb));
+  TriplePlan tp = triple_alloc(ctx, mc, pl.nb, 5 + perlane_table_slots(wb));
   triple_enter(ctx, mc, pl.in(), tp, 0);
   Prog p;
   if (exps) {
@@ -2953,7 +2974,7 @@ uint32_t* dual_pow_n3(pgpu_ctx* ctx, const pgpu_pubkey* pk, const uint32_t* x, c
   if (use3) {
     // the interleaved ladder on the three-digit kernel: residues modulo n^3 as a0 + a1 n + a2 n^2
     const int wb = triple_window_bits(nb, mn3.triple.root->WT);       // 7-bit (or 5-bit) windows of the per-number exponent
-    const uint32_t tab2 = 5 + (1u << wb);
+    const uint32_t tab2 = 5 + (uint32_t)perlane_table_slots(wb);
     TriplePlan tp = triple_alloc(ctx, mn3, nb, (int)tab2 + (1 << (dual_sliding_bits(wb) - 1)));   // slots: 0 x, 1 y, 2 tmp, 3 out, 5.. / tab2.. the tables
     triple_enter(ctx, mn3, pc.in(), tp, 0);
     triple_enter(ctx, mn3, pc.in() + pc.slot_words, tp, 1);
@@ -3176,8 +3197,8 @@ void pow_n3_crt(const pgpu_seckey* sk, const uint32_t* base, int wb, const uint3
     // both halves on the three-digit kernel (digits modulo p and q, 37 limbs for 2048-bit keys): a squaring is 37 rows
     // where the wave-sliced 110-limb kernel has 110 -- what counts for the half-size, latency-bound batches of the response
     const int win = exps ? triple_window_bits(nb, mp3.triple.root->WT) : 5;
-    const uint32_t tab2 = 5 + (1u << win);
-    const int nslots = base2 ? (int)tab2 + (1 << (dual_sliding_bits(win) - 1)) : 5 + (1 << win);
+    const uint32_t tab2 = 5 + (uint32_t)perlane_table_slots(win);
+    const int nslots = base2 ? (int)tab2 + (1 << (dual_sliding_bits(win) - 1)) : 5 + perlane_table_slots(win);
     TriplePlan tp = triple_alloc(ctx, mp3, nb, nslots), tq = triple_alloc(ctx, mq3, nb, nslots);
     uint32_t* g = ctx->ws_t<uint32_t>(S * 6);       // generic slots (W limbs): 0 x_p, 1 x_q, 2 A, 3 B, 4 h, 5 scratch
     for (int half = 0; half < 2; ++half) {

@@ -32,7 +32,7 @@ import sys
 LB = 28
 MASK = (1 << LB) - 1
 BLOCK = 256
-OPS = dict(END=0, LOAD=1, STORE=2, LOADC=3, SQR=4, MUL=5, MULC=6, MULV=7, ADD=8, SETOFF=9, MULCV=10, MULV5=11, MULV7=12)
+OPS = dict(END=0, LOAD=1, STORE=2, LOADC=3, SQR=4, MUL=5, MULC=6, MULV=7, ADD=8, SETOFF=9, MULCV=10, MULV5=11, MULV7=12, STORET=13)
 
 
 class Gen:
@@ -307,7 +307,9 @@ class Gen:
         e("s_addc_u32 s5, s5, 0")
         e("s_waitcnt lgkmcnt(0)")
         e("s_and_b32 s18, s16, 0xff")
-        for nm in ("SQR", "MUL", "MULC", "MULV", "MULV5", "MULV7", "MULCV", "LOAD", "STORE", "LOADC", "ADD"):
+        # MULV7 / STORET (number-major tables) exist on the three-digit kernels only; the host emits them nowhere else
+        nm_tables = ("MULV7", "STORET") if getattr(self, "number_major_tables", False) else ()
+        for nm in ("SQR", "MUL", "MULC", "MULV", "MULV5") + nm_tables + ("MULCV", "LOAD", "STORE", "LOADC", "ADD"):
             e(f"s_cmp_eq_u32 s18, {OPS[nm]}")
             e(f"s_cbranch_scc1 L_{nm.lower()}")
         e("s_endpgm")  # END (and anything unsupported: the host never sends those)
@@ -347,9 +349,9 @@ class Gen:
         self.stage_to_lds(St)
         e("s_branch L_montmul")
 
-        for lbl, per_word, wbits in (("L_mulv", 7, 4), ("L_mulv5", 5, 5), ("L_mulv7", 4, 7)):
+        for lbl, per_word, wbits in (("L_mulv", 7, 4), ("L_mulv5", 5, 5)):
             # per-number table index: window `arg` of this number's own exponent -- 4 bits, 7 per 28-bit limb (MULV), or 5
-            # bits, 5 per 25-bit word of the repacked exponent (MULV5), or 7 bits, 4 per limb (MULV7); table slot = aux + digit.  Uniform control flow,
+            # bits, 5 per 25-bit word of the repacked exponent (MULV5); table slot = aux + digit.  Uniform control flow,
             # per-lane gather address.
             e(f"{lbl}:")
             e(f"s_mul_hi_u32 s{g.s_t1}, s17, {((1 << 32) + per_word - 1) // per_word}")   # q = arg / per_word
@@ -382,6 +384,9 @@ class Gen:
             e("s_waitcnt vmcnt(0)")
             self.stage_to_lds(St)
             e("s_branch L_montmul")
+
+        if nm_tables:
+            self.number_major_ops(St)
 
         e("L_mulcv:")
         # fixed-base comb: a <- consts[aux + 16*arg + digit], digit = 4-bit window `arg` of this number's exponent
@@ -2180,9 +2185,14 @@ class GenQ3(Gen):
       product   two passes: (a0 b0 | a1 b0 | a2 b0 | a0 b2), then (a0 b1 | a1 b1) with lanes 2, 3 masked off: 12 H^2
                 multiplies in 16 H^2 issue slots, against 18 H^2.
     Multiplier streams come from the LDS column of the staged operand (each lane its own row offset), multiplicand
-    vectors are the lanes' own digits (lane 3 copies the one it needs by DPP).  No inter-wave traffic, no barriers.
+    vectors are the lanes' own digits (lane 3 copies the one it needs by DPP).  No inter-wave traffic; one barrier, after
+    the block has copied the constants to LDS.
+    The constants enter once per pass, not once per row: the accumulators of a pass START at (0 | C1 | C2 | 0) by lane
+    (limb j of the constant is the initial value of column j, which is all the per-row addition ever did), read from a
+    small LDS table [H][4 lanes] of zero-extended limbs.  A hop is then DPP move, T0 -= m (a signed multiply-add with the
+    lane's -1 / 0 mask), quotient digit.
     Slot layout: 3H limbs -- a0 | a1 | a2.  `nmod` points at n (H limbs, padded to an even count) followed by the
-    interleaved pairs (C1_i, C2_i), streamed one pair per row by scalar loads."""
+    interleaved pairs (C1_i, C2_i)."""
 
     def __init__(self, H=74):
         Gen.__init__(self, H, 4)
@@ -2197,7 +2207,9 @@ class GenQ3(Gen):
         self.sq_rows = True
         self.sq_rows_k = False
         self.lds_a = 0
-        self.lds_bytes = (3 * H + 1) * self.NPB * 4
+        self.lds_c = (3 * H + 1) * self.NPB * 4          # constants table: [H][4] zero-extended limbs (0 | C1_j | C2_j | 0)
+        self.lds_bytes = self.lds_c + H * 32
+        assert self.lds_c + H * 32 < 65536                # LDS instruction offsets are 16 bits
         self.vX = 2 * H
         e = 3 * H
         for nm in ["ai", "ain", "m", "t1", "sh", "l1mask", "l2mask", "l12mask", "l3mask"]:
@@ -2208,7 +2220,7 @@ class GenQ3(Gen):
         e += 2
         self.v_d = e          # pair (adjustment, 0)
         e += 2
-        for nm in ["goff", "aread", "awrite", "arow", "t2", "t3", "t4", "koff"]:
+        for nm in ["goff", "aread", "awrite", "arow", "t2", "t3", "t4", "koff", "caddr", "tgoff"]:
             setattr(self, "v_" + nm, e)
             e += 1
         self.v_addr = self.v_arow
@@ -2221,7 +2233,66 @@ class GenQ3(Gen):
         self.n_vgpr = e
         assert e <= 256, e
         self.s_coff = 99
+        self.number_major_tables = True
         self.npad = (H + 1) // 2 * 2    # n occupies an even number of words so that the pairs are 8-byte aligned
+
+    def wide_chunks(self):
+        """(first limb, dwords) pieces covering the H limbs of a digit with the widest loads / stores"""
+        out, j = [], 0
+        while j < self.H:
+            n = 4 if self.H - j >= 4 else 2 if self.H - j >= 2 else 1
+            out.append((j, n))
+            j += n
+        return out
+
+    def number_major_ops(self, St):
+        """Tables that are gathered per number (the windows of per-number exponents) are stored NUMBER-major inside their
+        slots -- [number][3H limbs] instead of [3H limbs][number] -- by STORET, and read back by MULV7: a lane's digit is 4 H
+        contiguous bytes, fetched with 16-byte loads that use every byte of the lines they touch.  (Limb-major, a gather
+        reads one dword per line: neighbouring numbers want different table entries.)"""
+        g, e = self, self.e
+        H = self.H
+        sfx = {4: "x4", 2: "x2", 1: ""}
+        e("L_storet:")
+        self.slot_base()
+        self.mask_digit_lanes(True)
+        for j, n in self.wide_chunks():
+            src = self.X(j) if n == 1 else f"v[{g.vX + j}:{g.vX + j + n - 1}]"
+            e(f"global_store_dword{sfx[n]} v{g.v_tgoff}, {src}, s[{g.s_sbase}:{g.s_sbase + 1}] offset:{4 * j}")
+        e("s_waitcnt vmcnt(0)")
+        self.mask_digit_lanes(False)
+        e("s_branch L_next")
+
+        e("L_mulv7:")
+        # table entry = aux + the 7-bit window `arg` of this number's own exponent (4 windows per 28-bit limb)
+        e(f"s_lshr_b32 s{g.s_t1}, s17, 2")                                 # q = arg / 4
+        e("s_and_b32 s98, s17, 3")
+        e("s_mul_i32 s98, s98, 7")                                         # shift = 7 (arg % 4)
+        e(f"s_mul_hi_u32 s{g.s_sbase + 1}, s{g.s_t1}, s3")                 # digits + q * nb*4
+        e(f"s_mul_i32 s{g.s_sbase}, s{g.s_t1}, s3")
+        e(f"s_add_u32 s{g.s_sbase}, s{g.s_sbase}, s12")
+        e(f"s_addc_u32 s{g.s_sbase + 1}, s{g.s_sbase + 1}, s13")
+        e(f"v_subrev_u32 v{g.v_t2}, {self.lds_a}, v{g.v_aread}")           # gl*4
+        e(f"s_mul_i32 s{g.s_t0}, s2, {self.NPB * 4}")
+        e(f"v_add_u32 v{g.v_t2}, s{g.s_t0}, v{g.v_t2}")                    # g*4
+        e(f"global_load_dword v{g.v_t3}, v{g.v_t2}, s[{g.s_sbase}:{g.s_sbase + 1}]")
+        e("s_waitcnt vmcnt(0)")
+        e(f"v_lshrrev_b32 v{g.v_t3}, s98, v{g.v_t3}")
+        e(f"v_and_b32 v{g.v_t3}, 127, v{g.v_t3}")                          # digit
+        e(f"s_mul_i32 s{g.s_t0}, s3, {self.WT}")                           # slot stride in bytes
+        e(f"v_mul_lo_u32 v{g.v_t3}, v{g.v_t3}, s{g.s_t0}")                  # digit * stride (host guarantees < 2^32)
+        e("s_lshr_b32 s17, s16, 8")                                        # aux = first table slot
+        e(f"s_mul_hi_u32 s{g.s_sbase + 1}, s17, s{g.s_t0}")
+        e(f"s_mul_i32 s{g.s_sbase}, s17, s{g.s_t0}")
+        e(f"s_add_u32 s{g.s_sbase}, s{g.s_sbase}, s10")
+        e(f"s_addc_u32 s{g.s_sbase + 1}, s{g.s_sbase + 1}, s11")
+        e(f"v_add_u32 v{g.v_addr}, v{g.v_t3}, v{g.v_tgoff}")
+        for j, n in self.wide_chunks():
+            dst = St[j] if n == 1 else f"v[{j}:{j + n - 1}]"
+            e(f"global_load_dword{sfx[n]} {dst}, v{g.v_addr}, s[{g.s_sbase}:{g.s_sbase + 1}] offset:{4 * j}")
+        e("s_waitcnt vmcnt(0)")
+        self.stage_to_lds(St)
+        e("s_branch L_montmul")
 
     def set_exec(self, mask4):
         """exec <- the lanes of every quad selected by the 4-bit mask"""
@@ -2261,6 +2332,8 @@ class GenQ3(Gen):
         e(f"v_mul_u32_u24 v{g.v_awrite}, {H * NPB * 4}, v{g.v_t4}")
         e(f"v_add_u32 v{g.v_awrite}, v{g.v_awrite}, v{g.v_aread}")
         e(f"v_mul_u32_u24 v{g.v_koff}, {H * 4}, v{g.v_t4}")
+        e(f"v_mul_u32_u24 v{g.v_tgoff}, {3 * H * 4}, v{g.v_t3}")      # number-major table slots: this lane's digit of number g
+        e(f"v_add_u32 v{g.v_tgoff}, v{g.v_tgoff}, v{g.v_koff}")
         for lane, reg in ((1, g.v_l1mask), (2, g.v_l2mask), (3, g.v_l3mask)):
             e(f"v_cmp_eq_u32 vcc, {lane}, v{g.v_t1}")
             e("s_nop 1")
@@ -2282,15 +2355,33 @@ class GenQ3(Gen):
             else:
                 raise RuntimeError("cannot tile the modulus into SGPR loads")
         e("s_waitcnt lgkmcnt(0)")
-        e(f"s_add_u32 s6, s6, {4 * self.npad}")           # s[6:7] -> the (C1_i, C2_i) pairs
-        e("s_addc_u32 s7, s7, 0")
+        # constants table in LDS: thread t < H copies the pair (C1_t, C2_t) as the four zero-extended limbs of row t
+        e(f"v_lshlrev_b32 v{g.v_caddr}, 3, v{g.v_t1}")    # this lane's column of the table: (lane & 3) * 8
+        e(f"v_cmp_gt_u32 vcc, {H}, v0")
+        e("s_and_saveexec_b64 s[0:1], vcc")
+        e("v_lshlrev_b32 v0, 3, v0")                      # t * 8
+        e(f"global_load_dwordx2 v[2:3], v0, s[6:7] offset:{4 * self.npad}")
+        e("v_lshlrev_b32 v0, 2, v0")                      # t * 32
+        e("v_mov_b32 v4, 0")
+        e("v_mov_b32 v5, 0")
+        e("s_waitcnt vmcnt(0)")
+        e("v_mov_b32 v6, v3")                             # (C2_t, 0)
+        e("v_mov_b32 v7, 0")
+        e("v_mov_b32 v3, 0")                              # (C1_t, 0)
+        e(f"ds_write_b64 v0, v[4:5] offset:{self.lds_c}")
+        e(f"ds_write_b64 v0, v[2:3] offset:{self.lds_c + 8}")
+        e(f"ds_write_b64 v0, v[6:7] offset:{self.lds_c + 16}")
+        e(f"ds_write_b64 v0, v[4:5] offset:{self.lds_c + 24}")
+        e("s_mov_b64 exec, s[0:1]")
+        e("s_waitcnt lgkmcnt(0)")
+        e("s_barrier")
         for j in range(H):
             e(f"v_mov_b32 {self.X(j)}, 0")
 
     def row(self, cur, nxt, link2, use_sh, first=False):
-        """one Montgomery row modulo n in every active lane; s[0:1] <- this row's (C1_i, C2_i); hop 1: lane 1 takes
-        C1_i - m(lane 0) into column 0; hop 2 (link2): lane 2 takes C2_i - m(lane 1).  first: the accumulators are not
-        read (row 0 of a pass: no zeroing of T beforehand)"""
+        """one Montgomery row modulo n in every active lane.  Hop 1: lane 1 takes -m(lane 0) into column 0 (its C1 limb is
+        in the accumulator since the pass began); hop 2 (link2): lane 2 takes -m(lane 1).  first: row 0 of a pass (every
+        accumulator, the top one too, still holds its initial constant)"""
         g, e = self, self.e
         H = self.H
         row = self.NPB * 4
@@ -2299,30 +2390,25 @@ class GenQ3(Gen):
         e("s_waitcnt lgkmcnt(0)")
         e(f"ds_read_b32 v{nxt}, v{g.v_arow}")
         e(f"v_add_u32 v{g.v_arow}, {row}, v{g.v_arow}")
-        e("s_mov_b64 s[0:1], s[100:101]")
-        e(f"s_add_u32 s{g.s_coff}, s{g.s_coff}, 8")
-        e(f"s_load_dwordx2 s[100:101], s[6:7], s{g.s_coff}")
         a = f"v{cur}"
         if use_sh:
             e(f"v_lshlrev_b32 v{cur}, v{g.v_sh}, v{cur}")
         # Column 0 is complete after the FIRST multiply of pass A (only a * x_0 lands in it), so the quotient digit and the
-        # two link hops (each a chain of dependent instructions: multiply, mask, DPP move, subtract, mask, 64-bit add) are
-        # started right away and their steps are spread between the remaining multiplies of pass A: no s_nop for the DPP
-        # hazard, and at one wave per SIMD -- a 16 384-number batch -- nothing waits on a result that is still in flight.
+        # two link hops (each a chain of dependent instructions: multiply, mask, DPP move, signed multiply-add) are started
+        # right away and their steps are spread between the remaining multiplies of pass A: no s_nop for the DPP hazard, and
+        # at one wave per SIMD -- a 16 384-number batch -- nothing waits on a result that is still in flight.
         chain = [f"v_mul_lo_u32 {m}, {self.Tlo(0)}, s14", f"v_and_b32 {m}, {hex(MASK)}, {m}"]
-        for hop, (cs, mask) in enumerate((("s0", g.v_l1mask), ("s1", g.v_l2mask))):
+        for hop, mask in enumerate((g.v_l1mask, g.v_l2mask)):
             if hop == 1 and not link2:
                 break
             chain += [f"v_mov_b32_dpp v{g.v_d}, {m} quad_perm:[0,0,1,2] row_mask:0xf bank_mask:0xf",
-                      f"v_sub_u32 v{g.v_d}, {cs}, v{g.v_d}",
-                      f"v_and_b32 v{g.v_d}, v{g.v_d}, v{mask}",
-                      f"v_lshl_add_u64 {self.T(0)}, {self.T(0)}, 0, {self.P(g.v_d)}",
+                      f"v_mad_i64_i32 {self.T(0)}, vcc, v{g.v_d}, v{mask}, {self.T(0)}",     # T0 -= m of the lane below (mask: -1 / 0)
                       f"v_mul_lo_u32 {m}, {self.Tlo(0)}, s14",
                       f"v_and_b32 {m}, {hex(MASK)}, {m}"]
         gap = min(3, (H - 1) // len(chain))                # multiplies between two steps of the chain (>= 2 covers the DPP hazard)
         assert gap >= 2, "pass A is too short to hide the link chain"
         self.align8()
-        addend = lambda j: "0" if (first or j == H - 1) else self.T(j)
+        addend = lambda j: "0" if (j == H - 1 and not first) else self.T(j)
         self.mad(self.T(0), a, self.X(0), addend(0))
         j = 1
         for step in chain:
@@ -2330,7 +2416,7 @@ class GenQ3(Gen):
                 self.mad(self.T(j), a, self.X(j), addend(j))
                 j += 1
             e(step)
-            if step.startswith("v_mov_b32_dpp") or step.startswith("v_and") or step.startswith("v_sub"):
+            if step.startswith("v_mov_b32_dpp") or step.startswith("v_and"):
                 self.align8()
         while j < H:
             self.mad(self.T(j), a, self.X(j), addend(j))
@@ -2350,16 +2436,15 @@ class GenQ3(Gen):
         g, e = self, self.e
         H = self.H
         row = self.NPB * 4
-        e(f"v_mov_b32 v{g.v_d + 1}, 0")
+        for j in range(H):                                   # accumulators <- (0 | C1_j | C2_j | 0) by lane
+            e(f"ds_read_b64 {self.T(j)}, v{g.v_caddr} offset:{self.lds_c + 32 * j}")
         e(f"v_and_b32 v{g.v_t1}, {(off3 - off012) * row}, v{g.v_l3mask}")
         e(f"v_add_u32 v{g.v_arow}, v{g.v_aread}, v{g.v_t1}")
         if off012:
             e(f"v_add_u32 v{g.v_arow}, {off012 * row}, v{g.v_arow}")
         e(f"ds_read_b32 v{g.v_ain}, v{g.v_arow}")
         e(f"v_add_u32 v{g.v_arow}, {row}, v{g.v_arow}")
-        e(f"s_mov_b32 s{g.s_coff}, 0")
-        e("s_load_dwordx2 s[100:101], s[6:7], 0x0")
-        self.row(g.v_ain, g.v_ai, link2, use_sh, first=True)       # row 0 starts the accumulators: T is never zeroed
+        self.row(g.v_ain, g.v_ai, link2, use_sh, first=True)
         if H % 2:
             e("s_mov_b32 s19, 1")
             ra, rb = g.v_ai, g.v_ain

@@ -19,7 +19,8 @@ enum VmOp : uint32_t {
   VM_SETOFF = 9,  // operand number offset for LOAD/STORE/MUL/ADD <- arg
   VM_MULCV = 10,  // x <- x*consts[aux + 16*arg + window(arg) of this number's exponent]*R^-1  (fixed-base comb table)
   VM_MULV5 = 11,  // MULV with 5-bit windows: `digits` holds the exponents repacked as 25-bit words (5 windows each), 32-entry table
-  VM_MULV7 = 12,  // MULV with 7-bit windows: 4 per 28-bit exponent limb (no repacking), 128-entry table
+  VM_MULV7 = 12,  // MULV with 7-bit windows: 4 per 28-bit exponent limb (no repacking), 128-entry table of NUMBER-major slots
+  VM_STORET = 13, // mem[arg] <- x, number-major inside the slot ([number][WT limbs]): the layout VM_MULV7 gathers from
 };
 
 struct VmSeg {

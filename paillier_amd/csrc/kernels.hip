@@ -75,6 +75,12 @@ __global__ void __launch_bounds__(VM_BLOCK, (3 * WL + 24 <= 256) ? 2 : 1) vm_ker
       for (int j = 0; j < WL; ++j) p[(size_t)j * nb] = x[j];
       continue;
     }
+    if (op == VM_STORET) {  // number-major inside the slot: [number][WT limbs] (tables gathered per number, see VM_MULV7)
+      uint32_t* p = sg.mem + (size_t)arg * WT * nb + (g + goff) * WT + (size_t)k * WL;
+#pragma unroll
+      for (int j = 0; j < WL; ++j) p[j] = x[j];
+      continue;
+    }
     if (op == VM_ADD) {  // lazy limb-wise add; the program must renormalise with a MULC before squaring
       const uint32_t* p = sg.mem + ((size_t)arg * WT + (size_t)k * WL) * nb + g + goff;
 #pragma unroll
@@ -108,14 +114,19 @@ __global__ void __launch_bounds__(VM_BLOCK, (3 * WL + 24 <= 256) ? 2 : 1) vm_ker
         // 5-bit windows of the exponent repacked as 25-bit words (5 windows per word); 32-entry table
         const uint32_t eword = sg.digits[(size_t)(arg / 5u) * nb + g];
         slot = (size_t)(w0 >> 8) + ((eword >> (5u * (arg % 5u))) & 31u);
-      } else if (op == VM_MULV7) {
-        // 7-bit windows, 4 per 28-bit limb; 128-entry table
+      }
+      if (op == VM_MULV7) {
+        // 7-bit windows, 4 per 28-bit limb; 128-entry table whose slots are number-major (written by VM_STORET)
         const uint32_t elimb = sg.digits[(size_t)(arg / 4u) * nb + g];
         slot = (size_t)(w0 >> 8) + ((elimb >> (7u * (arg % 4u))) & 127u);
-      }
-      const uint32_t* p = sg.mem + (slot * WT + (size_t)k * WL) * nb + g + goff;
+        const uint32_t* p = sg.mem + slot * WT * nb + (g + goff) * WT + (size_t)k * WL;
 #pragma unroll
-      for (int j = 0; j < WL; ++j) col[j * NPB] = p[(size_t)j * nb];
+        for (int j = 0; j < WL; ++j) col[j * NPB] = p[j];
+      } else {
+        const uint32_t* p = sg.mem + (slot * WT + (size_t)k * WL) * nb + g + goff;
+#pragma unroll
+        for (int j = 0; j < WL; ++j) col[j * NPB] = p[(size_t)j * nb];
+      }
     }
     montmul<WL, K>(x, s_a + gl, NPB, s_n + k * WL, sg.n0inv, is_first, not_last);
   }
