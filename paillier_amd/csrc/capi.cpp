@@ -654,6 +654,32 @@ struct pgpu_pubkey {
   std::vector<std::pair<int, int>> combine_consts;  // (total servers l, index of (4 (l!)^2)^-1 * R mod n in mn.consts)
 };
 
+// order of the unit group modulo pr^3, split as 2^t m for the Montgomery reduction modulo its odd part
+struct ExpOrder {
+  bool ok = false;
+  BigU ord;
+  ModCtx modd;           // m
+  int t = 0;
+  uint32_t minv = 0;     // m^-1 mod 2^t
+  DevLimbs m_limbs;      // m as w limbs
+  int w = 0;             // limbs of a reduced exponent (< 2 ord)
+  void init(pgpu_ctx* ctx, const BigU& pr) {
+    ord = pr * pr * (pr - BigU(1));
+    t = 0;
+    while (!ord.bit((size_t)t)) ++t;
+    if (t > 20) return;                                  // (k m must stay below 2^48 per limb in the lift kernel)
+    const BigU m = hostbig::shr(ord, (size_t)t);
+    modd.init(ctx, m);
+    modd.upload();
+    uint32_t m0 = m.d[0], x = m0;
+    for (int i = 0; i < 6; ++i) x *= 2u - m0 * x;
+    minv = x & ((1u << t) - 1u);
+    w = (int)((ord.bit_length() + 1 + LB - 1) / LB);
+    m_limbs.set(m, w);
+    ok = true;
+  }
+};
+
 struct pgpu_seckey {
   pgpu_ctx* ctx;
   const pgpu_pubkey* pk;
@@ -695,7 +721,17 @@ struct pgpu_seckey {
   DevLimbs q_limbs, p2_limbs;            // q as mq.WT limbs, p^2 as mp2.WT limbs
   DevLimbs q2_limbs;                     // q^2 as mq2.WT limbs
   DevLimbs tkc_p, ttc_p, tkc_q, ttc_q;   // three-digit kernel constants for the ladders modulo p^3 and q^3 (mp3 / mq3 .triple)
+  ExpOrder eo_p, eo_q;                   // exponent reduction modulo the orders of the units modulo p^3 / q^3
 };
+
+// Exponents of ladders modulo pr^3 can be taken modulo the order of its unit group, ord = pr^2 (pr - 1) = 2^t m: a quarter
+// shorter than the exponents modulo n^2 the DDLEQ prover raises to (the holder of the factorisation only).
+static BigU order_fixup(const BigU& e, const BigU& ord) {
+  if (e < ord) return e;
+  BigU r = e % ord;
+  if (r < BigU(3)) r = r + ord;      // x^e = 0 for a non-unit x and e >= 3: keep the reduced exponent >= 3 as well
+  return r;
+}
 
 // Constants of the pair kernel for a prime of H limbs: its limbs, then Cadj -- the multiple of the prime whose limbs
 // 0..H-1 can all be taken from [2^28, 2^29), so that Cadj - m is limb-wise non-negative for every quotient m < 2^(28 H).
@@ -1736,6 +1772,8 @@ int pgpu_seckey_create(pgpu_ctx* ctx, const pgpu_pubkey* pk, const uint8_t* lamb
                 (size_t)LB * sk->mp3.WT >= sk->mp3.nbits + 3 && (size_t)LB * sk->mq3.WT >= sk->mq3.nbits + 3) {
               setup_triple(sk->mp3, sk->mp, sk->mp2, sk->tkc_p, sk->ttc_p, sk->pinv2k.d, sk->pinv2k_2.d, sk->p_limbs.d, sk->p2_limbs.d);
               setup_triple(sk->mq3, sk->mq, sk->mq2, sk->tkc_q, sk->ttc_q, sk->qinv2k.d, sk->qinv2k_2.d, sk->q_limbs.d, sk->q2_limbs.d);
+              sk->eo_p.init(ctx, p);
+              sk->eo_q.init(ctx, q);
             }
           }
         }
@@ -3211,13 +3249,39 @@ void pow_n3_crt(const pgpu_seckey* sk, const uint32_t* base, int wb, const uint3
         triple_enter(ctx, m3, g + 5 * S, t, 1);
       }
     }
-    Prog pp;
-    if (base2) emit_modexp_dual(pp, we, *e, 0, 1, 2, 3, 5, tab2, 0, win);
-    else if (exps) emit_modexp_perlane(pp, we, 0, NO_SLOT, 2, 3, 5, NO_SLOT, 0, win);
-    else emit_modexp_shared(pp, *e, 0, NO_SLOT, 2, 3, 5, NO_SLOT, true, true);
-    pp.end();
-    if (exps) exps = triple_windows(ctx, exps, we, nb, win);
-    SegSpec sp{&mp3, &pp, tp.mem, exps}, sq{&mq3, &pp, tq.mem, exps};
+    // Exponents modulo the orders of the unit groups of p^3 and q^3 (a quarter shorter than exponents modulo n^2): each half
+    // gets its own reduced exponents and its own program.  PGPU_EXP_ORDER=0 (experiments) keeps the exponents as given.
+    static const bool order_on = [] { const char* v = getenv("PGPU_EXP_ORDER"); return v ? atoi(v) != 0 : true; }();
+    const bool reduce_e = order_on && sk->eo_p.ok && sk->eo_q.ok;
+    const uint32_t* ex[2] = {exps, exps};
+    int wex[2] = {we, we};
+    BigU es[2];
+    if (e) es[0] = es[1] = *e;
+    for (int half = 0; half < 2 && reduce_e; ++half) {
+      const ExpOrder& eo = half ? sk->eo_q : sk->eo_p;
+      if (exps && (size_t)we * LB > eo.ord.bit_length() + LB && we <= 2 * eo.modd.WT) {
+        uint32_t* em = ctx->ws_t<uint32_t>((size_t)eo.modd.WT * nb);
+        reduce_mod(ctx, eo.modd, exps, we, em, nb);
+        uint32_t* er = ctx->ws_t<uint32_t>((size_t)eo.w * nb);
+        launch_exp_order_lift(exps, we, em, eo.modd.WT, eo.m_limbs.d, eo.t, eo.minv, er, eo.w, nb, ctx->stream);
+        ex[half] = er;
+        wex[half] = eo.w;
+      }
+      if (e) {
+        const BigU r = order_fixup(*e, eo.ord);
+        if (r.bit_length() >= 64) es[half] = r;
+      }
+    }
+    Prog pp, pq;
+    for (int half = 0; half < 2; ++half) {
+      Prog& pr = half ? pq : pp;
+      if (base2) emit_modexp_dual(pr, wex[half], es[half], 0, 1, 2, 3, 5, tab2, 0, win);
+      else if (exps) emit_modexp_perlane(pr, wex[half], 0, NO_SLOT, 2, 3, 5, NO_SLOT, 0, win);
+      else emit_modexp_shared(pr, es[half], 0, NO_SLOT, 2, 3, 5, NO_SLOT, true, true);
+      pr.end();
+    }
+    SegSpec sp{&mp3, &pp, tp.mem, ex[0] ? triple_windows(ctx, ex[0], wex[0], nb, win) : nullptr},
+            sq{&mq3, &pq, tq.mem, ex[1] ? triple_windows(ctx, ex[1], wex[1], nb, win) : nullptr};
     sp.pair = mp3.triple.kconsts; sp.pair_n0inv = sk->mp.n0inv; sp.pair_h = tp.H; sp.pair_lanes = 3; sp.tconsts = mp3.triple.tconsts;
     sq.pair = mq3.triple.kconsts; sq.pair_n0inv = sk->mq.n0inv; sq.pair_h = tq.H; sq.pair_lanes = 3; sq.tconsts = mq3.triple.tconsts;
     run_vm(ctx, nb, sp, &sq, true);

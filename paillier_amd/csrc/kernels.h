@@ -82,3 +82,7 @@ void launch_clear_where(const int32_t* flags, size_t count, int32_t* ok, hipStre
 void launch_gather_rows(const uint32_t* table, int w, const int32_t* idx, size_t count, uint32_t* out, size_t nb, hipStream_t st);
 // per-number exponents as 28-bit limbs [we][nb] -> 25-bit words [we5][nb] (5 windows of 5 bits per word), for VM_MULV5
 void launch_repack_windows5(const uint32_t* in, int we, uint32_t* out, int we5, size_t nb, hipStream_t st);
+// out (wo limbs) = e mod 2^t m given em = e mod m (m odd, wo limbs, zero padded; minv = m^-1 mod 2^t); + the order when the
+// result fell below 3 although e did not (keeps x^e = 0 for non-unit x)
+void launch_exp_order_lift(const uint32_t* e, int we, const uint32_t* em, int wm, const uint32_t* m, int t, uint32_t minv,
+                           uint32_t* out, int wo, size_t nb, hipStream_t st);

@@ -983,6 +983,42 @@ void launch_clear_where(const int32_t* flags, size_t count, int32_t* ok, hipStre
 void launch_gather_rows(const uint32_t* table, int w, const int32_t* idx, size_t count, uint32_t* out, size_t nb, hipStream_t st) {
   hipLaunchKernelGGL(k_gather_rows, HELPER_GRID(nb), 0, st, table, w, idx, count, out, nb);
 }
+// Exponent reduction modulo the group order ord = 2^t m (m odd) once e mod m is known (Montgomery needs the odd part):
+//   out = em + m k,  k = (e - em) m^-1 mod 2^t   (the CRT lift: out = e mod ord),
+// and out += ord when that left an exponent below 3 although e itself was larger: x^e of a NON-unit x (a multiple of the
+// prime) is 0 for e >= 3 and must stay so, and for units adding the order changes nothing.
+__global__ void k_exp_order_lift(const uint32_t* __restrict__ e, int we, const uint32_t* __restrict__ em, int wm,
+                                 const uint32_t* __restrict__ m, int t, uint32_t minv, uint32_t* __restrict__ out, int wo,
+                                 size_t nb) {
+  size_t g = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (g >= nb) return;
+  const uint32_t tmask = (1u << t) - 1u;
+  const uint32_t k = ((e[g] - em[g]) * minv) & tmask;
+  uint64_t acc = 0;
+  bool small = true, same = true;
+  for (int i = 0; i < wo; ++i) {
+    acc += (i < wm ? em[(size_t)i * nb + g] : 0u) + (uint64_t)m[i] * k;
+    const uint32_t v = (uint32_t)acc & LMASK;
+    acc >>= LB;
+    out[(size_t)i * nb + g] = v;
+    small = small && (i == 0 ? v < 3u : v == 0u);
+    same = same && (i < we ? e[(size_t)i * nb + g] == v : v == 0u);
+  }
+  for (int i = wo; i < we; ++i) same = same && e[(size_t)i * nb + g] == 0u;
+  if (small && !same) {
+    acc = 0;
+    for (int i = 0; i < wo; ++i) {
+      acc += out[(size_t)i * nb + g] + ((uint64_t)m[i] << t);
+      out[(size_t)i * nb + g] = (uint32_t)acc & LMASK;
+      acc >>= LB;
+    }
+  }
+}
+void launch_exp_order_lift(const uint32_t* e, int we, const uint32_t* em, int wm, const uint32_t* m, int t, uint32_t minv,
+                           uint32_t* out, int wo, size_t nb, hipStream_t st) {
+  hipLaunchKernelGGL(k_exp_order_lift, HELPER_GRID(nb), 0, st, e, we, em, wm, m, t, minv, out, wo, nb);
+}
+
 void launch_repack_windows5(const uint32_t* in, int we, uint32_t* out, int we5, size_t nb, hipStream_t st) {
   hipLaunchKernelGGL(k_repack_windows5, HELPER_GRID(nb), 0, st, in, we, out, we5, nb);
 }
