@@ -263,6 +263,7 @@ def main():
 
     def timed(fn, steps):
         fn()
+        fn()    # (a call that grew the library's workspace is followed by one that may consolidate it: both are warm-up)
         torch.cuda.synchronize()
         ms, mads, kern = [], 0.0, ""
         t = time.perf_counter()

@@ -102,7 +102,11 @@ struct pgpu_ctx {
     bytes = round_up(bytes ? bytes : 1, 256);
     for (auto& c : chunks)
       if (c.cap - c.used >= bytes) { void* p = c.p + c.used; c.used += bytes; return p; }
-    Chunk c{nullptr, round_up(bytes, 64 << 20), bytes};
+    // geometric growth (a new chunk is at least as large as everything before it, up to 8 GiB): the list stays short, so
+    // the consolidation in reset_ws() -- a free and a multi-GiB hipMalloc inside some later call -- stays rare
+    size_t total = 0;
+    for (auto& k : chunks) total += k.cap;
+    Chunk c{nullptr, std::max(round_up(bytes, 64 << 20), std::min<size_t>(total, (size_t)8 << 30)), bytes};
     HIPCHK(hipMalloc((void**)&c.p, c.cap));
     chunks.push_back(c);
     return c.p;
@@ -1913,6 +1917,50 @@ uint32_t* decrypt1_crt(const pgpu_seckey* sk, const uint32_t* c_limbs, size_t nb
 }
 
 
+// base^e mod n for a holder of the factorisation: ladders modulo p and q (half the width, exponents modulo p - 1 and
+// q - 1) in one two-segment launch, then Garner as in decrypt1_crt.  base: canonical, mn.WT limbs.  Returns mn.WT limbs.
+uint32_t* pow_n_crt(const pgpu_seckey* sk, const uint32_t* base, const BigU& e, size_t nb) {
+  pgpu_ctx* ctx = sk->ctx;
+  const ModCtx &mp = sk->mp, &mq = sk->mq;
+  const int W1 = mp.WT, WN = sk->pk->mn.WT;
+  const size_t S1 = (size_t)W1 * nb;
+  // slots per half: 0 in, 2 tmp, 3 out, 5..36 table
+  uint32_t *memp = ctx->ws_t<uint32_t>(S1 * 37), *memq = ctx->ws_t<uint32_t>(S1 * 37);
+  reduce_mod(ctx, mp, base, WN, memp, nb);
+  reduce_mod(ctx, mq, base, WN, memq, nb);
+  auto half_exp = [&](const BigU& pr) {
+    const BigU ord = pr - BigU(1);
+    BigU r = e % ord;
+    if (r.is_zero() && !e.is_zero()) r = ord;       // 0^e stays 0 for a base that is a multiple of the prime
+    return r;
+  };
+  Prog pp, pq;
+  emit_modexp_shared(pp, half_exp(sk->p), 0, NO_SLOT, 2, 3, 5, NO_SLOT, true);
+  pp.end();
+  emit_modexp_shared(pq, half_exp(sk->q), 0, NO_SLOT, 2, 3, 5, NO_SLOT, true);
+  pq.end();
+  SegSpec sp{&mp, &pp, memp, nullptr}, sq{&mq, &pq, memq, nullptr};
+  run_vm(ctx, nb, sp, &sq, true);
+  // small memory: 2 x_p, 3 x_q, 4 B, 5 A, 6 h
+  uint32_t* m1 = ctx->ws_t<uint32_t>(S1 * 7);
+  HIPCHK(hipMemcpyAsync(m1 + 2 * S1, memp + 3 * S1, S1 * 4, hipMemcpyDeviceToDevice, ctx->stream));
+  HIPCHK(hipMemcpyAsync(m1 + 3 * S1, memq + 3 * S1, S1 * 4, hipMemcpyDeviceToDevice, ctx->stream));
+  launch_canon(m1 + 2 * S1, mp.d_nmod, W1, nb, ctx->stream);     // one integer x_p in both places it is used
+  launch_canon(m1 + 3 * S1, mq.d_nmod, W1, nb, ctx->stream);
+  Prog c;
+  c.op(VM_LOAD, 2); c.op(VM_MULC, (uint32_t)sk->c_pinvR); c.op(VM_STORE, 4);           // B = x_p * p^-1 mod q
+  c.op(VM_LOAD, 3); c.op(VM_MULC, (uint32_t)sk->c_pinvR); c.op(VM_STORE, 5);           // A = x_q * p^-1 mod q
+  c.end();
+  SegSpec sc{&mq, &c, m1, nullptr};
+  run_vm(ctx, nb, sc, nullptr, false);
+  launch_canon(m1 + 4 * S1, mq.d_nmod, W1, nb, ctx->stream);
+  launch_canon(m1 + 5 * S1, mq.d_nmod, W1, nb, ctx->stream);
+  launch_sub_mod(m1 + 5 * S1, m1 + 4 * S1, mq.d_nmod, m1 + 6 * S1, W1, nb, ctx->stream);  // h = A - B mod q
+  uint32_t* res = ctx->ws_t<uint32_t>((size_t)WN * nb);
+  launch_mul_const_add(m1 + 6 * S1, W1, sk->p_limbs.d, W1, m1 + 2 * S1, W1, 0, res, WN, nb, ctx->stream);   // x_p + p h
+  return res;
+}
+
 // The reference's L(u, n) = Div(u - 1, n) (paillier.go:436-440; Euclidean: floor for u >= 1 and -1 for u = 0) for a
 // canonical u of `wu` limbs: floor((u-1)/n) = ((u-1) - ((u-1) mod n)) / n -- Montgomery reductions mod n plus one
 // exact division.  Returns the quotient (wq limbs: mn.WT for u < n^2, mn2.WT for u < n^3); zf[g] = (u == 0), for which
@@ -3492,11 +3540,23 @@ int pgpu_ddleq_prove(const pgpu_seckey* sk, size_t batch, const uint8_t* ct1, co
       uint32_t* z2 = ctx->ws_t<uint32_t>((size_t)W2 * nbg);
       reduce_mod(ctx, mn2, z, W3, z2, nbg);
       uint32_t* sres = ctx->ws_t<uint32_t>((size_t)W1 * nbg);
-      shared_pow(ctx, mn, z2, W2, ns_inv, nbg, sres);                          // z^nsInv mod n
+      if (sk->has_crt && sk->mp.WT * 2 == W1) {                                // z^nsInv mod n through p and q
+        uint32_t* z1 = ctx->ws_t<uint32_t>((size_t)W1 * nbg);
+        reduce_mod(ctx, mn, z2, W2, z1, nbg);
+        sres = pow_n_crt(sk, z1, ns_inv, nbg);
+      } else {
+        shared_pow(ctx, mn, z2, W2, ns_inv, nbg, sres);                        // z^nsInv mod n
+      }
       uint32_t* s3 = zext(ctx, sres, W1, W3, nbg);
       // c = ((s^an * b)^en)^-1 * s^xn ; f = y * c mod n^3   (ddleq.go:103-114)
+      // en = e^n mod n^2 (ddleq.go:104) = (x a^-1)^n = x^n (a^n)^-1: both powers are at hand, so an inversion replaces the ladder
       uint32_t* en = ctx->ws_t<uint32_t>((size_t)W2 * nbg);
-      shared_pow(ctx, mn2, ge, W2, N, nbg, en);
+      {
+        uint32_t* an1 = ctx->ws_t<uint32_t>((size_t)W2 * nbg);
+        launch_restride(gan, nbg, cnt, mn2.d_consts + (size_t)C_ONE * W2, an1, nbg, W2, ctx->stream);   // padding lanes: 1
+        uint32_t* ani = batch_inverse(ctx, mn2, an1, nbg, cnt);
+        modmul_arrays(ctx, mn2, gxn, ani, nbg, en);
+      }
       uint32_t* cc = ctx->ws_t<uint32_t>((size_t)W3 * nbg);
       uint32_t* sx = ctx->ws_t<uint32_t>((size_t)W3 * nbg);
       {
