@@ -1961,6 +1961,84 @@ uint32_t* pow_n_crt(const pgpu_seckey* sk, const uint32_t* base, const BigU& e, 
   return res;
 }
 
+// base^e mod n^2 for a holder of the factorisation (base < n, canonical, mn.WT limbs): both halves -- modulo p^2 and q^2,
+// exponents modulo p (p-1) and q (q-1) -- in pair form on the pair kernel in ONE two-segment launch (the ladder of the
+// headline Decrypt with another exponent), then Garner in Z_{q^2}.  Returns mn2.WT canonical limbs.
+bool pow_n2_crt_usable(const pgpu_seckey* sk) {
+  pgpu_ctx* ctx = sk->ctx;
+  return sk->has_pair && sk->has_crt2 && sk->c_rh_p2 >= 0 && sk->c_p2invR >= 0 && ctx->use_asm && ctx->use_pair &&
+         sk->pk->mn.WT == sk->mp2.WT && sk->pk->mn2.WT == 2 * sk->mp2.WT;
+}
+uint32_t* pow_n2_crt(const pgpu_seckey* sk, const uint32_t* base, const BigU& e, size_t nb) {
+  pgpu_ctx* ctx = sk->ctx;
+  const int H = sk->mp.WT, W2 = sk->mp2.WT, WN2 = sk->pk->mn2.WT;
+  const size_t S1 = (size_t)H * nb, S2 = (size_t)W2 * nb;
+  uint32_t* xh[2];
+  uint32_t* mem[2];
+  Prog lad[2];
+  for (int half = 0; half < 2; ++half) {
+    const ModCtx &m1 = half ? sk->mq : sk->mp, &m2 = half ? sk->mq2 : sk->mp2;
+    const BigU& pr = half ? sk->q : sk->p;
+    // slots (W2 limbs): 0 x, 2 pair form in, 3 out, 5..36 table
+    uint32_t* mm = mem[half] = ctx->ws_t<uint32_t>(S2 * 37);
+    reduce_mod(ctx, m2, base, sk->pk->mn.WT, mm, nb);
+    Prog a;                                                             // X = x R_H mod prime^2
+    a.op(VM_LOAD, 0); a.op(VM_MULC, C_R2); a.op(VM_MULC, (uint32_t)(half ? sk->c_rh_q2 : sk->c_rh_p2)); a.op(VM_STORE, 3); a.end();
+    SegSpec sa{&m2, &a, mm, nullptr};
+    run_vm(ctx, nb, sa, nullptr, false);
+    launch_canon(mm + 3 * S2, m2.d_nmod, W2, nb, ctx->stream);
+    uint32_t* x0 = ctx->ws_t<uint32_t>(S1);                             // digits X = X0 + X1 prime -> slot 2
+    uint32_t* tb = ctx->ws_t<uint32_t>(S2);
+    reduce_mod(ctx, m1, mm + 3 * S2, W2, x0, nb);
+    launch_div_exact(mm + 3 * S2, W2, 0, x0, H, tb, (half ? sk->qinv2k : sk->pinv2k).d, m1.d_nmod, H, mm + 2 * S2 + S1, H, nb, nb,
+                     nullptr, 0, ctx->stream);
+    HIPCHK(hipMemcpyAsync(mm + 2 * S2, x0, S1 * 4, hipMemcpyDeviceToDevice, ctx->stream));
+    const BigU ord = pr * (pr - BigU(1));
+    BigU eh = e;
+    if (!(e < ord)) {
+      eh = e % ord;
+      if (eh < BigU(2)) eh = eh + ord;     // x^e = 0 modulo prime^2 for a multiple of the prime and e >= 2: keep it so
+    }
+    if (eh.bit_length() < 64) eh = e;
+    emit_modexp_shared(lad[half], eh, 2, NO_SLOT, 2, 3, 5, NO_SLOT, true, true);
+    lad[half].end();
+  }
+  {
+    SegSpec sp{&sk->mp2, &lad[0], mem[0], nullptr}, sq{&sk->mq2, &lad[1], mem[1], nullptr};
+    sp.pair = sk->pair_p.d; sp.pair_n0inv = sk->mp.n0inv; sp.pair_h = H; sp.pair_lanes = sk->pair_lanes;
+    sq.pair = sk->pair_q.d; sq.pair_n0inv = sk->mq.n0inv; sq.pair_h = H; sq.pair_lanes = sk->pair_lanes;
+    run_vm(ctx, nb, sp, &sq, true);
+  }
+  for (int half = 0; half < 2; ++half) {
+    const ModCtx& m2 = half ? sk->mq2 : sk->mp2;
+    uint32_t* mm = mem[half];
+    // F~ = F0 + F1 prime, then out of pair and Montgomery form
+    launch_mul_const_add(mm + 3 * S2 + S1, H, (half ? sk->q_limbs1 : sk->p_limbs).d, H, mm + 3 * S2, H, 0, mm + 2 * S2, W2, nb, ctx->stream);
+    Prog a;
+    a.op(VM_LOAD, 2); a.op(VM_MULC, (uint32_t)(half ? sk->c_rh_q2 : sk->c_rh_p2)); a.op(VM_STORE, 3); a.end();
+    SegSpec sa{&m2, &a, mm, nullptr};
+    run_vm(ctx, nb, sa, nullptr, false);
+    launch_canon(mm + 3 * S2, m2.d_nmod, W2, nb, ctx->stream);
+    xh[half] = mm + 3 * S2;
+  }
+  // Garner: x = x_p + p^2 ((x_q - x_p) p^-2 mod q^2); slots: 0 x_p, 1 x_q, 2 B, 3 A, 4 h
+  uint32_t* g = ctx->ws_t<uint32_t>(S2 * 5);
+  HIPCHK(hipMemcpyAsync(g, xh[0], S2 * 4, hipMemcpyDeviceToDevice, ctx->stream));
+  HIPCHK(hipMemcpyAsync(g + S2, xh[1], S2 * 4, hipMemcpyDeviceToDevice, ctx->stream));
+  Prog c;
+  c.op(VM_LOAD, 0); c.op(VM_MULC, (uint32_t)sk->c_p2invR); c.op(VM_STORE, 2);
+  c.op(VM_LOAD, 1); c.op(VM_MULC, (uint32_t)sk->c_p2invR); c.op(VM_STORE, 3);
+  c.end();
+  SegSpec sc{&sk->mq2, &c, g, nullptr};
+  run_vm(ctx, nb, sc, nullptr, false);
+  launch_canon(g + 2 * S2, sk->mq2.d_nmod, W2, nb, ctx->stream);
+  launch_canon(g + 3 * S2, sk->mq2.d_nmod, W2, nb, ctx->stream);
+  launch_sub_mod(g + 3 * S2, g + 2 * S2, sk->mq2.d_nmod, g + 4 * S2, W2, nb, ctx->stream);
+  uint32_t* res = ctx->ws_t<uint32_t>((size_t)WN2 * nb);
+  launch_mul_const_add(g + 4 * S2, W2, sk->p2_limbs.d, W2, g, W2, 0, res, WN2, nb, ctx->stream);
+  return res;
+}
+
 // The reference's L(u, n) = Div(u - 1, n) (paillier.go:436-440; Euclidean: floor for u >= 1 and -1 for u = 0) for a
 // canonical u of `wu` limbs: floor((u-1)/n) = ((u-1) - ((u-1) mod n)) / n -- Montgomery reductions mod n plus one
 // exact division.  Returns the quotient (wq limbs: mn.WT for u < n^2, mn2.WT for u < n^3); zf[g] = (u == 0), for which
@@ -3455,8 +3533,13 @@ int pgpu_ddleq_prove(const pgpu_seckey* sk, size_t batch, const uint8_t* ct1, co
     uint32_t* xn = ctx->ws_t<uint32_t>((size_t)W2 * nb);
     {
       uint32_t* ax = concat2(ctx, al, xl, W1, nb);
-      uint32_t* axn = ctx->ws_t<uint32_t>((size_t)W2 * 2 * nb);
-      shared_pow(ctx, mn2, ax, W1, N, 2 * nb, axn);
+      uint32_t* axn;
+      if (pow_n2_crt_usable(sk)) {
+        axn = pow_n2_crt(sk, ax, N, 2 * nb);                 // the prover holds p and q
+      } else {
+        axn = ctx->ws_t<uint32_t>((size_t)W2 * 2 * nb);
+        shared_pow(ctx, mn2, ax, W1, N, 2 * nb, axn);
+      }
       split2(ctx, axn, 0, W2, nb, an);
       split2(ctx, axn, 1, W2, nb, xn);
     }
