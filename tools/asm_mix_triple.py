@@ -1,0 +1,67 @@
+#!/usr/bin/env python3
+"""Instruction mix of the three-digit kernel vm_asm_74_48 (level-two Encrypt / NestedRandomize / DDLEQ), counted from the
+generator's own output: issue slots per squaring and per product (loop bodies times their trip counts).  At one wave per
+SIMD every instruction -- scalar, LDS and waits included -- takes an issue slot of its own."""
+import os, sys, re, json, collections
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, "paillier_amd", "csrc"))
+import gen_vm_asm
+
+H = int(sys.argv[1]) if len(sys.argv) > 1 else 74
+lines = gen_vm_asm.make_gen(H, 48).generate().splitlines()
+
+
+def classify(seg):
+    c = collections.Counter()
+    for ln in seg:
+        ln = ln.strip()
+        if not ln or ln.endswith(":") or ln.startswith(".") or ln.startswith("//") or ln.startswith(";"):
+            continue
+        op = ln.split()[0]
+        if op in ("v_mad_u64_u32",):
+            c["mad"] += 1
+        elif op.startswith("v_"):
+            c["valu_other"] += 1
+        elif op.startswith("ds_"):
+            c["lds"] += 1
+        elif op in ("s_waitcnt", "s_nop"):
+            c["wait"] += 1
+        elif op.startswith("s_"):
+            c["salu"] += 1
+    return c
+
+
+def find(label):
+    return next(i for i, l in enumerate(lines) if l.strip() == label + ":")
+
+
+def region(start, end_label_branch):
+    """dynamic counts of the code from `start` to the first `s_branch L_next` after it; loops L_q* run (H - peeled)/2 times"""
+    i = find(start)
+    j = next(k for k in range(i, len(lines)) if lines[k].strip() == "s_branch L_next")
+    tot = collections.Counter()
+    k = i
+    while k < j:
+        m = re.match(r"^(L_q\w+):", lines[k].strip())
+        if m:
+            lbl = m.group(1)
+            e = next(x for x in range(k, j) if lines[x].strip() == f"s_cbranch_scc1 {lbl}")
+            trips = (H - (1 if H % 2 else 2)) // 2
+            body = classify(lines[k:e + 1])
+            for key, v in body.items():
+                tot[key] += v * trips
+            k = e + 1
+        else:
+            for key, v in classify([lines[k]]).items():
+                tot[key] += v
+            k += 1
+    return tot
+
+
+out = {}
+for name, lbl, useful in (("squaring", "L_montsq", 8 * H * H / 4), ("product", "L_montmul", 12 * H * H / 4)):
+    t = region(lbl, None)
+    slots = sum(t.values())
+    out[name] = dict(t, issue_slots=slots, valu=t["mad"] + t["valu_other"], counted_mads_per_lane=useful,
+                     counted_share_of_issue_slots=round(useful / slots, 4), mad_share_of_valu=round(t["mad"] / (t["mad"] + t["valu_other"]), 4))
+print(json.dumps({"kernel": f"vm_asm_{H}_48", **out}, indent=1))
