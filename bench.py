@@ -497,7 +497,7 @@ def main():
     alg_bytes = cb + pb  # read c (n^2 bytes) + write m (n bytes)
     what = {2048: "pair kernel: x^(p-1) mod p^2 and x^(q-1) mod q^2 ladders, both halves in one launch",
             1024: "CRT modexp over p^2 and q^2",
-            3072: "two-lane pair kernel: ladders modulo p^2 and q^2, both halves in one launch"}[args.bits]
+            3072: "one-lane pair kernel (quotient digits in LDS, multiplier digits streamed): ladders modulo p^2 and q^2, both halves in one launch"}[args.bits]
     roofline = {
         "bound": "valu",  # integer multiply issue (v_mad_u64_u32); neither HBM nor MFMA binds
         "kernel": f"{prof['kernel']} ({what})",

@@ -1693,7 +1693,7 @@ int pgpu_seckey_create(pgpu_ctx* ctx, const pgpu_pubkey* pk, const uint8_t* lamb
         sk->qinv2k.set(inv_mod_pow2(q, (size_t)LB * sk->mq.WT), sk->mq.WT);
         sk->p_limbs.set(p, sk->mp.WT);
         sk->q_limbs1.set(q, sk->mq.WT);
-        const int pair_tag = vm_asm_available(sk->mp.WT, 16) && sk->mp2.K == 1 ? 16 : 32;
+        const int pair_tag = vm_asm_available(sk->mp.WT, 16) ? 16 : 32;   // one lane per number (GenP: 37 limbs, GenP2: 55)
         if (sk->mp.K == 1 && sk->mp2.WT == 2 * sk->mp.WT && vm_asm_available(sk->mp.WT, pair_tag)) {
           sk->pair_lanes = pair_tag == 16 ? 1 : 2;
           sk->pair_small2 = sk->pair_lanes == 1 && vm_asm_available(sk->mp.WT, 32);   // two-lane variant for small batches

@@ -1664,6 +1664,381 @@ class GenP(Gen):
         return "\n".join(self.lines) + "\n"
 
 
+class GenP2(GenP):
+    """One-lane pair kernel for primes too wide for GenP's register map (H = 55 limbs: the CRT halves p^2, q^2 of 3072-bit
+    keys).  Same arithmetic and the same digits as GenP -- a squaring is 3.5 H^2 multiplies, a product 5 H^2, where the
+    two-lane kernel (GenQ) issues 4 H^2 and 8 H^2 -- but 5 H registers of operands and accumulators plus H quotient digits
+    do not fit 256 VGPRs (two waves per SIMD) at H = 55, and neither does GenP's LDS staging of both multiplier streams
+    (2H + 1 words per lane: 113 KB per block).  What moves:
+      * the quotient digits m_i of phase 1 go to the lane's LDS column (one ds_write per row, no VALU slot) and come back as
+        the seeds Cadj_j - m_j of phase 2; Cadj sits in an LDS table the block fills once (p alone takes 55 SGPRs);
+      * a squaring stores its doubled multipliers 2 a0_k over the same LDS words at the phase boundary, where the new a0
+        replaces the old one -- H + 1 words per lane in all: 56.5 KB per block, two blocks per CU;
+      * a product streams its multiplier digits b0_i, b1_i straight from memory (slot, constant) through two rings of five
+        registers, four rows ahead of their use (vmcnt-counted), and parks the new a0 in the LDS column until phase 2,
+        which still multiplies by the old one, has finished.  Both phases of a product are loops of five-row bodies.
+    VGPRs: T 2H | a0 H | a1 H | 29 others = 249."""
+
+    RB = 5   # rows per loop body of a product = registers per multiplier ring
+    PD = 4   # rows between a multiplier's load and its use
+
+    def __init__(self, H=55):
+        assert H % 2 == 1 and H % self.RB == 0 and H > 2 * self.RB
+        self.H = H
+        self.WL = self.WT = 2 * H
+        self.K = 1
+        self.NPB = BLOCK
+        self.depth = 8
+        self.lines, self.deferred = [], []
+        self.name = f"vm_asm_{H}_16"
+        self.sq_rows, self.sq_rows_k, self.sq_self_staged = True, False, True
+        self.n_sgpr, self.n_vreg, self.flush = True, False, False
+        self.vX = 2 * H
+        e = 4 * H
+        for nm in ["ai", "ain", "m", "t1", "t2", "t3", "t4", "goff", "aread", "arow", "mrow", "zero", "vb"]:
+            setattr(self, "v_" + nm, e)
+            e += 1
+        self.v_awrite, self.v_addr, self.v_koff = self.v_aread, self.v_arow, self.v_zero
+        self.ring0 = list(range(e, e + self.RB))
+        e += self.RB
+        self.ring1 = list(range(e, e + self.RB))
+        e += self.RB
+        e = (e + 1) // 2 * 2
+        self.v_y0 = e
+        e += 2
+        self.v_c = self.v_p1 = e
+        e += 2
+        self.n_vgpr = e
+        assert e <= 256, f"VGPR budget exceeded: {e}"
+        self.s_N = 20
+        assert self.s_N + H <= 76
+        self.s_b0, self.s_b1, self.s_bstride, self.s_bstart = 76, 78, 80, 82
+        self.s_sbase = 94
+        self.s_t0, self.s_t1 = 96, 97
+        self.n_sgpr_count = 102
+        self.lds_n = 0
+        self.lds_a = (H * 4 + 255) // 256 * 256            # Cadj table first, then the lanes' columns [H + 1][256]
+        self.lds_bytes = self.lds_a + (H + 1) * BLOCK * 4
+        self.row = BLOCK * 4
+
+    # ---------------------------------------------------------------------------------------------
+    def prologue(self):
+        g, e, H = self, self.e, self.H
+        e('.amdgcn_target "amdgcn-amd-amdhsa--gfx950"')
+        e(".text")
+        e(f".globl {self.name}")
+        e(".p2align 8")
+        e(f".type {self.name},@function")
+        e(f"{self.name}:")
+        self.select_segment()
+        e("s_load_dwordx8 s[4:11], s[0:1], 0x0")    # prog, nmod, consts, mem
+        e("s_load_dwordx4 s[12:15], s[0:1], 0x20")  # digits, n0inv, nb
+        e("s_waitcnt lgkmcnt(0)")
+        e("s_lshl_b32 s3, s15, 2")                  # byte stride between limb rows
+        e(f"s_lshl_b32 s{g.s_t0}, s2, 8")
+        e(f"v_add_lshl_u32 v{g.v_goff}, s{g.s_t0}, v0, 2")      # (blk * 256 + lane) * 4
+        e(f"v_lshlrev_b32 v{g.v_aread}, 2, v0")
+        e(f"v_add_u32 v{g.v_aread}, {self.lds_a}, v{g.v_aread}")
+        e(f"v_mov_b32 v{g.v_zero}, 0")
+        off, s, rem = 0, self.s_N, H                            # p -> SGPRs
+        while rem > 0:
+            for cnt in (16, 8, 4, 2, 1):
+                align = 4 if cnt >= 4 else cnt
+                if cnt <= rem and s % align == 0:
+                    if cnt == 1:
+                        e(f"s_load_dword s{s}, s[6:7], {hex(off)}")
+                    else:
+                        e(f"s_load_dwordx{cnt} s[{s}:{s + cnt - 1}], s[6:7], {hex(off)}")
+                    off += 4 * cnt
+                    s += cnt
+                    rem -= cnt
+                    break
+            else:
+                raise RuntimeError("cannot tile the modulus into SGPR loads")
+        e(f"v_lshlrev_b32 v{g.v_t3}, 2, v0")                    # Cadj -> LDS words [0, H)
+        e(f"v_cmp_gt_u32 vcc, {H}, v0")
+        e("s_nop 1")
+        e("s_and_saveexec_b64 s[96:97], vcc")
+        e(f"global_load_dword v{g.v_t1}, v{g.v_t3}, s[6:7] offset:{H * 4}")
+        e("s_waitcnt vmcnt(0)")
+        e(f"ds_write_b32 v{g.v_t3}, v{g.v_t1}")
+        e("s_waitcnt lgkmcnt(0)")
+        e("s_mov_b64 exec, s[96:97]")
+        e("s_waitcnt lgkmcnt(0)")
+        e("s_barrier")
+        for j in range(2 * H):
+            e(f"v_mov_b32 {self.X(j)}, 0")
+
+    def dispatcher(self):
+        g, e, H = self, self.e, self.H
+        Xs = [self.X(j) for j in range(2 * H)]
+        St = [f"v{j}" for j in range(2 * H)]
+        M = hex(MASK)
+        e("L_next:")
+        e("s_load_dwordx2 s[16:17], s[4:5], 0x0")
+        e("s_add_u32 s4, s4, 8")
+        e("s_addc_u32 s5, s5, 0")
+        e("s_waitcnt lgkmcnt(0)")
+        e("s_and_b32 s18, s16, 0xff")
+        for nm in ("SQR", "MUL", "MULC", "LOAD", "STORE", "LOADC", "ADD"):
+            e(f"s_cmp_eq_u32 s18, {OPS[nm]}")
+            e(f"s_cbranch_scc1 L_{nm.lower()}")
+        e("s_endpgm")  # END (the host sends this kernel shared-exponent ladders only: no per-number table opcodes)
+
+        e("L_load:")
+        self.slot_base()
+        self.load_slot_into(Xs)
+        e("s_branch L_next")
+        e("L_loadc:")
+        self.const_base()
+        self.load_const_into(Xs)
+        e("s_branch L_next")
+        e("L_store:")
+        self.slot_base()
+        e(f"v_mov_b32 v{g.v_addr}, v{g.v_goff}")
+        for j in range(2 * H):
+            e(f"global_store_dword v{g.v_addr}, {Xs[j]}, s[{g.s_sbase}:{g.s_sbase + 1}]")
+            if j != 2 * H - 1:
+                e(f"v_add_u32 v{g.v_addr}, s3, v{g.v_addr}")
+        e("s_waitcnt vmcnt(0)")
+        e("s_branch L_next")
+        e("L_add:")
+        # digit-wise sum, carried at once (GenP leaves it lazy; at H = 55 the accumulators of the product that follows have
+        # no room for 29-bit limbs: 3 H products of 2^57).  The digits' values are what the next product sees, not the limbs.
+        self.slot_base()
+        self.load_slot_into(St)
+        for j in range(2 * H):
+            e(f"v_add_u32 {Xs[j]}, {Xs[j]}, {St[j]}")
+        for d in (0, H):
+            for j in range(H - 1):
+                e(f"v_lshrrev_b32 v{g.v_t1}, {LB}, {Xs[d + j]}")
+                e(f"v_and_b32 {Xs[d + j]}, {M}, {Xs[d + j]}")
+                e(f"v_add_u32 {Xs[d + j + 1]}, {Xs[d + j + 1]}, v{g.v_t1}")
+        e("s_branch L_next")
+        e("L_mul:")
+        self.slot_base()
+        e(f"s_mov_b64 s[{g.s_bstart}:{g.s_bstart + 1}], s[{g.s_sbase}:{g.s_sbase + 1}]")
+        e(f"s_mov_b32 s{g.s_bstride}, s3")
+        e(f"v_mov_b32 v{g.v_vb}, v{g.v_goff}")
+        e("s_branch L_montmul")
+        e("L_mulc:")
+        self.const_base()
+        e(f"s_mov_b64 s[{g.s_bstart}:{g.s_bstart + 1}], s[{g.s_sbase}:{g.s_sbase + 1}]")
+        e(f"s_mov_b32 s{g.s_bstride}, 4")
+        e(f"v_mov_b32 v{g.v_vb}, 0")
+        e("s_branch L_montmul")
+        e("L_sqr:")
+        e("s_branch L_montsq")
+
+    # ---- the phase boundary: c0 leaves the accumulators, the seeds Cadj_k - m_k enter them ---------------------------
+    def boundary(self, sq):
+        """Columns k = 0..H-1 hold c0 (position H + k).  Carry them out one by one; a freed column at once receives m_k (from
+        the lane's LDS column) in its low and Cadj_k (LDS table) in its high register.  Squaring: the LDS word takes 2 a0_k
+        (the multiplier of phase-2 row k) and the new a0_k replaces the old one; product: the LDS word takes the new a0_k."""
+        g, e, H = self, self.e, self.H
+        M = hex(MASK)
+        cpair = self.P(g.v_c)
+        tmp = [g.v_t1, g.v_t2]
+        for k in range(H):
+            t = f"v{tmp[k % 2]}"
+            if k:
+                e(f"v_lshl_add_u64 {self.T(k)}, {self.T(k)}, 0, {cpair}")
+            if sq:
+                e(f"v_add_u32 {t}, {self.X0(k)}, {self.X0(k)}")
+                e(f"v_and_b32 {self.X0(k)}, {M}, {self.Tlo(k)}")
+            else:
+                e(f"v_and_b32 {t}, {M}, {self.Tlo(k)}")
+            if k < H - 1:
+                e(f"v_lshrrev_b64 {cpair}, {LB}, {self.T(k)}")
+            e(f"ds_read_b32 {self.Tlo(k)}, v{g.v_aread} offset:{k * self.row}")
+            e(f"ds_read_b32 {self.Thi(k)}, v{g.v_zero} offset:{4 * k}")
+            e(f"ds_write_b32 v{g.v_aread}, {t} offset:{k * self.row}")
+
+    def seeds(self, fold_top):
+        g, e, H = self, self.e, self.H
+        e("s_waitcnt lgkmcnt(0)")
+        for j in range(H):
+            e(f"v_sub_u32 {self.Tlo(j)}, {self.Thi(j)}, {self.Tlo(j)}")     # Cadj_j - m_j >= 0 limb by limb
+            e(f"v_mov_b32 {self.Thi(j)}, 0")
+        if fold_top:
+            # the rows of a product re-create the top column from zero, every one of them (no peeled first row): its seed
+            # moves into the column below, 28 bits up (< 2^57: the accumulators have the room)
+            e(f"v_lshlrev_b64 {self.P(g.v_y0)}, {LB}, {self.T(H - 1)}")
+            e(f"v_lshl_add_u64 {self.T(H - 2)}, {self.T(H - 2)}, 0, {self.P(g.v_y0)}")
+
+    # ---- squaring -----------------------------------------------------------------------------------------------
+    def phase1_sq(self):
+        g, e, H = self, self.e, self.H
+        m = f"v{g.v_m}"
+        fresh = set(range(H))
+
+        def acc(pos, a, b):
+            c = pos % H
+            if c in fresh:
+                fresh.discard(c)
+                self.mad(self.T(c), a, b, "0")
+            else:
+                self.mad(self.T(c), a, b, self.T(c))
+
+        for i in range(H):
+            ai = self.X0(i)
+            e(f"v_add_u32 v{g.v_ai}, {ai}, {ai}")
+            self.align8()
+            acc(2 * i, ai, ai)
+            for j in range(i + 1, H):
+                acc(i + j, f"v{g.v_ai}", self.X0(j))
+            c0 = i % H
+            assert c0 not in fresh
+            e(f"v_mul_lo_u32 {m}, {self.Tlo(c0)}, s14")
+            e(f"v_and_b32 {m}, {hex(MASK)}, {m}")
+            e(f"ds_write_b32 v{g.v_aread}, {m} offset:{i * self.row}")
+            self.align8()
+            for j in range(H):
+                acc(i + j, m, self.Pm(j))
+            e(f"v_lshrrev_b64 {self.P(g.v_c)}, {LB}, {self.T(c0)}")
+            e(f"v_lshl_add_u64 {self.T((i + 1) % H)}, {self.T((i + 1) % H)}, 0, {self.P(g.v_c)}")
+            fresh.add(c0)
+        for pos in range(H, 2 * H):
+            c = pos % H
+            assert c == pos - H
+            if c in fresh:
+                e(f"v_mov_b64 {self.T(c)}, 0")
+                fresh.discard(c)
+
+    def carry_into_x1(self):
+        g, e, H = self, self.e, self.H
+        M = hex(MASK)
+        c = self.P(g.v_c)
+        e(f"v_mov_b64 {self.T(H - 1)}, 0")
+        e(f"v_and_b32 {self.X1(0)}, {M}, {self.Tlo(0)}")
+        e(f"v_lshrrev_b64 {c}, {LB}, {self.T(0)}")
+        for j in range(1, H):
+            e(f"v_lshl_add_u64 {self.T(j)}, {self.T(j)}, 0, {c}")
+            e(f"v_and_b32 {self.X1(j)}, {M}, {self.Tlo(j)}")
+            if j < H - 1:
+                e(f"v_lshrrev_b64 {c}, {LB}, {self.T(j)}")
+
+    def montsq(self):
+        g, e, H = self, self.e, self.H
+        row = self.row
+        e("L_montsq:")
+        self.phase1_sq()
+        self.boundary(True)
+        self.seeds(False)
+        # phase 2 as in GenP: multipliers 2 a0_i from the LDS column, row 0 keeps the seed of the top column
+        e(f"v_mov_b32 v{g.v_arow}, v{g.v_aread}")
+        e(f"ds_read_b32 v{g.v_ain}, v{g.v_arow}")
+        e(f"v_add_u32 v{g.v_arow}, {row}, v{g.v_arow}")
+        self.phase2_row(True, g.v_ain, g.v_ai, g.v_t2, g.v_t3, True, 0, row)
+        e("s_mov_b32 s19, 1")
+        e(".p2align 6")
+        e("L_p2s:")
+        self.phase2_row(True, g.v_ai, g.v_ain, g.v_t3, g.v_t2, False, 0, None)
+        self.phase2_row(True, g.v_ain, g.v_ai, g.v_t2, g.v_t3, False, row, 2 * row)
+        e("s_add_u32 s19, s19, 2")
+        e(f"s_cmp_lt_u32 s19, {H}")
+        e("s_cbranch_scc1 L_p2s")
+        e("s_waitcnt lgkmcnt(0)")
+        self.carry_into_x1()
+        e("s_branch L_next")
+
+    # ---- product ------------------------------------------------------------------------------------------------
+    def issue_loads(self, slot, both):
+        """multiplier digits of the next row in line -> ring registers `slot`; the row pointers move on"""
+        g, e = self, self.e
+        e(f"global_load_dword v{g.ring0[slot]}, v{g.v_vb}, s[{g.s_b0}:{g.s_b0 + 1}]")
+        e(f"s_add_u32 s{g.s_b0}, s{g.s_b0}, s{g.s_bstride}")
+        e(f"s_addc_u32 s{g.s_b0 + 1}, s{g.s_b0 + 1}, 0")
+        if both:
+            e(f"global_load_dword v{g.ring1[slot]}, v{g.v_vb}, s[{g.s_b1}:{g.s_b1 + 1}]")
+            e(f"s_add_u32 s{g.s_b1}, s{g.s_b1}, s{g.s_bstride}")
+            e(f"s_addc_u32 s{g.s_b1 + 1}, s{g.s_b1 + 1}, 0")
+
+    def mul_row(self, r, phase, rows_left):
+        """row r of a five-row body.  phase 1: T += b0_i a0, quotient digit to LDS, T = (T + m p) >> 28.  phase 2:
+        T += b0_i a1 + b1_i a0, the same reduction.  rows_left: rows after this one in the product's phase (tail body), or
+        None inside the loop: decides the vmcnt to wait for and whether row i + PD is still to be fetched."""
+        g, e, H = self, self.e, self.H
+        per = 2 if phase == 2 else 1
+        newer = self.PD - 1 if rows_left is None else min(self.PD - 1, rows_left)
+        e(f"s_waitcnt vmcnt({per * newer})")
+        if rows_left is None or rows_left >= self.PD:
+            self.issue_loads((r + self.PD) % self.RB, phase == 2)
+        b0 = f"v{g.ring0[r]}"
+        m = f"v{g.v_m}"
+        self.align8()
+        if phase == 1:
+            for j in range(H):
+                self.mad(self.T(j), b0, self.X0(j), "0" if j == H - 1 else self.T(j))
+        else:
+            b1 = f"v{g.ring1[r]}"
+            for j in range(H):
+                self.mad(self.T(j), b0, self.X1(j), "0" if j == H - 1 else self.T(j))
+            for j in range(H):
+                self.mad(self.T(j), b1, self.X0(j), self.T(j))
+        e(f"v_mul_lo_u32 {m}, {self.Tlo(0)}, s14")
+        e(f"v_and_b32 {m}, {hex(MASK)}, {m}")
+        if phase == 1:
+            e(f"ds_write_b32 v{g.v_mrow}, {m} offset:{r * self.row}")
+        self.align8()
+        self.mad(self.P(g.v_y0), m, self.Pm(0), self.T(0))
+        self.mad(self.T(0), m, self.Pm(1), self.T(1))
+        e(f"v_lshrrev_b64 {self.P(g.v_c)}, {LB}, {self.P(g.v_y0)}")
+        for j in range(2, H):
+            self.mad(self.T(j - 1), m, self.Pm(j), self.T(j))
+            if j == 4:
+                e(f"v_lshl_add_u64 {self.T(0)}, {self.T(0)}, 0, {self.P(g.v_c)}")
+
+    def mul_phase(self, phase):
+        g, e, H, RB = self, self.e, self.H, self.RB
+        e(f"s_mov_b64 s[{g.s_b0}:{g.s_b0 + 1}], s[{g.s_bstart}:{g.s_bstart + 1}]")
+        if phase == 2:
+            e(f"s_mul_i32 s{g.s_t0}, s{g.s_bstride}, {H}")
+            e(f"s_add_u32 s{g.s_b1}, s{g.s_bstart}, s{g.s_t0}")
+            e(f"s_addc_u32 s{g.s_b1 + 1}, s{g.s_bstart + 1}, 0")
+        for r in range(self.PD):
+            self.issue_loads(r, phase == 2)
+        if phase == 1:
+            for j in range(H - 1):
+                e(f"v_mov_b64 {self.T(j)}, 0")
+            e(f"v_mov_b32 v{g.v_mrow}, v{g.v_aread}")
+        else:
+            self.seeds(True)
+        e("s_mov_b32 s19, 0")
+        e(".p2align 6")
+        e(f"L_m{phase}:")
+        for r in range(RB):
+            self.mul_row(r, phase, None)
+        if phase == 1:
+            e(f"v_add_u32 v{g.v_mrow}, {RB * self.row}, v{g.v_mrow}")
+        e(f"s_add_u32 s19, s19, {RB}")
+        e(f"s_cmp_lt_u32 s19, {H - RB}")
+        e(f"s_cbranch_scc1 L_m{phase}")
+        for r in range(RB):
+            self.mul_row(r, phase, RB - 1 - r)
+
+    def montmul(self):
+        g, e, H = self, self.e, self.H
+        e("L_montmul:")
+        self.mul_phase(1)
+        e(f"v_mov_b64 {self.T(H - 1)}, 0")
+        self.boundary(False)
+        self.mul_phase(2)
+        self.carry_into_x1()
+        for k in range(H):
+            e(f"ds_read_b32 {self.X0(k)}, v{g.v_aread} offset:{k * self.row}")
+        e("s_waitcnt lgkmcnt(0)")
+        e("s_branch L_next")
+
+    def generate(self):
+        self.prologue()
+        self.dispatcher()
+        self.montmul()
+        self.montsq()
+        self.epilogue()
+        return "\n".join(self.lines) + "\n"
+
+
 class GenQ(Gen):
     """In-wave pair kernel for moduli N = n^2 with n PUBLIC (Encrypt, ConstMult, PartialDecrypt, proofs): the residue
     y R mod n^2 = a0 + a1 n (R = 2^(28 H), H = limbs of n) lives in two neighbouring lanes -- lane 0 holds a0, lane 1
@@ -2562,8 +2937,8 @@ class GenQ3(Gen):
         return "\n".join(self.lines) + "\n"
 
 
-SHAPES = [(74, 1), (37, 1), (55, 1), (55, 2), (74, 2), (55, 4), (74, 4), (37, 2), (37, 4), (37, 16), (74, 32), (55, 32), (37, 32), (37, 64), (74, 48), (37, 48)]
-PAIR = {(37, 16)}           # (H, 16): the pair kernel for N = p^2 with H-limb p (GenP); 16 is a tag, not a lane count
+SHAPES = [(74, 1), (37, 1), (55, 1), (55, 2), (74, 2), (55, 4), (74, 4), (37, 2), (37, 4), (37, 16), (55, 16), (74, 32), (55, 32), (37, 32), (37, 64), (74, 48), (37, 48)]
+PAIR = {(37, 16), (55, 16)}  # (H, 16): the pair kernel for N = p^2 with H-limb p (GenP); 16 is a tag, not a lane count
 PAIR4 = {(37, 64)}          # (WL, 64): GenQ4, the two digits of GenQ(2 WL) sliced over two lanes each
 PAIR2 = {(74, 32), (55, 32), (37, 32)}          # (H, 32): the two-lane pair kernel for N = n^2 with H-limb n (GenQ)
 WAVE_SLICED = {(74, 2), (55, 2)}     # shapes whose slices live in different waves (GenW) instead of neighbouring lanes (Gen)
@@ -2572,7 +2947,7 @@ TRIPLE = {(74, 48), (37, 48)}        # (H, 48): GenQ3, residues modulo n^3 as th
 
 def make_gen(wl, k):
     if (wl, k) in PAIR:
-        return GenP(wl)
+        return GenP2(wl) if wl > 37 else GenP(wl)
     if (wl, k) in PAIR2:
         return GenQ(wl)
     if (wl, k) in PAIR4:

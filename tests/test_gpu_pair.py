@@ -13,8 +13,12 @@ from model28 import to_limbs, from_limbs
 
 pytestmark = pytest.mark.gpu
 G = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
-END, LOAD, STORE, SQR, MUL = 0, 1, 2, 4, 5
+END, LOAD, STORE, SQR, MUL, MULC, ADD = 0, 1, 2, 4, 5, 6, 8
+C_ONE = 3          # constant 1 of every modulus context: the pair (1, 0)
 LB = 28
+# one-lane pair kernels: GenP (37-limb primes, 2048-bit keys) and GenP2 (55-limb primes, 3072-bit keys: quotient digits in
+# LDS, multiplier digits of a product streamed from memory)
+ONE_LANE = [("2048", 37), ("3072", 55)]
 
 
 @pytest.fixture(scope="module")
@@ -38,12 +42,12 @@ def pair_model(p, H, cadj):
     return pmul, R
 
 
-def test_pair_products_match_the_integer_model(ctx):
-    k = json.load(open(os.path.join(G, "keys.json")))["paillier"]["2048"]
+@pytest.mark.parametrize("bits,H", ONE_LANE)
+def test_pair_products_match_the_integer_model(ctx, bits, H):
+    k = json.load(open(os.path.join(G, "keys.json")))["paillier"][bits]
     p = int(k["p"], 16)
     rng = random.Random(20)
-    nb, nslots = 256, 6
-    H = 37
+    nb, nslots = 512, 6
     mem = np.zeros((nslots, 2 * H, nb), dtype=np.uint32)
     vals = {}
     for s in (0, 1):
@@ -57,7 +61,8 @@ def test_pair_products_match_the_integer_model(ctx):
             vals[s, g] = a
             mem[s, :H, g] = to_limbs(a[0], H)
             mem[s, H:, g] = to_limbs(a[1], H)
-    prog = [LOAD, 0, SQR, 0, STORE, 2, LOAD, 0, MUL, 1, STORE, 3, SQR, 0, SQR, 0, MUL, 0, STORE, 4, END, 0]
+    prog = [LOAD, 0, SQR, 0, STORE, 2, LOAD, 0, MUL, 1, STORE, 3, SQR, 0, SQR, 0, MUL, 0, STORE, 4,
+            LOAD, 0, ADD, 1, MULC, C_ONE, STORE, 5, END, 0]
     out, consts, h = ctx.pair_debug_run(p, prog, mem, nslots, nb)
     assert h == H and from_limbs(consts[:H]) == p
     cadj = from_limbs(consts[H:])
@@ -70,16 +75,18 @@ def test_pair_products_match_the_integer_model(ctx):
         t = pmul(xy, xy)
         t = pmul(t, t)
         t = pmul(t, x)
-        for slot, want in ((2, sq), (3, xy), (4, t)):
+        s1 = pmul((x[0] + y[0], x[1] + y[1]), (1, 0))        # ADD is digit-wise and lazy; the product after it normalises
+        for slot, want in ((2, sq), (3, xy), (4, t), (5, s1)):
             got = (from_limbs(out[slot, :H, g]), from_limbs(out[slot, H:, g]))
             assert got == want, (g, slot)
             assert all(int(v) < (1 << LB) for v in out[slot, :, g])
 
 
-def test_pair_ladder_is_a_modexp(ctx):
-    k = json.load(open(os.path.join(G, "keys.json")))["paillier"]["2048"]
+@pytest.mark.parametrize("bits,H", ONE_LANE)
+def test_pair_ladder_is_a_modexp(ctx, bits, H):
+    k = json.load(open(os.path.join(G, "keys.json")))["paillier"][bits]
     q = int(k["q"], 16)
-    H, nb, nslots = 37, 256, 3
+    nb, nslots = 256, 3
     rng = random.Random(21)
     R = 1 << (LB * H)
     q2 = q * q
@@ -194,9 +201,11 @@ def test_two_lane_pair_kernel_matches_the_integer_model(ctx, lanes):
         assert got == xv * yv * rinv % n2
 
 
-def test_decrypt_3072_on_the_two_lane_pair_kernel(ctx):
-    """3072-bit keys: the CRT ladders modulo p^2, q^2 (55-limb primes) run on the two-lane pair kernel when the batch
-    fills the chip; force it for a small batch and compare with the ordinary kernels and the oracle."""
+@pytest.mark.parametrize("one_lane", [0, 1])
+def test_decrypt_3072_on_the_pair_kernels(ctx, one_lane):
+    """3072-bit keys: the CRT ladders modulo p^2, q^2 (55-limb primes) run on the one-lane pair kernel GenP2 when the batch
+    fills the chip (one_lane = 1 forces it for this small batch) and on the two-lane kernel below that (one_lane = 0);
+    compare both with the ordinary kernels and the oracle."""
     import paillier_amd as pa
     from oracle import paillier_oracle as po
     k = json.load(open(os.path.join(G, "keys.json")))["paillier"]["3072"]
@@ -206,17 +215,19 @@ def test_decrypt_3072_on_the_two_lane_pair_kernel(ctx):
     sk = pa.SecretKey(ctx, pk, lam)
     sk_o = po.SecretKey(N=n, G=n + 1, Lambda=lam)
     rng = random.Random(24)
-    cts = [rng.randrange(n * n) for _ in range(300)] + [0, 1, p, q, n, n * n - 1]
+    cts = [rng.randrange(n * n) for _ in range(300)] + [0, 1, p, q, n, n * n - 1, p * p, 7 * q]
     try:
-        ctx.set_flag("lanes_wanted", 1)
+        ctx.set_flag("lanes_wanted", 1 if one_lane else 0)
         ctx.set_flag("pair", 1)
-        with_pair = sk.DecryptBatch(cts)
+        with_pair, st = sk.DecryptBatch(cts, return_status=True)
         ctx.set_flag("pair", 0)
-        without = sk.DecryptBatch(cts)
+        without, st0 = sk.DecryptBatch(cts, return_status=True)
     finally:
         ctx.set_flag("pair", 1)
         ctx.set_flag("lanes_wanted", 0)
-    assert with_pair == without
+    assert with_pair == without and list(st) == list(st0)
+    from math import gcd
+    assert [bool(v & pa.LANE_NONUNIT) for v in st] == [gcd(c, n) != 1 for c in cts]
     assert with_pair[:20] + with_pair[-6:] == [po.decrypt(sk_o, po.Ciphertext(c)) for c in cts[:20] + cts[-6:]]
 
 
