@@ -75,6 +75,7 @@ struct pgpu_ctx {
   int last_vm_asm = 0;       // number of VM launches of the last call that ran the assembly kernel
   bool use_pair = true;      // Decrypt ladders mod p^2 on the pair kernel (pgpu_ctx_set_flag("pair", 0): the 2H-limb kernel)
   bool use_triple = true;    // ladders modulo n^3 on the three-digit kernel (pgpu_ctx_set_flag("triple", 0): the 3H-limb kernels)
+  bool use_shared_chain = true;   // several shared exponents on ONE base share the chain of squarings (pgpu_partial_decrypt_multi)
   size_t lanes_wanted = 0;   // 0: default occupancy target; tests set 1 to run every modulus at its natural shape
 
   void bind() { HIPCHK(hipSetDevice(device)); }
@@ -479,6 +480,89 @@ void emit_modexp_dual(Prog& p, int we, const BigU& e, uint32_t in1, uint32_t in2
   p.op(VM_STORE, out);
 }
 
+// x^(e_0), x^(e_1), ... for SEVERAL shared exponents on ONE base with a single chain of squarings (right-to-left sliding
+// windows, Yao's buckets): the chain x, x^2, x^4, ... is walked once; where a window of e_s starts (a one bit at position j,
+// value d = bits [j, j + w), odd), the current power x^(2^j) is multiplied into bucket B_s[(d-1)/2]; at the end
+//   x^(e_s) = prod_d B_s[d]^d = R_0 * (R_1 R_2 ... R_(K-1))^2,    R_k = prod_(i >= k) B_s[i]   (d = 2k + 1)
+// -- bits/(w+1) + 2 * 2^(w-1) products per exponent beside ONE chain of `bits` squarings, where separate left-to-right
+// ladders square `bits` times EACH (three servers' PartialDecrypt of the same ciphertexts: 50 % of the multiplies).  The
+// operation sequence depends on the exponents (the key's shares), never on the bases.
+// The base is in slot `in` in the kernel's working form (pair digits); one_const = 1 in that form.  Slots: bp, run, acc
+// (scratch), out0 + s (results, lazy), bucket0 + s * 2^(w-1) + k.
+void emit_multi_exp_shared_base(Prog& p, const std::vector<BigU>& es, uint32_t in, uint32_t bp, uint32_t run, uint32_t acc,
+                                uint32_t out0, uint32_t bucket0, int w, uint32_t one_const) {
+  const uint32_t K = 1u << (w - 1);
+  const size_t S = es.size();
+  size_t nbits = 0;
+  for (auto& e : es) nbits = std::max(nbits, e.bit_length());
+  // window starts: at[j] = list of (server, bucket)
+  std::vector<std::vector<std::pair<uint32_t, uint32_t>>> at(nbits + 1);
+  size_t last_start = 0;
+  for (size_t s = 0; s < S; ++s) {
+    const BigU& e = es[s];
+    for (size_t j = 0; j < e.bit_length();) {
+      if (!e.bit(j)) { ++j; continue; }
+      uint32_t d = 0;
+      for (int b = 0; b < w; ++b) if (j + b < e.bit_length()) d |= (uint32_t)e.bit(j + b) << b;
+      at[j].push_back({(uint32_t)s, d >> 1});
+      last_start = std::max(last_start, j);
+      j += w;
+    }
+  }
+  std::vector<char> touched(S * K, 0);
+  auto bucket = [&](uint32_t s, uint32_t k) { return bucket0 + s * K + k; };
+  p.op(VM_LOAD, in);
+  for (size_t j = 0; j <= last_start && nbits; ++j) {
+    if (j) p.op(VM_SQR);                                   // x^(2^j)
+    bool stored = false, dirty = false;
+    for (auto& sk : at[j]) {
+      const uint32_t b = bucket(sk.first, sk.second);
+      if (!touched[sk.first * K + sk.second]) {
+        if (dirty) { p.op(VM_LOAD, bp); dirty = false; }
+        p.op(VM_STORE, b);
+        touched[sk.first * K + sk.second] = 1;
+      } else {
+        if (dirty) { p.op(VM_LOAD, bp); dirty = false; }
+        if (!stored) { p.op(VM_STORE, bp); stored = true; }
+        p.op(VM_MUL, b);
+        p.op(VM_STORE, b);
+        dirty = true;
+      }
+    }
+    if (dirty && j < last_start) p.op(VM_LOAD, bp);
+  }
+  for (size_t s = 0; s < S; ++s) {
+    bool run_empty = true, acc_empty = true;
+    for (uint32_t k = K - 1; k >= 1; --k) {
+      bool x_is_run = false;
+      if (touched[s * K + k]) {
+        if (run_empty) { p.op(VM_LOAD, bucket((uint32_t)s, k)); run_empty = false; }
+        else { p.op(VM_LOAD, run); p.op(VM_MUL, bucket((uint32_t)s, k)); }
+        p.op(VM_STORE, run);
+        x_is_run = true;
+      }
+      if (!run_empty) {
+        if (acc_empty) { if (!x_is_run) p.op(VM_LOAD, run); acc_empty = false; }
+        else { p.op(VM_LOAD, acc); p.op(VM_MUL, run); }
+        p.op(VM_STORE, acc);
+      }
+    }
+    // R_0 -> its slot (run, or the bucket itself), then acc^2 * R_0
+    uint32_t r0 = NO_SLOT;
+    if (touched[s * K]) {
+      if (run_empty) r0 = bucket((uint32_t)s, 0);
+      else { p.op(VM_LOAD, run); p.op(VM_MUL, bucket((uint32_t)s, 0)); p.op(VM_STORE, run); r0 = run; }
+    } else if (!run_empty) r0 = run;
+    if (!acc_empty) {
+      p.op(VM_LOAD, acc);
+      p.op(VM_SQR);
+      p.op(VM_MUL, r0);            // (acc non-empty implies run non-empty, so R_0 exists)
+    } else if (r0 != NO_SLOT) p.op(VM_LOAD, r0);
+    else p.op(VM_LOADC, one_const);                        // e_s = 0: gmp.Int.Exp gives 1
+    p.op(VM_STORE, out0 + (uint32_t)s);
+  }
+}
+
 struct SegSpec {
   const ModCtx* mc;
   const Prog* prog;
@@ -874,6 +958,7 @@ int pgpu_ctx_set_flag(pgpu_ctx* ctx, const char* name, int value) {
   if (strcmp(name, "asm") == 0) { ctx->use_asm = value != 0; return PGPU_OK; }
   if (strcmp(name, "pair") == 0) { ctx->use_pair = value != 0; return PGPU_OK; }
   if (strcmp(name, "triple") == 0) { ctx->use_triple = value != 0; return PGPU_OK; }
+  if (strcmp(name, "shared_chain") == 0) { ctx->use_shared_chain = value != 0; return PGPU_OK; }
   if (strcmp(name, "lanes_wanted") == 0) { ctx->lanes_wanted = value > 0 ? (size_t)value : 0; return PGPU_OK; }
   if (strcmp(name, "cu_partition") == 0) {
     // value = (parts << 16) | part: confine this context's (own) stream to the part-th of `parts` equal slices of the
@@ -2903,6 +2988,43 @@ int pgpu_partial_decrypt_multi(const pgpu_pubkey* pk, int total_servers, int n_s
       HIPCHK(hipMemcpyAsync(ent + 2 * SW, x0, S1 * 4, hipMemcpyDeviceToDevice, ctx->stream));
     }
     const size_t lanes_target = ctx->lanes_wanted ? ctx->lanes_wanted : (size_t)1024 * 64;
+    auto leave_pair_form = [&](uint32_t* pm, uint32_t out_slot, uint8_t* dst) {
+      // F~ = F0 + F1 n, out of pair and Montgomery form (slots 2 and 3 of pm are free by now)
+      launch_mul_const_add(pm + out_slot * SW + S1, H, pi.n_limbs, H, pm + out_slot * SW, H, 0, pm + 2 * SW, W2, nb, ctx->stream);
+      Prog a;
+      a.op(VM_LOAD, 2); a.op(VM_MULC, (uint32_t)pi.c_rh); a.op(VM_STORE, 3); a.end();
+      SegSpec sa{&mc, &a, pm, nullptr};
+      run_vm(ctx, nb, sa, nullptr, false);
+      launch_canon(pm + 3 * SW, mc.d_nmod, W2, nb, ctx->stream);
+      pack_result(ctx, pm + 3 * SW, W2, nb, batch, dst, out_stride, mc.nbytes, mem);
+    };
+    if (n_shares >= 2 && ctx->use_shared_chain && pi.c_one_pair >= 0 && nb * 8 >= lanes_target) {
+      // One chain of squarings for all the servers (emit_multi_exp_shared_base): the ciphertexts are the same, only the
+      // exponents differ.  A batch that fills at least half the chip on its own takes this path; smaller ones are bound by
+      // the length of the operation sequence, where separate ladders side by side (below) are shorter.
+      const int w = 7;
+      const uint32_t K = 1u << (w - 1);
+      const size_t per_server = (size_t)K * SW * 4;
+      const int group = (int)std::max<size_t>(1, std::min<size_t>((size_t)n_shares, ((size_t)12 << 30) / per_server));
+      for (int k0 = 0; k0 < n_shares; k0 += group) {
+        const int S = std::min(group, n_shares - k0);
+        const uint32_t OUT0 = 6, B0 = 6 + (uint32_t)S;
+        uint32_t* pm = ctx->ws_t<uint32_t>(SW * (size_t)(B0 + (size_t)S * K));
+        HIPCHK(hipMemcpyAsync(pm + 2 * SW, ent + 2 * SW, SW * 4, hipMemcpyDeviceToDevice, ctx->stream));
+        Prog pr;
+        emit_multi_exp_shared_base(pr, std::vector<BigU>(es.begin() + k0, es.begin() + k0 + S), 2, 3, 4, 5, OUT0, B0, w,
+                                   (uint32_t)pi.c_one_pair);
+        pr.end();
+        SegSpec sg{&mc, &pr, pm, nullptr};
+        const int lanes = (nb * 2 >= lanes_target || !(H % 2 == 0 && vm_asm_available(H / 2, 64))) ? 2 : 4;
+        sg.pair = pi.consts; sg.pair_n0inv = mn.n0inv; sg.pair_h = H; sg.pair_lanes = lanes;
+        run_vm(ctx, nb, sg, nullptr, true);
+        for (int j = 0; j < S; ++j) leave_pair_form(pm, OUT0 + (uint32_t)j, outs[k0 + j]);
+      }
+      for (auto& e : es) wipe_vec(e.d);
+      HIPCHK(hipStreamSynchronize(ctx->stream));
+      return;
+    }
     for (int k = 0; k < n_shares;) {
       // two servers per launch: 2 x 16 384 numbers x 2 lanes are exactly one wave per SIMD.  (Three segments -- the kernels
       // take up to three -- would be 1.5 waves per SIMD: the SIMDs that got two waves take as long as a full second wave,
@@ -2922,16 +3044,7 @@ int pgpu_partial_decrypt_multi(const pgpu_pubkey* pk, int total_servers, int n_s
         sg[j].pair = pi.consts; sg[j].pair_n0inv = mn.n0inv; sg[j].pair_h = H; sg[j].pair_lanes = lanes;
       }
       run_vm(ctx, nb, sg[0], segs >= 2 ? &sg[1] : nullptr, true, 0, segs == 3 ? &sg[2] : nullptr);
-      for (int j = 0; j < segs; ++j) {
-        // F~ = F0 + F1 n, out of pair and Montgomery form
-        launch_mul_const_add(pm[j] + 3 * SW + S1, H, pi.n_limbs, H, pm[j] + 3 * SW, H, 0, pm[j] + 2 * SW, W2, nb, ctx->stream);
-        Prog a;
-        a.op(VM_LOAD, 2); a.op(VM_MULC, (uint32_t)pi.c_rh); a.op(VM_STORE, 3); a.end();
-        SegSpec sa{&mc, &a, pm[j], nullptr};
-        run_vm(ctx, nb, sa, nullptr, false);
-        launch_canon(pm[j] + 3 * SW, mc.d_nmod, W2, nb, ctx->stream);
-        pack_result(ctx, pm[j] + 3 * SW, W2, nb, batch, outs[k + j], out_stride, mc.nbytes, mem);
-      }
+      for (int j = 0; j < segs; ++j) leave_pair_form(pm[j], 3, outs[k + j]);
       k += segs;
     }
     for (auto& e : es) wipe_vec(e.d);

@@ -77,6 +77,16 @@ def test_asm_generator_model():
             assert p1.count("v_mad_u64_u32") == H * (H - 1) // 2 + H + H * H + 2 * H        # + the peeled phase-2 row
             assert sq.split("L_p2s:")[1].split("s_cbranch_scc1 L_p2s")[0].count("v_mad_u64_u32") == 2 * 2 * H
             mm = text.split("L_montmul:")[1].split("L_montsq:")[0]
+            if isinstance(g, gen_vm_asm.GenP2):
+                # the wider one-lane kernel: both phases of a product are loops of five-row bodies (2H / 3H multiplies a
+                # row) followed by a five-row tail; LDS for two workgroups per CU
+                RB = g.RB
+                assert mm.split("L_m1:")[1].split("s_cbranch_scc1 L_m1")[0].count("v_mad_u64_u32") == RB * 2 * H
+                assert mm.split("L_m2:")[1].split("s_cbranch_scc1 L_m2")[0].count("v_mad_u64_u32") == RB * 3 * H
+                assert mm.count("v_mad_u64_u32") == 2 * RB * 5 * H
+                assert mm.count("global_load_dword") == 3 * g.PD + 3 * (RB + 1)     # ring fills + one load per row and stream
+                assert g.lds_bytes * 2 <= 160 * 1024
+                continue
             assert mm.split("L_p2m:")[0].count("v_mad_u64_u32") == 2 * H * H + 3 * H
             assert mm.split("L_p2m:")[1].split("s_cbranch_scc1 L_p2m")[0].count("v_mad_u64_u32") == 2 * 3 * H
             continue

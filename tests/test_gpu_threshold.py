@@ -147,3 +147,40 @@ def test_partial_decrypt_multi_servers(ctx, bits):
             assert [be_to_ints(o) for o in outs] == want
         finally:
             ctx.set_flag("pair", 1)
+
+
+@pytest.mark.parametrize("lanes_wanted,nshares", [(1, 3), (4096, 5), (1, 2)])
+def test_partial_decrypt_multi_shares_one_chain_of_squarings(ctx, lanes_wanted, nshares):
+    """A batch that fills the chip takes pgpu_partial_decrypt_multi's shared chain: right-to-left sliding windows into Yao
+    buckets, ONE chain of squarings for all the shares (capi.cpp emit_multi_exp_shared_base).  Forced here for a small batch
+    (lanes_wanted = 1: the two-lane pair kernel; 4096: the four-lane one) and compared with c^(2 Delta s_i) mod n^2
+    (thresholdkey.go:192-201) from Python and with the separate ladders (flag off)."""
+    import numpy as np
+    import paillier_amd as pa
+    from paillier_amd.api import be_to_ints, ints_to_be
+    k = json.load(open(os.path.join(G, "keys.json")))["threshold"]["2048"]
+    n, total, thr = int(k["n"], 16), k["total"], k["threshold"]
+    shares = [int(s, 16) for s in k["shares"]][:nshares]
+    if nshares == 2:
+        shares[1] = (1 << 300) + 12345          # a short exponent next to a long one (still on the pair path)
+    tk = pa.ThresholdPublicKey(ctx, n, total=total, threshold=thr)
+    cb = tk.cipher_bytes()
+    rng = random.Random(77 + nshares)
+    n2 = n * n
+    cts = [rng.randrange(n2) for _ in range(290)] + [0, 1, n2 - 1, n, 3 * n]
+    rows = ints_to_be(cts, cb)
+    got = {}
+    try:
+        ctx.set_flag("lanes_wanted", lanes_wanted)
+        for flag in (1, 0):
+            ctx.set_flag("shared_chain", flag)
+            outs = [np.zeros((len(cts), cb), dtype=np.uint8) for _ in shares]
+            tk.partial_decrypt_multi_raw(shares, len(cts), rows, cb, outs, cb)
+            got[flag] = [be_to_ints(o) for o in outs]
+    finally:
+        ctx.set_flag("shared_chain", 1)
+        ctx.set_flag("lanes_wanted", 0)
+    assert got[1] == got[0]
+    delta2 = 2 * 120
+    for s, col in zip(shares, got[1]):
+        assert col[:24] + col[-5:] == [pow(c, delta2 * s, n2) for c in cts[:24] + cts[-5:]]
