@@ -317,6 +317,19 @@ def main():
         checks["encrypt_2048"] = (n2k, em_h[:64], er_h[:64], ec[:64].cpu().numpy())
         del ec2
 
+        # the headline kernel with a deeper queue: 131072 ciphertexts = four waves' worth of work per SIMD slot pair, so the
+        # hardware dispatcher refills CUs as their first workgroups retire (at 65536 every workgroup is resident from the
+        # start and the launch lasts as long as its slowest CU).  Same Decrypt, same key; the ciphertexts are the Encrypt
+        # batch above twice.
+        BB = 2 * BE
+        bc = torch.cat([ec, ec]).contiguous()
+        bo = torch.zeros((BB, 256), dtype=torch.uint8, device=dev)
+        dt, vms, mads, kern = timed(lambda: one_call(lambda: sk2.decrypt_raw(BB, bc.data_ptr(), 512, bo.data_ptr(), 256, MEM_DEVICE)), ES)
+        assert torch.equal(bo[:BE], em) and torch.equal(bo[BE:], em), "[bench] Decrypt-2048 x 131072 round trip failed"
+        extras.append(entry("decrypt_2048_b131072", "Batch 131072 Decrypt, 2048-bit n, level 1, CRT (the headline path, twice the batch)",
+                            "decryptions/s", BB, dt, vms, mads, kern, "131072-lane round trip"))
+        del bc, bo
+
         # config 3: Batch 65536 Decrypt, 3072-bit
         p3, q3, n3k, lam3 = paillier_key(3072)
         pk3 = pa.PublicKey(ctx, n3k, n3k + 1)

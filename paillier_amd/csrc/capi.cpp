@@ -274,12 +274,30 @@ struct Prog {
       has_mulv = true;
       gather_slots = std::max<uint32_t>(gather_slots, o == VM_MULV ? 17u : o == VM_MULV5 ? 33u : 129u);
     }
+    if (aux >> 22) api_throw(PGPU_ERR_INVALID, "internal: table slot does not fit the instruction word");
     w.push_back(o | (aux << 8));
     w.push_back(arg);
     if (o == VM_SQR || o == VM_MUL || o == VM_MULC || o == VM_MULV || o == VM_MULCV || o == VM_MULV5 || o == VM_MULV7) montmuls += 1;
     if (o == VM_SQR) sqrs += 1;
   }
-  void end() { op(VM_END); }
+  // Bits 30..31 of an instruction word: the priority the wave takes when it gets there -- 3, 2, 1, 0 over four stretches of a
+  // long program (by products done), so that of two waves sharing a SIMD the one that leads yields to the one behind
+  // (gen_vm_asm.py fair_share; the hipcc kernels ignore the bits).  What is lost is the END of the launch, where the wave
+  // that finishes first leaves the other one alone on the SIMD for most of the last stretch -- so the stretches shrink
+  // geometrically (80 %, 16 %, 3.2 %, 0.8 %: the wave that yields crawls at ~7 % of the other's speed, so a stretch has to be
+  // longer than 7 % of the one before it or the leader would run out of program while the other is still catching up).
+  void end() {
+    op(VM_END);
+    if (montmuls < 256) return;
+    double done = 0;
+    for (size_t i = 0; i + 1 < w.size(); i += 2) {
+      const uint32_t o = w[i] & 0xFFu;
+      const double f = done / montmuls;
+      const uint32_t quarter = f < 0.80 ? 0u : f < 0.96 ? 1u : f < 0.992 ? 2u : 3u;
+      w[i] = (w[i] & 0x3FFFFFFFu) | ((3u - quarter) << 30);
+      if (o == VM_SQR || o == VM_MUL || o == VM_MULC || o == VM_MULV || o == VM_MULCV || o == VM_MULV5 || o == VM_MULV7) done += 1;
+    }
+  }
 };
 
 constexpr uint32_t NO_SLOT = 0xFFFFFFFFu;

@@ -132,6 +132,7 @@ class Gen:
         """Up to three program segments per launch (VmArgs: seg[3], then seg0_blocks, seg1_blocks): blocks [0, b0) run segment
         0, [b0, b0 + b1) segment 1, the rest segment 2.  Leaves s[0:1] at this block's VmSeg and s2 = block index inside it."""
         e = self.e
+        stagger = getattr(self, "stagger", 0)
         e(f"s_load_dwordx2 s[4:5], s[0:1], {hex(3 * 48)}")     # seg0_blocks, seg1_blocks
         e("s_waitcnt lgkmcnt(0)")
         e("s_cmp_ge_u32 s2, s4")
@@ -139,6 +140,12 @@ class Gen:
         e("s_sub_u32 s2, s2, s4")                               # block index inside segment 1 (or beyond)
         e("s_add_u32 s0, s0, 48")
         e("s_addc_u32 s1, s1, 0")
+        for _ in range(stagger):
+            # The blocks of segment 1 start a fraction of a product late.  With every block resident from the start (the two
+            # halves of a 65536-ciphertext Decrypt are exactly two waves per SIMD), block i of segment 0 and block i of segment 1
+            # share a CU and would run their table builds and first windows in lock step -- both waves of a SIMD waiting for
+            # memory at the same moments.
+            e("s_sleep 127")
         e("s_cmp_ge_u32 s2, s5")
         e("s_cbranch_scc0 L_seg0")
         e("s_sub_u32 s2, s2, s5")                               # block index inside segment 2
@@ -158,6 +165,7 @@ class Gen:
         e(f"{self.name}:")
         # s[0:1] kernarg, s2 workgroup id, v0 workitem id
         self.select_segment()
+        self.timing_begin()
         e("s_load_dwordx8 s[4:11], s[0:1], 0x0")   # prog, nmod, consts, mem
         e("s_load_dwordx4 s[12:15], s[0:1], 0x20")  # digits, n0inv, nb
         e("s_waitcnt lgkmcnt(0)")
@@ -238,6 +246,61 @@ class Gen:
         for j in range(WL):
             e(f"v_mov_b32 {self.X(j)}, 0")
 
+    def fair_share(self):
+        """Issue arbitration between the waves of a SIMD is oldest-first: of two co-resident waves running the same long
+        program the older one takes every slot it can use and the younger one only the bubbles it leaves (~7 % of the slots),
+        so the older wave finishes after 55 % of the launch and the younger then runs ALONE for the other 45 % -- and a single
+        wave cannot fill the SIMD (it issues at ~93 % of the rate two interleaved waves reach).  Measured with the wave
+        timeline of tools/wave_timeline.py: 1 024 waves of a 2 048-wave launch end at 15.6 ms, the other 1 024 at 28.4 ms.  A
+        launch whose workgroups are all resident from the start -- 65 536 ciphertexts are exactly two waves per SIMD -- loses
+        ~3 % that way.  So a wave's priority FALLS with its progress: the host writes 3, 2, 1, 0 into the top two bits of the
+        instruction words of the four quarters of a long program (Prog::end), and the wave that leads enters the next quarter
+        with the lower priority, lets the other one catch up, and so on: they finish within a fraction of a quarter of each
+        other.  (s_setprio takes an immediate: four-way branch.)"""
+        if not getattr(self, "fair", True):
+            return
+        e = self.e
+        e("s_lshr_b32 s18, s16, 30")
+        for k in range(3):
+            e(f"s_cmp_lg_u32 s18, {k}")
+            e(f"s_cbranch_scc1 L_prio{k + 1}")
+            e(f"s_setprio {k}")
+            e("s_branch L_prio_done")
+            e(f"L_prio{k + 1}:")
+        e("s_setprio 3")
+        e("L_prio_done:")
+
+    def timing_begin(self):
+        """Debug builds (PGPU_GEN_TIMING=1, K == 1 kernels, tools/wave_timeline.py): every wave notes when it started ..."""
+        if not getattr(self, "timing", False):
+            return
+        e = self.e
+        e("s_memrealtime s[100:101]")
+        e("v_readfirstlane_b32 s99, v0")
+        e("s_lshr_b32 s99, s99, 6")
+        e("s_lshl_b32 s98, s2, 2")
+        e("s_add_u32 s99, s99, s98")           # wave index inside the segment
+        e("s_waitcnt lgkmcnt(0)")
+
+    def end_of_program(self):
+        """... and, at END, writes (start, end) of the 100 MHz real-time counter, HW_ID and XCC_ID to the first words of slot 0
+        (32 bytes per wave, lane 0 only).  Product builds end the program here."""
+        e = self.e
+        if getattr(self, "timing", False):
+            e("s_memrealtime s[96:97]")
+            e("s_getreg_b32 s98, hwreg(HW_REG_HW_ID)")
+            e("s_getreg_b32 s18, hwreg(20, 0, 32)")       # XCC_ID
+            e("s_waitcnt lgkmcnt(0)")
+            e("s_mov_b64 exec, 1")
+            for i, sr in enumerate(("s100", "s101", "s96", "s97", "s98", "s18")):
+                e(f"v_mov_b32 v{i}, {sr}")
+            e("s_lshl_b32 s99, s99, 5")
+            e("v_mov_b32 v6, s99")
+            e("global_store_dwordx4 v6, v[0:3], s[10:11]")
+            e("global_store_dwordx2 v6, v[4:5], s[10:11] offset:16")
+            e("s_waitcnt vmcnt(0)")
+        e("s_endpgm")
+
     # scalar base of a memory slot: s[sbase] = mem + arg * WT*nb*4
     def slot_base(self):
         g = self
@@ -306,13 +369,14 @@ class Gen:
         e("s_add_u32 s4, s4, 8")
         e("s_addc_u32 s5, s5, 0")
         e("s_waitcnt lgkmcnt(0)")
+        self.fair_share()
         e("s_and_b32 s18, s16, 0xff")
         # MULV7 / STORET (number-major tables) exist on the three-digit kernels only; the host emits them nowhere else
         nm_tables = ("MULV7", "STORET") if getattr(self, "number_major_tables", False) else ()
         for nm in ("SQR", "MUL", "MULC", "MULV", "MULV5") + nm_tables + ("MULCV", "LOAD", "STORE", "LOADC", "ADD"):
             e(f"s_cmp_eq_u32 s18, {OPS[nm]}")
             e(f"s_cbranch_scc1 L_{nm.lower()}")
-        e("s_endpgm")  # END (and anything unsupported: the host never sends those)
+        self.end_of_program()  # END (and anything unsupported: the host never sends those)
 
         e("L_load:")
         self.slot_base()
@@ -371,7 +435,7 @@ class Gen:
             e(f"v_and_b32 v{g.v_t3}, {(1 << wbits) - 1}, v{g.v_t3}")           # digit
             e(f"s_mul_i32 s{g.s_t0}, s3, {self.WT}")                           # slot stride in bytes
             e(f"v_mul_lo_u32 v{g.v_t3}, v{g.v_t3}, s{g.s_t0}")                  # digit * stride (host guarantees < 2^32)
-            e("s_lshr_b32 s17, s16, 8")                                        # aux = first table slot
+            e("s_bfe_u32 s17, s16, 0x160008")                                  # aux = first table slot (bits 8..29)
             e(f"s_mul_hi_u32 s{g.s_sbase + 1}, s17, s{g.s_t0}")
             e(f"s_mul_i32 s{g.s_sbase}, s17, s{g.s_t0}")
             e(f"s_add_u32 s{g.s_sbase}, s{g.s_sbase}, s10")
@@ -407,7 +471,7 @@ class Gen:
         e(f"v_and_b32 v{g.v_t3}, 15, v{g.v_t3}")                           # digit
         e(f"v_mul_u32_u24 v{g.v_t3}, {self.WT * 4}, v{g.v_t3}")            # digit * entry bytes
         e(f"v_add_u32 v{g.v_t3}, v{g.v_t3}, v{g.v_koff}")
-        e("s_lshr_b32 s98, s16, 8")                                        # aux
+        e("s_bfe_u32 s98, s16, 0x160008")                                  # aux (bits 8..29)
         e("s_lshl_b32 s17, s17, 4")                                        # 16*arg
         e("s_add_u32 s17, s17, s98")
         e(f"s_mul_hi_u32 s{g.s_sbase + 1}, s17, {self.WT * 4}")
@@ -943,6 +1007,7 @@ class GenW(Gen):
     """
 
     def __init__(self, WL, S, depth=8):
+        self.fair = False          # the two waves of a number wait for each other's ring words: no priority games here
         assert S == 2, "two wave slices for now"
         Gen.__init__(self, WL, 1, depth)
         self.S = S
@@ -1487,6 +1552,9 @@ class GenP(Gen):
         self.sq_self_staged = True # a squaring writes its (doubled) multipliers to the LDS column itself, row by row
         self.vM = 2 * H            # quotient digits m_i of phase 1 (phase 2 starts from Cadj_i - m_i)
         self.vA = 3 * H            # new a0 of a MUL (the old one is still an operand of phase 2)
+        import os
+        self.stagger = int(os.environ.get("PGPU_GEN_STAGGER", "0"))        # experiments (measured: no effect)
+        self.timing = os.environ.get("PGPU_GEN_TIMING", "0") == "1"        # debug build for tools/wave_timeline.py
 
     def X0(self, j):
         return self.X(j)
@@ -1779,6 +1847,7 @@ class GenP2(GenP):
         e("s_add_u32 s4, s4, 8")
         e("s_addc_u32 s5, s5, 0")
         e("s_waitcnt lgkmcnt(0)")
+        self.fair_share()
         e("s_and_b32 s18, s16, 0xff")
         for nm in ("SQR", "MUL", "MULC", "LOAD", "STORE", "LOADC", "ADD"):
             e(f"s_cmp_eq_u32 s18, {OPS[nm]}")
@@ -2656,7 +2725,7 @@ class GenQ3(Gen):
         e(f"v_and_b32 v{g.v_t3}, 127, v{g.v_t3}")                          # digit
         e(f"s_mul_i32 s{g.s_t0}, s3, {self.WT}")                           # slot stride in bytes
         e(f"v_mul_lo_u32 v{g.v_t3}, v{g.v_t3}, s{g.s_t0}")                  # digit * stride (host guarantees < 2^32)
-        e("s_lshr_b32 s17, s16, 8")                                        # aux = first table slot
+        e("s_bfe_u32 s17, s16, 0x160008")                                  # aux = first table slot (bits 8..29)
         e(f"s_mul_hi_u32 s{g.s_sbase + 1}, s17, s{g.s_t0}")
         e(f"s_mul_i32 s{g.s_sbase}, s17, s{g.s_t0}")
         e(f"s_add_u32 s{g.s_sbase}, s{g.s_sbase}, s10")

@@ -100,7 +100,7 @@ __global__ void __launch_bounds__(VM_BLOCK, (3 * WL + 24 <= 256) ? 2 : 1) vm_ker
       // fixed-base comb: table entry (window arg, digit of this number's exponent) of a table shared by the batch
       const uint32_t elimb = sg.digits[(size_t)(arg / 7u) * nb + g];
       const uint32_t digit = (elimb >> (4u * (arg % 7u))) & 15u;
-      const uint32_t* p = sg.consts + ((size_t)(w0 >> 8) + 16u * arg + digit) * WT + (size_t)k * WL;
+      const uint32_t* p = sg.consts + ((size_t)((w0 >> 8) & 0x3FFFFFu) + 16u * arg + digit) * WT + (size_t)k * WL;
 #pragma unroll
       for (int j = 0; j < WL; ++j) col[j * NPB] = p[j];
     } else {
@@ -109,16 +109,16 @@ __global__ void __launch_bounds__(VM_BLOCK, (3 * WL + 24 <= 256) ? 2 : 1) vm_ker
         // arg = index of a 4-bit window of this number's own exponent (7 windows per 28-bit limb);
         // aux = first table slot.  The table index differs per number: a gather, not a branch.
         const uint32_t elimb = sg.digits[(size_t)(arg / 7u) * nb + g];
-        slot = (size_t)(w0 >> 8) + ((elimb >> (4u * (arg % 7u))) & 15u);
+        slot = (size_t)((w0 >> 8) & 0x3FFFFFu) + ((elimb >> (4u * (arg % 7u))) & 15u);
       } else if (op == VM_MULV5) {
         // 5-bit windows of the exponent repacked as 25-bit words (5 windows per word); 32-entry table
         const uint32_t eword = sg.digits[(size_t)(arg / 5u) * nb + g];
-        slot = (size_t)(w0 >> 8) + ((eword >> (5u * (arg % 5u))) & 31u);
+        slot = (size_t)((w0 >> 8) & 0x3FFFFFu) + ((eword >> (5u * (arg % 5u))) & 31u);
       }
       if (op == VM_MULV7) {
         // 7-bit windows, 4 per 28-bit limb; 128-entry table whose slots are number-major (written by VM_STORET)
         const uint32_t elimb = sg.digits[(size_t)(arg / 4u) * nb + g];
-        slot = (size_t)(w0 >> 8) + ((elimb >> (7u * (arg % 4u))) & 127u);
+        slot = (size_t)((w0 >> 8) & 0x3FFFFFu) + ((elimb >> (7u * (arg % 4u))) & 127u);
         const uint32_t* p = sg.mem + slot * WT * nb + (g + goff) * WT + (size_t)k * WL;
 #pragma unroll
         for (int j = 0; j < WL; ++j) col[j * NPB] = p[j];
