@@ -23,18 +23,20 @@ if [ "$what" = all ] || [ "$what" = pmc ]; then
   python3 - "$out" <<'PY'
 import csv, glob, sys, collections
 out = sys.argv[1]
-kernels = ["vm_asm_37_16", "vm_asm_74_32", "vm_asm_55_32", "vm_asm_74_48", "vm_asm_37_64", "vm_asm_55_2", "vm_asm_55_4"]
+kernels = ["vm_asm_37_16", "vm_asm_74_32", "vm_asm_55_16", "vm_asm_74_48", "vm_asm_37_48", "vm_asm_37_64"]
 acc = collections.defaultdict(lambda: collections.defaultdict(list))
 for f in glob.glob(f"{out}/pmc_*/**/*counter_collection.csv", recursive=True):
     per = collections.defaultdict(float)
     for r in csv.DictReader(open(f)):
         for k in kernels:
             if r["Kernel_Name"].startswith(k):
-                per[(k, r["Dispatch_Id"], r["Counter_Name"])] += float(r["Counter_Value"])
+                # one entry per launch shape: the same kernel runs 65536- and 131072-ciphertext batches in bench.py
+                kk = f'{k} grid {r["Grid_Size"]}' if "Grid_Size" in r else k
+                per[(kk, r["Dispatch_Id"], r["Counter_Name"])] += float(r["Counter_Value"])
     for (k, d, c), v in per.items():
         acc[k][c].append(v)
 with open(f"{out}/bench_pmc_summary.txt", "w") as o:
-    for k in kernels:
+    for k in sorted(acc):
         if not acc[k]:
             continue
         o.write(f"[{k}]  (per dispatch; median over the dispatches of the run; sums over all SEs / XCDs)\n")
