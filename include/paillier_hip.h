@@ -168,8 +168,9 @@ int pgpu_partial_decrypt(const pgpu_pubkey* pk, int total_servers, const uint8_t
 
 /* ThresholdSecretKey.PartialDecrypt of ONE ciphertext batch by SEVERAL servers (a process that holds more than one share:
  * the shape of the reference's own BenchmarkThresholdDecrypt, thresholdkey_test.go:396-427): outs[k][i] = c[i]^(2 * l! * shares[k]).
- * The entry conversion of the ciphertexts is done once and the ladders of two servers share a launch, so that a batch which
- * alone would leave the chip half empty runs on the efficient two-lane kernel. */
+ * The entry conversion of the ciphertexts is done once.  From 8 192 ciphertexts up all the shares' ladders share ONE chain of
+ * squarings (right-to-left windows into buckets; three servers cost about 1.5 ladders); below that the ladders of two servers
+ * share a launch.  Same integers either way. */
 int pgpu_partial_decrypt_multi(const pgpu_pubkey* pk, int total_servers, int n_shares, const uint8_t* const* shares_be,
                                const size_t* share_lens, size_t batch, const uint8_t* c, size_t c_stride, uint8_t* const* outs,
                                size_t out_stride, int mem);
