@@ -76,6 +76,7 @@ struct pgpu_ctx {
   bool use_pair = true;      // Decrypt ladders mod p^2 on the pair kernel (pgpu_ctx_set_flag("pair", 0): the 2H-limb kernel)
   bool use_triple = true;    // ladders modulo n^3 on the three-digit kernel (pgpu_ctx_set_flag("triple", 0): the 3H-limb kernels)
   bool use_shared_chain = true;   // several shared exponents on ONE base share the chain of squarings (pgpu_partial_decrypt_multi)
+  bool use_lift = true;           // level-two Encrypt: r^(n^2) mod n^3 as (r^n mod n^2)^n mod n^3
   size_t lanes_wanted = 0;   // 0: default occupancy target; tests set 1 to run every modulus at its natural shape
 
   void bind() { HIPCHK(hipSetDevice(device)); }
@@ -977,6 +978,7 @@ int pgpu_ctx_set_flag(pgpu_ctx* ctx, const char* name, int value) {
   if (strcmp(name, "pair") == 0) { ctx->use_pair = value != 0; return PGPU_OK; }
   if (strcmp(name, "triple") == 0) { ctx->use_triple = value != 0; return PGPU_OK; }
   if (strcmp(name, "shared_chain") == 0) { ctx->use_shared_chain = value != 0; return PGPU_OK; }
+  if (strcmp(name, "lift") == 0) { ctx->use_lift = value != 0; return PGPU_OK; }
   if (strcmp(name, "lanes_wanted") == 0) { ctx->lanes_wanted = value > 0 ? (size_t)value : 0; return PGPU_OK; }
   if (strcmp(name, "cu_partition") == 0) {
     // value = (parts << 16) | part: confine this context's (own) stream to the part-th of `parts` equal slices of the
@@ -2626,6 +2628,21 @@ static void encrypt_core(const pgpu_pubkey* pk, int level, size_t batch, const u
   const size_t nb = round_up(batch, VM_BLOCK);
   ModexpPlan pl = modexp_alloc(ctx, mc, nb, 32);
   build_gm(ctx, pk, level, m, m_stride, batch, mem, nb, pl.post());
+  if (level == PGPU_LEVEL_TWO && ctx->use_lift) {
+    // r^(n^2) mod n^3 = ((r mod n^2)^n mod n^2)^n mod n^3 for EVERY integer r: x = x' (mod n^k) implies x^n = x'^n (mod n^(k+1))
+    // (binomial: the second term of (x' + t n^k)^n is n x'^(n-1) t n^k).  Half of the 4 096 squarings of paillier.go:213's
+    // Exp(r, n^2, n^3) move to the modulus n^2, where a squaring costs half as much: level-two Encrypt -20 %.
+    const ModCtx& m2 = pk->mn2;
+    ModexpPlan p2 = modexp_alloc(ctx, m2, nb, 32);
+    if (r_limbs) reduce_mod(ctx, m2, r_limbs, mc.WT, p2.in(), nb);
+    else unpack_mod(ctx, m2, r, r_stride, batch, mem, p2.in(), nb, true);
+    modexp_shared_run(ctx, m2, p2, pk->N, false, false, true);              // y = r^n mod n^2
+    launch_copy_limbs(p2.out(), 0, m2.WT, pl.in(), mc.WT, nb, ctx->stream);
+    modexp_shared_run(ctx, mc, pl, pk->N, false, true, true);               // y^n * g^m mod n^3
+    pack_result(ctx, pl.out(), mc.WT, nb, batch, c, c_stride, mc.nbytes, mem);
+    HIPCHK(hipStreamSynchronize(ctx->stream));
+    return;
+  }
   if (r_limbs) HIPCHK(hipMemcpyAsync(pl.in(), r_limbs, (size_t)mc.WT * nb * 4, hipMemcpyDeviceToDevice, ctx->stream));
   else unpack_mod(ctx, mc, r, r_stride, batch, mem, pl.in(), nb);
   const BigU& ns = (level == PGPU_LEVEL_ONE) ? pk->N : pk->mn2.N;

@@ -132,3 +132,32 @@ def test_host_randomness_forms(ctx):
     nested = pk.NestedEncryptBatch(ms)
     assert sk.NestedDecryptBatch(nested) == ms
     assert sk.NestedDecryptBatch(nested[:2]) == [po.nested_decrypt(sk_o, po.Ciphertext(c, po.ENC_LEVEL_TWO)) for c in nested[:2]]
+
+
+@pytest.mark.parametrize("bits", ["1024", "2048"])
+def test_level_two_encrypt_lifts_through_n_squared(ctx, bits):
+    """Level-two EncryptWithR computes r^(n^2) mod n^3 (paillier.go:213) as ((r mod n^2)^n mod n^2)^n mod n^3 -- an identity
+    for EVERY integer r (x = x' mod n^k implies x^n = x'^n mod n^(k+1)), units or not, reduced or not.  With the lift switched
+    off the literal exponentiation runs; both must give the oracle's integers."""
+    import paillier_amd as pa
+    from paillier_amd import ENC_LEVEL_TWO
+    k = json.load(open(os.path.join(G, "keys.json")))["paillier"][bits]
+    p, q = int(k["p"], 16), int(k["q"], 16)
+    n = p * q
+    n2, n3 = n * n, n ** 3
+    rng = random.Random(int(bits) + 9)
+    rs = [1, 2, n - 1, p, q, 3 * p, n2 - 1, n + 5, n2 - n - 1] + [rng.randrange(1, n) for _ in range(280)] + [rng.randrange(n2) for _ in range(8)]
+    ms = [rng.randrange(n2) for _ in rs]
+    pk = pa.PublicKey(ctx, n, n + 1)
+    sk_o = po.PublicKey(N=n, G=n + 1)
+    got = {}
+    try:
+        for flag in (1, 0):
+            ctx.set_flag("lift", flag)
+            got[flag] = pk.EncryptWithRBatch(ms, rs, level=ENC_LEVEL_TWO)
+    finally:
+        ctx.set_flag("lift", 1)
+    assert got[1] == got[0]
+    idx = list(range(12)) + list(range(len(rs) - 8, len(rs)))
+    assert [got[1][i] for i in idx] == [po.encrypt_with_r_at_level(sk_o, ms[i], rs[i], po.ENC_LEVEL_TWO).C for i in idx]
+    assert [got[1][i] for i in idx] == [pow(rs[i], n2, n3) * (1 + ms[i] * n + ms[i] * (ms[i] - 1) // 2 * n2) % n3 for i in idx]
