@@ -1928,7 +1928,6 @@ uint32_t* decrypt1_crt(const pgpu_seckey* sk, const uint32_t* c_limbs, size_t nb
   // big VM memory: slots 0,1 = c (lo, hi); P: tmp 2, out 3, table 4..35; Q: tmp 36, out 37, table 38..69; 70..73 chunks of c
   uint32_t* mem = ctx->ws_t<uint32_t>(S2 * 74);
   bool pair_done = false;
-  HIPCHK(hipMemcpyAsync(mem, c_limbs, S2 * 2 * 4, hipMemcpyDeviceToDevice, ctx->stream));
   uint32_t *up = mem + 3 * S2, *uq = mem + 37 * S2;
   // (the two-lane kernel needs 2 lanes x 2 halves per ciphertext to fill the chip; below that the finer slicings win)
   const size_t lanes_target = ctx->lanes_wanted ? ctx->lanes_wanted : (size_t)1024 * 64;
@@ -1946,8 +1945,7 @@ uint32_t* decrypt1_crt(const pgpu_seckey* sk, const uint32_t* c_limbs, size_t nb
     //          (F1 + Cadj - m'') R^-1 = (F - 1)/p mod p = L_p -- Paillier's L function falls out of the last Montgomery step.
     pair_done = true;
     const uint32_t CH = 70;
-    for (int k2 = 0; k2 < 4; ++k2)
-      launch_copy_limbs(c_limbs, k2 * W1, W1, mem + (size_t)(CH + k2) * S2, W2, nb, ctx->stream);
+    launch_copy_chunks(c_limbs, W1, 4, mem + (size_t)CH * S2, S2, W2, nb, ctx->stream);
     {
       auto entry = [&](Prog& pr, const int* ck, int onep, uint32_t acc) {
         pr.op(VM_LOAD, CH); pr.op(VM_MULC, (uint32_t)ck[0]); pr.op(VM_STORE, acc);
@@ -1971,6 +1969,7 @@ uint32_t* decrypt1_crt(const pgpu_seckey* sk, const uint32_t* c_limbs, size_t nb
       run_vm(ctx, nb, sp, &sq, true);
     }
   } else {
+    HIPCHK(hipMemcpyAsync(mem, c_limbs, S2 * 2 * 4, hipMemcpyDeviceToDevice, ctx->stream));
     Prog pp, pq;
     emit_modexp_shared(pp, sk->p - BigU(1), 0, 1, 2, 3, 4, NO_SLOT, true);
     pp.end();
@@ -2505,12 +2504,19 @@ int pgpu_decrypt(const pgpu_seckey* sk, int level, size_t batch, const uint8_t* 
     std::vector<int32_t> hstat(batch, 0);
     if (crt) {
       res = decrypt1_crt(sk, cl, nb, batch, d_status);
+      // the plaintexts are packed while the status words travel to the host (no idle GPU behind the read-back); only when a
+      // lane turns out to be a non-unit are they packed again after its recomputation
+      pack_result(ctx, res, pk->mn.WT, nb, batch, m, m_stride, pk->mn.nbytes, mem);
       HIPCHK(hipMemcpyAsync(hstat.data(), d_status, batch * 4, hipMemcpyDeviceToHost, ctx->stream));
       HIPCHK(hipStreamSynchronize(ctx->stream));
       std::vector<uint32_t> idx;
       for (size_t i = 0; i < batch; ++i)
         if (hstat[i] & PGPU_LANE_NONUNIT) idx.push_back((uint32_t)i);
-      if (!idx.empty()) {
+      if (idx.empty()) {
+        if (status) memcpy(status, hstat.data(), batch * 4);
+        return;
+      }
+      {
         // gcd(c, n) != 1 on these lanes: the CRT shortcut (L exact) does not apply; run the reference formula on them
         const size_t nbg = round_up(idx.size(), VM_BLOCK);
         uint32_t* d_idx = ctx->upload_words(idx);

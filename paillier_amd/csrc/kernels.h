@@ -58,6 +58,7 @@ void launch_is_zero(const uint32_t* x, int w, size_t nb, int32_t* flags, hipStre
 void launch_select_const(const int32_t* flags, const uint32_t* c, uint32_t* x, int w, size_t nb, hipStream_t st);
 void launch_sub_mod(const uint32_t* a, const uint32_t* b, const uint32_t* q, uint32_t* out, int w, size_t nb, hipStream_t st);
 void launch_copy_limbs(const uint32_t* in, int l0, int w, uint32_t* out, int wo, size_t nb, hipStream_t st);
+void launch_copy_chunks(const uint32_t* in, int w, int nchunks, uint32_t* out, size_t out_stride, int wo, size_t nb, hipStream_t st);
 void launch_fill_const(const uint32_t* c, uint32_t* out, int wo, size_t nb, hipStream_t st);
 void launch_gather(const uint32_t* in, size_t nb_in, const uint32_t* idx, size_t n_idx, uint32_t* out, size_t nb_out, int w, hipStream_t st);
 void launch_scatter(const uint32_t* in, size_t nb_in, const uint32_t* idx, size_t n_idx, uint32_t* out, size_t nb_out, int w, hipStream_t st);

@@ -171,6 +171,25 @@ __global__ void k_unpack_be(const uint8_t* __restrict__ in, size_t stride, size_
   size_t g = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (g >= nb) return;
   const uint8_t* p = in + g * stride;
+  if (g < count && ((nbytes | stride | (size_t)(uintptr_t)in) & 3) == 0) {
+    // whole 32-bit words through a sliding 64-bit window: one word load per 32 bits instead of five byte loads per limb
+    const uint32_t* pw = (const uint32_t*)p;
+    const size_t nw = nbytes / 4;
+    uint64_t win = 0;
+    int have = 0;
+    size_t k = 0;
+    for (int l = 0; l < wt; ++l) {
+      if (have < LB && k < nw) {
+        win |= (uint64_t)__builtin_bswap32(pw[nw - 1 - k]) << have;
+        have += 32;
+        ++k;
+      }
+      out[(size_t)l * nb + g] = (uint32_t)win & LMASK;
+      win >>= LB;
+      have = have > LB ? have - LB : 0;
+    }
+    return;
+  }
   for (int l = 0; l < wt; ++l) {
     uint32_t v = 0;
     if (g < count) {
@@ -575,6 +594,15 @@ __global__ void k_copy_limbs(const uint32_t* __restrict__ in, int l0, int w, uin
   for (int l = 0; l < wo; ++l) out[(size_t)l * nb + g] = (l < w) ? in[(size_t)(l0 + l) * nb + g] : 0u;
 }
 
+// the same for `nchunks` consecutive w-limb pieces of `in` at once: piece k -> out + k * out_stride (wo limbs each, zero-extended)
+__global__ void k_copy_chunks(const uint32_t* __restrict__ in, int w, int nchunks, uint32_t* __restrict__ out, size_t out_stride,
+                              int wo, size_t nb) {
+  size_t g = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (g >= nb) return;
+  for (int k = 0; k < nchunks; ++k)
+    for (int l = 0; l < wo; ++l) out[(size_t)k * out_stride + (size_t)l * nb + g] = (l < w) ? in[(size_t)(k * w + l) * nb + g] : 0u;
+}
+
 // fill a limb-major array with a uniform constant (wo limbs)
 __global__ void k_fill_const(const uint32_t* __restrict__ c, uint32_t* __restrict__ out, int wo, size_t nb) {
   size_t g = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -928,6 +956,9 @@ void launch_sub_mod(const uint32_t* a, const uint32_t* b, const uint32_t* q, uin
 }
 void launch_copy_limbs(const uint32_t* in, int l0, int w, uint32_t* out, int wo, size_t nb, hipStream_t st) {
   hipLaunchKernelGGL(k_copy_limbs, HELPER_GRID(nb), 0, st, in, l0, w, out, wo, nb);
+}
+void launch_copy_chunks(const uint32_t* in, int w, int nchunks, uint32_t* out, size_t out_stride, int wo, size_t nb, hipStream_t st) {
+  hipLaunchKernelGGL(k_copy_chunks, HELPER_GRID(nb), 0, st, in, w, nchunks, out, out_stride, wo, nb);
 }
 void launch_fill_const(const uint32_t* c, uint32_t* out, int wo, size_t nb, hipStream_t st) {
   hipLaunchKernelGGL(k_fill_const, HELPER_GRID(nb), 0, st, c, out, wo, nb);
