@@ -227,6 +227,38 @@ def test_ddleq_prove_on_device(ctx):
     assert "cannot prove re-encryption" in str(ei.value)
 
 
+def test_ddleq_prove_3072_bit_key(ctx):
+    """The prover at 3072 bits: halves modulo p^3, q^3 on the three-digit kernel for 55-limb primes (vm_asm_55_48), a^n | x^n
+    through p^2, q^2 on the one-lane pair kernel for 55-limb primes (vm_asm_55_16); the verifier's n^3 is 9 216 bits (the
+    compiler-generated (83,4) kernel).  Few instances: the oracle's 9 216-bit powers are slow."""
+    import json as _json
+    import paillier_amd as pa
+    k = _json.load(open(os.path.join(G, "keys.json")))["paillier"]["3072"]
+    p, q = int(k["p"], 16), int(k["q"], 16)
+    n, lam = p * q, (p - 1) * (q - 1)
+    sk_o = po.SecretKey(N=n, G=n + 1, Lambda=lam)
+    pk = pa.PublicKey(ctx, n, n + 1)
+    sk = pa.SecretKey(ctx, pk, lam)
+    rng = random.Random(3072)
+    B = 3
+    ct1 = [po.encrypt_with_r_at_level(sk_o, po.encrypt_with_r(sk_o, rng.randrange(n), po.rand_unit(n, rng)).C,
+                                      po.rand_unit(n, rng), po.ENC_LEVEL_TWO).C for _ in range(B)]
+    a_s, b_s, xs, ys = ([po.rand_unit(n, rng) for _ in range(B)] for _ in range(4))
+    ct2 = [po.nested_randomize_with_ab(sk_o, po.Ciphertext(c, 1), a, b).C for c, a, b in zip(ct1, a_s, b_s)]
+    assert pk.NestedRandomizeWithABBatch(ct1, a_s, b_s) == ct2
+    al, es, fs = sk.ProveDDLEQInstancesBatch(ct1, ct2, a_s, b_s, xs, ys)
+    refs = [po.prove_ddleq_instance_xy(sk_o, po.Ciphertext(c1, 1), po.Ciphertext(c2, 1), a, b, x, y)
+            for c1, c2, a, b, x, y in zip(ct1, ct2, a_s, b_s, xs, ys)]
+    assert (al, es, fs) == ([r.Alpha for r in refs], [r.E for r in refs], [r.F for r in refs])
+    # one verifier call: the three true statements and the same proofs against a neighbour's ct2
+    wrong = ct2[1:] + ct2[:1]
+    got = pk.VerifyDDLEQInstancesBatch(ct1 + ct1, ct2 + wrong, xs + xs, ys + ys, al + al, es + es, fs + fs)
+    assert got[:B] == [True] * B
+    assert got[B:] == [po.verify_ddleq_proof_instance(sk_o, po.Ciphertext(c1, 1), po.Ciphertext(c2, 1),
+                                                      po.DDLEQProofInstance(x, y, a_, e, f))
+                       for c1, c2, x, y, a_, e, f in zip(ct1, wrong, xs, ys, al, es, fs)]
+
+
 def test_whole_protocol_forms(ctx):
     """ProveDDLEQ / VerifyDDLEQProof with host-drawn randomness (ddleq_test.go:9-72) and CombinePartialDecryptionsZKP /
     VerifyDecryption (thresholdkey_test.go:294-394): completeness, and a cheating server being dropped."""
