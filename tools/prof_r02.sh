@@ -13,6 +13,15 @@ if [ "$what" = all ] || [ "$what" = kernel-trace ]; then
   cp "$f" $out/bench_kernel_stats.csv
   head -25 $out/bench_kernel_stats.csv
 fi
+if [ "$what" = all ] || [ "$what" = headline ]; then
+  # the headline alone: in the full run the same kernel also serves the DDLEQ prover (a^n | x^n modulo p^2, q^2), which
+  # would blur its average duration
+  timeout -k 10 200 rocprofv3 --kernel-trace --stats --output-format csv -d $out/kh -o kh -- python3 bench.py --steps 20 --warmup 5 --no-extra --no-traffic --no-cpu-baseline > $out/kh.log 2>&1
+  f=$(find $out/kh -name '*kernel_stats.csv' | head -1)
+  cp "$f" $out/headline_kernel_stats.csv
+  head -4 $out/headline_kernel_stats.csv
+  tail -1 $out/kh.log | cut -c1-400
+fi
 if [ "$what" = all ] || [ "$what" = pmc ]; then
   i=0
   for set in "SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_WAVES" "SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_INST_ANY SQ_ACTIVE_INST_VALU" "GRBM_GUI_ACTIVE" "FETCH_SIZE" "WRITE_SIZE"; do
