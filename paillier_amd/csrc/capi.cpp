@@ -2976,6 +2976,40 @@ int pgpu_partial_decrypt(const pgpu_pubkey* pk, int total_servers, const uint8_t
   });
 }
 
+// Pair-form entry / exit shared by the multi-share forms of PartialDecrypt (N = n^2, root n public).
+// entry: canonical residues x (slot 0 of `ent`, 4 slots of mc.WT limbs, stride nb) -> digits X0 | X1 of x R_H in slot 2
+static void pair_enter(pgpu_ctx* ctx, const ModCtx& mc, uint32_t* ent, size_t nb) {
+  const PairInfo& pi = mc.pairn;
+  const ModCtx& mn = *pi.root;
+  const int H = mn.WT, W2 = mc.WT;
+  const size_t S1 = (size_t)H * nb, SW = (size_t)W2 * nb;
+  Prog a;
+  a.op(VM_LOAD, 0); a.op(VM_MULC, C_R2); a.op(VM_MULC, (uint32_t)pi.c_rh); a.op(VM_STORE, 3); a.end();
+  SegSpec sa{&mc, &a, ent, nullptr};
+  run_vm(ctx, nb, sa, nullptr, false);
+  launch_canon(ent + 3 * SW, mc.d_nmod, W2, nb, ctx->stream);
+  uint32_t* x0 = ctx->ws_t<uint32_t>(S1);
+  uint32_t* tb = ctx->ws_t<uint32_t>(SW);
+  reduce_mod(ctx, mn, ent + 3 * SW, W2, x0, nb);
+  launch_div_exact(ent + 3 * SW, W2, 0, x0, H, tb, pi.dinv, mn.d_nmod, H, ent + 2 * SW + S1, H, nb, nb, nullptr, 0, ctx->stream);
+  HIPCHK(hipMemcpyAsync(ent + 2 * SW, x0, S1 * 4, hipMemcpyDeviceToDevice, ctx->stream));
+}
+// exit: F~ = F0 + F1 n of slot `out_slot` of pm (stride nb), out of pair and Montgomery form, packed to dst (`count` results;
+// slots 2 and 3 of pm are scratch by now)
+static void pair_leave_and_pack(pgpu_ctx* ctx, const ModCtx& mc, uint32_t* pm, uint32_t out_slot, size_t nb, size_t count, uint8_t* dst,
+                                size_t out_stride, int mem) {
+  const PairInfo& pi = mc.pairn;
+  const int H = pi.root->WT, W2 = mc.WT;
+  const size_t S1 = (size_t)H * nb, SW = (size_t)W2 * nb;
+  launch_mul_const_add(pm + out_slot * SW + S1, H, pi.n_limbs, H, pm + out_slot * SW, H, 0, pm + 2 * SW, W2, nb, ctx->stream);
+  Prog a;
+  a.op(VM_LOAD, 2); a.op(VM_MULC, (uint32_t)pi.c_rh); a.op(VM_STORE, 3); a.end();
+  SegSpec sa{&mc, &a, pm, nullptr};
+  run_vm(ctx, nb, sa, nullptr, false);
+  launch_canon(pm + 3 * SW, mc.d_nmod, W2, nb, ctx->stream);
+  pack_result(ctx, pm + 3 * SW, W2, nb, count, dst, out_stride, mc.nbytes, mem);
+}
+
 int pgpu_partial_decrypt_multi(const pgpu_pubkey* pk, int total_servers, int n_shares, const uint8_t* const* shares_be,
                                const size_t* share_lens, size_t batch, const uint8_t* c, size_t c_stride, uint8_t* const* outs,
                                size_t out_stride, int mem) {
@@ -3016,28 +3050,10 @@ int pgpu_partial_decrypt_multi(const pgpu_pubkey* pk, int total_servers, int n_s
     const size_t S1 = (size_t)H * nb, SW = (size_t)W2 * nb;
     uint32_t* ent = ctx->ws_t<uint32_t>(SW * 4);          // generic slots: 0 x, 1 -, 2 digits (X0 | X1), 3 X
     unpack_mod(ctx, mc, c, c_stride, batch, mem, ent, nb);
-    {
-      Prog a;
-      a.op(VM_LOAD, 0); a.op(VM_MULC, C_R2); a.op(VM_MULC, (uint32_t)pi.c_rh); a.op(VM_STORE, 3); a.end();
-      SegSpec sa{&mc, &a, ent, nullptr};
-      run_vm(ctx, nb, sa, nullptr, false);
-      launch_canon(ent + 3 * SW, mc.d_nmod, W2, nb, ctx->stream);
-      uint32_t* x0 = ctx->ws_t<uint32_t>(S1);
-      uint32_t* tb = ctx->ws_t<uint32_t>(SW);
-      reduce_mod(ctx, mn, ent + 3 * SW, W2, x0, nb);
-      launch_div_exact(ent + 3 * SW, W2, 0, x0, H, tb, pi.dinv, mn.d_nmod, H, ent + 2 * SW + S1, H, nb, nb, nullptr, 0, ctx->stream);
-      HIPCHK(hipMemcpyAsync(ent + 2 * SW, x0, S1 * 4, hipMemcpyDeviceToDevice, ctx->stream));
-    }
+    pair_enter(ctx, mc, ent, nb);
     const size_t lanes_target = ctx->lanes_wanted ? ctx->lanes_wanted : (size_t)1024 * 64;
     auto leave_pair_form = [&](uint32_t* pm, uint32_t out_slot, uint8_t* dst) {
-      // F~ = F0 + F1 n, out of pair and Montgomery form (slots 2 and 3 of pm are free by now)
-      launch_mul_const_add(pm + out_slot * SW + S1, H, pi.n_limbs, H, pm + out_slot * SW, H, 0, pm + 2 * SW, W2, nb, ctx->stream);
-      Prog a;
-      a.op(VM_LOAD, 2); a.op(VM_MULC, (uint32_t)pi.c_rh); a.op(VM_STORE, 3); a.end();
-      SegSpec sa{&mc, &a, pm, nullptr};
-      run_vm(ctx, nb, sa, nullptr, false);
-      launch_canon(pm + 3 * SW, mc.d_nmod, W2, nb, ctx->stream);
-      pack_result(ctx, pm + 3 * SW, W2, nb, batch, dst, out_stride, mc.nbytes, mem);
+      pair_leave_and_pack(ctx, mc, pm, out_slot, nb, batch, dst, out_stride, mem);
     };
     if (n_shares >= 2 && ctx->use_shared_chain && pi.c_one_pair >= 0 && nb * 8 >= lanes_target) {
       // One chain of squarings for all the servers (emit_multi_exp_shared_base): the ciphertexts are the same, only the
@@ -3116,6 +3132,53 @@ int pgpu_partial_decrypt_indexed(const pgpu_pubkey* pk, int total_servers, int n
       if (!shares_be[k]) api_throw(PGPU_ERR_INVALID, "null share");
       exps_big.push_back(BigU::from_be(shares_be[k], share_lens[k]) * two_delta);
       ebits = std::max(ebits, exps_big.back().bit_length());
+    }
+    // A shard of the sharded threshold flow is a contiguous, server-major range of units: one, two or three RUNS of units
+    // with the same share.  Those are shared-exponent ladders (sliding windows: 618 products where the per-unit form below
+    // needs 1 026 and a gather each), side by side as program segments of ONE launch.
+    {
+      struct Run { int share; size_t b, e; };
+      std::vector<Run> runs;
+      for (size_t i = 0; i < batch && runs.size() <= 3;) {
+        size_t j = i;
+        while (j < batch && share_index[j] == share_index[i]) ++j;
+        runs.push_back({share_index[i], i, j});
+        i = j;
+      }
+      const PairInfo& pi = mc.pairn;
+      bool ok = runs.size() <= 3 && !runs.empty() && runs.back().e == batch && pi.root && ctx->use_asm && ctx->use_pair &&
+                ctx->use_shared_chain;
+      for (auto& r : runs) ok = ok && exps_big[(size_t)r.share].bit_length() >= 256;
+      if (ok) {
+        const ModCtx& mn = *pi.root;
+        const int H = mn.WT, W2 = mc.WT;
+        const size_t SW = (size_t)W2 * nb;
+        uint32_t* ent = ctx->ws_t<uint32_t>(SW * 4);
+        unpack_mod(ctx, mc, c, c_stride, batch, mem, ent, nb);
+        pair_enter(ctx, mc, ent, nb);
+        size_t longest = 0;
+        for (auto& r : runs) longest = std::max(longest, r.e - r.b);
+        const size_t nbs = round_up(longest, VM_BLOCK), SWs = (size_t)W2 * nbs;
+        const size_t lanes_target = ctx->lanes_wanted ? ctx->lanes_wanted : (size_t)1024 * 64;
+        const int lanes = (runs.size() * nbs * 2 >= lanes_target || !(H % 2 == 0 && vm_asm_available(H / 2, 64))) ? 2 : 4;
+        uint32_t* pm[3];
+        Prog pr[3];
+        SegSpec sg[3];
+        for (size_t k = 0; k < runs.size(); ++k) {
+          pm[k] = ctx->ws_t<uint32_t>(SWs * (size_t)(5 + 32));      // pair slots: 2 in, 3 out, 5.. table
+          launch_restride(ent + 2 * SW + runs[k].b, nb, runs[k].e - runs[k].b, nullptr, pm[k] + 2 * SWs, nbs, W2, ctx->stream);
+          emit_modexp_shared(pr[k], exps_big[(size_t)runs[k].share], 2, NO_SLOT, 2, 3, 5, NO_SLOT, true, true);
+          pr[k].end();
+          sg[k] = SegSpec{&mc, &pr[k], pm[k], nullptr};
+          sg[k].pair = pi.consts; sg[k].pair_n0inv = mn.n0inv; sg[k].pair_h = H; sg[k].pair_lanes = lanes;
+        }
+        run_vm(ctx, nbs, sg[0], runs.size() >= 2 ? &sg[1] : nullptr, true, 0, runs.size() == 3 ? &sg[2] : nullptr);
+        for (size_t k = 0; k < runs.size(); ++k)
+          pair_leave_and_pack(ctx, mc, pm[k], 3, nbs, runs[k].e - runs[k].b, out + runs[k].b * out_stride, out_stride, mem);
+        for (auto& e : exps_big) wipe_vec(e.d);
+        HIPCHK(hipStreamSynchronize(ctx->stream));
+        return;
+      }
     }
     const int we = (int)((ebits + LB - 1) / LB);
     std::vector<uint32_t> table;

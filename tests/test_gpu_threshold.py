@@ -184,3 +184,39 @@ def test_partial_decrypt_multi_shares_one_chain_of_squarings(ctx, lanes_wanted, 
     delta2 = 2 * 120
     for s, col in zip(shares, got[1]):
         assert col[:24] + col[-5:] == [pow(c, delta2 * s, n2) for c in cts[:24] + cts[-5:]]
+
+
+@pytest.mark.parametrize("lens,lanes_wanted", [((300, 41), 0), ((7, 250, 130), 1), ((513,), 0)])
+def test_partial_decrypt_indexed_runs_of_one_share(ctx, lens, lanes_wanted):
+    """A rank's shard of the threshold flow (paillier_amd/dist.py) is one to three RUNS of units under the same share:
+    pgpu_partial_decrypt_indexed turns those into shared-exponent ladders, one program segment per run, in ONE launch.
+    Ragged run lengths, both pair kernels; equal to the per-unit ladders (flag off) and to c^(2 Delta s_i) mod n^2."""
+    import numpy as np
+    import paillier_amd as pa
+    from paillier_amd.api import be_to_ints, ints_to_be
+    k = json.load(open(os.path.join(G, "keys.json")))["threshold"]["2048"]
+    n, total, thr = int(k["n"], 16), k["total"], k["threshold"]
+    shares = [int(s, 16) for s in k["shares"]]
+    tk = pa.ThresholdPublicKey(ctx, n, total=total, threshold=thr)
+    cb = tk.cipher_bytes()
+    rng = random.Random(91 + len(lens))
+    n2 = n * n
+    which = [4, 1, 3][:len(lens)]                       # share numbers of the runs
+    idx = np.concatenate([np.full(m, w, dtype=np.int32) for m, w in zip(lens, which)])
+    cts = [rng.randrange(n2) for _ in range(len(idx))]
+    cts[0], cts[-1] = 0, n
+    rows = ints_to_be(cts, cb)
+    got = {}
+    try:
+        ctx.set_flag("lanes_wanted", lanes_wanted)
+        for flag in (1, 0):
+            ctx.set_flag("shared_chain", flag)
+            out = np.zeros((len(cts), cb), dtype=np.uint8)
+            tk.partial_decrypt_indexed_raw(shares, idx, len(cts), rows, cb, out, cb)
+            got[flag] = be_to_ints(out)
+    finally:
+        ctx.set_flag("shared_chain", 1)
+        ctx.set_flag("lanes_wanted", 0)
+    assert got[1] == got[0]
+    pick = list(range(0, len(cts), 37)) + [len(cts) - 1] + [sum(lens[:i + 1]) - 1 for i in range(len(lens))] + [sum(lens[:i]) for i in range(len(lens))]
+    assert [got[1][i] for i in pick] == [pow(cts[i], 2 * 120 * shares[int(idx[i])], n2) for i in pick]
