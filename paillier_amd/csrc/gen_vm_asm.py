@@ -132,7 +132,6 @@ class Gen:
         """Up to three program segments per launch (VmArgs: seg[3], then seg0_blocks, seg1_blocks): blocks [0, b0) run segment
         0, [b0, b0 + b1) segment 1, the rest segment 2.  Leaves s[0:1] at this block's VmSeg and s2 = block index inside it."""
         e = self.e
-        stagger = getattr(self, "stagger", 0)
         e(f"s_load_dwordx2 s[4:5], s[0:1], {hex(3 * 48)}")     # seg0_blocks, seg1_blocks
         e("s_waitcnt lgkmcnt(0)")
         e("s_cmp_ge_u32 s2, s4")
@@ -140,12 +139,6 @@ class Gen:
         e("s_sub_u32 s2, s2, s4")                               # block index inside segment 1 (or beyond)
         e("s_add_u32 s0, s0, 48")
         e("s_addc_u32 s1, s1, 0")
-        for _ in range(stagger):
-            # The blocks of segment 1 start a fraction of a product late.  With every block resident from the start (the two
-            # halves of a 65536-ciphertext Decrypt are exactly two waves per SIMD), block i of segment 0 and block i of segment 1
-            # share a CU and would run their table builds and first windows in lock step -- both waves of a SIMD waiting for
-            # memory at the same moments.
-            e("s_sleep 127")
         e("s_cmp_ge_u32 s2, s5")
         e("s_cbranch_scc0 L_seg0")
         e("s_sub_u32 s2, s2, s5")                               # block index inside segment 2
@@ -1553,7 +1546,6 @@ class GenP(Gen):
         self.vM = 2 * H            # quotient digits m_i of phase 1 (phase 2 starts from Cadj_i - m_i)
         self.vA = 3 * H            # new a0 of a MUL (the old one is still an operand of phase 2)
         import os
-        self.stagger = int(os.environ.get("PGPU_GEN_STAGGER", "0"))        # experiments (measured: no effect)
         self.timing = os.environ.get("PGPU_GEN_TIMING", "0") == "1"        # debug build for tools/wave_timeline.py
 
     def X0(self, j):
