@@ -77,6 +77,32 @@ func (k *GPUPublicKey) AltEncryptWithRBatch(m, r []*gmp.Int, level EncryptionLev
 	return cts(unpack(out, cs), level, AlternativeEncryption), nil
 }
 
+// AltEncryptBatch: PublicKey.AltEncryptAtLevel (paillier.go:244-255): one fresh r in Z_n^* per message (the library's draw,
+// as in EncryptBatch), then the alternative encryption with it.
+func (k *GPUPublicKey) AltEncryptBatch(m []*gmp.Int, level EncryptionLevel) ([]*Ciphertext, error) {
+	rs := k.plainBytes(EncLevelOne)
+	rb := make([]byte, len(m)*rs)
+	if err := status(C.pgpu_random_units(k.h, C.size_t(len(m)), p8(rb), C.size_t(rs), C.PGPU_MEM_HOST)); err != nil {
+		return nil, err
+	}
+	return k.AltEncryptWithRBatch(m, unpack(rb, rs), level)
+}
+
+// EncryptZeroBatch / EncryptOneBatch: `count` fresh encryptions of 0 / 1 (paillier.go:272-289).
+func (k *GPUPublicKey) EncryptZeroBatch(count int, level EncryptionLevel) ([]*Ciphertext, error) {
+	return k.EncryptBatch(constants(count, 0), level)
+}
+func (k *GPUPublicKey) EncryptOneBatch(count int, level EncryptionLevel) ([]*Ciphertext, error) {
+	return k.EncryptBatch(constants(count, 1), level)
+}
+func constants(count int, v int64) []*gmp.Int {
+	out := make([]*gmp.Int, count)
+	for i := range out {
+		out[i] = gmp.NewInt(v)
+	}
+	return out
+}
+
 // DecryptBatch: SecretKey.Decrypt (paillier.go:292-303) for every ciphertext (all of one level).
 func (s *GPUSecretKey) DecryptBatch(c []*Ciphertext) ([]*gmp.Int, error) {
 	if len(c) == 0 {

@@ -343,6 +343,19 @@ class PublicKey:
                                                     _ptr(rred), MEM_HOST))
         return be_to_ints(out), be_to_ints(rred)
 
+    def AltEncryptBatch(self, ms: Sequence[int], level: int = ENC_LEVEL_ONE) -> List[int]:
+        """paillier.go:244-255 AltEncryptAtLevel: r drawn from Z_n^* as GetRandomNumberInMultiplicativeGroup does (on the
+        device-checked path of random_units), then AltEncryptWithRAtLevel."""
+        return self.AltEncryptWithRBatch(ms, self.random_units(len(ms)), level)[0]
+
+    def EncryptZeroBatch(self, count: int, level: int = ENC_LEVEL_ONE) -> List[int]:
+        """paillier.go:272-274,282-284 EncryptZero / EncryptZeroAtLevel, `count` fresh ones."""
+        return self.EncryptBatch([0] * count, level)
+
+    def EncryptOneBatch(self, count: int, level: int = ENC_LEVEL_ONE) -> List[int]:
+        """paillier.go:277-279,287-289 EncryptOne / EncryptOneAtLevel, `count` fresh ones."""
+        return self.EncryptBatch([1] * count, level)
+
     def AddBatch(self, *cts: Sequence[int], level: int = ENC_LEVEL_ONE) -> List[int]:
         """operations.go:11-29 Add(cts...), element-wise over the batch: every positional argument is one operand vector."""
         cb = self.cipher_bytes(level)

@@ -162,3 +162,21 @@ def test_level_two_encrypt_lifts_through_n_squared(ctx, bits):
     idx = list(range(12)) + list(range(len(rs) - 8, len(rs)))
     assert [got[1][i] for i in idx] == [po.encrypt_with_r_at_level(sk_o, ms[i], rs[i], po.ENC_LEVEL_TWO).C for i in idx]
     assert [got[1][i] for i in idx] == [pow(rs[i], n2, n3) * (1 + ms[i] * n + ms[i] * (ms[i] - 1) // 2 * n2) % n3 for i in idx]
+
+
+def test_alt_encrypt_and_constant_forms_with_library_randomness(ctx):
+    """AltEncryptAtLevel (paillier.go:244-255), EncryptZero / EncryptOne (+AtLevel, :272-289): fresh randomness from the
+    library, so the check is decryption (paillier_test.go:100-156)."""
+    import paillier_amd as pa
+    from paillier_amd import ENC_LEVEL_ONE, ENC_LEVEL_TWO
+    sk_o, p, q = po.keygen_seeded(1024, 1)
+    n = sk_o.N
+    pk = pa.PublicKey(ctx, n, n + 1, sk_o.H, sk_o.K)
+    sk = pa.SecretKey(ctx, pk, sk_o.Lambda)
+    rng = random.Random(5)
+    for level, bound in ((ENC_LEVEL_ONE, n), (ENC_LEVEL_TWO, n * n)):
+        ms = [0, 1, bound - 1] + [rng.randrange(bound) for _ in range(5)]
+        a, b = pk.AltEncryptBatch(ms, level), pk.AltEncryptBatch(ms, level)
+        assert a != b and sk.DecryptBatch(a, level=level) == ms == sk.DecryptBatch(b, level=level)
+        assert sk.DecryptBatch(pk.EncryptZeroBatch(3, level), level=level) == [0, 0, 0]
+        assert sk.DecryptBatch(pk.EncryptOneBatch(3, level), level=level) == [1, 1, 1]
