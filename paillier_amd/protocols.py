@@ -251,6 +251,21 @@ def verify_decryption(tk: ThresholdPublicKey, verification_key: int, verificatio
         raise ValueError("The decrypted message is not the same than the one in the shares")
 
 
+def verify_partial_decryption(tk: ThresholdPublicKey, ID: int, share: int, verification_key: int,
+                              verification_keys: Sequence[int], trials: int = 1) -> None:
+    """thresholdkey.go:258-275 VerifyPartialDecryption: a server tests its own share -- encrypt a random m < n, make the
+    partial decryption with its proof, verify the proof; raises ValueError("Invalid share") as the reference returns that
+    error.  `trials` independent tests in one batch (the reference does one)."""
+    import secrets
+    n = tk.N
+    ms = [secrets.randbelow(n) for _ in range(trials)]
+    cts = tk.EncryptBatch(ms)
+    rs = [secrets.randbelow(n * n) for _ in range(trials)]             # thresholdkey.go:233
+    proofs = partial_decryption_with_zkp_batch(tk, ID, share, verification_key, cts, rs)
+    if not all(verify_proof_batch(tk, verification_key, verification_keys, proofs)):
+        raise ValueError("Invalid share")
+
+
 def create_verification_keys(tk: ThresholdPublicKey, v: int, shares: Sequence[int]) -> List[int]:
     """thresholdkey_generator.go:246-254 createVerificationKeys: v_i = v^(l! * s_i) mod n^2 for every server, as one batch
     with per-server exponents (the modexp-heavy part of threshold key generation; l = 100 in the

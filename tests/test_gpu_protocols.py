@@ -291,6 +291,10 @@ def test_whole_protocol_forms(ctx):
         rs = [rng.randrange(tn * tn) for _ in cts]
         d, es, zs = tk.PartialDecryptionWithZKPBatch(sid, shares[sid - 1], v, cts, rs)
         return [pr.PartialDecryptionZKP(sid, di, ei, zi, ci) for di, ei, zi, ci in zip(d, es, zs, cts)]
+    # VerifyPartialDecryption (thresholdkey.go:258-275): a right share passes, a wrong one is an "Invalid share"
+    pr.verify_partial_decryption(tk, 2, shares[1], v, vks, trials=3)
+    with pytest.raises(ValueError, match="Invalid share"):
+        pr.verify_partial_decryption(tk, 2, shares[1] + 1, v, vks)
     srv = [proofs_of(s) for s in (1, 2, 4, 5)]
     assert pr.combine_partial_decryptions_zkp(tk, v, vks, srv) == ms
     pr.verify_decryption(tk, v, vks, cts, ms, srv)
