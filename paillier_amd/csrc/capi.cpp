@@ -1412,6 +1412,38 @@ uint32_t* tree_inverse(pgpu_ctx* ctx, const ModCtx& mc, const uint32_t* x, size_
   return out;
 }
 
+// Are ALL of x[0 .. count) units modulo N?  The up-sweep of the same product tree and one gcd on the host -- half the
+// launches of tree_inverse and no inverses; what the randomness filter needs (utils.go:43: gcd(r, n) = 1) in the
+// overwhelmingly likely case that every draw is a unit.
+bool all_units(pgpu_ctx* ctx, const ModCtx& mc, const uint32_t* x, size_t nb, size_t count) {
+  const int WT = mc.WT;
+  size_t nbt = VM_BLOCK;
+  int L = 8;
+  while (nbt < count) { nbt <<= 1; ++L; }
+  const size_t sw = (size_t)WT * nbt;
+  uint32_t* mem = ctx->ws_t<uint32_t>(sw * 3);                      // slots: 0 V, 1 U (upper half moved down), 2 O
+  HIPCHK(hipMemsetAsync(mem + sw, 0, sw * 4, ctx->stream));
+  launch_restride(x, nb, count, mc.d_consts + (size_t)C_ONE * WT, mem, nbt, WT, ctx->stream);
+  // (plain residues multiplied with Montgomery products: every level loses a factor R, all of them units -- the gcd of the
+  // root with N is that of the product)
+  for (int k = 0; k < L; ++k) {
+    const size_t half = nbt >> (k + 1);
+    HIPCHK(hipMemcpy2DAsync(mem + sw, nbt * 4, mem + half, nbt * 4, half * 4, (size_t)WT, hipMemcpyDeviceToDevice, ctx->stream));
+    Prog p;
+    p.op(VM_LOAD, 0); p.op(VM_MUL, 1); p.op(VM_STORE, 0); p.end();
+    SegSpec sg{&mc, &p, mem, nullptr};
+    run_vm(ctx, nbt, sg, nullptr, false, std::max<size_t>(VM_BLOCK, half));
+  }
+  launch_canon(mem, mc.d_nmod, WT, nbt, ctx->stream);
+  std::vector<uint8_t> rb(mc.nbytes);
+  uint8_t* d_rb = (uint8_t*)ctx->ws(mc.nbytes);
+  launch_pack_be(mem, WT, nbt, 1, d_rb, mc.nbytes, mc.nbytes, ctx->stream);
+  HIPCHK(hipMemcpyAsync(rb.data(), d_rb, mc.nbytes, hipMemcpyDeviceToHost, ctx->stream));
+  HIPCHK(hipStreamSynchronize(ctx->stream));
+  BigU root = BigU::from_be(rb.data(), rb.size()), rinv;
+  return hostbig::modinv(root, mc.N, rinv);
+}
+
 // gmp.Int.ModInverse for a batch.  d_bad (device int32[nb], may be null) receives 1 on the lanes that are not units and 0
 // elsewhere; those lanes get the result 0 (mpz_invert leaves its result undefined there and the reference never checks).
 // One hostile element must not cost the honest ones their answers: when the tree's root cannot be inverted, a per-lane
@@ -2712,7 +2744,7 @@ static void draw_below(const std::vector<uint8_t>& n_be, uint8_t top_mask, uint8
     wipe_vec(pool);
   };
   const size_t total = only ? n_only : count;
-  const size_t nthreads = std::max<size_t>(1, std::min<size_t>({(size_t)8, (size_t)std::thread::hardware_concurrency(), total / 2048 + 1}));
+  const size_t nthreads = std::max<size_t>(1, std::min<size_t>({(size_t)16, (size_t)std::thread::hardware_concurrency(), total / 2048 + 1}));
   if (nthreads == 1) { fill(0, total); return; }
   std::vector<std::thread> th;
   std::vector<std::string> errs(nthreads);
@@ -2743,8 +2775,9 @@ static uint32_t* random_units_device(const pgpu_pubkey* pk, size_t count, size_t
     launch_unpack_be(stage, k, k, count, limbs, mn.WT, nb, ctx->stream);
     // padding lanes: 1 (a unit), so that the tree sees units only
     launch_restride(limbs, nb, count, mn.d_consts + (size_t)C_ONE * mn.WT, limbs, nb, mn.WT, ctx->stream);
+    if (all_units(ctx, mn, limbs, nb, count)) break;
     bool any_bad = false;
-    (void)batch_inverse(ctx, mn, limbs, nb, count, d_bad, &any_bad);
+    (void)batch_inverse(ctx, mn, limbs, nb, count, d_bad, &any_bad);      // names the lanes to redraw
     if (!any_bad) break;
     std::vector<int32_t> bad(count);
     HIPCHK(hipMemcpyAsync(bad.data(), d_bad, count * 4, hipMemcpyDeviceToHost, ctx->stream));
