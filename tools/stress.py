@@ -11,7 +11,7 @@ K = json.load(open(os.path.join(ROOT, "tests/golden/keys.json")))
 ctx = pa.Context(0)
 B = int(sys.argv[1]) if len(sys.argv) > 1 else 20000
 rng = random.Random(99)
-for bits, natural in ((1024, 0), (2048, 0), (2048, 1)):
+for bits, natural in ((1024, 0), (2048, 0), (2048, 1), (3072, 1)):
     # natural = 1: every modulus on its natural kernel shape (n^2 of the 2048-bit key: the wave-sliced 148-limb kernel)
     ctx.set_flag("lanes_wanted", natural)
     k = K["paillier"][str(bits)]
