@@ -245,7 +245,6 @@ def test_ddleq_prove_3072_bit_key(ctx):
                                       po.rand_unit(n, rng), po.ENC_LEVEL_TWO).C for _ in range(B)]
     a_s, b_s, xs, ys = ([po.rand_unit(n, rng) for _ in range(B)] for _ in range(4))
     ct2 = [po.nested_randomize_with_ab(sk_o, po.Ciphertext(c, 1), a, b).C for c, a, b in zip(ct1, a_s, b_s)]
-    assert pk.NestedRandomizeWithABBatch(ct1, a_s, b_s) == ct2
     al, es, fs = sk.ProveDDLEQInstancesBatch(ct1, ct2, a_s, b_s, xs, ys)
     refs = [po.prove_ddleq_instance_xy(sk_o, po.Ciphertext(c1, 1), po.Ciphertext(c2, 1), a, b, x, y)
             for c1, c2, a, b, x, y in zip(ct1, ct2, a_s, b_s, xs, ys)]
