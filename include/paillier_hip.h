@@ -73,8 +73,13 @@ int pgpu_ctx_last_profile(pgpu_ctx* ctx, double* vm_ms, int* vm_launches, double
  * hipcc-generated kernels of identical semantics (used by the parity tests to cross-check the two).
  * "pair" (default 1): run the Decrypt ladders modulo p^2 / q^2 on the pair kernel (two base-p digits per residue); 0
  * keeps them on the ordinary 2H-limb kernel.
+ * "triple" (default 1): ladders modulo n^3 on the three-digit kernel.  "shared_chain" (default 1): several shares on the
+ * same ciphertexts share one chain of squarings (pgpu_partial_decrypt_multi), runs of units under one share become
+ * shared-exponent ladders (pgpu_partial_decrypt_indexed).  "lift" (default 1): level-two Encrypt computes r^(n^2) mod n^3
+ * as (r^n mod n^2)^n mod n^3.  All of these change the work done, never a result (the tests switch them off to compare).
  * "lanes_wanted" (default 0 = fill the chip): the lane count below which a batch is re-sliced over more lanes per
- * number; 1 keeps every modulus on its natural kernel shape whatever the batch size (tests). */
+ * number; 1 keeps every modulus on its natural kernel shape whatever the batch size (tests).
+ * "cu_partition": (parts << 16) | part confines an own-stream context to one slice of the compute units. */
 int pgpu_ctx_set_flag(pgpu_ctx* ctx, const char* name, int value);
 /* number of VM launches of the last batch call that ran the assembly kernel */
 int pgpu_ctx_last_vm_asm(pgpu_ctx* ctx);
