@@ -3029,8 +3029,7 @@ static void pair_enter(pgpu_ctx* ctx, const ModCtx& mc, uint32_t* ent, size_t nb
 }
 // exit: F~ = F0 + F1 n of slot `out_slot` of pm (stride nb), out of pair and Montgomery form, packed to dst (`count` results;
 // slots 2 and 3 of pm are scratch by now)
-static void pair_leave_and_pack(pgpu_ctx* ctx, const ModCtx& mc, uint32_t* pm, uint32_t out_slot, size_t nb, size_t count, uint8_t* dst,
-                                size_t out_stride, int mem) {
+static uint32_t* pair_leave(pgpu_ctx* ctx, const ModCtx& mc, uint32_t* pm, uint32_t out_slot, size_t nb) {
   const PairInfo& pi = mc.pairn;
   const int H = pi.root->WT, W2 = mc.WT;
   const size_t S1 = (size_t)H * nb, SW = (size_t)W2 * nb;
@@ -3040,7 +3039,42 @@ static void pair_leave_and_pack(pgpu_ctx* ctx, const ModCtx& mc, uint32_t* pm, u
   SegSpec sa{&mc, &a, pm, nullptr};
   run_vm(ctx, nb, sa, nullptr, false);
   launch_canon(pm + 3 * SW, mc.d_nmod, W2, nb, ctx->stream);
-  pack_result(ctx, pm + 3 * SW, W2, nb, count, dst, out_stride, mc.nbytes, mem);
+  return pm + 3 * SW;                                     // canonical, stride nb
+}
+static void pair_leave_and_pack(pgpu_ctx* ctx, const ModCtx& mc, uint32_t* pm, uint32_t out_slot, size_t nb, size_t count, uint8_t* dst,
+                                size_t out_stride, int mem) {
+  pack_result(ctx, pair_leave(ctx, mc, pm, out_slot, nb), mc.WT, nb, count, dst, out_stride, mc.nbytes, mem);
+}
+
+// x^(per-number exponent, `we` limbs) * y^(shared exponent e) modulo N = n^2 as ONE interleaved ladder on the pair kernels
+// (4-bit windows of the per-number exponent, sliding windows of e).  x, y: canonical residues (mc.WT limbs, stride nb).
+// Returns the canonical result, or nullptr when the pair kernels do not serve this key / batch.
+static uint32_t* dual_pow_pair(pgpu_ctx* ctx, const ModCtx& mc, const uint32_t* x, const uint32_t* exps, int we, const uint32_t* y,
+                               const BigU& e, size_t nb) {
+  const PairInfo& pi = mc.pairn;
+  if (!(pi.root && pi.c_one_pair >= 0 && ctx->use_asm && ctx->use_pair)) return nullptr;
+  const int H = pi.root->WT, W2 = mc.WT;
+  const size_t lanes_target = ctx->lanes_wanted ? ctx->lanes_wanted : (size_t)1024 * 64;
+  const bool two = nb * 2 >= lanes_target;
+  if (!two && !(H % 2 == 0 && vm_asm_available(H / 2, 64))) return nullptr;
+  const int wb = (uint64_t)nb * W2 * 4 * 33 < (1ull << 32) ? 5 : 4;       // MULV5 / MULV gathers with 32-bit offsets
+  if ((uint64_t)nb * W2 * 4 * 17 >= (1ull << 32)) return nullptr;
+  const uint32_t tab2 = 5 + (1u << wb);
+  const size_t SW = (size_t)W2 * nb;
+  uint32_t* pm = ctx->ws_t<uint32_t>(SW * (size_t)(tab2 + 32));           // 0 x, 1 y, 2 tmp, 3 out, 5.. / tab2.. the tables
+  uint32_t* ent = ctx->ws_t<uint32_t>(SW * 4);
+  for (int k = 0; k < 2; ++k) {
+    HIPCHK(hipMemcpyAsync(ent, k ? y : x, SW * 4, hipMemcpyDeviceToDevice, ctx->stream));
+    pair_enter(ctx, mc, ent, nb);
+    HIPCHK(hipMemcpyAsync(pm + (size_t)k * SW, ent + 2 * SW, SW * 4, hipMemcpyDeviceToDevice, ctx->stream));
+  }
+  Prog pd;
+  emit_modexp_dual(pd, we, e, 0, 1, 2, 3, 5, tab2, pi.c_one_pair, wb);
+  pd.end();
+  SegSpec sp{&mc, &pd, pm, wb == 5 ? windows5_of(ctx, exps, we, nb) : exps};
+  sp.pair = pi.consts; sp.pair_n0inv = pi.root->n0inv; sp.pair_h = H; sp.pair_lanes = two ? 2 : 4;
+  run_vm(ctx, nb, sp, nullptr, true);
+  return pair_leave(ctx, mc, pm, 3, nb);
 }
 
 int pgpu_partial_decrypt_multi(const pgpu_pubkey* pk, int total_servers, int n_shares, const uint8_t* const* shares_be,
@@ -3385,6 +3419,39 @@ uint32_t* dual_pow_n3(pgpu_ctx* ctx, const pgpu_pubkey* pk, const uint32_t* x, c
   ModexpPlan pc = modexp_alloc(ctx, mn3, nb, use3 ? 0 : 48);   // slots: 0 x, 1 y, 2 tmp, 3 out, 5..20 / 21..52 the two tables
   HIPCHK(hipMemcpyAsync(pc.in(), x, pc.slot_words * 4, hipMemcpyDeviceToDevice, ctx->stream));
   HIPCHK(hipMemcpyAsync(pc.in() + pc.slot_words, y, pc.slot_words * 4, hipMemcpyDeviceToDevice, ctx->stream));
+  if (use3 && ctx->use_lift) {
+    // x^e y^(n^2) = (x^(e1) y^n)^n x^(e0) with e = e0 + e1 n, and W^n mod n^3 depends on W mod n^2 only (the lift of
+    // encrypt_core: x = x' mod n^k implies x^n = x'^n mod n^(k+1), any integers).  So: W = x^(e1) y^n modulo n^2 -- an
+    // interleaved ladder of 2 048 squarings on the pair kernel, half the price of squarings modulo n^3 -- and then
+    // W^n x^(e0) modulo n^3, an interleaved ladder of 2 048 squarings where the literal form needs 4 096.
+    const ModCtx& mn = pk->mn;
+    const int W1 = mn.WT;
+    const size_t S1 = (size_t)W1 * nb;
+    uint32_t* e0 = ctx->ws_t<uint32_t>(S1);
+    uint32_t* e1 = ctx->ws_t<uint32_t>(S1);
+    uint32_t* tb = ctx->ws_t<uint32_t>((size_t)W2 * nb);
+    reduce_mod(ctx, mn, exps, W2, e0, nb);
+    launch_div_exact(exps, W2, 0, e0, W1, tb, pk->ninv2k.d, mn.d_nmod, W1, e1, W1, nb, nb, nullptr, 0, ctx->stream);
+    uint32_t* x2 = ctx->ws_t<uint32_t>((size_t)W2 * nb);
+    uint32_t* y2 = ctx->ws_t<uint32_t>((size_t)W2 * nb);
+    reduce_mod(ctx, mn2, x, W3, x2, nb);
+    reduce_mod(ctx, mn2, y, W3, y2, nb);
+    uint32_t* wv = dual_pow_pair(ctx, mn2, x2, e1, W1, y2, pk->N, nb);
+    if (wv) {
+      launch_copy_limbs(wv, 0, W2, pc.in() + pc.slot_words, W3, nb, ctx->stream);      // slot 1 <- W, zero-extended
+      const int wb = triple_window_bits(nb, mn3.triple.root->WT);
+      const uint32_t tab2 = 5 + (uint32_t)perlane_table_slots(wb);
+      TriplePlan tp = triple_alloc(ctx, mn3, nb, (int)tab2 + (1 << (dual_sliding_bits(wb) - 1)));
+      triple_enter(ctx, mn3, pc.in(), tp, 0);
+      triple_enter(ctx, mn3, pc.in() + pc.slot_words, tp, 1);
+      Prog pd;
+      emit_modexp_dual(pd, W1, pk->N, 0, 1, 2, 3, 5, tab2, 0, wb);
+      pd.end();
+      triple_run(ctx, mn3, tp, pd, triple_windows(ctx, e0, W1, nb, wb));
+      triple_exit(ctx, mn3, tp, 3, pc.out(), nullptr);
+      return pc.out();
+    }
+  }
   if (use3) {
     // the interleaved ladder on the three-digit kernel: residues modulo n^3 as a0 + a1 n + a2 n^2
     const int wb = triple_window_bits(nb, mn3.triple.root->WT);       // 7-bit (or 5-bit) windows of the per-number exponent
