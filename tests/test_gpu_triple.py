@@ -144,3 +144,40 @@ def test_ddleq_verify_2048_on_and_off(ctx):
             assert got == [i != 3 for i in range(16)]
         finally:
             ctx.set_flag("triple", 1)
+
+
+def test_split_through_n_squared_on_and_off(ctx):
+    """NestedRandomize and the DDLEQ verifier compute x^e y^(n^2) mod n^3 as (x^(e1) y^n mod n^2)^n x^(e0), e = e0 + e1 n
+    (capi.cpp dual_pow_n3).  With pgpu_ctx_set_flag("lift", 0) the literal interleaved ladder of 4 096 squarings runs: same
+    integers, same verdicts, and both equal the committed 2048-bit fixtures / pow()."""
+    import paillier_amd as pa
+    H_ = lambda xs: [int(x, 16) for x in xs]
+    k = json.load(open(os.path.join(G, "keys.json")))["paillier"]["2048"]
+    n = int(k["n"], 16)
+    n2, n3 = n * n, n ** 3
+    pk = pa.PublicKey(ctx, n, n + 1)
+    d = json.load(open(os.path.join(G, "proofs.json")))["ddleq"]
+    st = [{kk: int(v, 16) for kk, v in s.items()} for s in d["statements"]]
+    ins = d["instances"][:12]
+    col = lambda key: [st[i["s"]][key] for i in ins]
+    xs, ys = H_(i["x"] for i in ins), H_(i["y"] for i in ins)
+    al, es, fs = H_(i["alpha"] for i in ins), H_(i["e"] for i in ins), H_(i["f"] for i in ins)
+    wrong = [st[(i["s"] + 1) % 4]["ct2"] for i in ins]
+    rng = random.Random(4096)
+    cts = [rng.randrange(n3) for _ in range(40)] + [0, 1, n, n2, n3 - 1, 3 * n2]     # non-units and small values ride along
+    a_s = [rng.randrange(1, n) for _ in cts]
+    b_s = [rng.randrange(1, n) for _ in cts]
+    got = {}
+    for flag in (1, 0):
+        ctx.set_flag("lift", flag)
+        try:
+            got[flag] = (pk.VerifyDDLEQInstancesBatch(col("ct1"), col("ct2"), xs, ys, al, es, fs),
+                         pk.VerifyDDLEQInstancesBatch(col("ct1"), wrong, xs, ys, al, es, fs),
+                         pk.NestedRandomizeWithABBatch(cts, a_s, b_s))
+        finally:
+            ctx.set_flag("lift", 1)
+    assert got[1] == got[0]
+    assert got[1][0] == [True] * len(ins)
+    assert got[1][1] == [bool(i["verify_wrong_ct2"]) for i in ins]
+    pick = list(range(6)) + list(range(len(cts) - 6, len(cts)))
+    assert [got[1][2][i] for i in pick] == [pow(cts[i], pow(a_s[i], n, n2), n3) * pow(b_s[i], n2, n3) % n3 for i in pick]
