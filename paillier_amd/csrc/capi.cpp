@@ -499,6 +499,57 @@ void emit_modexp_dual(Prog& p, int we, const BigU& e, uint32_t in1, uint32_t in2
   p.op(VM_STORE, out);
 }
 
+// The general interleaved ladder: x^(per-number exponent) * prod_k y_k^(e_k) with ONE chain of squarings -- one base with
+// per-number windows (optional: we == 0 leaves it out) and any number of bases with shared exponents, each with its own
+// sliding windows over odd powers.  All inputs already in the kernel's working form (digit kernels), `one` = the constant
+// holding 1 in that form.  Sliding windows: 6 bits below 1 500 exponent bits, dual_sliding_bits(wb) above.
+struct SharedBase { BigU e; uint32_t in; uint32_t tab; };
+static int shared_window_bits(const BigU& e, int wb) { return e.bit_length() < 1500 ? 6 : dual_sliding_bits(wb); }
+void emit_modexp_multi(Prog& p, int we, uint32_t in1, uint32_t tab1, int wb, const std::vector<SharedBase>& sh, uint32_t tmp,
+                       uint32_t out, uint32_t one) {
+  if (we > 0) {
+    p.op(VM_LOAD, in1);
+    emit_power_table(p, tab1, one, wb);
+  }
+  long nbits = (long)we * LB;
+  std::vector<std::vector<int>> mul_at(sh.size());
+  for (size_t k = 0; k < sh.size(); ++k) {
+    const BigU& e = sh[k].e;
+    const int sw = shared_window_bits(e, wb);
+    const uint32_t nodd = 1u << (sw - 1);
+    nbits = std::max<long>(nbits, (long)e.bit_length());
+    p.op(VM_LOAD, sh[k].in);
+    p.op(VM_STORE, sh[k].tab + 0);
+    p.op(VM_SQR);
+    p.op(VM_STORE, tmp);
+    p.op(VM_LOAD, sh[k].tab + 0);
+    for (uint32_t j = 1; j < nodd; ++j) { p.op(VM_MUL, tmp); p.op(VM_STORE, sh[k].tab + j); }
+  }
+  for (size_t k = 0; k < sh.size(); ++k) {
+    const BigU& e = sh[k].e;
+    const int sw = shared_window_bits(e, wb);
+    mul_at[k].assign((size_t)std::max<long>(nbits, 1), -1);
+    for (long i = (long)e.bit_length() - 1; i >= 0;) {
+      if (!e.bit((size_t)i)) { --i; continue; }
+      long l = std::max<long>(i - sw + 1, 0);
+      while (!e.bit((size_t)l)) ++l;
+      uint32_t val = 0;
+      for (long b = i; b >= l; --b) val = (val << 1) | (uint32_t)e.bit((size_t)b);
+      mul_at[k][(size_t)l] = (int)(val >> 1);
+      i = l - 1;
+    }
+  }
+  const long nwin = we > 0 ? perlane_windows(we, wb) : 0;
+  p.op(VM_LOADC, one);
+  for (long b = nbits - 1; b >= 0; --b) {
+    if (b != nbits - 1) p.op(VM_SQR);
+    if (we > 0 && b % wb == 0 && b / wb < nwin) p.op(perlane_op(wb), (uint32_t)(b / wb), tab1);
+    for (size_t k = 0; k < sh.size(); ++k)
+      if (mul_at[k][(size_t)b] >= 0) p.op(VM_MUL, sh[k].tab + (uint32_t)mul_at[k][(size_t)b]);
+  }
+  p.op(VM_STORE, out);
+}
+
 // x^(e_0), x^(e_1), ... for SEVERAL shared exponents on ONE base with a single chain of squarings (right-to-left sliding
 // windows, Yao's buckets): the chain x, x^2, x^4, ... is walked once; where a window of e_s starts (a one bit at position j,
 // value d = bits [j, j + w), odd), the current power x^(2^j) is multiplied into bucket B_s[(d-1)/2]; at the end
@@ -3663,6 +3714,70 @@ void shared_pow(pgpu_ctx* ctx, const ModCtx& mc, const uint32_t* base, int wb, c
   HIPCHK(hipMemcpyAsync(out, pl.out(), (size_t)mc.WT * nb * 4, hipMemcpyDeviceToDevice, ctx->stream));
 }
 
+// W = x^(per-number exponent r1, `we` limbs) [* y^(s1)] modulo p^2 (half 0) and modulo q^2 (half 1): interleaved ladders in
+// pair form on the one-lane pair kernel, both halves in ONE two-segment launch.  xs / ys: canonical residues modulo p^2 / q^2
+// (mp2.WT limbs, stride nb).  outs[half]: canonical results.  False when the one-lane pair kernel does not serve this key.
+bool pow_p2_multi_crt(const pgpu_seckey* sk, const uint32_t* const xs[2], const uint32_t* const r1[2], int we,
+                      const uint32_t* const ys[2], const BigU s1[2], size_t nb, uint32_t* outs[2]) {
+  pgpu_ctx* ctx = sk->ctx;
+  if (!(sk->has_pair && sk->pair_lanes == 1 && sk->c_onep_p2 >= 0 && sk->c_onep_q2 >= 0 && sk->c_rh_p2 >= 0 && ctx->use_asm &&
+        ctx->use_pair && sk->mp2.WT == 2 * sk->mp.WT && sk->mq2.WT == 2 * sk->mq.WT))
+    return false;
+  // one lane per number when the two halves fill the chip that way, else two (as Decrypt chooses)
+  const size_t lanes_target = ctx->lanes_wanted ? ctx->lanes_wanted : (size_t)1024 * 64;
+  const int lanes = (sk->pair_small2 && nb * 2 < lanes_target) ? 2 : 1;
+  const int H = sk->mp.WT, W2 = sk->mp2.WT;
+  const size_t S1 = (size_t)H * nb, S2 = (size_t)W2 * nb;
+  const int wb = 4;                                           // per-number windows: VM_MULV
+  if ((uint64_t)nb * W2 * 4 * 17 >= (1ull << 32)) return false;
+  const uint32_t TAB1 = 5, TAB2 = TAB1 + (1u << wb);
+  uint32_t* mem[2];
+  Prog pr[2];
+  uint32_t* ent = ctx->ws_t<uint32_t>(S2 * 4);
+  uint32_t* x0 = ctx->ws_t<uint32_t>(S1);
+  uint32_t* tb = ctx->ws_t<uint32_t>(S2);
+  for (int half = 0; half < 2; ++half) {
+    const ModCtx &m1 = half ? sk->mq : sk->mp, &m2 = half ? sk->mq2 : sk->mp2;
+    mem[half] = ctx->ws_t<uint32_t>(S2 * (size_t)(TAB2 + 64));      // 0 x, 1 y, 2 tmp, 3 out, 5.. / TAB2.. the tables
+    for (int k = 0; k < (ys ? 2 : 1); ++k) {
+      // pair-form entry: X = v R_H mod prime^2, then its digits X0 + X1 prime
+      HIPCHK(hipMemcpyAsync(ent, k ? ys[half] : xs[half], S2 * 4, hipMemcpyDeviceToDevice, ctx->stream));
+      Prog a;
+      a.op(VM_LOAD, 0); a.op(VM_MULC, C_R2); a.op(VM_MULC, (uint32_t)(half ? sk->c_rh_q2 : sk->c_rh_p2)); a.op(VM_STORE, 3); a.end();
+      SegSpec sa{&m2, &a, ent, nullptr};
+      run_vm(ctx, nb, sa, nullptr, false);
+      launch_canon(ent + 3 * S2, m2.d_nmod, W2, nb, ctx->stream);
+      reduce_mod(ctx, m1, ent + 3 * S2, W2, x0, nb);
+      uint32_t* slot = mem[half] + (size_t)k * S2;
+      launch_div_exact(ent + 3 * S2, W2, 0, x0, H, tb, (half ? sk->qinv2k : sk->pinv2k).d, m1.d_nmod, H, slot + S1, H, nb, nb, nullptr, 0,
+                       ctx->stream);
+      HIPCHK(hipMemcpyAsync(slot, x0, S1 * 4, hipMemcpyDeviceToDevice, ctx->stream));
+    }
+    std::vector<SharedBase> sh;
+    if (ys) sh.push_back(SharedBase{s1[half], 1, TAB2});
+    emit_modexp_multi(pr[half], r1 ? we : 0, 0, TAB1, wb, sh, 2, 3, (uint32_t)(half ? sk->c_onep_q2 : sk->c_onep_p2));
+    pr[half].end();
+  }
+  {
+    SegSpec sp{&sk->mp2, &pr[0], mem[0], r1 ? r1[0] : nullptr}, sq{&sk->mq2, &pr[1], mem[1], r1 ? r1[1] : nullptr};
+    sp.pair = sk->pair_p.d; sp.pair_n0inv = sk->mp.n0inv; sp.pair_h = H; sp.pair_lanes = lanes;
+    sq.pair = sk->pair_q.d; sq.pair_n0inv = sk->mq.n0inv; sq.pair_h = H; sq.pair_lanes = lanes;
+    run_vm(ctx, nb, sp, &sq, true);
+  }
+  for (int half = 0; half < 2; ++half) {
+    const ModCtx& m2 = half ? sk->mq2 : sk->mp2;
+    uint32_t* mm = mem[half];
+    launch_mul_const_add(mm + 3 * S2 + S1, H, (half ? sk->q_limbs1 : sk->p_limbs).d, H, mm + 3 * S2, H, 0, mm + 2 * S2, W2, nb, ctx->stream);
+    Prog a;
+    a.op(VM_LOAD, 2); a.op(VM_MULC, (uint32_t)(half ? sk->c_rh_q2 : sk->c_rh_p2)); a.op(VM_STORE, 3); a.end();
+    SegSpec sa{&m2, &a, mm, nullptr};
+    run_vm(ctx, nb, sa, nullptr, false);
+    launch_canon(mm + 3 * S2, m2.d_nmod, W2, nb, ctx->stream);
+    outs[half] = mm + 3 * S2;
+  }
+  return true;
+}
+
 // out = base^e mod n^3 for a holder of the factorisation (the DDLEQ prover): two ladders modulo p^3 and q^3 -- half the
 // width, the same exponent -- in one two-segment launch, then Garner.  2.6x fewer limb products than the ladder modulo
 // n^3, the same canonical residue.  Per-number exponents (exps: we limbs each) or one shared exponent (*e).
@@ -3680,18 +3795,7 @@ void pow_n3_crt(const pgpu_seckey* sk, const uint32_t* base, int wb, const uint3
     const int win = exps ? triple_window_bits(nb, mp3.triple.root->WT) : 5;
     const uint32_t tab2 = 5 + (uint32_t)perlane_table_slots(win);
     const int nslots = base2 ? (int)tab2 + (1 << (dual_sliding_bits(win) - 1)) : 5 + perlane_table_slots(win);
-    TriplePlan tp = triple_alloc(ctx, mp3, nb, nslots), tq = triple_alloc(ctx, mq3, nb, nslots);
     uint32_t* g = ctx->ws_t<uint32_t>(S * 6);       // generic slots (W limbs): 0 x_p, 1 x_q, 2 A, 3 B, 4 h, 5 scratch
-    for (int half = 0; half < 2; ++half) {
-      const ModCtx& m3 = half ? mq3 : mp3;
-      const TriplePlan& t = half ? tq : tp;
-      reduce_mod(ctx, m3, base, wb, g + 5 * S, nb);
-      triple_enter(ctx, m3, g + 5 * S, t, 0);
-      if (base2) {
-        reduce_mod(ctx, m3, base2, wb2, g + 5 * S, nb);
-        triple_enter(ctx, m3, g + 5 * S, t, 1);
-      }
-    }
     // Exponents modulo the orders of the unit groups of p^3 and q^3 (a quarter shorter than exponents modulo n^2): each half
     // gets its own reduced exponents and its own program.  PGPU_EXP_ORDER=0 (experiments) keeps the exponents as given.
     static const bool order_on = [] { const char* v = getenv("PGPU_EXP_ORDER"); return v ? atoi(v) != 0 : true; }();
@@ -3715,6 +3819,106 @@ void pow_n3_crt(const pgpu_seckey* sk, const uint32_t* base, int wb, const uint3
         if (r.bit_length() >= 64) es[half] = r;
       }
     }
+    auto garner = [&](const TriplePlan& tp, const TriplePlan& tq) {
+      triple_exit(ctx, mp3, tp, 3, g + 0 * S, nullptr);     // x_p, canonical
+      triple_exit(ctx, mq3, tq, 3, g + 1 * S, nullptr);     // x_q
+      Prog c;
+      c.op(VM_LOAD, 0); c.op(VM_MULC, (uint32_t)sk->c_p3invR); c.op(VM_STORE, 3);
+      c.op(VM_LOAD, 1); c.op(VM_MULC, (uint32_t)sk->c_p3invR); c.op(VM_STORE, 2);
+      c.end();
+      SegSpec sc{&mq3, &c, g, nullptr};
+      run_vm(ctx, nb, sc, nullptr, false);
+      launch_canon(g + 2 * S, mq3.d_nmod, W, nb, ctx->stream);
+      launch_canon(g + 3 * S, mq3.d_nmod, W, nb, ctx->stream);
+      launch_sub_mod(g + 2 * S, g + 3 * S, mq3.d_nmod, g + 4 * S, W, nb, ctx->stream);                  // h = (x_q - x_p) / p^3 mod q^3
+      launch_mul_const_add(g + 4 * S, W, sk->p3_limbs.d, W, g, W, 0, out, W3, nb, ctx->stream);          // x_p + p^3 h
+    };
+    // p-adic split of the exponents (the lift of encrypt_core, one prime at a time): with r = r0 + r1 p,
+    //     x^r = (x^(r1))^p x^(r0)   and   W^p mod p^3 depends on W mod p^2 only,
+    // so W = x^(r1) [y^(s1)] is an interleaved ladder of 2 047 squarings modulo p^2 -- on the one-lane pair kernel, 3.5 H^2
+    // multiplies a squaring -- and W^p x^(r0) [y^(s0)] an interleaved ladder of 1 024 squarings modulo p^3, where the ladder
+    // on the whole reduced exponent squares 3 071 times modulo p^3 (8 H^2 issue slots each).
+    const bool reduced_pn = !exps || (ex[0] != exps && ex[1] != exps && wex[0] == sk->eo_p.w && wex[1] == sk->eo_q.w);
+    const size_t lanes_target_s = ctx->lanes_wanted ? ctx->lanes_wanted : (size_t)1024 * 64;
+    // (below one wave per SIMD for the stage modulo p^2 the ladders are bound by their length, and one ladder is shorter than two)
+    if (ctx->use_lift && reduce_e && (exps || base2) && reduced_pn && win == 7 && sk->mp2.WT == 2 * sk->mp.WT && nb * 4 >= lanes_target_s &&
+        sk->eo_p.w <= 3 * sk->mp.WT && sk->pinv2k_2.d && (uint64_t)nb * 3 * sk->mp.WT * 4 * 129 < (1ull << 32)) {
+      const int H = sk->mp.WT, W2 = sk->mp2.WT;
+      const size_t S1 = (size_t)H * nb, S2 = (size_t)W2 * nb;
+      const uint32_t *r0[2] = {nullptr, nullptr}, *r1[2] = {nullptr, nullptr}, *x2[2], *y2[2] = {nullptr, nullptr};
+      BigU s0[2], s1[2];
+      uint32_t* tbx = ctx->ws_t<uint32_t>(S);
+      uint32_t *xr[2], *yr3[2] = {nullptr, nullptr};
+      for (int half = 0; half < 2; ++half) {
+        const ModCtx &m1 = half ? sk->mq : sk->mp, &m2 = half ? sk->mq2 : sk->mp2, &m3 = half ? mq3 : mp3;
+        if (exps) {
+          uint32_t* t2 = ctx->ws_t<uint32_t>(S2);
+          uint32_t* d0 = ctx->ws_t<uint32_t>(S1);
+          uint32_t* d1 = ctx->ws_t<uint32_t>(S2);
+          reduce_mod(ctx, m2, ex[half], wex[half], t2, nb);
+          reduce_mod(ctx, m1, t2, W2, d0, nb);                                                       // r0 = r mod prime
+          launch_div_exact(ex[half], wex[half], 0, d0, H, tbx, (half ? sk->qinv2k_2 : sk->pinv2k_2).d, m1.d_nmod, H, d1, W2, nb, nb,
+                           nullptr, 0, ctx->stream);                                                 // r1 = (r - r0) / prime
+          r0[half] = d0;
+          r1[half] = d1;
+        }
+        if (base2) hostbig::divmod(es[half], half ? sk->q : sk->p, s1[half], s0[half]);
+        // the bases modulo prime^3 (kept for stage B) and modulo prime^2 (stage A)
+        xr[half] = ctx->ws_t<uint32_t>(S);
+        reduce_mod(ctx, m3, base, wb, xr[half], nb);
+        uint32_t* xx = ctx->ws_t<uint32_t>(S2);
+        reduce_mod(ctx, m2, xr[half], W, xx, nb);
+        x2[half] = xx;
+        if (base2) {
+          uint32_t* yr = ctx->ws_t<uint32_t>(S);
+          reduce_mod(ctx, m3, base2, wb2, yr, nb);
+          yr3[half] = yr;
+          uint32_t* yy = ctx->ws_t<uint32_t>(S2);
+          reduce_mod(ctx, m2, yr, W, yy, nb);
+          y2[half] = yy;
+        }
+      }
+      uint32_t* wv[2];
+      if (pow_p2_multi_crt(sk, x2, exps ? r1 : nullptr, W2, base2 ? y2 : nullptr, s1, nb, wv)) {
+        // stage B: slots 0 x, 1 W, 2 tmp, 3 out, 4 y, 5.. the per-number table (128 + 64), then W's and y's odd powers
+        const uint32_t TABW = 5 + (uint32_t)perlane_table_slots(win), TABY = TABW + 64;
+        TriplePlan up = triple_alloc(ctx, mp3, nb, (int)TABY + 64), uq = triple_alloc(ctx, mq3, nb, (int)TABY + 64);
+        Prog pb[2];
+        for (int half = 0; half < 2; ++half) {
+          const ModCtx& m3 = half ? mq3 : mp3;
+          const TriplePlan& t = half ? uq : up;
+          triple_enter(ctx, m3, xr[half], t, 0);
+          uint32_t* wz = ctx->ws_t<uint32_t>(S);
+          launch_copy_limbs(wv[half], 0, W2, wz, W, nb, ctx->stream);
+          triple_enter(ctx, m3, wz, t, 1);
+          std::vector<SharedBase> sh;
+          sh.push_back(SharedBase{half ? sk->q : sk->p, 1, TABW});
+          if (base2) {
+            triple_enter(ctx, m3, yr3[half], t, 4);
+            sh.push_back(SharedBase{s0[half], 4, TABY});
+          }
+          emit_modexp_multi(pb[half], exps ? H : 0, 0, 5, win, sh, 2, 3, 0);
+          pb[half].end();
+        }
+        SegSpec sp{&mp3, &pb[0], up.mem, r0[0]}, sq{&mq3, &pb[1], uq.mem, r0[1]};
+        sp.pair = mp3.triple.kconsts; sp.pair_n0inv = sk->mp.n0inv; sp.pair_h = up.H; sp.pair_lanes = 3; sp.tconsts = mp3.triple.tconsts;
+        sq.pair = mq3.triple.kconsts; sq.pair_n0inv = sk->mq.n0inv; sq.pair_h = uq.H; sq.pair_lanes = 3; sq.tconsts = mq3.triple.tconsts;
+        run_vm(ctx, nb, sp, &sq, true);
+        garner(up, uq);
+        return;
+      }
+    }
+    TriplePlan tp = triple_alloc(ctx, mp3, nb, nslots), tq = triple_alloc(ctx, mq3, nb, nslots);
+    for (int half = 0; half < 2; ++half) {
+      const ModCtx& m3 = half ? mq3 : mp3;
+      const TriplePlan& t = half ? tq : tp;
+      reduce_mod(ctx, m3, base, wb, g + 5 * S, nb);
+      triple_enter(ctx, m3, g + 5 * S, t, 0);
+      if (base2) {
+        reduce_mod(ctx, m3, base2, wb2, g + 5 * S, nb);
+        triple_enter(ctx, m3, g + 5 * S, t, 1);
+      }
+    }
     Prog pp, pq;
     for (int half = 0; half < 2; ++half) {
       Prog& pr = half ? pq : pp;
@@ -3728,18 +3932,7 @@ void pow_n3_crt(const pgpu_seckey* sk, const uint32_t* base, int wb, const uint3
     sp.pair = mp3.triple.kconsts; sp.pair_n0inv = sk->mp.n0inv; sp.pair_h = tp.H; sp.pair_lanes = 3; sp.tconsts = mp3.triple.tconsts;
     sq.pair = mq3.triple.kconsts; sq.pair_n0inv = sk->mq.n0inv; sq.pair_h = tq.H; sq.pair_lanes = 3; sq.tconsts = mq3.triple.tconsts;
     run_vm(ctx, nb, sp, &sq, true);
-    triple_exit(ctx, mp3, tp, 3, g + 0 * S, nullptr);     // x_p, canonical
-    triple_exit(ctx, mq3, tq, 3, g + 1 * S, nullptr);     // x_q
-    Prog c;
-    c.op(VM_LOAD, 0); c.op(VM_MULC, (uint32_t)sk->c_p3invR); c.op(VM_STORE, 3);
-    c.op(VM_LOAD, 1); c.op(VM_MULC, (uint32_t)sk->c_p3invR); c.op(VM_STORE, 2);
-    c.end();
-    SegSpec sc{&mq3, &c, g, nullptr};
-    run_vm(ctx, nb, sc, nullptr, false);
-    launch_canon(g + 2 * S, mq3.d_nmod, W, nb, ctx->stream);
-    launch_canon(g + 3 * S, mq3.d_nmod, W, nb, ctx->stream);
-    launch_sub_mod(g + 2 * S, g + 3 * S, mq3.d_nmod, g + 4 * S, W, nb, ctx->stream);                  // h = (x_q - x_p) / p^3 mod q^3
-    launch_mul_const_add(g + 4 * S, W, sk->p3_limbs.d, W, g, W, 0, out, W3, nb, ctx->stream);          // x_p + p^3 h
+    garner(tp, tq);
     return;
   }
   // slots: P: in 0, in2 1, tmp 2, out 3, tables 4..51;  Q: the same + QO;  A, B, h after them

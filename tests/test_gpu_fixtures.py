@@ -95,6 +95,31 @@ def test_ddleq_2048_kernels_off(ctx, keys):
         ctx.set_flag("asm", 1)
 
 
+def test_ddleq_2048_prover_with_the_p_adic_split_forced(ctx, keys):
+    """A batch that fills the chip makes the prover split its ladders modulo p^3, q^3 by the base-p digits of the (reduced)
+    exponents: x^(r0 + r1 p) = (x^(r1) mod p^2)^p x^(r0) (capi.cpp pow_n3_crt / pow_p2_multi_crt).  lanes_wanted = 1 forces that
+    path -- one lane per number modulo p^2 -- for the 64 fixture instances; lanes_wanted = 4096 its two-lane variant; with
+    the lift off the unsplit ladders run.  All must land on the committed Alpha / E / F."""
+    pk, sk = keys
+    d = load("proofs.json")["ddleq"]
+    st = [{k: int(v, 16) for k, v in s.items()} for s in d["statements"]]
+    ins = d["instances"]
+    col = lambda key: [st[i["s"]][key] for i in ins]
+    xs, ys = H(i["x"] for i in ins), H(i["y"] for i in ins)
+    want = [i["digest"] for i in ins]
+    for lanes_wanted, lift in ((1, 1), (4096, 1), (1, 0)):
+        ctx.set_flag("lanes_wanted", lanes_wanted)
+        ctx.set_flag("lift", lift)
+        try:
+            al, es, fs = sk.ProveDDLEQInstancesBatch(col("ct1"), col("ct2"), col("a"), col("b"), xs, ys)
+        finally:
+            ctx.set_flag("lanes_wanted", 0)
+            ctx.set_flag("lift", 1)
+        dg = [hashlib.sha256(a.to_bytes(768, "big") + e.to_bytes(512, "big") + f.to_bytes(768, "big")).hexdigest()
+              for a, e, f in zip(al, es, fs)]
+        assert dg == want, (lanes_wanted, lift)
+
+
 def test_encrypt_2048_on_the_full_batch_kernel(ctx, keys):
     """EncryptWithR at 2048 bits with lanes_wanted = 1: the batch keeps the kernel shape a 65 536-ciphertext batch uses
     (vm_asm_74_32, the two-lane pair kernel) instead of the small-batch re-slicing, and is compared with the committed c."""
