@@ -732,6 +732,10 @@ void run_vm(pgpu_ctx* ctx, size_t nb, const SegSpec& s0, const SegSpec* s1, bool
     HIPCHK(hipEventRecord(ev->a, ctx->stream));
   }
   if (pair && !use_asm) api_throw(PGPU_ERR_UNSUPPORTED, "the pair kernel exists in assembly only");
+  if (pair && s0.pair_lanes == 1 && s0.pair_h > 37)
+    for (int i = 0; i < 3; ++i)
+      if (ss[i] && ss[i]->prog->has_mulv)   // (an opcode a kernel does not know ends its program: refuse, never compute garbage)
+        api_throw(PGPU_ERR_UNSUPPORTED, "internal: per-number windows on the one-lane pair kernel for 55-limb primes");
   if (ev) snprintf(ev->name, sizeof ev->name, use_asm ? "vm_asm_%d_%d" : "vm_kernel<%d,%d>", WL, K);
   hipError_t e = use_asm ? launch_vm_asm(WL, K, a, blocks, ctx->stream) : launch_vm(WL, K, a, blocks, ctx->stream);
   if (use_asm) ctx->last_vm_asm++;
@@ -3723,6 +3727,7 @@ bool pow_p2_multi_crt(const pgpu_seckey* sk, const uint32_t* const xs[2], const 
   if (!(sk->has_pair && sk->pair_lanes == 1 && sk->c_onep_p2 >= 0 && sk->c_onep_q2 >= 0 && sk->c_rh_p2 >= 0 && ctx->use_asm &&
         ctx->use_pair && sk->mp2.WT == 2 * sk->mp.WT && sk->mq2.WT == 2 * sk->mq.WT))
     return false;
+  if (r1 && sk->mp.WT > 37) return false;   // per-number windows (VM_MULV): the one-lane kernel for 55-limb primes has shared-exponent opcodes only
   // one lane per number when the two halves fill the chip that way, else two (as Decrypt chooses)
   const size_t lanes_target = ctx->lanes_wanted ? ctx->lanes_wanted : (size_t)1024 * 64;
   const int lanes = (sk->pair_small2 && nb * 2 < lanes_target) ? 2 : 1;

@@ -245,7 +245,14 @@ def test_ddleq_prove_3072_bit_key(ctx):
                                       po.rand_unit(n, rng), po.ENC_LEVEL_TWO).C for _ in range(B)]
     a_s, b_s, xs, ys = ([po.rand_unit(n, rng) for _ in range(B)] for _ in range(4))
     ct2 = [po.nested_randomize_with_ab(sk_o, po.Ciphertext(c, 1), a, b).C for c, a, b in zip(ct1, a_s, b_s)]
-    al, es, fs = sk.ProveDDLEQInstancesBatch(ct1, ct2, a_s, b_s, xs, ys)
+    # lanes_wanted = 1: the kernel shapes of a chip-filling batch -- the one-lane pair kernel for 55-limb primes, and the
+    # prover's p-adic split is attempted (it needs per-number windows modulo p^2, which that kernel does not have: the
+    # library must fall back to the unsplit ladders, not compute garbage)
+    ctx.set_flag("lanes_wanted", 1)
+    try:
+        al, es, fs = sk.ProveDDLEQInstancesBatch(ct1, ct2, a_s, b_s, xs, ys)
+    finally:
+        ctx.set_flag("lanes_wanted", 0)
     refs = [po.prove_ddleq_instance_xy(sk_o, po.Ciphertext(c1, 1), po.Ciphertext(c2, 1), a, b, x, y)
             for c1, c2, a, b, x, y in zip(ct1, ct2, a_s, b_s, xs, ys)]
     assert (al, es, fs) == ([r.Alpha for r in refs], [r.E for r in refs], [r.F for r in refs])
