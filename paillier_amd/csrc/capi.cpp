@@ -271,6 +271,7 @@ struct Prog {
   void op(uint32_t o, uint32_t arg = 0, uint32_t aux = 0) {
     if (o == VM_SETOFF) asm_ok = false;
     if (o == VM_MULV7 || o == VM_STORET) nm_tables = true;
+    if (o == VM_MULCV) has_mulv = true;        // (any per-number gather: kernels without those opcodes must not get the program)
     if (o == VM_MULV || o == VM_MULV5 || o == VM_MULV7) {
       has_mulv = true;
       gather_slots = std::max<uint32_t>(gather_slots, o == VM_MULV ? 17u : o == VM_MULV5 ? 33u : 129u);
