@@ -266,12 +266,13 @@ struct Prog {
   double montmuls = 0, sqrs = 0;
   bool asm_ok = true;  // only opcodes the assembly kernel implements
   bool has_mulv = false;
+  bool wide_gathers = false;  // table opcodes other than the 4-bit VM_MULV
   bool nm_tables = false;     // VM_MULV7 / VM_STORET: among the assembly kernels only the three-digit ones implement them
   uint32_t gather_slots = 1;  // slots a per-number gather spans (table entries + 1): its offsets are 32-bit in the assembly kernels
   void op(uint32_t o, uint32_t arg = 0, uint32_t aux = 0) {
     if (o == VM_SETOFF) asm_ok = false;
     if (o == VM_MULV7 || o == VM_STORET) nm_tables = true;
-    if (o == VM_MULCV) has_mulv = true;        // (any per-number gather: kernels without those opcodes must not get the program)
+    if (o == VM_MULCV || o == VM_MULV5 || o == VM_MULV7 || o == VM_STORET) wide_gathers = true;   // (kernels without these opcodes must not get the program)
     if (o == VM_MULV || o == VM_MULV5 || o == VM_MULV7) {
       has_mulv = true;
       gather_slots = std::max<uint32_t>(gather_slots, o == VM_MULV ? 17u : o == VM_MULV5 ? 33u : 129u);
@@ -735,8 +736,8 @@ void run_vm(pgpu_ctx* ctx, size_t nb, const SegSpec& s0, const SegSpec* s1, bool
   if (pair && !use_asm) api_throw(PGPU_ERR_UNSUPPORTED, "the pair kernel exists in assembly only");
   if (pair && s0.pair_lanes == 1 && s0.pair_h > 37)
     for (int i = 0; i < 3; ++i)
-      if (ss[i] && ss[i]->prog->has_mulv)   // (an opcode a kernel does not know ends its program: refuse, never compute garbage)
-        api_throw(PGPU_ERR_UNSUPPORTED, "internal: per-number windows on the one-lane pair kernel for 55-limb primes");
+      if (ss[i] && ss[i]->prog->wide_gathers)   // (an opcode a kernel does not know ends its program: refuse, never compute garbage)
+        api_throw(PGPU_ERR_UNSUPPORTED, "internal: the one-lane pair kernel for 55-limb primes has 4-bit per-number windows only");
   if (ev) snprintf(ev->name, sizeof ev->name, use_asm ? "vm_asm_%d_%d" : "vm_kernel<%d,%d>", WL, K);
   hipError_t e = use_asm ? launch_vm_asm(WL, K, a, blocks, ctx->stream) : launch_vm(WL, K, a, blocks, ctx->stream);
   if (use_asm) ctx->last_vm_asm++;
@@ -3728,7 +3729,6 @@ bool pow_p2_multi_crt(const pgpu_seckey* sk, const uint32_t* const xs[2], const 
   if (!(sk->has_pair && sk->pair_lanes == 1 && sk->c_onep_p2 >= 0 && sk->c_onep_q2 >= 0 && sk->c_rh_p2 >= 0 && ctx->use_asm &&
         ctx->use_pair && sk->mp2.WT == 2 * sk->mp.WT && sk->mq2.WT == 2 * sk->mq.WT))
     return false;
-  if (r1 && sk->mp.WT > 37) return false;   // per-number windows (VM_MULV): the one-lane kernel for 55-limb primes has shared-exponent opcodes only
   // one lane per number when the two halves fill the chip that way, else two (as Decrypt chooses)
   const size_t lanes_target = ctx->lanes_wanted ? ctx->lanes_wanted : (size_t)1024 * 64;
   const int lanes = (sk->pair_small2 && nb * 2 < lanes_target) ? 2 : 1;
@@ -4021,7 +4021,7 @@ int pgpu_ddleq_prove(const pgpu_seckey* sk, size_t batch, const uint8_t* ct1, co
     const ModCtx &mn = pk->mn, &mn2 = pk->mn2, &mn3 = *pk->mn3;
     const int W1 = mn.WT, W2 = mn2.WT, W3 = mn3.WT;
     // the prover holds the factorisation: exponentiations modulo n^3 go through p^3 and q^3 (pow_n3_crt)
-    const bool crt3 = sk->has_crt2 && sk->c_p3invR >= 0 && 2 * sk->mp3.WT == W3 && ctx->use_pair;
+    const bool crt3 = sk->has_crt2 && sk->c_p3invR >= 0 && 2 * sk->mp3.WT >= W3 && ctx->use_pair;
     auto perlane3 = [&](const uint32_t* base, const uint32_t* exps, int we, size_t nbx, uint32_t* outp) {
       if (crt3) pow_n3_crt(sk, base, W3, exps, we, nullptr, nbx, outp);
       else perlane_pow(ctx, mn3, base, exps, we, nbx, outp);

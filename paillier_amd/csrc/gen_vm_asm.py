@@ -1841,10 +1841,10 @@ class GenP2(GenP):
         e("s_waitcnt lgkmcnt(0)")
         self.fair_share()
         e("s_and_b32 s18, s16, 0xff")
-        for nm in ("SQR", "MUL", "MULC", "LOAD", "STORE", "LOADC", "ADD"):
+        for nm in ("SQR", "MUL", "MULC", "MULV", "LOAD", "STORE", "LOADC", "ADD"):
             e(f"s_cmp_eq_u32 s18, {OPS[nm]}")
             e(f"s_cbranch_scc1 L_{nm.lower()}")
-        e("s_endpgm")  # END (the host sends this kernel shared-exponent ladders only: no per-number table opcodes)
+        self.end_of_program()  # END (per-number windows: 4-bit VM_MULV only; the host refuses other table opcodes for this kernel)
 
         e("L_load:")
         self.slot_base()
@@ -1887,6 +1887,29 @@ class GenP2(GenP):
         e(f"s_mov_b64 s[{g.s_bstart}:{g.s_bstart + 1}], s[{g.s_sbase}:{g.s_sbase + 1}]")
         e(f"s_mov_b32 s{g.s_bstride}, 4")
         e(f"v_mov_b32 v{g.v_vb}, 0")
+        e("s_branch L_montmul")
+        e("L_mulv:")
+        # per-number table index: 4-bit window `arg` of this number's own exponent (7 windows per 28-bit limb of `digits`);
+        # the operand streams from slot aux + digit -- the same multiplier rings as MUL, with a per-lane address
+        e(f"s_mul_hi_u32 s{g.s_t1}, s17, {((1 << 32) + 6) // 7}")            # q = arg / 7
+        e(f"s_mul_i32 s98, s{g.s_t1}, 7")
+        e("s_sub_u32 s98, s17, s98")
+        e("s_lshl_b32 s98, s98, 2")                                          # shift = 4 (arg % 7)
+        e(f"s_mul_hi_u32 s{g.s_sbase + 1}, s{g.s_t1}, s3")                    # digits + q * nb*4
+        e(f"s_mul_i32 s{g.s_sbase}, s{g.s_t1}, s3")
+        e(f"s_add_u32 s{g.s_sbase}, s{g.s_sbase}, s12")
+        e(f"s_addc_u32 s{g.s_sbase + 1}, s{g.s_sbase + 1}, s13")
+        e(f"global_load_dword v{g.v_t3}, v{g.v_goff}, s[{g.s_sbase}:{g.s_sbase + 1}]")
+        e("s_waitcnt vmcnt(0)")
+        e(f"v_lshrrev_b32 v{g.v_t3}, s98, v{g.v_t3}")
+        e(f"v_and_b32 v{g.v_t3}, 15, v{g.v_t3}")                             # digit
+        e(f"s_mul_i32 s{g.s_t0}, s3, {2 * H}")                                # slot stride in bytes (< 2^32: host)
+        e(f"v_mul_lo_u32 v{g.v_t3}, v{g.v_t3}, s{g.s_t0}")                    # digit * stride (the host keeps 17 slots below 2^32)
+        e(f"v_add_u32 v{g.v_vb}, v{g.v_t3}, v{g.v_goff}")
+        e("s_bfe_u32 s17, s16, 0x160008")                                    # aux = first table slot
+        self.slot_base()
+        e(f"s_mov_b64 s[{g.s_bstart}:{g.s_bstart + 1}], s[{g.s_sbase}:{g.s_sbase + 1}]")
+        e(f"s_mov_b32 s{g.s_bstride}, s3")
         e("s_branch L_montmul")
         e("L_sqr:")
         e("s_branch L_montsq")

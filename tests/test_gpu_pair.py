@@ -13,7 +13,7 @@ from model28 import to_limbs, from_limbs
 
 pytestmark = pytest.mark.gpu
 G = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
-END, LOAD, STORE, SQR, MUL, MULC, ADD = 0, 1, 2, 4, 5, 6, 8
+END, LOAD, STORE, SQR, MUL, MULC, MULV, ADD = 0, 1, 2, 4, 5, 6, 7, 8
 C_ONE = 3          # constant 1 of every modulus context: the pair (1, 0)
 LB = 28
 # one-lane pair kernels: GenP (37-limb primes, 2048-bit keys) and GenP2 (55-limb primes, 3072-bit keys: quotient digits in

@@ -228,9 +228,10 @@ def test_ddleq_prove_on_device(ctx):
 
 
 def test_ddleq_prove_3072_bit_key(ctx):
-    """The prover at 3072 bits: halves modulo p^3, q^3 on the three-digit kernel for 55-limb primes (vm_asm_55_48), a^n | x^n
-    through p^2, q^2 on the one-lane pair kernel for 55-limb primes (vm_asm_55_16); the verifier's n^3 is 9 216 bits (the
-    compiler-generated (83,4) kernel).  Few instances: the oracle's 9 216-bit powers are slow."""
+    """The prover at 3072 bits: halves modulo p^3, q^3 on the three-digit kernel for 55-limb primes (vm_asm_55_48), split by the
+    base-p digits of the exponents through p^2, q^2 on the one-lane pair kernel for 55-limb primes (vm_asm_55_16, 4-bit
+    per-number windows), a^n | x^n through p^2, q^2 on it as well; the verifier's n^3 is 9 216 bits (the compiler-generated
+    (83,4) kernel).  Few instances: the oracle's 9 216-bit powers are slow."""
     import json as _json
     import paillier_amd as pa
     k = _json.load(open(os.path.join(G, "keys.json")))["paillier"]["3072"]
@@ -239,8 +240,8 @@ def test_ddleq_prove_3072_bit_key(ctx):
     sk_o = po.SecretKey(N=n, G=n + 1, Lambda=lam)
     pk = pa.PublicKey(ctx, n, n + 1)
     sk = pa.SecretKey(ctx, pk, lam)
-    rng = random.Random(3072)
-    B = 3
+    rng = random.Random(3073)      # (a seed for which both challenge bits occur among the four instances)
+    B = 4
     ct1 = [po.encrypt_with_r_at_level(sk_o, po.encrypt_with_r(sk_o, rng.randrange(n), po.rand_unit(n, rng)).C,
                                       po.rand_unit(n, rng), po.ENC_LEVEL_TWO).C for _ in range(B)]
     a_s, b_s, xs, ys = ([po.rand_unit(n, rng) for _ in range(B)] for _ in range(4))
@@ -256,6 +257,7 @@ def test_ddleq_prove_3072_bit_key(ctx):
     refs = [po.prove_ddleq_instance_xy(sk_o, po.Ciphertext(c1, 1), po.Ciphertext(c2, 1), a, b, x, y)
             for c1, c2, a, b, x, y in zip(ct1, ct2, a_s, b_s, xs, ys)]
     assert (al, es, fs) == ([r.Alpha for r in refs], [r.E for r in refs], [r.F for r in refs])
+    assert len({r.E != r.X for r in refs}) == 2, "both challenge bits should occur (change the seed)"
     # one verifier call: the three true statements and the same proofs against a neighbour's ct2
     wrong = ct2[1:] + ct2[:1]
     got = pk.VerifyDDLEQInstancesBatch(ct1 + ct1, ct2 + wrong, xs + xs, ys + ys, al + al, es + es, fs + fs)
