@@ -321,6 +321,11 @@ def main():
         assert torch.equal(eo, em), "[bench] Encrypt (library randomness): Decrypt(Encrypt(m)) != m"
         extras[-1].update({"encrypt_with_library_randomness_per_s": BE / dt_rng, "fraction_of_with_r": dt / dt_rng})
         checks["encrypt_2048"] = (n2k, em_h[:64], er_h[:64], ec[:64].cpu().numpy())
+        # the same call on the SECRET key (SecretKey embeds PublicKey in the reference): r^n through p^2 and q^2
+        dt_sk, vms_sk, mads_sk, kern_sk = timed(lambda: one_call(lambda: sk2.encrypt_with_r_raw(
+            BE, em.data_ptr(), 256, er.data_ptr(), 256, ec2.data_ptr(), 512, MEM_DEVICE)), ES)
+        assert torch.equal(ec2, ec), "[bench] key holder's EncryptWithR differs from the public path"
+        extras[-1].update({"key_holder_encryptions_per_s": BE / dt_sk, "key_holder_kernel": kern_sk})
         del ec2
 
         # the headline kernel with a deeper queue: 131072 ciphertexts = four waves' worth of work per SIMD slot pair, so the

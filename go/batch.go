@@ -49,6 +49,23 @@ func (k *GPUPublicKey) EncryptWithRBatch(m, r []*gmp.Int, level EncryptionLevel)
 	return cts(unpack(out, cs), level, RegularEncryption), nil
 }
 
+// EncryptWithRBatch on the SECRET key: SecretKey embeds PublicKey (paillier.go:60-64), so sk.EncryptWithR is the same
+// method; the key holder's r^n goes through p^2 and q^2 (pgpu_encrypt_with_r_sk): identical ciphertexts, a third of the work.
+func (s *GPUSecretKey) EncryptWithRBatch(m, r []*gmp.Int, level EncryptionLevel) ([]*Ciphertext, error) {
+	if len(m) != len(r) {
+		return nil, errors.New("paillier: len(m) != len(r)")
+	}
+	k := s.pub
+	ms, rs, cs := maxLen(m, k.plainBytes(level)), maxLen(r, k.plainBytes(EncLevelOne)), k.cipherBytes(level)
+	mb, rb, out := pack(m, ms), pack(r, rs), make([]byte, len(m)*cs)
+	rc := C.pgpu_encrypt_with_r_sk(s.h, C.int(level), C.size_t(len(m)), p8(mb), C.size_t(ms), p8(rb), C.size_t(rs), p8(out),
+		C.size_t(cs), C.PGPU_MEM_HOST)
+	if err := status(rc); err != nil {
+		return nil, err
+	}
+	return cts(unpack(out, cs), level, RegularEncryption), nil
+}
+
 // EncryptBatch: PublicKey.EncryptAtLevel (paillier.go:258-269): one fresh r in Z_n^* per message, drawn by the library
 // from the operating system's CSPRNG exactly as utils.go:36-49 does (uniform below n by rejection, gcd(r, n) = 1).
 func (k *GPUPublicKey) EncryptBatch(m []*gmp.Int, level EncryptionLevel) ([]*Ciphertext, error) {

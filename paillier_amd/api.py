@@ -60,6 +60,7 @@ SIGNATURES = {
     "pgpu_seckey_destroy": (None, [_vp]),
     "pgpu_seckey_has_crt": (_int, [_vp]),
     "pgpu_encrypt_with_r": (_int, [_vp, _int, _sz, _vp, _sz, _vp, _sz, _vp, _sz, _int]),
+    "pgpu_encrypt_with_r_sk": (_int, [_vp, _int, _sz, _vp, _sz, _vp, _sz, _vp, _sz, _int]),
     "pgpu_encrypt": (_int, [_vp, _int, _sz, _vp, _sz, _vp, _sz, _vp, _sz, _int]),
     "pgpu_random_units": (_int, [_vp, _sz, _vp, _sz, _int]),
     "pgpu_alt_encrypt_with_r": (_int, [_vp, _int, _sz, _vp, _sz, _vp, _sz, _vp, _sz, _vp, _int]),
@@ -565,6 +566,20 @@ class SecretKey:
         cb3, pb1, pb2 = pk.cipher_bytes(ENC_LEVEL_TWO), pk.plain_bytes(ENC_LEVEL_ONE), pk.plain_bytes(ENC_LEVEL_TWO)
         _check(self.ctx.lib.pgpu_ddleq_prove(self.h, batch, _ptr(ct1), _ptr(ct2), cb3, _ptr(a), _ptr(b), _ptr(x), _ptr(y), pb1,
                                              _ptr(alpha), _ptr(e), pb2, _ptr(f), mem))
+
+    def EncryptWithRBatch(self, ms: Sequence[int], rs: Sequence[int], level: int = ENC_LEVEL_ONE) -> List[int]:
+        """sk.EncryptWithR (SecretKey embeds PublicKey, paillier.go:60-64,185): the key holder's r^n goes through p^2 and q^2
+        (pgpu_encrypt_with_r_sk); the ciphertexts are the public path's."""
+        pk = self.pk
+        pb, cb, rb = pk.plain_bytes(level), pk.cipher_bytes(level), pk.plain_bytes()
+        rlen = max(rb, max((int(r).bit_length() + 7) // 8 for r in rs))
+        mb, rbuf = ints_to_be(ms, pb), ints_to_be(rs, rlen)
+        out = np.zeros((len(ms), cb), dtype=np.uint8)
+        _check(self.ctx.lib.pgpu_encrypt_with_r_sk(self.h, level, len(ms), _ptr(mb), pb, _ptr(rbuf), rlen, _ptr(out), cb, MEM_HOST))
+        return be_to_ints(out)
+
+    def encrypt_with_r_raw(self, batch, m, m_stride, r, r_stride, c, c_stride, mem=MEM_HOST, level=ENC_LEVEL_ONE):
+        _check(self.ctx.lib.pgpu_encrypt_with_r_sk(self.h, level, batch, _ptr(m), m_stride, _ptr(r), r_stride, _ptr(c), c_stride, mem))
 
     def NestedDecryptBatch(self, cts: Sequence[int]) -> List[int]:
         """paillier.go:344-355: peel the level-two layer, then decrypt at level one (0 stays 0: the reference's edge case)."""

@@ -4006,6 +4006,43 @@ uint32_t* zext(pgpu_ctx* ctx, const uint32_t* in, int w, int wo, size_t nb) {
 
 extern "C" {
 
+// EncryptWithR for the holder of the secret key (SecretKey embeds PublicKey in the reference: sk.EncryptWithR is the same
+// method): r^n mod n^2 through p^2 and q^2 -- half the width, the exponent modulo p (p - 1) -- on the one-lane pair kernel of
+// Decrypt, then Garner and the closed form of G^m.  The same integers as pgpu_encrypt_with_r, a third of its multiplies.
+int pgpu_encrypt_with_r_sk(const pgpu_seckey* sk, int level, size_t batch, const uint8_t* m, size_t m_stride, const uint8_t* r,
+                           size_t r_stride, uint8_t* c, size_t c_stride, int mem) {
+  if (!sk) return fail(PGPU_ERR_INVALID, "null key");
+  pgpu_ctx* ctx = sk->ctx;
+  const pgpu_pubkey* pk = sk->pk;
+  if (level != PGPU_LEVEL_ONE || !pk->g_is_n_plus_1 || !pow_n2_crt_usable(sk))
+    return pgpu_encrypt_with_r(pk, level, batch, m, m_stride, r, r_stride, c, c_stride, mem);   // nothing to gain: the public path
+  return guarded([&] {
+    check_batch_args(m, c, batch);
+    if (!r) api_throw(PGPU_ERR_INVALID, "null buffer");
+    ctx->bind();
+    ctx->reset_ws();
+    const ModCtx &mn = pk->mn, &mn2 = pk->mn2;
+    const size_t nb = round_up(batch, VM_BLOCK);
+    uint32_t* gm = ctx->ws_t<uint32_t>((size_t)mn2.WT * nb);
+    build_gm(ctx, pk, level, m, m_stride, batch, mem, nb, gm);                       // 1 + (m mod n) n
+    uint32_t* rl = ctx->ws_t<uint32_t>((size_t)mn.WT * nb);
+    unpack_mod(ctx, mn, r, r_stride, batch, mem, rl, nb, true);                      // r^n mod n^2 depends on r mod n only
+    uint32_t* rn = pow_n2_crt(sk, rl, pk->N, nb);                                    // canonical, mn2.WT limbs
+    // c = r^n * g^m mod n^2
+    const size_t sw = (size_t)mn2.WT * nb;
+    uint32_t* mem2 = ctx->ws_t<uint32_t>(sw * 3);
+    HIPCHK(hipMemcpyAsync(mem2, rn, sw * 4, hipMemcpyDeviceToDevice, ctx->stream));
+    HIPCHK(hipMemcpyAsync(mem2 + sw, gm, sw * 4, hipMemcpyDeviceToDevice, ctx->stream));
+    Prog p;
+    p.op(VM_LOAD, 0); p.op(VM_MULC, C_R2); p.op(VM_MUL, 1); p.op(VM_STORE, 2); p.end();
+    SegSpec sg{&mn2, &p, mem2, nullptr};
+    run_vm(ctx, nb, sg, nullptr, false);
+    launch_canon(mem2 + 2 * sw, mn2.d_nmod, mn2.WT, nb, ctx->stream);
+    pack_result(ctx, mem2 + 2 * sw, mn2.WT, nb, batch, c, c_stride, mn2.nbytes, mem);
+    HIPCHK(hipStreamSynchronize(ctx->stream));
+  });
+}
+
 int pgpu_ddleq_prove(const pgpu_seckey* sk, size_t batch, const uint8_t* ct1, const uint8_t* ct2, size_t ct_stride,
                      const uint8_t* a, const uint8_t* b, const uint8_t* x, const uint8_t* y, size_t n_stride, uint8_t* alpha,
                      uint8_t* e_out, size_t e_stride, uint8_t* f_out, int mem) {
