@@ -49,7 +49,7 @@ func (k *GPUPublicKey) EncryptWithRBatch(m, r []*gmp.Int, level EncryptionLevel)
 	return cts(unpack(out, cs), level, RegularEncryption), nil
 }
 
-// EncryptWithRBatch on the SECRET key: SecretKey embeds PublicKey (paillier.go:60-64), so sk.EncryptWithR is the same
+// EncryptWithRBatch on the SECRET key: SecretKey embeds PublicKey (paillier.go:59-62), so sk.EncryptWithR is the same
 // method; the key holder's r^n goes through p^2 and q^2 (pgpu_encrypt_with_r_sk): identical ciphertexts, a third of the work.
 func (s *GPUSecretKey) EncryptWithRBatch(m, r []*gmp.Int, level EncryptionLevel) ([]*Ciphertext, error) {
 	if len(m) != len(r) {

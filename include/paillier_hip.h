@@ -112,7 +112,7 @@ int pgpu_seckey_has_crt(const pgpu_seckey* sk);
  *   c[i] = G^m[i] * r[i]^(n^s) mod n^(s+1)                                                        */
 int pgpu_encrypt_with_r(const pgpu_pubkey* pk, int level, size_t batch, const uint8_t* m, size_t m_stride,
                         const uint8_t* r, size_t r_stride, uint8_t* c, size_t c_stride, int mem);
-/* The same for the holder of the secret key (in the reference SecretKey embeds PublicKey, paillier.go:60-64: sk.EncryptWithR is
+/* The same for the holder of the secret key (in the reference SecretKey embeds PublicKey, paillier.go:59-62: sk.EncryptWithR is
  * the same method): r^n mod n^2 through p^2 and q^2.  Identical ciphertexts, a third of the multiplies; level two and keys
  * without the factorisation take the public path. */
 int pgpu_encrypt_with_r_sk(const pgpu_seckey* sk, int level, size_t batch, const uint8_t* m, size_t m_stride,

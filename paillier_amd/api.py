@@ -568,7 +568,7 @@ class SecretKey:
                                              _ptr(alpha), _ptr(e), pb2, _ptr(f), mem))
 
     def EncryptWithRBatch(self, ms: Sequence[int], rs: Sequence[int], level: int = ENC_LEVEL_ONE) -> List[int]:
-        """sk.EncryptWithR (SecretKey embeds PublicKey, paillier.go:60-64,185): the key holder's r^n goes through p^2 and q^2
+        """sk.EncryptWithR (SecretKey embeds PublicKey, paillier.go:59-62,185): the key holder's r^n goes through p^2 and q^2
         (pgpu_encrypt_with_r_sk); the ciphertexts are the public path's."""
         pk = self.pk
         pb, cb, rb = pk.plain_bytes(level), pk.cipher_bytes(level), pk.plain_bytes()
