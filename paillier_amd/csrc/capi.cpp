@@ -506,14 +506,16 @@ void emit_modexp_dual(Prog& p, int we, const BigU& e, uint32_t in1, uint32_t in2
 // sliding windows over odd powers.  All inputs already in the kernel's working form (digit kernels), `one` = the constant
 // holding 1 in that form.  Sliding windows: 6 bits below 1 500 exponent bits, dual_sliding_bits(wb) above.
 struct SharedBase { BigU e; uint32_t in; uint32_t tab; };
+struct PerNumberBase { int we; uint32_t in; uint32_t tab; uint32_t first_window; };   // windows first_window.. of the `digits` rows
 static int shared_window_bits(const BigU& e, int wb) { return e.bit_length() < 1500 ? 6 : dual_sliding_bits(wb); }
-void emit_modexp_multi(Prog& p, int we, uint32_t in1, uint32_t tab1, int wb, const std::vector<SharedBase>& sh, uint32_t tmp,
+void emit_modexp_multi(Prog& p, const std::vector<PerNumberBase>& pn, int wb, const std::vector<SharedBase>& sh, uint32_t tmp,
                        uint32_t out, uint32_t one) {
-  if (we > 0) {
-    p.op(VM_LOAD, in1);
-    emit_power_table(p, tab1, one, wb);
+  long nbits = 0;
+  for (auto& b : pn) {
+    p.op(VM_LOAD, b.in);
+    emit_power_table(p, b.tab, one, wb);
+    nbits = std::max<long>(nbits, (long)b.we * LB);
   }
-  long nbits = (long)we * LB;
   std::vector<std::vector<int>> mul_at(sh.size());
   for (size_t k = 0; k < sh.size(); ++k) {
     const BigU& e = sh[k].e;
@@ -541,11 +543,11 @@ void emit_modexp_multi(Prog& p, int we, uint32_t in1, uint32_t tab1, int wb, con
       i = l - 1;
     }
   }
-  const long nwin = we > 0 ? perlane_windows(we, wb) : 0;
   p.op(VM_LOADC, one);
   for (long b = nbits - 1; b >= 0; --b) {
     if (b != nbits - 1) p.op(VM_SQR);
-    if (we > 0 && b % wb == 0 && b / wb < nwin) p.op(perlane_op(wb), (uint32_t)(b / wb), tab1);
+    for (auto& q : pn)
+      if (b % wb == 0 && b / wb < perlane_windows(q.we, wb)) p.op(perlane_op(wb), (uint32_t)(b / wb) + q.first_window, q.tab);
     for (size_t k = 0; k < sh.size(); ++k)
       if (mul_at[k][(size_t)b] >= 0) p.op(VM_MUL, sh[k].tab + (uint32_t)mul_at[k][(size_t)b]);
   }
@@ -3761,7 +3763,9 @@ bool pow_p2_multi_crt(const pgpu_seckey* sk, const uint32_t* const xs[2], const 
     }
     std::vector<SharedBase> sh;
     if (ys) sh.push_back(SharedBase{s1[half], 1, TAB2});
-    emit_modexp_multi(pr[half], r1 ? we : 0, 0, TAB1, wb, sh, 2, 3, (uint32_t)(half ? sk->c_onep_q2 : sk->c_onep_p2));
+    std::vector<PerNumberBase> pn;
+    if (r1) pn.push_back(PerNumberBase{we, 0, TAB1, 0});
+    emit_modexp_multi(pr[half], pn, wb, sh, 2, 3, (uint32_t)(half ? sk->c_onep_q2 : sk->c_onep_p2));
     pr[half].end();
   }
   {
@@ -3903,7 +3907,9 @@ void pow_n3_crt(const pgpu_seckey* sk, const uint32_t* base, int wb, const uint3
             triple_enter(ctx, m3, yr3[half], t, 4);
             sh.push_back(SharedBase{s0[half], 4, TABY});
           }
-          emit_modexp_multi(pb[half], exps ? H : 0, 0, 5, win, sh, 2, 3, 0);
+          std::vector<PerNumberBase> pn;
+          if (exps) pn.push_back(PerNumberBase{H, 0, 5, 0});
+          emit_modexp_multi(pb[half], pn, win, sh, 2, 3, 0);
           pb[half].end();
         }
         SegSpec sp{&mp3, &pb[0], up.mem, r0[0]}, sq{&mq3, &pb[1], uq.mem, r0[1]};
@@ -3982,6 +3988,62 @@ void pow_n3_crt(const pgpu_seckey* sk, const uint32_t* base, int wb, const uint3
   launch_canon(mem + (size_t)SB * S, mq3.d_nmod, W, nb, ctx->stream);
   launch_sub_mod(mem + (size_t)SA * S, mem + (size_t)SB * S, mq3.d_nmod, mem + (size_t)SH * S, W, nb, ctx->stream);  // h = (x_q - x_p) / p^3 mod q^3
   launch_mul_const_add(mem + (size_t)SH * S, W, sk->p3_limbs.d, W, xp, W, 0, out, W3, nb, ctx->stream);              // x_p + p^3 h
+}
+
+// out = A^(ea) * B^(eb) mod n^3 for the holder of the factorisation, BOTH exponents per number and already reduced modulo the
+// group orders of p^3 and q^3 (ea[half], eb[half]: eo.w limbs): one interleaved ladder per half on the three-digit kernel --
+// two per-number window tables hang off one chain of squarings -- then Garner.  A, B: W3-limb residues.  False when the
+// three-digit kernels do not serve this key / batch.
+bool pow_n3_crt_two(const pgpu_seckey* sk, const uint32_t* A, const uint32_t* const ea[2], const uint32_t* B,
+                    const uint32_t* const eb[2], size_t nb, uint32_t* out) {
+  pgpu_ctx* ctx = sk->ctx;
+  const ModCtx &mp3 = sk->mp3, &mq3 = sk->mq3;
+  const int W = mp3.WT, W3 = sk->pk->mn3->WT;
+  const size_t S = (size_t)W * nb;
+  if (!(triple_usable(ctx, mp3) && triple_usable(ctx, mq3) && sk->eo_p.ok && sk->eo_q.ok && sk->eo_p.w == sk->eo_q.w)) return false;
+  const int H = mp3.triple.root->WT, we = sk->eo_p.w;
+  if (triple_window_bits(nb, H) != 7) return false;
+  const int win = 7;
+  const uint32_t TABA = 5, TABB = TABA + (uint32_t)perlane_table_slots(win);
+  TriplePlan tp = triple_alloc(ctx, mp3, nb, (int)TABB + perlane_table_slots(win)), tq = triple_alloc(ctx, mq3, nb, (int)TABB + perlane_table_slots(win));
+  uint32_t* g = ctx->ws_t<uint32_t>(S * 6);       // generic slots (W limbs): 0 x_p, 1 x_q, 2 A, 3 B, 4 h, 5 scratch
+  Prog pr[2];
+  const uint32_t* dg[2];
+  for (int half = 0; half < 2; ++half) {
+    const ModCtx& m3 = half ? mq3 : mp3;
+    const TriplePlan& t = half ? tq : tp;
+    reduce_mod(ctx, m3, A, W3, g + 5 * S, nb);
+    triple_enter(ctx, m3, g + 5 * S, t, 0);
+    reduce_mod(ctx, m3, B, W3, g + 5 * S, nb);
+    triple_enter(ctx, m3, g + 5 * S, t, 1);
+    // the two exponents of a number one after the other in the rows of `digits`: windows 0 .. 4 we - 1 and 4 we .. 8 we - 1
+    uint32_t* d2 = ctx->ws_t<uint32_t>((size_t)2 * we * nb);
+    HIPCHK(hipMemcpyAsync(d2, ea[half], (size_t)we * nb * 4, hipMemcpyDeviceToDevice, ctx->stream));
+    HIPCHK(hipMemcpyAsync(d2 + (size_t)we * nb, eb[half], (size_t)we * nb * 4, hipMemcpyDeviceToDevice, ctx->stream));
+    dg[half] = d2;
+    std::vector<PerNumberBase> pn;
+    pn.push_back(PerNumberBase{we, 0, TABA, 0});
+    pn.push_back(PerNumberBase{we, 1, TABB, (uint32_t)perlane_windows(we, win)});
+    emit_modexp_multi(pr[half], pn, win, {}, 2, 3, 0);
+    pr[half].end();
+  }
+  SegSpec sp{&mp3, &pr[0], tp.mem, dg[0]}, sq{&mq3, &pr[1], tq.mem, dg[1]};
+  sp.pair = mp3.triple.kconsts; sp.pair_n0inv = sk->mp.n0inv; sp.pair_h = tp.H; sp.pair_lanes = 3; sp.tconsts = mp3.triple.tconsts;
+  sq.pair = mq3.triple.kconsts; sq.pair_n0inv = sk->mq.n0inv; sq.pair_h = tq.H; sq.pair_lanes = 3; sq.tconsts = mq3.triple.tconsts;
+  run_vm(ctx, nb, sp, &sq, true);
+  triple_exit(ctx, mp3, tp, 3, g + 0 * S, nullptr);
+  triple_exit(ctx, mq3, tq, 3, g + 1 * S, nullptr);
+  Prog c;
+  c.op(VM_LOAD, 0); c.op(VM_MULC, (uint32_t)sk->c_p3invR); c.op(VM_STORE, 3);
+  c.op(VM_LOAD, 1); c.op(VM_MULC, (uint32_t)sk->c_p3invR); c.op(VM_STORE, 2);
+  c.end();
+  SegSpec sc{&mq3, &c, g, nullptr};
+  run_vm(ctx, nb, sc, nullptr, false);
+  launch_canon(g + 2 * S, mq3.d_nmod, W, nb, ctx->stream);
+  launch_canon(g + 3 * S, mq3.d_nmod, W, nb, ctx->stream);
+  launch_sub_mod(g + 2 * S, g + 3 * S, mq3.d_nmod, g + 4 * S, W, nb, ctx->stream);                  // h = (x_q - x_p) / p^3 mod q^3
+  launch_mul_const_add(g + 4 * S, W, sk->p3_limbs.d, W, g, W, 0, out, W3, nb, ctx->stream);          // x_p + p^3 h
+  return true;
 }
 
 // [w][nb] arrays a, b  ->  one [w][2 nb] array (a's numbers first): two independent batches share one launch
@@ -4193,9 +4255,51 @@ int pgpu_ddleq_prove(const pgpu_seckey* sk, size_t batch, const uint8_t* ct1, co
         uint32_t* ani = batch_inverse(ctx, mn2, an1, nbg, cnt);
         modmul_arrays(ctx, mn2, gxn, ani, nbg, en);
       }
+      uint32_t* c5 = nullptr;
+      if (crt3 && ctx->use_lift && sk->eo_p.ok && sk->eo_q.ok && sk->eo_p.w == sk->eo_q.w && W2 <= 2 * sk->eo_p.modd.WT &&
+          W2 <= 2 * sk->eo_q.modd.WT) {
+        // c = ((s^an b)^en)^-1 s^xn = s^(xn - an en) b^(-en)  (ddleq.go:107-112) whenever s and b are units: ONE interleaved
+        // ladder with two per-number exponents, computed modulo the group orders of p^3 and q^3 (ord = 2^t m: the odd part
+        // through a Montgomery product modulo m, the 2-part from the lowest limbs, then the CRT lift), instead of the ladders
+        // s^an | s^xn, (.)^en and a batch inversion modulo n^3.  A non-unit s or b (the reference's ModInverse is then
+        // undefined) keeps the literal sequence below and its error.
+        uint32_t* sb = ctx->ws_t<uint32_t>((size_t)W1 * nbg);
+        modmul_arrays(ctx, mn, sres, gb, nbg, sb);
+        launch_restride(sb, nbg, cnt, mn.d_consts + (size_t)C_ONE * W1, sb, nbg, W1, ctx->stream);
+        if (all_units(ctx, mn, sb, nbg, cnt)) {
+          const uint32_t *es[2], *eb[2];
+          uint32_t* ls = ctx->ws_t<uint32_t>(nbg);
+          uint32_t* lb = ctx->ws_t<uint32_t>(nbg);
+          launch_exp_low_combine(gxn, gan, en, ls, lb, nbg, ctx->stream);
+          for (int half = 0; half < 2; ++half) {
+            const ExpOrder& eo_ = half ? sk->eo_q : sk->eo_p;
+            const ModCtx& mm = eo_.modd;
+            const size_t sm = (size_t)mm.WT * nbg;
+            uint32_t *am = ctx->ws_t<uint32_t>(sm), *em_ = ctx->ws_t<uint32_t>(sm), *xm = ctx->ws_t<uint32_t>(sm),
+                     *pm = ctx->ws_t<uint32_t>(sm), *esm = ctx->ws_t<uint32_t>(sm), *ebm = ctx->ws_t<uint32_t>(sm),
+                     *zero = ctx->ws_t<uint32_t>(sm);
+            HIPCHK(hipMemsetAsync(zero, 0, sm * 4, ctx->stream));
+            reduce_mod(ctx, mm, gan, W2, am, nbg);
+            reduce_mod(ctx, mm, en, W2, em_, nbg);
+            reduce_mod(ctx, mm, gxn, W2, xm, nbg);
+            modmul_arrays(ctx, mm, am, em_, nbg, pm);                                       // an en mod m
+            launch_sub_mod(xm, pm, mm.d_nmod, esm, mm.WT, nbg, ctx->stream);                 // xn - an en mod m
+            launch_sub_mod(zero, em_, mm.d_nmod, ebm, mm.WT, nbg, ctx->stream);              // -en mod m
+            uint32_t* e1 = ctx->ws_t<uint32_t>((size_t)eo_.w * nbg);
+            uint32_t* e2 = ctx->ws_t<uint32_t>((size_t)eo_.w * nbg);
+            launch_exp_order_lift(ls, 1, esm, mm.WT, eo_.m_limbs.d, eo_.t, eo_.minv, e1, eo_.w, nbg, ctx->stream);
+            launch_exp_order_lift(lb, 1, ebm, mm.WT, eo_.m_limbs.d, eo_.t, eo_.minv, e2, eo_.w, nbg, ctx->stream);
+            es[half] = e1;
+            eb[half] = e2;
+          }
+          uint32_t* b3n = zext(ctx, gb, W1, W3, nbg);
+          uint32_t* o = ctx->ws_t<uint32_t>((size_t)W3 * nbg);
+          if (pow_n3_crt_two(sk, s3, es, b3n, eb, nbg, o)) c5 = o;
+        }
+      }
       uint32_t* cc = ctx->ws_t<uint32_t>((size_t)W3 * nbg);
       uint32_t* sx = ctx->ws_t<uint32_t>((size_t)W3 * nbg);
-      {
+      if (!c5) {
         // s^(a^n) and s^(x^n) (ddleq.go:107,112): same base, independent exponents -> one launch
         uint32_t* ss2 = concat2(ctx, s3, s3, W3, nbg);
         uint32_t* ee2 = concat2(ctx, gan, gxn, W2, nbg);
@@ -4204,14 +4308,16 @@ int pgpu_ddleq_prove(const pgpu_seckey* sk, size_t batch, const uint8_t* ct1, co
         split2(ctx, o2, 0, W3, nbg, cc);
         split2(ctx, o2, 1, W3, nbg, sx);
       }
-      uint32_t* b3 = zext(ctx, gb, W1, W3, nbg);
-      uint32_t* cb = ctx->ws_t<uint32_t>((size_t)W3 * nbg);
-      modmul_arrays(ctx, mn3, cc, b3, nbg, cb);
-      perlane3(cb, en, W2, nbg, cc);
-      launch_restride(cc, nbg, cnt, mn3.d_consts + (size_t)C_ONE * W3, cc, nbg, W3, ctx->stream);
-      uint32_t* ci = batch_inverse(ctx, mn3, cc, nbg, cnt);
-      uint32_t* c5 = ctx->ws_t<uint32_t>((size_t)W3 * nbg);
-      modmul_arrays(ctx, mn3, ci, sx, nbg, c5);
+      if (!c5) {
+        uint32_t* b3 = zext(ctx, gb, W1, W3, nbg);
+        uint32_t* cb = ctx->ws_t<uint32_t>((size_t)W3 * nbg);
+        modmul_arrays(ctx, mn3, cc, b3, nbg, cb);
+        perlane3(cb, en, W2, nbg, cc);
+        launch_restride(cc, nbg, cnt, mn3.d_consts + (size_t)C_ONE * W3, cc, nbg, W3, ctx->stream);
+        uint32_t* ci = batch_inverse(ctx, mn3, cc, nbg, cnt);
+        c5 = ctx->ws_t<uint32_t>((size_t)W3 * nbg);
+        modmul_arrays(ctx, mn3, ci, sx, nbg, c5);
+      }
       uint32_t* y3 = zext(ctx, gy, W1, W3, nbg);
       uint32_t* gf = ctx->ws_t<uint32_t>((size_t)W3 * nbg);
       modmul_arrays(ctx, mn3, y3, c5, nbg, gf);

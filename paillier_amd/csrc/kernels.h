@@ -85,5 +85,7 @@ void launch_gather_rows(const uint32_t* table, int w, const int32_t* idx, size_t
 void launch_repack_windows5(const uint32_t* in, int we, uint32_t* out, int we5, size_t nb, hipStream_t st);
 // out (wo limbs) = e mod 2^t m given em = e mod m (m odd, wo limbs, zero padded; minv = m^-1 mod 2^t); + the order when the
 // result fell below 3 although e did not (keeps x^e = 0 for non-unit x)
+// ls = x - a e, lb = -e modulo 2^28 from the lowest limbs (exponent arithmetic modulo the 2-part of a group order)
+void launch_exp_low_combine(const uint32_t* x, const uint32_t* a, const uint32_t* e, uint32_t* ls, uint32_t* lb, size_t nb, hipStream_t st);
 void launch_exp_order_lift(const uint32_t* e, int we, const uint32_t* em, int wm, const uint32_t* m, int t, uint32_t minv,
                            uint32_t* out, int wo, size_t nb, hipStream_t st);

@@ -1045,6 +1045,18 @@ __global__ void k_exp_order_lift(const uint32_t* __restrict__ e, int we, const u
     }
   }
 }
+// Low limbs of two exponent expressions (all that the CRT lift over the 2-part of a group order looks at):
+//   ls = x - a * e,   lb = -e      modulo 2^28, from the lowest limbs of x, a, e (limb-major arrays: limb 0 of number g at [g])
+__global__ void k_exp_low_combine(const uint32_t* __restrict__ x, const uint32_t* __restrict__ a, const uint32_t* __restrict__ e,
+                                  uint32_t* __restrict__ ls, uint32_t* __restrict__ lb, size_t nb) {
+  size_t g = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (g >= nb) return;
+  ls[g] = (x[g] - a[g] * e[g]) & LMASK;
+  lb[g] = (0u - e[g]) & LMASK;
+}
+void launch_exp_low_combine(const uint32_t* x, const uint32_t* a, const uint32_t* e, uint32_t* ls, uint32_t* lb, size_t nb, hipStream_t st) {
+  hipLaunchKernelGGL(k_exp_low_combine, HELPER_GRID(nb), 0, st, x, a, e, ls, lb, nb);
+}
 void launch_exp_order_lift(const uint32_t* e, int we, const uint32_t* em, int wm, const uint32_t* m, int t, uint32_t minv,
                            uint32_t* out, int wo, size_t nb, hipStream_t st) {
   hipLaunchKernelGGL(k_exp_order_lift, HELPER_GRID(nb), 0, st, e, we, em, wm, m, t, minv, out, wo, nb);
