@@ -136,3 +136,41 @@ def test_wide_strides_are_reduced_not_truncated(ctx):
     out = np.zeros((5, cb), dtype=np.uint8)
     pk.encrypt_with_r_raw(5, mb, 200, rb, 180, out, cb)
     assert be_to_ints(out) == [po.encrypt_with_r(sk_o, m, r).C for m, r in zip(ms, rs)]
+
+
+def test_ddleq_prover_with_a_non_unit_b(ctx):
+    """The prover's response for challenge bit 1 inverts (s^an b)^en modulo n^3 (ddleq.go:107-110).  The engine computes it as
+    s^(xn - an en) b^(-en) -- valid for units only: with b a multiple of p the unit test must send the batch down the literal
+    sequence, whose inversion then fails as before (mpz_invert of a non-unit is undefined in the reference); instances with
+    challenge bit 0 never touch that code and must still come out right."""
+    import json
+    import os
+    import paillier_amd as pa
+    from oracle import paillier_oracle as po
+    G_ = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+    k = json.load(open(os.path.join(G_, "keys.json")))["paillier"]["2048"]
+    p, q = int(k["p"], 16), int(k["q"], 16)
+    n, lam = p * q, (p - 1) * (q - 1)
+    sk_o = po.SecretKey(N=n, G=n + 1, Lambda=lam)
+    pk = pa.PublicKey(ctx, n, n + 1)
+    sk = pa.SecretKey(ctx, pk, lam)
+    rng = random.Random(808)
+    B = 6
+    ct1 = [po.encrypt_with_r_at_level(sk_o, po.encrypt_with_r(sk_o, rng.randrange(n), po.rand_unit(n, rng)).C,
+                                      po.rand_unit(n, rng), po.ENC_LEVEL_TWO).C for _ in range(B)]
+    a_s = [po.rand_unit(n, rng) for _ in range(B)]
+    b_s = [p * rng.randrange(1, q) for _ in range(B)]                   # non-units
+    ct2 = [po.nested_randomize_with_ab(sk_o, po.Ciphertext(c, 1), a, b).C for c, a, b in zip(ct1, a_s, b_s)]
+    xs, ys = [po.rand_unit(n, rng) for _ in range(B)], [po.rand_unit(n, rng) for _ in range(B)]
+    n2, n3 = n * n, n ** 3
+    bits = [po.random_oracle_bit(c1, c2, x, y, pow(c1, pow(x, n, n2), n3) * pow(y, n2, n3) % n3)
+            for c1, c2, x, y in zip(ct1, ct2, xs, ys)]
+    assert any(bits) and not all(bits)
+    zero = [i for i, b in enumerate(bits) if not b]
+    pick = lambda v: [v[i] for i in zero]
+    al, es, fs = sk.ProveDDLEQInstancesBatch(pick(ct1), pick(ct2), pick(a_s), pick(b_s), pick(xs), pick(ys))
+    assert (es, fs) == (pick(xs), pick(ys))
+    assert pk.VerifyDDLEQInstancesBatch(pick(ct1), pick(ct2), pick(xs), pick(ys), al, es, fs) == [True] * len(zero)
+    with pytest.raises(pa.PaillierHipError) as ei:
+        sk.ProveDDLEQInstancesBatch(ct1, ct2, a_s, b_s, xs, ys)
+    assert ei.value.code == -5            # PGPU_ERR_NOT_INVERTIBLE
