@@ -4225,18 +4225,11 @@ int pgpu_ddleq_prove(const pgpu_seckey* sk, size_t batch, const uint8_t* ct1, co
       // s = ExtractRandonness(ct1) at level two (operations.go:75-91)
       BigU ns_inv;
       if (!hostbig::modinv(N2 % sk->lambda, sk->lambda, ns_inv)) api_throw(PGPU_ERR_NOT_INVERTIBLE, "n^2 is not invertible mod lambda");
-      const bool crt2 = sk->has_crt2 && 2 * sk->mp3.WT >= W3;
-      const int WC3 = crt2 ? 2 * sk->mp3.WT : W3;
-      uint32_t* v = decrypt2_units_or_generic(sk, crt2 ? zext(ctx, gc1, W3, WC3, nbg) : gc1, WC3, nbg, cnt, crt2,
-                                              nullptr);                        // Decrypt(ct1): W2 limbs
-      uint32_t* gv = ctx->ws_t<uint32_t>((size_t)W3 * nbg);
-      gm2_from_reduced(ctx, pk, v, nbg, gv);                                   // G^v mod n^3
-      launch_restride(gv, nbg, cnt, mn3.d_consts + (size_t)C_ONE * W3, gv, nbg, W3, ctx->stream);
-      uint32_t* gvi = batch_inverse(ctx, mn3, gv, nbg, cnt);
-      uint32_t* z = ctx->ws_t<uint32_t>((size_t)W3 * nbg);
-      modmul_arrays(ctx, mn3, gvi, gc1, nbg, z);
+      // z = G^(-v) ct1 mod n^3 with v = Decrypt(ct1) (operations.go:81-86) is only ever used modulo n (:88), and
+      // G^v = (1 + n)^v = 1 (mod n) whatever v is (the prover requires G = n + 1): z = ct1 (mod n).  No decryption, no G^v,
+      // no inversion modulo n^3 -- the same s.
       uint32_t* z2 = ctx->ws_t<uint32_t>((size_t)W2 * nbg);
-      reduce_mod(ctx, mn2, z, W3, z2, nbg);
+      reduce_mod(ctx, mn2, gc1, W3, z2, nbg);
       uint32_t* sres = ctx->ws_t<uint32_t>((size_t)W1 * nbg);
       if (sk->has_crt && sk->mp.WT * 2 == W1) {                                // z^nsInv mod n through p and q
         uint32_t* z1 = ctx->ws_t<uint32_t>((size_t)W1 * nbg);

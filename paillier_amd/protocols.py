@@ -69,6 +69,11 @@ def extract_randomness_batch(sk: SecretKey, cts: Sequence[int], level: int = ENC
     n = pk.N
     ns, ns1, mod1 = (n, mods.n2, mods.m2) if level == ENC_LEVEL_ONE else (mods.n2, mods.n3, mods.m3)
     ns_inv = pow(ns, -1, sk.Lambda)                       # ModInverse(ns, Lambda): one scalar per key
+    if pk.G == n + 1:
+        # z = G^(-v) c is only used modulo n (:88), and (1 + n)^v = 1 (mod n) whatever v = Decrypt(c) is: z = c (mod n).
+        # The same r without the decryption, G^v and the inversion (what the DDLEQ prover on the device does as well).
+        z = [int(c) % n for c in cts]
+        return mods.m1.exp_batch(z, ns_inv)
     v = sk.DecryptBatch(cts, level=level)
     gv = mod1.exp_batch([pk.G] * len(cts), v)             # G^v mod n^(s+1), per-ciphertext exponent
     gv_inv = mod1.inv_batch(gv)
