@@ -4217,8 +4217,15 @@ int pgpu_ddleq_prove(const pgpu_seckey* sk, size_t batch, const uint8_t* ct1, co
       // padding lanes of the compacted batch must be invertible: fill a with 1 there
       launch_restride(ga, nbg, cnt, mn.d_consts + (size_t)C_ONE * W1, ga, nbg, W1, ctx->stream);
       // e = x * a^-1 mod n^2 (ddleq.go:94-99)
+      // a^-1 and (a^n)^-1 modulo n^2 (the second one for en below) from ONE inversion tree: both batches side by side
       uint32_t* a2 = zext(ctx, ga, W1, W2, nbg);
-      uint32_t* ainv = batch_inverse(ctx, mn2, a2, nbg, cnt);
+      uint32_t* an1 = ctx->ws_t<uint32_t>((size_t)W2 * nbg);
+      launch_restride(gan, nbg, cnt, mn2.d_consts + (size_t)C_ONE * W2, an1, nbg, W2, ctx->stream);   // padding lanes: 1
+      uint32_t* inv2 = batch_inverse(ctx, mn2, concat2(ctx, a2, an1, W2, nbg), 2 * nbg, 2 * nbg);
+      uint32_t* ainv = ctx->ws_t<uint32_t>((size_t)W2 * nbg);
+      uint32_t* ani = ctx->ws_t<uint32_t>((size_t)W2 * nbg);
+      split2(ctx, inv2, 0, W2, nbg, ainv);
+      split2(ctx, inv2, 1, W2, nbg, ani);
       uint32_t* x2 = zext(ctx, gx, W1, W2, nbg);
       uint32_t* ge = ctx->ws_t<uint32_t>((size_t)W2 * nbg);
       modmul_arrays(ctx, mn2, x2, ainv, nbg, ge);
@@ -4242,12 +4249,7 @@ int pgpu_ddleq_prove(const pgpu_seckey* sk, size_t batch, const uint8_t* ct1, co
       // c = ((s^an * b)^en)^-1 * s^xn ; f = y * c mod n^3   (ddleq.go:103-114)
       // en = e^n mod n^2 (ddleq.go:104) = (x a^-1)^n = x^n (a^n)^-1: both powers are at hand, so an inversion replaces the ladder
       uint32_t* en = ctx->ws_t<uint32_t>((size_t)W2 * nbg);
-      {
-        uint32_t* an1 = ctx->ws_t<uint32_t>((size_t)W2 * nbg);
-        launch_restride(gan, nbg, cnt, mn2.d_consts + (size_t)C_ONE * W2, an1, nbg, W2, ctx->stream);   // padding lanes: 1
-        uint32_t* ani = batch_inverse(ctx, mn2, an1, nbg, cnt);
-        modmul_arrays(ctx, mn2, gxn, ani, nbg, en);
-      }
+      modmul_arrays(ctx, mn2, gxn, ani, nbg, en);
       uint32_t* c5 = nullptr;
       if (crt3 && ctx->use_lift && sk->eo_p.ok && sk->eo_q.ok && sk->eo_p.w == sk->eo_q.w && W2 <= 2 * sk->eo_p.modd.WT &&
           W2 <= 2 * sk->eo_q.modd.WT) {
