@@ -261,6 +261,7 @@ struct DevLimbs {
 // ------------------------------------------------------------------------------------------------
 // VM programs
 // ------------------------------------------------------------------------------------------------
+static bool g_wave_priorities = true;   // pgpu_ctx_set_flag("fair", 0): no priority bits in the programs (A/B measurements)
 struct Prog {
   std::vector<uint32_t> w;
   double montmuls = 0, sqrs = 0;
@@ -291,7 +292,7 @@ struct Prog {
   // longer than 7 % of the one before it or the leader would run out of program while the other is still catching up).
   void end() {
     op(VM_END);
-    if (montmuls < 256) return;
+    if (montmuls < 256 || !g_wave_priorities) return;
     double done = 0;
     for (size_t i = 0; i + 1 < w.size(); i += 2) {
       const uint32_t o = w[i] & 0xFFu;
@@ -1038,6 +1039,7 @@ int pgpu_ctx_set_flag(pgpu_ctx* ctx, const char* name, int value) {
   if (strcmp(name, "triple") == 0) { ctx->use_triple = value != 0; return PGPU_OK; }
   if (strcmp(name, "shared_chain") == 0) { ctx->use_shared_chain = value != 0; return PGPU_OK; }
   if (strcmp(name, "lift") == 0) { ctx->use_lift = value != 0; return PGPU_OK; }
+  if (strcmp(name, "fair") == 0) { g_wave_priorities = value != 0; return PGPU_OK; }   // process-wide
   if (strcmp(name, "lanes_wanted") == 0) { ctx->lanes_wanted = value > 0 ? (size_t)value : 0; return PGPU_OK; }
   if (strcmp(name, "cu_partition") == 0) {
     // value = (parts << 16) | part: confine this context's (own) stream to the part-th of `parts` equal slices of the
