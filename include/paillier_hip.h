@@ -79,6 +79,8 @@ int pgpu_ctx_last_profile(pgpu_ctx* ctx, double* vm_ms, int* vm_launches, double
  * as (r^n mod n^2)^n mod n^3.  All of these change the work done, never a result (the tests switch them off to compare).
  * "lanes_wanted" (default 0 = fill the chip): the lane count below which a batch is re-sliced over more lanes per
  * number; 1 keeps every modulus on its natural kernel shape whatever the batch size (tests).
+ * "fair" (default 1, process-wide): programs carry wave priorities that fall with progress, so that the waves sharing a SIMD
+ * finish together (0: A/B measurements).
  * "cu_partition": (parts << 16) | part confines an own-stream context to one slice of the compute units. */
 int pgpu_ctx_set_flag(pgpu_ctx* ctx, const char* name, int value);
 /* number of VM launches of the last batch call that ran the assembly kernel */
