@@ -721,7 +721,11 @@ void run_vm(pgpu_ctx* ctx, size_t nb, const SegSpec& s0, const SegSpec* s1, bool
       const double H = s0.pair_h;
       mulp = 12.0 * H * H;
       sq = 8.0 * H * H;
-    } else if (pair && s0.pair_lanes >= 2) {   // GenQ / GenQ4: one / two Montgomery passes modulo n in every digit lane
+    } else if (pair && s0.pair_lanes == 4) {   // GenQ4: a squaring is one pass of H rows of 2 * H/2 multiplies in four lanes; a
+      const double H = s0.pair_h;              // product one pass with two multiplier streams (3 * H/2 multiplies a row)
+      mulp = 6.0 * H * H;
+      sq = 4.0 * H * H;
+    } else if (pair && s0.pair_lanes >= 2) {   // GenQ: one / two Montgomery passes modulo n in every digit lane
       const double H = s0.pair_h;
       mulp = 8.0 * H * H;
       sq = 4.0 * H * H;

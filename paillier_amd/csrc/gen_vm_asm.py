@@ -315,6 +315,7 @@ class Gen:
         """regs[j] <- limb j of mem[slot] for this lane (slot base already in s[sbase])"""
         g = self
         e = self.e
+        e("s_waitcnt vmcnt(0)")     # STORE does not wait for its write acknowledgements: whoever reads memory next does
         e(f"v_mov_b32 v{g.v_addr}, v{g.v_goff}")
         for j in range(self.WL):
             e(f"global_load_dword {regs[j]}, v{g.v_addr}, s[{g.s_sbase}:{g.s_sbase + 1}]")
@@ -389,7 +390,9 @@ class Gen:
             e(f"global_store_dword v{g.v_addr}, {Xs[j]}, s[{g.s_sbase}:{g.s_sbase + 1}]")
             if j != self.WL - 1:
                 e(f"v_add_u32 v{g.v_addr}, s3, v{g.v_addr}")
-        e("s_waitcnt vmcnt(0)")
+        # no wait for the write acknowledgements (1 - 2 us with nothing to hide them at one wave per SIMD): store data leave
+        # the registers at issue, every path that reads memory starts with s_waitcnt vmcnt(0) or waits before its dependent
+        # loads (the per-number gathers), and outstanding stores complete after s_endpgm
         self.mask_digit_lanes(False)
         e("s_branch L_next")
 
@@ -2168,9 +2171,15 @@ class GenQ(Gen):
         self.v_p1 = e
         self.v_c = e
         e += 2
+        self.v_caddr = e
+        e += 1
         self.n_vgpr = e
         assert e <= 256, e
-        self.s_cadj, self.s_cadj_n, self.s_coff = 99, 100, 101
+        # constants table in LDS: [H][2 lanes] zero-extended limbs (0 | Cadj_j): the accumulators of a linked pass START there
+        # (limb i of Cadj is the initial value of column i of digit one), as in GenQ3 -- no per-row scalar load / subtract / mask
+        self.lds_c = 0                                   # (in front of the a columns: LDS instruction offsets are 16 bits)
+        self.lds_a = H * 16
+        self.lds_bytes = self.lds_a + (self.WT + 1) * self.NPB * 4
 
     def prologue(self):
         # the K = 2 lane mapping of the base class, with the modulus (H limbs, shared by both lanes) in SGPRs
@@ -2195,6 +2204,7 @@ class GenQ(Gen):
         e(f"v_mul_lo_u32 v{g.v_t4}, v{g.v_t1}, s{g.s_t1}")
         e(f"v_add_lshl_u32 v{g.v_goff}, v{g.v_t4}, v{g.v_t3}, 2")
         e(f"v_lshlrev_b32 v{g.v_aread}, 2, v{g.v_t2}")
+        e(f"v_add_u32 v{g.v_aread}, {self.lds_a}, v{g.v_aread}")
         e(f"v_mul_u32_u24 v{g.v_t4}, {H * NPB * 4}, v{g.v_t1}")
         e(f"v_add_u32 v{g.v_awrite}, v{g.v_t4}, v{g.v_aread}")
         e(f"v_mul_u32_u24 v{g.v_koff}, {H * 4}, v{g.v_t1}")
@@ -2218,45 +2228,64 @@ class GenQ(Gen):
             else:
                 raise RuntimeError("cannot tile the modulus into SGPR loads")
         e("s_waitcnt lgkmcnt(0)")
-        e(f"s_add_u32 s6, s6, {4 * H}")                  # s[6:7] -> Cadj
-        e("s_addc_u32 s7, s7, 0")
+        # constants table: thread t < H writes row t = (0 | Cadj_t), zero-extended to 64 bits
+        e(f"v_lshlrev_b32 v{g.v_caddr}, 3, v{g.v_t1}")   # this lane's column of the table: k * 8
+        e(f"v_cmp_gt_u32 vcc, {H}, v0")
+        e("s_and_saveexec_b64 s[96:97], vcc")
+        e(f"v_lshlrev_b32 v{g.v_t3}, 2, v0")
+        e(f"global_load_dword v{g.v_p1}, v{g.v_t3}, s[6:7] offset:{4 * H}")
+        e(f"v_mov_b32 v{g.v_p1 + 1}, 0")
+        e(f"v_mov_b32 v{g.v_p0}, 0")
+        e(f"v_mov_b32 v{g.v_p0 + 1}, 0")
+        e(f"v_lshlrev_b32 v{g.v_t3}, 2, v{g.v_t3}")      # t * 16
+        e("s_waitcnt vmcnt(0)")
+        e(f"ds_write_b64 v{g.v_t3}, {self.P(g.v_p0)} offset:{self.lds_c}")
+        e(f"ds_write_b64 v{g.v_t3}, {self.P(g.v_p1)} offset:{self.lds_c + 8}")
+        e("s_mov_b64 exec, s[96:97]")
+        e("s_waitcnt lgkmcnt(0)")
+        e("s_barrier")
         for j in range(H):
             e(f"v_mov_b32 {self.X(j)}, 0")
 
-    def row(self, cur, nxt, aoff, link, use_sh, first):
-        """one Montgomery row modulo n in both lanes.  cur/nxt: multiplier registers (this row / prefetch); aoff: byte
-        offset of the multiplier stream inside the a column; link: lane 1 takes Cadj_i - m_i(lane 0) into column 0."""
+    def row(self, cur, nxt, aoff, link, use_sh, first=False, bump=0):
+        """one Montgomery row modulo n in both lanes.  cur/nxt: multiplier registers (this row / prefetch at byte offset aoff of
+        the row pointer); link: lane 1 takes -m_i of lane 0 into column 0 (its Cadj limb has been in the accumulator since the
+        pass began); first: row 0 of a pass (the top accumulator still holds its initial value); bump: advance the row pointer.
+        Column 0 is complete after the FIRST multiply of pass A: the quotient digit and the link hop (a chain of dependent
+        instructions) are spread between the remaining multiplies -- no s_nop, no scalar load, nothing waits."""
         g, e = self, self.e
         H = self.H
-        row = self.NPB * 4
         N = lambda j: f"s{g.s_N + j}"
         m = f"v{g.v_m}"
         e("s_waitcnt lgkmcnt(0)")
         e(f"ds_read_b32 v{nxt}, v{g.v_arow} offset:{aoff}")
-        e(f"v_add_u32 v{g.v_arow}, {row}, v{g.v_arow}")
-        if link:
-            e(f"s_mov_b32 s{g.s_cadj}, s{g.s_cadj_n}")
-            e(f"s_add_u32 s{g.s_coff}, s{g.s_coff}, 4")
-            e(f"s_load_dword s{g.s_cadj_n}, s[6:7], s{g.s_coff}")
+        if bump:
+            e(f"v_add_u32 v{g.v_arow}, {bump}, v{g.v_arow}")
         a = f"v{cur}"
         if use_sh:
             e(f"v_lshlrev_b32 v{cur}, v{g.v_sh}, v{cur}")
-        self.align8()
-        for j in range(H):
-            if j == H - 1:
-                self.mad(self.T(j), a, self.X(j), "0")
-            else:
-                self.mad(self.T(j), a, self.X(j), self.T(j))
-        e(f"v_mul_lo_u32 {m}, {self.Tlo(0)}, s14")
-        e(f"v_and_b32 {m}, {hex(MASK)}, {m}")
+        chain = [f"v_mul_lo_u32 {m}, {self.Tlo(0)}, s14", f"v_and_b32 {m}, {hex(MASK)}, {m}"]
         if link:
-            e("s_nop 1")
-            e(f"v_mov_b32_dpp v{g.v_d}, {m} quad_perm:[0,0,2,2] row_mask:0xf bank_mask:0xf")
-            e(f"v_sub_u32 v{g.v_d}, s{g.s_cadj}, v{g.v_d}")
-            e(f"v_and_b32 v{g.v_d}, v{g.v_d}, v{g.v_l1mask}")
-            e(f"v_lshl_add_u64 {self.T(0)}, {self.T(0)}, 0, {self.P(g.v_d)}")
-            e(f"v_mul_lo_u32 {m}, {self.Tlo(0)}, s14")
-            e(f"v_and_b32 {m}, {hex(MASK)}, {m}")
+            chain += [f"v_mov_b32_dpp v{g.v_d}, {m} quad_perm:[0,0,2,2] row_mask:0xf bank_mask:0xf",
+                      f"v_mad_i64_i32 {self.T(0)}, vcc, v{g.v_d}, v{g.v_l1mask}, {self.T(0)}",      # lane 1: T0 -= m of lane 0
+                      f"v_mul_lo_u32 {m}, {self.Tlo(0)}, s14",
+                      f"v_and_b32 {m}, {hex(MASK)}, {m}"]
+        gap = min(3, (H - 1) // len(chain))
+        assert gap >= 2
+        addend = lambda j: "0" if (j == H - 1 and not first) else self.T(j)
+        self.align8()
+        self.mad(self.T(0), a, self.X(0), addend(0))
+        j = 1
+        for step in chain:
+            for _ in range(gap):
+                self.mad(self.T(j), a, self.X(j), addend(j))
+                j += 1
+            e(step)
+            if step.startswith("v_mov_b32_dpp") or step.startswith("v_and"):
+                self.align8()
+        while j < H:
+            self.mad(self.T(j), a, self.X(j), addend(j))
+            j += 1
         self.align8()
         self.mad(self.P(g.v_y0), m, N(0), self.T(0))
         self.mad(self.T(0), m, N(1), self.T(1))
@@ -2271,27 +2300,27 @@ class GenQ(Gen):
         g, e = self, self.e
         H = self.H
         row = self.NPB * 4
-        for j in range(H - 1):
-            e(f"v_mov_b64 {self.T(j)}, 0")
-        e(f"v_mov_b32 v{g.v_d + 1}, 0")
+        if link:
+            for j in range(H):                                   # accumulators <- (0 | Cadj_j) by lane
+                e(f"ds_read_b64 {self.T(j)}, v{g.v_caddr} offset:{self.lds_c + 16 * j}")
+        else:
+            for j in range(H):
+                e(f"v_mov_b64 {self.T(j)}, 0")
         e(f"v_mov_b32 v{g.v_arow}, v{g.v_aread}")
         e(f"ds_read_b32 v{g.v_ain}, v{g.v_arow} offset:{aoff}")
-        e(f"v_add_u32 v{g.v_arow}, {row}, v{g.v_arow}")
-        if link:
-            e(f"s_mov_b32 s{g.s_coff}, 0")
-            e(f"s_load_dword s{g.s_cadj_n}, s[6:7], 0x0")
+        # row 0 peeled (every accumulator still holds its initial value); an even number of rows must remain for the loop
+        self.row(g.v_ain, g.v_ai, aoff + row, link, use_sh, first=True, bump=(row if H % 2 else 0))
         if H % 2:
-            # odd row count: one peeled row, then the two-row loop with the multiplier registers swapped
-            self.row(g.v_ain, g.v_ai, aoff, link, use_sh, False)
             e("s_mov_b32 s19, 1")
-            ra, rb = g.v_ai, g.v_ain
+            ra, rb, o = g.v_ai, g.v_ain, 0
         else:
-            e("s_mov_b32 s19, 0")
-            ra, rb = g.v_ain, g.v_ai
+            self.row(g.v_ai, g.v_ain, aoff + 2 * row, link, use_sh, bump=2 * row)
+            e("s_mov_b32 s19, 2")
+            ra, rb, o = g.v_ain, g.v_ai, 0
         e(".p2align 6")
         e(f"L_q{tag}:")
-        self.row(ra, rb, aoff, link, use_sh, False)
-        self.row(rb, ra, aoff, link, use_sh, False)
+        self.row(ra, rb, aoff + o + row, link, use_sh)
+        self.row(rb, ra, aoff + o + 2 * row, link, use_sh, bump=2 * row)
         e("s_add_u32 s19, s19, 2")
         e(f"s_cmp_lt_u32 s19, {H}")
         e(f"s_cbranch_scc1 L_q{tag}")
@@ -2376,9 +2405,13 @@ class GenQ4(Gen):
     """The two-lane pair kernel with every digit sliced over two lanes: 4 lanes per number (lanes 0,1 = the two 37-limb
     slices of a0, lanes 2,3 = those of a1 -- the slot layout of the (37,4) shape).  Inside a digit the two slices work as
     in the two-lane shapes of Gen (quotient digit broadcast and boundary column by DPP, modulus slice in VGPRs); between
-    the digits the link of GenQ (lane 2 takes Cadj_i - m_i from lane 0 in row i).  A squaring is 74 rows of 74 multiplies
-    per lane -- half of the (37,4) kernel's 148 rows -- which is what counts when a batch is too small to fill the chip
-    and the ladder's latency is the run time."""
+    the digits the link of GenQ (lane 2 takes -m_i from lane 0 in row i; Cadj enters as the initial value of digit one's
+    accumulators).  A squaring is 74 rows of 74 multiplies per lane -- half of the (37,4) kernel's 148 rows -- which is what
+    counts when a batch is too small to fill the chip and the ladder's latency is the run time.
+    A product is ONE pass too: the lanes of digit one keep a copy of a0 next to their own a1 (37 more registers, taken by
+    DPP) and run two multiplier streams per row -- b0 against a1 and b1 against a0 -- into the same accumulators, so
+    c1 = (a1 b0 + a0 b1 + Cadj - m) R^-1 comes out of one Montgomery reduction; the lanes of digit zero read zeros as
+    their second stream.  74 rows of 111 multiplies instead of two passes of 74 rows of 74."""
 
     def __init__(self, WL=37):
         Gen.__init__(self, WL, 2)
@@ -2397,13 +2430,22 @@ class GenQ4(Gen):
         e = (e + 1) // 2 * 2
         self.v_d = e                    # pair (adjustment, 0)
         e += 2
-        self.vR2 = e                    # pass-1 result of a product (digit a0 b1), 37 limbs
+        self.vR2 = e                    # a product's second multiplicand: the copy of a0 in the lanes of digit one
         e += WL
+        self.v_ai2, self.v_ain2, self.v_arow2, self.v_bump2 = e, e + 1, e + 2, e + 3
+        e += 4
         self.n_vgpr = e
         assert e <= 256, e
         self._xb = self.vX
-        self.s_cadj, self.s_cadj_n, self.s_coff = 99, 100, 101
-        self.lds_bytes = self.lds_a + (self.WTslot + 1) * self.NPB * 4
+        self.v_caddr = self.n_vgpr
+        self.n_vgpr += 1
+        assert self.n_vgpr <= 256, self.n_vgpr
+        # constants table in LDS: [WL][4 lanes] zero-extended limbs (0 | 0 | Cadj_j | Cadj_(WL+j)): the accumulators of a linked
+        # pass START there (limb i of Cadj is the initial value of column i of digit one), as in GenQ3
+        self.lds_c = self.lds_a + (self.WTslot + 1) * self.NPB * 4
+        self.lds_z = self.lds_c + WL * 32       # 1 KB of zeros: the second multiplier stream of the lanes of digit zero
+        self.lds_bytes = self.lds_z + 1024
+        assert self.lds_bytes < 65536
 
     def X(self, j):
         return f"v{self._xb + j}"
@@ -2438,6 +2480,7 @@ class GenQ4(Gen):
         e("s_waitcnt lgkmcnt(0)")
         e("s_lshl_b32 s3, s15, 2")
         e(f"v_and_b32 v{g.v_t1}, 3, v0")                  # k4 = 2 d + s
+        e(f"v_lshlrev_b32 v{g.v_caddr}, 3, v{g.v_t1}")    # this lane's column of the constants table: k4 * 8
         e(f"v_lshrrev_b32 v{g.v_t2}, 2, v0")              # gl
         e(f"s_mul_i32 s{g.s_t0}, s2, {NPB}")
         e(f"v_add_u32 v{g.v_t3}, s{g.s_t0}, v{g.v_t2}")   # g
@@ -2471,48 +2514,83 @@ class GenQ4(Gen):
             e(f"global_load_dword v{g.v_p1}, v{g.v_t3}, s[6:7] offset:{sgi * WL * 4}")
             e("s_waitcnt vmcnt(0)")
             e(f"ds_write_b32 v{g.v_t3}, v{g.v_p1} offset:{sgi * self.WLp * 4}")
+        # constants table: thread t < WL writes row t = (0 | 0 | Cadj_t | Cadj_(WL+t)), zero-extended to 64 bits
+        e(f"global_load_dword v{g.v_p0}, v{g.v_t3}, s[6:7] offset:{4 * self.H}")
+        e(f"global_load_dword v{g.v_p1}, v{g.v_t3}, s[6:7] offset:{4 * self.H + 4 * WL}")
+        e(f"v_mov_b32 v{g.v_p0 + 1}, 0")
+        e(f"v_mov_b32 v{g.v_p1 + 1}, 0")
+        e(f"v_mov_b32 v{g.v_y0}, 0")
+        e(f"v_mov_b32 v{g.v_y0 + 1}, 0")
+        e(f"v_lshlrev_b32 v{g.v_t4}, 3, v{g.v_t3}")        # t * 32
+        e("s_waitcnt vmcnt(0)")
+        e(f"ds_write_b64 v{g.v_t4}, {self.P(g.v_y0)} offset:{self.lds_c}")
+        e(f"ds_write_b64 v{g.v_t4}, {self.P(g.v_y0)} offset:{self.lds_c + 8}")
+        e(f"ds_write_b64 v{g.v_t4}, {self.P(g.v_p0)} offset:{self.lds_c + 16}")
+        e(f"ds_write_b64 v{g.v_t4}, {self.P(g.v_p1)} offset:{self.lds_c + 24}")
         e("s_waitcnt lgkmcnt(0)")
         e("s_mov_b64 exec, s[96:97]")
+        e(f"v_mov_b32 v{g.v_p0}, 0")
+        e(f"ds_write_b32 v{g.v_t3}, v{g.v_p0} offset:{self.lds_z}")      # every thread zeroes one word of the zero rows
+        e("s_waitcnt lgkmcnt(0)")
         e("s_barrier")
         for j in range(WL):
             e(f"ds_read_b32 v{g.v_N + j}, v{g.v_nbase} offset:{4 * j}")
         e("s_waitcnt lgkmcnt(0)")
-        e(f"s_add_u32 s6, s6, {4 * self.H}")              # s[6:7] -> Cadj
-        e("s_addc_u32 s7, s7, 0")
         for j in range(WL):
             e(f"v_mov_b32 {self.X(j)}, 0")
 
-    def row(self, cur, nxt, aoff, link, use_sh):
+    def row(self, cur, nxt, aoff, link, bump, cur2=None, nxt2=None):
+        """one Montgomery row modulo n in the four lanes of a number.  cur / nxt: multiplier registers (this row / prefetch at
+        byte offset aoff of the row pointer); link: lane 2 takes -m_i of lane 0 into column 0 (its Cadj limb has been in the
+        accumulator since the pass began); bump: advance the row pointers by two rows afterwards; cur2 / nxt2: the second
+        multiplier stream of a product (against the multiplicand copy vR2).
+        Column 0 is complete after the FIRST multiplies of pass A, so the quotient digit, the link hop and the broadcast to the
+        digit's upper slice -- a chain of dependent instructions -- start right away and are spread between the remaining
+        multiplies of pass A: no s_nop for the DPP hazard, nothing waits on a result in flight (what counts at one wave per
+        SIMD, where every instruction of the wave, scalar or not, takes an issue slot)."""
         g, e = self, self.e
         WL = self.WL
-        row = self.NPB * 4
         N = lambda j: f"v{g.v_N + j}"
         m = f"v{g.v_m}"
         e("s_waitcnt lgkmcnt(0)")
         e(f"ds_read_b32 v{nxt}, v{g.v_arow} offset:{aoff}")
-        e(f"v_add_u32 v{g.v_arow}, {row}, v{g.v_arow}")
-        if link:
-            e(f"s_mov_b32 s{g.s_cadj}, s{g.s_cadj_n}")
-            e(f"s_add_u32 s{g.s_coff}, s{g.s_coff}, 4")
-            e(f"s_load_dword s{g.s_cadj_n}, s[6:7], s{g.s_coff}")
-        if use_sh:
-            e(f"v_lshlrev_b32 v{cur}, v{g.v_sh}, v{cur}")
+        if cur2 is not None:
+            e(f"ds_read_b32 v{nxt2}, v{g.v_arow2} offset:{aoff}")
+        if bump:
+            e(f"v_add_u32 v{g.v_arow}, {bump}, v{g.v_arow}")
+            if cur2 is not None:
+                e(f"v_add_u32 v{g.v_arow2}, v{g.v_bump2}, v{g.v_arow2}")
         a = f"v{cur}"
-        self.align8()
-        for j in range(WL):
-            self.mad(self.T(j), a, self.X(j), self.T(j))
-        e(f"v_mul_lo_u32 {m}, {self.Tlo(0)}, s14")
-        e(f"v_and_b32 {m}, {hex(MASK)}, {m}")
-        e("s_nop 1")
+        chain = [f"v_mul_lo_u32 {m}, {self.Tlo(0)}, s14", f"v_and_b32 {m}, {hex(MASK)}, {m}"]
         if link:
-            e(f"v_mov_b32_dpp v{g.v_d}, {m} quad_perm:[0,1,0,3] row_mask:0xf bank_mask:0xf")
-            e(f"v_sub_u32 v{g.v_d}, s{g.s_cadj}, v{g.v_d}")
-            e(f"v_and_b32 v{g.v_d}, v{g.v_d}, v{g.v_l2mask}")
-            e(f"v_lshl_add_u64 {self.T(0)}, {self.T(0)}, 0, {self.P(g.v_d)}")
-            e(f"v_mul_lo_u32 {m}, {self.Tlo(0)}, s14")
-            e(f"v_and_b32 {m}, {hex(MASK)}, {m}")
-            e("s_nop 1")
-        e(f"v_mov_b32_dpp {m}, {m} quad_perm:[0,0,2,2] row_mask:0xf bank_mask:0xf")
+            chain += [f"v_mov_b32_dpp v{g.v_d}, {m} quad_perm:[0,1,0,3] row_mask:0xf bank_mask:0xf",
+                      f"v_mad_i64_i32 {self.T(0)}, vcc, v{g.v_d}, v{g.v_l2mask}, {self.T(0)}",      # lane 2: T0 -= m of lane 0
+                      f"v_mul_lo_u32 {m}, {self.Tlo(0)}, s14",
+                      f"v_and_b32 {m}, {hex(MASK)}, {m}"]
+        chain.append(f"v_mov_b32_dpp {m}, {m} quad_perm:[0,0,2,2] row_mask:0xf bank_mask:0xf")
+        muls = []
+        for j in range(WL):
+            muls.append((self.T(j), a, self.X(j)))
+            if cur2 is not None:
+                muls.append((self.T(j), f"v{cur2}", f"v{g.vR2 + j}"))
+        head = 1 if cur2 is None else 2                  # multiplies that complete column 0
+        gap = min(3, (len(muls) - head) // len(chain))
+        assert gap >= 2
+        self.align8()
+        k = 0
+        for _ in range(head):
+            self.mad(muls[k][0], muls[k][1], muls[k][2], muls[k][0])
+            k += 1
+        for step in chain:
+            for _ in range(gap):
+                self.mad(muls[k][0], muls[k][1], muls[k][2], muls[k][0])
+                k += 1
+            e(step)
+            if step.startswith("v_mov_b32_dpp") or step.startswith("v_and"):
+                self.align8()
+        while k < len(muls):
+            self.mad(muls[k][0], muls[k][1], muls[k][2], muls[k][0])
+            k += 1
         self.align8()
         self.mad(self.P(g.v_y0), m, N(0), self.T(0))
         self.mad(self.T(0), m, N(1), self.T(1))
@@ -2528,24 +2606,34 @@ class GenQ4(Gen):
         e(f"v_and_b32 {self.Tlo(WL - 1)}, {self.Tlo(WL - 1)}, v{g.v_notlast}")
         e(f"v_and_b32 {self.Thi(WL - 1)}, {self.Thi(WL - 1)}, v{g.v_notlast}")
 
-    def passes(self, tag, aoff, link, use_sh):
+    def passes(self, tag, two_streams):
+        """H linked rows: T <- (b0 stream) * X [+ (b1 stream | zeros) * vR2] * R^-1, accumulators starting at the constants"""
         g, e = self, self.e
         WL, H = self.WL, self.H
         row = self.NPB * 4
-        for j in range(WL):
-            e(f"v_mov_b64 {self.T(j)}, 0")
-        e(f"v_mov_b32 v{g.v_d + 1}, 0")
+        for j in range(WL):                                      # accumulators <- (0 | 0 | Cadj_j | Cadj_(WL+j)) by lane
+            e(f"ds_read_b64 {self.T(j)}, v{g.v_caddr} offset:{self.lds_c + 32 * j}")
         e(f"v_mov_b32 v{g.v_arow}, v{g.v_aread}")
-        e(f"ds_read_b32 v{g.v_ain}, v{g.v_arow} offset:{aoff}")
-        e(f"v_add_u32 v{g.v_arow}, {row}, v{g.v_arow}")
-        if link:
-            e(f"s_mov_b32 s{g.s_coff}, 0")
-            e(f"s_load_dword s{g.s_cadj_n}, s[6:7], 0x0")
+        e(f"ds_read_b32 v{g.v_ain}, v{g.v_arow}")
+        if two_streams:
+            # stream two: rows H.. of the a column (b1) in the lanes of digit one, the zero rows in the lanes of digit zero
+            e(f"v_add_u32 v{g.v_arow2}, {H * row}, v{g.v_aread}")
+            e(f"v_mov_b32 v{g.v_t2}, {self.lds_z}")
+            e(f"v_xor_b32 v{g.v_t2}, v{g.v_t2}, v{g.v_arow2}")
+            e(f"v_or_b32 v{g.v_t3}, v{g.v_l2mask}, v{g.v_l3mask}")
+            e(f"v_and_b32 v{g.v_t2}, v{g.v_t2}, v{g.v_t3}")
+            e(f"v_xor_b32 v{g.v_arow2}, {self.lds_z}, v{g.v_t2}")      # digit one: aread + H rows; digit zero: lds_z
+            e(f"v_and_b32 v{g.v_bump2}, {2 * row}, v{g.v_t3}")
+            e(f"ds_read_b32 v{g.v_ain2}, v{g.v_arow2}")
         e("s_mov_b32 s19, 0")
         e(".p2align 6")
         e(f"L_q{tag}:")
-        self.row(g.v_ain, g.v_ai, aoff, link, use_sh)
-        self.row(g.v_ai, g.v_ain, aoff, link, use_sh)
+        if two_streams:
+            self.row(g.v_ain, g.v_ai, row, True, 0, g.v_ain2, g.v_ai2)
+            self.row(g.v_ai, g.v_ain, 2 * row, True, 2 * row, g.v_ai2, g.v_ain2)
+        else:
+            self.row(g.v_ain, g.v_ai, row, True, 0)
+            self.row(g.v_ai, g.v_ain, 2 * row, True, 2 * row)
         e("s_add_u32 s19, s19, 2")
         e(f"s_cmp_lt_u32 s19, {H}")
         e(f"s_cbranch_scc1 L_q{tag}")
@@ -2554,69 +2642,23 @@ class GenQ4(Gen):
     def montsq(self):
         g, e = self, self.e
         e("L_montsq:")
-        self.passes("s", 0, True, True)
+        # digit one computes 2 a0 a1: its lanes double their MULTIPLICAND once (a 29-bit limb times a 28-bit multiplier over
+        # 74 rows, plus the reduction, stays below 2^64 per column) instead of the multiplier in every row
+        for j in range(self.WL):
+            e(f"v_lshlrev_b32 {self.X(j)}, v{g.v_sh}, {self.X(j)}")
+        self.passes("s", False)
         self.normalize()
         e("s_branch L_next")
 
     def montmul(self):
         g, e = self, self.e
-        WL, H = self.WL, self.H
-        row = self.NPB * 4
         e("L_montmul:")
-        # pass 1: digit lanes 0,1: r2 = a0 b1 R^-1 (multiplier rows H..2H-1); lanes 2,3 run along, result dropped
-        self.passes("m1", H * row, False, False)
-        self._xb = self.vR2
-        self.normalize()
-        self._xb = self.vX
-        # lanes of digit 0 park r2 in the LDS rows that held b1: row H + 37 s + j
-
-        def park_addr():
-            e(f"v_not_b32 v{g.v_t4}, v{g.v_isfirst}")                   # -1 for slice 1
-            e(f"v_and_b32 v{g.v_t4}, {WL * row}, v{g.v_t4}")
-            e(f"v_add_u32 v{g.v_t4}, v{g.v_t4}, v{g.v_aread}")
-            e(f"v_add_u32 v{g.v_t4}, {H * row}, v{g.v_t4}")
-        park_addr()
-        e("s_mov_b64 s[96:97], exec")
-        e("s_mov_b32 s98, 0x33333333")
-        e("s_mov_b32 exec_lo, s98")
-        e("s_mov_b32 exec_hi, s98")
-        for j in range(WL):
-            e(f"ds_write_b32 v{g.v_t4}, v{g.vR2 + j} offset:{j * row}")
-        e("s_mov_b64 exec, s[96:97]")
-        # pass 2: digit 0: t = a0 b0 R^-1; digit 1: r1 = (a1 b0 + Cadj - m) R^-1
-        self.passes("m2", 0, True, False)
-        self.normalize()
-        park_addr()                     # (normalize() uses the scratch registers)
-        e("s_mov_b32 s98, 0xcccccccc")
-        e("s_mov_b32 exec_lo, s98")
-        e("s_mov_b32 exec_hi, s98")
-        St = [f"v{j}" for j in range(WL)]
-        for j in range(WL):
-            e(f"ds_read_b32 {St[j]}, v{g.v_t4} offset:{j * row}")
-        e("s_waitcnt lgkmcnt(0)")
-        # c1 = r1 + r2 with the limbs brought back below 2^28 + 4 (carry-save: x_j = (s_j & M) + (s_{j-1} >> 28); the carry out of a
-        # slice's top limb enters limb 0 of the next slice by DPP; the digit's top limb keeps its excess) -- see GenQ.montmul
-        M = hex(MASK)
-        for j in range(WL):
-            e(f"v_add_u32 {self.X(j)}, {self.X(j)}, {St[j]}")
-        # carries, from the top down so that every s_{j-1} is still unmodified when it is read
-        e(f"v_lshrrev_b32 v{g.v_t2}, {LB}, {self.X(WL - 1)}")                   # carry out of this slice's top limb
-        e(f"v_and_b32 v{g.v_t2}, v{g.v_t2}, v{g.v_isfirst}")                    # only slice 0 passes it on ...
-        e(f"v_not_b32 v{g.v_t3}, v{g.v_isfirst}")
-        e(f"v_or_b32 v{g.v_t3}, {M}, v{g.v_t3}")                                # ... and only slice 0 masks its top limb
-        for j in range(WL - 1, 0, -1):
-            e(f"v_lshrrev_b32 v{g.v_t1}, {LB}, {self.X(j - 1)}")
-            if j == WL - 1:
-                e(f"v_and_b32 {self.X(j)}, {self.X(j)}, v{g.v_t3}")
-            else:
-                e(f"v_and_b32 {self.X(j)}, {M}, {self.X(j)}")
-            e(f"v_add_u32 {self.X(j)}, {self.X(j)}, v{g.v_t1}")
-        e(f"v_and_b32 {self.X(0)}, {M}, {self.X(0)}")
-        e("s_mov_b64 exec, s[96:97]")
         e("s_nop 1")
-        e(f"v_mov_b32_dpp v{g.v_t1}, v{g.v_t2} quad_perm:[0,0,2,2] row_mask:0xf bank_mask:0xf")   # lane 3 <- lane 2 (and 1 <- 0: zero)
-        e(f"v_and_b32 v{g.v_t1}, v{g.v_t1}, v{g.v_l3mask}")
-        e(f"v_add_u32 {self.X(0)}, {self.X(0)}, v{g.v_t1}")
+        for j in range(self.WL):                                 # lanes 2, 3 <- the slices of a0 (lanes 0, 1 keep a copy of their own)
+            e(f"v_mov_b32_dpp v{g.vR2 + j}, {self.X(j)} quad_perm:[0,1,0,1] row_mask:0xf bank_mask:0xf")
+        # digit zero: t = a0 b0 R^-1 (second stream: zeros); digit one: c1 = (a1 b0 + a0 b1 + Cadj - m) R^-1
+        self.passes("m", True)
+        self.normalize()
         e("s_branch L_next")
 
     def generate(self):

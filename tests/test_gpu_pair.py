@@ -141,8 +141,8 @@ def test_decrypt_does_not_depend_on_the_pair_switch(ctx, one_lane):
 @pytest.mark.parametrize("lanes", [2, 4])
 def test_two_lane_pair_kernel_matches_the_integer_model(ctx, lanes):
     """GenQ (lanes = 2): N = n^2 with a public 74-limb n, digit a0 in lane 0 and a1 in lane 1; GenQ4 (lanes = 4): every
-    digit sliced over two lanes.  A product adds the two partial results r1 + r2 limb-wise (a lazy digit below 4n), so
-    digits are compared as integers."""
+    digit sliced over two lanes.  The two-lane product adds the two partial results r1 + r2 limb-wise (a lazy digit below
+    4n), so digits are compared as integers; the four-lane product reduces a1 b0 + a0 b1 + Cadj - m in one pass."""
     k = json.load(open(os.path.join(G, "keys.json")))["paillier"]["2048"]
     n = int(k["p"], 16) * int(k["q"], 16)
     rng = random.Random(23)
@@ -176,9 +176,11 @@ def test_two_lane_pair_kernel_matches_the_integer_model(ctx, lanes):
         t, m = mont(a[0] * a[0])
         return (t, mont(2 * a[0] * a[1] + cadj - m)[0])
 
-    def pmul(a, b):      # x = a (registers), b = the slot operand: r2 = a0 b1, then t = a0 b0 and r1 = a1 b0 + Cadj - m
-        r2, _ = mont(a[0] * b[1])
+    def pmul(a, b):      # x = a (registers), b = the slot operand
         t, m = mont(a[0] * b[0])
+        if lanes == 4:   # one pass, two multiplier streams in the lanes of digit one: a single reduction of the whole cross term
+            return (t, mont(a[1] * b[0] + a[0] * b[1] + cadj - m)[0])
+        r2, _ = mont(a[0] * b[1])              # two passes: r2 = a0 b1, then t = a0 b0 and r1 = a1 b0 + Cadj - m
         r1, _ = mont(a[1] * b[0] + cadj - m)
         return (t, r1 + r2)
 
