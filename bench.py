@@ -106,6 +106,69 @@ def measure_traffic_pmc(bits: int, batch: int, timeout_s: float = 150.0):
         shutil.rmtree(tmp, ignore_errors=True)
 
 
+def measure_clock_pmc(bits: int, batch: int, timeout_s: float = 150.0):
+    """Sustained clock of the dominant kernel's launches in a child pass of this command under `rocprofv3 --pmc
+    GRBM_GUI_ACTIVE SQ_WAVE_CYCLES SQ_WAVES` (no tracing domain): effective clock = GRBM_GUI_ACTIVE / 8 XCDs / dispatch duration
+    (MI355X_MICROARCH.md "DVFS give-back"; within 3 % of the in-kernel clock on dispatches of 10 ms or more), and how much of the
+    launch its waves were resident: SQ_WAVE_CYCLES / (SQ_WAVES x kernel cycles) -- 0.98 when the co-resident waves of a SIMD
+    finish together, 0.75 when one of them runs alone for the second half.  A slow bench run is thereby
+    attributable: low clock_ghz = the box / power management, low wave_cycles_ratio = scheduling.  Note the profiled pass itself
+    clocks a few per cent below an un-profiled run (same guide).  Returns a dict or None."""
+    import csv
+    import glob
+    import shutil
+    import tempfile
+    if shutil.which("rocprofv3") is None:
+        return None
+    if any("rocprof" in os.environ.get(k, "").lower() for k in ("LD_PRELOAD", "ROCP_TOOL_LIBRARIES", "HSA_TOOLS_LIB")):
+        return None
+    tmp = tempfile.mkdtemp(prefix="bench_clk_", dir="/tmp")
+    try:
+        cmd = ["rocprofv3", "--pmc", "GRBM_GUI_ACTIVE", "SQ_WAVE_CYCLES", "SQ_WAVES", "--output-format", "csv", "-d", tmp, "-o", "p",
+               "--", sys.executable, os.path.abspath(__file__), "--gpus", "1", "--steps", "3", "--warmup", "1", "--bits", str(bits),
+               "--batch", str(batch), "--headline-only"]
+        r = subprocess.run(cmd, cwd="/tmp", env=dict(os.environ, TMPDIR="/tmp"), stdout=subprocess.PIPE, stderr=subprocess.PIPE,
+                           timeout=timeout_s)
+        if r.returncode != 0:
+            return None
+        kern = None
+        for line in r.stdout.decode(errors="ignore").splitlines():
+            if line.startswith("{"):
+                kern = json.loads(line)["roofline"]["kernel_name"]
+        per = {}
+        for f in glob.glob(os.path.join(tmp, "**", "*counter_collection.csv"), recursive=True):
+            for row in csv.DictReader(open(f)):
+                if kern and row["Kernel_Name"].startswith(kern):
+                    d = per.setdefault(row["Dispatch_Id"], {"s": None, "e": None})
+                    d[row["Counter_Name"]] = d.get(row["Counter_Name"], 0.0) + float(row["Counter_Value"])
+                    if "Start_Timestamp" in row and "End_Timestamp" in row:
+                        d["s"], d["e"] = int(row["Start_Timestamp"]), int(row["End_Timestamp"])
+        clocks, ratios = [], []
+        for d in per.values():
+            if d["s"] is None or d["e"] is None or d["e"] - d["s"] < 5e6 or "GRBM_GUI_ACTIVE" not in d:
+                continue                                  # (the quotient reads high on short dispatches: the table build etc.)
+            cyc = d["GRBM_GUI_ACTIVE"] / 8.0
+            clocks.append(cyc / (d["e"] - d["s"]))
+            if d.get("SQ_WAVES") and d.get("SQ_WAVE_CYCLES"):
+                ratios.append(d["SQ_WAVE_CYCLES"] / (d["SQ_WAVES"] * cyc))
+        if not clocks:
+            return None
+        clocks.sort()
+        ratios.sort()
+        return {"clock_ghz": clocks[len(clocks) // 2], "launches": len(clocks),
+                "wave_cycles_ratio_raw": ratios[len(ratios) // 2] if ratios else None,
+                # the SQ counters of this pass cover one shader engine in four (raw 0.245 = 0.98 / 4 on the headline launch)
+                "wave_cycles_ratio": 4.0 * ratios[len(ratios) // 2] if ratios else None,
+                "source": "rocprofv3 --pmc GRBM_GUI_ACTIVE SQ_WAVE_CYCLES SQ_WAVES, one child pass of this command (headline only); "
+                          "GRBM_GUI_ACTIVE / 8 / dispatch duration, median over the dominant kernel's launches; the ratio is "
+                          "SQ_WAVE_CYCLES / (SQ_WAVES x kernel cycles) as the counters come (SQ counters are sampled per shader "
+                          "engine: compare runs with each other, not with 1.0)"}
+    except Exception:  # noqa: BLE001 -- optional
+        return None
+    finally:
+        shutil.rmtree(tmp, ignore_errors=True)
+
+
 def host_cpu_info():
     """CPU model / sockets / cores / threads of the host and what this process may use of it."""
     info = {"model": None, "sockets": None, "physical_cores": None, "logical_cpus": os.cpu_count()}
@@ -169,9 +232,10 @@ def main():
         print(f"[bench] WORLD_SIZE={world} but --gpus {args.gpus}: refusing to report a mislabelled run", file=sys.stderr)
         sys.exit(2)
 
-    traffic, traffic_note = None, "not measured (--no-traffic / N > 1)"
+    traffic, traffic_note, clock = None, "not measured (--no-traffic / N > 1)", None
     if world == 1 and not args.no_traffic:
         traffic, traffic_note = measure_traffic_pmc(args.bits, args.batch)   # child processes; before any GPU call here
+        clock = measure_clock_pmc(args.bits, args.batch)
 
     import numpy as np
     import torch
@@ -265,16 +329,17 @@ def main():
     extras, checks = [], {}
 
     def timed(fn, steps):
+        """(seconds per call -- MAX over ranks, between barriers --, this rank's VM-kernel ms, executed multiply-adds, kernel)"""
         fn()
         fn()    # (a call that grew the library's workspace is followed by one that may consolidate it: both are warm-up)
-        torch.cuda.synchronize()
+        barrier()
         ms, mads, kern = [], 0.0, ""
         t = time.perf_counter()
         for _ in range(steps):
             mads, vms, kern = fn()
             ms.append(vms)
-        torch.cuda.synchronize()
-        return (time.perf_counter() - t) / steps, sum(ms) / len(ms), mads, kern
+        barrier()
+        return pdist.max_over_ranks(time.perf_counter() - t, dev) / steps, sum(ms) / len(ms), mads, kern
 
     def one_call(fn):
         """run one C-ABI call and return (mads, vm_ms, kernel) of it"""
@@ -282,19 +347,28 @@ def main():
         pr_ = ctx.last_profile()
         return pr_["vm_mads"], pr_["vm_ms"], pr_["kernel"]
 
-    def entry(name, workload, unit, count, dt, vms, mads, kern, parity):
-        return {"config": name, "workload": workload, "value": count / dt, "unit": unit, "ms_per_batch": dt * 1e3,
-                "kernel": kern, "kernel_ms_per_batch": vms, "executed_mad28": mads,
-                "frac": (mads / (vms * 1e-3) / PEAK_MAD_PER_S) if vms else None, "parity": parity}
+    def entry(name, workload, unit, count, dt, vms, mads, kern, parity, scaling="weak"):
+        """count = units of the WHOLE job (all ranks) per call; dt = MAX-over-ranks seconds per call; vms / mads = rank 0's
+        kernel time and executed multiply-adds (its `frac` is therefore a per-GPU figure on every N)"""
+        e = {"config": name, "workload": workload, "value": count / dt, "unit": unit, "ms_per_batch": dt * 1e3,
+             "kernel": kern, "kernel_ms_per_batch": vms, "executed_mad28": mads,
+             "frac": (mads / (vms * 1e-3) / PEAK_MAD_PER_S) if vms else None, "parity": parity}
+        if world > 1:
+            e.update({"scaling": scaling, "n_gpus": world})
+        return e
 
-    if not args.no_extra and world == 1:
+    def all_ranks_ok(flag, what):
+        if not pdist.min_over_ranks(1 if flag else 0, dev):
+            raise SystemExit(f"[bench] {what}" + (" (on some rank)" if world > 1 else ""))
+
+    if not args.no_extra:
         ES = args.extra_steps
-        # config 2: Batch 65536 Encrypt, 2048-bit
+        # config 2: Batch 65536 Encrypt, 2048-bit -- per GPU (weak scaling: independent ciphertexts, no exchange)
         p2, q2, n2k, lam2 = paillier_key(2048)
         pk2 = pk if args.bits == 2048 else pa.PublicKey(ctx, n2k, n2k + 1)
         sk2 = sk if args.bits == 2048 else pa.SecretKey(ctx, pk2, lam2)
         BE = 65536
-        rg = np.random.default_rng(2)
+        rg = np.random.default_rng(2 + 1000 * rank)
         em_h, er_h = rand_below(n2k, BE, 256, rg), rand_below(n2k, BE, 256, rg)
         er_h[:, -1] |= 1
         em, er = torch.from_numpy(em_h).to(dev), torch.from_numpy(er_h).to(dev)
@@ -303,36 +377,37 @@ def main():
         dt, vms, mads, kern = timed(lambda: one_call(lambda: pk2.encrypt_with_r_raw(
             BE, em.data_ptr(), 256, er.data_ptr(), 256, ec.data_ptr(), 512, MEM_DEVICE)), ES)
         sk2.decrypt_raw(BE, ec.data_ptr(), 512, eo.data_ptr(), 256, MEM_DEVICE)
-        assert torch.equal(eo, em), "[bench] Encrypt-2048: Decrypt(Encrypt(m, r)) != m"
-        extras.append(entry("encrypt_2048", "Batch 65536 EncryptWithR, 2048-bit n, level 1 (r^n * (1+n)^m mod n^2)",
-                            "encryptions/s", BE, dt, vms, mads, kern, "65536-lane decrypt round trip"))
-        # the same batch with the library drawing r itself (PublicKey.Encrypt, paillier.go:258-269): getrandom(2) on host
-        # threads + rejection below n, gcd test on the device
-        ec2 = torch.zeros((BE, 512), dtype=torch.uint8, device=dev)
-        for _ in range(2):      # warm-up as in timed(): the first calls grow the library's workspace and start its host threads
-            pk2.encrypt_raw(BE, em.data_ptr(), 256, ec2.data_ptr(), 512, None, 0, MEM_DEVICE)
-        torch.cuda.synchronize()
-        t = time.perf_counter()
-        for _ in range(ES):
-            pk2.encrypt_raw(BE, em.data_ptr(), 256, ec2.data_ptr(), 512, None, 0, MEM_DEVICE)
-        torch.cuda.synchronize()
-        dt_rng = (time.perf_counter() - t) / ES
-        sk2.decrypt_raw(BE, ec2.data_ptr(), 512, eo.data_ptr(), 256, MEM_DEVICE)
-        assert torch.equal(eo, em), "[bench] Encrypt (library randomness): Decrypt(Encrypt(m)) != m"
-        extras[-1].update({"encrypt_with_library_randomness_per_s": BE / dt_rng, "fraction_of_with_r": dt / dt_rng})
-        checks["encrypt_2048"] = (n2k, em_h[:64], er_h[:64], ec[:64].cpu().numpy())
-        # the same call on the SECRET key (SecretKey embeds PublicKey in the reference): r^n through p^2 and q^2
-        dt_sk, vms_sk, mads_sk, kern_sk = timed(lambda: one_call(lambda: sk2.encrypt_with_r_raw(
-            BE, em.data_ptr(), 256, er.data_ptr(), 256, ec2.data_ptr(), 512, MEM_DEVICE)), ES)
-        assert torch.equal(ec2, ec), "[bench] key holder's EncryptWithR differs from the public path"
-        extras[-1].update({"key_holder_encryptions_per_s": BE / dt_sk, "key_holder_kernel": kern_sk})
-        del ec2
+        all_ranks_ok(torch.equal(eo, em), "Encrypt-2048: Decrypt(Encrypt(m, r)) != m")
+        extras.append(entry("encrypt_2048", "Batch 65536 EncryptWithR per GPU, 2048-bit n, level 1 (r^n * (1+n)^m mod n^2)",
+                            "encryptions/s", world * BE, dt, vms, mads, kern, "65536-lane decrypt round trip on every rank"))
+        if world == 1:
+            # the same batch with the library drawing r itself (PublicKey.Encrypt, paillier.go:258-269): getrandom(2) on host
+            # threads + rejection below n, gcd test on the device
+            ec2 = torch.zeros((BE, 512), dtype=torch.uint8, device=dev)
+            for _ in range(2):      # warm-up as in timed(): the first calls grow the library's workspace and start its host threads
+                pk2.encrypt_raw(BE, em.data_ptr(), 256, ec2.data_ptr(), 512, None, 0, MEM_DEVICE)
+            torch.cuda.synchronize()
+            t = time.perf_counter()
+            for _ in range(ES):
+                pk2.encrypt_raw(BE, em.data_ptr(), 256, ec2.data_ptr(), 512, None, 0, MEM_DEVICE)
+            torch.cuda.synchronize()
+            dt_rng = (time.perf_counter() - t) / ES
+            sk2.decrypt_raw(BE, ec2.data_ptr(), 512, eo.data_ptr(), 256, MEM_DEVICE)
+            assert torch.equal(eo, em), "[bench] Encrypt (library randomness): Decrypt(Encrypt(m)) != m"
+            extras[-1].update({"encrypt_with_library_randomness_per_s": BE / dt_rng, "fraction_of_with_r": dt / dt_rng})
+            checks["encrypt_2048"] = (n2k, em_h[:64], er_h[:64], ec[:64].cpu().numpy())
+            # the same call on the SECRET key (SecretKey embeds PublicKey in the reference): r^n through p^2 and q^2
+            dt_sk, vms_sk, mads_sk, kern_sk = timed(lambda: one_call(lambda: sk2.encrypt_with_r_raw(
+                BE, em.data_ptr(), 256, er.data_ptr(), 256, ec2.data_ptr(), 512, MEM_DEVICE)), ES)
+            assert torch.equal(ec2, ec), "[bench] key holder's EncryptWithR differs from the public path"
+            extras[-1].update({"key_holder_encryptions_per_s": BE / dt_sk, "key_holder_kernel": kern_sk})
+            del ec2
 
         # the headline kernel with a deeper queue: 131072 ciphertexts = four waves' worth of work per SIMD slot pair, so the
         # hardware dispatcher refills CUs as their first workgroups retire (at 65536 every workgroup is resident from the
         # start and the launch lasts as long as its slowest CU).  Same Decrypt, same key; the ciphertexts are the Encrypt
         # batch above twice.
-        if args.deep_queue:
+        if args.deep_queue and world == 1:
             BB = 2 * BE
             bc = torch.cat([ec, ec]).contiguous()
             bo = torch.zeros((BB, 256), dtype=torch.uint8, device=dev)
@@ -341,12 +416,13 @@ def main():
             extras.append(entry("decrypt_2048_b131072", "Batch 131072 Decrypt, 2048-bit n, level 1, CRT (the headline path, twice the batch)",
                                 "decryptions/s", BB, dt, vms, mads, kern, "131072-lane round trip"))
             del bc, bo
+        del em, er, ec, eo
 
-        # config 3: Batch 65536 Decrypt, 3072-bit
+        # config 3: Batch 65536 Decrypt, 3072-bit -- per GPU (weak scaling)
         p3, q3, n3k, lam3 = paillier_key(3072)
         pk3 = pa.PublicKey(ctx, n3k, n3k + 1)
         sk3 = pa.SecretKey(ctx, pk3, lam3)
-        rg = np.random.default_rng(3)
+        rg = np.random.default_rng(3 + 1000 * rank)
         dm_h, dr_h = rand_below(n3k, BE, 384, rg), rand_below(n3k, BE, 384, rg)
         dr_h[:, -1] |= 1
         dm, dr = torch.from_numpy(dm_h).to(dev), torch.from_numpy(dr_h).to(dev)
@@ -355,15 +431,16 @@ def main():
         pk3.encrypt_with_r_raw(BE, dm.data_ptr(), 384, dr.data_ptr(), 384, dc.data_ptr(), 768, MEM_DEVICE)
         dt, vms, mads, kern = timed(lambda: one_call(lambda: sk3.decrypt_raw(
             BE, dc.data_ptr(), 768, do.data_ptr(), 384, MEM_DEVICE)), ES)
-        assert torch.equal(do, dm), "[bench] Decrypt-3072 round trip failed"
-        extras.append(entry("decrypt_3072", "Batch 65536 Decrypt, 3072-bit n, level 1, CRT over p^2, q^2", "decryptions/s",
-                            BE, dt, vms, mads, kern, "65536-lane round trip"))
-        checks["decrypt_3072"] = (n3k, lam3, dc[:32].cpu().numpy(), do[:32].cpu().numpy())
+        all_ranks_ok(torch.equal(do, dm), "Decrypt-3072 round trip failed")
+        extras.append(entry("decrypt_3072", "Batch 65536 Decrypt per GPU, 3072-bit n, level 1, CRT over p^2, q^2", "decryptions/s",
+                            world * BE, dt, vms, mads, kern, "65536-lane round trip on every rank"))
+        if world == 1:
+            checks["decrypt_3072"] = (n3k, lam3, dc[:32].cpu().numpy(), do[:32].cpu().numpy())
         del pk3, sk3, dm, dr, dc, do
 
-        # level-two (Damgard-Jurik s = 2) EncryptWithR, 16384 ciphertexts: r^(n^2) (1+n)^m mod n^3 on the three-digit kernel
+        # level-two (Damgard-Jurik s = 2) EncryptWithR, 16384 ciphertexts per GPU: r^(n^2) (1+n)^m mod n^3 on the three-digit kernel
         BL = 16384
-        rg = np.random.default_rng(6)
+        rg = np.random.default_rng(6 + 1000 * rank)
         lm_h, lr_h = rand_below(n2k * n2k, BL, 512, rg), rand_below(n2k, BL, 256, rg)
         lr_h[:, -1] |= 1
         lm, lr = torch.from_numpy(lm_h).to(dev), torch.from_numpy(lr_h).to(dev)
@@ -372,33 +449,46 @@ def main():
         dt, vms, mads, kern = timed(lambda: one_call(lambda: pk2.encrypt_with_r_raw(
             BL, lm.data_ptr(), 512, lr.data_ptr(), 256, lc.data_ptr(), 768, MEM_DEVICE, level=1)), ES)
         sk2.decrypt_raw(BL, lc.data_ptr(), 768, lo.data_ptr(), 512, MEM_DEVICE, level=1)
-        assert torch.equal(lo, lm), "[bench] level-two Encrypt: Decrypt(Encrypt(m, r)) != m"
-        extras.append(entry("encrypt_l2_2048", "Batch 16384 level-two EncryptWithR, 2048-bit n (r^(n^2) * (1+n)^m mod n^3)",
-                            "encryptions/s", BL, dt, vms, mads, kern, "16384-lane level-two decrypt round trip"))
+        all_ranks_ok(torch.equal(lo, lm), "level-two Encrypt: Decrypt(Encrypt(m, r)) != m")
+        extras.append(entry("encrypt_l2_2048", "Batch 16384 level-two EncryptWithR per GPU, 2048-bit n (r^(n^2) * (1+n)^m mod n^3)",
+                            "encryptions/s", world * BL, dt, vms, mads, kern, "16384-lane level-two decrypt round trip on every rank"))
         del lm, lr, lc, lo
 
-        # config 5: DDLEQ prove / verify, 2048-bit, 16384 (statement, instance) pairs, secpar = 1 each
-        BD = 16384
-        rg = np.random.default_rng(5)
+        # config 5: DDLEQ prove / verify, 2048-bit, 16384 (statement, instance) pairs IN TOTAL -- strong scaling: the pairs are
+        # split over the ranks (shard_slice), every rank proves and verifies its own slice, no exchange (independent proofs)
+        BD_ALL = 16384
         cb3, pb2 = pk2.cipher_bytes(1), pk2.plain_bytes(1)
-        tb = lambda a: torch.from_numpy(a).to(dev)
-        def unit():
-            a = rand_below(n2k, BD, 256, rg)
-            a[:, -1] |= 1
-            return a
-        dmsg, r1, r2, da_h, db_h, dx_h, dy_h = rand_below(n2k, BD, 256, rg), unit(), unit(), unit(), unit(), unit(), unit()
-        inner = torch.zeros((BD, 512), dtype=torch.uint8, device=dev)
-        ct1 = torch.zeros((BD, cb3), dtype=torch.uint8, device=dev)
-        pk2.encrypt_with_r_raw(BD, tb(dmsg).data_ptr(), 256, tb(r1).data_ptr(), 256, inner.data_ptr(), 512, MEM_DEVICE)
-        pk2.encrypt_with_r_raw(BD, inner.data_ptr(), 512, tb(r2).data_ptr(), 256, ct1.data_ptr(), cb3, MEM_DEVICE, level=1)
-        # ct2 = NestedRandomize(ct1; a, b) = ct1^(a^n mod n^2) * b^(n^2) mod n^3  (operations.go:96-118)
-        da, db, dx, dy = tb(da_h), tb(db_h), tb(dx_h), tb(dy_h)
-        ct2 = torch.zeros((BD, cb3), dtype=torch.uint8, device=dev)
-        dt, vms, mads, kern = timed(lambda: one_call(lambda: pk2.nested_randomize_with_ab_raw(
-            BD, ct1.data_ptr(), da.data_ptr(), db.data_ptr(), ct2.data_ptr(), MEM_DEVICE)), 1)
+        tb = lambda a_: torch.from_numpy(np.ascontiguousarray(a_)).to(dev)
+
+        def ddleq_statements(count, seed):
+            """`count` statements (ct1, ct2 = NestedRandomize(ct1; a, b), a, b) of the WHOLE job from one seed; returns this
+            rank's slice (device tensors) and the NestedRandomize timing of it"""
+            rg_ = np.random.default_rng(seed)
+            def unit(k):
+                a_ = rand_below(n2k, k, 256, rg_)
+                a_[:, -1] |= 1
+                return a_
+            msg, r1, r2, a_h, b_h = rand_below(n2k, count, 256, rg_), unit(count), unit(count), unit(count), unit(count)
+            lo_, hi_ = pdist.shard_slice(count, rank, world)
+            k = hi_ - lo_
+            inner = torch.zeros((k, 512), dtype=torch.uint8, device=dev)
+            c1 = torch.zeros((k, cb3), dtype=torch.uint8, device=dev)
+            pk2.encrypt_with_r_raw(k, tb(msg[lo_:hi_]).data_ptr(), 256, tb(r1[lo_:hi_]).data_ptr(), 256, inner.data_ptr(), 512, MEM_DEVICE)
+            pk2.encrypt_with_r_raw(k, inner.data_ptr(), 512, tb(r2[lo_:hi_]).data_ptr(), 256, c1.data_ptr(), cb3, MEM_DEVICE, level=1)
+            a_d, b_d = tb(a_h[lo_:hi_]), tb(b_h[lo_:hi_])
+            c2 = torch.zeros((k, cb3), dtype=torch.uint8, device=dev)
+            # ct2 = NestedRandomize(ct1; a, b) = ct1^(a^n mod n^2) * b^(n^2) mod n^3  (operations.go:96-118)
+            tm_ = timed(lambda: one_call(lambda: pk2.nested_randomize_with_ab_raw(
+                k, c1.data_ptr(), a_d.data_ptr(), b_d.data_ptr(), c2.data_ptr(), MEM_DEVICE)), 1)
+            return k, c1, c2, a_d, b_d, (lambda kk: unit(kk)), tm_
+
+        BD, ct1, ct2, da, db, unit, (dt, vms, mads, kern) = ddleq_statements(BD_ALL, 5)
         extras.append(entry("nested_randomize_2048", "16384 NestedRandomize (a, b supplied), 2048-bit n: ct^(a^n) * b^(n^2) mod n^3 "
-                            "(operations.go:96-118), the statements of the DDLEQ config", "ciphertexts/s", BD, dt, vms, mads, kern,
-                            "the DDLEQ prover's sanity check recomputes every ct2 (below)"))
+                            "(operations.go:96-118), the statements of the DDLEQ config", "ciphertexts/s", BD_ALL, dt, vms, mads, kern,
+                            "the DDLEQ prover's sanity check recomputes every ct2 (below)", scaling="strong"))
+        lo_d, hi_d = pdist.shard_slice(BD_ALL, rank, world)
+        dxy = unit(2 * BD_ALL)                                  # the draws x | y of the whole job; this rank's rows of each
+        dx, dy = tb(dxy[:BD_ALL][lo_d:hi_d]), tb(dxy[BD_ALL:][lo_d:hi_d])
         al = torch.zeros((BD, cb3), dtype=torch.uint8, device=dev)
         pe = torch.zeros((BD, pb2), dtype=torch.uint8, device=dev)
         pf = torch.zeros((BD, cb3), dtype=torch.uint8, device=dev)
@@ -408,16 +498,53 @@ def main():
             pe.data_ptr(), pf.data_ptr(), MEM_DEVICE)), 1)
         extras.append(entry("ddleq_prove_2048", "16384 DDLEQ instances (secpar = 1 each), 2048-bit n: sanity check, Alpha, "
                             "Fiat-Shamir bit, response through level-two ExtractRandonness (ddleq.go:55-127)",
-                            "instances/s", BD, dt, vms, mads, kern, "every proof verifies (below)"))
+                            "instances/s", BD_ALL, dt, vms, mads, kern, "every proof verifies (below)", scaling="strong"))
         dt, vms, mads, kern = timed(lambda: one_call(lambda: pk2.ddleq_verify_raw(
             BD, ct1.data_ptr(), ct2.data_ptr(), dx.data_ptr(), dy.data_ptr(), al.data_ptr(), pe.data_ptr(), pf.data_ptr(), okh,
             MEM_DEVICE)), ES)
-        assert okh.all(), "[bench] DDLEQ: a proof made by the prover was rejected by the verifier"
+        all_ranks_ok(bool(okh.all()), "DDLEQ: a proof made by the prover was rejected by the verifier")
         extras.append(entry("ddleq_verify_2048", "16384 DDLEQ instances, 2048-bit n: hash bit + check^(E^n) * F^(n^2) mod n^3 "
-                            "(ddleq.go:129-153)", "instances/s", BD, dt, vms, mads, kern, "16384 of 16384 accepted"))
-        S = 8
-        checks["ddleq_2048"] = (n2k, lam2, [x[:S].cpu().numpy() for x in (ct1, ct2, da, db, dx, dy, al, pe, pf)])
-        del inner, ct1, ct2, al, pe, pf
+                            "(ddleq.go:129-153)", "instances/s", BD_ALL, dt, vms, mads, kern, "16384 of 16384 accepted", scaling="strong"))
+        if world == 1:
+            S = 8
+            checks["ddleq_2048"] = (n2k, lam2, [x_[:S].cpu().numpy() for x_ in (ct1, ct2, da, db, dx, dy, al, pe, pf)])
+        del ct1, ct2, da, db, dx, dy, al, pe, pf
+
+        # the same config as the reference's own test drives it (ddleq_test.go:74-88): ProveDDLEQ with secpar = 40 -- 1536
+        # statements x 40 instances = 61440 instances per call; what depends on the statement only is computed once per
+        # statement (pgpu_ddleq_prove_secpar).  Statements split over the ranks.  (The size is chosen so that every launch of
+        # the call fills whole waves per SIMD: a launch a few per cent over such a boundary runs up to twice as long --
+        # DESIGN.md "wave quantisation" -- and hoisting only pays once the per-instance launches fill the chip.)
+        SP, NS_ALL = 40, 1536
+        NS, s1, s2, sa, sb, unit, _ = ddleq_statements(NS_ALL, 55)
+        lo_s, hi_s = pdist.shard_slice(NS_ALL, rank, world)
+        sxy = unit(2 * NS_ALL * SP)
+        sx, sy = tb(sxy[:NS_ALL * SP][lo_s * SP:hi_s * SP]), tb(sxy[NS_ALL * SP:][lo_s * SP:hi_s * SP])
+        BI = NS * SP
+        al = torch.zeros((BI, cb3), dtype=torch.uint8, device=dev)
+        pe = torch.zeros((BI, pb2), dtype=torch.uint8, device=dev)
+        pf = torch.zeros((BI, cb3), dtype=torch.uint8, device=dev)
+        dt, vms, mads, kern = timed(lambda: one_call(lambda: sk2.ddleq_prove_secpar_raw(
+            NS, SP, s1.data_ptr(), s2.data_ptr(), sa.data_ptr(), sb.data_ptr(), sx.data_ptr(), sy.data_ptr(), al.data_ptr(),
+            pe.data_ptr(), pf.data_ptr(), MEM_DEVICE)), 1)
+        # verify: every instance against its statement (rows of ct1 / ct2 repeated per instance)
+        rep = torch.arange(NS, device=dev).repeat_interleave(SP)
+        okh = np.zeros(BI, dtype=np.int32)
+        r1_, r2_ = s1[rep].contiguous(), s2[rep].contiguous()
+        pk2.ddleq_verify_raw(BI, r1_.data_ptr(), r2_.data_ptr(), sx.data_ptr(), sy.data_ptr(), al.data_ptr(), pe.data_ptr(),
+                             pf.data_ptr(), okh, MEM_DEVICE)
+        all_ranks_ok(bool(okh.all()), "DDLEQ secpar 40: a proof made by the prover was rejected by the verifier")
+        by_name = {e_["config"]: e_ for e_ in extras}
+        e40 = entry("ddleq_prove_2048_secpar40", "1536 DDLEQ statements x secpar 40 = 61440 instances (ProveDDLEQ, ddleq.go:27-40, at the "
+                    "reference's test setting ddleq_test.go:74-88), 2048-bit n: sanity check, a^n, a^-1, ExtractRandonness once per "
+                    "statement; x^n, Alpha, Fiat-Shamir bit and the response per instance", "instances/s", NS_ALL * SP, dt, vms, mads,
+                    kern, "all 61440 instances verify against their statements", scaling="strong")
+        e40["speedup_over_secpar1_instances"] = e40["value"] / by_name["ddleq_prove_2048"]["value"]
+        extras.append(e40)
+        if world == 1:
+            checks["ddleq_secpar40"] = (n2k, lam2, SP, [x_.cpu().numpy() for x_ in (s1[:1], s2[:1], sa[:1], sb[:1], sx[:SP], sy[:SP],
+                                                                                    al[:SP], pe[:SP], pf[:SP])])
+        del s1, s2, sa, sb, sx, sy, al, pe, pf, r1_, r2_
 
     # config 4: threshold decryption (t = 3, l = 5), 16384 ciphertexts per step over the `world` ranks -- strong scaling:
     # (server, ciphertext) units sharded over the ranks, all-gather of the 512-byte partials (RCCL), local combine
@@ -541,6 +668,9 @@ def main():
         # (written once, one entry read per window product), not re-reads of the inputs
         "traffic": traffic,
         "traffic_source": traffic_note,
+        # sustained clock of this kernel's launches in a profiled child pass (attributes slow runs: box clock vs scheduling)
+        "clock_ghz": clock["clock_ghz"] if clock else None,
+        "clock": clock,
         "hbm": {"achieved": alg_bytes * B / (vm_ms_avg * 1e-3) / 1e9, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                 "frac": alg_bytes * B / (vm_ms_avg * 1e-3) / 1e9 / HBM_PEAK_GBPS, "alg_bytes_per_decrypt": alg_bytes,
                 "traffic_GBps": (traffic / (vm_ms_avg * 1e-3) / 1e9) if traffic else None},
@@ -617,6 +747,13 @@ def main():
                                            "cpu_per_s": len(c1) / tp, "cpu_threads": min(threads, len(c1))})
             by["ddleq_verify_2048"].update({"parity": by["ddleq_verify_2048"]["parity"] + f"; {len(c1)} verdicts == libgmp oracle",
                                             "cpu_per_s": len(c1) / tv, "cpu_threads": min(threads, len(c1))})
+        if "ddleq_secpar40" in checks:
+            from paillier_amd.api import be_to_ints
+            nn, ll, sp, arrs = checks["ddleq_secpar40"]
+            c1, c2, a_, b_, x_, y_, al_, e_, f_ = [be_to_ints(a) for a in arrs]
+            wal, wes, wfs, bits = go.ddleq_prove_batch(nn, ll, c1 * sp, c2 * sp, a_ * sp, b_ * sp, x_, y_, threads=threads)
+            assert (wal, wes, wfs) == (al_, e_, f_), "[bench] DDLEQ secpar-40 prover differs from the libgmp oracle"
+            by["ddleq_prove_2048_secpar40"]["parity"] += f"; the {sp} instances of statement 0 == libgmp oracle (proveDDLEQInstance each)"
         if "threshold_2048" in checks:
             from oracle import paillier_oracle as po
             from paillier_amd.api import be_to_ints

@@ -11,8 +11,15 @@
 // tests/c/test_cabi.c, tests/cpp/test_host_mirror.cpp and the ctypes mirror paillier_amd/api.py.
 //
 // Operand format at the boundary: what gmp.Int.Bytes() gives, left-padded with zeros to a fixed stride, element-major.
-// cgo rule: no Go pointer is retained by C after a call returns; every buffer below is a Go slice passed for the duration
-// of one blocking call.
+// cgo rules honoured here:
+//   - a Go slice is passed to C only as a DIRECT argument of one blocking call (cgo pins it for that call) and C keeps no
+//     Go pointer afterwards;
+//   - no Go pointer is ever STORED in C memory: the entry points that take arrays of buffers (pgpu_add_many, pgpu_sub_many,
+//     pgpu_partial_decrypt_multi, pgpu_partial_decrypt_indexed, pgpu_combine_partial_decryptions, pgpu_random_oracle_digest)
+//     get C.malloc'd pointer arrays whose entries point at C.malloc'd copies of the operands (cbufs below), and their
+//     outputs are copied back with C.GoBytes;
+//   - pgpu_last_error() is thread-local in the library: every method that makes a C call pins its goroutine to one OS
+//     thread (runtime.LockOSThread) from the call to the reading of the message.
 package paillier
 
 /*
@@ -20,12 +27,16 @@ package paillier
 #include <stdint.h>
 #include <stdlib.h>
 #include "paillier_hip.h"
+
+// PGPU_STREAM_NEW is a cast of -1 to a pointer: made here, in C, so that Go never forms that pointer value itself
+static void* pgpu_stream_new(void) { return PGPU_STREAM_NEW; }
 */
 import "C"
 
 import (
 	"errors"
 	"fmt"
+	"runtime"
 	"unsafe"
 
 	gmp "github.com/ncw/gmp"
@@ -43,6 +54,8 @@ type GPUError struct {
 
 func (e *GPUError) Error() string { return fmt.Sprintf("paillier_hip [%d]: %s", e.Code, e.Msg) }
 
+// status turns a C status code into an error.  The caller has pinned its goroutine to an OS thread (pin) before the C call:
+// the library's last-error message is thread-local, and a goroutine may otherwise move between two cgo calls.
 func status(rc C.int) error {
 	if rc == C.PGPU_OK {
 		return nil
@@ -50,8 +63,63 @@ func status(rc C.int) error {
 	return &GPUError{int(rc), C.GoString(C.pgpu_last_error())}
 }
 
+// pin locks the calling goroutine to its OS thread and returns the function that undoes it:  defer pin()()
+func pin() func() {
+	runtime.LockOSThread()
+	return runtime.UnlockOSThread
+}
+
+// cbufs owns C copies of operand buffers and C output buffers plus a C array of pointers to them: what the entry points
+// with `const uint8_t* const*` / `uint8_t* const*` parameters take.  Nothing in it is Go memory.
+type cbufs struct {
+	ptrs *[1 << 20]*C.uint8_t
+	n    int
+	lens []int
+}
+
+func newCbufs(n int) *cbufs {
+	if n >= 1<<20 {
+		panic("paillier: too many operand buffers")
+	}
+	sz := n
+	if sz == 0 {
+		sz = 1
+	}
+	return &cbufs{ptrs: (*[1 << 20]*C.uint8_t)(C.calloc(C.size_t(sz), C.size_t(unsafe.Sizeof(uintptr(0))))), n: n, lens: make([]int, n)}
+}
+
+// in stores a C copy of b as entry i
+func (c *cbufs) in(i int, b []byte) {
+	c.ptrs[i] = (*C.uint8_t)(C.CBytes(b))
+	c.lens[i] = len(b)
+}
+
+// out allocates a zeroed C buffer of n bytes as entry i
+func (c *cbufs) out(i, n int) {
+	if n == 0 {
+		n = 1
+	}
+	c.ptrs[i] = (*C.uint8_t)(C.calloc(C.size_t(n), 1))
+	c.lens[i] = n
+}
+
+func (c *cbufs) array() **C.uint8_t { return &c.ptrs[0] }
+
+// bytes copies entry i back into Go memory
+func (c *cbufs) bytes(i, n int) []byte { return C.GoBytes(unsafe.Pointer(c.ptrs[i]), C.int(n)) }
+
+func (c *cbufs) free() {
+	for i := 0; i < c.n; i++ {
+		if c.ptrs[i] != nil {
+			C.free(unsafe.Pointer(c.ptrs[i]))
+		}
+	}
+	C.free(unsafe.Pointer(c.ptrs))
+}
+
 // NewGPU opens HIP device `device` on the default stream.
 func NewGPU(device int) (*GPU, error) {
+	defer pin()()
 	var ctx *C.pgpu_ctx
 	if err := status(C.pgpu_ctx_create(C.int(device), nil, &ctx)); err != nil {
 		return nil, err
@@ -62,8 +130,9 @@ func NewGPU(device int) (*GPU, error) {
 // NewGPUOwnStream opens a context with a stream of its own; part/parts confine it to one slice of the compute units
 // (parts == 0: the whole device) so that several contexts run small batches side by side.
 func NewGPUOwnStream(device, part, parts int) (*GPU, error) {
+	defer pin()()
 	var ctx *C.pgpu_ctx
-	if err := status(C.pgpu_ctx_create(C.int(device), unsafe.Pointer(^uintptr(0)), &ctx)); err != nil {
+	if err := status(C.pgpu_ctx_create(C.int(device), C.pgpu_stream_new(), &ctx)); err != nil {
 		return nil, err
 	}
 	g := &GPU{ctx}
@@ -143,6 +212,7 @@ type GPUPublicKey struct {
 
 // Upload precomputes the key on the device (paillier.go:46-57 fields N, G, H, K).
 func (g *GPU) Upload(pk *PublicKey) (*GPUPublicKey, error) {
+	defer pin()()
 	n, gg := bytesOf(pk.N), bytesOf(pk.G)
 	var hb, kb []byte
 	if pk.H != nil {
@@ -177,6 +247,7 @@ type GPUSecretKey struct {
 }
 
 func (k *GPUPublicKey) UploadSecret(sk *SecretKey) (*GPUSecretKey, error) {
+	defer pin()()
 	l := bytesOf(sk.Lambda)
 	var h *C.pgpu_seckey
 	if err := status(C.pgpu_seckey_create(k.g.ctx, k.h, p8(l), C.size_t(len(l)), &h)); err != nil {

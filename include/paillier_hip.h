@@ -254,6 +254,16 @@ int pgpu_ddleq_prove(const pgpu_seckey* sk, size_t batch, const uint8_t* ct1, co
                      const uint8_t* a, const uint8_t* b, const uint8_t* x, const uint8_t* y, size_t n_stride, uint8_t* alpha,
                      uint8_t* e_out, size_t e_stride, uint8_t* f_out, int mem);
 
+/* SecretKey.ProveDDLEQ (ddleq.go:27-40) for a batch of statements: `secpar` instances per statement (soundness 1 - 2^-secpar
+ * each), draws supplied.  ct1, ct2, a, b hold n_statements rows; x, y, alpha, e_out, f_out hold n_statements * secpar rows,
+ * statement-major (instance k of statement j in row j * secpar + k).  What proveDDLEQInstance (ddleq.go:55-127) recomputes in
+ * every instance although it depends on the statement only -- the sanity check (:62-69), a^n, a^-1, ExtractRandonness(ct1)
+ * (:103) -- is computed once per statement; the integers are those of `secpar` calls of proveDDLEQInstance with the same
+ * draws.  Strides as for pgpu_ddleq_prove, which is the secpar = 1 case.  A false statement returns PGPU_ERR_INVALID. */
+int pgpu_ddleq_prove_secpar(const pgpu_seckey* sk, size_t n_statements, size_t secpar, const uint8_t* ct1, const uint8_t* ct2,
+                            size_t ct_stride, const uint8_t* a, const uint8_t* b, const uint8_t* x, const uint8_t* y, size_t n_stride,
+                            uint8_t* alpha, uint8_t* e_out, size_t e_stride, uint8_t* f_out, int mem);
+
 /* ---- generic modular batch primitives (the gmp.Int seam: Exp / Mul+Mod) ------------------------ */
 
 /* Load an odd modulus (big-endian).  Precomputes -N^-1 mod 2^28, R mod N, R^2 mod N, R^3 mod N. */

@@ -79,6 +79,7 @@ SIGNATURES = {
     "pgpu_share_zkp_prove": (_int, [_vp, _int, _vp, _sz, _vp, _sz, _sz, _vp, _sz, _vp, _sz, _vp, _sz, _vp, _vp, _sz, _int]),
     "pgpu_share_zkp_verify": (_int, [_vp, _vp, _sz, _vp, _sz, _sz, _vp, _sz, _vp, _sz, _vp, _vp, _sz, _vp, _int]),
     "pgpu_ddleq_prove": (_int, [_vp, _sz, _vp, _vp, _sz, _vp, _vp, _vp, _vp, _sz, _vp, _vp, _sz, _vp, _int]),
+    "pgpu_ddleq_prove_secpar": (_int, [_vp, _sz, _sz, _vp, _vp, _sz, _vp, _vp, _vp, _vp, _sz, _vp, _vp, _sz, _vp, _int]),
     "pgpu_const_mult": (_int, [_vp, _int, _sz, _vp, _sz, _vp, _sz, _sz, _vp, _sz, _int]),
     "pgpu_modulus_create": (_int, [_vp, _vp, _sz, C.POINTER(_vp)]),
     "pgpu_modulus_destroy": (None, [_vp]),
@@ -91,6 +92,46 @@ SIGNATURES = {
 }
 
 
+def hip_runtimes_mapped() -> List[str]:
+    """Paths of the libamdhip64 copies mapped into this process (more than one = two HIP runtimes: the second one to
+    initialise finds no device)."""
+    seen = []
+    try:
+        for line in open("/proc/self/maps"):
+            f = line.rsplit(" ", 1)[-1].strip()
+            if "libamdhip64" in f and f not in seen:
+                seen.append(f)
+    except OSError:
+        pass
+    return seen
+
+
+def _preload_hip_runtime():
+    """ONE HIP runtime per process.  libpaillier_hip.so needs `libamdhip64.so.7` (by SONAME: the system ROCm's, /opt/rocm/lib);
+    PyTorch ships its own copy of the same runtime and asks for it by FILE name (`libamdhip64.so`, found through its RPATH),
+    which the loader does not match against an already mapped SONAME.  So `import torch` AFTER this library maps a second HIP
+    runtime, and the runtime that initialises second reports "No HIP GPUs are available" (the first holds the device).  The
+    other order works by itself: torch's copy carries the SONAME libamdhip64.so.7 and satisfies this library's dependency.
+    Fix: when PyTorch is installed but not imported yet, map ITS runtime first (RTLD_GLOBAL), exactly what `import torch`
+    would have done; both then share it in either order.  PGPU_HIP_RUNTIME=system keeps the system runtime (a process that
+    never imports torch does not care)."""
+    if os.environ.get("PGPU_HIP_RUNTIME", "").lower() == "system" or hip_runtimes_mapped():
+        return
+    try:
+        import importlib.util
+        spec = importlib.util.find_spec("torch")
+    except (ImportError, ValueError):
+        spec = None
+    if spec is None or not spec.origin:
+        return
+    cand = os.path.join(os.path.dirname(spec.origin), "lib", "libamdhip64.so")
+    if os.path.exists(cand):
+        try:
+            C.CDLL(cand, mode=C.RTLD_GLOBAL)
+        except OSError:
+            pass                       # fall back to the system runtime: the library still works on its own
+
+
 def load_library():
     """Loads libpaillier_hip.so; raises if it has not been built (there is no fallback)."""
     global _lib
@@ -99,7 +140,12 @@ def load_library():
     path = library_path()
     if not os.path.exists(path):
         raise PaillierHipError(-100, f"{path} not found: run `python -c 'import __graft_entry__ as g; g.build()'` first")
+    _preload_hip_runtime()
     lib = C.CDLL(path)
+    if len(hip_runtimes_mapped()) > 1:
+        raise PaillierHipError(-100, "two HIP runtimes are mapped into this process (" + ", ".join(hip_runtimes_mapped()) +
+                               "): the second one to initialise will find no GPU; import paillier_amd (or torch) before whatever "
+                               "loaded the other copy, or link everything against one libamdhip64")
     for name, (res, args) in SIGNATURES.items():
         fn = getattr(lib, name)
         fn.restype = res
@@ -566,6 +612,31 @@ class SecretKey:
         cb3, pb1, pb2 = pk.cipher_bytes(ENC_LEVEL_TWO), pk.plain_bytes(ENC_LEVEL_ONE), pk.plain_bytes(ENC_LEVEL_TWO)
         _check(self.ctx.lib.pgpu_ddleq_prove(self.h, batch, _ptr(ct1), _ptr(ct2), cb3, _ptr(a), _ptr(b), _ptr(x), _ptr(y), pb1,
                                              _ptr(alpha), _ptr(e), pb2, _ptr(f), mem))
+
+    def ddleq_prove_secpar_raw(self, n_statements, secpar, ct1, ct2, a, b, x, y, alpha, e, f, mem=MEM_HOST):
+        """pgpu_ddleq_prove_secpar on raw buffers with the natural strides: ct1, ct2, a, b one row per statement; x, y, alpha, e,
+        f one row per (statement, instance), statement-major."""
+        pk = self.pk
+        cb3, pb1, pb2 = pk.cipher_bytes(ENC_LEVEL_TWO), pk.plain_bytes(ENC_LEVEL_ONE), pk.plain_bytes(ENC_LEVEL_TWO)
+        _check(self.ctx.lib.pgpu_ddleq_prove_secpar(self.h, n_statements, secpar, _ptr(ct1), _ptr(ct2), cb3, _ptr(a), _ptr(b),
+                                                    _ptr(x), _ptr(y), pb1, _ptr(alpha), _ptr(e), pb2, _ptr(f), mem))
+
+    def ProveDDLEQBatch(self, secpar: int, ct1s, ct2s, a_s, b_s, xs, ys):
+        """ddleq.go:27-40 ProveDDLEQ for a batch of statements with the draws supplied: xs[j][k], ys[j][k] = the draws of
+        instance k of statement j.  The per-statement work (sanity check, a^n, a^-1, ExtractRandonness(ct1)) is done once per
+        statement on the device.  Returns (alphas, es, fs), each [statement][instance]."""
+        pk = self.pk
+        cb3, pb1, pb2 = pk.cipher_bytes(ENC_LEVEL_TWO), pk.plain_bytes(ENC_LEVEL_ONE), pk.plain_bytes(ENC_LEVEL_TWO)
+        S = len(ct1s)
+        flat = lambda v: [t for row in v for t in row]
+        assert all(len(r) == secpar for r in xs) and all(len(r) == secpar for r in ys) and len(xs) == len(ys) == S
+        bufs = [ints_to_be(ct1s, cb3), ints_to_be(ct2s, cb3), ints_to_be(a_s, pb1), ints_to_be(b_s, pb1), ints_to_be(flat(xs), pb1),
+                ints_to_be(flat(ys), pb1)]
+        B = S * secpar
+        al, eo, fo = np.zeros((B, cb3), np.uint8), np.zeros((B, pb2), np.uint8), np.zeros((B, cb3), np.uint8)
+        self.ddleq_prove_secpar_raw(S, secpar, *bufs, al, eo, fo, MEM_HOST)
+        rows = lambda v: [v[j * secpar:(j + 1) * secpar] for j in range(S)]
+        return rows(be_to_ints(al)), rows(be_to_ints(eo)), rows(be_to_ints(fo))
 
     def EncryptWithRBatch(self, ms: Sequence[int], rs: Sequence[int], level: int = ENC_LEVEL_ONE) -> List[int]:
         """sk.EncryptWithR (SecretKey embeds PublicKey, paillier.go:59-62,185): the key holder's r^n goes through p^2 and q^2

@@ -6,6 +6,7 @@
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
+#include <atomic>
 #include <memory>
 #include <mutex>
 #include <set>
@@ -53,6 +54,12 @@ void wipe(void* p, size_t n) {
   while (n--) *v++ = 0;
 }
 template <class T> void wipe_vec(std::vector<T>& v) { if (!v.empty()) wipe(v.data(), v.size() * sizeof(T)); }
+// wipes host copies of secret exponents on EVERY exit of the enclosing scope, exceptions included
+template <class V> struct WipeOnExit {
+  V& v;
+  explicit WipeOnExit(V& v_) : v(v_) {}
+  ~WipeOnExit() { for (auto& e : v) wipe_vec(e.d); }
+};
 
 }  // namespace
 
@@ -261,9 +268,13 @@ struct DevLimbs {
 // ------------------------------------------------------------------------------------------------
 // VM programs
 // ------------------------------------------------------------------------------------------------
-static bool g_wave_priorities = true;   // pgpu_ctx_set_flag("fair", 0): no priority bits in the programs (A/B measurements)
+// pgpu_ctx_set_flag("fair", 0): no priority bits in the programs.  A measurement switch (A/B runs of the wave-priority scheme),
+// deliberately PROCESS-wide -- programs are built without a context at hand -- and atomic: other contexts' threads read it
+// while they build programs.  Product code never clears it.
+static std::atomic<bool> g_wave_priorities{true};
 struct Prog {
   std::vector<uint32_t> w;
+  ~Prog() { wipe_vec(w); }   // a ladder program spells out its exponent window by window: p - 1, q - 1, lambda, shares ...
   double montmuls = 0, sqrs = 0;
   bool asm_ok = true;  // only opcodes the assembly kernel implements
   bool has_mulv = false;
@@ -292,7 +303,7 @@ struct Prog {
   // longer than 7 % of the one before it or the leader would run out of program while the other is still catching up).
   void end() {
     op(VM_END);
-    if (montmuls < 256 || !g_wave_priorities) return;
+    if (montmuls < 256 || !g_wave_priorities.load(std::memory_order_relaxed)) return;
     double done = 0;
     for (size_t i = 0; i + 1 < w.size(); i += 2) {
       const uint32_t o = w[i] & 0xFFu;
@@ -1043,7 +1054,7 @@ int pgpu_ctx_set_flag(pgpu_ctx* ctx, const char* name, int value) {
   if (strcmp(name, "triple") == 0) { ctx->use_triple = value != 0; return PGPU_OK; }
   if (strcmp(name, "shared_chain") == 0) { ctx->use_shared_chain = value != 0; return PGPU_OK; }
   if (strcmp(name, "lift") == 0) { ctx->use_lift = value != 0; return PGPU_OK; }
-  if (strcmp(name, "fair") == 0) { g_wave_priorities = value != 0; return PGPU_OK; }   // process-wide
+  if (strcmp(name, "fair") == 0) { g_wave_priorities.store(value != 0, std::memory_order_relaxed); return PGPU_OK; }   // process-wide (see above)
   if (strcmp(name, "lanes_wanted") == 0) { ctx->lanes_wanted = value > 0 ? (size_t)value : 0; return PGPU_OK; }
   if (strcmp(name, "cu_partition") == 0) {
     // value = (parts << 16) | part: confine this context's (own) stream to the part-th of `parts` equal slices of the
@@ -1091,6 +1102,10 @@ int pgpu_ctx_last_profile(pgpu_ctx* ctx, double* vm_ms, int* vm_launches, double
       HIPCHK(hipEventElapsedTime(&t, ctx->evs[i].a, ctx->evs[i].b));
       ms += t;
       mads += ctx->evs[i].mads;
+      // PGPU_PROFILE_DUMP=1 (measurements): one line per profiled VM launch of the last call
+      static const bool dump = [] { const char* e = getenv("PGPU_PROFILE_DUMP"); return e && atoi(e) != 0; }();
+      if (dump) fprintf(stderr, "[pgpu] launch %2zu %-16s %9.3f ms %14.0f mads  %.3f of peak\n", i, ctx->evs[i].name, t, ctx->evs[i].mads,
+                        t > 0 ? ctx->evs[i].mads / (t * 1e-3) / 39.3216e12 : 0.0);
     }
     if (vm_ms) *vm_ms = ms;
     if (vm_launches) *vm_launches = (int)ctx->evs_used;
@@ -3065,7 +3080,9 @@ int pgpu_partial_decrypt(const pgpu_pubkey* pk, int total_servers, const uint8_t
     const ModCtx& mc = pk->mn2;
     const size_t nb = round_up(batch, VM_BLOCK);
     // thresholdkey.go:195: exp = Share * (2 * delta), delta = l!
-    BigU e = BigU::from_be(share_be, share_len) * (BigU(2) * factorial_big(total_servers));
+    std::vector<BigU> ev{BigU::from_be(share_be, share_len) * (BigU(2) * factorial_big(total_servers))};
+    WipeOnExit<std::vector<BigU>> wipe_e(ev);
+    const BigU& e = ev[0];
     ModexpPlan pl = modexp_alloc(ctx, mc, nb, 32);
     unpack_mod(ctx, mc, c, c_stride, batch, mem, pl.in(), nb);
     modexp_shared_run(ctx, mc, pl, e, false, false, true);
@@ -3156,6 +3173,7 @@ int pgpu_partial_decrypt_multi(const pgpu_pubkey* pk, int total_servers, int n_s
     const size_t nb = round_up(batch, VM_BLOCK);
     const BigU two_delta = BigU(2) * factorial_big(total_servers);
     std::vector<BigU> es;
+    WipeOnExit<std::vector<BigU>> wipe_es(es);             // share * 2 delta: wiped on every exit, the fallbacks and errors too
     for (int k = 0; k < n_shares; ++k) {
       if (!shares_be[k] || !outs[k]) api_throw(PGPU_ERR_INVALID, "null share / output buffer");
       es.push_back(BigU::from_be(shares_be[k], share_lens[k]) * two_delta);       // thresholdkey.go:195
@@ -3195,10 +3213,11 @@ int pgpu_partial_decrypt_multi(const pgpu_pubkey* pk, int total_servers, int n_s
       const uint32_t K = 1u << (w - 1);
       const size_t per_server = (size_t)K * SW * 4;
       const int group = (int)std::max<size_t>(1, std::min<size_t>((size_t)n_shares, ((size_t)12 << 30) / per_server));
+      // one slot array for every group, sized for the largest (the bump workspace releases nothing before the next call)
+      uint32_t* pm = ctx->ws_t<uint32_t>(SW * (size_t)(6 + (size_t)group + (size_t)group * K));
       for (int k0 = 0; k0 < n_shares; k0 += group) {
         const int S = std::min(group, n_shares - k0);
         const uint32_t OUT0 = 6, B0 = 6 + (uint32_t)S;
-        uint32_t* pm = ctx->ws_t<uint32_t>(SW * (size_t)(B0 + (size_t)S * K));
         HIPCHK(hipMemcpyAsync(pm + 2 * SW, ent + 2 * SW, SW * 4, hipMemcpyDeviceToDevice, ctx->stream));
         Prog pr;
         emit_multi_exp_shared_base(pr, std::vector<BigU>(es.begin() + k0, es.begin() + k0 + S), 2, 3, 4, 5, OUT0, B0, w,
@@ -3210,7 +3229,6 @@ int pgpu_partial_decrypt_multi(const pgpu_pubkey* pk, int total_servers, int n_s
         run_vm(ctx, nb, sg, nullptr, true);
         for (int j = 0; j < S; ++j) leave_pair_form(pm, OUT0 + (uint32_t)j, outs[k0 + j]);
       }
-      for (auto& e : es) wipe_vec(e.d);
       HIPCHK(hipStreamSynchronize(ctx->stream));
       return;
     }
@@ -3236,7 +3254,6 @@ int pgpu_partial_decrypt_multi(const pgpu_pubkey* pk, int total_servers, int n_s
       for (int j = 0; j < segs; ++j) leave_pair_form(pm[j], 3, outs[k + j]);
       k += segs;
     }
-    for (auto& e : es) wipe_vec(e.d);
     HIPCHK(hipStreamSynchronize(ctx->stream));
   });
 }
@@ -3259,6 +3276,7 @@ int pgpu_partial_decrypt_indexed(const pgpu_pubkey* pk, int total_servers, int n
     // units of SEVERAL servers share one launch (a few thousand ciphertexts per server cannot fill the chip on their own)
     const BigU two_delta = BigU(2) * factorial_big(total_servers);
     std::vector<BigU> exps_big;
+    WipeOnExit<std::vector<BigU>> wipe_exps(exps_big);
     size_t ebits = 1;
     for (int k = 0; k < n_shares; ++k) {
       if (!shares_be[k]) api_throw(PGPU_ERR_INVALID, "null share");
@@ -3317,6 +3335,7 @@ int pgpu_partial_decrypt_indexed(const pgpu_pubkey* pk, int total_servers, int n
     for (auto& e : exps_big) {
       auto l = e.to_limbs(LB, (size_t)we);
       table.insert(table.end(), l.begin(), l.end());
+      wipe_vec(l);
       wipe_vec(e.d);
     }
     uint32_t* d_table = ctx->upload_words(table);
@@ -4064,6 +4083,20 @@ void split2(pgpu_ctx* ctx, const uint32_t* in, int which, int w, size_t nb, uint
   HIPCHK(hipMemcpy2DAsync(out, nb * 4, in + (size_t)which * nb, 2 * nb * 4, nb * 4, (size_t)w, hipMemcpyDeviceToDevice, ctx->stream));
 }
 
+// [w][nba + nbb] <- a ([w][nba]) | b ([w][nbb]): two batches of different sizes side by side in one launch
+uint32_t* concat_ab(pgpu_ctx* ctx, const uint32_t* a, size_t nba, const uint32_t* b, size_t nbb, int w) {
+  const size_t t = nba + nbb;
+  uint32_t* o = ctx->ws_t<uint32_t>((size_t)w * t);
+  HIPCHK(hipMemcpy2DAsync(o, t * 4, a, nba * 4, nba * 4, (size_t)w, hipMemcpyDeviceToDevice, ctx->stream));
+  HIPCHK(hipMemcpy2DAsync(o + nba, t * 4, b, nbb * 4, nbb * 4, (size_t)w, hipMemcpyDeviceToDevice, ctx->stream));
+  return o;
+}
+// part `which` (0: the first nba numbers, 1: the nbb after them) of a [w][nba + nbb] array
+void split_ab(pgpu_ctx* ctx, const uint32_t* in, size_t nba, size_t nbb, int which, int w, uint32_t* out) {
+  const size_t t = nba + nbb, n = which ? nbb : nba;
+  HIPCHK(hipMemcpy2DAsync(out, n * 4, in + (which ? nba : 0), t * 4, n * 4, (size_t)w, hipMemcpyDeviceToDevice, ctx->stream));
+}
+
 uint32_t* zext(pgpu_ctx* ctx, const uint32_t* in, int w, int wo, size_t nb) {
   uint32_t* o = ctx->ws_t<uint32_t>((size_t)wo * nb);
   launch_copy_limbs(in, 0, w, o, wo, nb, ctx->stream);
@@ -4111,14 +4144,19 @@ int pgpu_encrypt_with_r_sk(const pgpu_seckey* sk, int level, size_t batch, const
   });
 }
 
-int pgpu_ddleq_prove(const pgpu_seckey* sk, size_t batch, const uint8_t* ct1, const uint8_t* ct2, size_t ct_stride,
-                     const uint8_t* a, const uint8_t* b, const uint8_t* x, const uint8_t* y, size_t n_stride, uint8_t* alpha,
-                     uint8_t* e_out, size_t e_stride, uint8_t* f_out, int mem) {
-  if (!sk || !ct1 || !ct2 || !a || !b || !x || !y || !alpha || !e_out || !f_out) return fail(PGPU_ERR_INVALID, "null argument");
+// ProveDDLEQ (ddleq.go:27-40) for `n_statements` statements (ct1, ct2, a, b) with `secpar` instances each -- draws x, y
+// supplied, instance k of statement j in row j * secpar + k of x / y / alpha / e / f.  What ddleq.go:55-127 recomputes in every
+// instance although it depends on the statement only is computed ONCE per statement: the sanity check ct1^(a^n) b^(n^2) == ct2
+// (:62-69), a^n (:104), a^-1 (:95) and (a^n)^-1, s = ExtractRandonness(ct1) (:103) and the unit tests of s and b; per instance
+// remain x^n, alpha = ct1^(x^n) y^(n^2), the challenge bit and -- for bit 1 -- the response ladder.  The integers are those of
+// `secpar` calls of proveDDLEQInstance with the same draws.  secpar = 1 is pgpu_ddleq_prove.
+static void ddleq_prove_impl(const pgpu_seckey* sk, size_t S, size_t secpar, const uint8_t* ct1, const uint8_t* ct2, size_t ct_stride,
+                             const uint8_t* a, const uint8_t* b, const uint8_t* x, const uint8_t* y, size_t n_stride, uint8_t* alpha,
+                             uint8_t* e_out, size_t e_stride, uint8_t* f_out, int mem) {
   pgpu_ctx* ctx = sk->ctx;
   const pgpu_pubkey* pk = sk->pk;
-  return guarded([&] {
-    if (batch == 0) api_throw(PGPU_ERR_INVALID, "empty batch");
+  {
+    if (S == 0 || secpar == 0) api_throw(PGPU_ERR_INVALID, "empty batch");
     if (!pk->mn3 || sk->c_mu2R < 0) api_throw(PGPU_ERR_UNSUPPORTED, "level two is not available for this key");
     if (!pk->g_is_n_plus_1) api_throw(PGPU_ERR_UNSUPPORTED, "DDLEQ prover assumes G = N+1");
     ctx->bind();
@@ -4135,59 +4173,76 @@ int pgpu_ddleq_prove(const pgpu_seckey* sk, size_t batch, const uint8_t* ct1, co
       if (crt3) pow_n3_crt(sk, base, wb, nullptr, 0, &ex, nbx, outp);
       else shared_pow(ctx, mn3, base, wb, ex, nbx, outp);
     };
-    const size_t nb = round_up(batch, VM_BLOCK);
+    const size_t batch = S * secpar;                        // instances
+    const size_t nbs = round_up(S, VM_BLOCK), nb = round_up(batch, VM_BLOCK);
     if (ct_stride != mn3.nbytes) api_throw(PGPU_ERR_INVALID, "ciphertext stride must be the byte length of n^3");
     if (n_stride * 8 > (size_t)LB * W1 + 7) api_throw(PGPU_ERR_INVALID, "a, b, x, y must fit the width of n");
-    auto up = [&](const uint8_t* buf, size_t stride, int w) {
-      uint32_t* l = ctx->ws_t<uint32_t>((size_t)w * nb);
-      unpack_operand(ctx, buf, stride, stride, batch, mem, l, w, nb);
+    auto up = [&](const uint8_t* buf, size_t stride, int w, size_t count, size_t nbx) {
+      uint32_t* l = ctx->ws_t<uint32_t>((size_t)w * nbx);
+      unpack_operand(ctx, buf, stride, stride, count, mem, l, w, nbx);
       return l;
     };
-    uint32_t *c1 = up(ct1, ct_stride, W3), *c2 = up(ct2, ct_stride, W3);
-    uint32_t *al = up(a, n_stride, W1), *bl = up(b, n_stride, W1), *xl = up(x, n_stride, W1), *yl = up(y, n_stride, W1);
+    // per statement (S numbers, row stride nbs) ...
+    uint32_t *c1s = up(ct1, ct_stride, W3, S, nbs), *c2s = up(ct2, ct_stride, W3, S, nbs);
+    uint32_t *al = up(a, n_stride, W1, S, nbs), *bl = up(b, n_stride, W1, S, nbs);
+    // ... and per instance (S * secpar numbers, row stride nb)
+    uint32_t *xl = up(x, n_stride, W1, batch, nb), *yl = up(y, n_stride, W1, batch, nb);
+    uint32_t* d_stmt = nullptr;                              // instance -> its statement
+    if (secpar > 1) {
+      std::vector<uint32_t> st(batch);
+      for (size_t i = 0; i < batch; ++i) st[i] = (uint32_t)(i / secpar);
+      d_stmt = ctx->upload_words(st);
+    }
+    auto expand = [&](uint32_t* in, int w) {                 // a per-statement array repeated for the instances of its statement
+      if (secpar == 1) return in;
+      uint32_t* o = ctx->ws_t<uint32_t>((size_t)w * nb);
+      launch_gather(in, nbs, d_stmt, batch, o, nb, w, ctx->stream);
+      return o;
+    };
+    uint32_t *c1 = expand(c1s, W3), *c2 = expand(c2s, W3);
     const BigU &N = pk->N, &N2 = mn2.N;
-    // ---- sanity check (ddleq.go:62-69): ct1^(a^n mod n^2) * b^(n^2) mod n^3 == ct2, else the reference panics
-    // Independent exponentiations of the same shape share a launch (twice the numbers: the chip is filled better and, for
-    // the half-size batches of the response, a latency-bound launch is saved outright): a^n | x^n, then the sanity value and
-    // alpha -- ct1^(a^n) b^(n^2) | ct1^(x^n) y^(n^2) -- and further down s^(a^n) | s^(x^n).
-    uint32_t* an = ctx->ws_t<uint32_t>((size_t)W2 * nb);
+    // ---- sanity check (ddleq.go:62-69): ct1^(a^n mod n^2) * b^(n^2) mod n^3 == ct2, else the reference panics -- once per
+    // statement.  Independent exponentiations of the same shape share a launch (the chip is filled better and, for the half-size
+    // batches of the response, a latency-bound launch is saved outright): a^n (S numbers) | x^n (S secpar numbers), then the
+    // sanity value and alpha -- ct1^(a^n) b^(n^2) | ct1^(x^n) y^(n^2) -- and further down s^(a^n) | s^(x^n).
+    uint32_t* an = ctx->ws_t<uint32_t>((size_t)W2 * nbs);
     uint32_t* xn = ctx->ws_t<uint32_t>((size_t)W2 * nb);
     {
-      uint32_t* ax = concat2(ctx, al, xl, W1, nb);
+      uint32_t* ax = concat_ab(ctx, al, nbs, xl, nb, W1);
       uint32_t* axn;
       if (pow_n2_crt_usable(sk)) {
-        axn = pow_n2_crt(sk, ax, N, 2 * nb);                 // the prover holds p and q
+        axn = pow_n2_crt(sk, ax, N, nbs + nb);               // the prover holds p and q
       } else {
-        axn = ctx->ws_t<uint32_t>((size_t)W2 * 2 * nb);
-        shared_pow(ctx, mn2, ax, W1, N, 2 * nb, axn);
+        axn = ctx->ws_t<uint32_t>((size_t)W2 * (nbs + nb));
+        shared_pow(ctx, mn2, ax, W1, N, nbs + nb, axn);
       }
-      split2(ctx, axn, 0, W2, nb, an);
-      split2(ctx, axn, 1, W2, nb, xn);
+      split_ab(ctx, axn, nbs, nb, 0, W2, an);
+      split_ab(ctx, axn, nbs, nb, 1, W2, xn);
     }
-    uint32_t* bn2 = ctx->ws_t<uint32_t>((size_t)W3 * nb);
+    uint32_t* bn2 = ctx->ws_t<uint32_t>((size_t)W3 * nbs);
     uint32_t* t3 = ctx->ws_t<uint32_t>((size_t)W3 * nb);
-    uint32_t* san = ctx->ws_t<uint32_t>((size_t)W3 * nb);
+    uint32_t* san = ctx->ws_t<uint32_t>((size_t)W3 * nbs);
     uint32_t* alp = ctx->ws_t<uint32_t>((size_t)W3 * nb);
     if (crt3) {
       // ct1^(a^n) * b^(n^2) and ct1^(x^n) * y^(n^2): one interleaved ladder per number and CRT half, both batches in one launch
-      uint32_t* cc2 = concat2(ctx, c1, c1, W3, nb);
-      uint32_t* ee2 = concat2(ctx, an, xn, W2, nb);
-      uint32_t* by2 = concat2(ctx, bl, yl, W1, nb);
-      uint32_t* o2 = ctx->ws_t<uint32_t>((size_t)W3 * 2 * nb);
-      pow_n3_crt(sk, cc2, W3, ee2, W2, &N2, 2 * nb, o2, by2, W1);
-      split2(ctx, o2, 0, W3, nb, san);
-      split2(ctx, o2, 1, W3, nb, alp);
+      uint32_t* cc2 = concat_ab(ctx, c1s, nbs, c1, nb, W3);
+      uint32_t* ee2 = concat_ab(ctx, an, nbs, xn, nb, W2);
+      uint32_t* by2 = concat_ab(ctx, bl, nbs, yl, nb, W1);
+      uint32_t* o2 = ctx->ws_t<uint32_t>((size_t)W3 * (nbs + nb));
+      pow_n3_crt(sk, cc2, W3, ee2, W2, &N2, nbs + nb, o2, by2, W1);
+      split_ab(ctx, o2, nbs, nb, 0, W3, san);
+      split_ab(ctx, o2, nbs, nb, 1, W3, alp);
     } else {
-      shared3(bl, W1, N2, nb, bn2);
-      perlane3(c1, an, W2, nb, t3);
-      modmul_arrays(ctx, mn3, t3, bn2, nb, san);
+      shared3(bl, W1, N2, nbs, bn2);
+      perlane3(c1s, an, W2, nbs, t3);
+      modmul_arrays(ctx, mn3, t3, bn2, nbs, san);
     }
-    int32_t* d_ok = ctx->ws_t<int32_t>(nb);
-    launch_equal(san, c2, W3, nb, batch, d_ok, ctx->stream);
-    std::vector<int32_t> hok(batch);
-    HIPCHK(hipMemcpyAsync(hok.data(), d_ok, batch * 4, hipMemcpyDeviceToHost, ctx->stream));
+    int32_t* d_ok = ctx->ws_t<int32_t>(nbs);
+    launch_equal(san, c2s, W3, nbs, S, d_ok, ctx->stream);
+    std::vector<int32_t> hok(S);
+    HIPCHK(hipMemcpyAsync(hok.data(), d_ok, S * 4, hipMemcpyDeviceToHost, ctx->stream));
     HIPCHK(hipStreamSynchronize(ctx->stream));
-    for (size_t i = 0; i < batch; ++i)
+    for (size_t i = 0; i < S; ++i)
       if (!hok[i]) api_throw(PGPU_ERR_INVALID, "cannot prove re-encryption because inputs are wrong");
     // ---- alpha = ct1^(x^n) * y^(n^2) mod n^3 (ddleq.go:81-87); with CRT it came out of the launch above
     uint32_t* yn2 = ctx->ws_t<uint32_t>((size_t)W3 * nb);
@@ -4208,49 +4263,74 @@ int pgpu_ddleq_prove(const pgpu_seckey* sk, size_t batch, const uint8_t* ct1, co
     // default outputs: e = x, f = y (chalBit false)
     uint32_t* eo = zext(ctx, xl, W1, W2, nb);
     uint32_t* fo = zext(ctx, yl, W1, W3, nb);
-    std::vector<uint32_t> idx;
-    for (size_t i = 0; i < batch; ++i) if (hch[i]) idx.push_back((uint32_t)i);
+    // instances with challenge bit 1, the statements they belong to (each once) and where an instance finds its statement
+    std::vector<uint32_t> idx, sidx, pos;
+    for (size_t i = 0; i < batch; ++i)
+      if (hch[i]) {
+        const uint32_t st = (uint32_t)(i / secpar);
+        if (sidx.empty() || sidx.back() != st) sidx.push_back(st);
+        idx.push_back((uint32_t)i);
+        pos.push_back((uint32_t)sidx.size() - 1);
+      }
     if (!idx.empty()) {
       const size_t cnt = idx.size(), nbg = round_up(cnt, VM_BLOCK);
+      const size_t scnt = sidx.size(), nbq = round_up(scnt, VM_BLOCK);
       uint32_t* d_idx = ctx->upload_words(idx);
-      auto gat = [&](const uint32_t* in, int w) {
+      uint32_t* d_sidx = ctx->upload_words(sidx);
+      uint32_t* d_pos = ctx->upload_words(pos);
+      auto gat = [&](const uint32_t* in, int w) {            // per-instance array -> the compacted instances
         uint32_t* o = ctx->ws_t<uint32_t>((size_t)w * nbg);
         launch_gather(in, nb, d_idx, cnt, o, nbg, w, ctx->stream);
         return o;
       };
-      uint32_t *ga = gat(al, W1), *gb = gat(bl, W1), *gx = gat(xl, W1), *gy = gat(yl, W1), *gc1 = gat(c1, W3), *gan = gat(an, W2),
-               *gxn = gat(xn, W2);
+      auto gats = [&](const uint32_t* in, int w) {           // per-statement array -> the compacted statements
+        uint32_t* o = ctx->ws_t<uint32_t>((size_t)w * nbq);
+        launch_gather(in, nbs, d_sidx, scnt, o, nbq, w, ctx->stream);
+        return o;
+      };
+      auto per_inst = [&](uint32_t* in, int w) {             // compacted-statement array -> one entry per compacted instance
+        if (secpar == 1) return in;                          // (secpar = 1: the two compactions coincide)
+        uint32_t* o = ctx->ws_t<uint32_t>((size_t)w * nbg);
+        launch_gather(in, nbq, d_pos, cnt, o, nbg, w, ctx->stream);
+        return o;
+      };
+      uint32_t *gx = gat(xl, W1), *gy = gat(yl, W1), *gxn = gat(xn, W2);
+      // ---- once per statement: a^-1, (a^n)^-1, s, the unit test of s b
+      uint32_t *qa = gats(al, W1), *qb = gats(bl, W1), *qc1 = gats(c1s, W3), *qan = gats(an, W2);
       // padding lanes of the compacted batch must be invertible: fill a with 1 there
-      launch_restride(ga, nbg, cnt, mn.d_consts + (size_t)C_ONE * W1, ga, nbg, W1, ctx->stream);
-      // e = x * a^-1 mod n^2 (ddleq.go:94-99)
+      launch_restride(qa, nbq, scnt, mn.d_consts + (size_t)C_ONE * W1, qa, nbq, W1, ctx->stream);
       // a^-1 and (a^n)^-1 modulo n^2 (the second one for en below) from ONE inversion tree: both batches side by side
-      uint32_t* a2 = zext(ctx, ga, W1, W2, nbg);
-      uint32_t* an1 = ctx->ws_t<uint32_t>((size_t)W2 * nbg);
-      launch_restride(gan, nbg, cnt, mn2.d_consts + (size_t)C_ONE * W2, an1, nbg, W2, ctx->stream);   // padding lanes: 1
-      uint32_t* inv2 = batch_inverse(ctx, mn2, concat2(ctx, a2, an1, W2, nbg), 2 * nbg, 2 * nbg);
-      uint32_t* ainv = ctx->ws_t<uint32_t>((size_t)W2 * nbg);
-      uint32_t* ani = ctx->ws_t<uint32_t>((size_t)W2 * nbg);
-      split2(ctx, inv2, 0, W2, nbg, ainv);
-      split2(ctx, inv2, 1, W2, nbg, ani);
-      uint32_t* x2 = zext(ctx, gx, W1, W2, nbg);
-      uint32_t* ge = ctx->ws_t<uint32_t>((size_t)W2 * nbg);
-      modmul_arrays(ctx, mn2, x2, ainv, nbg, ge);
+      uint32_t* a2 = zext(ctx, qa, W1, W2, nbq);
+      uint32_t* an1 = ctx->ws_t<uint32_t>((size_t)W2 * nbq);
+      launch_restride(qan, nbq, scnt, mn2.d_consts + (size_t)C_ONE * W2, an1, nbq, W2, ctx->stream);   // padding lanes: 1
+      uint32_t* inv2 = batch_inverse(ctx, mn2, concat2(ctx, a2, an1, W2, nbq), 2 * nbq, 2 * nbq);
+      uint32_t* qainv = ctx->ws_t<uint32_t>((size_t)W2 * nbq);
+      uint32_t* qani = ctx->ws_t<uint32_t>((size_t)W2 * nbq);
+      split2(ctx, inv2, 0, W2, nbq, qainv);
+      split2(ctx, inv2, 1, W2, nbq, qani);
       // s = ExtractRandonness(ct1) at level two (operations.go:75-91)
       BigU ns_inv;
       if (!hostbig::modinv(N2 % sk->lambda, sk->lambda, ns_inv)) api_throw(PGPU_ERR_NOT_INVERTIBLE, "n^2 is not invertible mod lambda");
       // z = G^(-v) ct1 mod n^3 with v = Decrypt(ct1) (operations.go:81-86) is only ever used modulo n (:88), and
       // G^v = (1 + n)^v = 1 (mod n) whatever v is (the prover requires G = n + 1): z = ct1 (mod n).  No decryption, no G^v,
       // no inversion modulo n^3 -- the same s.
-      uint32_t* z2 = ctx->ws_t<uint32_t>((size_t)W2 * nbg);
-      reduce_mod(ctx, mn2, gc1, W3, z2, nbg);
-      uint32_t* sres = ctx->ws_t<uint32_t>((size_t)W1 * nbg);
+      uint32_t* z2 = ctx->ws_t<uint32_t>((size_t)W2 * nbq);
+      reduce_mod(ctx, mn2, qc1, W3, z2, nbq);
+      uint32_t* qs = ctx->ws_t<uint32_t>((size_t)W1 * nbq);
       if (sk->has_crt && sk->mp.WT * 2 == W1) {                                // z^nsInv mod n through p and q
-        uint32_t* z1 = ctx->ws_t<uint32_t>((size_t)W1 * nbg);
-        reduce_mod(ctx, mn, z2, W2, z1, nbg);
-        sres = pow_n_crt(sk, z1, ns_inv, nbg);
+        uint32_t* z1 = ctx->ws_t<uint32_t>((size_t)W1 * nbq);
+        reduce_mod(ctx, mn, z2, W2, z1, nbq);
+        qs = pow_n_crt(sk, z1, ns_inv, nbq);
       } else {
-        shared_pow(ctx, mn, z2, W2, ns_inv, nbg, sres);                        // z^nsInv mod n
+        shared_pow(ctx, mn, z2, W2, ns_inv, nbq, qs);                          // z^nsInv mod n
       }
+      // ---- per instance
+      uint32_t *ainv = per_inst(qainv, W2), *ani = per_inst(qani, W2), *gan = per_inst(qan, W2), *sres = per_inst(qs, W1),
+               *gb = per_inst(qb, W1);
+      // e = x * a^-1 mod n^2 (ddleq.go:94-99)
+      uint32_t* x2 = zext(ctx, gx, W1, W2, nbg);
+      uint32_t* ge = ctx->ws_t<uint32_t>((size_t)W2 * nbg);
+      modmul_arrays(ctx, mn2, x2, ainv, nbg, ge);
       uint32_t* s3 = zext(ctx, sres, W1, W3, nbg);
       // c = ((s^an * b)^en)^-1 * s^xn ; f = y * c mod n^3   (ddleq.go:103-114)
       // en = e^n mod n^2 (ddleq.go:104) = (x a^-1)^n = x^n (a^n)^-1: both powers are at hand, so an inversion replaces the ladder
@@ -4263,11 +4343,11 @@ int pgpu_ddleq_prove(const pgpu_seckey* sk, size_t batch, const uint8_t* ct1, co
         // ladder with two per-number exponents, computed modulo the group orders of p^3 and q^3 (ord = 2^t m: the odd part
         // through a Montgomery product modulo m, the 2-part from the lowest limbs, then the CRT lift), instead of the ladders
         // s^an | s^xn, (.)^en and a batch inversion modulo n^3.  A non-unit s or b (the reference's ModInverse is then
-        // undefined) keeps the literal sequence below and its error.
-        uint32_t* sb = ctx->ws_t<uint32_t>((size_t)W1 * nbg);
-        modmul_arrays(ctx, mn, sres, gb, nbg, sb);
-        launch_restride(sb, nbg, cnt, mn.d_consts + (size_t)C_ONE * W1, sb, nbg, W1, ctx->stream);
-        if (all_units(ctx, mn, sb, nbg, cnt)) {
+        // undefined) keeps the literal sequence below and its error.  (The unit test is per statement.)
+        uint32_t* sb = ctx->ws_t<uint32_t>((size_t)W1 * nbq);
+        modmul_arrays(ctx, mn, qs, qb, nbq, sb);
+        launch_restride(sb, nbq, scnt, mn.d_consts + (size_t)C_ONE * W1, sb, nbq, W1, ctx->stream);
+        if (all_units(ctx, mn, sb, nbq, scnt)) {
           const uint32_t *es[2], *eb[2];
           uint32_t* ls = ctx->ws_t<uint32_t>(nbg);
           uint32_t* lb = ctx->ws_t<uint32_t>(nbg);
@@ -4329,6 +4409,23 @@ int pgpu_ddleq_prove(const pgpu_seckey* sk, size_t batch, const uint8_t* ct1, co
     pack_result(ctx, eo, W2, nb, batch, e_out, e_stride, std::min(e_stride, mn2.nbytes), mem);
     pack_result(ctx, fo, W3, nb, batch, f_out, ct_stride, mn3.nbytes, mem);
     HIPCHK(hipStreamSynchronize(ctx->stream));
+  }
+}
+
+int pgpu_ddleq_prove(const pgpu_seckey* sk, size_t batch, const uint8_t* ct1, const uint8_t* ct2, size_t ct_stride,
+                     const uint8_t* a, const uint8_t* b, const uint8_t* x, const uint8_t* y, size_t n_stride, uint8_t* alpha,
+                     uint8_t* e_out, size_t e_stride, uint8_t* f_out, int mem) {
+  if (!sk || !ct1 || !ct2 || !a || !b || !x || !y || !alpha || !e_out || !f_out) return fail(PGPU_ERR_INVALID, "null argument");
+  return guarded([&] { ddleq_prove_impl(sk, batch, 1, ct1, ct2, ct_stride, a, b, x, y, n_stride, alpha, e_out, e_stride, f_out, mem); });
+}
+
+int pgpu_ddleq_prove_secpar(const pgpu_seckey* sk, size_t n_statements, size_t secpar, const uint8_t* ct1, const uint8_t* ct2,
+                            size_t ct_stride, const uint8_t* a, const uint8_t* b, const uint8_t* x, const uint8_t* y, size_t n_stride,
+                            uint8_t* alpha, uint8_t* e_out, size_t e_stride, uint8_t* f_out, int mem) {
+  if (!sk || !ct1 || !ct2 || !a || !b || !x || !y || !alpha || !e_out || !f_out) return fail(PGPU_ERR_INVALID, "null argument");
+  if (secpar && n_statements > ((size_t)1 << 31) / secpar) return fail(PGPU_ERR_INVALID, "n_statements * secpar is too large");
+  return guarded([&] {
+    ddleq_prove_impl(sk, n_statements, secpar, ct1, ct2, ct_stride, a, b, x, y, n_stride, alpha, e_out, e_stride, f_out, mem);
   });
 }
 

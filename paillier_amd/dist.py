@@ -116,3 +116,20 @@ def threshold_decrypt_sharded(c, n_servers: int, rank: int, world: int, partial_
     if ce == cb:
         return None, (cb, ce)
     return combine_fn([parts[s, cb:ce].contiguous() for s in range(n_servers)]), (cb, ce)
+
+
+def ddleq_prove_verify_sharded(n_statements: int, rank: int, world: int, prove_fn, verify_fn, device=None):
+    """ProveDDLEQ + VerifyDDLEQProof (ddleq.go:27-53) for `n_statements` statements with the statements sharded over the ranks
+    (BASELINE config 5).  Proofs of different statements are independent: rank r proves and verifies the contiguous slice
+    shard_slice(n_statements, r, world) with the key replicated, and the ONLY cross-rank step is the MIN-reduction of the
+    verdict flag -- no data-path collective (scaling: strong, the whole job is fixed).
+
+      prove_fn   (begin, end) -> proofs of statements [begin, end)      (any object verify_fn understands; [] for an empty slice)
+      verify_fn  (begin, end, proofs) -> sequence of bool, one verdict per statement of the slice
+    Returns ((begin, end), proofs of this rank's slice, verdicts of this rank's slice, every statement of every rank accepted)."""
+    b, e = shard_slice(n_statements, rank, world)
+    proofs = prove_fn(b, e) if e > b else []
+    verdicts = list(verify_fn(b, e, proofs)) if e > b else []
+    if len(verdicts) != e - b:
+        raise ValueError("verify_fn must return one verdict per statement of the slice")
+    return (b, e), proofs, verdicts, bool(min_over_ranks(1 if all(verdicts) else 0, device))

@@ -205,10 +205,37 @@ def verify_ddleq_instances(pk: PublicKey, ct1s: Sequence[int], ct2s: Sequence[in
 # ---------------------------------------------------------------------------------------------------------------
 
 def prove_ddleq(sk: SecretKey, secpar: int, ct1: int, ct2: int, a: int, b: int) -> List[DDLEQProofInstance]:
-    """ddleq.go:27-40 ProveDDLEQ: `secpar` independent instances for ONE statement, proved as one device batch."""
-    xs, ys = sk.pk.random_units(secpar), sk.pk.random_units(secpar)
-    al, es, fs = sk.ProveDDLEQInstancesBatch([ct1] * secpar, [ct2] * secpar, [a] * secpar, [b] * secpar, xs, ys)
-    return [DDLEQProofInstance(x, y, A, e, f) for x, y, A, e, f in zip(xs, ys, al, es, fs)]
+    """ddleq.go:27-40 ProveDDLEQ: `secpar` independent instances for ONE statement, proved as one device batch; what depends
+    on the statement only is computed once (pgpu_ddleq_prove_secpar)."""
+    return prove_ddleq_batch(sk, secpar, [ct1], [ct2], [a], [b])[0]
+
+
+def prove_ddleq_batch(sk: SecretKey, secpar: int, ct1s: Sequence[int], ct2s: Sequence[int], a_s: Sequence[int],
+                      b_s: Sequence[int]) -> List[List[DDLEQProofInstance]]:
+    """ProveDDLEQ (ddleq.go:27-40) for a batch of statements: one proof of `secpar` instances per statement, randomness drawn as
+    crypto/rand does there (utils.go:26-49)."""
+    S = len(ct1s)
+    flat_x, flat_y = sk.pk.random_units(S * secpar), sk.pk.random_units(S * secpar)
+    xs = [flat_x[j * secpar:(j + 1) * secpar] for j in range(S)]
+    ys = [flat_y[j * secpar:(j + 1) * secpar] for j in range(S)]
+    al, es, fs = sk.ProveDDLEQBatch(secpar, ct1s, ct2s, a_s, b_s, xs, ys)
+    return [[DDLEQProofInstance(xs[j][k], ys[j][k], al[j][k], es[j][k], fs[j][k]) for k in range(secpar)] for j in range(S)]
+
+
+def verify_ddleq_proof_batch(pk: PublicKey, ct1s: Sequence[int], ct2s: Sequence[int],
+                             proofs: Sequence[Sequence[DDLEQProofInstance]]) -> List[bool]:
+    """VerifyDDLEQProof (ddleq.go:44-53) for a batch of statements: one verdict per statement (every instance must verify), all
+    instances of all statements in one device batch."""
+    flat = [(c1, c2, p) for c1, c2, pr in zip(ct1s, ct2s, proofs) for p in pr]
+    if not flat:
+        return [True] * len(ct1s)
+    ok = pk.VerifyDDLEQInstancesBatch([t[0] for t in flat], [t[1] for t in flat], [t[2].X for t in flat], [t[2].Y for t in flat],
+                                      [t[2].Alpha for t in flat], [t[2].E for t in flat], [t[2].F for t in flat])
+    out, k = [], 0
+    for pr in proofs:
+        out.append(all(ok[k:k + len(pr)]))
+        k += len(pr)
+    return out
 
 
 def verify_ddleq_proof(pk: PublicKey, ct1: int, ct2: int, proof: Sequence[DDLEQProofInstance]) -> bool:

@@ -115,6 +115,11 @@ int main(int argc, char** argv) {
   CHECK(launches >= 1 && mads > 0 && strncmp(pgpu_ctx_last_kernel(ctx), "vm_", 3) == 0 && pgpu_ctx_last_vm_asm(ctx) >= 1);
   OK(pgpu_decrypt(sk, PGPU_LEVEL_ONE, B, c, cb, out, pb, PGPU_MEM_HOST, PGPU_DECRYPT_DEFAULT, st));
   CHECK(memcmp(out, m, B * pb) == 0 && st[0] == PGPU_LANE_OK);
+  /* the key holder's EncryptWithR (SecretKey embeds PublicKey, paillier.go:59-62): r^n through p^2, q^2 -- the same ciphertexts */
+  { uint8_t* c2 = (uint8_t*)calloc(B, cb);
+    OK(pgpu_encrypt_with_r_sk(sk, PGPU_LEVEL_ONE, B, m, pb, r, pb, c2, cb, PGPU_MEM_HOST));
+    CHECK(memcmp(c2, c, B * cb) == 0 && same(c2, get("enc_c"), cb));
+    free(c2); }
   free(c);
   e = get("dec_c");
   c = pack(e, cb);
@@ -211,6 +216,11 @@ int main(int argc, char** argv) {
     for (s = 0; s < 3; ++s) { size_t i; for (i = 0; i < nt; ++i) { memcpy(un + (s * nt + i) * tcb, cc + i * tcb, tcb); idx[s * nt + i] = s; } }
     OK(pgpu_partial_decrypt_indexed(tpk, 5, 3, shp, shl, 3 * nt, un, tcb, idx, uo, tcb, PGPU_MEM_HOST));
     for (s = 0; s < 3; ++s) CHECK(memcmp(uo + (size_t)s * nt * tcb, parts[s], nt * tcb) == 0);
+    /* one ciphertext batch under the three shares held by one process (pgpu_partial_decrypt_multi) */
+    { uint8_t* mo[3]; uint8_t* const* mop = mo;
+      for (s = 0; s < 3; ++s) mo[s] = (uint8_t*)calloc(nt, tcb);
+      OK(pgpu_partial_decrypt_multi(tpk, 5, 3, shp, shl, nt, cc, tcb, mop, tcb, PGPU_MEM_HOST));
+      for (s = 0; s < 3; ++s) { CHECK(memcmp(mo[s], parts[s], nt * tcb) == 0); free(mo[s]); } }
     /* share-decryption proof: prove with the committed r, compare (dec, E, Z), verify */
     { const entry_t* zc = get("z_c"); size_t nz = (size_t)zc->n, zs = tcb + 48; uint8_t* zcb = pack(zc, tcb); uint8_t* zr = pack(get("z_r"), tcb);
       uint8_t* dec = (uint8_t*)calloc(nz, tcb); uint8_t* ee = (uint8_t*)calloc(nz, 32); uint8_t* zz = (uint8_t*)calloc(nz, zs);
@@ -249,6 +259,25 @@ int main(int argc, char** argv) {
     OK(pgpu_ddleq_verify(pk, nd, c1, c2, cb3, dx, dy, pb, al, cb3, ee, pb2, ff, cb3, st, PGPU_MEM_HOST));
     CHECK(st[0] == 0 && st[1] == 1);
     CHECK(pgpu_ddleq_prove(sk, 2, c1, c2 + cb3, cb3, da, db, dx, dy, pb, al, ee, pb2, ff, PGPU_MEM_HOST) == PGPU_ERR_INVALID);   /* false statement */
+    /* ProveDDLEQ with secpar instances per statement (ddleq.go:27-40, pgpu_ddleq_prove_secpar): the fixture's rows i and i + 4
+     * are two instances of the same statement (make_golden.py: statement = i mod 4), so ONE statement (row 0) with secpar 2
+     * and the draws of rows 0 and 4 must give the committed rows 0 and 4; nd statements with secpar 1 the committed rows */
+    if (nd >= 8) {
+      uint8_t *x2 = (uint8_t*)calloc(2, pb), *y2 = (uint8_t*)calloc(2, pb);
+      memcpy(x2, dx, pb); memcpy(x2 + pb, dx + 4 * pb, pb); memcpy(y2, dy, pb); memcpy(y2 + pb, dy + 4 * pb, pb);
+      OK(pgpu_ddleq_prove_secpar(sk, 1, 2, c1, c2, cb3, da, db, x2, y2, pb, al, ee, pb2, ff, PGPU_MEM_HOST));
+      { const entry_t *wa = get("d_alpha"), *we = get("d_e"), *wf = get("d_f"); uint8_t* w = (uint8_t*)calloc(1, cb3); int k;
+        for (k = 0; k < 2; ++k) {
+          put(wa->hex[4 * k], w, cb3); CHECK(memcmp(al + (size_t)k * cb3, w, cb3) == 0);
+          put(we->hex[4 * k], w, pb2); CHECK(memcmp(ee + (size_t)k * pb2, w, pb2) == 0);
+          put(wf->hex[4 * k], w, cb3); CHECK(memcmp(ff + (size_t)k * cb3, w, cb3) == 0);
+        }
+        free(w); }
+      free(x2); free(y2);
+    }
+    OK(pgpu_ddleq_prove_secpar(sk, nd, 1, c1, c2, cb3, da, db, dx, dy, pb, al, ee, pb2, ff, PGPU_MEM_HOST));
+    CHECK(same(al, get("d_alpha"), cb3) && same(ee, get("d_e"), pb2) && same(ff, get("d_f"), cb3));
+    CHECK(pgpu_ddleq_prove_secpar(sk, 1, 0, c1, c2, cb3, da, db, dx, dy, pb, al, ee, pb2, ff, PGPU_MEM_HOST) == PGPU_ERR_INVALID);
     free(c1); free(c2); free(da); free(db); free(dx); free(dy); free(al); free(ee); free(ff); }
 
   /* ---- error conventions */

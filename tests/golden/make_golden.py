@@ -165,9 +165,48 @@ def proofs_fixture():
     print("wrote proofs.json")
 
 
+def secpar_fixture():
+    """ProveDDLEQ (ddleq.go:27-40) at the reference's test setting secpar = 40 (ddleq_test.go:74-88): ONE statement -- statement 0
+    of proofs.json -- with 40 instances, draws supplied, and statement 1 with 40 more (the second statement pins the
+    statement-major row order of a batch of statements).
+    Each instance is the oracle's proveDDLEQInstance on its own, i.e. what the reference computes per instance WITHOUT hoisting.
+    A file of its own so that the older fixtures stay byte-identical."""
+    import hashlib
+    K = json.load(open(os.path.join(HERE, "keys.json")))
+    k = K["paillier"]["2048"]
+    p, q = int(k["p"], 16), int(k["q"], 16)
+    sk = po.SecretKey(N=p * q, G=p * q + 1, Lambda=(p - 1) * (q - 1))
+    n, n2, n3 = sk.N, sk.N ** 2, sk.N ** 3
+    nb2, nb3 = (n2.bit_length() + 7) // 8, (n3.bit_length() + 7) // 8
+    L2 = po.ENC_LEVEL_TWO
+    st = json.load(open(os.path.join(HERE, "proofs.json")))["ddleq"]["statements"]
+    rng = random.Random(7040)
+    out = {"key_bits": 2048, "secpar": 40, "statements_of": "proofs.json ddleq.statements[0], [1]",
+           "digest_of": "sha256(alpha[768 B] || e[512 B] || f[768 B]), big-endian fixed width", "proofs": []}
+    for j in (0, 1):
+        s = {kk: int(vv, 16) for kk, vv in st[j].items()}
+        inst = []
+        for i in range(40):
+            x, y = po.rand_unit(n, rng), po.rand_unit(n, rng)
+            pf = po.prove_ddleq_instance_xy(sk, po.Ciphertext(s["ct1"], L2), po.Ciphertext(s["ct2"], L2), s["a"], s["b"], x, y)
+            assert po.verify_ddleq_proof_instance(sk, po.Ciphertext(s["ct1"], L2), po.Ciphertext(s["ct2"], L2), pf)
+            rec = {"x": hx(x), "y": hx(y), "bit": int(po.random_oracle_bit(s["ct1"], s["ct2"], x, y, pf.Alpha)),
+                   "digest": hashlib.sha256(fixed(pf.Alpha, nb3) + fixed(pf.E, nb2) + fixed(pf.F, nb3)).hexdigest()}
+            if i < 4:
+                rec.update({"alpha": hx(pf.Alpha), "e": hx(pf.E), "f": hx(pf.F)})
+            inst.append(rec)
+            print("secpar fixture: statement", j, "instance", i, "bit", rec["bit"], flush=True)
+        out["proofs"].append({"statement": j, "instances": inst})
+    with open(os.path.join(HERE, "ddleq_secpar40.json"), "w") as f:
+        json.dump(out, f, indent=0, sort_keys=True)
+    print("wrote ddleq_secpar40.json")
+
+
 def main():
     if len(sys.argv) > 1 and sys.argv[1] == "4096":
         return extra_4096()
+    if len(sys.argv) > 1 and sys.argv[1] == "secpar":
+        return secpar_fixture()
     if len(sys.argv) > 1 and sys.argv[1] == "proofs":
         return proofs_fixture()
     keys = {}

@@ -5,6 +5,7 @@ import ctypes
 import os
 import re
 import subprocess
+import sys
 
 import pytest
 
@@ -91,9 +92,13 @@ def test_asm_generator_model():
             assert mm.split("L_p2m:")[1].split("s_cbranch_scc1 L_p2m")[0].count("v_mad_u64_u32") == 2 * 3 * H
             continue
         if (wl, k) in gen_vm_asm.PAIR4:
-            for lbl, where in (("L_qs", "L_montsq:"), ("L_qm1", "L_montmul:"), ("L_qm2", "L_montmul:")):
+            # four-lane pair kernel: a squaring is one pass of two-row bodies of 2 WL multiplies per lane; a product is ONE pass
+            # too, with two multiplier streams (3 WL multiplies a row); one quotient link per row; no s_nop inside a row
+            for lbl, where, per_row in (("L_qs", "L_montsq:", 2 * wl), ("L_qm", "L_montmul:", 3 * wl)):
                 body = text.split(where)[1].split(lbl + ":")[1].split("s_cbranch_scc1 " + lbl)[0]
-                assert body.count("v_mad_u64_u32") == 2 * 2 * wl          # two rows of 2 WL multiplies per lane
+                assert body.count("v_mad_u64_u32") == 2 * per_row
+                assert body.count("quad_perm:[0,1,0,3]") == 2 and body.count("s_nop") == 0
+            assert g.lds_bytes * 2 <= 160 * 1024
             continue
         if (wl, k) in gen_vm_asm.TRIPLE:
             # three-digit kernel: every pass is a loop of two single-lane rows of 2H multiplies (a squaring: one pass in four
@@ -110,6 +115,7 @@ def test_asm_generator_model():
             for lbl, where in (("L_qs", "L_montsq:"), ("L_qm1", "L_montmul:"), ("L_qm2", "L_montmul:")):
                 body = text.split(where)[1].split(lbl + ":")[1].split("s_cbranch_scc1 " + lbl)[0]
                 assert body.count("v_mad_u64_u32") == 2 * 2 * wl
+                assert body.count("s_nop") == 0 and body.count("s_load_dword") == 0      # Cadj enters once per pass, not per row
             assert g.lds_bytes * 2 <= 160 * 1024
             continue
         if (wl, k) in gen_vm_asm.WAVE_SLICED:
@@ -127,3 +133,19 @@ def test_asm_generator_model():
             row = row.split("s_add_u32 s19, s19, 1")[0]
         bodies = 2 if (wl * k) % 2 == 0 else 1       # the row loop is unrolled by two when the limb count is even
         assert row.count("v_mad_u64_u32") == 2 * wl * bodies
+
+
+def _run_py(code):
+    import subprocess
+    r = subprocess.run([sys.executable, "-c", code], cwd=ROOT, capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr[-2000:]
+    return r.stdout
+
+
+def test_one_hip_runtime_whichever_is_loaded_first():
+    """libpaillier_hip.so and PyTorch must share ONE libamdhip64 in a process, in either load order (two copies: the second
+    runtime to initialise finds no GPU -- VERDICT r2).  No GPU needed: only the mappings are inspected."""
+    pytest.importorskip("torch")
+    first_lib = _run_py("from paillier_amd import api; api.load_library(); import torch; print(len(api.hip_runtimes_mapped()))")
+    first_torch = _run_py("import torch; from paillier_amd import api; api.load_library(); print(len(api.hip_runtimes_mapped()))")
+    assert first_lib.strip().splitlines()[-1] == "1" and first_torch.strip().splitlines()[-1] == "1"

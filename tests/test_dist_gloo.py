@@ -169,3 +169,74 @@ def test_threshold_partial_exchange_combine_two_ranks_cpu(ids, count):
 def test_threshold_partial_exchange_combine_two_ranks_gpu():
     """The same flow with the HIP path doing PartialDecrypt and Combine (two gloo ranks sharing GPU 0)."""
     _run_threshold(2, [1, 3, 5], 9, use_gpu=True)
+
+
+def _ddleq_inputs(n_statements):
+    """statements (ct1, ct2 = NestedRandomize(ct1; a, b), a, b) on a toy key -- the oracle plays the kernels on CPU ranks"""
+    import random
+    from oracle import paillier_oracle as po
+    sk, p, q = po.keygen_seeded(256, 31)
+    n = sk.N
+    rng = random.Random(91)
+    L2 = po.ENC_LEVEL_TWO
+    st = []
+    for _ in range(n_statements):
+        inner = po.encrypt_with_r(sk, rng.randrange(n), po.rand_unit(n, rng)).C
+        ct1 = po.encrypt_with_r_at_level(sk, inner, po.rand_unit(n, rng), L2).C
+        a, b = po.rand_unit(n, rng), po.rand_unit(n, rng)
+        st.append((ct1, po.nested_randomize_with_ab(sk, po.Ciphertext(ct1, L2), a, b).C, a, b))
+    return sk, st
+
+
+def _ddleq_worker(rank, world, port, n_statements, secpar, tamper, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    import random
+    from paillier_amd import dist as pd
+    from oracle import paillier_oracle as po
+    sk, st = _ddleq_inputs(n_statements)
+    L2 = po.ENC_LEVEL_TWO
+    rng = random.Random(1000 + rank)
+
+    def prove_fn(b, e):
+        out = []
+        for (c1, c2, a, bb) in st[b:e]:
+            out.append([po.prove_ddleq_instance_xy(sk, po.Ciphertext(c1, L2), po.Ciphertext(c2, L2), a, bb, po.rand_unit(sk.N, rng),
+                                                   po.rand_unit(sk.N, rng)) for _ in range(secpar)])
+        if tamper is not None and b <= tamper < e:
+            out[tamper - b][0].F ^= 1
+        return out
+
+    def verify_fn(b, e, proofs):
+        return [all(po.verify_ddleq_proof_instance(sk, po.Ciphertext(c1, L2), po.Ciphertext(c2, L2), pf) for pf in pr)
+                for (c1, c2, _, _), pr in zip(st[b:e], proofs)]
+
+    (b, e), proofs, verdicts, all_ok = pd.ddleq_prove_verify_sharded(n_statements, rank, world, prove_fn, verify_fn)
+    q.put((rank, b, e, len(proofs), verdicts, all_ok))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("n_statements,secpar,tamper", [(5, 3, None), (4, 2, 3), (1, 2, None)])
+def test_ddleq_statements_shard_over_two_ranks_cpu(n_statements, secpar, tamper):
+    """BASELINE config 5 on two gloo ranks with the oracle as the kernels: the statements split contiguously (5 over 2 ranks: 3 +
+    2; 1 over 2: the second rank's slice is empty), every rank proves and verifies its own slice, and the MIN-reduced flag tells
+    EVERY rank when some rank's proof failed (a tampered F on the last statement)."""
+    world, port = 2, _free_port()
+    ctxm = mp.get_context("spawn")
+    q = ctxm.Queue()
+    procs = [ctxm.Process(target=_ddleq_worker, args=(r, world, port, n_statements, secpar, tamper, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = sorted(q.get(timeout=300) for _ in range(world))
+    for p in procs:
+        p.join(timeout=120)
+        assert p.exitcode == 0
+    covered = 0
+    for rank, b, e, nproofs, verdicts, all_ok in res:
+        assert b == covered and nproofs == e - b == len(verdicts)
+        covered = e
+        assert all_ok == (tamper is None)                      # the same flag on every rank
+        for j, v in enumerate(verdicts):
+            assert v == (tamper is None or b + j != tamper)
+    assert covered == n_statements

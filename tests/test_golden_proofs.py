@@ -58,6 +58,29 @@ def test_ddleq_fixture_reproduces_from_libgmp():
         assert (pf.Alpha, pf.E, pf.F) == (al[i], es[i], fs[i])
 
 
+def test_ddleq_secpar40_fixture_reproduces_from_libgmp():
+    """tests/golden/ddleq_secpar40.json (make_golden.py secpar): ProveDDLEQ at the reference's test setting secpar = 40
+    (ddleq_test.go:74-88) for two statements -- each instance is proveDDLEQInstance on its own in both oracles (no hoisting)."""
+    sk, p, q = key2048()
+    n = sk.N
+    d = load("ddleq_secpar40.json")
+    st = [{k: int(v, 16) for k, v in s.items()} for s in load("proofs.json")["ddleq"]["statements"]]
+    assert d["secpar"] == 40 and [pr["statement"] for pr in d["proofs"]] == [0, 1]
+    for pr in d["proofs"]:
+        s, ins = st[pr["statement"]], pr["instances"]
+        assert len(ins) == 40 and 0 < sum(i["bit"] for i in ins) < 40
+        xs, ys = H(i["x"] for i in ins), H(i["y"] for i in ins)
+        rep = lambda key: [s[key]] * 40
+        al, es, fs, bits = go.ddleq_prove_batch(n, sk.Lambda, rep("ct1"), rep("ct2"), rep("a"), rep("b"), xs, ys, threads=8)
+        assert bits == [i["bit"] for i in ins]
+        dg = [hashlib.sha256(a.to_bytes(768, "big") + e.to_bytes(512, "big") + f.to_bytes(768, "big")).hexdigest()
+              for a, e, f in zip(al, es, fs)]
+        assert dg == [i["digest"] for i in ins]
+        for i, rec in enumerate(ins[:4]):
+            assert (al[i], es[i], fs[i]) == (int(rec["alpha"], 16), int(rec["e"], 16), int(rec["f"], 16))
+        assert all(go.ddleq_verify_batch(n, rep("ct1"), rep("ct2"), xs, ys, al, es, fs, threads=8))
+
+
 def test_sub_level2_random_oracle_reproduce():
     sk, p, q = key2048()
     P = load("proofs.json")

@@ -4,6 +4,7 @@ committed fixtures.  The compile step alone (header is valid C99, every call typ
 import json
 import os
 import subprocess
+import sys
 
 import pytest
 
@@ -57,3 +58,24 @@ def test_c99_boundary_runs(tmp_path):
     out = subprocess.run([str(exe), str(vec)], capture_output=True, text=True, timeout=600)
     assert out.returncode == 0, out.stdout + out.stderr
     assert "c abi ok" in out.stdout
+
+
+@pytest.mark.gpu
+def test_library_first_then_torch_on_the_gpu():
+    """The order that used to fail (`No HIP GPUs are available` once torch initialised after the library): create a
+    context and run a batch FIRST, then initialise torch's CUDA state and use both on the same device."""
+    import subprocess
+    code = (
+        "import paillier_amd as pa\n"
+        "from paillier_amd import api\n"
+        "ctx = pa.Context(0)\n"
+        "m = pa.Modulus(ctx, (1 << 127) - 1)\n"
+        "assert m.exp_batch([3, 5], 65537) == [pow(3, 65537, (1 << 127) - 1), pow(5, 65537, (1 << 127) - 1)]\n"
+        "import torch\n"
+        "assert torch.cuda.is_available()\n"
+        "t = torch.arange(8, device='cuda').sum().item()\n"
+        "assert t == 28 and len(api.hip_runtimes_mapped()) == 1\n"
+        "assert m.exp_batch([7], 3) == [343]\n"
+        "print('ok')\n")
+    r = subprocess.run([sys.executable, "-c", code], cwd=ROOT, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0 and r.stdout.strip().endswith("ok"), (r.stdout[-500:], r.stderr[-2000:])

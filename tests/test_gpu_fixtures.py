@@ -73,6 +73,69 @@ def test_ddleq_2048_prove_and_verify(ctx, keys):
     assert "cannot prove re-encryption" in str(ei.value)
 
 
+def _digests(al, es, fs):
+    return [hashlib.sha256(a.to_bytes(768, "big") + e.to_bytes(512, "big") + f.to_bytes(768, "big")).hexdigest()
+            for a, e, f in zip(al, es, fs)]
+
+
+def test_ddleq_2048_secpar40_hoisted(ctx, keys):
+    """pgpu_ddleq_prove_secpar (ProveDDLEQ, ddleq.go:27-40, at the reference's test setting secpar = 40: ddleq_test.go:74-88) for
+    two statements: the sanity check, a^n, a^-1 and ExtractRandonness(ct1) are computed once per statement, and every Alpha / E /
+    F must be byte for byte what the oracle's proveDDLEQInstance gave for that instance on its own (ddleq_secpar40.json)."""
+    import paillier_amd as pa
+    from paillier_amd import protocols as pr
+    pk, sk = keys
+    d = load("ddleq_secpar40.json")
+    st = [{k: int(v, 16) for k, v in s.items()} for s in load("proofs.json")["ddleq"]["statements"]]
+    ss = [st[p["statement"]] for p in d["proofs"]]
+    xs = [H(i["x"] for i in p["instances"]) for p in d["proofs"]]
+    ys = [H(i["y"] for i in p["instances"]) for p in d["proofs"]]
+    col = lambda key: [s[key] for s in ss]
+    al, es, fs = sk.ProveDDLEQBatch(40, col("ct1"), col("ct2"), col("a"), col("b"), xs, ys)
+    assert ctx.last_vm_asm() > 0
+    for j, p in enumerate(d["proofs"]):
+        ins = p["instances"]
+        assert _digests(al[j], es[j], fs[j]) == [i["digest"] for i in ins], j
+        for k, rec in enumerate(ins[:4]):
+            assert (al[j][k], es[j][k], fs[j][k]) == (int(rec["alpha"], 16), int(rec["e"], 16), int(rec["f"], 16))
+        bits = [int(e != x or f != y) for e, f, x, y in zip(es[j], fs[j], xs[j], ys[j])]
+        assert bits == [i["bit"] for i in ins] and 0 < sum(bits) < 40
+    # one statement alone (n_statements = 1), and the secpar = 1 entry point on the same rows: the same integers
+    a1, e1, f1 = sk.ProveDDLEQBatch(40, col("ct1")[1:], col("ct2")[1:], col("a")[1:], col("b")[1:], xs[1:], ys[1:])
+    assert (a1[0], e1[0], f1[0]) == (al[1], es[1], fs[1])
+    a2, e2, f2 = sk.ProveDDLEQInstancesBatch([ss[0]["ct1"]] * 40, [ss[0]["ct2"]] * 40, [ss[0]["a"]] * 40, [ss[0]["b"]] * 40, xs[0], ys[0])
+    assert (a2, e2, f2) == (al[0], es[0], fs[0])
+    # VerifyDDLEQProof per statement (ddleq.go:44-53): all instances of a statement must verify
+    proofs = [[pr.DDLEQProofInstance(xs[j][k], ys[j][k], al[j][k], es[j][k], fs[j][k]) for k in range(40)] for j in range(2)]
+    assert pr.verify_ddleq_proof_batch(pk, col("ct1"), col("ct2"), proofs) == [True, True]
+    proofs[1][17] = pr.DDLEQProofInstance(xs[1][17], ys[1][17], al[1][17], es[1][17], fs[1][17] ^ 1)
+    assert pr.verify_ddleq_proof_batch(pk, col("ct1"), col("ct2"), proofs) == [True, False]
+    # a false statement among true ones: the reference panics (ddleq.go:68)
+    with pytest.raises(pa.PaillierHipError) as ei:
+        sk.ProveDDLEQBatch(40, col("ct1"), [ss[0]["ct2"], ss[0]["ct2"]], col("a"), col("b"), xs, ys)
+    assert "cannot prove re-encryption" in str(ei.value)
+
+
+def test_ddleq_2048_secpar16_from_the_64_instance_fixture(ctx, keys):
+    """The 64 committed instances of proofs.json are 16 instances of each of 4 statements: as ONE pgpu_ddleq_prove_secpar call
+    (4 statements, secpar 16; also with the p-adic split forced) they must land on the same digests."""
+    pk, sk = keys
+    d = load("proofs.json")["ddleq"]
+    st = [{k: int(v, 16) for k, v in s.items()} for s in d["statements"]]
+    ins = d["instances"]
+    by = [[i for i in ins if i["s"] == j] for j in range(4)]
+    xs, ys = [H(i["x"] for i in b) for b in by], [H(i["y"] for i in b) for b in by]
+    col = lambda key: [s[key] for s in st]
+    for lanes_wanted in (0, 1):
+        ctx.set_flag("lanes_wanted", lanes_wanted)
+        try:
+            al, es, fs = sk.ProveDDLEQBatch(16, col("ct1"), col("ct2"), col("a"), col("b"), xs, ys)
+        finally:
+            ctx.set_flag("lanes_wanted", 0)
+        for j in range(4):
+            assert _digests(al[j], es[j], fs[j]) == [i["digest"] for i in by[j]], (lanes_wanted, j)
+
+
 def test_ddleq_2048_kernels_off(ctx, keys):
     """The same fixture with the assembly / pair kernels switched off (hipcc VM kernels, ladders modulo n^3 instead of
     p^3, q^3): every implementation of the path must land on the committed numbers."""

@@ -1,14 +1,20 @@
 #!/usr/bin/env python3
-"""Instruction mix of the three-digit kernel vm_asm_74_48 (level-two Encrypt / NestedRandomize / DDLEQ), counted from the
-generator's own output: issue slots per squaring and per product (loop bodies times their trip counts).  At one wave per
-SIMD every instruction -- scalar, LDS and waits included -- takes an issue slot of its own."""
+"""Instruction mix of the multi-lane digit kernels, counted from the generator's own output: issue slots per squaring and per
+product (loop bodies times their trip counts).  At one wave per SIMD every instruction -- scalar, LDS and waits included --
+takes an issue slot of its own.
+  asm_mix_triple.py [H]        the three-digit kernel vm_asm_<H>_48 (level-two Encrypt / NestedRandomize / DDLEQ; default 74)
+  asm_mix_triple.py 37 64      the four-lane pair kernel vm_asm_37_64 (PartialDecrypt / the mod-n^2 stages at 16 384 numbers)
+  asm_mix_triple.py 74 32      the two-lane pair kernel vm_asm_74_32 (Encrypt-2048)"""
 import os, sys, re, json, collections
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, os.path.join(ROOT, "paillier_amd", "csrc"))
 import gen_vm_asm
 
 H = int(sys.argv[1]) if len(sys.argv) > 1 else 74
-lines = gen_vm_asm.make_gen(H, 48).generate().splitlines()
+TAG = int(sys.argv[2]) if len(sys.argv) > 2 else 48
+GEN = gen_vm_asm.make_gen(H, TAG)
+lines = GEN.generate().splitlines()
+ROWS = {48: H, 64: 2 * H, 32: H}[TAG]                      # rows of a pass
 
 
 def classify(seg):
@@ -46,7 +52,8 @@ def region(start, end_label_branch):
         if m:
             lbl = m.group(1)
             e = next(x for x in range(k, j) if lines[x].strip() == f"s_cbranch_scc1 {lbl}")
-            trips = (H - (1 if H % 2 else 2)) // 2
+            peeled = 0 if TAG == 64 else (1 if ROWS % 2 else 2)
+            trips = (ROWS - peeled) // 2
             body = classify(lines[k:e + 1])
             for key, v in body.items():
                 tot[key] += v * trips
@@ -59,9 +66,13 @@ def region(start, end_label_branch):
 
 
 out = {}
-for name, lbl, useful in (("squaring", "L_montsq", 8 * H * H / 4), ("product", "L_montmul", 12 * H * H / 4)):
+# multiplies the algorithm needs, per lane of a number: three-digit kernel 8 H^2 / 12 H^2 over 4 lanes; pair kernels (digit of
+# D limbs) 4 D^2 / 6 D^2 over 4 lanes (GenQ4: one-pass product) or 4 D^2 / 6 D^2 needed of 4 D^2 / 8 D^2 executed over 2 lanes (GenQ)
+D = ROWS
+USEFUL = {48: (8 * H * H / 4, 12 * H * H / 4), 64: (4 * D * D / 4, 6 * D * D / 4), 32: (4 * D * D / 2, 6 * D * D / 2)}[TAG]
+for name, lbl, useful in (("squaring", "L_montsq", USEFUL[0]), ("product", "L_montmul", USEFUL[1])):
     t = region(lbl, None)
     slots = sum(t.values())
     out[name] = dict(t, issue_slots=slots, valu=t["mad"] + t["valu_other"], counted_mads_per_lane=useful,
                      counted_share_of_issue_slots=round(useful / slots, 4), mad_share_of_valu=round(t["mad"] / (t["mad"] + t["valu_other"]), 4))
-print(json.dumps({"kernel": f"vm_asm_{H}_48", **out}, indent=1))
+print(json.dumps({"kernel": f"vm_asm_{H}_{TAG}", "vgprs": GEN.n_vgpr, "lds_bytes": GEN.lds_bytes, **out}, indent=1))

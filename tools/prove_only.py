@@ -1,5 +1,7 @@
 #!/usr/bin/env python3
-"""DDLEQ prover alone (16384 instances, 2048-bit), for profiling: prints the time of each call."""
+"""DDLEQ prover alone (16384 instances, 2048-bit), for profiling: prints the time of each call.
+   prove_only.py [instances] [secpar]     secpar > 1: instances / secpar statements through pgpu_ddleq_prove_secpar
+   PGPU_PROFILE_DUMP=1 lists every profiled VM launch of a call."""
 import json, os, sys, time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
@@ -13,14 +15,17 @@ n = p * q
 dev = torch.device("cuda", 0)
 ctx = pa.Context(0, torch.cuda.current_stream().cuda_stream)
 pk = pa.PublicKey(ctx, n); sk = pa.SecretKey(ctx, pk, (p - 1) * (q - 1))
-B = int(sys.argv[1]) if len(sys.argv) > 1 else 16384
+SP = int(sys.argv[2]) if len(sys.argv) > 2 else 1
+BI = int(sys.argv[1]) if len(sys.argv) > 1 else 16384          # instances
+B = BI // SP                                                    # statements
+BI = B * SP
 rg = np.random.default_rng(5)
-def below(mod, nb):
-    raw = rg.integers(0, 256, size=(B, nb), dtype=np.uint8); raw[:, 0] %= np.uint8(max(1, min(255, mod >> (8 * (nb - 1))))); return raw
-def unit():
-    a = below(n, 256); a[:, -1] |= 1; return a
+def below(mod, nb, cnt=None):
+    raw = rg.integers(0, 256, size=(cnt or B, nb), dtype=np.uint8); raw[:, 0] %= np.uint8(max(1, min(255, mod >> (8 * (nb - 1))))); return raw
+def unit(cnt=None):
+    a = below(n, 256, cnt); a[:, -1] |= 1; return a
 tb = lambda a: torch.from_numpy(a).to(dev)
-msg, r1, r2, a_, b_, x_, y_ = below(n, 256), unit(), unit(), unit(), unit(), unit(), unit()
+msg, r1, r2, a_, b_, x_, y_ = below(n, 256), unit(), unit(), unit(), unit(), unit(BI), unit(BI)
 inner = torch.zeros((B, 512), dtype=torch.uint8, device=dev); ct1 = torch.zeros((B, 768), dtype=torch.uint8, device=dev)
 pk.encrypt_with_r_raw(B, tb(msg).data_ptr(), 256, tb(r1).data_ptr(), 256, inner.data_ptr(), 512, MEM_DEVICE)
 pk.encrypt_with_r_raw(B, inner.data_ptr(), 512, tb(r2).data_ptr(), 256, ct1.data_ptr(), 768, MEM_DEVICE, level=1)
@@ -32,10 +37,13 @@ m2.exp_raw(B, da.data_ptr(), 256, n.to_bytes(256, "big"), 256, 0, an.data_ptr(),
 m3.exp_raw(B, ct1.data_ptr(), 768, an.data_ptr(), 512, 512, t3.data_ptr(), 768, MEM_DEVICE)
 m3.exp_raw(B, db.data_ptr(), 256, (n * n).to_bytes(512, "big"), 512, 0, bn2.data_ptr(), 768, MEM_DEVICE)
 m3.mul_raw(B, t3.data_ptr(), 768, bn2.data_ptr(), 768, ct2.data_ptr(), 768, MEM_DEVICE)
-al = torch.zeros((B, 768), dtype=torch.uint8, device=dev); pe = torch.zeros((B, 512), dtype=torch.uint8, device=dev); pf = torch.zeros((B, 768), dtype=torch.uint8, device=dev)
+al = torch.zeros((BI, 768), dtype=torch.uint8, device=dev); pe = torch.zeros((BI, 512), dtype=torch.uint8, device=dev); pf = torch.zeros((BI, 768), dtype=torch.uint8, device=dev)
 torch.cuda.synchronize()
 print("PROVE_BEGIN", flush=True)
 for _ in range(2):
     t = time.perf_counter()
-    sk.ddleq_prove_raw(B, ct1.data_ptr(), ct2.data_ptr(), da.data_ptr(), db.data_ptr(), dx.data_ptr(), dy.data_ptr(), al.data_ptr(), pe.data_ptr(), pf.data_ptr(), MEM_DEVICE)
-    print("prove", B, (time.perf_counter() - t) * 1e3, "ms", ctx.last_profile(), flush=True)
+    if SP == 1:
+        sk.ddleq_prove_raw(B, ct1.data_ptr(), ct2.data_ptr(), da.data_ptr(), db.data_ptr(), dx.data_ptr(), dy.data_ptr(), al.data_ptr(), pe.data_ptr(), pf.data_ptr(), MEM_DEVICE)
+    else:
+        sk.ddleq_prove_secpar_raw(B, SP, ct1.data_ptr(), ct2.data_ptr(), da.data_ptr(), db.data_ptr(), dx.data_ptr(), dy.data_ptr(), al.data_ptr(), pe.data_ptr(), pf.data_ptr(), MEM_DEVICE)
+    print("prove", B, "x", SP, (time.perf_counter() - t) * 1e3, "ms", ctx.last_profile(), flush=True)
