@@ -76,7 +76,9 @@ int pgpu_ctx_last_profile(pgpu_ctx* ctx, double* vm_ms, int* vm_launches, double
  * "triple" (default 1): ladders modulo n^3 on the three-digit kernel.  "shared_chain" (default 1): several shares on the
  * same ciphertexts share one chain of squarings (pgpu_partial_decrypt_multi), runs of units under one share become
  * shared-exponent ladders (pgpu_partial_decrypt_indexed).  "lift" (default 1): level-two Encrypt computes r^(n^2) mod n^3
- * as (r^n mod n^2)^n mod n^3.  All of these change the work done, never a result (the tests switch them off to compare).
+ * as (r^n mod n^2)^n mod n^3.  "side" (default 1): a call may issue work that depends on no ladder in flight to a second
+ * stream of the context (the DDLEQ prover's per-statement chains run beside its big launches); 0 keeps one stream.
+ * All of these change the work done, never a result (the tests switch them off to compare).
  * "lanes_wanted" (default 0 = fill the chip): the lane count below which a batch is re-sliced over more lanes per
  * number; 1 keeps every modulus on its natural kernel shape whatever the batch size (tests).
  * "fair" (default 1, process-wide): programs carry wave priorities that fall with progress, so that the waves sharing a SIMD

@@ -85,6 +85,20 @@ struct pgpu_ctx {
   bool use_shared_chain = true;   // several shared exponents on ONE base share the chain of squarings (pgpu_partial_decrypt_multi)
   bool use_lift = true;           // level-two Encrypt: r^(n^2) mod n^3 as (r^n mod n^2)^n mod n^3
   size_t lanes_wanted = 0;   // 0: default occupancy target; tests set 1 to run every modulus at its natural shape
+  // A second stream for work of a call that depends on no ladder in flight (SideStream below; the DDLEQ prover's
+  // per-statement chains run beside its big launches).  pgpu_ctx_set_flag("side", 0): everything on the one stream.
+  bool use_side = true;
+  hipStream_t side = nullptr;
+  std::vector<hipEvent_t> sync_evs;
+  size_t sync_used = 0;
+  hipEvent_t next_sync_ev() {
+    if (sync_used == sync_evs.size()) {
+      hipEvent_t e;
+      HIPCHK(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+      sync_evs.push_back(e);
+    }
+    return sync_evs[sync_used++];
+  }
 
   void bind() { HIPCHK(hipSetDevice(device)); }
 
@@ -102,6 +116,7 @@ struct pgpu_ctx {
       chunks.push_back(c);
     }
     for (auto& c : chunks) c.used = 0;
+    sync_used = 0;
     for (auto& h : host_keep) wipe_vec(h);   // ladder programs encode secret exponents (p - 1, q - 1, shares)
     host_keep.clear();
     evs_used = 0;
@@ -141,6 +156,7 @@ struct pgpu_ctx {
   }
   // zero the workspace (intermediate values of the last call, ladder programs of secret exponents)
   void wipe_ws() {
+    if (side) (void)hipStreamSynchronize(side);
     for (auto& c : chunks) (void)hipMemsetAsync(c.p, 0, c.cap, stream);
     (void)hipStreamSynchronize(stream);
     for (auto& h : host_keep) wipe_vec(h);
@@ -149,7 +165,54 @@ struct pgpu_ctx {
     wipe_ws();
     for (auto& c : chunks) (void)hipFree(c.p);
     for (auto& e : evs) { (void)hipEventDestroy(e.a); (void)hipEventDestroy(e.b); }
+    for (auto& e : sync_evs) (void)hipEventDestroy(e);
+    if (side) (void)hipStreamDestroy(side);
     if (own_stream) (void)hipStreamDestroy(stream);
+  }
+};
+
+// Work of ONE call on two streams.  Every helper of this file issues to ctx->stream; between enter() and leave() that is the
+// side stream.  enter(after) orders the side work behind an event of the main stream (mark()), leave() goes back WITHOUT making
+// the main stream wait, join() makes the main stream wait for everything the side stream was given.  Host-side synchronisation
+// inside side work (the root of an inversion tree goes through the host) waits for the side stream only: issue the main
+// stream's long launch BEFORE entering, and it runs meanwhile.  Disabled (ctx->use_side == false): everything stays on the one
+// stream, in program order -- the same results.
+struct SideStream {
+  pgpu_ctx* c;
+  hipStream_t main_stream;
+  bool on, entered = false, dirty = false;
+  explicit SideStream(pgpu_ctx* c_) : c(c_), main_stream(c_->stream), on(c_->use_side) {
+    if (on && !c->side) HIPCHK(hipStreamCreateWithFlags(&c->side, hipStreamNonBlocking));
+  }
+  hipEvent_t mark() {                       // "everything issued to the main stream so far"
+    if (!on) return nullptr;
+    hipEvent_t e = c->next_sync_ev();
+    HIPCHK(hipEventRecord(e, main_stream));
+    return e;
+  }
+  void enter(hipEvent_t after) {
+    if (!on) return;
+    if (after) HIPCHK(hipStreamWaitEvent(c->side, after, 0));
+    c->stream = c->side;
+    entered = dirty = true;
+  }
+  void leave() {
+    if (!on) return;
+    c->stream = main_stream;
+    entered = false;
+  }
+  void join() {
+    if (!on || !dirty) return;
+    if (entered) leave();
+    hipEvent_t e = c->next_sync_ev();
+    HIPCHK(hipEventRecord(e, c->side));
+    HIPCHK(hipStreamWaitEvent(main_stream, e, 0));
+    dirty = false;
+  }
+  ~SideStream() {                           // error paths: never leave the context on the side stream or the side stream busy
+    if (!on) return;
+    c->stream = main_stream;
+    if (dirty) (void)hipStreamSynchronize(c->side);
   }
 };
 
@@ -1054,6 +1117,7 @@ int pgpu_ctx_set_flag(pgpu_ctx* ctx, const char* name, int value) {
   if (strcmp(name, "triple") == 0) { ctx->use_triple = value != 0; return PGPU_OK; }
   if (strcmp(name, "shared_chain") == 0) { ctx->use_shared_chain = value != 0; return PGPU_OK; }
   if (strcmp(name, "lift") == 0) { ctx->use_lift = value != 0; return PGPU_OK; }
+  if (strcmp(name, "side") == 0) { ctx->use_side = value != 0; return PGPU_OK; }
   if (strcmp(name, "fair") == 0) { g_wave_priorities.store(value != 0, std::memory_order_relaxed); return PGPU_OK; }   // process-wide (see above)
   if (strcmp(name, "lanes_wanted") == 0) { ctx->lanes_wanted = value > 0 ? (size_t)value : 0; return PGPU_OK; }
   if (strcmp(name, "cu_partition") == 0) {
@@ -4201,6 +4265,33 @@ static void ddleq_prove_impl(const pgpu_seckey* sk, size_t S, size_t secpar, con
     };
     uint32_t *c1 = expand(c1s, W3), *c2 = expand(c2s, W3);
     const BigU &N = pk->N, &N2 = mn2.N;
+    // ---- what depends on the STATEMENT only and on no ladder of this call goes to the side stream, beside the big launches
+    // (the GPU was busy, but with ~800 small launches in a row between the ladders: 30 of 188 ms per 16 384 instances):
+    //   s = ExtractRandonness(ct1) (ddleq.go:103) for every statement -- a latency-bound launch beside the a^n | x^n
+    //   launch, which fills half the chip; then, behind a^n, the inversion tree for a^-1 | (a^n)^-1 and the unit test of s b
+    //   beside the Alpha ladders.  Which statements have an instance with challenge bit 1 is not known yet: all are done
+    //   (the side work is bound by launch latencies, not by its width).
+    SideStream side(ctx);
+    BigU ns_inv;
+    if (!hostbig::modinv(N2 % sk->lambda, sk->lambda, ns_inv)) api_throw(PGPU_ERR_NOT_INVERTIBLE, "n^2 is not invertible mod lambda");
+    uint32_t* qs = nullptr;                                  // s per statement (W1 limbs, stride nbs)
+    side.enter(side.mark());
+    {
+      // s = ExtractRandonness(ct1) at level two (operations.go:75-91): z = G^(-v) ct1 mod n^3 with v = Decrypt(ct1)
+      // (operations.go:81-86) is only ever used modulo n (:88), and G^v = (1 + n)^v = 1 (mod n) whatever v is (the prover
+      // requires G = n + 1): z = ct1 (mod n).  No decryption, no G^v, no inversion modulo n^3 -- the same s.
+      uint32_t* z2 = ctx->ws_t<uint32_t>((size_t)W2 * nbs);
+      reduce_mod(ctx, mn2, c1s, W3, z2, nbs);
+      if (sk->has_crt && sk->mp.WT * 2 == W1) {                                // z^nsInv mod n through p and q
+        uint32_t* z1 = ctx->ws_t<uint32_t>((size_t)W1 * nbs);
+        reduce_mod(ctx, mn, z2, W2, z1, nbs);
+        qs = pow_n_crt(sk, z1, ns_inv, nbs);
+      } else {
+        qs = ctx->ws_t<uint32_t>((size_t)W1 * nbs);
+        shared_pow(ctx, mn, z2, W2, ns_inv, nbs, qs);                          // z^nsInv mod n
+      }
+    }
+    side.leave();
     // ---- sanity check (ddleq.go:62-69): ct1^(a^n mod n^2) * b^(n^2) mod n^3 == ct2, else the reference panics -- once per
     // statement.  Independent exponentiations of the same shape share a launch (the chip is filled better and, for the half-size
     // batches of the response, a latency-bound launch is saved outright): a^n (S numbers) | x^n (S secpar numbers), then the
@@ -4219,6 +4310,7 @@ static void ddleq_prove_impl(const pgpu_seckey* sk, size_t S, size_t secpar, con
       split_ab(ctx, axn, nbs, nb, 0, W2, an);
       split_ab(ctx, axn, nbs, nb, 1, W2, xn);
     }
+    hipEvent_t an_ready = side.mark();
     uint32_t* bn2 = ctx->ws_t<uint32_t>((size_t)W3 * nbs);
     uint32_t* t3 = ctx->ws_t<uint32_t>((size_t)W3 * nb);
     uint32_t* san = ctx->ws_t<uint32_t>((size_t)W3 * nbs);
@@ -4240,6 +4332,34 @@ static void ddleq_prove_impl(const pgpu_seckey* sk, size_t S, size_t secpar, con
     int32_t* d_ok = ctx->ws_t<int32_t>(nbs);
     launch_equal(san, c2s, W3, nbs, S, d_ok, ctx->stream);
     std::vector<int32_t> hok(S);
+    // ---- side stream, behind a^n (the Alpha ladders above are in flight on the main stream): a^-1 and (a^n)^-1 modulo n^2 for
+    // every statement from ONE inversion tree (both batches side by side; a non-unit is flagged per lane and matters only if
+    // one of its instances draws challenge bit 1), and the unit test of s b for the one-ladder form of the response
+    uint32_t *qainv = ctx->ws_t<uint32_t>((size_t)W2 * nbs), *qani = ctx->ws_t<uint32_t>((size_t)W2 * nbs);
+    int32_t* d_badinv = ctx->ws_t<int32_t>(2 * nbs);
+    bool any_badinv = false, sb_units = false;
+    const bool one_ladder = crt3 && ctx->use_lift && sk->eo_p.ok && sk->eo_q.ok && sk->eo_p.w == sk->eo_q.w &&
+                            W2 <= 2 * sk->eo_p.modd.WT && W2 <= 2 * sk->eo_q.modd.WT;
+    side.enter(an_ready);
+    {
+      uint32_t* a1 = ctx->ws_t<uint32_t>((size_t)W1 * nbs);
+      launch_restride(al, nbs, S, mn.d_consts + (size_t)C_ONE * W1, a1, nbs, W1, ctx->stream);      // padding lanes: 1
+      uint32_t* a2 = zext(ctx, a1, W1, W2, nbs);
+      uint32_t* an1 = ctx->ws_t<uint32_t>((size_t)W2 * nbs);
+      launch_restride(an, nbs, S, mn2.d_consts + (size_t)C_ONE * W2, an1, nbs, W2, ctx->stream);
+      uint32_t* inv2 = batch_inverse(ctx, mn2, concat2(ctx, a2, an1, W2, nbs), 2 * nbs, 2 * nbs, d_badinv, &any_badinv);
+      split2(ctx, inv2, 0, W2, nbs, qainv);
+      split2(ctx, inv2, 1, W2, nbs, qani);
+      if (one_ladder) {
+        uint32_t* sb = ctx->ws_t<uint32_t>((size_t)W1 * nbs);
+        modmul_arrays(ctx, mn, qs, bl, nbs, sb);
+        launch_restride(sb, nbs, S, mn.d_consts + (size_t)C_ONE * W1, sb, nbs, W1, ctx->stream);
+        sb_units = all_units(ctx, mn, sb, nbs, S);
+      }
+    }
+    side.leave();
+    // (a device-to-host copy into pageable memory holds the host until the stream has got there: it comes after the side work
+    // has been issued, not before)
     HIPCHK(hipMemcpyAsync(hok.data(), d_ok, S * 4, hipMemcpyDeviceToHost, ctx->stream));
     HIPCHK(hipStreamSynchronize(ctx->stream));
     for (size_t i = 0; i < S; ++i)
@@ -4260,73 +4380,42 @@ static void ddleq_prove_impl(const pgpu_seckey* sk, size_t S, size_t secpar, con
     std::vector<int32_t> hch(batch);
     HIPCHK(hipMemcpyAsync(hch.data(), chal, batch * 4, hipMemcpyDeviceToHost, ctx->stream));
     HIPCHK(hipStreamSynchronize(ctx->stream));
+    side.join();                                             // the per-statement values are needed from here on
     // default outputs: e = x, f = y (chalBit false)
     uint32_t* eo = zext(ctx, xl, W1, W2, nb);
     uint32_t* fo = zext(ctx, yl, W1, W3, nb);
-    // instances with challenge bit 1, the statements they belong to (each once) and where an instance finds its statement
-    std::vector<uint32_t> idx, sidx, pos;
+    // instances with challenge bit 1 and the statement each belongs to
+    std::vector<uint32_t> idx, sti;
     for (size_t i = 0; i < batch; ++i)
       if (hch[i]) {
-        const uint32_t st = (uint32_t)(i / secpar);
-        if (sidx.empty() || sidx.back() != st) sidx.push_back(st);
         idx.push_back((uint32_t)i);
-        pos.push_back((uint32_t)sidx.size() - 1);
+        sti.push_back((uint32_t)(i / secpar));
       }
     if (!idx.empty()) {
       const size_t cnt = idx.size(), nbg = round_up(cnt, VM_BLOCK);
-      const size_t scnt = sidx.size(), nbq = round_up(scnt, VM_BLOCK);
+      if (any_badinv) {      // ModInverse(a, n^2) of a non-unit a (ddleq.go:95) is undefined in the reference: refuse, as before
+        std::vector<int32_t> hb(2 * nbs);
+        HIPCHK(hipMemcpyAsync(hb.data(), d_badinv, 2 * nbs * 4, hipMemcpyDeviceToHost, ctx->stream));
+        HIPCHK(hipStreamSynchronize(ctx->stream));
+        for (uint32_t st : sti)
+          if (hb[st] || hb[nbs + st])
+            api_throw(PGPU_ERR_NOT_INVERTIBLE, "ModInverse: an element of the batch is not invertible modulo the modulus");
+      }
       uint32_t* d_idx = ctx->upload_words(idx);
-      uint32_t* d_sidx = ctx->upload_words(sidx);
-      uint32_t* d_pos = ctx->upload_words(pos);
+      uint32_t* d_sti = ctx->upload_words(sti);
       auto gat = [&](const uint32_t* in, int w) {            // per-instance array -> the compacted instances
         uint32_t* o = ctx->ws_t<uint32_t>((size_t)w * nbg);
         launch_gather(in, nb, d_idx, cnt, o, nbg, w, ctx->stream);
         return o;
       };
-      auto gats = [&](const uint32_t* in, int w) {           // per-statement array -> the compacted statements
-        uint32_t* o = ctx->ws_t<uint32_t>((size_t)w * nbq);
-        launch_gather(in, nbs, d_sidx, scnt, o, nbq, w, ctx->stream);
-        return o;
-      };
-      auto per_inst = [&](uint32_t* in, int w) {             // compacted-statement array -> one entry per compacted instance
-        if (secpar == 1) return in;                          // (secpar = 1: the two compactions coincide)
+      auto per_inst = [&](const uint32_t* in, int w) {       // per-statement array -> one entry per compacted instance
         uint32_t* o = ctx->ws_t<uint32_t>((size_t)w * nbg);
-        launch_gather(in, nbq, d_pos, cnt, o, nbg, w, ctx->stream);
+        launch_gather(in, nbs, d_sti, cnt, o, nbg, w, ctx->stream);
         return o;
       };
       uint32_t *gx = gat(xl, W1), *gy = gat(yl, W1), *gxn = gat(xn, W2);
-      // ---- once per statement: a^-1, (a^n)^-1, s, the unit test of s b
-      uint32_t *qa = gats(al, W1), *qb = gats(bl, W1), *qc1 = gats(c1s, W3), *qan = gats(an, W2);
-      // padding lanes of the compacted batch must be invertible: fill a with 1 there
-      launch_restride(qa, nbq, scnt, mn.d_consts + (size_t)C_ONE * W1, qa, nbq, W1, ctx->stream);
-      // a^-1 and (a^n)^-1 modulo n^2 (the second one for en below) from ONE inversion tree: both batches side by side
-      uint32_t* a2 = zext(ctx, qa, W1, W2, nbq);
-      uint32_t* an1 = ctx->ws_t<uint32_t>((size_t)W2 * nbq);
-      launch_restride(qan, nbq, scnt, mn2.d_consts + (size_t)C_ONE * W2, an1, nbq, W2, ctx->stream);   // padding lanes: 1
-      uint32_t* inv2 = batch_inverse(ctx, mn2, concat2(ctx, a2, an1, W2, nbq), 2 * nbq, 2 * nbq);
-      uint32_t* qainv = ctx->ws_t<uint32_t>((size_t)W2 * nbq);
-      uint32_t* qani = ctx->ws_t<uint32_t>((size_t)W2 * nbq);
-      split2(ctx, inv2, 0, W2, nbq, qainv);
-      split2(ctx, inv2, 1, W2, nbq, qani);
-      // s = ExtractRandonness(ct1) at level two (operations.go:75-91)
-      BigU ns_inv;
-      if (!hostbig::modinv(N2 % sk->lambda, sk->lambda, ns_inv)) api_throw(PGPU_ERR_NOT_INVERTIBLE, "n^2 is not invertible mod lambda");
-      // z = G^(-v) ct1 mod n^3 with v = Decrypt(ct1) (operations.go:81-86) is only ever used modulo n (:88), and
-      // G^v = (1 + n)^v = 1 (mod n) whatever v is (the prover requires G = n + 1): z = ct1 (mod n).  No decryption, no G^v,
-      // no inversion modulo n^3 -- the same s.
-      uint32_t* z2 = ctx->ws_t<uint32_t>((size_t)W2 * nbq);
-      reduce_mod(ctx, mn2, qc1, W3, z2, nbq);
-      uint32_t* qs = ctx->ws_t<uint32_t>((size_t)W1 * nbq);
-      if (sk->has_crt && sk->mp.WT * 2 == W1) {                                // z^nsInv mod n through p and q
-        uint32_t* z1 = ctx->ws_t<uint32_t>((size_t)W1 * nbq);
-        reduce_mod(ctx, mn, z2, W2, z1, nbq);
-        qs = pow_n_crt(sk, z1, ns_inv, nbq);
-      } else {
-        shared_pow(ctx, mn, z2, W2, ns_inv, nbq, qs);                          // z^nsInv mod n
-      }
-      // ---- per instance
-      uint32_t *ainv = per_inst(qainv, W2), *ani = per_inst(qani, W2), *gan = per_inst(qan, W2), *sres = per_inst(qs, W1),
-               *gb = per_inst(qb, W1);
+      uint32_t *ainv = per_inst(qainv, W2), *ani = per_inst(qani, W2), *gan = per_inst(an, W2), *sres = per_inst(qs, W1),
+               *gb = per_inst(bl, W1);
       // e = x * a^-1 mod n^2 (ddleq.go:94-99)
       uint32_t* x2 = zext(ctx, gx, W1, W2, nbg);
       uint32_t* ge = ctx->ws_t<uint32_t>((size_t)W2 * nbg);
@@ -4337,17 +4426,13 @@ static void ddleq_prove_impl(const pgpu_seckey* sk, size_t S, size_t secpar, con
       uint32_t* en = ctx->ws_t<uint32_t>((size_t)W2 * nbg);
       modmul_arrays(ctx, mn2, gxn, ani, nbg, en);
       uint32_t* c5 = nullptr;
-      if (crt3 && ctx->use_lift && sk->eo_p.ok && sk->eo_q.ok && sk->eo_p.w == sk->eo_q.w && W2 <= 2 * sk->eo_p.modd.WT &&
-          W2 <= 2 * sk->eo_q.modd.WT) {
+      if (one_ladder) {
         // c = ((s^an b)^en)^-1 s^xn = s^(xn - an en) b^(-en)  (ddleq.go:107-112) whenever s and b are units: ONE interleaved
         // ladder with two per-number exponents, computed modulo the group orders of p^3 and q^3 (ord = 2^t m: the odd part
         // through a Montgomery product modulo m, the 2-part from the lowest limbs, then the CRT lift), instead of the ladders
         // s^an | s^xn, (.)^en and a batch inversion modulo n^3.  A non-unit s or b (the reference's ModInverse is then
-        // undefined) keeps the literal sequence below and its error.  (The unit test is per statement.)
-        uint32_t* sb = ctx->ws_t<uint32_t>((size_t)W1 * nbq);
-        modmul_arrays(ctx, mn, qs, qb, nbq, sb);
-        launch_restride(sb, nbq, scnt, mn.d_consts + (size_t)C_ONE * W1, sb, nbq, W1, ctx->stream);
-        if (all_units(ctx, mn, sb, nbq, scnt)) {
+        // undefined) keeps the literal sequence below and its error.  (The unit test ran per statement, on the side stream.)
+        if (sb_units) {
           const uint32_t *es[2], *eb[2];
           uint32_t* ls = ctx->ws_t<uint32_t>(nbg);
           uint32_t* lb = ctx->ws_t<uint32_t>(nbg);
