@@ -2731,6 +2731,20 @@ class GenQ3(Gen):
         self.v_p1 = e
         self.v_c = e
         e += 2
+        # ONE-pass product (H = 37, 55): lanes 1, 2 keep a copy of the digit below their own (H more registers, taken by DPP) and
+        # run two multiplier streams per row -- b0 against their own digit, b1 against the copy -- into the same accumulators:
+        #   lane 0: a0 b0 | lane 1: a1 b0 + a0 b1 - m0 + C1 | lane 2: a2 b0 + a1 b1 - m1 + C2 | helper: a0 b2 (second stream: zeros)
+        # One Montgomery reduction per digit, whose quotient digits go to the next digit as before: the same value modulo n^3
+        # in H rows of 3H multiplies instead of two passes of H rows of 2H.  H = 74 has no registers for it.
+        self.merged = (e + H + 4 <= 256)
+        if self.merged:
+            self.vY = e
+            e += H
+            self.v_ai2, self.v_ain2, self.v_arow2, self.v_bump2 = e, e + 1, e + 2, e + 3
+            e += 4
+            self.lds_z = self.lds_bytes                  # three rows of zeros: the second stream of lanes 0 and 3
+            self.lds_bytes += 1024
+            assert self.lds_bytes < 65536
         self.n_vgpr = e
         assert e <= 256, e
         self.s_coff = 99
@@ -2874,12 +2888,17 @@ class GenQ3(Gen):
         e(f"ds_write_b64 v0, v[6:7] offset:{self.lds_c + 16}")
         e(f"ds_write_b64 v0, v[4:5] offset:{self.lds_c + 24}")
         e("s_mov_b64 exec, s[0:1]")
+        if self.merged:
+            e(f"v_lshlrev_b32 v{g.v_t3}, 2, v{g.v_t2}")        # gl * 4 ... every thread zeroes one word of the zero rows
+            e(f"v_lshl_add_u32 v{g.v_t3}, v{g.v_t1}, 8, v{g.v_t3}")   # + (lane & 3) * 256
+            e("v_mov_b32 v2, 0")
+            e(f"ds_write_b32 v{g.v_t3}, v2 offset:{self.lds_z}")
         e("s_waitcnt lgkmcnt(0)")
         e("s_barrier")
         for j in range(H):
             e(f"v_mov_b32 {self.X(j)}, 0")
 
-    def row(self, cur, nxt, link2, use_sh, first=False):
+    def row(self, cur, nxt, link2, use_sh, first=False, cur2=None, nxt2=None):
         """one Montgomery row modulo n in every active lane.  Hop 1: lane 1 takes -m(lane 0) into column 0 (its C1 limb is
         in the accumulator since the pass began); hop 2 (link2): lane 2 takes -m(lane 1).  first: row 0 of a pass (every
         accumulator, the top one too, still holds its initial constant)"""
@@ -2891,6 +2910,9 @@ class GenQ3(Gen):
         e("s_waitcnt lgkmcnt(0)")
         e(f"ds_read_b32 v{nxt}, v{g.v_arow}")
         e(f"v_add_u32 v{g.v_arow}, {row}, v{g.v_arow}")
+        if cur2 is not None:
+            e(f"ds_read_b32 v{nxt2}, v{g.v_arow2}")
+            e(f"v_add_u32 v{g.v_arow2}, v{g.v_bump2}, v{g.v_arow2}")
         a = f"v{cur}"
         if use_sh:
             e(f"v_lshlrev_b32 v{cur}, v{g.v_sh}, v{cur}")
@@ -2906,22 +2928,30 @@ class GenQ3(Gen):
                       f"v_mad_i64_i32 {self.T(0)}, vcc, v{g.v_d}, v{mask}, {self.T(0)}",     # T0 -= m of the lane below (mask: -1 / 0)
                       f"v_mul_lo_u32 {m}, {self.Tlo(0)}, s14",
                       f"v_and_b32 {m}, {hex(MASK)}, {m}"]
-        gap = min(3, (H - 1) // len(chain))                # multiplies between two steps of the chain (>= 2 covers the DPP hazard)
+        addend = lambda j: "0" if (j == H - 1 and not first) else self.T(j)
+        muls = []
+        for j in range(H):
+            muls.append((self.T(j), a, self.X(j), addend(j)))
+            if cur2 is not None:
+                muls.append((self.T(j), f"v{cur2}", f"v{g.vY + j}", self.T(j)))
+        head = 1 if cur2 is None else 2                    # multiplies that complete column 0
+        gap = min(3, (len(muls) - head) // len(chain))     # multiplies between two steps of the chain (>= 2 covers the DPP hazard)
         assert gap >= 2, "pass A is too short to hide the link chain"
         self.align8()
-        addend = lambda j: "0" if (j == H - 1 and not first) else self.T(j)
-        self.mad(self.T(0), a, self.X(0), addend(0))
-        j = 1
+        k = 0
+        for _ in range(head):
+            self.mad(*muls[k])
+            k += 1
         for step in chain:
             for _ in range(gap):
-                self.mad(self.T(j), a, self.X(j), addend(j))
-                j += 1
+                self.mad(*muls[k])
+                k += 1
             e(step)
             if step.startswith("v_mov_b32_dpp") or step.startswith("v_and"):
                 self.align8()
-        while j < H:
-            self.mad(self.T(j), a, self.X(j), addend(j))
-            j += 1
+        while k < len(muls):
+            self.mad(*muls[k])
+            k += 1
         self.align8()
         self.mad(self.P(g.v_y0), m, N(0), self.T(0))
         self.mad(self.T(0), m, N(1), self.T(1))
@@ -2931,7 +2961,7 @@ class GenQ3(Gen):
             if j == 4:
                 e(f"v_lshl_add_u64 {self.T(0)}, {self.T(0)}, 0, {self.P(g.v_c)}")
 
-    def passes(self, tag, off012, off3, link2, use_sh):
+    def passes(self, tag, off012, off3, link2, use_sh, two_streams=False):
         """H rows: T <- (multiplier stream) * X * R^-1 with the quotient links.  off012 / off3: first row of the stream
         read by the digit lanes / by the helper lane."""
         g, e = self, self.e
@@ -2945,18 +2975,31 @@ class GenQ3(Gen):
             e(f"v_add_u32 v{g.v_arow}, {off012 * row}, v{g.v_arow}")
         e(f"ds_read_b32 v{g.v_ain}, v{g.v_arow}")
         e(f"v_add_u32 v{g.v_arow}, {row}, v{g.v_arow}")
-        self.row(g.v_ain, g.v_ai, link2, use_sh, first=True)
+        s2 = lambda c2, n2: dict(cur2=c2, nxt2=n2) if two_streams else {}
+        if two_streams:
+            # stream two: rows H.. of the a column (b1) in lanes 1, 2; the zero rows in lanes 0 and 3 (pointer not advanced)
+            e(f"v_add_u32 v{g.v_arow2}, {H * row}, v{g.v_aread}")
+            e(f"v_mov_b32 v{g.v_t1}, {self.lds_z}")
+            e(f"v_xor_b32 v{g.v_t1}, v{g.v_t1}, v{g.v_arow2}")
+            e(f"v_and_b32 v{g.v_t1}, v{g.v_t1}, v{g.v_l12mask}")
+            e(f"v_xor_b32 v{g.v_arow2}, {self.lds_z}, v{g.v_t1}")       # lanes 1, 2: aread + H rows; lanes 0, 3: lds_z
+            e(f"v_and_b32 v{g.v_bump2}, {row}, v{g.v_l12mask}")
+            e(f"ds_read_b32 v{g.v_ain2}, v{g.v_arow2}")
+            e(f"v_add_u32 v{g.v_arow2}, v{g.v_bump2}, v{g.v_arow2}")
+        self.row(g.v_ain, g.v_ai, link2, use_sh, first=True, **s2(g.v_ain2 if two_streams else None, g.v_ai2 if two_streams else None))
         if H % 2:
             e("s_mov_b32 s19, 1")
             ra, rb = g.v_ai, g.v_ain
+            ra2, rb2 = (g.v_ai2, g.v_ain2) if two_streams else (None, None)
         else:
-            self.row(g.v_ai, g.v_ain, link2, use_sh)
+            self.row(g.v_ai, g.v_ain, link2, use_sh, **s2(g.v_ai2 if two_streams else None, g.v_ain2 if two_streams else None))
             e("s_mov_b32 s19, 2")
             ra, rb = g.v_ain, g.v_ai
+            ra2, rb2 = (g.v_ain2, g.v_ai2) if two_streams else (None, None)
         e(".p2align 6")
         e(f"L_q{tag}:")
-        self.row(ra, rb, link2, use_sh)
-        self.row(rb, ra, link2, use_sh)
+        self.row(ra, rb, link2, use_sh, **s2(ra2, rb2))
+        self.row(rb, ra, link2, use_sh, **s2(rb2, ra2))
         e("s_add_u32 s19, s19, 2")
         e(f"s_cmp_lt_u32 s19, {H}")
         e(f"s_cbranch_scc1 L_q{tag}")
@@ -3015,7 +3058,31 @@ class GenQ3(Gen):
         e("s_mov_b64 exec, -1")
         e("s_branch L_next")
 
+    def montmul_merged(self):
+        g, e = self, self.e
+        H = self.H
+        e("L_montmul:")
+        e("s_nop 1")
+        for j in range(H):                                   # lanes 1, 2 <- the digit below their own (a0, a1)
+            e(f"v_mov_b32_dpp v{g.vY + j}, {self.X(j)} quad_perm:[0,0,1,2] row_mask:0xf bank_mask:0xf")
+        for j in range(H):                                   # helper lane <- a0
+            e(f"v_mov_b32_dpp {self.X(j)}, {self.X(j)} quad_perm:[0,1,2,0] row_mask:0xf bank_mask:0xf")
+        # one pass: stream b0 in the digit lanes (a0 b0 -> a1 b0 -> a2 b0 chained) and b2 in the helper lane (a0 b2); stream b1
+        # against the copies in lanes 1, 2 (a0 b1, a1 b1), zeros elsewhere
+        self.passes("m", 0, 2 * H, True, False, two_streams=True)
+        self.carry_T(to_x=True)
+        # digit 2 += a0 b2 R^-1 (helper lane), as in the squaring
+        self.set_exec(0xc)
+        e("s_nop 4")
+        for j in range(H):
+            e(f"v_add_u32_dpp {self.X(j)}, {self.X(j)}, {self.X(j)} quad_perm:[0,1,3,3] row_mask:0xf bank_mask:0xf")
+        self.carry_X()
+        e("s_mov_b64 exec, -1")
+        e("s_branch L_next")
+
     def montmul(self):
+        if self.merged:
+            return self.montmul_merged()
         g, e = self, self.e
         H = self.H
         row = self.NPB * 4

@@ -103,9 +103,13 @@ def test_asm_generator_model():
         if (wl, k) in gen_vm_asm.TRIPLE:
             # three-digit kernel: every pass is a loop of two single-lane rows of 2H multiplies (a squaring: one pass in four
             # lanes; a product: two passes, the second in two lanes); two quotient links per row in the linked passes
-            for lbl, where, hops in (("L_qs", "L_montsq:", 2), ("L_qm1", "L_montmul:", 2), ("L_qm2", "L_montmul:", 1)):
+            # (H = 37, 55: the registers allow a copy of the digit below, and the product is ONE pass with two multiplier streams)
+            loops = ((("L_qs", "L_montsq:", 2, 2), ("L_qm", "L_montmul:", 2, 3)) if g.merged else
+                     (("L_qs", "L_montsq:", 2, 2), ("L_qm1", "L_montmul:", 2, 2), ("L_qm2", "L_montmul:", 1, 2)))
+            assert g.merged == (wl <= 55)
+            for lbl, where, hops, streams in loops:
                 body = text.split(where)[1].split(lbl + ":")[1].split("s_cbranch_scc1 " + lbl)[0]
-                assert body.count("v_mad_u64_u32") == 2 * 2 * wl
+                assert body.count("v_mad_u64_u32") == 2 * streams * wl
                 assert body.count("quad_perm:[0,0,1,2]") == 2 * hops
             assert g.lds_bytes * 2 <= 160 * 1024
             continue

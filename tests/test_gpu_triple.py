@@ -79,12 +79,20 @@ def test_digit_model(ctx, bits, H):
         assert got_sq == [t00, t1, t2 + t3], f"squaring digits, number {g}"
         assert (val(got_sq) * R - val(xs[g]) ** 2) % n3 == 0
         m00, t00 = redc(a0 * b0)
-        m10, t10 = redc(a1 * b0 + C1 - m00)
-        _, t20 = redc(a2 * b0 + C2 - m10)
         _, t02 = redc(a0 * b2)
-        m01, t01 = redc(a0 * b1)
-        _, t11 = redc(a1 * b1 + C1 - m01)
-        assert got_mul == [t00, t10 + t01, t20 + t02 + t11], f"product digits, number {g}"
+        if H <= 55:
+            # one pass (the kernel has the registers for a copy of the digit below): ONE reduction per digit of the whole
+            # coefficient, its quotient digits subtracted from the next digit
+            m1, t1 = redc(a1 * b0 + a0 * b1 + C1 - m00)
+            _, t2 = redc(a2 * b0 + a1 * b1 + C2 - m1)
+            want = [t00, t1, t2 + t02]
+        else:
+            m10, t10 = redc(a1 * b0 + C1 - m00)
+            _, t20 = redc(a2 * b0 + C2 - m10)
+            m01, t01 = redc(a0 * b1)
+            _, t11 = redc(a1 * b1 + C1 - m01)
+            want = [t00, t10 + t01, t20 + t02 + t11]
+        assert got_mul == want, f"product digits, number {g}"
         assert (val(got_mul) * R - val(xs[g]) * val(ys[g])) % n3 == 0
         assert all(int(v) < (1 << LB) for d in range(3) for v in out[2, d * H:(d + 1) * H - 1, g])   # canonical limbs below the top
 
