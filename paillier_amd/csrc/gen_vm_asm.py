@@ -2639,6 +2639,40 @@ class GenQ4(Gen):
         e(f"s_cbranch_scc1 L_q{tag}")
         e("s_waitcnt lgkmcnt(0)")
 
+    def normalize(self):
+        """accumulators -> limbs of the new x.  Two lanes per digit: both run the plain sequential carry of a one-lane number
+        over their own 37 columns (3 instructions a limb: every lane owns whole columns), then the lower slice's carry out of its
+        top column -- up to 2^36 -- enters the upper slice's two lowest limbs (limb 1 stays lazy by < 2^9: multiplicands and
+        multipliers have that headroom).  125 instructions where the carry-save form of the generic multi-lane shapes takes
+        350; the upper slice's top limb keeps the digit's excess, as everywhere."""
+        g, e = self, self.e
+        WL = self.WL
+        M = hex(MASK)
+        c = self.P(g.v_c)
+        e(f"v_not_b32 v{g.v_t1}, v{g.v_isfirst}")                       # -1 in the upper slice of a digit
+        e(f"v_or_b32 v{g.v_t2}, {M}, v{g.v_t1}")                         # top-limb mask: 28 bits below, everything above
+        e(f"v_and_b32 {self.X(0)}, {M}, {self.Tlo(0)}")
+        e(f"v_lshrrev_b64 {c}, {LB}, {self.T(0)}")
+        for j in range(1, WL):
+            e(f"v_lshl_add_u64 {self.T(j)}, {self.T(j)}, 0, {c}")
+            if j < WL - 1:
+                e(f"v_and_b32 {self.X(j)}, {M}, {self.Tlo(j)}")
+            else:
+                e(f"v_and_b32 {self.X(j)}, {self.Tlo(j)}, v{g.v_t2}")
+            e(f"v_lshrrev_b64 {c}, {LB}, {self.T(j)}")
+        # carry out of the lower slice -> the upper slice of the same digit (lanes 1 <- 0, 3 <- 2)
+        e("s_nop 1")
+        e(f"v_mov_b32_dpp v{g.v_p0}, v{g.v_c} quad_perm:[0,0,2,2] row_mask:0xf bank_mask:0xf")
+        e(f"v_mov_b32_dpp v{g.v_p0 + 1}, v{g.v_c + 1} quad_perm:[0,0,2,2] row_mask:0xf bank_mask:0xf")
+        e(f"v_and_b32 v{g.v_p0}, v{g.v_p0}, v{g.v_t1}")
+        e(f"v_and_b32 v{g.v_p0 + 1}, v{g.v_p0 + 1}, v{g.v_t1}")
+        e(f"v_mov_b32 v{g.v_c}, {self.X(0)}")
+        e(f"v_mov_b32 v{g.v_c + 1}, 0")
+        e(f"v_lshl_add_u64 {c}, {c}, 0, {self.P(g.v_p0)}")               # limb 0 + carry in (zero in the lower slice)
+        e(f"v_and_b32 {self.X(0)}, {M}, v{g.v_c}")
+        e(f"v_lshrrev_b64 {c}, {LB}, {c}")
+        e(f"v_add_u32 {self.X(1)}, {self.X(1)}, v{g.v_c}")
+
     def montsq(self):
         g, e = self, self.e
         e("L_montsq:")
