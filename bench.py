@@ -598,11 +598,20 @@ def main():
             note()
             return outs
 
+        def range_fn(rows, ub, ue):
+            # this rank's units straight from the ciphertext batch (pgpu_partial_decrypt_units): ciphertexts wanted under several
+            # of the rank's shares share one chain of squarings
+            o = torch.empty((ue - ub, 512), dtype=torch.uint8, device=dev)
+            tk.partial_decrypt_units_raw([shares[i - 1] for i in ids], rows.shape[0], rows.data_ptr(), 512, ub, ue, o.data_ptr(), 512,
+                                         MEM_DEVICE)
+            note()
+            return o
+
         def tstep():
             # one launch per rank once a rank's share of a server falls below what fills the chip on its own
             return pdist.threshold_decrypt_sharded(tc, len(ids), rank, world, partial_fn, combine_fn,
                                                    units_fn=units_fn if (len(ids) * BT) // world < 32768 else None,
-                                                   servers_fn=servers_fn)
+                                                   servers_fn=servers_fn, range_fn=range_fn)
 
         tstep()
         barrier()

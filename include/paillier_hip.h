@@ -189,6 +189,15 @@ int pgpu_partial_decrypt_multi(const pgpu_pubkey* pk, int total_servers, int n_s
                                const size_t* share_lens, size_t batch, const uint8_t* c, size_t c_stride, uint8_t* const* outs,
                                size_t out_stride, int mem);
 
+/* The shard of one rank of the sharded threshold flow: the (server, ciphertext) units u = s * batch + i of the contiguous,
+ * server-major range [unit_begin, unit_end) over ONE batch of ciphertexts (thresholdkey.go:192-201 for each unit; shares[s] is
+ * server s's share, only those the range touches are read).  Ciphertexts the range wants under several shares walk ONE chain
+ * of squarings for all of them; the rest run their ladders side by side in the same launch.  out: unit_end - unit_begin rows,
+ * in unit order.  Same integers as pgpu_partial_decrypt per server. */
+int pgpu_partial_decrypt_units(const pgpu_pubkey* pk, int total_servers, int n_shares, const uint8_t* const* shares_be,
+                               const size_t* share_lens, size_t batch, const uint8_t* c, size_t c_stride, size_t unit_begin,
+                               size_t unit_end, uint8_t* out, size_t out_stride, int mem);
+
 /* ThresholdSecretKey.PartialDecrypt for a batch of (share, ciphertext) UNITS: out[i] = c[i]^(2 * l! * shares[share_index[i]])
  * mod n^2.  One launch serves the units of several decryption servers (or any mix of them): the exponents become per-unit
  * operands of the ladder.  This is what a shard of a threshold batch looks like -- e.g. 16 384 ciphertexts x 3 servers over

@@ -72,6 +72,7 @@ SIGNATURES = {
     "pgpu_partial_decrypt": (_int, [_vp, _int, _vp, _sz, _sz, _vp, _sz, _vp, _sz, _int]),
     "pgpu_partial_decrypt_multi": (_int, [_vp, _int, _int, _vp, _vp, _sz, _vp, _sz, _vp, _sz, _int]),
     "pgpu_partial_decrypt_indexed": (_int, [_vp, _int, _int, _vp, _vp, _sz, _vp, _sz, _vp, _vp, _sz, _int]),
+    "pgpu_partial_decrypt_units": (_int, [_vp, _int, _int, _vp, _vp, _sz, _vp, _sz, _sz, _sz, _vp, _sz, _int]),
     "pgpu_combine_partial_decryptions": (_int, [_vp, _int, _int, _int, _vp, _sz, _vp, _sz, _vp, _sz, _int, _vp]),
     "pgpu_random_oracle_digest": (_int, [_vp, _int, _vp, _vp, _sz, _vp, _int]),
     "pgpu_nested_randomize_with_ab": (_int, [_vp, _sz, _vp, _sz, _vp, _vp, _sz, _vp, _sz, _int]),
@@ -531,6 +532,17 @@ class ThresholdPublicKey(PublicKey):
         si = np.ascontiguousarray(share_index, dtype=np.int32)
         _check(self.ctx.lib.pgpu_partial_decrypt_indexed(self.h, self.TotalNumberOfDecryptionServers, len(bs), arr, lens, batch,
                                                          _ptr(c), c_stride, _ptr(si), _ptr(out), out_stride, mem))
+
+    def partial_decrypt_units_raw(self, shares: Sequence[int], batch, c, c_stride, unit_begin: int, unit_end: int, out, out_stride,
+                                  mem=MEM_HOST):
+        """pgpu_partial_decrypt_units: the (server, ciphertext) units u = s * batch + i of [unit_begin, unit_end) over ONE
+        ciphertext batch (server s uses shares[s]; only the shares the range touches are read -- pass 0 for the others);
+        ciphertexts wanted under several shares share one chain of squarings."""
+        bs = [_be(s_) for s_ in shares]
+        arr = (C.c_char_p * len(bs))(*bs)
+        lens = (C.c_size_t * len(bs))(*[len(b) for b in bs])
+        _check(self.ctx.lib.pgpu_partial_decrypt_units(self.h, self.TotalNumberOfDecryptionServers, len(bs), arr, lens, batch,
+                                                       _ptr(c), c_stride, unit_begin, unit_end, _ptr(out), out_stride, mem))
 
     def combine_raw(self, ids: Sequence[int], batch, partial_ptrs: Sequence[int], stride, m, m_stride, mem=MEM_HOST,
                     status: Optional[np.ndarray] = None):

@@ -3322,6 +3322,118 @@ int pgpu_partial_decrypt_multi(const pgpu_pubkey* pk, int total_servers, int n_s
   });
 }
 
+// The shard of ONE rank of the sharded threshold flow (paillier_amd/dist.py): the (server, ciphertext) units u = s * batch + i
+// of the contiguous, server-major range [unit_begin, unit_end) over ONE ciphertext batch.  Such a range is a partial run of its
+// first server, whole runs of the servers between, a partial run of its last server -- so the ciphertext index range splits into
+// at most three intervals, each wanted under a fixed SET of shares.  An interval wanted under several shares walks ONE chain of
+// squarings for all of them (emit_multi_exp_shared_base: the ciphertexts are the same, only the exponents differ), an interval
+// wanted under one share runs its sliding-window ladder; the intervals are program segments of one launch.  (At N = 2 a rank
+// holds one server whole and half of the next: half of its ciphertexts need both exponents -- 1.5 ladders' worth of multiplies
+// instead of 3 half-batch ladders; pgpu_partial_decrypt_indexed, which is handed one ciphertext row per unit, cannot see that
+// two of its rows are the same ciphertext.)  out: unit_end - unit_begin rows in unit order.
+int pgpu_partial_decrypt_units(const pgpu_pubkey* pk, int total_servers, int n_shares, const uint8_t* const* shares_be,
+                               const size_t* share_lens, size_t batch, const uint8_t* c, size_t c_stride, size_t unit_begin,
+                               size_t unit_end, uint8_t* out, size_t out_stride, int mem) {
+  if (!pk || !shares_be || !share_lens) return fail(PGPU_ERR_INVALID, "null argument");
+  pgpu_ctx* ctx = pk->ctx;
+  return guarded([&] {
+    if (n_shares < 1 || n_shares > 256 || total_servers < 1) api_throw(PGPU_ERR_INVALID, "bad share count");
+    check_batch_args(c, out, batch);
+    if (unit_begin >= unit_end || unit_end > (size_t)n_shares * batch) api_throw(PGPU_ERR_INVALID, "unit range out of bounds");
+    ctx->bind();
+    ctx->reset_ws();
+    const ModCtx& mc = pk->mn2;
+    const size_t nb = round_up(batch, VM_BLOCK);
+    const BigU two_delta = BigU(2) * factorial_big(total_servers);
+    const int s_first = (int)(unit_begin / batch), s_last = (int)((unit_end - 1) / batch);
+    std::vector<BigU> es((size_t)n_shares);
+    WipeOnExit<std::vector<BigU>> wipe_es(es);
+    for (int k = s_first; k <= s_last; ++k) {
+      if (!shares_be[k]) api_throw(PGPU_ERR_INVALID, "null share");
+      es[(size_t)k] = BigU::from_be(shares_be[k], share_lens[k]) * two_delta;       // thresholdkey.go:195
+    }
+    // ciphertext range of server s inside the unit range
+    auto lo_of = [&](int sv) { return sv == s_first ? unit_begin - (size_t)sv * batch : (size_t)0; };
+    auto hi_of = [&](int sv) { return sv == s_last ? unit_end - (size_t)sv * batch : batch; };
+    const PairInfo& pi = mc.pairn;
+    bool ok = pi.root && pi.c_one_pair >= 0 && ctx->use_asm && ctx->use_pair && ctx->use_shared_chain;
+    for (int k = s_first; k <= s_last; ++k) ok = ok && es[(size_t)k].bit_length() >= 256;
+    // intervals of the ciphertext index range and the servers that want each
+    struct Interval { size_t b, e; std::vector<int> servers; };
+    std::vector<Interval> ivs;
+    {
+      std::vector<size_t> cuts{0, batch};
+      for (int k = s_first; k <= s_last; ++k) { cuts.push_back(lo_of(k)); cuts.push_back(hi_of(k)); }
+      std::sort(cuts.begin(), cuts.end());
+      cuts.erase(std::unique(cuts.begin(), cuts.end()), cuts.end());
+      for (size_t t = 0; t + 1 < cuts.size(); ++t) {
+        Interval iv{cuts[t], cuts[t + 1], {}};
+        for (int k = s_first; k <= s_last; ++k)
+          if (lo_of(k) <= iv.b && iv.e <= hi_of(k)) iv.servers.push_back(k);
+        if (!iv.servers.empty()) ivs.push_back(iv);
+      }
+    }
+    if (!ok || ivs.size() > 3) {
+      // no pair kernel for this key (or a range no rank of the sharded flow produces): server after server
+      for (int k = s_first; k <= s_last; ++k) {
+        const size_t b = lo_of(k), e = hi_of(k), cnt = e - b, nbk = round_up(cnt, VM_BLOCK);
+        ModexpPlan pl = modexp_alloc(ctx, mc, nbk, 32);
+        unpack_mod(ctx, mc, c + b * c_stride, c_stride, cnt, mem, pl.in(), nbk);
+        modexp_shared_run(ctx, mc, pl, es[(size_t)k], false, false, true);
+        pack_result(ctx, pl.out(), mc.WT, nbk, cnt, out + ((size_t)k * batch + b - unit_begin) * out_stride, out_stride, mc.nbytes, mem);
+      }
+      HIPCHK(hipStreamSynchronize(ctx->stream));
+      return;
+    }
+    const ModCtx& mn = *pi.root;
+    const int H = mn.WT, W2 = mc.WT;
+    const size_t SW = (size_t)W2 * nb;
+    uint32_t* ent = ctx->ws_t<uint32_t>(SW * 4);            // generic slots: 0 x, 1 -, 2 digits (X0 | X1), 3 X
+    unpack_mod(ctx, mc, c, c_stride, batch, mem, ent, nb);
+    pair_enter(ctx, mc, ent, nb);
+    size_t longest = 0;
+    for (auto& iv : ivs) longest = std::max(longest, iv.e - iv.b);
+    const size_t nbs = round_up(longest, VM_BLOCK), SWs = (size_t)W2 * nbs;
+    const size_t lanes_target = ctx->lanes_wanted ? ctx->lanes_wanted : (size_t)1024 * 64;
+    const int lanes = (ivs.size() * nbs * 2 >= lanes_target || !(H % 2 == 0 && vm_asm_available(H / 2, 64))) ? 2 : 4;
+    const int w = 7;
+    const uint32_t K = 1u << (w - 1);
+    uint32_t* pm[3];
+    Prog pr[3];
+    SegSpec sg[3];
+    uint32_t out0[3];
+    for (size_t t = 0; t < ivs.size(); ++t) {
+      const Interval& iv = ivs[t];
+      const size_t S = iv.servers.size();
+      if (S >= 2) {
+        // slots: 2 in, 3 bp, 4 run, 5 acc, 6.. results, then the buckets (64 per server)
+        out0[t] = 6;
+        const uint32_t B0 = 6 + (uint32_t)S;
+        pm[t] = ctx->ws_t<uint32_t>(SWs * (size_t)(B0 + S * K));
+        std::vector<BigU> ev;
+        WipeOnExit<std::vector<BigU>> wipe_ev(ev);
+        for (int k : iv.servers) ev.push_back(es[(size_t)k]);
+        emit_multi_exp_shared_base(pr[t], ev, 2, 3, 4, 5, out0[t], B0, w, (uint32_t)pi.c_one_pair);
+      } else {
+        out0[t] = 3;                                        // pair slots: 2 in, 3 out, 5.. table
+        pm[t] = ctx->ws_t<uint32_t>(SWs * (size_t)(5 + 32));
+        emit_modexp_shared(pr[t], es[(size_t)iv.servers[0]], 2, NO_SLOT, 2, 3, 5, NO_SLOT, true, true);
+      }
+      pr[t].end();
+      launch_restride(ent + 2 * SW + iv.b, nb, iv.e - iv.b, nullptr, pm[t] + 2 * SWs, nbs, W2, ctx->stream);
+      sg[t] = SegSpec{&mc, &pr[t], pm[t], nullptr};
+      sg[t].pair = pi.consts; sg[t].pair_n0inv = mn.n0inv; sg[t].pair_h = H; sg[t].pair_lanes = lanes;
+    }
+    run_vm(ctx, nbs, sg[0], ivs.size() >= 2 ? &sg[1] : nullptr, true, 0, ivs.size() == 3 ? &sg[2] : nullptr);
+    for (size_t t = 0; t < ivs.size(); ++t)
+      for (size_t j = 0; j < ivs[t].servers.size(); ++j) {
+        const size_t u0 = (size_t)ivs[t].servers[j] * batch + ivs[t].b - unit_begin;
+        pair_leave_and_pack(ctx, mc, pm[t], out0[t] + (uint32_t)j, nbs, ivs[t].e - ivs[t].b, out + u0 * out_stride, out_stride, mem);
+      }
+    HIPCHK(hipStreamSynchronize(ctx->stream));
+  });
+}
+
 int pgpu_partial_decrypt_indexed(const pgpu_pubkey* pk, int total_servers, int n_shares, const uint8_t* const* shares_be,
                                  const size_t* share_lens, size_t batch, const uint8_t* c, size_t c_stride,
                                  const int32_t* share_index, uint8_t* out, size_t out_stride, int mem) {

@@ -65,7 +65,7 @@ def all_gather_bytes(local, world: int):
 
 
 def threshold_decrypt_sharded(c, n_servers: int, rank: int, world: int, partial_fn, combine_fn, pad_rows: bool = True,
-                              units_fn=None, servers_fn=None):
+                              units_fn=None, servers_fn=None, range_fn=None):
     """Threshold decryption of B ciphertexts with the work sharded over `world` ranks and ONE exchange step
     (thresholdkey.go:149-201: every server's PartialDecrypt, then CombinePartialDecryptions).
 
@@ -83,6 +83,10 @@ def threshold_decrypt_sharded(c, n_servers: int, rank: int, world: int, partial_
                    call per server -- a shard of a few thousand units fills the GPU only when its servers share a launch
       servers_fn   optional, used when ONE rank holds every share (world == 1): (c) -> [rows of server 0, rows of server 1, ...]
                    for the whole batch in one call (pgpu_partial_decrypt_multi: two servers' ladders per launch)
+      range_fn     optional, preferred when given: (c, unit_begin, unit_end) -> uint8 tensor [unit_end - unit_begin,
+                   cipher_bytes]: this rank's units straight from the whole ciphertext batch (pgpu_partial_decrypt_units:
+                   ciphertexts the range wants under several shares walk one chain of squarings -- a rank that holds one
+                   server whole and half of the next, N = 2, computes 1.5 ladders' worth instead of 3 half-batch ladders)
     Returns (plaintext rows of this rank's ciphertext slice, (begin, end) of that slice).
     """
     import torch
@@ -91,7 +95,9 @@ def threshold_decrypt_sharded(c, n_servers: int, rank: int, world: int, partial_
     ub, ue = shard_slice(units, rank, world)
     per = -(-units // world) if pad_rows else (ue - ub)      # all-gather needs equal shapes
     local = torch.zeros((max(per, 1), cbytes), dtype=torch.uint8, device=c.device)
-    if servers_fn is not None and world == 1:
+    if range_fn is not None and ue > ub:
+        local[:ue - ub] = range_fn(c, ub, ue)
+    elif servers_fn is not None and world == 1:
         for s_, rows in enumerate(servers_fn(c)):
             local[s_ * B:(s_ + 1) * B] = rows
     elif units_fn is not None and ue > ub:

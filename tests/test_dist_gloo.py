@@ -132,7 +132,17 @@ def _threshold_worker(rank, world, port, ids, count, use_gpu, q):
             out = np.zeros((rows.shape[0], cb), dtype=np.uint8)
             tk.partial_decrypt_indexed_raw([shares[i - 1] for i in ids], server_index, rows.shape[0], rows, cb, out, cb)
             return torch.from_numpy(out)
-    out, (b, e) = pd.threshold_decrypt_sharded(c, len(ids), rank, world, partial_fn, combine_fn, units_fn=units_fn)
+    range_fn = None
+    if use_gpu:   # the rank's unit range straight from the ciphertext batch (pgpu_partial_decrypt_units); checked against units_fn
+        def range_fn(rows, ub, ue):
+            rows = rows.contiguous().numpy()
+            out = np.zeros((ue - ub, cb), dtype=np.uint8)
+            tk.partial_decrypt_units_raw([shares[i - 1] for i in ids], rows.shape[0], rows, cb, ub, ue, out, cb)
+            return torch.from_numpy(out)
+        out2, _ = pd.threshold_decrypt_sharded(c, len(ids), rank, world, partial_fn, combine_fn, units_fn=units_fn)
+    out, (b, e) = pd.threshold_decrypt_sharded(c, len(ids), rank, world, partial_fn, combine_fn, units_fn=units_fn, range_fn=range_fn)
+    if use_gpu and out is not None:
+        assert torch.equal(out, out2)
     q.put((rank, b, e, to_ints(out) if out is not None else []))
     dist.barrier()
     dist.destroy_process_group()

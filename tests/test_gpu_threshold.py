@@ -220,3 +220,57 @@ def test_partial_decrypt_indexed_runs_of_one_share(ctx, lens, lanes_wanted):
     assert got[1] == got[0]
     pick = list(range(0, len(cts), 37)) + [len(cts) - 1] + [sum(lens[:i + 1]) - 1 for i in range(len(lens))] + [sum(lens[:i]) for i in range(len(lens))]
     assert [got[1][i] for i in pick] == [pow(cts[i], 2 * 120 * shares[int(idx[i])], n2) for i in pick]
+
+
+@pytest.mark.parametrize("B,ub,ue,lanes_wanted", [(300, 0, 450, 0),        # N = 2, rank 0: server 0 whole + half of server 1
+                                                   (300, 450, 900, 1),      # N = 2, rank 1: half of server 1 + server 2 whole
+                                                   (300, 225, 450, 0),      # N = 4, rank 1: disjoint ciphertext ranges of two servers
+                                                   (257, 100, 700, 0),      # three servers touched: tail, whole, head
+                                                   (300, 0, 900, 0),        # N = 1: every unit, one chain for the three shares
+                                                   (300, 310, 590, 1)])     # inside one server
+def test_partial_decrypt_units_of_a_rank(ctx, B, ub, ue, lanes_wanted):
+    """pgpu_partial_decrypt_units: the contiguous, server-major unit range of ONE rank of the sharded threshold flow over the
+    whole ciphertext batch.  Ciphertexts the range wants under several shares walk ONE chain of squarings (N = 2: a rank holds
+    one server whole and half of the next).  Equal to the per-server ladders (shared_chain off / pgpu_partial_decrypt) and to
+    c^(2 Delta s_i) mod n^2; ragged sizes, c = 0 and c = n included, both pair kernels."""
+    import numpy as np
+    import paillier_amd as pa
+    from paillier_amd.api import be_to_ints, ints_to_be
+    k = json.load(open(os.path.join(G, "keys.json")))["threshold"]["2048"]
+    n, total, thr = int(k["n"], 16), k["total"], k["threshold"]
+    shares = [int(s, 16) for s in k["shares"]]
+    sh = [shares[0], shares[2], shares[4]]               # servers 1, 3, 5 hold unit blocks 0, 1, 2
+    tk = pa.ThresholdPublicKey(ctx, n, total=total, threshold=thr)
+    cb = tk.cipher_bytes()
+    rng = random.Random(B + ub)
+    n2 = n * n
+    cts = [rng.randrange(n2) for _ in range(B)]
+    cts[0], cts[-1] = 0, n
+    rows = ints_to_be(cts, cb)
+    got = {}
+    try:
+        ctx.set_flag("lanes_wanted", lanes_wanted)
+        for flag in (1, 0):
+            ctx.set_flag("shared_chain", flag)
+            out = np.zeros((ue - ub, cb), dtype=np.uint8)
+            tk.partial_decrypt_units_raw(sh, B, rows, cb, ub, ue, out, cb)
+            got[flag] = be_to_ints(out)
+            if flag:
+                assert ctx.last_vm_asm() > 0
+    finally:
+        ctx.set_flag("shared_chain", 1)
+        ctx.set_flag("lanes_wanted", 0)
+    assert got[1] == got[0]
+    # against the one-server entry point on the same units, and against pow on a sample
+    u = ub
+    while u < ue:
+        s, i0 = divmod(u, B)
+        cnt = min(ue - u, B - i0)
+        one = np.zeros((cnt, cb), dtype=np.uint8)
+        tk.partial_decrypt_raw(sh[s], cnt, rows[i0:i0 + cnt], cb, one, cb)
+        assert be_to_ints(one) == got[1][u - ub:u - ub + cnt], (s, i0, cnt)
+        u += cnt
+    pick = sorted(set(list(range(ub, ue, 53)) + [ub, ue - 1]))
+    assert [got[1][u - ub] for u in pick] == [pow(cts[u % B], 2 * 120 * sh[u // B], n2) for u in pick]
+    with pytest.raises(pa.PaillierHipError):
+        tk.partial_decrypt_units_raw(sh, B, rows, cb, 5, 3 * B + 1, np.zeros((3 * B, cb), dtype=np.uint8), cb)

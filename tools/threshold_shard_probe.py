@@ -30,6 +30,10 @@ for world in (1, 2, 4, 8):
     us = np.arange(0, units, dtype=np.int64)              # rank 0's range, server-major
     rows = c[torch.from_numpy(us % B).to(dev)].contiguous()
     out = torch.empty((units, 512), dtype=torch.uint8, device=dev)
+    t_rng = timed(lambda: tk.partial_decrypt_units_raw(sh, B, c.data_ptr(), 512, 0, units, out.data_ptr(), 512, MEM_DEVICE))
+    k_rng = ctx.last_profile()["kernel"]
+    # the LAST rank's range as well (at N = 2: the second half of server 1 + server 2 whole)
+    t_rng_last = timed(lambda: tk.partial_decrypt_units_raw(sh, B, c.data_ptr(), 512, 3 * B - units, 3 * B, out.data_ptr(), 512, MEM_DEVICE))
     t_idx = timed(lambda: tk.partial_decrypt_indexed_raw(sh, (us // B).astype(np.int32), units, rows.data_ptr(), 512, out.data_ptr(), 512, MEM_DEVICE))
     # the same units server by server (what partial_fn would do)
     def per_server():
@@ -43,5 +47,6 @@ for world in (1, 2, 4, 8):
     cnt = B // world
     outs = [torch.empty((cnt, 512), dtype=torch.uint8, device=dev) for _ in ids]
     t_multi = timed(lambda: tk.partial_decrypt_multi_raw(sh, cnt, c[:cnt].data_ptr(), 512, [o.data_ptr() for o in outs], 512, MEM_DEVICE))
-    print(json.dumps({"world": world, "units_per_rank": units, "indexed_ms": round(t_idx, 1), "server_by_server_ms": round(t_srv, 1),
+    print(json.dumps({"world": world, "units_per_rank": units, "units_range_ms": round(t_rng, 1), "units_range_last_rank_ms": round(t_rng_last, 1),
+                      "units_range_kernel": k_rng, "indexed_ms": round(t_idx, 1), "server_by_server_ms": round(t_srv, 1),
                       "ciphertext_sharded_multi_ms": round(t_multi, 1), "kernel": ctx.last_profile()["kernel"]}), flush=True)
