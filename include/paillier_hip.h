@@ -87,6 +87,8 @@ int pgpu_ctx_last_profile(pgpu_ctx* ctx, double* vm_ms, int* vm_launches, double
 int pgpu_ctx_set_flag(pgpu_ctx* ctx, const char* name, int value);
 /* number of VM launches of the last batch call that ran the assembly kernel */
 int pgpu_ctx_last_vm_asm(pgpu_ctx* ctx);
+/* ... and how many VM launches it made in all (equal to the above when nothing fell back to the compiler-generated kernel) */
+int pgpu_ctx_last_vm_launches(pgpu_ctx* ctx);
 /* name of the profiled VM launch of the last batch call that executed the most multiply-adds (its dominant kernel), as it
  * appears in a rocprof kernel trace, e.g. "vm_asm_37_16"; "" if the call profiled none.  Valid until the next call. */
 const char* pgpu_ctx_last_kernel(pgpu_ctx* ctx);

@@ -51,6 +51,7 @@ SIGNATURES = {
     "pgpu_ctx_last_profile": (_int, [_vp, C.POINTER(C.c_double), C.POINTER(_int), C.POINTER(C.c_double)]),
     "pgpu_ctx_set_flag": (_int, [_vp, C.c_char_p, _int]),
     "pgpu_ctx_last_vm_asm": (_int, [_vp]),
+    "pgpu_ctx_last_vm_launches": (_int, [_vp]),
     "pgpu_ctx_last_kernel": (C.c_char_p, [_vp]),
     "pgpu_pubkey_create": (_int, [_vp, _vp, _sz, _vp, _sz, _vp, _sz, _vp, _sz, C.POINTER(_vp)]),
     "pgpu_pubkey_destroy": (None, [_vp]),
@@ -218,6 +219,10 @@ class Context:
 
     def last_vm_asm(self) -> int:
         return self.lib.pgpu_ctx_last_vm_asm(self.h)
+
+    def last_vm_launches(self) -> int:
+        """VM launches of the last call, assembly or compiler-generated (== last_vm_asm() when nothing fell back)"""
+        return self.lib.pgpu_ctx_last_vm_launches(self.h)
 
     def random_oracle_digest_batch(self, columns: Sequence[Sequence[int]]) -> List[bytes]:
         """SHA-256(Bytes(col0[i]) || Bytes(col1[i]) || ...) on the device, one digest per row i."""

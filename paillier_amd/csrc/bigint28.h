@@ -15,7 +15,7 @@
 //
 // Register budget: gfx950 VALU instructions address 256 architectural VGPRs.  One lane can
 // hold WL 64-bit column accumulators (2 WL regs) + WL operand limbs: WL <= 74 -> 2048-bit
-// moduli with one lane per number.  Wider moduli are split over K in {2,4} ADJACENT lanes of a
+// moduli with one lane per number.  Wider moduli are split over K in {2,4,8} ADJACENT lanes of a
 // quad: lane k owns columns [k*WL, (k+1)*WL).  Per outer row the lanes exchange one 64-bit
 // accumulator (the column that crosses the slice boundary) and the Montgomery quotient digit
 // by DPP quad_perm moves -- no LDS, no shuffles through memory.
@@ -76,12 +76,30 @@ template <> struct Dpp<4> {
   static constexpr int kFromPrev = 0 | (0 << 2) | (1 << 4) | (2 << 6);  // [0,0,1,2]
   static constexpr int kBcast0 = 0;                                       // [0,0,0,0]
 };
+// K == 8: the slices of a number fill half a 16-lane DPP row; neighbours by row_shl:1 / row_shr:1 (what crosses into another
+// number is masked by is_first / not_last, as for the smaller shapes); the broadcast of slice 0 takes two steps (bcast0 below).
+template <> struct Dpp<8> {
+  static constexpr int kFromNext = 0x101;   // row_shl:1
+  static constexpr int kFromPrev = 0x111;   // row_shr:1
+  static constexpr int kBcast0 = 0;         // [0,0,0,0] inside each quad; the upper quad then takes it from 4 lanes down
+};
 template <int CTRL> PA_D uint32_t dpp_mov(uint32_t v) {
 #if defined(__HIP_DEVICE_COMPILE__)
   return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, CTRL, 0xF, 0xF, false);
 #else
   return v;
 #endif
+}
+// m of slice 0 of the same number
+template <int K> PA_D uint32_t bcast0(uint32_t m) {
+  uint32_t t = dpp_mov<Dpp<K>::kBcast0>(m);
+  if (K == 8) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    const uint32_t u = dpp_mov<0x114>(t);   // row_shr:4
+    t = (threadIdx.x & 4u) ? u : t;
+#endif
+  }
+  return t;
 }
 template <int CTRL> PA_D uint64_t dpp_mov64(uint64_t v) {
   uint32_t lo = dpp_mov<CTRL>((uint32_t)v), hi = dpp_mov<CTRL>((uint32_t)(v >> 32));
@@ -117,7 +135,7 @@ PA_D void montmul(uint32_t (&x)[WL], const uint32_t* a_col, int a_stride, const 
 #pragma unroll
     for (int j = 0; j < WL; ++j) t[j] = mad64(ai, x[j], t[j]);
     uint32_t m = ((uint32_t)t[0] * n0inv) & LMASK;
-    if (K > 1) m = dpp_mov<Dpp<K>::kBcast0>(m);
+    if (K > 1) m = bcast0<K>(m);
     const uint64_t y0 = mad64(m, n_seg[0], t[0]);
     uint64_t c = y0 >> LB;
     if (K > 1) c &= (uint64_t)is_first | ((uint64_t)is_first << 32);

@@ -80,6 +80,7 @@ struct pgpu_ctx {
   size_t evs_used = 0;
   bool use_asm = true;       // hand-scheduled VM kernels (pgpu_ctx_set_flag("asm", 0) selects the hipcc-generated ones)
   int last_vm_asm = 0;       // number of VM launches of the last call that ran the assembly kernel
+  int last_vm_launches = 0;  // number of VM launches of the last call, assembly or compiler-generated
   bool use_pair = true;      // Decrypt ladders mod p^2 on the pair kernel (pgpu_ctx_set_flag("pair", 0): the 2H-limb kernel)
   bool use_triple = true;    // ladders modulo n^3 on the three-digit kernel (pgpu_ctx_set_flag("triple", 0): the 3H-limb kernels)
   bool use_shared_chain = true;   // several shared exponents on ONE base share the chain of squarings (pgpu_partial_decrypt_multi)
@@ -121,6 +122,7 @@ struct pgpu_ctx {
     host_keep.clear();
     evs_used = 0;
     last_vm_asm = 0;
+    last_vm_launches = 0;
   }
   void* ws(size_t bytes) {
     bytes = round_up(bytes ? bytes : 1, 256);
@@ -263,7 +265,9 @@ struct ModCtx {
   size_t d_consts_cap = 0;
 
   static bool pick_shape(size_t bits, int& wl, int& k) {
-    struct S { int wl, k; } shapes[] = {{37, 1}, {55, 1}, {74, 1}, {55, 2}, {74, 2}, {55, 4}, {74, 4}, {83, 4}};
+    // (the widest shape is eight lanes of 42 limbs: 83 limbs in four lanes -- the shape of rounds 1 and 2 -- does not fit the
+    // register file next to its accumulators, so it existed in the compiler-generated kernel only, at 31 % of the issue peak)
+    struct S { int wl, k; } shapes[] = {{37, 1}, {55, 1}, {74, 1}, {55, 2}, {74, 2}, {55, 4}, {74, 4}, {42, 8}};
     for (auto s : shapes)
       if (bits + 3 <= (size_t)LB * s.wl * s.k) { wl = s.wl; k = s.k; return true; }
     return false;
@@ -275,7 +279,7 @@ struct ModCtx {
     if (!N.is_odd() || N.bit_length() < 2) api_throw(PGPU_ERR_INVALID, "modulus must be odd and at least 3");
     nbits = N.bit_length();
     nbytes = (nbits + 7) / 8;
-    if (!pick_shape(nbits, WL, K)) api_throw(PGPU_ERR_UNSUPPORTED, "modulus wider than 9293 bits is not built");
+    if (!pick_shape(nbits, WL, K)) api_throw(PGPU_ERR_UNSUPPORTED, "modulus wider than 9405 bits is not built");
     WT = WL * K;
     R = hostbig::shl(BigU(1), (size_t)LB * WT);
     uint32_t n0 = N.d[0], x = n0;  // Newton: x = n0^-1 mod 2^32
@@ -822,6 +826,7 @@ void run_vm(pgpu_ctx* ctx, size_t nb, const SegSpec& s0, const SegSpec* s1, bool
   if (ev) snprintf(ev->name, sizeof ev->name, use_asm ? "vm_asm_%d_%d" : "vm_kernel<%d,%d>", WL, K);
   hipError_t e = use_asm ? launch_vm_asm(WL, K, a, blocks, ctx->stream) : launch_vm(WL, K, a, blocks, ctx->stream);
   if (use_asm) ctx->last_vm_asm++;
+  ctx->last_vm_launches++;
   if (e != hipSuccess) throw HipError{e, "launch_vm"};
   if (profile) HIPCHK(hipEventRecord(ev->b, ctx->stream));
 }
@@ -1146,6 +1151,7 @@ int pgpu_ctx_set_flag(pgpu_ctx* ctx, const char* name, int value) {
 }
 
 int pgpu_ctx_last_vm_asm(pgpu_ctx* ctx) { return ctx ? ctx->last_vm_asm : 0; }
+int pgpu_ctx_last_vm_launches(pgpu_ctx* ctx) { return ctx ? ctx->last_vm_launches : 0; }
 
 const char* pgpu_ctx_last_kernel(pgpu_ctx* ctx) {
   if (!ctx) return "";

@@ -37,7 +37,7 @@ OPS = dict(END=0, LOAD=1, STORE=2, LOADC=3, SQR=4, MUL=5, MULC=6, MULV=7, ADD=8,
 
 class Gen:
     def __init__(self, WL, K, depth=8):
-        assert K in (1, 2, 4)
+        assert K in (1, 2, 4, 8)
         self.WL, self.K, self.WT = WL, K, WL * K
         self.NPB = BLOCK // K
         self.WLp = (WL + 3) // 4 * 4
@@ -58,7 +58,8 @@ class Gen:
         self.vX = 2 * WL
         e = 3 * WL
         singles = ["ai", "ain", "m", "t1"] + (["din", "drow"] if K == 1 else []) + \
-                  (["k", "sh", "mk", "mult", "km2", "islast"] if (K == 2 and WL <= 55) else [])
+                  (["k", "sh", "mk", "mult", "km2", "islast"] if (K == 2 and WL <= 55) else []) + \
+                  (["upmask", "mb"] if K == 8 else [])
         for nm in singles:
             setattr(self, "v_" + nm, e)
             e += 1
@@ -125,6 +126,27 @@ class Gen:
         measured here: Decrypt-3072 294k -> 343k/s from placement alone)."""
         self.e(".p2align 3")
 
+    # lane exchanges between the K slices of a number.  K <= 4: the slices sit in one quad (quad_perm).  K == 8: two quads of a
+    # 16-lane DPP row -- neighbours by row_shl / row_shr (what crosses into another number is masked by isfirst / notlast, as
+    # for the smaller shapes), the broadcast of slice 0 in two steps (its quad, then the quad above takes it from 4 lanes down).
+    def dpp_from_next(self):
+        return {2: "quad_perm:[1,1,3,3]", 4: "quad_perm:[1,2,3,3]", 8: "row_shl:1"}[self.K]
+
+    def dpp_from_prev(self):
+        return {2: "quad_perm:[0,0,2,2]", 4: "quad_perm:[0,0,1,2]", 8: "row_shr:1"}[self.K]
+
+    def emit_bcast0(self, m):
+        """m <- m of slice 0 of the same number (2 wait states since m was written are the caller's business)"""
+        g, e = self, self.e
+        if self.K == 8:
+            e(f"v_mov_b32_dpp {m}, {m} quad_perm:[0,0,0,0] row_mask:0xf bank_mask:0xf")
+            e("s_nop 1")
+            e(f"v_mov_b32_dpp v{g.v_mb}, {m} row_shr:4 row_mask:0xf bank_mask:0xf")
+            e(f"v_bfi_b32 {m}, v{g.v_upmask}, v{g.v_mb}, {m}")          # slices 4..7 take it from 4 lanes down
+        else:
+            bc = {2: "[0,0,2,2]", 4: "[0,0,0,0]"}[self.K]
+            e(f"v_mov_b32_dpp {m}, {m} quad_perm:{bc} row_mask:0xf bank_mask:0xf")
+
     def mad(self, dst, a, b, c):
         self.e(f"v_mad_u64_u32 {dst}, vcc, {a}, {b}, {c}")
 
@@ -165,7 +187,7 @@ class Gen:
         e("s_lshl_b32 s3, s15, 2")  # s3 = nb*4 : byte stride between limb rows
         # lane indices
         K, WL, NPB = self.K, self.WL, self.NPB
-        sh = {1: 0, 2: 1, 4: 2}[K]
+        sh = {1: 0, 2: 1, 4: 2, 8: 3}[K]
         e(f"v_and_b32 v{g.v_t1}, {K - 1}, v0")          # k
         e(f"v_lshrrev_b32 v{g.v_t2}, {sh}, v0")          # gl
         # g = blk*NPB + gl ; goff = (k*WL*nb + g)*4
@@ -189,6 +211,10 @@ class Gen:
         e(f"v_cmp_ne_u32 vcc, {K - 1}, v{g.v_t1}")
         e("s_nop 1")
         e(f"v_cndmask_b32 v{g.v_notlast}, 0, -1, vcc")
+        if K == 8:
+            e(f"v_cmp_le_u32 vcc, 4, v{g.v_t1}")
+            e("s_nop 1")
+            e(f"v_cndmask_b32 v{g.v_upmask}, 0, -1, vcc")
         if self.sq_rows_k:
             e(f"v_mov_b32 v{g.v_k}, v{g.v_t1}")
             e(f"v_not_b32 v{g.v_islast}, v{g.v_notlast}")
@@ -566,9 +592,8 @@ class Gen:
         e(f"v_mul_lo_u32 {m}, {self.Tlo(0)}, s14")
         e(f"v_and_b32 {m}, {hex(MASK)}, {m}")
         if K > 1:
-            bc = {2: "[0,0,2,2]", 4: "[0,0,0,0]"}[K]
             e("s_nop 1")
-            e(f"v_mov_b32_dpp {m}, {m} quad_perm:{bc} row_mask:0xf bank_mask:0xf")
+            self.emit_bcast0(m)
             self.align8()
         nextA = D
         for j in range(WL):
@@ -584,9 +609,9 @@ class Gen:
             if j == 1:
                 e(f"v_lshl_add_u64 {self.T(0)}, {self.T(0)}, 0, {self.P(g.v_c)}")
         if K > 1:
-            fn = {2: "[1,1,3,3]", 4: "[1,2,3,3]"}[K]
-            e(f"v_mov_b32_dpp {self.Tlo(WL - 1)}, v{g.v_y0} quad_perm:{fn} row_mask:0xf bank_mask:0xf")
-            e(f"v_mov_b32_dpp {self.Thi(WL - 1)}, v{g.v_y0 + 1} quad_perm:{fn} row_mask:0xf bank_mask:0xf")
+            fn = self.dpp_from_next()
+            e(f"v_mov_b32_dpp {self.Tlo(WL - 1)}, v{g.v_y0} {fn} row_mask:0xf bank_mask:0xf")
+            e(f"v_mov_b32_dpp {self.Thi(WL - 1)}, v{g.v_y0 + 1} {fn} row_mask:0xf bank_mask:0xf")
             e(f"v_and_b32 {self.Tlo(WL - 1)}, {self.Tlo(WL - 1)}, v{g.v_notlast}")
             e(f"v_and_b32 {self.Thi(WL - 1)}, {self.Thi(WL - 1)}, v{g.v_notlast}")
 
@@ -854,10 +879,10 @@ class Gen:
             e(f"v_and_b32 {self.Tlo(j)}, {hex(MASK)}, {self.Tlo(j)}")
             e(f"v_mov_b32 {self.Thi(j)}, 0")
         if K > 1:
-            fp = {2: "[0,0,2,2]", 4: "[0,0,1,2]"}[K]
+            fp = self.dpp_from_prev()
             e("s_nop 1")
-            e(f"v_mov_b32_dpp v{g.v_p0}, v{g.v_p1} quad_perm:{fp} row_mask:0xf bank_mask:0xf")
-            e(f"v_mov_b32_dpp v{g.v_p0 + 1}, v{g.v_p1 + 1} quad_perm:{fp} row_mask:0xf bank_mask:0xf")
+            e(f"v_mov_b32_dpp v{g.v_p0}, v{g.v_p1} {fp} row_mask:0xf bank_mask:0xf")
+            e(f"v_mov_b32_dpp v{g.v_p0 + 1}, v{g.v_p1 + 1} {fp} row_mask:0xf bank_mask:0xf")
             e(f"v_not_b32 v{g.v_t1}, v{g.v_isfirst}")
             e(f"v_and_b32 v{g.v_p0}, v{g.v_p0}, v{g.v_t1}")
             e(f"v_and_b32 v{g.v_p0 + 1}, v{g.v_p0 + 1}, v{g.v_t1}")
@@ -888,7 +913,7 @@ class Gen:
         # rolling registers: mid_prev (t1), hi_prev (t2), hi_prev2 (t3), s_prev (t4)
         mid_p, hi_p, hi_p2, s_p = f"v{g.v_t1}", f"v{g.v_t2}", f"v{g.v_t3}", f"v{g.v_t4}"
         if K > 1:
-            fp = {2: "[0,0,2,2]", 4: "[0,0,1,2]"}[K]
+            fp = self.dpp_from_prev()
             top, top2 = WL - 1, WL - 2
             # incoming mid_{-1}, hi_{-1}, hi_{-2} from the previous lane's top columns
             e(f"v_alignbit_b32 v{g.v_p0}, {self.Thi(top)}, {self.Tlo(top)}, {LB}")
@@ -897,9 +922,9 @@ class Gen:
             e(f"v_lshrrev_b32 v{g.v_p1}, {2 * LB - 32}, {self.Thi(top2)}")        # hi_top2
             e(f"v_not_b32 v{g.v_p1 + 1}, v{g.v_isfirst}")
             e("s_nop 1")
-            e(f"v_mov_b32_dpp {mid_p}, v{g.v_p0} quad_perm:{fp} row_mask:0xf bank_mask:0xf")
-            e(f"v_mov_b32_dpp {hi_p}, v{g.v_p0 + 1} quad_perm:{fp} row_mask:0xf bank_mask:0xf")
-            e(f"v_mov_b32_dpp {hi_p2}, v{g.v_p1} quad_perm:{fp} row_mask:0xf bank_mask:0xf")
+            e(f"v_mov_b32_dpp {mid_p}, v{g.v_p0} {fp} row_mask:0xf bank_mask:0xf")
+            e(f"v_mov_b32_dpp {hi_p}, v{g.v_p0 + 1} {fp} row_mask:0xf bank_mask:0xf")
+            e(f"v_mov_b32_dpp {hi_p2}, v{g.v_p1} {fp} row_mask:0xf bank_mask:0xf")
             e(f"v_and_b32 {mid_p}, {mid_p}, v{g.v_p1 + 1}")
             e(f"v_and_b32 {hi_p}, {hi_p}, v{g.v_p1 + 1}")
             e(f"v_and_b32 {hi_p2}, {hi_p2}, v{g.v_p1 + 1}")
@@ -919,11 +944,11 @@ class Gen:
             e(f"v_and_b32 {mid_p}, {M}, {mid_p}")
         # pass 2 (descending so s_{j-1} is still unmodified): x_j = (s_j & M) + (s_{j-1} >> 28)
         if K > 1:
-            fp = {2: "[0,0,2,2]", 4: "[0,0,1,2]"}[K]
+            fp = self.dpp_from_prev()
             e(f"v_lshrrev_b32 v{g.v_p0}, {LB}, {self.X(WL - 1)}")
             e(f"v_not_b32 v{g.v_p1 + 1}, v{g.v_isfirst}")
             e("s_nop 1")
-            e(f"v_mov_b32_dpp {s_p}, v{g.v_p0} quad_perm:{fp} row_mask:0xf bank_mask:0xf")
+            e(f"v_mov_b32_dpp {s_p}, v{g.v_p0} {fp} row_mask:0xf bank_mask:0xf")
             e(f"v_and_b32 {s_p}, {s_p}, v{g.v_p1 + 1}")
         for j in range(WL - 1, -1, -1):
             if j >= 1:
@@ -3164,7 +3189,7 @@ class GenQ3(Gen):
         return "\n".join(self.lines) + "\n"
 
 
-SHAPES = [(74, 1), (37, 1), (55, 1), (55, 2), (74, 2), (55, 4), (74, 4), (37, 2), (37, 4), (37, 16), (55, 16), (74, 32), (55, 32), (37, 32), (37, 64), (74, 48), (37, 48), (55, 48)]
+SHAPES = [(74, 1), (37, 1), (55, 1), (55, 2), (74, 2), (55, 4), (74, 4), (42, 8), (37, 2), (37, 4), (37, 16), (55, 16), (74, 32), (55, 32), (37, 32), (37, 64), (74, 48), (37, 48), (55, 48)]
 PAIR = {(37, 16), (55, 16)}  # (H, 16): the pair kernel for N = p^2 with H-limb p (GenP); 16 is a tag, not a lane count
 PAIR4 = {(37, 64)}          # (WL, 64): GenQ4, the two digits of GenQ(2 WL) sliced over two lanes each
 PAIR2 = {(74, 32), (55, 32), (37, 32)}          # (H, 32): the two-lane pair kernel for N = n^2 with H-limb n (GenQ)

@@ -19,8 +19,8 @@ def rand_odd(bits, rng):
     return rng.getrandbits(bits) | (1 << (bits - 1)) | 1
 
 
-# (modulus bits) -> kernel shape exercised: 1024 (37,1) 1536 (55,1) 2048 (74,1) 3072 (55,2) 4096 (74,2) 6144 (55,4)
-@pytest.mark.parametrize("bits", [1024, 1536, 2048, 3072, 4096, 6144, 521, 2069, 4141])
+# (modulus bits) -> kernel shape exercised: 1024 (37,1) 1536 (55,1) 2048 (74,1) 3072 (55,2) 4096 (74,2) 6144 (55,4) 9216 (42,8)
+@pytest.mark.parametrize("bits", [1024, 1536, 2048, 3072, 4096, 6144, 9216, 521, 2069, 4141])
 def test_modmul_matches_python(ctx, bits):
     import paillier_amd as pa
     rng = random.Random(bits)
@@ -32,7 +32,7 @@ def test_modmul_matches_python(ctx, bits):
     assert got == [x * y % n for x, y in zip(a, b)]
 
 
-@pytest.mark.parametrize("bits", [1024, 2048, 3072, 4096, 6144])
+@pytest.mark.parametrize("bits", [1024, 2048, 3072, 4096, 6144, 9216])
 def test_modexp_shared_matches_python(ctx, bits):
     import paillier_amd as pa
     rng = random.Random(bits + 1)
@@ -106,7 +106,7 @@ def test_add_constmult_1024(ctx, key1024):
     assert pk.ConstMultBatch(a[:40], ks[:40]) == [po.const_mult(sk_o, po.Ciphertext(x), kk).C for x, kk in zip(a, ks[:40])]
 
 
-@pytest.mark.parametrize("bits", [1024, 1536, 2048, 3072, 4096, 6144, 8192])
+@pytest.mark.parametrize("bits", [1024, 1536, 2048, 3072, 4096, 6144, 8192, 9216, 9400])
 def test_asm_kernel_matches_compiler_kernel(ctx, bits):
     """The hand-scheduled assembly VM kernel and the hipcc-generated one must agree bit for bit (and with Python)."""
     import paillier_amd as pa
@@ -162,7 +162,7 @@ def test_sub_1024(ctx, key1024):
     assert sk.DecryptBatch(got) == [(a - b) % sk_o.N for a, b in zip(ms1, ms2)]  # operations_test.go:52-70
 
 
-@pytest.mark.parametrize("bits", [1024, 2048, 3072, 4096, 6144])
+@pytest.mark.parametrize("bits", [1024, 2048, 3072, 4096, 6144, 9216])
 def test_asm_kernel_per_number_exponent(ctx, bits):
     """VM_MULV (per-number 4-bit windows, table gather) in the assembly kernel vs the hipcc kernel vs Python."""
     import paillier_amd as pa

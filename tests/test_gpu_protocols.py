@@ -230,8 +230,8 @@ def test_ddleq_prove_on_device(ctx):
 def test_ddleq_prove_3072_bit_key(ctx):
     """The prover at 3072 bits: halves modulo p^3, q^3 on the three-digit kernel for 55-limb primes (vm_asm_55_48), split by the
     base-p digits of the exponents through p^2, q^2 on the one-lane pair kernel for 55-limb primes (vm_asm_55_16, 4-bit
-    per-number windows), a^n | x^n through p^2, q^2 on it as well; the verifier's n^3 is 9 216 bits (the compiler-generated
-    (83,4) kernel).  Few instances: the oracle's 9 216-bit powers are slow."""
+    per-number windows), a^n | x^n through p^2, q^2 on it as well; the verifier's n^3 is 9 216 bits (vm_asm_42_8, eight lanes per
+    number: no launch falls back to the compiler-generated kernel).  Few instances: the oracle's 9 216-bit powers are slow."""
     import json as _json
     import paillier_amd as pa
     k = _json.load(open(os.path.join(G, "keys.json")))["paillier"]["3072"]
@@ -261,6 +261,7 @@ def test_ddleq_prove_3072_bit_key(ctx):
     # one verifier call: the three true statements and the same proofs against a neighbour's ct2
     wrong = ct2[1:] + ct2[:1]
     got = pk.VerifyDDLEQInstancesBatch(ct1 + ct1, ct2 + wrong, xs + xs, ys + ys, al + al, es + es, fs + fs)
+    assert ctx.last_vm_launches() > 0 and ctx.last_vm_asm() == ctx.last_vm_launches()      # the 9 216-bit n^3 included
     assert got[:B] == [True] * B
     assert got[B:] == [po.verify_ddleq_proof_instance(sk_o, po.Ciphertext(c1, 1), po.Ciphertext(c2, 1),
                                                       po.DDLEQProofInstance(x, y, a_, e, f))
