@@ -88,6 +88,7 @@ struct pgpu_ctx {
   size_t lanes_wanted = 0;   // 0: default occupancy target; tests set 1 to run every modulus at its natural shape
   // A second stream for work of a call that depends on no ladder in flight (SideStream below; the DDLEQ prover's
   // per-statement chains run beside its big launches).  pgpu_ctx_set_flag("side", 0): everything on the one stream.
+  bool use_lanes8 = true;    // shards too small for four lanes per number take the eight-lane pair kernel (pgpu_ctx_set_flag("lanes8", 0): never)
   bool use_side = true;
   hipStream_t side = nullptr;
   std::vector<hipEvent_t> sync_evs;
@@ -234,6 +235,10 @@ struct PairInfo {
   int c_one_pair = -1;                // index of the pair form of 1 (the digits of R_H mod n^2) in the consts of n^2
   const uint32_t* dinv = nullptr;     // n^-1 mod 2^(28 H)
   const uint32_t* n_limbs = nullptr;  // n as H limbs
+  // the eight-lane pair kernel (GenQ8: every digit in four lanes of h8 / 4 limbs; h8 = H rounded up to a multiple of 4):
+  int h8 = 0;
+  const uint32_t* consts8 = nullptr;  // device: n | Cadj, h8 limbs each, + one word of padding
+  const uint32_t* tconsts8 = nullptr; // device: [3][2 h8] pair digits of R_h8^2 R_H^-1 (radix R_H -> R_h8), of R_H (back), of R_h8 (= 1)
 };
 
 // A modulus N = n^3 whose root n is known can run its ladders on the three-digit kernel (GenQ3): residues as
@@ -766,8 +771,8 @@ void run_vm(pgpu_ctx* ctx, size_t nb, const SegSpec& s0, const SegSpec* s1, bool
   if (s1 && pair != (s1->pair != nullptr)) api_throw(PGPU_ERR_INVALID, "segment kind mismatch");
   if (s2 && pair != (s2->pair != nullptr)) api_throw(PGPU_ERR_INVALID, "segment kind mismatch");
   if (pair) {
-    WL = s0.pair_lanes == 4 ? s0.pair_h / 2 : s0.pair_h;
-    K = s0.pair_lanes == 4 ? 64 : s0.pair_lanes == 3 ? 48 : s0.pair_lanes == 2 ? 32 : 16;   // tags of the pair kernels, not lane counts
+    WL = s0.pair_lanes == 8 ? s0.pair_h / 4 : s0.pair_lanes == 4 ? s0.pair_h / 2 : s0.pair_h;
+    K = s0.pair_lanes == 8 ? 96 : s0.pair_lanes == 4 ? 64 : s0.pair_lanes == 3 ? 48 : s0.pair_lanes == 2 ? 32 : 16;   // tags of the pair kernels, not lane counts
   } else {
     static const size_t lanes_env = [] { const char* e = getenv("PGPU_LANES_WANTED"); return e ? (size_t)atoll(e) : (size_t)0; }();
     const size_t lanes_wanted = ctx->lanes_wanted ? ctx->lanes_wanted : lanes_env ? lanes_env : (size_t)1024 * 64;
@@ -799,7 +804,7 @@ void run_vm(pgpu_ctx* ctx, size_t nb, const SegSpec& s0, const SegSpec* s1, bool
       const double H = s0.pair_h;
       mulp = 12.0 * H * H;
       sq = 8.0 * H * H;
-    } else if (pair && s0.pair_lanes == 4) {   // GenQ4: a squaring is one pass of H rows of 2 * H/2 multiplies in four lanes; a
+    } else if (pair && (s0.pair_lanes == 4 || s0.pair_lanes == 8)) {   // GenQ4 / GenQ8: a squaring is one pass of H rows of 2 * H/2 multiplies in four lanes; a
       const double H = s0.pair_h;              // product one pass with two multiplier streams (3 * H/2 multiplies a row)
       mulp = 6.0 * H * H;
       sq = 4.0 * H * H;
@@ -899,6 +904,7 @@ struct pgpu_pubkey {
   struct FixedBase { BigU base; int idx; int nwin; };
   std::vector<FixedBase> fixed_bases;   // comb tables of other fixed bases mod n^2 (verification keys)
   DevLimbs pairn_consts;          // n | Cadj | pad for the two-lane pair kernel (mn2.pairn points here)
+  DevLimbs pairn_consts8, pairn_tconsts8;   // the same for the eight-lane pair kernel (76-limb digits) and its three constants
   DevLimbs triple_kconsts;        // n | (C1_i, C2_i) pairs | pad for the three-digit kernel (mn3->triple points here)
   DevLimbs triple_tconsts;        // its constants in digit form
   std::vector<std::pair<int, int>> combine_consts;  // (total servers l, index of (4 (l!)^2)^-1 * R mod n in mn.consts)
@@ -1123,6 +1129,7 @@ int pgpu_ctx_set_flag(pgpu_ctx* ctx, const char* name, int value) {
   if (strcmp(name, "shared_chain") == 0) { ctx->use_shared_chain = value != 0; return PGPU_OK; }
   if (strcmp(name, "lift") == 0) { ctx->use_lift = value != 0; return PGPU_OK; }
   if (strcmp(name, "side") == 0) { ctx->use_side = value != 0; return PGPU_OK; }
+  if (strcmp(name, "lanes8") == 0) { ctx->use_lanes8 = value != 0; return PGPU_OK; }
   if (strcmp(name, "fair") == 0) { g_wave_priorities.store(value != 0, std::memory_order_relaxed); return PGPU_OK; }   // process-wide (see above)
   if (strcmp(name, "lanes_wanted") == 0) { ctx->lanes_wanted = value > 0 ? (size_t)value : 0; return PGPU_OK; }
   if (strcmp(name, "cu_partition") == 0) {
@@ -1891,6 +1898,35 @@ int pgpu_pubkey_create(pgpu_ctx* ctx, const uint8_t* n_be, size_t n_len, const u
       }
       pi.dinv = pk->ninv2k.d;
       pi.n_limbs = pk->n_limbs.d;
+      // the eight-lane variant: digits of h8 = 76 limbs (74 padded to four slices of 19), Montgomery radix R_76; a number enters
+      // with one product by the pair digits of R_76^2 R_74^-1 and leaves with one by those of R_74
+      const int h8 = (H + 3) / 4 * 4;
+      if (H % 2 == 0 && vm_asm_available(h8 / 4, 96)) {
+        std::vector<uint32_t> pc8 = make_pair_consts(pk->N, h8);
+        pc8.push_back(0);
+        pk->pairn_consts8.w = (int)pc8.size();
+        HIPCHK(hipMalloc((void**)&pk->pairn_consts8.d, pc8.size() * 4));
+        HIPCHK(hipMemcpy(pk->pairn_consts8.d, pc8.data(), pc8.size() * 4, hipMemcpyHostToDevice));
+        const BigU r8 = hostbig::shl(BigU(1), (size_t)LB * h8) % n2;
+        BigU rh_inv;
+        if (hostbig::modinv(rh, n2, rh_inv)) {
+          const BigU vals[3] = {hostbig::mulmod(hostbig::mulmod(r8, r8, n2), rh_inv, n2), rh, r8};
+          std::vector<uint32_t> tc;
+          for (const BigU& v : vals) {
+            BigU d1, d0;
+            hostbig::divmod(v, pk->N, d1, d0);
+            auto l0 = d0.to_limbs(LB, (size_t)h8), l1 = d1.to_limbs(LB, (size_t)h8);
+            tc.insert(tc.end(), l0.begin(), l0.end());
+            tc.insert(tc.end(), l1.begin(), l1.end());
+          }
+          pk->pairn_tconsts8.w = (int)tc.size();
+          HIPCHK(hipMalloc((void**)&pk->pairn_tconsts8.d, tc.size() * 4));
+          HIPCHK(hipMemcpy(pk->pairn_tconsts8.d, tc.data(), tc.size() * 4, hipMemcpyHostToDevice));
+          pi.h8 = h8;
+          pi.consts8 = pk->pairn_consts8.d;
+          pi.tconsts8 = pk->pairn_tconsts8.d;
+        }
+      }
     }
     if (pk->mn3 && pk->mn.K == 1 && vm_asm_available(pk->mn.WT, 48) && (size_t)LB * pk->mn3->WT >= n3.bit_length() + 3) {
       setup_triple(*pk->mn3, pk->mn, pk->mn2, pk->triple_kconsts, pk->triple_tconsts, pk->ninv2k.d, pk->ninv2k_2.d, pk->n_limbs.d,
@@ -3401,7 +3437,13 @@ int pgpu_partial_decrypt_units(const pgpu_pubkey* pk, int total_servers, int n_s
     for (auto& iv : ivs) longest = std::max(longest, iv.e - iv.b);
     const size_t nbs = round_up(longest, VM_BLOCK), SWs = (size_t)W2 * nbs;
     const size_t lanes_target = ctx->lanes_wanted ? ctx->lanes_wanted : (size_t)1024 * 64;
-    const int lanes = (ivs.size() * nbs * 2 >= lanes_target || !(H % 2 == 0 && vm_asm_available(H / 2, 64))) ? 2 : 4;
+    int lanes = (ivs.size() * nbs * 2 >= lanes_target || !(H % 2 == 0 && vm_asm_available(H / 2, 64))) ? 2 : 4;
+    // A shard so small that even four lanes per number leave SIMDs empty is bound by the LATENCY of one ladder: eight lanes per
+    // number (GenQ8: 76-limb digits in four lanes each, 38 multiplies a row and lane instead of 74) while every wave still has
+    // a SIMD of its own.  The digits change radix on the way in and out (R_74 <-> R_76: one product each, inside the program).
+    if (lanes == 4 && pi.consts8 && ctx->use_lanes8 && ivs.size() * nbs * 8 <= lanes_target) lanes = 8;
+    const int Hk = lanes == 8 ? pi.h8 : H;                  // limbs of a digit in the kernel's slots
+    const size_t SWk = (size_t)2 * Hk * nbs;                // words of a kernel slot
     const int w = 7;
     const uint32_t K = 1u << (w - 1);
     uint32_t* pm[3];
@@ -3411,30 +3453,54 @@ int pgpu_partial_decrypt_units(const pgpu_pubkey* pk, int total_servers, int n_s
     for (size_t t = 0; t < ivs.size(); ++t) {
       const Interval& iv = ivs[t];
       const size_t S = iv.servers.size();
+      if (lanes == 8) { pr[t].op(VM_LOAD, 2); pr[t].op(VM_MULC, 0); pr[t].op(VM_STORE, 2); }       // radix R_74 -> R_76
       if (S >= 2) {
         // slots: 2 in, 3 bp, 4 run, 5 acc, 6.. results, then the buckets (64 per server)
         out0[t] = 6;
         const uint32_t B0 = 6 + (uint32_t)S;
-        pm[t] = ctx->ws_t<uint32_t>(SWs * (size_t)(B0 + S * K));
+        pm[t] = ctx->ws_t<uint32_t>(SWk * (size_t)(B0 + S * K));
         std::vector<BigU> ev;
         WipeOnExit<std::vector<BigU>> wipe_ev(ev);
         for (int k : iv.servers) ev.push_back(es[(size_t)k]);
-        emit_multi_exp_shared_base(pr[t], ev, 2, 3, 4, 5, out0[t], B0, w, (uint32_t)pi.c_one_pair);
+        emit_multi_exp_shared_base(pr[t], ev, 2, 3, 4, 5, out0[t], B0, w, lanes == 8 ? 2u : (uint32_t)pi.c_one_pair);
       } else {
         out0[t] = 3;                                        // pair slots: 2 in, 3 out, 5.. table
-        pm[t] = ctx->ws_t<uint32_t>(SWs * (size_t)(5 + 32));
+        pm[t] = ctx->ws_t<uint32_t>(SWk * (size_t)(5 + 32));
         emit_modexp_shared(pr[t], es[(size_t)iv.servers[0]], 2, NO_SLOT, 2, 3, 5, NO_SLOT, true, true);
       }
+      if (lanes == 8)
+        for (size_t j = 0; j < S; ++j) {                     // radix R_76 -> R_74
+          pr[t].op(VM_LOAD, out0[t] + (uint32_t)j); pr[t].op(VM_MULC, 1); pr[t].op(VM_STORE, out0[t] + (uint32_t)j);
+        }
       pr[t].end();
-      launch_restride(ent + 2 * SW + iv.b, nb, iv.e - iv.b, nullptr, pm[t] + 2 * SWs, nbs, W2, ctx->stream);
+      const size_t cnt = iv.e - iv.b;
+      if (lanes == 8) {
+        // digits of 74 limbs -> the kernel's digits of 76 limbs (zero-extended)
+        uint32_t* in = pm[t] + 2 * SWk;
+        HIPCHK(hipMemsetAsync(in, 0, SWk * 4, ctx->stream));
+        launch_restride(ent + 2 * SW + iv.b, nb, cnt, nullptr, in, nbs, H, ctx->stream);
+        launch_restride(ent + 2 * SW + (size_t)H * nb + iv.b, nb, cnt, nullptr, in + (size_t)Hk * nbs, nbs, H, ctx->stream);
+      } else {
+        launch_restride(ent + 2 * SW + iv.b, nb, cnt, nullptr, pm[t] + 2 * SWs, nbs, W2, ctx->stream);
+      }
       sg[t] = SegSpec{&mc, &pr[t], pm[t], nullptr};
-      sg[t].pair = pi.consts; sg[t].pair_n0inv = mn.n0inv; sg[t].pair_h = H; sg[t].pair_lanes = lanes;
+      sg[t].pair = lanes == 8 ? pi.consts8 : pi.consts; sg[t].pair_n0inv = mn.n0inv; sg[t].pair_h = Hk; sg[t].pair_lanes = lanes;
+      if (lanes == 8) sg[t].tconsts = pi.tconsts8;
     }
     run_vm(ctx, nbs, sg[0], ivs.size() >= 2 ? &sg[1] : nullptr, true, 0, ivs.size() == 3 ? &sg[2] : nullptr);
+    uint32_t* back = lanes == 8 ? ctx->ws_t<uint32_t>(SWs * 4) : nullptr;     // (pair_leave wants 74-limb digits and two scratch slots)
     for (size_t t = 0; t < ivs.size(); ++t)
       for (size_t j = 0; j < ivs[t].servers.size(); ++j) {
         const size_t u0 = (size_t)ivs[t].servers[j] * batch + ivs[t].b - unit_begin;
-        pair_leave_and_pack(ctx, mc, pm[t], out0[t] + (uint32_t)j, nbs, ivs[t].e - ivs[t].b, out + u0 * out_stride, out_stride, mem);
+        const size_t cnt = ivs[t].e - ivs[t].b;
+        if (lanes == 8) {
+          const uint32_t* res = pm[t] + (size_t)(out0[t] + j) * SWk;
+          launch_restride(res, nbs, nbs, nullptr, back, nbs, H, ctx->stream);
+          launch_restride(res + (size_t)Hk * nbs, nbs, nbs, nullptr, back + (size_t)H * nbs, nbs, H, ctx->stream);
+          pair_leave_and_pack(ctx, mc, back, 0, nbs, cnt, out + u0 * out_stride, out_stride, mem);
+        } else {
+          pair_leave_and_pack(ctx, mc, pm[t], out0[t] + (uint32_t)j, nbs, cnt, out + u0 * out_stride, out_stride, mem);
+        }
       }
     HIPCHK(hipStreamSynchronize(ctx->stream));
   });

@@ -2462,6 +2462,7 @@ class GenQ4(Gen):
         self.n_vgpr = e
         assert e <= 256, e
         self._xb = self.vX
+        self.lanes_per_number = 4
         self.v_caddr = self.n_vgpr
         self.n_vgpr += 1
         assert self.n_vgpr <= 256, self.n_vgpr
@@ -2471,6 +2472,14 @@ class GenQ4(Gen):
         self.lds_z = self.lds_c + WL * 32       # 1 KB of zeros: the second multiplier stream of the lanes of digit zero
         self.lds_bytes = self.lds_z + 1024
         assert self.lds_bytes < 65536
+        # lane exchanges (GenQ8 below re-uses the rows with four slices per digit)
+        self.dpp_link = "quad_perm:[0,1,0,3]"    # slice 0 of digit one <- slice 0 of digit zero
+        self.dpp_bcast = "quad_perm:[0,0,2,2]"   # every slice of a digit <- its slice 0
+        self.dpp_next = "quad_perm:[1,1,3,3]"    # slice s <- slice s + 1 of the same digit
+        self.dpp_prev = "quad_perm:[0,0,2,2]"    # slice s <- slice s - 1
+        self.dpp_copy0 = "quad_perm:[0,1,0,1]"   # the lanes of digit one <- the same slices of digit zero
+        self.v_linkmask = self.v_l2mask          # -1 in the lane that takes the link
+        self.v_d1mask = None                     # -1 in the lanes of digit one (GenQ4: l2mask | l3mask, formed where needed)
 
     def X(self, j):
         return f"v{self._xb + j}"
@@ -2588,11 +2597,11 @@ class GenQ4(Gen):
         a = f"v{cur}"
         chain = [f"v_mul_lo_u32 {m}, {self.Tlo(0)}, s14", f"v_and_b32 {m}, {hex(MASK)}, {m}"]
         if link:
-            chain += [f"v_mov_b32_dpp v{g.v_d}, {m} quad_perm:[0,1,0,3] row_mask:0xf bank_mask:0xf",
-                      f"v_mad_i64_i32 {self.T(0)}, vcc, v{g.v_d}, v{g.v_l2mask}, {self.T(0)}",      # lane 2: T0 -= m of lane 0
+            chain += [f"v_mov_b32_dpp v{g.v_d}, {m} {self.dpp_link} row_mask:0xf bank_mask:0xf",
+                      f"v_mad_i64_i32 {self.T(0)}, vcc, v{g.v_d}, v{g.v_linkmask}, {self.T(0)}",    # digit one, slice 0: T0 -= m of digit zero
                       f"v_mul_lo_u32 {m}, {self.Tlo(0)}, s14",
                       f"v_and_b32 {m}, {hex(MASK)}, {m}"]
-        chain.append(f"v_mov_b32_dpp {m}, {m} quad_perm:[0,0,2,2] row_mask:0xf bank_mask:0xf")
+        chain.append(f"v_mov_b32_dpp {m}, {m} {self.dpp_bcast} row_mask:0xf bank_mask:0xf")
         muls = []
         for j in range(WL):
             muls.append((self.T(j), a, self.X(j)))
@@ -2626,8 +2635,8 @@ class GenQ4(Gen):
             self.mad(self.T(j - 1), m, N(j), self.T(j))
             if j == 4:
                 e(f"v_lshl_add_u64 {self.T(0)}, {self.T(0)}, 0, {self.P(g.v_c)}")
-        e(f"v_mov_b32_dpp {self.Tlo(WL - 1)}, v{g.v_y0} quad_perm:[1,1,3,3] row_mask:0xf bank_mask:0xf")
-        e(f"v_mov_b32_dpp {self.Thi(WL - 1)}, v{g.v_y0 + 1} quad_perm:[1,1,3,3] row_mask:0xf bank_mask:0xf")
+        e(f"v_mov_b32_dpp {self.Tlo(WL - 1)}, v{g.v_y0} {self.dpp_next} row_mask:0xf bank_mask:0xf")
+        e(f"v_mov_b32_dpp {self.Thi(WL - 1)}, v{g.v_y0 + 1} {self.dpp_next} row_mask:0xf bank_mask:0xf")
         e(f"v_and_b32 {self.Tlo(WL - 1)}, {self.Tlo(WL - 1)}, v{g.v_notlast}")
         e(f"v_and_b32 {self.Thi(WL - 1)}, {self.Thi(WL - 1)}, v{g.v_notlast}")
 
@@ -2637,7 +2646,7 @@ class GenQ4(Gen):
         WL, H = self.WL, self.H
         row = self.NPB * 4
         for j in range(WL):                                      # accumulators <- (0 | 0 | Cadj_j | Cadj_(WL+j)) by lane
-            e(f"ds_read_b64 {self.T(j)}, v{g.v_caddr} offset:{self.lds_c + 32 * j}")
+            e(f"ds_read_b64 {self.T(j)}, v{g.v_caddr} offset:{self.lds_c + self.lanes_per_number * 8 * j}")
         e(f"v_mov_b32 v{g.v_arow}, v{g.v_aread}")
         e(f"ds_read_b32 v{g.v_ain}, v{g.v_arow}")
         if two_streams:
@@ -2645,7 +2654,10 @@ class GenQ4(Gen):
             e(f"v_add_u32 v{g.v_arow2}, {H * row}, v{g.v_aread}")
             e(f"v_mov_b32 v{g.v_t2}, {self.lds_z}")
             e(f"v_xor_b32 v{g.v_t2}, v{g.v_t2}, v{g.v_arow2}")
-            e(f"v_or_b32 v{g.v_t3}, v{g.v_l2mask}, v{g.v_l3mask}")
+            if g.v_d1mask is None:
+                e(f"v_or_b32 v{g.v_t3}, v{g.v_l2mask}, v{g.v_l3mask}")
+            else:
+                e(f"v_mov_b32 v{g.v_t3}, v{g.v_d1mask}")
             e(f"v_and_b32 v{g.v_t2}, v{g.v_t2}, v{g.v_t3}")
             e(f"v_xor_b32 v{g.v_arow2}, {self.lds_z}, v{g.v_t2}")      # digit one: aread + H rows; digit zero: lds_z
             e(f"v_and_b32 v{g.v_bump2}, {2 * row}, v{g.v_t3}")
@@ -2674,8 +2686,9 @@ class GenQ4(Gen):
         WL = self.WL
         M = hex(MASK)
         c = self.P(g.v_c)
-        e(f"v_not_b32 v{g.v_t1}, v{g.v_isfirst}")                       # -1 in the upper slice of a digit
-        e(f"v_or_b32 v{g.v_t2}, {M}, v{g.v_t1}")                         # top-limb mask: 28 bits below, everything above
+        e(f"v_not_b32 v{g.v_t2}, v{g.v_notlast}")                       # -1 in the top slice of a digit
+        e(f"v_or_b32 v{g.v_t2}, {M}, v{g.v_t2}")                         # top-limb mask: 28 bits below the top slice, everything in it
+        e(f"v_not_b32 v{g.v_t1}, v{g.v_isfirst}")                       # -1 in every slice that has one below it
         e(f"v_and_b32 {self.X(0)}, {M}, {self.Tlo(0)}")
         e(f"v_lshrrev_b64 {c}, {LB}, {self.T(0)}")
         for j in range(1, WL):
@@ -2685,10 +2698,11 @@ class GenQ4(Gen):
             else:
                 e(f"v_and_b32 {self.X(j)}, {self.Tlo(j)}, v{g.v_t2}")
             e(f"v_lshrrev_b64 {c}, {LB}, {self.T(j)}")
-        # carry out of the lower slice -> the upper slice of the same digit (lanes 1 <- 0, 3 <- 2)
+        # carry out of a slice -> the next slice of the same digit (it lands in that slice's two lowest limbs and goes no
+        # further: the slices' own carries out were taken before it came in)
         e("s_nop 1")
-        e(f"v_mov_b32_dpp v{g.v_p0}, v{g.v_c} quad_perm:[0,0,2,2] row_mask:0xf bank_mask:0xf")
-        e(f"v_mov_b32_dpp v{g.v_p0 + 1}, v{g.v_c + 1} quad_perm:[0,0,2,2] row_mask:0xf bank_mask:0xf")
+        e(f"v_mov_b32_dpp v{g.v_p0}, v{g.v_c} {self.dpp_prev} row_mask:0xf bank_mask:0xf")
+        e(f"v_mov_b32_dpp v{g.v_p0 + 1}, v{g.v_c + 1} {self.dpp_prev} row_mask:0xf bank_mask:0xf")
         e(f"v_and_b32 v{g.v_p0}, v{g.v_p0}, v{g.v_t1}")
         e(f"v_and_b32 v{g.v_p0 + 1}, v{g.v_p0 + 1}, v{g.v_t1}")
         e(f"v_mov_b32 v{g.v_c}, {self.X(0)}")
@@ -2713,8 +2727,8 @@ class GenQ4(Gen):
         g, e = self, self.e
         e("L_montmul:")
         e("s_nop 1")
-        for j in range(self.WL):                                 # lanes 2, 3 <- the slices of a0 (lanes 0, 1 keep a copy of their own)
-            e(f"v_mov_b32_dpp v{g.vR2 + j}, {self.X(j)} quad_perm:[0,1,0,1] row_mask:0xf bank_mask:0xf")
+        for j in range(self.WL):                                 # digit one <- the slices of a0 (digit zero: whatever, times zero)
+            e(f"v_mov_b32_dpp v{g.vR2 + j}, {self.X(j)} {self.dpp_copy0} row_mask:0xf bank_mask:0xf")
         # digit zero: t = a0 b0 R^-1 (second stream: zeros); digit one: c1 = (a1 b0 + a0 b1 + Cadj - m) R^-1
         self.passes("m", True)
         self.normalize()
@@ -2727,6 +2741,129 @@ class GenQ4(Gen):
         self.montsq()
         self.epilogue()
         return "\n".join(self.lines) + "\n"
+
+
+class GenQ8(GenQ4):
+    """The pair kernel with every digit sliced over FOUR lanes: 8 lanes per number (lanes 0..3 = the 19-limb slices of a0, lanes
+    4..7 = those of a1; a digit is 76 limbs -- the 74 limbs of a 2048-bit n padded: the host converts between the two radices
+    R_74 and R_76 with one product on the way in and one on the way out).  The rows, the one-pass product and the carry
+    normalisation are GenQ4's with the exchanges of a four-slice number (one quad per digit; the link and the copy of a0 cross to
+    the quad above by row_shr:4).  A squaring is 76 rows of 38 multiplies per lane where GenQ4 has 74 rows of 74: what counts
+    when a batch is far too small to fill the chip and the LATENCY of one ladder is the run time (a rank's 6 144 units of the
+    sharded threshold flow at N = 8)."""
+
+    def __init__(self, WL=19):
+        Gen.__init__(self, WL, 4)
+        assert self.n_vreg and not self.flush
+        self.H = 4 * WL
+        self.WTslot = 8 * WL
+        self.WT = self.WTslot
+        self.NPB = BLOCK // 8
+        self.name = f"vm_asm_{WL}_96"
+        self.sq_rows = True
+        self.sq_rows_k = False
+        self.lanes_per_number = 8
+        self.lds_a = (4 * self.WLp * 4 + 15) // 16 * 16
+        e = self.n_vgpr
+        self.v_sh, self.v_l2mask, self.v_l3mask = e, e + 1, e + 2      # l2mask: the link lane (k8 == 4); l3mask: digit one (k8 >= 4)
+        e += 3
+        e = (e + 1) // 2 * 2
+        self.v_d = e
+        e += 2
+        self.vR2 = e
+        e += WL
+        self.v_ai2, self.v_ain2, self.v_arow2, self.v_bump2 = e, e + 1, e + 2, e + 3
+        e += 4
+        self._xb = self.vX
+        self.v_caddr = e
+        e += 1
+        self.n_vgpr = e
+        assert e <= 256, e
+        self.lds_c = self.lds_a + (self.WTslot + 1) * self.NPB * 4
+        self.lds_z = self.lds_c + WL * 64
+        self.lds_bytes = self.lds_z + 1024
+        assert self.lds_bytes < 65536
+        self.dpp_link = "row_shr:4"
+        self.dpp_bcast = "quad_perm:[0,0,0,0]"
+        self.dpp_next = "quad_perm:[1,2,3,3]"
+        self.dpp_prev = "quad_perm:[0,0,1,2]"
+        self.dpp_copy0 = "row_shr:4"
+        self.v_linkmask = self.v_l2mask
+        self.v_d1mask = self.v_l3mask
+
+    def prologue(self):
+        g, e = self, self.e
+        WL, NPB = self.WL, self.NPB
+        e(f'.amdgcn_target "amdgcn-amd-amdhsa--gfx950"')
+        e(".text")
+        e(f".globl {self.name}")
+        e(".p2align 8")
+        e(f".type {self.name},@function")
+        e(f"{self.name}:")
+        self.select_segment()
+        e("s_load_dwordx8 s[4:11], s[0:1], 0x0")
+        e("s_load_dwordx4 s[12:15], s[0:1], 0x20")
+        e("s_waitcnt lgkmcnt(0)")
+        e("s_lshl_b32 s3, s15, 2")
+        e(f"v_and_b32 v{g.v_t1}, 7, v0")                  # k8 = 4 d + s
+        e(f"v_lshlrev_b32 v{g.v_caddr}, 3, v{g.v_t1}")    # this lane's column of the constants table: k8 * 8
+        e(f"v_lshrrev_b32 v{g.v_t2}, 3, v0")              # gl
+        e(f"s_mul_i32 s{g.s_t0}, s2, {NPB}")
+        e(f"v_add_u32 v{g.v_t3}, s{g.s_t0}, v{g.v_t2}")   # g
+        e(f"s_mul_i32 s{g.s_t1}, s15, {WL}")
+        e(f"v_mul_lo_u32 v{g.v_t4}, v{g.v_t1}, s{g.s_t1}")
+        e(f"v_add_lshl_u32 v{g.v_goff}, v{g.v_t4}, v{g.v_t3}, 2")
+        e(f"v_lshlrev_b32 v{g.v_aread}, 2, v{g.v_t2}")
+        e(f"v_add_u32 v{g.v_aread}, {self.lds_a}, v{g.v_aread}")
+        e(f"v_mul_u32_u24 v{g.v_t4}, {WL * NPB * 4}, v{g.v_t1}")
+        e(f"v_add_u32 v{g.v_awrite}, v{g.v_t4}, v{g.v_aread}")
+        e(f"v_mul_u32_u24 v{g.v_koff}, {WL * 4}, v{g.v_t1}")
+        e(f"v_and_b32 v{g.v_t4}, 3, v{g.v_t1}")           # s
+        e(f"v_mul_u32_u24 v{g.v_nbase}, {self.WLp * 4}, v{g.v_t4}")
+        e(f"v_lshrrev_b32 v{g.v_sh}, 2, v{g.v_t1}")       # d (kept; a squaring uses it as the multiplicand shift)
+        e(f"v_cmp_eq_u32 vcc, 0, v{g.v_t4}")
+        e("s_nop 1")
+        e(f"v_cndmask_b32 v{g.v_isfirst}, 0, -1, vcc")
+        e(f"v_cmp_ne_u32 vcc, 3, v{g.v_t4}")
+        e("s_nop 1")
+        e(f"v_cndmask_b32 v{g.v_notlast}, 0, -1, vcc")
+        e(f"v_cmp_eq_u32 vcc, 4, v{g.v_t1}")
+        e("s_nop 1")
+        e(f"v_cndmask_b32 v{g.v_l2mask}, 0, -1, vcc")
+        e(f"v_cmp_le_u32 vcc, 4, v{g.v_t1}")
+        e("s_nop 1")
+        e(f"v_cndmask_b32 v{g.v_l3mask}, 0, -1, vcc")
+        # modulus n (4 slices) -> LDS -> this lane's slice in VGPRs
+        e(f"v_lshlrev_b32 v{g.v_t3}, 2, v0")
+        e(f"v_cmp_gt_u32 vcc, {WL}, v0")
+        e("s_nop 1")
+        e("s_and_saveexec_b64 s[96:97], vcc")
+        for sgi in range(4):
+            e(f"global_load_dword v{g.v_p1}, v{g.v_t3}, s[6:7] offset:{sgi * WL * 4}")
+            e("s_waitcnt vmcnt(0)")
+            e(f"ds_write_b32 v{g.v_t3}, v{g.v_p1} offset:{sgi * self.WLp * 4}")
+        # constants table: thread t < WL writes row t = (0 0 0 0 | Cadj_t, Cadj_(WL+t), Cadj_(2WL+t), Cadj_(3WL+t)), zero-extended
+        e(f"v_lshlrev_b32 v{g.v_t4}, 4, v{g.v_t3}")        # t * 64
+        e(f"v_mov_b32 v{g.v_y0}, 0")
+        e(f"v_mov_b32 v{g.v_y0 + 1}, 0")
+        e(f"v_mov_b32 v{g.v_p0 + 1}, 0")
+        for sgi in range(4):
+            e(f"ds_write_b64 v{g.v_t4}, {self.P(g.v_y0)} offset:{self.lds_c + 8 * sgi}")
+        for sgi in range(4):
+            e(f"global_load_dword v{g.v_p0}, v{g.v_t3}, s[6:7] offset:{4 * self.H + 4 * WL * sgi}")
+            e("s_waitcnt vmcnt(0)")
+            e(f"ds_write_b64 v{g.v_t4}, {self.P(g.v_p0)} offset:{self.lds_c + 32 + 8 * sgi}")
+        e("s_waitcnt lgkmcnt(0)")
+        e("s_mov_b64 exec, s[96:97]")
+        e(f"v_mov_b32 v{g.v_p0}, 0")
+        e(f"ds_write_b32 v{g.v_t3}, v{g.v_p0} offset:{self.lds_z}")      # every thread zeroes one word of the zero rows
+        e("s_waitcnt lgkmcnt(0)")
+        e("s_barrier")
+        for j in range(WL):
+            e(f"ds_read_b32 v{g.v_N + j}, v{g.v_nbase} offset:{4 * j}")
+        e("s_waitcnt lgkmcnt(0)")
+        for j in range(WL):
+            e(f"v_mov_b32 {self.X(j)}, 0")
 
 
 class GenQ3(Gen):
@@ -3189,9 +3326,10 @@ class GenQ3(Gen):
         return "\n".join(self.lines) + "\n"
 
 
-SHAPES = [(74, 1), (37, 1), (55, 1), (55, 2), (74, 2), (55, 4), (74, 4), (42, 8), (37, 2), (37, 4), (37, 16), (55, 16), (74, 32), (55, 32), (37, 32), (37, 64), (74, 48), (37, 48), (55, 48)]
+SHAPES = [(74, 1), (37, 1), (55, 1), (55, 2), (74, 2), (55, 4), (74, 4), (42, 8), (37, 2), (37, 4), (37, 16), (55, 16), (74, 32), (55, 32), (37, 32), (37, 64), (19, 96), (74, 48), (37, 48), (55, 48)]
 PAIR = {(37, 16), (55, 16)}  # (H, 16): the pair kernel for N = p^2 with H-limb p (GenP); 16 is a tag, not a lane count
 PAIR4 = {(37, 64)}          # (WL, 64): GenQ4, the two digits of GenQ(2 WL) sliced over two lanes each
+PAIR8 = {(19, 96)}          # (WL, 96): GenQ8, the two digits sliced over four lanes each (76-limb digits)
 PAIR2 = {(74, 32), (55, 32), (37, 32)}          # (H, 32): the two-lane pair kernel for N = n^2 with H-limb n (GenQ)
 WAVE_SLICED = {(74, 2), (55, 2)}     # shapes whose slices live in different waves (GenW) instead of neighbouring lanes (Gen)
 TRIPLE = {(74, 48), (37, 48), (55, 48)}        # (H, 48): GenQ3, residues modulo n^3 as three base-n digits in the lanes of a quad
@@ -3204,6 +3342,8 @@ def make_gen(wl, k):
         return GenQ(wl)
     if (wl, k) in PAIR4:
         return GenQ4(wl)
+    if (wl, k) in PAIR8:
+        return GenQ8(wl)
     if (wl, k) in TRIPLE:
         return GenQ3(wl)
     return GenW(wl, k) if (wl, k) in WAVE_SLICED else Gen(wl, k)

@@ -203,3 +203,25 @@ if "ddleq2048" in which:  # BASELINE config 5 (per-instance throughput, secpar =
                       "prove_instances_per_s": B / t_p, "verify_instances_per_s_host_orchestrated": B / t_v,
                       "verify_instances_per_s_device_resident": B / t_vd, "prove_instances_per_s_device_resident": B / t_pd,
                       "parity": "all verify; instance 0 vs oracle"}), flush=True)
+
+if "l2_3072" in which:   # level two at 3072 bits: n^3 is 9 216 bits -- vm_asm_42_8, eight lanes per number (round 3; rounds 1-2: hipcc (83,4))
+    n, lam = key(3072)
+    pk = pa.PublicKey(ctx, n); sk = pa.SecretKey(ctx, pk, lam)
+    B = 8192; rng = np.random.default_rng(33)
+    m_h = rand_below(n * n, B, 768, rng); r_h = rand_below(n, B, 384, rng); r_h[:, -1] |= 1
+    m = torch.from_numpy(m_h).to(dev); r = torch.from_numpy(r_h).to(dev)
+    c = torch.zeros((B, 1152), dtype=torch.uint8, device=dev); o = torch.zeros((B, 768), dtype=torch.uint8, device=dev)
+    dt = timed(lambda: pk.encrypt_with_r_raw(B, m.data_ptr(), 768, r.data_ptr(), 384, c.data_ptr(), 1152, MEM_DEVICE, level=1), reps=2)
+    prof = ctx.last_profile()
+    all_asm = ctx.last_vm_asm() == ctx.last_vm_launches()
+    dtd = timed(lambda: sk.decrypt_raw(B, c.data_ptr(), 1152, o.data_ptr(), 768, MEM_DEVICE, level=1), reps=2)
+    profd = ctx.last_profile()
+    assert torch.equal(o, m), "level-two round trip at 3072 bits"
+    mi, ri, ci = be_to_ints(m_h[:2]), be_to_ints(r_h[:2]), be_to_ints(c[:2].cpu().numpy())
+    sk_o = po.SecretKey(N=n, G=n + 1, Lambda=lam)
+    assert ci == [po.encrypt_with_r_at_level(sk_o, a, b, po.ENC_LEVEL_TWO).C for a, b in zip(mi, ri)]
+    print(json.dumps({"config": "Batch 8192 level-two EncryptWithR / Decrypt, 3072-bit n (n^3 = 9216 bits)", "encrypt_l2_3072_per_s": B / dt,
+                      "encrypt_kernel": prof["kernel"], "encrypt_vm_ms": prof["vm_ms"],
+                      "encrypt_frac_of_issue_peak": prof["vm_mads"] / (prof["vm_ms"] * 1e-3) / 39.3216e12,
+                      "every_vm_launch_in_assembly": bool(all_asm), "decrypt_l2_3072_per_s": B / dtd, "decrypt_kernel": profd["kernel"],
+                      "parity": "8192-lane round trip + 2 lanes vs oracle"}), flush=True)
