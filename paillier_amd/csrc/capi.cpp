@@ -1257,13 +1257,32 @@ void modexp_pair(pgpu_ctx* ctx, const ModCtx& mc, const ModexpPlan& pl, const Bi
     HIPCHK(hipMemcpyAsync(mem + 2 * SW, x0, S1 * 4, hipMemcpyDeviceToDevice, ctx->stream));
   }
   // (3) the ladder in pair form
-  {
+  if (lanes == 8 && !exps) {
+    // eight lanes per number (GenQ8, shared exponents only): slots of 2 x 76 limbs of their own; the digits are zero-extended,
+    // change radix R_74 -> R_76 with the first product of the program and come back with its last
+    const int H8 = pi.h8;
+    const size_t SW8 = (size_t)2 * H8 * nb;
+    uint32_t* m8 = ctx->ws_t<uint32_t>(SW8 * (size_t)(5 + 32));        // pair slots: 2 in, 3 out, 5.. table
+    HIPCHK(hipMemsetAsync(m8 + 2 * SW8, 0, SW8 * 4, ctx->stream));
+    launch_restride(mem + 2 * SW, nb, nb, nullptr, m8 + 2 * SW8, nb, H, ctx->stream);
+    launch_restride(mem + 2 * SW + S1, nb, nb, nullptr, m8 + 2 * SW8 + (size_t)H8 * nb, nb, H, ctx->stream);
+    Prog p;
+    p.op(VM_LOAD, 2); p.op(VM_MULC, 0); p.op(VM_STORE, 2);
+    emit_modexp_shared(p, *e, 2, NO_SLOT, 2, 3, 5, NO_SLOT, true, true);
+    p.op(VM_LOAD, 3); p.op(VM_MULC, 1); p.op(VM_STORE, 3);
+    p.end();
+    SegSpec sp{&mc, &p, m8, nullptr};
+    sp.pair = pi.consts8; sp.pair_n0inv = mn.n0inv; sp.pair_h = H8; sp.pair_lanes = 8; sp.tconsts = pi.tconsts8;
+    run_vm(ctx, nb, sp, nullptr, true);
+    launch_restride(m8 + 3 * SW8, nb, nb, nullptr, mem + 3 * SW, nb, H, ctx->stream);
+    launch_restride(m8 + 3 * SW8 + (size_t)H8 * nb, nb, nb, nullptr, mem + 3 * SW + S1, nb, H, ctx->stream);
+  } else {
     Prog p;
     if (exps) emit_modexp_perlane(p, we, 2, NO_SLOT, 2, 3, 5, NO_SLOT, pi.c_one_pair);
     else emit_modexp_shared(p, *e, 2, NO_SLOT, 2, 3, 5, NO_SLOT, true, true);
     p.end();
     SegSpec sp{&mc, &p, mem, exps};
-    sp.pair = pi.consts; sp.pair_n0inv = mn.n0inv; sp.pair_h = H; sp.pair_lanes = lanes;
+    sp.pair = pi.consts; sp.pair_n0inv = mn.n0inv; sp.pair_h = H; sp.pair_lanes = lanes == 8 ? 4 : lanes;
     run_vm(ctx, nb, sp, nullptr, true);
   }
   // (4) F~ = F0 + F1 n, out of pair and Montgomery form, times the plain residue in the post slot
@@ -1407,7 +1426,10 @@ void modexp_shared_run(pgpu_ctx* ctx, const ModCtx& mc, const ModexpPlan& pl, co
   const bool two = pl.nb * 2 >= (ctx->lanes_wanted ? ctx->lanes_wanted : (size_t)1024 * 64);
   if (mc.pairn.root && ctx->use_asm && ctx->use_pair && !wide && skip_zero && e.bit_length() >= 256 &&
       (two || (mc.pairn.root->WT % 2 == 0 && vm_asm_available(mc.pairn.root->WT / 2, 64)))) {
-    modexp_pair(ctx, mc, pl, &e, nullptr, 0, use_post, two ? 2 : 4);
+    // (a batch that leaves SIMDs empty even at four lanes per number is bound by one ladder's latency: eight lanes, GenQ8)
+    const size_t lt = ctx->lanes_wanted ? ctx->lanes_wanted : (size_t)1024 * 64;
+    const bool eight = !two && mc.pairn.consts8 && ctx->use_lanes8 && pl.nb * 8 <= lt;
+    modexp_pair(ctx, mc, pl, &e, nullptr, 0, use_post, two ? 2 : eight ? 8 : 4);
     launch_canon(pl.out(), mc.d_nmod, mc.WT, pl.nb, ctx->stream);
     return;
   }
