@@ -108,7 +108,7 @@ struct pgpu_ctx {
     // Chunks are kept across calls (the same call sequence lands in the same chunks again: no allocation in steady
     // state).  Only a long tail of chunks is consolidated: that costs a device synchronisation and a large hipMalloc
     // (~100 ms), which must not land in a caller's second call.
-    if (chunks.size() > 8) {
+    if (chunks.size() > 12) {
       HIPCHK(hipStreamSynchronize(stream));
       size_t total = 0;
       for (auto& c : chunks) { total += c.cap; HIPCHK(hipFree(c.p)); }
@@ -129,11 +129,11 @@ struct pgpu_ctx {
     bytes = round_up(bytes ? bytes : 1, 256);
     for (auto& c : chunks)
       if (c.cap - c.used >= bytes) { void* p = c.p + c.used; c.used += bytes; return p; }
-    // geometric growth (a new chunk is at least as large as everything before it, up to 8 GiB): the list stays short, so
+    // geometric growth (a new chunk is at least as large as everything before it, up to 64 GiB of the 288): the list stays short, so
     // the consolidation in reset_ws() -- a free and a multi-GiB hipMalloc inside some later call -- stays rare
     size_t total = 0;
     for (auto& k : chunks) total += k.cap;
-    Chunk c{nullptr, std::max(round_up(bytes, 64 << 20), std::min<size_t>(total, (size_t)8 << 30)), bytes};
+    Chunk c{nullptr, std::max(round_up(bytes, 64 << 20), std::min<size_t>(total, (size_t)64 << 30)), bytes};
     HIPCHK(hipMalloc((void**)&c.p, c.cap));
     chunks.push_back(c);
     return c.p;
@@ -2173,7 +2173,10 @@ uint32_t* decrypt1_crt(const pgpu_seckey* sk, const uint32_t* c_limbs, size_t nb
   const size_t lanes_target = ctx->lanes_wanted ? ctx->lanes_wanted : (size_t)1024 * 64;
   // one lane per number (GenP) from one wave per SIMD upwards; two lanes per number (GenQ) from there down to one wave
   // per SIMD again; below that the ordinary kernels with their finer slicings
-  const int pair_lanes_now = (sk->pair_lanes == 1 && sk->pair_small2 && nb * 2 < lanes_target) ? 2 : sk->pair_lanes;
+  // two lanes per number while they leave every wave a SIMD of its own (both halves: 4 nb lanes); between half a wave and one
+  // wave per SIMD at one lane the two-lane kernel would put two waves on most SIMDs: 16.9 ms against 14.5 ms for 20 480 ...
+  // 30 720 ciphertexts (tools/decrypt_lanes_probe.py)
+  const int pair_lanes_now = (sk->pair_lanes == 1 && sk->pair_small2 && nb * 4 <= lanes_target) ? 2 : sk->pair_lanes;
   // (a two-lane digit pass is 2 H^2 multiplies per lane: shorter than any slicing of the 2H-limb kernels for H <= 55, so it
   // also wins when the batch is latency-bound; for H = 74 the 4-lane slicing has the same length and fills the chip better)
   if (sk->has_pair && ctx->use_asm && ctx->use_pair && (pair_lanes_now == 1 || W1 <= 55 || nb * 4 >= lanes_target)) {
@@ -4021,30 +4024,36 @@ void shared_pow(pgpu_ctx* ctx, const ModCtx& mc, const uint32_t* base, int wb, c
 // pair form on the one-lane pair kernel, both halves in ONE two-segment launch.  xs / ys: canonical residues modulo p^2 / q^2
 // (mp2.WT limbs, stride nb).  outs[half]: canonical results.  False when the one-lane pair kernel does not serve this key.
 bool pow_p2_multi_crt(const pgpu_seckey* sk, const uint32_t* const xs[2], const uint32_t* const r1[2], int we,
-                      const uint32_t* const ys[2], const BigU s1[2], size_t nb, uint32_t* outs[2]) {
+                      const uint32_t* const ys[2], const BigU s1[2], size_t nb, uint32_t* outs[2],
+                      const uint32_t* const xs_b[2] = nullptr, const uint32_t* const r1_b[2] = nullptr) {
+  // xs_b / r1_b: a SECOND base with per-number exponents (the response of the DDLEQ prover: s^(e_s) b^(e_b)), not together with ys
   pgpu_ctx* ctx = sk->ctx;
   if (!(sk->has_pair && sk->pair_lanes == 1 && sk->c_onep_p2 >= 0 && sk->c_onep_q2 >= 0 && sk->c_rh_p2 >= 0 && ctx->use_asm &&
         ctx->use_pair && sk->mp2.WT == 2 * sk->mp.WT && sk->mq2.WT == 2 * sk->mq.WT))
     return false;
   // one lane per number when the two halves fill the chip that way, else two (as Decrypt chooses)
   const size_t lanes_target = ctx->lanes_wanted ? ctx->lanes_wanted : (size_t)1024 * 64;
-  const int lanes = (sk->pair_small2 && nb * 2 < lanes_target) ? 2 : 1;
+  // (two lanes per number pay while they still leave every wave a SIMD of its own: above half a wave per SIMD at one lane, two
+  // lanes are two waves on most SIMDs -- 1.15 x the one-lane ladder -- and the one-lane kernel needs fewer multiplies)
+  const int lanes = (sk->pair_small2 && nb * 4 <= lanes_target) ? 2 : 1;
   const int H = sk->mp.WT, W2 = sk->mp2.WT;
   const size_t S1 = (size_t)H * nb, S2 = (size_t)W2 * nb;
   const int wb = 4;                                           // per-number windows: VM_MULV
   if ((uint64_t)nb * W2 * 4 * 17 >= (1ull << 32)) return false;
   const uint32_t TAB1 = 5, TAB2 = TAB1 + (1u << wb);
+  if (xs_b && (ys || !r1 || !r1_b)) return false;
   uint32_t* mem[2];
   Prog pr[2];
+  const uint32_t* dig[2] = {r1 ? r1[0] : nullptr, r1 ? r1[1] : nullptr};
   uint32_t* ent = ctx->ws_t<uint32_t>(S2 * 4);
   uint32_t* x0 = ctx->ws_t<uint32_t>(S1);
   uint32_t* tb = ctx->ws_t<uint32_t>(S2);
   for (int half = 0; half < 2; ++half) {
     const ModCtx &m1 = half ? sk->mq : sk->mp, &m2 = half ? sk->mq2 : sk->mp2;
     mem[half] = ctx->ws_t<uint32_t>(S2 * (size_t)(TAB2 + 64));      // 0 x, 1 y, 2 tmp, 3 out, 5.. / TAB2.. the tables
-    for (int k = 0; k < (ys ? 2 : 1); ++k) {
+    for (int k = 0; k < ((ys || xs_b) ? 2 : 1); ++k) {
       // pair-form entry: X = v R_H mod prime^2, then its digits X0 + X1 prime
-      HIPCHK(hipMemcpyAsync(ent, k ? ys[half] : xs[half], S2 * 4, hipMemcpyDeviceToDevice, ctx->stream));
+      HIPCHK(hipMemcpyAsync(ent, k ? (ys ? ys[half] : xs_b[half]) : xs[half], S2 * 4, hipMemcpyDeviceToDevice, ctx->stream));
       Prog a;
       a.op(VM_LOAD, 0); a.op(VM_MULC, C_R2); a.op(VM_MULC, (uint32_t)(half ? sk->c_rh_q2 : sk->c_rh_p2)); a.op(VM_STORE, 3); a.end();
       SegSpec sa{&m2, &a, ent, nullptr};
@@ -4060,11 +4069,19 @@ bool pow_p2_multi_crt(const pgpu_seckey* sk, const uint32_t* const xs[2], const 
     if (ys) sh.push_back(SharedBase{s1[half], 1, TAB2});
     std::vector<PerNumberBase> pn;
     if (r1) pn.push_back(PerNumberBase{we, 0, TAB1, 0});
+    if (xs_b) {
+      // the two exponents of a number one after the other in the rows of `digits` (as pow_n3_crt_two keeps them)
+      pn.push_back(PerNumberBase{we, 1, TAB2, (uint32_t)perlane_windows(we, wb)});
+      uint32_t* d2 = ctx->ws_t<uint32_t>((size_t)2 * we * nb);
+      HIPCHK(hipMemcpyAsync(d2, r1[half], (size_t)we * nb * 4, hipMemcpyDeviceToDevice, ctx->stream));
+      HIPCHK(hipMemcpyAsync(d2 + (size_t)we * nb, r1_b[half], (size_t)we * nb * 4, hipMemcpyDeviceToDevice, ctx->stream));
+      dig[half] = d2;
+    }
     emit_modexp_multi(pr[half], pn, wb, sh, 2, 3, (uint32_t)(half ? sk->c_onep_q2 : sk->c_onep_p2));
     pr[half].end();
   }
   {
-    SegSpec sp{&sk->mp2, &pr[0], mem[0], r1 ? r1[0] : nullptr}, sq{&sk->mq2, &pr[1], mem[1], r1 ? r1[1] : nullptr};
+    SegSpec sp{&sk->mp2, &pr[0], mem[0], dig[0]}, sq{&sk->mq2, &pr[1], mem[1], dig[1]};
     sp.pair = sk->pair_p.d; sp.pair_n0inv = sk->mp.n0inv; sp.pair_h = H; sp.pair_lanes = lanes;
     sq.pair = sk->pair_q.d; sq.pair_n0inv = sk->mq.n0inv; sq.pair_h = H; sq.pair_lanes = lanes;
     run_vm(ctx, nb, sp, &sq, true);
@@ -4299,6 +4316,90 @@ bool pow_n3_crt_two(const pgpu_seckey* sk, const uint32_t* A, const uint32_t* co
   const int H = mp3.triple.root->WT, we = sk->eo_p.w;
   if (triple_window_bits(nb, H) != 7) return false;
   const int win = 7;
+  // The p-adic split of BOTH exponents (what pow_n3_crt does for one): with e = e0 + e1 prime,
+  //     A^(ea) B^(eb) = (A^(ea1) B^(eb1))^prime * A^(ea0) B^(eb0)    and    W^prime mod prime^3 depends on W mod prime^2 only,
+  // so W is an interleaved ladder of 2 047 squarings modulo prime^2 on the one-lane pair kernel (two per-number exponents, 4-bit
+  // windows) and the rest an interleaved ladder of 1 024 squarings modulo prime^3 with two per-number exponents and the shared
+  // exponent prime on W -- where the unsplit ladder squares 3 071 times modulo prime^3.  Taken when the stage modulo prime^2
+  // fills the chip (the response batch of ProveDDLEQ at secpar 40: half of 61 440 instances).
+  {
+    const size_t lanes_target_s = ctx->lanes_wanted ? ctx->lanes_wanted : (size_t)1024 * 64;
+    const int H1 = sk->mp.WT, W2 = sk->mp2.WT;
+    if (ctx->use_lift && sk->mp2.WT == 2 * sk->mp.WT && sk->mq2.WT == 2 * sk->mq.WT && nb * 4 >= lanes_target_s && we <= 3 * H1 &&
+        sk->pinv2k_2.d && sk->qinv2k_2.d && (uint64_t)nb * 3 * H1 * 4 * 129 < (1ull << 32) && H1 == H) {
+      const size_t S1 = (size_t)H1 * nb, S2 = (size_t)W2 * nb;
+      const uint32_t *a0[2], *a1[2], *b0[2], *b1[2], *A2[2], *B2[2];
+      uint32_t *Ar[2], *Br[2];
+      uint32_t* tbx = ctx->ws_t<uint32_t>(S);
+      for (int half = 0; half < 2; ++half) {
+        const ModCtx &m1 = half ? sk->mq : sk->mp, &m2 = half ? sk->mq2 : sk->mp2, &m3 = half ? mq3 : mp3;
+        for (int k = 0; k < 2; ++k) {
+          const uint32_t* ex = k ? eb[half] : ea[half];
+          uint32_t* t2 = ctx->ws_t<uint32_t>(S2);
+          uint32_t* d0 = ctx->ws_t<uint32_t>(S1);
+          uint32_t* d1 = ctx->ws_t<uint32_t>(S2);
+          reduce_mod(ctx, m2, ex, we, t2, nb);
+          reduce_mod(ctx, m1, t2, W2, d0, nb);                                                       // e0 = e mod prime
+          launch_div_exact(ex, we, 0, d0, H1, tbx, (half ? sk->qinv2k_2 : sk->pinv2k_2).d, m1.d_nmod, H1, d1, W2, nb, nb, nullptr, 0,
+                           ctx->stream);                                                             // e1 = (e - e0) / prime
+          (k ? b0 : a0)[half] = d0;
+          (k ? b1 : a1)[half] = d1;
+          uint32_t* r3 = ctx->ws_t<uint32_t>(S);
+          reduce_mod(ctx, m3, k ? B : A, W3, r3, nb);
+          (k ? Br : Ar)[half] = r3;
+          uint32_t* r2 = ctx->ws_t<uint32_t>(S2);
+          reduce_mod(ctx, m2, r3, W, r2, nb);
+          (k ? B2 : A2)[half] = r2;
+        }
+      }
+      uint32_t* wv[2];
+      if (pow_p2_multi_crt(sk, A2, a1, W2, nullptr, nullptr, nb, wv, B2, b1)) {
+        // stage B: slots 0 A, 1 B, 2 tmp, 3 out, 4 W, 5.. A's table, then B's, then W's odd powers
+        const uint32_t TA = 5, TB = TA + (uint32_t)perlane_table_slots(win), TW = TB + (uint32_t)perlane_table_slots(win);
+        TriplePlan up = triple_alloc(ctx, mp3, nb, (int)TW + 64), uq = triple_alloc(ctx, mq3, nb, (int)TW + 64);
+        uint32_t* g2 = ctx->ws_t<uint32_t>(S * 6);
+        Prog pb[2];
+        const uint32_t* dg2[2];
+        for (int half = 0; half < 2; ++half) {
+          const ModCtx& m3 = half ? mq3 : mp3;
+          const TriplePlan& t = half ? uq : up;
+          triple_enter(ctx, m3, Ar[half], t, 0);
+          triple_enter(ctx, m3, Br[half], t, 1);
+          uint32_t* wz = ctx->ws_t<uint32_t>(S);
+          launch_copy_limbs(wv[half], 0, W2, wz, W, nb, ctx->stream);
+          triple_enter(ctx, m3, wz, t, 4);
+          uint32_t* d2 = ctx->ws_t<uint32_t>((size_t)2 * H1 * nb);
+          HIPCHK(hipMemcpyAsync(d2, a0[half], S1 * 4, hipMemcpyDeviceToDevice, ctx->stream));
+          HIPCHK(hipMemcpyAsync(d2 + S1, b0[half], S1 * 4, hipMemcpyDeviceToDevice, ctx->stream));
+          dg2[half] = d2;
+          std::vector<SharedBase> sh;
+          sh.push_back(SharedBase{half ? sk->q : sk->p, 4, TW});
+          std::vector<PerNumberBase> pn;
+          pn.push_back(PerNumberBase{H1, 0, TA, 0});
+          pn.push_back(PerNumberBase{H1, 1, TB, (uint32_t)perlane_windows(H1, win)});
+          emit_modexp_multi(pb[half], pn, win, sh, 2, 3, 0);
+          pb[half].end();
+        }
+        SegSpec sp{&mp3, &pb[0], up.mem, dg2[0]}, sq{&mq3, &pb[1], uq.mem, dg2[1]};
+        sp.pair = mp3.triple.kconsts; sp.pair_n0inv = sk->mp.n0inv; sp.pair_h = up.H; sp.pair_lanes = 3; sp.tconsts = mp3.triple.tconsts;
+        sq.pair = mq3.triple.kconsts; sq.pair_n0inv = sk->mq.n0inv; sq.pair_h = uq.H; sq.pair_lanes = 3; sq.tconsts = mq3.triple.tconsts;
+        run_vm(ctx, nb, sp, &sq, true);
+        triple_exit(ctx, mp3, up, 3, g2 + 0 * S, nullptr);
+        triple_exit(ctx, mq3, uq, 3, g2 + 1 * S, nullptr);
+        Prog c;
+        c.op(VM_LOAD, 0); c.op(VM_MULC, (uint32_t)sk->c_p3invR); c.op(VM_STORE, 3);
+        c.op(VM_LOAD, 1); c.op(VM_MULC, (uint32_t)sk->c_p3invR); c.op(VM_STORE, 2);
+        c.end();
+        SegSpec sc{&mq3, &c, g2, nullptr};
+        run_vm(ctx, nb, sc, nullptr, false);
+        launch_canon(g2 + 2 * S, mq3.d_nmod, W, nb, ctx->stream);
+        launch_canon(g2 + 3 * S, mq3.d_nmod, W, nb, ctx->stream);
+        launch_sub_mod(g2 + 2 * S, g2 + 3 * S, mq3.d_nmod, g2 + 4 * S, W, nb, ctx->stream);               // h = (x_q - x_p) / p^3 mod q^3
+        launch_mul_const_add(g2 + 4 * S, W, sk->p3_limbs.d, W, g2, W, 0, out, W3, nb, ctx->stream);       // x_p + p^3 h
+        return true;
+      }
+    }
+  }
   const uint32_t TABA = 5, TABB = TABA + (uint32_t)perlane_table_slots(win);
   TriplePlan tp = triple_alloc(ctx, mp3, nb, (int)TABB + perlane_table_slots(win)), tq = triple_alloc(ctx, mq3, nb, (int)TABB + perlane_table_slots(win));
   uint32_t* g = ctx->ws_t<uint32_t>(S * 6);       // generic slots (W limbs): 0 x_p, 1 x_q, 2 A, 3 B, 4 h, 5 scratch
@@ -4481,23 +4582,7 @@ static void ddleq_prove_impl(const pgpu_seckey* sk, size_t S, size_t secpar, con
     BigU ns_inv;
     if (!hostbig::modinv(N2 % sk->lambda, sk->lambda, ns_inv)) api_throw(PGPU_ERR_NOT_INVERTIBLE, "n^2 is not invertible mod lambda");
     uint32_t* qs = nullptr;                                  // s per statement (W1 limbs, stride nbs)
-    side.enter(side.mark());
-    {
-      // s = ExtractRandonness(ct1) at level two (operations.go:75-91): z = G^(-v) ct1 mod n^3 with v = Decrypt(ct1)
-      // (operations.go:81-86) is only ever used modulo n (:88), and G^v = (1 + n)^v = 1 (mod n) whatever v is (the prover
-      // requires G = n + 1): z = ct1 (mod n).  No decryption, no G^v, no inversion modulo n^3 -- the same s.
-      uint32_t* z2 = ctx->ws_t<uint32_t>((size_t)W2 * nbs);
-      reduce_mod(ctx, mn2, c1s, W3, z2, nbs);
-      if (sk->has_crt && sk->mp.WT * 2 == W1) {                                // z^nsInv mod n through p and q
-        uint32_t* z1 = ctx->ws_t<uint32_t>((size_t)W1 * nbs);
-        reduce_mod(ctx, mn, z2, W2, z1, nbs);
-        qs = pow_n_crt(sk, z1, ns_inv, nbs);
-      } else {
-        qs = ctx->ws_t<uint32_t>((size_t)W1 * nbs);
-        shared_pow(ctx, mn, z2, W2, ns_inv, nbs, qs);                          // z^nsInv mod n
-      }
-    }
-    side.leave();
+    hipEvent_t inputs_ready = side.mark();
     // ---- sanity check (ddleq.go:62-69): ct1^(a^n mod n^2) * b^(n^2) mod n^3 == ct2, else the reference panics -- once per
     // statement.  Independent exponentiations of the same shape share a launch (the chip is filled better and, for the half-size
     // batches of the response, a latency-bound launch is saved outright): a^n (S numbers) | x^n (S secpar numbers), then the
@@ -4516,6 +4601,29 @@ static void ddleq_prove_impl(const pgpu_seckey* sk, size_t S, size_t secpar, con
       split_ab(ctx, axn, nbs, nb, 0, W2, an);
       split_ab(ctx, axn, nbs, nb, 1, W2, xn);
     }
+    // Beside the a^n | x^n launch only where that launch leaves the second wave slot of the SIMDs free (one wave per SIMD or
+    // less: 16 384 instances at secpar 1): a launch that fills both slots would lose one of them on half the chip to the side
+    // launch for its whole length (measured at 32 768 instances: 48 -> 76 ms for 8 ms hidden).  Then s follows on the main stream.
+    // (A side launch of a few dozen waves -- the statements of a secpar-40 call -- costs the big launch next to nothing.)
+    const size_t lt0 = ctx->lanes_wanted ? ctx->lanes_wanted : (size_t)1024 * 64;
+    const bool s_beside = (nbs + nb) * 2 <= lt0 || nbs * 2 * 8 <= lt0;
+    if (s_beside) side.enter(inputs_ready);
+    {
+      // s = ExtractRandonness(ct1) at level two (operations.go:75-91): z = G^(-v) ct1 mod n^3 with v = Decrypt(ct1)
+      // (operations.go:81-86) is only ever used modulo n (:88), and G^v = (1 + n)^v = 1 (mod n) whatever v is (the prover
+      // requires G = n + 1): z = ct1 (mod n).  No decryption, no G^v, no inversion modulo n^3 -- the same s.
+      uint32_t* z2 = ctx->ws_t<uint32_t>((size_t)W2 * nbs);
+      reduce_mod(ctx, mn2, c1s, W3, z2, nbs);
+      if (sk->has_crt && sk->mp.WT * 2 == W1) {                                // z^nsInv mod n through p and q
+        uint32_t* z1 = ctx->ws_t<uint32_t>((size_t)W1 * nbs);
+        reduce_mod(ctx, mn, z2, W2, z1, nbs);
+        qs = pow_n_crt(sk, z1, ns_inv, nbs);
+      } else {
+        qs = ctx->ws_t<uint32_t>((size_t)W1 * nbs);
+        shared_pow(ctx, mn, z2, W2, ns_inv, nbs, qs);                          // z^nsInv mod n
+      }
+    }
+    if (s_beside) side.leave();
     hipEvent_t an_ready = side.mark();
     uint32_t* bn2 = ctx->ws_t<uint32_t>((size_t)W3 * nbs);
     uint32_t* t3 = ctx->ws_t<uint32_t>((size_t)W3 * nb);
