@@ -198,7 +198,7 @@ def _ddleq_inputs(n_statements):
     return sk, st
 
 
-def _ddleq_worker(rank, world, port, n_statements, secpar, tamper, q):
+def _ddleq_worker(rank, world, port, n_statements, secpar, tamper, q, use_gpu=False):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
     dist.init_process_group("gloo", rank=rank, world_size=world)
     import random
@@ -207,6 +207,34 @@ def _ddleq_worker(rank, world, port, n_statements, secpar, tamper, q):
     sk, st = _ddleq_inputs(n_statements)
     L2 = po.ENC_LEVEL_TWO
     rng = random.Random(1000 + rank)
+    if use_gpu:   # the product path: pgpu_ddleq_prove_secpar / pgpu_ddleq_verify on this rank's slice (both ranks share GPU 0)
+        import paillier_amd as pa
+        from paillier_amd import protocols as pr
+        ctx = pa.Context(0)
+        gpk = pa.PublicKey(ctx, sk.N, sk.N + 1)
+        gsk = pa.SecretKey(ctx, gpk, sk.Lambda)
+
+        def prove_fn(b, e):
+            out = pr.prove_ddleq_batch(gsk, secpar, [t[0] for t in st[b:e]], [t[1] for t in st[b:e]], [t[2] for t in st[b:e]],
+                                       [t[3] for t in st[b:e]])
+            # every instance must also satisfy the ORACLE's verifier (ddleq.go:129-153 restated)
+            for (c1, c2, _, _), prf in zip(st[b:e], out):
+                for i in prf:
+                    assert po.verify_ddleq_proof_instance(sk, po.Ciphertext(c1, L2), po.Ciphertext(c2, L2),
+                                                          po.DDLEQProofInstance(i.X, i.Y, i.Alpha, i.E, i.F))
+            if tamper is not None and b <= tamper < e:
+                i = out[tamper - b][0]
+                out[tamper - b][0] = pr.DDLEQProofInstance(i.X, i.Y, i.Alpha, i.E, i.F ^ 1)
+            return out
+
+        def verify_fn(b, e, proofs):
+            return pr.verify_ddleq_proof_batch(gpk, [t[0] for t in st[b:e]], [t[1] for t in st[b:e]], proofs)
+
+        (b, e), proofs, verdicts, all_ok = pd.ddleq_prove_verify_sharded(n_statements, rank, world, prove_fn, verify_fn)
+        q.put((rank, b, e, len(proofs), verdicts, all_ok))
+        dist.barrier()
+        dist.destroy_process_group()
+        return
 
     def prove_fn(b, e):
         out = []
@@ -250,3 +278,27 @@ def test_ddleq_statements_shard_over_two_ranks_cpu(n_statements, secpar, tamper)
         for j, v in enumerate(verdicts):
             assert v == (tamper is None or b + j != tamper)
     assert covered == n_statements
+
+
+@pytest.mark.gpu
+def test_ddleq_statements_shard_over_two_ranks_gpu():
+    """The same flow with the HIP path proving (pgpu_ddleq_prove_secpar, library-drawn x, y) and verifying each rank's slice --
+    two gloo ranks sharing GPU 0; every instance is also checked by the oracle's verifier; a tampered F on the last statement
+    is seen by every rank."""
+    world, port = 2, _free_port()
+    ctxm = mp.get_context("spawn")
+    q = ctxm.Queue()
+    procs = [ctxm.Process(target=_ddleq_worker, args=(r, world, port, 5, 3, 4, q, True)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = sorted(q.get(timeout=600) for _ in range(world))
+    for p in procs:
+        p.join(timeout=120)
+        assert p.exitcode == 0
+    covered = 0
+    for rank, b, e, nproofs, verdicts, all_ok in res:
+        assert b == covered and nproofs == e - b == len(verdicts)
+        covered = e
+        assert all_ok is False
+        assert verdicts == [b + j != 4 for j in range(e - b)]
+    assert covered == 5

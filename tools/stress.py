@@ -50,3 +50,45 @@ cts = tk.EncryptBatch(ms)
 parts = [tk.PartialDecryptBatch(i, shares[i - 1], cts) for i in (2, 4, 5)]
 assert tk.CombinePartialDecryptionsBatch(parts) == ms, "threshold"
 print("threshold ok", flush=True)
+# round 3: small batches (the eight-lane pair kernel, vm_asm_19_96), a rank's unit range with and without the shared chain,
+# DDLEQ at secpar 8 with library-drawn randomness, all against size-independent properties
+import numpy as np
+from paillier_amd import protocols as pr
+from paillier_amd.api import be_to_ints, ints_to_be
+Bs = min(B, 6000)
+cts_s = cts[:Bs]
+for i in (1, 3):
+    one = tk.PartialDecryptBatch(i, shares[i - 1], cts_s)
+    ctx.set_flag("lanes8", 0)
+    other = tk.PartialDecryptBatch(i, shares[i - 1], cts_s)
+    ctx.set_flag("lanes8", 1)
+    assert one == other, "eight-lane pair kernel == four-lane"
+cb = tk.cipher_bytes()
+rows = ints_to_be(cts_s, cb)
+sh3 = [shares[1], shares[3], shares[4]]
+for ub, ue in ((0, 3 * Bs), (Bs // 2, 2 * Bs + 17), (Bs + 5, 3 * Bs - 9)):
+    out = np.zeros((ue - ub, cb), dtype=np.uint8)
+    tk.partial_decrypt_units_raw(sh3, Bs, rows, cb, ub, ue, out, cb)
+    got = be_to_ints(out)
+    ctx.set_flag("shared_chain", 0)
+    out2 = np.zeros((ue - ub, cb), dtype=np.uint8)
+    tk.partial_decrypt_units_raw(sh3, Bs, rows, cb, ub, ue, out2, cb)
+    ctx.set_flag("shared_chain", 1)
+    assert got == be_to_ints(out2), "unit range: shared chain == separate ladders"
+full = np.zeros((3 * Bs, cb), dtype=np.uint8)
+tk.partial_decrypt_units_raw(sh3, Bs, rows, cb, 0, 3 * Bs, full, cb)
+cols = [be_to_ints(full[s * Bs:(s + 1) * Bs]) for s in range(3)]
+assert tk.CombinePartialDecryptionsBatch([(2, cols[0]), (4, cols[1]), (5, cols[2])]) == ms[:Bs], "threshold through the unit range"
+print("units / eight lanes ok", flush=True)
+k = K["paillier"]["2048"]
+p, q = int(k["p"], 16), int(k["q"], 16)
+n = p * q
+pk = pa.PublicKey(ctx, n, n + 1); sk = pa.SecretKey(ctx, pk, (p - 1) * (q - 1))
+S = max(8, min(B // 40, 256))
+c1 = pk.NestedEncryptBatch([rng.randrange(n) for _ in range(S)])
+a_s, b_s = pk.random_units(S), pk.random_units(S)
+c2 = pr.nested_randomize_with_ab_batch(pk, c1, a_s, b_s)
+proofs = pr.prove_ddleq_batch(sk, 8, c1, c2, a_s, b_s)
+assert pr.verify_ddleq_proof_batch(pk, c1, c2, proofs) == [True] * S, "ProveDDLEQ(secpar 8) verifies"
+assert sk.NestedDecryptBatch(c2) == sk.NestedDecryptBatch(c1), "NestedRandomize keeps the plaintext"
+print(f"ddleq secpar 8 x {S} statements ok", flush=True)
