@@ -78,6 +78,8 @@ int pgpu_ctx_last_profile(pgpu_ctx* ctx, double* vm_ms, int* vm_launches, double
  * shared-exponent ladders (pgpu_partial_decrypt_indexed).  "lift" (default 1): level-two Encrypt computes r^(n^2) mod n^3
  * as (r^n mod n^2)^n mod n^3.  "side" (default 1): a call may issue work that depends on no ladder in flight to a second
  * stream of the context (the DDLEQ prover's per-statement chains run beside its big launches); 0 keeps one stream.
+ * "lanes8" (default 1): batches too small to fill the chip at four lanes per number run ladders modulo n^2 on the eight-lane pair
+ * kernel; "muls" (default 1): bucket products of a shared chain of squarings leave the current power in registers (VM_MULS).
  * All of these change the work done, never a result (the tests switch them off to compare).
  * "lanes_wanted" (default 0 = fill the chip): the lane count below which a batch is re-sliced over more lanes per
  * number; 1 keeps every modulus on its natural kernel shape whatever the batch size (tests).

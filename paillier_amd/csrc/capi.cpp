@@ -88,6 +88,7 @@ struct pgpu_ctx {
   size_t lanes_wanted = 0;   // 0: default occupancy target; tests set 1 to run every modulus at its natural shape
   // A second stream for work of a call that depends on no ladder in flight (SideStream below; the DDLEQ prover's
   // per-statement chains run beside its big launches).  pgpu_ctx_set_flag("side", 0): everything on the one stream.
+  bool use_muls = true;      // bucket products of the shared chain as VM_MULS where the kernel has it (pgpu_ctx_set_flag("muls", 0): LOAD / MUL / STORE)
   bool use_lanes8 = true;    // shards too small for four lanes per number take the eight-lane pair kernel (pgpu_ctx_set_flag("lanes8", 0): never)
   bool use_side = true;
   hipStream_t side = nullptr;
@@ -352,10 +353,12 @@ struct Prog {
   bool has_mulv = false;
   bool wide_gathers = false;  // table opcodes other than the 4-bit VM_MULV
   bool nm_tables = false;     // VM_MULV7 / VM_STORET: among the assembly kernels only the three-digit ones implement them
+  bool needs_muls = false;    // VM_MULS: the four- and eight-lane pair kernels only
   uint32_t gather_slots = 1;  // slots a per-number gather spans (table entries + 1): its offsets are 32-bit in the assembly kernels
   void op(uint32_t o, uint32_t arg = 0, uint32_t aux = 0) {
     if (o == VM_SETOFF) asm_ok = false;
     if (o == VM_MULV7 || o == VM_STORET) nm_tables = true;
+    if (o == VM_MULS) needs_muls = true;
     if (o == VM_MULCV || o == VM_MULV5 || o == VM_MULV7 || o == VM_STORET) wide_gathers = true;   // (kernels without these opcodes must not get the program)
     if (o == VM_MULV || o == VM_MULV5 || o == VM_MULV7) {
       has_mulv = true;
@@ -364,7 +367,7 @@ struct Prog {
     if (aux >> 22) api_throw(PGPU_ERR_INVALID, "internal: table slot does not fit the instruction word");
     w.push_back(o | (aux << 8));
     w.push_back(arg);
-    if (o == VM_SQR || o == VM_MUL || o == VM_MULC || o == VM_MULV || o == VM_MULCV || o == VM_MULV5 || o == VM_MULV7) montmuls += 1;
+    if (o == VM_SQR || o == VM_MUL || o == VM_MULC || o == VM_MULV || o == VM_MULCV || o == VM_MULV5 || o == VM_MULV7 || o == VM_MULS) montmuls += 1;
     if (o == VM_SQR) sqrs += 1;
   }
   // Bits 30..31 of an instruction word: the priority the wave takes when it gets there -- 3, 2, 1, 0 over four stretches of a
@@ -382,7 +385,7 @@ struct Prog {
       const double f = done / montmuls;
       const uint32_t quarter = f < 0.80 ? 0u : f < 0.96 ? 1u : f < 0.992 ? 2u : 3u;
       w[i] = (w[i] & 0x3FFFFFFFu) | ((3u - quarter) << 30);
-      if (o == VM_SQR || o == VM_MUL || o == VM_MULC || o == VM_MULV || o == VM_MULCV || o == VM_MULV5 || o == VM_MULV7) done += 1;
+      if (o == VM_SQR || o == VM_MUL || o == VM_MULC || o == VM_MULV || o == VM_MULCV || o == VM_MULV5 || o == VM_MULV7 || o == VM_MULS) done += 1;
     }
   }
 };
@@ -648,7 +651,9 @@ void emit_modexp_multi(Prog& p, const std::vector<PerNumberBase>& pn, int wb, co
 // The base is in slot `in` in the kernel's working form (pair digits); one_const = 1 in that form.  Slots: bp, run, acc
 // (scratch), out0 + s (results, lazy), bucket0 + s * 2^(w-1) + k.
 void emit_multi_exp_shared_base(Prog& p, const std::vector<BigU>& es, uint32_t in, uint32_t bp, uint32_t run, uint32_t acc,
-                                uint32_t out0, uint32_t bucket0, int w, uint32_t one_const) {
+                                uint32_t out0, uint32_t bucket0, int w, uint32_t one_const, bool muls = false) {
+  // muls: the kernel has VM_MULS (bucket <- bucket * x with x left in the registers): a bucket product is one load and one
+  // store of the bucket -- no parking of the current power in `bp`, no reloading it afterwards
   const uint32_t K = 1u << (w - 1);
   const size_t S = es.size();
   size_t nbits = 0;
@@ -675,6 +680,11 @@ void emit_multi_exp_shared_base(Prog& p, const std::vector<BigU>& es, uint32_t i
     bool stored = false, dirty = false;
     for (auto& sk : at[j]) {
       const uint32_t b = bucket(sk.first, sk.second);
+      if (muls) {
+        p.op(touched[sk.first * K + sk.second] ? VM_MULS : VM_STORE, b);
+        touched[sk.first * K + sk.second] = 1;
+        continue;
+      }
       if (!touched[sk.first * K + sk.second]) {
         if (dirty) { p.op(VM_LOAD, bp); dirty = false; }
         p.op(VM_STORE, b);
@@ -824,6 +834,9 @@ void run_vm(pgpu_ctx* ctx, size_t nb, const SegSpec& s0, const SegSpec* s1, bool
     HIPCHK(hipEventRecord(ev->a, ctx->stream));
   }
   if (pair && !use_asm) api_throw(PGPU_ERR_UNSUPPORTED, "the pair kernel exists in assembly only");
+  for (int i = 0; i < 3; ++i)
+    if (ss[i] && ss[i]->prog->needs_muls && !(pair && (s0.pair_lanes == 4 || s0.pair_lanes == 8)))
+      api_throw(PGPU_ERR_UNSUPPORTED, "internal: VM_MULS on a kernel that does not implement it");
   if (pair && s0.pair_lanes == 1 && s0.pair_h > 37)
     for (int i = 0; i < 3; ++i)
       if (ss[i] && ss[i]->prog->wide_gathers)   // (an opcode a kernel does not know ends its program: refuse, never compute garbage)
@@ -1130,6 +1143,7 @@ int pgpu_ctx_set_flag(pgpu_ctx* ctx, const char* name, int value) {
   if (strcmp(name, "lift") == 0) { ctx->use_lift = value != 0; return PGPU_OK; }
   if (strcmp(name, "side") == 0) { ctx->use_side = value != 0; return PGPU_OK; }
   if (strcmp(name, "lanes8") == 0) { ctx->use_lanes8 = value != 0; return PGPU_OK; }
+  if (strcmp(name, "muls") == 0) { ctx->use_muls = value != 0; return PGPU_OK; }
   if (strcmp(name, "fair") == 0) { g_wave_priorities.store(value != 0, std::memory_order_relaxed); return PGPU_OK; }   // process-wide (see above)
   if (strcmp(name, "lanes_wanted") == 0) { ctx->lanes_wanted = value > 0 ? (size_t)value : 0; return PGPU_OK; }
   if (strcmp(name, "cu_partition") == 0) {
@@ -3351,11 +3365,11 @@ int pgpu_partial_decrypt_multi(const pgpu_pubkey* pk, int total_servers, int n_s
         const uint32_t OUT0 = 6, B0 = 6 + (uint32_t)S;
         HIPCHK(hipMemcpyAsync(pm + 2 * SW, ent + 2 * SW, SW * 4, hipMemcpyDeviceToDevice, ctx->stream));
         Prog pr;
+        const int lanes = (nb * 2 >= lanes_target || !(H % 2 == 0 && vm_asm_available(H / 2, 64))) ? 2 : 4;
         emit_multi_exp_shared_base(pr, std::vector<BigU>(es.begin() + k0, es.begin() + k0 + S), 2, 3, 4, 5, OUT0, B0, w,
-                                   (uint32_t)pi.c_one_pair);
+                                   (uint32_t)pi.c_one_pair, lanes == 4 && ctx->use_muls);
         pr.end();
         SegSpec sg{&mc, &pr, pm, nullptr};
-        const int lanes = (nb * 2 >= lanes_target || !(H % 2 == 0 && vm_asm_available(H / 2, 64))) ? 2 : 4;
         sg.pair = pi.consts; sg.pair_n0inv = mn.n0inv; sg.pair_h = H; sg.pair_lanes = lanes;
         run_vm(ctx, nb, sg, nullptr, true);
         for (int j = 0; j < S; ++j) leave_pair_form(pm, OUT0 + (uint32_t)j, outs[k0 + j]);
@@ -3487,7 +3501,8 @@ int pgpu_partial_decrypt_units(const pgpu_pubkey* pk, int total_servers, int n_s
         std::vector<BigU> ev;
         WipeOnExit<std::vector<BigU>> wipe_ev(ev);
         for (int k : iv.servers) ev.push_back(es[(size_t)k]);
-        emit_multi_exp_shared_base(pr[t], ev, 2, 3, 4, 5, out0[t], B0, w, lanes == 8 ? 2u : (uint32_t)pi.c_one_pair);
+        emit_multi_exp_shared_base(pr[t], ev, 2, 3, 4, 5, out0[t], B0, w, lanes == 8 ? 2u : (uint32_t)pi.c_one_pair,
+                                   lanes >= 4 && ctx->use_muls);
       } else {
         out0[t] = 3;                                        // pair slots: 2 in, 3 out, 5.. table
         pm[t] = ctx->ws_t<uint32_t>(SWk * (size_t)(5 + 32));

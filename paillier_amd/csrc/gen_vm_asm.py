@@ -32,7 +32,7 @@ import sys
 LB = 28
 MASK = (1 << LB) - 1
 BLOCK = 256
-OPS = dict(END=0, LOAD=1, STORE=2, LOADC=3, SQR=4, MUL=5, MULC=6, MULV=7, ADD=8, SETOFF=9, MULCV=10, MULV5=11, MULV7=12, STORET=13)
+OPS = dict(END=0, LOAD=1, STORE=2, LOADC=3, SQR=4, MUL=5, MULC=6, MULV=7, ADD=8, SETOFF=9, MULCV=10, MULV5=11, MULV7=12, STORET=13, MULS=14)
 
 
 class Gen:
@@ -393,7 +393,8 @@ class Gen:
         e("s_and_b32 s18, s16, 0xff")
         # MULV7 / STORET (number-major tables) exist on the three-digit kernels only; the host emits them nowhere else
         nm_tables = ("MULV7", "STORET") if getattr(self, "number_major_tables", False) else ()
-        for nm in ("SQR", "MUL", "MULC", "MULV", "MULV5") + nm_tables + ("MULCV", "LOAD", "STORE", "LOADC", "ADD"):
+        muls = ("MULS",) if getattr(self, "has_muls", False) else ()
+        for nm in ("SQR", "MUL", "MULC", "MULV", "MULV5") + nm_tables + muls + ("MULCV", "LOAD", "STORE", "LOADC", "ADD"):
             e(f"s_cmp_eq_u32 s18, {OPS[nm]}")
             e(f"s_cbranch_scc1 L_{nm.lower()}")
         self.end_of_program()  # END (and anything unsupported: the host never sends those)
@@ -434,6 +435,15 @@ class Gen:
         self.load_slot_into(St)
         self.stage_to_lds(St)
         e("s_branch L_montmul")
+
+        if muls:
+            # mem[arg] <- x * mem[arg]: the product lands in the registers of the multiplicand copy and goes straight back to the
+            # slot (its base stays in s[sbase] through the rows); x is not touched
+            e("L_muls:")
+            self.slot_base()
+            self.load_slot_into(St)
+            self.stage_to_lds(St)
+            e("s_branch L_montmuls")
 
         for lbl, per_word, wbits in (("L_mulv", 7, 4), ("L_mulv5", 5, 5)):
             # per-number table index: window `arg` of this number's own exponent -- 4 bits, 7 per 28-bit limb (MULV), or 5
@@ -2478,6 +2488,7 @@ class GenQ4(Gen):
         self.dpp_next = "quad_perm:[1,1,3,3]"    # slice s <- slice s + 1 of the same digit
         self.dpp_prev = "quad_perm:[0,0,2,2]"    # slice s <- slice s - 1
         self.dpp_copy0 = "quad_perm:[0,1,0,1]"   # the lanes of digit one <- the same slices of digit zero
+        self.has_muls = True
         self.v_linkmask = self.v_l2mask          # -1 in the lane that takes the link
         self.v_d1mask = None                     # -1 in the lanes of digit one (GenQ4: l2mask | l3mask, formed where needed)
 
@@ -2723,21 +2734,35 @@ class GenQ4(Gen):
         self.normalize()
         e("s_branch L_next")
 
-    def montmul(self):
+    def montmul(self, to_slot=False):
         g, e = self, self.e
-        e("L_montmul:")
+        e("L_montmuls:" if to_slot else "L_montmul:")
         e("s_nop 1")
         for j in range(self.WL):                                 # digit one <- the slices of a0 (digit zero: whatever, times zero)
             e(f"v_mov_b32_dpp v{g.vR2 + j}, {self.X(j)} {self.dpp_copy0} row_mask:0xf bank_mask:0xf")
         # digit zero: t = a0 b0 R^-1 (second stream: zeros); digit one: c1 = (a1 b0 + a0 b1 + Cadj - m) R^-1
-        self.passes("m", True)
+        self.passes("ms" if to_slot else "m", True)
+        if not to_slot:
+            self.normalize()
+            e("s_branch L_next")
+            return
+        # VM_MULS: the limbs of the product go to the registers of the multiplicand copy (dead after the rows) and from there to
+        # the slot the operand came from; x stays as it is
+        self._xb = self.vR2
         self.normalize()
+        self._xb = self.vX
+        e(f"v_mov_b32 v{g.v_addr}, v{g.v_goff}")
+        for j in range(self.WL):
+            e(f"global_store_dword v{g.v_addr}, v{g.vR2 + j}, s[{g.s_sbase}:{g.s_sbase + 1}]")
+            if j != self.WL - 1:
+                e(f"v_add_u32 v{g.v_addr}, s3, v{g.v_addr}")
         e("s_branch L_next")
 
     def generate(self):
         self.prologue()
         self.dispatcher()
         self.montmul()
+        self.montmul(to_slot=True)
         self.montsq()
         self.epilogue()
         return "\n".join(self.lines) + "\n"
@@ -2783,6 +2808,7 @@ class GenQ8(GenQ4):
         self.lds_z = self.lds_c + WL * 64
         self.lds_bytes = self.lds_z + 1024
         assert self.lds_bytes < 65536
+        self.has_muls = True
         self.dpp_link = "row_shr:4"
         self.dpp_bcast = "quad_perm:[0,0,0,0]"
         self.dpp_next = "quad_perm:[1,2,3,3]"

@@ -21,6 +21,8 @@ enum VmOp : uint32_t {
   VM_MULV5 = 11,  // MULV with 5-bit windows: `digits` holds the exponents repacked as 25-bit words (5 windows each), 32-entry table
   VM_MULV7 = 12,  // MULV with 7-bit windows: 4 per 28-bit exponent limb (no repacking), 128-entry table of NUMBER-major slots
   VM_STORET = 13, // mem[arg] <- x, number-major inside the slot ([number][WT limbs]): the layout VM_MULV7 gathers from
+  VM_MULS = 14,   // mem[arg] <- x*mem[arg]*R^-1, x unchanged (a bucket of the shared chain of squarings takes the current power
+                  // without the power leaving the registers; the four- and eight-lane pair kernels only)
 };
 
 struct VmSeg {

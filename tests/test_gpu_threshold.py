@@ -253,9 +253,11 @@ def test_partial_decrypt_units_of_a_rank(ctx, B, ub, ue, lanes_wanted):
         ctx.set_flag("lanes_wanted", lanes_wanted)
         # (shared_chain, lanes8): a shard this small takes the eight-lane pair kernel (vm_asm_19_96: 76-limb digits, the radix
         # changed on the way in and out) unless lanes8 is switched off -- then the four-lane one
-        for flag in ((1, 1), (1, 0), (0, 1)):
+        # (the third flag: bucket products as VM_MULS -- the current power never leaves the registers -- or as LOAD / MUL / STORE)
+        for flag in ((1, 1, 1), (1, 0, 1), (0, 1, 1), (1, 1, 0), (1, 0, 0)):
             ctx.set_flag("shared_chain", flag[0])
             ctx.set_flag("lanes8", flag[1])
+            ctx.set_flag("muls", flag[2])
             out = np.zeros((ue - ub, cb), dtype=np.uint8)
             tk.partial_decrypt_units_raw(sh, B, rows, cb, ub, ue, out, cb)
             got[flag] = be_to_ints(out)
@@ -265,11 +267,12 @@ def test_partial_decrypt_units_of_a_rank(ctx, B, ub, ue, lanes_wanted):
     finally:
         ctx.set_flag("shared_chain", 1)
         ctx.set_flag("lanes8", 1)
+        ctx.set_flag("muls", 1)
         ctx.set_flag("lanes_wanted", 0)
-    assert got[(1, 1)] == got[(1, 0)] == got[(0, 1)]
+    assert got[(1, 1, 1)] == got[(1, 0, 1)] == got[(0, 1, 1)] == got[(1, 1, 0)] == got[(1, 0, 0)]
     if lanes_wanted == 0:
-        assert kernels[(1, 1)] == "vm_asm_19_96" and kernels[(1, 0)] == "vm_asm_37_64", kernels
-    got = {1: got[(1, 1)]}
+        assert kernels[(1, 1, 1)] == "vm_asm_19_96" and kernels[(1, 0, 1)] == "vm_asm_37_64", kernels
+    got = {1: got[(1, 1, 1)]}
     # against the one-server entry point on the same units, and against pow on a sample
     u = ub
     while u < ue:
