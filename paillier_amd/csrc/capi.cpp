@@ -255,6 +255,8 @@ struct TripleInfo {
   const uint32_t* dinv2 = nullptr;    // n^-1 mod 2^(28 WT(n^2))
   const uint32_t* n_limbs = nullptr;  // n   as WT(n) limbs
   const uint32_t* n2_limbs = nullptr; // n^2 as WT(n^2) limbs
+  bool lanes6_only = false;           // the digit does not fit one lane (H > 74): only the two-lanes-per-digit kernel (GenQ6) serves it,
+                                      // and that one runs shared-exponent and limb-major per-number programs only
 };
 
 struct ModCtx {
@@ -781,8 +783,8 @@ void run_vm(pgpu_ctx* ctx, size_t nb, const SegSpec& s0, const SegSpec* s1, bool
   if (s1 && pair != (s1->pair != nullptr)) api_throw(PGPU_ERR_INVALID, "segment kind mismatch");
   if (s2 && pair != (s2->pair != nullptr)) api_throw(PGPU_ERR_INVALID, "segment kind mismatch");
   if (pair) {
-    WL = s0.pair_lanes == 8 ? s0.pair_h / 4 : s0.pair_lanes == 4 ? s0.pair_h / 2 : s0.pair_h;
-    K = s0.pair_lanes == 8 ? 96 : s0.pair_lanes == 4 ? 64 : s0.pair_lanes == 3 ? 48 : s0.pair_lanes == 2 ? 32 : 16;   // tags of the pair kernels, not lane counts
+    WL = s0.pair_lanes == 8 ? s0.pair_h / 4 : (s0.pair_lanes == 4 || s0.pair_lanes == 6) ? s0.pair_h / 2 : s0.pair_h;
+    K = s0.pair_lanes == 8 ? 96 : s0.pair_lanes == 6 ? 112 : s0.pair_lanes == 4 ? 64 : s0.pair_lanes == 3 ? 48 : s0.pair_lanes == 2 ? 32 : 16;   // tags of the pair kernels, not lane counts
   } else {
     static const size_t lanes_env = [] { const char* e = getenv("PGPU_LANES_WANTED"); return e ? (size_t)atoll(e) : (size_t)0; }();
     const size_t lanes_wanted = ctx->lanes_wanted ? ctx->lanes_wanted : lanes_env ? lanes_env : (size_t)1024 * 64;
@@ -792,14 +794,14 @@ void run_vm(pgpu_ctx* ctx, size_t nb, const SegSpec& s0, const SegSpec* s1, bool
     static const bool w74 = [] { const char* e = getenv("PGPU_W74"); return e ? atoi(e) != 0 : true; }();
     if (WL == 74 && K == 2 && !(w74 && ctx->use_asm)) { WL = 37; K = 4; }
   }
-  const uint32_t blocks_per_seg = (uint32_t)(launch_nb * (pair ? (s0.pair_lanes == 3 ? 4 : s0.pair_lanes) : K) / VM_BLOCK);
+  const uint32_t blocks_per_seg = (uint32_t)(launch_nb * (pair ? (s0.pair_lanes == 3 ? 4 : s0.pair_lanes == 6 ? 8 : s0.pair_lanes) : K) / VM_BLOCK);
   a.seg0_blocks = blocks_per_seg;
   a.seg1_blocks = blocks_per_seg;
   const uint32_t blocks = blocks_per_seg * (s2 ? 3 : s1 ? 2 : 1);
   const bool nm_tables = s0.prog->nm_tables || (s1 && s1->prog->nm_tables) || (s2 && s2->prog->nm_tables);
   const bool use_asm = ctx->use_asm && vm_asm_available(WL, K) && s0.prog->asm_ok && (!s1 || s1->prog->asm_ok) &&
                        (!s2 || s2->prog->asm_ok) && (!nm_tables || (pair && s0.pair_lanes == 3)) &&
-                       (uint64_t)nb * (s0.pair_lanes == 3 ? 3 * s0.pair_h : mc->WT) * 4 *
+                       (uint64_t)nb * ((s0.pair_lanes == 3 || s0.pair_lanes == 6) ? 3 * s0.pair_h : mc->WT) * 4 *
                                std::max(s0.prog->gather_slots, std::max(s1 ? s1->prog->gather_slots : 1u, s2 ? s2->prog->gather_slots : 1u)) < (1ull << 32);
   pgpu_ctx::Ev* ev = nullptr;
   if (profile) {
@@ -810,7 +812,7 @@ void run_vm(pgpu_ctx* ctx, size_t nb, const SegSpec& s0, const SegSpec* s1, bool
     // squaring rows: K == 1 triangular (WT^2 + WT(WT-1)/2 + WT); K == 2 slice-level symmetry (product part 1.5 WL^2 per lane)
     double sq = full;
     double mulp = full;
-    if (pair && s0.pair_lanes == 3) {   // GenQ3: a squaring is one pass in four lanes, a product 6 blocks (its second pass runs two lanes)
+    if (pair && (s0.pair_lanes == 3 || s0.pair_lanes == 6)) {   // GenQ3 / GenQ6: a squaring is one pass, a product 6 blocks (its second pass runs half the lanes)
       const double H = s0.pair_h;
       mulp = 12.0 * H * H;
       sq = 8.0 * H * H;
@@ -1337,9 +1339,9 @@ const uint32_t* triple_windows(pgpu_ctx* ctx, const uint32_t* exps, int we, size
   return wb == 5 ? windows5_of(ctx, exps, we, nb) : exps;
 }
 
-bool triple_usable(pgpu_ctx* ctx, const ModCtx& mc) {
+bool triple_usable(pgpu_ctx* ctx, const ModCtx& mc, bool allow6 = false) {
   static const bool env_on = [] { const char* e = getenv("PGPU_TRIPLE"); return e ? atoi(e) != 0 : true; }();
-  return env_on && mc.triple.root && ctx->use_asm && ctx->use_pair && ctx->use_triple;
+  return env_on && mc.triple.root && ctx->use_asm && ctx->use_pair && ctx->use_triple && (allow6 || !mc.triple.lanes6_only);
 }
 
 TriplePlan triple_alloc(pgpu_ctx* ctx, const ModCtx& mc, size_t nb, int slots) {
@@ -1405,7 +1407,11 @@ void triple_exit(pgpu_ctx* ctx, const ModCtx& mc, const TriplePlan& tp, uint32_t
 void triple_run(pgpu_ctx* ctx, const ModCtx& mc, const TriplePlan& tp, const Prog& p, const uint32_t* exps) {
   const TripleInfo& ti = mc.triple;
   SegSpec sp{&mc, &p, tp.mem, exps};
-  sp.pair = ti.kconsts; sp.pair_n0inv = ti.root->n0inv; sp.pair_h = tp.H; sp.pair_lanes = 3; sp.tconsts = ti.tconsts;
+  // two lanes per digit (GenQ6) where the digit does not fit a lane, or where the batch is so small that eight lanes per number
+  // still leave every wave a SIMD of its own (one ladder's latency is the run time); not for number-major tables
+  const size_t lt = ctx->lanes_wanted ? ctx->lanes_wanted : (size_t)1024 * 64;
+  const bool six = ti.lanes6_only || (ctx->use_lanes8 && !p.nm_tables && tp.H % 2 == 0 && vm_asm_available(tp.H / 2, 112) && tp.nb * 8 <= lt);
+  sp.pair = ti.kconsts; sp.pair_n0inv = ti.root->n0inv; sp.pair_h = tp.H; sp.pair_lanes = six ? 6 : 3; sp.tconsts = ti.tconsts;
   run_vm(ctx, tp.nb, sp, nullptr, true);
 }
 
@@ -1414,7 +1420,7 @@ void modexp_triple(pgpu_ctx* ctx, const ModCtx& mc, const ModexpPlan& pl, const 
                    bool use_post) {
   // digit slots: 0 in, 1 (unused), 2 tmp, 3 out, 5.. table (32 entries: sliding windows of a shared exponent, or the 5-bit
   // windows of per-number exponents -- a product costs two squarings here, so the wider window pays)
-  const int wb = exps ? triple_window_bits(pl.nb, mc.triple.root->WT) : 5;
+  const int wb = (exps && !mc.triple.lanes6_only) ? triple_window_bits(pl.nb, mc.triple.root->WT) : 5;   // (GenQ6: limb-major tables)
   TriplePlan tp = triple_alloc(ctx, mc, pl.nb, 5 + perlane_table_slots(wb));
   triple_enter(ctx, mc, pl.in(), tp, 0);
   Prog p;
@@ -1433,7 +1439,7 @@ void modexp_shared_run(pgpu_ctx* ctx, const ModCtx& mc, const ModexpPlan& pl, co
                        bool skip_zero) {
   // two lanes per number from one wave per SIMD upwards; below that four (each digit over two lanes: a squaring is half as
   // long as on the 4-lane 2H-limb kernel, which is what counts when the ladder's latency is the run time)
-  if (triple_usable(ctx, mc) && !wide && skip_zero && e.bit_length() >= 256) {
+  if (triple_usable(ctx, mc, true) && !wide && skip_zero && e.bit_length() >= 256) {
     modexp_triple(ctx, mc, pl, &e, nullptr, 0, use_post);
     return;
   }
@@ -1457,7 +1463,7 @@ void modexp_shared_run(pgpu_ctx* ctx, const ModCtx& mc, const ModexpPlan& pl, co
 
 void modexp_perlane_run(pgpu_ctx* ctx, const ModCtx& mc, const ModexpPlan& pl, const uint32_t* exps, int we, bool wide,
                         bool use_post) {
-  if (triple_usable(ctx, mc) && !wide && we >= 10 && (uint64_t)pl.nb * (mc.WT + 4) * 4 * 33 < (1ull << 32)) {
+  if (triple_usable(ctx, mc, true) && !wide && we >= 10 && (uint64_t)pl.nb * (mc.WT + 4) * 4 * 33 < (1ull << 32)) {
     modexp_triple(ctx, mc, pl, nullptr, exps, we, use_post);
     return;
   }
@@ -1767,10 +1773,11 @@ int pgpu_pair_debug_run(pgpu_ctx* ctx, const uint8_t* p_be, size_t p_len, int la
     ModCtx mp, mp2;
     mp.init(ctx, pr);
     mp2.init(ctx, pr * pr);
-    if (lanes == 3) {
+    if (lanes == 3 || lanes == 6) {
       // three-digit kernel: slots are [3H][nb] (a0 | a1 | a2), the root is `p_be`; constants: one entry, the zero-extended
-      // digits given in consts_out on entry are NOT used -- the test passes constants as slots
-      if (mp.K != 1 || !vm_asm_available(mp.WT, 48)) api_throw(PGPU_ERR_UNSUPPORTED, "no three-digit kernel for this width");
+      // digits given in consts_out on entry are NOT used -- the test passes constants as slots.  lanes = 6: two lanes per digit
+      if (lanes == 3 ? (mp.K != 1 || !vm_asm_available(mp.WT, 48)) : (mp.WT % 2 != 0 || !vm_asm_available(mp.WT / 2, 112)))
+        api_throw(PGPU_ERR_UNSUPPORTED, "no three-digit kernel for this width");
       const int H = mp.WT;
       if (h_out) *h_out = H;
       ModCtx mp3;
@@ -1786,7 +1793,7 @@ int pgpu_pair_debug_run(pgpu_ctx* ctx, const uint8_t* p_be, size_t p_len, int la
       p.w.assign(prog, prog + prog_words);
       p.asm_ok = true;
       SegSpec s{&mp3, &p, d, nullptr};
-      s.pair = d_kc; s.pair_n0inv = mp.n0inv; s.pair_h = H; s.pair_lanes = 3; s.tconsts = d;   // constant c = slot c
+      s.pair = d_kc; s.pair_n0inv = mp.n0inv; s.pair_h = H; s.pair_lanes = lanes; s.tconsts = d;   // constant c = slot c
       bool saved = ctx->use_asm;
       ctx->use_asm = true;
       try { run_vm(ctx, nb, s, nullptr, false); } catch (...) { ctx->use_asm = saved; throw; }
@@ -1795,7 +1802,7 @@ int pgpu_pair_debug_run(pgpu_ctx* ctx, const uint8_t* p_be, size_t p_len, int la
       HIPCHK(hipStreamSynchronize(ctx->stream));
       return;
     }
-    if (lanes != 1 && lanes != 2 && lanes != 4) api_throw(PGPU_ERR_INVALID, "lanes must be 1, 2, 3 or 4");
+    if (lanes != 1 && lanes != 2 && lanes != 4) api_throw(PGPU_ERR_INVALID, "lanes must be 1, 2, 3, 4 or 6");
     if (mp.K != 1 || mp2.WT != 2 * mp.WT ||
         !(lanes == 4 ? (mp.WT % 2 == 0 && vm_asm_available(mp.WT / 2, 64)) : vm_asm_available(mp.WT, lanes == 2 ? 32 : 16)))
       api_throw(PGPU_ERR_UNSUPPORTED, "no pair kernel for this width");
@@ -1964,9 +1971,12 @@ int pgpu_pubkey_create(pgpu_ctx* ctx, const uint8_t* n_be, size_t n_len, const u
         }
       }
     }
-    if (pk->mn3 && pk->mn.K == 1 && vm_asm_available(pk->mn.WT, 48) && (size_t)LB * pk->mn3->WT >= n3.bit_length() + 3) {
+    const bool one_lane_digit = pk->mn.K == 1 && vm_asm_available(pk->mn.WT, 48);
+    const bool two_lane_digit = pk->mn.WT % 2 == 0 && vm_asm_available(pk->mn.WT / 2, 112);     // 3072-bit keys: digits of 110 limbs
+    if (pk->mn3 && (one_lane_digit || two_lane_digit) && (size_t)LB * pk->mn3->WT >= n3.bit_length() + 3) {
       setup_triple(*pk->mn3, pk->mn, pk->mn2, pk->triple_kconsts, pk->triple_tconsts, pk->ninv2k.d, pk->ninv2k_2.d, pk->n_limbs.d,
                    pk->n2_limbs.d);
+      pk->mn3->triple.lanes6_only = !one_lane_digit;
     }
     pk->mn.upload();
     pk->mn2.upload();

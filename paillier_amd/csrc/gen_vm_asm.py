@@ -2687,8 +2687,8 @@ class GenQ4(Gen):
         e(f"s_cbranch_scc1 L_q{tag}")
         e("s_waitcnt lgkmcnt(0)")
 
-    def normalize(self):
-        """accumulators -> limbs of the new x.  Two lanes per digit: both run the plain sequential carry of a one-lane number
+    def normalize(self, dst=None):
+        """accumulators -> limbs of the new x (dst(j): where limb j goes; default the multiplicand registers).  Two lanes per digit: both run the plain sequential carry of a one-lane number
         over their own 37 columns (3 instructions a limb: every lane owns whole columns), then the lower slice's carry out of its
         top column -- up to 2^36 -- enters the upper slice's two lowest limbs (limb 1 stays lazy by < 2^9: multiplicands and
         multipliers have that headroom).  125 instructions where the carry-save form of the generic multi-lane shapes takes
@@ -2700,15 +2700,17 @@ class GenQ4(Gen):
         e(f"v_not_b32 v{g.v_t2}, v{g.v_notlast}")                       # -1 in the top slice of a digit
         e(f"v_or_b32 v{g.v_t2}, {M}, v{g.v_t2}")                         # top-limb mask: 28 bits below the top slice, everything in it
         e(f"v_not_b32 v{g.v_t1}, v{g.v_isfirst}")                       # -1 in every slice that has one below it
-        e(f"v_and_b32 {self.X(0)}, {M}, {self.Tlo(0)}")
+        dst = dst or self.X
+        # (shift before mask: dst(j) may be the low half of T(j) itself)
         e(f"v_lshrrev_b64 {c}, {LB}, {self.T(0)}")
+        e(f"v_and_b32 {dst(0)}, {M}, {self.Tlo(0)}")
         for j in range(1, WL):
             e(f"v_lshl_add_u64 {self.T(j)}, {self.T(j)}, 0, {c}")
-            if j < WL - 1:
-                e(f"v_and_b32 {self.X(j)}, {M}, {self.Tlo(j)}")
-            else:
-                e(f"v_and_b32 {self.X(j)}, {self.Tlo(j)}, v{g.v_t2}")
             e(f"v_lshrrev_b64 {c}, {LB}, {self.T(j)}")
+            if j < WL - 1:
+                e(f"v_and_b32 {dst(j)}, {M}, {self.Tlo(j)}")
+            else:
+                e(f"v_and_b32 {dst(j)}, {self.Tlo(j)}, v{g.v_t2}")
         # carry out of a slice -> the next slice of the same digit (it lands in that slice's two lowest limbs and goes no
         # further: the slices' own carries out were taken before it came in)
         e("s_nop 1")
@@ -2716,12 +2718,12 @@ class GenQ4(Gen):
         e(f"v_mov_b32_dpp v{g.v_p0 + 1}, v{g.v_c + 1} {self.dpp_prev} row_mask:0xf bank_mask:0xf")
         e(f"v_and_b32 v{g.v_p0}, v{g.v_p0}, v{g.v_t1}")
         e(f"v_and_b32 v{g.v_p0 + 1}, v{g.v_p0 + 1}, v{g.v_t1}")
-        e(f"v_mov_b32 v{g.v_c}, {self.X(0)}")
+        e(f"v_mov_b32 v{g.v_c}, {dst(0)}")
         e(f"v_mov_b32 v{g.v_c + 1}, 0")
         e(f"v_lshl_add_u64 {c}, {c}, 0, {self.P(g.v_p0)}")               # limb 0 + carry in (zero in the lower slice)
-        e(f"v_and_b32 {self.X(0)}, {M}, v{g.v_c}")
+        e(f"v_and_b32 {dst(0)}, {M}, v{g.v_c}")
         e(f"v_lshrrev_b64 {c}, {LB}, {c}")
-        e(f"v_add_u32 {self.X(1)}, {self.X(1)}, v{g.v_c}")
+        e(f"v_add_u32 {dst(1)}, {dst(1)}, v{g.v_c}")
 
     def montsq(self):
         g, e = self, self.e
@@ -2890,6 +2892,318 @@ class GenQ8(GenQ4):
         e("s_waitcnt lgkmcnt(0)")
         for j in range(WL):
             e(f"v_mov_b32 {self.X(j)}, 0")
+
+
+class GenQ6(GenQ4):
+    """The three-digit kernel with every digit sliced over TWO lanes: 8 lanes per number for moduli N = n^3 whose digit does not fit
+    one lane (H = 110: 3072-bit keys) or whose batch is bound by one ladder's latency (H = 74).  Lane k8 of a number:
+        0, 1 = the slices of a0 | 2, 3 = those of a2 | 4, 5 = those of a1 | 6, 7 = the helper digit
+    (a1 next to the helper: the helper takes its copy of a1 by a quad_perm confined to that quad with bank_mask; the quotient links
+    a0 -> a1 -> a2 cross the quads by row_shr:4 and row_shl:2).  Rows are GenQ4's (modulus slice in VGPRs, quotient digit
+    broadcast and boundary column inside the lane pair of a digit) with GenQ3's two hops in the chain; squaring one pass, product
+    two passes as GenQ3 at H = 74; carries inside a digit as GenQ4.normalize.  Shared-exponent programs only (no number-major
+    tables)."""
+
+    def __init__(self, WL):
+        Gen.__init__(self, WL, 2)
+        assert self.n_vreg and not self.flush
+        self.H = 2 * WL
+        self.WTslot = 6 * WL
+        self.WT = self.WTslot
+        self.NPB = BLOCK // 8
+        self.name = f"vm_asm_{WL}_112"
+        self.sq_rows = True
+        self.sq_rows_k = False
+        self.has_muls = False
+        self.lanes_per_number = 8
+        self.lds_a = (2 * self.WLp * 4 + 15) // 16 * 16
+        e = self.n_vgpr
+        for nm in ["sh", "l1mask", "l2mask", "hmask", "t5", "caddr"]:
+            setattr(self, "v_" + nm, e)
+            e += 1
+        e = (e + 1) // 2 * 2
+        self.v_d = e
+        e += 2
+        self.v_nbase = self.v_d         # (the modulus slice's LDS address is needed in the prologue only, v_d in the rows only)
+        self._xb = self.vX
+        self.n_vgpr = e
+        assert e <= 256, e
+        self.lds_c = self.lds_a + (self.WTslot + 1) * self.NPB * 4
+        self.lds_bytes = self.lds_c + WL * 64
+        assert self.lds_bytes < 65536
+        self.dpp_bcast = "quad_perm:[0,0,2,2]"
+        self.dpp_next = "quad_perm:[1,1,3,3]"
+        self.dpp_prev = "quad_perm:[0,0,2,2]"
+        self.npad = (self.H + 1) // 2 * 2
+
+    def set_exec8(self, mask8):
+        w = sum(mask8 << (8 * i) for i in range(4))
+        self.e(f"s_mov_b32 exec_lo, {hex(w)}")
+        self.e(f"s_mov_b32 exec_hi, {hex(w)}")
+
+    def mask_digit_lanes(self, on):
+        if on:
+            self.set_exec8(0x3f)
+        else:
+            self.e("s_mov_b64 exec, -1")
+
+    def prologue(self):
+        g, e = self, self.e
+        WL, NPB, H = self.WL, self.NPB, self.H
+        e(f'.amdgcn_target "amdgcn-amd-amdhsa--gfx950"')
+        e(".text")
+        e(f".globl {self.name}")
+        e(".p2align 8")
+        e(f".type {self.name},@function")
+        e(f"{self.name}:")
+        self.select_segment()
+        e("s_load_dwordx8 s[4:11], s[0:1], 0x0")
+        e("s_load_dwordx4 s[12:15], s[0:1], 0x20")
+        e("s_waitcnt lgkmcnt(0)")
+        e("s_lshl_b32 s3, s15, 2")
+        e(f"v_and_b32 v{g.v_t1}, 7, v0")                  # k8
+        e(f"v_lshlrev_b32 v{g.v_caddr}, 3, v{g.v_t1}")    # this lane's column of the constants table
+        e(f"v_lshrrev_b32 v{g.v_t2}, 3, v0")              # gl
+        e(f"s_mul_i32 s{g.s_t0}, s2, {NPB}")
+        e(f"v_add_u32 v{g.v_t3}, s{g.s_t0}, v{g.v_t2}")   # g
+        # slot position of the lane: digit dd = (0, 2, 1, 2)[k8 >> 1] (the helper aliases digit two; its stores are masked), slice s
+        e(f"v_lshrrev_b32 v{g.v_t4}, 1, v{g.v_t1}")       # q = k8 >> 1
+        e(f"v_and_b32 v{g.v_t5}, 1, v{g.v_t4}")           # t = q & 1
+        e(f"v_xor_b32 v{g.v_p0}, 1, v{g.v_t5}")           # t ^ 1
+        e(f"v_lshrrev_b32 v{g.v_p0 + 1}, 1, v{g.v_t4}")   # q >> 1
+        e(f"v_and_b32 v{g.v_p0}, v{g.v_p0}, v{g.v_p0 + 1}")
+        e(f"v_lshl_or_b32 v{g.v_t4}, v{g.v_t5}, 1, v{g.v_p0}")   # dd
+        e(f"v_and_b32 v{g.v_t5}, 1, v{g.v_t1}")           # s
+        e(f"v_lshl_or_b32 v{g.v_t4}, v{g.v_t4}, 1, v{g.v_t5}")   # kk = 2 dd + s
+        e(f"s_mul_i32 s{g.s_t1}, s15, {WL}")
+        e(f"v_mul_lo_u32 v{g.v_p0}, v{g.v_t4}, s{g.s_t1}")
+        e(f"v_add_lshl_u32 v{g.v_goff}, v{g.v_p0}, v{g.v_t3}, 2")
+        e(f"v_lshlrev_b32 v{g.v_aread}, 2, v{g.v_t2}")
+        e(f"v_add_u32 v{g.v_aread}, {self.lds_a}, v{g.v_aread}")
+        e(f"v_mul_u32_u24 v{g.v_p0}, {WL * NPB * 4}, v{g.v_t4}")
+        e(f"v_add_u32 v{g.v_awrite}, v{g.v_p0}, v{g.v_aread}")
+        e(f"v_mul_u32_u24 v{g.v_koff}, {WL * 4}, v{g.v_t4}")
+        e(f"v_mul_u32_u24 v{g.v_nbase}, {self.WLp * 4}, v{g.v_t5}")
+        e(f"v_cmp_eq_u32 vcc, 0, v{g.v_t5}")
+        e("s_nop 1")
+        e(f"v_cndmask_b32 v{g.v_isfirst}, 0, -1, vcc")
+        e(f"v_mov_b32 v{g.v_notlast}, v{g.v_isfirst}")
+        for val, reg in ((4, g.v_l1mask), (2, g.v_l2mask)):
+            e(f"v_cmp_eq_u32 vcc, {val}, v{g.v_t1}")
+            e("s_nop 1")
+            e(f"v_cndmask_b32 v{reg}, 0, -1, vcc")
+        e(f"v_cmp_le_u32 vcc, 6, v{g.v_t1}")
+        e("s_nop 1")
+        e(f"v_cndmask_b32 v{g.v_hmask}, 0, -1, vcc")
+        e(f"v_add_u32 v{g.v_sh}, 2, v{g.v_t1}")
+        e(f"v_bfe_u32 v{g.v_sh}, v{g.v_sh}, 2, 1")         # 1 in the lanes of a1 and a2 (k8 = 2 .. 5): they double their multiplicand
+        # modulus n (2 slices) -> LDS -> this lane's slice in VGPRs
+        e(f"v_lshlrev_b32 v{g.v_t3}, 2, v0")
+        e(f"v_cmp_gt_u32 vcc, {WL}, v0")
+        e("s_nop 1")
+        e("s_and_saveexec_b64 s[96:97], vcc")
+        for sgi in range(2):
+            e(f"global_load_dword v{g.v_p1}, v{g.v_t3}, s[6:7] offset:{sgi * WL * 4}")
+            e("s_waitcnt vmcnt(0)")
+            e(f"ds_write_b32 v{g.v_t3}, v{g.v_p1} offset:{sgi * self.WLp * 4}")
+        # constants table: thread t < WL writes row t = (0 0 | C2_t C2_(WL+t) | C1_t C1_(WL+t) | 0 0), zero-extended
+        e(f"v_lshlrev_b32 v{g.v_t4}, 4, v{g.v_t3}")        # t * 64
+        e(f"v_lshlrev_b32 v{g.v_t5}, 1, v{g.v_t3}")        # t * 8: the pair (C1_t, C2_t)
+        e(f"v_mov_b32 v{g.v_y0}, 0")
+        e(f"v_mov_b32 v{g.v_y0 + 1}, 0")
+        for k in (0, 1, 6, 7):
+            e(f"ds_write_b64 v{g.v_t4}, {self.P(g.v_y0)} offset:{self.lds_c + 8 * k}")
+        for sgi in range(2):
+            e(f"global_load_dwordx2 {self.P(g.v_p0)}, v{g.v_t5}, s[6:7] offset:{4 * self.npad + 8 * WL * sgi}")
+            e("s_waitcnt vmcnt(0)")
+            e(f"v_mov_b32 v{g.v_y0}, v{g.v_p0 + 1}")       # (C2, 0)
+            e(f"v_mov_b32 v{g.v_p0 + 1}, 0")               # (C1, 0)
+            e(f"ds_write_b64 v{g.v_t4}, {self.P(g.v_p0)} offset:{self.lds_c + 8 * (4 + sgi)}")
+            e(f"ds_write_b64 v{g.v_t4}, {self.P(g.v_y0)} offset:{self.lds_c + 8 * (2 + sgi)}")
+        e("s_waitcnt lgkmcnt(0)")
+        e("s_mov_b64 exec, s[96:97]")
+        e("s_barrier")
+        for j in range(WL):
+            e(f"ds_read_b32 v{g.v_N + j}, v{g.v_nbase} offset:{4 * j}")
+        e("s_waitcnt lgkmcnt(0)")
+        for j in range(WL):
+            e(f"v_mov_b32 {self.X(j)}, 0")
+
+    def row(self, cur, nxt, aoff, link2, bump):
+        """one Montgomery row modulo n in the eight lanes of a number.  Link one: slice 0 of a1 takes -m of a0; link two (link2):
+        slice 0 of a2 takes -m of a1; every quotient digit is then broadcast to the digit's upper slice."""
+        g, e = self, self.e
+        WL = self.WL
+        N = lambda j: f"v{g.v_N + j}"
+        m = f"v{g.v_m}"
+        e("s_waitcnt lgkmcnt(0)")
+        e(f"ds_read_b32 v{nxt}, v{g.v_arow} offset:{aoff}")
+        if bump:
+            e(f"v_add_u32 v{g.v_arow}, {bump}, v{g.v_arow}")
+        a = f"v{cur}"
+        chain = [f"v_mul_lo_u32 {m}, {self.Tlo(0)}, s14", f"v_and_b32 {m}, {hex(MASK)}, {m}"]
+        hops = [("row_shr:4", g.v_l1mask)] + ([("row_shl:2", g.v_l2mask)] if link2 else [])
+        for ctrl, mask in hops:
+            chain += [f"v_mov_b32_dpp v{g.v_d}, {m} {ctrl} row_mask:0xf bank_mask:0xf",
+                      f"v_mad_i64_i32 {self.T(0)}, vcc, v{g.v_d}, v{mask}, {self.T(0)}",
+                      f"v_mul_lo_u32 {m}, {self.Tlo(0)}, s14",
+                      f"v_and_b32 {m}, {hex(MASK)}, {m}"]
+        chain.append(f"v_mov_b32_dpp {m}, {m} {self.dpp_bcast} row_mask:0xf bank_mask:0xf")
+        gap = min(3, (WL - 1) // len(chain))
+        assert gap >= 2
+        self.align8()
+        self.mad(self.T(0), a, self.X(0), self.T(0))
+        k = 1
+        for step in chain:
+            for _ in range(gap):
+                self.mad(self.T(k), a, self.X(k), self.T(k))
+                k += 1
+            e(step)
+            if step.startswith("v_mov_b32_dpp") or step.startswith("v_and"):
+                self.align8()
+        while k < WL:
+            self.mad(self.T(k), a, self.X(k), self.T(k))
+            k += 1
+        self.align8()
+        self.mad(self.P(g.v_y0), m, N(0), self.T(0))
+        self.mad(self.T(0), m, N(1), self.T(1))
+        e(f"v_lshrrev_b64 {self.P(g.v_c)}, {LB}, {self.P(g.v_y0)}")
+        e(f"v_and_b32 v{g.v_c}, v{g.v_c}, v{g.v_isfirst}")
+        e(f"v_and_b32 v{g.v_c + 1}, v{g.v_c + 1}, v{g.v_isfirst}")
+        for j in range(2, WL):
+            self.mad(self.T(j - 1), m, N(j), self.T(j))
+            if j == 4:
+                e(f"v_lshl_add_u64 {self.T(0)}, {self.T(0)}, 0, {self.P(g.v_c)}")
+        e(f"v_mov_b32_dpp {self.Tlo(WL - 1)}, v{g.v_y0} {self.dpp_next} row_mask:0xf bank_mask:0xf")
+        e(f"v_mov_b32_dpp {self.Thi(WL - 1)}, v{g.v_y0 + 1} {self.dpp_next} row_mask:0xf bank_mask:0xf")
+        e(f"v_and_b32 {self.Tlo(WL - 1)}, {self.Tlo(WL - 1)}, v{g.v_notlast}")
+        e(f"v_and_b32 {self.Thi(WL - 1)}, {self.Thi(WL - 1)}, v{g.v_notlast}")
+
+    def passes(self, tag, off_d, off_h, link2):
+        """H rows.  off_d / off_h: first row of the multiplier stream read by the digit lanes / by the helper lanes."""
+        g, e = self, self.e
+        WL, H = self.WL, self.H
+        row = self.NPB * 4
+        for j in range(WL):                                      # accumulators <- (0 | C2 | C1 | 0) by lane
+            e(f"ds_read_b64 {self.T(j)}, v{g.v_caddr} offset:{self.lds_c + 64 * j}")
+        e(f"v_and_b32 v{g.v_t1}, {(off_h - off_d) * row}, v{g.v_hmask}")
+        e(f"v_add_u32 v{g.v_arow}, v{g.v_aread}, v{g.v_t1}")
+        if off_d:
+            e(f"v_add_u32 v{g.v_arow}, {off_d * row}, v{g.v_arow}")
+        e(f"ds_read_b32 v{g.v_ain}, v{g.v_arow}")
+        e("s_mov_b32 s19, 0")
+        e(".p2align 6")
+        e(f"L_q{tag}:")
+        self.row(g.v_ain, g.v_ai, row, link2, 0)
+        self.row(g.v_ai, g.v_ain, 2 * row, link2, 2 * row)
+        e("s_add_u32 s19, s19, 2")
+        e(f"s_cmp_lt_u32 s19, {H}")
+        e(f"s_cbranch_scc1 L_q{tag}")
+        e("s_waitcnt lgkmcnt(0)")
+
+    def carry_X2(self):
+        """lazy limbs (sums of up to three canonical limbs) of the active lanes -> canonical again inside every slice; the lower
+        slice's carry goes into limb 0 of the upper one (lazy by a few units); the upper slice's top limb keeps the excess"""
+        g, e = self, self.e
+        WL = self.WL
+        M = hex(MASK)
+        e(f"v_not_b32 v{g.v_t2}, v{g.v_notlast}")
+        e(f"v_or_b32 v{g.v_t2}, {M}, v{g.v_t2}")                         # top-limb mask
+        e(f"v_not_b32 v{g.v_t3}, v{g.v_isfirst}")
+        for j in range(WL):
+            if j:
+                e(f"v_add_u32 {self.X(j)}, {self.X(j)}, v{g.v_t1}")
+            e(f"v_lshrrev_b32 v{g.v_t1}, {LB}, {self.X(j)}")
+            if j < WL - 1:
+                e(f"v_and_b32 {self.X(j)}, {M}, {self.X(j)}")
+            else:
+                e(f"v_and_b32 {self.X(j)}, {self.X(j)}, v{g.v_t2}")
+        e("s_nop 1")
+        e(f"v_mov_b32_dpp v{g.v_t4}, v{g.v_t1} {self.dpp_prev} row_mask:0xf bank_mask:0xf")
+        e(f"v_and_b32 v{g.v_t4}, v{g.v_t4}, v{g.v_t3}")
+        e(f"v_add_u32 {self.X(0)}, {self.X(0)}, v{g.v_t4}")
+
+    def montsq(self):
+        g, e = self, self.e
+        WL, H = self.WL, self.H
+        e("L_montsq:")
+        e("s_nop 1")
+        for j in range(WL):      # helper <- a1 (its quad: lanes 4, 5 keep themselves, lanes 6, 7 take them); a1, a2 double
+            e(f"v_mov_b32_dpp {self.X(j)}, {self.X(j)} quad_perm:[0,1,0,1] row_mask:0xf bank_mask:0xa")
+        for j in range(WL):
+            e(f"v_lshlrev_b32 {self.X(j)}, v{g.v_sh}, {self.X(j)}")
+        self.passes("s", 0, H, True)
+        self.normalize()
+        # a2 += a1 a1 R^-1 (helper): lanes 2, 3 += lanes 6, 7
+        self.set_exec8(0xcc)
+        e("s_nop 4")
+        for j in range(WL):
+            e(f"v_add_u32_dpp {self.X(j)}, {self.X(j)}, {self.X(j)} row_shl:4 row_mask:0xf bank_mask:0x5")
+        self.carry_X2()
+        e("s_mov_b64 exec, -1")
+        e("s_branch L_next")
+
+    def park_addr(self):
+        """v_t4 <- LDS address of this lane's parking rows: a0 in the rows of b0, a1 in those of b2, slice s at row s WL"""
+        g, e = self, self.e
+        row = self.NPB * 4
+        e("s_nop 1")
+        e(f"v_mov_b32_dpp v{g.v_t4}, v{g.v_l1mask} {self.dpp_bcast} row_mask:0xf bank_mask:0xf")    # -1 in both lanes of a1
+        e(f"v_and_b32 v{g.v_t4}, {2 * self.H * row}, v{g.v_t4}")
+        e(f"v_not_b32 v{g.v_t3}, v{g.v_isfirst}")
+        e(f"v_and_b32 v{g.v_t3}, {self.WL * row}, v{g.v_t3}")
+        e(f"v_add3_u32 v{g.v_t4}, v{g.v_t4}, v{g.v_t3}, v{g.v_aread}")
+
+    def montmul(self):
+        g, e = self, self.e
+        WL, H = self.WL, self.H
+        row = self.NPB * 4
+        e("L_montmul:")
+        e("s_nop 1")
+        for j in range(WL):                                      # helper <- a0 (6 lanes down), every other lane keeps its digit
+            e(f"v_mov_b32_dpp v{g.v_t5}, {self.X(j)} row_shr:6 row_mask:0xf bank_mask:0xf")
+            e(f"v_bfi_b32 {self.X(j)}, v{g.v_hmask}, v{g.v_t5}, {self.X(j)}")
+        # pass 1: stream b0 in the digit lanes (a0 b0 -> a1 b0 -> a2 b0 chained), stream b2 in the helper lanes (a0 b2)
+        self.passes("m1", 0, 2 * H, True)
+        self.normalize(dst=self.Tlo)
+        # a0 and a1 still need their digits as multiplicands: park their results in the LDS rows of the finished streams
+        # (a0: rows of b0, a1: rows of b2); a2 and the helper are done: pass 2 runs with them masked off
+        self.park_addr()
+        self.set_exec8(0x33)
+        for j in range(WL):
+            e(f"ds_write_b32 v{g.v_t4}, {self.Tlo(j)} offset:{j * row}")
+        # pass 2: stream b1 in the lanes of a0, a1 (a0 b1 -> a1 b1 chained)
+        self.passes("m2", H, H, False)
+        self.normalize(dst=self.Tlo)
+        # (normalize uses the scratch registers: the park address again)
+        self.park_addr()
+        for j in range(WL):
+            e(f"ds_read_b32 {self.X(j)}, v{g.v_t4} offset:{j * row}")    # lanes of a0, a1: the parked t00 / t10
+        e("s_waitcnt lgkmcnt(0)")
+        # c0 = t00 | c1 = t10 + t01 | c2 = t20 + t02 + t11
+        self.set_exec8(0xcc)
+        e("s_nop 4")
+        for j in range(WL):      # a2 <- t20 + t02 (helper, 4 lanes up)
+            e(f"v_add_u32_dpp {self.X(j)}, {self.Tlo(j)}, {self.Tlo(j)} row_shl:4 row_mask:0xf bank_mask:0x5")
+        self.set_exec8(0x33)
+        e("s_nop 4")
+        for j in range(WL):      # a1 += t01 (pass two of a0, 4 lanes down)
+            e(f"v_add_u32_dpp {self.X(j)}, {self.Tlo(j)}, {self.X(j)} row_shr:4 row_mask:0xf bank_mask:0xa")
+        self.set_exec8(0x3c)
+        e("s_nop 4")
+        for j in range(WL):      # a2 += t11 (pass two of a1, 2 lanes up)
+            e(f"v_add_u32_dpp {self.X(j)}, {self.Tlo(j)}, {self.X(j)} row_shl:2 row_mask:0xf bank_mask:0x5")
+        self.carry_X2()
+        e("s_mov_b64 exec, -1")
+        e("s_branch L_next")
+
+    def generate(self):
+        self.prologue()
+        self.dispatcher()
+        self.montmul()
+        self.montsq()
+        self.epilogue()
+        return "\n".join(self.lines) + "\n"
 
 
 class GenQ3(Gen):
@@ -3352,10 +3666,11 @@ class GenQ3(Gen):
         return "\n".join(self.lines) + "\n"
 
 
-SHAPES = [(74, 1), (37, 1), (55, 1), (55, 2), (74, 2), (55, 4), (74, 4), (42, 8), (37, 2), (37, 4), (37, 16), (55, 16), (74, 32), (55, 32), (37, 32), (37, 64), (19, 96), (74, 48), (37, 48), (55, 48)]
+SHAPES = [(74, 1), (37, 1), (55, 1), (55, 2), (74, 2), (55, 4), (74, 4), (42, 8), (37, 2), (37, 4), (37, 16), (55, 16), (74, 32), (55, 32), (37, 32), (37, 64), (19, 96), (74, 48), (37, 48), (55, 48), (55, 112), (37, 112)]
 PAIR = {(37, 16), (55, 16)}  # (H, 16): the pair kernel for N = p^2 with H-limb p (GenP); 16 is a tag, not a lane count
 PAIR4 = {(37, 64)}          # (WL, 64): GenQ4, the two digits of GenQ(2 WL) sliced over two lanes each
 PAIR8 = {(19, 96)}          # (WL, 96): GenQ8, the two digits sliced over four lanes each (76-limb digits)
+TRIPLE2 = {(55, 112), (37, 112)}   # (WL, 112): GenQ6, three digits of 2 WL limbs, two lanes each (+ two helper lanes)
 PAIR2 = {(74, 32), (55, 32), (37, 32)}          # (H, 32): the two-lane pair kernel for N = n^2 with H-limb n (GenQ)
 WAVE_SLICED = {(74, 2), (55, 2)}     # shapes whose slices live in different waves (GenW) instead of neighbouring lanes (Gen)
 TRIPLE = {(74, 48), (37, 48), (55, 48)}        # (H, 48): GenQ3, residues modulo n^3 as three base-n digits in the lanes of a quad
@@ -3370,6 +3685,8 @@ def make_gen(wl, k):
         return GenQ4(wl)
     if (wl, k) in PAIR8:
         return GenQ8(wl)
+    if (wl, k) in TRIPLE2:
+        return GenQ6(wl)
     if (wl, k) in TRIPLE:
         return GenQ3(wl)
     return GenW(wl, k) if (wl, k) in WAVE_SLICED else Gen(wl, k)

@@ -34,8 +34,10 @@ def value(arr):
     return sum(int(x) << (LB * i) for i, x in enumerate(arr))
 
 
-@pytest.mark.parametrize("bits,H", [(1024, 37), (2048, 74)])
-def test_digit_model(ctx, bits, H):
+@pytest.mark.parametrize("bits,H,lanes", [(1024, 37, 3), (2048, 74, 3), (2048, 74, 6), (3072, 110, 6)])
+def test_digit_model(ctx, bits, H, lanes):
+    # lanes = 3: GenQ3, one lane per digit (+ a helper lane); lanes = 6: GenQ6, two lanes per digit (vm_asm_37_112, vm_asm_55_112:
+    # digits of 74 / 110 limbs), whose product is the two-pass form at every width
     rng = random.Random(bits)
     n = po.gen_prime_3mod4(bits // 2, rng) * po.gen_prime_3mod4(bits // 2, rng)
     R = 1 << (LB * H)
@@ -63,7 +65,7 @@ def test_digit_model(ctx, bits, H):
             mem[0, d * H:(d + 1) * H, g] = limbs(xs[g][d], H)
             mem[1, d * H:(d + 1) * H, g] = limbs(ys[g][d], H)
     prog = [OPS["LOAD"], 0, OPS["SQR"], 0, OPS["STORE"], 2, OPS["LOAD"], 0, OPS["MUL"], 1, OPS["STORE"], 3, OPS["END"], 0]
-    out, _, h = ctx.pair_debug_run(n, prog, mem, 4, nb, lanes=3)
+    out, _, h = ctx.pair_debug_run(n, prog, mem, 4, nb, lanes=lanes)
     assert h == H
     n3 = n ** 3
     val = lambda d: d[0] + d[1] * n + d[2] * n * n
@@ -80,7 +82,7 @@ def test_digit_model(ctx, bits, H):
         assert (val(got_sq) * R - val(xs[g]) ** 2) % n3 == 0
         m00, t00 = redc(a0 * b0)
         _, t02 = redc(a0 * b2)
-        if H <= 55:
+        if H <= 55 and lanes == 3:
             # one pass (the kernel has the registers for a copy of the digit below): ONE reduction per digit of the whole
             # coefficient, its quotient digits subtracted from the next digit
             m1, t1 = redc(a1 * b0 + a0 * b1 + C1 - m00)
@@ -117,7 +119,8 @@ def test_level_two_paths_on_and_off(ctx, bits):
         try:
             cts = pk.EncryptWithRBatch(ms, rs, level=pa.ENC_LEVEL_TWO)
             kern = ctx.last_profile()["kernel"]
-            assert kern.endswith("_48") == bool(flag), kern
+            # (a batch this small takes the two-lanes-per-digit variant of the three-digit kernel, vm_asm_<H/2>_112)
+            assert (kern.endswith("_48") or kern.endswith("_112")) == bool(flag), kern
             res[flag] = (cts, pk.ConstMultBatch(cts, ks, level=pa.ENC_LEVEL_TWO), pk.ConstMultBatch(cts, ks[5], level=pa.ENC_LEVEL_TWO))
         finally:
             ctx.set_flag("triple", 1)
