@@ -2475,12 +2475,13 @@ class GenQ4(Gen):
         self.lanes_per_number = 4
         self.v_caddr = self.n_vgpr
         self.n_vgpr += 1
+        self.alloc_row_regs()
         assert self.n_vgpr <= 256, self.n_vgpr
         # constants table in LDS: [WL][4 lanes] zero-extended limbs (0 | 0 | Cadj_j | Cadj_(WL+j)): the accumulators of a linked
         # pass START there (limb i of Cadj is the initial value of column i of digit one), as in GenQ3
         self.lds_c = self.lds_a + (self.WTslot + 1) * self.NPB * 4
-        self.lds_z = self.lds_c + WL * 32       # 1 KB of zeros: the second multiplier stream of the lanes of digit zero
-        self.lds_bytes = self.lds_z + 1024
+        self.lds_z = self.lds_c + WL * 32       # 2 KB of zeros: the second multiplier stream of the lanes of digit zero
+        self.lds_bytes = self.lds_z + 2048      # (a paired read reaches up to six rows past the pointer)
         assert self.lds_bytes < 65536
         # lane exchanges (GenQ8 below re-uses the rows with four slices per digit)
         self.dpp_link = "quad_perm:[0,1,0,3]"    # slice 0 of digit one <- slice 0 of digit zero
@@ -2494,6 +2495,22 @@ class GenQ4(Gen):
 
     def X(self, j):
         return f"v{self._xb + j}"
+
+    def alloc_row_regs(self):
+        """registers of the rows: the multiplier pairs of both streams (two rows are read at a time), the column that comes in
+        from the slice above (a pair whose high word stays zero), the limb masks"""
+        e = (self.n_vgpr + 1) // 2 * 2
+        self.v_pa, self.v_pb, self.v_pa2, self.v_pb2, self.v_in = e, e + 2, e + 4, e + 6, e + 8
+        e += 10
+        self.v_mask28, self.v_rxmask, self.v_bump4 = e, e + 1, e + 2
+        self.n_vgpr = e + 3
+
+    def init_row_regs(self):
+        g, e = self, self.e
+        e(f"v_mov_b32 v{g.v_mask28}, {hex(MASK)}")
+        e(f"v_and_b32 v{g.v_rxmask}, {hex(MASK)}, v{g.v_notlast}")     # a slice that has one above it takes that one's low column
+        e(f"v_mov_b32 v{g.v_in + 1}, 0")
+        e(f"v_mov_b32 v{g.v_bump4}, {4 * self.NPB * 4}")
 
     # slot / constant addressing uses the 4-lane slot width
     def slot_base(self):
@@ -2575,7 +2592,8 @@ class GenQ4(Gen):
         e("s_waitcnt lgkmcnt(0)")
         e("s_mov_b64 exec, s[96:97]")
         e(f"v_mov_b32 v{g.v_p0}, 0")
-        e(f"ds_write_b32 v{g.v_t3}, v{g.v_p0} offset:{self.lds_z}")      # every thread zeroes one word of the zero rows
+        e(f"ds_write_b32 v{g.v_t3}, v{g.v_p0} offset:{self.lds_z}")      # every thread zeroes two words of the zero rows
+        e(f"ds_write_b32 v{g.v_t3}, v{g.v_p0} offset:{self.lds_z + 1024}")
         e("s_waitcnt lgkmcnt(0)")
         e("s_barrier")
         for j in range(WL):
@@ -2583,83 +2601,106 @@ class GenQ4(Gen):
         e("s_waitcnt lgkmcnt(0)")
         for j in range(WL):
             e(f"v_mov_b32 {self.X(j)}, 0")
+        self.init_row_regs()
 
-    def row(self, cur, nxt, aoff, link, bump, cur2=None, nxt2=None):
-        """one Montgomery row modulo n in the four lanes of a number.  cur / nxt: multiplier registers (this row / prefetch at
-        byte offset aoff of the row pointer); link: lane 2 takes -m_i of lane 0 into column 0 (its Cadj limb has been in the
-        accumulator since the pass began); bump: advance the row pointers by two rows afterwards; cur2 / nxt2: the second
-        multiplier stream of a product (against the multiplicand copy vR2).
+    def read_pair(self, dst, ptr, first_row):
+        """multipliers of rows first_row, first_row + 1 past the row pointer -> the register pair dst"""
+        rowb = self.NPB * 4
+        if rowb == 256:
+            self.e(f"ds_read2st64_b32 v[{dst}:{dst + 1}], v{ptr} offset0:{first_row} offset1:{first_row + 1}")
+        else:
+            assert rowb % 4 == 0 and (first_row + 1) * rowb // 4 <= 255
+            self.e(f"ds_read2_b32 v[{dst}:{dst + 1}], v{ptr} offset0:{first_row * rowb // 4} offset1:{(first_row + 1) * rowb // 4}")
+
+    def row(self, a, link, a2=None):
+        """one Montgomery row modulo n in the lanes of a number.  a: this row's multiplier; link: the link lane takes -m_i of digit
+        zero into column 0 (its Cadj limb has been in the accumulator since the pass began); a2: the second multiplier stream of a
+        product (against the multiplicand copy vR2).
         Column 0 is complete after the FIRST multiplies of pass A, so the quotient digit, the link hop and the broadcast to the
-        digit's upper slice -- a chain of dependent instructions -- start right away and are spread between the remaining
-        multiplies of pass A: no s_nop for the DPP hazard, nothing waits on a result in flight (what counts at one wave per
-        SIMD, where every instruction of the wave, scalar or not, takes an issue slot)."""
+        digit's upper slices -- a chain of dependent instructions -- start right away and are spread between the remaining
+        multiplies of pass A: no s_nop for the DPP hazard, nothing waits on a result in flight.  At one wave per SIMD every
+        instruction of the wave, scalar or not, takes an issue slot, so the row is kept to what cannot be avoided:
+          - a limb mask and the lane exchange that follows it are ONE instruction (v_and_b32 with a DPP source);
+          - every slice keeps the carry of its own column 0 (the high part of y0) and hands only the LOW 28 bits to the slice
+            below, where they are the new top column: the same value as moving the whole column, without masking the carry by
+            lane, and the incoming column is a 32-bit register whose pair partner is a constant zero;
+          - multipliers are read two rows at a time."""
         g, e = self, self.e
         WL = self.WL
         N = lambda j: f"v{g.v_N + j}"
         m = f"v{g.v_m}"
-        e("s_waitcnt lgkmcnt(0)")
-        e(f"ds_read_b32 v{nxt}, v{g.v_arow} offset:{aoff}")
-        if cur2 is not None:
-            e(f"ds_read_b32 v{nxt2}, v{g.v_arow2} offset:{aoff}")
-        if bump:
-            e(f"v_add_u32 v{g.v_arow}, {bump}, v{g.v_arow}")
-            if cur2 is not None:
-                e(f"v_add_u32 v{g.v_arow2}, v{g.v_bump2}, v{g.v_arow2}")
-        a = f"v{cur}"
-        chain = [f"v_mul_lo_u32 {m}, {self.Tlo(0)}, s14", f"v_and_b32 {m}, {hex(MASK)}, {m}"]
+        IN = self.P(g.v_in)
+        chain = [f"v_mul_lo_u32 {m}, {self.Tlo(0)}, s14"]
         if link:
-            chain += [f"v_mov_b32_dpp v{g.v_d}, {m} {self.dpp_link} row_mask:0xf bank_mask:0xf",
+            chain += [f"v_and_b32_dpp v{g.v_d}, {m}, v{g.v_mask28} {self.dpp_link} row_mask:0xf bank_mask:0xf",
                       f"v_mad_i64_i32 {self.T(0)}, vcc, v{g.v_d}, v{g.v_linkmask}, {self.T(0)}",    # digit one, slice 0: T0 -= m of digit zero
-                      f"v_mul_lo_u32 {m}, {self.Tlo(0)}, s14",
-                      f"v_and_b32 {m}, {hex(MASK)}, {m}"]
-        chain.append(f"v_mov_b32_dpp {m}, {m} {self.dpp_bcast} row_mask:0xf bank_mask:0xf")
+                      f"v_mul_lo_u32 {m}, {self.Tlo(0)}, s14"]
+        chain.append(f"v_and_b32_dpp {m}, {m}, v{g.v_mask28} {self.dpp_bcast} row_mask:0xf bank_mask:0xf")
         muls = []
         for j in range(WL):
-            muls.append((self.T(j), a, self.X(j)))
-            if cur2 is not None:
-                muls.append((self.T(j), f"v{cur2}", f"v{g.vR2 + j}"))
-        head = 1 if cur2 is None else 2                  # multiplies that complete column 0
-        gap = min(3, (len(muls) - head) // len(chain))
+            muls.append((self.T(j), f"v{a}", self.X(j), IN if j == WL - 1 else self.T(j)))
+            if a2 is not None:
+                muls.append((self.T(j), f"v{a2}", f"v{g.vR2 + j}", self.T(j)))
+        head = 1 if a2 is None else 2                    # multiplies that complete column 0
+        gap = min(4, (len(muls) - head) // len(chain))
         assert gap >= 2
         self.align8()
         k = 0
         for _ in range(head):
-            self.mad(muls[k][0], muls[k][1], muls[k][2], muls[k][0])
+            self.mad(*muls[k])
             k += 1
         for step in chain:
             for _ in range(gap):
-                self.mad(muls[k][0], muls[k][1], muls[k][2], muls[k][0])
+                self.mad(*muls[k])
                 k += 1
             e(step)
-            if step.startswith("v_mov_b32_dpp") or step.startswith("v_and"):
-                self.align8()
         while k < len(muls):
-            self.mad(muls[k][0], muls[k][1], muls[k][2], muls[k][0])
+            self.mad(*muls[k])
             k += 1
-        self.align8()
         self.mad(self.P(g.v_y0), m, N(0), self.T(0))
         self.mad(self.T(0), m, N(1), self.T(1))
         e(f"v_lshrrev_b64 {self.P(g.v_c)}, {LB}, {self.P(g.v_y0)}")
-        e(f"v_and_b32 v{g.v_c}, v{g.v_c}, v{g.v_isfirst}")
-        e(f"v_and_b32 v{g.v_c + 1}, v{g.v_c + 1}, v{g.v_isfirst}")
         for j in range(2, WL):
             self.mad(self.T(j - 1), m, N(j), self.T(j))
             if j == 4:
                 e(f"v_lshl_add_u64 {self.T(0)}, {self.T(0)}, 0, {self.P(g.v_c)}")
-        e(f"v_mov_b32_dpp {self.Tlo(WL - 1)}, v{g.v_y0} {self.dpp_next} row_mask:0xf bank_mask:0xf")
-        e(f"v_mov_b32_dpp {self.Thi(WL - 1)}, v{g.v_y0 + 1} {self.dpp_next} row_mask:0xf bank_mask:0xf")
-        e(f"v_and_b32 {self.Tlo(WL - 1)}, {self.Tlo(WL - 1)}, v{g.v_notlast}")
-        e(f"v_and_b32 {self.Thi(WL - 1)}, {self.Thi(WL - 1)}, v{g.v_notlast}")
+        e(f"v_and_b32_dpp v{g.v_in}, v{g.v_y0}, v{g.v_rxmask} {self.dpp_next} row_mask:0xf bank_mask:0xf")
+
+    def row_pair(self, cur, nxt, link, ahead, bump, cur2=None, nxt2=None, count=False):
+        """two rows on the multiplier pair(s) cur; the pair(s) of the two rows `ahead` rows past the pointer are fetched into nxt;
+        bump: rows the pointers move on afterwards (2 before the loop, 4 inside it); count: the loop counter moves here (the 4-byte
+        scalar instructions are paired so that the multiply streams stay on 8-byte boundaries without padding)"""
+        g, e = self, self.e
+        rowb = self.NPB * 4
+        e("s_waitcnt lgkmcnt(0)")
+        if count:
+            e("s_add_u32 s19, s19, 1")
+        self.read_pair(nxt, g.v_arow, ahead)
+        if cur2 is not None:
+            self.read_pair(nxt2, g.v_arow2, ahead)
+        if bump == 4:
+            e(f"v_add_u32 v{g.v_arow}, v{g.v_bump4}, v{g.v_arow}")
+            if cur2 is not None:
+                e(f"v_lshl_add_u32 v{g.v_arow2}, v{g.v_bump2}, 1, v{g.v_arow2}")
+        elif bump:
+            assert bump == 2 and not count
+            e(f"v_add_u32 v{g.v_arow}, {2 * rowb}, v{g.v_arow}")
+            if cur2 is not None:
+                e(f"v_add_u32 v{g.v_arow2}, v{g.v_bump2}, v{g.v_arow2}")
+            e("s_nop 0")
+        self.row(cur, link, cur2)
+        self.row(cur + 1, link, None if cur2 is None else cur2 + 1)
 
     def passes(self, tag, two_streams):
         """H linked rows: T <- (b0 stream) * X [+ (b1 stream | zeros) * vR2] * R^-1, accumulators starting at the constants"""
         g, e = self, self.e
         WL, H = self.WL, self.H
         row = self.NPB * 4
+        assert H % 2 == 0
         for j in range(WL):                                      # accumulators <- (0 | 0 | Cadj_j | Cadj_(WL+j)) by lane
             e(f"ds_read_b64 {self.T(j)}, v{g.v_caddr} offset:{self.lds_c + self.lanes_per_number * 8 * j}")
         e(f"v_mov_b32 v{g.v_arow}, v{g.v_aread}")
-        e(f"ds_read_b32 v{g.v_ain}, v{g.v_arow}")
+        self.read_pair(g.v_pa, g.v_arow, 0)
         if two_streams:
             # stream two: rows H.. of the a column (b1) in the lanes of digit one, the zero rows in the lanes of digit zero
             e(f"v_add_u32 v{g.v_arow2}, {H * row}, v{g.v_aread}")
@@ -2672,20 +2713,25 @@ class GenQ4(Gen):
             e(f"v_and_b32 v{g.v_t2}, v{g.v_t2}, v{g.v_t3}")
             e(f"v_xor_b32 v{g.v_arow2}, {self.lds_z}, v{g.v_t2}")      # digit one: aread + H rows; digit zero: lds_z
             e(f"v_and_b32 v{g.v_bump2}, {2 * row}, v{g.v_t3}")
-            e(f"ds_read_b32 v{g.v_ain2}, v{g.v_arow2}")
+            self.read_pair(g.v_pa2, g.v_arow2, 0)
+        e("s_waitcnt lgkmcnt(0)")
+        e(f"v_mov_b32 v{g.v_in}, {self.Tlo(WL - 1)}")            # the top column's constant comes in as its first addend
+        s2 = lambda c2, n2: dict(cur2=c2, nxt2=n2) if two_streams else {}
+        pairs = H // 2
+        A, B = (g.v_pa, g.v_pa2), (g.v_pb, g.v_pb2)
+        if pairs % 2:
+            self.row_pair(A[0], B[0], True, 2, 2, **s2(A[1], B[1]))
+            A, B = B, A
         e("s_mov_b32 s19, 0")
         e(".p2align 6")
         e(f"L_q{tag}:")
-        if two_streams:
-            self.row(g.v_ain, g.v_ai, row, True, 0, g.v_ain2, g.v_ai2)
-            self.row(g.v_ai, g.v_ain, 2 * row, True, 2 * row, g.v_ai2, g.v_ain2)
-        else:
-            self.row(g.v_ain, g.v_ai, row, True, 0)
-            self.row(g.v_ai, g.v_ain, 2 * row, True, 2 * row)
-        e("s_add_u32 s19, s19, 2")
-        e(f"s_cmp_lt_u32 s19, {H}")
+        self.row_pair(A[0], B[0], True, 2, 0, count=True, **s2(A[1], B[1]))
+        self.row_pair(B[0], A[0], True, 4, 4, **s2(B[1], A[1]))
+        e(f"s_cmp_lt_u32 s19, {pairs // 2}")
         e(f"s_cbranch_scc1 L_q{tag}")
         e("s_waitcnt lgkmcnt(0)")
+        e(f"v_mov_b32 {self.Tlo(WL - 1)}, v{g.v_in}")            # the last row's incoming column is the top column of the result
+        e(f"v_mov_b32 {self.Thi(WL - 1)}, 0")
 
     def normalize(self, dst=None):
         """accumulators -> limbs of the new x (dst(j): where limb j goes; default the multiplicand registers).  Two lanes per digit: both run the plain sequential carry of a one-lane number
@@ -2805,7 +2851,8 @@ class GenQ8(GenQ4):
         self.v_caddr = e
         e += 1
         self.n_vgpr = e
-        assert e <= 256, e
+        self.alloc_row_regs()
+        assert self.n_vgpr <= 256, self.n_vgpr
         self.lds_c = self.lds_a + (self.WTslot + 1) * self.NPB * 4
         self.lds_z = self.lds_c + WL * 64
         self.lds_bytes = self.lds_z + 1024
@@ -2892,6 +2939,7 @@ class GenQ8(GenQ4):
         e("s_waitcnt lgkmcnt(0)")
         for j in range(WL):
             e(f"v_mov_b32 {self.X(j)}, 0")
+        self.init_row_regs()
 
 
 class GenQ6(GenQ4):

@@ -92,21 +92,24 @@ def test_asm_generator_model():
             assert mm.split("L_p2m:")[1].split("s_cbranch_scc1 L_p2m")[0].count("v_mad_u64_u32") == 2 * 3 * H
             continue
         if (wl, k) in gen_vm_asm.PAIR8:
-            # eight-lane pair kernel: GenQ4's rows with four slices per digit (19-limb slices of a 76-limb digit): two-row bodies of
+            # eight-lane pair kernel: GenQ4's rows with four slices per digit (19-limb slices of a 76-limb digit): four-row bodies of
             # 2 WL (squaring) / 3 WL (one-pass product) multiplies per lane, the link across quads by row_shr:4
             for lbl, where, per_row in (("L_qs", "L_montsq:", 2 * wl), ("L_qm", "L_montmul:", 3 * wl)):
                 body = text.split(where)[1].split(lbl + ":")[1].split("s_cbranch_scc1 " + lbl)[0]
-                assert body.count("v_mad_u64_u32") == 2 * per_row
-                assert body.count("row_shr:4") == 2 and body.count("s_nop") == 0
+                assert body.count("v_mad_u64_u32") == 4 * per_row
+                assert body.count("row_shr:4") == 4 and body.count("s_nop") == 0
+                assert len([l for l in body.splitlines() if l.strip() and not l.strip().startswith(".")]) - 4 * per_row <= 4 * 11
             assert g.H == 4 * wl and g.lds_bytes * 2 <= 160 * 1024
             continue
         if (wl, k) in gen_vm_asm.PAIR4:
-            # four-lane pair kernel: a squaring is one pass of two-row bodies of 2 WL multiplies per lane; a product is ONE pass
-            # too, with two multiplier streams (3 WL multiplies a row); one quotient link per row; no s_nop inside a row
+            # four-lane pair kernel: a squaring is one pass of four-row bodies of 2 WL multiplies per lane; a product is ONE pass
+            # too, with two multiplier streams (3 WL multiplies a row); one quotient link per row; no s_nop inside a row, and at
+            # most 11 instructions a row that are not multiplies (one wave per SIMD: each of them costs a multiply's issue slot)
             for lbl, where, per_row in (("L_qs", "L_montsq:", 2 * wl), ("L_qm", "L_montmul:", 3 * wl)):
                 body = text.split(where)[1].split(lbl + ":")[1].split("s_cbranch_scc1 " + lbl)[0]
-                assert body.count("v_mad_u64_u32") == 2 * per_row
-                assert body.count("quad_perm:[0,1,0,3]") == 2 and body.count("s_nop") == 0
+                assert body.count("v_mad_u64_u32") == 4 * per_row
+                assert body.count("quad_perm:[0,1,0,3]") == 4 and body.count("s_nop") == 0
+                assert len([l for l in body.splitlines() if l.strip() and not l.strip().startswith(".")]) - 4 * per_row <= 4 * 11
             assert g.lds_bytes * 2 <= 160 * 1024
             continue
         if (wl, k) in gen_vm_asm.TRIPLE2:
