@@ -2612,6 +2612,18 @@ class GenQ4(Gen):
             assert rowb % 4 == 0 and (first_row + 1) * rowb // 4 <= 255
             self.e(f"ds_read2_b32 v[{dst}:{dst + 1}], v{ptr} offset0:{first_row * rowb // 4} offset1:{(first_row + 1) * rowb // 4}")
 
+    def chain_steps(self, link):
+        """the dependent instructions between column 0 of a row and the quotient digit in every slice"""
+        g = self
+        m = f"v{g.v_m}"
+        chain = [f"v_mul_lo_u32 {m}, {self.Tlo(0)}, s14"]
+        if link:
+            chain += [f"v_and_b32_dpp v{g.v_d}, {m}, v{g.v_mask28} {self.dpp_link} row_mask:0xf bank_mask:0xf",
+                      f"v_mad_i64_i32 {self.T(0)}, vcc, v{g.v_d}, v{g.v_linkmask}, {self.T(0)}",    # digit one, slice 0: T0 -= m of digit zero
+                      f"v_mul_lo_u32 {m}, {self.Tlo(0)}, s14"]
+        chain.append(f"v_and_b32_dpp {m}, {m}, v{g.v_mask28} {self.dpp_bcast} row_mask:0xf bank_mask:0xf")
+        return chain
+
     def row(self, a, link, a2=None):
         """one Montgomery row modulo n in the lanes of a number.  a: this row's multiplier; link: the link lane takes -m_i of digit
         zero into column 0 (its Cadj limb has been in the accumulator since the pass began); a2: the second multiplier stream of a
@@ -2630,12 +2642,7 @@ class GenQ4(Gen):
         N = lambda j: f"v{g.v_N + j}"
         m = f"v{g.v_m}"
         IN = self.P(g.v_in)
-        chain = [f"v_mul_lo_u32 {m}, {self.Tlo(0)}, s14"]
-        if link:
-            chain += [f"v_and_b32_dpp v{g.v_d}, {m}, v{g.v_mask28} {self.dpp_link} row_mask:0xf bank_mask:0xf",
-                      f"v_mad_i64_i32 {self.T(0)}, vcc, v{g.v_d}, v{g.v_linkmask}, {self.T(0)}",    # digit one, slice 0: T0 -= m of digit zero
-                      f"v_mul_lo_u32 {m}, {self.Tlo(0)}, s14"]
-        chain.append(f"v_and_b32_dpp {m}, {m}, v{g.v_mask28} {self.dpp_bcast} row_mask:0xf bank_mask:0xf")
+        chain = self.chain_steps(link)
         muls = []
         for j in range(WL):
             muls.append((self.T(j), f"v{a}", self.X(j), IN if j == WL - 1 else self.T(j)))
@@ -2714,19 +2721,25 @@ class GenQ4(Gen):
             e(f"v_xor_b32 v{g.v_arow2}, {self.lds_z}, v{g.v_t2}")      # digit one: aread + H rows; digit zero: lds_z
             e(f"v_and_b32 v{g.v_bump2}, {2 * row}, v{g.v_t3}")
             self.read_pair(g.v_pa2, g.v_arow2, 0)
+        self.row_loop(tag, True, two_streams)
+
+    def row_loop(self, tag, link, two_streams):
+        """the H rows of a pass; the first multiplier pair(s) are on their way"""
+        g, e = self, self.e
+        WL, H = self.WL, self.H
         e("s_waitcnt lgkmcnt(0)")
         e(f"v_mov_b32 v{g.v_in}, {self.Tlo(WL - 1)}")            # the top column's constant comes in as its first addend
         s2 = lambda c2, n2: dict(cur2=c2, nxt2=n2) if two_streams else {}
         pairs = H // 2
-        A, B = (g.v_pa, g.v_pa2), (g.v_pb, g.v_pb2)
+        A, B = (g.v_pa, getattr(g, 'v_pa2', None)), (g.v_pb, getattr(g, 'v_pb2', None))
         if pairs % 2:
-            self.row_pair(A[0], B[0], True, 2, 2, **s2(A[1], B[1]))
+            self.row_pair(A[0], B[0], link, 2, 2, **s2(A[1], B[1]))
             A, B = B, A
         e("s_mov_b32 s19, 0")
         e(".p2align 6")
         e(f"L_q{tag}:")
-        self.row_pair(A[0], B[0], True, 2, 0, count=True, **s2(A[1], B[1]))
-        self.row_pair(B[0], A[0], True, 4, 4, **s2(B[1], A[1]))
+        self.row_pair(A[0], B[0], link, 2, 0, count=True, **s2(A[1], B[1]))
+        self.row_pair(B[0], A[0], link, 4, 4, **s2(B[1], A[1]))
         e(f"s_cmp_lt_u32 s19, {pairs // 2}")
         e(f"s_cbranch_scc1 L_q{tag}")
         e("s_waitcnt lgkmcnt(0)")
@@ -2976,6 +2989,20 @@ class GenQ6(GenQ4):
         self._xb = self.vX
         self.n_vgpr = e
         assert e <= 256, e
+        # the registers of GenQ4's rows come from slots of the base map that this kernel does not use (the two-lane squaring's
+        # scalars, the single multiplier registers and the alignment gap after them)
+        pool = sorted([self.v_ai, self.v_ain, self.v_k, 3 * WL + 5, self.v_mk, self.v_mult, self.v_km2, self.v_islast] +
+                      ([self.v_y0 - 1] if (3 * WL + 10) % 2 else []))
+        pairs = []
+        for r in list(pool):
+            if r % 2 == 0 and r in pool and r + 1 in pool and len(pairs) < 3:
+                pairs.append(r)
+                pool.remove(r)
+                pool.remove(r + 1)
+        assert len(pairs) == 3 and len(pool) >= 3, (pairs, pool)
+        self.v_pa, self.v_pb, self.v_in = pairs
+        self.v_mask28, self.v_rxmask, self.v_bump4 = pool[:3]
+        del self.v_ai, self.v_ain
         self.lds_c = self.lds_a + (self.WTslot + 1) * self.NPB * 4
         self.lds_bytes = self.lds_c + WL * 64
         assert self.lds_bytes < 65536
@@ -3076,59 +3103,24 @@ class GenQ6(GenQ4):
         e("s_waitcnt lgkmcnt(0)")
         for j in range(WL):
             e(f"v_mov_b32 {self.X(j)}, 0")
+        self.init_row_regs()
 
-    def row(self, cur, nxt, aoff, link2, bump):
-        """one Montgomery row modulo n in the eight lanes of a number.  Link one: slice 0 of a1 takes -m of a0; link two (link2):
-        slice 0 of a2 takes -m of a1; every quotient digit is then broadcast to the digit's upper slice."""
-        g, e = self, self.e
-        WL = self.WL
-        N = lambda j: f"v{g.v_N + j}"
+    def chain_steps(self, link2):
+        """Link one: slice 0 of a1 takes -m of a0; link two (link2): slice 0 of a2 takes -m of a1; every quotient digit is then
+        broadcast to the digit's upper slice."""
+        g = self
         m = f"v{g.v_m}"
-        e("s_waitcnt lgkmcnt(0)")
-        e(f"ds_read_b32 v{nxt}, v{g.v_arow} offset:{aoff}")
-        if bump:
-            e(f"v_add_u32 v{g.v_arow}, {bump}, v{g.v_arow}")
-        a = f"v{cur}"
-        chain = [f"v_mul_lo_u32 {m}, {self.Tlo(0)}, s14", f"v_and_b32 {m}, {hex(MASK)}, {m}"]
-        hops = [("row_shr:4", g.v_l1mask)] + ([("row_shl:2", g.v_l2mask)] if link2 else [])
-        for ctrl, mask in hops:
-            chain += [f"v_mov_b32_dpp v{g.v_d}, {m} {ctrl} row_mask:0xf bank_mask:0xf",
+        chain = [f"v_mul_lo_u32 {m}, {self.Tlo(0)}, s14"]
+        for ctrl, mask in [("row_shr:4", g.v_l1mask)] + ([("row_shl:2", g.v_l2mask)] if link2 else []):
+            chain += [f"v_and_b32_dpp v{g.v_d}, {m}, v{g.v_mask28} {ctrl} row_mask:0xf bank_mask:0xf",
                       f"v_mad_i64_i32 {self.T(0)}, vcc, v{g.v_d}, v{mask}, {self.T(0)}",
-                      f"v_mul_lo_u32 {m}, {self.Tlo(0)}, s14",
-                      f"v_and_b32 {m}, {hex(MASK)}, {m}"]
-        chain.append(f"v_mov_b32_dpp {m}, {m} {self.dpp_bcast} row_mask:0xf bank_mask:0xf")
-        gap = min(3, (WL - 1) // len(chain))
-        assert gap >= 2
-        self.align8()
-        self.mad(self.T(0), a, self.X(0), self.T(0))
-        k = 1
-        for step in chain:
-            for _ in range(gap):
-                self.mad(self.T(k), a, self.X(k), self.T(k))
-                k += 1
-            e(step)
-            if step.startswith("v_mov_b32_dpp") or step.startswith("v_and"):
-                self.align8()
-        while k < WL:
-            self.mad(self.T(k), a, self.X(k), self.T(k))
-            k += 1
-        self.align8()
-        self.mad(self.P(g.v_y0), m, N(0), self.T(0))
-        self.mad(self.T(0), m, N(1), self.T(1))
-        e(f"v_lshrrev_b64 {self.P(g.v_c)}, {LB}, {self.P(g.v_y0)}")
-        e(f"v_and_b32 v{g.v_c}, v{g.v_c}, v{g.v_isfirst}")
-        e(f"v_and_b32 v{g.v_c + 1}, v{g.v_c + 1}, v{g.v_isfirst}")
-        for j in range(2, WL):
-            self.mad(self.T(j - 1), m, N(j), self.T(j))
-            if j == 4:
-                e(f"v_lshl_add_u64 {self.T(0)}, {self.T(0)}, 0, {self.P(g.v_c)}")
-        e(f"v_mov_b32_dpp {self.Tlo(WL - 1)}, v{g.v_y0} {self.dpp_next} row_mask:0xf bank_mask:0xf")
-        e(f"v_mov_b32_dpp {self.Thi(WL - 1)}, v{g.v_y0 + 1} {self.dpp_next} row_mask:0xf bank_mask:0xf")
-        e(f"v_and_b32 {self.Tlo(WL - 1)}, {self.Tlo(WL - 1)}, v{g.v_notlast}")
-        e(f"v_and_b32 {self.Thi(WL - 1)}, {self.Thi(WL - 1)}, v{g.v_notlast}")
+                      f"v_mul_lo_u32 {m}, {self.Tlo(0)}, s14"]
+        chain.append(f"v_and_b32_dpp {m}, {m}, v{g.v_mask28} {self.dpp_bcast} row_mask:0xf bank_mask:0xf")
+        return chain
 
     def passes(self, tag, off_d, off_h, link2):
-        """H rows.  off_d / off_h: first row of the multiplier stream read by the digit lanes / by the helper lanes."""
+        """H rows (GenQ4's, with this kernel's chain).  off_d / off_h: first row of the multiplier stream read by the digit lanes /
+        by the helper lanes."""
         g, e = self, self.e
         WL, H = self.WL, self.H
         row = self.NPB * 4
@@ -3138,16 +3130,8 @@ class GenQ6(GenQ4):
         e(f"v_add_u32 v{g.v_arow}, v{g.v_aread}, v{g.v_t1}")
         if off_d:
             e(f"v_add_u32 v{g.v_arow}, {off_d * row}, v{g.v_arow}")
-        e(f"ds_read_b32 v{g.v_ain}, v{g.v_arow}")
-        e("s_mov_b32 s19, 0")
-        e(".p2align 6")
-        e(f"L_q{tag}:")
-        self.row(g.v_ain, g.v_ai, row, link2, 0)
-        self.row(g.v_ai, g.v_ain, 2 * row, link2, 2 * row)
-        e("s_add_u32 s19, s19, 2")
-        e(f"s_cmp_lt_u32 s19, {H}")
-        e(f"s_cbranch_scc1 L_q{tag}")
-        e("s_waitcnt lgkmcnt(0)")
+        self.read_pair(g.v_pa, g.v_arow, 0)
+        self.row_loop(tag, link2, False)
 
     def carry_X2(self):
         """lazy limbs (sums of up to three canonical limbs) of the active lanes -> canonical again inside every slice; the lower

@@ -113,12 +113,13 @@ def test_asm_generator_model():
             assert g.lds_bytes * 2 <= 160 * 1024
             continue
         if (wl, k) in gen_vm_asm.TRIPLE2:
-            # three-digit kernel with two lanes per digit: two-row bodies of 2 WL multiplies per lane in every pass (squaring: one
+            # three-digit kernel with two lanes per digit: four-row bodies of 2 WL multiplies per lane in every pass (squaring: one
             # pass; product: two), both quotient links in the linked passes (row_shr:4, row_shl:2), one in pass two of a product
             for lbl, where, hops in (("L_qs", "L_montsq:", 2), ("L_qm1", "L_montmul:", 2), ("L_qm2", "L_montmul:", 1)):
                 body = text.split(where)[1].split(lbl + ":")[1].split("s_cbranch_scc1 " + lbl)[0]
-                assert body.count("v_mad_u64_u32") == 2 * 2 * wl
-                assert body.count("v_mad_i64_i32") == 2 * hops and body.count("s_nop") == 0
+                assert body.count("v_mad_u64_u32") == 4 * 2 * wl
+                assert body.count("v_mad_i64_i32") == 4 * hops and body.count("s_nop") == 0
+                assert len([l for l in body.splitlines() if l.strip() and not l.strip().startswith(".")]) - 8 * wl <= 4 * (7 + 3 * hops)
             assert g.H == 2 * wl and g.n_vgpr <= 256 and g.lds_bytes * 2 <= 160 * 1024
             continue
         if (wl, k) in gen_vm_asm.TRIPLE:
