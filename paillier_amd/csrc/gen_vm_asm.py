@@ -3281,10 +3281,12 @@ class GenQ3(Gen):
         assert self.lds_c + H * 32 < 65536                # LDS instruction offsets are 16 bits
         self.vX = 2 * H
         e = 3 * H
-        for nm in ["ai", "ain", "m", "t1", "sh", "l1mask", "l2mask", "l12mask", "l3mask"]:
+        for nm in ["m", "t1", "sh", "l1mask", "l2mask", "l3mask", "mask28"]:
             setattr(self, "v_" + nm, e)
             e += 1
         e = (e + 1) // 2 * 2
+        self.v_pa, self.v_pb = e, e + 2      # multiplier pairs: two rows are read at a time
+        e += 4
         self.v_y0 = e
         e += 2
         self.v_d = e          # pair (adjustment, 0)
@@ -3304,14 +3306,16 @@ class GenQ3(Gen):
         #   lane 0: a0 b0 | lane 1: a1 b0 + a0 b1 - m0 + C1 | lane 2: a2 b0 + a1 b1 - m1 + C2 | helper: a0 b2 (second stream: zeros)
         # One Montgomery reduction per digit, whose quotient digits go to the next digit as before: the same value modulo n^3
         # in H rows of 3H multiplies instead of two passes of H rows of 2H.  H = 74 has no registers for it.
-        self.merged = (e + H + 4 <= 256)
+        self.merged = (e + H + 6 <= 256)
         if self.merged:
+            self.v_pa2, self.v_pb2 = e, e + 2            # (e is even here)
+            e += 4
             self.vY = e
             e += H
-            self.v_ai2, self.v_ain2, self.v_arow2, self.v_bump2 = e, e + 1, e + 2, e + 3
-            e += 4
-            self.lds_z = self.lds_bytes                  # three rows of zeros: the second stream of lanes 0 and 3
-            self.lds_bytes += 1024
+            self.v_arow2, self.v_bump2 = e, e + 1
+            e += 2
+            self.lds_z = self.lds_bytes                  # 2 KB of zeros: the second stream of lanes 0 and 3 (a paired read
+            self.lds_bytes += 2048                       # reaches up to six rows past the pointer)
             assert self.lds_bytes < 65536
         self.n_vgpr = e
         assert e <= 256, e
@@ -3421,7 +3425,7 @@ class GenQ3(Gen):
             e(f"v_cmp_eq_u32 vcc, {lane}, v{g.v_t1}")
             e("s_nop 1")
             e(f"v_cndmask_b32 v{reg}, 0, -1, vcc")
-        e(f"v_or_b32 v{g.v_l12mask}, v{g.v_l1mask}, v{g.v_l2mask}")
+        e(f"v_mov_b32 v{g.v_mask28}, {hex(MASK)}")
         off, s, rem = 0, self.s_N, H
         while rem > 0:
             for cnt in (16, 8, 4, 2, 1):
@@ -3461,49 +3465,40 @@ class GenQ3(Gen):
             e(f"v_lshl_add_u32 v{g.v_t3}, v{g.v_t1}, 8, v{g.v_t3}")   # + (lane & 3) * 256
             e("v_mov_b32 v2, 0")
             e(f"ds_write_b32 v{g.v_t3}, v2 offset:{self.lds_z}")
+            e(f"ds_write_b32 v{g.v_t3}, v2 offset:{self.lds_z + 1024}")
         e("s_waitcnt lgkmcnt(0)")
         e("s_barrier")
         for j in range(H):
             e(f"v_mov_b32 {self.X(j)}, 0")
 
-    def row(self, cur, nxt, link2, use_sh, first=False, cur2=None, nxt2=None):
-        """one Montgomery row modulo n in every active lane.  Hop 1: lane 1 takes -m(lane 0) into column 0 (its C1 limb is
-        in the accumulator since the pass began); hop 2 (link2): lane 2 takes -m(lane 1).  first: row 0 of a pass (every
-        accumulator, the top one too, still holds its initial constant)"""
+    def row(self, a, link2, first=False, a2=None):
+        """one Montgomery row modulo n in every active lane on the multiplier a (a2: the second stream of a one-pass product).
+        Hop 1: lane 1 takes -m(lane 0) into column 0 (its C1 limb is in the accumulator since the pass began); hop 2 (link2):
+        lane 2 takes -m(lane 1).  first: row 0 of a pass (every accumulator, the top one too, still holds its initial constant).
+        Column 0 is complete after the FIRST multiply of pass A (only a * x_0 lands in it), so the quotient digit and the two
+        link hops (each a chain of dependent instructions: multiply, mask + DPP move in one instruction, signed multiply-add)
+        are started right away and their steps are spread between the remaining multiplies of pass A: no s_nop for the DPP
+        hazard, and at one wave per SIMD -- a 16 384-number batch -- nothing waits on a result that is still in flight."""
         g, e = self, self.e
         H = self.H
-        row = self.NPB * 4
         N = lambda j: f"s{g.s_N + j}"
         m = f"v{g.v_m}"
-        e("s_waitcnt lgkmcnt(0)")
-        e(f"ds_read_b32 v{nxt}, v{g.v_arow}")
-        e(f"v_add_u32 v{g.v_arow}, {row}, v{g.v_arow}")
-        if cur2 is not None:
-            e(f"ds_read_b32 v{nxt2}, v{g.v_arow2}")
-            e(f"v_add_u32 v{g.v_arow2}, v{g.v_bump2}, v{g.v_arow2}")
-        a = f"v{cur}"
-        if use_sh:
-            e(f"v_lshlrev_b32 v{cur}, v{g.v_sh}, v{cur}")
-        # Column 0 is complete after the FIRST multiply of pass A (only a * x_0 lands in it), so the quotient digit and the
-        # two link hops (each a chain of dependent instructions: multiply, mask, DPP move, signed multiply-add) are started
-        # right away and their steps are spread between the remaining multiplies of pass A: no s_nop for the DPP hazard, and
-        # at one wave per SIMD -- a 16 384-number batch -- nothing waits on a result that is still in flight.
-        chain = [f"v_mul_lo_u32 {m}, {self.Tlo(0)}, s14", f"v_and_b32 {m}, {hex(MASK)}, {m}"]
+        chain = [f"v_mul_lo_u32 {m}, {self.Tlo(0)}, s14"]
         for hop, mask in enumerate((g.v_l1mask, g.v_l2mask)):
             if hop == 1 and not link2:
                 break
-            chain += [f"v_mov_b32_dpp v{g.v_d}, {m} quad_perm:[0,0,1,2] row_mask:0xf bank_mask:0xf",
+            chain += [f"v_and_b32_dpp v{g.v_d}, {m}, v{g.v_mask28} quad_perm:[0,0,1,2] row_mask:0xf bank_mask:0xf",
                       f"v_mad_i64_i32 {self.T(0)}, vcc, v{g.v_d}, v{mask}, {self.T(0)}",     # T0 -= m of the lane below (mask: -1 / 0)
-                      f"v_mul_lo_u32 {m}, {self.Tlo(0)}, s14",
-                      f"v_and_b32 {m}, {hex(MASK)}, {m}"]
+                      f"v_mul_lo_u32 {m}, {self.Tlo(0)}, s14"]
+        chain.append(f"v_and_b32 {m}, {hex(MASK)}, {m}")
         addend = lambda j: "0" if (j == H - 1 and not first) else self.T(j)
         muls = []
         for j in range(H):
-            muls.append((self.T(j), a, self.X(j), addend(j)))
-            if cur2 is not None:
-                muls.append((self.T(j), f"v{cur2}", f"v{g.vY + j}", self.T(j)))
-        head = 1 if cur2 is None else 2                    # multiplies that complete column 0
-        gap = min(3, (len(muls) - head) // len(chain))     # multiplies between two steps of the chain (>= 2 covers the DPP hazard)
+            muls.append((self.T(j), f"v{a}", self.X(j), addend(j)))
+            if a2 is not None:
+                muls.append((self.T(j), f"v{a2}", f"v{g.vY + j}", self.T(j)))
+        head = 1 if a2 is None else 2                      # multiplies that complete column 0
+        gap = min(4, (len(muls) - head) // len(chain))     # multiplies between two steps of the chain (>= 2 covers the DPP hazard)
         assert gap >= 2, "pass A is too short to hide the link chain"
         self.align8()
         k = 0
@@ -3515,12 +3510,9 @@ class GenQ3(Gen):
                 self.mad(*muls[k])
                 k += 1
             e(step)
-            if step.startswith("v_mov_b32_dpp") or step.startswith("v_and"):
-                self.align8()
         while k < len(muls):
             self.mad(*muls[k])
             k += 1
-        self.align8()
         self.mad(self.P(g.v_y0), m, N(0), self.T(0))
         self.mad(self.T(0), m, N(1), self.T(1))
         e(f"v_lshrrev_b64 {self.P(g.v_c)}, {LB}, {self.P(g.v_y0)}")
@@ -3528,6 +3520,37 @@ class GenQ3(Gen):
             self.mad(self.T(j - 1), m, N(j), self.T(j))
             if j == 4:
                 e(f"v_lshl_add_u64 {self.T(0)}, {self.T(0)}, 0, {self.P(g.v_c)}")
+
+    def read_pair(self, dst, ptr, first_row):
+        """multipliers of rows first_row, first_row + 1 past the row pointer -> the register pair dst (rows are 256 bytes)"""
+        assert self.NPB * 4 == 256
+        self.e(f"ds_read2st64_b32 v[{dst}:{dst + 1}], v{ptr} offset0:{first_row} offset1:{first_row + 1}")
+
+    def row_pair(self, cur, nxt, link2, use_sh, ahead, bump, first=False, cur2=None, nxt2=None, loop=None):
+        """two rows on the multiplier pair(s) cur; the pair(s) `ahead` rows past the pointers are fetched into nxt; bump: rows the
+        pointers move on afterwards; loop: 'count' moves the loop counter here, (limit) compares it here -- the 4-byte scalar
+        instructions sit in pairs so that the multiply streams stay on 8-byte boundaries without padding (a padding s_nop is an
+        issue slot like any other at one wave per SIMD)."""
+        g, e = self, self.e
+        rowb = self.NPB * 4
+        e("s_waitcnt lgkmcnt(0)")
+        if loop == "count":
+            e("s_add_u32 s19, s19, 1")
+        elif loop is not None:
+            e(f"s_cmp_lt_u32 s19, {loop}")
+        else:
+            e("s_nop 0")
+        self.read_pair(nxt, g.v_arow, ahead)
+        if cur2 is not None:
+            self.read_pair(nxt2, g.v_arow2, ahead)
+        if bump:
+            e(f"v_add_u32 v{g.v_arow}, {bump * rowb}, v{g.v_arow}")
+            if cur2 is not None:
+                e(f"v_lshl_add_u32 v{g.v_arow2}, v{g.v_bump2}, {1 if bump == 2 else 2}, v{g.v_arow2}")
+        if use_sh:
+            e(f"v_lshlrev_b64 {self.P(cur)}, v{g.v_sh}, {self.P(cur)}")     # both multipliers at once: 28-bit limbs stay in their words
+        self.row(cur, link2, first, cur2)
+        self.row(cur + 1, link2, False, None if cur2 is None else cur2 + 1)
 
     def passes(self, tag, off012, off3, link2, use_sh, two_streams=False):
         """H rows: T <- (multiplier stream) * X * R^-1 with the quotient links.  off012 / off3: first row of the stream
@@ -3541,35 +3564,52 @@ class GenQ3(Gen):
         e(f"v_add_u32 v{g.v_arow}, v{g.v_aread}, v{g.v_t1}")
         if off012:
             e(f"v_add_u32 v{g.v_arow}, {off012 * row}, v{g.v_arow}")
-        e(f"ds_read_b32 v{g.v_ain}, v{g.v_arow}")
-        e(f"v_add_u32 v{g.v_arow}, {row}, v{g.v_arow}")
-        s2 = lambda c2, n2: dict(cur2=c2, nxt2=n2) if two_streams else {}
         if two_streams:
             # stream two: rows H.. of the a column (b1) in lanes 1, 2; the zero rows in lanes 0 and 3 (pointer not advanced)
+            e(f"v_or_b32 v{g.v_t2}, v{g.v_l1mask}, v{g.v_l2mask}")
             e(f"v_add_u32 v{g.v_arow2}, {H * row}, v{g.v_aread}")
             e(f"v_mov_b32 v{g.v_t1}, {self.lds_z}")
             e(f"v_xor_b32 v{g.v_t1}, v{g.v_t1}, v{g.v_arow2}")
-            e(f"v_and_b32 v{g.v_t1}, v{g.v_t1}, v{g.v_l12mask}")
+            e(f"v_and_b32 v{g.v_t1}, v{g.v_t1}, v{g.v_t2}")
             e(f"v_xor_b32 v{g.v_arow2}, {self.lds_z}, v{g.v_t1}")       # lanes 1, 2: aread + H rows; lanes 0, 3: lds_z
-            e(f"v_and_b32 v{g.v_bump2}, {row}, v{g.v_l12mask}")
-            e(f"ds_read_b32 v{g.v_ain2}, v{g.v_arow2}")
-            e(f"v_add_u32 v{g.v_arow2}, v{g.v_bump2}, v{g.v_arow2}")
-        self.row(g.v_ain, g.v_ai, link2, use_sh, first=True, **s2(g.v_ain2 if two_streams else None, g.v_ai2 if two_streams else None))
+            e(f"v_and_b32 v{g.v_bump2}, {row}, v{g.v_t2}")
+        s2 = lambda c2, n2: dict(cur2=c2, nxt2=n2) if two_streams else {}
+        A, B = (g.v_pa, getattr(g, "v_pa2", None)), (g.v_pb, getattr(g, "v_pb2", None))
+        rows = H
+        first = True
         if H % 2:
-            e("s_mov_b32 s19, 1")
-            ra, rb = g.v_ai, g.v_ain
-            ra2, rb2 = (g.v_ai2, g.v_ain2) if two_streams else (None, None)
+            # an odd row count: row 0 on its own (its multiplier goes to the second register of the idle pair)
+            e(f"ds_read_b32 v{B[0] + 1}, v{g.v_arow}")
+            if two_streams:
+                e(f"ds_read_b32 v{B[1] + 1}, v{g.v_arow2}")
+            e(f"v_add_u32 v{g.v_arow}, {row}, v{g.v_arow}")
+            if two_streams:
+                e(f"v_add_u32 v{g.v_arow2}, v{g.v_bump2}, v{g.v_arow2}")
+            self.read_pair(A[0], g.v_arow, 0)
+            if two_streams:
+                self.read_pair(A[1], g.v_arow2, 0)
+            e("s_waitcnt lgkmcnt(0)")
+            if use_sh:
+                e(f"v_lshlrev_b32 v{B[0] + 1}, v{g.v_sh}, v{B[0] + 1}")
+            self.row(B[0] + 1, link2, True, (B[1] + 1) if two_streams else None)
+            rows -= 1
+            first = False
         else:
-            self.row(g.v_ai, g.v_ain, link2, use_sh, **s2(g.v_ai2 if two_streams else None, g.v_ain2 if two_streams else None))
-            e("s_mov_b32 s19, 2")
-            ra, rb = g.v_ain, g.v_ai
-            ra2, rb2 = (g.v_ain2, g.v_ai2) if two_streams else (None, None)
+            self.read_pair(A[0], g.v_arow, 0)
+            if two_streams:
+                self.read_pair(A[1], g.v_arow2, 0)
+        pairs = rows // 2
+        while first or pairs % 2:
+            self.row_pair(A[0], B[0], link2, use_sh, 2, 2, first=first, **s2(A[1], B[1]))
+            A, B = B, A
+            pairs -= 1
+            first = False
+        assert pairs > 0 and pairs % 2 == 0
+        e("s_mov_b32 s19, 0")
         e(".p2align 6")
         e(f"L_q{tag}:")
-        self.row(ra, rb, link2, use_sh, **s2(ra2, rb2))
-        self.row(rb, ra, link2, use_sh, **s2(rb2, ra2))
-        e("s_add_u32 s19, s19, 2")
-        e(f"s_cmp_lt_u32 s19, {H}")
+        self.row_pair(A[0], B[0], link2, use_sh, 2, 0, loop="count", **s2(A[1], B[1]))
+        self.row_pair(B[0], A[0], link2, use_sh, 4, 4, loop=pairs // 2, **s2(B[1], A[1]))
         e(f"s_cbranch_scc1 L_q{tag}")
         e("s_waitcnt lgkmcnt(0)")
         e(f"v_mov_b64 {self.T(H - 1)}, 0")
@@ -3613,7 +3653,8 @@ class GenQ3(Gen):
         e("s_nop 1")
         for j in range(H):                                   # helper lane <- a1 (lanes 0..2 keep their own digit)
             e(f"v_mov_b32_dpp {self.X(j)}, {self.X(j)} quad_perm:[0,1,2,1] row_mask:0xf bank_mask:0xf")
-        e(f"v_and_b32 v{g.v_sh}, 1, v{g.v_l12mask}")          # lanes 1, 2 double the multiplier: 2 a0 a1, 2 a0 a2
+        e(f"v_or_b32 v{g.v_sh}, v{g.v_l1mask}, v{g.v_l2mask}")
+        e(f"v_and_b32 v{g.v_sh}, 1, v{g.v_sh}")              # lanes 1, 2 double the multiplier: 2 a0 a1, 2 a0 a2
         self.passes("s", 0, H, True, True)
         self.carry_T(to_x=True)
         # digit 2 += a1 a1 R^-1 (helper lane): one DPP addition per limb with only lanes 2, 3 enabled (the source lane of a

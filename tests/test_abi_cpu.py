@@ -123,7 +123,7 @@ def test_asm_generator_model():
             assert g.H == 2 * wl and g.n_vgpr <= 256 and g.lds_bytes * 2 <= 160 * 1024
             continue
         if (wl, k) in gen_vm_asm.TRIPLE:
-            # three-digit kernel: every pass is a loop of two single-lane rows of 2H multiplies (a squaring: one pass in four
+            # three-digit kernel: every pass is a loop of four single-lane rows of 2H multiplies (a squaring: one pass in four
             # lanes; a product: two passes, the second in two lanes); two quotient links per row in the linked passes
             # (H = 37, 55: the registers allow a copy of the digit below, and the product is ONE pass with two multiplier streams)
             loops = ((("L_qs", "L_montsq:", 2, 2), ("L_qm", "L_montmul:", 2, 3)) if g.merged else
@@ -131,8 +131,9 @@ def test_asm_generator_model():
             assert g.merged == (wl <= 55)
             for lbl, where, hops, streams in loops:
                 body = text.split(where)[1].split(lbl + ":")[1].split("s_cbranch_scc1 " + lbl)[0]
-                assert body.count("v_mad_u64_u32") == 2 * streams * wl
-                assert body.count("quad_perm:[0,0,1,2]") == 2 * hops
+                assert body.count("v_mad_u64_u32") == 4 * streams * wl
+                assert body.count("quad_perm:[0,0,1,2]") == 4 * hops and body.count("s_nop") == 0
+                assert len([l for l in body.splitlines() if l.strip() and not l.strip().startswith(".")]) - 4 * streams * wl <= 4 * 13
             assert g.lds_bytes * 2 <= 160 * 1024
             continue
         if (wl, k) in gen_vm_asm.PAIR2:
