@@ -2161,7 +2161,140 @@ class GenP2(GenP):
         return "\n".join(self.lines) + "\n"
 
 
-class GenQ(Gen):
+class LaneRows:
+    """Rows of the kernels whose lanes own whole digits (GenQ: two lanes of a number modulo n^2; GenQ3: a quad modulo n^3): the
+    single-lane Montgomery row modulo n with the modulus in SGPRs, the quotient links between the lanes interleaved with the
+    multiplies, multipliers read (and, in a squaring, doubled) two rows at a time, four-row loop bodies.  hops(link) of the
+    kernel: the (DPP control, lane mask register) of every link of a row."""
+
+    def row(self, a, link2, first=False, a2=None):
+        """one Montgomery row modulo n in every active lane on the multiplier a (a2: the second stream of a one-pass product).
+        Hop 1: lane 1 takes -m(lane 0) into column 0 (its C1 limb is in the accumulator since the pass began); hop 2 (link2):
+        lane 2 takes -m(lane 1).  first: row 0 of a pass (every accumulator, the top one too, still holds its initial constant).
+        Column 0 is complete after the FIRST multiply of pass A (only a * x_0 lands in it), so the quotient digit and the two
+        link hops (each a chain of dependent instructions: multiply, mask + DPP move in one instruction, signed multiply-add)
+        are started right away and their steps are spread between the remaining multiplies of pass A: no s_nop for the DPP
+        hazard, and at one wave per SIMD -- a 16 384-number batch -- nothing waits on a result that is still in flight."""
+        g, e = self, self.e
+        H = self.H
+        N = lambda j: f"s{g.s_N + j}"
+        m = f"v{g.v_m}"
+        chain = [f"v_mul_lo_u32 {m}, {self.Tlo(0)}, s14"]
+        for ctrl, mask in self.hops(link2):
+            chain += [f"v_and_b32_dpp v{g.v_d}, {m}, v{g.v_mask28} {ctrl} row_mask:0xf bank_mask:0xf",
+                      f"v_mad_i64_i32 {self.T(0)}, vcc, v{g.v_d}, v{mask}, {self.T(0)}",     # T0 -= m of the lane below (mask: -1 / 0)
+                      f"v_mul_lo_u32 {m}, {self.Tlo(0)}, s14"]
+        chain.append(f"v_and_b32 {m}, {hex(MASK)}, {m}")
+        addend = lambda j: "0" if (j == H - 1 and not first) else self.T(j)
+        muls = []
+        for j in range(H):
+            muls.append((self.T(j), f"v{a}", self.X(j), addend(j)))
+            if a2 is not None:
+                muls.append((self.T(j), f"v{a2}", f"v{g.vY + j}", self.T(j)))
+        head = 1 if a2 is None else 2                      # multiplies that complete column 0
+        gap = min(4, (len(muls) - head) // len(chain))     # multiplies between two steps of the chain (>= 2 covers the DPP hazard)
+        assert gap >= 2, "pass A is too short to hide the link chain"
+        self.align8()
+        k = 0
+        for _ in range(head):
+            self.mad(*muls[k])
+            k += 1
+        for step in chain:
+            for _ in range(gap):
+                self.mad(*muls[k])
+                k += 1
+            e(step)
+        while k < len(muls):
+            self.mad(*muls[k])
+            k += 1
+        self.mad(self.P(g.v_y0), m, N(0), self.T(0))
+        self.mad(self.T(0), m, N(1), self.T(1))
+        e(f"v_lshrrev_b64 {self.P(g.v_c)}, {LB}, {self.P(g.v_y0)}")
+        for j in range(2, H):
+            self.mad(self.T(j - 1), m, N(j), self.T(j))
+            if j == 4:
+                e(f"v_lshl_add_u64 {self.T(0)}, {self.T(0)}, 0, {self.P(g.v_c)}")
+
+    def read_pair(self, dst, ptr, first_row):
+        """multipliers of rows first_row, first_row + 1 past the row pointer -> the register pair dst"""
+        u = self.NPB * 4 // 256                            # a row in units of 64 dwords
+        assert u * 256 == self.NPB * 4 and (first_row + 1) * u <= 255
+        self.e(f"ds_read2st64_b32 v[{dst}:{dst + 1}], v{ptr} offset0:{first_row * u} offset1:{(first_row + 1) * u}")
+
+    def row_pair(self, cur, nxt, link2, use_sh, ahead, bump, first=False, cur2=None, nxt2=None, loop=None):
+        """two rows on the multiplier pair(s) cur; the pair(s) `ahead` rows past the pointers are fetched into nxt; bump: rows the
+        pointers move on afterwards; loop: 'count' moves the loop counter here, (limit) compares it here -- the 4-byte scalar
+        instructions sit in pairs so that the multiply streams stay on 8-byte boundaries without padding (a padding s_nop is an
+        issue slot like any other at one wave per SIMD)."""
+        g, e = self, self.e
+        rowb = self.NPB * 4
+        e("s_waitcnt lgkmcnt(0)")
+        if loop == "count":
+            e("s_add_u32 s19, s19, 1")
+        elif loop is not None:
+            e(f"s_cmp_lt_u32 s19, {loop}")
+        else:
+            e("s_nop 0")
+        self.read_pair(nxt, g.v_arow, ahead)
+        if cur2 is not None:
+            self.read_pair(nxt2, g.v_arow2, ahead)
+        if bump:
+            e(f"v_add_u32 v{g.v_arow}, {bump * rowb}, v{g.v_arow}")
+            if cur2 is not None:
+                e(f"v_lshl_add_u32 v{g.v_arow2}, v{g.v_bump2}, {1 if bump == 2 else 2}, v{g.v_arow2}")
+        if use_sh:
+            e(f"v_lshlrev_b64 {self.P(cur)}, v{g.v_sh}, {self.P(cur)}")     # both multipliers at once: 28-bit limbs stay in their words
+        self.row(cur, link2, first, cur2)
+        self.row(cur + 1, link2, False, None if cur2 is None else cur2 + 1)
+
+    def rows(self, tag, link2, use_sh, two_streams=False):
+        """the H rows of a pass: the accumulators hold their initial values, the row pointer(s) are at row 0 of the stream(s)"""
+        g, e = self, self.e
+        H = self.H
+        row = self.NPB * 4
+        s2 = lambda c2, n2: dict(cur2=c2, nxt2=n2) if two_streams else {}
+        A, B = (g.v_pa, getattr(g, "v_pa2", None)), (g.v_pb, getattr(g, "v_pb2", None))
+        rows = H
+        first = True
+        if H % 2:
+            # an odd row count: row 0 on its own (its multiplier goes to the second register of the idle pair)
+            e(f"ds_read_b32 v{B[0] + 1}, v{g.v_arow}")
+            if two_streams:
+                e(f"ds_read_b32 v{B[1] + 1}, v{g.v_arow2}")
+            e(f"v_add_u32 v{g.v_arow}, {row}, v{g.v_arow}")
+            if two_streams:
+                e(f"v_add_u32 v{g.v_arow2}, v{g.v_bump2}, v{g.v_arow2}")
+            self.read_pair(A[0], g.v_arow, 0)
+            if two_streams:
+                self.read_pair(A[1], g.v_arow2, 0)
+            e("s_waitcnt lgkmcnt(0)")
+            if use_sh:
+                e(f"v_lshlrev_b32 v{B[0] + 1}, v{g.v_sh}, v{B[0] + 1}")
+            self.row(B[0] + 1, link2, True, (B[1] + 1) if two_streams else None)
+            rows -= 1
+            first = False
+        else:
+            self.read_pair(A[0], g.v_arow, 0)
+            if two_streams:
+                self.read_pair(A[1], g.v_arow2, 0)
+        pairs = rows // 2
+        while first or pairs % 2:
+            self.row_pair(A[0], B[0], link2, use_sh, 2, 2, first=first, **s2(A[1], B[1]))
+            A, B = B, A
+            pairs -= 1
+            first = False
+        assert pairs > 0 and pairs % 2 == 0
+        e("s_mov_b32 s19, 0")
+        e(".p2align 6")
+        e(f"L_q{tag}:")
+        self.row_pair(A[0], B[0], link2, use_sh, 2, 0, loop="count", **s2(A[1], B[1]))
+        self.row_pair(B[0], A[0], link2, use_sh, 4, 4, loop=pairs // 2, **s2(B[1], A[1]))
+        e(f"s_cbranch_scc1 L_q{tag}")
+        e("s_waitcnt lgkmcnt(0)")
+        e(f"v_mov_b64 {self.T(H - 1)}, 0")
+
+
+class GenQ(LaneRows, Gen):
     """In-wave pair kernel for moduli N = n^2 with n PUBLIC (Encrypt, ConstMult, PartialDecrypt, proofs): the residue
     y R mod n^2 = a0 + a1 n (R = 2^(28 H), H = limbs of n) lives in two neighbouring lanes -- lane 0 holds a0, lane 1
     holds a1 -- and both lanes run the single-lane Montgomery row modulo n (n in SGPRs, the same for both lanes):
@@ -2188,10 +2321,12 @@ class GenQ(Gen):
         # VGPR map of the single-lane shape plus the lane link
         self.vX = 2 * H
         e = 3 * H
-        for nm in ["ai", "ain", "m", "t1", "sh", "l1mask"]:
+        for nm in ["m", "t1", "sh", "l1mask", "mask28"]:
             setattr(self, "v_" + nm, e)
             e += 1
         e = (e + 1) // 2 * 2
+        self.v_pa, self.v_pb = e, e + 2      # multiplier pairs: two rows are read at a time
+        e += 4
         self.v_y0 = e
         e += 2
         self.v_d = e          # pair (adjustment, 0)
@@ -2247,6 +2382,7 @@ class GenQ(Gen):
         e("s_nop 1")
         e(f"v_cndmask_b32 v{g.v_isfirst}, 0, -1, vcc")
         e(f"v_not_b32 v{g.v_l1mask}, v{g.v_isfirst}")
+        e(f"v_mov_b32 v{g.v_mask28}, {hex(MASK)}")
         off, s, rem = 0, self.s_N, H
         while rem > 0:
             for cnt in (16, 8, 4, 2, 1):
@@ -2282,85 +2418,25 @@ class GenQ(Gen):
         for j in range(H):
             e(f"v_mov_b32 {self.X(j)}, 0")
 
-    def row(self, cur, nxt, aoff, link, use_sh, first=False, bump=0):
-        """one Montgomery row modulo n in both lanes.  cur/nxt: multiplier registers (this row / prefetch at byte offset aoff of
-        the row pointer); link: lane 1 takes -m_i of lane 0 into column 0 (its Cadj limb has been in the accumulator since the
-        pass began); first: row 0 of a pass (the top accumulator still holds its initial value); bump: advance the row pointer.
-        Column 0 is complete after the FIRST multiply of pass A: the quotient digit and the link hop (a chain of dependent
-        instructions) are spread between the remaining multiplies -- no s_nop, no scalar load, nothing waits."""
-        g, e = self, self.e
-        H = self.H
-        N = lambda j: f"s{g.s_N + j}"
-        m = f"v{g.v_m}"
-        e("s_waitcnt lgkmcnt(0)")
-        e(f"ds_read_b32 v{nxt}, v{g.v_arow} offset:{aoff}")
-        if bump:
-            e(f"v_add_u32 v{g.v_arow}, {bump}, v{g.v_arow}")
-        a = f"v{cur}"
-        if use_sh:
-            e(f"v_lshlrev_b32 v{cur}, v{g.v_sh}, v{cur}")
-        chain = [f"v_mul_lo_u32 {m}, {self.Tlo(0)}, s14", f"v_and_b32 {m}, {hex(MASK)}, {m}"]
-        if link:
-            chain += [f"v_mov_b32_dpp v{g.v_d}, {m} quad_perm:[0,0,2,2] row_mask:0xf bank_mask:0xf",
-                      f"v_mad_i64_i32 {self.T(0)}, vcc, v{g.v_d}, v{g.v_l1mask}, {self.T(0)}",      # lane 1: T0 -= m of lane 0
-                      f"v_mul_lo_u32 {m}, {self.Tlo(0)}, s14",
-                      f"v_and_b32 {m}, {hex(MASK)}, {m}"]
-        gap = min(3, (H - 1) // len(chain))
-        assert gap >= 2
-        addend = lambda j: "0" if (j == H - 1 and not first) else self.T(j)
-        self.align8()
-        self.mad(self.T(0), a, self.X(0), addend(0))
-        j = 1
-        for step in chain:
-            for _ in range(gap):
-                self.mad(self.T(j), a, self.X(j), addend(j))
-                j += 1
-            e(step)
-            if step.startswith("v_mov_b32_dpp") or step.startswith("v_and"):
-                self.align8()
-        while j < H:
-            self.mad(self.T(j), a, self.X(j), addend(j))
-            j += 1
-        self.align8()
-        self.mad(self.P(g.v_y0), m, N(0), self.T(0))
-        self.mad(self.T(0), m, N(1), self.T(1))
-        e(f"v_lshrrev_b64 {self.P(g.v_c)}, {LB}, {self.P(g.v_y0)}")
-        for j in range(2, H):
-            self.mad(self.T(j - 1), m, N(j), self.T(j))
-            if j == 4:
-                e(f"v_lshl_add_u64 {self.T(0)}, {self.T(0)}, 0, {self.P(g.v_c)}")
+    def hops(self, link):
+        return [("quad_perm:[0,0,2,2]", self.v_l1mask)] if link else []     # lane 1: T0 -= m of lane 0
 
     def passes(self, tag, aoff, link, use_sh):
-        """H rows: T <- (multiplier stream at aoff) * X * R^-1 (+ the lane link)"""
+        """H rows: T <- (multiplier stream at byte offset aoff of the a column) * X * R^-1 (+ the lane link: lane 1 takes -m_i of
+        lane 0 into column 0 of row i; its Cadj limb has been in the accumulator since the pass began)"""
         g, e = self, self.e
         H = self.H
-        row = self.NPB * 4
         if link:
             for j in range(H):                                   # accumulators <- (0 | Cadj_j) by lane
                 e(f"ds_read_b64 {self.T(j)}, v{g.v_caddr} offset:{self.lds_c + 16 * j}")
         else:
             for j in range(H):
                 e(f"v_mov_b64 {self.T(j)}, 0")
-        e(f"v_mov_b32 v{g.v_arow}, v{g.v_aread}")
-        e(f"ds_read_b32 v{g.v_ain}, v{g.v_arow} offset:{aoff}")
-        # row 0 peeled (every accumulator still holds its initial value); an even number of rows must remain for the loop
-        self.row(g.v_ain, g.v_ai, aoff + row, link, use_sh, first=True, bump=(row if H % 2 else 0))
-        if H % 2:
-            e("s_mov_b32 s19, 1")
-            ra, rb, o = g.v_ai, g.v_ain, 0
+        if aoff:
+            e(f"v_add_u32 v{g.v_arow}, {aoff}, v{g.v_aread}")
         else:
-            self.row(g.v_ai, g.v_ain, aoff + 2 * row, link, use_sh, bump=2 * row)
-            e("s_mov_b32 s19, 2")
-            ra, rb, o = g.v_ain, g.v_ai, 0
-        e(".p2align 6")
-        e(f"L_q{tag}:")
-        self.row(ra, rb, aoff + o + row, link, use_sh)
-        self.row(rb, ra, aoff + o + 2 * row, link, use_sh, bump=2 * row)
-        e("s_add_u32 s19, s19, 2")
-        e(f"s_cmp_lt_u32 s19, {H}")
-        e(f"s_cbranch_scc1 L_q{tag}")
-        e("s_waitcnt lgkmcnt(0)")
-        e(f"v_mov_b64 {self.T(H - 1)}, 0")
+            e(f"v_mov_b32 v{g.v_arow}, v{g.v_aread}")
+        self.rows(tag, link, use_sh)
 
     def normalize_to(self, dest):
         """sequential carry (every lane owns a whole H-limb digit); dest(j, reg_lo) emits the store of limb j"""
@@ -3238,7 +3314,7 @@ class GenQ6(GenQ4):
         return "\n".join(self.lines) + "\n"
 
 
-class GenQ3(Gen):
+class GenQ3(LaneRows, Gen):
     """Three-digit kernel for moduli N = n^3 with n PUBLIC (level-two Encrypt / ConstMult / NestedRandomize, the DDLEQ
     equations): the residue y R mod n^3 = a0 + a1 n + a2 n^2 (R = 2^(28 H), H = limbs of n, digits lazily reduced mod n)
     lives in the lanes of a quad -- lane d holds digit a_d, lane 3 is a helper -- and all four lanes run the single-lane
@@ -3322,6 +3398,9 @@ class GenQ3(Gen):
         self.s_coff = 99
         self.number_major_tables = True
         self.npad = (H + 1) // 2 * 2    # n occupies an even number of words so that the pairs are 8-byte aligned
+
+    def hops(self, link2):
+        return [("quad_perm:[0,0,1,2]", self.v_l1mask)] + ([("quad_perm:[0,0,1,2]", self.v_l2mask)] if link2 else [])
 
     def wide_chunks(self):
         """(first limb, dwords) pieces covering the H limbs of a digit with the widest loads / stores"""
@@ -3471,87 +3550,6 @@ class GenQ3(Gen):
         for j in range(H):
             e(f"v_mov_b32 {self.X(j)}, 0")
 
-    def row(self, a, link2, first=False, a2=None):
-        """one Montgomery row modulo n in every active lane on the multiplier a (a2: the second stream of a one-pass product).
-        Hop 1: lane 1 takes -m(lane 0) into column 0 (its C1 limb is in the accumulator since the pass began); hop 2 (link2):
-        lane 2 takes -m(lane 1).  first: row 0 of a pass (every accumulator, the top one too, still holds its initial constant).
-        Column 0 is complete after the FIRST multiply of pass A (only a * x_0 lands in it), so the quotient digit and the two
-        link hops (each a chain of dependent instructions: multiply, mask + DPP move in one instruction, signed multiply-add)
-        are started right away and their steps are spread between the remaining multiplies of pass A: no s_nop for the DPP
-        hazard, and at one wave per SIMD -- a 16 384-number batch -- nothing waits on a result that is still in flight."""
-        g, e = self, self.e
-        H = self.H
-        N = lambda j: f"s{g.s_N + j}"
-        m = f"v{g.v_m}"
-        chain = [f"v_mul_lo_u32 {m}, {self.Tlo(0)}, s14"]
-        for hop, mask in enumerate((g.v_l1mask, g.v_l2mask)):
-            if hop == 1 and not link2:
-                break
-            chain += [f"v_and_b32_dpp v{g.v_d}, {m}, v{g.v_mask28} quad_perm:[0,0,1,2] row_mask:0xf bank_mask:0xf",
-                      f"v_mad_i64_i32 {self.T(0)}, vcc, v{g.v_d}, v{mask}, {self.T(0)}",     # T0 -= m of the lane below (mask: -1 / 0)
-                      f"v_mul_lo_u32 {m}, {self.Tlo(0)}, s14"]
-        chain.append(f"v_and_b32 {m}, {hex(MASK)}, {m}")
-        addend = lambda j: "0" if (j == H - 1 and not first) else self.T(j)
-        muls = []
-        for j in range(H):
-            muls.append((self.T(j), f"v{a}", self.X(j), addend(j)))
-            if a2 is not None:
-                muls.append((self.T(j), f"v{a2}", f"v{g.vY + j}", self.T(j)))
-        head = 1 if a2 is None else 2                      # multiplies that complete column 0
-        gap = min(4, (len(muls) - head) // len(chain))     # multiplies between two steps of the chain (>= 2 covers the DPP hazard)
-        assert gap >= 2, "pass A is too short to hide the link chain"
-        self.align8()
-        k = 0
-        for _ in range(head):
-            self.mad(*muls[k])
-            k += 1
-        for step in chain:
-            for _ in range(gap):
-                self.mad(*muls[k])
-                k += 1
-            e(step)
-        while k < len(muls):
-            self.mad(*muls[k])
-            k += 1
-        self.mad(self.P(g.v_y0), m, N(0), self.T(0))
-        self.mad(self.T(0), m, N(1), self.T(1))
-        e(f"v_lshrrev_b64 {self.P(g.v_c)}, {LB}, {self.P(g.v_y0)}")
-        for j in range(2, H):
-            self.mad(self.T(j - 1), m, N(j), self.T(j))
-            if j == 4:
-                e(f"v_lshl_add_u64 {self.T(0)}, {self.T(0)}, 0, {self.P(g.v_c)}")
-
-    def read_pair(self, dst, ptr, first_row):
-        """multipliers of rows first_row, first_row + 1 past the row pointer -> the register pair dst (rows are 256 bytes)"""
-        assert self.NPB * 4 == 256
-        self.e(f"ds_read2st64_b32 v[{dst}:{dst + 1}], v{ptr} offset0:{first_row} offset1:{first_row + 1}")
-
-    def row_pair(self, cur, nxt, link2, use_sh, ahead, bump, first=False, cur2=None, nxt2=None, loop=None):
-        """two rows on the multiplier pair(s) cur; the pair(s) `ahead` rows past the pointers are fetched into nxt; bump: rows the
-        pointers move on afterwards; loop: 'count' moves the loop counter here, (limit) compares it here -- the 4-byte scalar
-        instructions sit in pairs so that the multiply streams stay on 8-byte boundaries without padding (a padding s_nop is an
-        issue slot like any other at one wave per SIMD)."""
-        g, e = self, self.e
-        rowb = self.NPB * 4
-        e("s_waitcnt lgkmcnt(0)")
-        if loop == "count":
-            e("s_add_u32 s19, s19, 1")
-        elif loop is not None:
-            e(f"s_cmp_lt_u32 s19, {loop}")
-        else:
-            e("s_nop 0")
-        self.read_pair(nxt, g.v_arow, ahead)
-        if cur2 is not None:
-            self.read_pair(nxt2, g.v_arow2, ahead)
-        if bump:
-            e(f"v_add_u32 v{g.v_arow}, {bump * rowb}, v{g.v_arow}")
-            if cur2 is not None:
-                e(f"v_lshl_add_u32 v{g.v_arow2}, v{g.v_bump2}, {1 if bump == 2 else 2}, v{g.v_arow2}")
-        if use_sh:
-            e(f"v_lshlrev_b64 {self.P(cur)}, v{g.v_sh}, {self.P(cur)}")     # both multipliers at once: 28-bit limbs stay in their words
-        self.row(cur, link2, first, cur2)
-        self.row(cur + 1, link2, False, None if cur2 is None else cur2 + 1)
-
     def passes(self, tag, off012, off3, link2, use_sh, two_streams=False):
         """H rows: T <- (multiplier stream) * X * R^-1 with the quotient links.  off012 / off3: first row of the stream
         read by the digit lanes / by the helper lane."""
@@ -3573,46 +3571,7 @@ class GenQ3(Gen):
             e(f"v_and_b32 v{g.v_t1}, v{g.v_t1}, v{g.v_t2}")
             e(f"v_xor_b32 v{g.v_arow2}, {self.lds_z}, v{g.v_t1}")       # lanes 1, 2: aread + H rows; lanes 0, 3: lds_z
             e(f"v_and_b32 v{g.v_bump2}, {row}, v{g.v_t2}")
-        s2 = lambda c2, n2: dict(cur2=c2, nxt2=n2) if two_streams else {}
-        A, B = (g.v_pa, getattr(g, "v_pa2", None)), (g.v_pb, getattr(g, "v_pb2", None))
-        rows = H
-        first = True
-        if H % 2:
-            # an odd row count: row 0 on its own (its multiplier goes to the second register of the idle pair)
-            e(f"ds_read_b32 v{B[0] + 1}, v{g.v_arow}")
-            if two_streams:
-                e(f"ds_read_b32 v{B[1] + 1}, v{g.v_arow2}")
-            e(f"v_add_u32 v{g.v_arow}, {row}, v{g.v_arow}")
-            if two_streams:
-                e(f"v_add_u32 v{g.v_arow2}, v{g.v_bump2}, v{g.v_arow2}")
-            self.read_pair(A[0], g.v_arow, 0)
-            if two_streams:
-                self.read_pair(A[1], g.v_arow2, 0)
-            e("s_waitcnt lgkmcnt(0)")
-            if use_sh:
-                e(f"v_lshlrev_b32 v{B[0] + 1}, v{g.v_sh}, v{B[0] + 1}")
-            self.row(B[0] + 1, link2, True, (B[1] + 1) if two_streams else None)
-            rows -= 1
-            first = False
-        else:
-            self.read_pair(A[0], g.v_arow, 0)
-            if two_streams:
-                self.read_pair(A[1], g.v_arow2, 0)
-        pairs = rows // 2
-        while first or pairs % 2:
-            self.row_pair(A[0], B[0], link2, use_sh, 2, 2, first=first, **s2(A[1], B[1]))
-            A, B = B, A
-            pairs -= 1
-            first = False
-        assert pairs > 0 and pairs % 2 == 0
-        e("s_mov_b32 s19, 0")
-        e(".p2align 6")
-        e(f"L_q{tag}:")
-        self.row_pair(A[0], B[0], link2, use_sh, 2, 0, loop="count", **s2(A[1], B[1]))
-        self.row_pair(B[0], A[0], link2, use_sh, 4, 4, loop=pairs // 2, **s2(B[1], A[1]))
-        e(f"s_cbranch_scc1 L_q{tag}")
-        e("s_waitcnt lgkmcnt(0)")
-        e(f"v_mov_b64 {self.T(H - 1)}, 0")
+        self.rows(tag, link2, use_sh, two_streams)
 
     def carry_T(self, to_x=False):
         """sequential carry through the accumulators: canonical limb j ends up in Tlo(j) (to_x: in X(j), the multiplicand

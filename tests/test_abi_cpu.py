@@ -137,12 +137,13 @@ def test_asm_generator_model():
             assert g.lds_bytes * 2 <= 160 * 1024
             continue
         if (wl, k) in gen_vm_asm.PAIR2:
-            # two-lane pair kernel: every pass is a loop of two single-lane rows of 2H multiplies; a squaring has one pass,
+            # two-lane pair kernel: every pass is a loop of four single-lane rows of 2H multiplies; a squaring has one pass,
             # a product two
             for lbl, where in (("L_qs", "L_montsq:"), ("L_qm1", "L_montmul:"), ("L_qm2", "L_montmul:")):
                 body = text.split(where)[1].split(lbl + ":")[1].split("s_cbranch_scc1 " + lbl)[0]
-                assert body.count("v_mad_u64_u32") == 2 * 2 * wl
+                assert body.count("v_mad_u64_u32") == 4 * 2 * wl
                 assert body.count("s_nop") == 0 and body.count("s_load_dword") == 0      # Cadj enters once per pass, not per row
+                assert len([l for l in body.splitlines() if l.strip() and not l.strip().startswith(".")]) - 8 * wl <= 4 * 10
             assert g.lds_bytes * 2 <= 160 * 1024
             continue
         if (wl, k) in gen_vm_asm.WAVE_SLICED:
