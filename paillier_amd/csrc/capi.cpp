@@ -88,6 +88,7 @@ struct pgpu_ctx {
   size_t lanes_wanted = 0;   // 0: default occupancy target; tests set 1 to run every modulus at its natural shape
   // A second stream for work of a call that depends on no ladder in flight (SideStream below; the DDLEQ prover's
   // per-statement chains run beside its big launches).  pgpu_ctx_set_flag("side", 0): everything on the one stream.
+  bool use_nm4 = true;       // per-number 4-bit window tables of the one-lane pair kernel number-major (pgpu_ctx_set_flag("nm4", 0): limb-major, VM_MULV)
   bool use_muls = true;      // bucket products of the shared chain as VM_MULS where the kernel has it (pgpu_ctx_set_flag("muls", 0): LOAD / MUL / STORE)
   bool use_lanes8 = true;    // shards too small for four lanes per number take the eight-lane pair kernel (pgpu_ctx_set_flag("lanes8", 0): never)
   bool use_side = true;
@@ -356,20 +357,24 @@ struct Prog {
   bool wide_gathers = false;  // table opcodes other than the 4-bit VM_MULV
   bool nm_tables = false;     // VM_MULV7 / VM_STORET: among the assembly kernels only the three-digit ones implement them
   bool needs_muls = false;    // VM_MULS: the four- and eight-lane pair kernels only
+  bool nm4 = false;           // VM_MULVT (with VM_STORET): the one-lane pair kernel for 37-limb primes only
+  bool mulv7 = false;
   uint32_t gather_slots = 1;  // slots a per-number gather spans (table entries + 1): its offsets are 32-bit in the assembly kernels
   void op(uint32_t o, uint32_t arg = 0, uint32_t aux = 0) {
     if (o == VM_SETOFF) asm_ok = false;
-    if (o == VM_MULV7 || o == VM_STORET) nm_tables = true;
+    if (o == VM_MULV7 || o == VM_STORET || o == VM_MULVT) nm_tables = true;
+    if (o == VM_MULVT) nm4 = true;
+    if (o == VM_MULV7) mulv7 = true;
     if (o == VM_MULS) needs_muls = true;
-    if (o == VM_MULCV || o == VM_MULV5 || o == VM_MULV7 || o == VM_STORET) wide_gathers = true;   // (kernels without these opcodes must not get the program)
-    if (o == VM_MULV || o == VM_MULV5 || o == VM_MULV7) {
+    if (o == VM_MULCV || o == VM_MULV5 || o == VM_MULV7 || o == VM_STORET || o == VM_MULVT) wide_gathers = true;   // (kernels without these opcodes must not get the program)
+    if (o == VM_MULV || o == VM_MULV5 || o == VM_MULV7 || o == VM_MULVT) {
       has_mulv = true;
-      gather_slots = std::max<uint32_t>(gather_slots, o == VM_MULV ? 17u : o == VM_MULV5 ? 33u : 129u);
+      gather_slots = std::max<uint32_t>(gather_slots, o == VM_MULV ? 17u : o == VM_MULVT ? 18u : o == VM_MULV5 ? 33u : 129u);
     }
     if (aux >> 22) api_throw(PGPU_ERR_INVALID, "internal: table slot does not fit the instruction word");
     w.push_back(o | (aux << 8));
     w.push_back(arg);
-    if (o == VM_SQR || o == VM_MUL || o == VM_MULC || o == VM_MULV || o == VM_MULCV || o == VM_MULV5 || o == VM_MULV7 || o == VM_MULS) montmuls += 1;
+    if (o == VM_SQR || o == VM_MUL || o == VM_MULC || o == VM_MULV || o == VM_MULCV || o == VM_MULV5 || o == VM_MULV7 || o == VM_MULS || o == VM_MULVT) montmuls += 1;
     if (o == VM_SQR) sqrs += 1;
   }
   // Bits 30..31 of an instruction word: the priority the wave takes when it gets there -- 3, 2, 1, 0 over four stretches of a
@@ -387,7 +392,7 @@ struct Prog {
       const double f = done / montmuls;
       const uint32_t quarter = f < 0.80 ? 0u : f < 0.96 ? 1u : f < 0.992 ? 2u : 3u;
       w[i] = (w[i] & 0x3FFFFFFFu) | ((3u - quarter) << 30);
-      if (o == VM_SQR || o == VM_MUL || o == VM_MULC || o == VM_MULV || o == VM_MULCV || o == VM_MULV5 || o == VM_MULV7 || o == VM_MULS) done += 1;
+      if (o == VM_SQR || o == VM_MUL || o == VM_MULC || o == VM_MULV || o == VM_MULCV || o == VM_MULV5 || o == VM_MULV7 || o == VM_MULS || o == VM_MULVT) done += 1;
     }
   }
 };
@@ -496,13 +501,25 @@ void emit_modexp_shared(Prog& p, const BigU& e, uint32_t in_lo, uint32_t in_hi, 
 // The wide windows pay where a product costs two squarings (the digit kernels): a 4 096-bit exponent takes 586 products
 // and a 63 + 63 table at 7 bits, 820 + 30 at 5, 1 024 + 14 at 4.
 static int perlane_windows(int we, int wb) { return wb == 4 ? we * 7 : wb == 5 ? (we * LB + 4) / 5 : we * 4; }
-static VmOp perlane_op(int wb) { return wb == 4 ? VM_MULV : wb == 5 ? VM_MULV5 : VM_MULV7; }
+static VmOp perlane_op(int wb, bool nm4 = false) { return wb == 4 ? (nm4 ? VM_MULVT : VM_MULV) : wb == 5 ? VM_MULV5 : VM_MULV7; }
 // table of x^0 .. x^(2^wb - 1) from x in the accumulator; the wide tables square for their even entries (a squaring
 // is half a product on the digit kernels).  The 7-bit table is gathered per number, so its 128 slots are number-major
 // (VM_STORET / VM_MULV7); the entries the build itself reads back (x and the ones that get squared) are kept limb-major as
 // well, in the 64 slots after the table.
 static int perlane_table_slots(int wb) { return wb == 7 ? 128 + 64 : 1 << wb; }
-static void emit_power_table(Prog& p, uint32_t tab, uint32_t one, int wb) {
+// nm4 (4-bit windows on the one-lane pair kernel): the 16 entries NUMBER-major (VM_STORET, gathered by VM_MULVT) and x once more
+// limb-major in slot tab + 16 -- the operand of the products that build the table.
+static void emit_power_table(Prog& p, uint32_t tab, uint32_t one, int wb, bool nm4 = false) {
+  if (wb == 4 && nm4) {
+    const uint32_t scr = tab + 16;
+    p.op(VM_STORET, tab + 1);
+    p.op(VM_STORE, scr);
+    p.op(VM_LOADC, one);
+    p.op(VM_STORET, tab + 0);
+    p.op(VM_LOAD, scr);
+    for (uint32_t k = 2; k < 16; ++k) { p.op(VM_MUL, scr); p.op(VM_STORET, tab + k); }
+    return;
+  }
   if (wb == 7) {
     const uint32_t scr = tab + 128;
     p.op(VM_STORET, tab + 1);
@@ -598,11 +615,11 @@ struct SharedBase { BigU e; uint32_t in; uint32_t tab; };
 struct PerNumberBase { int we; uint32_t in; uint32_t tab; uint32_t first_window; };   // windows first_window.. of the `digits` rows
 static int shared_window_bits(const BigU& e, int wb) { return e.bit_length() < 1500 ? 6 : dual_sliding_bits(wb); }
 void emit_modexp_multi(Prog& p, const std::vector<PerNumberBase>& pn, int wb, const std::vector<SharedBase>& sh, uint32_t tmp,
-                       uint32_t out, uint32_t one) {
+                       uint32_t out, uint32_t one, bool nm4 = false) {
   long nbits = 0;
   for (auto& b : pn) {
     p.op(VM_LOAD, b.in);
-    emit_power_table(p, b.tab, one, wb);
+    emit_power_table(p, b.tab, one, wb, nm4);
     nbits = std::max<long>(nbits, (long)b.we * LB);
   }
   std::vector<std::vector<int>> mul_at(sh.size());
@@ -636,7 +653,7 @@ void emit_modexp_multi(Prog& p, const std::vector<PerNumberBase>& pn, int wb, co
   for (long b = nbits - 1; b >= 0; --b) {
     if (b != nbits - 1) p.op(VM_SQR);
     for (auto& q : pn)
-      if (b % wb == 0 && b / wb < perlane_windows(q.we, wb)) p.op(perlane_op(wb), (uint32_t)(b / wb) + q.first_window, q.tab);
+      if (b % wb == 0 && b / wb < perlane_windows(q.we, wb)) p.op(perlane_op(wb, nm4), (uint32_t)(b / wb) + q.first_window, q.tab);
     for (size_t k = 0; k < sh.size(); ++k)
       if (mul_at[k][(size_t)b] >= 0) p.op(VM_MUL, sh[k].tab + (uint32_t)mul_at[k][(size_t)b]);
   }
@@ -799,8 +816,11 @@ void run_vm(pgpu_ctx* ctx, size_t nb, const SegSpec& s0, const SegSpec* s1, bool
   a.seg1_blocks = blocks_per_seg;
   const uint32_t blocks = blocks_per_seg * (s2 ? 3 : s1 ? 2 : 1);
   const bool nm_tables = s0.prog->nm_tables || (s1 && s1->prog->nm_tables) || (s2 && s2->prog->nm_tables);
+  const bool nm4 = s0.prog->nm4 || (s1 && s1->prog->nm4) || (s2 && s2->prog->nm4);
+  const bool mulv7 = s0.prog->mulv7 || (s1 && s1->prog->mulv7) || (s2 && s2->prog->mulv7);
+  if (nm4 && mulv7) api_throw(PGPU_ERR_UNSUPPORTED, "internal: 4-bit and 7-bit number-major tables in one launch");
   const bool use_asm = ctx->use_asm && vm_asm_available(WL, K) && s0.prog->asm_ok && (!s1 || s1->prog->asm_ok) &&
-                       (!s2 || s2->prog->asm_ok) && (!nm_tables || (pair && s0.pair_lanes == 3)) &&
+                       (!s2 || s2->prog->asm_ok) && (!nm_tables || (pair && (mulv7 ? s0.pair_lanes == 3 : nm4 ? (s0.pair_lanes == 1 && s0.pair_h == 37) : (s0.pair_lanes == 3 || (s0.pair_lanes == 1 && s0.pair_h == 37))))) &&
                        (uint64_t)nb * ((s0.pair_lanes == 3 || s0.pair_lanes == 6) ? 3 * s0.pair_h : mc->WT) * 4 *
                                std::max(s0.prog->gather_slots, std::max(s1 ? s1->prog->gather_slots : 1u, s2 ? s2->prog->gather_slots : 1u)) < (1ull << 32);
   pgpu_ctx::Ev* ev = nullptr;
@@ -1146,6 +1166,7 @@ int pgpu_ctx_set_flag(pgpu_ctx* ctx, const char* name, int value) {
   if (strcmp(name, "side") == 0) { ctx->use_side = value != 0; return PGPU_OK; }
   if (strcmp(name, "lanes8") == 0) { ctx->use_lanes8 = value != 0; return PGPU_OK; }
   if (strcmp(name, "muls") == 0) { ctx->use_muls = value != 0; return PGPU_OK; }
+  if (strcmp(name, "nm4") == 0) { ctx->use_nm4 = value != 0; return PGPU_OK; }
   if (strcmp(name, "fair") == 0) { g_wave_priorities.store(value != 0, std::memory_order_relaxed); return PGPU_OK; }   // process-wide (see above)
   if (strcmp(name, "lanes_wanted") == 0) { ctx->lanes_wanted = value > 0 ? (size_t)value : 0; return PGPU_OK; }
   if (strcmp(name, "cu_partition") == 0) {
@@ -4064,8 +4085,11 @@ bool pow_p2_multi_crt(const pgpu_seckey* sk, const uint32_t* const xs[2], const 
   const int H = sk->mp.WT, W2 = sk->mp2.WT;
   const size_t S1 = (size_t)H * nb, S2 = (size_t)W2 * nb;
   const int wb = 4;                                           // per-number windows: VM_MULV
-  if ((uint64_t)nb * W2 * 4 * 17 >= (1ull << 32)) return false;
-  const uint32_t TAB1 = 5, TAB2 = TAB1 + (1u << wb);
+  if ((uint64_t)nb * W2 * 4 * 18 >= (1ull << 32)) return false;
+  // per-number window tables number-major where the kernel has VM_STORET / VM_MULVT (one lane per number, 37-limb primes): a
+  // gather then reads 296 contiguous bytes per lane instead of 74 dwords in 74 different sectors
+  const bool nm4 = ctx->use_nm4 && lanes == 1 && H == 37;
+  const uint32_t TAB1 = 5, TAB2 = TAB1 + (1u << wb) + (nm4 ? 1u : 0u);
   if (xs_b && (ys || !r1 || !r1_b)) return false;
   uint32_t* mem[2];
   Prog pr[2];
@@ -4075,7 +4099,7 @@ bool pow_p2_multi_crt(const pgpu_seckey* sk, const uint32_t* const xs[2], const 
   uint32_t* tb = ctx->ws_t<uint32_t>(S2);
   for (int half = 0; half < 2; ++half) {
     const ModCtx &m1 = half ? sk->mq : sk->mp, &m2 = half ? sk->mq2 : sk->mp2;
-    mem[half] = ctx->ws_t<uint32_t>(S2 * (size_t)(TAB2 + 64));      // 0 x, 1 y, 2 tmp, 3 out, 5.. / TAB2.. the tables
+    mem[half] = ctx->ws_t<uint32_t>(S2 * (size_t)(TAB2 + 64));      // 0 x, 1 y, 2 tmp, 3 out, 5.. / TAB2.. the tables (+ 1 each: x limb-major)
     for (int k = 0; k < ((ys || xs_b) ? 2 : 1); ++k) {
       // pair-form entry: X = v R_H mod prime^2, then its digits X0 + X1 prime
       HIPCHK(hipMemcpyAsync(ent, k ? (ys ? ys[half] : xs_b[half]) : xs[half], S2 * 4, hipMemcpyDeviceToDevice, ctx->stream));
@@ -4102,7 +4126,7 @@ bool pow_p2_multi_crt(const pgpu_seckey* sk, const uint32_t* const xs[2], const 
       HIPCHK(hipMemcpyAsync(d2 + (size_t)we * nb, r1_b[half], (size_t)we * nb * 4, hipMemcpyDeviceToDevice, ctx->stream));
       dig[half] = d2;
     }
-    emit_modexp_multi(pr[half], pn, wb, sh, 2, 3, (uint32_t)(half ? sk->c_onep_q2 : sk->c_onep_p2));
+    emit_modexp_multi(pr[half], pn, wb, sh, 2, 3, (uint32_t)(half ? sk->c_onep_q2 : sk->c_onep_p2), nm4);
     pr[half].end();
   }
   {

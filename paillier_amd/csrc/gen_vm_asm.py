@@ -32,7 +32,8 @@ import sys
 LB = 28
 MASK = (1 << LB) - 1
 BLOCK = 256
-OPS = dict(END=0, LOAD=1, STORE=2, LOADC=3, SQR=4, MUL=5, MULC=6, MULV=7, ADD=8, SETOFF=9, MULCV=10, MULV5=11, MULV7=12, STORET=13, MULS=14)
+OPS = dict(END=0, LOAD=1, STORE=2, LOADC=3, SQR=4, MUL=5, MULC=6, MULV=7, ADD=8, SETOFF=9, MULCV=10, MULV5=11, MULV7=12, STORET=13, MULS=14,
+           MULVT=15)
 
 
 class Gen:
@@ -393,8 +394,10 @@ class Gen:
         e("s_and_b32 s18, s16, 0xff")
         # MULV7 / STORET (number-major tables) exist on the three-digit kernels only; the host emits them nowhere else
         nm_tables = ("MULV7", "STORET") if getattr(self, "number_major_tables", False) else ()
+        # MULVT / STORET (number-major tables with 4-bit windows): the one-lane pair kernel for 37-limb primes
+        nm4 = ("MULVT", "STORET") if getattr(self, "nm4_tables", False) else ()
         muls = ("MULS",) if getattr(self, "has_muls", False) else ()
-        for nm in ("SQR", "MUL", "MULC", "MULV", "MULV5") + nm_tables + muls + ("MULCV", "LOAD", "STORE", "LOADC", "ADD"):
+        for nm in ("SQR", "MUL", "MULC", "MULV", "MULV5") + nm_tables + nm4 + muls + ("MULCV", "LOAD", "STORE", "LOADC", "ADD"):
             e(f"s_cmp_eq_u32 s18, {OPS[nm]}")
             e(f"s_cbranch_scc1 L_{nm.lower()}")
         self.end_of_program()  # END (and anything unsupported: the host never sends those)
@@ -483,6 +486,8 @@ class Gen:
 
         if nm_tables:
             self.number_major_ops(St)
+        if nm4:
+            self.number_major4_ops(St)
 
         e("L_mulcv:")
         # fixed-base comb: a <- consts[aux + 16*arg + digit], digit = 4-bit window `arg` of this number's exponent
@@ -526,6 +531,77 @@ class Gen:
         if not getattr(self, "sq_self_staged", False):
             self.stage_to_lds(Xs)
         e("s_branch L_montsq" if (self.sq_rows or self.sq_rows_k or getattr(self, "sq_rows_w", False)) else "s_branch L_montmul")
+
+    def number_major4_ops(self, St):
+        """Tables that are gathered per number (the 4-bit windows of per-number exponents) stored NUMBER-major inside their slots --
+        [number][WT limbs] instead of [WT limbs][number] -- by STORET and read back by MULVT: a lane's WL limbs are contiguous
+        bytes, fetched with 16-byte loads that use every byte of the sectors they touch.  Limb-major, a gather reads ONE dword per
+        32-byte sector (neighbouring numbers want different table entries): the multi-exponentiation of the DDLEQ prover's
+        response fetched 145 GB in a 43 ms launch that way (profiles/r03_prove_traffic.txt)."""
+        g, e = self, self.e
+        WL = self.WL
+        assert WL * 4 <= 4095 and self.vX % 2 == 0
+        sfx = {4: "x4", 2: "x2", 1: ""}
+        chunks, j = [], 0
+        while j < WL:
+            n = 4 if WL - j >= 4 else 2 if WL - j >= 2 else 1
+            chunks.append((j, n))
+            j += n
+
+        def lane_offset(dst):
+            """dst <- byte offset of this lane's limbs inside a number-major slot: g * WT * 4 + k * WL * 4"""
+            e(f"v_subrev_u32 v{dst}, {self.lds_a}, v{g.v_aread}")            # gl*4
+            e(f"s_mul_i32 s{g.s_t0}, s2, {self.NPB * 4}")
+            e(f"v_add_u32 v{dst}, s{g.s_t0}, v{dst}")                        # g*4
+            e(f"s_mov_b32 s{g.s_t0}, {self.WT}")
+            e(f"v_mul_lo_u32 v{dst}, v{dst}, s{g.s_t0}")                     # g * WT * 4  (host guarantees < 2^32)
+            if self.K > 1:
+                e(f"v_add_u32 v{dst}, v{dst}, v{g.v_koff}")
+
+        e("L_storet:")
+        self.slot_base()
+        lane_offset(g.v_t2)
+        for j, n in chunks:
+            src = self.X(j) if n == 1 else f"v[{g.vX + j}:{g.vX + j + n - 1}]"
+            e(f"global_store_dword{sfx[n]} v{g.v_t2}, {src}, s[{g.s_sbase}:{g.s_sbase + 1}] offset:{4 * j}")
+        e("s_waitcnt vmcnt(0)")
+        e("s_branch L_next")
+
+        e("L_mulvt:")
+        # table entry = aux + the 4-bit window `arg` of this number's own exponent (7 windows per 28-bit limb), as MULV
+        e(f"s_mul_hi_u32 s{g.s_t1}, s17, {((1 << 32) + 6) // 7}")          # q = arg / 7
+        e(f"s_mul_i32 s98, s{g.s_t1}, 7")
+        e("s_sub_u32 s98, s17, s98")
+        e("s_lshl_b32 s98, s98, 2")                                        # shift = 4 (arg % 7)
+        e(f"s_mul_hi_u32 s{g.s_sbase + 1}, s{g.s_t1}, s3")                 # digits + q * nb*4
+        e(f"s_mul_i32 s{g.s_sbase}, s{g.s_t1}, s3")
+        e(f"s_add_u32 s{g.s_sbase}, s{g.s_sbase}, s12")
+        e(f"s_addc_u32 s{g.s_sbase + 1}, s{g.s_sbase + 1}, s13")
+        e(f"v_subrev_u32 v{g.v_t2}, {self.lds_a}, v{g.v_aread}")           # gl*4
+        e(f"s_mul_i32 s{g.s_t0}, s2, {self.NPB * 4}")
+        e(f"v_add_u32 v{g.v_t2}, s{g.s_t0}, v{g.v_t2}")                    # g*4
+        e(f"global_load_dword v{g.v_t3}, v{g.v_t2}, s[{g.s_sbase}:{g.s_sbase + 1}]")
+        e(f"s_mov_b32 s{g.s_t0}, {self.WT}")
+        e(f"v_mul_lo_u32 v{g.v_t2}, v{g.v_t2}, s{g.s_t0}")                 # g * WT * 4
+        if self.K > 1:
+            e(f"v_add_u32 v{g.v_t2}, v{g.v_t2}, v{g.v_koff}")
+        e("s_waitcnt vmcnt(0)")
+        e(f"v_lshrrev_b32 v{g.v_t3}, s98, v{g.v_t3}")
+        e(f"v_and_b32 v{g.v_t3}, 15, v{g.v_t3}")                           # digit
+        e(f"s_mul_i32 s{g.s_t0}, s3, {self.WT}")                           # slot stride in bytes
+        e(f"v_mul_lo_u32 v{g.v_t3}, v{g.v_t3}, s{g.s_t0}")                  # digit * stride (host guarantees < 2^32)
+        e("s_bfe_u32 s17, s16, 0x160008")                                  # aux = first table slot (bits 8..29)
+        e(f"s_mul_hi_u32 s{g.s_sbase + 1}, s17, s{g.s_t0}")
+        e(f"s_mul_i32 s{g.s_sbase}, s17, s{g.s_t0}")
+        e(f"s_add_u32 s{g.s_sbase}, s{g.s_sbase}, s10")
+        e(f"s_addc_u32 s{g.s_sbase + 1}, s{g.s_sbase + 1}, s11")
+        e(f"v_add_u32 v{g.v_addr}, v{g.v_t3}, v{g.v_t2}")
+        for j, n in chunks:
+            dst = St[j] if n == 1 else f"v[{j}:{j + n - 1}]"
+            e(f"global_load_dword{sfx[n]} {dst}, v{g.v_addr}, s[{g.s_sbase}:{g.s_sbase + 1}] offset:{4 * j}")
+        e("s_waitcnt vmcnt(0)")
+        self.stage_to_lds(St)
+        e("s_branch L_montmul")
 
     # ---------------------------------------------------------------------------------------------
     def gen_row(self, v_ai_cur, v_ai_next, swap_by_mov, mult_prep=None):
@@ -1581,6 +1657,7 @@ class GenP(Gen):
         self.name = f"vm_asm_{H}_16"
         self.sq_rows = True
         self.sq_self_staged = True # a squaring writes its (doubled) multipliers to the LDS column itself, row by row
+        self.nm4_tables = True     # STORET / MULVT: per-number window tables number-major
         self.vM = 2 * H            # quotient digits m_i of phase 1 (phase 2 starts from Cadj_i - m_i)
         self.vA = 3 * H            # new a0 of a MUL (the old one is still an operand of phase 2)
         import os
@@ -1818,6 +1895,7 @@ class GenP2(GenP):
         self.lds_a = (H * 4 + 255) // 256 * 256            # Cadj table first, then the lanes' columns [H + 1][256]
         self.lds_bytes = self.lds_a + (H + 1) * BLOCK * 4
         self.row = BLOCK * 4
+        self.nm4_tables = False    # (its own dispatcher: 4-bit limb-major windows only)
 
     # ---------------------------------------------------------------------------------------------
     def prologue(self):
