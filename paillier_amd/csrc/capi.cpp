@@ -362,19 +362,19 @@ struct Prog {
   uint32_t gather_slots = 1;  // slots a per-number gather spans (table entries + 1): its offsets are 32-bit in the assembly kernels
   void op(uint32_t o, uint32_t arg = 0, uint32_t aux = 0) {
     if (o == VM_SETOFF) asm_ok = false;
-    if (o == VM_MULV7 || o == VM_STORET || o == VM_MULVT) nm_tables = true;
-    if (o == VM_MULVT) nm4 = true;
+    if (o == VM_MULV7 || o == VM_STORET || o == VM_MULVT || o == VM_MULVT5) nm_tables = true;
+    if (o == VM_MULVT || o == VM_MULVT5) nm4 = true;
     if (o == VM_MULV7) mulv7 = true;
     if (o == VM_MULS) needs_muls = true;
-    if (o == VM_MULCV || o == VM_MULV5 || o == VM_MULV7 || o == VM_STORET || o == VM_MULVT) wide_gathers = true;   // (kernels without these opcodes must not get the program)
-    if (o == VM_MULV || o == VM_MULV5 || o == VM_MULV7 || o == VM_MULVT) {
+    if (o == VM_MULCV || o == VM_MULV5 || o == VM_MULV7 || o == VM_STORET || o == VM_MULVT || o == VM_MULVT5) wide_gathers = true;   // (kernels without these opcodes must not get the program)
+    if (o == VM_MULV || o == VM_MULV5 || o == VM_MULV7 || o == VM_MULVT || o == VM_MULVT5) {
       has_mulv = true;
-      gather_slots = std::max<uint32_t>(gather_slots, o == VM_MULV ? 17u : o == VM_MULVT ? 18u : o == VM_MULV5 ? 33u : 129u);
+      gather_slots = std::max<uint32_t>(gather_slots, o == VM_MULV ? 17u : o == VM_MULVT ? 18u : o == VM_MULV5 ? 33u : o == VM_MULVT5 ? 49u : 129u);
     }
     if (aux >> 22) api_throw(PGPU_ERR_INVALID, "internal: table slot does not fit the instruction word");
     w.push_back(o | (aux << 8));
     w.push_back(arg);
-    if (o == VM_SQR || o == VM_MUL || o == VM_MULC || o == VM_MULV || o == VM_MULCV || o == VM_MULV5 || o == VM_MULV7 || o == VM_MULS || o == VM_MULVT) montmuls += 1;
+    if (o == VM_SQR || o == VM_MUL || o == VM_MULC || o == VM_MULV || o == VM_MULCV || o == VM_MULV5 || o == VM_MULV7 || o == VM_MULS || o == VM_MULVT || o == VM_MULVT5) montmuls += 1;
     if (o == VM_SQR) sqrs += 1;
   }
   // Bits 30..31 of an instruction word: the priority the wave takes when it gets there -- 3, 2, 1, 0 over four stretches of a
@@ -392,7 +392,7 @@ struct Prog {
       const double f = done / montmuls;
       const uint32_t quarter = f < 0.80 ? 0u : f < 0.96 ? 1u : f < 0.992 ? 2u : 3u;
       w[i] = (w[i] & 0x3FFFFFFFu) | ((3u - quarter) << 30);
-      if (o == VM_SQR || o == VM_MUL || o == VM_MULC || o == VM_MULV || o == VM_MULCV || o == VM_MULV5 || o == VM_MULV7 || o == VM_MULS || o == VM_MULVT) done += 1;
+      if (o == VM_SQR || o == VM_MUL || o == VM_MULC || o == VM_MULV || o == VM_MULCV || o == VM_MULV5 || o == VM_MULV7 || o == VM_MULS || o == VM_MULVT || o == VM_MULVT5) done += 1;
     }
   }
 };
@@ -501,15 +501,30 @@ void emit_modexp_shared(Prog& p, const BigU& e, uint32_t in_lo, uint32_t in_hi, 
 // The wide windows pay where a product costs two squarings (the digit kernels): a 4 096-bit exponent takes 586 products
 // and a 63 + 63 table at 7 bits, 820 + 30 at 5, 1 024 + 14 at 4.
 static int perlane_windows(int we, int wb) { return wb == 4 ? we * 7 : wb == 5 ? (we * LB + 4) / 5 : we * 4; }
-static VmOp perlane_op(int wb, bool nm4 = false) { return wb == 4 ? (nm4 ? VM_MULVT : VM_MULV) : wb == 5 ? VM_MULV5 : VM_MULV7; }
+static VmOp perlane_op(int wb, bool nm4 = false) { return wb == 4 ? (nm4 ? VM_MULVT : VM_MULV) : wb == 5 ? (nm4 ? VM_MULVT5 : VM_MULV5) : VM_MULV7; }
 // table of x^0 .. x^(2^wb - 1) from x in the accumulator; the wide tables square for their even entries (a squaring
 // is half a product on the digit kernels).  The 7-bit table is gathered per number, so its 128 slots are number-major
 // (VM_STORET / VM_MULV7); the entries the build itself reads back (x and the ones that get squared) are kept limb-major as
 // well, in the 64 slots after the table.
-static int perlane_table_slots(int wb) { return wb == 7 ? 128 + 64 : 1 << wb; }
-// nm4 (4-bit windows on the one-lane pair kernel): the 16 entries NUMBER-major (VM_STORET, gathered by VM_MULVT) and x once more
-// limb-major in slot tab + 16 -- the operand of the products that build the table.
+static int perlane_table_slots(int wb, bool nm4 = false) { return wb == 7 ? 128 + 64 : nm4 ? (wb == 5 ? 32 + 16 : 16 + 1) : 1 << wb; }
+// nm4 (4- / 5-bit windows on the pair kernels): the entries NUMBER-major (VM_STORET, gathered by VM_MULVT / VM_MULVT5) and what the
+// build itself reads back limb-major behind them -- x in slot tab + 16 (4 bits), entries 1 .. 15 in slots tab + 32 + k (5 bits).
 static void emit_power_table(Prog& p, uint32_t tab, uint32_t one, int wb, bool nm4 = false) {
+  if (wb == 5 && nm4) {
+    const uint32_t scr = tab + 32;
+    p.op(VM_STORET, tab + 1);
+    p.op(VM_STORE, scr + 1);
+    p.op(VM_LOADC, one);
+    p.op(VM_STORET, tab + 0);
+    p.op(VM_LOAD, scr + 1);
+    for (uint32_t k = 2; k < 32; ++k) {
+      if (k % 2 == 0) { p.op(VM_LOAD, scr + k / 2); p.op(VM_SQR); }
+      else p.op(VM_MUL, scr + 1);
+      p.op(VM_STORET, tab + k);
+      if (k < 16) p.op(VM_STORE, scr + k);
+    }
+    return;
+  }
   if (wb == 4 && nm4) {
     const uint32_t scr = tab + 16;
     p.op(VM_STORET, tab + 1);
@@ -547,15 +562,15 @@ static void emit_power_table(Prog& p, uint32_t tab, uint32_t one, int wb, bool n
 }
 
 void emit_modexp_perlane(Prog& p, int we, uint32_t in_lo, uint32_t in_hi, uint32_t tmp, uint32_t out, uint32_t tab,
-                         uint32_t post_slot, int raw_one = -1, int wb = 4) {
+                         uint32_t post_slot, int raw_one = -1, int wb = 4, bool nm4 = false) {
   const uint32_t one = raw_one >= 0 ? (uint32_t)raw_one : (uint32_t)C_ONE_M;
   if (raw_one >= 0) p.op(VM_LOAD, in_lo); else emit_to_mont(p, in_lo, in_hi, tmp);
-  emit_power_table(p, tab, one, wb);
+  emit_power_table(p, tab, one, wb, nm4);
   const int nwin = perlane_windows(we, wb);
   p.op(VM_LOADC, one);
   for (int i = nwin - 1; i >= 0; --i) {
     if (i != nwin - 1) for (int s = 0; s < wb; ++s) p.op(VM_SQR);
-    p.op(perlane_op(wb), (uint32_t)i, tab);
+    p.op(perlane_op(wb, nm4), (uint32_t)i, tab);
   }
   if (raw_one < 0) { if (post_slot != NO_SLOT) p.op(VM_MUL, post_slot); else p.op(VM_MULC, C_ONE); }
   p.op(VM_STORE, out);
@@ -569,13 +584,13 @@ void emit_modexp_perlane(Prog& p, int we, uint32_t in_lo, uint32_t in_hi, uint32
 // x in slot in1, y in slot in2 (plain residues); result (plain, lazy) -> out.
 static int dual_sliding_bits(int wb) { return wb == 7 ? 7 : 6; }
 void emit_modexp_dual(Prog& p, int we, const BigU& e, uint32_t in1, uint32_t in2, uint32_t tmp, uint32_t out, uint32_t tab1,
-                      uint32_t tab2, int raw_one = -1, int wb = 4) {
+                      uint32_t tab2, int raw_one = -1, int wb = 4, bool nm4 = false) {
   // raw_one >= 0: in1 / in2 are already in the kernel's working form (digit kernels), raw_one = the constant holding 1 in
   // that form; no entry, no exit
   const uint32_t one_m = raw_one >= 0 ? (uint32_t)raw_one : (uint32_t)C_ONE_M;
   // tables
   if (raw_one >= 0) p.op(VM_LOAD, in1); else emit_to_mont(p, in1, NO_SLOT, tmp);
-  emit_power_table(p, tab1, one_m, wb);
+  emit_power_table(p, tab1, one_m, wb, nm4);
   const int sw = dual_sliding_bits(wb);
   const uint32_t nodd = 1u << (sw - 1);
   if (raw_one >= 0) p.op(VM_LOAD, in2); else emit_to_mont(p, in2, NO_SLOT, tmp);
@@ -600,7 +615,7 @@ void emit_modexp_dual(Prog& p, int we, const BigU& e, uint32_t in1, uint32_t in2
   p.op(VM_LOADC, one_m);
   for (long b = nbits - 1; b >= 0; --b) {
     if (b != nbits - 1) p.op(VM_SQR);
-    if (b % wb == 0 && b / wb < nwin) p.op(perlane_op(wb), (uint32_t)(b / wb), tab1);
+    if (b % wb == 0 && b / wb < nwin) p.op(perlane_op(wb, nm4), (uint32_t)(b / wb), tab1);
     if (mul_at[(size_t)b] >= 0) p.op(VM_MUL, tab2 + (uint32_t)mul_at[(size_t)b]);
   }
   if (raw_one < 0) p.op(VM_MULC, C_ONE);
@@ -819,8 +834,10 @@ void run_vm(pgpu_ctx* ctx, size_t nb, const SegSpec& s0, const SegSpec* s1, bool
   const bool nm4 = s0.prog->nm4 || (s1 && s1->prog->nm4) || (s2 && s2->prog->nm4);
   const bool mulv7 = s0.prog->mulv7 || (s1 && s1->prog->mulv7) || (s2 && s2->prog->mulv7);
   if (nm4 && mulv7) api_throw(PGPU_ERR_UNSUPPORTED, "internal: 4-bit and 7-bit number-major tables in one launch");
+  // VM_STORET / VM_MULVT / VM_MULVT5: GenP for 37-limb primes, GenQ (two lanes), GenQ4 (four lanes)
+  const bool nm4_kernel = pair && ((s0.pair_lanes == 1 && s0.pair_h == 37) || s0.pair_lanes == 2 || s0.pair_lanes == 4);
   const bool use_asm = ctx->use_asm && vm_asm_available(WL, K) && s0.prog->asm_ok && (!s1 || s1->prog->asm_ok) &&
-                       (!s2 || s2->prog->asm_ok) && (!nm_tables || (pair && (mulv7 ? s0.pair_lanes == 3 : nm4 ? (s0.pair_lanes == 1 && s0.pair_h == 37) : (s0.pair_lanes == 3 || (s0.pair_lanes == 1 && s0.pair_h == 37))))) &&
+                       (!s2 || s2->prog->asm_ok) && (!nm_tables || (pair && (mulv7 ? s0.pair_lanes == 3 : nm4 ? nm4_kernel : (s0.pair_lanes == 3 || nm4_kernel)))) &&
                        (uint64_t)nb * ((s0.pair_lanes == 3 || s0.pair_lanes == 6) ? 3 * s0.pair_h : mc->WT) * 4 *
                                std::max(s0.prog->gather_slots, std::max(s1 ? s1->prog->gather_slots : 1u, s2 ? s2->prog->gather_slots : 1u)) < (1ull << 32);
   pgpu_ctx::Ev* ev = nullptr;
@@ -1263,7 +1280,7 @@ ModexpPlan modexp_alloc(pgpu_ctx* ctx, const ModCtx& mc, size_t nb, int table_sl
   ModexpPlan pl;
   pl.nb = nb;
   pl.slot_words = (size_t)mc.WT * nb;
-  pl.mem = ctx->ws_t<uint32_t>(pl.slot_words * (size_t)(5 + table_slots));
+  pl.mem = ctx->ws_t<uint32_t>(pl.slot_words * (size_t)(5 + table_slots + 1));   // (+ 1: x limb-major behind a number-major 4-bit table)
   return pl;
 }
 
@@ -1315,7 +1332,8 @@ void modexp_pair(pgpu_ctx* ctx, const ModCtx& mc, const ModexpPlan& pl, const Bi
     launch_restride(m8 + 3 * SW8 + (size_t)H8 * nb, nb, nb, nullptr, mem + 3 * SW + S1, nb, H, ctx->stream);
   } else {
     Prog p;
-    if (exps) emit_modexp_perlane(p, we, 2, NO_SLOT, 2, 3, 5, NO_SLOT, pi.c_one_pair);
+    // per-number windows: the table number-major (GenQ / GenQ4 gather a lane's limbs as contiguous bytes)
+    if (exps) emit_modexp_perlane(p, we, 2, NO_SLOT, 2, 3, 5, NO_SLOT, pi.c_one_pair, 4, ctx->use_nm4 && (uint64_t)nb * W2 * 4 * 18 < (1ull << 32));
     else emit_modexp_shared(p, *e, 2, NO_SLOT, 2, 3, 5, NO_SLOT, true, true);
     p.end();
     SegSpec sp{&mc, &p, mem, exps};
@@ -3315,9 +3333,12 @@ static uint32_t* dual_pow_pair(pgpu_ctx* ctx, const ModCtx& mc, const uint32_t* 
   const size_t lanes_target = ctx->lanes_wanted ? ctx->lanes_wanted : (size_t)1024 * 64;
   const bool two = nb * 2 >= lanes_target;
   if (!two && !(H % 2 == 0 && vm_asm_available(H / 2, 64))) return nullptr;
-  const int wb = (uint64_t)nb * W2 * 4 * 33 < (1ull << 32) ? 5 : 4;       // MULV5 / MULV gathers with 32-bit offsets
-  if ((uint64_t)nb * W2 * 4 * 17 >= (1ull << 32)) return nullptr;
-  const uint32_t tab2 = 5 + (1u << wb);
+  // per-number window table number-major (VM_STORET / VM_MULVT5 / VM_MULVT): limb-major, the 16 384-number ladder of the DDLEQ
+  // verifier fetched 98 GB of 32-byte sectors for its dword gathers in a 43 ms launch (profiles/r03_bench_traffic.txt)
+  const bool nm4 = ctx->use_nm4;
+  const int wb = (uint64_t)nb * W2 * 4 * (uint64_t)(perlane_table_slots(5, nm4) + 1) < (1ull << 32) ? 5 : 4;   // gathers with 32-bit offsets
+  if ((uint64_t)nb * W2 * 4 * (uint64_t)(perlane_table_slots(4, nm4) + 1) >= (1ull << 32)) return nullptr;
+  const uint32_t tab2 = 5 + (uint32_t)perlane_table_slots(wb, nm4);
   const size_t SW = (size_t)W2 * nb;
   uint32_t* pm = ctx->ws_t<uint32_t>(SW * (size_t)(tab2 + 32));           // 0 x, 1 y, 2 tmp, 3 out, 5.. / tab2.. the tables
   uint32_t* ent = ctx->ws_t<uint32_t>(SW * 4);
@@ -3327,7 +3348,7 @@ static uint32_t* dual_pow_pair(pgpu_ctx* ctx, const ModCtx& mc, const uint32_t* 
     HIPCHK(hipMemcpyAsync(pm + (size_t)k * SW, ent + 2 * SW, SW * 4, hipMemcpyDeviceToDevice, ctx->stream));
   }
   Prog pd;
-  emit_modexp_dual(pd, we, e, 0, 1, 2, 3, 5, tab2, pi.c_one_pair, wb);
+  emit_modexp_dual(pd, we, e, 0, 1, 2, 3, 5, tab2, pi.c_one_pair, wb, nm4);
   pd.end();
   SegSpec sp{&mc, &pd, pm, wb == 5 ? windows5_of(ctx, exps, we, nb) : exps};
   sp.pair = pi.consts; sp.pair_n0inv = pi.root->n0inv; sp.pair_h = H; sp.pair_lanes = two ? 2 : 4;

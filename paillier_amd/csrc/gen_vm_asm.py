@@ -33,7 +33,7 @@ LB = 28
 MASK = (1 << LB) - 1
 BLOCK = 256
 OPS = dict(END=0, LOAD=1, STORE=2, LOADC=3, SQR=4, MUL=5, MULC=6, MULV=7, ADD=8, SETOFF=9, MULCV=10, MULV5=11, MULV7=12, STORET=13, MULS=14,
-           MULVT=15)
+           MULVT=15, MULVT5=16)
 
 
 class Gen:
@@ -394,8 +394,8 @@ class Gen:
         e("s_and_b32 s18, s16, 0xff")
         # MULV7 / STORET (number-major tables) exist on the three-digit kernels only; the host emits them nowhere else
         nm_tables = ("MULV7", "STORET") if getattr(self, "number_major_tables", False) else ()
-        # MULVT / STORET (number-major tables with 4-bit windows): the one-lane pair kernel for 37-limb primes
-        nm4 = ("MULVT", "STORET") if getattr(self, "nm4_tables", False) else ()
+        # MULVT / MULVT5 / STORET (number-major tables with 4- / 5-bit windows): the pair kernels GenP (37-limb primes), GenQ, GenQ4
+        nm4 = ("MULVT", "MULVT5", "STORET") if getattr(self, "nm4_tables", False) else ()
         muls = ("MULS",) if getattr(self, "has_muls", False) else ()
         for nm in ("SQR", "MUL", "MULC", "MULV", "MULV5") + nm_tables + nm4 + muls + ("MULCV", "LOAD", "STORE", "LOADC", "ADD"):
             e(f"s_cmp_eq_u32 s18, {OPS[nm]}")
@@ -559,49 +559,53 @@ class Gen:
                 e(f"v_add_u32 v{dst}, v{dst}, v{g.v_koff}")
 
         e("L_storet:")
+        self.mask_digit_lanes(True)
         self.slot_base()
         lane_offset(g.v_t2)
         for j, n in chunks:
             src = self.X(j) if n == 1 else f"v[{g.vX + j}:{g.vX + j + n - 1}]"
             e(f"global_store_dword{sfx[n]} v{g.v_t2}, {src}, s[{g.s_sbase}:{g.s_sbase + 1}] offset:{4 * j}")
         e("s_waitcnt vmcnt(0)")
+        self.mask_digit_lanes(False)
         e("s_branch L_next")
 
-        e("L_mulvt:")
-        # table entry = aux + the 4-bit window `arg` of this number's own exponent (7 windows per 28-bit limb), as MULV
-        e(f"s_mul_hi_u32 s{g.s_t1}, s17, {((1 << 32) + 6) // 7}")          # q = arg / 7
-        e(f"s_mul_i32 s98, s{g.s_t1}, 7")
-        e("s_sub_u32 s98, s17, s98")
-        e("s_lshl_b32 s98, s98, 2")                                        # shift = 4 (arg % 7)
-        e(f"s_mul_hi_u32 s{g.s_sbase + 1}, s{g.s_t1}, s3")                 # digits + q * nb*4
-        e(f"s_mul_i32 s{g.s_sbase}, s{g.s_t1}, s3")
-        e(f"s_add_u32 s{g.s_sbase}, s{g.s_sbase}, s12")
-        e(f"s_addc_u32 s{g.s_sbase + 1}, s{g.s_sbase + 1}, s13")
-        e(f"v_subrev_u32 v{g.v_t2}, {self.lds_a}, v{g.v_aread}")           # gl*4
-        e(f"s_mul_i32 s{g.s_t0}, s2, {self.NPB * 4}")
-        e(f"v_add_u32 v{g.v_t2}, s{g.s_t0}, v{g.v_t2}")                    # g*4
-        e(f"global_load_dword v{g.v_t3}, v{g.v_t2}, s[{g.s_sbase}:{g.s_sbase + 1}]")
-        e(f"s_mov_b32 s{g.s_t0}, {self.WT}")
-        e(f"v_mul_lo_u32 v{g.v_t2}, v{g.v_t2}, s{g.s_t0}")                 # g * WT * 4
-        if self.K > 1:
-            e(f"v_add_u32 v{g.v_t2}, v{g.v_t2}, v{g.v_koff}")
-        e("s_waitcnt vmcnt(0)")
-        e(f"v_lshrrev_b32 v{g.v_t3}, s98, v{g.v_t3}")
-        e(f"v_and_b32 v{g.v_t3}, 15, v{g.v_t3}")                           # digit
-        e(f"s_mul_i32 s{g.s_t0}, s3, {self.WT}")                           # slot stride in bytes
-        e(f"v_mul_lo_u32 v{g.v_t3}, v{g.v_t3}, s{g.s_t0}")                  # digit * stride (host guarantees < 2^32)
-        e("s_bfe_u32 s17, s16, 0x160008")                                  # aux = first table slot (bits 8..29)
-        e(f"s_mul_hi_u32 s{g.s_sbase + 1}, s17, s{g.s_t0}")
-        e(f"s_mul_i32 s{g.s_sbase}, s17, s{g.s_t0}")
-        e(f"s_add_u32 s{g.s_sbase}, s{g.s_sbase}, s10")
-        e(f"s_addc_u32 s{g.s_sbase + 1}, s{g.s_sbase + 1}, s11")
-        e(f"v_add_u32 v{g.v_addr}, v{g.v_t3}, v{g.v_t2}")
-        for j, n in chunks:
-            dst = St[j] if n == 1 else f"v[{j}:{j + n - 1}]"
-            e(f"global_load_dword{sfx[n]} {dst}, v{g.v_addr}, s[{g.s_sbase}:{g.s_sbase + 1}] offset:{4 * j}")
-        e("s_waitcnt vmcnt(0)")
-        self.stage_to_lds(St)
-        e("s_branch L_montmul")
+        for lbl, per_word, wbits in (("L_mulvt", 7, 4), ("L_mulvt5", 5, 5)):
+            # table entry = aux + the window `arg` of this number's own exponent, as MULV (4 bits, 7 per 28-bit limb) / MULV5 (5 bits,
+            # 5 per 25-bit word of the repacked exponent)
+            e(f"{lbl}:")
+            e(f"s_mul_hi_u32 s{g.s_t1}, s17, {((1 << 32) + per_word - 1) // per_word}")   # q = arg / per_word
+            e(f"s_mul_i32 s98, s{g.s_t1}, {per_word}")
+            e("s_sub_u32 s98, s17, s98")
+            e(f"s_mul_i32 s98, s98, {wbits}")                                  # shift = wbits * (arg % per_word)
+            e(f"s_mul_hi_u32 s{g.s_sbase + 1}, s{g.s_t1}, s3")                 # digits + q * nb*4
+            e(f"s_mul_i32 s{g.s_sbase}, s{g.s_t1}, s3")
+            e(f"s_add_u32 s{g.s_sbase}, s{g.s_sbase}, s12")
+            e(f"s_addc_u32 s{g.s_sbase + 1}, s{g.s_sbase + 1}, s13")
+            e(f"v_subrev_u32 v{g.v_t2}, {self.lds_a}, v{g.v_aread}")           # gl*4
+            e(f"s_mul_i32 s{g.s_t0}, s2, {self.NPB * 4}")
+            e(f"v_add_u32 v{g.v_t2}, s{g.s_t0}, v{g.v_t2}")                    # g*4
+            e(f"global_load_dword v{g.v_t3}, v{g.v_t2}, s[{g.s_sbase}:{g.s_sbase + 1}]")
+            e(f"s_mov_b32 s{g.s_t0}, {self.WT}")
+            e(f"v_mul_lo_u32 v{g.v_t2}, v{g.v_t2}, s{g.s_t0}")                 # g * WT * 4
+            if self.K > 1 or getattr(self, "lanes_per_number", 1) > 1:
+                e(f"v_add_u32 v{g.v_t2}, v{g.v_t2}, v{g.v_koff}")
+            e("s_waitcnt vmcnt(0)")
+            e(f"v_lshrrev_b32 v{g.v_t3}, s98, v{g.v_t3}")
+            e(f"v_and_b32 v{g.v_t3}, {(1 << wbits) - 1}, v{g.v_t3}")           # digit
+            e(f"s_mul_i32 s{g.s_t0}, s3, {self.WT}")                           # slot stride in bytes
+            e(f"v_mul_lo_u32 v{g.v_t3}, v{g.v_t3}, s{g.s_t0}")                  # digit * stride (host guarantees < 2^32)
+            e("s_bfe_u32 s17, s16, 0x160008")                                  # aux = first table slot (bits 8..29)
+            e(f"s_mul_hi_u32 s{g.s_sbase + 1}, s17, s{g.s_t0}")
+            e(f"s_mul_i32 s{g.s_sbase}, s17, s{g.s_t0}")
+            e(f"s_add_u32 s{g.s_sbase}, s{g.s_sbase}, s10")
+            e(f"s_addc_u32 s{g.s_sbase + 1}, s{g.s_sbase + 1}, s11")
+            e(f"v_add_u32 v{g.v_addr}, v{g.v_t3}, v{g.v_t2}")
+            for j, n in chunks:
+                dst = St[j] if n == 1 else f"v[{j}:{j + n - 1}]"
+                e(f"global_load_dword{sfx[n]} {dst}, v{g.v_addr}, s[{g.s_sbase}:{g.s_sbase + 1}] offset:{4 * j}")
+            e("s_waitcnt vmcnt(0)")
+            self.stage_to_lds(St)
+            e("s_branch L_montmul")
 
     # ---------------------------------------------------------------------------------------------
     def gen_row(self, v_ai_cur, v_ai_next, swap_by_mov, mult_prep=None):
@@ -2389,6 +2393,7 @@ class GenQ(LaneRows, Gen):
         assert 3 * H + 3 <= 255
         self.H = H
         self.name = f"vm_asm_{H}_32"
+        self.nm4_tables = True     # STORET / MULVT / MULVT5: per-number window tables number-major
         self.n_sgpr = True
         self.n_vreg = False
         self.flush = False
@@ -2610,6 +2615,7 @@ class GenQ4(Gen):
         self.WT = self.WTslot           # what the dispatcher's slot / constant addressing uses
         self.NPB = BLOCK // 4
         self.name = f"vm_asm_{WL}_64"
+        self.nm4_tables = True     # STORET / MULVT / MULVT5: per-number window tables number-major
         self.sq_rows = True
         self.sq_rows_k = False
         # extra registers after the base map

@@ -24,7 +24,8 @@ enum VmOp : uint32_t {
   VM_MULS = 14,   // mem[arg] <- x*mem[arg]*R^-1, x unchanged (a bucket of the shared chain of squarings takes the current power
                   // without the power leaving the registers; the four- and eight-lane pair kernels only)
   VM_MULVT = 15,  // VM_MULV (4-bit windows, 7 per exponent limb) on a table of NUMBER-major slots written by VM_STORET (the one-lane
-                  // pair kernel for 37-limb primes only)
+                  // pair kernel for 37-limb primes and the two- and four-lane pair kernels)
+  VM_MULVT5 = 16, // VM_MULV5 (5-bit windows of the repacked exponent) on a table of NUMBER-major slots; the same kernels
 };
 
 struct VmSeg {

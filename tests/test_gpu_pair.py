@@ -286,3 +286,35 @@ def test_decrypt_4096_bit_key(ctx, force_pair):
         assert a == sk.DecryptBatch(many, flags=pa.DECRYPT_NO_CRT)
     finally:
         ctx.set_flag("lanes_wanted", 0)
+
+
+@pytest.mark.parametrize("batch,lanes_wanted", [(96, 0), (96, 2 * 96), (700, 0)])
+def test_per_number_windows_number_major_and_limb_major(ctx, batch, lanes_wanted):
+    """x_i^(e_i) mod n^2 with one exponent per number on the pair kernels (two and four lanes per number): the window tables
+    number-major (VM_STORET / VM_MULVT, the default) and limb-major (flag nm4 = 0, VM_MULV) must give the same integers as pow();
+    the DDLEQ verifier's interleaved ladder (5-bit per-number windows: VM_MULVT5) is covered through ConstMult + the proofs'
+    fixtures, and here through a level-one ConstMult with per-ciphertext constants."""
+    import paillier_amd as pa
+    k = json.load(open(os.path.join(G, "keys.json")))["paillier"]["2048"]
+    n = int(k["n"], 16)
+    n2 = n * n
+    m2 = pa.Modulus(ctx, n2)
+    pk = pa.PublicKey(ctx, n, n + 1)
+    rng = random.Random(77 + batch)
+    xs = [rng.randrange(1, n2) for _ in range(batch)]
+    es = [rng.randrange(0, n) for _ in range(batch)]
+    es[0], es[1], es[2] = 0, 1, n - 1
+    want = [pow(x, e, n2) for x, e in zip(xs, es)]
+    got = {}
+    try:
+        ctx.set_flag("lanes_wanted", lanes_wanted)
+        for nm4 in (1, 0):
+            ctx.set_flag("nm4", nm4)
+            got[nm4] = m2.exp_batch(xs, es)
+            assert ctx.last_profile()["kernel"].startswith("vm_asm_"), ctx.last_profile()
+            got[("cm", nm4)] = pk.ConstMultBatch(xs, es)
+    finally:
+        ctx.set_flag("nm4", 1)
+        ctx.set_flag("lanes_wanted", 0)
+    assert got[1] == want and got[0] == want
+    assert got[("cm", 1)] == want and got[("cm", 0)] == want
