@@ -2414,9 +2414,13 @@ uint32_t* pow_n2_crt(const pgpu_seckey* sk, const uint32_t* base, const BigU& e,
     lad[half].end();
   }
   {
+    // (small batches on two lanes per number, as Decrypt chooses: a squaring is 37 rows of 74 multiplies instead of the one-lane
+    // kernel's 4 810 in a row -- the ladder's latency is the run time there)
+    const size_t lanes_target = ctx->lanes_wanted ? ctx->lanes_wanted : (size_t)1024 * 64;
+    const int lanes = (sk->pair_lanes == 1 && sk->pair_small2 && nb * 4 <= lanes_target) ? 2 : sk->pair_lanes;
     SegSpec sp{&sk->mp2, &lad[0], mem[0], nullptr}, sq{&sk->mq2, &lad[1], mem[1], nullptr};
-    sp.pair = sk->pair_p.d; sp.pair_n0inv = sk->mp.n0inv; sp.pair_h = H; sp.pair_lanes = sk->pair_lanes;
-    sq.pair = sk->pair_q.d; sq.pair_n0inv = sk->mq.n0inv; sq.pair_h = H; sq.pair_lanes = sk->pair_lanes;
+    sp.pair = sk->pair_p.d; sp.pair_n0inv = sk->mp.n0inv; sp.pair_h = H; sp.pair_lanes = lanes;
+    sq.pair = sk->pair_q.d; sq.pair_n0inv = sk->mq.n0inv; sq.pair_h = H; sq.pair_lanes = lanes;
     run_vm(ctx, nb, sp, &sq, true);
   }
   for (int half = 0; half < 2; ++half) {
