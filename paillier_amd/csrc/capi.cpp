@@ -835,7 +835,8 @@ void run_vm(pgpu_ctx* ctx, size_t nb, const SegSpec& s0, const SegSpec* s1, bool
   const bool mulv7 = s0.prog->mulv7 || (s1 && s1->prog->mulv7) || (s2 && s2->prog->mulv7);
   if (nm4 && mulv7) api_throw(PGPU_ERR_UNSUPPORTED, "internal: 4-bit and 7-bit number-major tables in one launch");
   // VM_STORET / VM_MULVT / VM_MULVT5: GenP for 37-limb primes, GenQ (two lanes), GenQ4 (four lanes)
-  const bool nm4_kernel = pair && ((s0.pair_lanes == 1 && s0.pair_h == 37) || s0.pair_lanes == 2 || s0.pair_lanes == 4);
+  // (the three-digit kernel: VM_MULVT5 beside its VM_MULV7; the host never sends it 4-bit windows)
+  const bool nm4_kernel = pair && ((s0.pair_lanes == 1 && s0.pair_h == 37) || s0.pair_lanes == 2 || s0.pair_lanes == 4 || s0.pair_lanes == 3);
   const bool use_asm = ctx->use_asm && vm_asm_available(WL, K) && s0.prog->asm_ok && (!s1 || s1->prog->asm_ok) &&
                        (!s2 || s2->prog->asm_ok) && (!nm_tables || (pair && (mulv7 ? s0.pair_lanes == 3 : nm4 ? nm4_kernel : (s0.pair_lanes == 3 || nm4_kernel)))) &&
                        (uint64_t)nb * ((s0.pair_lanes == 3 || s0.pair_lanes == 6) ? 3 * s0.pair_h : mc->WT) * 4 *
@@ -1460,11 +1461,14 @@ void modexp_triple(pgpu_ctx* ctx, const ModCtx& mc, const ModexpPlan& pl, const 
   // digit slots: 0 in, 1 (unused), 2 tmp, 3 out, 5.. table (32 entries: sliding windows of a shared exponent, or the 5-bit
   // windows of per-number exponents -- a product costs two squarings here, so the wider window pays)
   const int wb = (exps && !mc.triple.lanes6_only) ? triple_window_bits(pl.nb, mc.triple.root->WT) : 5;   // (GenQ6: limb-major tables)
-  TriplePlan tp = triple_alloc(ctx, mc, pl.nb, 5 + perlane_table_slots(wb));
+  // (5-bit windows -- batches whose 128-entry tables would not fit the 32-bit gather offsets -- on number-major tables as well:
+  // VM_MULVT5; the two-lanes-per-digit kernel has limb-major tables only)
+  const bool nm5 = exps && wb == 5 && !mc.triple.lanes6_only;
+  TriplePlan tp = triple_alloc(ctx, mc, pl.nb, 5 + perlane_table_slots(wb, nm5));
   triple_enter(ctx, mc, pl.in(), tp, 0);
   Prog p;
   if (exps) {
-    emit_modexp_perlane(p, we, 0, NO_SLOT, 2, 3, 5, NO_SLOT, 0, wb);
+    emit_modexp_perlane(p, we, 0, NO_SLOT, 2, 3, 5, NO_SLOT, 0, wb, nm5);
     exps = triple_windows(ctx, exps, we, pl.nb, wb);
   } else {
     emit_modexp_shared(p, *e, 0, NO_SLOT, 2, 3, 5, NO_SLOT, true, true);
@@ -3868,12 +3872,12 @@ uint32_t* dual_pow_n3(pgpu_ctx* ctx, const pgpu_pubkey* pk, const uint32_t* x, c
     if (wv) {
       launch_copy_limbs(wv, 0, W2, pc.in() + pc.slot_words, W3, nb, ctx->stream);      // slot 1 <- W, zero-extended
       const int wb = triple_window_bits(nb, mn3.triple.root->WT);
-      const uint32_t tab2 = 5 + (uint32_t)perlane_table_slots(wb);
+      const uint32_t tab2 = 5 + (uint32_t)perlane_table_slots(wb, wb == 5);
       TriplePlan tp = triple_alloc(ctx, mn3, nb, (int)tab2 + (1 << (dual_sliding_bits(wb) - 1)));
       triple_enter(ctx, mn3, pc.in(), tp, 0);
       triple_enter(ctx, mn3, pc.in() + pc.slot_words, tp, 1);
       Prog pd;
-      emit_modexp_dual(pd, W1, pk->N, 0, 1, 2, 3, 5, tab2, 0, wb);
+      emit_modexp_dual(pd, W1, pk->N, 0, 1, 2, 3, 5, tab2, 0, wb, wb == 5);
       pd.end();
       triple_run(ctx, mn3, tp, pd, triple_windows(ctx, e0, W1, nb, wb));
       triple_exit(ctx, mn3, tp, 3, pc.out(), nullptr);
@@ -3883,12 +3887,12 @@ uint32_t* dual_pow_n3(pgpu_ctx* ctx, const pgpu_pubkey* pk, const uint32_t* x, c
   if (use3) {
     // the interleaved ladder on the three-digit kernel: residues modulo n^3 as a0 + a1 n + a2 n^2
     const int wb = triple_window_bits(nb, mn3.triple.root->WT);       // 7-bit (or 5-bit) windows of the per-number exponent
-    const uint32_t tab2 = 5 + (uint32_t)perlane_table_slots(wb);
+    const uint32_t tab2 = 5 + (uint32_t)perlane_table_slots(wb, wb == 5);
     TriplePlan tp = triple_alloc(ctx, mn3, nb, (int)tab2 + (1 << (dual_sliding_bits(wb) - 1)));   // slots: 0 x, 1 y, 2 tmp, 3 out, 5.. / tab2.. the tables
     triple_enter(ctx, mn3, pc.in(), tp, 0);
     triple_enter(ctx, mn3, pc.in() + pc.slot_words, tp, 1);
     Prog pd;
-    emit_modexp_dual(pd, W2, mn2.N, 0, 1, 2, 3, 5, tab2, 0, wb);
+    emit_modexp_dual(pd, W2, mn2.N, 0, 1, 2, 3, 5, tab2, 0, wb, wb == 5);
     pd.end();
     triple_run(ctx, mn3, tp, pd, triple_windows(ctx, exps, W2, nb, wb));
     triple_exit(ctx, mn3, tp, 3, pc.out(), nullptr);
@@ -4189,8 +4193,9 @@ void pow_n3_crt(const pgpu_seckey* sk, const uint32_t* base, int wb, const uint3
     // both halves on the three-digit kernel (digits modulo p and q, 37 limbs for 2048-bit keys): a squaring is 37 rows
     // where the wave-sliced 110-limb kernel has 110 -- what counts for the half-size, latency-bound batches of the response
     const int win = exps ? triple_window_bits(nb, mp3.triple.root->WT) : 5;
-    const uint32_t tab2 = 5 + (uint32_t)perlane_table_slots(win);
-    const int nslots = base2 ? (int)tab2 + (1 << (dual_sliding_bits(win) - 1)) : 5 + perlane_table_slots(win);
+    const bool nm5 = exps && win == 5;          // (number-major 5-bit tables: VM_MULVT5)
+    const uint32_t tab2 = 5 + (uint32_t)perlane_table_slots(win, nm5);
+    const int nslots = base2 ? (int)tab2 + (1 << (dual_sliding_bits(win) - 1)) : 5 + perlane_table_slots(win, nm5);
     uint32_t* g = ctx->ws_t<uint32_t>(S * 6);       // generic slots (W limbs): 0 x_p, 1 x_q, 2 A, 3 B, 4 h, 5 scratch
     // Exponents modulo the orders of the unit groups of p^3 and q^3 (a quarter shorter than exponents modulo n^2): each half
     // gets its own reduced exponents and its own program.  PGPU_EXP_ORDER=0 (experiments) keeps the exponents as given.
@@ -4320,8 +4325,8 @@ void pow_n3_crt(const pgpu_seckey* sk, const uint32_t* base, int wb, const uint3
     Prog pp, pq;
     for (int half = 0; half < 2; ++half) {
       Prog& pr = half ? pq : pp;
-      if (base2) emit_modexp_dual(pr, wex[half], es[half], 0, 1, 2, 3, 5, tab2, 0, win);
-      else if (exps) emit_modexp_perlane(pr, wex[half], 0, NO_SLOT, 2, 3, 5, NO_SLOT, 0, win);
+      if (base2) emit_modexp_dual(pr, wex[half], es[half], 0, 1, 2, 3, 5, tab2, 0, win, nm5);
+      else if (exps) emit_modexp_perlane(pr, wex[half], 0, NO_SLOT, 2, 3, 5, NO_SLOT, 0, win, nm5);
       else emit_modexp_shared(pr, es[half], 0, NO_SLOT, 2, 3, 5, NO_SLOT, true, true);
       pr.end();
     }

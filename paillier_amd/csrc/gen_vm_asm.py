@@ -393,7 +393,7 @@ class Gen:
         self.fair_share()
         e("s_and_b32 s18, s16, 0xff")
         # MULV7 / STORET (number-major tables) exist on the three-digit kernels only; the host emits them nowhere else
-        nm_tables = ("MULV7", "STORET") if getattr(self, "number_major_tables", False) else ()
+        nm_tables = ("MULV7", "MULVT5", "STORET") if getattr(self, "number_major_tables", False) else ()
         # MULVT / MULVT5 / STORET (number-major tables with 4- / 5-bit windows): the pair kernels GenP (37-limb primes), GenQ, GenQ4
         nm4 = ("MULVT", "MULVT5", "STORET") if getattr(self, "nm4_tables", False) else ()
         muls = ("MULS",) if getattr(self, "has_muls", False) else ()
@@ -3513,36 +3513,39 @@ class GenQ3(LaneRows, Gen):
         self.mask_digit_lanes(False)
         e("s_branch L_next")
 
-        e("L_mulv7:")
-        # table entry = aux + the 7-bit window `arg` of this number's own exponent (4 windows per 28-bit limb)
-        e(f"s_lshr_b32 s{g.s_t1}, s17, 2")                                 # q = arg / 4
-        e("s_and_b32 s98, s17, 3")
-        e("s_mul_i32 s98, s98, 7")                                         # shift = 7 (arg % 4)
-        e(f"s_mul_hi_u32 s{g.s_sbase + 1}, s{g.s_t1}, s3")                 # digits + q * nb*4
-        e(f"s_mul_i32 s{g.s_sbase}, s{g.s_t1}, s3")
-        e(f"s_add_u32 s{g.s_sbase}, s{g.s_sbase}, s12")
-        e(f"s_addc_u32 s{g.s_sbase + 1}, s{g.s_sbase + 1}, s13")
-        e(f"v_subrev_u32 v{g.v_t2}, {self.lds_a}, v{g.v_aread}")           # gl*4
-        e(f"s_mul_i32 s{g.s_t0}, s2, {self.NPB * 4}")
-        e(f"v_add_u32 v{g.v_t2}, s{g.s_t0}, v{g.v_t2}")                    # g*4
-        e(f"global_load_dword v{g.v_t3}, v{g.v_t2}, s[{g.s_sbase}:{g.s_sbase + 1}]")
-        e("s_waitcnt vmcnt(0)")
-        e(f"v_lshrrev_b32 v{g.v_t3}, s98, v{g.v_t3}")
-        e(f"v_and_b32 v{g.v_t3}, 127, v{g.v_t3}")                          # digit
-        e(f"s_mul_i32 s{g.s_t0}, s3, {self.WT}")                           # slot stride in bytes
-        e(f"v_mul_lo_u32 v{g.v_t3}, v{g.v_t3}, s{g.s_t0}")                  # digit * stride (host guarantees < 2^32)
-        e("s_bfe_u32 s17, s16, 0x160008")                                  # aux = first table slot (bits 8..29)
-        e(f"s_mul_hi_u32 s{g.s_sbase + 1}, s17, s{g.s_t0}")
-        e(f"s_mul_i32 s{g.s_sbase}, s17, s{g.s_t0}")
-        e(f"s_add_u32 s{g.s_sbase}, s{g.s_sbase}, s10")
-        e(f"s_addc_u32 s{g.s_sbase + 1}, s{g.s_sbase + 1}, s11")
-        e(f"v_add_u32 v{g.v_addr}, v{g.v_t3}, v{g.v_tgoff}")
-        for j, n in self.wide_chunks():
-            dst = St[j] if n == 1 else f"v[{j}:{j + n - 1}]"
-            e(f"global_load_dword{sfx[n]} {dst}, v{g.v_addr}, s[{g.s_sbase}:{g.s_sbase + 1}] offset:{4 * j}")
-        e("s_waitcnt vmcnt(0)")
-        self.stage_to_lds(St)
-        e("s_branch L_montmul")
+        for lbl, per_word, wbits in (("L_mulv7", 4, 7), ("L_mulvt5", 5, 5)):
+            # table entry = aux + the window `arg` of this number's own exponent: 7 bits, 4 per 28-bit limb (MULV7), or -- batches
+            # whose 128-entry tables would not fit the 32-bit gather offsets -- 5 bits, 5 per 25-bit word of the repacked exponent (MULVT5)
+            e(f"{lbl}:")
+            e(f"s_mul_hi_u32 s{g.s_t1}, s17, {((1 << 32) + per_word - 1) // per_word}")   # q = arg / per_word
+            e(f"s_mul_i32 s98, s{g.s_t1}, {per_word}")
+            e("s_sub_u32 s98, s17, s98")
+            e(f"s_mul_i32 s98, s98, {wbits}")                                  # shift = wbits (arg % per_word)
+            e(f"s_mul_hi_u32 s{g.s_sbase + 1}, s{g.s_t1}, s3")                 # digits + q * nb*4
+            e(f"s_mul_i32 s{g.s_sbase}, s{g.s_t1}, s3")
+            e(f"s_add_u32 s{g.s_sbase}, s{g.s_sbase}, s12")
+            e(f"s_addc_u32 s{g.s_sbase + 1}, s{g.s_sbase + 1}, s13")
+            e(f"v_subrev_u32 v{g.v_t2}, {self.lds_a}, v{g.v_aread}")           # gl*4
+            e(f"s_mul_i32 s{g.s_t0}, s2, {self.NPB * 4}")
+            e(f"v_add_u32 v{g.v_t2}, s{g.s_t0}, v{g.v_t2}")                    # g*4
+            e(f"global_load_dword v{g.v_t3}, v{g.v_t2}, s[{g.s_sbase}:{g.s_sbase + 1}]")
+            e("s_waitcnt vmcnt(0)")
+            e(f"v_lshrrev_b32 v{g.v_t3}, s98, v{g.v_t3}")
+            e(f"v_and_b32 v{g.v_t3}, {(1 << wbits) - 1}, v{g.v_t3}")           # digit
+            e(f"s_mul_i32 s{g.s_t0}, s3, {self.WT}")                           # slot stride in bytes
+            e(f"v_mul_lo_u32 v{g.v_t3}, v{g.v_t3}, s{g.s_t0}")                  # digit * stride (host guarantees < 2^32)
+            e("s_bfe_u32 s17, s16, 0x160008")                                  # aux = first table slot (bits 8..29)
+            e(f"s_mul_hi_u32 s{g.s_sbase + 1}, s17, s{g.s_t0}")
+            e(f"s_mul_i32 s{g.s_sbase}, s17, s{g.s_t0}")
+            e(f"s_add_u32 s{g.s_sbase}, s{g.s_sbase}, s10")
+            e(f"s_addc_u32 s{g.s_sbase + 1}, s{g.s_sbase + 1}, s11")
+            e(f"v_add_u32 v{g.v_addr}, v{g.v_t3}, v{g.v_tgoff}")
+            for j, n in self.wide_chunks():
+                dst = St[j] if n == 1 else f"v[{j}:{j + n - 1}]"
+                e(f"global_load_dword{sfx[n]} {dst}, v{g.v_addr}, s[{g.s_sbase}:{g.s_sbase + 1}] offset:{4 * j}")
+            e("s_waitcnt vmcnt(0)")
+            self.stage_to_lds(St)
+            e("s_branch L_montmul")
 
     def set_exec(self, mask4):
         """exec <- the lanes of every quad selected by the 4-bit mask"""

@@ -183,3 +183,28 @@ def test_alt_encrypt_and_constant_forms_with_library_randomness(ctx):
         assert a != b and sk.DecryptBatch(a, level=level) == ms == sk.DecryptBatch(b, level=level)
         assert sk.DecryptBatch(pk.EncryptZeroBatch(3, level), level=level) == [0, 0, 0]
         assert sk.DecryptBatch(pk.EncryptOneBatch(3, level), level=level) == [1, 1, 1]
+
+
+def test_per_ciphertext_constants_beyond_the_seven_bit_tables(ctx):
+    """Level-two ConstMult with one constant per ciphertext at 40 960 ciphertexts: the 128-entry window tables of the three-digit
+    kernel would not fit its 32-bit gather offsets, so the ladder takes 5-bit windows -- on number-major tables (VM_STORET /
+    VM_MULVT5), like the 7-bit ones.  Sampled lanes against pow(); the same ciphertexts in two halves (7-bit windows) give the
+    same integers everywhere."""
+    import paillier_amd as pa
+    from paillier_amd import ENC_LEVEL_TWO
+    k = json.load(open(os.path.join(G, "keys.json")))["paillier"]["2048"]
+    n = int(k["n"], 16)
+    n3 = n ** 3
+    pk = pa.PublicKey(ctx, n, n + 1)
+    rng = random.Random(4096)
+    B = 40960
+    base = [rng.randrange(1, n3) for _ in range(64)]
+    cts = [base[i % 64] + i for i in range(B)]
+    ks = [rng.getrandbits(192) for _ in range(B)]       # short constants keep the run short; windows above them are zero
+    ks[0], ks[1] = 0, 1
+    got = pk.ConstMultBatch(cts, ks, level=ENC_LEVEL_TWO)
+    assert ctx.last_vm_asm() == ctx.last_vm_launches()
+    for i in (0, 1, 2, 77, 20479, 20480, B - 1):
+        assert got[i] == pow(cts[i], ks[i], n3), i
+    h = B // 2
+    assert pk.ConstMultBatch(cts[:h], ks[:h], level=ENC_LEVEL_TWO) + pk.ConstMultBatch(cts[h:], ks[h:], level=ENC_LEVEL_TWO) == got
