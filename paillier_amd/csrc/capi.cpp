@@ -93,6 +93,7 @@ struct pgpu_ctx {
   bool use_lanes8 = true;    // shards too small for four lanes per number take the eight-lane pair kernel (pgpu_ctx_set_flag("lanes8", 0): never)
   bool use_side = true;
   hipStream_t side = nullptr;
+  hipStream_t side2 = nullptr;   // second lane: the chain of small kernels of one CRT half (or one operand) beside the other's
   std::vector<hipEvent_t> sync_evs;
   size_t sync_used = 0;
   hipEvent_t next_sync_ev() {
@@ -162,6 +163,7 @@ struct pgpu_ctx {
   // zero the workspace (intermediate values of the last call, ladder programs of secret exponents)
   void wipe_ws() {
     if (side) (void)hipStreamSynchronize(side);
+    if (side2) (void)hipStreamSynchronize(side2);
     for (auto& c : chunks) (void)hipMemsetAsync(c.p, 0, c.cap, stream);
     (void)hipStreamSynchronize(stream);
     for (auto& h : host_keep) wipe_vec(h);
@@ -172,6 +174,7 @@ struct pgpu_ctx {
     for (auto& e : evs) { (void)hipEventDestroy(e.a); (void)hipEventDestroy(e.b); }
     for (auto& e : sync_evs) (void)hipEventDestroy(e);
     if (side) (void)hipStreamDestroy(side);
+    if (side2) (void)hipStreamDestroy(side2);
     if (own_stream) (void)hipStreamDestroy(stream);
   }
 };
@@ -185,9 +188,14 @@ struct pgpu_ctx {
 struct SideStream {
   pgpu_ctx* c;
   hipStream_t main_stream;
+  hipStream_t& s;                           // the lane's stream (created on first use)
   bool on, entered = false, dirty = false;
-  explicit SideStream(pgpu_ctx* c_) : c(c_), main_stream(c_->stream), on(c_->use_side) {
-    if (on && !c->side) HIPCHK(hipStreamCreateWithFlags(&c->side, hipStreamNonBlocking));
+  // lane 0: work of a call that is independent of its ladders (the prover's per-statement chains).  lane 1: one of two independent
+  // CHAINS of small kernels -- the entry into digit form of the q-half next to the p-half's, of operand y next to x's; each such
+  // kernel fills a fraction of the chip for tens of microseconds, two chains side by side take about the time of one.
+  explicit SideStream(pgpu_ctx* c_, int lane = 0) : c(c_), main_stream(c_->stream), s(lane ? c_->side2 : c_->side), on(c_->use_side) {
+    if (on && !s) HIPCHK(hipStreamCreateWithFlags(&s, hipStreamNonBlocking));
+    if (on && s == main_stream) on = false;   // (nested use of a lane from inside itself: stay in line)
   }
   hipEvent_t mark() {                       // "everything issued to the main stream so far"
     if (!on) return nullptr;
@@ -197,8 +205,8 @@ struct SideStream {
   }
   void enter(hipEvent_t after) {
     if (!on) return;
-    if (after) HIPCHK(hipStreamWaitEvent(c->side, after, 0));
-    c->stream = c->side;
+    if (after) HIPCHK(hipStreamWaitEvent(s, after, 0));
+    c->stream = s;
     entered = dirty = true;
   }
   void leave() {
@@ -210,15 +218,29 @@ struct SideStream {
     if (!on || !dirty) return;
     if (entered) leave();
     hipEvent_t e = c->next_sync_ev();
-    HIPCHK(hipEventRecord(e, c->side));
+    HIPCHK(hipEventRecord(e, s));
     HIPCHK(hipStreamWaitEvent(main_stream, e, 0));
     dirty = false;
   }
   ~SideStream() {                           // error paths: never leave the context on the side stream or the side stream busy
     if (!on) return;
     c->stream = main_stream;
-    if (dirty) (void)hipStreamSynchronize(c->side);
+    if (dirty) (void)hipStreamSynchronize(s);
   }
+};
+
+// Two independent chains of small kernels side by side:   Fork f(ctx);  for (k : {0, 1}) { f.chain(k); ... }  f.join();
+// chain(1) moves the context to lane 1 (ordered behind everything issued before the Fork was made), join() comes back and makes
+// the main stream wait.  With the side streams off: plain program order.
+struct Fork {
+  SideStream ss;
+  hipEvent_t start;
+  explicit Fork(pgpu_ctx* c) : ss(c, 1), start(ss.mark()) {}
+  void chain(int k) {
+    if (k == 1) ss.enter(start);
+    else if (ss.entered) ss.leave();
+  }
+  void join() { ss.join(); }
 };
 
 // ------------------------------------------------------------------------------------------------
@@ -2390,7 +2412,9 @@ uint32_t* pow_n2_crt(const pgpu_seckey* sk, const uint32_t* base, const BigU& e,
   uint32_t* xh[2];
   uint32_t* mem[2];
   Prog lad[2];
+  Fork in(ctx);                                                         // the q-half's entry chain beside the p-half's
   for (int half = 0; half < 2; ++half) {
+    in.chain(half);
     const ModCtx &m1 = half ? sk->mq : sk->mp, &m2 = half ? sk->mq2 : sk->mp2;
     const BigU& pr = half ? sk->q : sk->p;
     // slots (W2 limbs): 0 x, 2 pair form in, 3 out, 5..36 table
@@ -2417,6 +2441,7 @@ uint32_t* pow_n2_crt(const pgpu_seckey* sk, const uint32_t* base, const BigU& e,
     emit_modexp_shared(lad[half], eh, 2, NO_SLOT, 2, 3, 5, NO_SLOT, true, true);
     lad[half].end();
   }
+  in.join();
   {
     // (small batches on two lanes per number, as Decrypt chooses: a squaring is 37 rows of 74 multiplies instead of the one-lane
     // kernel's 4 810 in a row -- the ladder's latency is the run time there)
@@ -2427,7 +2452,9 @@ uint32_t* pow_n2_crt(const pgpu_seckey* sk, const uint32_t* base, const BigU& e,
     sq.pair = sk->pair_q.d; sq.pair_n0inv = sk->mq.n0inv; sq.pair_h = H; sq.pair_lanes = lanes;
     run_vm(ctx, nb, sp, &sq, true);
   }
+  Fork out(ctx);
   for (int half = 0; half < 2; ++half) {
+    out.chain(half);
     const ModCtx& m2 = half ? sk->mq2 : sk->mp2;
     uint32_t* mm = mem[half];
     // F~ = F0 + F1 prime, then out of pair and Montgomery form
@@ -2439,6 +2466,7 @@ uint32_t* pow_n2_crt(const pgpu_seckey* sk, const uint32_t* base, const BigU& e,
     launch_canon(mm + 3 * S2, m2.d_nmod, W2, nb, ctx->stream);
     xh[half] = mm + 3 * S2;
   }
+  out.join();
   // Garner: x = x_p + p^2 ((x_q - x_p) p^-2 mod q^2); slots: 0 x_p, 1 x_q, 2 B, 3 A, 4 h
   uint32_t* g = ctx->ws_t<uint32_t>(S2 * 5);
   HIPCHK(hipMemcpyAsync(g, xh[0], S2 * 4, hipMemcpyDeviceToDevice, ctx->stream));
@@ -4123,10 +4151,12 @@ bool pow_p2_multi_crt(const pgpu_seckey* sk, const uint32_t* const xs[2], const 
   uint32_t* mem[2];
   Prog pr[2];
   const uint32_t* dig[2] = {r1 ? r1[0] : nullptr, r1 ? r1[1] : nullptr};
-  uint32_t* ent = ctx->ws_t<uint32_t>(S2 * 4);
-  uint32_t* x0 = ctx->ws_t<uint32_t>(S1);
-  uint32_t* tb = ctx->ws_t<uint32_t>(S2);
+  Fork in(ctx);                                               // the q-half's entry chains beside the p-half's (buffers of their own)
   for (int half = 0; half < 2; ++half) {
+    in.chain(half);
+    uint32_t* ent = ctx->ws_t<uint32_t>(S2 * 4);
+    uint32_t* x0 = ctx->ws_t<uint32_t>(S1);
+    uint32_t* tb = ctx->ws_t<uint32_t>(S2);
     const ModCtx &m1 = half ? sk->mq : sk->mp, &m2 = half ? sk->mq2 : sk->mp2;
     mem[half] = ctx->ws_t<uint32_t>(S2 * (size_t)(TAB2 + 64));      // 0 x, 1 y, 2 tmp, 3 out, 5.. / TAB2.. the tables (+ 1 each: x limb-major)
     for (int k = 0; k < ((ys || xs_b) ? 2 : 1); ++k) {
@@ -4158,13 +4188,16 @@ bool pow_p2_multi_crt(const pgpu_seckey* sk, const uint32_t* const xs[2], const 
     emit_modexp_multi(pr[half], pn, wb, sh, 2, 3, (uint32_t)(half ? sk->c_onep_q2 : sk->c_onep_p2), nm4);
     pr[half].end();
   }
+  in.join();
   {
     SegSpec sp{&sk->mp2, &pr[0], mem[0], dig[0]}, sq{&sk->mq2, &pr[1], mem[1], dig[1]};
     sp.pair = sk->pair_p.d; sp.pair_n0inv = sk->mp.n0inv; sp.pair_h = H; sp.pair_lanes = lanes;
     sq.pair = sk->pair_q.d; sq.pair_n0inv = sk->mq.n0inv; sq.pair_h = H; sq.pair_lanes = lanes;
     run_vm(ctx, nb, sp, &sq, true);
   }
+  Fork out(ctx);
   for (int half = 0; half < 2; ++half) {
+    out.chain(half);
     const ModCtx& m2 = half ? sk->mq2 : sk->mp2;
     uint32_t* mm = mem[half];
     launch_mul_const_add(mm + 3 * S2 + S1, H, (half ? sk->q_limbs1 : sk->p_limbs).d, H, mm + 3 * S2, H, 0, mm + 2 * S2, W2, nb, ctx->stream);
@@ -4175,6 +4208,7 @@ bool pow_p2_multi_crt(const pgpu_seckey* sk, const uint32_t* const xs[2], const 
     launch_canon(mm + 3 * S2, m2.d_nmod, W2, nb, ctx->stream);
     outs[half] = mm + 3 * S2;
   }
+  out.join();
   return true;
 }
 
@@ -4205,7 +4239,9 @@ void pow_n3_crt(const pgpu_seckey* sk, const uint32_t* base, int wb, const uint3
     int wex[2] = {we, we};
     BigU es[2];
     if (e) es[0] = es[1] = *e;
+    Fork fe(ctx);                                   // (the q-half's chains of small kernels beside the p-half's, here and below)
     for (int half = 0; half < 2 && reduce_e; ++half) {
+      fe.chain(half);
       const ExpOrder& eo = half ? sk->eo_q : sk->eo_p;
       if (exps && (size_t)we * LB > eo.ord.bit_length() + LB && we <= 2 * eo.modd.WT) {
         uint32_t* em = ctx->ws_t<uint32_t>((size_t)eo.modd.WT * nb);
@@ -4220,9 +4256,14 @@ void pow_n3_crt(const pgpu_seckey* sk, const uint32_t* base, int wb, const uint3
         if (r.bit_length() >= 64) es[half] = r;
       }
     }
+    fe.join();
     auto garner = [&](const TriplePlan& tp, const TriplePlan& tq) {
+      Fork fx(ctx);
+      fx.chain(0);
       triple_exit(ctx, mp3, tp, 3, g + 0 * S, nullptr);     // x_p, canonical
+      fx.chain(1);
       triple_exit(ctx, mq3, tq, 3, g + 1 * S, nullptr);     // x_q
+      fx.join();
       Prog c;
       c.op(VM_LOAD, 0); c.op(VM_MULC, (uint32_t)sk->c_p3invR); c.op(VM_STORE, 3);
       c.op(VM_LOAD, 1); c.op(VM_MULC, (uint32_t)sk->c_p3invR); c.op(VM_STORE, 2);
@@ -4248,9 +4289,11 @@ void pow_n3_crt(const pgpu_seckey* sk, const uint32_t* base, int wb, const uint3
       const size_t S1 = (size_t)H * nb, S2 = (size_t)W2 * nb;
       const uint32_t *r0[2] = {nullptr, nullptr}, *r1[2] = {nullptr, nullptr}, *x2[2], *y2[2] = {nullptr, nullptr};
       BigU s0[2], s1[2];
-      uint32_t* tbx = ctx->ws_t<uint32_t>(S);
       uint32_t *xr[2], *yr3[2] = {nullptr, nullptr};
+      Fork fa(ctx);
       for (int half = 0; half < 2; ++half) {
+        fa.chain(half);
+        uint32_t* tbx = ctx->ws_t<uint32_t>(S);
         const ModCtx &m1 = half ? sk->mq : sk->mp, &m2 = half ? sk->mq2 : sk->mp2, &m3 = half ? mq3 : mp3;
         if (exps) {
           uint32_t* t2 = ctx->ws_t<uint32_t>(S2);
@@ -4279,13 +4322,16 @@ void pow_n3_crt(const pgpu_seckey* sk, const uint32_t* base, int wb, const uint3
           y2[half] = yy;
         }
       }
+      fa.join();
       uint32_t* wv[2];
       if (pow_p2_multi_crt(sk, x2, exps ? r1 : nullptr, W2, base2 ? y2 : nullptr, s1, nb, wv)) {
         // stage B: slots 0 x, 1 W, 2 tmp, 3 out, 4 y, 5.. the per-number table (128 + 64), then W's and y's odd powers
         const uint32_t TABW = 5 + (uint32_t)perlane_table_slots(win), TABY = TABW + 64;
         TriplePlan up = triple_alloc(ctx, mp3, nb, (int)TABY + 64), uq = triple_alloc(ctx, mq3, nb, (int)TABY + 64);
         Prog pb[2];
+        Fork fb(ctx);
         for (int half = 0; half < 2; ++half) {
+          fb.chain(half);
           const ModCtx& m3 = half ? mq3 : mp3;
           const TriplePlan& t = half ? uq : up;
           triple_enter(ctx, m3, xr[half], t, 0);
@@ -4303,6 +4349,7 @@ void pow_n3_crt(const pgpu_seckey* sk, const uint32_t* base, int wb, const uint3
           emit_modexp_multi(pb[half], pn, win, sh, 2, 3, 0);
           pb[half].end();
         }
+        fb.join();
         SegSpec sp{&mp3, &pb[0], up.mem, r0[0]}, sq{&mq3, &pb[1], uq.mem, r0[1]};
         sp.pair = mp3.triple.kconsts; sp.pair_n0inv = sk->mp.n0inv; sp.pair_h = up.H; sp.pair_lanes = 3; sp.tconsts = mp3.triple.tconsts;
         sq.pair = mq3.triple.kconsts; sq.pair_n0inv = sk->mq.n0inv; sq.pair_h = uq.H; sq.pair_lanes = 3; sq.tconsts = mq3.triple.tconsts;
@@ -4312,16 +4359,20 @@ void pow_n3_crt(const pgpu_seckey* sk, const uint32_t* base, int wb, const uint3
       }
     }
     TriplePlan tp = triple_alloc(ctx, mp3, nb, nslots), tq = triple_alloc(ctx, mq3, nb, nslots);
+    Fork fc(ctx);
     for (int half = 0; half < 2; ++half) {
+      fc.chain(half);
       const ModCtx& m3 = half ? mq3 : mp3;
       const TriplePlan& t = half ? tq : tp;
-      reduce_mod(ctx, m3, base, wb, g + 5 * S, nb);
-      triple_enter(ctx, m3, g + 5 * S, t, 0);
+      uint32_t* red = half ? ctx->ws_t<uint32_t>(S) : g + 5 * S;       // (a scratch slot per half: the chains run side by side)
+      reduce_mod(ctx, m3, base, wb, red, nb);
+      triple_enter(ctx, m3, red, t, 0);
       if (base2) {
-        reduce_mod(ctx, m3, base2, wb2, g + 5 * S, nb);
-        triple_enter(ctx, m3, g + 5 * S, t, 1);
+        reduce_mod(ctx, m3, base2, wb2, red, nb);
+        triple_enter(ctx, m3, red, t, 1);
       }
     }
+    fc.join();
     Prog pp, pq;
     for (int half = 0; half < 2; ++half) {
       Prog& pr = half ? pq : pp;
@@ -4409,8 +4460,10 @@ bool pow_n3_crt_two(const pgpu_seckey* sk, const uint32_t* A, const uint32_t* co
       const size_t S1 = (size_t)H1 * nb, S2 = (size_t)W2 * nb;
       const uint32_t *a0[2], *a1[2], *b0[2], *b1[2], *A2[2], *B2[2];
       uint32_t *Ar[2], *Br[2];
-      uint32_t* tbx = ctx->ws_t<uint32_t>(S);
+      Fork fa(ctx);                                 // (the q-half's chains of small kernels beside the p-half's, here and below)
       for (int half = 0; half < 2; ++half) {
+        fa.chain(half);
+        uint32_t* tbx = ctx->ws_t<uint32_t>(S);
         const ModCtx &m1 = half ? sk->mq : sk->mp, &m2 = half ? sk->mq2 : sk->mp2, &m3 = half ? mq3 : mp3;
         for (int k = 0; k < 2; ++k) {
           const uint32_t* ex = k ? eb[half] : ea[half];
@@ -4431,6 +4484,7 @@ bool pow_n3_crt_two(const pgpu_seckey* sk, const uint32_t* A, const uint32_t* co
           (k ? B2 : A2)[half] = r2;
         }
       }
+      fa.join();
       uint32_t* wv[2];
       if (pow_p2_multi_crt(sk, A2, a1, W2, nullptr, nullptr, nb, wv, B2, b1)) {
         // stage B: slots 0 A, 1 B, 2 tmp, 3 out, 4 W, 5.. A's table, then B's, then W's odd powers
@@ -4439,7 +4493,9 @@ bool pow_n3_crt_two(const pgpu_seckey* sk, const uint32_t* A, const uint32_t* co
         uint32_t* g2 = ctx->ws_t<uint32_t>(S * 6);
         Prog pb[2];
         const uint32_t* dg2[2];
+        Fork fb(ctx);
         for (int half = 0; half < 2; ++half) {
+          fb.chain(half);
           const ModCtx& m3 = half ? mq3 : mp3;
           const TriplePlan& t = half ? uq : up;
           triple_enter(ctx, m3, Ar[half], t, 0);
@@ -4459,12 +4515,17 @@ bool pow_n3_crt_two(const pgpu_seckey* sk, const uint32_t* A, const uint32_t* co
           emit_modexp_multi(pb[half], pn, win, sh, 2, 3, 0);
           pb[half].end();
         }
+        fb.join();
         SegSpec sp{&mp3, &pb[0], up.mem, dg2[0]}, sq{&mq3, &pb[1], uq.mem, dg2[1]};
         sp.pair = mp3.triple.kconsts; sp.pair_n0inv = sk->mp.n0inv; sp.pair_h = up.H; sp.pair_lanes = 3; sp.tconsts = mp3.triple.tconsts;
         sq.pair = mq3.triple.kconsts; sq.pair_n0inv = sk->mq.n0inv; sq.pair_h = uq.H; sq.pair_lanes = 3; sq.tconsts = mq3.triple.tconsts;
         run_vm(ctx, nb, sp, &sq, true);
+        Fork fx(ctx);
+        fx.chain(0);
         triple_exit(ctx, mp3, up, 3, g2 + 0 * S, nullptr);
+        fx.chain(1);
         triple_exit(ctx, mq3, uq, 3, g2 + 1 * S, nullptr);
+        fx.join();
         Prog c;
         c.op(VM_LOAD, 0); c.op(VM_MULC, (uint32_t)sk->c_p3invR); c.op(VM_STORE, 3);
         c.op(VM_LOAD, 1); c.op(VM_MULC, (uint32_t)sk->c_p3invR); c.op(VM_STORE, 2);
@@ -4484,13 +4545,16 @@ bool pow_n3_crt_two(const pgpu_seckey* sk, const uint32_t* A, const uint32_t* co
   uint32_t* g = ctx->ws_t<uint32_t>(S * 6);       // generic slots (W limbs): 0 x_p, 1 x_q, 2 A, 3 B, 4 h, 5 scratch
   Prog pr[2];
   const uint32_t* dg[2];
+  Fork fc(ctx);
   for (int half = 0; half < 2; ++half) {
+    fc.chain(half);
     const ModCtx& m3 = half ? mq3 : mp3;
     const TriplePlan& t = half ? tq : tp;
-    reduce_mod(ctx, m3, A, W3, g + 5 * S, nb);
-    triple_enter(ctx, m3, g + 5 * S, t, 0);
-    reduce_mod(ctx, m3, B, W3, g + 5 * S, nb);
-    triple_enter(ctx, m3, g + 5 * S, t, 1);
+    uint32_t* red = half ? ctx->ws_t<uint32_t>(S) : g + 5 * S;       // (a scratch slot per half: the chains run side by side)
+    reduce_mod(ctx, m3, A, W3, red, nb);
+    triple_enter(ctx, m3, red, t, 0);
+    reduce_mod(ctx, m3, B, W3, red, nb);
+    triple_enter(ctx, m3, red, t, 1);
     // the two exponents of a number one after the other in the rows of `digits`: windows 0 .. 4 we - 1 and 4 we .. 8 we - 1
     uint32_t* d2 = ctx->ws_t<uint32_t>((size_t)2 * we * nb);
     HIPCHK(hipMemcpyAsync(d2, ea[half], (size_t)we * nb * 4, hipMemcpyDeviceToDevice, ctx->stream));
@@ -4502,12 +4566,17 @@ bool pow_n3_crt_two(const pgpu_seckey* sk, const uint32_t* A, const uint32_t* co
     emit_modexp_multi(pr[half], pn, win, {}, 2, 3, 0);
     pr[half].end();
   }
+  fc.join();
   SegSpec sp{&mp3, &pr[0], tp.mem, dg[0]}, sq{&mq3, &pr[1], tq.mem, dg[1]};
   sp.pair = mp3.triple.kconsts; sp.pair_n0inv = sk->mp.n0inv; sp.pair_h = tp.H; sp.pair_lanes = 3; sp.tconsts = mp3.triple.tconsts;
   sq.pair = mq3.triple.kconsts; sq.pair_n0inv = sk->mq.n0inv; sq.pair_h = tq.H; sq.pair_lanes = 3; sq.tconsts = mq3.triple.tconsts;
   run_vm(ctx, nb, sp, &sq, true);
+  Fork fx(ctx);
+  fx.chain(0);
   triple_exit(ctx, mp3, tp, 3, g + 0 * S, nullptr);
+  fx.chain(1);
   triple_exit(ctx, mq3, tq, 3, g + 1 * S, nullptr);
+  fx.join();
   Prog c;
   c.op(VM_LOAD, 0); c.op(VM_MULC, (uint32_t)sk->c_p3invR); c.op(VM_STORE, 3);
   c.op(VM_LOAD, 1); c.op(VM_MULC, (uint32_t)sk->c_p3invR); c.op(VM_STORE, 2);
