@@ -3377,12 +3377,15 @@ static uint32_t* dual_pow_pair(pgpu_ctx* ctx, const ModCtx& mc, const uint32_t* 
   const uint32_t tab2 = 5 + (uint32_t)perlane_table_slots(wb, nm4);
   const size_t SW = (size_t)W2 * nb;
   uint32_t* pm = ctx->ws_t<uint32_t>(SW * (size_t)(tab2 + 32));           // 0 x, 1 y, 2 tmp, 3 out, 5.. / tab2.. the tables
-  uint32_t* ent = ctx->ws_t<uint32_t>(SW * 4);
+  Fork fk(ctx);                                                            // y's entry chain beside x's
   for (int k = 0; k < 2; ++k) {
+    fk.chain(k);
+    uint32_t* ent = ctx->ws_t<uint32_t>(SW * 4);
     HIPCHK(hipMemcpyAsync(ent, k ? y : x, SW * 4, hipMemcpyDeviceToDevice, ctx->stream));
     pair_enter(ctx, mc, ent, nb);
     HIPCHK(hipMemcpyAsync(pm + (size_t)k * SW, ent + 2 * SW, SW * 4, hipMemcpyDeviceToDevice, ctx->stream));
   }
+  fk.join();
   Prog pd;
   emit_modexp_dual(pd, we, e, 0, 1, 2, 3, 5, tab2, pi.c_one_pair, wb, nm4);
   pd.end();
@@ -3902,8 +3905,12 @@ uint32_t* dual_pow_n3(pgpu_ctx* ctx, const pgpu_pubkey* pk, const uint32_t* x, c
       const int wb = triple_window_bits(nb, mn3.triple.root->WT);
       const uint32_t tab2 = 5 + (uint32_t)perlane_table_slots(wb, wb == 5);
       TriplePlan tp = triple_alloc(ctx, mn3, nb, (int)tab2 + (1 << (dual_sliding_bits(wb) - 1)));
+      Fork ft(ctx);                                                        // the two entries into digit form side by side
+      ft.chain(0);
       triple_enter(ctx, mn3, pc.in(), tp, 0);
+      ft.chain(1);
       triple_enter(ctx, mn3, pc.in() + pc.slot_words, tp, 1);
+      ft.join();
       Prog pd;
       emit_modexp_dual(pd, W1, pk->N, 0, 1, 2, 3, 5, tab2, 0, wb, wb == 5);
       pd.end();
@@ -3917,8 +3924,12 @@ uint32_t* dual_pow_n3(pgpu_ctx* ctx, const pgpu_pubkey* pk, const uint32_t* x, c
     const int wb = triple_window_bits(nb, mn3.triple.root->WT);       // 7-bit (or 5-bit) windows of the per-number exponent
     const uint32_t tab2 = 5 + (uint32_t)perlane_table_slots(wb, wb == 5);
     TriplePlan tp = triple_alloc(ctx, mn3, nb, (int)tab2 + (1 << (dual_sliding_bits(wb) - 1)));   // slots: 0 x, 1 y, 2 tmp, 3 out, 5.. / tab2.. the tables
+    Fork ft(ctx);
+    ft.chain(0);
     triple_enter(ctx, mn3, pc.in(), tp, 0);
+    ft.chain(1);
     triple_enter(ctx, mn3, pc.in() + pc.slot_words, tp, 1);
+    ft.join();
     Prog pd;
     emit_modexp_dual(pd, W2, mn2.N, 0, 1, 2, 3, 5, tab2, 0, wb, wb == 5);
     pd.end();
