@@ -79,7 +79,9 @@ int pgpu_ctx_last_profile(pgpu_ctx* ctx, double* vm_ms, int* vm_launches, double
  * as (r^n mod n^2)^n mod n^3.  "side" (default 1): a call may issue work that depends on no ladder in flight to a second
  * stream of the context (the DDLEQ prover's per-statement chains run beside its big launches); 0 keeps one stream.
  * "lanes8" (default 1): batches too small to fill the chip at four lanes per number run ladders modulo n^2 on the eight-lane pair
- * kernel; "muls" (default 1): bucket products of a shared chain of squarings leave the current power in registers (VM_MULS).
+ * kernel (and ladders modulo n^3 on the three-digit kernel with two lanes per digit); "muls" (default 1): bucket products of a shared
+ * chain of squarings leave the current power in registers (VM_MULS); "nm4" (default 1): the window tables of per-number exponents
+ * on the pair kernels are stored number-major (VM_STORET / VM_MULVT / VM_MULVT5: contiguous gathers), 0: limb-major.
  * All of these change the work done, never a result (the tests switch them off to compare).
  * "lanes_wanted" (default 0 = fill the chip): the lane count below which a batch is re-sliced over more lanes per
  * number; 1 keeps every modulus on its natural kernel shape whatever the batch size (tests).
