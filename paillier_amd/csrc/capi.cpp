@@ -93,7 +93,7 @@ struct pgpu_ctx {
   bool use_lanes8 = true;    // shards too small for four lanes per number take the eight-lane pair kernel (pgpu_ctx_set_flag("lanes8", 0): never)
   bool use_side = true;
   hipStream_t side = nullptr;
-  hipStream_t side2 = nullptr;   // second lane: the chain of small kernels of one CRT half (or one operand) beside the other's
+  hipStream_t side_l[3] = {nullptr, nullptr, nullptr};   // further lanes: chains of small kernels of one CRT half / operand beside the others'
   std::vector<hipEvent_t> sync_evs;
   size_t sync_used = 0;
   hipEvent_t next_sync_ev() {
@@ -163,7 +163,7 @@ struct pgpu_ctx {
   // zero the workspace (intermediate values of the last call, ladder programs of secret exponents)
   void wipe_ws() {
     if (side) (void)hipStreamSynchronize(side);
-    if (side2) (void)hipStreamSynchronize(side2);
+    for (auto l : side_l) if (l) (void)hipStreamSynchronize(l);
     for (auto& c : chunks) (void)hipMemsetAsync(c.p, 0, c.cap, stream);
     (void)hipStreamSynchronize(stream);
     for (auto& h : host_keep) wipe_vec(h);
@@ -174,7 +174,7 @@ struct pgpu_ctx {
     for (auto& e : evs) { (void)hipEventDestroy(e.a); (void)hipEventDestroy(e.b); }
     for (auto& e : sync_evs) (void)hipEventDestroy(e);
     if (side) (void)hipStreamDestroy(side);
-    if (side2) (void)hipStreamDestroy(side2);
+    for (auto l : side_l) if (l) (void)hipStreamDestroy(l);
     if (own_stream) (void)hipStreamDestroy(stream);
   }
 };
@@ -190,10 +190,10 @@ struct SideStream {
   hipStream_t main_stream;
   hipStream_t& s;                           // the lane's stream (created on first use)
   bool on, entered = false, dirty = false;
-  // lane 0: work of a call that is independent of its ladders (the prover's per-statement chains).  lane 1: one of two independent
+  // lane 0: work of a call that is independent of its ladders (the prover's per-statement chains).  lanes 1 .. 3: independent
   // CHAINS of small kernels -- the entry into digit form of the q-half next to the p-half's, of operand y next to x's; each such
-  // kernel fills a fraction of the chip for tens of microseconds, two chains side by side take about the time of one.
-  explicit SideStream(pgpu_ctx* c_, int lane = 0) : c(c_), main_stream(c_->stream), s(lane ? c_->side2 : c_->side), on(c_->use_side) {
+  // kernel fills a fraction of the chip for tens of microseconds, chains side by side take about the time of one.
+  explicit SideStream(pgpu_ctx* c_, int lane = 0) : c(c_), main_stream(c_->stream), s(lane ? c_->side_l[lane - 1] : c_->side), on(c_->use_side) {
     if (on && !s) HIPCHK(hipStreamCreateWithFlags(&s, hipStreamNonBlocking));
     if (on && s == main_stream) on = false;   // (nested use of a lane from inside itself: stay in line)
   }
@@ -229,18 +229,33 @@ struct SideStream {
   }
 };
 
-// Two independent chains of small kernels side by side:   Fork f(ctx);  for (k : {0, 1}) { f.chain(k); ... }  f.join();
-// chain(1) moves the context to lane 1 (ordered behind everything issued before the Fork was made), join() comes back and makes
-// the main stream wait.  With the side streams off: plain program order.
+// Up to four independent chains of small kernels side by side:
+//     Fork f(ctx);  for (k : {0, 1}) { f.chain(k); ... }  f.join();            (Fork f(ctx, 4): chains 0 .. 3)
+// chain(0) is the stream the context was on; chain(k > 0) moves the context to side lane k (ordered behind everything issued before
+// the Fork was made; calls with the same k follow each other on their lane); join() comes back and makes the main stream wait
+// for every lane.  The chains must not share a buffer that one of them writes.  With the side streams off: plain program order.
 struct Fork {
-  SideStream ss;
-  hipEvent_t start;
-  explicit Fork(pgpu_ctx* c) : ss(c, 1), start(ss.mark()) {}
-  void chain(int k) {
-    if (k == 1) ss.enter(start);
-    else if (ss.entered) ss.leave();
+  std::vector<std::unique_ptr<SideStream>> lanes;
+  hipEvent_t start = nullptr;
+  int cur = 0;
+  explicit Fork(pgpu_ctx* c, int n = 2) {
+    for (int l = 1; l < n && l <= 3; ++l) lanes.emplace_back(new SideStream(c, l));
+    if (!lanes.empty()) start = lanes[0]->mark();
   }
-  void join() { ss.join(); }
+  void chain(int k) {
+    k %= (int)lanes.size() + 1;
+    if (cur > 0) lanes[(size_t)cur - 1]->leave();
+    cur = k;
+    if (k > 0) {
+      // (a lane whose stream is the one the context is on -- nested use -- stays in line: SideStream switched itself off)
+      lanes[(size_t)k - 1]->enter(lanes[(size_t)k - 1]->dirty ? nullptr : start);
+    }
+  }
+  void join() {
+    if (cur > 0) lanes[(size_t)cur - 1]->leave();
+    cur = 0;
+    for (auto& l : lanes) l->join();
+  }
 };
 
 // ------------------------------------------------------------------------------------------------
@@ -4162,15 +4177,15 @@ bool pow_p2_multi_crt(const pgpu_seckey* sk, const uint32_t* const xs[2], const 
   uint32_t* mem[2];
   Prog pr[2];
   const uint32_t* dig[2] = {r1 ? r1[0] : nullptr, r1 ? r1[1] : nullptr};
-  Fork in(ctx);                                               // the q-half's entry chains beside the p-half's (buffers of their own)
+  Fork in(ctx, 4);                                            // the entry chains of both halves and both operands side by side
   for (int half = 0; half < 2; ++half) {
-    in.chain(half);
-    uint32_t* ent = ctx->ws_t<uint32_t>(S2 * 4);
-    uint32_t* x0 = ctx->ws_t<uint32_t>(S1);
-    uint32_t* tb = ctx->ws_t<uint32_t>(S2);
     const ModCtx &m1 = half ? sk->mq : sk->mp, &m2 = half ? sk->mq2 : sk->mp2;
     mem[half] = ctx->ws_t<uint32_t>(S2 * (size_t)(TAB2 + 64));      // 0 x, 1 y, 2 tmp, 3 out, 5.. / TAB2.. the tables (+ 1 each: x limb-major)
     for (int k = 0; k < ((ys || xs_b) ? 2 : 1); ++k) {
+      in.chain(2 * half + k);
+      uint32_t* ent = ctx->ws_t<uint32_t>(S2 * 4);                   // (buffers of the chain's own)
+      uint32_t* x0 = ctx->ws_t<uint32_t>(S1);
+      uint32_t* tb = ctx->ws_t<uint32_t>(S2);
       // pair-form entry: X = v R_H mod prime^2, then its digits X0 + X1 prime
       HIPCHK(hipMemcpyAsync(ent, k ? (ys ? ys[half] : xs_b[half]) : xs[half], S2 * 4, hipMemcpyDeviceToDevice, ctx->stream));
       Prog a;
@@ -4301,9 +4316,9 @@ void pow_n3_crt(const pgpu_seckey* sk, const uint32_t* base, int wb, const uint3
       const uint32_t *r0[2] = {nullptr, nullptr}, *r1[2] = {nullptr, nullptr}, *x2[2], *y2[2] = {nullptr, nullptr};
       BigU s0[2], s1[2];
       uint32_t *xr[2], *yr3[2] = {nullptr, nullptr};
-      Fork fa(ctx);
+      Fork fa(ctx, 4);
       for (int half = 0; half < 2; ++half) {
-        fa.chain(half);
+        fa.chain(2 * half);
         uint32_t* tbx = ctx->ws_t<uint32_t>(S);
         const ModCtx &m1 = half ? sk->mq : sk->mp, &m2 = half ? sk->mq2 : sk->mp2, &m3 = half ? mq3 : mp3;
         if (exps) {
@@ -4325,6 +4340,7 @@ void pow_n3_crt(const pgpu_seckey* sk, const uint32_t* base, int wb, const uint3
         reduce_mod(ctx, m2, xr[half], W, xx, nb);
         x2[half] = xx;
         if (base2) {
+          fa.chain(2 * half + 1);
           uint32_t* yr = ctx->ws_t<uint32_t>(S);
           reduce_mod(ctx, m3, base2, wb2, yr, nb);
           yr3[half] = yr;
@@ -4340,18 +4356,20 @@ void pow_n3_crt(const pgpu_seckey* sk, const uint32_t* base, int wb, const uint3
         const uint32_t TABW = 5 + (uint32_t)perlane_table_slots(win), TABY = TABW + 64;
         TriplePlan up = triple_alloc(ctx, mp3, nb, (int)TABY + 64), uq = triple_alloc(ctx, mq3, nb, (int)TABY + 64);
         Prog pb[2];
-        Fork fb(ctx);
+        Fork fb(ctx, 4);
         for (int half = 0; half < 2; ++half) {
-          fb.chain(half);
           const ModCtx& m3 = half ? mq3 : mp3;
           const TriplePlan& t = half ? uq : up;
+          fb.chain(2 * half);
           triple_enter(ctx, m3, xr[half], t, 0);
+          fb.chain(2 * half + 1);
           uint32_t* wz = ctx->ws_t<uint32_t>(S);
           launch_copy_limbs(wv[half], 0, W2, wz, W, nb, ctx->stream);
           triple_enter(ctx, m3, wz, t, 1);
           std::vector<SharedBase> sh;
           sh.push_back(SharedBase{half ? sk->q : sk->p, 1, TABW});
           if (base2) {
+            fb.chain(2 * half);
             triple_enter(ctx, m3, yr3[half], t, 4);
             sh.push_back(SharedBase{s0[half], 4, TABY});
           }
@@ -4471,12 +4489,12 @@ bool pow_n3_crt_two(const pgpu_seckey* sk, const uint32_t* A, const uint32_t* co
       const size_t S1 = (size_t)H1 * nb, S2 = (size_t)W2 * nb;
       const uint32_t *a0[2], *a1[2], *b0[2], *b1[2], *A2[2], *B2[2];
       uint32_t *Ar[2], *Br[2];
-      Fork fa(ctx);                                 // (the q-half's chains of small kernels beside the p-half's, here and below)
+      Fork fa(ctx, 4);                              // (the chains of small kernels of both halves and both bases side by side, here and below)
       for (int half = 0; half < 2; ++half) {
-        fa.chain(half);
-        uint32_t* tbx = ctx->ws_t<uint32_t>(S);
         const ModCtx &m1 = half ? sk->mq : sk->mp, &m2 = half ? sk->mq2 : sk->mp2, &m3 = half ? mq3 : mp3;
         for (int k = 0; k < 2; ++k) {
+          fa.chain(2 * half + k);
+          uint32_t* tbx = ctx->ws_t<uint32_t>(S);
           const uint32_t* ex = k ? eb[half] : ea[half];
           uint32_t* t2 = ctx->ws_t<uint32_t>(S2);
           uint32_t* d0 = ctx->ws_t<uint32_t>(S1);
@@ -4504,13 +4522,15 @@ bool pow_n3_crt_two(const pgpu_seckey* sk, const uint32_t* A, const uint32_t* co
         uint32_t* g2 = ctx->ws_t<uint32_t>(S * 6);
         Prog pb[2];
         const uint32_t* dg2[2];
-        Fork fb(ctx);
+        Fork fb(ctx, 4);
         for (int half = 0; half < 2; ++half) {
-          fb.chain(half);
           const ModCtx& m3 = half ? mq3 : mp3;
           const TriplePlan& t = half ? uq : up;
+          fb.chain(2 * half);
           triple_enter(ctx, m3, Ar[half], t, 0);
+          fb.chain(2 * half + 1);
           triple_enter(ctx, m3, Br[half], t, 1);
+          fb.chain(2 * half);
           uint32_t* wz = ctx->ws_t<uint32_t>(S);
           launch_copy_limbs(wv[half], 0, W2, wz, W, nb, ctx->stream);
           triple_enter(ctx, m3, wz, t, 4);
@@ -4910,7 +4930,9 @@ static void ddleq_prove_impl(const pgpu_seckey* sk, size_t S, size_t secpar, con
           uint32_t* ls = ctx->ws_t<uint32_t>(nbg);
           uint32_t* lb = ctx->ws_t<uint32_t>(nbg);
           launch_exp_low_combine(gxn, gan, en, ls, lb, nbg, ctx->stream);
+          Fork fo(ctx);                                                  // the exponents modulo the two group orders side by side
           for (int half = 0; half < 2; ++half) {
+            fo.chain(half);
             const ExpOrder& eo_ = half ? sk->eo_q : sk->eo_p;
             const ModCtx& mm = eo_.modd;
             const size_t sm = (size_t)mm.WT * nbg;
@@ -4931,6 +4953,7 @@ static void ddleq_prove_impl(const pgpu_seckey* sk, size_t S, size_t secpar, con
             es[half] = e1;
             eb[half] = e2;
           }
+          fo.join();
           uint32_t* b3n = zext(ctx, gb, W1, W3, nbg);
           uint32_t* o = ctx->ws_t<uint32_t>((size_t)W3 * nbg);
           if (pow_n3_crt_two(sk, s3, es, b3n, eb, nbg, o)) c5 = o;
