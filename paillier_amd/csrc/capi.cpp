@@ -4886,6 +4886,7 @@ static void ddleq_prove_impl(const pgpu_seckey* sk, size_t S, size_t secpar, con
       }
     if (!idx.empty()) {
       const size_t cnt = idx.size(), nbg = round_up(cnt, VM_BLOCK);
+      if (getenv("PGPU_PROFILE_DUMP")) fprintf(stderr, "[pgpu] prove: %zu of %zu instances drew challenge bit 1 (response batch %zu)\n", cnt, batch, nbg);
       if (any_badinv) {      // ModInverse(a, n^2) of a non-unit a (ddleq.go:95) is undefined in the reference: refuse, as before
         std::vector<int32_t> hb(2 * nbs);
         HIPCHK(hipMemcpyAsync(hb.data(), d_badinv, 2 * nbs * 4, hipMemcpyDeviceToHost, ctx->stream));

@@ -19,7 +19,7 @@ SP = int(sys.argv[2]) if len(sys.argv) > 2 else 1
 BI = int(sys.argv[1]) if len(sys.argv) > 1 else 16384          # instances
 B = BI // SP                                                    # statements
 BI = B * SP
-rg = np.random.default_rng(5)
+rg = np.random.default_rng(int(os.environ.get("PROVE_SEED", "5")))
 def below(mod, nb, cnt=None):
     raw = rg.integers(0, 256, size=(cnt or B, nb), dtype=np.uint8); raw[:, 0] %= np.uint8(max(1, min(255, mod >> (8 * (nb - 1))))); return raw
 def unit(cnt=None):
