@@ -69,6 +69,15 @@ def test_asm_generator_model():
         g = gen_vm_asm.make_gen(wl, k)
         text = g.generate()
         assert g.n_vgpr <= 256
+        # number-major window tables: VM_STORET with VM_MULVT / VM_MULVT5 on the pair kernels that run per-number windows (the
+        # one-lane kernel for 37-limb primes, the two- and four-lane kernels), VM_MULV7 / VM_MULVT5 on the three-digit kernel
+        has = lambda lbl: f"\n{lbl}:" in text
+        if (wl, k) in ((37, 16), (74, 32), (55, 32), (37, 32), (37, 64)):
+            assert has("L_storet") and has("L_mulvt") and has("L_mulvt5") and not has("L_mulv7")
+        elif (wl, k) in gen_vm_asm.TRIPLE:
+            assert has("L_storet") and has("L_mulv7") and has("L_mulvt5") and not has("L_mulvt")
+        else:
+            assert not has("L_storet") and not has("L_mulvt") and not has("L_mulvt5")
         if (wl, k) in gen_vm_asm.PAIR:
             # pair kernel: H(H-1)/2 + H + H^2 multiplies in the unrolled phase 1 of a squaring, 2 H^2 in phase 1 of a product,
             # phase-2 rows of 2H (squaring) and 3H (product) multiplies, one peeled row + a two-row loop body each
