@@ -353,6 +353,11 @@ def main():
         e = {"config": name, "workload": workload, "value": count / dt, "unit": unit, "ms_per_batch": dt * 1e3,
              "kernel": kern, "kernel_ms_per_batch": vms, "executed_mad28": mads,
              "frac": (mads / (vms * 1e-3) / PEAK_MAD_PER_S) if vms else None, "parity": parity}
+        # the same multiplies over the CALL's wall time (rank 0's share of it): `frac` divides by the SUM of the VM launches' own
+        # durations -- a call whose launches overlap (the DDLEQ prover runs a side-stream ladder beside its first one) sums the
+        # overlapped time twice there, and a call with time between its ladders hides that time there
+        if vms and world == 1:
+            e["frac_of_call_time"] = mads / dt / PEAK_MAD_PER_S
         if world > 1:
             e.update({"scaling": scaling, "n_gpus": world})
         return e
