@@ -88,7 +88,8 @@ struct pgpu_ctx {
   size_t lanes_wanted = 0;   // 0: default occupancy target; tests set 1 to run every modulus at its natural shape
   // A second stream for work of a call that depends on no ladder in flight (SideStream below; the DDLEQ prover's
   // per-statement chains run beside its big launches).  pgpu_ctx_set_flag("side", 0): everything on the one stream.
-  bool use_nm4 = true;       // per-number 4-bit window tables of the one-lane pair kernel number-major (pgpu_ctx_set_flag("nm4", 0): limb-major, VM_MULV)
+  bool use_nm4 = true;       // per-number 4- / 5-bit window tables of the pair kernels number-major (pgpu_ctx_set_flag("nm4", 0): limb-major, VM_MULV / VM_MULV5)
+  bool use_early = true;     // the DDLEQ prover prepares its response for every statement / instance beside the Alpha ladders (pgpu_ctx_set_flag("early", 0): after the hash, for the bit-1 instances)
   bool use_muls = true;      // bucket products of the shared chain as VM_MULS where the kernel has it (pgpu_ctx_set_flag("muls", 0): LOAD / MUL / STORE)
   bool use_lanes8 = true;    // shards too small for four lanes per number take the eight-lane pair kernel (pgpu_ctx_set_flag("lanes8", 0): never)
   bool use_side = true;
@@ -1222,6 +1223,7 @@ int pgpu_ctx_set_flag(pgpu_ctx* ctx, const char* name, int value) {
   if (strcmp(name, "lanes8") == 0) { ctx->use_lanes8 = value != 0; return PGPU_OK; }
   if (strcmp(name, "muls") == 0) { ctx->use_muls = value != 0; return PGPU_OK; }
   if (strcmp(name, "nm4") == 0) { ctx->use_nm4 = value != 0; return PGPU_OK; }
+  if (strcmp(name, "early") == 0) { ctx->use_early = value != 0; return PGPU_OK; }
   if (strcmp(name, "fair") == 0) { g_wave_priorities.store(value != 0, std::memory_order_relaxed); return PGPU_OK; }   // process-wide (see above)
   if (strcmp(name, "lanes_wanted") == 0) { ctx->lanes_wanted = value > 0 ? (size_t)value : 0; return PGPU_OK; }
   if (strcmp(name, "cu_partition") == 0) {
@@ -4465,8 +4467,46 @@ void pow_n3_crt(const pgpu_seckey* sk, const uint32_t* base, int wb, const uint3
 // group orders of p^3 and q^3 (ea[half], eb[half]: eo.w limbs): one interleaved ladder per half on the three-digit kernel --
 // two per-number window tables hang off one chain of squarings -- then Garner.  A, B: W3-limb residues.  False when the
 // three-digit kernels do not serve this key / batch.
+// The two bases of the prover's response are per-STATEMENT values (s, b): their residues modulo prime^3 / prime^2 and their digit
+// forms can be made for every statement while the Alpha ladders run (side stream), before the challenge bits say which
+// instances need them; the response then GATHERS them by statement index instead of entering them between two dependent ladders.
+struct PreBases {
+  size_t nbs = 0;                       // statements (stride of the arrays below)
+  const uint32_t* r3[2][2] = {};        // [half][base]: canonical residues modulo prime^3 (mp3.WT limbs)
+  const uint32_t* r2[2][2] = {};        // ... modulo prime^2 (mp2.WT limbs)
+  TriplePlan dig[2];                    // [half]: slot 0 = A, slot 1 = B in digit form
+  const uint32_t* sti = nullptr;        // device: statement of every number of the call
+  size_t cnt = 0;                       // numbers of the call that are real (the rest is padding)
+};
+bool pre_bases_usable(const pgpu_seckey* sk) {
+  return triple_usable(sk->ctx, sk->mp3) && triple_usable(sk->ctx, sk->mq3) && sk->eo_p.ok && sk->eo_q.ok && sk->eo_p.w == sk->eo_q.w;
+}
+void pre_bases(const pgpu_seckey* sk, const uint32_t* A, const uint32_t* B, size_t nbs, PreBases& pre) {
+  pgpu_ctx* ctx = sk->ctx;
+  const ModCtx &mp3 = sk->mp3, &mq3 = sk->mq3;
+  const int W = mp3.WT, W2 = sk->mp2.WT, W3 = sk->pk->mn3->WT;
+  pre.nbs = nbs;
+  Fork f(ctx, 4);
+  for (int half = 0; half < 2; ++half) {
+    const ModCtx &m2 = half ? sk->mq2 : sk->mp2, &m3 = half ? mq3 : mp3;
+    pre.dig[half] = triple_alloc(ctx, m3, nbs, 2);
+    for (int k = 0; k < 2; ++k) {
+      f.chain(2 * half + k);
+      uint32_t* r3 = ctx->ws_t<uint32_t>((size_t)W * nbs);
+      reduce_mod(ctx, m3, k ? B : A, W3, r3, nbs);
+      uint32_t* r2 = ctx->ws_t<uint32_t>((size_t)W2 * nbs);
+      reduce_mod(ctx, m2, r3, W, r2, nbs);
+      triple_enter(ctx, m3, r3, pre.dig[half], (uint32_t)k);
+      pre.r3[half][k] = r3;
+      pre.r2[half][k] = r2;
+    }
+  }
+  f.join();
+}
+
 bool pow_n3_crt_two(const pgpu_seckey* sk, const uint32_t* A, const uint32_t* const ea[2], const uint32_t* B,
-                    const uint32_t* const eb[2], size_t nb, uint32_t* out) {
+                    const uint32_t* const eb[2], size_t nb, uint32_t* out, const PreBases* pre = nullptr) {
+  // pre: A and B are not read; number g of the call is statement pre->sti[g] of the prepared bases
   pgpu_ctx* ctx = sk->ctx;
   const ModCtx &mp3 = sk->mp3, &mq3 = sk->mq3;
   const int W = mp3.WT, W3 = sk->pk->mn3->WT;
@@ -4506,10 +4546,15 @@ bool pow_n3_crt_two(const pgpu_seckey* sk, const uint32_t* A, const uint32_t* co
           (k ? b0 : a0)[half] = d0;
           (k ? b1 : a1)[half] = d1;
           uint32_t* r3 = ctx->ws_t<uint32_t>(S);
-          reduce_mod(ctx, m3, k ? B : A, W3, r3, nb);
-          (k ? Br : Ar)[half] = r3;
           uint32_t* r2 = ctx->ws_t<uint32_t>(S2);
-          reduce_mod(ctx, m2, r3, W, r2, nb);
+          if (pre) {
+            launch_gather(pre->r3[half][k], pre->nbs, pre->sti, pre->cnt, r3, nb, W, ctx->stream);
+            launch_gather(pre->r2[half][k], pre->nbs, pre->sti, pre->cnt, r2, nb, W2, ctx->stream);
+          } else {
+            reduce_mod(ctx, m3, k ? B : A, W3, r3, nb);
+            reduce_mod(ctx, m2, r3, W, r2, nb);
+          }
+          (k ? Br : Ar)[half] = r3;
           (k ? B2 : A2)[half] = r2;
         }
       }
@@ -4527,9 +4572,11 @@ bool pow_n3_crt_two(const pgpu_seckey* sk, const uint32_t* A, const uint32_t* co
           const ModCtx& m3 = half ? mq3 : mp3;
           const TriplePlan& t = half ? uq : up;
           fb.chain(2 * half);
-          triple_enter(ctx, m3, Ar[half], t, 0);
+          if (pre) launch_gather(pre->dig[half].slot(0), pre->nbs, pre->sti, pre->cnt, t.slot(0), nb, 3 * t.H, ctx->stream);
+          else triple_enter(ctx, m3, Ar[half], t, 0);
           fb.chain(2 * half + 1);
-          triple_enter(ctx, m3, Br[half], t, 1);
+          if (pre) launch_gather(pre->dig[half].slot(1), pre->nbs, pre->sti, pre->cnt, t.slot(1), nb, 3 * t.H, ctx->stream);
+          else triple_enter(ctx, m3, Br[half], t, 1);
           fb.chain(2 * half);
           uint32_t* wz = ctx->ws_t<uint32_t>(S);
           launch_copy_limbs(wv[half], 0, W2, wz, W, nb, ctx->stream);
@@ -4581,11 +4628,16 @@ bool pow_n3_crt_two(const pgpu_seckey* sk, const uint32_t* A, const uint32_t* co
     fc.chain(half);
     const ModCtx& m3 = half ? mq3 : mp3;
     const TriplePlan& t = half ? tq : tp;
-    uint32_t* red = half ? ctx->ws_t<uint32_t>(S) : g + 5 * S;       // (a scratch slot per half: the chains run side by side)
-    reduce_mod(ctx, m3, A, W3, red, nb);
-    triple_enter(ctx, m3, red, t, 0);
-    reduce_mod(ctx, m3, B, W3, red, nb);
-    triple_enter(ctx, m3, red, t, 1);
+    if (pre) {
+      launch_gather(pre->dig[half].slot(0), pre->nbs, pre->sti, pre->cnt, t.slot(0), nb, 3 * t.H, ctx->stream);
+      launch_gather(pre->dig[half].slot(1), pre->nbs, pre->sti, pre->cnt, t.slot(1), nb, 3 * t.H, ctx->stream);
+    } else {
+      uint32_t* red = half ? ctx->ws_t<uint32_t>(S) : g + 5 * S;     // (a scratch slot per half: the chains run side by side)
+      reduce_mod(ctx, m3, A, W3, red, nb);
+      triple_enter(ctx, m3, red, t, 0);
+      reduce_mod(ctx, m3, B, W3, red, nb);
+      triple_enter(ctx, m3, red, t, 1);
+    }
     // the two exponents of a number one after the other in the rows of `digits`: windows 0 .. 4 we - 1 and 4 we .. 8 we - 1
     uint32_t* d2 = ctx->ws_t<uint32_t>((size_t)2 * we * nb);
     HIPCHK(hipMemcpyAsync(d2, ea[half], (size_t)we * nb * 4, hipMemcpyDeviceToDevice, ctx->stream));
@@ -4830,7 +4882,9 @@ static void ddleq_prove_impl(const pgpu_seckey* sk, size_t S, size_t secpar, con
     // one of its instances draws challenge bit 1), and the unit test of s b for the one-ladder form of the response
     uint32_t *qainv = ctx->ws_t<uint32_t>((size_t)W2 * nbs), *qani = ctx->ws_t<uint32_t>((size_t)W2 * nbs);
     int32_t* d_badinv = ctx->ws_t<int32_t>(2 * nbs);
-    bool any_badinv = false, sb_units = false;
+    bool any_badinv = false, sb_units = false, early = false;
+    uint32_t *ge_all = nullptr, *es_all[2] = {nullptr, nullptr}, *eb_all[2] = {nullptr, nullptr};
+    PreBases pre;
     const bool one_ladder = crt3 && ctx->use_lift && sk->eo_p.ok && sk->eo_q.ok && sk->eo_p.w == sk->eo_q.w &&
                             W2 <= 2 * sk->eo_p.modd.WT && W2 <= 2 * sk->eo_q.modd.WT;
     side.enter(an_ready);
@@ -4848,6 +4902,55 @@ static void ddleq_prove_impl(const pgpu_seckey* sk, size_t S, size_t secpar, con
         modmul_arrays(ctx, mn, qs, bl, nbs, sb);
         launch_restride(sb, nbs, S, mn.d_consts + (size_t)C_ONE * W1, sb, nbs, W1, ctx->stream);
         sb_units = all_units(ctx, mn, sb, nbs, S);
+      }
+      // The response's per-statement bases (s, b: residues modulo p^3, q^3, p^2, q^2 and digit forms) and, for EVERY instance, its
+      // e = x a^-1, e^n = x^n (a^n)^-1 and the two exponents of the one-ladder response modulo the group orders: nothing here
+      // depends on the challenge bits, so it is done now, beside the Alpha ladders, and the instances that draw bit 1 gather it
+      // afterwards (between the hash and the response ladder there is then a handful of gathers instead of ~150 small kernels).
+      if (one_ladder && sb_units && ctx->use_early && pre_bases_usable(sk)) {
+        early = true;
+        std::vector<uint32_t> stall(nb, 0);
+        for (size_t i = 0; i < batch; ++i) stall[i] = (uint32_t)(i / secpar);
+        const uint32_t* d_stall = ctx->upload_words(stall);
+        auto per_inst_all = [&](const uint32_t* in, int w) {
+          uint32_t* o = ctx->ws_t<uint32_t>((size_t)w * nb);
+          launch_gather(in, nbs, d_stall, batch, o, nb, w, ctx->stream);
+          return o;
+        };
+        uint32_t *ainv_a = per_inst_all(qainv, W2), *ani_a = per_inst_all(qani, W2), *gan_a = per_inst_all(an, W2);
+        uint32_t* x2a = zext(ctx, xl, W1, W2, nb);
+        ge_all = ctx->ws_t<uint32_t>((size_t)W2 * nb);
+        modmul_arrays(ctx, mn2, x2a, ainv_a, nb, ge_all);                     // e = x a^-1 mod n^2 (ddleq.go:94-99)
+        uint32_t* en_a = ctx->ws_t<uint32_t>((size_t)W2 * nb);
+        modmul_arrays(ctx, mn2, xn, ani_a, nb, en_a);                         // e^n = x^n (a^n)^-1
+        uint32_t* ls = ctx->ws_t<uint32_t>(nb);
+        uint32_t* lb = ctx->ws_t<uint32_t>(nb);
+        launch_exp_low_combine(xn, gan_a, en_a, ls, lb, nb, ctx->stream);
+        Fork fo(ctx);
+        for (int half = 0; half < 2; ++half) {
+          fo.chain(half);
+          const ExpOrder& eo_ = half ? sk->eo_q : sk->eo_p;
+          const ModCtx& mm = eo_.modd;
+          const size_t sm = (size_t)mm.WT * nb;
+          uint32_t *am = ctx->ws_t<uint32_t>(sm), *em_ = ctx->ws_t<uint32_t>(sm), *xm = ctx->ws_t<uint32_t>(sm),
+                   *pm = ctx->ws_t<uint32_t>(sm), *esm = ctx->ws_t<uint32_t>(sm), *ebm = ctx->ws_t<uint32_t>(sm),
+                   *zero = ctx->ws_t<uint32_t>(sm);
+          HIPCHK(hipMemsetAsync(zero, 0, sm * 4, ctx->stream));
+          reduce_mod(ctx, mm, gan_a, W2, am, nb);
+          reduce_mod(ctx, mm, en_a, W2, em_, nb);
+          reduce_mod(ctx, mm, xn, W2, xm, nb);
+          modmul_arrays(ctx, mm, am, em_, nb, pm);                                         // an en mod m
+          launch_sub_mod(xm, pm, mm.d_nmod, esm, mm.WT, nb, ctx->stream);                   // xn - an en mod m
+          launch_sub_mod(zero, em_, mm.d_nmod, ebm, mm.WT, nb, ctx->stream);                // -en mod m
+          uint32_t* e1 = ctx->ws_t<uint32_t>((size_t)eo_.w * nb);
+          uint32_t* e2 = ctx->ws_t<uint32_t>((size_t)eo_.w * nb);
+          launch_exp_order_lift(ls, 1, esm, mm.WT, eo_.m_limbs.d, eo_.t, eo_.minv, e1, eo_.w, nb, ctx->stream);
+          launch_exp_order_lift(lb, 1, ebm, mm.WT, eo_.m_limbs.d, eo_.t, eo_.minv, e2, eo_.w, nb, ctx->stream);
+          es_all[half] = e1;
+          eb_all[half] = e2;
+        }
+        fo.join();
+        pre_bases(sk, zext(ctx, qs, W1, W3, nbs), zext(ctx, bl, W1, W3, nbs), nbs, pre);
       }
     }
     side.leave();
@@ -4907,6 +5010,21 @@ static void ddleq_prove_impl(const pgpu_seckey* sk, size_t S, size_t secpar, con
         launch_gather(in, nbs, d_sti, cnt, o, nbg, w, ctx->stream);
         return o;
       };
+      if (early) {
+        // everything but the ladder itself is at hand (side stream, above): gather it for the instances with bit 1
+        uint32_t* ge = gat(ge_all, W2);
+        const uint32_t* es[2] = {gat(es_all[0], sk->eo_p.w), gat(es_all[1], sk->eo_q.w)};
+        const uint32_t* eb[2] = {gat(eb_all[0], sk->eo_p.w), gat(eb_all[1], sk->eo_q.w)};
+        pre.sti = d_sti;
+        pre.cnt = cnt;
+        uint32_t* c5 = ctx->ws_t<uint32_t>((size_t)W3 * nbg);
+        if (!pow_n3_crt_two(sk, nullptr, es, nullptr, eb, nbg, c5, &pre)) api_throw(PGPU_ERR_UNSUPPORTED, "internal: the early response path lost its kernel");
+        uint32_t* y3 = zext(ctx, gat(yl, W1), W1, W3, nbg);
+        uint32_t* gf = ctx->ws_t<uint32_t>((size_t)W3 * nbg);
+        modmul_arrays(ctx, mn3, y3, c5, nbg, gf);                             // f = y c mod n^3 (ddleq.go:114)
+        launch_scatter(ge, nbg, d_idx, cnt, eo, nb, W2, ctx->stream);
+        launch_scatter(gf, nbg, d_idx, cnt, fo, nb, W3, ctx->stream);
+      } else {
       uint32_t *gx = gat(xl, W1), *gy = gat(yl, W1), *gxn = gat(xn, W2);
       uint32_t *ainv = per_inst(qainv, W2), *ani = per_inst(qani, W2), *gan = per_inst(an, W2), *sres = per_inst(qs, W1),
                *gb = per_inst(bl, W1);
@@ -4986,6 +5104,7 @@ static void ddleq_prove_impl(const pgpu_seckey* sk, size_t S, size_t secpar, con
       modmul_arrays(ctx, mn3, y3, c5, nbg, gf);
       launch_scatter(ge, nbg, d_idx, cnt, eo, nb, W2, ctx->stream);
       launch_scatter(gf, nbg, d_idx, cnt, fo, nb, W3, ctx->stream);
+      }
     }
     pack_result(ctx, alp, W3, nb, batch, alpha, ct_stride, mn3.nbytes, mem);
     pack_result(ctx, eo, W2, nb, batch, e_out, e_stride, std::min(e_stride, mn2.nbytes), mem);

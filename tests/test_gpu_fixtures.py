@@ -128,18 +128,22 @@ def test_ddleq_2048_secpar16_from_the_64_instance_fixture(ctx, keys):
     col = lambda key: [s[key] for s in st]
     # side = 0: the per-statement chains on the one stream, in order.  lanes_wanted = 1: the one-lane pair kernel, whose per-number
     # window tables are number-major (VM_STORET / VM_MULVT); nm4 = 0: the same ladders on limb-major tables (VM_MULV)
-    for lanes_wanted, side, nm4 in ((0, 1, 1), (1, 1, 1), (1, 1, 0), (0, 0, 1)):
+    # early = 0: the response is prepared after the hash for the instances with challenge bit 1 (default: for every statement and
+    # instance beside the Alpha ladders, gathered afterwards)
+    for lanes_wanted, side, nm4, early in ((0, 1, 1, 1), (1, 1, 1, 1), (1, 1, 0, 1), (0, 0, 1, 1), (0, 1, 1, 0), (1, 0, 1, 0)):
         ctx.set_flag("lanes_wanted", lanes_wanted)
         ctx.set_flag("side", side)
         ctx.set_flag("nm4", nm4)
+        ctx.set_flag("early", early)
         try:
             al, es, fs = sk.ProveDDLEQBatch(16, col("ct1"), col("ct2"), col("a"), col("b"), xs, ys)
         finally:
             ctx.set_flag("lanes_wanted", 0)
             ctx.set_flag("side", 1)
             ctx.set_flag("nm4", 1)
+            ctx.set_flag("early", 1)
         for j in range(4):
-            assert _digests(al[j], es[j], fs[j]) == [i["digest"] for i in by[j]], (lanes_wanted, side, nm4, j)
+            assert _digests(al[j], es[j], fs[j]) == [i["digest"] for i in by[j]], (lanes_wanted, side, nm4, early, j)
 
 
 def test_ddleq_2048_kernels_off(ctx, keys):
