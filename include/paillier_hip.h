@@ -83,7 +83,9 @@ int pgpu_ctx_last_profile(pgpu_ctx* ctx, double* vm_ms, int* vm_launches, double
  * chain of squarings leave the current power in registers (VM_MULS); "nm4" (default 1): the window tables of per-number exponents
  * on the pair kernels are stored number-major (VM_STORET / VM_MULVT / VM_MULVT5: contiguous gathers), 0: limb-major; "early"
  * (default 1): the DDLEQ prover prepares its response for every statement and instance beside the Alpha ladders and gathers it
- * for the instances whose challenge bit is 1 (0: prepared after the hash, for those instances only).
+ * for the instances whose challenge bit is 1 (0: prepared after the hash, for those instances only); "handover" (default 1): a
+ * power modulo n^2 that the next ladder modulo n^3 needs modulo n^2 only goes from the pair kernel to the digit kernel as
+ * (a0, a1, 0) without leaving Montgomery / pair form (0: exit and re-entry).
  * All of these change the work done, never a result (the tests switch them off to compare).
  * "lanes_wanted" (default 0 = fill the chip): the lane count below which a batch is re-sliced over more lanes per
  * number; 1 keeps every modulus on its natural kernel shape whatever the batch size (tests).

@@ -90,6 +90,7 @@ struct pgpu_ctx {
   // per-statement chains run beside its big launches).  pgpu_ctx_set_flag("side", 0): everything on the one stream.
   bool use_nm4 = true;       // per-number 4- / 5-bit window tables of the pair kernels number-major (pgpu_ctx_set_flag("nm4", 0): limb-major, VM_MULV / VM_MULV5)
   bool use_early = true;     // the DDLEQ prover prepares its response for every statement / instance beside the Alpha ladders (pgpu_ctx_set_flag("early", 0): after the hash, for the bit-1 instances)
+  bool use_handover = true;  // a power modulo n^2 that is only needed modulo n^2 by the next ladder modulo n^3 stays in pair form: (a0, a1, 0) is its digit form (pgpu_ctx_set_flag("handover", 0): exit and re-entry)
   bool use_muls = true;      // bucket products of the shared chain as VM_MULS where the kernel has it (pgpu_ctx_set_flag("muls", 0): LOAD / MUL / STORE)
   bool use_lanes8 = true;    // shards too small for four lanes per number take the eight-lane pair kernel (pgpu_ctx_set_flag("lanes8", 0): never)
   bool use_side = true;
@@ -1224,6 +1225,7 @@ int pgpu_ctx_set_flag(pgpu_ctx* ctx, const char* name, int value) {
   if (strcmp(name, "muls") == 0) { ctx->use_muls = value != 0; return PGPU_OK; }
   if (strcmp(name, "nm4") == 0) { ctx->use_nm4 = value != 0; return PGPU_OK; }
   if (strcmp(name, "early") == 0) { ctx->use_early = value != 0; return PGPU_OK; }
+  if (strcmp(name, "handover") == 0) { ctx->use_handover = value != 0; return PGPU_OK; }
   if (strcmp(name, "fair") == 0) { g_wave_priorities.store(value != 0, std::memory_order_relaxed); return PGPU_OK; }   // process-wide (see above)
   if (strcmp(name, "lanes_wanted") == 0) { ctx->lanes_wanted = value > 0 ? (size_t)value : 0; return PGPU_OK; }
   if (strcmp(name, "cu_partition") == 0) {
@@ -1328,7 +1330,9 @@ void reduce_mod(pgpu_ctx* ctx, const ModCtx& mc, const uint32_t* in, int w_in, u
 
 // pl.in() (canonical, < N) ^ e [* pl.post()] mod N = n^2 on the two-lane pair kernel; result lazy in pl.out()
 void modexp_pair(pgpu_ctx* ctx, const ModCtx& mc, const ModexpPlan& pl, const BigU* e, const uint32_t* exps, int we,
-                 bool use_post, int lanes) {
+                 bool use_post, int lanes, uint32_t** raw_out = nullptr) {
+  // raw_out: the result stays in PAIR form -- *raw_out = its digits (a0 | a1, 2H limbs, stride nb), F R_H = a0 + a1 n (mod n^2) --
+  // for a caller that continues modulo n^3 on the digit kernel (pair_digits of modexp_triple); pl.out() is not written
   const PairInfo& pi = mc.pairn;
   const ModCtx& mn = *pi.root;
   const int H = mn.WT, W2 = mc.WT;
@@ -1379,6 +1383,10 @@ void modexp_pair(pgpu_ctx* ctx, const ModCtx& mc, const ModexpPlan& pl, const Bi
     SegSpec sp{&mc, &p, mem, exps};
     sp.pair = pi.consts; sp.pair_n0inv = mn.n0inv; sp.pair_h = H; sp.pair_lanes = lanes == 8 ? 4 : lanes;
     run_vm(ctx, nb, sp, nullptr, true);
+  }
+  if (raw_out) {
+    *raw_out = mem + 3 * SW;
+    return;
   }
   // (4) F~ = F0 + F1 n, out of pair and Montgomery form, times the plain residue in the post slot
   {
@@ -1459,6 +1467,13 @@ void triple_enter(pgpu_ctx* ctx, const ModCtx& mc, const uint32_t* x, const Trip
   launch_div_exact(Y, W2, 0, d + S1, H, tb, ti.dinv1, mn.d_nmod, H, d + 2 * S1, H, nb, nb, nullptr, 0, ctx->stream);   // X2
 }
 
+// pair form (a0 | a1: 2H limbs, stride tp.nb) of a value that matters modulo n^2 only -> digit form (a0, a1, 0) in slot `slot`
+void triple_from_pair(pgpu_ctx* ctx, const uint32_t* pair_digits, const TriplePlan& tp, uint32_t slot) {
+  const size_t S1 = (size_t)tp.H * tp.nb;
+  HIPCHK(hipMemcpyAsync(tp.slot(slot), pair_digits, 2 * S1 * 4, hipMemcpyDeviceToDevice, ctx->stream));
+  HIPCHK(hipMemsetAsync(tp.slot(slot) + 2 * S1, 0, S1 * 4, ctx->stream));
+}
+
 // digit form in slot `slot` (value F R_H) -> canonical F [* post] mod n^3 in `out` (WT(n^3) limbs); post: plain residue
 void triple_exit(pgpu_ctx* ctx, const ModCtx& mc, const TriplePlan& tp, uint32_t slot, uint32_t* out, const uint32_t* post) {
   const TripleInfo& ti = mc.triple;
@@ -1496,7 +1511,11 @@ void triple_run(pgpu_ctx* ctx, const ModCtx& mc, const TriplePlan& tp, const Pro
 
 // pl.in() (canonical, < n^3) ^ e [* pl.post()] mod n^3 on the three-digit kernel; canonical result in pl.out()
 void modexp_triple(pgpu_ctx* ctx, const ModCtx& mc, const ModexpPlan& pl, const BigU* e, const uint32_t* exps, int we,
-                   bool use_post) {
+                   bool use_post, const uint32_t* pair_digits = nullptr) {
+  // pair_digits: the base is the result W of a ladder modulo n^2 that is still in pair form, W R_H = a0 + a1 n (mod n^2), and only
+  // W mod n^2 matters (the lift: x = x' (mod n^2) implies x^n = x'^n (mod n^3)).  Then (a0, a1, 0) IS the digit form of a valid
+  // base: it stands for W'' = (a0 + a1 n) R_H^-1 mod n^3, and W'' = W (mod n^2) because n^2 divides n^3 -- no exit from pair form,
+  // no entry into digit form (about 30 small kernels between two ladders that depend on each other): one copy and one memset.
   // digit slots: 0 in, 1 (unused), 2 tmp, 3 out, 5.. table (32 entries: sliding windows of a shared exponent, or the 5-bit
   // windows of per-number exponents -- a product costs two squarings here, so the wider window pays)
   const int wb = (exps && !mc.triple.lanes6_only) ? triple_window_bits(pl.nb, mc.triple.root->WT) : 5;   // (GenQ6: limb-major tables)
@@ -1504,7 +1523,8 @@ void modexp_triple(pgpu_ctx* ctx, const ModCtx& mc, const ModexpPlan& pl, const 
   // VM_MULVT5; the two-lanes-per-digit kernel has limb-major tables only)
   const bool nm5 = exps && wb == 5 && !mc.triple.lanes6_only;
   TriplePlan tp = triple_alloc(ctx, mc, pl.nb, 5 + perlane_table_slots(wb, nm5));
-  triple_enter(ctx, mc, pl.in(), tp, 0);
+  if (pair_digits) triple_from_pair(ctx, pair_digits, tp, 0);
+  else triple_enter(ctx, mc, pl.in(), tp, 0);
   Prog p;
   if (exps) {
     emit_modexp_perlane(p, we, 0, NO_SLOT, 2, 3, 5, NO_SLOT, 0, wb, nm5);
@@ -1518,21 +1538,25 @@ void modexp_triple(pgpu_ctx* ctx, const ModCtx& mc, const ModexpPlan& pl, const 
 }
 
 void modexp_shared_run(pgpu_ctx* ctx, const ModCtx& mc, const ModexpPlan& pl, const BigU& e, bool wide, bool use_post,
-                       bool skip_zero) {
+                       bool skip_zero, uint32_t** raw_pair_out = nullptr, const uint32_t* pair_digits_in = nullptr) {
+  // raw_pair_out: if the ladder runs on a pair kernel its result may stay in pair form (*raw_pair_out set, pl.out() not written);
+  // pair_digits_in: the base of a ladder modulo n^3, still in the pair form of the ladder modulo n^2 before it (modexp_triple)
+  if (raw_pair_out) *raw_pair_out = nullptr;
   // two lanes per number from one wave per SIMD upwards; below that four (each digit over two lanes: a squaring is half as
   // long as on the 4-lane 2H-limb kernel, which is what counts when the ladder's latency is the run time)
   if (triple_usable(ctx, mc, true) && !wide && skip_zero && e.bit_length() >= 256) {
-    modexp_triple(ctx, mc, pl, &e, nullptr, 0, use_post);
+    modexp_triple(ctx, mc, pl, &e, nullptr, 0, use_post, pair_digits_in);
     return;
   }
+  if (pair_digits_in) api_throw(PGPU_ERR_UNSUPPORTED, "internal: pair digits handed to a ladder that is not on the digit kernel");
   const bool two = pl.nb * 2 >= (ctx->lanes_wanted ? ctx->lanes_wanted : (size_t)1024 * 64);
   if (mc.pairn.root && ctx->use_asm && ctx->use_pair && !wide && skip_zero && e.bit_length() >= 256 &&
       (two || (mc.pairn.root->WT % 2 == 0 && vm_asm_available(mc.pairn.root->WT / 2, 64)))) {
     // (a batch that leaves SIMDs empty even at four lanes per number is bound by one ladder's latency: eight lanes, GenQ8)
     const size_t lt = ctx->lanes_wanted ? ctx->lanes_wanted : (size_t)1024 * 64;
     const bool eight = !two && mc.pairn.consts8 && ctx->use_lanes8 && pl.nb * 8 <= lt;
-    modexp_pair(ctx, mc, pl, &e, nullptr, 0, use_post, two ? 2 : eight ? 8 : 4);
-    launch_canon(pl.out(), mc.d_nmod, mc.WT, pl.nb, ctx->stream);
+    modexp_pair(ctx, mc, pl, &e, nullptr, 0, use_post, two ? 2 : eight ? 8 : 4, use_post ? nullptr : raw_pair_out);
+    if (!(raw_pair_out && *raw_pair_out)) launch_canon(pl.out(), mc.d_nmod, mc.WT, pl.nb, ctx->stream);
     return;
   }
   Prog p;
@@ -3001,9 +3025,17 @@ static void encrypt_core(const pgpu_pubkey* pk, int level, size_t batch, const u
     ModexpPlan p2 = modexp_alloc(ctx, m2, nb, 32);
     if (r_limbs) reduce_mod(ctx, m2, r_limbs, mc.WT, p2.in(), nb);
     else unpack_mod(ctx, m2, r, r_stride, batch, mem, p2.in(), nb, true);
-    modexp_shared_run(ctx, m2, p2, pk->N, false, false, true);              // y = r^n mod n^2
-    launch_copy_limbs(p2.out(), 0, m2.WT, pl.in(), mc.WT, nb, ctx->stream);
-    modexp_shared_run(ctx, mc, pl, pk->N, false, true, true);               // y^n * g^m mod n^3
+    // (the power stays in pair form when the second ladder runs on the digit kernel of the same n: (a0, a1, 0) is its base)
+    uint32_t* raw = nullptr;
+    const bool digit_next = ctx->use_handover && triple_usable(ctx, mc, true) && pk->N.bit_length() >= 256 && m2.pairn.root &&
+                            mc.triple.root && m2.pairn.root->WT == mc.triple.root->WT;
+    modexp_shared_run(ctx, m2, p2, pk->N, false, false, true, digit_next ? &raw : nullptr);   // y = r^n mod n^2
+    if (raw) {
+      modexp_shared_run(ctx, mc, pl, pk->N, false, true, true, nullptr, raw);                 // y^n * g^m mod n^3
+    } else {
+      launch_copy_limbs(p2.out(), 0, m2.WT, pl.in(), mc.WT, nb, ctx->stream);
+      modexp_shared_run(ctx, mc, pl, pk->N, false, true, true);
+    }
     pack_result(ctx, pl.out(), mc.WT, nb, batch, c, c_stride, mc.nbytes, mem);
     HIPCHK(hipStreamSynchronize(ctx->stream));
     return;
@@ -3379,7 +3411,8 @@ static void pair_leave_and_pack(pgpu_ctx* ctx, const ModCtx& mc, uint32_t* pm, u
 // (4-bit windows of the per-number exponent, sliding windows of e).  x, y: canonical residues (mc.WT limbs, stride nb).
 // Returns the canonical result, or nullptr when the pair kernels do not serve this key / batch.
 static uint32_t* dual_pow_pair(pgpu_ctx* ctx, const ModCtx& mc, const uint32_t* x, const uint32_t* exps, int we, const uint32_t* y,
-                               const BigU& e, size_t nb) {
+                               const BigU& e, size_t nb, uint32_t** raw_out = nullptr) {
+  // raw_out: the result stays in pair form (a0 | a1, stride nb): *raw_out and the return value point at its digits
   const PairInfo& pi = mc.pairn;
   if (!(pi.root && pi.c_one_pair >= 0 && ctx->use_asm && ctx->use_pair)) return nullptr;
   const int H = pi.root->WT, W2 = mc.WT;
@@ -3409,6 +3442,7 @@ static uint32_t* dual_pow_pair(pgpu_ctx* ctx, const ModCtx& mc, const uint32_t* 
   SegSpec sp{&mc, &pd, pm, wb == 5 ? windows5_of(ctx, exps, we, nb) : exps};
   sp.pair = pi.consts; sp.pair_n0inv = pi.root->n0inv; sp.pair_h = H; sp.pair_lanes = two ? 2 : 4;
   run_vm(ctx, nb, sp, nullptr, true);
+  if (raw_out) return *raw_out = pm + 3 * SW;
   return pair_leave(ctx, mc, pm, 3, nb);
 }
 
@@ -3916,17 +3950,26 @@ uint32_t* dual_pow_n3(pgpu_ctx* ctx, const pgpu_pubkey* pk, const uint32_t* x, c
     uint32_t* y2 = ctx->ws_t<uint32_t>((size_t)W2 * nb);
     reduce_mod(ctx, mn2, x, W3, x2, nb);
     reduce_mod(ctx, mn2, y, W3, y2, nb);
-    uint32_t* wv = dual_pow_pair(ctx, mn2, x2, e1, W1, y2, pk->N, nb);
+    // x enters digit form beside the W ladder (a side lane); W itself is handed over in pair form -- (a0, a1, 0) is the digit form
+    // of a representative of W mod n^2, which is all the lift needs (modexp_triple) -- where the pair kernel and the digit
+    // kernel share the root n
+    const int wb = triple_window_bits(nb, mn3.triple.root->WT);
+    const uint32_t tab2 = 5 + (uint32_t)perlane_table_slots(wb, wb == 5);
+    TriplePlan tp = triple_alloc(ctx, mn3, nb, (int)tab2 + (1 << (dual_sliding_bits(wb) - 1)));
+    const bool hand = ctx->use_handover && mn2.pairn.root && mn2.pairn.root->WT == mn3.triple.root->WT;
+    Fork ft(ctx, 3);
+    ft.chain(2);                                   // (lane 2: dual_pow_pair forks its own two entries over lanes 0 and 1)
+    triple_enter(ctx, mn3, pc.in(), tp, 0);
+    ft.chain(0);
+    uint32_t* raw = nullptr;
+    uint32_t* wv = dual_pow_pair(ctx, mn2, x2, e1, W1, y2, pk->N, nb, hand ? &raw : nullptr);
     if (wv) {
-      launch_copy_limbs(wv, 0, W2, pc.in() + pc.slot_words, W3, nb, ctx->stream);      // slot 1 <- W, zero-extended
-      const int wb = triple_window_bits(nb, mn3.triple.root->WT);
-      const uint32_t tab2 = 5 + (uint32_t)perlane_table_slots(wb, wb == 5);
-      TriplePlan tp = triple_alloc(ctx, mn3, nb, (int)tab2 + (1 << (dual_sliding_bits(wb) - 1)));
-      Fork ft(ctx);                                                        // the two entries into digit form side by side
-      ft.chain(0);
-      triple_enter(ctx, mn3, pc.in(), tp, 0);
-      ft.chain(1);
-      triple_enter(ctx, mn3, pc.in() + pc.slot_words, tp, 1);
+      if (raw) {
+        triple_from_pair(ctx, raw, tp, 1);
+      } else {
+        launch_copy_limbs(wv, 0, W2, pc.in() + pc.slot_words, W3, nb, ctx->stream);    // slot 1 <- W, zero-extended
+        triple_enter(ctx, mn3, pc.in() + pc.slot_words, tp, 1);
+      }
       ft.join();
       Prog pd;
       emit_modexp_dual(pd, W1, pk->N, 0, 1, 2, 3, 5, tab2, 0, wb, wb == 5);
@@ -4156,7 +4199,9 @@ void shared_pow(pgpu_ctx* ctx, const ModCtx& mc, const uint32_t* base, int wb, c
 // (mp2.WT limbs, stride nb).  outs[half]: canonical results.  False when the one-lane pair kernel does not serve this key.
 bool pow_p2_multi_crt(const pgpu_seckey* sk, const uint32_t* const xs[2], const uint32_t* const r1[2], int we,
                       const uint32_t* const ys[2], const BigU s1[2], size_t nb, uint32_t* outs[2],
-                      const uint32_t* const xs_b[2] = nullptr, const uint32_t* const r1_b[2] = nullptr) {
+                      const uint32_t* const xs_b[2] = nullptr, const uint32_t* const r1_b[2] = nullptr, bool raw = false) {
+  // raw: outs[half] = the results still in pair form (a0 | a1, 2H limbs, stride nb) for a caller that continues modulo prime^3
+  // on the digit kernel, where (a0, a1, 0) is their digit form (modexp_triple); else canonical residues modulo prime^2
   // xs_b / r1_b: a SECOND base with per-number exponents (the response of the DDLEQ prover: s^(e_s) b^(e_b)), not together with ys
   pgpu_ctx* ctx = sk->ctx;
   if (!(sk->has_pair && sk->pair_lanes == 1 && sk->c_onep_p2 >= 0 && sk->c_onep_q2 >= 0 && sk->c_rh_p2 >= 0 && ctx->use_asm &&
@@ -4222,6 +4267,11 @@ bool pow_p2_multi_crt(const pgpu_seckey* sk, const uint32_t* const xs[2], const 
     sp.pair = sk->pair_p.d; sp.pair_n0inv = sk->mp.n0inv; sp.pair_h = H; sp.pair_lanes = lanes;
     sq.pair = sk->pair_q.d; sq.pair_n0inv = sk->mq.n0inv; sq.pair_h = H; sq.pair_lanes = lanes;
     run_vm(ctx, nb, sp, &sq, true);
+  }
+  if (raw) {
+    outs[0] = mem[0] + 3 * S2;
+    outs[1] = mem[1] + 3 * S2;
+    return true;
   }
   Fork out(ctx);
   for (int half = 0; half < 2; ++half) {
@@ -4353,7 +4403,9 @@ void pow_n3_crt(const pgpu_seckey* sk, const uint32_t* base, int wb, const uint3
       }
       fa.join();
       uint32_t* wv[2];
-      if (pow_p2_multi_crt(sk, x2, exps ? r1 : nullptr, W2, base2 ? y2 : nullptr, s1, nb, wv)) {
+      // (W stays in pair form: the digit kernel of the same prime takes (a0, a1, 0) as W's digit form)
+      const bool hand = ctx->use_handover && sk->mp.WT == mp3.triple.root->WT && sk->mq.WT == mq3.triple.root->WT;
+      if (pow_p2_multi_crt(sk, x2, exps ? r1 : nullptr, W2, base2 ? y2 : nullptr, s1, nb, wv, nullptr, nullptr, hand)) {
         // stage B: slots 0 x, 1 W, 2 tmp, 3 out, 4 y, 5.. the per-number table (128 + 64), then W's and y's odd powers
         const uint32_t TABW = 5 + (uint32_t)perlane_table_slots(win), TABY = TABW + 64;
         TriplePlan up = triple_alloc(ctx, mp3, nb, (int)TABY + 64), uq = triple_alloc(ctx, mq3, nb, (int)TABY + 64);
@@ -4365,9 +4417,13 @@ void pow_n3_crt(const pgpu_seckey* sk, const uint32_t* base, int wb, const uint3
           fb.chain(2 * half);
           triple_enter(ctx, m3, xr[half], t, 0);
           fb.chain(2 * half + 1);
-          uint32_t* wz = ctx->ws_t<uint32_t>(S);
-          launch_copy_limbs(wv[half], 0, W2, wz, W, nb, ctx->stream);
-          triple_enter(ctx, m3, wz, t, 1);
+          if (hand) {
+            triple_from_pair(ctx, wv[half], t, 1);
+          } else {
+            uint32_t* wz = ctx->ws_t<uint32_t>(S);
+            launch_copy_limbs(wv[half], 0, W2, wz, W, nb, ctx->stream);
+            triple_enter(ctx, m3, wz, t, 1);
+          }
           std::vector<SharedBase> sh;
           sh.push_back(SharedBase{half ? sk->q : sk->p, 1, TABW});
           if (base2) {
@@ -4560,7 +4616,8 @@ bool pow_n3_crt_two(const pgpu_seckey* sk, const uint32_t* A, const uint32_t* co
       }
       fa.join();
       uint32_t* wv[2];
-      if (pow_p2_multi_crt(sk, A2, a1, W2, nullptr, nullptr, nb, wv, B2, b1)) {
+      const bool hand = ctx->use_handover && sk->mp.WT == mp3.triple.root->WT && sk->mq.WT == mq3.triple.root->WT;
+      if (pow_p2_multi_crt(sk, A2, a1, W2, nullptr, nullptr, nb, wv, B2, b1, hand)) {
         // stage B: slots 0 A, 1 B, 2 tmp, 3 out, 4 W, 5.. A's table, then B's, then W's odd powers
         const uint32_t TA = 5, TB = TA + (uint32_t)perlane_table_slots(win), TW = TB + (uint32_t)perlane_table_slots(win);
         TriplePlan up = triple_alloc(ctx, mp3, nb, (int)TW + 64), uq = triple_alloc(ctx, mq3, nb, (int)TW + 64);
@@ -4578,9 +4635,13 @@ bool pow_n3_crt_two(const pgpu_seckey* sk, const uint32_t* A, const uint32_t* co
           if (pre) launch_gather(pre->dig[half].slot(1), pre->nbs, pre->sti, pre->cnt, t.slot(1), nb, 3 * t.H, ctx->stream);
           else triple_enter(ctx, m3, Br[half], t, 1);
           fb.chain(2 * half);
-          uint32_t* wz = ctx->ws_t<uint32_t>(S);
-          launch_copy_limbs(wv[half], 0, W2, wz, W, nb, ctx->stream);
-          triple_enter(ctx, m3, wz, t, 4);
+          if (hand) {
+            triple_from_pair(ctx, wv[half], t, 4);
+          } else {
+            uint32_t* wz = ctx->ws_t<uint32_t>(S);
+            launch_copy_limbs(wv[half], 0, W2, wz, W, nb, ctx->stream);
+            triple_enter(ctx, m3, wz, t, 4);
+          }
           uint32_t* d2 = ctx->ws_t<uint32_t>((size_t)2 * H1 * nb);
           HIPCHK(hipMemcpyAsync(d2, a0[half], S1 * 4, hipMemcpyDeviceToDevice, ctx->stream));
           HIPCHK(hipMemcpyAsync(d2 + S1, b0[half], S1 * 4, hipMemcpyDeviceToDevice, ctx->stream));
