@@ -192,3 +192,38 @@ def test_split_through_n_squared_on_and_off(ctx):
     assert got[1][1] == [bool(i["verify_wrong_ct2"]) for i in ins]
     pick = list(range(6)) + list(range(len(cts) - 6, len(cts)))
     assert [got[1][2][i] for i in pick] == [pow(cts[i], pow(a_s[i], n, n2), n3) * pow(b_s[i], n2, n3) % n3 for i in pick]
+
+
+@pytest.mark.parametrize("batch", [70, 600])
+def test_pair_form_handed_to_the_digit_kernel(ctx, batch):
+    """The power modulo n^2 of a lift goes to the ladder modulo n^3 as (a0, a1, 0) -- its pair digits with a zero third digit --
+    instead of leaving pair form and entering digit form (flag handover = 0): level-two Encrypt (incl. r = 1, r = n - 1, whose
+    power has digit a1 = 0 or small), NestedRandomize-style dual ladders through VerifyDDLEQ, both ways, same integers; the
+    encryptions also against the oracle."""
+    import paillier_amd as pa
+    k = json.load(open(os.path.join(G, "keys.json")))["paillier"]["2048"]
+    p, q = int(k["p"], 16), int(k["q"], 16)
+    n, lam = p * q, (p - 1) * (q - 1)
+    n2 = n * n
+    sk_o = po.SecretKey(N=n, G=n + 1, Lambda=lam)
+    pk = pa.PublicKey(ctx, n, n + 1)
+    rng = random.Random(batch)
+    ms = [0, 1, n2 - 1] + [rng.randrange(n2) for _ in range(batch - 3)]
+    rs = [1, n - 1, 2] + [po.rand_unit(n, rng) for _ in range(batch - 3)]
+    H_ = lambda xs: [int(x, 16) for x in xs]
+    d = json.load(open(os.path.join(G, "proofs.json")))["ddleq"]
+    st = [{kk: int(v, 16) for kk, v in s.items()} for s in d["statements"]]
+    ins = d["instances"][:16]
+    col = lambda key: [st[i["s"]][key] for i in ins]
+    xs, ys = H_(i["x"] for i in ins), H_(i["y"] for i in ins)
+    al, es, fs = H_(i["alpha"] for i in ins), H_(i["e"] for i in ins), H_(i["f"] for i in ins)
+    res = {}
+    for flag in (1, 0):
+        ctx.set_flag("handover", flag)
+        try:
+            res[flag] = pk.EncryptWithRBatch(ms, rs, level=pa.ENC_LEVEL_TWO)
+            assert pk.VerifyDDLEQInstancesBatch(col("ct1"), col("ct2"), xs, ys, al, es, fs) == [True] * 16
+        finally:
+            ctx.set_flag("handover", 1)
+    assert res[1] == res[0]
+    assert res[1][:8] == [po.encrypt_with_r_at_level(sk_o, m, r, po.ENC_LEVEL_TWO).C for m, r in zip(ms[:8], rs[:8])]
