@@ -4968,7 +4968,9 @@ static void ddleq_prove_impl(const pgpu_seckey* sk, size_t S, size_t secpar, con
       // e = x a^-1, e^n = x^n (a^n)^-1 and the two exponents of the one-ladder response modulo the group orders: nothing here
       // depends on the challenge bits, so it is done now, beside the Alpha ladders, and the instances that draw bit 1 gather it
       // afterwards (between the hash and the response ladder there is then a handful of gathers instead of ~150 small kernels).
-      if (one_ladder && sb_units && ctx->use_early && pre_bases_usable(sk)) {
+      // (only where the response ladder is certain to take pow_n3_crt_two's kernels whatever the number of bit-1 instances turns out
+      // to be: its 7-bit window tables must fit the gather offsets even if every instance draws bit 1)
+      if (one_ladder && sb_units && ctx->use_early && pre_bases_usable(sk) && triple_window_bits(nb, sk->mp3.triple.root->WT) == 7) {
         early = true;
         std::vector<uint32_t> stall(nb, 0);
         for (size_t i = 0; i < batch; ++i) stall[i] = (uint32_t)(i / secpar);
