@@ -50,3 +50,12 @@ for _ in range(2):
     else:
         sk.ddleq_prove_secpar_raw(B, SP, ct1.data_ptr(), ct2.data_ptr(), da.data_ptr(), db.data_ptr(), dx.data_ptr(), dy.data_ptr(), al.data_ptr(), pe.data_ptr(), pf.data_ptr(), MEM_DEVICE)
     print("prove", B, "x", SP, (time.perf_counter() - t) * 1e3, "ms", ctx.last_profile(), flush=True)
+if os.environ.get("PROVE_VERIFY"):
+    # every instance against its statement (device-resident pgpu_ddleq_verify; statement rows repeated per instance)
+    rep = lambda tns: tns.repeat_interleave(SP, dim=0).contiguous() if SP > 1 else tns
+    c1r, c2r = rep(ct1), rep(ct2)
+    ok = np.zeros(BI, dtype=np.int32)
+    t = time.perf_counter()
+    pk.ddleq_verify_raw(BI, c1r.data_ptr(), c2r.data_ptr(), dx.data_ptr(), dy.data_ptr(), al.data_ptr(), pe.data_ptr(), pf.data_ptr(), ok, MEM_DEVICE)
+    print("verify", BI, (time.perf_counter() - t) * 1e3, "ms; accepted", int(ok.sum()), "of", BI, ctx.last_profile(), flush=True)
+    assert int(ok.sum()) == BI
