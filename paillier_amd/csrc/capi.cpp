@@ -4361,8 +4361,11 @@ void pow_n3_crt(const pgpu_seckey* sk, const uint32_t* base, int wb, const uint3
     const bool reduced_pn = !exps || (ex[0] != exps && ex[1] != exps && wex[0] == sk->eo_p.w && wex[1] == sk->eo_q.w);
     const size_t lanes_target_s = ctx->lanes_wanted ? ctx->lanes_wanted : (size_t)1024 * 64;
     // (below one wave per SIMD for the stage modulo p^2 the ladders are bound by their length, and one ladder is shorter than two)
-    if (ctx->use_lift && reduce_e && (exps || base2) && reduced_pn && win == 7 && sk->mp2.WT == 2 * sk->mp.WT && nb * 4 >= lanes_target_s &&
-        sk->eo_p.w <= 3 * sk->mp.WT && sk->pinv2k_2.d && (uint64_t)nb * 3 * sk->mp.WT * 4 * 129 < (1ull << 32)) {
+    // (7-bit windows of r0 while their 128-entry tables fit the 32-bit gather offsets -- 75 000 numbers for 37-limb primes --
+    // and 5-bit windows on number-major tables beyond: a big batch keeps the split, it does not fall back to the long ladder)
+    if (ctx->use_lift && reduce_e && (exps || base2) && reduced_pn && (win == 7 || nm5) && sk->mp2.WT == 2 * sk->mp.WT && nb * 4 >= lanes_target_s &&
+        sk->eo_p.w <= 3 * sk->mp.WT && sk->pinv2k_2.d &&
+        (uint64_t)nb * 3 * sk->mp.WT * 4 * (uint64_t)(perlane_table_slots(win, nm5) + 1) < (1ull << 32)) {
       const int H = sk->mp.WT, W2 = sk->mp2.WT;
       const size_t S1 = (size_t)H * nb, S2 = (size_t)W2 * nb;
       const uint32_t *r0[2] = {nullptr, nullptr}, *r1[2] = {nullptr, nullptr}, *x2[2], *y2[2] = {nullptr, nullptr};
@@ -4407,7 +4410,7 @@ void pow_n3_crt(const pgpu_seckey* sk, const uint32_t* base, int wb, const uint3
       const bool hand = ctx->use_handover && sk->mp.WT == mp3.triple.root->WT && sk->mq.WT == mq3.triple.root->WT;
       if (pow_p2_multi_crt(sk, x2, exps ? r1 : nullptr, W2, base2 ? y2 : nullptr, s1, nb, wv, nullptr, nullptr, hand)) {
         // stage B: slots 0 x, 1 W, 2 tmp, 3 out, 4 y, 5.. the per-number table (128 + 64), then W's and y's odd powers
-        const uint32_t TABW = 5 + (uint32_t)perlane_table_slots(win), TABY = TABW + 64;
+        const uint32_t TABW = 5 + (uint32_t)perlane_table_slots(win, nm5), TABY = TABW + 64;
         TriplePlan up = triple_alloc(ctx, mp3, nb, (int)TABY + 64), uq = triple_alloc(ctx, mq3, nb, (int)TABY + 64);
         Prog pb[2];
         Fork fb(ctx, 4);
@@ -4433,11 +4436,12 @@ void pow_n3_crt(const pgpu_seckey* sk, const uint32_t* base, int wb, const uint3
           }
           std::vector<PerNumberBase> pn;
           if (exps) pn.push_back(PerNumberBase{H, 0, 5, 0});
-          emit_modexp_multi(pb[half], pn, win, sh, 2, 3, 0);
+          emit_modexp_multi(pb[half], pn, win, sh, 2, 3, 0, nm5);
           pb[half].end();
         }
         fb.join();
-        SegSpec sp{&mp3, &pb[0], up.mem, r0[0]}, sq{&mq3, &pb[1], uq.mem, r0[1]};
+        SegSpec sp{&mp3, &pb[0], up.mem, r0[0] ? triple_windows(ctx, r0[0], H, nb, win) : nullptr},
+                sq{&mq3, &pb[1], uq.mem, r0[1] ? triple_windows(ctx, r0[1], H, nb, win) : nullptr};
         sp.pair = mp3.triple.kconsts; sp.pair_n0inv = sk->mp.n0inv; sp.pair_h = up.H; sp.pair_lanes = 3; sp.tconsts = mp3.triple.tconsts;
         sq.pair = mq3.triple.kconsts; sq.pair_n0inv = sk->mq.n0inv; sq.pair_h = uq.H; sq.pair_lanes = 3; sq.tconsts = mq3.triple.tconsts;
         run_vm(ctx, nb, sp, &sq, true);
