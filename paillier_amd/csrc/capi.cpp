@@ -1720,6 +1720,51 @@ uint32_t* tree_inverse(pgpu_ctx* ctx, const ModCtx& mc, const uint32_t* x, size_
 // Are ALL of x[0 .. count) units modulo N?  The up-sweep of the same product tree and one gcd on the host -- half the
 // launches of tree_inverse and no inverses; what the randomness filter needs (utils.go:43: gcd(r, n) = 1) in the
 // overwhelmingly likely case that every draw is a unit.
+// all_units in two halves for a caller that has something to run meanwhile: begin() issues the product tree (to the stream the
+// context is on) and leaves the root's bytes on the device, finish() fetches them, waits and tests the gcd on the host.
+struct UnitCheck {
+  pgpu_ctx* ctx = nullptr;
+  const ModCtx* mc = nullptr;
+  uint8_t* d_rb = nullptr;
+  hipStream_t st = nullptr;
+  std::unique_ptr<SideStream> side;
+  bool begun = false;
+  void begin(pgpu_ctx* c, const ModCtx& m, const uint32_t* x, size_t nb, size_t count);
+  bool finish() {
+    std::vector<uint8_t> rb(mc->nbytes);
+    HIPCHK(hipMemcpyAsync(rb.data(), d_rb, mc->nbytes, hipMemcpyDeviceToHost, st));
+    HIPCHK(hipStreamSynchronize(st));
+    if (side) side->dirty = false;
+    BigU root = BigU::from_be(rb.data(), rb.size()), rinv;
+    return hostbig::modinv(root, mc->N, rinv);
+  }
+};
+void UnitCheck::begin(pgpu_ctx* c, const ModCtx& m, const uint32_t* x, size_t nb, size_t count) {
+  ctx = c;
+  mc = &m;
+  st = c->stream;
+  begun = true;
+  const int WT = m.WT;
+  size_t nbt = VM_BLOCK;
+  int L = 8;
+  while (nbt < count) { nbt <<= 1; ++L; }
+  const size_t sw = (size_t)WT * nbt;
+  uint32_t* mem = ctx->ws_t<uint32_t>(sw * 3);                      // slots: 0 V, 1 U (upper half moved down), 2 O
+  HIPCHK(hipMemsetAsync(mem + sw, 0, sw * 4, ctx->stream));
+  launch_restride(x, nb, count, m.d_consts + (size_t)C_ONE * WT, mem, nbt, WT, ctx->stream);
+  for (int k = 0; k < L; ++k) {
+    const size_t half = nbt >> (k + 1);
+    HIPCHK(hipMemcpy2DAsync(mem + sw, nbt * 4, mem + half, nbt * 4, half * 4, (size_t)WT, hipMemcpyDeviceToDevice, ctx->stream));
+    Prog p;
+    p.op(VM_LOAD, 0); p.op(VM_MUL, 1); p.op(VM_STORE, 0); p.end();
+    SegSpec sg{&m, &p, mem, nullptr};
+    run_vm(ctx, nbt, sg, nullptr, false, std::max<size_t>(VM_BLOCK, half));
+  }
+  launch_canon(mem, m.d_nmod, WT, nbt, ctx->stream);
+  d_rb = (uint8_t*)ctx->ws(m.nbytes);
+  launch_pack_be(mem, WT, nbt, 1, d_rb, m.nbytes, m.nbytes, ctx->stream);
+}
+
 bool all_units(pgpu_ctx* ctx, const ModCtx& mc, const uint32_t* x, size_t nb, size_t count) {
   const int WT = mc.WT;
   size_t nbt = VM_BLOCK;
@@ -3117,7 +3162,11 @@ static void draw_below(const std::vector<uint8_t>& n_be, uint8_t top_mask, uint8
 
 // `count` uniform elements of Z_n^* as canonical limbs on the device (mn.WT limbs, stride nb); host_out (optional): the
 // same values as big-endian bytes, k = byte length of n per element
-static uint32_t* random_units_device(const pgpu_pubkey* pk, size_t count, size_t nb, std::vector<uint8_t>* host_out) {
+static uint32_t* random_units_device(const pgpu_pubkey* pk, size_t count, size_t nb, std::vector<uint8_t>* host_out,
+                                     UnitCheck* deferred = nullptr) {
+  // deferred: the unit test of the draws is only STARTED (on the side stream); the caller runs its ladder on them meanwhile and
+  // asks deferred->finish() afterwards -- a non-unit among uniform draws modulo an honest n would be a factor of n, so the
+  // test all but never fails, and when it does the caller draws again the careful way
   pgpu_ctx* ctx = pk->ctx;
   const ModCtx& mn = pk->mn;
   std::vector<uint8_t> n_be = pk->N.to_be_min();
@@ -3134,6 +3183,13 @@ static uint32_t* random_units_device(const pgpu_pubkey* pk, size_t count, size_t
     launch_unpack_be(stage, k, k, count, limbs, mn.WT, nb, ctx->stream);
     // padding lanes: 1 (a unit), so that the tree sees units only
     launch_restride(limbs, nb, count, mn.d_consts + (size_t)C_ONE * mn.WT, limbs, nb, mn.WT, ctx->stream);
+    if (deferred && ctx->use_side) {
+      deferred->side.reset(new SideStream(ctx, 0));
+      deferred->side->enter(deferred->side->mark());
+      deferred->begin(ctx, mn, limbs, nb, count);
+      deferred->side->leave();
+      break;
+    }
     if (all_units(ctx, mn, limbs, nb, count)) break;
     bool any_bad = false;
     (void)batch_inverse(ctx, mn, limbs, nb, count, d_bad, &any_bad);      // names the lanes to redraw
@@ -3177,14 +3233,20 @@ int pgpu_encrypt(const pgpu_pubkey* pk, int level, size_t batch, const uint8_t* 
     ctx->reset_ws();
     const ModCtx& mc = cipher_mod(pk, level);
     const size_t nb = round_up(batch, VM_BLOCK);
-    uint32_t* r1 = random_units_device(pk, batch, nb, nullptr);          // paillier.go:263: r in Z_n^* for either level
-    if (r_out) pack_result(ctx, r1, pk->mn.WT, nb, batch, r_out, r_stride, pk->mn.nbytes, mem);
-    uint32_t* rw = r1;
-    if (mc.WT != pk->mn.WT) {                                            // zero-extend to the width of n^(s+1)
-      rw = ctx->ws_t<uint32_t>((size_t)mc.WT * nb);
-      launch_copy_limbs(r1, 0, pk->mn.WT, rw, mc.WT, nb, ctx->stream);
+    // the gcd test of the draws runs beside the ladder (side stream); should it ever fail, the call is redone with the test first
+    for (int attempt = 0; attempt < 2; ++attempt) {
+      UnitCheck chk;
+      uint32_t* r1 = random_units_device(pk, batch, nb, nullptr, attempt == 0 ? &chk : nullptr);   // paillier.go:263: r in Z_n^* for either level
+      if (r_out) pack_result(ctx, r1, pk->mn.WT, nb, batch, r_out, r_stride, pk->mn.nbytes, mem);
+      uint32_t* rw = r1;
+      if (mc.WT != pk->mn.WT) {                                            // zero-extend to the width of n^(s+1)
+        rw = ctx->ws_t<uint32_t>((size_t)mc.WT * nb);
+        launch_copy_limbs(r1, 0, pk->mn.WT, rw, mc.WT, nb, ctx->stream);
+      }
+      encrypt_core(pk, level, batch, m, m_stride, nullptr, 0, rw, c, c_stride, mem);
+      if (!chk.begun || chk.finish()) break;
+      ctx->reset_ws();
     }
-    encrypt_core(pk, level, batch, m, m_stride, nullptr, 0, rw, c, c_stride, mem);
   });
 }
 
