@@ -4427,7 +4427,7 @@ void pow_n3_crt(const pgpu_seckey* sk, const uint32_t* base, int wb, const uint3
     // and 5-bit windows on number-major tables beyond: a big batch keeps the split, it does not fall back to the long ladder)
     if (ctx->use_lift && reduce_e && (exps || base2) && reduced_pn && (win == 7 || nm5) && sk->mp2.WT == 2 * sk->mp.WT && nb * 4 >= lanes_target_s &&
         sk->eo_p.w <= 3 * sk->mp.WT && sk->pinv2k_2.d &&
-        (uint64_t)nb * 3 * sk->mp.WT * 4 * (uint64_t)(perlane_table_slots(win, nm5) + 1) < (1ull << 32)) {
+        (uint64_t)nb * 3 * sk->mp.WT * 4 * (uint64_t)((1u << win) + 1) < (1ull << 32)) {   // (what the gathers address: the number-major entries)
       const int H = sk->mp.WT, W2 = sk->mp2.WT;
       const size_t S1 = (size_t)H * nb, S2 = (size_t)W2 * nb;
       const uint32_t *r0[2] = {nullptr, nullptr}, *r1[2] = {nullptr, nullptr}, *x2[2], *y2[2] = {nullptr, nullptr};
