@@ -152,7 +152,26 @@ func (k *GPUPublicKey) many(ops [][]*Ciphertext, sub bool) ([]*Ciphertext, error
 	cs := k.cipherBytes(level)
 	stride := cs
 	for _, op := range ops {
+		if len(op) != batch { // the C side reads `batch` rows of every operand
+			return nil, errors.New("paillier: operand batches differ in length")
+		}
 		stride = maxLen(cvals(op), stride)
+	}
+	if len(ops) == 2 {
+		// the common two-operand form: flat buffers as direct arguments (pgpu_add / pgpu_sub), no pointer array, no C copies
+		a, b, out := pack(cvals(ops[0]), stride), pack(cvals(ops[1]), stride), make([]byte, batch*cs)
+		var rc C.int
+		if sub {
+			rc = C.pgpu_sub(k.h, C.int(level), C.size_t(batch), p8(a), C.size_t(stride), p8(b), C.size_t(stride), p8(out), C.size_t(cs),
+				C.PGPU_MEM_HOST, nil)
+		} else {
+			rc = C.pgpu_add(k.h, C.int(level), C.size_t(batch), p8(a), C.size_t(stride), p8(b), C.size_t(stride), p8(out), C.size_t(cs),
+				C.PGPU_MEM_HOST)
+		}
+		if err := status(rc); err != nil {
+			return nil, err
+		}
+		return cts(unpack(out, cs), level, MixedEncryption), nil
 	}
 	in := newCbufs(len(ops)) // C copies of the operands: no Go pointer is stored in C memory
 	defer in.free()
@@ -306,6 +325,48 @@ func (k *GPUPublicKey) PartialDecryptIndexedBatch(tsks []*ThresholdSecretKey, se
 	res := make([]*PartialDecryption, len(c))
 	for i, v := range unpack(out, cs) {
 		res[i] = &PartialDecryption{tsks[serverIndex[i]].ID, v}
+	}
+	return res, nil
+}
+
+// PartialDecryptUnitsBatch: what ONE rank of the sharded threshold flow computes (BASELINE config 4 over N GPUs).  The
+// (server, ciphertext) units u = s*len(c) + i of the whole job -- server-major over tsks and the ONE ciphertext batch c -- are
+// split into contiguous ranges; this call computes the range [unitBegin, unitEnd): res[u - unitBegin] =
+// tsks[u / len(c)].PartialDecrypt(c[u % len(c)]) (thresholdkey.go:192-201).  Unlike PartialDecryptIndexedBatch the library sees
+// that two units are the SAME ciphertext under two shares: such ciphertexts walk one chain of squarings for both exponents
+// (pgpu_partial_decrypt_units; a rank of two holds one server whole and half of the next).  Only the shares of the servers
+// the range touches are read.
+func (k *GPUPublicKey) PartialDecryptUnitsBatch(tsks []*ThresholdSecretKey, c []*gmp.Int, unitBegin, unitEnd int) ([]*PartialDecryption, error) {
+	defer pin()()
+	n := len(tsks)
+	if n == 0 || len(c) == 0 {
+		return nil, errors.New("paillier: no shares or no ciphertexts")
+	}
+	if unitBegin < 0 || unitBegin >= unitEnd || unitEnd > n*len(c) {
+		return nil, errors.New("paillier: unit range out of bounds")
+	}
+	cs := k.cipherBytes(EncLevelOne)
+	cb, out := pack(c, cs), make([]byte, (unitEnd-unitBegin)*cs)
+	shp := newCbufs(n) // the shares in C memory: no Go pointer is stored in a C array
+	defer shp.free()
+	lens := (*[1 << 20]C.size_t)(C.calloc(C.size_t(n), C.size_t(unsafe.Sizeof(C.size_t(0)))))
+	defer C.free(unsafe.Pointer(lens))
+	for i, t := range tsks {
+		sh := bytesOf(t.Share)
+		shp.in(i, sh)
+		lens[i] = C.size_t(len(sh))
+	}
+	rc := C.pgpu_partial_decrypt_units(k.h, C.int(tsks[0].TotalNumberOfDecryptionServers), C.int(n), shp.array(), &lens[0],
+		C.size_t(len(c)), p8(cb), C.size_t(cs), C.size_t(unitBegin), C.size_t(unitEnd), p8(out), C.size_t(cs), C.PGPU_MEM_HOST)
+	for i := range tsks { // the C copies of the shares are secrets: clear them before they are freed
+		C.memset(unsafe.Pointer(shp.ptrs[i]), 0, C.size_t(shp.lens[i]))
+	}
+	if err := status(rc); err != nil {
+		return nil, err
+	}
+	res := make([]*PartialDecryption, unitEnd-unitBegin)
+	for j, v := range unpack(out, cs) {
+		res[j] = &PartialDecryption{tsks[(unitBegin+j)/len(c)].ID, v}
 	}
 	return res, nil
 }

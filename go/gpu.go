@@ -15,7 +15,7 @@
 //   - a Go slice is passed to C only as a DIRECT argument of one blocking call (cgo pins it for that call) and C keeps no
 //     Go pointer afterwards;
 //   - no Go pointer is ever STORED in C memory: the entry points that take arrays of buffers (pgpu_add_many, pgpu_sub_many,
-//     pgpu_partial_decrypt_multi, pgpu_partial_decrypt_indexed, pgpu_combine_partial_decryptions, pgpu_random_oracle_digest)
+//     pgpu_partial_decrypt_multi, pgpu_partial_decrypt_indexed, pgpu_partial_decrypt_units, pgpu_combine_partial_decryptions, pgpu_random_oracle_digest)
 //     get C.malloc'd pointer arrays whose entries point at C.malloc'd copies of the operands (cbufs below), and their
 //     outputs are copied back with C.GoBytes;
 //   - pgpu_last_error() is thread-local in the library: every method that makes a C call pins its goroutine to one OS
@@ -154,6 +154,40 @@ func (g *GPU) Close() {
 	}
 }
 
+// Version is the library's version string (pgpu_version).
+func Version() string { return C.GoString(C.pgpu_version()) }
+
+// SetFlag flips a runtime switch of the context (pgpu_ctx_set_flag: "asm", "pair", "side", "lanes_wanted" ...; measurement
+// and test switches -- the defaults are the product configuration).
+func (g *GPU) SetFlag(name string, value int) error {
+	defer pin()()
+	cn := C.CString(name)
+	defer C.free(unsafe.Pointer(cn))
+	return status(C.pgpu_ctx_set_flag(g.ctx, cn, C.int(value)))
+}
+
+// Profile of the LAST batch call on this context: HIP-event time of its big-integer VM launches, their number (how many of
+// them ran the hand-scheduled assembly kernels) and the 28-bit multiply-adds they executed; Kernel names the dominant one.
+type Profile struct {
+	VMms         float64
+	Launches     int
+	AsmLaunch    int
+	AllLaunch    int
+	MultiplyAdds float64
+	Kernel       string
+}
+
+func (g *GPU) LastProfile() (Profile, error) {
+	defer pin()()
+	var ms, mads C.double
+	var n C.int
+	if err := status(C.pgpu_ctx_last_profile(g.ctx, &ms, &n, &mads)); err != nil {
+		return Profile{}, err
+	}
+	return Profile{float64(ms), int(n), int(C.pgpu_ctx_last_vm_asm(g.ctx)), int(C.pgpu_ctx_last_vm_launches(g.ctx)), float64(mads),
+		C.GoString(C.pgpu_ctx_last_kernel(g.ctx))}, nil
+}
+
 // ---- packing -------------------------------------------------------------------------------------------------------
 
 func pack(xs []*gmp.Int, stride int) []byte {
@@ -257,3 +291,7 @@ func (k *GPUPublicKey) UploadSecret(sk *SecretKey) (*GPUSecretKey, error) {
 }
 
 func (s *GPUSecretKey) Close() { C.pgpu_seckey_destroy(s.h); s.h = nil }
+
+// HasCRT reports whether (n, lambda) factored n, i.e. whether Decrypt runs over p^2 and q^2 (pgpu_seckey_has_crt); keys whose
+// Lambda is not phi(n) take the reference's formula verbatim.
+func (s *GPUSecretKey) HasCRT() bool { return C.pgpu_seckey_has_crt(s.h) != 0 }

@@ -26,6 +26,11 @@
 extern "C" {
 #endif
 
+/* the library is built with -fvisibility=hidden: only what this header (and paillier_hip_debug.h) declares is exported */
+#if defined(__GNUC__)
+#pragma GCC visibility push(default)
+#endif
+
 #define PGPU_OK 0
 #define PGPU_ERR_INVALID (-1)       /* bad argument (size, level, null pointer, even modulus ...) */
 #define PGPU_ERR_NO_DEVICE (-2)     /* no HIP device / not gfx950 */
@@ -310,21 +315,11 @@ int pgpu_modinv(const pgpu_modulus* mod, size_t batch, const uint8_t* x, size_t 
 int pgpu_modmul(const pgpu_modulus* mod, size_t batch, const uint8_t* a, size_t a_stride, size_t a_len,
                 const uint8_t* b, size_t b_stride, size_t b_len, uint8_t* out, size_t out_stride, int mem);
 
-/* ---- test hook -------------------------------------------------------------------------------------- */
-/* Runs a raw VM program (kernels.h opcodes; pairs of words) on raw slot memory: host array of 28-bit limbs,
- * limb-major [slot][WT][nb], nb a multiple of 256.  use_asm selects the assembly or the hipcc kernel.
- * For tests only: lets the two implementations of the VM be compared opcode by opcode. */
-int pgpu_vm_debug_run(const pgpu_modulus* mod, const uint32_t* prog, size_t prog_words, uint32_t* mem_host,
-                      size_t nslots, size_t nb, int use_asm, int* wt_out);
+/* (Test hooks -- raw VM programs, the planning predicates -- are NOT part of this boundary: include/paillier_hip_debug.h.) */
 
-/* Same for the pair kernel (residues modulo p^2 as two base-p digits, the Decrypt ladder of 2048-bit keys): slots are
- * [2H][nb] limb arrays (digit a0 in limbs 0..H-1, a1 in limbs H..2H-1), SQR / MUL are the pair operations.
- * lanes = 1: the one-lane kernel for N = p^2 with a 37-limb prime (Decrypt); lanes = 2: the two-lane kernel for N = n^2 with
- * a 74-limb public n (Encrypt, PartialDecrypt, ...; any odd n).
- * consts_out (optional, 2H words) receives the kernel's constants p | Cadj, h_out the digit width H. */
-int pgpu_pair_debug_run(pgpu_ctx* ctx, const uint8_t* p_be, size_t p_len, int lanes, const uint32_t* prog, size_t prog_words,
-                        uint32_t* mem_host, size_t nslots, size_t nb, uint32_t* consts_out, int* h_out);
-
+#if defined(__GNUC__)
+#pragma GCC visibility pop
+#endif
 #ifdef __cplusplus
 }
 #endif

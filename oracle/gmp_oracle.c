@@ -221,6 +221,166 @@ int oracle_decrypt_crt_batch(const uint8_t* p_be, size_t p_len, const uint8_t* q
   return used;
 }
 
+/* paillier.go:206-218 EncryptWithRAtLevel at level two (s = 2: ns = n^2, ns1 = n^3): c = G^m * r^(n^2) mod n^3, verbatim. */
+int oracle_encrypt_l2_batch(const uint8_t* n_be, size_t n_len, const uint8_t* g_be, size_t g_len, size_t batch,
+                            const uint8_t* m, size_t m_stride, const uint8_t* r, size_t r_stride, uint8_t* c_out,
+                            size_t c_stride, int threads) {
+  mpz_t n, n2, n3, g;
+  mpz_inits(n, n2, n3, g, NULL);
+  imp(n, n_be, n_len);
+  imp(g, g_be, g_len);
+  mpz_mul(n2, n, n);
+  mpz_mul(n3, n2, n);
+  int used = 1;
+#ifdef _OPENMP
+  if (threads > 0) omp_set_num_threads(threads);
+#pragma omp parallel
+#endif
+  {
+#ifdef _OPENMP
+#pragma omp single
+    used = omp_get_num_threads();
+#endif
+    mpz_t mi, ri, gm, rn, ci;
+    mpz_inits(mi, ri, gm, rn, ci, NULL);
+#ifdef _OPENMP
+#pragma omp for schedule(dynamic, 1)
+#endif
+    for (long i = 0; i < (long)batch; ++i) {
+      imp(mi, m + (size_t)i * m_stride, m_stride);
+      imp(ri, r + (size_t)i * r_stride, r_stride);
+      gmp_exp(gm, g, mi, n3);    /* :213 Exp(G, m, ns1) */
+      gmp_exp(rn, ri, n2, n3);   /* :214 Exp(r, ns, ns1) */
+      mpz_mul(ci, gm, rn);       /* :216 */
+      mpz_mod(ci, ci, n3);
+      expo(ci, c_out + (size_t)i * c_stride, c_stride);
+    }
+    mpz_clears(mi, ri, gm, rn, ci, NULL);
+  }
+  mpz_clears(n, n2, n3, g, NULL);
+  return used;
+}
+
+/* operations.go:96-118 NestedRandomize with the draws a, b supplied: an = a^n mod n^2, bn2 = b^(n^2) mod n^3,
+ * r = ct^an * bn2 mod n^3 -- three mpz_powm, in the reference's order. */
+int oracle_nested_randomize_batch(const uint8_t* n_be, size_t n_len, size_t batch, const uint8_t* ct, size_t ct_stride,
+                                  const uint8_t* a, const uint8_t* b, size_t ab_stride, uint8_t* out, size_t out_stride,
+                                  int threads) {
+  mpz_t n, n2, n3;
+  mpz_inits(n, n2, n3, NULL);
+  imp(n, n_be, n_len);
+  mpz_mul(n2, n, n);
+  mpz_mul(n3, n2, n);
+  int used = 1;
+#ifdef _OPENMP
+  if (threads > 0) omp_set_num_threads(threads);
+#pragma omp parallel
+#endif
+  {
+#ifdef _OPENMP
+#pragma omp single
+    used = omp_get_num_threads();
+#endif
+    mpz_t ai, bi, an, bn2, r;
+    mpz_inits(ai, bi, an, bn2, r, NULL);
+#ifdef _OPENMP
+#pragma omp for schedule(dynamic, 1)
+#endif
+    for (long i = 0; i < (long)batch; ++i) {
+      imp(r, ct + (size_t)i * ct_stride, ct_stride);
+      imp(ai, a + (size_t)i * ab_stride, ab_stride);
+      imp(bi, b + (size_t)i * ab_stride, ab_stride);
+      gmp_exp(an, ai, n, n2);      /* :108 */
+      gmp_exp(bn2, bi, n2, n3);    /* :109 */
+      gmp_exp(r, r, an, n3);       /* :112 */
+      mpz_mul(r, r, bn2);          /* :113 */
+      mpz_mod(r, r, n3);           /* :114 */
+      expo(r, out + (size_t)i * out_stride, out_stride);
+    }
+    mpz_clears(ai, bi, an, bn2, r, NULL);
+  }
+  mpz_clears(n, n2, n3, NULL);
+  return used;
+}
+
+/* Threshold decryption of one ciphertext as the reference's own benchmark drives it (thresholdkey_test.go:396-427): t servers
+ * call PartialDecrypt (thresholdkey.go:192-201: c^(2 delta s_i) mod n^2), then CombinePartialDecryptions (:149-161) --
+ * computeLambda / updateLambda with Euclidean Div (:91-107), updateCprime / exp with ModInverse for a negative lambda
+ * (:118-138), L and combineSharesConstant recomputed per call (:63-66,143-146).  ids: the servers' 1-based IDs; shares
+ * concatenated big-endian with stride sh_stride.  partials_out (optional): t rows per ciphertext, server-major per ciphertext. */
+int oracle_threshold_decrypt_batch(const uint8_t* n_be, size_t n_len, int total_servers, int t, const int* ids,
+                                   const uint8_t* shares, size_t sh_stride, size_t batch, const uint8_t* c, size_t c_stride,
+                                   uint8_t* m_out, size_t m_stride, uint8_t* partials_out, int threads) {
+  mpz_t n, n2, delta, two_delta;
+  mpz_inits(n, n2, delta, two_delta, NULL);
+  imp(n, n_be, n_len);
+  mpz_mul(n2, n, n);
+  mpz_fac_ui(delta, (unsigned long)total_servers);          /* utils.go:17-23 Factorial */
+  mpz_mul_ui(two_delta, delta, 2);
+  int used = 1;
+#ifdef _OPENMP
+  if (threads > 0) omp_set_num_threads(threads);
+#pragma omp parallel
+#endif
+  {
+#ifdef _OPENMP
+#pragma omp single
+    used = omp_get_num_threads();
+#endif
+    mpz_t ci, e, cprime, lambda, num, two_l, ret, tmp, l, cst;
+    mpz_inits(ci, e, cprime, lambda, num, two_l, ret, tmp, l, cst, NULL);
+    mpz_t* dec = (mpz_t*)malloc((size_t)t * sizeof(mpz_t));
+    for (int k = 0; k < t; ++k) mpz_init(dec[k]);
+#ifdef _OPENMP
+#pragma omp for schedule(dynamic, 1)
+#endif
+    for (long i = 0; i < (long)batch; ++i) {
+      imp(ci, c + (size_t)i * c_stride, c_stride);
+      for (int k = 0; k < t; ++k) {                          /* PartialDecrypt, one server after the other */
+        imp(e, shares + (size_t)k * sh_stride, sh_stride);
+        mpz_mul(e, e, two_delta);                            /* :195 exp = Share * (2 delta) */
+        gmp_exp(dec[k], ci, e, n2);                          /* :197 */
+        if (partials_out) expo(dec[k], partials_out + ((size_t)i * (size_t)t + (size_t)k) * c_stride, c_stride);
+      }
+      mpz_set_ui(cprime, 1);                                 /* :154 */
+      for (int k = 0; k < t; ++k) {
+        mpz_set(lambda, delta);                              /* computeLambda :104-112 */
+        for (int j = 0; j < t; ++j) {
+          if (ids[j] == ids[k]) continue;
+          mpz_mul_si(num, lambda, -(long)ids[j]);            /* updateLambda :92 */
+          long den = (long)ids[k] - (long)ids[j];
+          /* gmp.Int.Div: Euclidean division (remainder in [0, |den|)): floor(num / den) for den > 0, and for den < 0
+           * num = q den + r = (-q) |den| + r, i.e. q = -floor(num / |den|) */
+          mpz_fdiv_q_ui(lambda, num, (unsigned long)(den > 0 ? den : -den));
+          if (den < 0) mpz_neg(lambda, lambda);
+        }
+        mpz_mul_ui(two_l, lambda, 2);                        /* updateCprime :127 */
+        if (mpz_sgn(two_l) < 0) {                            /* exp :134-140 */
+          mpz_neg(tmp, two_l);
+          gmp_exp(ret, dec[k], tmp, n2);
+          mpz_invert(ret, ret, n2);
+        } else {
+          gmp_exp(ret, dec[k], two_l, n2);
+        }
+        mpz_mul(cprime, cprime, ret);                        /* :129-130 */
+        mpz_mod(cprime, cprime, n2);
+      }
+      L_fn(l, cprime, n);                                    /* computeDecryption :144 */
+      mpz_mul(tmp, delta, delta);                            /* combineSharesConstant :63-66, per call */
+      mpz_mul_ui(tmp, tmp, 4);
+      mpz_invert(cst, tmp, n);
+      mpz_mul(l, cst, l);                                    /* :145 */
+      mpz_mod(l, l, n);
+      expo(l, m_out + (size_t)i * m_stride, m_stride);
+    }
+    for (int k = 0; k < t; ++k) mpz_clear(dec[k]);
+    free(dec);
+    mpz_clears(ci, e, cprime, lambda, num, two_l, ret, tmp, l, cst, NULL);
+  }
+  mpz_clears(n, n2, delta, two_delta, NULL);
+  return used;
+}
+
 /* ---- SHA-256 (FIPS 180-4), for the Fiat-Shamir transcripts of random_oracle.go / thresholdkey.go:319-326 ---- */
 typedef struct { uint32_t h[8]; uint8_t buf[64]; size_t fill; uint64_t total; } sha256_t;
 static const uint32_t SK[64] = {

@@ -19,7 +19,8 @@ def load():
         _lib = C.CDLL(_PATH)
         _lib.oracle_gmp_version.restype = C.c_char_p
         for name in ("oracle_decrypt_batch", "oracle_encrypt_batch", "oracle_modexp_batch", "oracle_decrypt_crt_batch",
-                     "oracle_ddleq_verify_batch", "oracle_ddleq_prove_batch"):
+                     "oracle_ddleq_verify_batch", "oracle_ddleq_prove_batch", "oracle_encrypt_l2_batch", "oracle_nested_randomize_batch",
+                     "oracle_threshold_decrypt_batch"):
             getattr(_lib, name).restype = C.c_int
     return _lib
 
@@ -59,6 +60,47 @@ def modexp_batch_raw(mod, e, b_buf: np.ndarray, o_stride: int, threads: int = 1)
     used = lib.oracle_modexp_batch(mb, C.c_size_t(len(mb)), eb, C.c_size_t(len(eb)), C.c_size_t(b_buf.shape[0]),
                                    _p(b_buf), C.c_size_t(b_buf.shape[1]), _p(out), C.c_size_t(o_stride), threads)
     return out, used
+
+
+def encrypt_l2_batch_raw(n, g, m_buf: np.ndarray, r_buf: np.ndarray, c_stride: int, threads: int = 1):
+    """paillier.go:206-218 at level two: c = G^m r^(n^2) mod n^3 (m_buf: residues modulo n^2)."""
+    lib = load()
+    nb, gb = _be(n), _be(g)
+    out = np.zeros((m_buf.shape[0], c_stride), dtype=np.uint8)
+    used = lib.oracle_encrypt_l2_batch(nb, C.c_size_t(len(nb)), gb, C.c_size_t(len(gb)), C.c_size_t(m_buf.shape[0]),
+                                       _p(m_buf), C.c_size_t(m_buf.shape[1]), _p(r_buf), C.c_size_t(r_buf.shape[1]),
+                                       _p(out), C.c_size_t(c_stride), threads)
+    return out, used
+
+
+def nested_randomize_batch_raw(n, ct_buf: np.ndarray, a_buf: np.ndarray, b_buf: np.ndarray, threads: int = 1):
+    """operations.go:96-118 with the draws supplied: ct^(a^n mod n^2) * b^(n^2) mod n^3."""
+    lib = load()
+    nb = _be(n)
+    assert a_buf.shape == b_buf.shape and a_buf.shape[0] == ct_buf.shape[0]
+    out = np.zeros_like(ct_buf)
+    used = lib.oracle_nested_randomize_batch(nb, C.c_size_t(len(nb)), C.c_size_t(ct_buf.shape[0]), _p(ct_buf),
+                                             C.c_size_t(ct_buf.shape[1]), _p(a_buf), _p(b_buf), C.c_size_t(a_buf.shape[1]), _p(out),
+                                             C.c_size_t(out.shape[1]), threads)
+    return out, used
+
+
+def threshold_decrypt_batch_raw(n, total_servers, ids, shares, c_buf: np.ndarray, m_stride: int, threads: int = 1,
+                                want_partials: bool = False):
+    """thresholdkey.go:192-201 + :149-161 per ciphertext: PartialDecrypt under every share of `ids` (1-based server IDs, shares[k]
+    the share of ids[k]), then CombinePartialDecryptions.  Returns (plaintexts, threads_used[, partials uint8[batch, t, stride]])."""
+    lib = load()
+    nb = _be(n)
+    t = len(ids)
+    ss = max(len(_be(s)) for s in shares)
+    sh = np.frombuffer(b"".join(int(s).to_bytes(ss, "big") for s in shares), dtype=np.uint8).copy()
+    idarr = (C.c_int * t)(*[int(i) for i in ids])
+    out = np.zeros((c_buf.shape[0], m_stride), dtype=np.uint8)
+    parts = np.zeros((c_buf.shape[0], t, c_buf.shape[1]), dtype=np.uint8) if want_partials else None
+    used = lib.oracle_threshold_decrypt_batch(nb, C.c_size_t(len(nb)), int(total_servers), t, idarr, _p(sh), C.c_size_t(ss),
+                                              C.c_size_t(c_buf.shape[0]), _p(c_buf), C.c_size_t(c_buf.shape[1]), _p(out),
+                                              C.c_size_t(m_stride), _p(parts) if want_partials else None, threads)
+    return (out, used, parts) if want_partials else (out, used)
 
 
 def _ints_to_be(vals, stride):

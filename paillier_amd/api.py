@@ -87,10 +87,15 @@ SIGNATURES = {
     "pgpu_modulus_destroy": (None, [_vp]),
     "pgpu_modulus_bytes": (_sz, [_vp]),
     "pgpu_modexp": (_int, [_vp, _sz, _vp, _sz, _sz, _vp, _sz, _sz, _vp, _sz, _int]),
-    "pgpu_vm_debug_run": (_int, [_vp, _vp, _sz, _vp, _sz, _sz, _int, C.POINTER(_int)]),
-    "pgpu_pair_debug_run": (_int, [_vp, _vp, _sz, _int, _vp, _sz, _vp, _sz, _sz, _vp, C.POINTER(_int)]),
     "pgpu_modinv": (_int, [_vp, _sz, _vp, _sz, _sz, _vp, _sz, _int, _vp]),
     "pgpu_modmul": (_int, [_vp, _sz, _vp, _sz, _sz, _vp, _sz, _sz, _vp, _sz, _int]),
+}
+
+# test hooks (include/paillier_hip_debug.h: not part of the drop-in boundary)
+DEBUG_SIGNATURES = {
+    "pgpu_vm_debug_run": (_int, [_vp, _vp, _sz, _vp, _sz, _sz, _int, C.POINTER(_int)]),
+    "pgpu_pair_debug_run": (_int, [_vp, _vp, _sz, _int, _vp, _sz, _vp, _sz, _sz, _vp, C.POINTER(_int)]),
+    "pgpu_plan_query": (_int, [C.c_char_p, _vp, _int, _vp, _int]),
 }
 
 
@@ -148,12 +153,28 @@ def load_library():
         raise PaillierHipError(-100, "two HIP runtimes are mapped into this process (" + ", ".join(hip_runtimes_mapped()) +
                                "): the second one to initialise will find no GPU; import paillier_amd (or torch) before whatever "
                                "loaded the other copy, or link everything against one libamdhip64")
-    for name, (res, args) in SIGNATURES.items():
+    for name, (res, args) in list(SIGNATURES.items()) + list(DEBUG_SIGNATURES.items()):
         fn = getattr(lib, name)
         fn.restype = res
         fn.argtypes = args
     _lib = lib
     return lib
+
+
+def version() -> str:
+    """pgpu_version()"""
+    return load_library().pgpu_version().decode()
+
+
+def plan_query(what: str, *args: int) -> List[int]:
+    """The planning predicates of csrc/plan.hpp by name (pgpu_plan_query; no GPU, no context): tests/test_plan_cpu.py."""
+    lib = load_library()
+    a = (C.c_uint64 * max(1, len(args)))(*[int(v) for v in args])
+    out = (C.c_int64 * 8)()
+    n = lib.pgpu_plan_query(what.encode(), a, len(args), out, 8)
+    if n < 0:
+        raise PaillierHipError(n, lib.pgpu_last_error().decode())
+    return [int(out[i]) for i in range(n)]
 
 
 def _check(rc: int):
@@ -286,7 +307,7 @@ class Modulus:
                                         out_stride, mem))
 
     def vm_debug_run(self, prog_words: Sequence[int], mem: np.ndarray, nslots: int, nb: int, use_asm: bool) -> np.ndarray:
-        """Test hook (include/paillier_hip.h pgpu_vm_debug_run).  mem: uint32[nslots, WT, nb]; returns the memory after the run."""
+        """Test hook (include/paillier_hip_debug.h pgpu_vm_debug_run).  mem: uint32[nslots, WT, nb]; returns the memory after the run."""
         pw = np.asarray(prog_words, dtype=np.uint32)
         m = np.ascontiguousarray(mem, dtype=np.uint32).copy()
         wt = C.c_int()
@@ -416,8 +437,13 @@ class PublicKey:
         bufs = [ints_to_be(op, st) for op in cts]
         ptrs = (C.c_void_p * len(bufs))(*[b.ctypes.data for b in bufs])
         B = len(cts[0])
+        if any(len(op) != B for op in cts):
+            raise ValueError("Add: operand vectors differ in length")
         out = np.zeros((B, cb), dtype=np.uint8)
-        _check(self.ctx.lib.pgpu_add_many(self.h, level, len(bufs), B, ptrs, st, _ptr(out), cb, MEM_HOST))
+        if len(bufs) == 2:      # the two-operand form takes flat buffers (what the Go shim does too)
+            _check(self.ctx.lib.pgpu_add(self.h, level, B, _ptr(bufs[0]), st, _ptr(bufs[1]), st, _ptr(out), cb, MEM_HOST))
+        else:
+            _check(self.ctx.lib.pgpu_add_many(self.h, level, len(bufs), B, ptrs, st, _ptr(out), cb, MEM_HOST))
         return be_to_ints(out)
 
     def SubBatch(self, *cts: Sequence[int], level: int = ENC_LEVEL_ONE, return_status: bool = False):
@@ -430,9 +456,15 @@ class PublicKey:
         ptrs = (C.c_void_p * len(bufs))(*[b.ctypes.data for b in bufs])
         B = len(cts[0])
         out = np.zeros((B, st if len(cts) == 1 else cb), dtype=np.uint8)
+        if any(len(op) != B for op in cts):
+            raise ValueError("Sub: operand vectors differ in length")
         status = np.zeros(B, dtype=np.int32) if return_status else None
-        _check(self.ctx.lib.pgpu_sub_many(self.h, level, len(bufs), B, ptrs, st, _ptr(out), out.shape[1], MEM_HOST,
-                                          _ptr(status) if return_status else None))
+        if len(bufs) == 2:
+            _check(self.ctx.lib.pgpu_sub(self.h, level, B, _ptr(bufs[0]), st, _ptr(bufs[1]), st, _ptr(out), out.shape[1], MEM_HOST,
+                                         _ptr(status) if return_status else None))
+        else:
+            _check(self.ctx.lib.pgpu_sub_many(self.h, level, len(bufs), B, ptrs, st, _ptr(out), out.shape[1], MEM_HOST,
+                                              _ptr(status) if return_status else None))
         return (be_to_ints(out), status) if return_status else be_to_ints(out)
 
     def ConstMultBatch(self, cts: Sequence[int], k, level: int = ENC_LEVEL_ONE) -> List[int]:
@@ -646,7 +678,11 @@ class SecretKey:
         cb3, pb1, pb2 = pk.cipher_bytes(ENC_LEVEL_TWO), pk.plain_bytes(ENC_LEVEL_ONE), pk.plain_bytes(ENC_LEVEL_TWO)
         S = len(ct1s)
         flat = lambda v: [t for row in v for t in row]
-        assert all(len(r) == secpar for r in xs) and all(len(r) == secpar for r in ys) and len(xs) == len(ys) == S
+        # the C side reads S rows of every per-statement buffer and S * secpar rows of x and y: refuse ragged input here
+        if not (len(ct2s) == len(a_s) == len(b_s) == len(xs) == len(ys) == S):
+            raise ValueError("ProveDDLEQBatch: ct1s, ct2s, a_s, b_s, xs, ys must have one entry per statement")
+        if secpar < 1 or not (all(len(r) == secpar for r in xs) and all(len(r) == secpar for r in ys)):
+            raise ValueError("ProveDDLEQBatch: every statement needs exactly secpar draws x and y")
         bufs = [ints_to_be(ct1s, cb3), ints_to_be(ct2s, cb3), ints_to_be(a_s, pb1), ints_to_be(b_s, pb1), ints_to_be(flat(xs), pb1),
                 ints_to_be(flat(ys), pb1)]
         B = S * secpar

@@ -1,0 +1,1183 @@
+// ddleq.cpp -- NestedRandomize (operations.go:96-118), the DDLEQ proofs (ddleq.go:27-153) and RandomOracleDigest
+// (random_oracle.go:10-32): interleaved ladders modulo n^3, the key holder's halves modulo p^3 / q^3, the prover.
+#include "engine.hpp"
+
+extern "C" {
+
+int pgpu_random_oracle_digest(pgpu_ctx* ctx, int nparts, const uint8_t* const* parts, const size_t* strides, size_t batch,
+                              uint8_t* digests, int mem) {
+  if (!ctx || !parts || !strides || !digests) return fail(PGPU_ERR_INVALID, "null argument");
+  return guarded([&] {
+    if (nparts < 0 || nparts > 6) api_throw(PGPU_ERR_INVALID, "0..6 transcript parts");
+    if (batch == 0) api_throw(PGPU_ERR_INVALID, "empty batch");
+    ctx->bind();
+    ctx->reset_ws();
+    const size_t nb = round_up(batch, VM_BLOCK);
+    const uint32_t* dp[6];
+    int dw[6];
+    for (int i = 0; i < nparts; ++i) {
+      if (!parts[i]) api_throw(PGPU_ERR_INVALID, "null part");
+      dw[i] = std::max<int>(1, (int)((strides[i] * 8 + LB - 1) / LB));
+      uint32_t* l = ctx->ws_t<uint32_t>((size_t)dw[i] * nb);
+      unpack_operand(ctx, parts[i], strides[i], strides[i], batch, mem, l, dw[i], nb);
+      dp[i] = l;
+    }
+    uint32_t* dg = ctx->ws_t<uint32_t>(8 * nb);
+    launch_sha256_transcript(dp, dw, nparts, nb, batch, dg, nullptr, ctx->stream);
+    // digests: 32 bytes each, big-endian words
+    std::vector<uint32_t> h(8 * nb);
+    HIPCHK(hipMemcpyAsync(h.data(), dg, 8 * nb * 4, hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHK(hipStreamSynchronize(ctx->stream));
+    std::vector<uint8_t> outb(32 * batch);
+    for (size_t g = 0; g < batch; ++g)
+      for (int i = 0; i < 8; ++i) {
+        uint32_t v = h[(size_t)i * nb + g];
+        outb[g * 32 + 4 * i + 0] = (uint8_t)(v >> 24); outb[g * 32 + 4 * i + 1] = (uint8_t)(v >> 16);
+        outb[g * 32 + 4 * i + 2] = (uint8_t)(v >> 8);  outb[g * 32 + 4 * i + 3] = (uint8_t)v;
+      }
+    if (mem == PGPU_MEM_HOST) memcpy(digests, outb.data(), outb.size());
+    else HIPCHK(hipMemcpy(digests, outb.data(), outb.size(), hipMemcpyHostToDevice));
+  });
+}
+
+}  // extern "C"
+
+namespace pgi {
+// x^(per-number exponent, W2 limbs) * y^(n^2) mod n^3 as ONE interleaved ladder (emit_modexp_dual): the verifier's
+// check^(E^n) * F^(n^2) (ddleq.go:143-152) and NestedRandomize's ct^(a^n) * b^(n^2) (operations.go:108-114).
+// x, y: W3-limb arrays (any value below R); returns the canonical result (W3 limbs, stride nb).
+uint32_t* dual_pow_n3(pgpu_ctx* ctx, const pgpu_pubkey* pk, const uint32_t* x, const uint32_t* exps, const uint32_t* y, size_t nb) {
+  const ModCtx &mn2 = pk->mn2, &mn3 = *pk->mn3;
+  const int W2 = mn2.WT, W3 = mn3.WT;
+  const bool use3 = triple_usable(ctx, mn3) && plan::triple_batch_fits(nb, W3);
+  ModexpPlan pc = modexp_alloc(ctx, mn3, nb, use3 ? 0 : 48);   // slots: 0 x, 1 y, 2 tmp, 3 out, 5..20 / 21..52 the two tables
+  HIPCHK(hipMemcpyAsync(pc.in(), x, pc.slot_words * 4, hipMemcpyDeviceToDevice, ctx->stream));
+  HIPCHK(hipMemcpyAsync(pc.in() + pc.slot_words, y, pc.slot_words * 4, hipMemcpyDeviceToDevice, ctx->stream));
+  if (use3 && ctx->use_lift) {
+    // x^e y^(n^2) = (x^(e1) y^n)^n x^(e0) with e = e0 + e1 n, and W^n mod n^3 depends on W mod n^2 only (the lift of
+    // encrypt_core: x = x' mod n^k implies x^n = x'^n mod n^(k+1), any integers).  So: W = x^(e1) y^n modulo n^2 -- an
+    // interleaved ladder of 2 048 squarings on the pair kernel, half the price of squarings modulo n^3 -- and then
+    // W^n x^(e0) modulo n^3, an interleaved ladder of 2 048 squarings where the literal form needs 4 096.
+    const ModCtx& mn = pk->mn;
+    const int W1 = mn.WT;
+    const size_t S1 = (size_t)W1 * nb;
+    uint32_t* e0 = ctx->ws_t<uint32_t>(S1);
+    uint32_t* e1 = ctx->ws_t<uint32_t>(S1);
+    uint32_t* tb = ctx->ws_t<uint32_t>((size_t)W2 * nb);
+    reduce_mod(ctx, mn, exps, W2, e0, nb);
+    launch_div_exact(exps, W2, 0, e0, W1, tb, pk->ninv2k.d, mn.d_nmod, W1, e1, W1, nb, nb, nullptr, 0, ctx->stream);
+    uint32_t* x2 = ctx->ws_t<uint32_t>((size_t)W2 * nb);
+    uint32_t* y2 = ctx->ws_t<uint32_t>((size_t)W2 * nb);
+    reduce_mod(ctx, mn2, x, W3, x2, nb);
+    reduce_mod(ctx, mn2, y, W3, y2, nb);
+    // x enters digit form beside the W ladder (a side lane); W itself is handed over in pair form -- (a0, a1, 0) is the digit form
+    // of a representative of W mod n^2, which is all the lift needs (modexp_triple) -- where the pair kernel and the digit
+    // kernel share the root n
+    const int wb = triple_window_bits(nb, mn3.triple.root->WT);
+    const uint32_t tab2 = 5 + (uint32_t)perlane_table_slots(wb, wb == 5);
+    TriplePlan tp = triple_alloc(ctx, mn3, nb, (int)tab2 + (1 << (dual_sliding_bits(wb) - 1)));
+    const bool hand = ctx->use_handover && mn2.pairn.root && mn2.pairn.root->WT == mn3.triple.root->WT;
+    Fork ft(ctx, 3);
+    ft.chain(2);                                   // (lane 2: dual_pow_pair forks its own two entries over lanes 0 and 1)
+    triple_enter(ctx, mn3, pc.in(), tp, 0);
+    ft.chain(0);
+    uint32_t* raw = nullptr;
+    uint32_t* wv = dual_pow_pair(ctx, mn2, x2, e1, W1, y2, pk->N, nb, hand ? &raw : nullptr);
+    if (wv) {
+      if (raw) {
+        triple_from_pair(ctx, raw, tp, 1);
+      } else {
+        launch_copy_limbs(wv, 0, W2, pc.in() + pc.slot_words, W3, nb, ctx->stream);    // slot 1 <- W, zero-extended
+        triple_enter(ctx, mn3, pc.in() + pc.slot_words, tp, 1);
+      }
+      ft.join();
+      Prog pd;
+      emit_modexp_dual(pd, W1, pk->N, 0, 1, 2, 3, 5, tab2, 0, wb, wb == 5);
+      pd.end();
+      triple_run(ctx, mn3, tp, pd, triple_windows(ctx, e0, W1, nb, wb));
+      triple_exit(ctx, mn3, tp, 3, pc.out(), nullptr);
+      return pc.out();
+    }
+  }
+  if (use3) {
+    // the interleaved ladder on the three-digit kernel: residues modulo n^3 as a0 + a1 n + a2 n^2
+    const int wb = triple_window_bits(nb, mn3.triple.root->WT);       // 7-bit (or 5-bit) windows of the per-number exponent
+    const uint32_t tab2 = 5 + (uint32_t)perlane_table_slots(wb, wb == 5);
+    TriplePlan tp = triple_alloc(ctx, mn3, nb, (int)tab2 + (1 << (dual_sliding_bits(wb) - 1)));   // slots: 0 x, 1 y, 2 tmp, 3 out, 5.. / tab2.. the tables
+    Fork ft(ctx);
+    ft.chain(0);
+    triple_enter(ctx, mn3, pc.in(), tp, 0);
+    ft.chain(1);
+    triple_enter(ctx, mn3, pc.in() + pc.slot_words, tp, 1);
+    ft.join();
+    Prog pd;
+    emit_modexp_dual(pd, W2, mn2.N, 0, 1, 2, 3, 5, tab2, 0, wb, wb == 5);
+    pd.end();
+    triple_run(ctx, mn3, tp, pd, triple_windows(ctx, exps, W2, nb, wb));
+    triple_exit(ctx, mn3, tp, 3, pc.out(), nullptr);
+  } else {
+    Prog pd;
+    emit_modexp_dual(pd, W2, mn2.N, 0, 1, 2, 3, 5, 21);
+    pd.end();
+    SegSpec sd{&mn3, &pd, pc.mem, exps};
+    run_vm(ctx, nb, sd, nullptr, true);
+    launch_canon(pc.out(), mn3.d_nmod, W3, nb, ctx->stream);
+  }
+  return pc.out();
+}
+}  // namespace pgi
+
+extern "C" {
+
+int pgpu_nested_randomize_with_ab(const pgpu_pubkey* pk, size_t batch, const uint8_t* ct, size_t ct_stride, const uint8_t* a,
+                                  const uint8_t* b, size_t ab_stride, uint8_t* out, size_t out_stride, int mem) {
+  if (!pk || !ct || !a || !b || !out) return fail(PGPU_ERR_INVALID, "null argument");
+  pgpu_ctx* ctx = pk->ctx;
+  return guarded([&] {
+    if (batch == 0) api_throw(PGPU_ERR_INVALID, "empty batch");
+    if (!pk->mn3) api_throw(PGPU_ERR_UNSUPPORTED, "n^3 is wider than the built kernels");
+    ctx->bind();
+    ctx->reset_ws();
+    const ModCtx &mn2 = pk->mn2, &mn3 = *pk->mn3;
+    const int W2 = mn2.WT, W3 = mn3.WT;
+    const size_t nb = round_up(batch, VM_BLOCK);
+    // an = a^n mod n^2 (operations.go:108); r = ct^an * b^(n^2) mod n^3 (:109-114)
+    ModexpPlan pa_ = modexp_alloc(ctx, mn2, nb, 32);
+    unpack_mod(ctx, mn2, a, ab_stride, batch, mem, pa_.in(), nb);
+    modexp_shared_run(ctx, mn2, pa_, pk->N, false, false, true);
+    uint32_t* x = ctx->ws_t<uint32_t>((size_t)W3 * nb);
+    uint32_t* y = ctx->ws_t<uint32_t>((size_t)W3 * nb);
+    unpack_mod(ctx, mn3, ct, ct_stride, batch, mem, x, nb);
+    unpack_mod(ctx, mn3, b, ab_stride, batch, mem, y, nb);
+    uint32_t* res = dual_pow_n3(ctx, pk, x, pa_.out(), y, nb);
+    pack_result(ctx, res, W3, nb, batch, out, out_stride, mn3.nbytes, mem);
+    HIPCHK(hipStreamSynchronize(ctx->stream));
+    (void)W2;
+  });
+}
+
+int pgpu_ddleq_verify(const pgpu_pubkey* pk, size_t batch, const uint8_t* ct1, const uint8_t* ct2, size_t ct_stride,
+                      const uint8_t* x, const uint8_t* y, size_t xy_stride, const uint8_t* alpha, size_t alpha_stride,
+                      const uint8_t* e, size_t e_stride, const uint8_t* f, size_t f_stride, int32_t* ok, int mem) {
+  if (!pk || !ct1 || !ct2 || !x || !y || !alpha || !e || !f || !ok) return fail(PGPU_ERR_INVALID, "null argument");
+  pgpu_ctx* ctx = pk->ctx;
+  return guarded([&] {
+    if (batch == 0) api_throw(PGPU_ERR_INVALID, "empty batch");
+    if (!pk->mn3) api_throw(PGPU_ERR_UNSUPPORTED, "n^3 is wider than the built kernels");
+    ctx->bind();
+    ctx->reset_ws();
+    const ModCtx &mn2 = pk->mn2, &mn3 = *pk->mn3;
+    const int W2 = mn2.WT, W3 = mn3.WT;
+    const size_t nb = round_up(batch, VM_BLOCK);
+    auto wof = [](size_t stride) { return std::max<int>(1, (int)((stride * 8 + LB - 1) / LB)); };
+    // transcript operands exactly as given (ddleq.go:136: RandomOracleBit(ct1, ct2, X, Y, Alpha); ct1 is skipped by
+    // random_oracle.go:24-26)
+    const int wc = std::max(wof(ct_stride), W3), wxy = wof(xy_stride), wa = std::max(wof(alpha_stride), W3);
+    uint32_t* c1 = ctx->ws_t<uint32_t>((size_t)wc * nb);
+    uint32_t* c2 = ctx->ws_t<uint32_t>((size_t)wc * nb);
+    uint32_t* xl = ctx->ws_t<uint32_t>((size_t)wxy * nb);
+    uint32_t* yl = ctx->ws_t<uint32_t>((size_t)wxy * nb);
+    uint32_t* al = ctx->ws_t<uint32_t>((size_t)wa * nb);
+    unpack_operand(ctx, ct1, ct_stride, ct_stride, batch, mem, c1, wc, nb);
+    unpack_operand(ctx, ct2, ct_stride, ct_stride, batch, mem, c2, wc, nb);
+    unpack_operand(ctx, x, xy_stride, xy_stride, batch, mem, xl, wxy, nb);
+    unpack_operand(ctx, y, xy_stride, xy_stride, batch, mem, yl, wxy, nb);
+    unpack_operand(ctx, alpha, alpha_stride, alpha_stride, batch, mem, al, wa, nb);
+    int32_t* chal = ctx->ws_t<int32_t>(nb);
+    HIPCHK(hipMemsetAsync(chal, 0, nb * 4, ctx->stream));
+    const uint32_t* parts[4] = {c2, xl, yl, al};
+    const int widths[4] = {wc, wxy, wxy, wa};
+    launch_sha256_transcript(parts, widths, 4, nb, batch, nullptr, chal, ctx->stream);
+    if (wc != W3) api_throw(PGPU_ERR_INVALID, "ciphertext stride must be the byte length of n^3");
+    // en = E^n mod n^2 ; fn2 = F^(n^2) mod n^3                                   (ddleq.go:143-144)
+    ModexpPlan pe = modexp_alloc(ctx, mn2, nb, 32);
+    // E is a residue modulo n^2 in every honest proof (ddleq.go:94-99); a wider field (up to twice the width) is reduced
+    // by the ordinary kernel's two-chunk entry, the usual width takes the pair-kernel path
+    const bool ewide = e_stride * 8 > (size_t)LB * W2;
+    unpack_operand(ctx, e, e_stride, std::min(e_stride, 2 * mn2.nbytes), batch, mem, pe.in(), ewide ? 2 * W2 : W2, nb);
+    modexp_shared_run(ctx, mn2, pe, pk->N, ewide, false, true);
+    // check = chalBit ? ct2 : ct1 ; check^en * F^(n^2) mod n^3 == alpha           (ddleq.go:138-152)
+    // one interleaved ladder: the squarings of check^en and of F^(n^2) are shared (emit_modexp_dual)
+    if (f_stride * 8 > (size_t)LB * W3 + 7) api_throw(PGPU_ERR_INVALID, "F wider than n^3");
+    uint32_t* chk = ctx->ws_t<uint32_t>((size_t)W3 * nb);
+    uint32_t* fl = ctx->ws_t<uint32_t>((size_t)W3 * nb);
+    launch_select(chal, c2, c1, chk, W3, nb, ctx->stream);
+    unpack_operand(ctx, f, f_stride, f_stride, batch, mem, fl, W3, nb);
+    uint32_t* got = dual_pow_n3(ctx, pk, chk, pe.out(), fl, nb);
+    int32_t* d_ok = ctx->ws_t<int32_t>(nb);
+    if (wa != W3) api_throw(PGPU_ERR_INVALID, "alpha stride must be the byte length of n^3");
+    launch_equal(got, al, W3, nb, batch, d_ok, ctx->stream);
+    HIPCHK(hipMemcpyAsync(ok, d_ok, batch * 4, hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHK(hipStreamSynchronize(ctx->stream));
+  });
+}
+
+}  // extern "C"
+
+namespace pgi {
+
+// W = x^(per-number exponent r1, `we` limbs) [* y^(s1)] modulo p^2 (half 0) and modulo q^2 (half 1): interleaved ladders in
+// pair form on the one-lane pair kernel, both halves in ONE two-segment launch.  xs / ys: canonical residues modulo p^2 / q^2
+// (mp2.WT limbs, stride nb).  outs[half]: canonical results.  False when the one-lane pair kernel does not serve this key.
+bool pow_p2_multi_crt(const pgpu_seckey* sk, const uint32_t* const xs[2], const uint32_t* const r1[2], int we,
+                      const uint32_t* const ys[2], const BigU s1[2], size_t nb, uint32_t* outs[2],
+                      const uint32_t* const xs_b[2] = nullptr, const uint32_t* const r1_b[2] = nullptr, bool raw = false) {
+  // raw: outs[half] = the results still in pair form (a0 | a1, 2H limbs, stride nb) for a caller that continues modulo prime^3
+  // on the digit kernel, where (a0, a1, 0) is their digit form (modexp_triple); else canonical residues modulo prime^2
+  // xs_b / r1_b: a SECOND base with per-number exponents (the response of the DDLEQ prover: s^(e_s) b^(e_b)), not together with ys
+  pgpu_ctx* ctx = sk->ctx;
+  if (!(sk->has_pair && sk->pair_lanes == 1 && sk->c_onep_p2 >= 0 && sk->c_onep_q2 >= 0 && sk->c_rh_p2 >= 0 && ctx->use_asm &&
+        ctx->use_pair && sk->mp2.WT == 2 * sk->mp.WT && sk->mq2.WT == 2 * sk->mq.WT))
+    return false;
+  // one lane per number when the two halves fill the chip that way, else two (as Decrypt chooses)
+  // (two lanes per number pay while they still leave every wave a SIMD of its own: above half a wave per SIMD at one lane, two
+  // lanes are two waves on most SIMDs -- 1.15 x the one-lane ladder -- and the one-lane kernel needs fewer multiplies)
+  const int lanes = plan::crt_pair_lanes(1, sk->pair_small2, nb, plan::lanes_target(ctx->lanes_wanted));
+  const int H = sk->mp.WT, W2 = sk->mp2.WT;
+  const size_t S1 = (size_t)H * nb, S2 = (size_t)W2 * nb;
+  const int wb = 4;                                           // per-number windows: VM_MULV
+  if (!plan::pair_nm4_fits(nb, W2)) return false;
+  // per-number window tables number-major where the kernel has VM_STORET / VM_MULVT (one lane per number, 37-limb primes): a
+  // gather then reads 296 contiguous bytes per lane instead of 74 dwords in 74 different sectors
+  const bool nm4 = ctx->use_nm4 && lanes == 1 && H == 37;
+  const uint32_t TAB1 = 5, TAB2 = TAB1 + (1u << wb) + (nm4 ? 1u : 0u);
+  if (xs_b && (ys || !r1 || !r1_b)) return false;
+  uint32_t* mem[2];
+  Prog pr[2];
+  const uint32_t* dig[2] = {r1 ? r1[0] : nullptr, r1 ? r1[1] : nullptr};
+  Fork in(ctx, 4);                                            // the entry chains of both halves and both operands side by side
+  for (int half = 0; half < 2; ++half) {
+    const ModCtx &m1 = half ? sk->mq : sk->mp, &m2 = half ? sk->mq2 : sk->mp2;
+    mem[half] = ctx->ws_t<uint32_t>(S2 * (size_t)(TAB2 + 64));      // 0 x, 1 y, 2 tmp, 3 out, 5.. / TAB2.. the tables (+ 1 each: x limb-major)
+    for (int k = 0; k < ((ys || xs_b) ? 2 : 1); ++k) {
+      in.chain(2 * half + k);
+      uint32_t* ent = ctx->ws_t<uint32_t>(S2 * 4);                   // (buffers of the chain's own)
+      uint32_t* x0 = ctx->ws_t<uint32_t>(S1);
+      uint32_t* tb = ctx->ws_t<uint32_t>(S2);
+      // pair-form entry: X = v R_H mod prime^2, then its digits X0 + X1 prime
+      HIPCHK(hipMemcpyAsync(ent, k ? (ys ? ys[half] : xs_b[half]) : xs[half], S2 * 4, hipMemcpyDeviceToDevice, ctx->stream));
+      Prog a;
+      a.op(VM_LOAD, 0); a.op(VM_MULC, C_R2); a.op(VM_MULC, (uint32_t)(half ? sk->c_rh_q2 : sk->c_rh_p2)); a.op(VM_STORE, 3); a.end();
+      SegSpec sa{&m2, &a, ent, nullptr};
+      run_vm(ctx, nb, sa, nullptr, false);
+      launch_canon(ent + 3 * S2, m2.d_nmod, W2, nb, ctx->stream);
+      reduce_mod(ctx, m1, ent + 3 * S2, W2, x0, nb);
+      uint32_t* slot = mem[half] + (size_t)k * S2;
+      launch_div_exact(ent + 3 * S2, W2, 0, x0, H, tb, (half ? sk->qinv2k : sk->pinv2k).d, m1.d_nmod, H, slot + S1, H, nb, nb, nullptr, 0,
+                       ctx->stream);
+      HIPCHK(hipMemcpyAsync(slot, x0, S1 * 4, hipMemcpyDeviceToDevice, ctx->stream));
+    }
+    std::vector<SharedBase> sh;
+    if (ys) sh.push_back(SharedBase{s1[half], 1, TAB2});
+    std::vector<PerNumberBase> pn;
+    if (r1) pn.push_back(PerNumberBase{we, 0, TAB1, 0});
+    if (xs_b) {
+      // the two exponents of a number one after the other in the rows of `digits` (as pow_n3_crt_two keeps them)
+      pn.push_back(PerNumberBase{we, 1, TAB2, (uint32_t)perlane_windows(we, wb)});
+      uint32_t* d2 = ctx->ws_t<uint32_t>((size_t)2 * we * nb);
+      HIPCHK(hipMemcpyAsync(d2, r1[half], (size_t)we * nb * 4, hipMemcpyDeviceToDevice, ctx->stream));
+      HIPCHK(hipMemcpyAsync(d2 + (size_t)we * nb, r1_b[half], (size_t)we * nb * 4, hipMemcpyDeviceToDevice, ctx->stream));
+      dig[half] = d2;
+    }
+    emit_modexp_multi(pr[half], pn, wb, sh, 2, 3, (uint32_t)(half ? sk->c_onep_q2 : sk->c_onep_p2), nm4);
+    pr[half].end();
+  }
+  in.join();
+  {
+    SegSpec sp{&sk->mp2, &pr[0], mem[0], dig[0]}, sq{&sk->mq2, &pr[1], mem[1], dig[1]};
+    sp.pair = sk->pair_p.d; sp.pair_n0inv = sk->mp.n0inv; sp.pair_h = H; sp.pair_lanes = lanes;
+    sq.pair = sk->pair_q.d; sq.pair_n0inv = sk->mq.n0inv; sq.pair_h = H; sq.pair_lanes = lanes;
+    run_vm(ctx, nb, sp, &sq, true);
+  }
+  if (raw) {
+    outs[0] = mem[0] + 3 * S2;
+    outs[1] = mem[1] + 3 * S2;
+    return true;
+  }
+  Fork out(ctx);
+  for (int half = 0; half < 2; ++half) {
+    out.chain(half);
+    const ModCtx& m2 = half ? sk->mq2 : sk->mp2;
+    uint32_t* mm = mem[half];
+    launch_mul_const_add(mm + 3 * S2 + S1, H, (half ? sk->q_limbs1 : sk->p_limbs).d, H, mm + 3 * S2, H, 0, mm + 2 * S2, W2, nb, ctx->stream);
+    Prog a;
+    a.op(VM_LOAD, 2); a.op(VM_MULC, (uint32_t)(half ? sk->c_rh_q2 : sk->c_rh_p2)); a.op(VM_STORE, 3); a.end();
+    SegSpec sa{&m2, &a, mm, nullptr};
+    run_vm(ctx, nb, sa, nullptr, false);
+    launch_canon(mm + 3 * S2, m2.d_nmod, W2, nb, ctx->stream);
+    outs[half] = mm + 3 * S2;
+  }
+  out.join();
+  return true;
+}
+
+// out = base^e mod n^3 for a holder of the factorisation (the DDLEQ prover): two ladders modulo p^3 and q^3 -- half the
+// width, the same exponent -- in one two-segment launch, then Garner.  2.6x fewer limb products than the ladder modulo
+// n^3, the same canonical residue.  Per-number exponents (exps: we limbs each) or one shared exponent (*e).
+void pow_n3_crt(const pgpu_seckey* sk, const uint32_t* base, int wb, const uint32_t* exps, int we, const BigU* e, size_t nb,
+                uint32_t* out, const uint32_t* base2 = nullptr, int wb2 = 0) {
+  // base2 != nullptr: out = base^(per-number exps) * base2^(*e), one interleaved ladder per half (emit_modexp_dual)
+  pgpu_ctx* ctx = sk->ctx;
+  const ModCtx &mp3 = sk->mp3, &mq3 = sk->mq3;
+  const int W = mp3.WT, W3 = sk->pk->mn3->WT;
+  const size_t S = (size_t)W * nb;
+  // (plan.hpp: window width of the per-number exponents and the gate of the p-adic split, decided in ONE place)
+  const plan::Crt3Ladder lad = plan::crt3_ladder(nb, sk->mp.WT, W, plan::lanes_target(ctx->lanes_wanted), exps != nullptr, true);
+  if (triple_usable(ctx, mp3) && triple_usable(ctx, mq3) && lad.triple && (exps || base2 || e->bit_length() >= 64)) {
+    // both halves on the three-digit kernel (digits modulo p and q, 37 limbs for 2048-bit keys): a squaring is 37 rows
+    // where the wave-sliced 110-limb kernel has 110 -- what counts for the half-size, latency-bound batches of the response
+    const int win = lad.win;
+    const bool nm5 = lad.nm5;                    // (number-major 5-bit tables: VM_MULVT5)
+    const uint32_t tab2 = 5 + (uint32_t)perlane_table_slots(win, nm5);
+    const int nslots = base2 ? (int)tab2 + (1 << (dual_sliding_bits(win) - 1)) : 5 + perlane_table_slots(win, nm5);
+    uint32_t* g = ctx->ws_t<uint32_t>(S * 6);       // generic slots (W limbs): 0 x_p, 1 x_q, 2 A, 3 B, 4 h, 5 scratch
+    // Exponents modulo the orders of the unit groups of p^3 and q^3 (a quarter shorter than exponents modulo n^2): each half
+    // gets its own reduced exponents and its own program.  PGPU_EXP_ORDER=0 (experiments) keeps the exponents as given.
+    static const bool order_on = [] { const char* v = getenv("PGPU_EXP_ORDER"); return v ? atoi(v) != 0 : true; }();
+    const bool reduce_e = order_on && sk->eo_p.ok && sk->eo_q.ok;
+    const uint32_t* ex[2] = {exps, exps};
+    int wex[2] = {we, we};
+    BigU es[2];
+    if (e) es[0] = es[1] = *e;
+    Fork fe(ctx);                                   // (the q-half's chains of small kernels beside the p-half's, here and below)
+    for (int half = 0; half < 2 && reduce_e; ++half) {
+      fe.chain(half);
+      const ExpOrder& eo = half ? sk->eo_q : sk->eo_p;
+      if (exps && (size_t)we * LB > eo.ord.bit_length() + LB && we <= 2 * eo.modd.WT) {
+        uint32_t* em = ctx->ws_t<uint32_t>((size_t)eo.modd.WT * nb);
+        reduce_mod(ctx, eo.modd, exps, we, em, nb);
+        uint32_t* er = ctx->ws_t<uint32_t>((size_t)eo.w * nb);
+        launch_exp_order_lift(exps, we, em, eo.modd.WT, eo.m_limbs.d, eo.t, eo.minv, er, eo.w, nb, ctx->stream);
+        ex[half] = er;
+        wex[half] = eo.w;
+      }
+      if (e) {
+        const BigU r = order_fixup(*e, eo.ord);
+        if (r.bit_length() >= 64) es[half] = r;
+      }
+    }
+    fe.join();
+    auto garner = [&](const TriplePlan& tp, const TriplePlan& tq) {
+      Fork fx(ctx);
+      fx.chain(0);
+      triple_exit(ctx, mp3, tp, 3, g + 0 * S, nullptr);     // x_p, canonical
+      fx.chain(1);
+      triple_exit(ctx, mq3, tq, 3, g + 1 * S, nullptr);     // x_q
+      fx.join();
+      Prog c;
+      c.op(VM_LOAD, 0); c.op(VM_MULC, (uint32_t)sk->c_p3invR); c.op(VM_STORE, 3);
+      c.op(VM_LOAD, 1); c.op(VM_MULC, (uint32_t)sk->c_p3invR); c.op(VM_STORE, 2);
+      c.end();
+      SegSpec sc{&mq3, &c, g, nullptr};
+      run_vm(ctx, nb, sc, nullptr, false);
+      launch_canon(g + 2 * S, mq3.d_nmod, W, nb, ctx->stream);
+      launch_canon(g + 3 * S, mq3.d_nmod, W, nb, ctx->stream);
+      launch_sub_mod(g + 2 * S, g + 3 * S, mq3.d_nmod, g + 4 * S, W, nb, ctx->stream);                  // h = (x_q - x_p) / p^3 mod q^3
+      launch_mul_const_add(g + 4 * S, W, sk->p3_limbs.d, W, g, W, 0, out, W3, nb, ctx->stream);          // x_p + p^3 h
+    };
+    // p-adic split of the exponents (the lift of encrypt_core, one prime at a time): with r = r0 + r1 p,
+    //     x^r = (x^(r1))^p x^(r0)   and   W^p mod p^3 depends on W mod p^2 only,
+    // so W = x^(r1) [y^(s1)] is an interleaved ladder of 2 047 squarings modulo p^2 -- on the one-lane pair kernel, 3.5 H^2
+    // multiplies a squaring -- and W^p x^(r0) [y^(s0)] an interleaved ladder of 1 024 squarings modulo p^3, where the ladder
+    // on the whole reduced exponent squares 3 071 times modulo p^3 (8 H^2 issue slots each).
+    const bool reduced_pn = !exps || (ex[0] != exps && ex[1] != exps && wex[0] == sk->eo_p.w && wex[1] == sk->eo_q.w);
+    // (below one wave per SIMD for the stage modulo p^2 the ladders are bound by their length, and one ladder is shorter than two)
+    // (7-bit windows of r0 while their 128-entry tables fit the 32-bit gather offsets -- 75 000 numbers for 37-limb primes --
+    // and 5-bit windows on number-major tables beyond: a big batch keeps the split, it does not fall back to the long ladder)
+    const bool split_prereq = ctx->use_lift && reduce_e && (exps || base2) && reduced_pn && (win == 7 || nm5) && sk->mp2.WT == 2 * sk->mp.WT &&
+                              sk->eo_p.w <= 3 * sk->mp.WT && sk->pinv2k_2.d && mp3.triple.root->WT == sk->mp.WT;
+    if (split_prereq && lad.split) {
+      const int H = sk->mp.WT, W2 = sk->mp2.WT;
+      const size_t S1 = (size_t)H * nb, S2 = (size_t)W2 * nb;
+      const uint32_t *r0[2] = {nullptr, nullptr}, *r1[2] = {nullptr, nullptr}, *x2[2], *y2[2] = {nullptr, nullptr};
+      BigU s0[2], s1[2];
+      uint32_t *xr[2], *yr3[2] = {nullptr, nullptr};
+      Fork fa(ctx, 4);
+      for (int half = 0; half < 2; ++half) {
+        fa.chain(2 * half);
+        uint32_t* tbx = ctx->ws_t<uint32_t>(S);
+        const ModCtx &m1 = half ? sk->mq : sk->mp, &m2 = half ? sk->mq2 : sk->mp2, &m3 = half ? mq3 : mp3;
+        if (exps) {
+          uint32_t* t2 = ctx->ws_t<uint32_t>(S2);
+          uint32_t* d0 = ctx->ws_t<uint32_t>(S1);
+          uint32_t* d1 = ctx->ws_t<uint32_t>(S2);
+          reduce_mod(ctx, m2, ex[half], wex[half], t2, nb);
+          reduce_mod(ctx, m1, t2, W2, d0, nb);                                                       // r0 = r mod prime
+          launch_div_exact(ex[half], wex[half], 0, d0, H, tbx, (half ? sk->qinv2k_2 : sk->pinv2k_2).d, m1.d_nmod, H, d1, W2, nb, nb,
+                           nullptr, 0, ctx->stream);                                                 // r1 = (r - r0) / prime
+          r0[half] = d0;
+          r1[half] = d1;
+        }
+        if (base2) hostbig::divmod(es[half], half ? sk->q : sk->p, s1[half], s0[half]);
+        // the bases modulo prime^3 (kept for stage B) and modulo prime^2 (stage A)
+        xr[half] = ctx->ws_t<uint32_t>(S);
+        reduce_mod(ctx, m3, base, wb, xr[half], nb);
+        uint32_t* xx = ctx->ws_t<uint32_t>(S2);
+        reduce_mod(ctx, m2, xr[half], W, xx, nb);
+        x2[half] = xx;
+        if (base2) {
+          fa.chain(2 * half + 1);
+          uint32_t* yr = ctx->ws_t<uint32_t>(S);
+          reduce_mod(ctx, m3, base2, wb2, yr, nb);
+          yr3[half] = yr;
+          uint32_t* yy = ctx->ws_t<uint32_t>(S2);
+          reduce_mod(ctx, m2, yr, W, yy, nb);
+          y2[half] = yy;
+        }
+      }
+      fa.join();
+      uint32_t* wv[2];
+      // (W stays in pair form: the digit kernel of the same prime takes (a0, a1, 0) as W's digit form)
+      const bool hand = ctx->use_handover && sk->mp.WT == mp3.triple.root->WT && sk->mq.WT == mq3.triple.root->WT;
+      if (pow_p2_multi_crt(sk, x2, exps ? r1 : nullptr, W2, base2 ? y2 : nullptr, s1, nb, wv, nullptr, nullptr, hand)) {
+        // stage B: slots 0 x, 1 W, 2 tmp, 3 out, 4 y, 5.. the per-number table (128 + 64), then W's and y's odd powers
+        const uint32_t TABW = 5 + (uint32_t)perlane_table_slots(win, nm5), TABY = TABW + 64;
+        TriplePlan up = triple_alloc(ctx, mp3, nb, (int)TABY + 64), uq = triple_alloc(ctx, mq3, nb, (int)TABY + 64);
+        Prog pb[2];
+        Fork fb(ctx, 4);
+        for (int half = 0; half < 2; ++half) {
+          const ModCtx& m3 = half ? mq3 : mp3;
+          const TriplePlan& t = half ? uq : up;
+          fb.chain(2 * half);
+          triple_enter(ctx, m3, xr[half], t, 0);
+          fb.chain(2 * half + 1);
+          if (hand) {
+            triple_from_pair(ctx, wv[half], t, 1);
+          } else {
+            uint32_t* wz = ctx->ws_t<uint32_t>(S);
+            launch_copy_limbs(wv[half], 0, W2, wz, W, nb, ctx->stream);
+            triple_enter(ctx, m3, wz, t, 1);
+          }
+          std::vector<SharedBase> sh;
+          sh.push_back(SharedBase{half ? sk->q : sk->p, 1, TABW});
+          if (base2) {
+            fb.chain(2 * half);
+            triple_enter(ctx, m3, yr3[half], t, 4);
+            sh.push_back(SharedBase{s0[half], 4, TABY});
+          }
+          std::vector<PerNumberBase> pn;
+          if (exps) pn.push_back(PerNumberBase{H, 0, 5, 0});
+          emit_modexp_multi(pb[half], pn, win, sh, 2, 3, 0, nm5);
+          pb[half].end();
+        }
+        fb.join();
+        SegSpec sp{&mp3, &pb[0], up.mem, r0[0] ? triple_windows(ctx, r0[0], H, nb, win) : nullptr},
+                sq{&mq3, &pb[1], uq.mem, r0[1] ? triple_windows(ctx, r0[1], H, nb, win) : nullptr};
+        sp.pair = mp3.triple.kconsts; sp.pair_n0inv = sk->mp.n0inv; sp.pair_h = up.H; sp.pair_lanes = 3; sp.tconsts = mp3.triple.tconsts;
+        sq.pair = mq3.triple.kconsts; sq.pair_n0inv = sk->mq.n0inv; sq.pair_h = uq.H; sq.pair_lanes = 3; sq.tconsts = mq3.triple.tconsts;
+        run_vm(ctx, nb, sp, &sq, true);
+        garner(up, uq);
+        return;
+      }
+    }
+    TriplePlan tp = triple_alloc(ctx, mp3, nb, nslots), tq = triple_alloc(ctx, mq3, nb, nslots);
+    Fork fc(ctx);
+    for (int half = 0; half < 2; ++half) {
+      fc.chain(half);
+      const ModCtx& m3 = half ? mq3 : mp3;
+      const TriplePlan& t = half ? tq : tp;
+      uint32_t* red = half ? ctx->ws_t<uint32_t>(S) : g + 5 * S;       // (a scratch slot per half: the chains run side by side)
+      reduce_mod(ctx, m3, base, wb, red, nb);
+      triple_enter(ctx, m3, red, t, 0);
+      if (base2) {
+        reduce_mod(ctx, m3, base2, wb2, red, nb);
+        triple_enter(ctx, m3, red, t, 1);
+      }
+    }
+    fc.join();
+    Prog pp, pq;
+    for (int half = 0; half < 2; ++half) {
+      Prog& pr = half ? pq : pp;
+      if (base2) emit_modexp_dual(pr, wex[half], es[half], 0, 1, 2, 3, 5, tab2, 0, win, nm5);
+      else if (exps) emit_modexp_perlane(pr, wex[half], 0, NO_SLOT, 2, 3, 5, NO_SLOT, 0, win, nm5);
+      else emit_modexp_shared(pr, es[half], 0, NO_SLOT, 2, 3, 5, NO_SLOT, true, true);
+      pr.end();
+    }
+    SegSpec sp{&mp3, &pp, tp.mem, ex[0] ? triple_windows(ctx, ex[0], wex[0], nb, win) : nullptr},
+            sq{&mq3, &pq, tq.mem, ex[1] ? triple_windows(ctx, ex[1], wex[1], nb, win) : nullptr};
+    sp.pair = mp3.triple.kconsts; sp.pair_n0inv = sk->mp.n0inv; sp.pair_h = tp.H; sp.pair_lanes = 3; sp.tconsts = mp3.triple.tconsts;
+    sq.pair = mq3.triple.kconsts; sq.pair_n0inv = sk->mq.n0inv; sq.pair_h = tq.H; sq.pair_lanes = 3; sq.tconsts = mq3.triple.tconsts;
+    run_vm(ctx, nb, sp, &sq, true);
+    garner(tp, tq);
+    return;
+  }
+  // slots: P: in 0, in2 1, tmp 2, out 3, tables 4..51;  Q: the same + QO;  A, B, h after them
+  const uint32_t QO = 56, SA = 112, SB = 113, SH = 114;
+  uint32_t* mem = ctx->ws_t<uint32_t>(S * 115);
+  reduce_mod(ctx, mp3, base, wb, mem + 0 * S, nb);
+  reduce_mod(ctx, mq3, base, wb, mem + (size_t)QO * S, nb);
+  if (base2) {
+    reduce_mod(ctx, mp3, base2, wb2, mem + 1 * S, nb);
+    reduce_mod(ctx, mq3, base2, wb2, mem + (size_t)(QO + 1) * S, nb);
+  }
+  {
+    Prog pp, pq;
+    if (base2) {
+      emit_modexp_dual(pp, we, *e, 0, 1, 2, 3, 4, 20);
+      emit_modexp_dual(pq, we, *e, QO, QO + 1, QO + 2, QO + 3, QO + 4, QO + 20);
+    } else if (exps) {
+      emit_modexp_perlane(pp, we, 0, NO_SLOT, 2, 3, 4, NO_SLOT);
+      emit_modexp_perlane(pq, we, QO, NO_SLOT, QO + 2, QO + 3, QO + 4, NO_SLOT);
+    } else {
+      emit_modexp_shared(pp, *e, 0, NO_SLOT, 2, 3, 4, NO_SLOT, true);
+      emit_modexp_shared(pq, *e, QO, NO_SLOT, QO + 2, QO + 3, QO + 4, NO_SLOT, true);
+    }
+    pp.end();
+    pq.end();
+    SegSpec sp{&mp3, &pp, mem, exps}, sq{&mq3, &pq, mem, exps};
+    run_vm(ctx, nb, sp, &sq, true);
+  }
+  uint32_t *xp = mem + 3 * S, *xq = mem + (size_t)(QO + 3) * S;
+  launch_canon(xp, mp3.d_nmod, W, nb, ctx->stream);     // ONE integer x_p for both uses below
+  launch_canon(xq, mq3.d_nmod, W, nb, ctx->stream);
+  {
+    Prog c;
+    c.op(VM_LOAD, 3);      c.op(VM_MULC, (uint32_t)sk->c_p3invR); c.op(VM_STORE, SB);
+    c.op(VM_LOAD, QO + 3); c.op(VM_MULC, (uint32_t)sk->c_p3invR); c.op(VM_STORE, SA);
+    c.end();
+    SegSpec sc{&mq3, &c, mem, nullptr};
+    run_vm(ctx, nb, sc, nullptr, false);
+  }
+  launch_canon(mem + (size_t)SA * S, mq3.d_nmod, W, nb, ctx->stream);
+  launch_canon(mem + (size_t)SB * S, mq3.d_nmod, W, nb, ctx->stream);
+  launch_sub_mod(mem + (size_t)SA * S, mem + (size_t)SB * S, mq3.d_nmod, mem + (size_t)SH * S, W, nb, ctx->stream);  // h = (x_q - x_p) / p^3 mod q^3
+  launch_mul_const_add(mem + (size_t)SH * S, W, sk->p3_limbs.d, W, xp, W, 0, out, W3, nb, ctx->stream);              // x_p + p^3 h
+}
+
+// out = A^(ea) * B^(eb) mod n^3 for the holder of the factorisation, BOTH exponents per number and already reduced modulo the
+// group orders of p^3 and q^3 (ea[half], eb[half]: eo.w limbs): one interleaved ladder per half on the three-digit kernel --
+// two per-number window tables hang off one chain of squarings -- then Garner.  A, B: W3-limb residues.  False when the
+// three-digit kernels do not serve this key / batch.
+// The two bases of the prover's response are per-STATEMENT values (s, b): their residues modulo prime^3 / prime^2 and their digit
+// forms can be made for every statement while the Alpha ladders run (side stream), before the challenge bits say which
+// instances need them; the response then GATHERS them by statement index instead of entering them between two dependent ladders.
+struct PreBases {
+  size_t nbs = 0;                       // statements (stride of the arrays below)
+  const uint32_t* r3[2][2] = {};        // [half][base]: canonical residues modulo prime^3 (mp3.WT limbs)
+  const uint32_t* r2[2][2] = {};        // ... modulo prime^2 (mp2.WT limbs)
+  TriplePlan dig[2];                    // [half]: slot 0 = A, slot 1 = B in digit form
+  const uint32_t* sti = nullptr;        // device: statement of every number of the call
+  size_t cnt = 0;                       // numbers of the call that are real (the rest is padding)
+};
+bool pre_bases_usable(const pgpu_seckey* sk) {
+  return triple_usable(sk->ctx, sk->mp3) && triple_usable(sk->ctx, sk->mq3) && sk->eo_p.ok && sk->eo_q.ok && sk->eo_p.w == sk->eo_q.w;
+}
+void pre_bases(const pgpu_seckey* sk, const uint32_t* A, const uint32_t* B, size_t nbs, PreBases& pre) {
+  pgpu_ctx* ctx = sk->ctx;
+  const ModCtx &mp3 = sk->mp3, &mq3 = sk->mq3;
+  const int W = mp3.WT, W2 = sk->mp2.WT, W3 = sk->pk->mn3->WT;
+  pre.nbs = nbs;
+  Fork f(ctx, 4);
+  for (int half = 0; half < 2; ++half) {
+    const ModCtx &m2 = half ? sk->mq2 : sk->mp2, &m3 = half ? mq3 : mp3;
+    pre.dig[half] = triple_alloc(ctx, m3, nbs, 2);
+    for (int k = 0; k < 2; ++k) {
+      f.chain(2 * half + k);
+      uint32_t* r3 = ctx->ws_t<uint32_t>((size_t)W * nbs);
+      reduce_mod(ctx, m3, k ? B : A, W3, r3, nbs);
+      uint32_t* r2 = ctx->ws_t<uint32_t>((size_t)W2 * nbs);
+      reduce_mod(ctx, m2, r3, W, r2, nbs);
+      triple_enter(ctx, m3, r3, pre.dig[half], (uint32_t)k);
+      pre.r3[half][k] = r3;
+      pre.r2[half][k] = r2;
+    }
+  }
+  f.join();
+}
+
+bool pow_n3_crt_two(const pgpu_seckey* sk, const uint32_t* A, const uint32_t* const ea[2], const uint32_t* B,
+                    const uint32_t* const eb[2], size_t nb, uint32_t* out, const PreBases* pre = nullptr) {
+  // pre: A and B are not read; number g of the call is statement pre->sti[g] of the prepared bases
+  pgpu_ctx* ctx = sk->ctx;
+  const ModCtx &mp3 = sk->mp3, &mq3 = sk->mq3;
+  const int W = mp3.WT, W3 = sk->pk->mn3->WT;
+  const size_t S = (size_t)W * nb;
+  if (!(triple_usable(ctx, mp3) && triple_usable(ctx, mq3) && sk->eo_p.ok && sk->eo_q.ok && sk->eo_p.w == sk->eo_q.w)) return false;
+  const int H = mp3.triple.root->WT, we = sk->eo_p.w;
+  const plan::Crt3Two two = plan::crt3_two(nb, H, plan::lanes_target(ctx->lanes_wanted), true);
+  if (!two.usable) return false;
+  const int win = 7;
+  // The p-adic split of BOTH exponents (what pow_n3_crt does for one): with e = e0 + e1 prime,
+  //     A^(ea) B^(eb) = (A^(ea1) B^(eb1))^prime * A^(ea0) B^(eb0)    and    W^prime mod prime^3 depends on W mod prime^2 only,
+  // so W is an interleaved ladder of 2 047 squarings modulo prime^2 on the one-lane pair kernel (two per-number exponents, 4-bit
+  // windows) and the rest an interleaved ladder of 1 024 squarings modulo prime^3 with two per-number exponents and the shared
+  // exponent prime on W -- where the unsplit ladder squares 3 071 times modulo prime^3.  Taken when the stage modulo prime^2
+  // fills the chip (the response batch of ProveDDLEQ at secpar 40: half of 61 440 instances).
+  {
+    const int H1 = sk->mp.WT, W2 = sk->mp2.WT;
+    if (ctx->use_lift && sk->mp2.WT == 2 * sk->mp.WT && sk->mq2.WT == 2 * sk->mq.WT && we <= 3 * H1 &&
+        sk->pinv2k_2.d && sk->qinv2k_2.d && H1 == H && two.split) {
+      const size_t S1 = (size_t)H1 * nb, S2 = (size_t)W2 * nb;
+      const uint32_t *a0[2], *a1[2], *b0[2], *b1[2], *A2[2], *B2[2];
+      uint32_t *Ar[2], *Br[2];
+      Fork fa(ctx, 4);                              // (the chains of small kernels of both halves and both bases side by side, here and below)
+      for (int half = 0; half < 2; ++half) {
+        const ModCtx &m1 = half ? sk->mq : sk->mp, &m2 = half ? sk->mq2 : sk->mp2, &m3 = half ? mq3 : mp3;
+        for (int k = 0; k < 2; ++k) {
+          fa.chain(2 * half + k);
+          uint32_t* tbx = ctx->ws_t<uint32_t>(S);
+          const uint32_t* ex = k ? eb[half] : ea[half];
+          uint32_t* t2 = ctx->ws_t<uint32_t>(S2);
+          uint32_t* d0 = ctx->ws_t<uint32_t>(S1);
+          uint32_t* d1 = ctx->ws_t<uint32_t>(S2);
+          reduce_mod(ctx, m2, ex, we, t2, nb);
+          reduce_mod(ctx, m1, t2, W2, d0, nb);                                                       // e0 = e mod prime
+          launch_div_exact(ex, we, 0, d0, H1, tbx, (half ? sk->qinv2k_2 : sk->pinv2k_2).d, m1.d_nmod, H1, d1, W2, nb, nb, nullptr, 0,
+                           ctx->stream);                                                             // e1 = (e - e0) / prime
+          (k ? b0 : a0)[half] = d0;
+          (k ? b1 : a1)[half] = d1;
+          uint32_t* r3 = ctx->ws_t<uint32_t>(S);
+          uint32_t* r2 = ctx->ws_t<uint32_t>(S2);
+          if (pre) {
+            launch_gather(pre->r3[half][k], pre->nbs, pre->sti, pre->cnt, r3, nb, W, ctx->stream);
+            launch_gather(pre->r2[half][k], pre->nbs, pre->sti, pre->cnt, r2, nb, W2, ctx->stream);
+          } else {
+            reduce_mod(ctx, m3, k ? B : A, W3, r3, nb);
+            reduce_mod(ctx, m2, r3, W, r2, nb);
+          }
+          (k ? Br : Ar)[half] = r3;
+          (k ? B2 : A2)[half] = r2;
+        }
+      }
+      fa.join();
+      uint32_t* wv[2];
+      const bool hand = ctx->use_handover && sk->mp.WT == mp3.triple.root->WT && sk->mq.WT == mq3.triple.root->WT;
+      if (pow_p2_multi_crt(sk, A2, a1, W2, nullptr, nullptr, nb, wv, B2, b1, hand)) {
+        // stage B: slots 0 A, 1 B, 2 tmp, 3 out, 4 W, 5.. A's table, then B's, then W's odd powers
+        const uint32_t TA = 5, TB = TA + (uint32_t)perlane_table_slots(win), TW = TB + (uint32_t)perlane_table_slots(win);
+        TriplePlan up = triple_alloc(ctx, mp3, nb, (int)TW + 64), uq = triple_alloc(ctx, mq3, nb, (int)TW + 64);
+        uint32_t* g2 = ctx->ws_t<uint32_t>(S * 6);
+        Prog pb[2];
+        const uint32_t* dg2[2];
+        Fork fb(ctx, 4);
+        for (int half = 0; half < 2; ++half) {
+          const ModCtx& m3 = half ? mq3 : mp3;
+          const TriplePlan& t = half ? uq : up;
+          fb.chain(2 * half);
+          if (pre) launch_gather(pre->dig[half].slot(0), pre->nbs, pre->sti, pre->cnt, t.slot(0), nb, 3 * t.H, ctx->stream);
+          else triple_enter(ctx, m3, Ar[half], t, 0);
+          fb.chain(2 * half + 1);
+          if (pre) launch_gather(pre->dig[half].slot(1), pre->nbs, pre->sti, pre->cnt, t.slot(1), nb, 3 * t.H, ctx->stream);
+          else triple_enter(ctx, m3, Br[half], t, 1);
+          fb.chain(2 * half);
+          if (hand) {
+            triple_from_pair(ctx, wv[half], t, 4);
+          } else {
+            uint32_t* wz = ctx->ws_t<uint32_t>(S);
+            launch_copy_limbs(wv[half], 0, W2, wz, W, nb, ctx->stream);
+            triple_enter(ctx, m3, wz, t, 4);
+          }
+          uint32_t* d2 = ctx->ws_t<uint32_t>((size_t)2 * H1 * nb);
+          HIPCHK(hipMemcpyAsync(d2, a0[half], S1 * 4, hipMemcpyDeviceToDevice, ctx->stream));
+          HIPCHK(hipMemcpyAsync(d2 + S1, b0[half], S1 * 4, hipMemcpyDeviceToDevice, ctx->stream));
+          dg2[half] = d2;
+          std::vector<SharedBase> sh;
+          sh.push_back(SharedBase{half ? sk->q : sk->p, 4, TW});
+          std::vector<PerNumberBase> pn;
+          pn.push_back(PerNumberBase{H1, 0, TA, 0});
+          pn.push_back(PerNumberBase{H1, 1, TB, (uint32_t)perlane_windows(H1, win)});
+          emit_modexp_multi(pb[half], pn, win, sh, 2, 3, 0);
+          pb[half].end();
+        }
+        fb.join();
+        SegSpec sp{&mp3, &pb[0], up.mem, dg2[0]}, sq{&mq3, &pb[1], uq.mem, dg2[1]};
+        sp.pair = mp3.triple.kconsts; sp.pair_n0inv = sk->mp.n0inv; sp.pair_h = up.H; sp.pair_lanes = 3; sp.tconsts = mp3.triple.tconsts;
+        sq.pair = mq3.triple.kconsts; sq.pair_n0inv = sk->mq.n0inv; sq.pair_h = uq.H; sq.pair_lanes = 3; sq.tconsts = mq3.triple.tconsts;
+        run_vm(ctx, nb, sp, &sq, true);
+        Fork fx(ctx);
+        fx.chain(0);
+        triple_exit(ctx, mp3, up, 3, g2 + 0 * S, nullptr);
+        fx.chain(1);
+        triple_exit(ctx, mq3, uq, 3, g2 + 1 * S, nullptr);
+        fx.join();
+        Prog c;
+        c.op(VM_LOAD, 0); c.op(VM_MULC, (uint32_t)sk->c_p3invR); c.op(VM_STORE, 3);
+        c.op(VM_LOAD, 1); c.op(VM_MULC, (uint32_t)sk->c_p3invR); c.op(VM_STORE, 2);
+        c.end();
+        SegSpec sc{&mq3, &c, g2, nullptr};
+        run_vm(ctx, nb, sc, nullptr, false);
+        launch_canon(g2 + 2 * S, mq3.d_nmod, W, nb, ctx->stream);
+        launch_canon(g2 + 3 * S, mq3.d_nmod, W, nb, ctx->stream);
+        launch_sub_mod(g2 + 2 * S, g2 + 3 * S, mq3.d_nmod, g2 + 4 * S, W, nb, ctx->stream);               // h = (x_q - x_p) / p^3 mod q^3
+        launch_mul_const_add(g2 + 4 * S, W, sk->p3_limbs.d, W, g2, W, 0, out, W3, nb, ctx->stream);       // x_p + p^3 h
+        return true;
+      }
+    }
+  }
+  const uint32_t TABA = 5, TABB = TABA + (uint32_t)perlane_table_slots(win);
+  TriplePlan tp = triple_alloc(ctx, mp3, nb, (int)TABB + perlane_table_slots(win)), tq = triple_alloc(ctx, mq3, nb, (int)TABB + perlane_table_slots(win));
+  uint32_t* g = ctx->ws_t<uint32_t>(S * 6);       // generic slots (W limbs): 0 x_p, 1 x_q, 2 A, 3 B, 4 h, 5 scratch
+  Prog pr[2];
+  const uint32_t* dg[2];
+  Fork fc(ctx);
+  for (int half = 0; half < 2; ++half) {
+    fc.chain(half);
+    const ModCtx& m3 = half ? mq3 : mp3;
+    const TriplePlan& t = half ? tq : tp;
+    if (pre) {
+      launch_gather(pre->dig[half].slot(0), pre->nbs, pre->sti, pre->cnt, t.slot(0), nb, 3 * t.H, ctx->stream);
+      launch_gather(pre->dig[half].slot(1), pre->nbs, pre->sti, pre->cnt, t.slot(1), nb, 3 * t.H, ctx->stream);
+    } else {
+      uint32_t* red = half ? ctx->ws_t<uint32_t>(S) : g + 5 * S;     // (a scratch slot per half: the chains run side by side)
+      reduce_mod(ctx, m3, A, W3, red, nb);
+      triple_enter(ctx, m3, red, t, 0);
+      reduce_mod(ctx, m3, B, W3, red, nb);
+      triple_enter(ctx, m3, red, t, 1);
+    }
+    // the two exponents of a number one after the other in the rows of `digits`: windows 0 .. 4 we - 1 and 4 we .. 8 we - 1
+    uint32_t* d2 = ctx->ws_t<uint32_t>((size_t)2 * we * nb);
+    HIPCHK(hipMemcpyAsync(d2, ea[half], (size_t)we * nb * 4, hipMemcpyDeviceToDevice, ctx->stream));
+    HIPCHK(hipMemcpyAsync(d2 + (size_t)we * nb, eb[half], (size_t)we * nb * 4, hipMemcpyDeviceToDevice, ctx->stream));
+    dg[half] = d2;
+    std::vector<PerNumberBase> pn;
+    pn.push_back(PerNumberBase{we, 0, TABA, 0});
+    pn.push_back(PerNumberBase{we, 1, TABB, (uint32_t)perlane_windows(we, win)});
+    emit_modexp_multi(pr[half], pn, win, {}, 2, 3, 0);
+    pr[half].end();
+  }
+  fc.join();
+  SegSpec sp{&mp3, &pr[0], tp.mem, dg[0]}, sq{&mq3, &pr[1], tq.mem, dg[1]};
+  sp.pair = mp3.triple.kconsts; sp.pair_n0inv = sk->mp.n0inv; sp.pair_h = tp.H; sp.pair_lanes = 3; sp.tconsts = mp3.triple.tconsts;
+  sq.pair = mq3.triple.kconsts; sq.pair_n0inv = sk->mq.n0inv; sq.pair_h = tq.H; sq.pair_lanes = 3; sq.tconsts = mq3.triple.tconsts;
+  run_vm(ctx, nb, sp, &sq, true);
+  Fork fx(ctx);
+  fx.chain(0);
+  triple_exit(ctx, mp3, tp, 3, g + 0 * S, nullptr);
+  fx.chain(1);
+  triple_exit(ctx, mq3, tq, 3, g + 1 * S, nullptr);
+  fx.join();
+  Prog c;
+  c.op(VM_LOAD, 0); c.op(VM_MULC, (uint32_t)sk->c_p3invR); c.op(VM_STORE, 3);
+  c.op(VM_LOAD, 1); c.op(VM_MULC, (uint32_t)sk->c_p3invR); c.op(VM_STORE, 2);
+  c.end();
+  SegSpec sc{&mq3, &c, g, nullptr};
+  run_vm(ctx, nb, sc, nullptr, false);
+  launch_canon(g + 2 * S, mq3.d_nmod, W, nb, ctx->stream);
+  launch_canon(g + 3 * S, mq3.d_nmod, W, nb, ctx->stream);
+  launch_sub_mod(g + 2 * S, g + 3 * S, mq3.d_nmod, g + 4 * S, W, nb, ctx->stream);                  // h = (x_q - x_p) / p^3 mod q^3
+  launch_mul_const_add(g + 4 * S, W, sk->p3_limbs.d, W, g, W, 0, out, W3, nb, ctx->stream);          // x_p + p^3 h
+  return true;
+}
+
+// [w][nb] arrays a, b  ->  one [w][2 nb] array (a's numbers first): two independent batches share one launch
+uint32_t* concat2(pgpu_ctx* ctx, const uint32_t* a, const uint32_t* b, int w, size_t nb) {
+  uint32_t* o = ctx->ws_t<uint32_t>((size_t)w * 2 * nb);
+  HIPCHK(hipMemcpy2DAsync(o, 2 * nb * 4, a, nb * 4, nb * 4, (size_t)w, hipMemcpyDeviceToDevice, ctx->stream));
+  HIPCHK(hipMemcpy2DAsync(o + nb, 2 * nb * 4, b, nb * 4, nb * 4, (size_t)w, hipMemcpyDeviceToDevice, ctx->stream));
+  return o;
+}
+// half `which` (0 / 1) of a [w][2 nb] array -> [w][nb]
+void split2(pgpu_ctx* ctx, const uint32_t* in, int which, int w, size_t nb, uint32_t* out) {
+  HIPCHK(hipMemcpy2DAsync(out, nb * 4, in + (size_t)which * nb, 2 * nb * 4, nb * 4, (size_t)w, hipMemcpyDeviceToDevice, ctx->stream));
+}
+
+// [w][nba + nbb] <- a ([w][nba]) | b ([w][nbb]): two batches of different sizes side by side in one launch
+uint32_t* concat_ab(pgpu_ctx* ctx, const uint32_t* a, size_t nba, const uint32_t* b, size_t nbb, int w) {
+  const size_t t = nba + nbb;
+  uint32_t* o = ctx->ws_t<uint32_t>((size_t)w * t);
+  HIPCHK(hipMemcpy2DAsync(o, t * 4, a, nba * 4, nba * 4, (size_t)w, hipMemcpyDeviceToDevice, ctx->stream));
+  HIPCHK(hipMemcpy2DAsync(o + nba, t * 4, b, nbb * 4, nbb * 4, (size_t)w, hipMemcpyDeviceToDevice, ctx->stream));
+  return o;
+}
+// part `which` (0: the first nba numbers, 1: the nbb after them) of a [w][nba + nbb] array
+void split_ab(pgpu_ctx* ctx, const uint32_t* in, size_t nba, size_t nbb, int which, int w, uint32_t* out) {
+  const size_t t = nba + nbb, n = which ? nbb : nba;
+  HIPCHK(hipMemcpy2DAsync(out, n * 4, in + (which ? nba : 0), t * 4, n * 4, (size_t)w, hipMemcpyDeviceToDevice, ctx->stream));
+}
+
+uint32_t* zext(pgpu_ctx* ctx, const uint32_t* in, int w, int wo, size_t nb) {
+  uint32_t* o = ctx->ws_t<uint32_t>((size_t)wo * nb);
+  launch_copy_limbs(in, 0, w, o, wo, nb, ctx->stream);
+  return o;
+}
+
+}  // namespace pgi
+
+extern "C" {
+
+// ProveDDLEQ (ddleq.go:27-40) for `n_statements` statements (ct1, ct2, a, b) with `secpar` instances each -- draws x, y
+// supplied, instance k of statement j in row j * secpar + k of x / y / alpha / e / f.  What ddleq.go:55-127 recomputes in every
+// instance although it depends on the statement only is computed ONCE per statement: the sanity check ct1^(a^n) b^(n^2) == ct2
+// (:62-69), a^n (:104), a^-1 (:95) and (a^n)^-1, s = ExtractRandonness(ct1) (:103) and the unit tests of s and b; per instance
+// remain x^n, alpha = ct1^(x^n) y^(n^2), the challenge bit and -- for bit 1 -- the response ladder.  The integers are those of
+// `secpar` calls of proveDDLEQInstance with the same draws.  secpar = 1 is pgpu_ddleq_prove.
+static void ddleq_prove_impl(const pgpu_seckey* sk, size_t S, size_t secpar, const uint8_t* ct1, const uint8_t* ct2, size_t ct_stride,
+                             const uint8_t* a, const uint8_t* b, const uint8_t* x, const uint8_t* y, size_t n_stride, uint8_t* alpha,
+                             uint8_t* e_out, size_t e_stride, uint8_t* f_out, int mem) {
+  pgpu_ctx* ctx = sk->ctx;
+  const pgpu_pubkey* pk = sk->pk;
+  {
+    if (S == 0 || secpar == 0) api_throw(PGPU_ERR_INVALID, "empty batch");
+    if (!pk->mn3 || sk->c_mu2R < 0) api_throw(PGPU_ERR_UNSUPPORTED, "level two is not available for this key");
+    if (!pk->g_is_n_plus_1) api_throw(PGPU_ERR_UNSUPPORTED, "DDLEQ prover assumes G = N+1");
+    ctx->bind();
+    ctx->reset_ws();
+    const ModCtx &mn = pk->mn, &mn2 = pk->mn2, &mn3 = *pk->mn3;
+    const int W1 = mn.WT, W2 = mn2.WT, W3 = mn3.WT;
+    // the prover holds the factorisation: exponentiations modulo n^3 go through p^3 and q^3 (pow_n3_crt)
+    const bool crt3 = sk->has_crt2 && sk->c_p3invR >= 0 && 2 * sk->mp3.WT >= W3 && ctx->use_pair;
+    auto perlane3 = [&](const uint32_t* base, const uint32_t* exps, int we, size_t nbx, uint32_t* outp) {
+      if (crt3) pow_n3_crt(sk, base, W3, exps, we, nullptr, nbx, outp);
+      else perlane_pow(ctx, mn3, base, exps, we, nbx, outp);
+    };
+    auto shared3 = [&](const uint32_t* base, int wb, const BigU& ex, size_t nbx, uint32_t* outp) {
+      if (crt3) pow_n3_crt(sk, base, wb, nullptr, 0, &ex, nbx, outp);
+      else shared_pow(ctx, mn3, base, wb, ex, nbx, outp);
+    };
+    const size_t batch = S * secpar;                        // instances
+    const size_t nbs = round_up(S, VM_BLOCK), nb = round_up(batch, VM_BLOCK);
+    if (ct_stride != mn3.nbytes) api_throw(PGPU_ERR_INVALID, "ciphertext stride must be the byte length of n^3");
+    if (n_stride * 8 > (size_t)LB * W1 + 7) api_throw(PGPU_ERR_INVALID, "a, b, x, y must fit the width of n");
+    auto up = [&](const uint8_t* buf, size_t stride, int w, size_t count, size_t nbx) {
+      uint32_t* l = ctx->ws_t<uint32_t>((size_t)w * nbx);
+      unpack_operand(ctx, buf, stride, stride, count, mem, l, w, nbx);
+      return l;
+    };
+    // per statement (S numbers, row stride nbs) ...
+    uint32_t *c1s = up(ct1, ct_stride, W3, S, nbs), *c2s = up(ct2, ct_stride, W3, S, nbs);
+    uint32_t *al = up(a, n_stride, W1, S, nbs), *bl = up(b, n_stride, W1, S, nbs);
+    // ... and per instance (S * secpar numbers, row stride nb)
+    uint32_t *xl = up(x, n_stride, W1, batch, nb), *yl = up(y, n_stride, W1, batch, nb);
+    uint32_t* d_stmt = nullptr;                              // instance -> its statement
+    if (secpar > 1) {
+      std::vector<uint32_t> st(batch);
+      for (size_t i = 0; i < batch; ++i) st[i] = (uint32_t)(i / secpar);
+      d_stmt = ctx->upload_words(st);
+    }
+    auto expand = [&](uint32_t* in, int w) {                 // a per-statement array repeated for the instances of its statement
+      if (secpar == 1) return in;
+      uint32_t* o = ctx->ws_t<uint32_t>((size_t)w * nb);
+      launch_gather(in, nbs, d_stmt, batch, o, nb, w, ctx->stream);
+      return o;
+    };
+    uint32_t *c1 = expand(c1s, W3), *c2 = expand(c2s, W3);
+    const BigU &N = pk->N, &N2 = mn2.N;
+    // ---- what depends on the STATEMENT only and on no ladder of this call goes to the side stream, beside the big launches
+    // (the GPU was busy, but with ~800 small launches in a row between the ladders: 30 of 188 ms per 16 384 instances):
+    //   s = ExtractRandonness(ct1) (ddleq.go:103) for every statement -- a latency-bound launch beside the a^n | x^n
+    //   launch, which fills half the chip; then, behind a^n, the inversion tree for a^-1 | (a^n)^-1 and the unit test of s b
+    //   beside the Alpha ladders.  Which statements have an instance with challenge bit 1 is not known yet: all are done
+    //   (the side work is bound by launch latencies, not by its width).
+    SideStream side(ctx);
+    BigU ns_inv;
+    if (!hostbig::modinv(N2 % sk->lambda, sk->lambda, ns_inv)) api_throw(PGPU_ERR_NOT_INVERTIBLE, "n^2 is not invertible mod lambda");
+    uint32_t* qs = nullptr;                                  // s per statement (W1 limbs, stride nbs)
+    hipEvent_t inputs_ready = side.mark();
+    // ---- sanity check (ddleq.go:62-69): ct1^(a^n mod n^2) * b^(n^2) mod n^3 == ct2, else the reference panics -- once per
+    // statement.  Independent exponentiations of the same shape share a launch (the chip is filled better and, for the half-size
+    // batches of the response, a latency-bound launch is saved outright): a^n (S numbers) | x^n (S secpar numbers), then the
+    // sanity value and alpha -- ct1^(a^n) b^(n^2) | ct1^(x^n) y^(n^2) -- and further down s^(a^n) | s^(x^n).
+    uint32_t* an = ctx->ws_t<uint32_t>((size_t)W2 * nbs);
+    uint32_t* xn = ctx->ws_t<uint32_t>((size_t)W2 * nb);
+    {
+      uint32_t* ax = concat_ab(ctx, al, nbs, xl, nb, W1);
+      uint32_t* axn;
+      if (pow_n2_crt_usable(sk)) {
+        axn = pow_n2_crt(sk, ax, N, nbs + nb);               // the prover holds p and q
+      } else {
+        axn = ctx->ws_t<uint32_t>((size_t)W2 * (nbs + nb));
+        shared_pow(ctx, mn2, ax, W1, N, nbs + nb, axn);
+      }
+      split_ab(ctx, axn, nbs, nb, 0, W2, an);
+      split_ab(ctx, axn, nbs, nb, 1, W2, xn);
+    }
+    // Beside the a^n | x^n launch only where that launch leaves the second wave slot of the SIMDs free (one wave per SIMD or
+    // less: 16 384 instances at secpar 1): a launch that fills both slots would lose one of them on half the chip to the side
+    // launch for its whole length (measured at 32 768 instances: 48 -> 76 ms for 8 ms hidden).  Then s follows on the main stream.
+    // (A side launch of a few dozen waves -- the statements of a secpar-40 call -- costs the big launch next to nothing.)
+    const bool s_beside = plan::extract_beside(nbs, nb, plan::lanes_target(ctx->lanes_wanted));
+    if (s_beside) side.enter(inputs_ready);
+    {
+      // s = ExtractRandonness(ct1) at level two (operations.go:75-91): z = G^(-v) ct1 mod n^3 with v = Decrypt(ct1)
+      // (operations.go:81-86) is only ever used modulo n (:88), and G^v = (1 + n)^v = 1 (mod n) whatever v is (the prover
+      // requires G = n + 1): z = ct1 (mod n).  No decryption, no G^v, no inversion modulo n^3 -- the same s.
+      uint32_t* z2 = ctx->ws_t<uint32_t>((size_t)W2 * nbs);
+      reduce_mod(ctx, mn2, c1s, W3, z2, nbs);
+      if (sk->has_crt && sk->mp.WT * 2 == W1) {                                // z^nsInv mod n through p and q
+        uint32_t* z1 = ctx->ws_t<uint32_t>((size_t)W1 * nbs);
+        reduce_mod(ctx, mn, z2, W2, z1, nbs);
+        qs = pow_n_crt(sk, z1, ns_inv, nbs);
+      } else {
+        qs = ctx->ws_t<uint32_t>((size_t)W1 * nbs);
+        shared_pow(ctx, mn, z2, W2, ns_inv, nbs, qs);                          // z^nsInv mod n
+      }
+    }
+    if (s_beside) side.leave();
+    hipEvent_t an_ready = side.mark();
+    uint32_t* bn2 = ctx->ws_t<uint32_t>((size_t)W3 * nbs);
+    uint32_t* t3 = ctx->ws_t<uint32_t>((size_t)W3 * nb);
+    uint32_t* san = ctx->ws_t<uint32_t>((size_t)W3 * nbs);
+    uint32_t* alp = ctx->ws_t<uint32_t>((size_t)W3 * nb);
+    if (crt3) {
+      // ct1^(a^n) * b^(n^2) and ct1^(x^n) * y^(n^2): one interleaved ladder per number and CRT half, both batches in one launch
+      uint32_t* cc2 = concat_ab(ctx, c1s, nbs, c1, nb, W3);
+      uint32_t* ee2 = concat_ab(ctx, an, nbs, xn, nb, W2);
+      uint32_t* by2 = concat_ab(ctx, bl, nbs, yl, nb, W1);
+      uint32_t* o2 = ctx->ws_t<uint32_t>((size_t)W3 * (nbs + nb));
+      pow_n3_crt(sk, cc2, W3, ee2, W2, &N2, nbs + nb, o2, by2, W1);
+      split_ab(ctx, o2, nbs, nb, 0, W3, san);
+      split_ab(ctx, o2, nbs, nb, 1, W3, alp);
+    } else {
+      shared3(bl, W1, N2, nbs, bn2);
+      perlane3(c1s, an, W2, nbs, t3);
+      modmul_arrays(ctx, mn3, t3, bn2, nbs, san);
+    }
+    int32_t* d_ok = ctx->ws_t<int32_t>(nbs);
+    launch_equal(san, c2s, W3, nbs, S, d_ok, ctx->stream);
+    std::vector<int32_t> hok(S);
+    // ---- side stream, behind a^n (the Alpha ladders above are in flight on the main stream): a^-1 and (a^n)^-1 modulo n^2 for
+    // every statement from ONE inversion tree (both batches side by side; a non-unit is flagged per lane and matters only if
+    // one of its instances draws challenge bit 1), and the unit test of s b for the one-ladder form of the response
+    uint32_t *qainv = ctx->ws_t<uint32_t>((size_t)W2 * nbs), *qani = ctx->ws_t<uint32_t>((size_t)W2 * nbs);
+    int32_t* d_badinv = ctx->ws_t<int32_t>(2 * nbs);
+    bool any_badinv = false, sb_units = false, early = false;
+    uint32_t *ge_all = nullptr, *es_all[2] = {nullptr, nullptr}, *eb_all[2] = {nullptr, nullptr};
+    PreBases pre;
+    const bool one_ladder = crt3 && ctx->use_lift && sk->eo_p.ok && sk->eo_q.ok && sk->eo_p.w == sk->eo_q.w &&
+                            W2 <= 2 * sk->eo_p.modd.WT && W2 <= 2 * sk->eo_q.modd.WT;
+    side.enter(an_ready);
+    {
+      uint32_t* a1 = ctx->ws_t<uint32_t>((size_t)W1 * nbs);
+      launch_restride(al, nbs, S, mn.d_consts + (size_t)C_ONE * W1, a1, nbs, W1, ctx->stream);      // padding lanes: 1
+      uint32_t* a2 = zext(ctx, a1, W1, W2, nbs);
+      uint32_t* an1 = ctx->ws_t<uint32_t>((size_t)W2 * nbs);
+      launch_restride(an, nbs, S, mn2.d_consts + (size_t)C_ONE * W2, an1, nbs, W2, ctx->stream);
+      uint32_t* inv2 = batch_inverse(ctx, mn2, concat2(ctx, a2, an1, W2, nbs), 2 * nbs, 2 * nbs, d_badinv, &any_badinv);
+      split2(ctx, inv2, 0, W2, nbs, qainv);
+      split2(ctx, inv2, 1, W2, nbs, qani);
+      if (one_ladder) {
+        uint32_t* sb = ctx->ws_t<uint32_t>((size_t)W1 * nbs);
+        modmul_arrays(ctx, mn, qs, bl, nbs, sb);
+        launch_restride(sb, nbs, S, mn.d_consts + (size_t)C_ONE * W1, sb, nbs, W1, ctx->stream);
+        sb_units = all_units(ctx, mn, sb, nbs, S);
+      }
+      // The response's per-statement bases (s, b: residues modulo p^3, q^3, p^2, q^2 and digit forms) and, for EVERY instance, its
+      // e = x a^-1, e^n = x^n (a^n)^-1 and the two exponents of the one-ladder response modulo the group orders: nothing here
+      // depends on the challenge bits, so it is done now, beside the Alpha ladders, and the instances that draw bit 1 gather it
+      // afterwards (between the hash and the response ladder there is then a handful of gathers instead of ~150 small kernels).
+      // (only where the response ladder is certain to take pow_n3_crt_two's kernels whatever the number of bit-1 instances turns out
+      // to be: its 7-bit window tables must fit the gather offsets even if every instance draws bit 1)
+      if (one_ladder && sb_units && ctx->use_early && pre_bases_usable(sk) && plan::early_response_ok(nb, sk->mp3.triple.root->WT)) {
+        early = true;
+        std::vector<uint32_t> stall(nb, 0);
+        for (size_t i = 0; i < batch; ++i) stall[i] = (uint32_t)(i / secpar);
+        const uint32_t* d_stall = ctx->upload_words(stall);
+        auto per_inst_all = [&](const uint32_t* in, int w) {
+          uint32_t* o = ctx->ws_t<uint32_t>((size_t)w * nb);
+          launch_gather(in, nbs, d_stall, batch, o, nb, w, ctx->stream);
+          return o;
+        };
+        uint32_t *ainv_a = per_inst_all(qainv, W2), *ani_a = per_inst_all(qani, W2), *gan_a = per_inst_all(an, W2);
+        uint32_t* x2a = zext(ctx, xl, W1, W2, nb);
+        ge_all = ctx->ws_t<uint32_t>((size_t)W2 * nb);
+        modmul_arrays(ctx, mn2, x2a, ainv_a, nb, ge_all);                     // e = x a^-1 mod n^2 (ddleq.go:94-99)
+        uint32_t* en_a = ctx->ws_t<uint32_t>((size_t)W2 * nb);
+        modmul_arrays(ctx, mn2, xn, ani_a, nb, en_a);                         // e^n = x^n (a^n)^-1
+        uint32_t* ls = ctx->ws_t<uint32_t>(nb);
+        uint32_t* lb = ctx->ws_t<uint32_t>(nb);
+        launch_exp_low_combine(xn, gan_a, en_a, ls, lb, nb, ctx->stream);
+        Fork fo(ctx);
+        for (int half = 0; half < 2; ++half) {
+          fo.chain(half);
+          const ExpOrder& eo_ = half ? sk->eo_q : sk->eo_p;
+          const ModCtx& mm = eo_.modd;
+          const size_t sm = (size_t)mm.WT * nb;
+          uint32_t *am = ctx->ws_t<uint32_t>(sm), *em_ = ctx->ws_t<uint32_t>(sm), *xm = ctx->ws_t<uint32_t>(sm),
+                   *pm = ctx->ws_t<uint32_t>(sm), *esm = ctx->ws_t<uint32_t>(sm), *ebm = ctx->ws_t<uint32_t>(sm),
+                   *zero = ctx->ws_t<uint32_t>(sm);
+          HIPCHK(hipMemsetAsync(zero, 0, sm * 4, ctx->stream));
+          reduce_mod(ctx, mm, gan_a, W2, am, nb);
+          reduce_mod(ctx, mm, en_a, W2, em_, nb);
+          reduce_mod(ctx, mm, xn, W2, xm, nb);
+          modmul_arrays(ctx, mm, am, em_, nb, pm);                                         // an en mod m
+          launch_sub_mod(xm, pm, mm.d_nmod, esm, mm.WT, nb, ctx->stream);                   // xn - an en mod m
+          launch_sub_mod(zero, em_, mm.d_nmod, ebm, mm.WT, nb, ctx->stream);                // -en mod m
+          uint32_t* e1 = ctx->ws_t<uint32_t>((size_t)eo_.w * nb);
+          uint32_t* e2 = ctx->ws_t<uint32_t>((size_t)eo_.w * nb);
+          launch_exp_order_lift(ls, 1, esm, mm.WT, eo_.m_limbs.d, eo_.t, eo_.minv, e1, eo_.w, nb, ctx->stream);
+          launch_exp_order_lift(lb, 1, ebm, mm.WT, eo_.m_limbs.d, eo_.t, eo_.minv, e2, eo_.w, nb, ctx->stream);
+          es_all[half] = e1;
+          eb_all[half] = e2;
+        }
+        fo.join();
+        pre_bases(sk, zext(ctx, qs, W1, W3, nbs), zext(ctx, bl, W1, W3, nbs), nbs, pre);
+      }
+    }
+    side.leave();
+    // (a device-to-host copy into pageable memory holds the host until the stream has got there: it comes after the side work
+    // has been issued, not before)
+    HIPCHK(hipMemcpyAsync(hok.data(), d_ok, S * 4, hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHK(hipStreamSynchronize(ctx->stream));
+    for (size_t i = 0; i < S; ++i)
+      if (!hok[i]) api_throw(PGPU_ERR_INVALID, "cannot prove re-encryption because inputs are wrong");
+    // ---- alpha = ct1^(x^n) * y^(n^2) mod n^3 (ddleq.go:81-87); with CRT it came out of the launch above
+    uint32_t* yn2 = ctx->ws_t<uint32_t>((size_t)W3 * nb);
+    if (!crt3) {
+      shared3(yl, W1, N2, nb, yn2);
+      perlane3(c1, xn, W2, nb, t3);
+      modmul_arrays(ctx, mn3, t3, yn2, nb, alp);
+    }
+    // ---- challenge bit = LSB SHA-256(ct2 || x || y || alpha)  (ddleq.go:91; ct1 is skipped: random_oracle.go:24-26)
+    int32_t* chal = ctx->ws_t<int32_t>(nb);
+    HIPCHK(hipMemsetAsync(chal, 0, nb * 4, ctx->stream));
+    const uint32_t* parts[4] = {c2, xl, yl, alp};
+    const int widths[4] = {W3, W1, W1, W3};
+    launch_sha256_transcript(parts, widths, 4, nb, batch, nullptr, chal, ctx->stream);
+    std::vector<int32_t> hch(batch);
+    HIPCHK(hipMemcpyAsync(hch.data(), chal, batch * 4, hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHK(hipStreamSynchronize(ctx->stream));
+    side.join();                                             // the per-statement values are needed from here on
+    // default outputs: e = x, f = y (chalBit false)
+    uint32_t* eo = zext(ctx, xl, W1, W2, nb);
+    uint32_t* fo = zext(ctx, yl, W1, W3, nb);
+    // instances with challenge bit 1 and the statement each belongs to
+    std::vector<uint32_t> idx, sti;
+    for (size_t i = 0; i < batch; ++i)
+      if (hch[i]) {
+        idx.push_back((uint32_t)i);
+        sti.push_back((uint32_t)(i / secpar));
+      }
+    if (!idx.empty()) {
+      const size_t cnt = idx.size(), nbg = round_up(cnt, VM_BLOCK);
+      if (getenv("PGPU_PROFILE_DUMP")) fprintf(stderr, "[pgpu] prove: %zu of %zu instances drew challenge bit 1 (response batch %zu)\n", cnt, batch, nbg);
+      if (any_badinv) {      // ModInverse(a, n^2) of a non-unit a (ddleq.go:95) is undefined in the reference: refuse, as before
+        std::vector<int32_t> hb(2 * nbs);
+        HIPCHK(hipMemcpyAsync(hb.data(), d_badinv, 2 * nbs * 4, hipMemcpyDeviceToHost, ctx->stream));
+        HIPCHK(hipStreamSynchronize(ctx->stream));
+        for (uint32_t st : sti)
+          if (hb[st] || hb[nbs + st])
+            api_throw(PGPU_ERR_NOT_INVERTIBLE, "ModInverse: an element of the batch is not invertible modulo the modulus");
+      }
+      uint32_t* d_idx = ctx->upload_words(idx);
+      uint32_t* d_sti = ctx->upload_words(sti);
+      auto gat = [&](const uint32_t* in, int w) {            // per-instance array -> the compacted instances
+        uint32_t* o = ctx->ws_t<uint32_t>((size_t)w * nbg);
+        launch_gather(in, nb, d_idx, cnt, o, nbg, w, ctx->stream);
+        return o;
+      };
+      auto per_inst = [&](const uint32_t* in, int w) {       // per-statement array -> one entry per compacted instance
+        uint32_t* o = ctx->ws_t<uint32_t>((size_t)w * nbg);
+        launch_gather(in, nbs, d_sti, cnt, o, nbg, w, ctx->stream);
+        return o;
+      };
+      if (early) {
+        // everything but the ladder itself is at hand (side stream, above): gather it for the instances with bit 1
+        uint32_t* ge = gat(ge_all, W2);
+        const uint32_t* es[2] = {gat(es_all[0], sk->eo_p.w), gat(es_all[1], sk->eo_q.w)};
+        const uint32_t* eb[2] = {gat(eb_all[0], sk->eo_p.w), gat(eb_all[1], sk->eo_q.w)};
+        pre.sti = d_sti;
+        pre.cnt = cnt;
+        uint32_t* c5 = ctx->ws_t<uint32_t>((size_t)W3 * nbg);
+        if (!pow_n3_crt_two(sk, nullptr, es, nullptr, eb, nbg, c5, &pre)) api_throw(PGPU_ERR_UNSUPPORTED, "internal: the early response path lost its kernel");
+        uint32_t* y3 = zext(ctx, gat(yl, W1), W1, W3, nbg);
+        uint32_t* gf = ctx->ws_t<uint32_t>((size_t)W3 * nbg);
+        modmul_arrays(ctx, mn3, y3, c5, nbg, gf);                             // f = y c mod n^3 (ddleq.go:114)
+        launch_scatter(ge, nbg, d_idx, cnt, eo, nb, W2, ctx->stream);
+        launch_scatter(gf, nbg, d_idx, cnt, fo, nb, W3, ctx->stream);
+      } else {
+      uint32_t *gx = gat(xl, W1), *gy = gat(yl, W1), *gxn = gat(xn, W2);
+      uint32_t *ainv = per_inst(qainv, W2), *ani = per_inst(qani, W2), *gan = per_inst(an, W2), *sres = per_inst(qs, W1),
+               *gb = per_inst(bl, W1);
+      // e = x * a^-1 mod n^2 (ddleq.go:94-99)
+      uint32_t* x2 = zext(ctx, gx, W1, W2, nbg);
+      uint32_t* ge = ctx->ws_t<uint32_t>((size_t)W2 * nbg);
+      modmul_arrays(ctx, mn2, x2, ainv, nbg, ge);
+      uint32_t* s3 = zext(ctx, sres, W1, W3, nbg);
+      // c = ((s^an * b)^en)^-1 * s^xn ; f = y * c mod n^3   (ddleq.go:103-114)
+      // en = e^n mod n^2 (ddleq.go:104) = (x a^-1)^n = x^n (a^n)^-1: both powers are at hand, so an inversion replaces the ladder
+      uint32_t* en = ctx->ws_t<uint32_t>((size_t)W2 * nbg);
+      modmul_arrays(ctx, mn2, gxn, ani, nbg, en);
+      uint32_t* c5 = nullptr;
+      if (one_ladder) {
+        // c = ((s^an b)^en)^-1 s^xn = s^(xn - an en) b^(-en)  (ddleq.go:107-112) whenever s and b are units: ONE interleaved
+        // ladder with two per-number exponents, computed modulo the group orders of p^3 and q^3 (ord = 2^t m: the odd part
+        // through a Montgomery product modulo m, the 2-part from the lowest limbs, then the CRT lift), instead of the ladders
+        // s^an | s^xn, (.)^en and a batch inversion modulo n^3.  A non-unit s or b (the reference's ModInverse is then
+        // undefined) keeps the literal sequence below and its error.  (The unit test ran per statement, on the side stream.)
+        if (sb_units) {
+          const uint32_t *es[2], *eb[2];
+          uint32_t* ls = ctx->ws_t<uint32_t>(nbg);
+          uint32_t* lb = ctx->ws_t<uint32_t>(nbg);
+          launch_exp_low_combine(gxn, gan, en, ls, lb, nbg, ctx->stream);
+          Fork fo(ctx);                                                  // the exponents modulo the two group orders side by side
+          for (int half = 0; half < 2; ++half) {
+            fo.chain(half);
+            const ExpOrder& eo_ = half ? sk->eo_q : sk->eo_p;
+            const ModCtx& mm = eo_.modd;
+            const size_t sm = (size_t)mm.WT * nbg;
+            uint32_t *am = ctx->ws_t<uint32_t>(sm), *em_ = ctx->ws_t<uint32_t>(sm), *xm = ctx->ws_t<uint32_t>(sm),
+                     *pm = ctx->ws_t<uint32_t>(sm), *esm = ctx->ws_t<uint32_t>(sm), *ebm = ctx->ws_t<uint32_t>(sm),
+                     *zero = ctx->ws_t<uint32_t>(sm);
+            HIPCHK(hipMemsetAsync(zero, 0, sm * 4, ctx->stream));
+            reduce_mod(ctx, mm, gan, W2, am, nbg);
+            reduce_mod(ctx, mm, en, W2, em_, nbg);
+            reduce_mod(ctx, mm, gxn, W2, xm, nbg);
+            modmul_arrays(ctx, mm, am, em_, nbg, pm);                                       // an en mod m
+            launch_sub_mod(xm, pm, mm.d_nmod, esm, mm.WT, nbg, ctx->stream);                 // xn - an en mod m
+            launch_sub_mod(zero, em_, mm.d_nmod, ebm, mm.WT, nbg, ctx->stream);              // -en mod m
+            uint32_t* e1 = ctx->ws_t<uint32_t>((size_t)eo_.w * nbg);
+            uint32_t* e2 = ctx->ws_t<uint32_t>((size_t)eo_.w * nbg);
+            launch_exp_order_lift(ls, 1, esm, mm.WT, eo_.m_limbs.d, eo_.t, eo_.minv, e1, eo_.w, nbg, ctx->stream);
+            launch_exp_order_lift(lb, 1, ebm, mm.WT, eo_.m_limbs.d, eo_.t, eo_.minv, e2, eo_.w, nbg, ctx->stream);
+            es[half] = e1;
+            eb[half] = e2;
+          }
+          fo.join();
+          uint32_t* b3n = zext(ctx, gb, W1, W3, nbg);
+          uint32_t* o = ctx->ws_t<uint32_t>((size_t)W3 * nbg);
+          if (pow_n3_crt_two(sk, s3, es, b3n, eb, nbg, o)) c5 = o;
+        }
+      }
+      uint32_t* cc = ctx->ws_t<uint32_t>((size_t)W3 * nbg);
+      uint32_t* sx = ctx->ws_t<uint32_t>((size_t)W3 * nbg);
+      if (!c5) {
+        // s^(a^n) and s^(x^n) (ddleq.go:107,112): same base, independent exponents -> one launch
+        uint32_t* ss2 = concat2(ctx, s3, s3, W3, nbg);
+        uint32_t* ee2 = concat2(ctx, gan, gxn, W2, nbg);
+        uint32_t* o2 = ctx->ws_t<uint32_t>((size_t)W3 * 2 * nbg);
+        perlane3(ss2, ee2, W2, 2 * nbg, o2);
+        split2(ctx, o2, 0, W3, nbg, cc);
+        split2(ctx, o2, 1, W3, nbg, sx);
+      }
+      if (!c5) {
+        uint32_t* b3 = zext(ctx, gb, W1, W3, nbg);
+        uint32_t* cb = ctx->ws_t<uint32_t>((size_t)W3 * nbg);
+        modmul_arrays(ctx, mn3, cc, b3, nbg, cb);
+        perlane3(cb, en, W2, nbg, cc);
+        launch_restride(cc, nbg, cnt, mn3.d_consts + (size_t)C_ONE * W3, cc, nbg, W3, ctx->stream);
+        uint32_t* ci = batch_inverse(ctx, mn3, cc, nbg, cnt);
+        c5 = ctx->ws_t<uint32_t>((size_t)W3 * nbg);
+        modmul_arrays(ctx, mn3, ci, sx, nbg, c5);
+      }
+      uint32_t* y3 = zext(ctx, gy, W1, W3, nbg);
+      uint32_t* gf = ctx->ws_t<uint32_t>((size_t)W3 * nbg);
+      modmul_arrays(ctx, mn3, y3, c5, nbg, gf);
+      launch_scatter(ge, nbg, d_idx, cnt, eo, nb, W2, ctx->stream);
+      launch_scatter(gf, nbg, d_idx, cnt, fo, nb, W3, ctx->stream);
+      }
+    }
+    pack_result(ctx, alp, W3, nb, batch, alpha, ct_stride, mn3.nbytes, mem);
+    pack_result(ctx, eo, W2, nb, batch, e_out, e_stride, std::min(e_stride, mn2.nbytes), mem);
+    pack_result(ctx, fo, W3, nb, batch, f_out, ct_stride, mn3.nbytes, mem);
+    HIPCHK(hipStreamSynchronize(ctx->stream));
+  }
+}
+
+int pgpu_ddleq_prove(const pgpu_seckey* sk, size_t batch, const uint8_t* ct1, const uint8_t* ct2, size_t ct_stride,
+                     const uint8_t* a, const uint8_t* b, const uint8_t* x, const uint8_t* y, size_t n_stride, uint8_t* alpha,
+                     uint8_t* e_out, size_t e_stride, uint8_t* f_out, int mem) {
+  if (!sk || !ct1 || !ct2 || !a || !b || !x || !y || !alpha || !e_out || !f_out) return fail(PGPU_ERR_INVALID, "null argument");
+  return guarded([&] { ddleq_prove_impl(sk, batch, 1, ct1, ct2, ct_stride, a, b, x, y, n_stride, alpha, e_out, e_stride, f_out, mem); });
+}
+
+int pgpu_ddleq_prove_secpar(const pgpu_seckey* sk, size_t n_statements, size_t secpar, const uint8_t* ct1, const uint8_t* ct2,
+                            size_t ct_stride, const uint8_t* a, const uint8_t* b, const uint8_t* x, const uint8_t* y, size_t n_stride,
+                            uint8_t* alpha, uint8_t* e_out, size_t e_stride, uint8_t* f_out, int mem) {
+  if (!sk || !ct1 || !ct2 || !a || !b || !x || !y || !alpha || !e_out || !f_out) return fail(PGPU_ERR_INVALID, "null argument");
+  if (secpar && n_statements > ((size_t)1 << 31) / secpar) return fail(PGPU_ERR_INVALID, "n_statements * secpar is too large");
+  return guarded([&] {
+    ddleq_prove_impl(sk, n_statements, secpar, ct1, ct2, ct_stride, a, b, x, y, n_stride, alpha, e_out, e_stride, f_out, mem);
+  });
+}
+
+}  // extern "C"

@@ -1,0 +1,723 @@
+// engine.hpp -- internal header of libpaillier_hip.so (nothing here is part of the C ABI: that is include/paillier_hip.h).
+//
+// Translation units:
+//   ctx.cpp        contexts, runtime switches, profile of the last call, error text
+//   keys.cpp       key handles: moduli and their Montgomery / pair / digit-form constants, CRT material
+//   vm_emit.cpp    programs of the big-integer VM and run_vm, the one place that launches a VM kernel
+//   modexp.cpp     ladders on the kernel family that fits, reduction, batch inversion; pgpu_modexp / modmul / modinv
+//   paillier.cpp   Encrypt / Decrypt / Add / Sub / ConstMult, randomness
+//   threshold.cpp  PartialDecrypt (batch forms), Combine, share ZKP
+//   ddleq.cpp      NestedRandomize, DDLEQ prove / verify, RandomOracleDigest
+//   debug.cpp      test hooks (include/paillier_hip_debug.h)
+//   plan.hpp       every size decision (lanes per number, window widths, split gates): pure functions, CPU-tested
+//   kernels.hip / asm_loader.cpp / gen_vm_asm.py   the device side
+// Host code here runs once per key or once per batch call; everything per ciphertext happens on the GPU.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdarg.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+#include <algorithm>
+#include <atomic>
+#include <memory>
+#include <mutex>
+#include <set>
+#include <string>
+#include <thread>
+#include <vector>
+
+#include "../../include/paillier_hip.h"
+#include "hostbig.hpp"
+#include "kernels.h"
+#include "plan.hpp"
+
+namespace pgi {
+
+using hostbig::BigU;
+
+constexpr int LB = plan::LB;
+extern thread_local std::string g_err;
+int fail(int code, const char* fmt, ...);
+
+struct HipError { hipError_t e; const char* what; };
+#define HIPCHK(x)                                                      \
+  do {                                                                 \
+    hipError_t e_ = (x);                                               \
+    if (e_ != hipSuccess) throw ::pgi::HipError{e_, #x};               \
+  } while (0)
+
+struct ApiError { int code; std::string msg; };
+[[noreturn]] void api_throw(int code, const std::string& m);
+
+inline size_t round_up(size_t v, size_t m) { return (v + m - 1) / m * m; }
+
+// overwrite key material before its storage is released (not elided: volatile stores)
+void wipe(void* p, size_t n);
+
+template <class T> void wipe_vec(std::vector<T>& v) { if (!v.empty()) wipe(v.data(), v.size() * sizeof(T)); }
+// wipes host copies of secret exponents on EVERY exit of the enclosing scope, exceptions included
+template <class V> struct WipeOnExit {
+  V& v;
+  explicit WipeOnExit(V& v_) : v(v_) {}
+  ~WipeOnExit() { for (auto& e : v) wipe_vec(e.d); }
+};
+
+}  // namespace pgi
+using namespace pgi;
+
+// ------------------------------------------------------------------------------------------------
+// Context: device, stream, workspace pool, profile events
+// ------------------------------------------------------------------------------------------------
+struct pgpu_ctx {
+  int device = 0;
+  hipStream_t stream = nullptr;
+  bool own_stream = false;   // created by pgpu_ctx_create(device, PGPU_STREAM_NEW): destroyed with the context
+  // workspace: list of chunks, bump allocated, reset per API call
+  struct Chunk { char* p; size_t cap; size_t used; };
+  std::vector<Chunk> chunks;
+  std::vector<std::vector<uint32_t>> host_keep;  // host buffers that async copies read from
+  // profile of the last call
+  struct Ev { hipEvent_t a, b; double mads; char name[32]; };
+  std::vector<Ev> evs;
+  size_t evs_used = 0;
+  bool use_asm = true;       // hand-scheduled VM kernels (pgpu_ctx_set_flag("asm", 0) selects the hipcc-generated ones)
+  int last_vm_asm = 0;       // number of VM launches of the last call that ran the assembly kernel
+  int last_vm_launches = 0;  // number of VM launches of the last call, assembly or compiler-generated
+  bool use_pair = true;      // Decrypt ladders mod p^2 on the pair kernel (pgpu_ctx_set_flag("pair", 0): the 2H-limb kernel)
+  bool use_triple = true;    // ladders modulo n^3 on the three-digit kernel (pgpu_ctx_set_flag("triple", 0): the 3H-limb kernels)
+  bool use_shared_chain = true;   // several shared exponents on ONE base share the chain of squarings (pgpu_partial_decrypt_multi)
+  bool use_lift = true;           // level-two Encrypt: r^(n^2) mod n^3 as (r^n mod n^2)^n mod n^3
+  size_t lanes_wanted = 0;   // 0: default occupancy target; tests set 1 to run every modulus at its natural shape
+  // A second stream for work of a call that depends on no ladder in flight (SideStream below; the DDLEQ prover's
+  // per-statement chains run beside its big launches).  pgpu_ctx_set_flag("side", 0): everything on the one stream.
+  bool use_nm4 = true;       // per-number 4- / 5-bit window tables of the pair kernels number-major (pgpu_ctx_set_flag("nm4", 0): limb-major, VM_MULV / VM_MULV5)
+  bool use_early = true;     // the DDLEQ prover prepares its response for every statement / instance beside the Alpha ladders (pgpu_ctx_set_flag("early", 0): after the hash, for the bit-1 instances)
+  bool use_handover = true;  // a power modulo n^2 that is only needed modulo n^2 by the next ladder modulo n^3 stays in pair form: (a0, a1, 0) is its digit form (pgpu_ctx_set_flag("handover", 0): exit and re-entry)
+  bool use_muls = true;      // bucket products of the shared chain as VM_MULS where the kernel has it (pgpu_ctx_set_flag("muls", 0): LOAD / MUL / STORE)
+  bool use_lanes8 = true;    // shards too small for four lanes per number take the eight-lane pair kernel (pgpu_ctx_set_flag("lanes8", 0): never)
+  bool use_side = true;
+  hipStream_t side = nullptr;
+  hipStream_t side_l[3] = {nullptr, nullptr, nullptr};   // further lanes: chains of small kernels of one CRT half / operand beside the others'
+  std::vector<hipEvent_t> sync_evs;
+  size_t sync_used = 0;
+  hipEvent_t next_sync_ev() {
+    if (sync_used == sync_evs.size()) {
+      hipEvent_t e;
+      HIPCHK(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+      sync_evs.push_back(e);
+    }
+    return sync_evs[sync_used++];
+  }
+
+  void bind() { HIPCHK(hipSetDevice(device)); }
+
+  void reset_ws() {
+    // Chunks are kept across calls (the same call sequence lands in the same chunks again: no allocation in steady
+    // state).  Only a long tail of chunks is consolidated: that costs a device synchronisation and a large hipMalloc
+    // (~100 ms), which must not land in a caller's second call.
+    if (chunks.size() > 12) {
+      HIPCHK(hipStreamSynchronize(stream));
+      size_t total = 0;
+      for (auto& c : chunks) { total += c.cap; HIPCHK(hipFree(c.p)); }
+      chunks.clear();
+      Chunk c{nullptr, round_up(total, 1 << 20), 0};
+      HIPCHK(hipMalloc((void**)&c.p, c.cap));
+      chunks.push_back(c);
+    }
+    for (auto& c : chunks) c.used = 0;
+    sync_used = 0;
+    for (auto& h : host_keep) wipe_vec(h);   // ladder programs encode secret exponents (p - 1, q - 1, shares)
+    host_keep.clear();
+    evs_used = 0;
+    last_vm_asm = 0;
+    last_vm_launches = 0;
+  }
+  void* ws(size_t bytes) {
+    bytes = round_up(bytes ? bytes : 1, 256);
+    for (auto& c : chunks)
+      if (c.cap - c.used >= bytes) { void* p = c.p + c.used; c.used += bytes; return p; }
+    // geometric growth (a new chunk is at least as large as everything before it, up to 64 GiB of the 288): the list stays short, so
+    // the consolidation in reset_ws() -- a free and a multi-GiB hipMalloc inside some later call -- stays rare
+    size_t total = 0;
+    for (auto& k : chunks) total += k.cap;
+    Chunk c{nullptr, std::max(round_up(bytes, 64 << 20), std::min<size_t>(total, (size_t)64 << 30)), bytes};
+    HIPCHK(hipMalloc((void**)&c.p, c.cap));
+    chunks.push_back(c);
+    return c.p;
+  }
+  template <class T> T* ws_t(size_t n) { return (T*)ws(n * sizeof(T)); }
+
+  uint32_t* upload_words(const std::vector<uint32_t>& v) {
+    host_keep.push_back(v);
+    uint32_t* d = ws_t<uint32_t>(v.size());
+    HIPCHK(hipMemcpyAsync(d, host_keep.back().data(), v.size() * 4, hipMemcpyHostToDevice, stream));
+    return d;
+  }
+  Ev& next_ev() {
+    if (evs_used == evs.size()) {
+      Ev e;
+      HIPCHK(hipEventCreate(&e.a));
+      HIPCHK(hipEventCreate(&e.b));
+      e.mads = 0;
+      e.name[0] = 0;
+      evs.push_back(e);
+    }
+    return evs[evs_used++];
+  }
+  // zero the workspace (intermediate values of the last call, ladder programs of secret exponents)
+  void wipe_ws() {
+    if (side) (void)hipStreamSynchronize(side);
+    for (auto l : side_l) if (l) (void)hipStreamSynchronize(l);
+    for (auto& c : chunks) (void)hipMemsetAsync(c.p, 0, c.cap, stream);
+    (void)hipStreamSynchronize(stream);
+    for (auto& h : host_keep) wipe_vec(h);
+  }
+  ~pgpu_ctx() {
+    wipe_ws();
+    for (auto& c : chunks) (void)hipFree(c.p);
+    for (auto& e : evs) { (void)hipEventDestroy(e.a); (void)hipEventDestroy(e.b); }
+    for (auto& e : sync_evs) (void)hipEventDestroy(e);
+    if (side) (void)hipStreamDestroy(side);
+    for (auto l : side_l) if (l) (void)hipStreamDestroy(l);
+    if (own_stream) (void)hipStreamDestroy(stream);
+  }
+};
+
+namespace pgi {
+
+// Work of ONE call on two streams.  Every helper of this file issues to ctx->stream; between enter() and leave() that is the
+// side stream.  enter(after) orders the side work behind an event of the main stream (mark()), leave() goes back WITHOUT making
+// the main stream wait, join() makes the main stream wait for everything the side stream was given.  Host-side synchronisation
+// inside side work (the root of an inversion tree goes through the host) waits for the side stream only: issue the main
+// stream's long launch BEFORE entering, and it runs meanwhile.  Disabled (ctx->use_side == false): everything stays on the one
+// stream, in program order -- the same results.
+struct SideStream {
+  pgpu_ctx* c;
+  hipStream_t main_stream;
+  hipStream_t& s;                           // the lane's stream (created on first use)
+  bool on, entered = false, dirty = false;
+  // lane 0: work of a call that is independent of its ladders (the prover's per-statement chains).  lanes 1 .. 3: independent
+  // CHAINS of small kernels -- the entry into digit form of the q-half next to the p-half's, of operand y next to x's; each such
+  // kernel fills a fraction of the chip for tens of microseconds, chains side by side take about the time of one.
+  explicit SideStream(pgpu_ctx* c_, int lane = 0) : c(c_), main_stream(c_->stream), s(lane ? c_->side_l[lane - 1] : c_->side), on(c_->use_side) {
+    if (on && !s) HIPCHK(hipStreamCreateWithFlags(&s, hipStreamNonBlocking));
+    if (on && s == main_stream) on = false;   // (nested use of a lane from inside itself: stay in line)
+  }
+  hipEvent_t mark() {                       // "everything issued to the main stream so far"
+    if (!on) return nullptr;
+    hipEvent_t e = c->next_sync_ev();
+    HIPCHK(hipEventRecord(e, main_stream));
+    return e;
+  }
+  void enter(hipEvent_t after) {
+    if (!on) return;
+    if (after) HIPCHK(hipStreamWaitEvent(s, after, 0));
+    c->stream = s;
+    entered = dirty = true;
+  }
+  void leave() {
+    if (!on) return;
+    c->stream = main_stream;
+    entered = false;
+  }
+  void join() {
+    if (!on || !dirty) return;
+    if (entered) leave();
+    hipEvent_t e = c->next_sync_ev();
+    HIPCHK(hipEventRecord(e, s));
+    HIPCHK(hipStreamWaitEvent(main_stream, e, 0));
+    dirty = false;
+  }
+  ~SideStream() {                           // error paths: never leave the context on the side stream or the side stream busy
+    if (!on) return;
+    c->stream = main_stream;
+    if (dirty) (void)hipStreamSynchronize(s);
+  }
+};
+
+// Up to four independent chains of small kernels side by side:
+//     Fork f(ctx);  for (k : {0, 1}) { f.chain(k); ... }  f.join();            (Fork f(ctx, 4): chains 0 .. 3)
+// chain(0) is the stream the context was on; chain(k > 0) moves the context to side lane k (ordered behind everything issued before
+// the Fork was made; calls with the same k follow each other on their lane); join() comes back and makes the main stream wait
+// for every lane.  The chains must not share a buffer that one of them writes.  With the side streams off: plain program order.
+struct Fork {
+  std::vector<std::unique_ptr<SideStream>> lanes;
+  hipEvent_t start = nullptr;
+  int cur = 0;
+  explicit Fork(pgpu_ctx* c, int n = 2) {
+    for (int l = 1; l < n && l <= 3; ++l) lanes.emplace_back(new SideStream(c, l));
+    if (!lanes.empty()) start = lanes[0]->mark();
+  }
+  void chain(int k) {
+    k %= (int)lanes.size() + 1;
+    if (cur > 0) lanes[(size_t)cur - 1]->leave();
+    cur = k;
+    if (k > 0) {
+      // (a lane whose stream is the one the context is on -- nested use -- stays in line: SideStream switched itself off)
+      lanes[(size_t)k - 1]->enter(lanes[(size_t)k - 1]->dirty ? nullptr : start);
+    }
+  }
+  void join() {
+    if (cur > 0) lanes[(size_t)cur - 1]->leave();
+    cur = 0;
+    for (auto& l : lanes) l->join();
+  }
+};
+
+// ------------------------------------------------------------------------------------------------
+// Modulus context: Montgomery constants for one odd modulus on the device
+// ------------------------------------------------------------------------------------------------
+enum { C_R2 = 0, C_R3 = 1, C_ONE_M = 2, C_ONE = 3, C_USER = 4 };
+
+struct ModCtx;
+// A modulus N = n^2 whose root n is known can run its shared-exponent ladders on the two-lane pair kernel (GenQ).
+struct PairInfo {
+  const ModCtx* root = nullptr;       // n
+  const uint32_t* consts = nullptr;   // device: n | Cadj (H limbs each) + one word of padding
+  int c_rh = -1;                      // index of R_H mod n^2 (plain) in the consts of n^2
+  int c_one_pair = -1;                // index of the pair form of 1 (the digits of R_H mod n^2) in the consts of n^2
+  const uint32_t* dinv = nullptr;     // n^-1 mod 2^(28 H)
+  const uint32_t* n_limbs = nullptr;  // n as H limbs
+  // the eight-lane pair kernel (GenQ8: every digit in four lanes of h8 / 4 limbs; h8 = H rounded up to a multiple of 4):
+  int h8 = 0;
+  const uint32_t* consts8 = nullptr;  // device: n | Cadj, h8 limbs each, + one word of padding
+  const uint32_t* tconsts8 = nullptr; // device: [3][2 h8] pair digits of R_h8^2 R_H^-1 (radix R_H -> R_h8), of R_H (back), of R_h8 (= 1)
+};
+
+// A modulus N = n^3 whose root n is known can run its ladders on the three-digit kernel (GenQ3): residues as
+// a0 + a1 n + a2 n^2 in the lanes of a quad.
+struct TripleInfo {
+  const ModCtx* root = nullptr;       // n
+  const ModCtx* mid = nullptr;        // n^2 (digit split)
+  const uint32_t* kconsts = nullptr;  // device: n (padded to an even count) | (C1_i, C2_i) pairs | two words of padding
+  const uint32_t* tconsts = nullptr;  // device: constants in digit form, [c][3H]; entry 0 = the digit form of 1
+  int c_rh = -1;                      // in the consts of n^3: R_H mod n^3 (plain): entry into the digit form
+  int c_exit = -1;                    // in the consts of n^3: R R_H^-1 mod n^3 (plain): exit from it
+  const uint32_t* dinv1 = nullptr;    // n^-1 mod 2^(28 WT(n))
+  const uint32_t* dinv2 = nullptr;    // n^-1 mod 2^(28 WT(n^2))
+  const uint32_t* n_limbs = nullptr;  // n   as WT(n) limbs
+  const uint32_t* n2_limbs = nullptr; // n^2 as WT(n^2) limbs
+  bool lanes6_only = false;           // the digit does not fit one lane (H > 74): only the two-lanes-per-digit kernel (GenQ6) serves it,
+                                      // and that one runs shared-exponent and limb-major per-number programs only
+};
+
+struct ModCtx {
+  pgpu_ctx* ctx = nullptr;
+  PairInfo pairn;
+  TripleInfo triple;
+  BigU N, R;
+  size_t nbits = 0, nbytes = 0;
+  int WL = 0, K = 0, WT = 0;
+  uint32_t n0inv = 0;
+  std::vector<BigU> consts;
+  uint32_t* d_nmod = nullptr;
+  uint32_t* d_consts = nullptr;
+  size_t d_consts_cap = 0;
+
+  static bool pick_shape(size_t bits, int& wl, int& k) {
+    // (the widest shape is eight lanes of 42 limbs: 83 limbs in four lanes -- the shape of rounds 1 and 2 -- does not fit the
+    // register file next to its accumulators, so it existed in the compiler-generated kernel only, at 31 % of the issue peak)
+    struct S { int wl, k; } shapes[] = {{37, 1}, {55, 1}, {74, 1}, {55, 2}, {74, 2}, {55, 4}, {74, 4}, {42, 8}};
+    for (auto s : shapes)
+      if (bits + 3 <= (size_t)LB * s.wl * s.k) { wl = s.wl; k = s.k; return true; }
+    return false;
+  }
+
+  void init(pgpu_ctx* c, const BigU& n) {
+    ctx = c;
+    N = n;
+    if (!N.is_odd() || N.bit_length() < 2) api_throw(PGPU_ERR_INVALID, "modulus must be odd and at least 3");
+    nbits = N.bit_length();
+    nbytes = (nbits + 7) / 8;
+    if (!pick_shape(nbits, WL, K)) api_throw(PGPU_ERR_UNSUPPORTED, "modulus wider than 9405 bits is not built");
+    WT = WL * K;
+    R = hostbig::shl(BigU(1), (size_t)LB * WT);
+    uint32_t n0 = N.d[0], x = n0;  // Newton: x = n0^-1 mod 2^32
+    for (int i = 0; i < 6; ++i) x *= 2u - n0 * x;
+    n0inv = (0u - x) & ((1u << LB) - 1);
+    BigU r1 = R % N, r2 = hostbig::mulmod(r1, r1, N), r3 = hostbig::mulmod(r2, r1, N);
+    consts = {r2, r3, r1, BigU(1)};
+  }
+  int add_const(const BigU& v) {  // v < 2N (any value below R works as a Montgomery operand)
+    consts.push_back(v);
+    return (int)consts.size() - 1;
+  }
+  // Montgomery form of v
+  BigU to_mont(const BigU& v) const { return hostbig::mulmod(v % N, R % N, N); }
+  void upload() {
+    ctx->bind();
+    if (!d_nmod) HIPCHK(hipMalloc((void**)&d_nmod, (size_t)WT * 4));
+    std::vector<uint32_t> nl = N.to_limbs(LB, WT);
+    HIPCHK(hipMemcpy(d_nmod, nl.data(), nl.size() * 4, hipMemcpyHostToDevice));
+    if (consts.size() > d_consts_cap) {
+      if (d_consts) HIPCHK(hipFree(d_consts));
+      d_consts_cap = consts.size() + 8;
+      HIPCHK(hipMalloc((void**)&d_consts, d_consts_cap * WT * 4));
+    }
+    std::vector<uint32_t> all;
+    for (auto& c : consts) {
+      auto l = c.to_limbs(LB, WT);
+      all.insert(all.end(), l.begin(), l.end());
+    }
+    HIPCHK(hipMemcpy(d_consts, all.data(), all.size() * 4, hipMemcpyHostToDevice));
+  }
+  ~ModCtx() {   // a modulus may be secret (p, q and their powers): nothing of it outlives the handle
+    if (d_nmod) { (void)hipMemset(d_nmod, 0, (size_t)WT * 4); (void)hipFree(d_nmod); }
+    if (d_consts) { (void)hipMemset(d_consts, 0, d_consts_cap * WT * 4); (void)hipFree(d_consts); }
+    wipe_vec(N.d);
+    for (auto& c : consts) wipe_vec(c.d);
+  }
+};
+
+// device copy of an arbitrary constant as `w` canonical 28-bit limbs
+struct DevLimbs {
+  uint32_t* d = nullptr;
+  int w = 0;
+  void set(const BigU& v, int width) {
+    w = width;
+    auto l = v.to_limbs(LB, width);
+    if (!d) HIPCHK(hipMalloc((void**)&d, (size_t)width * 4));
+    HIPCHK(hipMemcpy(d, l.data(), l.size() * 4, hipMemcpyHostToDevice));
+  }
+  ~DevLimbs() { if (d) { (void)hipMemset(d, 0, (size_t)w * 4); (void)hipFree(d); } }
+};
+
+// ------------------------------------------------------------------------------------------------
+// VM programs
+// ------------------------------------------------------------------------------------------------
+// pgpu_ctx_set_flag("fair", 0): no priority bits in the programs.  A measurement switch (A/B runs of the wave-priority scheme),
+// deliberately PROCESS-wide -- programs are built without a context at hand -- and atomic: other contexts' threads read it
+// while they build programs.  Product code never clears it.
+extern std::atomic<bool> g_wave_priorities;
+struct Prog {
+  std::vector<uint32_t> w;
+  ~Prog() { wipe_vec(w); }   // a ladder program spells out its exponent window by window: p - 1, q - 1, lambda, shares ...
+  double montmuls = 0, sqrs = 0;
+  bool asm_ok = true;  // only opcodes the assembly kernel implements
+  bool has_mulv = false;
+  bool wide_gathers = false;  // table opcodes other than the 4-bit VM_MULV
+  bool nm_tables = false;     // VM_MULV7 / VM_STORET: among the assembly kernels only the three-digit ones implement them
+  bool needs_muls = false;    // VM_MULS: the four- and eight-lane pair kernels only
+  bool nm4 = false;           // VM_MULVT (with VM_STORET): the one-lane pair kernel for 37-limb primes only
+  bool mulv7 = false;
+  uint32_t gather_slots = 1;  // slots a per-number gather spans (table entries + 1): its offsets are 32-bit in the assembly kernels
+  void op(uint32_t o, uint32_t arg = 0, uint32_t aux = 0) {
+    if (o == VM_SETOFF) asm_ok = false;
+    if (o == VM_MULV7 || o == VM_STORET || o == VM_MULVT || o == VM_MULVT5) nm_tables = true;
+    if (o == VM_MULVT || o == VM_MULVT5) nm4 = true;
+    if (o == VM_MULV7) mulv7 = true;
+    if (o == VM_MULS) needs_muls = true;
+    if (o == VM_MULCV || o == VM_MULV5 || o == VM_MULV7 || o == VM_STORET || o == VM_MULVT || o == VM_MULVT5) wide_gathers = true;   // (kernels without these opcodes must not get the program)
+    if (o == VM_MULV || o == VM_MULV5 || o == VM_MULV7 || o == VM_MULVT || o == VM_MULVT5) {
+      has_mulv = true;
+      gather_slots = std::max<uint32_t>(gather_slots, o == VM_MULV ? 17u : o == VM_MULVT ? 18u : o == VM_MULV5 ? 33u : o == VM_MULVT5 ? 49u : 129u);
+    }
+    if (aux >> 22) api_throw(PGPU_ERR_INVALID, "internal: table slot does not fit the instruction word");
+    w.push_back(o | (aux << 8));
+    w.push_back(arg);
+    if (o == VM_SQR || o == VM_MUL || o == VM_MULC || o == VM_MULV || o == VM_MULCV || o == VM_MULV5 || o == VM_MULV7 || o == VM_MULS || o == VM_MULVT || o == VM_MULVT5) montmuls += 1;
+    if (o == VM_SQR) sqrs += 1;
+  }
+  // Bits 30..31 of an instruction word: the priority the wave takes when it gets there -- 3, 2, 1, 0 over four stretches of a
+  // long program (by products done), so that of two waves sharing a SIMD the one that leads yields to the one behind
+  // (gen_vm_asm.py fair_share; the hipcc kernels ignore the bits).  What is lost is the END of the launch, where the wave
+  // that finishes first leaves the other one alone on the SIMD for most of the last stretch -- so the stretches shrink
+  // geometrically (80 %, 16 %, 3.2 %, 0.8 %: the wave that yields crawls at ~7 % of the other's speed, so a stretch has to be
+  // longer than 7 % of the one before it or the leader would run out of program while the other is still catching up).
+  void end() {
+    op(VM_END);
+    if (montmuls < 256 || !g_wave_priorities.load(std::memory_order_relaxed)) return;
+    double done = 0;
+    for (size_t i = 0; i + 1 < w.size(); i += 2) {
+      const uint32_t o = w[i] & 0xFFu;
+      const double f = done / montmuls;
+      const uint32_t quarter = f < 0.80 ? 0u : f < 0.96 ? 1u : f < 0.992 ? 2u : 3u;
+      w[i] = (w[i] & 0x3FFFFFFFu) | ((3u - quarter) << 30);
+      if (o == VM_SQR || o == VM_MUL || o == VM_MULC || o == VM_MULV || o == VM_MULCV || o == VM_MULV5 || o == VM_MULV7 || o == VM_MULS || o == VM_MULVT || o == VM_MULVT5) done += 1;
+    }
+  }
+};
+
+constexpr uint32_t NO_SLOT = 0xFFFFFFFFu;
+
+// ---- vm_emit.cpp ---------------------------------------------------------------------------------------------------------------
+using plan::perlane_windows;
+using plan::perlane_table_slots;
+using plan::dual_sliding_bits;
+using plan::triple_window_bits;
+void emit_to_mont(Prog& p, uint32_t lo, uint32_t hi, uint32_t tmp);
+void emit_modexp_shared(Prog& p, const BigU& e, uint32_t in_lo, uint32_t in_hi, uint32_t tmp, uint32_t out, uint32_t tab,
+                        uint32_t post_slot, bool skip_zero_digits, bool raw = false);
+void emit_modexp_perlane(Prog& p, int we, uint32_t in_lo, uint32_t in_hi, uint32_t tmp, uint32_t out, uint32_t tab,
+                         uint32_t post_slot, int raw_one = -1, int wb = 4, bool nm4 = false);
+void emit_modexp_dual(Prog& p, int we, const BigU& e, uint32_t in1, uint32_t in2, uint32_t tmp, uint32_t out, uint32_t tab1,
+                      uint32_t tab2, int raw_one = -1, int wb = 4, bool nm4 = false);
+
+struct SharedBase { BigU e; uint32_t in; uint32_t tab; };
+struct PerNumberBase { int we; uint32_t in; uint32_t tab; uint32_t first_window; };   // windows first_window.. of the `digits` rows
+void emit_modexp_multi(Prog& p, const std::vector<PerNumberBase>& pn, int wb, const std::vector<SharedBase>& sh, uint32_t tmp,
+                       uint32_t out, uint32_t one, bool nm4 = false);
+void emit_multi_exp_shared_base(Prog& p, const std::vector<BigU>& es, uint32_t in, uint32_t bp, uint32_t run, uint32_t acc,
+                                uint32_t out0, uint32_t bucket0, int w, uint32_t one_const, bool muls = false);
+
+struct SegSpec {
+  const ModCtx* mc;
+  const Prog* prog;
+  uint32_t* mem;
+  const uint32_t* digits;
+  // pair kernel (N = p^2 as two base-p digits, gen_vm_asm.py GenP): `pair` = device array p | Cadj (H limbs each),
+  // pair_n0inv = -p^-1 mod 2^28, pair_h = H.  mc stays the 2H-limb modulus p^2 (slot size, accounting).
+  const uint32_t* pair = nullptr;
+  uint32_t pair_n0inv = 0;
+  int pair_h = 0;
+  int pair_lanes = 1;   // 1: GenP (one lane holds both digits); 2: GenQ (one digit per lane); 4: GenQ4 (two lanes per digit);
+                        // 3: GenQ3 (three digits modulo n^3 in a quad; `tconsts` = its constant table, slots are 3H limbs)
+  const uint32_t* tconsts = nullptr;
+};
+
+// launch one VM kernel with 1 to 3 segments of `nb` numbers each (same modulus shape; s2 only together with s1)
+void run_vm(pgpu_ctx* ctx, size_t nb, const SegSpec& s0, const SegSpec* s1, bool profile, size_t launch_nb = 0,
+            const SegSpec* s2 = nullptr);
+void unpack_operand(pgpu_ctx* ctx, const uint8_t* buf, size_t stride, size_t nbytes, size_t count, int mem,
+                    uint32_t* out, int wt, size_t nb);
+void pack_result(pgpu_ctx* ctx, const uint32_t* in, int wt, size_t nb, size_t count, uint8_t* out, size_t stride,
+                 size_t nbytes, int mem);
+
+template <class F> int guarded(F&& f) {
+  try {
+    f();
+    return PGPU_OK;
+  } catch (const HipError& e) {
+    return fail(PGPU_ERR_HIP, "HIP error: %s (%s)", hipGetErrorString(e.e), e.what);
+  } catch (const ApiError& e) {
+    return fail(e.code, "%s", e.msg.c_str());
+  } catch (const std::exception& e) {
+    return fail(PGPU_ERR_INVALID, "%s", e.what());
+  }
+}
+
+}  // namespace pgi
+
+// ------------------------------------------------------------------------------------------------
+// Opaque handle types
+// ------------------------------------------------------------------------------------------------
+struct pgpu_modulus {
+  pgpu_ctx* ctx;
+  ModCtx mc;
+};
+
+struct pgpu_pubkey {
+  pgpu_ctx* ctx;
+  BigU N, G, H, Kk;
+  bool g_is_n_plus_1;
+  ModCtx mn, mn2;                 // moduli n, n^2  (level one)
+  std::unique_ptr<ModCtx> mn3;    // n^3 (level two), built when the width is supported
+  DevLimbs n_limbs;               // n as mn.WT limbs (multiplicand of the closed-form g^m)
+  DevLimbs ninv2k;                // n^-1 mod 2^(28 mn.WT): exact division by n (the L function)
+  DevLimbs ninv2k_2;              // n^-1 mod 2^(28 mn2.WT): quotients up to n^2 (level two)
+  DevLimbs n2_limbs;              // n^2 as mn2.WT limbs
+  int c_inv2R = -1;               // 2^-1 * R mod n in mn.consts        (binomial of the level-two g^m)
+  int c_ninv2R_2 = -1;            // n * 2^-1 * R mod n^2 in mn2.consts (Damgard-Jurik recovery, paillier.go:326-331)
+  struct AltTab { bool built = false; int base = 0; int nwin = 0; size_t kbits = 0; } alt[2];  // fixed-base comb tables of h_s
+  struct FixedBase { BigU base; int idx; int nwin; };
+  std::vector<FixedBase> fixed_bases;   // comb tables of other fixed bases mod n^2 (verification keys)
+  DevLimbs pairn_consts;          // n | Cadj | pad for the two-lane pair kernel (mn2.pairn points here)
+  DevLimbs pairn_consts8, pairn_tconsts8;   // the same for the eight-lane pair kernel (76-limb digits) and its three constants
+  DevLimbs triple_kconsts;        // n | (C1_i, C2_i) pairs | pad for the three-digit kernel (mn3->triple points here)
+  DevLimbs triple_tconsts;        // its constants in digit form
+  std::vector<std::pair<int, int>> combine_consts;  // (total servers l, index of (4 (l!)^2)^-1 * R mod n in mn.consts)
+};
+
+namespace pgi {
+// order of the unit group modulo pr^3, split as 2^t m for the Montgomery reduction modulo its odd part
+struct ExpOrder {
+  bool ok = false;
+  BigU ord;
+  ModCtx modd;           // m
+  int t = 0;
+  uint32_t minv = 0;     // m^-1 mod 2^t
+  DevLimbs m_limbs;      // m as w limbs
+  int w = 0;             // limbs of a reduced exponent (< 2 ord)
+  void init(pgpu_ctx* ctx, const BigU& pr) {
+    ord = pr * pr * (pr - BigU(1));
+    t = 0;
+    while (!ord.bit((size_t)t)) ++t;
+    if (t > 20) return;                                  // (k m must stay below 2^48 per limb in the lift kernel)
+    const BigU m = hostbig::shr(ord, (size_t)t);
+    modd.init(ctx, m);
+    modd.upload();
+    uint32_t m0 = m.d[0], x = m0;
+    for (int i = 0; i < 6; ++i) x *= 2u - m0 * x;
+    minv = x & ((1u << t) - 1u);
+    w = (int)((ord.bit_length() + 1 + LB - 1) / LB);
+    m_limbs.set(m, w);
+    ok = true;
+  }
+};
+}  // namespace pgi
+
+struct pgpu_seckey {
+  pgpu_ctx* ctx;
+  const pgpu_pubkey* pk;
+  BigU lambda;
+  bool has_crt = false;
+  BigU p, q;
+  ModCtx mp, mq, mp2, mq2;       // moduli p, q, p^2, q^2
+  int c_hpR = -1, c_hqR = -1;    // constants: hp*R mod p in mp, hq*R mod q in mq
+  int c_pinvR = -1;              // p^-1 * R mod q in mq
+  DevLimbs pinv2k, qinv2k;       // p^-1 mod 2^(28 mp.WT), q^-1 mod 2^(28 mq.WT)
+  DevLimbs p_limbs;              // p as mp.WT limbs
+  // generic path (reference formula)
+  ModCtx smn, smn2;              // the key's own constant tables for n and n^2: secret-derived constants never enter the
+                                 // (shared, longer-lived) public key's tables
+  int c_muR = -1;                // lambda^-1 mod n, times R mod n, in smn
+  DevLimbs n_minus_mu;           // (n - mu) mod n, the answer for c == 0 (L(-1) = -1)
+  int c_mu2R = -1;               // lambda^-1 mod n^2, times R mod n^2, in smn2 (level two)
+  ~pgpu_seckey() { wipe_vec(lambda.d); wipe_vec(p.d); wipe_vec(q.d); }
+  // pair kernel for the p^2 / q^2 ladders (GenP): p | Cadj limb arrays, R_H mod p^2 as a plain constant of mp2 / mq2
+  bool has_pair = false;
+  bool pair_small2 = false;        // 37-limb primes: below one wave per SIMD the two-lane kernel fills the chip better
+  int pair_lanes = 1;              // 1: GenP (both digits in one lane, 37-limb primes); 2: GenQ (one digit per lane: 55 / 74 limbs)
+  DevLimbs pair_p, pair_q;
+  int c_rh_p2 = -1, c_rh_q2 = -1;
+  int c_pk_p2[4] = {-1, -1, -1, -1}, c_pk_q2[4] = {-1, -1, -1, -1};   // pair forms of R_H^(k+2): chunk k of c enters the ladder
+  int c_onep_p2 = -1, c_onep_q2 = -1;                                 // pair form of 1 (normalises a lazy pair)
+  DevLimbs q_limbs1;               // q as mq.WT limbs (p_limbs is above)
+  // level-two CRT over p^3 and q^3
+  bool has_crt2 = false;
+  ModCtx mp3, mq3;
+  int c_qinv_p = -1, c_pinv_q = -1;      // q^-1 mod p in mp, p^-1 mod q in mq, stored plain (x*R (x) c = x*c)
+  int c_inv2R_p = -1, c_inv2R_q = -1;    // 2^-1 * R
+  int c_q2R = -1, c_p2R = -1;            // q^2 * R mod p^2 in mp2, p^2 * R mod q^2 in mq2
+  int c_hp2R = -1, c_hq2R = -1;          // (q (p-1))^-1 * R mod p^2 in mp2, (p (q-1))^-1 * R mod q^2 in mq2
+  int c_p2invR = -1;                     // (p^2)^-1 * R mod q^2 in mq2
+  int c_p3invR = -1;                     // (p^3)^-1 * R mod q^3 in mq3 (Garner for exponentiations modulo n^3)
+  DevLimbs p3_limbs;                     // p^3 as mp3.WT limbs
+  DevLimbs pinv2k_2, qinv2k_2;           // p^-1 mod 2^(28 mp2.WT), q^-1 mod 2^(28 mq2.WT)
+  DevLimbs q_limbs, p2_limbs;            // q as mq.WT limbs, p^2 as mp2.WT limbs
+  DevLimbs q2_limbs;                     // q^2 as mq2.WT limbs
+  DevLimbs tkc_p, ttc_p, tkc_q, ttc_q;   // three-digit kernel constants for the ladders modulo p^3 and q^3 (mp3 / mq3 .triple)
+  ExpOrder eo_p, eo_q;                   // exponent reduction modulo the orders of the units modulo p^3 / q^3
+};
+
+namespace pgi {
+
+// ---- keys.cpp / ctx.cpp --------------------------------------------------------------------------------------------------------
+BigU order_fixup(const BigU& e, const BigU& ord);
+std::vector<uint32_t> make_pair_consts(const BigU& pr, int H);
+std::vector<uint32_t> make_triple_kconsts(const BigU& n, int H);
+bool ctx_alive(pgpu_ctx* c);
+
+// ---- modexp.cpp ----------------------------------------------------------------------------------------------------------------
+
+// out[i] = base[i]^e mod N on an already-unpacked base array (slot layout described inline).
+// Returns the device array of canonical results (WT limbs, limb-major).
+// base_wide: the base occupies 2*WT limbs (slots 0 and 1).  post: optional plain multiplicand array.
+struct ModexpPlan {
+  size_t nb;
+  uint32_t* mem;     // slots: 0 in_lo, 1 in_hi, 2 tmp, 3 out, 4 post, 5.. table
+  uint32_t* out() const { return mem + 3 * slot_words; }
+  uint32_t* in() const { return mem; }
+  uint32_t* post() const { return mem + 4 * slot_words; }
+  size_t slot_words;
+};
+struct TriplePlan {
+  uint32_t* mem;        // [slot][3H][nb]
+  size_t slot_words;    // 3H * nb
+  size_t nb;
+  int H;
+  uint32_t* slot(uint32_t i) const { return mem + (size_t)i * slot_words; }
+};
+
+ModexpPlan modexp_alloc(pgpu_ctx* ctx, const ModCtx& mc, size_t nb, int table_slots);
+void reduce_mod(pgpu_ctx* ctx, const ModCtx& mc, const uint32_t* in, int w_in, uint32_t* out, size_t nb);
+void unpack_mod(pgpu_ctx* ctx, const ModCtx& mc, const uint8_t* buf, size_t stride, size_t count, int mem, uint32_t* out,
+                size_t nb, bool canonical = false);
+void modexp_pair(pgpu_ctx* ctx, const ModCtx& mc, const ModexpPlan& pl, const BigU* e, const uint32_t* exps, int we,
+                 bool use_post, int lanes, uint32_t** raw_out = nullptr);
+const uint32_t* windows5_of(pgpu_ctx* ctx, const uint32_t* exps, int we, size_t nb);
+const uint32_t* triple_windows(pgpu_ctx* ctx, const uint32_t* exps, int we, size_t nb, int wb);
+bool triple_usable(pgpu_ctx* ctx, const ModCtx& mc, bool allow6 = false);
+TriplePlan triple_alloc(pgpu_ctx* ctx, const ModCtx& mc, size_t nb, int slots);
+void triple_enter(pgpu_ctx* ctx, const ModCtx& mc, const uint32_t* x, const TriplePlan& tp, uint32_t slot);
+void triple_from_pair(pgpu_ctx* ctx, const uint32_t* pair_digits, const TriplePlan& tp, uint32_t slot);
+void triple_exit(pgpu_ctx* ctx, const ModCtx& mc, const TriplePlan& tp, uint32_t slot, uint32_t* out, const uint32_t* post);
+void triple_run(pgpu_ctx* ctx, const ModCtx& mc, const TriplePlan& tp, const Prog& p, const uint32_t* exps);
+void modexp_triple(pgpu_ctx* ctx, const ModCtx& mc, const ModexpPlan& pl, const BigU* e, const uint32_t* exps, int we,
+                   bool use_post, const uint32_t* pair_digits = nullptr);
+void modexp_shared_run(pgpu_ctx* ctx, const ModCtx& mc, const ModexpPlan& pl, const BigU& e, bool wide, bool use_post,
+                       bool skip_zero, uint32_t** raw_pair_out = nullptr, const uint32_t* pair_digits_in = nullptr);
+void modexp_perlane_run(pgpu_ctx* ctx, const ModCtx& mc, const ModexpPlan& pl, const uint32_t* exps, int we, bool wide,
+                        bool use_post);
+uint32_t* tree_inverse(pgpu_ctx* ctx, const ModCtx& mc, const uint32_t* x, size_t nb, size_t count);
+
+// Are ALL of x[0 .. count) units modulo N?  The up-sweep of the same product tree and one gcd on the host -- half the
+// launches of tree_inverse and no inverses; what the randomness filter needs (utils.go:43: gcd(r, n) = 1) in the
+// overwhelmingly likely case that every draw is a unit.
+// all_units in two halves for a caller that has something to run meanwhile: begin() issues the product tree (to the stream the
+// context is on) and leaves the root's bytes on the device, finish() fetches them, waits and tests the gcd on the host.
+struct UnitCheck {
+  pgpu_ctx* ctx = nullptr;
+  const ModCtx* mc = nullptr;
+  uint8_t* d_rb = nullptr;
+  hipStream_t st = nullptr;
+  std::unique_ptr<SideStream> side;
+  bool begun = false;
+  void begin(pgpu_ctx* c, const ModCtx& m, const uint32_t* x, size_t nb, size_t count);
+  bool finish() {
+    std::vector<uint8_t> rb(mc->nbytes);
+    HIPCHK(hipMemcpyAsync(rb.data(), d_rb, mc->nbytes, hipMemcpyDeviceToHost, st));
+    HIPCHK(hipStreamSynchronize(st));
+    if (side) side->dirty = false;
+    BigU root = BigU::from_be(rb.data(), rb.size()), rinv;
+    return hostbig::modinv(root, mc->N, rinv);
+  }
+};
+bool all_units(pgpu_ctx* ctx, const ModCtx& mc, const uint32_t* x, size_t nb, size_t count);
+uint32_t* batch_inverse(pgpu_ctx* ctx, const ModCtx& mc, const uint32_t* x, size_t nb, size_t count, int32_t* d_bad = nullptr,
+                        bool* any_bad = nullptr);
+
+// After a batch_inverse with per-lane flags: OR PGPU_LANE_NOT_INVERTIBLE into the caller's status array, or -- when the caller
+// passed none -- report the failure through the return code once the outputs have been written (finish_bad_lanes()).
+struct BadLanes {
+  bool any = false;
+  std::vector<int32_t> host;
+  void collect(pgpu_ctx* ctx, const int32_t* d_bad, size_t batch, bool any_bad) {
+    if (!any_bad) return;
+    any = true;
+    host.resize(batch);
+    HIPCHK(hipMemcpyAsync(host.data(), d_bad, batch * 4, hipMemcpyDeviceToHost, ctx->stream));
+    HIPCHK(hipStreamSynchronize(ctx->stream));
+  }
+  void finish(int32_t* status, size_t batch) const {
+    if (status) {
+      for (size_t i = 0; i < batch; ++i) status[i] = (any && host[i]) ? PGPU_LANE_NOT_INVERTIBLE : PGPU_LANE_OK;
+      return;
+    }
+    if (any)
+      api_throw(PGPU_ERR_NOT_INVERTIBLE, "ModInverse of a non-unit: the invertible lanes were computed, the others are zero "
+                                         "(pass a status array to get them per lane)");
+  }
+};
+
+void check_batch_args(const void* a, const void* b, size_t batch);
+void pair_enter(pgpu_ctx* ctx, const ModCtx& mc, uint32_t* ent, size_t nb);
+uint32_t* pair_leave(pgpu_ctx* ctx, const ModCtx& mc, uint32_t* pm, uint32_t out_slot, size_t nb);
+void pair_leave_and_pack(pgpu_ctx* ctx, const ModCtx& mc, uint32_t* pm, uint32_t out_slot, size_t nb, size_t count, uint8_t* dst,
+                         size_t out_stride, int mem);
+uint32_t* dual_pow_pair(pgpu_ctx* ctx, const ModCtx& mc, const uint32_t* x, const uint32_t* exps, int we, const uint32_t* y,
+                        const BigU& e, size_t nb, uint32_t** raw_out = nullptr);
+void perlane_pow(pgpu_ctx* ctx, const ModCtx& mc, const uint32_t* base, const uint32_t* exps, int we, size_t nb, uint32_t* out);
+void modmul_arrays(pgpu_ctx* ctx, const ModCtx& mc, const uint32_t* a, const uint32_t* b, size_t nb, uint32_t* out);
+void shared_pow(pgpu_ctx* ctx, const ModCtx& mc, const uint32_t* base, int wb, const BigU& e, size_t nb, uint32_t* out);
+
+// ---- paillier.cpp --------------------------------------------------------------------------------------------------------------
+const ModCtx& cipher_mod(const pgpu_pubkey* pk, int level);
+uint32_t* pow_n_crt(const pgpu_seckey* sk, const uint32_t* base, const BigU& e, size_t nb);
+bool pow_n2_crt_usable(const pgpu_seckey* sk);
+uint32_t* pow_n2_crt(const pgpu_seckey* sk, const uint32_t* base, const BigU& e, size_t nb);
+uint32_t* L_times_const(pgpu_ctx* ctx, const pgpu_pubkey* pk, const uint32_t* u, size_t nb, size_t count, const ModCtx& mn,
+                        int c_const, const uint32_t* neg_const);
+
+}  // namespace pgi

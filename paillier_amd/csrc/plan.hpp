@@ -1,0 +1,123 @@
+// plan.hpp -- every SIZE decision of the engine in one place: which kernel shape, how many lanes per number, which window
+// width, whether a ladder is split.  Pure host functions of (batch size, limb counts, occupancy target, switches) -- no HIP, no
+// context, no key material -- so that they can be unit-tested without a GPU (tests/test_plan_cpu.py through pgpu_plan_query of
+// include/paillier_hip_debug.h) and so that two call sites cannot disagree about the same bound.  (Round 3 shipped a regression
+// exactly there: the split gate of the prover's Alpha ladder bounded 128 + 64 table slots where the window-width choice bounded
+// the 128 entries the gathers address; between 50 121 and 74 986 numbers the p-adic split was silently dropped.)
+//
+// Vocabulary: nb = numbers of a launch (padded to 256); H = limbs of a digit (37 for the primes of a 2048-bit key, 74 for its n);
+// lt = lanes that fill the chip with one wave per SIMD (1024 SIMDs x 64), or the caller's override (pgpu_ctx_set_flag
+// "lanes_wanted").
+#pragma once
+#include <stddef.h>
+#include <stdint.h>
+
+namespace plan {
+
+constexpr int LB = 28;                          // bits of a limb
+constexpr size_t kChipLanes = (size_t)1024 * 64;   // 256 CUs x 4 SIMDs x 64 lanes: one wave on every SIMD
+constexpr uint64_t kGatherSpan = 1ull << 32;    // per-number table gathers of the assembly kernels use 32-bit byte offsets
+
+inline size_t lanes_target(size_t ctx_lanes_wanted) { return ctx_lanes_wanted ? ctx_lanes_wanted : kChipLanes; }
+
+// ---- per-number window tables -------------------------------------------------------------------------------------------------
+// windows of a `we`-limb exponent: 4 bits = 7 per 28-bit limb (VM_MULV / VM_MULVT), 7 bits = 4 per limb (VM_MULV7), 5 bits = 5
+// per repacked 25-bit word (VM_MULV5 / VM_MULVT5)
+inline int perlane_windows(int we, int wb) { return wb == 4 ? we * 7 : wb == 5 ? (we * LB + 4) / 5 : we * 4; }
+// slots a table OCCUPIES: the 2^wb gathered entries and, for number-major tables (nm), the limb-major copies of the entries the
+// table build itself reads back (7 bits: 64; 5 bits: 16; 4 bits: x alone)
+inline int perlane_table_slots(int wb, bool nm = false) { return wb == 7 ? 128 + 64 : nm ? (wb == 5 ? 32 + 16 : 16 + 1) : 1 << wb; }
+// entries a GATHER can address (+ 1: the lane's own offset inside the last entry).  Only these must lie within the 32-bit
+// offsets -- the limb-major scratch copies behind a number-major table are reached through 64-bit slot bases.
+inline int gather_entries(int wb) { return (1 << wb) + 1; }
+inline bool gather_fits(size_t nb, int slot_limbs, int entries) { return (uint64_t)nb * (uint64_t)slot_limbs * 4u * (uint64_t)entries < kGatherSpan; }
+
+// sliding-window width of the SHARED exponent that rides on the same chain of squarings as per-number windows of wb bits
+inline int dual_sliding_bits(int wb) { return wb == 7 ? 7 : 6; }
+
+// three-digit kernels (slots of 3H limbs): 7-bit per-number windows while the 128 gathered entries stay inside the offsets
+// (75 000 numbers for 37-limb digits, 37 000 for 74-limb digits), else 5-bit windows (number-major as well: VM_MULVT5)
+inline int triple_window_bits(size_t nb, int H) { return gather_fits(nb, 3 * H, gather_entries(7)) ? 7 : 5; }
+// the three-digit kernel serves a batch at all (its widest unconditional gather: 32 limb-major entries of a WT(n^3)-limb slot)
+inline bool triple_batch_fits(size_t nb, int wt3) { return gather_fits(nb, wt3 + 4, 33); }
+
+// pair kernels, per-number windows: number-major 4-bit tables (VM_MULVT) while 16 entries + x fit
+inline bool pair_nm4_fits(size_t nb, int w2) { return gather_fits(nb, w2, 18); }
+// ... limb-major 4-bit tables (VM_MULV)
+inline bool pair_mulv_fits(size_t nb, int w2) { return gather_fits(nb, w2, 17); }
+// interleaved ladder modulo n^2 (dual_pow_pair): 5-bit windows while the table fits, else 4-bit, else not on the pair kernels (0)
+inline int dual_pair_window_bits(size_t nb, int w2, bool nm) {
+  if (gather_fits(nb, w2, perlane_table_slots(5, nm) + 1)) return 5;
+  if (gather_fits(nb, w2, perlane_table_slots(4, nm) + 1)) return 4;
+  return 0;
+}
+
+// ---- lanes per number -----------------------------------------------------------------------------------------------------------
+// Shared-exponent ladder modulo n^2 in pair form (GenQ 2 lanes / GenQ4 4 lanes / GenQ8 8 lanes per number).  `numbers` = all the
+// numbers of the launch (segments included).  Two lanes from one wave per SIMD upwards; below that four (a squaring is half as
+// long: the ladder's latency is the run time); eight while every wave still has a SIMD of its own.  0: no pair kernel fits.
+inline int pair_lanes_shared(size_t numbers, size_t lt, bool have4, bool have8) {
+  if (numbers * 2 >= lt) return 2;
+  if (!have4) return 2;
+  if (have8 && numbers * 8 <= lt) return 8;
+  return 4;
+}
+// a batch below one wave per SIMD at two lanes per number needs the four-lane kernel; a key whose digits it does not serve
+// (odd limb counts) leaves such batches to the other kernel families
+inline bool pair_kernel_serves(size_t numbers, size_t lt, bool have4) { return numbers * 2 >= lt || have4; }
+// ... without the eight-lane kernel in play (per-number windows, program segments that share a launch)
+inline int pair_lanes_2or4(size_t numbers, size_t lt, bool have4) { return (numbers * 2 >= lt || !have4) ? 2 : 4; }
+
+// CRT halves modulo p^2, q^2 on the one-lane pair kernel (GenP, 37-limb primes): two lanes per number only while they leave every
+// wave a SIMD of its own (both halves: 4 nb lanes); between half a wave and one wave per SIMD at one lane, two lanes would put
+// two waves on most SIMDs (16.9 against 14.5 ms for 20 480 ... 30 720 ciphertexts)
+inline int crt_pair_lanes(int key_lanes, bool have_two_lane_variant, size_t nb, size_t lt) {
+  return (key_lanes == 1 && have_two_lane_variant && nb * 4 <= lt) ? 2 : key_lanes;
+}
+// whether the CRT halves of Decrypt take the pair kernels at all at this batch size
+inline bool crt_pair_usable(int lanes_now, int prime_limbs, size_t nb, size_t lt) { return lanes_now == 1 || prime_limbs <= 55 || nb * 4 >= lt; }
+
+// three-digit kernel: two lanes per digit (GenQ6) for batches so small that eight lanes per number still leave every wave a SIMD
+inline bool triple_two_lanes_per_digit(size_t nb, size_t lt) { return nb * 8 <= lt; }
+
+// several shares on the same ciphertexts: ONE chain of squarings when the batch fills at least half the chip on its own
+inline bool shared_chain_pays(size_t nb, size_t lt) { return nb * 8 >= lt; }
+
+// ---- the key holder's ladders modulo p^3, q^3 (DDLEQ prover) -------------------------------------------------------------------
+struct Crt3Ladder {
+  bool triple;     // both halves on the three-digit kernel
+  int win;         // per-number window bits there (7 / 5)
+  bool nm5;        // 5-bit windows on number-major tables
+  bool split;      // p-adic split: a stage of 2 047 squarings modulo p^2 on the pair kernel, then 1 024 modulo p^3
+};
+// per_number: the ladder has per-number exponents (Alpha / sanity / response); prereq: what the split needs from the key and the
+// switches (lift on, exponents reduced modulo the group orders, the pair kernel for p^2 ...), decided by the caller
+inline Crt3Ladder crt3_ladder(size_t nb, int H, int wt3, size_t lt, bool per_number, bool prereq) {
+  Crt3Ladder l{};
+  l.triple = triple_batch_fits(nb, wt3);
+  l.win = per_number ? triple_window_bits(nb, H) : 5;
+  l.nm5 = per_number && l.win == 5;
+  // below one wave per SIMD for the stage modulo p^2 a ladder's length binds and one ladder is shorter than two; the windows of
+  // r0 on the digit kernel must fit the gather offsets -- the ENTRIES the gathers address (gather_entries), not the slots the
+  // table occupies
+  l.split = l.triple && prereq && per_number && nb * 4 >= lt && gather_fits(nb, 3 * H, gather_entries(l.win));
+  return l;
+}
+// the response ladder with two per-number exponents (pow_n3_crt_two): 7-bit windows only; its own p-adic split likewise
+struct Crt3Two { bool usable; bool split; };
+inline Crt3Two crt3_two(size_t nb, int H, size_t lt, bool prereq) {
+  Crt3Two t{};
+  t.usable = triple_window_bits(nb, H) == 7;
+  t.split = t.usable && prereq && nb * 4 >= lt && gather_fits(nb, 3 * H, gather_entries(7));
+  return t;
+}
+// the response may be prepared for EVERY instance before the challenge bits are known only where its kernels are certain
+// whatever the number of bit-1 instances turns out to be (all of them at worst)
+inline bool early_response_ok(size_t nb_instances, int H) { return triple_window_bits(nb_instances, H) == 7; }
+// s = ExtractRandonness on the side stream BESIDE the a^n | x^n launch: only where that launch leaves the second wave slot of
+// the SIMDs free (one wave per SIMD or less) or the side launch is a few dozen waves
+inline bool extract_beside(size_t nb_statements, size_t nb_instances, size_t lt) {
+  return (nb_statements + nb_instances) * 2 <= lt || nb_statements * 2 * 8 <= lt;
+}
+
+}  // namespace plan

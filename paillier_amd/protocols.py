@@ -226,9 +226,11 @@ def verify_ddleq_proof_batch(pk: PublicKey, ct1s: Sequence[int], ct2s: Sequence[
                              proofs: Sequence[Sequence[DDLEQProofInstance]]) -> List[bool]:
     """VerifyDDLEQProof (ddleq.go:44-53) for a batch of statements: one verdict per statement (every instance must verify), all
     instances of all statements in one device batch."""
+    if not (len(ct1s) == len(ct2s) == len(proofs)):      # (a statement without a proof must not pass for want of a verdict)
+        raise ValueError("verify_ddleq_proof_batch: one ct2 and one proof per statement")
     flat = [(c1, c2, p) for c1, c2, pr in zip(ct1s, ct2s, proofs) for p in pr]
     if not flat:
-        return [True] * len(ct1s)
+        return [True] * len(proofs)
     ok = pk.VerifyDDLEQInstancesBatch([t[0] for t in flat], [t[1] for t in flat], [t[2].X for t in flat], [t[2].Y for t in flat],
                                       [t[2].Alpha for t in flat], [t[2].E for t in flat], [t[2].F for t in flat])
     out, k = [], 0

@@ -112,7 +112,8 @@ int main(int argc, char** argv) {
   OK(pgpu_encrypt_with_r(pk, PGPU_LEVEL_ONE, B, m, pb, r, pb, c, cb, PGPU_MEM_HOST));
   CHECK(same(c, get("enc_c"), cb));
   OK(pgpu_ctx_last_profile(ctx, &ms, &launches, &mads));
-  CHECK(launches >= 1 && mads > 0 && strncmp(pgpu_ctx_last_kernel(ctx), "vm_", 3) == 0 && pgpu_ctx_last_vm_asm(ctx) >= 1);
+  CHECK(launches >= 1 && mads > 0 && strncmp(pgpu_ctx_last_kernel(ctx), "vm_", 3) == 0 && pgpu_ctx_last_vm_asm(ctx) >= 1 &&
+        pgpu_ctx_last_vm_launches(ctx) >= pgpu_ctx_last_vm_asm(ctx));
   OK(pgpu_decrypt(sk, PGPU_LEVEL_ONE, B, c, cb, out, pb, PGPU_MEM_HOST, PGPU_DECRYPT_DEFAULT, st));
   CHECK(memcmp(out, m, B * pb) == 0 && st[0] == PGPU_LANE_OK);
   /* the key holder's EncryptWithR (SecretKey embeds PublicKey, paillier.go:59-62): r^n through p^2, q^2 -- the same ciphertexts */
@@ -216,6 +217,22 @@ int main(int argc, char** argv) {
     for (s = 0; s < 3; ++s) { size_t i; for (i = 0; i < nt; ++i) { memcpy(un + (s * nt + i) * tcb, cc + i * tcb, tcb); idx[s * nt + i] = s; } }
     OK(pgpu_partial_decrypt_indexed(tpk, 5, 3, shp, shl, 3 * nt, un, tcb, idx, uo, tcb, PGPU_MEM_HOST));
     for (s = 0; s < 3; ++s) CHECK(memcmp(uo + (size_t)s * nt * tcb, parts[s], nt * tcb) == 0);
+    /* the unit range of one rank of the sharded flow straight from the ciphertext batch (pgpu_partial_decrypt_units; what
+     * paillier_amd/dist.py shard_slice hands rank r of w): rank 0 of 2 -- one server whole and part of the next, the ciphertexts
+     * wanted under both shares walk ONE chain of squarings --, rank 7 of 8 -- the tail of the last server --, and the whole job */
+    { static const int rw[3][2] = {{0, 2}, {7, 8}, {0, 1}}; int t;
+      for (t = 0; t < 3; ++t) {
+        size_t total = 3 * nt, w = (size_t)rw[t][1], r = (size_t)rw[t][0], base = total / w, rem = total % w;
+        size_t ub = r * base + (r < rem ? r : rem), ue = ub + base + (r < rem ? 1 : 0);
+        uint8_t* ro = (uint8_t*)calloc(ue - ub + 1, tcb);
+        CHECK(ub < ue);
+        OK(pgpu_partial_decrypt_units(tpk, 5, 3, shp, shl, nt, cc, tcb, ub, ue, ro, tcb, PGPU_MEM_HOST));
+        CHECK(memcmp(ro, uo + ub * tcb, (ue - ub) * tcb) == 0);
+        free(ro);
+      }
+      CHECK(pgpu_partial_decrypt_units(tpk, 5, 3, shp, shl, nt, cc, tcb, 2, 2, uo, tcb, PGPU_MEM_HOST) == PGPU_ERR_INVALID);           /* empty range */
+      CHECK(pgpu_partial_decrypt_units(tpk, 5, 3, shp, shl, nt, cc, tcb, 0, 3 * nt + 1, uo, tcb, PGPU_MEM_HOST) == PGPU_ERR_INVALID);  /* past the job */
+    }
     /* one ciphertext batch under the three shares held by one process (pgpu_partial_decrypt_multi) */
     { uint8_t* mo[3]; uint8_t* const* mop = mo;
       for (s = 0; s < 3; ++s) mo[s] = (uint8_t*)calloc(nt, tcb);

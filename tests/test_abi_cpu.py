@@ -38,6 +38,46 @@ def test_python_binding_covers_the_header(lib):
     assert sorted(SIGNATURES) == declared_symbols()
 
 
+def test_debug_hooks_are_not_part_of_the_boundary(lib):
+    """Test hooks (raw VM programs, the planning predicates) live in include/paillier_hip_debug.h: exported for the tests,
+    declared nowhere in the drop-in header, bound by no Go / C / C++ host."""
+    from paillier_amd.api import DEBUG_SIGNATURES
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    import abi_coverage
+    dbg = [s for s in abi_coverage.declared("paillier_hip_debug.h") if s not in declared_symbols()]
+    assert sorted(dbg) == sorted(DEBUG_SIGNATURES) and len(dbg) == 3
+    for s in dbg:
+        assert hasattr(lib, s)
+        assert s not in declared_symbols()
+        for f in (("go", "gpu.go"), ("go", "batch.go"), ("tests", "c", "test_cabi.c"), ("paillier_amd", "host", "paillier.hpp")):
+            assert s not in open(os.path.join(ROOT, *f)).read(), f"{s} leaked into {f[-1]}"
+
+
+def test_every_entry_point_is_bound_in_go_called_from_c_and_from_python():
+    """header <-> Go shim <-> plain-C test <-> ctypes, one line per symbol, no gaps."""
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    import abi_coverage
+    rows = abi_coverage.coverage()
+    assert len(rows) == len(declared_symbols())
+    for r in rows:
+        assert r["go"], f"{r['symbol']} has no Go binding in go/*.go"
+        assert r["c"], f"{r['symbol']} is not called by tests/c/test_cabi.c"
+        assert r["py"], f"{r['symbol']} is not called by paillier_amd/*.py"
+    table = open(os.path.join(ROOT, "INTEGRATION.md")).read()
+    for r in rows:
+        assert f"| `{r['symbol']}` | `{r['go']}` |" in table, f"INTEGRATION.md 3b is stale for {r['symbol']} (python tools/abi_coverage.py)"
+
+
+def test_library_exports_only_the_headers(lib):
+    """-fvisibility=hidden: the dynamic symbol table holds the pgpu_* functions of the two headers and no other function."""
+    out = subprocess.run(["nm", "-D", "--defined-only", os.path.join(ROOT, "paillier_amd", "libpaillier_hip.so")], capture_output=True,
+                         text=True, check=True).stdout
+    funcs = sorted(l.split()[-1] for l in out.splitlines() if len(l.split()) == 3 and l.split()[1] in "Tt")
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    import abi_coverage
+    assert funcs == sorted(set(declared_symbols()) | set(abi_coverage.declared("paillier_hip_debug.h")))
+
+
 def test_no_cpu_fallback(lib):
     """Without a gfx950 device context creation must fail loudly; nothing computes on the CPU."""
     import torch

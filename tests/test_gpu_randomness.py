@@ -54,3 +54,28 @@ def test_random_units_rejects_non_units(ctx):
         if n == 105:                                   # 48 units, ~104 draws each: a crude uniformity check (6 sigma)
             assert seen.min() > 104 - 62 and seen.max() < 104 + 62
         assert counts.sum() == 5000 and counts[[r for r in range(n) if r not in set(units)]].sum() == 0
+
+
+@pytest.mark.parametrize("side", [1, 0])
+@pytest.mark.parametrize("n", [105, 101 * 103])
+def test_encrypt_redoes_the_call_when_a_draw_is_not_a_unit(n, side):
+    """pgpu_encrypt only STARTS the gcd test of its draws before the ladder (side stream) and asks for the verdict afterwards; if a
+    draw was not a unit the whole call is redone with the test first (careful redraw).  For an honest modulus that branch never
+    runs; toy moduli with many non-units (105: 54 % of the draws; 101 * 103, thresholdkey_test.go:58: 2 %) take it on every call.
+    What comes back must be the SECOND attempt's outputs: every r a unit (utils.go:43) and c the ciphertext of exactly that r.
+    side = 0: no side stream, the test runs first."""
+    import paillier_amd as pa
+    ctx = pa.Context(0)
+    ctx.set_flag("side", side)
+    pk = pa.PublicKey(ctx, n, n + 1)
+    rng = random.Random(n + side)
+    B = 700
+    ms = [0, 1, n - 1] + [rng.randrange(n) for _ in range(B - 3)]
+    for _ in range(3):
+        cts, rs = pk.EncryptBatch(ms, return_r=True)
+        assert len(cts) == len(rs) == B
+        assert all(0 < r < n and math.gcd(r, n) == 1 for r in rs), "a non-unit r came back: the first attempt's buffer was returned"
+        n2 = n * n
+        assert cts == [(1 + m * n) % n2 * pow(r, n, n2) % n2 for m, r in zip(ms, rs)]       # paillier.go:206-218 with G = n + 1
+        assert cts == pk.EncryptWithRBatch(ms, rs)
+    assert len({tuple(pk.EncryptBatch(ms[:50], return_r=True)[1]) for _ in range(3)}) == 3   # fresh draws every call

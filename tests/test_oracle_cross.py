@@ -45,3 +45,77 @@ def test_key4096_vectors_against_libgmp():
     assert go.decrypt_batch(n, lam, cs) == ms
     wc, wm = ([int(x, 16) for x in k[key]] for key in ("weird_c", "weird_m"))
     assert go.decrypt_batch(n, lam, wc) == wm
+
+
+def _be_rows(vals, stride):
+    import numpy as np
+    return np.frombuffer(b"".join(int(v).to_bytes(stride, "big") for v in vals), dtype=np.uint8).reshape(len(vals), stride).copy()
+
+
+def _ints(arr):
+    return [int.from_bytes(bytes(r), "big") for r in arr.reshape(-1, arr.shape[-1])]
+
+
+def test_threshold_restatement_reference_kats():
+    """The libgmp PartialDecrypt + Combine restatement (bench.py's CPU baseline beside BASELINE config 4) on the reference's own
+    toy KATs: TestDecrypt (thresholdkey_test.go:58-74: N = 10403, share 862, l = 10, c = 56 -> partial decryption 40644522) and
+    TestDecryption (:267-281: N = 637753, l = 2, shares of servers 1, 2 -> message 100 through Combine)."""
+    c = _be_rows([56], 8)
+    out, used, parts = go.threshold_decrypt_batch_raw(10403, 10, [1], [862], c, 8, want_partials=True)
+    assert _ints(parts) == [40644522]
+    # TestDecryption combines two GIVEN partial decryptions; the restatement computes its own from shares, so re-derive here: a
+    # (2, 2) sharing of a toy key and every quantity through the Python-int oracle as well
+    p, p1, q, q1 = 839, 419, 887, 443                     # TestInitShortcuts' safe primes (thresholdkey_generator_test.go:213-230)
+    n = p * q
+    assert n == 744193
+    tsks = po.threshold_keys_from_primes(p, p1, q, q1, 5, 3, random.Random(7))
+    rng = random.Random(8)
+    cts = [po.encrypt_with_r(tsks[0], m, po.rand_unit(n, rng)).C for m in (0, 1, 100, n - 1, 31337)]
+    for ids in ([1, 2, 3], [1, 3, 5], [5, 2, 4], [2, 4, 5, 1]):
+        shares = [tsks[i - 1].Share for i in ids]
+        out, used, parts = go.threshold_decrypt_batch_raw(n, 5, ids, shares, _be_rows(cts, 8), 4, threads=2, want_partials=True)
+        want_parts = [po.partial_decrypt(tsks[i - 1], c).Decryption for c in cts for i in ids]
+        assert _ints(parts) == want_parts
+        assert _ints(out) == [po.combine_partial_decryptions(tsks[0], [po.partial_decrypt(tsks[i - 1], c) for i in ids]) for c in cts]
+        assert _ints(out) == [0, 1, 100, n - 1, 31337]
+
+
+def test_threshold_restatement_against_the_2048_bit_fixtures():
+    """... and on the committed 2048-bit fixture (tests/golden/proofs.json: partials of all five servers, Combine for every
+    3-subset of 5 -- every subset has a negative Lagrange coefficient, i.e. the ModInverse branch of thresholdkey.go:134-138)."""
+    import itertools
+    import json
+    import os
+    G = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+    t = json.load(open(os.path.join(G, "keys.json")))["threshold"]["2048"]
+    th = json.load(open(os.path.join(G, "proofs.json")))["threshold"]
+    n, shares = int(t["n"], 16), [int(s, 16) for s in t["shares"]]
+    cs, ms = [int(x, 16) for x in th["c"]], [int(x, 16) for x in th["m"]]
+    for ids in list(itertools.combinations(range(1, 6), 3))[:4] + [(5, 3, 1)]:
+        out, used, parts = go.threshold_decrypt_batch_raw(n, 5, list(ids), [shares[i - 1] for i in ids], _be_rows(cs, 512), 256,
+                                                          threads=2, want_partials=True)
+        assert _ints(out) == ms
+        got = parts.reshape(len(cs), 3, 512)
+        for k, i in enumerate(ids):
+            assert _ints(got[:, k, :]) == [int(x, 16) for x in th["partials"][i - 1]]
+
+
+def test_level_two_and_nested_randomize_restatements():
+    """libgmp EncryptWithRAtLevel (level two) and NestedRandomize against the Python-int oracle and the committed fixtures."""
+    import json
+    import os
+    G = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+    k = json.load(open(os.path.join(G, "keys.json")))["paillier"]["2048"]
+    P = json.load(open(os.path.join(G, "proofs.json")))
+    n = int(k["n"], 16)
+    l2 = P["level2"]
+    ms, rs, cs = ([int(x, 16) for x in l2[key]] for key in ("m", "r", "c"))
+    rstride = max(256, max((r.bit_length() + 7) // 8 for r in rs))
+    out, _ = go.encrypt_l2_batch_raw(n, n + 1, _be_rows(ms, 512), _be_rows(rs, rstride), 768, threads=2)
+    assert _ints(out) == cs
+    st = P["ddleq"]["statements"]
+    ct1, ct2, a, b = ([int(s[key], 16) for s in st] for key in ("ct1", "ct2", "a", "b"))
+    out, _ = go.nested_randomize_batch_raw(n, _be_rows(ct1, 768), _be_rows(a, 256), _be_rows(b, 256), threads=2)
+    assert _ints(out) == ct2
+    pk = po.PublicKey(N=n, G=n + 1)
+    assert ct2[:2] == [po.nested_randomize_with_ab(pk, po.Ciphertext(c, 1), x, y).C for c, x, y in zip(ct1[:2], a[:2], b[:2])]

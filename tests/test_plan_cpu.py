@@ -1,0 +1,185 @@
+"""The planning predicates (paillier_amd/csrc/plan.hpp) on the CPU, through pgpu_plan_query of include/paillier_hip_debug.h.
+
+Every size decision of the engine -- lanes per number, window widths, whether a ladder is split -- is a pure function there, and
+the protocol bodies call the same functions.  Round 3 shipped a regression in exactly such a predicate (the split gate of the
+prover's Alpha ladder bounded the 192 slots a 7-bit table occupies where the window-width choice bounded the 128 entries its
+gathers address: between 50 121 and 74 986 numbers the p-adic split was dropped, secpar-40 prove 204 k -> 166 k instances/s);
+these tests pin the decisions at the batch sizes BASELINE.json's configs produce and at the boundaries in between.
+"""
+import os
+import re
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+H37, WT3_P = 37, 110        # 2048-bit key: limbs of a prime, limbs of p^3 (two slices of 55)
+H74 = 74                    # limbs of n
+
+
+@pytest.fixture(scope="module")
+def q():
+    import __graft_entry__ as ge
+    ge.build()
+    from paillier_amd import api
+    return api.plan_query
+
+
+def pad(n):
+    return (n + 255) // 256 * 256
+
+
+# numbers per launch of the prover's Alpha ladder (statements + instances, both padded to 256):
+#   secpar 1, 16 384 statements: 32 768;  secpar 40, 1 536 statements: 1 536 + 61 440 = 62 976 (the bench shape);
+#   rank of 8 at secpar 1: 4 096;  tools/prove_only.py 65 536 / 98 304: 131 072 / 196 608
+ALPHA = [
+    # nb        triple win nm5 split
+    (4096,      1,     7,  0,  0),      # below one wave per SIMD for the p^2 stage: one ladder is shorter than two
+    (8192,      1,     7,  0,  0),
+    (16384,     1,     7,  0,  1),      # 4 nb = 65 536 lanes: the split starts here
+    (32768,     1,     7,  0,  1),
+    (pad(50000), 1,    7,  0,  1),
+    (50176,     1,     7,  0,  1),      # the first size the round-3 regression dropped (x193 bound: 50 120)
+    (62976,     1,     7,  0,  1),      # BENCH ddleq_prove_2048_secpar40
+    (pad(74000), 1,    7,  0,  1),
+    (74752,     1,     7,  0,  1),      # last multiple of 256 with 7-bit tables inside the gather offsets (74 986)
+    (75008,     1,     5,  1,  1),      # beyond: 5-bit windows on number-major tables, the split STAYS
+    (80000,     1,     5,  1,  1),
+    (98304,     1,     5,  1,  1),
+    (131072,    1,     5,  1,  1),
+    (196608,    1,     5,  1,  1),
+    (262144,    1,     5,  1,  1),
+    (524288,    0,     5,  1,  0),      # the digit kernel's own limb-major gathers no longer fit: generic kernels
+]
+
+
+@pytest.mark.parametrize("nb,triple,win,nm5,split", ALPHA)
+def test_alpha_ladder_plan(q, nb, triple, win, nm5, split):
+    assert q("crt3_ladder", nb, H37, WT3_P, 0, 1, 1) == [triple, win, nm5, split]
+
+
+def test_split_gate_and_window_choice_agree_everywhere(q):
+    """The two predicates that disagreed in round 3: wherever the window choice says 7 bits the split gate must accept the 7-bit
+    table, and wherever it says 5 the 5-bit one -- for every multiple of 256 up to 300 000 numbers and both digit widths."""
+    for H, wt3 in ((H37, WT3_P), (H74, 222)):
+        for nb in range(16384, 300001, 256):
+            triple, win, nm5, split = q("crt3_ladder", nb, H, wt3, 0, 1, 1)
+            assert win == q("triple_window_bits", nb, H)[0]
+            assert nm5 == (win == 5)
+            if triple:
+                assert split == 1, (H, nb, win)
+
+
+def test_gathers_address_entries_not_slots(q):
+    """A 7-bit table OCCUPIES 128 + 64 slots; its gathers ADDRESS 128 entries (+ the lane's own offset): only those bound nb."""
+    assert q("perlane_table_slots", 7, 0) == [192] and q("gather_entries", 7) == [129]
+    assert q("perlane_table_slots", 5, 1) == [48] and q("gather_entries", 5) == [33]
+    assert q("perlane_table_slots", 4, 1) == [17] and q("perlane_table_slots", 4, 0) == [16] and q("perlane_table_slots", 5, 0) == [32]
+    # 7-bit windows on the digit kernels: up to 74 987 numbers for 37-limb digits, 37 493 for 74-limb digits
+    assert q("triple_window_bits", 74987, H37) == [7] and q("triple_window_bits", 74988, H37) == [5]
+    assert q("triple_window_bits", 37493, H74) == [7] and q("triple_window_bits", 37494, H74) == [5]
+
+
+def test_shared_exponent_ladders_without_per_number_windows(q):
+    for nb in (8192, 65536, 131072):
+        triple, win, nm5, split = q("crt3_ladder", nb, H37, WT3_P, 0, 0, 1)
+        assert (win, nm5, split) == (5, 0, 0) and triple == 1
+
+
+def test_split_needs_its_prerequisites_and_the_occupancy_target(q):
+    assert q("crt3_ladder", 62976, H37, WT3_P, 0, 1, 0)[3] == 0            # lift off / no pair kernel for p^2 ...
+    assert q("crt3_ladder", 4096, H37, WT3_P, 1, 1, 1)[3] == 1             # lanes_wanted = 1 (tests force the split on toy batches)
+    assert q("crt3_ladder", 16128, H37, WT3_P, 0, 1, 1)[3] == 0            # just below one wave per SIMD
+
+
+RESPONSE = [
+    # nb (bit-1 instances)  usable split
+    (256,    1, 0),
+    (8192,   1, 0),     # secpar 1 x 16 384: about half the instances
+    (8448,   1, 0),
+    (16384,  1, 1),
+    (30720,  1, 1),     # secpar 40 x 1 536: about half of 61 440
+    (61440,  1, 1),
+    (74752,  1, 1),
+    (75008,  0, 0),     # two per-number tables of 7-bit windows: beyond the offsets the literal sequence takes over
+]
+
+
+@pytest.mark.parametrize("nb,usable,split", RESPONSE)
+def test_response_ladder_plan(q, nb, usable, split):
+    assert q("crt3_two", nb, H37, 0, 1) == [usable, split]
+
+
+def test_early_response_only_where_its_kernels_are_certain(q):
+    assert q("early_response_ok", 16384, H37) == [1] and q("early_response_ok", 61440, H37) == [1]
+    assert q("early_response_ok", 98304, H37) == [0]
+
+
+def test_extract_randomness_beside_the_first_launch(q):
+    assert q("extract_beside", 16384, 16384, 0) == [1]       # secpar 1 x 16 384: the a^n | x^n launch is one wave per SIMD
+    assert q("extract_beside", 1536, 61440, 0) == [1]        # secpar 40: the side launch is a few dozen waves
+    assert q("extract_beside", 32768, 32768, 0) == [0]       # both wave slots taken: s follows on the main stream
+    assert q("extract_beside", 2048, 2048, 0) == [1]
+
+
+PAIR_SHARED = [
+    # numbers  have4 have8 -> lanes
+    (65536, 1, 1, 2), (32768, 1, 1, 2), (32512, 1, 1, 4), (16384, 1, 1, 4), (12288, 1, 1, 4), (8448, 1, 1, 4),
+    (8192, 1, 1, 8), (6144, 1, 1, 8), (2048, 1, 1, 8), (256, 1, 1, 8),
+    (8192, 1, 0, 4), (2048, 0, 0, 2), (16384, 0, 1, 2),
+]
+
+
+@pytest.mark.parametrize("numbers,have4,have8,lanes", PAIR_SHARED)
+def test_pair_lanes_for_shared_exponents(q, numbers, have4, have8, lanes):
+    """PartialDecrypt / Encrypt modulo n^2: two lanes from one wave per SIMD upwards, four below, eight while every wave still
+    has a SIMD of its own (a rank's 6 144 units of BASELINE config 4 at N = 8)."""
+    assert q("pair_lanes_shared", numbers, 0, have4, have8) == [lanes]
+    if not have8:
+        assert q("pair_lanes_2or4", numbers, 0, have4) == [lanes]
+
+
+def test_pair_kernel_serves(q):
+    assert q("pair_kernel_serves", 32768, 0, 0) == [1] and q("pair_kernel_serves", 16384, 0, 0) == [0]
+    assert q("pair_kernel_serves", 256, 0, 1) == [1]
+
+
+CRT_LANES = [
+    # nb      lanes usable      (one-lane kernel of a 2048-bit key with its two-lane variant)
+    (65536, 1, 1), (32768, 1, 1), (30720, 1, 1), (20480, 1, 1), (16640, 1, 1), (16384, 2, 1), (8192, 2, 1), (256, 2, 1),
+]
+
+
+@pytest.mark.parametrize("nb,lanes,usable", CRT_LANES)
+def test_crt_halves_lane_choice(q, nb, lanes, usable):
+    """Decrypt-2048 (the headline at 65 536): one lane per number down to 16 385 ciphertexts, two below."""
+    assert q("crt_pair_lanes", 1, 1, nb, 0) == [lanes, usable]
+
+
+def test_dual_ladder_windows_and_tables(q):
+    W2 = 148
+    assert q("dual_pair_window_bits", 16384, W2, 1) == [5] and q("dual_pair_window_bits", 61440, W2, 1) == [5]
+    assert q("dual_pair_window_bits", 148224, W2, 1) == [4]          # 49 slots of 5-bit windows no longer fit, 18 of 4-bit do
+    assert q("dual_pair_window_bits", 402944, W2, 1) == [4] and q("dual_pair_window_bits", 403200, W2, 1) == [0]
+    assert q("pair_nm4_fits", 402944, W2) == [1] and q("pair_nm4_fits", 403200, W2) == [0]
+    assert q("shared_chain_pays", 8192, 0) == [1] and q("shared_chain_pays", 7936, 0) == [0]
+    assert q("triple_two_lanes_per_digit", 8192, 0) == [1] and q("triple_two_lanes_per_digit", 8448, 0) == [0]
+
+
+def test_unknown_decision_is_an_error(q):
+    from paillier_amd.api import PaillierHipError
+    with pytest.raises(PaillierHipError):
+        q("no_such_decision", 1, 2)
+    with pytest.raises(PaillierHipError):
+        q("crt3_ladder", 1, 2)          # too few arguments
+
+
+def test_no_size_predicate_outside_plan_hpp():
+    """The protocol bodies must not grow private copies of these bounds again: the 32-bit gather span and the chip's lane count
+    appear in plan.hpp only."""
+    csrc = os.path.join(ROOT, "paillier_amd", "csrc")
+    for f in sorted(os.listdir(csrc)):
+        if not f.endswith((".cpp", ".hpp")) or f in ("plan.hpp", "hostbig.hpp"):      # (hostbig: the digit base of its long division)
+            continue
+        src = open(os.path.join(csrc, f)).read()
+        src = re.sub(r"//[^\n]*", "", src)
+        assert "1ull << 32" not in src and "1024 * 64" not in src, f"{f} carries a size predicate of its own: move it to plan.hpp"
