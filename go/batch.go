@@ -614,6 +614,84 @@ func (g *GPU) RandomOracleDigestBatch(cols ...[]*gmp.Int) ([][32]byte, error) {
 	return res, nil
 }
 
+// ---- wire format (paillier.go:374-401) ---------------------------------------------------------------------------------------
+
+// CiphertextsFromBytesBatch: PublicKey.NewCiphertextFromBytes (paillier.go:376-391) for a batch of blobs as Ciphertext.Bytes()
+// writes them (encoding/gob, a fresh encoder per ciphertext): one C call walks all the blobs (host threads) and returns the
+// values in one flat buffer (pgpu_gob_unpack).  The errors of the reference's decoder ("no data provided", malformed data) fail
+// the batch.  To keep the ciphertexts on the device for DecryptBatch-style calls on device buffers use the C entry point with
+// PGPU_MEM_DEVICE directly.
+func (k *GPUPublicKey) CiphertextsFromBytesBatch(blobs [][]byte) ([]*Ciphertext, error) {
+	defer pin()()
+	n := len(blobs)
+	if n == 0 {
+		return nil, nil
+	}
+	offs := make([]C.size_t, n+1)
+	stride, total := 1, 0
+	for i, b := range blobs {
+		total += len(b)
+		offs[i+1] = C.size_t(total)
+		if len(b) > stride {
+			stride = len(b) // the magnitude of C is shorter than its blob
+		}
+	}
+	cat := make([]byte, 0, total+1)
+	for _, b := range blobs {
+		cat = append(cat, b...)
+	}
+	if len(cat) == 0 {
+		cat = append(cat, 0)
+	}
+	out := make([]byte, n*stride)
+	levels, methods := make([]C.int32_t, n), make([]C.int32_t, n)
+	rc := C.pgpu_gob_unpack(k.g.ctx, C.size_t(n), p8(cat), &offs[0], p8(out), C.size_t(stride), C.PGPU_MEM_HOST, &levels[0], &methods[0])
+	if err := status(rc); err != nil {
+		return nil, err
+	}
+	res := make([]*Ciphertext, n)
+	for i, v := range unpack(out, stride) {
+		res[i] = &Ciphertext{C: v, Level: EncryptionLevel(levels[i]), EncMethod: EncryptionMethod(methods[i])}
+	}
+	return res, nil
+}
+
+// CiphertextBytesBatch: Ciphertext.Bytes() (paillier.go:393-401) for every ciphertext: res[i] is the gob blob of c[i]
+// (pgpu_gob_pack; one C call per (Level, EncMethod) group, normally one).
+func (k *GPUPublicKey) CiphertextBytesBatch(c []*Ciphertext) ([][]byte, error) {
+	defer pin()()
+	res := make([][]byte, len(c))
+	type key struct {
+		l EncryptionLevel
+		m EncryptionMethod
+	}
+	groups := map[key][]int{}
+	for i, ct := range c {
+		kk := key{ct.Level, ct.EncMethod}
+		groups[kk] = append(groups[kk], i)
+	}
+	for kk, idx := range groups {
+		vals := make([]*gmp.Int, len(idx))
+		for j, i := range idx {
+			vals[j] = c[i].C
+		}
+		stride := maxLen(vals, 1)
+		in := pack(vals, stride)
+		cap := len(idx) * int(C.pgpu_gob_max_bytes(C.size_t(stride)))
+		blobs := make([]byte, cap)
+		offs := make([]C.size_t, len(idx)+1)
+		rc := C.pgpu_gob_pack(k.g.ctx, C.size_t(len(idx)), p8(in), C.size_t(stride), C.PGPU_MEM_HOST, C.int(kk.l), C.int(kk.m), p8(blobs),
+			C.size_t(cap), &offs[0])
+		if err := status(rc); err != nil {
+			return nil, err
+		}
+		for j, i := range idx {
+			res[i] = append([]byte(nil), blobs[offs[j]:offs[j+1]]...)
+		}
+	}
+	return res, nil
+}
+
 // ---- whole-protocol batch forms (the reference's signatures, one slice element per call of the scalar method) -----------------
 
 func randomUnits(k *GPUPublicKey, count int) ([]*gmp.Int, error) {

@@ -315,6 +315,27 @@ int pgpu_modinv(const pgpu_modulus* mod, size_t batch, const uint8_t* x, size_t 
 int pgpu_modmul(const pgpu_modulus* mod, size_t batch, const uint8_t* a, size_t a_stride, size_t a_len,
                 const uint8_t* b, size_t b_stride, size_t b_len, uint8_t* out, size_t out_stride, int mem);
 
+/* ---- wire format: Ciphertext.Bytes() / PublicKey.NewCiphertextFromBytes (paillier.go:374-401) for a batch ------------------
+ * The reference serialises a ciphertext with encoding/gob (a fresh encoder per ciphertext: every blob carries the type
+ * definitions of Ciphertext{C *gmp.Int; Level; EncMethod} and of gmp.Int's GobEncoder form, then the value).  These two entry
+ * points move a whole batch between that format and the flat fixed-stride big-endian buffers every other entry point takes, so
+ * that batches can arrive and leave in the reference's own format.  Blobs live in HOST memory (they come from / go to the
+ * network), concatenated, blob i = bytes [offsets[i], offsets[i+1]); the flat buffer lives where `mem` says -- with
+ * PGPU_MEM_DEVICE the payload bytes are moved by a kernel and never return to the host (feed pgpu_decrypt(..., PGPU_MEM_DEVICE)
+ * directly).  With PGPU_MEM_HOST nothing touches the device and ctx may be NULL.
+ * pgpu_gob_unpack: levels / methods (optional host int32[batch]) receive Ciphertext.Level / EncMethod.  Accepts any gob type ids
+ * and field order (fields match by name), as Go's decoder does; errors as NewCiphertextFromBytes ("no data provided", malformed
+ * data) fail the call with PGPU_ERR_INVALID; so do a negative C and a C wider than out_stride.
+ * pgpu_gob_pack: every ciphertext of the batch carries the same Level / EncMethod.  blobs_cap: capacity of `blobs`;
+ * batch * pgpu_gob_max_bytes(stride) always suffices.  offsets: host size_t[batch + 1], written.
+ * Parity: byte-identical to the restatement in paillier_amd/wire.py, which is pinned to the gob specification's own example and
+ * math/big's documented GobEncode layout -- NOT to a Go toolchain (none in the build image: see INTEGRATION.md). */
+size_t pgpu_gob_max_bytes(size_t value_bytes);
+int pgpu_gob_unpack(pgpu_ctx* ctx, size_t batch, const uint8_t* blobs, const size_t* offsets, uint8_t* out, size_t out_stride,
+                    int mem, int32_t* levels, int32_t* methods);
+int pgpu_gob_pack(pgpu_ctx* ctx, size_t batch, const uint8_t* in, size_t stride, int mem, int level, int enc_method, uint8_t* blobs,
+                  size_t blobs_cap, size_t* offsets);
+
 /* (Test hooks -- raw VM programs, the planning predicates -- are NOT part of this boundary: include/paillier_hip_debug.h.) */
 
 #if defined(__GNUC__)

@@ -88,6 +88,9 @@ SIGNATURES = {
     "pgpu_modulus_bytes": (_sz, [_vp]),
     "pgpu_modexp": (_int, [_vp, _sz, _vp, _sz, _sz, _vp, _sz, _sz, _vp, _sz, _int]),
     "pgpu_modinv": (_int, [_vp, _sz, _vp, _sz, _sz, _vp, _sz, _int, _vp]),
+    "pgpu_gob_max_bytes": (_sz, [_sz]),
+    "pgpu_gob_unpack": (_int, [_vp, _sz, _vp, _vp, _vp, _sz, _int, _vp, _vp]),
+    "pgpu_gob_pack": (_int, [_vp, _sz, _vp, _sz, _int, _int, _int, _vp, _sz, _vp]),
     "pgpu_modmul": (_int, [_vp, _sz, _vp, _sz, _sz, _vp, _sz, _sz, _vp, _sz, _int]),
 }
 
@@ -175,6 +178,33 @@ def plan_query(what: str, *args: int) -> List[int]:
     if n < 0:
         raise PaillierHipError(n, lib.pgpu_last_error().decode())
     return [int(out[i]) for i in range(n)]
+
+
+def gob_unpack_raw(ctx, blobs: Sequence[bytes], out, out_stride: int, mem: int = MEM_HOST):
+    """pgpu_gob_unpack: NewCiphertextFromBytes (paillier.go:376-391) for a batch of gob blobs.  `out`: numpy uint8[batch, stride]
+    (MEM_HOST) or a device pointer (MEM_DEVICE); ctx may be None for MEM_HOST.  Returns (levels, methods)."""
+    lib = load_library()
+    n = len(blobs)
+    offs = np.zeros(n + 1, dtype=np.uint64)
+    offs[1:] = np.cumsum([len(b) for b in blobs])
+    cat = np.frombuffer(b"".join(blobs) or b"\0", dtype=np.uint8)
+    levels, methods = np.zeros(n, dtype=np.int32), np.zeros(n, dtype=np.int32)
+    _check(lib.pgpu_gob_unpack(ctx.h if ctx is not None else None, n, _ptr(cat), _ptr(offs), _ptr(out), out_stride, mem,
+                               _ptr(levels), _ptr(methods)))
+    return levels, methods
+
+
+def gob_pack_raw(ctx, batch: int, buf, stride: int, level: int = 0, enc_method: int = 0, mem: int = MEM_HOST) -> List[bytes]:
+    """pgpu_gob_pack: Ciphertext.Bytes() (paillier.go:393-401) for every row of a flat big-endian buffer (numpy array for MEM_HOST,
+    device pointer for MEM_DEVICE).  Returns one gob blob per ciphertext."""
+    lib = load_library()
+    cap = batch * lib.pgpu_gob_max_bytes(stride)
+    blobs = np.zeros(cap, dtype=np.uint8)
+    offs = np.zeros(batch + 1, dtype=np.uint64)
+    _check(lib.pgpu_gob_pack(ctx.h if ctx is not None else None, batch, _ptr(buf), stride, mem, level, enc_method, _ptr(blobs), cap,
+                             _ptr(offs)))
+    raw = blobs.tobytes()
+    return [raw[int(offs[i]):int(offs[i + 1])] for i in range(batch)]
 
 
 def _check(rc: int):

@@ -8,6 +8,7 @@
 //   paillier.cpp   Encrypt / Decrypt / Add / Sub / ConstMult, randomness
 //   threshold.cpp  PartialDecrypt (batch forms), Combine, share ZKP
 //   ddleq.cpp      NestedRandomize, DDLEQ prove / verify, RandomOracleDigest
+//   wire.cpp       the gob wire format of Ciphertext at the ABI (batch <-> flat buffers)
 //   debug.cpp      test hooks (include/paillier_hip_debug.h)
 //   plan.hpp       every size decision (lanes per number, window widths, split gates): pure functions, CPU-tested
 //   kernels.hip / asm_loader.cpp / gen_vm_asm.py   the device side

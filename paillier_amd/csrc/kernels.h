@@ -94,3 +94,10 @@ void launch_repack_windows5(const uint32_t* in, int we, uint32_t* out, int we5, 
 void launch_exp_low_combine(const uint32_t* x, const uint32_t* a, const uint32_t* e, uint32_t* ls, uint32_t* lb, size_t nb, hipStream_t st);
 void launch_exp_order_lift(const uint32_t* e, int we, const uint32_t* em, int wm, const uint32_t* m, int t, uint32_t minv,
                            uint32_t* out, int wo, size_t nb, hipStream_t st);
+// wire format (encoding/gob of Ciphertext): payload bytes between gob blobs and the fixed-stride big-endian buffers
+void launch_bytes_gather_be(const uint8_t* src, const uint64_t* off, const uint32_t* len, size_t count, uint8_t* out, size_t stride,
+                            hipStream_t st);
+void launch_be_lengths(const uint8_t* in, size_t stride, size_t count, uint32_t* len, hipStream_t st);
+void launch_gob_emit(const uint8_t* in, size_t stride, const uint32_t* len, const uint64_t* off, size_t count, const uint8_t* prefix,
+                     uint32_t prefix_len, const uint8_t* head, uint32_t head_len, const uint8_t* tail, uint32_t tail_len, uint8_t* dst,
+                     hipStream_t st);

@@ -860,6 +860,65 @@ __global__ void k_clear_where(const int32_t* __restrict__ flags, size_t count, i
 
 // one wave per block: the helpers are latency-bound at the batch sizes of the level-two / threshold paths (16384 lanes =
 // 256 one-wave blocks = every CU), and bandwidth-bound ones lose nothing
+// ---- wire format (Ciphertext.Bytes() / NewCiphertextFromBytes, paillier.go:374-401: encoding/gob) -----------------------------
+// HBM-bound byte movers; one 64-lane block per ciphertext, lanes stride over its bytes (coalesced within an element).
+// unpack: the big-endian magnitude of element g is len[g] bytes at src + off[g] (found by the host's walk over the gob messages);
+// it lands right-aligned in the element's fixed stride, zero-padded on the left.
+__global__ void k_bytes_gather_be(const uint8_t* __restrict__ src, const uint64_t* __restrict__ off, const uint32_t* __restrict__ len,
+                                  size_t count, uint8_t* __restrict__ out, size_t stride) {
+  const size_t g = blockIdx.x;
+  if (g >= count) return;
+  const uint8_t* s = src + off[g];
+  const size_t n = len[g], pad = stride - n;
+  uint8_t* d = out + g * stride;
+  for (size_t i = threadIdx.x; i < stride; i += blockDim.x) d[i] = i < pad ? (uint8_t)0 : s[i - pad];
+}
+// pack, step 1: significant bytes of every fixed-stride big-endian element (0 for the value 0)
+__global__ void k_be_lengths(const uint8_t* __restrict__ in, size_t stride, size_t count, uint32_t* __restrict__ len) {
+  const size_t g = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (g >= count) return;
+  const uint8_t* p = in + g * stride;
+  size_t z = 0;
+  while (z < stride && p[z] == 0) ++z;
+  len[g] = (uint32_t)(stride - z);
+}
+// gob's unsigned integer: one byte below 128, else the negated byte count followed by the big-endian bytes
+__device__ inline uint32_t gob_uint(uint8_t* d, uint32_t v) {
+  if (v < 128) { d[0] = (uint8_t)v; return 1; }
+  const uint32_t nb = v < (1u << 8) ? 1 : v < (1u << 16) ? 2 : v < (1u << 24) ? 3 : 4;
+  d[0] = (uint8_t)(256 - nb);
+  for (uint32_t i = 0; i < nb; ++i) d[1 + i] = (uint8_t)(v >> (8 * (nb - 1 - i)));
+  return 1 + nb;
+}
+// pack, step 2: blob g at dst + off[g] = prefix (the two type-definition messages: constant) | length of the value message |
+// head (type id, field delta of C) | length of GobEncode() | version byte | magnitude | tail (Level / EncMethod fields, end)
+__global__ void k_gob_emit(const uint8_t* __restrict__ in, size_t stride, const uint32_t* __restrict__ len, const uint64_t* __restrict__ off,
+                           size_t count, const uint8_t* __restrict__ prefix, uint32_t prefix_len, const uint8_t* __restrict__ head,
+                           uint32_t head_len, const uint8_t* __restrict__ tail, uint32_t tail_len, uint8_t* __restrict__ dst) {
+  const size_t g = blockIdx.x;
+  if (g >= count) return;
+  __shared__ uint32_t s_at;
+  uint8_t* d = dst + off[g];
+  const uint32_t n = len[g], glen = n + 1;
+  for (uint32_t i = threadIdx.x; i < prefix_len; i += blockDim.x) d[i] = prefix[i];
+  if (threadIdx.x == 0) {
+    uint8_t tmp[8];
+    const uint32_t lg = gob_uint(tmp, glen);
+    uint32_t at = prefix_len;
+    at += gob_uint(d + at, head_len + lg + glen + tail_len);          // length of the value message
+    for (uint32_t i = 0; i < head_len; ++i) d[at + i] = head[i];
+    at += head_len;
+    at += gob_uint(d + at, glen);
+    d[at++] = 2;                                                       // GobEncode: version 1 << 1 | sign 0
+    s_at = at;
+  }
+  __syncthreads();
+  const uint32_t at = s_at;
+  const uint8_t* p = in + g * stride + (stride - n);
+  for (uint32_t i = threadIdx.x; i < n; i += blockDim.x) d[at + i] = p[i];
+  for (uint32_t i = threadIdx.x; i < tail_len; i += blockDim.x) d[at + n + i] = tail[i];
+}
+
 #define HELPER_GRID(nb) dim3((unsigned)(((nb) + 63) / 64)), dim3(64)
 
 void launch_unpack_be(const uint8_t* in, size_t stride, size_t nbytes, size_t count, uint32_t* out, int wt, size_t nb, hipStream_t st) {
@@ -1007,6 +1066,19 @@ void launch_unit_flags(const uint32_t* x, const uint32_t* nmod, int w, size_t nb
 }
 void launch_or_flags(const int32_t* flags, size_t count, int32_t* status, int32_t flag, hipStream_t st) {
   hipLaunchKernelGGL(k_or_flags, HELPER_GRID(count ? count : 1), 0, st, flags, count, status, flag);
+}
+void launch_bytes_gather_be(const uint8_t* src, const uint64_t* off, const uint32_t* len, size_t count, uint8_t* out, size_t stride,
+                            hipStream_t st) {
+  hipLaunchKernelGGL(k_bytes_gather_be, dim3((unsigned)(count ? count : 1)), dim3(64), 0, st, src, off, len, count, out, stride);
+}
+void launch_be_lengths(const uint8_t* in, size_t stride, size_t count, uint32_t* len, hipStream_t st) {
+  hipLaunchKernelGGL(k_be_lengths, HELPER_GRID(count ? count : 1), 0, st, in, stride, count, len);
+}
+void launch_gob_emit(const uint8_t* in, size_t stride, const uint32_t* len, const uint64_t* off, size_t count, const uint8_t* prefix,
+                     uint32_t prefix_len, const uint8_t* head, uint32_t head_len, const uint8_t* tail, uint32_t tail_len, uint8_t* dst,
+                     hipStream_t st) {
+  hipLaunchKernelGGL(k_gob_emit, dim3((unsigned)(count ? count : 1)), dim3(64), 0, st, in, stride, len, off, count, prefix, prefix_len,
+                     head, head_len, tail, tail_len, dst);
 }
 void launch_clear_where(const int32_t* flags, size_t count, int32_t* ok, hipStream_t st) {
   hipLaunchKernelGGL(k_clear_where, HELPER_GRID(count ? count : 1), 0, st, flags, count, ok);

@@ -193,6 +193,20 @@ int main(int argc, char** argv) {
     CHECK(memcmp(out, m, B * pb) == 0);
     pgpu_pubkey_destroy(apk); free(cc); free(red); }
 
+  /* ---- wire format (paillier.go:374-401): Bytes() of the committed ciphertexts and back, host and device-kernel paths agree */
+  { size_t W = (size_t)get("enc_c")->n; size_t cap = W * pgpu_gob_max_bytes(cb); uint8_t* blobs = (uint8_t*)calloc(cap, 1); uint8_t* back = (uint8_t*)calloc(W, cb + 8);
+    size_t* offs = (size_t*)calloc(W + 1, sizeof(size_t)); int32_t lv[MAXV], me[MAXV]; size_t i;
+    uint8_t* encc = pack(get("enc_c"), cb);
+    OK(pgpu_gob_pack(ctx, W, encc, cb, PGPU_MEM_HOST, PGPU_LEVEL_ONE, 0, blobs, cap, offs));
+    CHECK(offs[0] == 0 && offs[W] <= cap && offs[1] > cb);
+    CHECK(blobs[offs[1] - 1] == 0 && blobs[offs[W] - 1] == 0);                          /* every value message ends its struct */
+    OK(pgpu_gob_unpack(NULL, W, blobs, offs, back, cb + 8, PGPU_MEM_HOST, lv, me));     /* host buffers: no context needed */
+    for (i = 0; i < W; ++i) CHECK(memcmp(back + i * (cb + 8) + 8, encc + i * cb, cb) == 0 && lv[i] == 0 && me[i] == 0);
+    CHECK(pgpu_gob_unpack(ctx, W, blobs, offs, back, 8, PGPU_MEM_HOST, NULL, NULL) == PGPU_ERR_INVALID);   /* C wider than the stride */
+    CHECK(pgpu_gob_pack(ctx, W, encc, cb, PGPU_MEM_HOST, 0, 0, blobs, 16, offs) == PGPU_ERR_INVALID);       /* buffer too small */
+    { size_t zero[2] = {0, 0}; CHECK(pgpu_gob_unpack(ctx, 1, blobs, zero, back, cb, PGPU_MEM_HOST, NULL, NULL) == PGPU_ERR_INVALID); }  /* "no data provided" */
+    free(blobs); free(back); free(offs); free(encc); }
+
   /* ---- threshold decryption (thresholdkey.go:149-201): committed partials and plaintexts */
   { const entry_t* tc = get("t_c"); size_t nt = (size_t)tc->n, tl = bytes_of(get("t_n")->hex[0]), tcb = 2 * tl;
     uint8_t* cc = pack(tc, tcb); uint8_t* parts[3]; const uint8_t* cparts[3]; int ids[3] = {1, 3, 5}; int s;

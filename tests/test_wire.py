@@ -61,3 +61,78 @@ def test_batch_bridge_to_the_c_abi_format():
     assert buf.shape == (10, 512) and levels == [0] * 10 and methods == [2] * 10
     assert [int.from_bytes(buf[i].tobytes(), "big") for i in range(10)] == vals
     assert wire.unpack_gob_batch(buf, 0, 2) == blobs
+
+
+# ---- the same format at the C ABI (pgpu_gob_pack / pgpu_gob_unpack, paillier_amd/csrc/wire.cpp), host-memory mode: nothing
+# touches the device and no context is needed, so the byte-for-byte comparison with the restatement above runs in the CPU suite
+@pytest.fixture(scope="module")
+def api():
+    import __graft_entry__ as ge
+    ge.build()
+    from paillier_amd import api
+    api.load_library()
+    return api
+
+
+def _rows(vals, stride):
+    return np.frombuffer(b"".join(int(v).to_bytes(stride, "big") for v in vals), dtype=np.uint8).reshape(len(vals), stride).copy()
+
+
+@pytest.mark.parametrize("level,method", [(0, 0), (1, 0), (0, 2), (1, 1)])
+def test_c_abi_pack_is_the_python_restatement_byte_for_byte(api, level, method):
+    rng = random.Random(10 * level + method)
+    vals = [0, 1, 127, 128, 255, 256, (1 << 1016) - 1, 1 << 1016, (1 << 4096) - 1] + [rng.getrandbits(rng.choice([7, 900, 2048, 4095, 4096]))
+                                                                                          for _ in range(9000)]
+    blobs = api.gob_pack_raw(None, len(vals), _rows(vals, 512), 512, level, method)
+    assert blobs == [wire.ciphertext_to_gob(v, level, method) for v in vals]
+    assert blobs == wire.unpack_gob_batch(_rows(vals, 512), level, method)
+    assert max(len(b) for b in blobs) <= api.load_library().pgpu_gob_max_bytes(512)
+
+
+def test_c_abi_unpack_accepts_what_the_python_decoder_accepts(api):
+    rng = random.Random(5)
+    vals = [0, 1, (1 << 4096) - 1] + [rng.getrandbits(rng.choice([1, 64, 1023, 4096])) for _ in range(9000)]
+    lv = [rng.randrange(2) for _ in vals]
+    me = [rng.randrange(3) for _ in vals]
+    blobs = [wire.ciphertext_to_gob(v, a, b) for v, a, b in zip(vals, lv, me)]
+    # other type ids (a process that used gob for other types first), swapped field order, a non-minimal magnitude
+    c = rng.getrandbits(4000)
+    alt = wire.message(wire.struct_typedef(70, "Ciphertext", [("Level", wire.T_INT), ("C", 71), ("EncMethod", wire.T_INT)]))
+    alt += wire.message(wire.gobencoder_typedef(71, "Int"))
+    alt += wire.message(wire.enc_int(70) + b"\x01" + wire.enc_int(1) + b"\x01" + wire.enc_string(b"\x02\x00\x00" + c.to_bytes(500, "big")) + b"\x00")
+    blobs.append(alt)
+    vals.append(c); lv.append(1); me.append(0)
+    out = np.full((len(blobs), 512), 0xAA, dtype=np.uint8)
+    levels, methods = api.gob_unpack_raw(None, blobs, out, 512)
+    assert [int.from_bytes(out[i].tobytes(), "big") for i in range(len(vals))] == vals
+    assert list(levels) == lv and list(methods) == me
+    buf, l2, m2 = wire.pack_gob_batch(blobs, 512)
+    assert (buf == out).all() and l2 == lv and m2 == me
+
+
+def test_c_abi_unpack_errors(api):
+    good = wire.ciphertext_to_gob(12345)
+    out = np.zeros((2, 8), dtype=np.uint8)
+    for bad in (b"", good[:-3], good[:10], b"\x05abc", wire.ciphertext_to_gob(-5)):
+        with pytest.raises(api.PaillierHipError) as ei:
+            api.gob_unpack_raw(None, [good, bad], out, 8)
+        assert ei.value.code == -1
+    with pytest.raises(api.PaillierHipError, match="no data provided"):          # paillier.go:377
+        api.gob_unpack_raw(None, [b""], out, 8)
+    with pytest.raises(api.PaillierHipError, match="wider"):
+        api.gob_unpack_raw(None, [wire.ciphertext_to_gob(1 << 64)], out, 8)
+    with pytest.raises(api.PaillierHipError):                                      # a device buffer needs a context
+        api.gob_unpack_raw(None, [good], 0x1000, 8, mem=api.MEM_DEVICE)
+    # an undefined type, an unknown field
+    undefined = wire.message(wire.enc_int(65) + b"\x01\x02\x02\x05\x00")
+    with pytest.raises(api.PaillierHipError):
+        api.gob_unpack_raw(None, [undefined], out, 8)
+    other = wire.message(wire.struct_typedef(65, "Ciphertext", [("Q", wire.T_INT)])) + wire.message(wire.enc_int(65) + b"\x01\x02\x00")
+    with pytest.raises(api.PaillierHipError, match="no field Q"):
+        api.gob_unpack_raw(None, [other], out, 8)
+    # a too small blob buffer is refused, never overrun
+    lib = api.load_library()
+    blobs = np.zeros(16, dtype=np.uint8)
+    offs = np.zeros(3, dtype=np.uint64)
+    rows = _rows([1, 2], 8)
+    assert lib.pgpu_gob_pack(None, 2, rows.ctypes.data, 8, api.MEM_HOST, 0, 0, blobs.ctypes.data, 16, offs.ctypes.data) == -1
