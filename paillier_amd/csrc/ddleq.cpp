@@ -216,6 +216,10 @@ int pgpu_ddleq_verify(const pgpu_pubkey* pk, size_t batch, const uint8_t* ct1, c
 
 namespace pgi {
 
+uint32_t* zext(pgpu_ctx* ctx, const uint32_t* in, int w, int wo, size_t nb);
+uint32_t* concat2(pgpu_ctx* ctx, const uint32_t* a, const uint32_t* b, int w, size_t nb);
+void split2(pgpu_ctx* ctx, const uint32_t* in, int which, int w, size_t nb, uint32_t* out);
+
 // W = x^(per-number exponent r1, `we` limbs) [* y^(s1)] modulo p^2 (half 0) and modulo q^2 (half 1): interleaved ladders in
 // pair form on the one-lane pair kernel, both halves in ONE two-segment launch.  xs / ys: canonical residues modulo p^2 / q^2
 // (mp2.WT limbs, stride nb).  outs[half]: canonical results.  False when the one-lane pair kernel does not serve this key.
@@ -309,6 +313,354 @@ bool pow_p2_multi_crt(const pgpu_seckey* sk, const uint32_t* const xs[2], const 
   }
   out.join();
   return true;
+}
+
+// Garner for residues modulo p^3 and q^3 (canonical, mp3.WT limbs, stride nb): out = x_p + p^3 ((x_q - x_p) p^-3 mod q^3), WT(n^3) limbs
+void garner_n3(const pgpu_seckey* sk, const uint32_t* xp, const uint32_t* xq, size_t nb, uint32_t* out) {
+  pgpu_ctx* ctx = sk->ctx;
+  const ModCtx& mq3 = sk->mq3;
+  const int W = mq3.WT, W3 = sk->pk->mn3->WT;
+  const size_t S = (size_t)W * nb;
+  uint32_t* g = ctx->ws_t<uint32_t>(S * 5);       // slots: 0 x_p, 1 x_q, 2 A, 3 B, 4 h
+  HIPCHK(hipMemcpyAsync(g, xp, S * 4, hipMemcpyDeviceToDevice, ctx->stream));
+  HIPCHK(hipMemcpyAsync(g + S, xq, S * 4, hipMemcpyDeviceToDevice, ctx->stream));
+  Prog c;
+  c.op(VM_LOAD, 0); c.op(VM_MULC, (uint32_t)sk->c_p3invR); c.op(VM_STORE, 3);
+  c.op(VM_LOAD, 1); c.op(VM_MULC, (uint32_t)sk->c_p3invR); c.op(VM_STORE, 2);
+  c.end();
+  SegSpec sc{&mq3, &c, g, nullptr};
+  run_vm(ctx, nb, sc, nullptr, false);
+  launch_canon(g + 2 * S, mq3.d_nmod, W, nb, ctx->stream);
+  launch_canon(g + 3 * S, mq3.d_nmod, W, nb, ctx->stream);
+  launch_sub_mod(g + 2 * S, g + 3 * S, mq3.d_nmod, g + 4 * S, W, nb, ctx->stream);                  // h = (x_q - x_p) / p^3 mod q^3
+  launch_mul_const_add(g + 4 * S, W, sk->p3_limbs.d, W, g, W, 0, out, W3, nb, ctx->stream);          // x_p + p^3 h
+}
+
+// ---- powers modulo n^3 through the STRUCTURE of the unit group (round 4) ---------------------------------------------------------
+// Z*_{n^3} = <1 + n> x T, T = the Teichmueller lifts omega(u) = u^(n^2) of Z*_n, and the key holder can read both coordinates of
+// ct = (1 + n)^m rho^(n^2): m is the level-two plaintext (one CRT decryption PER STATEMENT), and the T-part of any product is
+// determined by the product modulo n.  So for X = ct^e * y^(n^2) -- the prover's sanity value ct1^(a^n) b^(n^2) (ddleq.go:62-69)
+// and Alpha = ct1^(x^n) y^(n^2) (:81-87) --
+//     X = (1 + n)^(m e mod n^2) * omega(X mod n),        X mod p = (ct mod p)^(e mod (p-1)) * (y mod p)^(n^2 mod (p-1)),
+// and modulo p^3 the lift is omega_p(t) = t * (t^(p-1))^z with z = -(p-1)^-1 in Z_p: t^(p-1) = 1 + p a, and
+// (1 + p a)^z = 1 + z p a + C(z, 2) p^2 a^2 (mod p^3) is three small products.  Per number: one product modulo n^2 and the closed
+// form of (1 + n)^k, ONE interleaved ladder of 1 036 squarings modulo p (and q: 37-limb numbers), ONE ladder of 1 023 squarings
+// modulo p^3 (and q^3) for t^(p-1), Garner -- 16 M multiply-adds per number and half where the p-adic split of pow_n3_crt needs
+// 2 047 squarings modulo p^2 plus 1 024 modulo p^3: 26 M.  The same integers for every unit ct, y; a lane whose ct or y is not a
+// unit fails an exact division (d_status / the statement flags) and the caller falls back to the literal ladders.
+// omega(t) = t^(n^2) mod n^3 from t modulo the primes: t[half] = canonical residues modulo p / q (mp.WT limbs, stride nb).  Modulo
+// pr^3 the lift is t (t^(pr-1))^z, z = -(pr - 1)^-1 in Z_pr: w = t^(pr-1) on the digit kernel (the ladder of the level-two
+// decryption, both halves in one launch), a = (w - 1) / pr (exact for every unit t: lanes where it is not are flagged in d_status),
+// (1 + pr a)^z = 1 + pr (z a mod pr^2) + pr^2 (C(z,2) a^2 mod pr); then Garner.  T: WT(n^3) limbs, stride nb.
+void teichmueller_lift(const pgpu_seckey* sk, uint32_t* const t[2], size_t nb, int32_t* d_status, uint32_t* T) {
+  pgpu_ctx* ctx = sk->ctx;
+  const ModCtx &mp3 = sk->mp3, &mq3 = sk->mq3;
+  const int H = sk->mp.WT, P2 = sk->mp2.WT, W = mp3.WT;
+  const size_t S1 = (size_t)H * nb, S2 = (size_t)P2 * nb, S = (size_t)W * nb;
+  TriplePlan tp = triple_alloc(ctx, mp3, nb, 5 + 32), tq = triple_alloc(ctx, mq3, nb, 5 + 32);
+  uint32_t* tz[2];
+  Fork f2(ctx);
+  for (int half = 0; half < 2; ++half) {
+    f2.chain(half);
+    tz[half] = zext(ctx, t[half], H, W, nb);
+    triple_enter(ctx, half ? mq3 : mp3, tz[half], half ? tq : tp, 0);
+  }
+  f2.join();
+  {
+    Prog pp, pq;
+    emit_modexp_shared(pp, sk->p - BigU(1), 0, NO_SLOT, 2, 3, 5, NO_SLOT, true, true);
+    pp.end();
+    emit_modexp_shared(pq, sk->q - BigU(1), 0, NO_SLOT, 2, 3, 5, NO_SLOT, true, true);
+    pq.end();
+    SegSpec sp{&mp3, &pp, tp.mem, nullptr}, sq{&mq3, &pq, tq.mem, nullptr};
+    sp.pair = mp3.triple.kconsts; sp.pair_n0inv = sk->mp.n0inv; sp.pair_h = tp.H; sp.pair_lanes = 3; sp.tconsts = mp3.triple.tconsts;
+    sq.pair = mq3.triple.kconsts; sq.pair_n0inv = sk->mq.n0inv; sq.pair_h = tq.H; sq.pair_lanes = 3; sq.tconsts = mq3.triple.tconsts;
+    run_vm(ctx, nb, sp, &sq, true);
+  }
+  // a = (w - 1) / pr (exact for every unit t), c = (1 + pr a)^z = 1 + pr (z a mod pr^2) + pr^2 (C(z,2) a^2 mod pr), tau = t c
+  uint32_t* tau[2];
+  Fork f3(ctx);
+  for (int half = 0; half < 2; ++half) {
+    f3.chain(half);
+    const ModCtx &m1 = half ? sk->mq : sk->mp, &m2 = half ? sk->mq2 : sk->mp2, &m3 = half ? mq3 : mp3;
+    uint32_t* w = ctx->ws_t<uint32_t>(S);
+    triple_exit(ctx, m3, half ? tq : tp, 3, w, nullptr);
+    uint32_t* v2 = ctx->ws_t<uint32_t>(S2 * 2);                          // slots (P2 limbs): 0 a, 1 z a
+    uint32_t* tb = ctx->ws_t<uint32_t>(S);
+    launch_div_exact(w, W, 1, nullptr, 0, tb, (half ? sk->qinv2k_2 : sk->pinv2k_2).d, m1.d_nmod, H, v2, P2, nb, nb, d_status,
+                     PGPU_LANE_NONUNIT, ctx->stream);
+    {
+      Prog a;
+      a.op(VM_LOAD, 0); a.op(VM_MULC, (uint32_t)(half ? sk->c_lz_q2 : sk->c_lz_p2)); a.op(VM_STORE, 1); a.end();
+      SegSpec sa{&m2, &a, v2, nullptr};
+      run_vm(ctx, nb, sa, nullptr, false);
+      launch_canon(v2 + S2, m2.d_nmod, P2, nb, ctx->stream);
+    }
+    uint32_t* v1 = ctx->ws_t<uint32_t>(S1 * 2);                          // slots (H limbs): 0 a mod pr, 1 C(z,2) a^2
+    reduce_mod(ctx, m1, v2, P2, v1, nb);
+    {
+      Prog a;
+      a.op(VM_LOAD, 0); a.op(VM_MULC, C_R2); a.op(VM_SQR); a.op(VM_MULC, (uint32_t)(half ? sk->c_lz2_q : sk->c_lz2_p)); a.op(VM_STORE, 1);
+      a.end();
+      SegSpec sa{&m1, &a, v1, nullptr};
+      run_vm(ctx, nb, sa, nullptr, false);
+      launch_canon(v1 + S1, m1.d_nmod, H, nb, ctx->stream);
+    }
+    uint32_t* c1 = ctx->ws_t<uint32_t>(S);
+    uint32_t* cf = ctx->ws_t<uint32_t>(S);
+    launch_mul_const_add(v2 + S2, P2, (half ? sk->q_limbs : sk->p_limbs).d, H, nullptr, 0, 1, c1, W, nb, ctx->stream);          // 1 + pr (z a)
+    launch_mul_const_add(v1 + S1, H, (half ? sk->q2_limbs : sk->p2_limbs).d, P2, c1, W, 0, cf, W, nb, ctx->stream);          // + pr^2 (...)
+    launch_canon(cf, m3.d_nmod, W, nb, ctx->stream);
+    tau[half] = ctx->ws_t<uint32_t>(S);
+    modmul_arrays(ctx, m3, tz[half], cf, nb, tau[half]);
+  }
+  f3.join();
+  garner_n3(sk, tau[0], tau[1], nb, T);
+}
+
+struct StructBase {
+  const uint32_t* m = nullptr;            // level-two plaintext of ct per statement (mn2.WT limbs, stride nbs)
+  const uint32_t* cpr[2] = {nullptr, nullptr};   // ct mod p, ct mod q per statement (mp.WT limbs, stride nbs)
+  size_t nbs = 0;
+};
+bool struct_pow_usable(const pgpu_seckey* sk) {
+  pgpu_ctx* ctx = sk->ctx;
+  static const bool env_on = [] { const char* v = getenv("PGPU_STRUCT"); return v ? atoi(v) != 0 : true; }();
+  return env_on && ctx->use_struct && sk->has_lift && sk->has_crt2 && sk->c_p3invR >= 0 && triple_usable(ctx, sk->mp3) &&
+         triple_usable(ctx, sk->mq3) && sk->pk->g_is_n_plus_1 && sk->mp.K == 1 && sk->mq.K == 1 && sk->mp.WT == sk->mq.WT &&
+         (sk->p - BigU(1)).bit_length() >= 64 && (sk->q - BigU(1)).bit_length() >= 64 && 2 * sk->mp3.WT >= sk->pk->mn3->WT;
+}
+// per statement: m = Decrypt_2(ct) through p^3, q^3 and ct modulo the primes.  ct: WT(n^3) limbs, stride nbs; d_status (nbs
+// entries, zeroed by the caller) receives PGPU_LANE_NONUNIT for the first `count` statements
+void struct_base(const pgpu_seckey* sk, const uint32_t* ct, size_t nbs, size_t count, int32_t* d_status, StructBase& sb) {
+  pgpu_ctx* ctx = sk->ctx;
+  const int W3 = sk->pk->mn3->WT, W = sk->mp3.WT, H = sk->mp.WT;
+  sb.nbs = nbs;
+  sb.m = decrypt2_crt(sk, zext(ctx, ct, W3, 2 * W, nbs), nbs, count, d_status);
+  for (int half = 0; half < 2; ++half) {
+    uint32_t* r3 = ctx->ws_t<uint32_t>((size_t)W * nbs);
+    reduce_mod(ctx, half ? sk->mq3 : sk->mp3, ct, W3, r3, nbs);
+    uint32_t* r1 = ctx->ws_t<uint32_t>((size_t)H * nbs);
+    reduce_mod_wide(ctx, half ? sk->mq : sk->mp, r3, W, r1, nbs);
+    sb.cpr[half] = r1;
+  }
+}
+// X[g] = ct[sti[g]]^(e[g]) * y[g]^(n^2) mod n^3 for g < nb (sti == nullptr: number g belongs to statement g).  e: mn2.WT limbs,
+// y: mn.WT limbs, out: WT(n^3) limbs, all stride nb.  d_status (nb entries, zeroed by the caller) is flagged where the lift met a
+// non-unit.
+void struct_pow_n3(const pgpu_seckey* sk, const StructBase& sb, const uint32_t* sti, const uint32_t* e, const uint32_t* y, size_t nb,
+                   uint32_t* out, int32_t* d_status) {
+  pgpu_ctx* ctx = sk->ctx;
+  const pgpu_pubkey* pk = sk->pk;
+  const ModCtx &mn = pk->mn, &mn2 = pk->mn2, &mn3 = *pk->mn3, &mp3 = sk->mp3, &mq3 = sk->mq3;
+  const int W1 = mn.WT, W2 = mn2.WT, W3 = mn3.WT, H = sk->mp.WT, P2 = sk->mp2.WT, W = mp3.WT;
+  const size_t S1 = (size_t)H * nb, S2 = (size_t)P2 * nb, S = (size_t)W * nb;
+  auto per_number = [&](const uint32_t* in, int w) -> const uint32_t* {
+    if (!sti) return in;
+    uint32_t* o = ctx->ws_t<uint32_t>((size_t)w * nb);
+    launch_gather(in, sb.nbs, sti, nb, o, nb, w, ctx->stream);
+    return o;
+  };
+  // (1) the <1 + n> coordinate: k = m e mod n^2, G = (1 + n)^k = 1 + k n + C(k, 2) n^2 -- needed only at the very end: a chain of
+  // small kernels on a lane of its own, beside the ladders modulo the primes (one lane per number: a wave slot of every SIMD is free)
+  uint32_t* G = ctx->ws_t<uint32_t>((size_t)W3 * nb);
+  SideStream g_lane(ctx, 2);
+  g_lane.enter(g_lane.mark());
+  {
+    uint32_t* kk = ctx->ws_t<uint32_t>((size_t)W2 * nb);
+    modmul_arrays(ctx, mn2, per_number(sb.m, W2), e, nb, kk);
+    gm2_from_reduced(ctx, pk, kk, nb, G);
+  }
+  g_lane.leave();
+  // (2) X modulo the primes: interleaved ladders with the exponents modulo p - 1, q - 1, both halves in one launch
+  // slots (H limbs): 0 ct mod pr, 1 y mod pr, 2 tmp, 3 out, 5 .. the windows of e (number-major where the kernel has VM_MULVT: a
+  // limb-major gather reads one dword per 32-byte sector), then the 32 odd powers of y
+  const bool nm4 = ctx->use_nm4 && ctx->use_asm && H == 37 && plan::pair_nm4_fits(nb, H);
+  uint32_t* mem1[2];
+  const uint32_t* ex[2];
+  Prog lad[2];
+  Fork f1(ctx);
+  for (int half = 0; half < 2; ++half) {
+    f1.chain(half);
+    const ExpOrder& eo = half ? sk->eo1_q : sk->eo1_p;
+    const ModCtx& m1 = half ? sk->mq : sk->mp;
+    mem1[half] = ctx->ws_t<uint32_t>(S1 * 54);
+    uint32_t* em = ctx->ws_t<uint32_t>((size_t)eo.modd.WT * nb);
+    reduce_mod_wide(ctx, eo.modd, e, W2, em, nb);
+    uint32_t* er = ctx->ws_t<uint32_t>((size_t)eo.w * nb);
+    launch_exp_order_lift(e, W2, em, eo.modd.WT, eo.m_limbs.d, eo.t, eo.minv, er, eo.w, nb, ctx->stream);
+    ex[half] = er;
+    HIPCHK(hipMemcpyAsync(mem1[half], per_number(sb.cpr[half], H), S1 * 4, hipMemcpyDeviceToDevice, ctx->stream));
+    reduce_mod(ctx, m1, y, W1, mem1[half] + S1, nb);
+    emit_modexp_dual(lad[half], eo.w, half ? sk->n2_mod_q1 : sk->n2_mod_p1, 0, 1, 2, 3, 5, 5 + (uint32_t)perlane_table_slots(4, nm4), -1, 4, nm4);
+    lad[half].end();
+  }
+  f1.join();
+  {
+    SegSpec sp{&sk->mp, &lad[0], mem1[0], ex[0]}, sq{&sk->mq, &lad[1], mem1[1], ex[1]};
+    run_vm(ctx, nb, sp, &sq, true);
+  }
+  // (3) the lift of X mod n and (4) X = (1 + n)^k * omega(X mod n)
+  uint32_t* tt[2];
+  for (int half = 0; half < 2; ++half) {
+    tt[half] = mem1[half] + 3 * S1;
+    launch_canon(tt[half], (half ? sk->mq : sk->mp).d_nmod, H, nb, ctx->stream);
+  }
+  uint32_t* T = ctx->ws_t<uint32_t>((size_t)W3 * nb);
+  teichmueller_lift(sk, tt, nb, d_status, T);
+  g_lane.join();
+  modmul_arrays(ctx, mn3, G, T, nb, out);
+}
+
+// ---- the prover's response for challenge bit 1 through the same structure (ProveDDLEQ with secpar > 1) ---------------------------
+// c = ((s^an b)^en)^-1 s^xn = s^(E1) b^(E2) modulo n^3 for units (ddleq.go:107-112), E1 = xn - an en, E2 = -en, and both bases
+// belong to the STATEMENT: s = ExtractRandonness(ct1), b.  Write the integers s, b as (1 + n)^(mu) omega(.) -- mu = their level-two
+// "plaintext", one CRT decryption each per statement --; then
+//     c = (1 + n)^(mu_s E1 + mu_b E2 mod n^2) * omega(s^E1 b^E2 mod n):
+// per instance two products modulo n^2 and a closed form, ONE ladder modulo p (and q) with two per-number exponents modulo p - 1,
+// and ONE lift -- where pow_n3_crt_two squares 3 071 times modulo p^3 (or 2 047 times modulo p^2 and 1 024 modulo p^3) on two
+// 128-entry tables.  Worth it from a few instances per statement (plan::response_by_structure).
+struct RespBase {
+  const uint32_t *mu_s = nullptr, *mu_b = nullptr;                 // mn2.WT limbs, stride nbs
+  const uint32_t *sp[2] = {nullptr, nullptr}, *bp[2] = {nullptr, nullptr};   // s, b modulo p and q: mp.WT limbs, stride nbs
+  size_t nbs = 0;
+};
+// s, b: canonical residues modulo n (mn.WT limbs, stride nbs); d_status (nbs entries, zeroed) flags non-units among the first `count`
+void resp_base(const pgpu_seckey* sk, const uint32_t* s, const uint32_t* b, size_t nbs, size_t count, int32_t* d_status, RespBase& rb) {
+  pgpu_ctx* ctx = sk->ctx;
+  const int W1 = sk->pk->mn.WT, W = sk->mp3.WT, H = sk->mp.WT;
+  rb.nbs = nbs;
+  // (both decryptions in one launch: 2 nbs numbers)
+  uint32_t* both = concat2(ctx, zext(ctx, s, W1, 2 * W, nbs), zext(ctx, b, W1, 2 * W, nbs), 2 * W, nbs);
+  int32_t* st2 = ctx->ws_t<int32_t>(2 * nbs);
+  HIPCHK(hipMemsetAsync(st2, 0, 2 * nbs * 4, ctx->stream));
+  const uint32_t* mu = decrypt2_crt(sk, both, 2 * nbs, 2 * nbs, st2);
+  const int W2 = sk->pk->mn2.WT;
+  uint32_t *ms = ctx->ws_t<uint32_t>((size_t)W2 * nbs), *mb = ctx->ws_t<uint32_t>((size_t)W2 * nbs);
+  split2(ctx, mu, 0, W2, nbs, ms);
+  split2(ctx, mu, 1, W2, nbs, mb);
+  rb.mu_s = ms;
+  rb.mu_b = mb;
+  launch_or_flags(st2, count, d_status, PGPU_LANE_NONUNIT, ctx->stream);
+  launch_or_flags(st2 + nbs, count, d_status, PGPU_LANE_NONUNIT, ctx->stream);
+  for (int half = 0; half < 2; ++half) {
+    const ModCtx& m1 = half ? sk->mq : sk->mp;
+    uint32_t *x = ctx->ws_t<uint32_t>((size_t)H * nbs), *y = ctx->ws_t<uint32_t>((size_t)H * nbs);
+    reduce_mod_wide(ctx, m1, s, W1, x, nbs);
+    reduce_mod_wide(ctx, m1, b, W1, y, nbs);
+    rb.sp[half] = x;
+    rb.bp[half] = y;
+  }
+}
+// per-instance exponents of the response, for EVERY instance (the challenge bits are not known yet): E1 mod n^2, and E1, E2 modulo
+// p - 1 and q - 1 (the odd part through a Montgomery product, the 2-part from the lowest limbs, then the CRT lift)
+struct RespExps {
+  uint32_t* e1n = nullptr;                                          // (xn - an en) mod n^2, mn2.WT limbs
+  uint32_t* e1p[2] = {nullptr, nullptr};                            // E1 mod (pr - 1): eo1.w limbs
+  uint32_t* e2p[2] = {nullptr, nullptr};                            // E2 mod (pr - 1)
+};
+void resp_exps(const pgpu_seckey* sk, const uint32_t* xn, const uint32_t* an, const uint32_t* en, size_t nb, RespExps& re) {
+  pgpu_ctx* ctx = sk->ctx;
+  const ModCtx& mn2 = sk->pk->mn2;
+  const int W2 = mn2.WT;
+  uint32_t* t = ctx->ws_t<uint32_t>((size_t)W2 * nb);
+  modmul_arrays(ctx, mn2, an, en, nb, t);
+  re.e1n = ctx->ws_t<uint32_t>((size_t)W2 * nb);
+  launch_sub_mod(xn, t, mn2.d_nmod, re.e1n, W2, nb, ctx->stream);
+  uint32_t* ls = ctx->ws_t<uint32_t>(nb);
+  uint32_t* lb = ctx->ws_t<uint32_t>(nb);
+  launch_exp_low_combine(xn, an, en, ls, lb, nb, ctx->stream);
+  Fork fo(ctx);
+  for (int half = 0; half < 2; ++half) {
+    fo.chain(half);
+    const ExpOrder& eo = half ? sk->eo1_q : sk->eo1_p;
+    const ModCtx& mm = eo.modd;
+    const size_t sm = (size_t)mm.WT * nb;
+    uint32_t *am = ctx->ws_t<uint32_t>(sm), *em = ctx->ws_t<uint32_t>(sm), *xm = ctx->ws_t<uint32_t>(sm), *pm = ctx->ws_t<uint32_t>(sm),
+             *esm = ctx->ws_t<uint32_t>(sm), *ebm = ctx->ws_t<uint32_t>(sm), *zero = ctx->ws_t<uint32_t>(sm);
+    HIPCHK(hipMemsetAsync(zero, 0, sm * 4, ctx->stream));
+    reduce_mod_wide(ctx, mm, an, W2, am, nb);
+    reduce_mod_wide(ctx, mm, en, W2, em, nb);
+    reduce_mod_wide(ctx, mm, xn, W2, xm, nb);
+    modmul_arrays(ctx, mm, am, em, nb, pm);                                            // an en mod m
+    launch_sub_mod(xm, pm, mm.d_nmod, esm, mm.WT, nb, ctx->stream);                      // xn - an en mod m
+    launch_sub_mod(zero, em, mm.d_nmod, ebm, mm.WT, nb, ctx->stream);                    // -en mod m
+    re.e1p[half] = ctx->ws_t<uint32_t>((size_t)eo.w * nb);
+    re.e2p[half] = ctx->ws_t<uint32_t>((size_t)eo.w * nb);
+    launch_exp_order_lift(ls, 1, esm, mm.WT, eo.m_limbs.d, eo.t, eo.minv, re.e1p[half], eo.w, nb, ctx->stream);
+    launch_exp_order_lift(lb, 1, ebm, mm.WT, eo.m_limbs.d, eo.t, eo.minv, re.e2p[half], eo.w, nb, ctx->stream);
+  }
+  fo.join();
+}
+// c[g] = s^(E1) b^(E2) mod n^3 for the `nb` (compacted) instances with challenge bit 1: sti[g] = statement of instance g (device,
+// nb entries), e1n / en: E1 and e^n modulo n^2 (mn2.WT limbs), e1p / e2p: the exponents modulo p - 1, q - 1 (eo1.w limbs); all stride
+// nb.  out: WT(n^3) limbs.  d_status (nb entries, zeroed) is flagged where the lift met a non-unit.
+void struct_response(const pgpu_seckey* sk, const RespBase& rb, const uint32_t* sti, const uint32_t* e1n, const uint32_t* en,
+                     const uint32_t* const e1p[2], const uint32_t* const e2p[2], size_t nb, uint32_t* out, int32_t* d_status) {
+  pgpu_ctx* ctx = sk->ctx;
+  const pgpu_pubkey* pk = sk->pk;
+  const ModCtx &mn2 = pk->mn2, &mn3 = *pk->mn3;
+  const int W2 = mn2.WT, W3 = mn3.WT, H = sk->mp.WT;
+  const size_t S1 = (size_t)H * nb;
+  auto per_number = [&](const uint32_t* in, int w) {
+    uint32_t* o = ctx->ws_t<uint32_t>((size_t)w * nb);
+    launch_gather(in, rb.nbs, sti, nb, o, nb, w, ctx->stream);
+    return o;
+  };
+  // the <1 + n> coordinate on a lane of its own: k = mu_s E1 - mu_b en mod n^2, G = (1 + n)^k
+  uint32_t* G = ctx->ws_t<uint32_t>((size_t)W3 * nb);
+  SideStream g_lane(ctx, 2);
+  g_lane.enter(g_lane.mark());
+  {
+    uint32_t *k1 = ctx->ws_t<uint32_t>((size_t)W2 * nb), *k2 = ctx->ws_t<uint32_t>((size_t)W2 * nb), *kk = ctx->ws_t<uint32_t>((size_t)W2 * nb);
+    modmul_arrays(ctx, mn2, per_number(rb.mu_s, W2), e1n, nb, k1);
+    modmul_arrays(ctx, mn2, per_number(rb.mu_b, W2), en, nb, k2);
+    launch_sub_mod(k1, k2, mn2.d_nmod, kk, W2, nb, ctx->stream);
+    gm2_from_reduced(ctx, pk, kk, nb, G);
+  }
+  g_lane.leave();
+  // c modulo the primes: (s mod pr)^(E1) (b mod pr)^(E2), one chain of squarings, two per-number window tables; both halves in one launch
+  const int we = sk->eo1_p.w, wb = 4;
+  const bool nm4 = ctx->use_nm4 && ctx->use_asm && H == 37 && plan::pair_nm4_fits(nb, H);
+  const uint32_t TA = 5, TB = TA + (uint32_t)perlane_table_slots(wb, nm4), NS = TB + (uint32_t)perlane_table_slots(wb, nm4);
+  uint32_t* mem1[2];
+  const uint32_t* dig[2];
+  Prog lad[2];
+  Fork f1(ctx);
+  for (int half = 0; half < 2; ++half) {
+    f1.chain(half);
+    mem1[half] = ctx->ws_t<uint32_t>(S1 * (size_t)NS);             // slots (H limbs): 0 s, 1 b, 2 tmp, 3 out, TA.. / TB.. the tables
+    HIPCHK(hipMemcpyAsync(mem1[half], per_number(rb.sp[half], H), S1 * 4, hipMemcpyDeviceToDevice, ctx->stream));
+    HIPCHK(hipMemcpyAsync(mem1[half] + S1, per_number(rb.bp[half], H), S1 * 4, hipMemcpyDeviceToDevice, ctx->stream));
+    // the two exponents of a number one after the other in the rows of `digits`
+    uint32_t* d2 = ctx->ws_t<uint32_t>((size_t)2 * we * nb);
+    HIPCHK(hipMemcpyAsync(d2, e1p[half], (size_t)we * nb * 4, hipMemcpyDeviceToDevice, ctx->stream));
+    HIPCHK(hipMemcpyAsync(d2 + (size_t)we * nb, e2p[half], (size_t)we * nb * 4, hipMemcpyDeviceToDevice, ctx->stream));
+    dig[half] = d2;
+    Prog& pr = lad[half];
+    pr.op(VM_LOAD, 0); pr.op(VM_MULC, C_R2); pr.op(VM_STORE, 0);     // into Montgomery form (the generic kernel's working form)
+    pr.op(VM_LOAD, 1); pr.op(VM_MULC, C_R2); pr.op(VM_STORE, 1);
+    std::vector<PerNumberBase> pn;
+    pn.push_back(PerNumberBase{we, 0, TA, 0});
+    pn.push_back(PerNumberBase{we, 1, TB, (uint32_t)perlane_windows(we, wb)});
+    emit_modexp_multi(pr, pn, wb, {}, 2, 3, (uint32_t)C_ONE_M, nm4);
+    pr.op(VM_LOAD, 3); pr.op(VM_MULC, C_ONE); pr.op(VM_STORE, 3);    // and out of it
+    pr.end();
+  }
+  f1.join();
+  {
+    SegSpec sp{&sk->mp, &lad[0], mem1[0], dig[0]}, sq{&sk->mq, &lad[1], mem1[1], dig[1]};
+    run_vm(ctx, nb, sp, &sq, true);
+  }
+  uint32_t* tt[2];
+  for (int half = 0; half < 2; ++half) {
+    tt[half] = mem1[half] + 3 * S1;
+    launch_canon(tt[half], (half ? sk->mq : sk->mp).d_nmod, H, nb, ctx->stream);
+  }
+  uint32_t* T = ctx->ws_t<uint32_t>((size_t)W3 * nb);
+  teichmueller_lift(sk, tt, nb, d_status, T);
+  g_lane.join();
+  modmul_arrays(ctx, mn3, G, T, nb, out);
 }
 
 // out = base^e mod n^3 for a holder of the factorisation (the DDLEQ prover): two ladders modulo p^3 and q^3 -- half the
@@ -886,6 +1238,24 @@ static void ddleq_prove_impl(const pgpu_seckey* sk, size_t S, size_t secpar, con
     // launch for its whole length (measured at 32 768 instances: 48 -> 76 ms for 8 ms hidden).  Then s follows on the main stream.
     // (A side launch of a few dozen waves -- the statements of a secpar-40 call -- costs the big launch next to nothing.)
     const bool s_beside = plan::extract_beside(nbs, nb, plan::lanes_target(ctx->lanes_wanted));
+    // The structure path's per-statement part (struct_pow_n3 below) -- the level-two plaintext of ct1 through p^3, q^3 and ct1 modulo
+    // the primes -- depends on the inputs only: it runs beside the a^n | x^n launch (one lane per number: one wave per SIMD at
+    // 16 384 instances; the decryption's digit kernel fills the other wave slots), and the main stream waits for it -- not for s,
+    // which has the side stream to itself -- before the ladders modulo the primes.
+    const size_t nt = nbs + nb;
+    int32_t *d_st_stmt = nullptr, *d_st_num = nullptr;
+    const bool by_struct = crt3 && struct_pow_usable(sk);
+    StructBase sbase;
+    SideStream base_lane(ctx, 3);      // (a lane of its own: s keeps the side stream, beside the same launch)
+    if (by_struct) {
+      d_st_stmt = ctx->ws_t<int32_t>(nbs);
+      d_st_num = ctx->ws_t<int32_t>(nt);
+      base_lane.enter(inputs_ready);
+      HIPCHK(hipMemsetAsync(d_st_stmt, 0, nbs * 4, ctx->stream));
+      HIPCHK(hipMemsetAsync(d_st_num, 0, nt * 4, ctx->stream));
+      struct_base(sk, c1s, nbs, S, d_st_stmt, sbase);
+      base_lane.leave();
+    }
     if (s_beside) side.enter(inputs_ready);
     {
       // s = ExtractRandonness(ct1) at level two (operations.go:75-91): z = G^(-v) ct1 mod n^3 with v = Decrypt(ct1)
@@ -908,15 +1278,34 @@ static void ddleq_prove_impl(const pgpu_seckey* sk, size_t S, size_t secpar, con
     uint32_t* t3 = ctx->ws_t<uint32_t>((size_t)W3 * nb);
     uint32_t* san = ctx->ws_t<uint32_t>((size_t)W3 * nbs);
     uint32_t* alp = ctx->ws_t<uint32_t>((size_t)W3 * nb);
-    if (crt3) {
-      // ct1^(a^n) * b^(n^2) and ct1^(x^n) * y^(n^2): one interleaved ladder per number and CRT half, both batches in one launch
+    // ct1^(a^n) * b^(n^2) and ct1^(x^n) * y^(n^2), both batches (S statements | S secpar instances) in the same launches
+    auto literal_ladders = [&] {
+      // one interleaved ladder per number and CRT half on ct1 itself (pow_n3_crt: the p-adic split for batches that fill the chip)
       uint32_t* cc2 = concat_ab(ctx, c1s, nbs, c1, nb, W3);
       uint32_t* ee2 = concat_ab(ctx, an, nbs, xn, nb, W2);
       uint32_t* by2 = concat_ab(ctx, bl, nbs, yl, nb, W1);
-      uint32_t* o2 = ctx->ws_t<uint32_t>((size_t)W3 * (nbs + nb));
-      pow_n3_crt(sk, cc2, W3, ee2, W2, &N2, nbs + nb, o2, by2, W1);
+      uint32_t* o2 = ctx->ws_t<uint32_t>((size_t)W3 * nt);
+      pow_n3_crt(sk, cc2, W3, ee2, W2, &N2, nt, o2, by2, W1);
       split_ab(ctx, o2, nbs, nb, 0, W3, san);
       split_ab(ctx, o2, nbs, nb, 1, W3, alp);
+    };
+    // Through the structure of the unit group where the key serves it (struct_pow_n3): ct1's plaintext once per statement, then per
+    // number a ladder modulo the primes and ONE lift modulo p^3, q^3.  Lanes that meet a non-unit are flagged; if a REAL lane is
+    // (never for honest inputs) the literal ladders redo the launch after the host has seen the flags (below).
+    if (by_struct) {
+      base_lane.join();                                      // the main stream waits for the per-statement part (not for s)
+      std::vector<uint32_t> sv(nt, 0);                       // statement of every number: the sanity values | the instances
+      for (size_t g = 0; g < S; ++g) sv[g] = (uint32_t)g;
+      for (size_t i = 0; i < batch; ++i) sv[nbs + i] = (uint32_t)(i / secpar);
+      const uint32_t* d_sv = ctx->upload_words(sv);
+      uint32_t* ee2 = concat_ab(ctx, an, nbs, xn, nb, W2);
+      uint32_t* by2 = concat_ab(ctx, bl, nbs, yl, nb, W1);
+      uint32_t* o2 = ctx->ws_t<uint32_t>((size_t)W3 * nt);
+      struct_pow_n3(sk, sbase, d_sv, ee2, by2, nt, o2, d_st_num);
+      split_ab(ctx, o2, nbs, nb, 0, W3, san);
+      split_ab(ctx, o2, nbs, nb, 1, W3, alp);
+    } else if (crt3) {
+      literal_ladders();
     } else {
       shared3(bl, W1, N2, nbs, bn2);
       perlane3(c1s, an, W2, nbs, t3);
@@ -930,7 +1319,11 @@ static void ddleq_prove_impl(const pgpu_seckey* sk, size_t S, size_t secpar, con
     // one of its instances draws challenge bit 1), and the unit test of s b for the one-ladder form of the response
     uint32_t *qainv = ctx->ws_t<uint32_t>((size_t)W2 * nbs), *qani = ctx->ws_t<uint32_t>((size_t)W2 * nbs);
     int32_t* d_badinv = ctx->ws_t<int32_t>(2 * nbs);
-    bool any_badinv = false, sb_units = false, early = false;
+    bool any_badinv = false, sb_units = false, early = false, resp_struct = false;
+    RespBase rbase;
+    RespExps rexps;
+    uint32_t* en_all = nullptr;
+    int32_t* d_st_rstmt = nullptr;
     uint32_t *ge_all = nullptr, *es_all[2] = {nullptr, nullptr}, *eb_all[2] = {nullptr, nullptr};
     PreBases pre;
     const bool one_ladder = crt3 && ctx->use_lift && sk->eo_p.ok && sk->eo_q.ok && sk->eo_p.w == sk->eo_q.w &&
@@ -957,8 +1350,14 @@ static void ddleq_prove_impl(const pgpu_seckey* sk, size_t S, size_t secpar, con
       // afterwards (between the hash and the response ladder there is then a handful of gathers instead of ~150 small kernels).
       // (only where the response ladder is certain to take pow_n3_crt_two's kernels whatever the number of bit-1 instances turns out
       // to be: its 7-bit window tables must fit the gather offsets even if every instance draws bit 1)
-      if (one_ladder && sb_units && ctx->use_early && pre_bases_usable(sk) && plan::early_response_ok(nb, sk->mp3.triple.root->WT)) {
-        early = true;
+      // From a few instances per statement on, the response goes through the structure of the unit group (struct_response): the
+      // per-statement part -- the level-two "plaintexts" of s and b, s and b modulo the primes -- and every instance's exponents
+      // are made here as well.
+      resp_struct = by_struct && one_ladder && sb_units && plan::response_by_structure(S, batch);
+      const bool early_cond = one_ladder && sb_units && ctx->use_early && pre_bases_usable(sk) &&
+                              plan::early_response_ok(nb, sk->mp3.triple.root->WT);
+      if (resp_struct || early_cond) {
+        early = !resp_struct;
         std::vector<uint32_t> stall(nb, 0);
         for (size_t i = 0; i < batch; ++i) stall[i] = (uint32_t)(i / secpar);
         const uint32_t* d_stall = ctx->upload_words(stall);
@@ -973,6 +1372,13 @@ static void ddleq_prove_impl(const pgpu_seckey* sk, size_t S, size_t secpar, con
         modmul_arrays(ctx, mn2, x2a, ainv_a, nb, ge_all);                     // e = x a^-1 mod n^2 (ddleq.go:94-99)
         uint32_t* en_a = ctx->ws_t<uint32_t>((size_t)W2 * nb);
         modmul_arrays(ctx, mn2, xn, ani_a, nb, en_a);                         // e^n = x^n (a^n)^-1
+        if (resp_struct) {
+          d_st_rstmt = ctx->ws_t<int32_t>(nbs);
+          HIPCHK(hipMemsetAsync(d_st_rstmt, 0, nbs * 4, ctx->stream));
+          resp_base(sk, qs, bl, nbs, S, d_st_rstmt, rbase);
+          en_all = en_a;
+          resp_exps(sk, xn, gan_a, en_a, nb, rexps);
+        } else {
         uint32_t* ls = ctx->ws_t<uint32_t>(nb);
         uint32_t* lb = ctx->ws_t<uint32_t>(nb);
         launch_exp_low_combine(xn, gan_a, en_a, ls, lb, nb, ctx->stream);
@@ -1001,13 +1407,32 @@ static void ddleq_prove_impl(const pgpu_seckey* sk, size_t S, size_t secpar, con
         }
         fo.join();
         pre_bases(sk, zext(ctx, qs, W1, W3, nbs), zext(ctx, bl, W1, W3, nbs), nbs, pre);
+        }
       }
     }
     side.leave();
     // (a device-to-host copy into pageable memory holds the host until the stream has got there: it comes after the side work
     // has been issued, not before)
     HIPCHK(hipMemcpyAsync(hok.data(), d_ok, S * 4, hipMemcpyDeviceToHost, ctx->stream));
+    std::vector<int32_t> hst_stmt, hst_num;
+    if (by_struct) {
+      hst_stmt.resize(S);
+      hst_num.resize(nt);
+      HIPCHK(hipMemcpyAsync(hst_stmt.data(), d_st_stmt, S * 4, hipMemcpyDeviceToHost, ctx->stream));
+      HIPCHK(hipMemcpyAsync(hst_num.data(), d_st_num, nt * 4, hipMemcpyDeviceToHost, ctx->stream));
+    }
     HIPCHK(hipStreamSynchronize(ctx->stream));
+    if (by_struct) {
+      bool nonunit = false;
+      for (size_t g = 0; g < S; ++g) nonunit = nonunit || hst_stmt[g] || hst_num[g];
+      for (size_t i = 0; i < batch; ++i) nonunit = nonunit || hst_num[nbs + i];
+      if (nonunit) {      // a ct1, b or y that is not a unit: the structure theorem does not apply -- the reference's formula verbatim
+        literal_ladders();
+        launch_equal(san, c2s, W3, nbs, S, d_ok, ctx->stream);
+        HIPCHK(hipMemcpyAsync(hok.data(), d_ok, S * 4, hipMemcpyDeviceToHost, ctx->stream));
+        HIPCHK(hipStreamSynchronize(ctx->stream));
+      }
+    }
     for (size_t i = 0; i < S; ++i)
       if (!hok[i]) api_throw(PGPU_ERR_INVALID, "cannot prove re-encryption because inputs are wrong");
     // ---- alpha = ct1^(x^n) * y^(n^2) mod n^3 (ddleq.go:81-87); with CRT it came out of the launch above
@@ -1060,7 +1485,35 @@ static void ddleq_prove_impl(const pgpu_seckey* sk, size_t S, size_t secpar, con
         launch_gather(in, nbs, d_sti, cnt, o, nbg, w, ctx->stream);
         return o;
       };
-      if (early) {
+      bool done = false;
+      if (resp_struct) {
+        // through the structure of the unit group: gather the prepared exponents of the bit-1 instances; one ladder modulo the primes, one lift
+        uint32_t* ge = gat(ge_all, W2);
+        const uint32_t* e1p[2] = {gat(rexps.e1p[0], sk->eo1_p.w), gat(rexps.e1p[1], sk->eo1_q.w)};
+        const uint32_t* e2p[2] = {gat(rexps.e2p[0], sk->eo1_p.w), gat(rexps.e2p[1], sk->eo1_q.w)};
+        int32_t* d_st_r = ctx->ws_t<int32_t>(nbg);
+        HIPCHK(hipMemsetAsync(d_st_r, 0, nbg * 4, ctx->stream));
+        std::vector<uint32_t> sti_pad(sti);
+        sti_pad.resize(nbg, 0);                                            // (padding lanes: statement 0's bases)
+        uint32_t* c5 = ctx->ws_t<uint32_t>((size_t)W3 * nbg);
+        struct_response(sk, rbase, ctx->upload_words(sti_pad), gat(rexps.e1n, W2), gat(en_all, W2), e1p, e2p, nbg, c5, d_st_r);
+        std::vector<int32_t> hr(cnt), hs(S);
+        HIPCHK(hipMemcpyAsync(hr.data(), d_st_r, cnt * 4, hipMemcpyDeviceToHost, ctx->stream));
+        HIPCHK(hipMemcpyAsync(hs.data(), d_st_rstmt, S * 4, hipMemcpyDeviceToHost, ctx->stream));
+        HIPCHK(hipStreamSynchronize(ctx->stream));
+        bool nonunit = false;
+        for (size_t i = 0; i < cnt; ++i) nonunit = nonunit || hr[i] || hs[sti[i]];
+        if (!nonunit) {
+          uint32_t* y3 = zext(ctx, gat(yl, W1), W1, W3, nbg);
+          uint32_t* gf = ctx->ws_t<uint32_t>((size_t)W3 * nbg);
+          modmul_arrays(ctx, mn3, y3, c5, nbg, gf);                           // f = y c mod n^3 (ddleq.go:114)
+          launch_scatter(ge, nbg, d_idx, cnt, eo, nb, W2, ctx->stream);
+          launch_scatter(gf, nbg, d_idx, cnt, fo, nb, W3, ctx->stream);
+          done = true;
+        }
+      }
+      if (!done && early) {
+        done = true;
         // everything but the ladder itself is at hand (side stream, above): gather it for the instances with bit 1
         uint32_t* ge = gat(ge_all, W2);
         const uint32_t* es[2] = {gat(es_all[0], sk->eo_p.w), gat(es_all[1], sk->eo_q.w)};
@@ -1074,7 +1527,8 @@ static void ddleq_prove_impl(const pgpu_seckey* sk, size_t S, size_t secpar, con
         modmul_arrays(ctx, mn3, y3, c5, nbg, gf);                             // f = y c mod n^3 (ddleq.go:114)
         launch_scatter(ge, nbg, d_idx, cnt, eo, nb, W2, ctx->stream);
         launch_scatter(gf, nbg, d_idx, cnt, fo, nb, W3, ctx->stream);
-      } else {
+      }
+      if (!done) {
       uint32_t *gx = gat(xl, W1), *gy = gat(yl, W1), *gxn = gat(xn, W2);
       uint32_t *ainv = per_inst(qainv, W2), *ani = per_inst(qani, W2), *gan = per_inst(an, W2), *sres = per_inst(qs, W1),
                *gb = per_inst(bl, W1);

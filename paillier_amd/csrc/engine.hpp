@@ -96,6 +96,7 @@ struct pgpu_ctx {
   bool use_early = true;     // the DDLEQ prover prepares its response for every statement / instance beside the Alpha ladders (pgpu_ctx_set_flag("early", 0): after the hash, for the bit-1 instances)
   bool use_handover = true;  // a power modulo n^2 that is only needed modulo n^2 by the next ladder modulo n^3 stays in pair form: (a0, a1, 0) is its digit form (pgpu_ctx_set_flag("handover", 0): exit and re-entry)
   bool use_muls = true;      // bucket products of the shared chain as VM_MULS where the kernel has it (pgpu_ctx_set_flag("muls", 0): LOAD / MUL / STORE)
+  bool use_struct = true;    // the key holder's ct^e y^(n^2) mod n^3 through the structure of the unit group: plaintext of ct, ladders modulo the primes, Teichmueller lift (pgpu_ctx_set_flag("struct", 0): the ladders on ct itself)
   bool use_lanes8 = true;    // shards too small for four lanes per number take the eight-lane pair kernel (pgpu_ctx_set_flag("lanes8", 0): never)
   bool use_side = true;
   hipStream_t side = nullptr;
@@ -531,7 +532,8 @@ struct pgpu_pubkey {
 };
 
 namespace pgi {
-// order of the unit group modulo pr^3, split as 2^t m for the Montgomery reduction modulo its odd part
+// order of the unit group modulo pr^3 (power = 2: pr^2 (pr - 1)) or modulo pr (power = 0: pr - 1), split as 2^t m for the
+// Montgomery reduction modulo its odd part
 struct ExpOrder {
   bool ok = false;
   BigU ord;
@@ -540,8 +542,9 @@ struct ExpOrder {
   uint32_t minv = 0;     // m^-1 mod 2^t
   DevLimbs m_limbs;      // m as w limbs
   int w = 0;             // limbs of a reduced exponent (< 2 ord)
-  void init(pgpu_ctx* ctx, const BigU& pr) {
-    ord = pr * pr * (pr - BigU(1));
+  void init(pgpu_ctx* ctx, const BigU& pr, int power = 2) {
+    ord = pr - BigU(1);
+    for (int i = 0; i < power; ++i) ord = ord * pr;
     t = 0;
     while (!ord.bit((size_t)t)) ++t;
     if (t > 20) return;                                  // (k m must stay below 2^48 per limb in the lift kernel)
@@ -600,6 +603,14 @@ struct pgpu_seckey {
   DevLimbs q2_limbs;                     // q^2 as mq2.WT limbs
   DevLimbs tkc_p, ttc_p, tkc_q, ttc_q;   // three-digit kernel constants for the ladders modulo p^3 and q^3 (mp3 / mq3 .triple)
   ExpOrder eo_p, eo_q;                   // exponent reduction modulo the orders of the units modulo p^3 / q^3
+  // The key holder's powers modulo n^3 through the STRUCTURE of the unit group, Z*_{n^3} = <1 + n> x (Teichmueller lifts of Z*_n)
+  // (ddleq.cpp struct_pow_n3): ladders modulo the primes with exponents modulo p - 1, q - 1, then the lift
+  // omega_p(t) = t (t^(p-1))^z, z = -(p - 1)^-1 in Z_p, by the binomial series modulo p^3
+  bool has_lift = false;
+  ExpOrder eo1_p, eo1_q;                 // exponent reduction modulo p - 1, q - 1
+  BigU n2_mod_p1, n2_mod_q1;             // n^2 mod (p - 1), n^2 mod (q - 1): the shared exponent of y^(n^2) in each half
+  int c_lz_p2 = -1, c_lz_q2 = -1;        // z R mod p^2 in mp2, mod q^2 in mq2 (z taken modulo prime^2)
+  int c_lz2_p = -1, c_lz2_q = -1;        // z (z - 1) / 2 mod p in mp, mod q in mq, stored plain
 };
 
 namespace pgi {
@@ -633,6 +644,7 @@ struct TriplePlan {
 
 ModexpPlan modexp_alloc(pgpu_ctx* ctx, const ModCtx& mc, size_t nb, int table_slots);
 void reduce_mod(pgpu_ctx* ctx, const ModCtx& mc, const uint32_t* in, int w_in, uint32_t* out, size_t nb);
+void reduce_mod_wide(pgpu_ctx* ctx, const ModCtx& mc, const uint32_t* in, int w_in, uint32_t* out, size_t nb);
 void unpack_mod(pgpu_ctx* ctx, const ModCtx& mc, const uint8_t* buf, size_t stride, size_t count, int mem, uint32_t* out,
                 size_t nb, bool canonical = false);
 void modexp_pair(pgpu_ctx* ctx, const ModCtx& mc, const ModexpPlan& pl, const BigU* e, const uint32_t* exps, int we,
@@ -720,5 +732,7 @@ bool pow_n2_crt_usable(const pgpu_seckey* sk);
 uint32_t* pow_n2_crt(const pgpu_seckey* sk, const uint32_t* base, const BigU& e, size_t nb);
 uint32_t* L_times_const(pgpu_ctx* ctx, const pgpu_pubkey* pk, const uint32_t* u, size_t nb, size_t count, const ModCtx& mn,
                         int c_const, const uint32_t* neg_const);
+uint32_t* decrypt2_crt(const pgpu_seckey* sk, const uint32_t* c_limbs, size_t nb, size_t count, int32_t* d_status);
+void gm2_from_reduced(pgpu_ctx* ctx, const pgpu_pubkey* pk, const uint32_t* mred, size_t nb, uint32_t* post);
 
 }  // namespace pgi

@@ -3808,7 +3808,13 @@ def make_gen(wl, k):
         return GenQ6(wl)
     if (wl, k) in TRIPLE:
         return GenQ3(wl)
-    return GenW(wl, k) if (wl, k) in WAVE_SLICED else Gen(wl, k)
+    if (wl, k) in WAVE_SLICED:
+        return GenW(wl, k)
+    g = Gen(wl, k)
+    # the one-lane 37-limb kernel runs the key holder's ladders modulo the primes of a 2048-bit key with per-number exponents
+    # (struct_pow_n3): number-major window tables there too (a limb-major gather reads one dword per 32-byte sector)
+    g.nm4_tables = (wl, k) == (37, 1)
+    return g
 
 
 if __name__ == "__main__":

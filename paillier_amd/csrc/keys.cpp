@@ -376,6 +376,29 @@ int pgpu_seckey_create(pgpu_ctx* ctx, const pgpu_pubkey* pk, const uint8_t* lamb
               setup_triple(sk->mq3, sk->mq, sk->mq2, sk->tkc_q, sk->ttc_q, sk->qinv2k.d, sk->qinv2k_2.d, sk->q_limbs.d, sk->q2_limbs.d);
               sk->eo_p.init(ctx, p);
               sk->eo_q.init(ctx, q);
+              // the Teichmueller lift and the exponents modulo p - 1, q - 1 (struct_pow_n3)
+              sk->eo1_p.init(ctx, p, 0);
+              sk->eo1_q.init(ctx, q, 0);
+              if (sk->eo1_p.ok && sk->eo1_q.ok && sk->eo1_p.w == sk->eo1_q.w && sk->eo1_p.modd.WT == sk->mp.WT &&
+                  sk->eo1_q.modd.WT == sk->mq.WT) {
+                const BigU n2v = n * n;
+                sk->n2_mod_p1 = n2v % (p - BigU(1));
+                sk->n2_mod_q1 = n2v % (q - BigU(1));
+                auto lift_consts = [&](const BigU& pr, const BigU& pr2, ModCtx& m1, ModCtx& m2, int& c_z, int& c_z2) {
+                  BigU inv;
+                  if (!hostbig::modinv((pr - BigU(1)) % pr2, pr2, inv)) return false;
+                  const BigU z = (pr2 - inv) % pr2;                                   // -(pr - 1)^-1 mod pr^2
+                  const BigU zz = z.is_zero() ? BigU(0) : hostbig::shr(z * (z - BigU(1)), 1) % pr;   // C(z, 2) mod pr
+                  c_z = m2.add_const(m2.to_mont(z));
+                  c_z2 = m1.add_const(zz);
+                  return true;
+                };
+                if (lift_consts(p, p2, sk->mp, sk->mp2, sk->c_lz_p2, sk->c_lz2_p) &&
+                    lift_consts(q, q2, sk->mq, sk->mq2, sk->c_lz_q2, sk->c_lz2_q)) {
+                  sk->mp.upload(); sk->mq.upload(); sk->mp2.upload(); sk->mq2.upload();
+                  sk->has_lift = true;
+                }
+              }
             }
           }
         }

@@ -287,6 +287,20 @@ void reduce_mod(pgpu_ctx* ctx, const ModCtx& mc, const uint32_t* in, int w_in, u
   HIPCHK(hipMemcpyAsync(out, mem + 3 * sw, sw * 4, hipMemcpyDeviceToDevice, ctx->stream));
 }
 
+// x mod N for an array of ANY width: Horner over WT-limb chunks from the top, every step one reduce_mod of [chunk | remainder]
+void reduce_mod_wide(pgpu_ctx* ctx, const ModCtx& mc, const uint32_t* in, int w_in, uint32_t* out, size_t nb) {
+  const int WT = mc.WT;
+  if (w_in <= 2 * WT) { reduce_mod(ctx, mc, in, w_in, out, nb); return; }
+  const size_t sw = (size_t)WT * nb;
+  const int nchunks = (w_in + WT - 1) / WT;
+  uint32_t* arr = ctx->ws_t<uint32_t>(2 * sw);   // [chunk | running remainder]: the value chunk + rem * 2^(28 WT)
+  launch_copy_limbs(in, (nchunks - 1) * WT, w_in - (nchunks - 1) * WT, arr + sw, WT, nb, ctx->stream);
+  for (int k = nchunks - 2; k >= 0; --k) {
+    launch_copy_limbs(in, k * WT, WT, arr, WT, nb, ctx->stream);
+    reduce_mod(ctx, mc, arr, 2 * WT, k ? arr + sw : out, nb);
+  }
+}
+
 // Stage an operand that is read modulo N, whatever its stride.  Up to the width of the modulus the bytes go straight into
 // WT limbs (a Montgomery operand may be any value below R; `canonical` additionally reduces it below N).  A wider stride
 // is unpacked whole and reduced chunk by chunk (Horner over WT-limb chunks), so that no leading byte is silently

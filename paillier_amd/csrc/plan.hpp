@@ -114,6 +114,9 @@ inline Crt3Two crt3_two(size_t nb, int H, size_t lt, bool prereq) {
 // the response may be prepared for EVERY instance before the challenge bits are known only where its kernels are certain
 // whatever the number of bit-1 instances turns out to be (all of them at worst)
 inline bool early_response_ok(size_t nb_instances, int H) { return triple_window_bits(nb_instances, H) == 7; }
+// the response through the structure of the unit group costs two level-two decryptions PER STATEMENT (of s and of b) and saves
+// more than half of every bit-1 instance's ladder: from four instances per statement
+inline bool response_by_structure(size_t statements, size_t instances) { return instances >= 4 * statements; }
 // s = ExtractRandonness on the side stream BESIDE the a^n | x^n launch: only where that launch leaves the second wave slot of
 // the SIMDs free (one wave per SIMD or less) or the side launch is a few dozen waves
 inline bool extract_beside(size_t nb_statements, size_t nb_instances, size_t lt) {

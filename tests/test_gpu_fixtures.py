@@ -130,11 +130,15 @@ def test_ddleq_2048_secpar16_from_the_64_instance_fixture(ctx, keys):
     # window tables are number-major (VM_STORET / VM_MULVT); nm4 = 0: the same ladders on limb-major tables (VM_MULV)
     # early = 0: the response is prepared after the hash for the instances with challenge bit 1 (default: for every statement and
     # instance beside the Alpha ladders, gathered afterwards)
-    for lanes_wanted, side, nm4, early in ((0, 1, 1, 1), (1, 1, 1, 1), (1, 1, 0, 1), (0, 0, 1, 1), (0, 1, 1, 0), (1, 0, 1, 0)):
+    # struct = 0: the sanity values and Alpha by ladders on ct1 itself (pow_n3_crt) instead of through the structure of the unit
+    # group (struct_pow_n3: plaintext of ct1, ladders modulo the primes, Teichmueller lift)
+    for lanes_wanted, side, nm4, early, struct in ((0, 1, 1, 1, 1), (1, 1, 1, 1, 1), (1, 1, 0, 1, 1), (0, 0, 1, 1, 1), (0, 1, 1, 0, 1),
+                                                    (1, 0, 1, 0, 1), (0, 1, 1, 1, 0), (1, 1, 1, 1, 0), (1, 1, 0, 1, 0), (0, 0, 1, 0, 0)):
         ctx.set_flag("lanes_wanted", lanes_wanted)
         ctx.set_flag("side", side)
         ctx.set_flag("nm4", nm4)
         ctx.set_flag("early", early)
+        ctx.set_flag("struct", struct)
         try:
             al, es, fs = sk.ProveDDLEQBatch(16, col("ct1"), col("ct2"), col("a"), col("b"), xs, ys)
         finally:
@@ -142,8 +146,9 @@ def test_ddleq_2048_secpar16_from_the_64_instance_fixture(ctx, keys):
             ctx.set_flag("side", 1)
             ctx.set_flag("nm4", 1)
             ctx.set_flag("early", 1)
+            ctx.set_flag("struct", 1)
         for j in range(4):
-            assert _digests(al[j], es[j], fs[j]) == [i["digest"] for i in by[j]], (lanes_wanted, side, nm4, early, j)
+            assert _digests(al[j], es[j], fs[j]) == [i["digest"] for i in by[j]], (lanes_wanted, side, nm4, early, struct, j)
 
 
 def test_ddleq_2048_kernels_off(ctx, keys):
@@ -183,11 +188,13 @@ def test_ddleq_2048_prover_with_the_p_adic_split_forced(ctx, keys):
     for lanes_wanted, lift in ((1, 1), (4096, 1), (1, 0)):
         ctx.set_flag("lanes_wanted", lanes_wanted)
         ctx.set_flag("lift", lift)
+        ctx.set_flag("struct", 0)         # (the ladders on ct1 itself: the default takes the structure path for Alpha)
         try:
             al, es, fs = sk.ProveDDLEQInstancesBatch(col("ct1"), col("ct2"), col("a"), col("b"), xs, ys)
         finally:
             ctx.set_flag("lanes_wanted", 0)
             ctx.set_flag("lift", 1)
+            ctx.set_flag("struct", 1)
         dg = [hashlib.sha256(a.to_bytes(768, "big") + e.to_bytes(512, "big") + f.to_bytes(768, "big")).hexdigest()
               for a, e, f in zip(al, es, fs)]
         assert dg == want, (lanes_wanted, lift)

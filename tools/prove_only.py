@@ -15,7 +15,7 @@ n = p * q
 dev = torch.device("cuda", 0)
 ctx = pa.Context(0, torch.cuda.current_stream().cuda_stream)
 pk = pa.PublicKey(ctx, n); sk = pa.SecretKey(ctx, pk, (p - 1) * (q - 1))
-for flag in ("early", "side", "nm4", "handover"):                            # PROVE_EARLY=0 etc.: A/B runs of the prover's switches
+for flag in ("early", "side", "nm4", "handover", "struct"):                            # PROVE_EARLY=0 etc.: A/B runs of the prover's switches
     if os.environ.get("PROVE_" + flag.upper()) is not None:
         ctx.set_flag(flag, int(os.environ["PROVE_" + flag.upper()]))
 SP = int(sys.argv[2]) if len(sys.argv) > 2 else 1
@@ -43,7 +43,7 @@ m3.mul_raw(B, t3.data_ptr(), 768, bn2.data_ptr(), 768, ct2.data_ptr(), 768, MEM_
 al = torch.zeros((BI, 768), dtype=torch.uint8, device=dev); pe = torch.zeros((BI, 512), dtype=torch.uint8, device=dev); pf = torch.zeros((BI, 768), dtype=torch.uint8, device=dev)
 torch.cuda.synchronize()
 print("PROVE_BEGIN", flush=True)
-for _ in range(2):
+for _ in range(int(os.environ.get("PROVE_REPS", "2"))):
     t = time.perf_counter()
     if SP == 1:
         sk.ddleq_prove_raw(B, ct1.data_ptr(), ct2.data_ptr(), da.data_ptr(), db.data_ptr(), dx.data_ptr(), dy.data_ptr(), al.data_ptr(), pe.data_ptr(), pf.data_ptr(), MEM_DEVICE)
