@@ -362,6 +362,11 @@ void teichmueller_lift(const pgpu_seckey* sk, uint32_t* const t[2], size_t nb, i
   Fork f2(ctx);
   for (int half = 0; half < 2; ++half) {
     f2.chain(half);
+    {                                                    // a t that is a multiple of the prime has no lift: flag the lane
+      int32_t* zf = ctx->ws_t<int32_t>(nb);
+      launch_is_zero(t[half], H, nb, zf, ctx->stream);
+      launch_or_flags(zf, nb, d_status, PGPU_LANE_NONUNIT, ctx->stream);
+    }
     tz[half] = zext(ctx, t[half], H, W, nb);
     triple_enter(ctx, half ? mq3 : mp3, tz[half], half ? tq : tp, 0);
   }
@@ -387,8 +392,9 @@ void teichmueller_lift(const pgpu_seckey* sk, uint32_t* const t[2], size_t nb, i
     triple_exit(ctx, m3, half ? tq : tp, 3, w, nullptr);
     uint32_t* v2 = ctx->ws_t<uint32_t>(S2 * 2);                          // slots (P2 limbs): 0 a, 1 z a
     uint32_t* tb = ctx->ws_t<uint32_t>(S);
-    launch_div_exact(w, W, 1, nullptr, 0, tb, (half ? sk->qinv2k_2 : sk->pinv2k_2).d, m1.d_nmod, H, v2, P2, nb, nb, d_status,
-                     PGPU_LANE_NONUNIT, ctx->stream);
+    // (t^(pr-1) = 1 modulo pr for every unit t: the division is exact and needs no check -- the non-units are the t = 0, flagged above)
+    launch_div_exact(w, W, 1, nullptr, 0, tb, (half ? sk->qinv2k_2 : sk->pinv2k_2).d, m1.d_nmod, H, v2, P2, nb, nb, nullptr, 0,
+                     ctx->stream);
     {
       Prog a;
       a.op(VM_LOAD, 0); a.op(VM_MULC, (uint32_t)(half ? sk->c_lz_q2 : sk->c_lz_p2)); a.op(VM_STORE, 1); a.end();
@@ -432,11 +438,17 @@ bool struct_pow_usable(const pgpu_seckey* sk) {
 }
 // per statement: m = Decrypt_2(ct) through p^3, q^3 and ct modulo the primes.  ct: WT(n^3) limbs, stride nbs; d_status (nbs
 // entries, zeroed by the caller) receives PGPU_LANE_NONUNIT for the first `count` statements
-void struct_base(const pgpu_seckey* sk, const uint32_t* ct, size_t nbs, size_t count, int32_t* d_status, StructBase& sb) {
+// (two steps: the residues feed the ladders modulo the primes, the plaintext only the closed form at the very end -- a caller
+// with streams to spare lets the second run beside those ladders)
+void struct_base_plaintext(const pgpu_seckey* sk, const uint32_t* ct, size_t nbs, size_t count, int32_t* d_status, StructBase& sb) {
+  pgpu_ctx* ctx = sk->ctx;
+  sb.nbs = nbs;
+  sb.m = decrypt2_crt(sk, zext(ctx, ct, sk->pk->mn3->WT, 2 * sk->mp3.WT, nbs), nbs, count, d_status);
+}
+void struct_base_residues(const pgpu_seckey* sk, const uint32_t* ct, size_t nbs, StructBase& sb) {
   pgpu_ctx* ctx = sk->ctx;
   const int W3 = sk->pk->mn3->WT, W = sk->mp3.WT, H = sk->mp.WT;
   sb.nbs = nbs;
-  sb.m = decrypt2_crt(sk, zext(ctx, ct, W3, 2 * W, nbs), nbs, count, d_status);
   for (int half = 0; half < 2; ++half) {
     uint32_t* r3 = ctx->ws_t<uint32_t>((size_t)W * nbs);
     reduce_mod(ctx, half ? sk->mq3 : sk->mp3, ct, W3, r3, nbs);
@@ -449,7 +461,8 @@ void struct_base(const pgpu_seckey* sk, const uint32_t* ct, size_t nbs, size_t c
 // y: mn.WT limbs, out: WT(n^3) limbs, all stride nb.  d_status (nb entries, zeroed by the caller) is flagged where the lift met a
 // non-unit.
 void struct_pow_n3(const pgpu_seckey* sk, const StructBase& sb, const uint32_t* sti, const uint32_t* e, const uint32_t* y, size_t nb,
-                   uint32_t* out, int32_t* d_status) {
+                   uint32_t* out, int32_t* d_status, hipEvent_t plaintext_ready = nullptr) {
+  // plaintext_ready: sb.m is still being computed on another stream of the context; only the lane of the closed form waits for it
   pgpu_ctx* ctx = sk->ctx;
   const pgpu_pubkey* pk = sk->pk;
   const ModCtx &mn = pk->mn, &mn2 = pk->mn2, &mn3 = *pk->mn3, &mp3 = sk->mp3, &mq3 = sk->mq3;
@@ -466,6 +479,7 @@ void struct_pow_n3(const pgpu_seckey* sk, const StructBase& sb, const uint32_t* 
   uint32_t* G = ctx->ws_t<uint32_t>((size_t)W3 * nb);
   SideStream g_lane(ctx, 2);
   g_lane.enter(g_lane.mark());
+  if (plaintext_ready) HIPCHK(hipStreamWaitEvent(ctx->stream, plaintext_ready, 0));
   {
     uint32_t* kk = ctx->ws_t<uint32_t>((size_t)W2 * nb);
     modmul_arrays(ctx, mn2, per_number(sb.m, W2), e, nb, kk);
@@ -1239,21 +1253,31 @@ static void ddleq_prove_impl(const pgpu_seckey* sk, size_t S, size_t secpar, con
     // (A side launch of a few dozen waves -- the statements of a secpar-40 call -- costs the big launch next to nothing.)
     const bool s_beside = plan::extract_beside(nbs, nb, plan::lanes_target(ctx->lanes_wanted));
     // The structure path's per-statement part (struct_pow_n3 below) -- the level-two plaintext of ct1 through p^3, q^3 and ct1 modulo
-    // the primes -- depends on the inputs only: it runs beside the a^n | x^n launch (one lane per number: one wave per SIMD at
-    // 16 384 instances; the decryption's digit kernel fills the other wave slots), and the main stream waits for it -- not for s,
-    // which has the side stream to itself -- before the ladders modulo the primes.
+    // the primes -- depends on the inputs only: it is issued beside the a^n | x^n launch on a lane of its own (s has the side
+    // stream), and runs where wave slots are free: beside that launch at 16 384 instances (one lane per number: one wave per SIMD),
+    // beside the ladders modulo the primes otherwise.
     const size_t nt = nbs + nb;
     int32_t *d_st_stmt = nullptr, *d_st_num = nullptr;
     const bool by_struct = crt3 && struct_pow_usable(sk);
     StructBase sbase;
     SideStream base_lane(ctx, 3);      // (a lane of its own: s keeps the side stream, beside the same launch)
+    hipEvent_t residues_ready = nullptr, plaintext_ready = nullptr;
     if (by_struct) {
       d_st_stmt = ctx->ws_t<int32_t>(nbs);
       d_st_num = ctx->ws_t<int32_t>(nt);
       base_lane.enter(inputs_ready);
       HIPCHK(hipMemsetAsync(d_st_stmt, 0, nbs * 4, ctx->stream));
       HIPCHK(hipMemsetAsync(d_st_num, 0, nt * 4, ctx->stream));
-      struct_base(sk, c1s, nbs, S, d_st_stmt, sbase);
+      struct_base_residues(sk, c1s, nbs, sbase);
+      if (base_lane.on) {
+        residues_ready = ctx->next_sync_ev();
+        HIPCHK(hipEventRecord(residues_ready, ctx->stream));
+      }
+      struct_base_plaintext(sk, c1s, nbs, S, d_st_stmt, sbase);
+      if (base_lane.on) {
+        plaintext_ready = ctx->next_sync_ev();
+        HIPCHK(hipEventRecord(plaintext_ready, ctx->stream));
+      }
       base_lane.leave();
     }
     if (s_beside) side.enter(inputs_ready);
@@ -1293,7 +1317,9 @@ static void ddleq_prove_impl(const pgpu_seckey* sk, size_t S, size_t secpar, con
     // number a ladder modulo the primes and ONE lift modulo p^3, q^3.  Lanes that meet a non-unit are flagged; if a REAL lane is
     // (never for honest inputs) the literal ladders redo the launch after the host has seen the flags (below).
     if (by_struct) {
-      base_lane.join();                                      // the main stream waits for the per-statement part (not for s)
+      // the main stream waits for ct1 modulo the primes only; the decryption (a latency-bound launch when the statements are few) goes
+      // on beside the ladders modulo the primes, and the lane of the closed form waits for it
+      if (residues_ready) HIPCHK(hipStreamWaitEvent(ctx->stream, residues_ready, 0));
       std::vector<uint32_t> sv(nt, 0);                       // statement of every number: the sanity values | the instances
       for (size_t g = 0; g < S; ++g) sv[g] = (uint32_t)g;
       for (size_t i = 0; i < batch; ++i) sv[nbs + i] = (uint32_t)(i / secpar);
@@ -1301,7 +1327,8 @@ static void ddleq_prove_impl(const pgpu_seckey* sk, size_t S, size_t secpar, con
       uint32_t* ee2 = concat_ab(ctx, an, nbs, xn, nb, W2);
       uint32_t* by2 = concat_ab(ctx, bl, nbs, yl, nb, W1);
       uint32_t* o2 = ctx->ws_t<uint32_t>((size_t)W3 * nt);
-      struct_pow_n3(sk, sbase, d_sv, ee2, by2, nt, o2, d_st_num);
+      struct_pow_n3(sk, sbase, d_sv, ee2, by2, nt, o2, d_st_num, plaintext_ready);
+      base_lane.join();
       split_ab(ctx, o2, nbs, nb, 0, W3, san);
       split_ab(ctx, o2, nbs, nb, 1, W3, alp);
     } else if (crt3) {
