@@ -35,6 +35,7 @@ int pgpu_pair_debug_run(pgpu_ctx* ctx, const uint8_t* p_be, size_t p_len, int la
  *   "crt3_ladder"         (nb, H, wt3, lanes_wanted, per_number, prereq) -> triple, win, nm5, split
  *   "crt3_two"            (nb, H, lanes_wanted, prereq)            -> usable, split
  *   "early_response_ok"   (nb_instances, H)                        -> ok
+ *   "response_by_structure" (statements, instances, nb_instances, lanes_wanted) -> ok
  *   "extract_beside"      (nb_statements, nb_instances, lanes_wanted) -> ok
  *   "pair_lanes_shared"   (numbers, lanes_wanted, have4, have8)    -> lanes
  *   "pair_lanes_2or4"     (numbers, lanes_wanted, have4)           -> lanes

@@ -1380,7 +1380,7 @@ static void ddleq_prove_impl(const pgpu_seckey* sk, size_t S, size_t secpar, con
       // From a few instances per statement on, the response goes through the structure of the unit group (struct_response): the
       // per-statement part -- the level-two "plaintexts" of s and b, s and b modulo the primes -- and every instance's exponents
       // are made here as well.
-      resp_struct = by_struct && one_ladder && sb_units && plan::response_by_structure(S, batch);
+      resp_struct = by_struct && one_ladder && sb_units && plan::response_by_structure(S, batch, nb, plan::lanes_target(ctx->lanes_wanted));
       const bool early_cond = one_ladder && sb_units && ctx->use_early && pre_bases_usable(sk) &&
                               plan::early_response_ok(nb, sk->mp3.triple.root->WT);
       if (resp_struct || early_cond) {

@@ -116,7 +116,12 @@ inline Crt3Two crt3_two(size_t nb, int H, size_t lt, bool prereq) {
 inline bool early_response_ok(size_t nb_instances, int H) { return triple_window_bits(nb_instances, H) == 7; }
 // the response through the structure of the unit group costs two level-two decryptions PER STATEMENT (of s and of b) and saves
 // more than half of every bit-1 instance's ladder: from four instances per statement
-inline bool response_by_structure(size_t statements, size_t instances) { return instances >= 4 * statements; }
+// ... and for batches so small that the chip is mostly idle (up to 4 096 instances; at 8 192 it measured slower: 101 against
+// 96 ms): there the extra decryptions run beside the other launches for free and the response's latency -- one ladder of 3 071
+// squarings modulo p^3 -- becomes one ladder modulo the primes plus one lift of 1 023
+inline bool response_by_structure(size_t statements, size_t instances, size_t nb_instances = 0, size_t lt = kChipLanes) {
+  return instances >= 4 * statements || (nb_instances != 0 && nb_instances * 16 <= lt);
+}
 // s = ExtractRandonness on the side stream BESIDE the a^n | x^n launch: only where that launch leaves the second wave slot of
 // the SIMDs free (one wave per SIMD or less) or the side launch is a few dozen waves
 inline bool extract_beside(size_t nb_statements, size_t nb_instances, size_t lt) {

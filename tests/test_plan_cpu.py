@@ -114,6 +114,18 @@ def test_early_response_only_where_its_kernels_are_certain(q):
     assert q("early_response_ok", 98304, H37) == [0]
 
 
+def test_response_through_the_structure_of_the_unit_group(q):
+    """From four instances per statement (the per-statement decryptions of s and b amortise), and for batches so small that the
+    chip is mostly idle (the response's latency: one ladder modulo the primes + one lift instead of 3 071 squarings modulo p^3)."""
+    assert q("response_by_structure", 1536, 61440, 61440, 0) == [1]          # BENCH ddleq_prove_2048_secpar40
+    assert q("response_by_structure", 16384, 16384, 16384, 0) == [0]         # BENCH ddleq_prove_2048 (secpar 1)
+    assert q("response_by_structure", 4, 16, 256, 0) == [1] and q("response_by_structure", 5, 15, 256, 0) == [1]
+    assert q("response_by_structure", 2048, 2048, 2048, 0) == [1]            # a rank's 2 048 instances at N = 8
+    assert q("response_by_structure", 4096, 4096, 4096, 0) == [1] and q("response_by_structure", 4352, 4352, 4352, 0) == [0]
+    assert q("response_by_structure", 8192, 8192, 8192, 0) == [0]
+    assert q("response_by_structure", 16384, 49152, 49152, 0) == [0] and q("response_by_structure", 16384, 65536, 65536, 0) == [1]
+
+
 def test_extract_randomness_beside_the_first_launch(q):
     assert q("extract_beside", 16384, 16384, 0) == [1]       # secpar 1 x 16 384: the a^n | x^n launch is one wave per SIMD
     assert q("extract_beside", 1536, 61440, 0) == [1]        # secpar 40: the side launch is a few dozen waves
