@@ -90,7 +90,10 @@ int pgpu_ctx_last_profile(pgpu_ctx* ctx, double* vm_ms, int* vm_launches, double
  * (default 1): the DDLEQ prover prepares its response for every statement and instance beside the Alpha ladders and gathers it
  * for the instances whose challenge bit is 1 (0: prepared after the hash, for those instances only); "handover" (default 1): a
  * power modulo n^2 that the next ladder modulo n^3 needs modulo n^2 only goes from the pair kernel to the digit kernel as
- * (a0, a1, 0) without leaving Montgomery / pair form (0: exit and re-entry).
+ * (a0, a1, 0) without leaving Montgomery / pair form (0: exit and re-entry); "struct" (default 1): the DDLEQ prover computes
+ * ct1^e y^(n^2) mod n^3 (sanity value, Alpha) -- and from four instances per statement its response -- through the structure of the
+ * unit group: the level-two plaintext of ct1 once per statement, ladders modulo the primes, one Teichmueller lift per number (0:
+ * ladders on ct1 itself; non-unit inputs always take those).
  * All of these change the work done, never a result (the tests switch them off to compare).
  * "lanes_wanted" (default 0 = fill the chip): the lane count below which a batch is re-sliced over more lanes per
  * number; 1 keeps every modulus on its natural kernel shape whatever the batch size (tests).
