@@ -270,6 +270,11 @@ def main():
     except OSError:
         PLAN = {"per_unit": {}, "tolerance": 0.01}
     plan_dev = {}
+    try:
+        with open(os.path.join(ROOT, "profiles", "r04_rank_floor.json")) as f:
+            RANK_FLOOR = json.load(f)
+    except OSError:
+        RANK_FLOOR = {}
 
     def plan_check(name, mads_per_unit, applies=True):
         """fraction by which this run's executed multiply-adds per unit differ from the committed table (None: not comparable)"""
@@ -379,11 +384,23 @@ def main():
             e["frac_of_call_time"] = mads / dt / PEAK_MAD_PER_S
         if world > 1:
             e.update({"scaling": scaling, "n_gpus": world})
+            # a strong-scaled entry's rank runs a SMALL shard: what that shard takes on one GPU (measured, profiles/r04_rank_floor.json)
+            fl = RANK_FLOOR.get(name, {}).get(str(world))
+            if scaling == "strong" and fl:
+                e["predicted_rank_floor_ms"] = fl
+                e["predicted_rank_floor_note"] = RANK_FLOOR[name].get("unit", "")
         # rank 0's executed multiply-adds per unit of ITS share against the committed plan table (weak-scaled configs keep their
         # per-rank shape on every N; a strong-scaled config's per-rank shape -- and plan -- changes with N: checked at N = 1 only)
         units_rank0 = count / world
         e["executed_mad28_per_unit"] = mads / units_rank0 if units_rank0 else None
         e["plan_deviation"] = plan_check(name, e["executed_mad28_per_unit"], applies=(world == 1 or scaling == "weak"))
+        # a config whose algorithm needs fewer multiplies than the ladders of the reference's formula (the prover through the
+        # structure of the unit group): its `frac` prices only what it executes; the rate in units of the LITERAL algorithm's
+        # multiplies says what the saving is worth (above the executed fraction: that much work is simply not done)
+        lit = PLAN.get("literal_per_unit", {}).get(name)
+        if lit and world == 1:
+            e["literal_algorithm"] = {"mad28_per_unit": lit, "equivalent_frac_of_call_time": lit * count / dt / PEAK_MAD_PER_S,
+                                      "multiplies_saved": 1.0 - e["executed_mad28_per_unit"] / lit}
         return e
 
     def all_ranks_ok(flag, what):
