@@ -347,10 +347,12 @@ void garner_n3(const pgpu_seckey* sk, const uint32_t* xp, const uint32_t* xq, si
 // form of (1 + n)^k, ONE interleaved ladder of 1 036 squarings modulo p (and q: 37-limb numbers), ONE ladder of 1 023 squarings
 // modulo p^3 (and q^3) for t^(p-1), Garner -- 16 M multiply-adds per number and half where the p-adic split of pow_n3_crt needs
 // 2 047 squarings modulo p^2 plus 1 024 modulo p^3: 26 M.  The same integers for every unit ct, y; a lane whose ct or y is not a
-// unit fails an exact division (d_status / the statement flags) and the caller falls back to the literal ladders.
+// unit is flagged (the decryption's exact division per statement, the lift's zero test per number) and the caller falls back to the
+// literal ladders.
+
 // omega(t) = t^(n^2) mod n^3 from t modulo the primes: t[half] = canonical residues modulo p / q (mp.WT limbs, stride nb).  Modulo
 // pr^3 the lift is t (t^(pr-1))^z, z = -(pr - 1)^-1 in Z_pr: w = t^(pr-1) on the digit kernel (the ladder of the level-two
-// decryption, both halves in one launch), a = (w - 1) / pr (exact for every unit t: lanes where it is not are flagged in d_status),
+// decryption, both halves in one launch), a = (w - 1) / pr (exact for every unit t; a t that is 0 modulo the prime is flagged in d_status),
 // (1 + pr a)^z = 1 + pr (z a mod pr^2) + pr^2 (C(z,2) a^2 mod pr); then Garner.  T: WT(n^3) limbs, stride nb.
 void teichmueller_lift(const pgpu_seckey* sk, uint32_t* const t[2], size_t nb, int32_t* d_status, uint32_t* T) {
   pgpu_ctx* ctx = sk->ctx;
