@@ -1,4 +1,4 @@
-// kernels.h -- launch interface between capi.cpp (host orchestration) and kernels.hip.
+// kernels.h -- launch interface between the host translation units (engine.hpp: orchestration) and kernels.hip.
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>

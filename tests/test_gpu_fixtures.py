@@ -175,7 +175,7 @@ def test_ddleq_2048_kernels_off(ctx, keys):
 
 def test_ddleq_2048_prover_with_the_p_adic_split_forced(ctx, keys):
     """A batch that fills the chip makes the prover split its ladders modulo p^3, q^3 by the base-p digits of the (reduced)
-    exponents: x^(r0 + r1 p) = (x^(r1) mod p^2)^p x^(r0) (capi.cpp pow_n3_crt / pow_p2_multi_crt).  lanes_wanted = 1 forces that
+    exponents: x^(r0 + r1 p) = (x^(r1) mod p^2)^p x^(r0) (ddleq.cpp pow_n3_crt / pow_p2_multi_crt).  lanes_wanted = 1 forces that
     path -- one lane per number modulo p^2 -- for the 64 fixture instances; lanes_wanted = 4096 its two-lane variant; with
     the lift off the unsplit ladders run.  All must land on the committed Alpha / E / F."""
     pk, sk = keys

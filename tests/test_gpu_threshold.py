@@ -152,7 +152,7 @@ def test_partial_decrypt_multi_servers(ctx, bits):
 @pytest.mark.parametrize("lanes_wanted,nshares", [(1, 3), (4096, 5), (1, 2)])
 def test_partial_decrypt_multi_shares_one_chain_of_squarings(ctx, lanes_wanted, nshares):
     """A batch that fills the chip takes pgpu_partial_decrypt_multi's shared chain: right-to-left sliding windows into Yao
-    buckets, ONE chain of squarings for all the shares (capi.cpp emit_multi_exp_shared_base).  Forced here for a small batch
+    buckets, ONE chain of squarings for all the shares (vm_emit.cpp emit_multi_exp_shared_base).  Forced here for a small batch
     (lanes_wanted = 1: the two-lane pair kernel; 4096: the four-lane one) and compared with c^(2 Delta s_i) mod n^2
     (thresholdkey.go:192-201) from Python and with the separate ladders (flag off)."""
     import numpy as np

@@ -159,7 +159,7 @@ def test_ddleq_verify_2048_on_and_off(ctx):
 
 def test_split_through_n_squared_on_and_off(ctx):
     """NestedRandomize and the DDLEQ verifier compute x^e y^(n^2) mod n^3 as (x^(e1) y^n mod n^2)^n x^(e0), e = e0 + e1 n
-    (capi.cpp dual_pow_n3).  With pgpu_ctx_set_flag("lift", 0) the literal interleaved ladder of 4 096 squarings runs: same
+    (ddleq.cpp dual_pow_n3).  With pgpu_ctx_set_flag("lift", 0) the literal interleaved ladder of 4 096 squarings runs: same
     integers, same verdicts, and both equal the committed 2048-bit fixtures / pow()."""
     import paillier_amd as pa
     H_ = lambda xs: [int(x, 16) for x in xs]
