@@ -656,7 +656,13 @@ def main():
             note()
             return o
 
+        shard_mode = pdist.threshold_shard_mode(BT, world)
+
         def tstep():
+            # every rank of this bench holds all t shares: while a rank keeps >= 4 096 ciphertexts it takes a ciphertext slice under
+            # all of them (one chain of squarings per ciphertext, no exchange); below that, (server, ciphertext) unit ranges
+            if shard_mode == "ciphertext":
+                return pdist.threshold_decrypt_ciphertext_major(tc, len(ids), rank, world, range_fn, combine_fn)
             # one launch per rank once a rank's share of a server falls below what fills the chip on its own
             return pdist.threshold_decrypt_sharded(tc, len(ids), rank, world, partial_fn, combine_fn,
                                                    units_fn=units_fn if (len(ids) * BT) // world < 32768 else None,
@@ -674,13 +680,15 @@ def main():
         if not tok:
             raise SystemExit("[bench] threshold decryption: Combine(PartialDecrypt x 3) != m on some rank")
         e = entry("threshold_2048", f"t=3 of l=5, servers {ids}, 16384 ciphertexts per step, 2048-bit safe-prime key: 3 x "
-                  f"PartialDecrypt + CombinePartialDecryptions; (server, ciphertext) units sharded over {world} rank(s), "
-                  f"all-gather of the partials" + ((" over gloo (rehearsal)" if args.rehearse_one_gpu else " over RCCL") if world > 1
-                                                  else " (single rank: no exchange)") +
+                  f"PartialDecrypt + CombinePartialDecryptions; " +
+                  (f"ciphertext slices over {world} ranks that hold every share (one chain of squarings per ciphertext, no exchange)"
+                   if shard_mode == "ciphertext" else
+                   f"(server, ciphertext) units sharded over {world} rank(s), all-gather of the partials" +
+                   ((" over gloo (rehearsal)" if args.rehearse_one_gpu else " over RCCL") if world > 1 else " (single rank: no exchange)")) +
                   ", local combine", "threshold decryptions/s", BT, tel / args.extra_steps,
                   acc["ms"] / args.extra_steps, acc["mads"] / args.extra_steps, acc["kern"],
                   "all 16384 plaintexts recovered on every rank", scaling="strong")
-        e.update({"scaling": "strong", "n_gpus": world, "exchange_bytes_per_step": len(ids) * BT * 512 if world > 1 else 0,
+        e.update({"scaling": "strong", "n_gpus": world, "shard": shard_mode, "exchange_bytes_per_step": len(ids) * BT * 512 if (world > 1 and shard_mode == "units") else 0,
                   "kernel_ms_note": "rank 0's share of the step"})
         extras.append(e)
         if world == 1:

@@ -37,6 +37,8 @@ int pgpu_pair_debug_run(pgpu_ctx* ctx, const uint8_t* p_be, size_t p_len, int la
  *   "early_response_ok"   (nb_instances, H)                        -> ok
  *   "response_by_structure" (statements, instances, nb_instances, lanes_wanted) -> ok
  *   "extract_beside"      (nb_statements, nb_instances, lanes_wanted) -> ok
+ *   "shared_chain_groups" (nb_ciphertexts, n_shares, lanes_wanted, have_eight_lane_kernel) -> groups of shares with a chain of squarings each
+ *   "exclusive_cus"       (nb_statements, nb_instances, lanes_wanted) -> ok   (a compute unit per workgroup for the call's concurrent launches)
  *   "pair_lanes_shared"   (numbers, lanes_wanted, have4, have8)    -> lanes
  *   "pair_lanes_2or4"     (numbers, lanes_wanted, have4)           -> lanes
  *   "crt_pair_lanes"      (key_lanes, have_two_lane_variant, nb, lanes_wanted) -> lanes, usable (for 37-limb primes)

@@ -32,6 +32,8 @@ class PaillierHipError(RuntimeError):
 
 
 def library_path() -> str:
+    if os.environ.get("PGPU_LIBRARY"):            # an alternative build of the same sources (A/B measurements: tools/)
+        return os.environ["PGPU_LIBRARY"]
     return os.path.join(os.path.dirname(os.path.abspath(__file__)), "libpaillier_hip.so")
 
 

@@ -11,7 +11,8 @@ namespace {
 struct Blob { int wl, k; const unsigned char* data; size_t size; const char* name; };
 #include "vm_asm_blobs.inc"   // defines: static const Blob kBlobs[]; static const int kNumBlobs;
 
-struct Loaded { hipModule_t mod = nullptr; hipFunction_t fn = nullptr; bool tried = false; hipError_t err = hipSuccess; };
+struct Loaded { hipModule_t mod = nullptr; hipFunction_t fn = nullptr; bool tried = false; hipError_t err = hipSuccess; int lds_static = -1; };
+constexpr int kLdsPerCU = 160 * 1024;
 constexpr int kMaxDevices = 16;
 constexpr int kMaxBlobs = 64;
 static_assert(kNumBlobs <= kMaxBlobs, "g_loaded is indexed by blob: raise kMaxBlobs when gen_vm_asm.SHAPES grows");
@@ -27,7 +28,7 @@ int find_blob(int wl, int k) {
 
 bool vm_asm_available(int wl, int k) { return find_blob(wl, k) >= 0; }
 
-hipError_t launch_vm_asm(int wl, int k, const VmArgs& a, uint32_t blocks, hipStream_t st) {
+hipError_t launch_vm_asm(int wl, int k, const VmArgs& a, uint32_t blocks, hipStream_t st, bool exclusive) {
   int i = find_blob(wl, k);
   if (i < 0) return hipErrorInvalidValue;
   int dev = 0;
@@ -42,11 +43,15 @@ hipError_t launch_vm_asm(int wl, int k, const VmArgs& a, uint32_t blocks, hipStr
       hipError_t e = hipModuleLoadData(&L.mod, kBlobs[i].data);
       if (e == hipSuccess) e = hipModuleGetFunction(&L.fn, L.mod, kBlobs[i].name);
       if (e != hipSuccess) { L.fn = nullptr; L.err = e; }
+      int v = 0;
+      if (L.fn && hipFuncGetAttribute(&v, HIP_FUNC_ATTRIBUTE_SHARED_SIZE_BYTES, L.fn) == hipSuccess && v >= 0 && v <= kLdsPerCU) L.lds_static = v;
     }
     if (!L.fn) return L.err != hipSuccess ? L.err : hipErrorInvalidValue;   // the first load error, every time
   }
   VmArgs args = a;
   size_t size = sizeof(VmArgs);
   void* extra[] = {HIP_LAUNCH_PARAM_BUFFER_POINTER, &args, HIP_LAUNCH_PARAM_BUFFER_SIZE, &size, HIP_LAUNCH_PARAM_END};
-  return hipModuleLaunchKernel(g_loaded[i][dev].fn, blocks, 1, 1, VM_BLOCK, 1, 1, 0, st, nullptr, extra);
+  const Loaded& L = g_loaded[i][dev];
+  const unsigned dyn = exclusive && L.lds_static >= 0 ? (unsigned)(kLdsPerCU - L.lds_static) : 0u;
+  return hipModuleLaunchKernel(L.fn, blocks, 1, 1, VM_BLOCK, 1, 1, dyn, st, nullptr, extra);
 }

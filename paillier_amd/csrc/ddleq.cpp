@@ -1,5 +1,6 @@
 // ddleq.cpp -- NestedRandomize (operations.go:96-118), the DDLEQ proofs (ddleq.go:27-153) and RandomOracleDigest
 // (random_oracle.go:10-32): interleaved ladders modulo n^3, the key holder's halves modulo p^3 / q^3, the prover.
+#include <chrono>
 #include "engine.hpp"
 
 extern "C" {
@@ -1194,6 +1195,28 @@ static void ddleq_prove_impl(const pgpu_seckey* sk, size_t S, size_t secpar, con
     };
     const size_t batch = S * secpar;                        // instances
     const size_t nbs = round_up(S, VM_BLOCK), nb = round_up(batch, VM_BLOCK);
+    // PGPU_HOST_TRACE=1 (measurements): when the HOST passed each stage of the call (ms from its start) -- where it waited for the device
+    static const bool host_trace = [] { const char* e = getenv("PGPU_HOST_TRACE"); return e && atoi(e) != 0; }();
+    const auto ht0 = std::chrono::steady_clock::now();
+    std::vector<std::pair<const char*, double>> ht_log;
+    auto HT = [&](const char* what) {
+      if (host_trace) ht_log.emplace_back(what, std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - ht0).count());
+    };
+    struct HtDump {
+      std::vector<std::pair<const char*, double>>& l;
+      ~HtDump() {
+        if (l.empty()) return;
+        fprintf(stderr, "[pgpu] prove host:");
+        for (auto& x : l) fprintf(stderr, " %s %.2f |", x.first, x.second);
+        fprintf(stderr, "\n");
+      }
+    } ht_dump{ht_log};
+    struct ExclusiveCall {
+      pgpu_ctx* c;
+      ExclusiveCall(pgpu_ctx* c_, bool on) : c(c_) { c->exclusive_call = on; }
+      ~ExclusiveCall() { c->exclusive_call = false; }
+    } exclusive_call(ctx, getenv("PGPU_EXCL_FORCE") ? atoi(getenv("PGPU_EXCL_FORCE")) != 0
+                                                    : plan::exclusive_cus(nbs, nb, plan::lanes_target(ctx->lanes_wanted)));
     if (ct_stride != mn3.nbytes) api_throw(PGPU_ERR_INVALID, "ciphertext stride must be the byte length of n^3");
     if (n_stride * 8 > (size_t)LB * W1 + 7) api_throw(PGPU_ERR_INVALID, "a, b, x, y must fit the width of n");
     auto up = [&](const uint8_t* buf, size_t stride, int w, size_t count, size_t nbx) {
@@ -1248,6 +1271,7 @@ static void ddleq_prove_impl(const pgpu_seckey* sk, size_t S, size_t secpar, con
       }
       split_ab(ctx, axn, nbs, nb, 0, W2, an);
       split_ab(ctx, axn, nbs, nb, 1, W2, xn);
+      HT("a^n|x^n issued");
     }
     // Beside the a^n | x^n launch only where that launch leaves the second wave slot of the SIMDs free (one wave per SIMD or
     // less: 16 384 instances at secpar 1): a launch that fills both slots would lose one of them on half the chip to the side
@@ -1299,6 +1323,7 @@ static void ddleq_prove_impl(const pgpu_seckey* sk, size_t S, size_t secpar, con
       }
     }
     if (s_beside) side.leave();
+    HT("s issued");
     hipEvent_t an_ready = side.mark();
     uint32_t* bn2 = ctx->ws_t<uint32_t>((size_t)W3 * nbs);
     uint32_t* t3 = ctx->ws_t<uint32_t>((size_t)W3 * nb);
@@ -1330,6 +1355,7 @@ static void ddleq_prove_impl(const pgpu_seckey* sk, size_t S, size_t secpar, con
       uint32_t* by2 = concat_ab(ctx, bl, nbs, yl, nb, W1);
       uint32_t* o2 = ctx->ws_t<uint32_t>((size_t)W3 * nt);
       struct_pow_n3(sk, sbase, d_sv, ee2, by2, nt, o2, d_st_num, plaintext_ready);
+      HT("alpha issued");
       base_lane.join();
       split_ab(ctx, o2, nbs, nb, 0, W3, san);
       split_ab(ctx, o2, nbs, nb, 1, W3, alp);
@@ -1365,6 +1391,7 @@ static void ddleq_prove_impl(const pgpu_seckey* sk, size_t S, size_t secpar, con
       uint32_t* an1 = ctx->ws_t<uint32_t>((size_t)W2 * nbs);
       launch_restride(an, nbs, S, mn2.d_consts + (size_t)C_ONE * W2, an1, nbs, W2, ctx->stream);
       uint32_t* inv2 = batch_inverse(ctx, mn2, concat2(ctx, a2, an1, W2, nbs), 2 * nbs, 2 * nbs, d_badinv, &any_badinv);
+      HT("inversions");
       split2(ctx, inv2, 0, W2, nbs, qainv);
       split2(ctx, inv2, 1, W2, nbs, qani);
       if (one_ladder) {
@@ -1372,6 +1399,7 @@ static void ddleq_prove_impl(const pgpu_seckey* sk, size_t S, size_t secpar, con
         modmul_arrays(ctx, mn, qs, bl, nbs, sb);
         launch_restride(sb, nbs, S, mn.d_consts + (size_t)C_ONE * W1, sb, nbs, W1, ctx->stream);
         sb_units = all_units(ctx, mn, sb, nbs, S);
+        HT("unit test");
       }
       // The response's per-statement bases (s, b: residues modulo p^3, q^3, p^2, q^2 and digit forms) and, for EVERY instance, its
       // e = x a^-1, e^n = x^n (a^n)^-1 and the two exponents of the one-ladder response modulo the group orders: nothing here
@@ -1405,8 +1433,10 @@ static void ddleq_prove_impl(const pgpu_seckey* sk, size_t S, size_t secpar, con
           d_st_rstmt = ctx->ws_t<int32_t>(nbs);
           HIPCHK(hipMemsetAsync(d_st_rstmt, 0, nbs * 4, ctx->stream));
           resp_base(sk, qs, bl, nbs, S, d_st_rstmt, rbase);
+          HT("resp_base issued");
           en_all = en_a;
           resp_exps(sk, xn, gan_a, en_a, nb, rexps);
+          HT("resp_exps issued");
         } else {
         uint32_t* ls = ctx->ws_t<uint32_t>(nb);
         uint32_t* lb = ctx->ws_t<uint32_t>(nb);
@@ -1450,7 +1480,9 @@ static void ddleq_prove_impl(const pgpu_seckey* sk, size_t S, size_t secpar, con
       HIPCHK(hipMemcpyAsync(hst_stmt.data(), d_st_stmt, S * 4, hipMemcpyDeviceToHost, ctx->stream));
       HIPCHK(hipMemcpyAsync(hst_num.data(), d_st_num, nt * 4, hipMemcpyDeviceToHost, ctx->stream));
     }
+    HT("side issued");
     HIPCHK(hipStreamSynchronize(ctx->stream));
+    HT("alpha known");
     if (by_struct) {
       bool nonunit = false;
       for (size_t g = 0; g < S; ++g) nonunit = nonunit || hst_stmt[g] || hst_num[g];
@@ -1481,6 +1513,7 @@ static void ddleq_prove_impl(const pgpu_seckey* sk, size_t S, size_t secpar, con
     HIPCHK(hipMemcpyAsync(hch.data(), chal, batch * 4, hipMemcpyDeviceToHost, ctx->stream));
     HIPCHK(hipStreamSynchronize(ctx->stream));
     side.join();                                             // the per-statement values are needed from here on
+    HT("hash known");
     // default outputs: e = x, f = y (chalBit false)
     uint32_t* eo = zext(ctx, xl, W1, W2, nb);
     uint32_t* fo = zext(ctx, yl, W1, W3, nb);
@@ -1526,6 +1559,7 @@ static void ddleq_prove_impl(const pgpu_seckey* sk, size_t S, size_t secpar, con
         sti_pad.resize(nbg, 0);                                            // (padding lanes: statement 0's bases)
         uint32_t* c5 = ctx->ws_t<uint32_t>((size_t)W3 * nbg);
         struct_response(sk, rbase, ctx->upload_words(sti_pad), gat(rexps.e1n, W2), gat(en_all, W2), e1p, e2p, nbg, c5, d_st_r);
+        HT("response issued");
         std::vector<int32_t> hr(cnt), hs(S);
         HIPCHK(hipMemcpyAsync(hr.data(), d_st_r, cnt * 4, hipMemcpyDeviceToHost, ctx->stream));
         HIPCHK(hipMemcpyAsync(hs.data(), d_st_rstmt, S * 4, hipMemcpyDeviceToHost, ctx->stream));

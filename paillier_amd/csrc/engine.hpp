@@ -94,6 +94,10 @@ struct pgpu_ctx {
   // per-statement chains run beside its big launches).  pgpu_ctx_set_flag("side", 0): everything on the one stream.
   bool use_nm4 = true;       // per-number 4- / 5-bit window tables of the pair kernels number-major (pgpu_ctx_set_flag("nm4", 0): limb-major, VM_MULV / VM_MULV5)
   bool use_early = true;     // the DDLEQ prover prepares its response for every statement / instance beside the Alpha ladders (pgpu_ctx_set_flag("early", 0): after the hash, for the bit-1 instances)
+  bool use_exclusive = true; // concurrent small launches of one call take a compute unit each (see exclusive_call; pgpu_ctx_set_flag("exclusive", 0): the dispatcher's placement)
+  bool exclusive_call = false;   // set by a protocol function for the length of a call whose concurrent launches together fit the chip's compute units: every
+                                 // workgroup then asks for the whole LDS of a CU, so the dispatcher cannot stack the side lanes' workgroups on the CUs the main
+                                 // launch runs on (it starts every queue's workgroups from the same CUs: 17.5 -> 28 ms for a^n | x^n of 2 048 instances)
   bool use_handover = true;  // a power modulo n^2 that is only needed modulo n^2 by the next ladder modulo n^3 stays in pair form: (a0, a1, 0) is its digit form (pgpu_ctx_set_flag("handover", 0): exit and re-entry)
   bool use_muls = true;      // bucket products of the shared chain as VM_MULS where the kernel has it (pgpu_ctx_set_flag("muls", 0): LOAD / MUL / STORE)
   bool use_struct = true;    // the key holder's ct^e y^(n^2) mod n^3 through the structure of the unit group: plaintext of ct, ladders modulo the primes, Teichmueller lift (pgpu_ctx_set_flag("struct", 0): the ladders on ct itself)

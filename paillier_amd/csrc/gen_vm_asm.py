@@ -27,6 +27,7 @@ Four generators share the VM contract (kernarg block, opcodes, slot layout):
   GenP   N = p^2, p known, 37 limbs: a residue is two base-p digits in ONE lane; a product is two Montgomery steps mod p
   GenQ   N = n^2 (or p^2), root known: the two digits in TWO neighbouring lanes, quotient digits by DPP
 """
+import os
 import sys
 
 LB = 28
@@ -1685,6 +1686,7 @@ class GenP(Gen):
         H = self.H
         row = self.NPB * 4
         m = f"v{g.v_m}"
+        single = getattr(self, "single_digit", False)      # GenM: the modulus is p itself, there is no phase 2
         fresh = set(range(H))
 
         def acc(pos, a, b):
@@ -1702,7 +1704,8 @@ class GenP(Gen):
             if sq:
                 ai = self.X0(i)
                 e(f"v_add_u32 v{g.v_ai}, {ai}, {ai}")
-                e(f"ds_write_b32 v{g.v_awrite}, v{g.v_ai} offset:{i * row}")     # phase 2 multiplies by 2 a0_i
+                if not single:
+                    e(f"ds_write_b32 v{g.v_awrite}, v{g.v_ai} offset:{i * row}")     # phase 2 multiplies by 2 a0_i
                 self.align8()
                 acc(2 * i, ai, ai)
                 for j in range(i + 1, H):
@@ -1717,7 +1720,7 @@ class GenP(Gen):
                     acc(i + j, f"v{cur}", self.X0(j))
             c0 = i % H
             assert c0 not in fresh
-            mi = f"v{g.vM + i}"                      # the quotient digit stays in its own register for phase 2
+            mi = m if single else f"v{g.vM + i}"     # the quotient digit stays in its own register for phase 2
             e(f"v_mul_lo_u32 {mi}, {self.Tlo(c0)}, s14")
             e(f"v_and_b32 {mi}, {hex(MASK)}, {mi}")
             self.align8()
@@ -1833,6 +1836,47 @@ class GenP(Gen):
         for j in range(H):
             e(f"v_mov_b32 {self.X0(j)}, v{g.vA + j}")
         e("s_branch L_next")
+
+    def generate(self):
+        self.prologue()
+        self.dispatcher()
+        self.montmul()
+        self.montsq()
+        self.epilogue()
+        return "\n".join(self.lines) + "\n"
+
+
+class GenM(Gen):
+    """One-lane kernel for an odd number H of limbs with the product fully unrolled (GenP's phase 1 alone: static column
+    renaming instead of the register shift, triangular squaring rows without a computed jump, no LDS traffic in a squaring):
+    the ladders modulo the PRIMES of a 2048-bit key (struct_pow_n3, the s ladder).  Same VM contract, slots and operations as
+    Gen(H, 1) -- only L_montmul / L_montsq differ; a result is congruent to Gen's modulo p and as lazily reduced."""
+
+    def __init__(self, H=37):
+        Gen.__init__(self, H, 1)
+        assert H % 2 == 1 and self.n_sgpr
+        self.H = H
+        self.sq_rows = True
+        self.sq_self_staged = True     # a squaring reads its operand from the registers only
+        self.single_digit = True
+        self.nm4_tables = True
+
+    X0 = GenP.X0
+    Pm = GenP.Pm
+    phase1 = GenP.phase1
+
+    def X1(self, j):
+        raise AssertionError("single digit")
+
+    def montsq(self):
+        self.e("L_montsq:")
+        self.phase1(True, self.X0)
+        self.e("s_branch L_next")
+
+    def montmul(self):
+        self.e("L_montmul:")
+        self.phase1(False, self.X0)      # (b = X is last read by the final row's products; the carry pass comes after them)
+        self.e("s_branch L_next")
 
     def generate(self):
         self.prologue()
@@ -2074,6 +2118,7 @@ class GenP2(GenP):
     def phase1_sq(self):
         g, e, H = self, self.e, self.H
         m = f"v{g.v_m}"
+        single = getattr(self, "single_digit", False)      # GenM: the modulus is p itself, there is no phase 2
         fresh = set(range(H))
 
         def acc(pos, a, b):
@@ -3810,11 +3855,15 @@ def make_gen(wl, k):
         return GenQ3(wl)
     if (wl, k) in WAVE_SLICED:
         return GenW(wl, k)
-    g = Gen(wl, k)
-    # the one-lane 37-limb kernel runs the key holder's ladders modulo the primes of a 2048-bit key with per-number exponents
-    # (struct_pow_n3): number-major window tables there too (a limb-major gather reads one dword per 32-byte sector)
-    g.nm4_tables = (wl, k) == (37, 1)
-    return g
+    if (wl, k) == (37, 1) and os.environ.get("PGPU_GEN_LOOPED37", "0") == "1":      # A/B builds: the looped rows of Gen with the same tables
+        g = Gen(wl, k)
+        g.nm4_tables = True
+        return g
+    if (wl, k) == (37, 1):
+        # the one-lane 37-limb kernel runs the key holder's ladders modulo the primes of a 2048-bit key with per-number exponents
+        # (struct_pow_n3): unrolled products, number-major window tables (a limb-major gather reads one dword per 32-byte sector)
+        return GenM(wl)
+    return Gen(wl, k)
 
 
 if __name__ == "__main__":

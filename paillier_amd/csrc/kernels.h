@@ -47,7 +47,9 @@ struct VmArgs {
 hipError_t launch_vm(int wl, int k, const VmArgs& a, uint32_t blocks, hipStream_t st);
 // hand-scheduled assembly versions (asm_loader.cpp); same arguments, bit-identical results
 bool vm_asm_available(int wl, int k);
-hipError_t launch_vm_asm(int wl, int k, const VmArgs& a, uint32_t blocks, hipStream_t st);
+// exclusive: every workgroup asks for all of a compute unit's LDS (dynamic part on top of the kernel's own), so that no other workgroup that uses LDS
+// shares its CU -- one wave per SIMD for launches that run beside each other (engine.hpp exclusive_call)
+hipError_t launch_vm_asm(int wl, int k, const VmArgs& a, uint32_t blocks, hipStream_t st, bool exclusive = false);
 static_assert(sizeof(VmArgs) == 152, "VmArgs layout is hard-coded in gen_vm_asm.py (select_segment)");
 
 void launch_unpack_be(const uint8_t* in, size_t stride, size_t nbytes, size_t count, uint32_t* out, int wt, size_t nb, hipStream_t st);

@@ -128,4 +128,25 @@ inline bool extract_beside(size_t nb_statements, size_t nb_instances, size_t lt)
   return (nb_statements + nb_instances) * 2 <= lt || nb_statements * 2 * 8 <= lt;
 }
 
+// A ciphertext range wanted under S shares (threshold.cpp, a ciphertext-major shard): ONE shared chain of squarings carries S window
+// products per window on its critical path (4 103 squarings + S x 586 products of 1.5 squarings each for config 4).  Where the chip
+// has room -- eight lanes per number and still a SIMD per wave for every group -- the shares split into up to three groups with a
+// chain each: 4 096 ciphertexts x 3 shares in two groups (2 + 1), 2 048 in three.
+inline int shared_chain_groups(size_t nbs, int S, size_t lt, bool have8) {
+  if (!have8 || S < 2 || nbs == 0) return 1;
+  const size_t room = lt / (nbs * 8);
+  return (int)std::max<size_t>(1, std::min<size_t>(std::min(S, 3), room));
+}
+
+// Launches of one call that run BESIDE each other (main stream + side lanes) take a compute unit per workgroup (the whole LDS of the
+// CU is asked for) where all of them together roughly fit the chip: the dispatcher otherwise starts every queue's workgroups from the
+// same CUs, and three latency-bound launches share the SIMDs of a quarter of the chip while the rest idles.  The prover's widest
+// launch is a^n | x^n: (statements + instances) numbers, two primes, two lanes each at this size (128 workgroups at 4 096 instances);
+// the two side lanes are at most as wide.  Measured (ms per call, dispatcher's placement | a CU per workgroup): 2 048 instances
+// 75.0 | 58.5, 4 096: 79.0 | 69.2, 8 192: 95 | 101 (the launches no longer fit side by side: a second round of workgroups).
+constexpr uint32_t kExclusiveMaxBlocks = 128;
+inline bool exclusive_cus(size_t nb_statements, size_t nb_instances, size_t lt = kChipLanes) {
+  return (nb_statements + nb_instances) * 8 <= lt;
+}
+
 }  // namespace plan

@@ -281,6 +281,25 @@ int pgpu_partial_decrypt_units(const pgpu_pubkey* pk, int total_servers, int n_s
         if (!iv.servers.empty()) ivs.push_back(iv);
       }
     }
+    // One ciphertext range under several shares (a ciphertext-major shard): a single chain would carry every share's window products
+    // on its critical path; where the chip has room the shares split into groups with a chain each (plan::shared_chain_groups)
+    if (ok && ivs.size() == 1 && ivs[0].servers.size() >= 2) {
+      const PairInfo& pi0 = mc.pairn;
+      const int H0 = pi0.root->WT;
+      const bool have8 = H0 % 2 == 0 && vm_asm_available(H0 / 2, 64) && pi0.consts8 && ctx->use_lanes8;
+      const Interval whole = ivs[0];
+      const int groups = plan::shared_chain_groups(round_up(whole.e - whole.b, VM_BLOCK), (int)whole.servers.size(),
+                                                   plan::lanes_target(ctx->lanes_wanted), have8);
+      if (groups > 1) {
+        ivs.clear();
+        const size_t S = whole.servers.size();
+        for (int g = 0; g < groups; ++g) {                 // S = 3 in two groups: {s0}, {s1, s2}
+          Interval iv{whole.b, whole.e, {}};
+          for (size_t j = S * (size_t)g / groups; j < S * (size_t)(g + 1) / groups; ++j) iv.servers.push_back(whole.servers[j]);
+          ivs.push_back(iv);
+        }
+      }
+    }
     if (!ok || ivs.size() > 3) {
       // no pair kernel for this key (or a range no rank of the sharded flow produces): server after server
       for (int k = s_first; k <= s_last; ++k) {

@@ -467,7 +467,9 @@ void run_vm(pgpu_ctx* ctx, size_t nb, const SegSpec& s0, const SegSpec* s1, bool
       if (ss[i] && ss[i]->prog->wide_gathers)   // (an opcode a kernel does not know ends its program: refuse, never compute garbage)
         api_throw(PGPU_ERR_UNSUPPORTED, "internal: the one-lane pair kernel for 55-limb primes has 4-bit per-number windows only");
   if (ev) snprintf(ev->name, sizeof ev->name, use_asm ? "vm_asm_%d_%d" : "vm_kernel<%d,%d>", WL, K);
-  hipError_t e = use_asm ? launch_vm_asm(WL, K, a, blocks, ctx->stream) : launch_vm(WL, K, a, blocks, ctx->stream);
+  // (a launch wider than half the chip's CUs keeps the dispatcher's placement: two of its workgroups per CU beat a second round)
+  const bool exclusive = use_asm && ctx->use_exclusive && ctx->exclusive_call && blocks <= plan::kExclusiveMaxBlocks;
+  hipError_t e = use_asm ? launch_vm_asm(WL, K, a, blocks, ctx->stream, exclusive) : launch_vm(WL, K, a, blocks, ctx->stream);
   if (use_asm) ctx->last_vm_asm++;
   ctx->last_vm_launches++;
   if (e != hipSuccess) throw HipError{e, "launch_vm"};

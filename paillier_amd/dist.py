@@ -124,6 +124,37 @@ def threshold_decrypt_sharded(c, n_servers: int, rank: int, world: int, partial_
     return combine_fn([parts[s, cb:ce].contiguous() for s in range(n_servers)]), (cb, ce)
 
 
+def threshold_shard_mode(n_ciphertexts: int, world: int) -> str:
+    """Which shard of the threshold flow a holder of EVERY share should take.  Measured per rank on one MI355X (t = 3, 2048-bit key,
+    16 384 ciphertexts, tools/threshold_shard_probe.py): unit ranges 81 / 70 / 59 / 36 ms at N = 1 / 2 / 4 / 8 plus the exchange of the
+    partials; ciphertext slices 81 / 49 / 43 / 36 ms and no exchange (the t ladders of a ciphertext share a chain of squarings while
+    the chip is full, and split into chains of their own on the eight-lane kernel as it empties: plan::shared_chain_groups).  So:
+    "ciphertext" whenever there is more than one rank; a single rank is the same call either way."""
+    return "ciphertext" if world > 1 else "units"
+
+
+def threshold_decrypt_ciphertext_major(c, n_servers: int, rank: int, world: int, range_fn, combine_fn):
+    """Threshold decryption of B ciphertexts by ranks that ALL hold every one of the t shares (shares replicated -- a benchmark or a
+    single trust domain with several GPUs; with one share per machine use threshold_decrypt_sharded): rank r takes the ciphertexts
+    shard_slice(B, r, world), computes their partial decryptions under all t shares (thresholdkey.go:192-201; one call,
+    pgpu_partial_decrypt_units over the slice's whole unit range: the t ladders of a ciphertext share one chain of squarings) and
+    combines them locally (thresholdkey.go:149-190).  No exchange step at all.
+
+      range_fn     (c_rows, unit_begin, unit_end) -> uint8 tensor [unit_end - unit_begin, cipher_bytes], units server-major over c_rows
+      combine_fn   ([rows of server 0, rows of server 1, ...]) -> uint8 tensor [rows, plain_bytes]
+    Returns (plaintext rows of this rank's ciphertext slice, (begin, end) of that slice)."""
+    B, cbytes = int(c.shape[0]), int(c.shape[1])
+    cb, ce = shard_slice(B, rank, world)
+    if ce == cb:
+        return None, (cb, ce)
+    cnt = ce - cb
+    parts = range_fn(c[cb:ce], 0, n_servers * cnt)
+    if tuple(parts.shape) != (n_servers * cnt, cbytes):
+        raise ValueError("range_fn must return one row per (server, ciphertext) unit of the slice")
+    parts = parts.view(n_servers, cnt, cbytes)
+    return combine_fn([parts[s_] for s_ in range(n_servers)]), (cb, ce)
+
+
 def ddleq_prove_verify_sharded(n_statements: int, rank: int, world: int, prove_fn, verify_fn, device=None):
     """ProveDDLEQ + VerifyDDLEQProof (ddleq.go:27-53) for `n_statements` statements with the statements sharded over the ranks
     (BASELINE config 5).  Proofs of different statements are independent: rank r proves and verifies the contiguous slice

@@ -143,6 +143,15 @@ def _threshold_worker(rank, world, port, ids, count, use_gpu, q):
     out, (b, e) = pd.threshold_decrypt_sharded(c, len(ids), rank, world, partial_fn, combine_fn, units_fn=units_fn, range_fn=range_fn)
     if use_gpu and out is not None:
         assert torch.equal(out, out2)
+    # the ciphertext-major shard (every rank holds every share: no exchange) gives the same plaintexts for the same slice
+    if range_fn is None:
+        def range_fn(rows, ub, ue):          # CPU rehearsal: server-major units of the slice, one oracle call each
+            vals = to_ints(rows)
+            return to_rows([po.partial_decrypt(tsk[ids[u // len(vals)]], vals[u % len(vals)]).Decryption for u in range(ub, ue)], cb)
+    out3, (b3, e3) = pd.threshold_decrypt_ciphertext_major(c, len(ids), rank, world, range_fn, combine_fn)
+    assert (b3, e3) == (b, e)
+    if out is not None:
+        assert torch.equal(out, out3)
     q.put((rank, b, e, to_ints(out) if out is not None else []))
     dist.barrier()
     dist.destroy_process_group()

@@ -226,7 +226,9 @@ def test_partial_decrypt_indexed_runs_of_one_share(ctx, lens, lanes_wanted):
                                                    (300, 450, 900, 1),      # N = 2, rank 1: half of server 1 + server 2 whole
                                                    (300, 225, 450, 0),      # N = 4, rank 1: disjoint ciphertext ranges of two servers
                                                    (257, 100, 700, 0),      # three servers touched: tail, whole, head
-                                                   (300, 0, 900, 0),        # N = 1: every unit, one chain for the three shares
+                                                   (300, 0, 900, 0),        # every unit of a small batch: a chain per share (three groups)
+                                                   (300, 0, 900, 8192),     # ... room for two groups: {s0}, {s1, s2}
+                                                   (300, 0, 900, 4096),     # ... for one: one chain for the three shares
                                                    (300, 310, 590, 1)])     # inside one server
 def test_partial_decrypt_units_of_a_rank(ctx, B, ub, ue, lanes_wanted):
     """pgpu_partial_decrypt_units: the contiguous, server-major unit range of ONE rank of the sharded threshold flow over the

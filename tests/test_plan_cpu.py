@@ -131,6 +131,19 @@ def test_extract_randomness_beside_the_first_launch(q):
     assert q("extract_beside", 1536, 61440, 0) == [1]        # secpar 40: the side launch is a few dozen waves
     assert q("extract_beside", 32768, 32768, 0) == [0]       # both wave slots taken: s follows on the main stream
     assert q("extract_beside", 2048, 2048, 0) == [1]
+    # a ciphertext-major threshold shard: groups of shares with a chain each while every group still has a SIMD per wave at 8 lanes
+    assert q("shared_chain_groups", 16384, 3, 0, 1) == [1]
+    assert q("shared_chain_groups", 8192, 3, 0, 1) == [1]
+    assert q("shared_chain_groups", 4096, 3, 0, 1) == [2]
+    assert q("shared_chain_groups", 2048, 3, 0, 1) == [3]
+    assert q("shared_chain_groups", 256, 2, 0, 1) == [2]
+    assert q("shared_chain_groups", 2048, 3, 0, 0) == [1]
+    # a compute unit per workgroup for the concurrent launches of a small call: up to 4 096 instances at secpar 1 (measured: 8 192 loses)
+    assert q("exclusive_cus", 2048, 2048, 0) == [1]
+    assert q("exclusive_cus", 4096, 4096, 0) == [1]
+    assert q("exclusive_cus", 8192, 8192, 0) == [0]
+    assert q("exclusive_cus", 256, 8192, 0) == [0]
+    assert q("exclusive_cus", 256, 4096, 0) == [1]
 
 
 PAIR_SHARED = [

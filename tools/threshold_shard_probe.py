@@ -47,6 +47,11 @@ for world in (1, 2, 4, 8):
     cnt = B // world
     outs = [torch.empty((cnt, 512), dtype=torch.uint8, device=dev) for _ in ids]
     t_multi = timed(lambda: tk.partial_decrypt_multi_raw(sh, cnt, c[:cnt].data_ptr(), 512, [o.data_ptr() for o in outs], 512, MEM_DEVICE))
-    print(json.dumps({"world": world, "units_per_rank": units, "units_range_ms": round(t_rng, 1), "units_range_last_rank_ms": round(t_rng_last, 1),
+    # ciphertext-major shard: the rank's B / world ciphertexts under ALL shares through the units entry point (the whole unit range of
+    # the slice: one shared chain of squarings, the lane count the plan picks for so small a batch)
+    outc = torch.empty((3 * cnt, 512), dtype=torch.uint8, device=dev)
+    t_cm = timed(lambda: tk.partial_decrypt_units_raw(sh, cnt, c[:cnt].data_ptr(), 512, 0, 3 * cnt, outc.data_ptr(), 512, MEM_DEVICE))
+    k_cm = ctx.last_profile()["kernel"]
+    print(json.dumps({"world": world, "ciphertext_major_units_ms": round(t_cm, 1), "ciphertext_major_kernel": k_cm, "units_per_rank": units, "units_range_ms": round(t_rng, 1), "units_range_last_rank_ms": round(t_rng_last, 1),
                       "units_range_kernel": k_rng, "indexed_ms": round(t_idx, 1), "server_by_server_ms": round(t_srv, 1),
                       "ciphertext_sharded_multi_ms": round(t_multi, 1), "kernel": ctx.last_profile()["kernel"]}), flush=True)
