@@ -205,6 +205,15 @@ def test_asm_generator_model():
             assert sq.count("v_mad_u64_u32") == 2 * (wl - 1) + 2 * wl + 1          # two rows + one diagonal
             assert g.lds_bytes * 2 <= 160 * 1024, "two workgroups per CU must fit in LDS"
             continue
+        if isinstance(g, gen_vm_asm.GenM):
+            # the unrolled one-lane kernel: H(H-1)/2 + H + H^2 multiplies in a squaring, 2 H^2 in a product, no loop, and a squaring
+            # touches no LDS
+            H = wl
+            sq = text.split("L_montsq:")[1].split("s_branch L_next")[0]
+            mm = text.split("L_montmul:")[1].split("s_branch L_next")[0]
+            assert sq.count("v_mad_u64_u32") == H * (H - 1) // 2 + H + H * H and sq.count("ds_") == 0 and "s_cbranch" not in sq
+            assert mm.count("v_mad_u64_u32") == 2 * H * H and mm.count("ds_read_b32") == H and "s_cbranch" not in mm
+            continue
         row = text.split("L_row:")[1].split("s_cbranch_scc1 L_row")[0]
         if "L_noflush" in row:
             row = row.split("s_add_u32 s19, s19, 1")[0]
