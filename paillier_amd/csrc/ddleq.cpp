@@ -74,8 +74,14 @@ uint32_t* dual_pow_n3(pgpu_ctx* ctx, const pgpu_pubkey* pk, const uint32_t* x, c
     // x enters digit form beside the W ladder (a side lane); W itself is handed over in pair form -- (a0, a1, 0) is the digit form
     // of a representative of W mod n^2, which is all the lift needs (modexp_triple) -- where the pair kernel and the digit
     // kernel share the root n
-    const int wb = triple_window_bits(nb, mn3.triple.root->WT);
-    const uint32_t tab2 = 5 + (uint32_t)perlane_table_slots(wb, wb == 5);
+    // (a batch so small that one ladder's latency is the run time takes two lanes per digit -- GenQ6, limb-major 5-bit tables:
+    // 2 048 squarings modulo n^3 in ~25 ms where the one-lane digits take 77 whatever the batch)
+    const int H3 = mn3.triple.root->WT;
+    const bool six = ctx->use_lanes8 && H3 % 2 == 0 && vm_asm_available(H3 / 2, 112) &&
+                     plan::triple_two_lanes_per_digit(nb, plan::lanes_target(ctx->lanes_wanted));
+    const int wb = six ? 5 : triple_window_bits(nb, H3);
+    const bool nm5 = !six && wb == 5;
+    const uint32_t tab2 = 5 + (uint32_t)perlane_table_slots(wb, nm5);
     TriplePlan tp = triple_alloc(ctx, mn3, nb, (int)tab2 + (1 << (dual_sliding_bits(wb) - 1)));
     const bool hand = ctx->use_handover && mn2.pairn.root && mn2.pairn.root->WT == mn3.triple.root->WT;
     Fork ft(ctx, 3);
@@ -93,7 +99,7 @@ uint32_t* dual_pow_n3(pgpu_ctx* ctx, const pgpu_pubkey* pk, const uint32_t* x, c
       }
       ft.join();
       Prog pd;
-      emit_modexp_dual(pd, W1, pk->N, 0, 1, 2, 3, 5, tab2, 0, wb, wb == 5);
+      emit_modexp_dual(pd, W1, pk->N, 0, 1, 2, 3, 5, tab2, 0, wb, nm5);
       pd.end();
       triple_run(ctx, mn3, tp, pd, triple_windows(ctx, e0, W1, nb, wb));
       triple_exit(ctx, mn3, tp, 3, pc.out(), nullptr);

@@ -556,29 +556,53 @@ uint32_t* dual_pow_pair(pgpu_ctx* ctx, const ModCtx& mc, const uint32_t* x, cons
   const bool have4 = H % 2 == 0 && vm_asm_available(H / 2, 64);
   if (!plan::pair_kernel_serves(nb, plan::lanes_target(ctx->lanes_wanted), have4)) return nullptr;
   const bool two = plan::pair_lanes_2or4(nb, plan::lanes_target(ctx->lanes_wanted), have4) == 2;
+  // A batch so small that eight lanes per number still leave every wave a SIMD of its own is bound by the ladder's latency: GenQ8
+  // (76-limb digits over four lanes each; the radix changes R_74 <-> R_76 by one product on the way in and out, inside the program;
+  // limb-major 5-bit tables -- the gathers of so few numbers are not what the launch waits for).  2 048 numbers: 36.6 -> 2x ms.
+  const bool eight = have4 && pi.consts8 && ctx->use_lanes8 &&
+                     plan::pair_lanes_shared(nb, plan::lanes_target(ctx->lanes_wanted), have4, true) == 8;
   // per-number window table number-major (VM_STORET / VM_MULVT5 / VM_MULVT): limb-major, the 16 384-number ladder of the DDLEQ
   // verifier fetched 98 GB of 32-byte sectors for its dword gathers in a 43 ms launch (profiles/r03_bench_traffic.txt)
-  const bool nm4 = ctx->use_nm4;
-  const int wb = plan::dual_pair_window_bits(nb, W2, nm4);                 // gathers with 32-bit offsets
+  const bool nm4 = ctx->use_nm4 && !eight;
+  const int Hk = eight ? pi.h8 : H;                                        // limbs of a digit in the kernel's slots
+  const int wb = plan::dual_pair_window_bits(nb, 2 * Hk, nm4);             // gathers with 32-bit offsets
   if (!wb) return nullptr;
   const uint32_t tab2 = 5 + (uint32_t)perlane_table_slots(wb, nm4);
-  const size_t SW = (size_t)W2 * nb;
-  uint32_t* pm = ctx->ws_t<uint32_t>(SW * (size_t)(tab2 + 32));           // 0 x, 1 y, 2 tmp, 3 out, 5.. / tab2.. the tables
+  const size_t SW = (size_t)W2 * nb, SWk = (size_t)2 * Hk * nb;
+  uint32_t* pm = ctx->ws_t<uint32_t>(SWk * (size_t)(tab2 + 32));          // 0 x, 1 y, 2 tmp, 3 out, 5.. / tab2.. the tables
+  if (eight) HIPCHK(hipMemsetAsync(pm, 0, 2 * SWk * 4, ctx->stream));
   Fork fk(ctx);                                                            // y's entry chain beside x's
   for (int k = 0; k < 2; ++k) {
     fk.chain(k);
     uint32_t* ent = ctx->ws_t<uint32_t>(SW * 4);
     HIPCHK(hipMemcpyAsync(ent, k ? y : x, SW * 4, hipMemcpyDeviceToDevice, ctx->stream));
     pair_enter(ctx, mc, ent, nb);
-    HIPCHK(hipMemcpyAsync(pm + (size_t)k * SW, ent + 2 * SW, SW * 4, hipMemcpyDeviceToDevice, ctx->stream));
+    if (eight) {                                                           // digits of 74 limbs -> 76 (zero-extended)
+      launch_restride(ent + 2 * SW, nb, nb, nullptr, pm + (size_t)k * SWk, nb, H, ctx->stream);
+      launch_restride(ent + 2 * SW + (size_t)H * nb, nb, nb, nullptr, pm + (size_t)k * SWk + (size_t)Hk * nb, nb, H, ctx->stream);
+    } else {
+      HIPCHK(hipMemcpyAsync(pm + (size_t)k * SW, ent + 2 * SW, SW * 4, hipMemcpyDeviceToDevice, ctx->stream));
+    }
   }
   fk.join();
   Prog pd;
-  emit_modexp_dual(pd, we, e, 0, 1, 2, 3, 5, tab2, pi.c_one_pair, wb, nm4);
+  if (eight)
+    for (uint32_t k = 0; k < 2; ++k) { pd.op(VM_LOAD, k); pd.op(VM_MULC, 0); pd.op(VM_STORE, k); }          // radix R_74 -> R_76
+  emit_modexp_dual(pd, we, e, 0, 1, 2, 3, 5, tab2, eight ? 2 : pi.c_one_pair, wb, nm4);
+  if (eight) { pd.op(VM_MULC, 1); pd.op(VM_STORE, 3); }                                                      // radix R_76 -> R_74
   pd.end();
   SegSpec sp{&mc, &pd, pm, wb == 5 ? windows5_of(ctx, exps, we, nb) : exps};
-  sp.pair = pi.consts; sp.pair_n0inv = pi.root->n0inv; sp.pair_h = H; sp.pair_lanes = two ? 2 : 4;
+  sp.pair = eight ? pi.consts8 : pi.consts; sp.pair_n0inv = pi.root->n0inv; sp.pair_h = Hk; sp.pair_lanes = eight ? 8 : two ? 2 : 4;
+  if (eight) sp.tconsts = pi.tconsts8;
   run_vm(ctx, nb, sp, nullptr, true);
+  if (eight) {
+    uint32_t* back = ctx->ws_t<uint32_t>(SW * 4);                          // (pair_leave wants 74-limb digits and two scratch slots)
+    const uint32_t* res = pm + 3 * SWk;
+    launch_restride(res, nb, nb, nullptr, back, nb, H, ctx->stream);
+    launch_restride(res + (size_t)Hk * nb, nb, nb, nullptr, back + (size_t)H * nb, nb, H, ctx->stream);
+    if (raw_out) return *raw_out = back;
+    return pair_leave(ctx, mc, back, 0, nb);
+  }
   if (raw_out) return *raw_out = pm + 3 * SW;
   return pair_leave(ctx, mc, pm, 3, nb);
 }

@@ -145,16 +145,21 @@ def test_ddleq_verify_2048_on_and_off(ctx):
     wrong = [st[(i["s"] + 1) % 4]["ct2"] for i in ins]
     fs_bad = list(fs)
     fs_bad[3] ^= 1 << 4000
-    for flag in (1, 0):
+    # (triple, lanes8): a batch this small takes two lanes per digit (vm_asm_37_112, limb-major 5-bit tables) unless lanes8 is off --
+    # then the one-lane digits with number-major 7-bit tables (vm_asm_74_48); triple off: the generic kernel
+    for flag, l8, suffix in ((1, 1, "_112"), (1, 0, "_48"), (0, 1, None)):
         ctx.set_flag("triple", flag)
+        ctx.set_flag("lanes8", l8)
         try:
             assert pk.VerifyDDLEQInstancesBatch(col("ct1"), col("ct2"), xs, ys, al, es, fs) == [True] * 16
-            assert ctx.last_profile()["kernel"].endswith("_48") == bool(flag)
+            kern = ctx.last_profile()["kernel"]
+            assert kern.endswith(suffix) if suffix else not (kern.endswith("_48") or kern.endswith("_112")), kern
             assert pk.VerifyDDLEQInstancesBatch(col("ct1"), wrong, xs, ys, al, es, fs) == [bool(i["verify_wrong_ct2"]) for i in ins]
             got = pk.VerifyDDLEQInstancesBatch(col("ct1"), col("ct2"), xs, ys, al, es, fs_bad)
             assert got == [i != 3 for i in range(16)]
         finally:
             ctx.set_flag("triple", 1)
+            ctx.set_flag("lanes8", 1)
 
 
 def test_split_through_n_squared_on_and_off(ctx):
