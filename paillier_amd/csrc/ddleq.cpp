@@ -1294,7 +1294,17 @@ static void ddleq_prove_impl(const pgpu_seckey* sk, size_t S, size_t secpar, con
     StructBase sbase;
     SideStream base_lane(ctx, 3);      // (a lane of its own: s keeps the side stream, beside the same launch)
     hipEvent_t residues_ready = nullptr, plaintext_ready = nullptr;
+    // (a call whose launches fill the chip: the side lanes' ladders yield to the main stream's -- a^n | x^n gates everything behind it, the
+    // plaintext of ct1 is needed after the lifts, s after the hash)
+    static const int bg_env = [] { const char* e = getenv("PGPU_BG"); return e ? atoi(e) : -1; }();
+    const bool side_yields = bg_env >= 0 ? bg_env != 0 : !ctx->exclusive_call;
+    struct Background {
+      pgpu_ctx* c; bool on;
+      Background(pgpu_ctx* c_, bool on_) : c(c_), on(on_) { if (on) c->background_launch = true; }
+      ~Background() { if (on) c->background_launch = false; }
+    };
     if (by_struct) {
+      Background bg(ctx, side_yields);
       d_st_stmt = ctx->ws_t<int32_t>(nbs);
       d_st_num = ctx->ws_t<int32_t>(nt);
       base_lane.enter(inputs_ready);
@@ -1314,6 +1324,7 @@ static void ddleq_prove_impl(const pgpu_seckey* sk, size_t S, size_t secpar, con
     }
     if (s_beside) side.enter(inputs_ready);
     {
+      Background bg(ctx, side_yields && s_beside);
       // s = ExtractRandonness(ct1) at level two (operations.go:75-91): z = G^(-v) ct1 mod n^3 with v = Decrypt(ct1)
       // (operations.go:81-86) is only ever used modulo n (:88), and G^v = (1 + n)^v = 1 (mod n) whatever v is (the prover
       // requires G = n + 1): z = ct1 (mod n).  No decryption, no G^v, no inversion modulo n^3 -- the same s.
@@ -1375,12 +1386,27 @@ static void ddleq_prove_impl(const pgpu_seckey* sk, size_t S, size_t secpar, con
     int32_t* d_ok = ctx->ws_t<int32_t>(nbs);
     launch_equal(san, c2s, W3, nbs, S, d_ok, ctx->stream);
     std::vector<int32_t> hok(S);
+    // ---- challenge bit = LSB SHA-256(ct2 || x || y || alpha)  (ddleq.go:91; ct1 is skipped: random_oracle.go:24-26).  With the CRT
+    // path Alpha is on the main stream by now: the hash follows it at once -- the host is about to wait inside the side section (the
+    // inversion tree inverts its root on the host) and would otherwise launch the hash only after that: 8 of 133 ms at 16 384 instances.
+    // The sanity flags are read together with the bits; a failed check discards them.
+    int32_t* chal = ctx->ws_t<int32_t>(nb);
+    const uint32_t* parts[4] = {c2, xl, yl, alp};
+    const int widths[4] = {W3, W1, W1, W3};
+    auto hash_bits = [&] {
+      HIPCHK(hipMemsetAsync(chal, 0, nb * 4, ctx->stream));
+      launch_sha256_transcript(parts, widths, 4, nb, batch, nullptr, chal, ctx->stream);
+    };
+    const bool hash_early = crt3;
+    if (hash_early) hash_bits();
+    std::vector<int32_t> hch(batch);
     // ---- side stream, behind a^n (the Alpha ladders above are in flight on the main stream): a^-1 and (a^n)^-1 modulo n^2 for
     // every statement from ONE inversion tree (both batches side by side; a non-unit is flagged per lane and matters only if
     // one of its instances draws challenge bit 1), and the unit test of s b for the one-ladder form of the response
     uint32_t *qainv = ctx->ws_t<uint32_t>((size_t)W2 * nbs), *qani = ctx->ws_t<uint32_t>((size_t)W2 * nbs);
     int32_t* d_badinv = ctx->ws_t<int32_t>(2 * nbs);
     bool any_badinv = false, sb_units = false, early = false, resp_struct = false;
+    const uint8_t* sb_root = nullptr;
     RespBase rbase;
     RespExps rexps;
     uint32_t* en_all = nullptr;
@@ -1404,7 +1430,10 @@ static void ddleq_prove_impl(const pgpu_seckey* sk, size_t S, size_t secpar, con
         uint32_t* sb = ctx->ws_t<uint32_t>((size_t)W1 * nbs);
         modmul_arrays(ctx, mn, qs, bl, nbs, sb);
         launch_restride(sb, nbs, S, mn.d_consts + (size_t)C_ONE * W1, sb, nbs, W1, ctx->stream);
-        sb_units = all_units(ctx, mn, sb, nbs, S);
+        // (no wait: the root of the product tree goes to pinned memory and is looked at once the hash is known -- the side lane
+        // crawls beside the lifts, and a host that waits for it here issues the response's preparation 35 ms late)
+        sb_root = all_units_begin(ctx, mn, sb, nbs, S);
+        sb_units = true;                                     // assumed; checked below, before anything uses the prepared response
         HT("unit test");
       }
       // The response's per-statement bases (s, b: residues modulo p^3, q^3, p^2, q^2 and digit forms) and, for EVERY instance, its
@@ -1486,6 +1515,7 @@ static void ddleq_prove_impl(const pgpu_seckey* sk, size_t S, size_t secpar, con
       HIPCHK(hipMemcpyAsync(hst_stmt.data(), d_st_stmt, S * 4, hipMemcpyDeviceToHost, ctx->stream));
       HIPCHK(hipMemcpyAsync(hst_num.data(), d_st_num, nt * 4, hipMemcpyDeviceToHost, ctx->stream));
     }
+    if (hash_early) HIPCHK(hipMemcpyAsync(hch.data(), chal, batch * 4, hipMemcpyDeviceToHost, ctx->stream));
     HT("side issued");
     HIPCHK(hipStreamSynchronize(ctx->stream));
     HT("alpha known");
@@ -1497,6 +1527,10 @@ static void ddleq_prove_impl(const pgpu_seckey* sk, size_t S, size_t secpar, con
         literal_ladders();
         launch_equal(san, c2s, W3, nbs, S, d_ok, ctx->stream);
         HIPCHK(hipMemcpyAsync(hok.data(), d_ok, S * 4, hipMemcpyDeviceToHost, ctx->stream));
+        if (hash_early) {                                  // (Alpha changed: hash it again)
+          hash_bits();
+          HIPCHK(hipMemcpyAsync(hch.data(), chal, batch * 4, hipMemcpyDeviceToHost, ctx->stream));
+        }
         HIPCHK(hipStreamSynchronize(ctx->stream));
       }
     }
@@ -1509,16 +1543,18 @@ static void ddleq_prove_impl(const pgpu_seckey* sk, size_t S, size_t secpar, con
       perlane3(c1, xn, W2, nb, t3);
       modmul_arrays(ctx, mn3, t3, yn2, nb, alp);
     }
-    // ---- challenge bit = LSB SHA-256(ct2 || x || y || alpha)  (ddleq.go:91; ct1 is skipped: random_oracle.go:24-26)
-    int32_t* chal = ctx->ws_t<int32_t>(nb);
-    HIPCHK(hipMemsetAsync(chal, 0, nb * 4, ctx->stream));
-    const uint32_t* parts[4] = {c2, xl, yl, alp};
-    const int widths[4] = {W3, W1, W1, W3};
-    launch_sha256_transcript(parts, widths, 4, nb, batch, nullptr, chal, ctx->stream);
-    std::vector<int32_t> hch(batch);
-    HIPCHK(hipMemcpyAsync(hch.data(), chal, batch * 4, hipMemcpyDeviceToHost, ctx->stream));
-    HIPCHK(hipStreamSynchronize(ctx->stream));
+    if (!hash_early) {
+      hash_bits();
+      HIPCHK(hipMemcpyAsync(hch.data(), chal, batch * 4, hipMemcpyDeviceToHost, ctx->stream));
+      HIPCHK(hipStreamSynchronize(ctx->stream));
+    }
     side.join();                                             // the per-statement values are needed from here on
+    if (sb_root) {
+      // s b a unit for every statement?  (never false for honest inputs; if it is, what was prepared for the one-ladder response is dropped)
+      HIPCHK(hipStreamSynchronize(ctx->stream));
+      sb_units = all_units_end(mn, sb_root);
+      if (!sb_units) early = resp_struct = false;
+    }
     HT("hash known");
     // default outputs: e = x, f = y (chalBit false)
     uint32_t* eo = zext(ctx, xl, W1, W2, nb);

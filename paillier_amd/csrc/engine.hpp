@@ -98,6 +98,7 @@ struct pgpu_ctx {
   bool exclusive_call = false;   // set by a protocol function for the length of a call whose concurrent launches together fit the chip's compute units: every
                                  // workgroup then asks for the whole LDS of a CU, so the dispatcher cannot stack the side lanes' workgroups on the CUs the main
                                  // launch runs on (it starts every queue's workgroups from the same CUs: 17.5 -> 28 ms for a^n | x^n of 2 048 instances)
+  bool background_launch = false; // set around side-lane ladders of a LARGE call (see run_vm): their long programs run at wave priority 0
   bool use_handover = true;  // a power modulo n^2 that is only needed modulo n^2 by the next ladder modulo n^3 stays in pair form: (a0, a1, 0) is its digit form (pgpu_ctx_set_flag("handover", 0): exit and re-entry)
   bool use_muls = true;      // bucket products of the shared chain as VM_MULS where the kernel has it (pgpu_ctx_set_flag("muls", 0): LOAD / MUL / STORE)
   bool use_struct = true;    // the key holder's ct^e y^(n^2) mod n^3 through the structure of the unit group: plaintext of ct, ladders modulo the primes, Teichmueller lift (pgpu_ctx_set_flag("struct", 0): the ladders on ct itself)
@@ -132,6 +133,7 @@ struct pgpu_ctx {
       chunks.push_back(c);
     }
     for (auto& c : chunks) c.used = 0;
+    pinned_used = 0;
     sync_used = 0;
     for (auto& h : host_keep) wipe_vec(h);   // ladder programs encode secret exponents (p - 1, q - 1, shares)
     host_keep.clear();
@@ -179,7 +181,21 @@ struct pgpu_ctx {
     (void)hipStreamSynchronize(stream);
     for (auto& h : host_keep) wipe_vec(h);
   }
+  // Page-locked host memory for small results the host reads LATER (flags, a tree's root): a device-to-host copy into pageable memory
+  // holds the host until the stream has got there, one into pinned memory is just another command of the stream.  Reset per call.
+  uint8_t* pinned_base = nullptr;
+  size_t pinned_used = 0;
+  static constexpr size_t kPinnedBytes = (size_t)1 << 20;
+  void* pinned(size_t bytes) {
+    bytes = round_up(bytes ? bytes : 1, 64);
+    if (!pinned_base) HIPCHK(hipHostMalloc((void**)&pinned_base, kPinnedBytes, hipHostMallocDefault));
+    if (pinned_used + bytes > kPinnedBytes) throw HipError{hipErrorOutOfMemory, "pinned scratch"};
+    void* ptr = pinned_base + pinned_used;
+    pinned_used += bytes;
+    return ptr;
+  }
   ~pgpu_ctx() {
+    if (pinned_base) (void)hipHostFree(pinned_base);
     wipe_ws();
     for (auto& c : chunks) (void)hipFree(c.p);
     for (auto& e : evs) { (void)hipEventDestroy(e.a); (void)hipEventDestroy(e.b); }
@@ -433,7 +449,13 @@ struct Prog {
   // longer than 7 % of the one before it or the leader would run out of program while the other is still catching up).
   void end() {
     op(VM_END);
-    if (montmuls < 256 || !g_wave_priorities.load(std::memory_order_relaxed)) return;
+    if (!g_wave_priorities.load(std::memory_order_relaxed)) return;
+    if (montmuls < 256) {
+      // a short program is a link of a chain between dependent ladders: top priority for all of it (next to a side lane's long ladder
+      // at priority 3 .. 1 a priority-0 wave only gets the slots the ladder leaves: 3.4 ms for three products, r04 trace)
+      for (size_t i = 0; i + 1 < w.size(); i += 2) w[i] = (w[i] & 0x3FFFFFFFu) | (3u << 30);
+      return;
+    }
     double done = 0;
     for (size_t i = 0; i + 1 < w.size(); i += 2) {
       const uint32_t o = w[i] & 0xFFu;
@@ -692,6 +714,10 @@ struct UnitCheck {
   }
 };
 bool all_units(pgpu_ctx* ctx, const ModCtx& mc, const uint32_t* x, size_t nb, size_t count);
+// ... in two halves: begin() issues the product tree and the copy of its root into pinned memory (no wait); end() -- after the stream
+// that ran begin() has been synchronised -- inverts the root on the host
+const uint8_t* all_units_begin(pgpu_ctx* ctx, const ModCtx& mc, const uint32_t* x, size_t nb, size_t count);
+bool all_units_end(const ModCtx& mc, const uint8_t* root_be);
 uint32_t* batch_inverse(pgpu_ctx* ctx, const ModCtx& mc, const uint32_t* x, size_t nb, size_t count, int32_t* d_bad = nullptr,
                         bool* any_bad = nullptr);
 

@@ -164,10 +164,18 @@ hipError_t launch_vm(int wl, int k, const VmArgs& a, uint32_t blocks, hipStream_
 // Helper kernels (one lane per number; generic width)
 // ------------------------------------------------------------------------------------------
 
+// Helper kernels are links of CHAINS between dependent ladders: tens of microseconds each, but next to a long ladder of a side lane
+// whose waves run at s_setprio 3 .. 1 (gen_vm_asm.py fair_share) a priority-0 wave gets only the issue slots the ladder leaves --
+// k_canon 0.9 ms, a three-product VM program 3.4 ms between the prover's a^n | x^n and Alpha launches (r04 trace).  They take the top
+// priority for their few instructions.
+#define CHAIN_PRIORITY() __builtin_amdgcn_s_setprio(3)
+
+
 // big-endian bytes, element-major with fixed stride  ->  28-bit limbs, limb-major.
 // Elements >= count are written as zero (padding lanes).
 __global__ void k_unpack_be(const uint8_t* __restrict__ in, size_t stride, size_t nbytes, size_t count,
                             uint32_t* __restrict__ out, int wt, size_t nb) {
+  CHAIN_PRIORITY();
   size_t g = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (g >= nb) return;
   const uint8_t* p = in + g * stride;
@@ -211,6 +219,7 @@ __global__ void k_unpack_be(const uint8_t* __restrict__ in, size_t stride, size_
 // (the caller guarantees the value fits).
 __global__ void k_pack_be(const uint32_t* __restrict__ in, int wt, size_t nb, size_t count,
                           uint8_t* __restrict__ out, size_t stride, size_t nbytes) {
+  CHAIN_PRIORITY();
   size_t g = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (g >= count) return;
   uint8_t* p = out + g * stride;
@@ -243,6 +252,7 @@ __global__ void k_pack_be(const uint32_t* __restrict__ in, int wt, size_t nb, si
 // Lazy limbs (any limb < 2^32, value < 3N) -> canonical residue in [0, N), in place.
 // Sequential carry, then up to two conditional subtractions of N.
 __global__ void k_canon(uint32_t* __restrict__ x, const uint32_t* __restrict__ nmod, int wt, size_t nb) {
+  CHAIN_PRIORITY();
   size_t g = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (g >= nb) return;
   uint64_t c = 0;
@@ -273,6 +283,7 @@ __global__ void k_canon(uint32_t* __restrict__ x, const uint32_t* __restrict__ n
 __global__ void k_mul_const_add(const uint32_t* __restrict__ a, int wa, const uint32_t* __restrict__ bconst, int wb,
                                 const uint32_t* __restrict__ addv, int wadd, uint32_t add_small,
                                 uint32_t* __restrict__ out, int wo, size_t nb) {
+  CHAIN_PRIORITY();
   size_t g = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (g >= nb) return;
   uint64_t acc = add_small, carry_hi = 0;  // 128-bit column accumulator (acc + carry_hi * 2^64)
@@ -306,6 +317,7 @@ __global__ void k_div_exact(const uint32_t* __restrict__ u, int wu, uint32_t sub
                             const uint32_t* __restrict__ dinv, const uint32_t* __restrict__ d, int wd,
                             uint32_t* __restrict__ l, int wl, size_t nb, size_t count, int32_t* __restrict__ status,
                             int32_t flag) {
+  CHAIN_PRIORITY();
   size_t g = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (g >= nb) return;
   int32_t br = 0;
@@ -354,6 +366,7 @@ __global__ void __launch_bounds__(256) k_div_exact_t(const uint32_t* __restrict_
                                                      const uint32_t* __restrict__ dinv, const uint32_t* __restrict__ d,
                                                      uint32_t* __restrict__ l, size_t nb, size_t count,
                                                      int32_t* __restrict__ status, int32_t flag) {
+  CHAIN_PRIORITY();
   static_assert(WL <= 128 && WD <= 128, "single 64-bit column accumulator: <= 128 products of canonical limbs");
   size_t g = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (g >= nb) return;
@@ -398,6 +411,7 @@ template <int WU, int WL, int WS>
 __global__ void __launch_bounds__(256) k_div_exact_nc(const uint32_t* __restrict__ u, uint32_t sub_small,
                                                       const uint32_t* __restrict__ subv, const uint32_t* __restrict__ dinv,
                                                       uint32_t* __restrict__ l, size_t nb) {
+  CHAIN_PRIORITY();
   static_assert(WL <= 255 && WL <= WU, "a column of <= 255 products of canonical limbs fits the 64-bit accumulator");
   size_t g = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (g >= nb) return;
@@ -424,6 +438,7 @@ template <int WA, int WB, int WO>
 __global__ void __launch_bounds__(256) k_mul_const_add_t(const uint32_t* __restrict__ a, const uint32_t* __restrict__ bconst,
                                                          const uint32_t* __restrict__ addv, int wadd, uint32_t add_small,
                                                          uint32_t* __restrict__ out, size_t nb) {
+  CHAIN_PRIORITY();
   static_assert(WA <= 74 || WB <= 74, "single 64-bit column accumulator: a column has min(WA, WB) <= 74 products of a 29-bit by a 28-bit limb, below 2^64");
   size_t g = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (g >= nb) return;
@@ -447,6 +462,7 @@ __global__ void __launch_bounds__(256) k_mul_const_add_t(const uint32_t* __restr
 __global__ void __launch_bounds__(64) k_mul_const_add_lds(const uint32_t* __restrict__ a, int wa, const uint32_t* __restrict__ bconst,
                                                          int wb, const uint32_t* __restrict__ addv, int wadd, uint32_t add_small,
                                                          uint32_t* __restrict__ out, int wo, size_t nb) {
+  CHAIN_PRIORITY();
   extern __shared__ uint32_t mca_lds[];
   uint32_t* xs = mca_lds;
   uint32_t* bs = mca_lds + (size_t)wa * 64;
@@ -480,6 +496,7 @@ __global__ void __launch_bounds__(64) k_mul_const_add_lds(const uint32_t* __rest
 
 // out = x - 1 (w limbs); x == 0 wraps to all-ones limbs (callers flag that lane separately)
 __global__ void k_sub_one(const uint32_t* __restrict__ x, uint32_t* __restrict__ out, int w, size_t nb) {
+  CHAIN_PRIORITY();
   size_t g = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (g >= nb) return;
   int32_t br = 1;
@@ -492,6 +509,7 @@ __global__ void k_sub_one(const uint32_t* __restrict__ x, uint32_t* __restrict__
 
 // clear every bit >= `bits` of a w-limb number (r mod 2^bits)
 __global__ void k_mask_bits(uint32_t* __restrict__ x, int w, size_t nb, size_t bits) {
+  CHAIN_PRIORITY();
   size_t g = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (g >= nb) return;
   for (int l = 0; l < w; ++l) {
@@ -505,6 +523,7 @@ __global__ void k_mask_bits(uint32_t* __restrict__ x, int w, size_t nb, size_t b
 // Used only for the unreduced c^4 and c_i^2 that feed the Fiat-Shamir hash (thresholdkey.go:241,248).
 __global__ void k_mul_plain(const uint32_t* __restrict__ a, int wa, const uint32_t* __restrict__ b, int wb,
                             uint32_t* __restrict__ out, size_t nb) {
+  CHAIN_PRIORITY();
   size_t g = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (g >= nb) return;
   uint64_t acc = 0, hi = 0;
@@ -525,6 +544,7 @@ __global__ void k_mul_plain(const uint32_t* __restrict__ a, int wa, const uint32
 
 // 32-byte big-endian digests (uint32 words, limb-major [8][nb]) -> 10 canonical 28-bit limbs (the integer E)
 __global__ void k_digest_to_limbs(const uint32_t* __restrict__ dg, uint32_t* __restrict__ out, size_t nb) {
+  CHAIN_PRIORITY();
   size_t g = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (g >= nb) return;
   // value = sum_i word[i] * 2^(32 (7 - i))
@@ -540,6 +560,7 @@ __global__ void k_digest_to_limbs(const uint32_t* __restrict__ dg, uint32_t* __r
 
 // flags[g] = (x == 0)
 __global__ void k_is_zero(const uint32_t* __restrict__ x, int w, size_t nb, int32_t* __restrict__ flags) {
+  CHAIN_PRIORITY();
   size_t g = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (g >= nb) return;
   uint32_t o = 0;
@@ -551,6 +572,7 @@ __global__ void k_is_zero(const uint32_t* __restrict__ x, int w, size_t nb, int3
 // x^(p-1) in pair form: it is 1 for every unit and 0 or p for a multiple of p.
 __global__ void k_flag_not_one(const uint32_t* __restrict__ x, int w, size_t nb, size_t count, int32_t* __restrict__ status,
                                int32_t flag) {
+  CHAIN_PRIORITY();
   size_t g = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (g >= count) return;
   uint32_t o = x[g] ^ 1u;
@@ -561,6 +583,7 @@ __global__ void k_flag_not_one(const uint32_t* __restrict__ x, int w, size_t nb,
 // x <- c (uniform constant, w limbs) on the lanes whose flag is set
 __global__ void k_select_const(const int32_t* __restrict__ flags, const uint32_t* __restrict__ c, uint32_t* __restrict__ x,
                                int w, size_t nb) {
+  CHAIN_PRIORITY();
   size_t g = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (g >= nb || !flags[g]) return;
   for (int l = 0; l < w; ++l) x[(size_t)l * nb + g] = c[l];
@@ -569,6 +592,7 @@ __global__ void k_select_const(const int32_t* __restrict__ flags, const uint32_t
 // out = (a - b) mod q for canonical a, b in [0, q): a - b + (a < b ? q : 0)
 __global__ void k_sub_mod(const uint32_t* __restrict__ a, const uint32_t* __restrict__ b,
                           const uint32_t* __restrict__ q, uint32_t* __restrict__ out, int w, size_t nb) {
+  CHAIN_PRIORITY();
   size_t g = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (g >= nb) return;
   int32_t br = 0;
@@ -589,6 +613,7 @@ __global__ void k_sub_mod(const uint32_t* __restrict__ a, const uint32_t* __rest
 
 // copy `w` limbs (zero-extending to wo) between limb-major arrays, optionally starting at source limb `l0`
 __global__ void k_copy_limbs(const uint32_t* __restrict__ in, int l0, int w, uint32_t* __restrict__ out, int wo, size_t nb) {
+  CHAIN_PRIORITY();
   size_t g = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (g >= nb) return;
   for (int l = 0; l < wo; ++l) out[(size_t)l * nb + g] = (l < w) ? in[(size_t)(l0 + l) * nb + g] : 0u;
@@ -597,6 +622,7 @@ __global__ void k_copy_limbs(const uint32_t* __restrict__ in, int l0, int w, uin
 // the same for `nchunks` consecutive w-limb pieces of `in` at once: piece k -> out + k * out_stride (wo limbs each, zero-extended)
 __global__ void k_copy_chunks(const uint32_t* __restrict__ in, int w, int nchunks, uint32_t* __restrict__ out, size_t out_stride,
                               int wo, size_t nb) {
+  CHAIN_PRIORITY();
   size_t g = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (g >= nb) return;
   for (int k = 0; k < nchunks; ++k)
@@ -605,6 +631,7 @@ __global__ void k_copy_chunks(const uint32_t* __restrict__ in, int w, int nchunk
 
 // fill a limb-major array with a uniform constant (wo limbs)
 __global__ void k_fill_const(const uint32_t* __restrict__ c, uint32_t* __restrict__ out, int wo, size_t nb) {
+  CHAIN_PRIORITY();
   size_t g = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (g >= nb) return;
   for (int l = 0; l < wo; ++l) out[(size_t)l * nb + g] = c[l];
@@ -613,12 +640,14 @@ __global__ void k_fill_const(const uint32_t* __restrict__ c, uint32_t* __restric
 // gather / scatter of selected numbers (used to re-run flagged lanes on the generic path)
 __global__ void k_gather(const uint32_t* __restrict__ in, size_t nb_in, const uint32_t* __restrict__ idx, size_t n_idx,
                          uint32_t* __restrict__ out, size_t nb_out, int w) {
+  CHAIN_PRIORITY();
   size_t g = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (g >= nb_out) return;
   for (int l = 0; l < w; ++l) out[(size_t)l * nb_out + g] = (g < n_idx) ? in[(size_t)l * nb_in + idx[g]] : 0u;
 }
 __global__ void k_scatter(const uint32_t* __restrict__ in, size_t nb_in, const uint32_t* __restrict__ idx, size_t n_idx,
                           uint32_t* __restrict__ out, size_t nb_out, int w) {
+  CHAIN_PRIORITY();
   size_t g = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (g >= n_idx) return;
   for (int l = 0; l < w; ++l) out[(size_t)l * nb_out + idx[g]] = in[(size_t)l * nb_in + g];
@@ -627,6 +656,7 @@ __global__ void k_scatter(const uint32_t* __restrict__ in, size_t nb_in, const u
 // out[l][g] (stride nb_out) = g < count ? in[l][g] (stride nb_in) : fill[l]   (re-stride / pad a batch)
 __global__ void k_restride(const uint32_t* __restrict__ in, size_t nb_in, size_t count, const uint32_t* __restrict__ fill,
                            uint32_t* __restrict__ out, size_t nb_out, int w) {
+  CHAIN_PRIORITY();
   size_t g = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (g >= nb_out) return;
   for (int l = 0; l < w; ++l) out[(size_t)l * nb_out + g] = (g < count) ? in[(size_t)l * nb_in + g] : (fill ? fill[l] : 0u);
@@ -635,6 +665,7 @@ __global__ void k_restride(const uint32_t* __restrict__ in, size_t nb_in, size_t
 // out[g] = g < half ? lo[g] : hi[g - half]   for g < 2*half   (all arrays limb-major with stride nb)
 __global__ void k_merge_halves(const uint32_t* __restrict__ lo, const uint32_t* __restrict__ hi, size_t half,
                                uint32_t* __restrict__ out, size_t nb, int w) {
+  CHAIN_PRIORITY();
   size_t g = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (g >= 2 * half) return;
   const uint32_t* src = g < half ? lo + g : hi + (g - half);
@@ -717,6 +748,7 @@ struct Sha256 {
 // read as a big-endian integer (RandomOracleBit, random_oracle.go:10-16)
 __global__ void k_sha256_transcript(ShaArgs a, size_t nb, size_t count, uint32_t* __restrict__ digest_out,
                                     int32_t* __restrict__ bit_out) {
+  CHAIN_PRIORITY();
   size_t g = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (g >= count) return;
   Sha256 s;
@@ -748,6 +780,7 @@ __global__ void k_sha256_transcript(ShaArgs a, size_t nb, size_t count, uint32_t
 // ok[g] = (a == b) limb-wise (canonical numbers)
 __global__ void k_equal(const uint32_t* __restrict__ a, const uint32_t* __restrict__ b, int w, size_t nb, size_t count,
                         int32_t* __restrict__ ok) {
+  CHAIN_PRIORITY();
   size_t g = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (g >= count) return;
   uint32_t d = 0;
@@ -758,6 +791,7 @@ __global__ void k_equal(const uint32_t* __restrict__ a, const uint32_t* __restri
 // out <- flags[g] ? a : b   (w limbs)
 __global__ void k_select(const int32_t* __restrict__ flags, const uint32_t* __restrict__ a, const uint32_t* __restrict__ b,
                          uint32_t* __restrict__ out, int w, size_t nb) {
+  CHAIN_PRIORITY();
   size_t g = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (g >= nb) return;
   const uint32_t* src = flags[g] ? a : b;
@@ -771,6 +805,7 @@ __global__ void k_select(const int32_t* __restrict__ flags, const uint32_t* __re
 // gives the reference the same information per call.  O(bits) iterations of O(w) limb operations per lane, divergent.
 __global__ void k_unit_flags(const uint32_t* __restrict__ x, const uint32_t* __restrict__ nmod, int w, size_t nb, size_t count,
                              uint32_t* __restrict__ work, int32_t* __restrict__ flags) {
+  CHAIN_PRIORITY();
   size_t g = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (g >= nb) return;
   if (g >= count) { flags[g] = 0; return; }
@@ -828,6 +863,7 @@ __global__ void k_unit_flags(const uint32_t* __restrict__ x, const uint32_t* __r
 // out[l][g] = table[idx[g]][l]: per-number exponent limbs from a small table of exponents (one row per key share)
 __global__ void k_gather_rows(const uint32_t* __restrict__ table, int w, const int32_t* __restrict__ idx, size_t count,
                               uint32_t* __restrict__ out, size_t nb) {
+  CHAIN_PRIORITY();
   size_t g = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (g >= nb) return;
   const uint32_t* row = table + (size_t)(g < count ? idx[g] : 0) * w;
@@ -836,6 +872,7 @@ __global__ void k_gather_rows(const uint32_t* __restrict__ table, int w, const i
 
 // exponent limbs (28 bits) -> 25-bit words: word k = bits [25 k, 25 k + 25) of the number
 __global__ void k_repack_windows5(const uint32_t* __restrict__ in, int we, uint32_t* __restrict__ out, int we5, size_t nb) {
+  CHAIN_PRIORITY();
   size_t g = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (g >= nb) return;
   for (int k = 0; k < we5; ++k) {
@@ -848,12 +885,14 @@ __global__ void k_repack_windows5(const uint32_t* __restrict__ in, int we, uint3
 
 // status[g] |= flag where flags[g] != 0 (g < count)
 __global__ void k_or_flags(const int32_t* __restrict__ flags, size_t count, int32_t* __restrict__ status, int32_t flag) {
+  CHAIN_PRIORITY();
   size_t g = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (g < count && flags[g]) status[g] |= flag;
 }
 
 // ok[g] = 0 where flags[g] != 0
 __global__ void k_clear_where(const int32_t* __restrict__ flags, size_t count, int32_t* __restrict__ ok) {
+  CHAIN_PRIORITY();
   size_t g = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (g < count && flags[g]) ok[g] = 0;
 }
@@ -866,6 +905,7 @@ __global__ void k_clear_where(const int32_t* __restrict__ flags, size_t count, i
 // it lands right-aligned in the element's fixed stride, zero-padded on the left.
 __global__ void k_bytes_gather_be(const uint8_t* __restrict__ src, const uint64_t* __restrict__ off, const uint32_t* __restrict__ len,
                                   size_t count, uint8_t* __restrict__ out, size_t stride) {
+  CHAIN_PRIORITY();
   const size_t g = blockIdx.x;
   if (g >= count) return;
   const uint8_t* s = src + off[g];
@@ -875,6 +915,7 @@ __global__ void k_bytes_gather_be(const uint8_t* __restrict__ src, const uint64_
 }
 // pack, step 1: significant bytes of every fixed-stride big-endian element (0 for the value 0)
 __global__ void k_be_lengths(const uint8_t* __restrict__ in, size_t stride, size_t count, uint32_t* __restrict__ len) {
+  CHAIN_PRIORITY();
   const size_t g = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (g >= count) return;
   const uint8_t* p = in + g * stride;
@@ -895,6 +936,7 @@ __device__ inline uint32_t gob_uint(uint8_t* d, uint32_t v) {
 __global__ void k_gob_emit(const uint8_t* __restrict__ in, size_t stride, const uint32_t* __restrict__ len, const uint64_t* __restrict__ off,
                            size_t count, const uint8_t* __restrict__ prefix, uint32_t prefix_len, const uint8_t* __restrict__ head,
                            uint32_t head_len, const uint8_t* __restrict__ tail, uint32_t tail_len, uint8_t* __restrict__ dst) {
+  CHAIN_PRIORITY();
   const size_t g = blockIdx.x;
   if (g >= count) return;
   __shared__ uint32_t s_at;
@@ -1117,6 +1159,7 @@ void launch_gather_rows(const uint32_t* table, int w, const int32_t* idx, size_t
 __global__ void k_exp_order_lift(const uint32_t* __restrict__ e, int we, const uint32_t* __restrict__ em, int wm,
                                  const uint32_t* __restrict__ m, int t, uint32_t minv, uint32_t* __restrict__ out, int wo,
                                  size_t nb) {
+  CHAIN_PRIORITY();
   size_t g = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (g >= nb) return;
   const uint32_t tmask = (1u << t) - 1u;
@@ -1145,6 +1188,7 @@ __global__ void k_exp_order_lift(const uint32_t* __restrict__ e, int we, const u
 //   ls = x - a * e,   lb = -e      modulo 2^28, from the lowest limbs of x, a, e (limb-major arrays: limb 0 of number g at [g])
 __global__ void k_exp_low_combine(const uint32_t* __restrict__ x, const uint32_t* __restrict__ a, const uint32_t* __restrict__ e,
                                   uint32_t* __restrict__ ls, uint32_t* __restrict__ lb, size_t nb) {
+  CHAIN_PRIORITY();
   size_t g = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (g >= nb) return;
   ls[g] = (x[g] - a[g] * e[g]) & LMASK;

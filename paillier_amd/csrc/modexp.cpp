@@ -439,7 +439,7 @@ void UnitCheck::begin(pgpu_ctx* c, const ModCtx& m, const uint32_t* x, size_t nb
   launch_pack_be(mem, WT, nbt, 1, d_rb, m.nbytes, m.nbytes, ctx->stream);
 }
 
-bool all_units(pgpu_ctx* ctx, const ModCtx& mc, const uint32_t* x, size_t nb, size_t count) {
+const uint8_t* all_units_begin(pgpu_ctx* ctx, const ModCtx& mc, const uint32_t* x, size_t nb, size_t count) {
   const int WT = mc.WT;
   size_t nbt = VM_BLOCK;
   int L = 8;
@@ -459,13 +459,20 @@ bool all_units(pgpu_ctx* ctx, const ModCtx& mc, const uint32_t* x, size_t nb, si
     run_vm(ctx, nbt, sg, nullptr, false, std::max<size_t>(VM_BLOCK, half));
   }
   launch_canon(mem, mc.d_nmod, WT, nbt, ctx->stream);
-  std::vector<uint8_t> rb(mc.nbytes);
+  uint8_t* rb = (uint8_t*)ctx->pinned(mc.nbytes);
   uint8_t* d_rb = (uint8_t*)ctx->ws(mc.nbytes);
   launch_pack_be(mem, WT, nbt, 1, d_rb, mc.nbytes, mc.nbytes, ctx->stream);
-  HIPCHK(hipMemcpyAsync(rb.data(), d_rb, mc.nbytes, hipMemcpyDeviceToHost, ctx->stream));
-  HIPCHK(hipStreamSynchronize(ctx->stream));
-  BigU root = BigU::from_be(rb.data(), rb.size()), rinv;
+  HIPCHK(hipMemcpyAsync(rb, d_rb, mc.nbytes, hipMemcpyDeviceToHost, ctx->stream));
+  return rb;
+}
+bool all_units_end(const ModCtx& mc, const uint8_t* root_be) {
+  BigU root = BigU::from_be(root_be, mc.nbytes), rinv;
   return hostbig::modinv(root, mc.N, rinv);
+}
+bool all_units(pgpu_ctx* ctx, const ModCtx& mc, const uint32_t* x, size_t nb, size_t count) {
+  const uint8_t* rb = all_units_begin(ctx, mc, x, nb, count);
+  HIPCHK(hipStreamSynchronize(ctx->stream));
+  return all_units_end(mc, rb);
 }
 
 // gmp.Int.ModInverse for a batch.  d_bad (device int32[nb], may be null) receives 1 on the lanes that are not units and 0

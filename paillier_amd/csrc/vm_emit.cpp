@@ -376,7 +376,16 @@ void run_vm(pgpu_ctx* ctx, size_t nb, const SegSpec& s0, const SegSpec* s1, bool
   for (int i = 0; i < 3; ++i) {
     if (!ss[i]) continue;
     VmSeg& g = a.seg[i];
-    g.prog = ctx->upload_words(ss[i]->prog->w);
+    if (ctx->background_launch && ss[i]->prog->montmuls >= 256) {
+      // a long ladder on a side lane whose result is not needed before the main stream's next ladders are done: priority 0 throughout, so
+      // that it takes the issue slots the main stream's waves leave instead of an equal share of their SIMDs
+      std::vector<uint32_t> bg(ss[i]->prog->w);
+      for (size_t k = 0; k + 1 < bg.size(); k += 2) bg[k] &= 0x3FFFFFFFu;
+      g.prog = ctx->upload_words(bg);
+      wipe_vec(bg);
+    } else {
+      g.prog = ctx->upload_words(ss[i]->prog->w);
+    }
     g.nmod = ss[i]->pair ? const_cast<uint32_t*>(ss[i]->pair) : ss[i]->mc->d_nmod;
     g.consts = ss[i]->tconsts ? const_cast<uint32_t*>(ss[i]->tconsts) : ss[i]->mc->d_consts;
     g.mem = ss[i]->mem;
