@@ -132,13 +132,17 @@ def test_ddleq_2048_secpar16_from_the_64_instance_fixture(ctx, keys):
     # instance beside the Alpha ladders, gathered afterwards)
     # struct = 0: the sanity values and Alpha by ladders on ct1 itself (pow_n3_crt) instead of through the structure of the unit
     # group (struct_pow_n3: plaintext of ct1, ladders modulo the primes, Teichmueller lift)
-    for lanes_wanted, side, nm4, early, struct in ((0, 1, 1, 1, 1), (1, 1, 1, 1, 1), (1, 1, 0, 1, 1), (0, 0, 1, 1, 1), (0, 1, 1, 0, 1),
-                                                    (1, 0, 1, 0, 1), (0, 1, 1, 1, 0), (1, 1, 1, 1, 0), (1, 1, 0, 1, 0), (0, 0, 1, 0, 0)):
+    # exclusive = 0: the placement of the call's concurrent launches left to the dispatcher (default for a call this small: every
+    # workgroup asks for a whole compute unit's LDS; with lanes_wanted = 1 the plan never asks for it)
+    for lanes_wanted, side, nm4, early, struct, excl in ((0, 1, 1, 1, 1, 1), (0, 1, 1, 1, 1, 0), (1, 1, 1, 1, 1, 1), (1, 1, 0, 1, 1, 1),
+                                                          (0, 0, 1, 1, 1, 1), (0, 1, 1, 0, 1, 1), (1, 0, 1, 0, 1, 1), (0, 1, 1, 1, 0, 1),
+                                                          (1, 1, 1, 1, 0, 1), (1, 1, 0, 1, 0, 1), (0, 0, 1, 0, 0, 0)):
         ctx.set_flag("lanes_wanted", lanes_wanted)
         ctx.set_flag("side", side)
         ctx.set_flag("nm4", nm4)
         ctx.set_flag("early", early)
         ctx.set_flag("struct", struct)
+        ctx.set_flag("exclusive", excl)
         try:
             al, es, fs = sk.ProveDDLEQBatch(16, col("ct1"), col("ct2"), col("a"), col("b"), xs, ys)
         finally:
@@ -147,8 +151,9 @@ def test_ddleq_2048_secpar16_from_the_64_instance_fixture(ctx, keys):
             ctx.set_flag("nm4", 1)
             ctx.set_flag("early", 1)
             ctx.set_flag("struct", 1)
+            ctx.set_flag("exclusive", 1)
         for j in range(4):
-            assert _digests(al[j], es[j], fs[j]) == [i["digest"] for i in by[j]], (lanes_wanted, side, nm4, early, struct, j)
+            assert _digests(al[j], es[j], fs[j]) == [i["digest"] for i in by[j]], (lanes_wanted, side, nm4, early, struct, excl, j)
 
 
 def test_ddleq_2048_kernels_off(ctx, keys):

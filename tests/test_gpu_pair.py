@@ -288,7 +288,7 @@ def test_decrypt_4096_bit_key(ctx, force_pair):
         ctx.set_flag("lanes_wanted", 0)
 
 
-@pytest.mark.parametrize("batch,lanes_wanted", [(96, 0), (96, 2 * 96), (700, 0)])
+@pytest.mark.parametrize("batch,lanes_wanted", [(96, 0), (96, 2 * 96), (400, 0)])
 def test_per_number_windows_number_major_and_limb_major(ctx, batch, lanes_wanted):
     """x_i^(e_i) mod n^2 with one exponent per number on the pair kernels (two and four lanes per number): the window tables
     number-major (VM_STORET / VM_MULVT, the default) and limb-major (flag nm4 = 0, VM_MULV) must give the same integers as pow();

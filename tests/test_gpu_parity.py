@@ -38,7 +38,7 @@ def test_modexp_shared_matches_python(ctx, bits):
     rng = random.Random(bits + 1)
     n = rand_odd(bits, rng)
     mod = pa.Modulus(ctx, n)
-    bases = [rng.randrange(n) for _ in range(70)] + [0, 1, n - 1]
+    bases = [rng.randrange(n) for _ in range(70 if bits <= 4096 else 24)] + [0, 1, n - 1]       # (the oracle's wide powers are the slow part)
     for e in (rng.getrandbits(bits // 2), 0, 1, 2, 31, 32, rng.getrandbits(200) << 77):
         got = mod.exp_batch(bases, e)
         assert got == [po.gmp_exp(x, e, n) for x in bases], f"e={e:#x}"
