@@ -28,7 +28,7 @@ int find_blob(int wl, int k) {
 
 bool vm_asm_available(int wl, int k) { return find_blob(wl, k) >= 0; }
 
-hipError_t launch_vm_asm(int wl, int k, const VmArgs& a, uint32_t blocks, hipStream_t st, bool exclusive) {
+hipError_t launch_vm_asm(int wl, int k, const VmArgs& a, uint32_t blocks, hipStream_t st, int lds_share) {
   int i = find_blob(wl, k);
   if (i < 0) return hipErrorInvalidValue;
   int dev = 0;
@@ -52,6 +52,10 @@ hipError_t launch_vm_asm(int wl, int k, const VmArgs& a, uint32_t blocks, hipStr
   size_t size = sizeof(VmArgs);
   void* extra[] = {HIP_LAUNCH_PARAM_BUFFER_POINTER, &args, HIP_LAUNCH_PARAM_BUFFER_SIZE, &size, HIP_LAUNCH_PARAM_END};
   const Loaded& L = g_loaded[i][dev];
-  const unsigned dyn = exclusive && L.lds_static >= 0 ? (unsigned)(kLdsPerCU - L.lds_static) : 0u;
+  unsigned dyn = 0;
+  if (L.lds_static >= 0) {
+    const int want = lds_share == 1 ? kLdsPerCU : lds_share == 2 ? kLdsPerCU / 2 + 2048 : 0;
+    if (want > L.lds_static) dyn = (unsigned)(want - L.lds_static);
+  }
   return hipModuleLaunchKernel(L.fn, blocks, 1, 1, VM_BLOCK, 1, 1, dyn, st, nullptr, extra);
 }

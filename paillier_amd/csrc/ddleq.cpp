@@ -1294,10 +1294,12 @@ static void ddleq_prove_impl(const pgpu_seckey* sk, size_t S, size_t secpar, con
     StructBase sbase;
     SideStream base_lane(ctx, 3);      // (a lane of its own: s keeps the side stream, beside the same launch)
     hipEvent_t residues_ready = nullptr, plaintext_ready = nullptr;
-    // (a call whose launches fill the chip: the side lanes' ladders yield to the main stream's -- a^n | x^n gates everything behind it, the
-    // plaintext of ct1 is needed after the lifts, s after the hash)
-    static const int bg_env = [] { const char* e = getenv("PGPU_BG"); return e ? atoi(e) : -1; }();
-    const bool side_yields = bg_env >= 0 ? bg_env != 0 : !ctx->exclusive_call;
+    // (PGPU_BG=1, measurements: the side lanes' ladders of a call that fills the chip at wave priority 0 -- a^n | x^n gates everything
+    // behind it, the plaintext of ct1 is needed after the lifts, s after the hash.  Measured with the main launch spread over the CUs
+    // (run_vm): 16 384 instances 130.4 ms without, 132.6 +- 4 with -- what a^n | x^n gains, the ladder modulo the primes and the lifts
+    // lose to the side launches that are still running beside them; secpar 40 the same within noise.  Off.)
+    static const int bg_env = [] { const char* e = getenv("PGPU_BG"); return e ? atoi(e) : 0; }();
+    const bool side_yields = bg_env != 0 && !ctx->exclusive_call;
     struct Background {
       pgpu_ctx* c; bool on;
       Background(pgpu_ctx* c_, bool on_) : c(c_), on(on_) { if (on) c->background_launch = true; }

@@ -49,7 +49,10 @@ hipError_t launch_vm(int wl, int k, const VmArgs& a, uint32_t blocks, hipStream_
 bool vm_asm_available(int wl, int k);
 // exclusive: every workgroup asks for all of a compute unit's LDS (dynamic part on top of the kernel's own), so that no other workgroup that uses LDS
 // shares its CU -- one wave per SIMD for launches that run beside each other (engine.hpp exclusive_call)
-hipError_t launch_vm_asm(int wl, int k, const VmArgs& a, uint32_t blocks, hipStream_t st, bool exclusive = false);
+// lds_share: 1 = the whole LDS of a CU (as above); 2 = more than half of it: at most ONE workgroup of such a launch per CU (other
+// launches' workgroups still fit beside it) -- a launch of up to 256 workgroups then spreads over all CUs, one wave per SIMD, where the
+// dispatcher sometimes stacks two of its workgroups on half the CUs (the prover's a^n | x^n launch: 28 or 47 ms, call by call)
+hipError_t launch_vm_asm(int wl, int k, const VmArgs& a, uint32_t blocks, hipStream_t st, int lds_share = 0);
 static_assert(sizeof(VmArgs) == 152, "VmArgs layout is hard-coded in gen_vm_asm.py (select_segment)");
 
 void launch_unpack_be(const uint8_t* in, size_t stride, size_t nbytes, size_t count, uint32_t* out, int wt, size_t nb, hipStream_t st);

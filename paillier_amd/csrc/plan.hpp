@@ -15,6 +15,7 @@
 namespace plan {
 
 constexpr int LB = 28;                          // bits of a limb
+constexpr uint32_t kChipCUs = 256;
 constexpr size_t kChipLanes = (size_t)1024 * 64;   // 256 CUs x 4 SIMDs x 64 lanes: one wave on every SIMD
 constexpr uint64_t kGatherSpan = 1ull << 32;    // per-number table gathers of the assembly kernels use 32-bit byte offsets
 
@@ -138,15 +139,16 @@ inline int shared_chain_groups(size_t nbs, int S, size_t lt, bool have8) {
   return (int)std::max<size_t>(1, std::min<size_t>(std::min(S, 3), room));
 }
 
-// Launches of one call that run BESIDE each other (main stream + side lanes) take a compute unit per workgroup (the whole LDS of the
-// CU is asked for) where all of them together roughly fit the chip: the dispatcher otherwise starts every queue's workgroups from the
-// same CUs, and three latency-bound launches share the SIMDs of a quarter of the chip while the rest idles.  The prover's widest
-// launch is a^n | x^n: (statements + instances) numbers, two primes, two lanes each at this size (128 workgroups at 4 096 instances);
-// the two side lanes are at most as wide.  Measured (ms per call, dispatcher's placement | a CU per workgroup): 2 048 instances
-// 75.0 | 58.5, 4 096: 79.0 | 69.2, 8 192: 95 | 101 (the launches no longer fit side by side: a second round of workgroups).
+// Launches of one call that run BESIDE each other (main stream + side lanes): a launch of at most kExclusiveMaxBlocks workgroups asks
+// for the whole LDS of a compute unit per workgroup (run_vm), so that it lands on CUs of its own: the dispatcher otherwise starts every
+// queue's workgroups from the same CUs, and three latency-bound launches share the SIMDs of a quarter of the chip while the rest idles.
+// Measured on the prover (ms per call, dispatcher's placement | a CU per workgroup): 2 048 instances 74.9 | 58.5, 4 096: 77.5 | 71.1,
+// 8 192: 97.4 | 93.1, 12 288: 115.5 | 113.8, 16 384: 130.3 | 129.0, 1 536 x 40: 203 | 200 -- wider launches keep their placement (two
+// workgroups per CU beat a second round), so the rule holds for every call size.
 constexpr uint32_t kExclusiveMaxBlocks = 128;
 inline bool exclusive_cus(size_t nb_statements, size_t nb_instances, size_t lt = kChipLanes) {
-  return (nb_statements + nb_instances) * 8 <= lt;
+  (void)nb_statements; (void)nb_instances; (void)lt;
+  return true;
 }
 
 }  // namespace plan

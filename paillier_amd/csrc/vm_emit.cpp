@@ -478,7 +478,13 @@ void run_vm(pgpu_ctx* ctx, size_t nb, const SegSpec& s0, const SegSpec* s1, bool
   if (ev) snprintf(ev->name, sizeof ev->name, use_asm ? "vm_asm_%d_%d" : "vm_kernel<%d,%d>", WL, K);
   // (a launch wider than half the chip's CUs keeps the dispatcher's placement: two of its workgroups per CU beat a second round)
   const bool exclusive = use_asm && ctx->use_exclusive && ctx->exclusive_call && blocks <= plan::kExclusiveMaxBlocks;
-  hipError_t e = use_asm ? launch_vm_asm(WL, K, a, blocks, ctx->stream, exclusive) : launch_vm(WL, K, a, blocks, ctx->stream);
+  // A main-stream launch of at most one workgroup per CU spreads over the CUs (see launch_vm_asm); the side lanes' launches keep
+  // their own LDS size and fit beside it.
+  static const int spread_env = [] { const char* v = getenv("PGPU_SPREAD"); return v ? atoi(v) : 1; }();
+  const bool on_side = ctx->stream == ctx->side || ctx->stream == ctx->side_l[0] || ctx->stream == ctx->side_l[1] || ctx->stream == ctx->side_l[2];
+  const bool spread = use_asm && ctx->use_exclusive && spread_env && !on_side && blocks <= plan::kChipCUs && montmuls >= 256;
+  const int lds_share = exclusive ? 1 : spread ? 2 : 0;
+  hipError_t e = use_asm ? launch_vm_asm(WL, K, a, blocks, ctx->stream, lds_share) : launch_vm(WL, K, a, blocks, ctx->stream);
   if (use_asm) ctx->last_vm_asm++;
   ctx->last_vm_launches++;
   if (e != hipSuccess) throw HipError{e, "launch_vm"};

@@ -138,12 +138,11 @@ def test_extract_randomness_beside_the_first_launch(q):
     assert q("shared_chain_groups", 2048, 3, 0, 1) == [3]
     assert q("shared_chain_groups", 256, 2, 0, 1) == [2]
     assert q("shared_chain_groups", 2048, 3, 0, 0) == [1]
-    # a compute unit per workgroup for the concurrent launches of a small call: up to 4 096 instances at secpar 1 (measured: 8 192 loses)
+    # a compute unit per workgroup for the small concurrent launches of a prover call: every call size (launches wider than 128
+    # workgroups never take part -- run_vm)
     assert q("exclusive_cus", 2048, 2048, 0) == [1]
-    assert q("exclusive_cus", 4096, 4096, 0) == [1]
-    assert q("exclusive_cus", 8192, 8192, 0) == [0]
-    assert q("exclusive_cus", 256, 8192, 0) == [0]
-    assert q("exclusive_cus", 256, 4096, 0) == [1]
+    assert q("exclusive_cus", 16384, 16384, 0) == [1]
+    assert q("exclusive_cus", 1536, 61440, 0) == [1]
 
 
 PAIR_SHARED = [
