@@ -543,7 +543,7 @@ def main():
         okh = np.zeros(BD, dtype=np.int32)
         dt, vms, mads, kern = timed(lambda: one_call(lambda: sk2.ddleq_prove_raw(
             BD, ct1.data_ptr(), ct2.data_ptr(), da.data_ptr(), db.data_ptr(), dx.data_ptr(), dy.data_ptr(), al.data_ptr(),
-            pe.data_ptr(), pf.data_ptr(), MEM_DEVICE)), 1)
+            pe.data_ptr(), pf.data_ptr(), MEM_DEVICE)), max(ES, 3))       # (a call's time varies by a few per cent: three of them)
         extras.append(entry("ddleq_prove_2048", "16384 DDLEQ instances (secpar = 1 each), 2048-bit n: sanity check, Alpha, "
                             "Fiat-Shamir bit, response through level-two ExtractRandonness (ddleq.go:55-127)",
                             "instances/s", BD_ALL, dt, vms, mads, kern, "every proof verifies (below)", scaling="strong"))
@@ -575,7 +575,7 @@ def main():
         pf = torch.zeros((BI, cb3), dtype=torch.uint8, device=dev)
         dt, vms, mads, kern = timed(lambda: one_call(lambda: sk2.ddleq_prove_secpar_raw(
             NS, SP, s1.data_ptr(), s2.data_ptr(), sa.data_ptr(), sb.data_ptr(), sx.data_ptr(), sy.data_ptr(), al.data_ptr(),
-            pe.data_ptr(), pf.data_ptr(), MEM_DEVICE)), 1)
+            pe.data_ptr(), pf.data_ptr(), MEM_DEVICE)), max(ES, 2))
         # verify: every instance against its statement (rows of ct1 / ct2 repeated per instance)
         rep = torch.arange(NS, device=dev).repeat_interleave(SP)
         okh = np.zeros(BI, dtype=np.int32)
