@@ -335,7 +335,9 @@ func (k *GPUPublicKey) PartialDecryptIndexedBatch(tsks []*ThresholdSecretKey, se
 // tsks[u / len(c)].PartialDecrypt(c[u % len(c)]) (thresholdkey.go:192-201).  Unlike PartialDecryptIndexedBatch the library sees
 // that two units are the SAME ciphertext under two shares: such ciphertexts walk one chain of squarings for both exponents
 // (pgpu_partial_decrypt_units; a rank of two holds one server whole and half of the next).  Only the shares of the servers
-// the range touches are read.
+// the range touches are read.  A holder of EVERY share shards by ciphertexts instead: rank r calls this with its slice of c and the
+// slice's whole unit range [0, len(tsks)*len(slice)) and combines locally -- no exchange (paillier_amd/dist.py
+// threshold_decrypt_ciphertext_major; the shares of a ciphertext then split into chains of their own as the batch shrinks).
 func (k *GPUPublicKey) PartialDecryptUnitsBatch(tsks []*ThresholdSecretKey, c []*gmp.Int, unitBegin, unitEnd int) ([]*PartialDecryption, error) {
 	defer pin()()
 	n := len(tsks)

@@ -214,7 +214,9 @@ int pgpu_partial_decrypt_multi(const pgpu_pubkey* pk, int total_servers, int n_s
  * server-major range [unit_begin, unit_end) over ONE batch of ciphertexts (thresholdkey.go:192-201 for each unit; shares[s] is
  * server s's share, only those the range touches are read).  Ciphertexts the range wants under several shares walk ONE chain
  * of squarings for all of them; the rest run their ladders side by side in the same launch.  out: unit_end - unit_begin rows,
- * in unit order.  Same integers as pgpu_partial_decrypt per server. */
+ * in unit order.  Same integers as pgpu_partial_decrypt per server.  (The whole unit range of a ciphertext SLICE is the shard of a
+ * rank that holds every share: from 8 192 ciphertexts one chain for all shares, below that the shares split into up to three groups
+ * with a chain each while every group keeps a SIMD per wave on the eight-lane kernel.) */
 int pgpu_partial_decrypt_units(const pgpu_pubkey* pk, int total_servers, int n_shares, const uint8_t* const* shares_be,
                                const size_t* share_lens, size_t batch, const uint8_t* c, size_t c_stride, size_t unit_begin,
                                size_t unit_end, uint8_t* out, size_t out_stride, int mem);
