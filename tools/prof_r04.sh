@@ -38,7 +38,7 @@ for f in glob.glob(f"{out}/pmc_*/**/*counter_collection.csv", recursive=True):
     per = collections.defaultdict(float)
     for r in csv.DictReader(open(f)):
         for k in kernels:
-            if r["Kernel_Name"].startswith(k):
+            if r["Kernel_Name"] in (k, k + ".kd"):          # (exact: vm_asm_37_1 is a prefix of vm_asm_37_16)
                 # one entry per launch shape: the same kernel runs 65536- and 131072-ciphertext batches in bench.py
                 kk = f'{k} grid {r["Grid_Size"]}' if "Grid_Size" in r else k
                 per[(kk, r["Dispatch_Id"], r["Counter_Name"])] += float(r["Counter_Value"])
