@@ -733,6 +733,12 @@ struct Sha256 {
     ++fill; ++total;
     if (fill == 64) block();
   }
+  // a whole big-endian word at once; only while the block position is word-aligned
+  __device__ void put_word(uint32_t x) {
+    w[fill >> 2] = x;
+    fill += 4; total += 4;
+    if (fill == 64) block();
+  }
   __device__ void finish() {
     uint64_t bits = total * 8;
     put(0x80); --total;
@@ -763,13 +769,30 @@ __global__ void k_sha256_transcript(ShaArgs a, size_t nb, size_t count, uint32_t
       if (v) { top = (long)l * LB + (31 - __clz(v)); break; }
     }
     if (top < 0) continue;                       // zero: Bytes() is empty
-    for (long byte = top / 8; byte >= 0; --byte) {
+    auto byte_at = [&](long byte) {
       long bit = byte * 8;
       int l = (int)(bit / LB), sh = (int)(bit % LB);
       uint64_t v = p[(size_t)l * nb + g];
       if (l + 1 < w) v |= (uint64_t)p[(size_t)(l + 1) * nb + g] << LB;
-      s.put((uint8_t)(v >> sh));
+      return (uint8_t)(v >> sh);
+    };
+    long byte = top / 8;
+    // bytes one at a time up to a word boundary of the block, then whole words (the transcript of a DDLEQ instance is 2 KB per
+    // lane and sits between Alpha and the response on the prover's critical path: 1.8 ms byte by byte), then the tail
+    while (byte >= 0 && (s.fill & 3)) s.put(byte_at(byte--));
+    if (byte >= 3) {
+      long bit = (byte - 3) * 8;                 // lowest bit of the word whose top byte is `byte`
+      int l = (int)(bit / LB), sh = (int)(bit % LB);
+      for (; byte >= 3; byte -= 4) {
+        uint64_t v = p[(size_t)l * nb + g];
+        if (l + 1 < w) v |= (uint64_t)p[(size_t)(l + 1) * nb + g] << LB;
+        if (l + 2 < w) v |= (uint64_t)p[(size_t)(l + 2) * nb + g] << (2 * LB);
+        s.put_word((uint32_t)(v >> sh));
+        sh -= 32;
+        while (sh < 0) { sh += LB; --l; }
+      }
     }
+    while (byte >= 0) s.put(byte_at(byte--));
   }
   s.finish();
   if (digest_out)
