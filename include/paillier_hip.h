@@ -96,7 +96,8 @@ int pgpu_ctx_last_profile(pgpu_ctx* ctx, double* vm_ms, int* vm_launches, double
  * ladders on ct1 itself; non-unit inputs always take those); "exclusive" (default 1): placement by LDS size -- the small concurrent launches
  * of a prover call (up to 128 workgroups) ask for the whole LDS of a compute unit per workgroup, so that the side lanes' workgroups
  * land on idle CUs instead of the ones the main launch runs on, and a main-stream ladder of at most one workgroup per CU asks for more
- * than half of it, so that it spreads over all CUs (0: the dispatcher's placement).
+ * than half of it, so that it spreads over all CUs (0: the dispatcher's placement); "background" (default 0): the prover's side-lane
+ * ladders run at wave priority 0 (measured: no gain).
  * All of these change the work done, never a result (the tests switch them off to compare).
  * "lanes_wanted" (default 0 = fill the chip): the lane count below which a batch is re-sliced over more lanes per
  * number; 1 keeps every modulus on its natural kernel shape whatever the batch size (tests).

@@ -82,6 +82,7 @@ int pgpu_ctx_set_flag(pgpu_ctx* ctx, const char* name, int value) {
   if (strcmp(name, "shared_chain") == 0) { ctx->use_shared_chain = value != 0; return PGPU_OK; }
   if (strcmp(name, "lift") == 0) { ctx->use_lift = value != 0; return PGPU_OK; }
   if (strcmp(name, "side") == 0) { ctx->use_side = value != 0; return PGPU_OK; }
+  if (strcmp(name, "background") == 0) { ctx->use_background = value != 0; return PGPU_OK; }
   if (strcmp(name, "exclusive") == 0) { ctx->use_exclusive = value != 0; return PGPU_OK; }
   if (strcmp(name, "struct") == 0) { ctx->use_struct = value != 0; return PGPU_OK; }
   if (strcmp(name, "lanes8") == 0) { ctx->use_lanes8 = value != 0; return PGPU_OK; }

@@ -1221,8 +1221,7 @@ static void ddleq_prove_impl(const pgpu_seckey* sk, size_t S, size_t secpar, con
       pgpu_ctx* c;
       ExclusiveCall(pgpu_ctx* c_, bool on) : c(c_) { c->exclusive_call = on; }
       ~ExclusiveCall() { c->exclusive_call = false; }
-    } exclusive_call(ctx, getenv("PGPU_EXCL_FORCE") ? atoi(getenv("PGPU_EXCL_FORCE")) != 0
-                                                    : plan::exclusive_cus(nbs, nb, plan::lanes_target(ctx->lanes_wanted)));
+    } exclusive_call(ctx, plan::exclusive_cus(nbs, nb, plan::lanes_target(ctx->lanes_wanted)));
     if (ct_stride != mn3.nbytes) api_throw(PGPU_ERR_INVALID, "ciphertext stride must be the byte length of n^3");
     if (n_stride * 8 > (size_t)LB * W1 + 7) api_throw(PGPU_ERR_INVALID, "a, b, x, y must fit the width of n");
     auto up = [&](const uint8_t* buf, size_t stride, int w, size_t count, size_t nbx) {
@@ -1294,12 +1293,11 @@ static void ddleq_prove_impl(const pgpu_seckey* sk, size_t S, size_t secpar, con
     StructBase sbase;
     SideStream base_lane(ctx, 3);      // (a lane of its own: s keeps the side stream, beside the same launch)
     hipEvent_t residues_ready = nullptr, plaintext_ready = nullptr;
-    // (PGPU_BG=1, measurements: the side lanes' ladders of a call that fills the chip at wave priority 0 -- a^n | x^n gates everything
-    // behind it, the plaintext of ct1 is needed after the lifts, s after the hash.  Measured with the main launch spread over the CUs
-    // (run_vm): 16 384 instances 130.4 ms without, 132.6 +- 4 with -- what a^n | x^n gains, the ladder modulo the primes and the lifts
-    // lose to the side launches that are still running beside them; secpar 40 the same within noise.  Off.)
-    static const int bg_env = [] { const char* e = getenv("PGPU_BG"); return e ? atoi(e) : 0; }();
-    const bool side_yields = bg_env != 0 && !ctx->exclusive_call;
+    // (flag "background", measurements: the side lanes' ladders of a call that fills the chip at wave priority 0 -- a^n | x^n gates
+    // everything behind it, the plaintext of ct1 is needed after the lifts, s after the hash.  Measured with the main launch spread over
+    // the CUs (run_vm): 16 384 instances 130.4 ms without, 132.6 +- 4 with -- what a^n | x^n gains, the ladder modulo the primes and the
+    // lifts lose to the side launches that are still running beside them; secpar 40 the same within noise.  Off by default.)
+    const bool side_yields = ctx->use_background;
     struct Background {
       pgpu_ctx* c; bool on;
       Background(pgpu_ctx* c_, bool on_) : c(c_), on(on_) { if (on) c->background_launch = true; }

@@ -98,6 +98,7 @@ struct pgpu_ctx {
   bool exclusive_call = false;   // set by a protocol function for the length of a call whose concurrent launches together fit the chip's compute units: every
                                  // workgroup then asks for the whole LDS of a CU, so the dispatcher cannot stack the side lanes' workgroups on the CUs the main
                                  // launch runs on (it starts every queue's workgroups from the same CUs: 17.5 -> 28 ms for a^n | x^n of 2 048 instances)
+  bool use_background = false;   // the prover's side-lane ladders at wave priority 0 (pgpu_ctx_set_flag("background", 1): measured, no gain -- ddleq.cpp)
   bool background_launch = false; // set around side-lane ladders of a LARGE call (see run_vm): their long programs run at wave priority 0
   bool use_handover = true;  // a power modulo n^2 that is only needed modulo n^2 by the next ladder modulo n^3 stays in pair form: (a0, a1, 0) is its digit form (pgpu_ctx_set_flag("handover", 0): exit and re-entry)
   bool use_muls = true;      // bucket products of the shared chain as VM_MULS where the kernel has it (pgpu_ctx_set_flag("muls", 0): LOAD / MUL / STORE)

@@ -136,13 +136,14 @@ def test_ddleq_2048_secpar16_from_the_64_instance_fixture(ctx, keys):
     # workgroup asks for a whole compute unit's LDS; with lanes_wanted = 1 the plan never asks for it)
     for lanes_wanted, side, nm4, early, struct, excl in ((0, 1, 1, 1, 1, 1), (0, 1, 1, 1, 1, 0), (1, 1, 1, 1, 1, 1), (1, 1, 0, 1, 1, 1),
                                                           (0, 0, 1, 1, 1, 1), (0, 1, 1, 0, 1, 1), (1, 0, 1, 0, 1, 1), (0, 1, 1, 1, 0, 1),
-                                                          (1, 1, 1, 1, 0, 1), (1, 1, 0, 1, 0, 1), (0, 0, 1, 0, 0, 0)):
+                                                          (1, 1, 1, 1, 0, 1), (1, 1, 0, 1, 0, 1), (0, 0, 1, 0, 0, 0), (0, 1, 1, 1, 1, 2)):
         ctx.set_flag("lanes_wanted", lanes_wanted)
         ctx.set_flag("side", side)
         ctx.set_flag("nm4", nm4)
         ctx.set_flag("early", early)
         ctx.set_flag("struct", struct)
-        ctx.set_flag("exclusive", excl)
+        ctx.set_flag("exclusive", excl & 1)
+        ctx.set_flag("background", excl >> 1)        # (excl = 2: the side lanes' ladders at wave priority 0, placement left alone)
         try:
             al, es, fs = sk.ProveDDLEQBatch(16, col("ct1"), col("ct2"), col("a"), col("b"), xs, ys)
         finally:
@@ -152,6 +153,7 @@ def test_ddleq_2048_secpar16_from_the_64_instance_fixture(ctx, keys):
             ctx.set_flag("early", 1)
             ctx.set_flag("struct", 1)
             ctx.set_flag("exclusive", 1)
+            ctx.set_flag("background", 0)
         for j in range(4):
             assert _digests(al[j], es[j], fs[j]) == [i["digest"] for i in by[j]], (lanes_wanted, side, nm4, early, struct, excl, j)
 
