@@ -46,6 +46,7 @@ int pgpu_pair_debug_run(pgpu_ctx* ctx, const uint8_t* p_be, size_t p_len, int la
  *   "pair_nm4_fits"       (nb, w2)                                 -> ok
  *   "shared_chain_pays"   (nb, lanes_wanted)                       -> ok
  *   "triple_two_lanes_per_digit" (nb, lanes_wanted)                -> ok
+ *   "dual_n3_two_ladders" (nb, lanes_wanted) -> ok   (x^(e0) and W^n modulo n^3 as two eight-lane ladders side by side)
  *   "perlane_table_slots" (wb, nm)                                 -> slots
  *   "gather_entries"      (wb)                                     -> entries
  * lanes_wanted = 0 means the default (one wave on every SIMD: 65 536 lanes).  Returns the number of outputs written, or

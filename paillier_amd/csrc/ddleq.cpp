@@ -84,6 +84,51 @@ uint32_t* dual_pow_n3(pgpu_ctx* ctx, const pgpu_pubkey* pk, const uint32_t* x, c
     const uint32_t tab2 = 5 + (uint32_t)perlane_table_slots(wb, nm5);
     TriplePlan tp = triple_alloc(ctx, mn3, nb, (int)tab2 + (1 << (dual_sliding_bits(wb) - 1)));
     const bool hand = ctx->use_handover && mn2.pairn.root && mn2.pairn.root->WT == mn3.triple.root->WT;
+    // A batch so small that two eight-lane ladders still find a SIMD per wave side by side: x^(e0) does not depend on W, so it runs as a
+    // ladder of its own on a side lane -- beside the W ladder modulo n^2 and W^n modulo n^3 -- and one product joins them.  The chain
+    // E^n -> W -> W^n is then the run time (2 048 numbers: the interleaved ladder 45 ms, W^n alone 34); launches on CUs of their own.
+    const bool two_ladders = six && plan::dual_n3_two_ladders(nb, plan::lanes_target(ctx->lanes_wanted));
+    if (two_ladders) {
+      struct Excl {
+        pgpu_ctx* c; bool was;
+        explicit Excl(pgpu_ctx* c_) : c(c_), was(c_->exclusive_call) { c->exclusive_call = true; }
+        ~Excl() { c->exclusive_call = was; }
+      } excl(ctx);
+      TriplePlan tx = triple_alloc(ctx, mn3, nb, 5 + perlane_table_slots(5, false));
+      TriplePlan tw = triple_alloc(ctx, mn3, nb, 5 + 32);
+      Fork ft(ctx, 3);
+      ft.chain(2);
+      triple_enter(ctx, mn3, pc.in(), tx, 0);
+      {
+        Prog px;
+        emit_modexp_perlane(px, W1, 0, NO_SLOT, 2, 3, 5, NO_SLOT, 0, 5, false);
+        px.end();
+        triple_run(ctx, mn3, tx, px, triple_windows(ctx, e0, W1, nb, 5));
+      }
+      ft.chain(0);
+      uint32_t* raw = nullptr;
+      uint32_t* wv = dual_pow_pair(ctx, mn2, x2, e1, W1, y2, pk->N, nb, hand ? &raw : nullptr);
+      if (wv) {
+        if (raw) {
+          triple_from_pair(ctx, raw, tw, 0);
+        } else {
+          launch_copy_limbs(wv, 0, W2, pc.in() + pc.slot_words, W3, nb, ctx->stream);    // slot 1 <- W, zero-extended
+          triple_enter(ctx, mn3, pc.in() + pc.slot_words, tw, 0);
+        }
+        Prog pw;
+        emit_modexp_shared(pw, pk->N, 0, NO_SLOT, 2, 3, 5, NO_SLOT, true, true);
+        pw.end();
+        triple_run(ctx, mn3, tw, pw, nullptr);
+        ft.join();
+        HIPCHK(hipMemcpyAsync(tw.slot(1), tx.slot(3), tw.slot_words * 4, hipMemcpyDeviceToDevice, ctx->stream));
+        Prog pm;
+        pm.op(VM_LOAD, 3); pm.op(VM_MUL, 1); pm.op(VM_STORE, 3); pm.end();
+        triple_run(ctx, mn3, tw, pm, nullptr);
+        triple_exit(ctx, mn3, tw, 3, pc.out(), nullptr);
+        return pc.out();
+      }
+      ft.join();                                   // (no pair kernel for this key: the interleaved ladder below)
+    }
     Fork ft(ctx, 3);
     ft.chain(2);                                   // (lane 2: dual_pow_pair forks its own two entries over lanes 0 and 1)
     triple_enter(ctx, mn3, pc.in(), tp, 0);

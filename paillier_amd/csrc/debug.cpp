@@ -135,6 +135,7 @@ int pgpu_plan_query(const char* what, const uint64_t* a, int nargs, int64_t* out
   if (w == "dual_pair_window_bits" && need(3, 1)) { out[0] = plan::dual_pair_window_bits((size_t)a[0], (int)a[1], a[2] != 0); return 1; }
   if (w == "pair_nm4_fits" && need(2, 1)) { out[0] = plan::pair_nm4_fits((size_t)a[0], (int)a[1]); return 1; }
   if (w == "shared_chain_pays" && need(2, 1)) { out[0] = plan::shared_chain_pays((size_t)a[0], lt(1)); return 1; }
+  if (w == "dual_n3_two_ladders" && need(2, 1)) { out[0] = plan::dual_n3_two_ladders((size_t)a[0], lt(1)); return 1; }
   if (w == "triple_two_lanes_per_digit" && need(2, 1)) { out[0] = plan::triple_two_lanes_per_digit((size_t)a[0], lt(1)); return 1; }
   if (w == "perlane_table_slots" && need(2, 1)) { out[0] = plan::perlane_table_slots((int)a[0], a[1] != 0); return 1; }
   if (w == "gather_entries" && need(1, 1)) { out[0] = plan::gather_entries((int)a[0]); return 1; }

@@ -80,6 +80,9 @@ inline bool crt_pair_usable(int lanes_now, int prime_limbs, size_t nb, size_t lt
 
 // three-digit kernel: two lanes per digit (GenQ6) for batches so small that eight lanes per number still leave every wave a SIMD
 inline bool triple_two_lanes_per_digit(size_t nb, size_t lt) { return nb * 8 <= lt; }
+// ... and x^(e0) W^n modulo n^3 (the verifier, NestedRandomize) as TWO such ladders side by side instead of one interleaved chain while
+// both still find a SIMD per wave: up to 4 096 numbers
+inline bool dual_n3_two_ladders(size_t nb, size_t lt) { return nb * 8 * 2 <= lt; }
 
 // several shares on the same ciphertexts: ONE chain of squarings when the batch fills at least half the chip on its own
 inline bool shared_chain_pays(size_t nb, size_t lt) { return nb * 8 >= lt; }

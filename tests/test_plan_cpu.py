@@ -131,6 +131,10 @@ def test_extract_randomness_beside_the_first_launch(q):
     assert q("extract_beside", 1536, 61440, 0) == [1]        # secpar 40: the side launch is a few dozen waves
     assert q("extract_beside", 32768, 32768, 0) == [0]       # both wave slots taken: s follows on the main stream
     assert q("extract_beside", 2048, 2048, 0) == [1]
+    # the verifier's x^(e0) W^n modulo n^3 as two eight-lane ladders side by side: up to 4 096 numbers
+    assert q("dual_n3_two_ladders", 2048, 0) == [1]
+    assert q("dual_n3_two_ladders", 4096, 0) == [1]
+    assert q("dual_n3_two_ladders", 8192, 0) == [0]
     # a ciphertext-major threshold shard: groups of shares with a chain each while every group still has a SIMD per wave at 8 lanes
     assert q("shared_chain_groups", 16384, 3, 0, 1) == [1]
     assert q("shared_chain_groups", 8192, 3, 0, 1) == [1]
