@@ -47,7 +47,44 @@ namespace pgi {
 // x^(per-number exponent, W2 limbs) * y^(n^2) mod n^3 as ONE interleaved ladder (emit_modexp_dual): the verifier's
 // check^(E^n) * F^(n^2) (ddleq.go:143-152) and NestedRandomize's ct^(a^n) * b^(n^2) (operations.go:108-114).
 // x, y: W3-limb arrays (any value below R); returns the canonical result (W3 limbs, stride nb).
-uint32_t* dual_pow_n3(pgpu_ctx* ctx, const pgpu_pubkey* pk, const uint32_t* x, const uint32_t* exps, const uint32_t* y, size_t nb) {
+// (does a batch of nb numbers take the two-ladder form below?  Its callers then run y^n modulo n^2 beside their own first ladder.)
+static bool dual_n3_two(pgpu_ctx* ctx, const pgpu_pubkey* pk, size_t nb) {
+  const ModCtx &mn2 = pk->mn2, &mn3 = *pk->mn3;
+  if (!(triple_usable(ctx, mn3) && plan::triple_batch_fits(nb, mn3.WT) && ctx->use_lift)) return false;
+  const int H3 = mn3.triple.root->WT;
+  const PairInfo& pi = mn2.pairn;
+  const bool six = ctx->use_lanes8 && H3 % 2 == 0 && vm_asm_available(H3 / 2, 112) &&
+                   plan::triple_two_lanes_per_digit(nb, plan::lanes_target(ctx->lanes_wanted));
+  return six && pi.root && pi.c_one_pair >= 0 && ctx->use_asm && ctx->use_pair && ctx->use_side &&
+         plan::dual_n3_two_ladders(nb, plan::lanes_target(ctx->lanes_wanted));
+}
+// y^n modulo n^2 (y: W3 limbs, any value below R) on a side lane, beside the caller's ladder that produces the per-number exponents;
+// join() before dual_pow_n3 uses it
+struct YPower {
+  SideStream lane;
+  uint32_t* yn = nullptr;
+  YPower(pgpu_ctx* ctx, const pgpu_pubkey* pk, const uint32_t* y, size_t nb, bool wanted) : lane(ctx, 2) {
+    if (!wanted || !lane.on) return;
+    const ModCtx &mn2 = pk->mn2, &mn3 = *pk->mn3;
+    hipEvent_t ready = lane.mark();
+    lane.enter(ready);
+    uint32_t* y2 = ctx->ws_t<uint32_t>((size_t)mn2.WT * nb);
+    reduce_mod(ctx, mn2, y, mn3.WT, y2, nb);
+    yn = ctx->ws_t<uint32_t>((size_t)mn2.WT * nb);
+    shared_pow(ctx, mn2, y2, mn2.WT, pk->N, nb, yn);
+    lane.leave();
+  }
+  const uint32_t* get() { lane.join(); return yn; }
+};
+struct ExclusiveScope {
+  pgpu_ctx* c; bool was;
+  ExclusiveScope(pgpu_ctx* c_, bool on) : c(c_), was(c_->exclusive_call) { if (on) c->exclusive_call = true; }
+  ~ExclusiveScope() { c->exclusive_call = was; }
+};
+
+uint32_t* dual_pow_n3(pgpu_ctx* ctx, const pgpu_pubkey* pk, const uint32_t* x, const uint32_t* exps, const uint32_t* y, size_t nb,
+                      const uint32_t* yn2 = nullptr) {
+  // yn2 (optional): y^n modulo n^2, canonical -- the two-ladder form then runs x^(e1) alone and multiplies
   const ModCtx &mn2 = pk->mn2, &mn3 = *pk->mn3;
   const int W2 = mn2.WT, W3 = mn3.WT;
   const bool use3 = triple_usable(ctx, mn3) && plan::triple_batch_fits(nb, W3);
@@ -89,11 +126,7 @@ uint32_t* dual_pow_n3(pgpu_ctx* ctx, const pgpu_pubkey* pk, const uint32_t* x, c
     // E^n -> W -> W^n is then the run time (2 048 numbers: the interleaved ladder 45 ms, W^n alone 34); launches on CUs of their own.
     const bool two_ladders = six && plan::dual_n3_two_ladders(nb, plan::lanes_target(ctx->lanes_wanted));
     if (two_ladders) {
-      struct Excl {
-        pgpu_ctx* c; bool was;
-        explicit Excl(pgpu_ctx* c_) : c(c_), was(c_->exclusive_call) { c->exclusive_call = true; }
-        ~Excl() { c->exclusive_call = was; }
-      } excl(ctx);
+      ExclusiveScope excl(ctx, true);
       TriplePlan tx = triple_alloc(ctx, mn3, nb, 5 + perlane_table_slots(5, false));
       TriplePlan tw = triple_alloc(ctx, mn3, nb, 5 + 32);
       Fork ft(ctx, 3);
@@ -107,7 +140,7 @@ uint32_t* dual_pow_n3(pgpu_ctx* ctx, const pgpu_pubkey* pk, const uint32_t* x, c
       }
       ft.chain(0);
       uint32_t* raw = nullptr;
-      uint32_t* wv = dual_pow_pair(ctx, mn2, x2, e1, W1, y2, pk->N, nb, hand ? &raw : nullptr);
+      uint32_t* wv = dual_pow_pair(ctx, mn2, x2, e1, W1, yn2 ? yn2 : y2, pk->N, nb, hand ? &raw : nullptr, yn2 != nullptr);
       if (wv) {
         if (raw) {
           triple_from_pair(ctx, raw, tw, 0);
@@ -194,14 +227,18 @@ int pgpu_nested_randomize_with_ab(const pgpu_pubkey* pk, size_t batch, const uin
     const int W2 = mn2.WT, W3 = mn3.WT;
     const size_t nb = round_up(batch, VM_BLOCK);
     // an = a^n mod n^2 (operations.go:108); r = ct^an * b^(n^2) mod n^3 (:109-114)
-    ModexpPlan pa_ = modexp_alloc(ctx, mn2, nb, 32);
-    unpack_mod(ctx, mn2, a, ab_stride, batch, mem, pa_.in(), nb);
-    modexp_shared_run(ctx, mn2, pa_, pk->N, false, false, true);
+    // (a batch so small that the ladders are latency: b^n modulo n^2 runs beside a^n, on CUs of its own -- dual_pow_n3's two-ladder form)
+    const bool two = dual_n3_two(ctx, pk, nb);
+    ExclusiveScope excl(ctx, two);
     uint32_t* x = ctx->ws_t<uint32_t>((size_t)W3 * nb);
     uint32_t* y = ctx->ws_t<uint32_t>((size_t)W3 * nb);
     unpack_mod(ctx, mn3, ct, ct_stride, batch, mem, x, nb);
     unpack_mod(ctx, mn3, b, ab_stride, batch, mem, y, nb);
-    uint32_t* res = dual_pow_n3(ctx, pk, x, pa_.out(), y, nb);
+    YPower bn(ctx, pk, y, nb, two);
+    ModexpPlan pa_ = modexp_alloc(ctx, mn2, nb, 32);
+    unpack_mod(ctx, mn2, a, ab_stride, batch, mem, pa_.in(), nb);
+    modexp_shared_run(ctx, mn2, pa_, pk->N, false, false, true);
+    uint32_t* res = dual_pow_n3(ctx, pk, x, pa_.out(), y, nb, bn.get());
     pack_result(ctx, res, W3, nb, batch, out, out_stride, mn3.nbytes, mem);
     HIPCHK(hipStreamSynchronize(ctx->stream));
     (void)W2;
@@ -242,6 +279,13 @@ int pgpu_ddleq_verify(const pgpu_pubkey* pk, size_t batch, const uint8_t* ct1, c
     launch_sha256_transcript(parts, widths, 4, nb, batch, nullptr, chal, ctx->stream);
     if (wc != W3) api_throw(PGPU_ERR_INVALID, "ciphertext stride must be the byte length of n^3");
     // en = E^n mod n^2 ; fn2 = F^(n^2) mod n^3                                   (ddleq.go:143-144)
+    // (a batch so small that the ladders are latency: F^n modulo n^2 runs beside E^n, on CUs of its own -- dual_pow_n3's two-ladder form)
+    if (f_stride * 8 > (size_t)LB * W3 + 7) api_throw(PGPU_ERR_INVALID, "F wider than n^3");
+    const bool two = dual_n3_two(ctx, pk, nb);
+    ExclusiveScope excl(ctx, two);
+    uint32_t* fl = ctx->ws_t<uint32_t>((size_t)W3 * nb);
+    unpack_operand(ctx, f, f_stride, f_stride, batch, mem, fl, W3, nb);
+    YPower fn(ctx, pk, fl, nb, two);
     ModexpPlan pe = modexp_alloc(ctx, mn2, nb, 32);
     // E is a residue modulo n^2 in every honest proof (ddleq.go:94-99); a wider field (up to twice the width) is reduced
     // by the ordinary kernel's two-chunk entry, the usual width takes the pair-kernel path
@@ -250,12 +294,9 @@ int pgpu_ddleq_verify(const pgpu_pubkey* pk, size_t batch, const uint8_t* ct1, c
     modexp_shared_run(ctx, mn2, pe, pk->N, ewide, false, true);
     // check = chalBit ? ct2 : ct1 ; check^en * F^(n^2) mod n^3 == alpha           (ddleq.go:138-152)
     // one interleaved ladder: the squarings of check^en and of F^(n^2) are shared (emit_modexp_dual)
-    if (f_stride * 8 > (size_t)LB * W3 + 7) api_throw(PGPU_ERR_INVALID, "F wider than n^3");
     uint32_t* chk = ctx->ws_t<uint32_t>((size_t)W3 * nb);
-    uint32_t* fl = ctx->ws_t<uint32_t>((size_t)W3 * nb);
     launch_select(chal, c2, c1, chk, W3, nb, ctx->stream);
-    unpack_operand(ctx, f, f_stride, f_stride, batch, mem, fl, W3, nb);
-    uint32_t* got = dual_pow_n3(ctx, pk, chk, pe.out(), fl, nb);
+    uint32_t* got = dual_pow_n3(ctx, pk, chk, pe.out(), fl, nb, fn.get());
     int32_t* d_ok = ctx->ws_t<int32_t>(nb);
     if (wa != W3) api_throw(PGPU_ERR_INVALID, "alpha stride must be the byte length of n^3");
     launch_equal(got, al, W3, nb, batch, d_ok, ctx->stream);

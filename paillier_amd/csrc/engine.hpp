@@ -750,8 +750,10 @@ void pair_enter(pgpu_ctx* ctx, const ModCtx& mc, uint32_t* ent, size_t nb);
 uint32_t* pair_leave(pgpu_ctx* ctx, const ModCtx& mc, uint32_t* pm, uint32_t out_slot, size_t nb);
 void pair_leave_and_pack(pgpu_ctx* ctx, const ModCtx& mc, uint32_t* pm, uint32_t out_slot, size_t nb, size_t count, uint8_t* dst,
                          size_t out_stride, int mem);
+// x^(per-number exponent) * y^e modulo n^2 as one interleaved ladder on the pair kernels; y_ready: y already IS y'^e (a caller that
+// ran that ladder beside another one): the per-number ladder and one product
 uint32_t* dual_pow_pair(pgpu_ctx* ctx, const ModCtx& mc, const uint32_t* x, const uint32_t* exps, int we, const uint32_t* y,
-                        const BigU& e, size_t nb, uint32_t** raw_out = nullptr);
+                        const BigU& e, size_t nb, uint32_t** raw_out = nullptr, bool y_ready = false);
 void perlane_pow(pgpu_ctx* ctx, const ModCtx& mc, const uint32_t* base, const uint32_t* exps, int we, size_t nb, uint32_t* out);
 void modmul_arrays(pgpu_ctx* ctx, const ModCtx& mc, const uint32_t* a, const uint32_t* b, size_t nb, uint32_t* out);
 void shared_pow(pgpu_ctx* ctx, const ModCtx& mc, const uint32_t* base, int wb, const BigU& e, size_t nb, uint32_t* out);

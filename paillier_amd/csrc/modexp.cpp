@@ -555,7 +555,7 @@ void pair_leave_and_pack(pgpu_ctx* ctx, const ModCtx& mc, uint32_t* pm, uint32_t
 // (4-bit windows of the per-number exponent, sliding windows of e).  x, y: canonical residues (mc.WT limbs, stride nb).
 // Returns the canonical result, or nullptr when the pair kernels do not serve this key / batch.
 uint32_t* dual_pow_pair(pgpu_ctx* ctx, const ModCtx& mc, const uint32_t* x, const uint32_t* exps, int we, const uint32_t* y,
-                               const BigU& e, size_t nb, uint32_t** raw_out) {
+                               const BigU& e, size_t nb, uint32_t** raw_out, bool y_ready) {
   // raw_out: the result stays in pair form (a0 | a1, stride nb): *raw_out and the return value point at its digits
   const PairInfo& pi = mc.pairn;
   if (!(pi.root && pi.c_one_pair >= 0 && ctx->use_asm && ctx->use_pair)) return nullptr;
@@ -595,7 +595,13 @@ uint32_t* dual_pow_pair(pgpu_ctx* ctx, const ModCtx& mc, const uint32_t* x, cons
   Prog pd;
   if (eight)
     for (uint32_t k = 0; k < 2; ++k) { pd.op(VM_LOAD, k); pd.op(VM_MULC, 0); pd.op(VM_STORE, k); }          // radix R_74 -> R_76
-  emit_modexp_dual(pd, we, e, 0, 1, 2, 3, 5, tab2, eight ? 2 : pi.c_one_pair, wb, nm4);
+  if (y_ready) {
+    // slot 1 already holds the power of y (in pair form): x^(its own exponent), then one product
+    emit_modexp_perlane(pd, we, 0, NO_SLOT, 2, 3, 5, NO_SLOT, eight ? 2 : pi.c_one_pair, wb, nm4);
+    pd.op(VM_LOAD, 3); pd.op(VM_MUL, 1); pd.op(VM_STORE, 3);
+  } else {
+    emit_modexp_dual(pd, we, e, 0, 1, 2, 3, 5, tab2, eight ? 2 : pi.c_one_pair, wb, nm4);
+  }
   if (eight) { pd.op(VM_MULC, 1); pd.op(VM_STORE, 3); }                                                      // radix R_76 -> R_74
   pd.end();
   SegSpec sp{&mc, &pd, pm, wb == 5 ? windows5_of(ctx, exps, we, nb) : exps};
