@@ -494,6 +494,74 @@ __global__ void __launch_bounds__(64) k_mul_const_add_lds(const uint32_t* __rest
   }
 }
 
+// Wide products of a per-number operand by a uniform constant as a LOOP over blocks of KB output columns (the fully unrolled
+// templates above are 100 - 300 KB of straight-line code at these widths and run at the speed of the instruction fetch: 1.1 ms for
+// 148 x 74 limbs on 16 384 numbers, 2.8 ms for the truncated 148 x 148).  One wave per block; the operand x sits limb-major in LDS
+// ([wx][64], conflict-free), the constant comes through wave-uniform loads.  For a block of KB columns and KB consecutive limbs of x
+// the 2 KB - 1 constant limbs it needs are fetched once: 3 KB - 1 loads for KB^2 multiplies.  One 64-bit accumulator per column:
+// min(wx, wb) products of a <= 29-bit by a 28-bit limb must stay below 2^64 (min <= 110; 148 for canonical operands -- the launcher checks).
+//   out[c] = sum_i x[i] b[c - i] (+ addv[c]) (+ add_small at c = 0), c < wo;   x = a - sub_small - subv (borrows propagated) when `sub`.
+template <int KB>
+__global__ void __launch_bounds__(64) k_mul_blocked(const uint32_t* __restrict__ a, int wx, bool sub, uint32_t sub_small,
+                                                    const uint32_t* __restrict__ subv, int wsub, const uint32_t* __restrict__ bconst,
+                                                    int wb, const uint32_t* __restrict__ addv, int wadd, uint32_t add_small,
+                                                    uint32_t* __restrict__ out, int wo, size_t nb) {
+  CHAIN_PRIORITY();
+  extern __shared__ uint32_t mb_lds[];
+  uint32_t* xs = mb_lds;                        // [wx][64]
+  const int lane = threadIdx.x;
+  const size_t g = (size_t)blockIdx.x * 64 + lane;
+  if (g < nb) {
+    if (sub) {
+      int32_t br = 0;
+      for (int i = 0; i < wx; ++i) {
+        int32_t v = (int32_t)a[(size_t)i * nb + g] - br - (i == 0 ? (int32_t)sub_small : 0) -
+                    ((subv && i < wsub) ? (int32_t)subv[(size_t)i * nb + g] : 0);
+        br = v < 0;
+        xs[i * 64 + lane] = (uint32_t)(v + (br << LB)) & LMASK;
+      }
+    } else {
+      for (int i = 0; i < wx; ++i) xs[i * 64 + lane] = a[(size_t)i * nb + g];
+    }
+  } else {
+    for (int i = 0; i < wx; ++i) xs[i * 64 + lane] = 0;
+  }
+  __syncthreads();
+  if (g >= nb) return;
+  uint64_t carry = add_small;
+  for (int c0 = 0; c0 < wo; c0 += KB) {
+    uint64_t acc[KB];
+#pragma unroll
+    for (int k = 0; k < KB; ++k) acc[k] = 0;
+    const int i_lo = c0 - (wb - 1) > 0 ? c0 - (wb - 1) : 0;
+    const int i_hi = c0 + KB - 1 < wx - 1 ? c0 + KB - 1 : wx - 1;
+    for (int i0 = i_lo; i0 <= i_hi; i0 += KB) {
+      uint32_t xi[KB], bw[2 * KB - 1];
+#pragma unroll
+      for (int ii = 0; ii < KB; ++ii) xi[ii] = i0 + ii <= i_hi ? xs[(i0 + ii) * 64 + lane] : 0u;
+#pragma unroll
+      for (int t = 0; t < 2 * KB - 1; ++t) {
+        const int j = c0 - i0 + t - (KB - 1);           // = (c0 + k) - (i0 + ii) with t = k - ii + KB - 1
+        bw[t] = (j >= 0 && j < wb) ? bconst[j] : 0u;
+      }
+#pragma unroll
+      for (int k = 0; k < KB; ++k)
+#pragma unroll
+        for (int ii = 0; ii < KB; ++ii) acc[k] += (uint64_t)xi[ii] * bw[k - ii + KB - 1];
+    }
+#pragma unroll
+    for (int k = 0; k < KB; ++k) {
+      const int c = c0 + k;
+      if (c < wo) {
+        uint64_t v = acc[k] + carry;
+        if (addv && c < wadd) v += addv[(size_t)c * nb + g];
+        out[(size_t)c * nb + g] = (uint32_t)v & LMASK;
+        carry = v >> LB;
+      }
+    }
+  }
+}
+
 // out = x - 1 (w limbs); x == 0 wraps to all-ones limbs (callers flag that lane separately)
 __global__ void k_sub_one(const uint32_t* __restrict__ x, uint32_t* __restrict__ out, int w, size_t nb) {
   CHAIN_PRIORITY();
@@ -1010,6 +1078,13 @@ void launch_mul_const_add(const uint32_t* a, int wa, const uint32_t* bconst, int
     hipLaunchKernelGGL((k_mul_const_add_t<37, 74, 110>), HELPER_GRID(nb), 0, st, a, bconst, addv, wadd, add_small, out, nb);
     return;
   }
+  // wide products on the blocked loop kernel (see k_mul_blocked): the closed form of (1 + n)^k modulo n^3 (148 x 74), the exit from
+  // the three-digit form (74 x 148), Garner modulo p^3 q^3 (110 x 110)
+  if ((size_t)wa * wb >= 74u * 110u && (wa < wb ? wa : wb) <= 110 && (size_t)wa * 256 <= 60 * 1024 && (!addv || wadd <= wo)) {
+    hipLaunchKernelGGL((k_mul_blocked<8>), dim3((unsigned)((nb + 63) / 64)), dim3(64), (size_t)wa * 256, st, a, wa, false, 0u,
+                       (const uint32_t*)nullptr, 0, bconst, wb, addv, wadd, add_small, out, wo, nb);
+    return;
+  }
   // (the closed form of (1 + n)^k modulo n^3 of a 2048-bit key: 1 + k n and + C(k, 2) n^2)
   if (wa == 148 && wb == 74 && wo == 220 && (!addv || wadd <= 220)) {
     hipLaunchKernelGGL((k_mul_const_add_t<148, 74, 220>), HELPER_GRID(nb), 0, st, a, bconst, addv, wadd, add_small, out, nb);
@@ -1075,7 +1150,9 @@ void launch_div_exact(const uint32_t* u, int wu, uint32_t sub_small, const uint3
     return;
   }
   if (!status && subv && wu == 220 && wl == 148 && wsub == 74) {     // digit split of the three-digit form, 2048-bit keys
-    hipLaunchKernelGGL((k_div_exact_nc<220, 148, 74>), HELPER_GRID(nb), 0, st, u, sub_small, subv, dinv, l, nb);
+    // l = (u - sub) dinv mod 2^(28 wl): a truncated product of canonical limbs (148 products a column: below 2^64) on the blocked kernel
+    hipLaunchKernelGGL((k_mul_blocked<8>), dim3((unsigned)((nb + 63) / 64)), dim3(64), (size_t)wl * 256, st, u, wl, true, sub_small,
+                       subv, wsub, dinv, wl, (const uint32_t*)nullptr, 0, 0u, l, wl, nb);
     return;
   }
   if (!status && (!subv || wsub == 37) && wu == 110 && wl == 74) {   // 1024-bit keys, and the halves modulo p^3 of 2048-bit keys
