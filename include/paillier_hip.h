@@ -333,8 +333,11 @@ int pgpu_modmul(const pgpu_modulus* mod, size_t batch, const uint8_t* a, size_t 
  * PGPU_MEM_DEVICE the payload bytes are moved by a kernel and never return to the host (feed pgpu_decrypt(..., PGPU_MEM_DEVICE)
  * directly).  With PGPU_MEM_HOST nothing touches the device and ctx may be NULL.
  * pgpu_gob_unpack: levels / methods (optional host int32[batch]) receive Ciphertext.Level / EncMethod.  Accepts any gob type ids
- * and field order (fields match by name), as Go's decoder does; errors as NewCiphertextFromBytes ("no data provided", malformed
- * data) fail the call with PGPU_ERR_INVALID; so do a negative C and a C wider than out_stride.
+ * and field order (fields match by name), as Go's decoder does, and skips value fields Ciphertext does not have when they are of
+ * gob's basic types or GobEncoder values (extra fields of other types -- nested structs, slices, maps -- are an error; Go would
+ * skip those too).  Errors as NewCiphertextFromBytes ("no data provided", malformed data) fail the call with PGPU_ERR_INVALID;
+ * so do a value without C, a negative C and a C wider than out_stride.  Blobs are untrusted input: every length, count and
+ * field delta is checked against the bytes that are there before it is used (tests/test_wire.py's malformed cases).
  * pgpu_gob_pack: every ciphertext of the batch carries the same Level / EncMethod.  blobs_cap: capacity of `blobs`;
  * batch * pgpu_gob_max_bytes(stride) always suffices.  offsets: host size_t[batch + 1], written.
  * Parity: byte-identical to the restatement in paillier_amd/wire.py, which is pinned to the gob specification's own example and

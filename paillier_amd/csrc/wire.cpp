@@ -16,7 +16,9 @@
 //
 // Status: written from the gob specification and math/big's GobEncode layout, byte-identical to the
 // Python restatement paillier_amd/wire.py (tests/test_gpu_wire.py); NOT cross-checked against a Go toolchain (none here): parity
-// with Go's own output is unpinned.  The decoder accepts any type ids and field order, as gob does (fields match by NAME).
+// with Go's own output is unpinned.  The decoder accepts any type ids and field order, as gob does (fields match by NAME), and
+// skips value fields Ciphertext lacks when they are of gob's basic types or GobEncoder values; anything else it cannot walk
+// (nested structs, maps, slices as extra fields) is an error, where Go's decoder would skip those too.
 #include "engine.hpp"
 
 namespace pgi {
@@ -120,19 +122,27 @@ struct Reader {
   bool done() const { return i >= n; }
 };
 
+// Field deltas are 64-bit integers straight off the wire: the index advances in unsigned arithmetic and is checked against the
+// number of fields BEFORE anything is indexed (a delta of 2^64 - 1 must not wrap the index to -2).  f is -1 before the first field.
+size_t next_field(long& f, uint64_t d, size_t nfields, const char* what) {
+  const uint64_t next = (uint64_t)(f + 1) + d;                                        // = index + 1; f + 1 >= 0, d >= 1
+  if (d > (uint64_t)nfields || next > (uint64_t)nfields) api_throw(PGPU_ERR_INVALID, std::string("gob: ") + what + " field index out of range");
+  f = (long)(next - 1);
+  return (size_t)f;
+}
+
 void read_common(Reader& r, std::string* name) {
   long f = -1;
   for (;;) {
     const uint64_t d = r.uint();
     if (d == 0) return;
-    f += (long)d;
+    next_field(f, d, 2, "CommonType");
     if (f == 0) { const uint64_t k = r.uint(); const uint8_t* p = r.take((size_t)k); if (name) name->assign((const char*)p, (size_t)k); }
-    else if (f == 1) (void)r.sint();
-    else api_throw(PGPU_ERR_INVALID, "gob: unknown CommonType field");
+    else (void)r.sint();
   }
 }
 
-struct Parsed { size_t off = 0, len = 0; int32_t level = 0, method = 0; };
+struct Parsed { size_t off = 0, len = 0; int32_t level = 0, method = 0; bool has_c = false; };
 
 // NewCiphertextFromBytes (paillier.go:376-391) for one blob: where the magnitude of C sits, Level, EncMethod
 Parsed gob_parse(const uint8_t* data, size_t n) {
@@ -146,6 +156,7 @@ Parsed gob_parse(const uint8_t* data, size_t n) {
     const uint8_t* bp = r.take((size_t)blen);
     Reader body(bp, (size_t)blen);
     const int64_t tid = body.sint();
+    if (tid == INT64_MIN) api_throw(PGPU_ERR_INVALID, "gob: bad type id");
     if (tid < 0) {                                                                    // a type definition
       const uint64_t f = body.uint();
       if (f == 3) {                                                                   // StructT
@@ -154,19 +165,20 @@ Parsed gob_parse(const uint8_t* data, size_t n) {
         for (;;) {
           const uint64_t d = body.uint();
           if (d == 0) break;
-          g += (long)d;
+          next_field(g, d, 2, "structType");                                          // {CommonType, Field []fieldType}
           if (g == 0) read_common(body, nullptr);
-          else if (g == 1) {
+          else {
             const uint64_t nf = body.uint();
+            if (nf > blen) api_throw(PGPU_ERR_INVALID, "gob: more fields than bytes");   // (every field takes >= 1 byte)
             for (uint64_t k = 0; k < nf; ++k) {
               Field fd{"", 0};
               long h = -1;
               for (;;) {
                 const uint64_t d2 = body.uint();
                 if (d2 == 0) break;
-                h += (long)d2;
+                next_field(h, d2, 2, "fieldType");                                    // {Name string, Id typeId}
                 if (h == 0) { const uint64_t l = body.uint(); const uint8_t* p = body.take((size_t)l); fd.name.assign((const char*)p, (size_t)l); }
-                else if (h == 1) fd.id = body.sint();
+                else fd.id = body.sint();
               }
               fields.push_back(fd);
             }
@@ -190,9 +202,7 @@ Parsed gob_parse(const uint8_t* data, size_t n) {
     for (;;) {
       const uint64_t d = body.uint();
       if (d == 0) break;
-      f += (long)d;
-      if (f >= (long)fields->size()) api_throw(PGPU_ERR_INVALID, "gob: field index out of range");
-      const Field& fd = (*fields)[(size_t)f];
+      const Field& fd = (*fields)[next_field(f, d, fields->size(), "value")];
       if (fd.name == "C") {
         if (std::find(gobenc.begin(), gobenc.end(), fd.id) == gobenc.end()) api_throw(PGPU_ERR_INVALID, "gob: field C is not a GobEncoder type");
         const uint64_t l = body.uint();
@@ -203,14 +213,21 @@ Parsed gob_parse(const uint8_t* data, size_t n) {
         while (z < l && p[z] == 0) ++z;                                               // (a non-minimal magnitude: skip zeros)
         out.off = (size_t)(p - data) + z;
         out.len = (size_t)l - z;
+        out.has_c = true;
       } else if (fd.name == "Level") {
         out.level = (int32_t)body.sint();
       } else if (fd.name == "EncMethod") {
         out.method = (int32_t)body.sint();
       } else {
-        api_throw(PGPU_ERR_INVALID, "gob: type mismatch: no field " + fd.name + " in Ciphertext");
+        // a wire field the receiver's struct lacks: Go's decoder skips its value and goes on; so does this one, for the types
+        // whose extent is known without their definition (gob's basic types and GobEncoder values)
+        if (std::find(gobenc.begin(), gobenc.end(), fd.id) != gobenc.end() || fd.id == 5 || fd.id == 6) (void)body.take((size_t)body.uint());
+        else if (fd.id >= 1 && fd.id <= 4) (void)body.uint();                        // bool, int, uint, float: one varint
+        else if (fd.id == 7) { (void)body.uint(); (void)body.uint(); }               // complex
+        else api_throw(PGPU_ERR_INVALID, "gob: cannot skip field " + fd.name + " (not in Ciphertext, not a basic type)");
       }
     }
+    if (!out.has_c) api_throw(PGPU_ERR_INVALID, "gob: the value has no field C");     // (Go: a Ciphertext with a nil C)
     return out;
   }
   api_throw(PGPU_ERR_INVALID, "gob: no value in the data");
@@ -222,9 +239,15 @@ template <class F> void on_host_threads(size_t total, size_t grain, F&& f) {
   if (nthreads == 1) { f((size_t)0, total); return; }
   std::vector<std::thread> th;
   std::vector<std::string> errs(nthreads);
+  th.reserve(nthreads);
+  // a std::thread that cannot be started throws with the earlier ones still joinable: join them on every way out
+  struct Joiner { std::vector<std::thread>& th; ~Joiner() { for (auto& t : th) if (t.joinable()) t.join(); } } joiner{th};
   for (size_t t = 0; t < nthreads; ++t)
     th.emplace_back([&, t] {
-      try { f(total * t / nthreads, total * (t + 1) / nthreads); } catch (const ApiError& e) { errs[t] = e.msg.empty() ? "gob error" : e.msg; }
+      try { f(total * t / nthreads, total * (t + 1) / nthreads); }
+      catch (const ApiError& e) { errs[t] = e.msg.empty() ? "gob error" : e.msg; }
+      catch (const std::exception& e) { errs[t] = std::string("gob: ") + e.what(); }
+      catch (...) { errs[t] = "gob: unknown error"; }
     });
   for (auto& t : th) t.join();
   for (auto& e : errs) if (!e.empty()) api_throw(PGPU_ERR_INVALID, e);

@@ -140,7 +140,9 @@ def _read_common(r: _Reader):
 
 def ciphertext_from_gob(data: bytes) -> Tuple[int, int, int]:
     """NewCiphertextFromBytes (paillier.go:376-391): returns (C, Level, EncMethod).  Accepts any type ids and field order, as
-    gob does (fields are matched by NAME); fields the struct does not have are an error here."""
+    gob does (fields are matched by NAME).  A wire field the struct does not have is skipped when its extent is known without
+    its definition (gob's basic types, GobEncoder values), as Go's decoder skips it; a value without C is an error (Go would
+    hand back a Ciphertext with a nil C)."""
     if len(data) == 0:
         raise GobError("no data provided")                 # paillier.go:377
     r = _Reader(data)
@@ -158,9 +160,11 @@ def ciphertext_from_gob(data: bytes) -> Tuple[int, int, int]:
                     if d == 0:
                         break
                     g += d
+                    if g > 1:
+                        raise GobError("structType field index out of range")
                     if g == 0:
                         name, _ = _read_common(body)
-                    elif g == 1:
+                    else:
                         for _ in range(body.uint()):
                             fname, ftid, h = None, None, -1
                             while True:
@@ -168,9 +172,11 @@ def ciphertext_from_gob(data: bytes) -> Tuple[int, int, int]:
                                 if d2 == 0:
                                     break
                                 h += d2
+                                if h > 1:
+                                    raise GobError("fieldType field index out of range")
                                 if h == 0:
                                     fname = body.take(body.uint()).decode()
-                                elif h == 1:
+                                else:
                                     ftid = body.int()
                             fields.append((fname, ftid))
                 structs[-tid] = (name, fields)
@@ -184,7 +190,7 @@ def ciphertext_from_gob(data: bytes) -> Tuple[int, int, int]:
         if tid not in structs:
             raise GobError("value of an undefined type")
         _, fields = structs[tid]
-        c, level, method, f = 0, 0, 0, -1
+        c, level, method, f = None, 0, 0, -1
         while True:
             d = body.uint()
             if d == 0:
@@ -206,8 +212,16 @@ def ciphertext_from_gob(data: bytes) -> Tuple[int, int, int]:
                 level = body.int()
             elif fname == "EncMethod":
                 method = body.int()
+            elif ftid in gobenc or ftid in (5, 6):         # a field Ciphertext lacks: skipped, as Go's decoder does
+                body.take(body.uint())
+            elif ftid in (1, 2, 3, 4):
+                body.uint()
+            elif ftid == 7:
+                body.uint(), body.uint()
             else:
-                raise GobError(f"type mismatch: no field {fname} in Ciphertext")
+                raise GobError(f"cannot skip field {fname} (not in Ciphertext, not a basic type)")
+        if c is None:
+            raise GobError("the value has no field C")
         return c, level, method
     raise GobError("no value in gob data")
 

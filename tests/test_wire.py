@@ -128,11 +128,71 @@ def test_c_abi_unpack_errors(api):
     with pytest.raises(api.PaillierHipError):
         api.gob_unpack_raw(None, [undefined], out, 8)
     other = wire.message(wire.struct_typedef(65, "Ciphertext", [("Q", wire.T_INT)])) + wire.message(wire.enc_int(65) + b"\x01\x02\x00")
-    with pytest.raises(api.PaillierHipError, match="no field Q"):
+    with pytest.raises(api.PaillierHipError, match="no field C"):
         api.gob_unpack_raw(None, [other], out, 8)
+    with pytest.raises(wire.GobError, match="no field C"):
+        wire.ciphertext_from_gob(other)
     # a too small blob buffer is refused, never overrun
     lib = api.load_library()
     blobs = np.zeros(16, dtype=np.uint8)
     offs = np.zeros(3, dtype=np.uint64)
     rows = _rows([1, 2], 8)
     assert lib.pgpu_gob_pack(None, 2, rows.ctypes.data, 8, api.MEM_HOST, 0, 0, blobs.ctypes.data, 16, offs.ctypes.data) == -1
+
+
+def _typedefs(extra=()):
+    fields = [("C", 66), ("Level", wire.T_INT), ("EncMethod", wire.T_INT)] + list(extra)
+    return wire.message(wire.struct_typedef(65, "Ciphertext", fields)) + wire.message(wire.gobencoder_typedef(66, "Int"))
+
+
+def test_c_abi_unpack_survives_malformed_blobs(api):
+    """Blobs come from the network (wire.cpp:193): a field delta is a 64-bit integer off the wire and must be
+    bounded before the field table is indexed.  Each of these once read out of bounds or desynchronised the walk."""
+    out = np.zeros((2, 8), dtype=np.uint8)
+    good = wire.ciphertext_to_gob(12345)
+    huge = b"\xf8" + b"\xff" * 8                                     # the gob uint 2^64 - 1
+    wrap = b"\xf8" + b"\xff" * 7 + b"\xfe"                            # 2^64 - 2: -1 + delta wraps to -3
+    c_val = wire.enc_string(b"\x02\x07")
+    bad = {
+        "huge value delta": _typedefs() + wire.message(wire.enc_int(65) + huge + b"\x00"),
+        "wrapping value delta": _typedefs() + wire.message(wire.enc_int(65) + wrap + b"\x00"),
+        "delta back to -1": _typedefs() + wire.message(wire.enc_int(65) + b"\x01" + c_val + huge + b"\x00"),
+        "delta past the last field": _typedefs() + wire.message(wire.enc_int(65) + b"\x04\x02\x00"),
+        "truncated varint": _typedefs() + wire.message(wire.enc_int(65) + b"\x01" + b"\xfc\x01"),
+        "varint wider than 8 bytes": _typedefs() + wire.message(wire.enc_int(65) + b"\xf7" + b"\x01" * 9),
+        "type id INT64_MIN": wire.message(huge + b"\x03\x00"),
+        "huge structType delta": wire.message(wire.enc_int(-65) + b"\x03" + huge + b"\x00\x00") + good,
+        "huge CommonType delta": wire.message(wire.enc_int(-65) + b"\x03\x01" + huge + b"\x00\x00\x00") + good,
+        "huge fieldType delta": wire.message(wire.enc_int(-65) + b"\x03\x02\x01" + huge + b"\x00\x00\x00") + good,
+        "nf larger than the body": wire.message(wire.enc_int(-65) + b"\x03\x02" + huge + b"\x00\x00") + good,
+        "C longer than the blob": _typedefs() + wire.message(wire.enc_int(65) + b"\x01" + huge + b"\x02\x07\x00"),
+        "message longer than the blob": _typedefs() + huge + wire.enc_int(65),
+    }
+    for name, blob in bad.items():
+        with pytest.raises(api.PaillierHipError) as ei:
+            api.gob_unpack_raw(None, [good, blob], out, 8)
+        assert ei.value.code == -1, name
+        with pytest.raises(wire.GobError):
+            wire.ciphertext_from_gob(blob)
+    # the control: the same prefix with a well-formed value
+    levels, methods = api.gob_unpack_raw(None, [_typedefs() + wire.message(wire.enc_int(65) + b"\x01" + c_val + b"\x00")], out[:1], 8)
+    assert int.from_bytes(out[0].tobytes(), "big") == 7
+
+
+def test_fields_ciphertext_lacks_are_skipped_as_gob_does(api):
+    """Go's decoder ignores a wire field the receiving struct does not have (wire.cpp:211)."""
+    out = np.zeros((1, 8), dtype=np.uint8)
+    extra = [("Note", 6), ("Tag", wire.T_INT), ("Aux", 66), ("W", 4), ("Z", 7)]
+    value = (wire.enc_int(65) + b"\x01" + wire.enc_string(b"\x02\x01\x00") + b"\x01" + wire.enc_int(1)      # C = 256, Level = 1
+             + b"\x02" + wire.enc_string(b"hello") + b"\x01" + wire.enc_int(-9) + b"\x01" + wire.enc_string(b"\x02\x63")
+             + b"\x01" + b"\xfe\xf0\x3f" + b"\x01" + b"\x01\x02" + b"\x00")
+    blob = _typedefs(extra) + wire.message(value)
+    assert wire.ciphertext_from_gob(blob) == (256, 1, 0)
+    levels, methods = api.gob_unpack_raw(None, [blob], out, 8)
+    assert int.from_bytes(out[0].tobytes(), "big") == 256 and list(levels) == [1] and list(methods) == [0]
+    # a nested struct as an extra field cannot be walked without its definition: an error, not a desynchronised walk
+    nested = _typedefs([("S", 70)]) + wire.message(wire.enc_int(65) + b"\x04\x01\x02\x00\x00")
+    with pytest.raises(api.PaillierHipError, match="cannot skip"):
+        api.gob_unpack_raw(None, [nested], out, 8)
+    with pytest.raises(wire.GobError, match="cannot skip"):
+        wire.ciphertext_from_gob(nested)
