@@ -96,8 +96,15 @@ int pgpu_ctx_last_profile(pgpu_ctx* ctx, double* vm_ms, int* vm_launches, double
  * ladders on ct1 itself; non-unit inputs always take those); "exclusive" (default 1): placement by LDS size -- the small concurrent launches
  * of a prover call (up to 128 workgroups) ask for the whole LDS of a compute unit per workgroup, so that the side lanes' workgroups
  * land on idle CUs instead of the ones the main launch runs on, and a main-stream ladder of at most one workgroup per CU asks for more
- * than half of it, so that it spreads over all CUs (0: the dispatcher's placement); "background" (default 0): the prover's side-lane
+ * than half of it, so that it spreads over all CUs (0: the dispatcher's placement); "spread" (default 1): the second of those two rules
+ * alone (0: main-stream ladders keep the dispatcher's placement; both rules stop at the compute units the context's stream may use, so a
+ * context with a "cu_partition" narrower than its launch keeps the dispatcher's placement by itself); "w74" (default 1): moduli of two
+ * 74-limb slices on the wave-sliced assembly kernel (0: four lanes of 37 limbs); "exp_order" (default 1): the key holder's exponents
+ * modulo p^3, q^3 are reduced modulo the group orders on the device (0: used as given); "background" (default 0): the prover's side-lane
  * ladders run at wave priority 0 (measured: no gain).
+ * These names are the ONLY switches of the plan: the library reads no environment variable that changes what is launched (a Go host
+ * inherits its process environment from wherever it runs).  PGPU_PROFILE_DUMP / PGPU_HOST_TRACE (include/paillier_hip_debug.h) print
+ * timings to stderr and change nothing else.
  * All of these change the work done, never a result (the tests switch them off to compare).
  * "lanes_wanted" (default 0 = fill the chip): the lane count below which a batch is re-sliced over more lanes per
  * number; 1 keeps every modulus on its natural kernel shape whatever the batch size (tests).

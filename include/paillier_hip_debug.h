@@ -1,6 +1,12 @@
 /* paillier_hip_debug.h -- test hooks of libpaillier_hip.so.  NOT part of the drop-in boundary (that is paillier_hip.h): nothing
  * here replaces a reference call site, a Go / C caller never needs it, and it may change without notice.  Included by the
  * library's own debug.cpp, by tests/ and tools/ only.
+ *
+ * Environment variables the library reads -- two, both diagnostics that print to stderr and change nothing that is launched:
+ *   PGPU_PROFILE_DUMP=1   pgpu_ctx_last_profile prints one line per profiled VM launch of the last call (kernel, ms, multiply-adds,
+ *                         fraction of the issue peak); the prover prints how many instances drew challenge bit 1
+ *   PGPU_HOST_TRACE=1     the prover prints host-side time stamps of its stages
+ * Everything that changes the plan is a pgpu_ctx_set_flag name (paillier_hip.h); tests/test_plan_cpu.py enforces both statements.
  */
 #ifndef PAILLIER_HIP_DEBUG_H
 #define PAILLIER_HIP_DEBUG_H
@@ -38,7 +44,9 @@ int pgpu_pair_debug_run(pgpu_ctx* ctx, const uint8_t* p_be, size_t p_len, int la
  *   "response_by_structure" (statements, instances, nb_instances, lanes_wanted) -> ok
  *   "extract_beside"      (nb_statements, nb_instances, lanes_wanted) -> ok
  *   "shared_chain_groups" (nb_ciphertexts, n_shares, lanes_wanted, have_eight_lane_kernel) -> groups of shares with a chain of squarings each
- *   "exclusive_cus"       (nb_statements, nb_instances, lanes_wanted) -> ok   (a compute unit per workgroup for the call's concurrent launches)
+ *   "lds_share"           (blocks, stream_cus, on_side, in_exclusive_call, products, exclusive_flag, spread_flag) -> 0 | 1 | 2
+ *                         (LDS a workgroup asks for: the kernel's own | a whole CU's | just over half -- placement by LDS size)
+ *   "generic_shape"       (WL, K, launch_nb, segments, lanes_wanted, wave_sliced_ok) -> WL, K   (lanes per number of the generic kernels)
  *   "pair_lanes_shared"   (numbers, lanes_wanted, have4, have8)    -> lanes
  *   "pair_lanes_2or4"     (numbers, lanes_wanted, have4)           -> lanes
  *   "crt_pair_lanes"      (key_lanes, have_two_lane_variant, nb, lanes_wanted) -> lanes, usable (for 37-limb primes)

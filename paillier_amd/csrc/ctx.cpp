@@ -84,6 +84,9 @@ int pgpu_ctx_set_flag(pgpu_ctx* ctx, const char* name, int value) {
   if (strcmp(name, "side") == 0) { ctx->use_side = value != 0; return PGPU_OK; }
   if (strcmp(name, "background") == 0) { ctx->use_background = value != 0; return PGPU_OK; }
   if (strcmp(name, "exclusive") == 0) { ctx->use_exclusive = value != 0; return PGPU_OK; }
+  if (strcmp(name, "spread") == 0) { ctx->use_spread = value != 0; return PGPU_OK; }
+  if (strcmp(name, "w74") == 0) { ctx->use_w74 = value != 0; return PGPU_OK; }
+  if (strcmp(name, "exp_order") == 0) { ctx->use_exp_order = value != 0; return PGPU_OK; }
   if (strcmp(name, "struct") == 0) { ctx->use_struct = value != 0; return PGPU_OK; }
   if (strcmp(name, "lanes8") == 0) { ctx->use_lanes8 = value != 0; return PGPU_OK; }
   if (strcmp(name, "muls") == 0) { ctx->use_muls = value != 0; return PGPU_OK; }
@@ -112,6 +115,7 @@ int pgpu_ctx_set_flag(pgpu_ctx* ctx, const char* name, int value) {
       HIPCHK(hipExtStreamCreateWithCUMask(&ns, (uint32_t)mask.size(), mask.data()));
       HIPCHK(hipStreamDestroy(ctx->stream));
       ctx->stream = ns;
+      ctx->stream_cus = (uint32_t)(hi - lo);
     });
   }
   return fail(PGPU_ERR_INVALID, "unknown flag %s", name);

@@ -526,8 +526,7 @@ struct StructBase {
 };
 bool struct_pow_usable(const pgpu_seckey* sk) {
   pgpu_ctx* ctx = sk->ctx;
-  static const bool env_on = [] { const char* v = getenv("PGPU_STRUCT"); return v ? atoi(v) != 0 : true; }();
-  return env_on && ctx->use_struct && sk->has_lift && sk->has_crt2 && sk->c_p3invR >= 0 && triple_usable(ctx, sk->mp3) &&
+  return ctx->use_struct && sk->has_lift && sk->has_crt2 && sk->c_p3invR >= 0 && triple_usable(ctx, sk->mp3) &&
          triple_usable(ctx, sk->mq3) && sk->pk->g_is_n_plus_1 && sk->mp.K == 1 && sk->mq.K == 1 && sk->mp.WT == sk->mq.WT &&
          (sk->p - BigU(1)).bit_length() >= 64 && (sk->q - BigU(1)).bit_length() >= 64 && 2 * sk->mp3.WT >= sk->pk->mn3->WT;
 }
@@ -793,9 +792,8 @@ void pow_n3_crt(const pgpu_seckey* sk, const uint32_t* base, int wb, const uint3
     const int nslots = base2 ? (int)tab2 + (1 << (dual_sliding_bits(win) - 1)) : 5 + perlane_table_slots(win, nm5);
     uint32_t* g = ctx->ws_t<uint32_t>(S * 6);       // generic slots (W limbs): 0 x_p, 1 x_q, 2 A, 3 B, 4 h, 5 scratch
     // Exponents modulo the orders of the unit groups of p^3 and q^3 (a quarter shorter than exponents modulo n^2): each half
-    // gets its own reduced exponents and its own program.  PGPU_EXP_ORDER=0 (experiments) keeps the exponents as given.
-    static const bool order_on = [] { const char* v = getenv("PGPU_EXP_ORDER"); return v ? atoi(v) != 0 : true; }();
-    const bool reduce_e = order_on && sk->eo_p.ok && sk->eo_q.ok;
+    // gets its own reduced exponents and its own program (context flag "exp_order", 0: the exponents as given).
+    const bool reduce_e = ctx->use_exp_order && sk->eo_p.ok && sk->eo_q.ok;
     const uint32_t* ex[2] = {exps, exps};
     int wex[2] = {we, we};
     BigU es[2];
@@ -1307,7 +1305,7 @@ static void ddleq_prove_impl(const pgpu_seckey* sk, size_t S, size_t secpar, con
       pgpu_ctx* c;
       ExclusiveCall(pgpu_ctx* c_, bool on) : c(c_) { c->exclusive_call = on; }
       ~ExclusiveCall() { c->exclusive_call = false; }
-    } exclusive_call(ctx, plan::exclusive_cus(nbs, nb, plan::lanes_target(ctx->lanes_wanted)));
+    } exclusive_call(ctx, true);   // which of the call's launches take a CU per workgroup: plan::lds_share
     if (ct_stride != mn3.nbytes) api_throw(PGPU_ERR_INVALID, "ciphertext stride must be the byte length of n^3");
     if (n_stride * 8 > (size_t)LB * W1 + 7) api_throw(PGPU_ERR_INVALID, "a, b, x, y must fit the width of n");
     auto up = [&](const uint8_t* buf, size_t stride, int w, size_t count, size_t nbx) {

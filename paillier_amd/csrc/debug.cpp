@@ -122,7 +122,15 @@ int pgpu_plan_query(const char* what, const uint64_t* a, int nargs, int64_t* out
   if (w == "early_response_ok" && need(2, 1)) { out[0] = plan::early_response_ok((size_t)a[0], (int)a[1]); return 1; }
   if (w == "response_by_structure" && need(4, 1)) { out[0] = plan::response_by_structure((size_t)a[0], (size_t)a[1], (size_t)a[2], lt(3)); return 1; }
   if (w == "shared_chain_groups" && need(4, 1)) { out[0] = plan::shared_chain_groups((size_t)a[0], (int)a[1], lt(2), a[3] != 0); return 1; }
-  if (w == "exclusive_cus" && need(3, 1)) { out[0] = plan::exclusive_cus((size_t)a[0], (size_t)a[1], lt(2)); return 1; }
+  if (w == "lds_share" && need(7, 1)) {
+    out[0] = plan::lds_share((uint32_t)a[0], (uint32_t)a[1], a[2] != 0, a[3] != 0, a[4], a[5] != 0, a[6] != 0);
+    return 1;
+  }
+  if (w == "generic_shape" && need(6, 2)) {
+    const plan::GenericShape g = plan::generic_shape((int)a[0], (int)a[1], (size_t)a[2], (size_t)a[3], lt(4), a[5] != 0);
+    out[0] = g.WL; out[1] = g.K;
+    return 2;
+  }
   if (w == "extract_beside" && need(3, 1)) { out[0] = plan::extract_beside((size_t)a[0], (size_t)a[1], lt(2)); return 1; }
   if (w == "pair_lanes_shared" && need(4, 1)) { out[0] = plan::pair_lanes_shared((size_t)a[0], lt(1), a[2] != 0, a[3] != 0); return 1; }
   if (w == "pair_lanes_2or4" && need(3, 1)) { out[0] = plan::pair_lanes_2or4((size_t)a[0], lt(1), a[2] != 0); return 1; }

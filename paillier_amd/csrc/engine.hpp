@@ -98,6 +98,10 @@ struct pgpu_ctx {
   bool exclusive_call = false;   // set by a protocol function for the length of a call whose concurrent launches together fit the chip's compute units: every
                                  // workgroup then asks for the whole LDS of a CU, so the dispatcher cannot stack the side lanes' workgroups on the CUs the main
                                  // launch runs on (it starts every queue's workgroups from the same CUs: 17.5 -> 28 ms for a^n | x^n of 2 048 instances)
+  bool use_spread = true;    // a main-stream ladder of at most one workgroup per CU asks for just over half a CU's LDS (plan::lds_share; pgpu_ctx_set_flag("spread", 0): the dispatcher's placement)
+  uint32_t stream_cus = plan::kChipCUs;   // compute units this context's stream may use (pgpu_ctx_set_flag("cu_partition", ...) narrows it)
+  bool use_w74 = true;       // 74-limb two-slice moduli on the wave-sliced assembly kernel (pgpu_ctx_set_flag("w74", 0): four lanes of 37 limbs)
+  bool use_exp_order = true; // the key holder's exponents modulo p^3, q^3 reduced modulo the group orders (pgpu_ctx_set_flag("exp_order", 0): as given)
   bool use_background = false;   // the prover's side-lane ladders at wave priority 0 (pgpu_ctx_set_flag("background", 1): measured, no gain -- ddleq.cpp)
   bool background_launch = false; // set around side-lane ladders of a LARGE call (see run_vm): their long programs run at wave priority 0
   bool use_handover = true;  // a power modulo n^2 that is only needed modulo n^2 by the next ladder modulo n^3 stays in pair form: (a0, a1, 0) is its digit form (pgpu_ctx_set_flag("handover", 0): exit and re-entry)

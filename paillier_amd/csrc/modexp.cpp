@@ -106,8 +106,7 @@ const uint32_t* triple_windows(pgpu_ctx* ctx, const uint32_t* exps, int we, size
 }
 
 bool triple_usable(pgpu_ctx* ctx, const ModCtx& mc, bool allow6) {
-  static const bool env_on = [] { const char* e = getenv("PGPU_TRIPLE"); return e ? atoi(e) != 0 : true; }();
-  return env_on && mc.triple.root && ctx->use_asm && ctx->use_pair && ctx->use_triple && (allow6 || !mc.triple.lanes6_only);
+  return mc.triple.root && ctx->use_asm && ctx->use_pair && ctx->use_triple && (allow6 || !mc.triple.lanes6_only);
 }
 
 TriplePlan triple_alloc(pgpu_ctx* ctx, const ModCtx& mc, size_t nb, int slots) {

@@ -149,9 +149,37 @@ inline int shared_chain_groups(size_t nbs, int S, size_t lt, bool have8) {
 // 8 192: 97.4 | 93.1, 12 288: 115.5 | 113.8, 16 384: 130.3 | 129.0, 1 536 x 40: 203 | 200 -- wider launches keep their placement (two
 // workgroups per CU beat a second round), so the rule holds for every call size.
 constexpr uint32_t kExclusiveMaxBlocks = 128;
-inline bool exclusive_cus(size_t nb_statements, size_t nb_instances, size_t lt = kChipLanes) {
-  (void)nb_statements; (void)nb_instances; (void)lt;
-  return true;
+// How much of a CU's LDS a workgroup of an assembly launch asks for (run_vm -> launch_vm_asm): 0 the kernel's own, 1 all of it (a CU per
+// workgroup), 2 just over half (no two workgroups of the launch on one CU; a side lane's 30 - 60 KB still fit beside it).
+//   blocks        workgroups of the launch
+//   stream_cus    compute units the launch's stream may use: kChipCUs, or the slice of a context with a CU partition.  A launch that
+//                 asks for a CU (or half) per workgroup on FEWER CUs than it has workgroups would run in rounds, so both rules stop at
+//                 stream_cus: eight contexts on 32 CUs each keep the dispatcher's placement for their
+//                 64-workgroup ladders
+//   on_side       the launch goes to a side lane of the context
+//   in_exclusive_call  a protocol call whose launches run beside each other is in progress (the DDLEQ prover)
+//   products      Montgomery products of the program: short programs (links between ladders) are not worth a placement
+//   enabled / spread_enabled  the context flags "exclusive" and "spread"
+inline int lds_share(uint32_t blocks, uint32_t stream_cus, bool on_side, bool in_exclusive_call, uint64_t products, bool enabled,
+                     bool spread_enabled) {
+  if (!enabled) return 0;
+  if (in_exclusive_call && blocks <= kExclusiveMaxBlocks && blocks <= stream_cus) return 1;
+  if (spread_enabled && !on_side && blocks <= stream_cus && products >= 256) return 2;
+  return 0;
+}
+
+// ---- the generic kernels: lanes per number -------------------------------------------------------------------------------------
+// The same WT limbs can be sliced over more lanes (WL/2 limbs x 2K lanes).  The natural shape has the cheapest squarings (K == 1:
+// triangular rows; the wave-sliced two-slice kernels: every limb product once) and a single wave per SIMD already issues at ~88 % of
+// the two-wave rate, so it wins from one wave per SIMD upwards; below that the finer slicing wins (tools/occupancy_sweep.py:
+// Decrypt-2048 at 32 768: 1.24 M/s natural vs 1.01 M/s re-sliced; at 16 384: 0.63 vs 0.88 M/s).  Slices stay >= 37 limbs, K <= 4.
+// wave_sliced_ok: the 74-limb two-slice shape runs on the wave-sliced assembly kernel (context flags "asm" and "w74"); without it
+// those moduli take four lanes of 37 limbs.
+struct GenericShape { int WL, K; };
+inline GenericShape generic_shape(int WL, int K, size_t launch_nb, size_t segs, size_t lt, bool wave_sliced_ok) {
+  while (launch_nb * (size_t)K * segs < lt && K < 4 && WL % 2 == 0 && WL / 2 >= 37) { WL /= 2; K *= 2; }
+  if (WL == 74 && K == 2 && !wave_sliced_ok) { WL = 37; K = 4; }
+  return {WL, K};
 }
 
 }  // namespace plan

@@ -396,12 +396,7 @@ void run_vm(pgpu_ctx* ctx, size_t nb, const SegSpec& s0, const SegSpec* s1, bool
     sqrs += ss[i]->prog->sqrs;
   }
   if (launch_nb == 0) launch_nb = nb;  // numbers actually launched (<= nb, the row stride of the arrays)
-  // Occupancy-aware shape: the same WT limbs can be sliced over more lanes (WL/2 x 2K).  One lane per slice keeps the
-  // multiply count but fills the chip when the batch is small.  The natural shape has the cheapest squarings (K == 1:
-  // triangular rows; the wave-sliced 2-slice kernels: every limb product once), and a single wave per SIMD already
-  // issues at ~88 % of the two-wave rate, so it wins from one wave per SIMD (1024 SIMDs x 64 lanes) upwards; below that
-  // the finer slicing wins (tools/occupancy_sweep.py: Decrypt-2048 at 32768: 1.24 M/s natural vs 1.01 M/s re-sliced; at
-  // 16384: 0.63 vs 0.88 M/s; Encrypt-2048 at 32768: 295 k vs 271 k; at 16384: 148 k vs 251 k).
+  // lanes per number of the generic kernels: plan::generic_shape
   int WL = mc->WL, K = mc->K;
   const bool pair = s0.pair != nullptr;
   if (s1 && pair != (s1->pair != nullptr)) api_throw(PGPU_ERR_INVALID, "segment kind mismatch");
@@ -410,13 +405,10 @@ void run_vm(pgpu_ctx* ctx, size_t nb, const SegSpec& s0, const SegSpec* s1, bool
     WL = s0.pair_lanes == 8 ? s0.pair_h / 4 : (s0.pair_lanes == 4 || s0.pair_lanes == 6) ? s0.pair_h / 2 : s0.pair_h;
     K = s0.pair_lanes == 8 ? 96 : s0.pair_lanes == 6 ? 112 : s0.pair_lanes == 4 ? 64 : s0.pair_lanes == 3 ? 48 : s0.pair_lanes == 2 ? 32 : 16;   // tags of the pair kernels, not lane counts
   } else {
-    static const size_t lanes_env = [] { const char* e = getenv("PGPU_LANES_WANTED"); return e ? (size_t)atoll(e) : (size_t)0; }();
-    const size_t lanes_wanted = ctx->lanes_wanted ? ctx->lanes_wanted : plan::lanes_target(lanes_env);
-    const size_t segs = s2 ? 3 : s1 ? 2 : 1;
-    while (launch_nb * K * segs < lanes_wanted && K < 4 && WL % 2 == 0 && WL / 2 >= 37) { WL /= 2; K *= 2; }
-    // PGPU_W74=0 (experiments): the 4-lane slicing instead of the wave-sliced 148-limb kernel
-    static const bool w74 = [] { const char* e = getenv("PGPU_W74"); return e ? atoi(e) != 0 : true; }();
-    if (WL == 74 && K == 2 && !(w74 && ctx->use_asm)) { WL = 37; K = 4; }
+    const plan::GenericShape gs = plan::generic_shape(WL, K, launch_nb, s2 ? 3 : s1 ? 2 : 1, plan::lanes_target(ctx->lanes_wanted),
+                                                      ctx->use_w74 && ctx->use_asm);
+    WL = gs.WL;
+    K = gs.K;
   }
   const uint32_t blocks_per_seg = (uint32_t)(launch_nb * (pair ? (s0.pair_lanes == 3 ? 4 : s0.pair_lanes == 6 ? 8 : s0.pair_lanes) : K) / VM_BLOCK);
   a.seg0_blocks = blocks_per_seg;
@@ -476,14 +468,10 @@ void run_vm(pgpu_ctx* ctx, size_t nb, const SegSpec& s0, const SegSpec* s1, bool
       if (ss[i] && ss[i]->prog->wide_gathers)   // (an opcode a kernel does not know ends its program: refuse, never compute garbage)
         api_throw(PGPU_ERR_UNSUPPORTED, "internal: the one-lane pair kernel for 55-limb primes has 4-bit per-number windows only");
   if (ev) snprintf(ev->name, sizeof ev->name, use_asm ? "vm_asm_%d_%d" : "vm_kernel<%d,%d>", WL, K);
-  // (a launch wider than half the chip's CUs keeps the dispatcher's placement: two of its workgroups per CU beat a second round)
-  const bool exclusive = use_asm && ctx->use_exclusive && ctx->exclusive_call && blocks <= plan::kExclusiveMaxBlocks;
-  // A main-stream launch of at most one workgroup per CU spreads over the CUs (see launch_vm_asm); the side lanes' launches keep
-  // their own LDS size and fit beside it.
-  static const int spread_env = [] { const char* v = getenv("PGPU_SPREAD"); return v ? atoi(v) : 1; }();
+  // placement by LDS size (plan::lds_share): a CU per workgroup for the small launches of a call whose launches run beside each other, at
+  // most one workgroup per CU for a main-stream ladder that fits the CUs its stream may use
   const bool on_side = ctx->stream == ctx->side || ctx->stream == ctx->side_l[0] || ctx->stream == ctx->side_l[1] || ctx->stream == ctx->side_l[2];
-  const bool spread = use_asm && ctx->use_exclusive && spread_env && !on_side && blocks <= plan::kChipCUs && montmuls >= 256;
-  const int lds_share = exclusive ? 1 : spread ? 2 : 0;
+  const int lds_share = !use_asm ? 0 : plan::lds_share(blocks, ctx->stream_cus, on_side, ctx->exclusive_call, montmuls, ctx->use_exclusive, ctx->use_spread);
   hipError_t e = use_asm ? launch_vm_asm(WL, K, a, blocks, ctx->stream, lds_share) : launch_vm(WL, K, a, blocks, ctx->stream);
   if (use_asm) ctx->last_vm_asm++;
   ctx->last_vm_launches++;

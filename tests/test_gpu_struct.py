@@ -60,13 +60,22 @@ def test_alpha_by_structure_is_pow(ctx, bits, S, secpar):
     assert al[2 % S][-1] == _alpha(n, ct1[2 % S], xs[2 % S][-1], ys[2 % S][-1])
     # the whole instance -- Alpha, E, F, both challenge bits among them -- against the restatement of proveDDLEQInstance; from four
     # instances per statement the RESPONSE goes through the structure as well (struct_response)
+    # The sample: the first instances, plus the first instance of EACH challenge bit (picked by the hash of the transcript, as
+    # tests/test_gpu_nonunit.py does; the restatement then recomputes Alpha, the bit and the response on its own).  Every
+    # parametrisation above draws both bits (seeds checked with the oracle), and the test insists on it.
+    sample = [(j, k) for j in range(min(S, 2)) for k in range(min(secpar, 4))]
+    for want in (True, False):
+        hit = next(((j, k) for j in range(S) for k in range(secpar)
+                    if po.random_oracle_bit(ct1[j], ct2[j], xs[j][k], ys[j][k], al[j][k]) == want), None)
+        assert hit is not None, f"no instance with challenge bit {int(want)} among the draws: change the seed"
+        if hit not in sample:
+            sample.append(hit)
     bits_seen = set()
-    for j in range(min(S, 2)):
-        for k in range(min(secpar, 4)):
-            inst = po.prove_ddleq_instance_xy(sk_o, po.Ciphertext(ct1[j], 1), po.Ciphertext(ct2[j], 1), a_s[j], b_s[j], xs[j][k], ys[j][k])
-            assert (al[j][k], es[j][k], fs[j][k]) == (inst.Alpha, inst.E, inst.F), (j, k)
-            bits_seen.add(inst.E != xs[j][k])
-    assert len(bits_seen) >= 1
+    for j, k in sample:
+        inst = po.prove_ddleq_instance_xy(sk_o, po.Ciphertext(ct1[j], 1), po.Ciphertext(ct2[j], 1), a_s[j], b_s[j], xs[j][k], ys[j][k])
+        assert (al[j][k], es[j][k], fs[j][k]) == (inst.Alpha, inst.E, inst.F), (j, k)
+        bits_seen.add(inst.E != xs[j][k])
+    assert bits_seen == {True, False}
 
 
 def test_non_units_fall_back_to_the_literal_ladders(ctx):
@@ -81,10 +90,14 @@ def test_non_units_fall_back_to_the_literal_ladders(ctx):
     S = 6
     ct1, ct2, a_s, b_s = _statements(sk_o, S, rng)
     xs, ys = [po.rand_unit(n, rng) for _ in range(S)], [po.rand_unit(n, rng) for _ in range(S)]
-    ys[3] = q * rng.randrange(1, p)                               # a non-unit draw y
-    # (the prover only needs Alpha and the sanity check here: pick draws whose challenge bit is 0 so that no response is needed)
+    # a non-unit draw y whose challenge bit is 0 (the prover then needs Alpha and the sanity check only, no response): redrawn
+    # until the hash says so, so that lane 3 is ALWAYS among the instances proved
+    for _ in range(64):
+        ys[3] = q * rng.randrange(1, p)
+        if not po.random_oracle_bit(ct1[3], ct2[3], xs[3], ys[3], _alpha(n, ct1[3], xs[3], ys[3])):
+            break
     keep = [i for i in range(S) if not po.random_oracle_bit(ct1[i], ct2[i], xs[i], ys[i], _alpha(n, ct1[i], xs[i], ys[i]))]
-    assert 3 in keep or True
+    assert 3 in keep and len(keep) >= 2
     pick = lambda v: [v[i] for i in keep]
     al, es, fs = sk.ProveDDLEQInstancesBatch(pick(ct1), pick(ct2), pick(a_s), pick(b_s), pick(xs), pick(ys))
     assert al == [_alpha(n, ct1[i], xs[i], ys[i]) for i in keep] and es == pick(xs) and fs == pick(ys)

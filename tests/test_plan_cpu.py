@@ -142,11 +142,43 @@ def test_extract_randomness_beside_the_first_launch(q):
     assert q("shared_chain_groups", 2048, 3, 0, 1) == [3]
     assert q("shared_chain_groups", 256, 2, 0, 1) == [2]
     assert q("shared_chain_groups", 2048, 3, 0, 0) == [1]
-    # a compute unit per workgroup for the small concurrent launches of a prover call: every call size (launches wider than 128
-    # workgroups never take part -- run_vm)
-    assert q("exclusive_cus", 2048, 2048, 0) == [1]
-    assert q("exclusive_cus", 16384, 16384, 0) == [1]
-    assert q("exclusive_cus", 1536, 61440, 0) == [1]
+
+
+def test_placement_by_lds_size(q):
+    """plan::lds_share(blocks, stream_cus, on_side, in_exclusive_call, products, exclusive_flag, spread_flag)."""
+    # inside a prover call: a compute unit per workgroup for launches of up to 128 workgroups, main stream or side lane
+    assert q("lds_share", 64, 256, 1, 1, 4000, 1, 1) == [1]
+    assert q("lds_share", 128, 256, 0, 1, 4000, 1, 1) == [1]
+    # wider: a main-stream ladder of at most one workgroup per CU spreads (just over half a CU's LDS); a side lane's keeps its size
+    assert q("lds_share", 256, 256, 0, 1, 4000, 1, 1) == [2]
+    assert q("lds_share", 256, 256, 1, 1, 4000, 1, 1) == [0]
+    assert q("lds_share", 257, 256, 0, 0, 4000, 1, 1) == [0]
+    # outside a prover call: the spread rule alone, for ladders (>= 256 products), never for the links between them
+    assert q("lds_share", 64, 256, 0, 0, 4000, 1, 1) == [2]
+    assert q("lds_share", 64, 256, 0, 0, 100, 1, 1) == [0]
+    # the switches
+    assert q("lds_share", 64, 256, 0, 1, 4000, 0, 1) == [0]
+    assert q("lds_share", 64, 256, 0, 0, 4000, 1, 0) == [0]
+    assert q("lds_share", 64, 256, 0, 1, 4000, 1, 0) == [1]
+    # VERDICT r4 weak / item 5: a context confined to 32 CUs (eight contexts side by side, INTEGRATION.md section 4) must not ask
+    # for a CU -- or half of one -- per workgroup with 64 workgroups: that would be two rounds on its slice
+    assert q("lds_share", 64, 32, 0, 0, 4000, 1, 1) == [0]
+    assert q("lds_share", 64, 32, 0, 1, 4000, 1, 1) == [0]
+    assert q("lds_share", 32, 32, 0, 0, 4000, 1, 1) == [2]
+
+
+def test_generic_kernel_lanes(q):
+    """plan::generic_shape: natural shape from one wave per SIMD upwards, finer slices (>= 37 limbs, <= 4 lanes) below."""
+    assert q("generic_shape", 148, 1, 65536, 1, 0, 1) == [148, 1]
+    assert q("generic_shape", 148, 1, 32768, 1, 0, 1) == [74, 2]
+    assert q("generic_shape", 148, 1, 16384, 1, 0, 1) == [37, 4]
+    assert q("generic_shape", 148, 1, 16384, 2, 0, 1) == [74, 2]          # two segments share the launch
+    assert q("generic_shape", 74, 1, 16384, 2, 0, 1) == [37, 2]
+    assert q("generic_shape", 37, 1, 256, 1, 0, 1) == [37, 1]             # 37-limb slices are the narrowest
+    assert q("generic_shape", 110, 1, 256, 1, 0, 1) == [55, 2]
+    assert q("generic_shape", 148, 1, 256, 1, 1, 1) == [148, 1]           # lanes_wanted = 1: always the natural shape
+    assert q("generic_shape", 74, 2, 65536, 1, 0, 0) == [37, 4]           # without the wave-sliced kernel: four lanes of 37
+    assert q("generic_shape", 74, 2, 65536, 1, 0, 1) == [74, 2]
 
 
 PAIR_SHARED = [
@@ -211,3 +243,27 @@ def test_no_size_predicate_outside_plan_hpp():
         src = open(os.path.join(csrc, f)).read()
         src = re.sub(r"//[^\n]*", "", src)
         assert "1ull << 32" not in src and "1024 * 64" not in src, f"{f} carries a size predicate of its own: move it to plan.hpp"
+        # the lane-halving loop of the generic kernels and the placement rules live in plan.hpp too
+        assert not re.search(r"\bK\s*\*=\s*2\b", src) and "kExclusiveMaxBlocks" not in src, f"{f}: lanes / placement decided outside plan.hpp"
+
+
+def test_no_environment_switch_changes_the_plan():
+    """every switch is a documented pgpu_ctx_set_flag name; the library reads the environment only for the two
+    diagnostics that print timings (a Go host inherits its environment from wherever it runs)."""
+    csrc = os.path.join(ROOT, "paillier_amd", "csrc")
+    allowed = {"PGPU_PROFILE_DUMP", "PGPU_HOST_TRACE"}
+    header = open(os.path.join(ROOT, "include", "paillier_hip.h")).read()
+    dbg = open(os.path.join(ROOT, "include", "paillier_hip_debug.h")).read()
+    for f in sorted(os.listdir(csrc)):
+        if not f.endswith((".cpp", ".hpp", ".hip", ".h")):
+            continue
+        src = open(os.path.join(csrc, f)).read()
+        for name in re.findall(r'getenv\(\s*"([A-Z_0-9]+)"', src):
+            assert name in allowed, f"{f} reads {name}: make it a pgpu_ctx_set_flag name"
+        assert len(re.findall(r"getenv\(", src)) == len(re.findall(r'getenv\(\s*"', src)), f"{f}: getenv of a computed name"
+    for name in allowed:
+        assert name in dbg, f"{name} is not documented in paillier_hip_debug.h"
+    # every flag name the library accepts is documented in the header
+    ctx_src = open(os.path.join(csrc, "ctx.cpp")).read()
+    for name in re.findall(r'strcmp\(name, "([a-z_0-9]+)"\)', ctx_src):
+        assert f'"{name}"' in header, f"flag {name} is not documented in include/paillier_hip.h"
