@@ -270,11 +270,14 @@ def main():
     except OSError:
         PLAN = {"per_unit": {}, "tolerance": 0.01}
     plan_dev = {}
-    try:
-        with open(os.path.join(ROOT, "profiles", "r04_rank_floor.json")) as f:
-            RANK_FLOOR = json.load(f)
-    except OSError:
-        RANK_FLOOR = {}
+    RANK_FLOOR = {}
+    for rf in ("r05_rank_floor.json", "r04_rank_floor.json"):      # the newest table tools/rank_floor.py wrote
+        try:
+            with open(os.path.join(ROOT, "profiles", rf)) as f:
+                RANK_FLOOR = json.load(f)
+            break
+        except OSError:
+            continue
 
     def plan_check(name, mads_per_unit, applies=True):
         """fraction by which this run's executed multiply-adds per unit differ from the committed table (None: not comparable)"""
@@ -384,7 +387,7 @@ def main():
             e["frac_of_call_time"] = mads / dt / PEAK_MAD_PER_S
         if world > 1:
             e.update({"scaling": scaling, "n_gpus": world})
-            # a strong-scaled entry's rank runs a SMALL shard: what that shard takes on one GPU (measured, profiles/r04_rank_floor.json)
+            # a strong-scaled entry's rank runs a SMALL shard: what that shard takes on one GPU (measured, profiles/r0N_rank_floor.json)
             fl = RANK_FLOOR.get(name, {}).get(str(world))
             if scaling == "strong" and fl:
                 e["predicted_rank_floor_ms"] = fl
@@ -596,7 +599,8 @@ def main():
         del s1, s2, sa, sb, sx, sy, al, pe, pf, r1_, r2_
 
     # config 4: threshold decryption (t = 3, l = 5), 16384 ciphertexts per step over the `world` ranks -- strong scaling:
-    # (server, ciphertext) units sharded over the ranks, all-gather of the 512-byte partials (RCCL), local combine
+    # (server, ciphertext) units sharded over the ranks, all-gather of the 512-byte partials (RCCL), local combine; and, for
+    # N > 1, the no-exchange shard of ranks that hold every share beside it
     if not args.no_extra:
         kt = KEYS["threshold"]["2048"]
         tn, shares = int(kt["n"], 16), [int(s, 16) for s in kt["shares"]]
@@ -656,41 +660,46 @@ def main():
             note()
             return o
 
-        shard_mode = pdist.threshold_shard_mode(BT, world)
-
-        def tstep():
-            # every rank of this bench holds all t shares: while a rank keeps >= 4 096 ciphertexts it takes a ciphertext slice under
-            # all of them (one chain of squarings per ciphertext, no exchange); below that, (server, ciphertext) unit ranges
-            if shard_mode == "ciphertext":
-                return pdist.threshold_decrypt_ciphertext_major(tc, len(ids), rank, world, range_fn, combine_fn)
-            # one launch per rank once a rank's share of a server falls below what fills the chip on its own
-            return pdist.threshold_decrypt_sharded(tc, len(ids), rank, world, partial_fn, combine_fn,
-                                                   units_fn=units_fn if (len(ids) * BT) // world < 32768 else None,
-                                                   servers_fn=servers_fn, range_fn=range_fn)
-
-        tstep()
-        barrier()
-        acc.update(mads=0.0, ms=0.0, best=0.0)
-        t = time.perf_counter()
-        for _ in range(args.extra_steps):
-            tout, (sb, se) = tstep()
-        barrier()
-        tel = pdist.max_over_ranks(time.perf_counter() - t, dev)
-        tok = pdist.min_over_ranks(1 if (tout is None or torch.equal(tout, tm[sb:se])) else 0, dev)
-        if not tok:
-            raise SystemExit("[bench] threshold decryption: Combine(PartialDecrypt x 3) != m on some rank")
-        e = entry("threshold_2048", f"t=3 of l=5, servers {ids}, 16384 ciphertexts per step, 2048-bit safe-prime key: 3 x "
-                  f"PartialDecrypt + CombinePartialDecryptions; " +
-                  (f"ciphertext slices over {world} ranks that hold every share (one chain of squarings per ciphertext, no exchange)"
-                   if shard_mode == "ciphertext" else
-                   f"(server, ciphertext) units sharded over {world} rank(s), all-gather of the partials" +
-                   ((" over gloo (rehearsal)" if args.rehearse_one_gpu else " over RCCL") if world > 1 else " (single rank: no exchange)")) +
-                  ", local combine", "threshold decryptions/s", BT, tel / args.extra_steps,
-                  acc["ms"] / args.extra_steps, acc["mads"] / args.extra_steps, acc["kern"],
-                  "all 16384 plaintexts recovered on every rank", scaling="strong")
-        e.update({"scaling": "strong", "n_gpus": world, "shard": shard_mode, "exchange_bytes_per_step": len(ids) * BT * 512 if (world > 1 and shard_mode == "units") else 0,
-                  "kernel_ms_note": "rank 0's share of the step"})
-        extras.append(e)
+        fns = dict(partial_fn=partial_fn, combine_fn=combine_fn, servers_fn=servers_fn, range_fn=range_fn,
+                   # (one launch per rank once a rank's share of a server falls below what fills the chip on its own)
+                   units_fn=units_fn if (len(ids) * BT) // world < 32768 else None)
+        backend = "gloo (rehearsal)" if args.rehearse_one_gpu else "RCCL"
+        # `threshold_2048` is the flow BASELINE config 4 names on every N: the servers' shares on different ranks, unit ranges, ONE
+        # all-gather of the partials (RCCL over xGMI), local combine.  With N > 1 the no-exchange shard of a holder of every share is
+        # reported beside it (`threshold_2048_replicated`).  Both go through pdist.threshold_step (tests/test_dist_gloo.py calls the same).
+        for tname, shard_mode in pdist.threshold_bench_entries(world):
+            tmg = {}
+            tstep = lambda: pdist.threshold_step(shard_mode, tc, len(ids), rank, world, timings=tmg, **fns)
+            tstep()
+            barrier()
+            acc.update(mads=0.0, ms=0.0, best=0.0)
+            tmg.clear()
+            t = time.perf_counter()
+            for _ in range(args.extra_steps):
+                tout, (sb, se) = tstep()
+            barrier()
+            tel = pdist.max_over_ranks(time.perf_counter() - t, dev)
+            tok = pdist.min_over_ranks(1 if (tout is None or torch.equal(tout, tm[sb:se])) else 0, dev)
+            if not tok:
+                raise SystemExit(f"[bench] threshold decryption ({shard_mode} shard): Combine(PartialDecrypt x 3) != m on some rank")
+            exch_ms = pdist.max_over_ranks(tmg.get("exchange_s", 0.0), dev) / args.extra_steps * 1e3
+            e = entry(tname, f"t=3 of l=5, servers {ids}, 16384 ciphertexts per step, 2048-bit safe-prime key: 3 x "
+                      f"PartialDecrypt + CombinePartialDecryptions; " +
+                      (f"ciphertext slices over {world} ranks that hold every share (one chain of squarings per ciphertext, no exchange)"
+                       if shard_mode == "ciphertext" else
+                       f"(server, ciphertext) units sharded over {world} rank(s), all-gather of the partials" +
+                       (f" over {backend}" if world > 1 else " (single rank: no exchange)")) +
+                      ", local combine", "threshold decryptions/s", BT, tel / args.extra_steps,
+                      acc["ms"] / args.extra_steps, acc["mads"] / args.extra_steps, acc["kern"],
+                      "all 16384 plaintexts recovered on every rank", scaling="strong")
+            e.update({"scaling": "strong", "n_gpus": world, "shard": shard_mode,
+                      "exchange_bytes_per_step": tmg.get("exchange_bytes", 0), "exchange_padded_bytes_per_step": tmg.get("exchange_padded_bytes", 0),
+                      "exchange_ms_per_step": exch_ms if shard_mode == "units" and world > 1 else 0.0,
+                      "exchange_backend": tmg.get("exchange_backend"), "exchange_world_size": tmg.get("exchange_world", world),
+                      "kernel_ms_note": "rank 0's share of the step"})
+            if exch_ms and shard_mode == "units" and world > 1:
+                e["exchange_GBps"] = tmg.get("exchange_padded_bytes", 0) / (exch_ms * 1e-3) / 1e9
+            extras.append(e)
         if world == 1:
             checks["threshold_2048"] = (tn, shares, ids, tc[:64].cpu().numpy(), tm_h[:64])
 

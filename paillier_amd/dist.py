@@ -64,8 +64,14 @@ def all_gather_bytes(local, world: int):
     return out.view((world,) + tuple(local.shape)).to(dev)
 
 
+def _sync(t):
+    if getattr(t, "is_cuda", False):
+        import torch
+        torch.cuda.synchronize(t.device)
+
+
 def threshold_decrypt_sharded(c, n_servers: int, rank: int, world: int, partial_fn, combine_fn, pad_rows: bool = True,
-                              units_fn=None, servers_fn=None, range_fn=None):
+                              units_fn=None, servers_fn=None, range_fn=None, timings=None):
     """Threshold decryption of B ciphertexts with the work sharded over `world` ranks and ONE exchange step
     (thresholdkey.go:149-201: every server's PartialDecrypt, then CombinePartialDecryptions).
 
@@ -87,8 +93,13 @@ def threshold_decrypt_sharded(c, n_servers: int, rank: int, world: int, partial_
                    cipher_bytes]: this rank's units straight from the whole ciphertext batch (pgpu_partial_decrypt_units:
                    ciphertexts the range wants under several shares walk one chain of squarings -- a rank that holds one
                    server whole and half of the next, N = 2, computes 1.5 ladders' worth instead of 3 half-batch ladders)
+      timings      optional dict: receives what the exchange of this step cost -- "exchange_s" (seconds of the all-gather on this
+                   rank, between device synchronisations; added to what is there), "exchange_bytes" (payload: the partials of
+                   every unit), "exchange_padded_bytes" (what the collective moved into this rank), "exchange_world" (the world
+                   size the BACKEND reports) and "exchange_backend"
     Returns (plaintext rows of this rank's ciphertext slice, (begin, end) of that slice).
     """
+    import time
     import torch
     B, cbytes = int(c.shape[0]), int(c.shape[1])
     units = n_servers * B
@@ -112,7 +123,19 @@ def threshold_decrypt_sharded(c, n_servers: int, rank: int, world: int, partial_
             cnt = min(ue - u, B - i0)
             local[u - ub:u - ub + cnt] = partial_fn(s, c[i0:i0 + cnt])
             u += cnt
+    if timings is not None:
+        _sync(local)
+        t0 = time.perf_counter()
     g = all_gather_bytes(local, world).reshape(world * max(per, 1), cbytes)
+    if timings is not None:
+        import torch.distributed as dist
+        _sync(g)
+        live = world > 1 and dist.is_available() and dist.is_initialized()
+        timings["exchange_s"] = timings.get("exchange_s", 0.0) + (time.perf_counter() - t0)
+        timings["exchange_bytes"] = units * cbytes if world > 1 else 0
+        timings["exchange_padded_bytes"] = world * max(per, 1) * cbytes if world > 1 else 0
+        timings["exchange_world"] = dist.get_world_size() if live else 1
+        timings["exchange_backend"] = dist.get_backend() if live else None
     parts = torch.empty((units, cbytes), dtype=torch.uint8, device=c.device)
     for q in range(world):          # un-pad: rank q's units sit at rows [q*per, q*per + len_q)
         qb, qe = shard_slice(units, q, world)
@@ -124,8 +147,38 @@ def threshold_decrypt_sharded(c, n_servers: int, rank: int, world: int, partial_
     return combine_fn([parts[s, cb:ce].contiguous() for s in range(n_servers)]), (cb, ce)
 
 
+THRESHOLD_SHARDS = ("units", "ciphertext")
+
+
+def threshold_bench_entries(world: int):
+    """(entry name, shard) pairs bench.py reports for BASELINE config 4.  `threshold_2048` is ALWAYS the flow north_star names: the
+    servers' shares on different ranks, every rank computes its (server, ciphertext) unit range, the partials are all-gathered over
+    RCCL / xGMI, every rank combines its own ciphertext slice.  With more than one rank the bench adds the no-exchange shard of a
+    holder of every share beside it (`threshold_2048_replicated`); on one rank the two are the same call."""
+    return [("threshold_2048", "units")] + ([("threshold_2048_replicated", "ciphertext")] if world > 1 else [])
+
+
+def threshold_step(shard: str, c, n_servers: int, rank: int, world: int, *, partial_fn, combine_fn, units_fn=None, servers_fn=None,
+                   range_fn=None, timings=None):
+    """One threshold decryption of the batch `c` in the named shard -- the function bench.py times and the gloo tests call.
+      "units"       threshold_decrypt_sharded: unit ranges, ONE all-gather of the partials, local combine
+      "ciphertext"  threshold_decrypt_ciphertext_major: ciphertext slices under every share, no exchange (needs range_fn)
+    Returns (plaintext rows of this rank's ciphertext slice or None, (begin, end))."""
+    if shard == "units":
+        return threshold_decrypt_sharded(c, n_servers, rank, world, partial_fn, combine_fn, units_fn=units_fn, servers_fn=servers_fn,
+                                         range_fn=range_fn, timings=timings)
+    if shard == "ciphertext":
+        if range_fn is None:
+            raise ValueError("the ciphertext-major shard needs range_fn")
+        if timings is not None:
+            timings.update(exchange_bytes=0, exchange_padded_bytes=0, exchange_world=world, exchange_backend=None)
+            timings.setdefault("exchange_s", 0.0)
+        return threshold_decrypt_ciphertext_major(c, n_servers, rank, world, range_fn, combine_fn)
+    raise ValueError(f"unknown threshold shard {shard!r}: one of {THRESHOLD_SHARDS}")
+
+
 def threshold_shard_mode(n_ciphertexts: int, world: int) -> str:
-    """Which shard of the threshold flow a holder of EVERY share should take.  Measured per rank on one MI355X (t = 3, 2048-bit key,
+    """Which shard of the threshold flow a holder of EVERY share should take (a caller's choice; bench.py reports both).  Measured per rank on one MI355X (t = 3, 2048-bit key,
     16 384 ciphertexts, tools/threshold_shard_probe.py): unit ranges 81 / 70 / 59 / 36 ms at N = 1 / 2 / 4 / 8 plus the exchange of the
     partials; ciphertext slices 81 / 49 / 43 / 36 ms and no exchange (the t ladders of a ciphertext share a chain of squarings while
     the chip is full, and split into chains of their own on the eight-lane kernel as it empties: plan::shared_chain_groups).  So:

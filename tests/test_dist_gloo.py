@@ -60,6 +60,21 @@ def test_two_rank_sharding_and_exchange(total):
         assert allp == [[[1] * 8] * 3, [[2] * 8] * 3]
 
 
+def test_threshold_bench_entries():
+    """BASELINE config 4 in the N-rank bench: `threshold_2048` is the exchange flow on EVERY N; the no-exchange
+    shard of a holder of every share is a second entry beside it from two ranks up."""
+    from paillier_amd import dist as pd
+    assert pd.threshold_bench_entries(1) == [("threshold_2048", "units")]
+    for world in (2, 3, 4, 8):
+        assert pd.threshold_bench_entries(world) == [("threshold_2048", "units"), ("threshold_2048_replicated", "ciphertext")]
+    with pytest.raises(ValueError):
+        pd.threshold_step("rows", None, 3, 0, 1, partial_fn=None, combine_fn=None)
+    # bench.py goes through threshold_step for both and reports the exchange of the first
+    src = open(os.path.join(ROOT, "bench.py")).read()
+    assert "pdist.threshold_step(shard_mode" in src and "pdist.threshold_bench_entries(world)" in src
+    assert "exchange_bytes_per_step" in src and "exchange_ms_per_step" in src and "exchange_world_size" in src
+
+
 def test_shard_slice_properties():
     from paillier_amd.dist import shard_slice
     for total in (0, 1, 7, 16384, 65537):
@@ -140,7 +155,14 @@ def _threshold_worker(rank, world, port, ids, count, use_gpu, q):
             tk.partial_decrypt_units_raw([shares[i - 1] for i in ids], rows.shape[0], rows, cb, ub, ue, out, cb)
             return torch.from_numpy(out)
         out2, _ = pd.threshold_decrypt_sharded(c, len(ids), rank, world, partial_fn, combine_fn, units_fn=units_fn)
-    out, (b, e) = pd.threshold_decrypt_sharded(c, len(ids), rank, world, partial_fn, combine_fn, units_fn=units_fn, range_fn=range_fn)
+    # bench.py's tstep: pd.threshold_step in the shard of BASELINE config 4 -- unit ranges, ONE all-gather, local combine -- with
+    # the exchange accounted for
+    tm = {}
+    out, (b, e) = pd.threshold_step("units", c, len(ids), rank, world, partial_fn=partial_fn, combine_fn=combine_fn, units_fn=units_fn,
+                                    range_fn=range_fn, timings=tm)
+    assert tm["exchange_world"] == world == dist.get_world_size() and tm["exchange_backend"] == "gloo"
+    assert tm["exchange_bytes"] == len(ids) * count * cb and tm["exchange_padded_bytes"] >= tm["exchange_bytes"]
+    assert tm["exchange_padded_bytes"] == world * -(-len(ids) * count // world) * cb and tm["exchange_s"] > 0
     if use_gpu and out is not None:
         assert torch.equal(out, out2)
     # the ciphertext-major shard (every rank holds every share: no exchange) gives the same plaintexts for the same slice
@@ -148,8 +170,10 @@ def _threshold_worker(rank, world, port, ids, count, use_gpu, q):
         def range_fn(rows, ub, ue):          # CPU rehearsal: server-major units of the slice, one oracle call each
             vals = to_ints(rows)
             return to_rows([po.partial_decrypt(tsk[ids[u // len(vals)]], vals[u % len(vals)]).Decryption for u in range(ub, ue)], cb)
-    out3, (b3, e3) = pd.threshold_decrypt_ciphertext_major(c, len(ids), rank, world, range_fn, combine_fn)
-    assert (b3, e3) == (b, e)
+    tm3 = {}
+    out3, (b3, e3) = pd.threshold_step("ciphertext", c, len(ids), rank, world, partial_fn=partial_fn, combine_fn=combine_fn,
+                                       range_fn=range_fn, timings=tm3)
+    assert (b3, e3) == (b, e) and tm3["exchange_bytes"] == 0 and tm3["exchange_s"] == 0.0
     if out is not None:
         assert torch.equal(out, out3)
     q.put((rank, b, e, to_ints(out) if out is not None else []))

@@ -1,7 +1,8 @@
 #!/usr/bin/env python3
 """What ONE rank of the strong-scaled bench entries computes at N = 1, 2, 4, 8 (16384 / N statements or ciphertexts), measured on one GPU:
-NestedRandomize, DDLEQ prove, DDLEQ verify (config 5) and the ciphertext-major threshold shard (config 4).  Writes the table bench.py reads
-(profiles/r04_rank_floor.json) to stdout.   rank_floor.py [reps]"""
+NestedRandomize, DDLEQ prove, DDLEQ verify (config 5) and both threshold shards (config 4: `threshold_2048` = the slowest rank's unit range of
+the exchange flow, `threshold_2048_replicated` = a ciphertext slice under all three shares).  Writes the table bench.py reads
+(profiles/r05_rank_floor.json) to stdout.   rank_floor.py [reps]"""
 import json, os, sys, time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
@@ -29,7 +30,7 @@ def best(fn):
     for _ in range(REPS):
         t = time.perf_counter(); fn(); torch.cuda.synchronize(); ts.append((time.perf_counter() - t) * 1e3)
     return round(min(ts), 1)
-out = {"nested_randomize_2048": {}, "ddleq_prove_2048": {}, "ddleq_verify_2048": {}, "threshold_2048": {}}
+out = {"nested_randomize_2048": {}, "ddleq_prove_2048": {}, "ddleq_verify_2048": {}, "threshold_2048": {}, "threshold_2048_replicated": {}}
 for world in (1, 2, 4, 8):
     B = 16384 // world
     msg, r1, r2, a_, b_, x_, y_ = below(n, 256, B), unit(B), unit(B), unit(B), unit(B), unit(B), unit(B)
@@ -54,13 +55,21 @@ c = torch.from_numpy(raw).to(dev)
 for world in (1, 2, 4, 8):
     cnt = 16384 // world
     o = torch.empty((3 * cnt, 512), dtype=torch.uint8, device=dev)
-    out["threshold_2048"][str(world)] = best(lambda: tk.partial_decrypt_units_raw(sh, cnt, c[:cnt].data_ptr(), 512, 0, 3 * cnt, o.data_ptr(), 512, MEM_DEVICE))
+    out["threshold_2048_replicated"][str(world)] = best(lambda: tk.partial_decrypt_units_raw(sh, cnt, c[:cnt].data_ptr(), 512, 0, 3 * cnt, o.data_ptr(), 512, MEM_DEVICE))
+    # the exchange flow: rank r computes units [r * 3 * 16384 / N, (r + 1) * 3 * 16384 / N) of the whole batch (server-major); the slowest rank
+    # (one whose range straddles two servers) is the floor
+    per = 3 * 16384 // world
+    worst = 0.0
+    for r in range(world):
+        worst = max(worst, best(lambda: tk.partial_decrypt_units_raw(sh, 16384, c.data_ptr(), 512, r * per, (r + 1) * per, o.data_ptr(), 512, MEM_DEVICE)))
+    out["threshold_2048"][str(world)] = worst
 out["_comment"] = ("What ONE rank of a strong-scaled bench entry takes on its share (16384 / N statements or ciphertexts), measured on one GPU by "
                    "tools/rank_floor.py (best of %d calls).  bench.py --gpus N prints the figure for its N beside the entry (predicted_rank_floor_ms): "
                    "these entries are latency-bound by construction -- a ladder's length, not its width, is the run time of a small shard -- so an "
                    "N-GPU run cannot beat N x (job / floor)." % REPS)
 for k_, u in (("nested_randomize_2048", "ms per rank for 16384 / N ciphertexts"), ("ddleq_prove_2048", "ms per rank for 16384 / N instances"),
               ("ddleq_verify_2048", "ms per rank for 16384 / N instances"),
-              ("threshold_2048", "ms of partial decryption per rank: a slice of 16384 / N ciphertexts under all three shares (no exchange); the combine comes on top (4 - 5 ms at N = 1)")):
+              ("threshold_2048", "ms of partial decryption on the slowest rank: its range of the 3 x 16384 (server, ciphertext) units; the all-gather of the partials and the combine of 16384 / N ciphertexts come on top"),
+              ("threshold_2048_replicated", "ms of partial decryption per rank: a slice of 16384 / N ciphertexts under all three shares (no exchange); the combine comes on top (4 - 5 ms at N = 1)")):
     out[k_]["unit"] = u
 print(json.dumps(out, indent=1))
