@@ -465,6 +465,79 @@ def main():
             extras.append(entry("decrypt_2048_b131072", "Batch 131072 Decrypt, 2048-bit n, level 1, CRT (the headline path, twice the batch)",
                                 "decryptions/s", BB, dt, vms, mads, kern, "131072-lane round trip"))
             del bc, bo
+        # ---- the homomorphic operations (operations.go:11-64; the reference's own BenchmarkAdd / BenchmarkConstMul2,
+        # operations_test.go:165-198) on the ciphertexts of config 2: 65536 per GPU, weak-scaled like Encrypt ----------------------
+        hb = torch.flip(ec, dims=[0]).contiguous()                   # second operand: the same ciphertexts in reverse order
+        ho = torch.zeros((BE, 512), dtype=torch.uint8, device=dev)
+        ho2 = torch.zeros((BE, 512), dtype=torch.uint8, device=dev)
+
+        def hbm_note(e_, bytes_per_unit):
+            # Add / Sub are a handful of multiplies per 1.5 KB moved: the HBM side of the roofline is the one to read
+            e_["alg_bytes_per_unit"] = bytes_per_unit
+            e_["hbm_frac_of_call_time"] = bytes_per_unit * BE / (e_["ms_per_batch"] * 1e-3) / 1e9 / HBM_PEAK_GBPS
+            return e_
+
+        dt, vms, mads, kern = timed(lambda: one_call(lambda: pk2.add_raw(BE, ec.data_ptr(), 512, hb.data_ptr(), 512, ho.data_ptr(), 512, MEM_DEVICE)), ES)
+        add_rows = ho[:64].cpu().numpy()
+        extras.append(hbm_note(entry("add_2048", "65536 Add(a, b) per GPU, 2048-bit n, level 1: a * b mod n^2 (operations.go:11-29; "
+                                     "BenchmarkAdd, operations_test.go:165-172)", "additions/s", world * BE, dt, vms, mads, kern,
+                                     "Sub(Add(a, b), b) == a on all 65536 lanes (below)"), 3 * 512))
+        dt, vms, mads, kern = timed(lambda: one_call(lambda: pk2.sub_raw(BE, ho.data_ptr(), 512, hb.data_ptr(), 512, ho2.data_ptr(), 512, MEM_DEVICE)), ES)
+        all_ranks_ok(torch.equal(ho2, ec), "Sub(Add(a, b), b) != a")
+        sub_rows = ho2[:64].cpu().numpy()
+        extras.append(hbm_note(entry("sub_2048", "65536 Sub(a, b) per GPU, 2048-bit n, level 1: a * b^-1 mod n^2 (operations.go:32-55): "
+                                     "batch inversion as a product tree, one inversion of the root on the host", "subtractions/s",
+                                     world * BE, dt, vms, mads, kern, "Sub(Add(a, b), b) == a on all 65536 lanes"), 3 * 512))
+        # ConstMult with the reference benchmark's constant (BenchmarkConstMul2: k = 50^50 mod n^2 -- 283 bits, shared by the batch)
+        k50 = pow(50, 50, n2k * n2k)
+        k50b = np.frombuffer(k50.to_bytes((k50.bit_length() + 7) // 8, "big"), dtype=np.uint8).copy()
+        dt, vms, mads, kern = timed(lambda: one_call(lambda: pk2.const_mult_raw(BE, ec.data_ptr(), 512, k50b, k50b.size, 0, ho.data_ptr(), 512, MEM_DEVICE)), ES)
+        # ... the same constant as one exponent PER ciphertext (another ladder: per-number windows): the same ciphertexts out
+        k50rows = torch.from_numpy(np.tile(k50b, (BE, 1))).to(dev)
+        pk2.const_mult_raw(BE, ec.data_ptr(), 512, k50rows.data_ptr(), k50b.size, k50b.size, ho2.data_ptr(), 512, MEM_DEVICE)
+        all_ranks_ok(torch.equal(ho, ho2), "ConstMult: shared k and per-ciphertext k disagree")
+        extras.append(entry("const_mult_2048", "65536 ConstMult(c, k) per GPU, 2048-bit n, k = 50^50 mod n^2 shared (283 bits; "
+                            "BenchmarkConstMul2, operations_test.go:186-198): c^k mod n^2 (operations.go:58-64)", "ciphertexts/s",
+                            world * BE, dt, vms, mads, kern, "all 65536 == the per-ciphertext-exponent ladder on the same k"))
+        if world == 1:
+            checks["homomorphic_2048"] = (n2k, k50, ec[:64].cpu().numpy(), hb[:64].cpu().numpy(), ho[:64].cpu().numpy(), add_rows, sub_rows)
+        # ... and a full-width k per ciphertext (k < n^2: what NestedAdd / a plaintext-sized scalar costs)
+        kf_h = rand_below(n2k * n2k, BE, 512, np.random.default_rng(21 + 1000 * rank))
+        kf = torch.from_numpy(kf_h).to(dev)
+        dt, vms, mads, kern = timed(lambda: one_call(lambda: pk2.const_mult_raw(BE, ec.data_ptr(), 512, kf.data_ptr(), 512, 512, ho.data_ptr(), 512, MEM_DEVICE)), ES)
+        # parity at full size: Decrypt(c^k) == k * m mod n  <=>  Decrypt(c^k) == Decrypt(c^(k mod n)): checked through the group law
+        # c^k * c^(k') == c^(k + k') on a second exponent k' = 2^4096 - 1 - k (the bytewise complement): the product is c^(2^4096 - 1)
+        kc = (255 - kf).contiguous()
+        pk2.const_mult_raw(BE, ec.data_ptr(), 512, kc.data_ptr(), 512, 512, ho2.data_ptr(), 512, MEM_DEVICE)
+        hx = torch.zeros((BE, 512), dtype=torch.uint8, device=dev)
+        pk2.add_raw(BE, ho.data_ptr(), 512, ho2.data_ptr(), 512, hx.data_ptr(), 512, MEM_DEVICE)
+        ones = np.full(512, 255, dtype=np.uint8)
+        hw = torch.zeros((BE, 512), dtype=torch.uint8, device=dev)
+        pk2.const_mult_raw(BE, ec.data_ptr(), 512, ones, 512, 0, hw.data_ptr(), 512, MEM_DEVICE)
+        all_ranks_ok(torch.equal(hx, hw), "ConstMult: c^k * c^(2^4096 - 1 - k) != c^(2^4096 - 1)")
+        del hx
+        extras.append(entry("const_mult_2048_full_k", "65536 ConstMult(c, k) per GPU, 2048-bit n, one full-width k < n^2 per ciphertext "
+                            "(4096-bit exponents, per-number windows)", "ciphertexts/s", world * BE, dt, vms, mads, kern,
+                            "c^k * c^(2^4096 - 1 - k) == c^(2^4096 - 1) on all 65536 lanes"))
+        if world == 1:
+            checks["const_mult_full_2048"] = (n2k, ec[:32].cpu().numpy(), kf_h[:32], ho[:32].cpu().numpy())
+        del hb, ho, ho2, hw, kf, kc, k50rows
+
+        # AltEncryptWithRAtLevel (paillier.go:221-238): c = G^m * h^(r mod K) mod n^2 with h = (N - H)^N fixed per key -- a fixed-base
+        # comb table, no squarings.  65536 per GPU.
+        k2 = KEYS["paillier"]["2048"]
+        pka = pa.PublicKey(ctx, n2k, n2k + 1, int(k2["h"], 16), int(k2["k"], 16))
+        ac = torch.zeros((BE, 512), dtype=torch.uint8, device=dev)
+        dt, vms, mads, kern = timed(lambda: one_call(lambda: pka.alt_encrypt_with_r_raw(
+            BE, em.data_ptr(), 256, er.data_ptr(), 256, ac.data_ptr(), 512, None, MEM_DEVICE)), ES)
+        sk2.decrypt_raw(BE, ac.data_ptr(), 512, eo.data_ptr(), 256, MEM_DEVICE)
+        all_ranks_ok(torch.equal(eo, em), "AltEncrypt: Decrypt(AltEncrypt(m, r)) != m")
+        extras.append(entry("alt_encrypt_2048", "65536 AltEncryptWithR per GPU, 2048-bit n, level 1: (1+n)^m * h^(r mod K) mod n^2 "
+                            "(paillier.go:221-238)", "encryptions/s", world * BE, dt, vms, mads, kern,
+                            "65536-lane decrypt round trip on every rank"))
+        if world == 1:
+            checks["alt_encrypt_2048"] = (n2k, int(k2["h"], 16), int(k2["k"], 16), em_h[:64], er_h[:64], ac[:64].cpu().numpy())
+        del ac, pka
         del em, er, ec, eo
 
         # config 3: Batch 65536 Decrypt, 3072-bit -- per GPU (weak scaling)
@@ -703,6 +776,37 @@ def main():
         if world == 1:
             checks["threshold_2048"] = (tn, shares, ids, tc[:64].cpu().numpy(), tm_h[:64])
 
+    # the share-decryption proof (thresholdkey.go:225-326): PartialDecryptionWithZKP (r supplied) and VerifyProof for 16384
+    # ciphertexts IN TOTAL under one server's share -- strong scaling: ciphertexts split over the ranks, no exchange
+    if not args.no_extra:
+        zserver = 2
+        zv, zvks = int(kt["v"], 16), [int(x, 16) for x in kt["vks"]]
+        zlo, zhi = pdist.shard_slice(BT, rank, world)
+        BZ = zhi - zlo
+        zr_h = rand_below(tn * tn, BT, 512, np.random.default_rng(44))[zlo:zhi]
+        zr, zc = torch.from_numpy(np.ascontiguousarray(zr_h)).to(dev), tc[zlo:zhi].contiguous()
+        zdec = torch.zeros((BZ, 512), dtype=torch.uint8, device=dev)
+        ze = torch.zeros((BZ, 32), dtype=torch.uint8, device=dev)
+        zz = torch.zeros((BZ, 560), dtype=torch.uint8, device=dev)
+        dt, vms, mads, kern = timed(lambda: one_call(lambda: tk.share_zkp_prove_raw(
+            shares[zserver - 1], zv, BZ, zc.data_ptr(), 512, zr.data_ptr(), 512, zdec.data_ptr(), 512, ze.data_ptr(), zz.data_ptr(), 560,
+            MEM_DEVICE)), args.extra_steps)
+        extras.append(entry("share_zkp_prove_2048", "16384 PartialDecryptionWithZKP (r supplied), 2048-bit safe-prime key, one server: "
+                            "c^(2 delta s), (c^4)^r, V^r mod n^2, SHA-256 of the transcript, Z = r + E delta s (thresholdkey.go:225-257)",
+                            "proofs/s", BT, dt, vms, mads, kern, "every proof verifies (below)", scaling="strong"))
+        zok = np.zeros(BZ, dtype=np.int32)
+        dt, vms, mads, kern = timed(lambda: one_call(lambda: tk.share_zkp_verify_raw(
+            zv, zvks[zserver - 1], BZ, zc.data_ptr(), 512, zdec.data_ptr(), 512, ze.data_ptr(), zz.data_ptr(), 560, zok, MEM_DEVICE)),
+            args.extra_steps)
+        all_ranks_ok(bool(zok.all()), "share ZKP: a proof made by the prover was rejected by VerifyProof")
+        extras.append(entry("share_zkp_verify_2048", "16384 VerifyProof, 2048-bit safe-prime key, one server: (c^4)^Z (c_i^2)^-E, "
+                            "V^Z v_i^-E mod n^2, SHA-256 of the transcript (thresholdkey.go:278-311)", "proofs/s", BT, dt, vms, mads, kern,
+                            "16384 of 16384 accepted", scaling="strong"))
+        if world == 1:
+            checks["share_zkp_2048"] = (tn, shares[zserver - 1], zv, zvks[zserver - 1], zc[:32].cpu().numpy(), zr_h[:32],
+                                        zdec[:32].cpu().numpy(), ze[:32].cpu().numpy(), zz[:32].cpu().numpy())
+        del zr, zc, zdec, ze, zz
+
     if rank != 0:
         if world > 1:
             dist.barrier()
@@ -852,6 +956,58 @@ def main():
             by["nested_randomize_2048"].update({"parity": f"{len(c1h)} ciphertexts == libgmp oracle; " + by["nested_randomize_2048"]["parity"],
                                                 "cpu_per_s": len(c1h) / (time.perf_counter() - t), "cpu_threads": min(int(u), len(c1h))})
             assert (want == c2h).all(), "[bench] NestedRandomize differs from the libgmp oracle"
+        if "homomorphic_2048" in checks:
+            nn, k50_, ah, bh, cmh, add_rows_, sub_rows_ = checks["homomorphic_2048"]
+            reps = 64                                       # (an Add is ~2 us of libgmp: repeat the 64 pairs so that the clock sees it)
+            abig, bbig = np.tile(ah, (reps, 1)), np.tile(bh, (reps, 1))
+            go.add_sub_batch_raw(nn * nn, False, abig, bbig, 512, threads=threads)
+            t = time.perf_counter()
+            wadd, u, _ = go.add_sub_batch_raw(nn * nn, False, abig, bbig, 512, threads=threads)
+            ta = time.perf_counter() - t
+            t = time.perf_counter()
+            wsub, u2, oks = go.add_sub_batch_raw(nn * nn, True, wadd, bbig, 512, threads=threads)
+            ts = time.perf_counter() - t
+            assert (wsub == abig).all() and oks.all(), "[bench] libgmp Sub(Add(a, b), b) != a"
+            assert (wadd[:64] == add_rows_).all() and (wsub[:64] == sub_rows_).all(), "[bench] Add / Sub differ from the libgmp oracle"
+            for nm_ in ("add_2048", "sub_2048"):
+                by[nm_]["parity"] += "; 64 rows == libgmp oracle"
+            by["add_2048"].update({"cpu_per_s": len(abig) / ta, "cpu_threads": int(u),
+                                   "cpu_note": "libgmp Mul + Mod per operand (operations.go:18-21), 4096 pairs"})
+            by["sub_2048"].update({"cpu_per_s": len(abig) / ts, "cpu_threads": int(u2),
+                                   "cpu_note": "libgmp ModInverse + Mul + Mod (operations.go:43-47), 4096 pairs"})
+            t = time.perf_counter()
+            want, u = go.const_mult_batch_raw(nn * nn, ah, k50_, 512, threads=threads)
+            by["const_mult_2048"].update({"parity": by["const_mult_2048"]["parity"] + "; 64 ciphertexts == libgmp oracle",
+                                          "cpu_per_s": len(ah) / (time.perf_counter() - t), "cpu_threads": min(int(u), len(ah))})
+            assert (want == cmh).all(), "[bench] ConstMult differs from the libgmp oracle"
+        if "const_mult_full_2048" in checks:
+            nn, ch, kh, oh = checks["const_mult_full_2048"]
+            t = time.perf_counter()
+            want, u = go.const_mult_batch_raw(nn * nn, ch, kh, 512, threads=threads)
+            by["const_mult_2048_full_k"].update({"parity": by["const_mult_2048_full_k"]["parity"] + f"; {len(ch)} ciphertexts == libgmp oracle",
+                                                 "cpu_per_s": len(ch) / (time.perf_counter() - t), "cpu_threads": min(int(u), len(ch))})
+            assert (want == oh).all(), "[bench] ConstMult (full-width k) differs from the libgmp oracle"
+        if "alt_encrypt_2048" in checks:
+            nn, hh, kk_, mh, rh, ch = checks["alt_encrypt_2048"]
+            t = time.perf_counter()
+            want, u, _ = go.alt_encrypt_batch_raw(nn, nn + 1, hh, kk_, mh, rh, 512, threads=threads)
+            by["alt_encrypt_2048"].update({"parity": by["alt_encrypt_2048"]["parity"] + f"; {len(mh)} ciphertexts == libgmp oracle",
+                                           "cpu_per_s": len(mh) / (time.perf_counter() - t), "cpu_threads": min(int(u), len(mh))})
+            assert (want == ch).all(), "[bench] AltEncrypt differs from the libgmp oracle"
+        if "share_zkp_2048" in checks:
+            nn, sh_, v_, vi_, ch, rh, dh, eh, zh = checks["share_zkp_2048"]
+            t = time.perf_counter()
+            wd, we_, wz, u = go.share_zkp_prove_batch_raw(nn, 5, sh_, v_, ch, rh, 560, threads=threads)
+            tp = time.perf_counter() - t
+            assert (wd == dh).all() and (we_ == eh).all() and (wz == zh).all(), "[bench] share ZKP prover differs from the libgmp oracle"
+            t = time.perf_counter()
+            wok, u2 = go.share_zkp_verify_batch_raw(nn, v_, vi_, ch, dh, eh, zh, threads=threads)
+            tv = time.perf_counter() - t
+            assert wok.all(), "[bench] libgmp VerifyProof rejects a GPU proof"
+            by["share_zkp_prove_2048"].update({"parity": f"{len(ch)} proofs (Decryption, E, Z) == libgmp oracle; all 16384 verify",
+                                               "cpu_per_s": len(ch) / tp, "cpu_threads": min(int(u), len(ch))})
+            by["share_zkp_verify_2048"].update({"parity": by["share_zkp_verify_2048"]["parity"] + f"; {len(ch)} verdicts == libgmp oracle",
+                                                "cpu_per_s": len(ch) / tv, "cpu_threads": min(int(u2), len(ch))})
         if "threshold_2048" in checks:
             from oracle import paillier_oracle as po
             from paillier_amd.api import be_to_ints

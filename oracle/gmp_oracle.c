@@ -601,4 +601,202 @@ int oracle_ddleq_prove_batch(const uint8_t* n_be, size_t n_len, const uint8_t* l
   return bad ? -1 : 0;
 }
 
+/* ---- round 5: the rows of SURVEY 8(a) that had no CPU figure (Add / Sub / ConstMult, AltEncrypt, the share ZKP) ---------------- */
+
+#ifdef _OPENMP
+#define ORACLE_PAR_BEGIN(threads, used) \
+  if ((threads) > 0) omp_set_num_threads(threads); \
+  _Pragma("omp parallel") {                          \
+    _Pragma("omp single") (used) = omp_get_num_threads();
+#define ORACLE_FOR _Pragma("omp for schedule(dynamic, 4)")
+#else
+#define ORACLE_PAR_BEGIN(threads, used) { (void)(threads);
+#define ORACLE_FOR
+#endif
+#define ORACLE_PAR_END }
+
+/* operations.go:11-29 Add(a, b) and :32-55 Sub(a, b) with two operands, level one or two (mod = n^(s+1)).
+ * Add: accumulator 1, then Mod(Mul(acc, c.C)) per operand.  Sub: accumulator = a, then ModInverse(b) and Mod(Mul(acc, neg)).
+ * sub != 0 selects Sub.  A b that has no inverse: mpz_invert returns 0 and the reference goes on with an undefined value --
+ * ok_out[i] = 0 flags the lane and the row is written as zero. */
+int oracle_add_sub_batch(const uint8_t* mod_be, size_t mod_len, int sub, size_t batch, const uint8_t* a, size_t a_stride,
+                         const uint8_t* b, size_t b_stride, uint8_t* out, size_t o_stride, int32_t* ok_out, int threads) {
+  mpz_t ns1;
+  mpz_init(ns1);
+  imp(ns1, mod_be, mod_len);
+  int used = 1;
+  ORACLE_PAR_BEGIN(threads, used)
+    mpz_t ai, bi, acc, neg;
+    mpz_inits(ai, bi, acc, neg, NULL);
+    ORACLE_FOR
+    for (long i = 0; i < (long)batch; ++i) {
+      imp(ai, a + (size_t)i * a_stride, a_stride);
+      imp(bi, b + (size_t)i * b_stride, b_stride);
+      int ok = 1;
+      if (!sub) {
+        mpz_set_ui(acc, 1);                                    /* :12 */
+        mpz_mul(acc, acc, ai); mpz_mod(acc, acc, ns1);         /* :18-21, first operand */
+        mpz_mul(acc, acc, bi); mpz_mod(acc, acc, ns1);         /* second operand */
+      } else {
+        mpz_set(acc, ai);                                      /* :34 */
+        ok = mpz_invert(neg, bi, ns1) != 0;                    /* :43 */
+        if (ok) { mpz_mul(acc, acc, neg); mpz_mod(acc, acc, ns1); }   /* :44-47 */
+        else mpz_set_ui(acc, 0);
+      }
+      if (ok_out) ok_out[i] = ok;
+      expo(acc, out + (size_t)i * o_stride, o_stride);
+    }
+    mpz_clears(ai, bi, acc, neg, NULL);
+  ORACLE_PAR_END
+  mpz_clear(ns1);
+  return used;
+}
+
+/* operations.go:58-64 ConstMult: Exp(ct.C, k, n^(s+1)).  k_stride == 0: one shared k (BenchmarkConstMul2's shape,
+ * operations_test.go:186-198); otherwise k[i] per ciphertext. */
+int oracle_const_mult_batch(const uint8_t* mod_be, size_t mod_len, size_t batch, const uint8_t* c, size_t c_stride, const uint8_t* k,
+                            size_t k_len, size_t k_stride, uint8_t* out, size_t o_stride, int threads) {
+  mpz_t ns1;
+  mpz_init(ns1);
+  imp(ns1, mod_be, mod_len);
+  int used = 1;
+  ORACLE_PAR_BEGIN(threads, used)
+    mpz_t ci, ki, m;
+    mpz_inits(ci, ki, m, NULL);
+    ORACLE_FOR
+    for (long i = 0; i < (long)batch; ++i) {
+      imp(ci, c + (size_t)i * c_stride, c_stride);
+      imp(ki, k + (size_t)i * k_stride, k_len);
+      gmp_exp(m, ci, ki, ns1);                                 /* :62 */
+      expo(m, out + (size_t)i * o_stride, o_stride);
+    }
+    mpz_clears(ci, ki, m, NULL);
+  ORACLE_PAR_END
+  mpz_clear(ns1);
+  return used;
+}
+
+/* paillier.go:221-238 AltEncryptWithRAtLevel at level one: h1 = (N - H)^N mod N^2 once per key (the reference caches it,
+ * :416-425), then per ciphertext r.Mod(r, K), gm = Exp(G, m, n^2), hr = Exp(h, r, n^2), c = Mod(Mul(gm, hr), n^2).
+ * r_red_out (optional, r_stride bytes per row) receives r mod K -- the reference overwrites the caller's r. */
+int oracle_alt_encrypt_batch(const uint8_t* n_be, size_t n_len, const uint8_t* g_be, size_t g_len, const uint8_t* h_be, size_t h_len,
+                             const uint8_t* k_be, size_t k_len, size_t batch, const uint8_t* m, size_t m_stride, const uint8_t* r,
+                             size_t r_stride, uint8_t* c_out, size_t c_stride, uint8_t* r_red_out, int threads) {
+  mpz_t n, n2, g, H, K, h1;
+  mpz_inits(n, n2, g, H, K, h1, NULL);
+  imp(n, n_be, n_len); imp(g, g_be, g_len); imp(H, h_be, h_len); imp(K, k_be, k_len);
+  mpz_mul(n2, n, n);
+  mpz_sub(h1, n, H);                                           /* :419 */
+  gmp_exp(h1, h1, n, n2);                                      /* :420 */
+  int used = 1;
+  ORACLE_PAR_BEGIN(threads, used)
+    mpz_t mi, ri, gm, hr, ci;
+    mpz_inits(mi, ri, gm, hr, ci, NULL);
+    ORACLE_FOR
+    for (long i = 0; i < (long)batch; ++i) {
+      imp(mi, m + (size_t)i * m_stride, m_stride);
+      imp(ri, r + (size_t)i * r_stride, r_stride);
+      mpz_mod(ri, ri, K);                                      /* :228 */
+      gmp_exp(gm, g, mi, n2);                                  /* :233 */
+      gmp_exp(hr, h1, ri, n2);                                 /* :234 */
+      mpz_mul(ci, gm, hr); mpz_mod(ci, ci, n2);                /* :236 */
+      expo(ci, c_out + (size_t)i * c_stride, c_stride);
+      if (r_red_out) expo(ri, r_red_out + (size_t)i * r_stride, r_stride);
+    }
+    mpz_clears(mi, ri, gm, hr, ci, NULL);
+  ORACLE_PAR_END
+  mpz_clears(n, n2, g, H, K, h1, NULL);
+  return used;
+}
+
+/* thresholdkey.go:319-326 computeHash(a, b, c4, ci2) = SetBytes(SHA-256(a.Bytes() | b.Bytes() | c4.Bytes() | ci2.Bytes())) */
+static void zkp_hash(uint8_t d[32], const mpz_t a, const mpz_t b, const mpz_t c4, const mpz_t ci2) {
+  sha256_t s;
+  sha256_init(&s);
+  sha256_mpz(&s, a); sha256_mpz(&s, b); sha256_mpz(&s, c4); sha256_mpz(&s, ci2);
+  sha256_final(&s, d);
+}
+
+/* thresholdkey.go:225-257 PartialDecryptionWithZKP with the random r supplied (the reference draws it at :233):
+ * Decryption = c^(2 delta s) mod n^2 (PartialDecrypt :192-201); c4 = c^4 and ci2 = Decryption^2 UNREDUCED (Exp(., ., nil));
+ * a = c4^r, b = V^r mod n^2; E = hash; Z = r + E delta s (computeZ :313-317).  e_out: 32 bytes per proof. */
+int oracle_share_zkp_prove_batch(const uint8_t* n_be, size_t n_len, int total_servers, const uint8_t* share_be, size_t share_len,
+                                 const uint8_t* v_be, size_t v_len, size_t batch, const uint8_t* c, size_t c_stride, const uint8_t* r,
+                                 size_t r_stride, uint8_t* dec_out, size_t dec_stride, uint8_t* e_out, uint8_t* z_out, size_t z_stride,
+                                 int threads) {
+  mpz_t n, n2, share, V, delta;
+  mpz_inits(n, n2, share, V, delta, NULL);
+  imp(n, n_be, n_len); imp(share, share_be, share_len); imp(V, v_be, v_len);
+  mpz_mul(n2, n, n);
+  mpz_fac_ui(delta, (unsigned long)total_servers);
+  int used = 1;
+  ORACLE_PAR_BEGIN(threads, used)
+    mpz_t ci, ri, ex, dec, c4, a, b, ci2, E, Z;
+    mpz_inits(ci, ri, ex, dec, c4, a, b, ci2, E, Z, NULL);
+    ORACLE_FOR
+    for (long i = 0; i < (long)batch; ++i) {
+      uint8_t d[32];
+      imp(ci, c + (size_t)i * c_stride, c_stride);
+      imp(ri, r + (size_t)i * r_stride, r_stride);
+      mpz_mul_ui(ex, delta, 2); mpz_mul(ex, share, ex);        /* :195 */
+      gmp_exp(dec, ci, ex, n2);                                /* :199 */
+      mpz_pow_ui(c4, ci, 4);                                   /* :241 Exp(c, 4, nil) */
+      gmp_exp(a, c4, ri, n2);                                  /* :242 */
+      gmp_exp(b, V, ri, n2);                                   /* :245 */
+      mpz_pow_ui(ci2, dec, 2);                                 /* :248 */
+      zkp_hash(d, a, b, c4, ci2);                              /* :250 */
+      imp(E, d, 32);
+      mpz_mul(Z, E, delta); mpz_mul(Z, Z, share); mpz_add(Z, ri, Z);   /* :314-316 */
+      expo(dec, dec_out + (size_t)i * dec_stride, dec_stride);
+      memcpy(e_out + (size_t)i * 32, d, 32);
+      expo(Z, z_out + (size_t)i * z_stride, z_stride);
+    }
+    mpz_clears(ci, ri, ex, dec, c4, a, b, ci2, E, Z, NULL);
+  ORACLE_PAR_END
+  mpz_clears(n, n2, share, V, delta, NULL);
+  return used;
+}
+
+/* thresholdkey.go:278-311 VerifyProof: a = (c^4)^Z ((c_i^2)^E)^-1, b = V^Z (v_i^E)^-1 mod n^2 (verifyPart1 / verifyPart2),
+ * E == SHA-256(a | b | c^4 | c_i^2).  A (c_i^2)^E without an inverse: mpz_invert fails, the reference's a is undefined --
+ * ok_out[i] = 0. */
+int oracle_share_zkp_verify_batch(const uint8_t* n_be, size_t n_len, const uint8_t* v_be, size_t v_len, const uint8_t* vi_be,
+                                  size_t vi_len, size_t batch, const uint8_t* c, size_t c_stride, const uint8_t* dec, size_t dec_stride,
+                                  const uint8_t* e, const uint8_t* z, size_t z_stride, int32_t* ok_out, uint8_t* ab_out, int threads) {
+  /* ab_out (optional): a | b of verifyPart1 / verifyPart2 per proof, c_stride bytes each (what TestVerifyPart1/2 pin) */
+  mpz_t n, n2, V, vi;
+  mpz_inits(n, n2, V, vi, NULL);
+  imp(n, n_be, n_len); imp(V, v_be, v_len); imp(vi, vi_be, vi_len);
+  mpz_mul(n2, n, n);
+  int used = 1;
+  ORACLE_PAR_BEGIN(threads, used)
+    mpz_t ci, di, E, Z, c4, d2, a1, a2, a, b1, b2, b;
+    mpz_inits(ci, di, E, Z, c4, d2, a1, a2, a, b1, b2, b, NULL);
+    ORACLE_FOR
+    for (long i = 0; i < (long)batch; ++i) {
+      uint8_t d[32];
+      imp(ci, c + (size_t)i * c_stride, c_stride);
+      imp(di, dec + (size_t)i * dec_stride, dec_stride);
+      imp(E, e + (size_t)i * 32, 32);
+      imp(Z, z + (size_t)i * z_stride, z_stride);
+      mpz_pow_ui(c4, ci, 4);                                   /* :294 */
+      mpz_pow_ui(d2, di, 2);                                   /* :295 */
+      gmp_exp(a1, c4, Z, n2);                                  /* :297 */
+      gmp_exp(a2, d2, E, n2);                                  /* :298 */
+      int ok = mpz_invert(a2, a2, n2) != 0;                    /* :299 */
+      mpz_mul(a, a1, a2); mpz_mod(a, a, n2);                   /* :300 */
+      gmp_exp(b1, V, Z, n2);                                   /* :306 */
+      gmp_exp(b2, vi, E, n2);                                  /* :307 */
+      ok = (mpz_invert(b2, b2, n2) != 0) && ok;                /* :308 */
+      mpz_mul(b, b1, b2); mpz_mod(b, b, n2);                   /* :309 */
+      zkp_hash(d, a, b, c4, d2);                               /* :281-288 */
+      ok_out[i] = ok && memcmp(d, e + (size_t)i * 32, 32) == 0;   /* :290-291 */
+      if (ab_out) { expo(a, ab_out + (size_t)i * 2 * c_stride, c_stride); expo(b, ab_out + ((size_t)i * 2 + 1) * c_stride, c_stride); }
+    }
+    mpz_clears(ci, di, E, Z, c4, d2, a1, a2, a, b1, b2, b, NULL);
+  ORACLE_PAR_END
+  mpz_clears(n, n2, V, vi, NULL);
+  return used;
+}
+
 const char* oracle_gmp_version(void) { return gmp_version; }

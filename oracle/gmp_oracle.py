@@ -20,7 +20,8 @@ def load():
         _lib.oracle_gmp_version.restype = C.c_char_p
         for name in ("oracle_decrypt_batch", "oracle_encrypt_batch", "oracle_modexp_batch", "oracle_decrypt_crt_batch",
                      "oracle_ddleq_verify_batch", "oracle_ddleq_prove_batch", "oracle_encrypt_l2_batch", "oracle_nested_randomize_batch",
-                     "oracle_threshold_decrypt_batch"):
+                     "oracle_threshold_decrypt_batch", "oracle_add_sub_batch", "oracle_const_mult_batch", "oracle_alt_encrypt_batch",
+                     "oracle_share_zkp_prove_batch", "oracle_share_zkp_verify_batch"):
             getattr(_lib, name).restype = C.c_int
     return _lib
 
@@ -172,3 +173,71 @@ def ddleq_prove_batch(n, lam, ct1s, ct2s, a_s, b_s, xs, ys, threads=1):
     if rc != 0:
         raise RuntimeError("cannot prove re-encryption because inputs are wrong")
     return _be_to_ints(al), _be_to_ints(eo), _be_to_ints(fo), [int(v) for v in bits]
+
+
+# ---- round 5: Add / Sub / ConstMult, AltEncrypt, the share ZKP (rows of SURVEY 8(a) that had no CPU figure) ----------------------
+
+def add_sub_batch_raw(mod, sub: bool, a_buf: np.ndarray, b_buf: np.ndarray, o_stride: int, threads: int = 1):
+    """operations.go:11-29 Add(a, b) / :32-55 Sub(a, b) modulo `mod` = n^(s+1).  Returns (out, threads used, ok int32[batch])."""
+    lib = load()
+    mb = _be(mod)
+    out = np.zeros((a_buf.shape[0], o_stride), dtype=np.uint8)
+    ok = np.zeros(a_buf.shape[0], dtype=np.int32)
+    used = lib.oracle_add_sub_batch(mb, C.c_size_t(len(mb)), int(bool(sub)), C.c_size_t(a_buf.shape[0]), _p(a_buf),
+                                    C.c_size_t(a_buf.shape[1]), _p(b_buf), C.c_size_t(b_buf.shape[1]), _p(out), C.c_size_t(o_stride),
+                                    _p(ok), threads)
+    return out, used, ok
+
+
+def const_mult_batch_raw(mod, c_buf: np.ndarray, k, o_stride: int, threads: int = 1):
+    """operations.go:58-64 ConstMult: c^k mod `mod`; k an int (shared) or a uint8[batch, k_len] array (one per ciphertext)."""
+    lib = load()
+    mb = _be(mod)
+    out = np.zeros((c_buf.shape[0], o_stride), dtype=np.uint8)
+    if isinstance(k, int):
+        kb = np.frombuffer(_be(k), dtype=np.uint8).copy()
+        k_len, k_stride = kb.size, 0
+    else:
+        kb, k_len, k_stride = k, k.shape[1], k.shape[1]
+    used = lib.oracle_const_mult_batch(mb, C.c_size_t(len(mb)), C.c_size_t(c_buf.shape[0]), _p(c_buf), C.c_size_t(c_buf.shape[1]),
+                                       _p(kb), C.c_size_t(k_len), C.c_size_t(k_stride), _p(out), C.c_size_t(o_stride), threads)
+    return out, used
+
+
+def alt_encrypt_batch_raw(n, g, h, k, m_buf: np.ndarray, r_buf: np.ndarray, c_stride: int, threads: int = 1):
+    """paillier.go:221-238 AltEncryptWithRAtLevel, level one.  Returns (ciphertexts, threads used, r mod K rows)."""
+    lib = load()
+    nb, gb, hb, kb = _be(n), _be(g), _be(h), _be(k)
+    out = np.zeros((m_buf.shape[0], c_stride), dtype=np.uint8)
+    rred = np.zeros_like(r_buf)
+    used = lib.oracle_alt_encrypt_batch(nb, C.c_size_t(len(nb)), gb, C.c_size_t(len(gb)), hb, C.c_size_t(len(hb)), kb, C.c_size_t(len(kb)),
+                                        C.c_size_t(m_buf.shape[0]), _p(m_buf), C.c_size_t(m_buf.shape[1]), _p(r_buf),
+                                        C.c_size_t(r_buf.shape[1]), _p(out), C.c_size_t(c_stride), _p(rred), threads)
+    return out, used, rred
+
+
+def share_zkp_prove_batch_raw(n, total_servers, share, vkey, c_buf: np.ndarray, r_buf: np.ndarray, z_stride: int, threads: int = 1):
+    """thresholdkey.go:225-257 with r supplied.  Returns (decryptions, E rows uint8[batch, 32], Z rows, threads used)."""
+    lib = load()
+    nb, sb, vb = _be(n), _be(share), _be(vkey)
+    B, cs = c_buf.shape
+    dec, eo, zo = np.zeros((B, cs), np.uint8), np.zeros((B, 32), np.uint8), np.zeros((B, z_stride), np.uint8)
+    used = lib.oracle_share_zkp_prove_batch(nb, C.c_size_t(len(nb)), int(total_servers), sb, C.c_size_t(len(sb)), vb, C.c_size_t(len(vb)),
+                                            C.c_size_t(B), _p(c_buf), C.c_size_t(cs), _p(r_buf), C.c_size_t(r_buf.shape[1]), _p(dec),
+                                            C.c_size_t(cs), _p(eo), _p(zo), C.c_size_t(z_stride), threads)
+    return dec, eo, zo, used
+
+
+def share_zkp_verify_batch_raw(n, vkey, vi, c_buf: np.ndarray, dec_buf: np.ndarray, e_buf: np.ndarray, z_buf: np.ndarray, threads: int = 1,
+                               want_ab: bool = False):
+    """thresholdkey.go:278-311 VerifyProof for proofs of one server.  Returns (ok int32[batch], threads used[, a | b rows])."""
+    lib = load()
+    nb, vb, ib = _be(n), _be(vkey), _be(vi)
+    B = c_buf.shape[0]
+    assert e_buf.shape == (B, 32)
+    ok = np.zeros(B, dtype=np.int32)
+    ab = np.zeros((B, 2, c_buf.shape[1]), dtype=np.uint8) if want_ab else None
+    used = lib.oracle_share_zkp_verify_batch(nb, C.c_size_t(len(nb)), vb, C.c_size_t(len(vb)), ib, C.c_size_t(len(ib)), C.c_size_t(B),
+                                             _p(c_buf), C.c_size_t(c_buf.shape[1]), _p(dec_buf), C.c_size_t(dec_buf.shape[1]), _p(e_buf),
+                                             _p(z_buf), C.c_size_t(z_buf.shape[1]), _p(ok), _p(ab) if want_ab else None, threads)
+    return (ok, used, ab) if want_ab else (ok, used)

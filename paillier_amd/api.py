@@ -398,6 +398,26 @@ class PublicKey:
         _check(self.ctx.lib.pgpu_encrypt_with_r(self.h, level, batch, _ptr(m), m_stride, _ptr(r), r_stride, _ptr(c),
                                                 c_stride, mem))
 
+    def add_raw(self, batch, a, a_stride, b, b_stride, out, out_stride, mem=MEM_HOST, level=ENC_LEVEL_ONE):
+        """pgpu_add: out[i] = a[i] * b[i] mod n^(s+1) (operations.go:11-29 with two operands)."""
+        _check(self.ctx.lib.pgpu_add(self.h, level, batch, _ptr(a), a_stride, _ptr(b), b_stride, _ptr(out), out_stride, mem))
+
+    def sub_raw(self, batch, a, a_stride, b, b_stride, out, out_stride, mem=MEM_HOST, level=ENC_LEVEL_ONE,
+                status: Optional[np.ndarray] = None):
+        """pgpu_sub: out[i] = a[i] * b[i]^-1 mod n^(s+1) (operations.go:32-55 with two operands)."""
+        _check(self.ctx.lib.pgpu_sub(self.h, level, batch, _ptr(a), a_stride, _ptr(b), b_stride, _ptr(out), out_stride, mem,
+                                     _ptr(status) if status is not None else None))
+
+    def const_mult_raw(self, batch, c, c_stride, k, k_len, k_stride, out, out_stride, mem=MEM_HOST, level=ENC_LEVEL_ONE):
+        """pgpu_const_mult: out[i] = c[i]^k mod n^(s+1) (operations.go:58-64); k_stride 0 = one shared k (a HOST buffer of k_len
+        bytes), else k[i] at k + i * k_stride in `mem`."""
+        _check(self.ctx.lib.pgpu_const_mult(self.h, level, batch, _ptr(c), c_stride, _ptr(k), k_len, k_stride, _ptr(out), out_stride, mem))
+
+    def alt_encrypt_with_r_raw(self, batch, m, m_stride, r, r_stride, c, c_stride, r_reduced=None, mem=MEM_HOST, level=ENC_LEVEL_ONE):
+        """pgpu_alt_encrypt_with_r (paillier.go:221-238); r_reduced (optional, r_stride bytes per row) receives r mod K."""
+        _check(self.ctx.lib.pgpu_alt_encrypt_with_r(self.h, level, batch, _ptr(m), m_stride, _ptr(r), r_stride, _ptr(c), c_stride,
+                                                    _ptr(r_reduced) if r_reduced is not None else None, mem))
+
     # -- int forms ----------------------------------------------------------------------------------
     def EncryptWithRBatch(self, ms: Sequence[int], rs: Sequence[int], level: int = ENC_LEVEL_ONE) -> List[int]:
         """paillier.go:206-218 for each (m, r)."""
@@ -621,6 +641,21 @@ class ThresholdPublicKey(PublicKey):
         _check(self.ctx.lib.pgpu_combine_partial_decryptions(self.h, self.TotalNumberOfDecryptionServers, self.Threshold, n,
                                                              ida, batch, pa_, stride, _ptr(m), m_stride, mem,
                                                              _ptr(status) if status is not None else None))
+
+    def share_zkp_prove_raw(self, share: int, verification_key: int, batch, c, c_stride, r, r_stride, dec, dec_stride, e_out, z_out,
+                            z_stride, mem=MEM_HOST):
+        """pgpu_share_zkp_prove (thresholdkey.go:225-257, r supplied); e_out: 32 bytes per proof."""
+        sb, vb = _be(share), _be(verification_key)
+        _check(self.ctx.lib.pgpu_share_zkp_prove(self.h, self.TotalNumberOfDecryptionServers, sb, len(sb), vb, len(vb), batch,
+                                                 _ptr(c), c_stride, _ptr(r), r_stride, _ptr(dec), dec_stride, _ptr(e_out), _ptr(z_out),
+                                                 z_stride, mem))
+
+    def share_zkp_verify_raw(self, verification_key: int, vi: int, batch, c, c_stride, dec, dec_stride, e, z, z_stride, ok: np.ndarray,
+                             mem=MEM_HOST):
+        """pgpu_share_zkp_verify (thresholdkey.go:278-311) for proofs of one server; ok: host int32[batch]."""
+        vb, ib = _be(verification_key), _be(vi)
+        _check(self.ctx.lib.pgpu_share_zkp_verify(self.h, vb, len(vb), ib, len(ib), batch, _ptr(c), c_stride, _ptr(dec), dec_stride,
+                                                  _ptr(e), _ptr(z), z_stride, _ptr(ok), mem))
 
     def PartialDecryptionWithZKPBatch(self, ID: int, share: int, verification_key: int, cts: Sequence[int], rs: Sequence[int]):
         """thresholdkey.go:225-257 with r supplied, entirely on the device.  Returns (decryptions, Es, Zs)."""

@@ -119,3 +119,102 @@ def test_level_two_and_nested_randomize_restatements():
     assert _ints(out) == ct2
     pk = po.PublicKey(N=n, G=n + 1)
     assert ct2[:2] == [po.nested_randomize_with_ab(pk, po.Ciphertext(c, 1), x, y).C for c, x, y in zip(ct1[:2], a[:2], b[:2])]
+
+
+def _golden():
+    import json
+    import os
+    G = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+    return (json.load(open(os.path.join(G, "keys.json"))), json.load(open(os.path.join(G, "vectors.json"))),
+            json.load(open(os.path.join(G, "proofs.json"))))
+
+
+def test_add_sub_const_mult_restatements():
+    """libgmp Add / Sub / ConstMult (bench.py's CPU figures beside add_2048 / sub_2048 / const_mult_2048) against the committed
+    fixtures and the Python-int oracle, both levels; a subtrahend without an inverse is flagged."""
+    K, V, P = _golden()
+    k = K["paillier"]["2048"]
+    n = int(k["n"], 16)
+    n2, n3 = n * n, n ** 3
+    pk = po.PublicKey(N=n, G=n + 1)
+    v = V["2048"]
+    a, b, want = ([int(x, 16) for x in v["add"][key]] for key in ("a", "b", "out"))
+    out, _, ok = go.add_sub_batch_raw(n2, False, _be_rows(a, 512), _be_rows(b, 512), 512, threads=2)
+    assert _ints(out) == want == [po.add(pk, po.Ciphertext(x), po.Ciphertext(y)).C for x, y in zip(a, b)] and ok.all()
+    out, _, ok = go.add_sub_batch_raw(n2, True, _be_rows(a, 512), _be_rows(b, 512), 512, threads=2)
+    assert _ints(out) == [po.sub(pk, po.Ciphertext(x), po.Ciphertext(y)).C for x, y in zip(a, b)] and ok.all()
+    rng = random.Random(31)
+    a3, b3 = [rng.randrange(n3) for _ in range(5)], [rng.randrange(n3) | 1 for _ in range(5)]
+    import math
+    b3 = [x for x in b3 if math.gcd(x, n) == 1]
+    a3 = a3[:len(b3)]
+    out, _, ok = go.add_sub_batch_raw(n3, True, _be_rows(a3, 768), _be_rows(b3, 768), 768)
+    assert _ints(out) == [po.sub(pk, po.Ciphertext(x, 1), po.Ciphertext(y, 1)).C for x, y in zip(a3, b3)] and ok.all()
+    p_ = int(k["p"], 16)
+    out, _, ok = go.add_sub_batch_raw(n2, True, _be_rows(a[:2], 512), _be_rows([p_ * 7, b[1]], 512), 512)
+    assert list(ok) == [0, 1] and _ints(out)[0] == 0
+    # ConstMult: a shared k (the fixture's, and BenchmarkConstMul2's 50^50 mod n^2) and one k per ciphertext
+    cs, ks = ([int(x, 16) for x in v["const_mult"][key]] for key in ("c", "k"))
+    out, _ = go.const_mult_batch_raw(n2, _be_rows(cs, 512), ks[0], 512, threads=2)
+    assert _ints(out) == [int(x, 16) for x in v["const_mult"]["out_shared_k0"]]
+    kl = max(1, max((x.bit_length() + 7) // 8 for x in ks))
+    out, _ = go.const_mult_batch_raw(n2, _be_rows(cs, 512), _be_rows(ks, kl), 512, threads=2)
+    assert _ints(out) == [int(x, 16) for x in v["const_mult"]["out"]]
+    k50 = pow(50, 50, n2)
+    out, _ = go.const_mult_batch_raw(n2, _be_rows(cs[:3], 512), k50, 512)
+    assert _ints(out) == [po.const_mult(pk, po.Ciphertext(c), k50).C for c in cs[:3]]
+    out, _ = go.const_mult_batch_raw(n2, _be_rows(cs[:2], 512), 0, 512)             # gmp.Int.Exp(x, 0) = 1
+    assert _ints(out) == [1, 1]
+
+
+def test_alt_encrypt_restatement():
+    K, V, P = _golden()
+    k = K["paillier"]["2048"]
+    n, h, kk = int(k["n"], 16), int(k["h"], 16), int(k["k"], 16)
+    pk = po.PublicKey(N=n, G=n + 1, H=h, K=kk)
+    rng = random.Random(77)
+    ms = [0, 1, n - 1] + [rng.randrange(n) for _ in range(4)]
+    rs = [0, kk, kk + 5] + [rng.randrange(n) for _ in range(4)]
+    out, _, rred = go.alt_encrypt_batch_raw(n, n + 1, h, kk, _be_rows(ms, 256), _be_rows(rs, 256), 512, threads=2)
+    want = [po.alt_encrypt_with_r_at_level(pk, m, r, 0) for m, r in zip(ms, rs)]
+    assert _ints(out) == [w[0].C for w in want]
+    assert _ints(rred) == [w[1] for w in want] == [r % kk for r in rs]
+
+
+def test_share_zkp_restatement_fixtures_and_reference_kats():
+    """libgmp PartialDecryptionWithZKP / VerifyProof: the reference's own KATs for verifyPart1 / verifyPart2
+    (thresholdkey_test.go:109-135: 11986, 14602), the committed 2048-bit proofs (hash transcript included) and the Python oracle."""
+    # TestVerifyPart1: N = 131, C = 99, Decryption = 101, E = 112, Z = 88 -> a = 11986; TestVerifyPart2: V = 101, v_i = 77 -> b = 14602
+    e112 = (112).to_bytes(32, "big")
+    import numpy as np
+    ok, _, ab = go.share_zkp_verify_batch_raw(131, 101, 77, _be_rows([99], 4), _be_rows([101], 4),
+                                              np.frombuffer(e112, dtype=np.uint8).reshape(1, 32).copy(), _be_rows([88], 4), want_ab=True)
+    assert _ints(ab) == [11986, 14602] and list(ok) == [0]
+    K, V, P = _golden()
+    t = K["threshold"]["2048"]
+    n, v, vks, shares = int(t["n"], 16), int(t["v"], 16), [int(x, 16) for x in t["vks"]], [int(x, 16) for x in t["shares"]]
+    server = P["share_zkp"]["server"]
+    recs = P["share_zkp"]["proofs"]
+    col = lambda key: [int(r[key], 16) for r in recs]
+    cs, rs = col("c"), col("r")
+    zs_len = 512 + 48
+    dec, eo, zo, _ = go.share_zkp_prove_batch_raw(n, int(t["total"]), shares[server - 1], v, _be_rows(cs, 512), _be_rows(rs, 512), zs_len,
+                                                  threads=2)
+    assert _ints(dec) == col("dec") and _ints(eo) == col("e") and _ints(zo) == col("z")
+    ok, _, ab = go.share_zkp_verify_batch_raw(n, v, vks[server - 1], _be_rows(cs, 512), dec, eo, zo, threads=2, want_ab=True)
+    assert ok.all()
+    assert [x for x in _ints(ab)[0::2]] == col("verify_a") and [x for x in _ints(ab)[1::2]] == col("verify_b")
+    # a tampered Z, a tampered E, another server's verification key: rejected
+    zbad = zo.copy(); zbad[0, -1] ^= 1
+    ebad = eo.copy(); ebad[1, 0] ^= 0x80
+    assert list(go.share_zkp_verify_batch_raw(n, v, vks[server - 1], _be_rows(cs, 512), dec, eo, zbad)[0])[:2] == [0, 1]
+    assert list(go.share_zkp_verify_batch_raw(n, v, vks[server - 1], _be_rows(cs, 512), dec, ebad, zo)[0])[:2] == [1, 0]
+    assert not go.share_zkp_verify_batch_raw(n, v, vks[server % 5], _be_rows(cs, 512), dec, eo, zo)[0].any()
+    # and against the Python-int restatement on a fresh draw
+    tsk = po.ThresholdSecretKey(N=n, G=n + 1, TotalNumberOfDecryptionServers=int(t["total"]), Threshold=int(t["threshold"]),
+                                VerificationKey=v, VerificationKeys=vks, ID=server, Share=shares[server - 1])
+    rng = random.Random(3)
+    c1, r1 = rng.randrange(n * n), rng.randrange(n * n)
+    pd = po.partial_decryption_with_zkp_r(tsk, c1, r1)
+    dec, eo, zo, _ = go.share_zkp_prove_batch_raw(n, int(t["total"]), shares[server - 1], v, _be_rows([c1], 512), _be_rows([r1], 512), zs_len)
+    assert (_ints(dec), _ints(eo), _ints(zo)) == ([pd.Decryption], [pd.E], [pd.Z]) and po.verify_proof(pd)

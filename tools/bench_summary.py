@@ -24,13 +24,19 @@ if len(sys.argv) >= 3 and sys.argv[1] == "--plan-table":
     per = {"headline_decrypt_2048": j["roofline"]["alg_mad28_per_decrypt"]}
     for e in j.get("extra_configs", []):
         per[e["config"]] = e.get("executed_mad28_per_unit") or e["executed_mad28"] / round(e["value"] * e["ms_per_batch"] / 1e3)
+    import os
+    keep = {}
+    try:      # the yardstick of the literal algorithm is measured with "struct" off, not by this run: carried over
+        keep = json.load(open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "profiles", "plan_table.json"))).get("literal_per_unit", {})
+    except OSError:
+        pass
     print(json.dumps({
         "_comment": "Executed 28-bit multiply-adds per unit of every bench config on ONE GPU at the default shapes (bench.py asserts "
                     "its own counts against these, +-1 %, and prints plan_changed otherwise): a planning predicate that silently "
                     "moves a BASELINE shape onto another ladder changes these numbers before it changes a timing.  Regenerate ONLY "
                     "together with a deliberate change of the plan: python tools/bench_summary.py --plan-table <bench line> > "
                     "profiles/plan_table.json",
-        "tolerance": 0.01, "source": sys.argv[2], "per_unit": per}, indent=1))
+        "tolerance": 0.01, "source": sys.argv[2], "per_unit": per, "literal_per_unit": keep}, indent=1))
     sys.exit(0)
 
 j = last_line(sys.argv[1])
