@@ -3,8 +3,14 @@
  * least once and checks results against vectors the pytest driver (tests/test_gpu_c_abi.py) exports from the committed
  * fixtures (the JSON files under tests/golden) as "key hex hex ..." lines.
  *
- *   gcc -std=c99 -pedantic -Wall -Werror tests/c/test_cabi.c -Iinclude -Lpaillier_amd -lpaillier_hip -o test_cabi
+ *   gcc -std=c99 -pedantic -Wall -Werror -pthread tests/c/test_cabi.c -Iinclude -Lpaillier_amd -lpaillier_hip -o test_cabi
+ *
+ * The last section drives TWO contexts from TWO pthreads through the sharded flows of go/sharded.go (ShardedGPU: one context per
+ * device, one goroutine per device, slices by shard_slice, the threshold exchange through host memory): the ABI is
+ * thread-compatible per context the way cgo will use it.  On the one-GPU test box both contexts sit on device 0.
  */
+#define _POSIX_C_SOURCE 200809L
+#include <pthread.h>
 #include <stdint.h>
 #include <stdio.h>
 #include <stdlib.h>
@@ -75,6 +81,64 @@ static int same(const uint8_t* got, const entry_t* want, size_t stride) {
 }
 
 static size_t bytes_of(const char* hex) { return (strlen(hex) + 1) / 2; }
+
+/* ---- go/sharded.go in C: `world` workers, one context (own stream) and one set of key handles each -------------------------- */
+static void shard_slice(size_t total, size_t r, size_t w, size_t* b, size_t* e) {     /* paillier_amd/dist.py shard_slice */
+  size_t base = total / w, rem = total % w;
+  *b = r * base + (r < rem ? r : rem);
+  *e = *b + base + (r < rem ? 1 : 0);
+}
+
+typedef struct {
+  int rank, world, device;
+  pthread_barrier_t* bar;
+  /* keys (big-endian) */
+  const uint8_t *n, *g, *lambda, *tn, *tg; size_t nl, ll, tl;
+  const uint8_t* const* shares; const size_t* share_lens;
+  /* Decrypt: nd ciphertexts -> plaintexts */
+  const uint8_t* dc; size_t nd; uint8_t* dm;
+  /* threshold: nt ciphertexts; parts = the exchange buffer in host memory, server-major [3][nt][2 tl]; tm = plaintexts */
+  const uint8_t* tc; size_t nt; uint8_t* parts; uint8_t* tm;
+  int rc; char err[256];
+} worker_t;
+
+#define WOK(call) do { int rc_ = (call); if (rc_ != PGPU_OK) { w->rc = rc_ ? rc_ : -100; snprintf(w->err, sizeof w->err, "line %d: %s", __LINE__, pgpu_last_error()); goto done; } } while (0)
+
+static void* sharded_worker(void* arg) {
+  worker_t* w = (worker_t*)arg;
+  pgpu_ctx* ctx = NULL; pgpu_pubkey *pk = NULL, *tpk = NULL; pgpu_seckey* sk = NULL;
+  size_t b, e, ub, ue, s, tcb = 2 * w->tl;
+  static const int ids[3] = {1, 3, 5};
+  int crossed = 0;
+  w->rc = PGPU_OK;
+  WOK(pgpu_ctx_create(w->device, PGPU_STREAM_NEW, &ctx));
+  WOK(pgpu_pubkey_create(ctx, w->n, w->nl, w->g, w->nl, NULL, 0, NULL, 0, &pk));
+  WOK(pgpu_seckey_create(ctx, pk, w->lambda, w->ll, &sk));
+  WOK(pgpu_pubkey_create(ctx, w->tn, w->tl, w->tg, w->tl, NULL, 0, NULL, 0, &tpk));
+  /* ShardedSecretKey.DecryptBatch: this worker's slice of the ciphertexts */
+  shard_slice(w->nd, (size_t)w->rank, (size_t)w->world, &b, &e);
+  if (e > b) WOK(pgpu_decrypt(sk, PGPU_LEVEL_ONE, e - b, w->dc + b * 2 * w->nl, 2 * w->nl, w->dm + b * w->nl, w->nl, PGPU_MEM_HOST, PGPU_DECRYPT_DEFAULT, NULL));
+  /* ShardedPublicKey.ThresholdDecryptBatch, step 1: this worker's (server, ciphertext) unit range, straight into the exchange buffer */
+  shard_slice(3 * w->nt, (size_t)w->rank, (size_t)w->world, &ub, &ue);
+  if (ue > ub) WOK(pgpu_partial_decrypt_units(tpk, 5, 3, w->shares, w->share_lens, w->nt, w->tc, tcb, ub, ue, w->parts + ub * tcb, tcb, PGPU_MEM_HOST));
+  /* step 2: the exchange -- every worker's partials are in host memory once all have passed here */
+  pthread_barrier_wait(w->bar);
+  crossed = 1;
+  /* step 3: combine this worker's ciphertext slice */
+  shard_slice(w->nt, (size_t)w->rank, (size_t)w->world, &b, &e);
+  if (e > b) {
+    const uint8_t* cols[3];
+    for (s = 0; s < 3; ++s) cols[s] = w->parts + (s * w->nt + b) * tcb;
+    WOK(pgpu_combine_partial_decryptions(tpk, 5, 3, 3, ids, e - b, cols, tcb, w->tm + b * w->tl, w->tl, PGPU_MEM_HOST, NULL));
+  }
+done:
+  if (!crossed) pthread_barrier_wait(w->bar);          /* a failed worker must not leave the others waiting */
+  pgpu_seckey_destroy(sk);
+  pgpu_pubkey_destroy(pk);
+  pgpu_pubkey_destroy(tpk);
+  pgpu_ctx_destroy(ctx);
+  return NULL;
+}
 
 int main(int argc, char** argv) {
   pgpu_ctx* ctx = NULL;
@@ -310,6 +374,36 @@ int main(int argc, char** argv) {
     CHECK(same(al, get("d_alpha"), cb3) && same(ee, get("d_e"), pb2) && same(ff, get("d_f"), cb3));
     CHECK(pgpu_ddleq_prove_secpar(sk, 1, 0, c1, c2, cb3, da, db, dx, dy, pb, al, ee, pb2, ff, PGPU_MEM_HOST) == PGPU_ERR_INVALID);
     free(c1); free(c2); free(da); free(db); free(dx); free(dy); free(al); free(ee); free(ff); }
+
+  /* ---- two contexts, two threads: the sharded flows of go/sharded.go against the same fixtures ---------------------------------- */
+  { enum { WORLD = 2 };
+    const entry_t *dce = get("dec_c"), *tce = get("t_c");
+    size_t nd = (size_t)dce->n, nt = (size_t)tce->n, tl = bytes_of(get("t_n")->hex[0]), tcb = 2 * tl; int i, s; int ids3[3] = {1, 3, 5};
+    uint8_t* dcb = pack(dce, cb); uint8_t* tcbuf = pack(tce, tcb);
+    uint8_t* dm = (uint8_t*)calloc(nd, pb); uint8_t* parts = (uint8_t*)calloc(3 * nt, tcb); uint8_t* tm = (uint8_t*)calloc(nt, tl);
+    uint8_t tg[512]; uint8_t shb[3][1024]; const uint8_t* shp[3]; size_t shl[3];
+    pthread_barrier_t bar; pthread_t th[WORLD]; worker_t ws[WORLD];
+    memcpy(tg, tnb, tl); tg[tl - 1] += 1;
+    for (s = 0; s < 3; ++s) { const char* sh = get("t_shares")->hex[ids3[s] - 1]; shl[s] = bytes_of(sh); put(sh, shb[s], shl[s]); shp[s] = shb[s]; }
+    CHECK(pthread_barrier_init(&bar, NULL, WORLD) == 0);
+    for (i = 0; i < WORLD; ++i) {
+      worker_t* w = &ws[i];
+      memset(w, 0, sizeof *w);
+      w->rank = i; w->world = WORLD; w->device = 0; w->bar = &bar;
+      w->n = nb; w->g = gb; w->lambda = lb; w->tn = tnb; w->tg = tg; w->nl = nl; w->ll = ll; w->tl = tl;
+      w->shares = shp; w->share_lens = shl;
+      w->dc = dcb; w->nd = nd; w->dm = dm; w->tc = tcbuf; w->nt = nt; w->parts = parts; w->tm = tm;
+      CHECK(pthread_create(&th[i], NULL, sharded_worker, w) == 0);
+    }
+    for (i = 0; i < WORLD; ++i) pthread_join(th[i], NULL);
+    pthread_barrier_destroy(&bar);
+    for (i = 0; i < WORLD; ++i) if (ws[i].rc != PGPU_OK) { fprintf(stderr, "sharded worker %d failed (%d): %s\n", i, ws[i].rc, ws[i].err); return 1; }
+    CHECK(same(dm, get("dec_m"), pb));                              /* the slices, concatenated, are the batch's plaintexts */
+    CHECK(same(tm, get("t_m"), tl));
+    { char key[16]; for (s = 0; s < 3; ++s) { uint8_t* wv; sprintf(key, "t_part%d", ids3[s]); wv = pack(get(key), tcb);
+        CHECK(memcmp(parts + (size_t)s * nt * tcb, wv, nt * tcb) == 0); free(wv); } }   /* what went through the exchange */
+    free(dcb); free(tcbuf); free(dm); free(parts); free(tm);
+  }
 
   /* ---- error conventions */
   CHECK(pgpu_encrypt_with_r(pk, 7, B, m, pb, r, pb, out, cb, PGPU_MEM_HOST) == PGPU_ERR_INVALID);

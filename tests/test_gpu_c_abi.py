@@ -17,7 +17,7 @@ def build(tmp_path):
     ge.build()
     exe = tmp_path / "test_cabi"
     libdir = os.path.join(ROOT, "paillier_amd")
-    subprocess.check_call(["gcc", "-std=c99", "-pedantic", "-Wall", "-Werror", "-O1", os.path.join(ROOT, "tests", "c", "test_cabi.c"),
+    subprocess.check_call(["gcc", "-std=c99", "-pedantic", "-Wall", "-Werror", "-O1", "-pthread", os.path.join(ROOT, "tests", "c", "test_cabi.c"),
                            "-I" + os.path.join(ROOT, "include"), "-o", str(exe), f"-L{libdir}", "-lpaillier_hip",
                            f"-Wl,-rpath,{libdir}", "-Wl,-rpath,/opt/rocm/lib"])
     return exe

@@ -51,8 +51,12 @@ for B in [int(x) for x in (sys.argv[1:] or [512, 1024, 2048, 4096, 8192, 16384, 
 # ---- the same small batches overlapped: `width` independent PartialDecrypt calls (e.g. the servers of a threshold
 # decryption) on contexts with streams of their own, driven from host threads (paillier_amd.concurrent.Lanes)
 from paillier_amd.concurrent import Lanes
-for width, part in ((3, False), (3, True), (8, True)):
+# "spread" (plan::lds_share): a main-stream ladder of at most one workgroup per CU asks for just over half a CU's LDS; with a CU partition
+# narrower than the launch the rule switches itself off -- both settings are measured
+for width, part, spread in ((3, False, 1), (3, False, 0), (3, True, 1), (8, True, 1), (8, True, 0), (8, False, 1), (8, False, 0)):
     lanes = Lanes(0, width, partition_cus=part)
+    for cx in lanes.contexts:
+        cx.set_flag("spread", spread)
     bufs = [torch.zeros((4096, 512), dtype=torch.uint8, device=dev) for _ in range(width)]
 
     def call(cx, st, item):
@@ -70,7 +74,7 @@ for width, part in ((3, False), (3, True), (8, True)):
             lanes.map(call, items)
         torch.cuda.synchronize()
         dt = (time.perf_counter() - t) / 3
-        print(json.dumps({"op": "partial_decrypt_2048_overlapped", "calls_in_flight": width, "cu_partition": part, "batch_per_call": B, "ms": dt * 1e3,
+        print(json.dumps({"op": "partial_decrypt_2048_overlapped", "calls_in_flight": width, "cu_partition": part, "spread": spread, "batch_per_call": B, "ms": dt * 1e3,
                           "us_per_ct": dt / (B * width) * 1e6, "per_s": B * width / dt}), flush=True)
     lanes.close()
 
