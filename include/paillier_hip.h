@@ -81,7 +81,9 @@ int pgpu_ctx_last_profile(pgpu_ctx* ctx, double* vm_ms, int* vm_launches, double
  * "triple" (default 1): ladders modulo n^3 on the three-digit kernel.  "shared_chain" (default 1): several shares on the
  * same ciphertexts share one chain of squarings (pgpu_partial_decrypt_multi), runs of units under one share become
  * shared-exponent ladders (pgpu_partial_decrypt_indexed).  "lift" (default 1): level-two Encrypt computes r^(n^2) mod n^3
- * as (r^n mod n^2)^n mod n^3.  "side" (default 1): a call may issue work that depends on no ladder in flight to a second
+ * as (r^n mod n^2)^n mod n^3, and the key holder's x^n mod n^2 (pgpu_encrypt_with_r_sk, the DDLEQ prover's a^n | x^n) goes through the
+ * primes: t = x^q mod p, then the Teichmueller lift t^p mod p^2 (and likewise modulo q^2), a third fewer multiplies than the exponent
+ * n mod p (p - 1) in one ladder.  "side" (default 1): a call may issue work that depends on no ladder in flight to a second
  * stream of the context (the DDLEQ prover's per-statement chains run beside its big launches); 0 keeps one stream.
  * "lanes8" (default 1): batches too small to fill the chip at four lanes per number run ladders modulo n^2 on the eight-lane pair
  * kernel (and ladders modulo n^3 on the three-digit kernel with two lanes per digit); "muls" (default 1): bucket products of a shared
@@ -96,7 +98,9 @@ int pgpu_ctx_last_profile(pgpu_ctx* ctx, double* vm_ms, int* vm_launches, double
  * ladders on ct1 itself; non-unit inputs always take those); "exclusive" (default 1): placement by LDS size -- the small concurrent launches
  * of a prover call (up to 128 workgroups) ask for the whole LDS of a compute unit per workgroup, so that the side lanes' workgroups
  * land on idle CUs instead of the ones the main launch runs on, and a main-stream ladder of at most one workgroup per CU asks for more
- * than half of it, so that it spreads over all CUs (0: the dispatcher's placement); "spread" (default 1): the second of those two rules
+ * than half of it, so that it spreads over all CUs (0: the dispatcher's placement); "exclusive_short" (default 0): the links between ladders -- programs of a few
+ * products -- ask for a whole CU as well (round 4's rule: they then wait for an EMPTY compute unit and the side lanes' chains only move
+ * between the main stream's launches); "spread" (default 1): the second of those two rules
  * alone (0: main-stream ladders keep the dispatcher's placement; both rules stop at the compute units the context's stream may use, so a
  * context with a "cu_partition" narrower than its launch keeps the dispatcher's placement by itself); "w74" (default 1): moduli of two
  * 74-limb slices on the wave-sliced assembly kernel (0: four lanes of 37 limbs); "exp_order" (default 1): the key holder's exponents

@@ -1632,6 +1632,7 @@ static void ddleq_prove_impl(const pgpu_seckey* sk, size_t S, size_t secpar, con
       HIPCHK(hipMemcpyAsync(hch.data(), chal, batch * 4, hipMemcpyDeviceToHost, ctx->stream));
       HIPCHK(hipStreamSynchronize(ctx->stream));
     }
+    HT("flags checked");
     side.join();                                             // the per-statement values are needed from here on
     if (sb_root) {
       // s b a unit for every statement?  (never false for honest inputs; if it is, what was prepared for the one-ladder response is dropped)
@@ -1661,8 +1662,10 @@ static void ddleq_prove_impl(const pgpu_seckey* sk, size_t S, size_t secpar, con
           if (hb[st] || hb[nbs + st])
             api_throw(PGPU_ERR_NOT_INVERTIBLE, "ModInverse: an element of the batch is not invertible modulo the modulus");
       }
+      HT("bits sorted");
       uint32_t* d_idx = ctx->upload_words(idx);
       uint32_t* d_sti = ctx->upload_words(sti);
+      HT("idx uploaded");
       auto gat = [&](const uint32_t* in, int w) {            // per-instance array -> the compacted instances
         uint32_t* o = ctx->ws_t<uint32_t>((size_t)w * nbg);
         launch_gather(in, nb, d_idx, cnt, o, nbg, w, ctx->stream);
@@ -1710,7 +1713,9 @@ static void ddleq_prove_impl(const pgpu_seckey* sk, size_t S, size_t secpar, con
         pre.sti = d_sti;
         pre.cnt = cnt;
         uint32_t* c5 = ctx->ws_t<uint32_t>((size_t)W3 * nbg);
+        HT("gathers issued");
         if (!pow_n3_crt_two(sk, nullptr, es, nullptr, eb, nbg, c5, &pre)) api_throw(PGPU_ERR_UNSUPPORTED, "internal: the early response path lost its kernel");
+        HT("response issued");
         uint32_t* y3 = zext(ctx, gat(yl, W1), W1, W3, nbg);
         uint32_t* gf = ctx->ws_t<uint32_t>((size_t)W3 * nbg);
         modmul_arrays(ctx, mn3, y3, c5, nbg, gf);                             // f = y c mod n^3 (ddleq.go:114)
@@ -1802,7 +1807,9 @@ static void ddleq_prove_impl(const pgpu_seckey* sk, size_t S, size_t secpar, con
     pack_result(ctx, alp, W3, nb, batch, alpha, ct_stride, mn3.nbytes, mem);
     pack_result(ctx, eo, W2, nb, batch, e_out, e_stride, std::min(e_stride, mn2.nbytes), mem);
     pack_result(ctx, fo, W3, nb, batch, f_out, ct_stride, mn3.nbytes, mem);
+    HT("outputs issued");
     HIPCHK(hipStreamSynchronize(ctx->stream));
+    HT("done");
   }
 }
 

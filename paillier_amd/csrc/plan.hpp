@@ -160,10 +160,16 @@ constexpr uint32_t kExclusiveMaxBlocks = 128;
 //   in_exclusive_call  a protocol call whose launches run beside each other is in progress (the DDLEQ prover)
 //   products      Montgomery products of the program: short programs (links between ladders) are not worth a placement
 //   enabled / spread_enabled  the context flags "exclusive" and "spread"
+//   exclusive_short   (context flag, default 0) short programs take a CU per workgroup as well.  Round 4 did that; but a workgroup that
+//                 asks for a whole CU waits until a CU is EMPTY, and while a main-stream ladder sits on every CU (one workgroup each, or
+//                 two waves per SIMD) none is: the side lanes' chains of links -- the inversion tree, the exponents of the response --
+//                 then only move between the main stream's launches (the tree's root reached the host 28 ms after a^n was there, the
+//                 response's preparation ran into the lifts and held the call for 3 ms after Alpha was known).  A link is a few
+//                 products long: beside a ladder's workgroup it costs that ladder nothing measurable and it is gone in microseconds.
 inline int lds_share(uint32_t blocks, uint32_t stream_cus, bool on_side, bool in_exclusive_call, uint64_t products, bool enabled,
-                     bool spread_enabled) {
+                     bool spread_enabled, bool exclusive_short = false) {
   if (!enabled) return 0;
-  if (in_exclusive_call && blocks <= kExclusiveMaxBlocks && blocks <= stream_cus) return 1;
+  if (in_exclusive_call && blocks <= kExclusiveMaxBlocks && blocks <= stream_cus && (products >= 256 || exclusive_short)) return 1;
   if (spread_enabled && !on_side && blocks <= stream_cus && products >= 256) return 2;
   return 0;
 }

@@ -146,7 +146,10 @@ def test_extract_randomness_beside_the_first_launch(q):
 
 def test_placement_by_lds_size(q):
     """plan::lds_share(blocks, stream_cus, on_side, in_exclusive_call, products, exclusive_flag, spread_flag)."""
-    # inside a prover call: a compute unit per workgroup for launches of up to 128 workgroups, main stream or side lane
+    # inside a prover call: a compute unit per workgroup for LADDERS of up to 128 workgroups, main stream or side lane; the links
+    # between ladders (a few products) keep the kernel's own LDS -- a request for a whole CU waits for an empty one
+    assert q("lds_share", 64, 256, 1, 1, 12, 1, 1) == [0]
+    assert q("lds_share", 64, 256, 1, 1, 12, 1, 1, 1) == [1]          # flag "exclusive_short": round 4's rule
     assert q("lds_share", 64, 256, 1, 1, 4000, 1, 1) == [1]
     assert q("lds_share", 128, 256, 0, 1, 4000, 1, 1) == [1]
     # wider: a main-stream ladder of at most one workgroup per CU spreads (just over half a CU's LDS); a side lane's keeps its size
