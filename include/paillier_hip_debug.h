@@ -44,6 +44,7 @@ int pgpu_pair_debug_run(pgpu_ctx* ctx, const uint8_t* p_be, size_t p_len, int la
  *   "response_by_structure" (statements, instances, nb_instances, lanes_wanted) -> ok
  *   "extract_beside"      (nb_statements, nb_instances, lanes_wanted) -> ok
  *   "shared_chain_groups" (nb_ciphertexts, n_shares, lanes_wanted, have_eight_lane_kernel) -> groups of shares with a chain of squarings each
+ *   "lanes_target"        (lanes_wanted, stream_cus) -> lanes that fill what the context's stream may use with one wave per SIMD
  *   "lds_share"           (blocks, stream_cus, on_side, in_exclusive_call, products, exclusive_flag, spread_flag) -> 0 | 1 | 2
  *                         (LDS a workgroup asks for: the kernel's own | a whole CU's | just over half -- placement by LDS size)
  *   "generic_shape"       (WL, K, launch_nb, segments, lanes_wanted, wave_sliced_ok) -> WL, K   (lanes per number of the generic kernels)

@@ -54,9 +54,9 @@ static bool dual_n3_two(pgpu_ctx* ctx, const pgpu_pubkey* pk, size_t nb) {
   const int H3 = mn3.triple.root->WT;
   const PairInfo& pi = mn2.pairn;
   const bool six = ctx->use_lanes8 && H3 % 2 == 0 && vm_asm_available(H3 / 2, 112) &&
-                   plan::triple_two_lanes_per_digit(nb, plan::lanes_target(ctx->lanes_wanted));
+                   plan::triple_two_lanes_per_digit(nb, plan::lanes_target(ctx->lanes_wanted, ctx->stream_cus));
   return six && pi.root && pi.c_one_pair >= 0 && ctx->use_asm && ctx->use_pair && ctx->use_side &&
-         plan::dual_n3_two_ladders(nb, plan::lanes_target(ctx->lanes_wanted));
+         plan::dual_n3_two_ladders(nb, plan::lanes_target(ctx->lanes_wanted, ctx->stream_cus));
 }
 // y^n modulo n^2 (y: W3 limbs, any value below R) on a side lane, beside the caller's ladder that produces the per-number exponents;
 // join() before dual_pow_n3 uses it
@@ -115,7 +115,7 @@ uint32_t* dual_pow_n3(pgpu_ctx* ctx, const pgpu_pubkey* pk, const uint32_t* x, c
     // 2 048 squarings modulo n^3 in ~25 ms where the one-lane digits take 77 whatever the batch)
     const int H3 = mn3.triple.root->WT;
     const bool six = ctx->use_lanes8 && H3 % 2 == 0 && vm_asm_available(H3 / 2, 112) &&
-                     plan::triple_two_lanes_per_digit(nb, plan::lanes_target(ctx->lanes_wanted));
+                     plan::triple_two_lanes_per_digit(nb, plan::lanes_target(ctx->lanes_wanted, ctx->stream_cus));
     const int wb = six ? 5 : triple_window_bits(nb, H3);
     const bool nm5 = !six && wb == 5;
     const uint32_t tab2 = 5 + (uint32_t)perlane_table_slots(wb, nm5);
@@ -124,7 +124,7 @@ uint32_t* dual_pow_n3(pgpu_ctx* ctx, const pgpu_pubkey* pk, const uint32_t* x, c
     // A batch so small that two eight-lane ladders still find a SIMD per wave side by side: x^(e0) does not depend on W, so it runs as a
     // ladder of its own on a side lane -- beside the W ladder modulo n^2 and W^n modulo n^3 -- and one product joins them.  The chain
     // E^n -> W -> W^n is then the run time (2 048 numbers: the interleaved ladder 45 ms, W^n alone 34); launches on CUs of their own.
-    const bool two_ladders = six && plan::dual_n3_two_ladders(nb, plan::lanes_target(ctx->lanes_wanted));
+    const bool two_ladders = six && plan::dual_n3_two_ladders(nb, plan::lanes_target(ctx->lanes_wanted, ctx->stream_cus));
     if (two_ladders) {
       ExclusiveScope excl(ctx, true);
       TriplePlan tx = triple_alloc(ctx, mn3, nb, 5 + perlane_table_slots(5, false));
@@ -329,7 +329,7 @@ bool pow_p2_multi_crt(const pgpu_seckey* sk, const uint32_t* const xs[2], const 
   // one lane per number when the two halves fill the chip that way, else two (as Decrypt chooses)
   // (two lanes per number pay while they still leave every wave a SIMD of its own: above half a wave per SIMD at one lane, two
   // lanes are two waves on most SIMDs -- 1.15 x the one-lane ladder -- and the one-lane kernel needs fewer multiplies)
-  const int lanes = plan::crt_pair_lanes(1, sk->pair_small2, nb, plan::lanes_target(ctx->lanes_wanted));
+  const int lanes = plan::crt_pair_lanes(1, sk->pair_small2, nb, plan::lanes_target(ctx->lanes_wanted, ctx->stream_cus));
   const int H = sk->mp.WT, W2 = sk->mp2.WT;
   const size_t S1 = (size_t)H * nb, S2 = (size_t)W2 * nb;
   const int wb = 4;                                           // per-number windows: VM_MULV
@@ -782,7 +782,7 @@ void pow_n3_crt(const pgpu_seckey* sk, const uint32_t* base, int wb, const uint3
   const int W = mp3.WT, W3 = sk->pk->mn3->WT;
   const size_t S = (size_t)W * nb;
   // (plan.hpp: window width of the per-number exponents and the gate of the p-adic split, decided in ONE place)
-  const plan::Crt3Ladder lad = plan::crt3_ladder(nb, sk->mp.WT, W, plan::lanes_target(ctx->lanes_wanted), exps != nullptr, true);
+  const plan::Crt3Ladder lad = plan::crt3_ladder(nb, sk->mp.WT, W, plan::lanes_target(ctx->lanes_wanted, ctx->stream_cus), exps != nullptr, true);
   if (triple_usable(ctx, mp3) && triple_usable(ctx, mq3) && lad.triple && (exps || base2 || e->bit_length() >= 64)) {
     // both halves on the three-digit kernel (digits modulo p and q, 37 limbs for 2048-bit keys): a squaring is 37 rows
     // where the wave-sliced 110-limb kernel has 110 -- what counts for the half-size, latency-bound batches of the response
@@ -1053,7 +1053,7 @@ bool pow_n3_crt_two(const pgpu_seckey* sk, const uint32_t* A, const uint32_t* co
   const size_t S = (size_t)W * nb;
   if (!(triple_usable(ctx, mp3) && triple_usable(ctx, mq3) && sk->eo_p.ok && sk->eo_q.ok && sk->eo_p.w == sk->eo_q.w)) return false;
   const int H = mp3.triple.root->WT, we = sk->eo_p.w;
-  const plan::Crt3Two two = plan::crt3_two(nb, H, plan::lanes_target(ctx->lanes_wanted), true);
+  const plan::Crt3Two two = plan::crt3_two(nb, H, plan::lanes_target(ctx->lanes_wanted, ctx->stream_cus), true);
   if (!two.usable) return false;
   const int win = 7;
   // The p-adic split of BOTH exponents (what pow_n3_crt does for one): with e = e0 + e1 prime,
@@ -1366,7 +1366,7 @@ static void ddleq_prove_impl(const pgpu_seckey* sk, size_t S, size_t secpar, con
     // less: 16 384 instances at secpar 1): a launch that fills both slots would lose one of them on half the chip to the side
     // launch for its whole length (measured at 32 768 instances: 48 -> 76 ms for 8 ms hidden).  Then s follows on the main stream.
     // (A side launch of a few dozen waves -- the statements of a secpar-40 call -- costs the big launch next to nothing.)
-    const bool s_beside = plan::extract_beside(nbs, nb, plan::lanes_target(ctx->lanes_wanted));
+    const bool s_beside = plan::extract_beside(nbs, nb, plan::lanes_target(ctx->lanes_wanted, ctx->stream_cus));
     // The structure path's per-statement part (struct_pow_n3 below) -- the level-two plaintext of ct1 through p^3, q^3 and ct1 modulo
     // the primes -- depends on the inputs only: it is issued beside the a^n | x^n launch on a lane of its own (s has the side
     // stream), and runs where wave slots are free: beside that launch at 16 384 instances (one lane per number: one wave per SIMD),
@@ -1529,7 +1529,7 @@ static void ddleq_prove_impl(const pgpu_seckey* sk, size_t S, size_t secpar, con
       // From a few instances per statement on, the response goes through the structure of the unit group (struct_response): the
       // per-statement part -- the level-two "plaintexts" of s and b, s and b modulo the primes -- and every instance's exponents
       // are made here as well.
-      resp_struct = by_struct && one_ladder && sb_units && plan::response_by_structure(S, batch, nb, plan::lanes_target(ctx->lanes_wanted));
+      resp_struct = by_struct && one_ladder && sb_units && plan::response_by_structure(S, batch, nb, plan::lanes_target(ctx->lanes_wanted, ctx->stream_cus));
       const bool early_cond = one_ladder && sb_units && ctx->use_early && pre_bases_usable(sk) &&
                               plan::early_response_ok(nb, sk->mp3.triple.root->WT);
       if (resp_struct || early_cond) {

@@ -99,7 +99,7 @@ struct pgpu_ctx {
                                  // workgroup then asks for the whole LDS of a CU, so the dispatcher cannot stack the side lanes' workgroups on the CUs the main
                                  // launch runs on (it starts every queue's workgroups from the same CUs: 17.5 -> 28 ms for a^n | x^n of 2 048 instances)
   bool use_spread = true;    // a main-stream ladder of at most one workgroup per CU asks for just over half a CU's LDS (plan::lds_share; pgpu_ctx_set_flag("spread", 0): the dispatcher's placement)
-  bool use_exclusive_short = false;   // short programs of a prover call take a CU per workgroup too (pgpu_ctx_set_flag("exclusive_short", 1): round 4's rule; see plan::lds_share)
+  bool use_exclusive_short = true;    // short programs of a prover call take a CU per workgroup too (pgpu_ctx_set_flag("exclusive_short", 0): only ladders do; measured equal -- plan::lds_share)
   uint32_t stream_cus = plan::kChipCUs;   // compute units this context's stream may use (pgpu_ctx_set_flag("cu_partition", ...) narrows it)
   bool use_w74 = true;       // 74-limb two-slice moduli on the wave-sliced assembly kernel (pgpu_ctx_set_flag("w74", 0): four lanes of 37 limbs)
   bool use_exp_order = true; // the key holder's exponents modulo p^3, q^3 reduced modulo the group orders (pgpu_ctx_set_flag("exp_order", 0): as given)

@@ -182,7 +182,7 @@ void triple_run(pgpu_ctx* ctx, const ModCtx& mc, const TriplePlan& tp, const Pro
   // two lanes per digit (GenQ6) where the digit does not fit a lane, or where the batch is so small that eight lanes per number
   // still leave every wave a SIMD of its own (one ladder's latency is the run time); not for number-major tables
   const bool six = ti.lanes6_only || (ctx->use_lanes8 && !p.nm_tables && tp.H % 2 == 0 && vm_asm_available(tp.H / 2, 112) &&
-                                      plan::triple_two_lanes_per_digit(tp.nb, plan::lanes_target(ctx->lanes_wanted)));
+                                      plan::triple_two_lanes_per_digit(tp.nb, plan::lanes_target(ctx->lanes_wanted, ctx->stream_cus)));
   sp.pair = ti.kconsts; sp.pair_n0inv = ti.root->n0inv; sp.pair_h = tp.H; sp.pair_lanes = six ? 6 : 3; sp.tconsts = ti.tconsts;
   run_vm(ctx, tp.nb, sp, nullptr, true);
 }
@@ -228,8 +228,8 @@ void modexp_shared_run(pgpu_ctx* ctx, const ModCtx& mc, const ModexpPlan& pl, co
   }
   if (pair_digits_in) api_throw(PGPU_ERR_UNSUPPORTED, "internal: pair digits handed to a ladder that is not on the digit kernel");
   const bool have4 = mc.pairn.root && mc.pairn.root->WT % 2 == 0 && vm_asm_available(mc.pairn.root->WT / 2, 64);
-  const int lanes = plan::pair_lanes_shared(pl.nb, plan::lanes_target(ctx->lanes_wanted), have4, have4 && mc.pairn.consts8 && ctx->use_lanes8);
-  if (mc.pairn.root && ctx->use_asm && ctx->use_pair && !wide && skip_zero && e.bit_length() >= 256 && plan::pair_kernel_serves(pl.nb, plan::lanes_target(ctx->lanes_wanted), have4)) {
+  const int lanes = plan::pair_lanes_shared(pl.nb, plan::lanes_target(ctx->lanes_wanted, ctx->stream_cus), have4, have4 && mc.pairn.consts8 && ctx->use_lanes8);
+  if (mc.pairn.root && ctx->use_asm && ctx->use_pair && !wide && skip_zero && e.bit_length() >= 256 && plan::pair_kernel_serves(pl.nb, plan::lanes_target(ctx->lanes_wanted, ctx->stream_cus), have4)) {
     // (a batch that leaves SIMDs empty even at four lanes per number is bound by one ladder's latency: eight lanes, GenQ8)
     modexp_pair(ctx, mc, pl, &e, nullptr, 0, use_post, lanes, use_post ? nullptr : raw_pair_out);
     if (!(raw_pair_out && *raw_pair_out)) launch_canon(pl.out(), mc.d_nmod, mc.WT, pl.nb, ctx->stream);
@@ -253,8 +253,8 @@ void modexp_perlane_run(pgpu_ctx* ctx, const ModCtx& mc, const ModexpPlan& pl, c
     const bool have4 = mc.pairn.root && mc.pairn.root->WT % 2 == 0 && vm_asm_available(mc.pairn.root->WT / 2, 64);
     if (mc.pairn.root && mc.pairn.c_one_pair >= 0 && ctx->use_asm && ctx->use_pair && !wide && we >= 10 &&
         plan::pair_mulv_fits(pl.nb, mc.WT) &&                            // MULV gathers with 32-bit offsets
-        plan::pair_kernel_serves(pl.nb, plan::lanes_target(ctx->lanes_wanted), have4)) {
-      modexp_pair(ctx, mc, pl, nullptr, exps, we, use_post, plan::pair_lanes_2or4(pl.nb, plan::lanes_target(ctx->lanes_wanted), have4));
+        plan::pair_kernel_serves(pl.nb, plan::lanes_target(ctx->lanes_wanted, ctx->stream_cus), have4)) {
+      modexp_pair(ctx, mc, pl, nullptr, exps, we, use_post, plan::pair_lanes_2or4(pl.nb, plan::lanes_target(ctx->lanes_wanted, ctx->stream_cus), have4));
       launch_canon(pl.out(), mc.d_nmod, mc.WT, pl.nb, ctx->stream);
       return;
     }
@@ -560,13 +560,13 @@ uint32_t* dual_pow_pair(pgpu_ctx* ctx, const ModCtx& mc, const uint32_t* x, cons
   if (!(pi.root && pi.c_one_pair >= 0 && ctx->use_asm && ctx->use_pair)) return nullptr;
   const int H = pi.root->WT, W2 = mc.WT;
   const bool have4 = H % 2 == 0 && vm_asm_available(H / 2, 64);
-  if (!plan::pair_kernel_serves(nb, plan::lanes_target(ctx->lanes_wanted), have4)) return nullptr;
-  const bool two = plan::pair_lanes_2or4(nb, plan::lanes_target(ctx->lanes_wanted), have4) == 2;
+  if (!plan::pair_kernel_serves(nb, plan::lanes_target(ctx->lanes_wanted, ctx->stream_cus), have4)) return nullptr;
+  const bool two = plan::pair_lanes_2or4(nb, plan::lanes_target(ctx->lanes_wanted, ctx->stream_cus), have4) == 2;
   // A batch so small that eight lanes per number still leave every wave a SIMD of its own is bound by the ladder's latency: GenQ8
   // (76-limb digits over four lanes each; the radix changes R_74 <-> R_76 by one product on the way in and out, inside the program;
   // limb-major 5-bit tables -- the gathers of so few numbers are not what the launch waits for).  2 048 numbers: 36.6 -> 2x ms.
   const bool eight = have4 && pi.consts8 && ctx->use_lanes8 &&
-                     plan::pair_lanes_shared(nb, plan::lanes_target(ctx->lanes_wanted), have4, true) == 8;
+                     plan::pair_lanes_shared(nb, plan::lanes_target(ctx->lanes_wanted, ctx->stream_cus), have4, true) == 8;
   // per-number window table number-major (VM_STORET / VM_MULVT5 / VM_MULVT): limb-major, the 16 384-number ladder of the DDLEQ
   // verifier fetched 98 GB of 32-byte sectors for its dword gathers in a 43 ms launch (profiles/r03_bench_traffic.txt)
   const bool nm4 = ctx->use_nm4 && !eight;

@@ -27,7 +27,7 @@ uint32_t* decrypt1_crt(const pgpu_seckey* sk, const uint32_t* c_limbs, size_t nb
   bool pair_done = false;
   uint32_t *up = mem + 3 * S2, *uq = mem + 37 * S2;
   // (the two-lane kernel needs 2 lanes x 2 halves per ciphertext to fill the chip; below that the finer slicings win)
-  const size_t lanes_target = plan::lanes_target(ctx->lanes_wanted);
+  const size_t lanes_target = plan::lanes_target(ctx->lanes_wanted, ctx->stream_cus);
   // one lane per number (GenP) from one wave per SIMD upwards; two lanes per number (GenQ) from there down to one wave
   // per SIMD again; below that the ordinary kernels with their finer slicings
   // two lanes per number while they leave every wave a SIMD of its own (both halves: 4 nb lanes); between half a wave and one
@@ -263,7 +263,7 @@ uint32_t* pow_n2_crt(const pgpu_seckey* sk, const uint32_t* base, const BigU& e,
   {
     // (small batches on two lanes per number, as Decrypt chooses: a squaring is 37 rows of 74 multiplies instead of the one-lane
     // kernel's 4 810 in a row -- the ladder's latency is the run time there)
-    const int lanes = plan::crt_pair_lanes(sk->pair_lanes, sk->pair_small2, nb, plan::lanes_target(ctx->lanes_wanted));
+    const int lanes = plan::crt_pair_lanes(sk->pair_lanes, sk->pair_small2, nb, plan::lanes_target(ctx->lanes_wanted, ctx->stream_cus));
     SegSpec sp{&sk->mp2, &lad[0], mem[0], nullptr}, sq{&sk->mq2, &lad[1], mem[1], nullptr};
     sp.pair = sk->pair_p.d; sp.pair_n0inv = sk->mp.n0inv; sp.pair_h = H; sp.pair_lanes = lanes;
     sq.pair = sk->pair_q.d; sq.pair_n0inv = sk->mq.n0inv; sq.pair_h = H; sq.pair_lanes = lanes;

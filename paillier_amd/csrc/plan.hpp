@@ -19,7 +19,13 @@ constexpr uint32_t kChipCUs = 256;
 constexpr size_t kChipLanes = (size_t)1024 * 64;   // 256 CUs x 4 SIMDs x 64 lanes: one wave on every SIMD
 constexpr uint64_t kGatherSpan = 1ull << 32;    // per-number table gathers of the assembly kernels use 32-bit byte offsets
 
-inline size_t lanes_target(size_t ctx_lanes_wanted) { return ctx_lanes_wanted ? ctx_lanes_wanted : kChipLanes; }
+// stream_cus: compute units the context's stream may use: a context with a CU partition fills ITS slice.  Eight contexts on 32 CUs each,
+// a 2 048-ciphertext PartialDecrypt in flight on every one (tools/small_batch_sweep.py, profiles/r05_small_batch_overlap.jsonl): four lanes
+// per number -- one wave per SIMD of the slice -- where the whole chip's target picked eight lanes and two waves per SIMD: 72.2 -> 62.1 ms
+// for the eight calls; 4 096 ciphertexts each: 145.5 -> 120.0 ms.
+inline size_t lanes_target(size_t ctx_lanes_wanted, uint32_t stream_cus = kChipCUs) {
+  return ctx_lanes_wanted ? ctx_lanes_wanted : (size_t)stream_cus * 4 * 64;
+}
 
 // ---- per-number window tables -------------------------------------------------------------------------------------------------
 // windows of a `we`-limb exponent: 4 bits = 7 per 28-bit limb (VM_MULV / VM_MULVT), 7 bits = 4 per limb (VM_MULV7), 5 bits = 5
@@ -153,24 +159,26 @@ constexpr uint32_t kExclusiveMaxBlocks = 128;
 // workgroup), 2 just over half (no two workgroups of the launch on one CU; a side lane's 30 - 60 KB still fit beside it).
 //   blocks        workgroups of the launch
 //   stream_cus    compute units the launch's stream may use: kChipCUs, or the slice of a context with a CU partition.  A launch that
-//                 asks for a CU (or half) per workgroup on FEWER CUs than it has workgroups would run in rounds, so both rules stop at
-//                 stream_cus: eight contexts on 32 CUs each keep the dispatcher's placement for their
-//                 64-workgroup ladders
+//                 asks for a CU per workgroup on FEWER CUs than it has workgroups would run in rounds, so that rule stops at stream_cus;
+//                 the half-a-CU rule is for contexts that have the whole chip (eight contexts on 32 CUs each
+//                 keep the dispatcher's placement)
 //   on_side       the launch goes to a side lane of the context
 //   in_exclusive_call  a protocol call whose launches run beside each other is in progress (the DDLEQ prover)
 //   products      Montgomery products of the program: short programs (links between ladders) are not worth a placement
 //   enabled / spread_enabled  the context flags "exclusive" and "spread"
-//   exclusive_short   (context flag, default 0) short programs take a CU per workgroup as well.  Round 4 did that; but a workgroup that
-//                 asks for a whole CU waits until a CU is EMPTY, and while a main-stream ladder sits on every CU (one workgroup each, or
-//                 two waves per SIMD) none is: the side lanes' chains of links -- the inversion tree, the exponents of the response --
-//                 then only move between the main stream's launches (the tree's root reached the host 28 ms after a^n was there, the
-//                 response's preparation ran into the lifts and held the call for 3 ms after Alpha was known).  A link is a few
-//                 products long: beside a ladder's workgroup it costs that ladder nothing measurable and it is gone in microseconds.
+//   exclusive_short   (context flag, default 1) short programs -- the links between ladders -- take a CU per workgroup as well.  A workgroup
+//                 that asks for a whole CU waits until one is EMPTY, so with the flag on the side lanes' chains only move between the main
+//                 stream's launches (the inversion tree's root reaches the host at 48 ms of a 16 384-instance call, at 38 ms with the flag
+//                 off); with it off they run beside the ladders and slow them by as much: Alpha is known 2.4 ms later, the side lane is
+//                 done 1.9 ms earlier.  Measured, ms per call, on | off: 16 384 instances 120.6 | 120.6, 8 192: 91.5 | 92.5, 2 048: 54.5 |
+//                 55.0, 1 536 x 40: 181.7 | 183.9 -- the chip is the bottleneck either way; round 4's rule stays.
 inline int lds_share(uint32_t blocks, uint32_t stream_cus, bool on_side, bool in_exclusive_call, uint64_t products, bool enabled,
-                     bool spread_enabled, bool exclusive_short = false) {
+                     bool spread_enabled, bool exclusive_short = true) {
   if (!enabled) return 0;
   if (in_exclusive_call && blocks <= kExclusiveMaxBlocks && blocks <= stream_cus && (products >= 256 || exclusive_short)) return 1;
-  if (spread_enabled && !on_side && blocks <= stream_cus && products >= 256) return 2;
+  // (inside a CU partition the mask already keeps other contexts off these CUs, and the request only delays placement: eight contexts
+  // on 32 CUs each, 1 024 / 2 048 ciphertexts per call: 39.4 / 62.1 ms without it, 45.7 / 65.7 ms with it)
+  if (spread_enabled && !on_side && stream_cus == kChipCUs && blocks <= stream_cus && products >= 256) return 2;
   return 0;
 }
 

@@ -172,7 +172,7 @@ int pgpu_partial_decrypt_multi(const pgpu_pubkey* pk, int total_servers, int n_s
     uint32_t* ent = ctx->ws_t<uint32_t>(SW * 4);          // generic slots: 0 x, 1 -, 2 digits (X0 | X1), 3 X
     unpack_mod(ctx, mc, c, c_stride, batch, mem, ent, nb);
     pair_enter(ctx, mc, ent, nb);
-    const size_t lanes_target = plan::lanes_target(ctx->lanes_wanted);
+    const size_t lanes_target = plan::lanes_target(ctx->lanes_wanted, ctx->stream_cus);
     const bool have4 = H % 2 == 0 && vm_asm_available(H / 2, 64);
     auto leave_pair_form = [&](uint32_t* pm, uint32_t out_slot, uint8_t* dst) {
       pair_leave_and_pack(ctx, mc, pm, out_slot, nb, batch, dst, out_stride, mem);
@@ -289,7 +289,7 @@ int pgpu_partial_decrypt_units(const pgpu_pubkey* pk, int total_servers, int n_s
       const bool have8 = H0 % 2 == 0 && vm_asm_available(H0 / 2, 64) && pi0.consts8 && ctx->use_lanes8;
       const Interval whole = ivs[0];
       const int groups = plan::shared_chain_groups(round_up(whole.e - whole.b, VM_BLOCK), (int)whole.servers.size(),
-                                                   plan::lanes_target(ctx->lanes_wanted), have8);
+                                                   plan::lanes_target(ctx->lanes_wanted, ctx->stream_cus), have8);
       if (groups > 1) {
         ivs.clear();
         const size_t S = whole.servers.size();
@@ -325,7 +325,7 @@ int pgpu_partial_decrypt_units(const pgpu_pubkey* pk, int total_servers, int n_s
     // A shard so small that even four lanes per number leave SIMDs empty is bound by the LATENCY of one ladder: eight lanes per
     // number (GenQ8: 76-limb digits in four lanes each, 38 multiplies a row and lane instead of 74) while every wave still has
     // a SIMD of its own.  The digits change radix on the way in and out (R_74 <-> R_76: one product each, inside the program).
-    const int lanes = plan::pair_lanes_shared(ivs.size() * nbs, plan::lanes_target(ctx->lanes_wanted), have4, have4 && pi.consts8 && ctx->use_lanes8);
+    const int lanes = plan::pair_lanes_shared(ivs.size() * nbs, plan::lanes_target(ctx->lanes_wanted, ctx->stream_cus), have4, have4 && pi.consts8 && ctx->use_lanes8);
     const int Hk = lanes == 8 ? pi.h8 : H;                  // limbs of a digit in the kernel's slots
     const size_t SWk = (size_t)2 * Hk * nbs;                // words of a kernel slot
     const int w = 7;
@@ -442,7 +442,7 @@ int pgpu_partial_decrypt_indexed(const pgpu_pubkey* pk, int total_servers, int n
         size_t longest = 0;
         for (auto& r : runs) longest = std::max(longest, r.e - r.b);
         const size_t nbs = round_up(longest, VM_BLOCK), SWs = (size_t)W2 * nbs;
-        const int lanes = plan::pair_lanes_2or4(runs.size() * nbs, plan::lanes_target(ctx->lanes_wanted), H % 2 == 0 && vm_asm_available(H / 2, 64));
+        const int lanes = plan::pair_lanes_2or4(runs.size() * nbs, plan::lanes_target(ctx->lanes_wanted, ctx->stream_cus), H % 2 == 0 && vm_asm_available(H / 2, 64));
         uint32_t* pm[3];
         Prog pr[3];
         SegSpec sg[3];

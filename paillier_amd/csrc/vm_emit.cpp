@@ -405,7 +405,7 @@ void run_vm(pgpu_ctx* ctx, size_t nb, const SegSpec& s0, const SegSpec* s1, bool
     WL = s0.pair_lanes == 8 ? s0.pair_h / 4 : (s0.pair_lanes == 4 || s0.pair_lanes == 6) ? s0.pair_h / 2 : s0.pair_h;
     K = s0.pair_lanes == 8 ? 96 : s0.pair_lanes == 6 ? 112 : s0.pair_lanes == 4 ? 64 : s0.pair_lanes == 3 ? 48 : s0.pair_lanes == 2 ? 32 : 16;   // tags of the pair kernels, not lane counts
   } else {
-    const plan::GenericShape gs = plan::generic_shape(WL, K, launch_nb, s2 ? 3 : s1 ? 2 : 1, plan::lanes_target(ctx->lanes_wanted),
+    const plan::GenericShape gs = plan::generic_shape(WL, K, launch_nb, s2 ? 3 : s1 ? 2 : 1, plan::lanes_target(ctx->lanes_wanted, ctx->stream_cus),
                                                       ctx->use_w74 && ctx->use_asm);
     WL = gs.WL;
     K = gs.K;

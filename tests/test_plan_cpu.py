@@ -146,10 +146,10 @@ def test_extract_randomness_beside_the_first_launch(q):
 
 def test_placement_by_lds_size(q):
     """plan::lds_share(blocks, stream_cus, on_side, in_exclusive_call, products, exclusive_flag, spread_flag)."""
-    # inside a prover call: a compute unit per workgroup for LADDERS of up to 128 workgroups, main stream or side lane; the links
-    # between ladders (a few products) keep the kernel's own LDS -- a request for a whole CU waits for an empty one
-    assert q("lds_share", 64, 256, 1, 1, 12, 1, 1) == [0]
-    assert q("lds_share", 64, 256, 1, 1, 12, 1, 1, 1) == [1]          # flag "exclusive_short": round 4's rule
+    # inside a prover call: a compute unit per workgroup for launches of up to 128 workgroups, main stream or side lane -- links
+    # between ladders (a few products) included unless the flag "exclusive_short" is off
+    assert q("lds_share", 64, 256, 1, 1, 12, 1, 1) == [1]
+    assert q("lds_share", 64, 256, 1, 1, 12, 1, 1, 0) == [0]
     assert q("lds_share", 64, 256, 1, 1, 4000, 1, 1) == [1]
     assert q("lds_share", 128, 256, 0, 1, 4000, 1, 1) == [1]
     # wider: a main-stream ladder of at most one workgroup per CU spreads (just over half a CU's LDS); a side lane's keeps its size
@@ -167,7 +167,18 @@ def test_placement_by_lds_size(q):
     # for a CU -- or half of one -- per workgroup with 64 workgroups: that would be two rounds on its slice
     assert q("lds_share", 64, 32, 0, 0, 4000, 1, 1) == [0]
     assert q("lds_share", 64, 32, 0, 1, 4000, 1, 1) == [0]
-    assert q("lds_share", 32, 32, 0, 0, 4000, 1, 1) == [2]
+    assert q("lds_share", 32, 32, 0, 0, 4000, 1, 1) == [0]           # measured: 62.1 ms without the request, 65.7 with it
+    assert q("lds_share", 32, 32, 0, 1, 4000, 1, 1) == [1]
+
+
+def test_lanes_target_follows_the_cu_partition(q):
+    """A context confined to a slice of the compute units plans for that slice."""
+    assert q("lanes_target", 0, 256) == [65536]
+    assert q("lanes_target", 0, 32) == [8192]
+    assert q("lanes_target", 1, 32) == [1]                       # an explicit "lanes_wanted" wins
+    # eight contexts on 32 CUs each, 2 048 ciphertexts per PartialDecrypt call: four lanes per number (one wave per SIMD of the slice)
+    assert q("pair_lanes_shared", 2048, 8192, 1, 1) == [4]
+    assert q("pair_lanes_shared", 2048, 0, 1, 1) == [8]          # the same call with the whole chip to itself
 
 
 def test_generic_kernel_lanes(q):
