@@ -1252,166 +1252,229 @@ uint32_t* zext(pgpu_ctx* ctx, const uint32_t* in, int w, int wo, size_t nb) {
 
 }  // namespace pgi
 
-extern "C" {
-
 // ProveDDLEQ (ddleq.go:27-40) for `n_statements` statements (ct1, ct2, a, b) with `secpar` instances each -- draws x, y
 // supplied, instance k of statement j in row j * secpar + k of x / y / alpha / e / f.  What ddleq.go:55-127 recomputes in every
 // instance although it depends on the statement only is computed ONCE per statement: the sanity check ct1^(a^n) b^(n^2) == ct2
 // (:62-69), a^n (:104), a^-1 (:95) and (a^n)^-1, s = ExtractRandonness(ct1) (:103) and the unit tests of s and b; per instance
 // remain x^n, alpha = ct1^(x^n) y^(n^2), the challenge bit and -- for bit 1 -- the response ladder.  The integers are those of
 // `secpar` calls of proveDDLEQInstance with the same draws.  secpar = 1 is pgpu_ddleq_prove.
-static void ddleq_prove_impl(const pgpu_seckey* sk, size_t S, size_t secpar, const uint8_t* ct1, const uint8_t* ct2, size_t ct_stride,
-                             const uint8_t* a, const uint8_t* b, const uint8_t* x, const uint8_t* y, size_t n_stride, uint8_t* alpha,
-                             uint8_t* e_out, size_t e_stride, uint8_t* f_out, int mem) {
-  pgpu_ctx* ctx = sk->ctx;
-  const pgpu_pubkey* pk = sk->pk;
-  {
-    if (S == 0 || secpar == 0) api_throw(PGPU_ERR_INVALID, "empty batch");
-    if (!pk->mn3 || sk->c_mu2R < 0) api_throw(PGPU_ERR_UNSUPPORTED, "level two is not available for this key");
-    if (!pk->g_is_n_plus_1) api_throw(PGPU_ERR_UNSUPPORTED, "DDLEQ prover assumes G = N+1");
-    ctx->bind();
-    ctx->reset_ws();
-    const ModCtx &mn = pk->mn, &mn2 = pk->mn2, &mn3 = *pk->mn3;
-    const int W1 = mn.WT, W2 = mn2.WT, W3 = mn3.WT;
-    // the prover holds the factorisation: exponentiations modulo n^3 go through p^3 and q^3 (pow_n3_crt)
-    const bool crt3 = sk->has_crt2 && sk->c_p3invR >= 0 && 2 * sk->mp3.WT >= W3 && ctx->use_pair;
-    auto perlane3 = [&](const uint32_t* base, const uint32_t* exps, int we, size_t nbx, uint32_t* outp) {
-      if (crt3) pow_n3_crt(sk, base, W3, exps, we, nullptr, nbx, outp);
-      else perlane_pow(ctx, mn3, base, exps, we, nbx, outp);
-    };
-    auto shared3 = [&](const uint32_t* base, int wb, const BigU& ex, size_t nbx, uint32_t* outp) {
-      if (crt3) pow_n3_crt(sk, base, wb, nullptr, 0, &ex, nbx, outp);
-      else shared_pow(ctx, mn3, base, wb, ex, nbx, outp);
-    };
-    const size_t batch = S * secpar;                        // instances
-    const size_t nbs = round_up(S, VM_BLOCK), nb = round_up(batch, VM_BLOCK);
-    // PGPU_HOST_TRACE=1 (measurements): when the HOST passed each stage of the call (ms from its start) -- where it waited for the device
+//
+// One call = one ProveCall: its stages, in the order run() issues them (each stage only ISSUES work; the two places where the host
+// waits for the device are read_back() and, inside statement_side_work(), the inversion tree's root):
+//   unpack_inputs        operands to limbs; per-statement rows repeated for the instances of their statement
+//   powers_of_n          a^n | x^n modulo n^2 in one launch (through the primes and a Teichmueller lift for the key holder)
+//   structure_base       side lane: ct1 modulo the primes, the level-two plaintext of ct1 (what the structure path needs per statement)
+//   extract_randomness   s = ExtractRandonness(ct1), on the side stream where the a^n | x^n launch leaves room
+//   sanity_and_alpha     ct1^(a^n) b^(n^2) | ct1^(x^n) y^(n^2): structure path, literal ladders or (no factorisation) plain ladders;
+//                        the comparison with ct2; the hash right behind Alpha
+//   statement_side_work  side stream: a^-1 | (a^n)^-1 from one inversion tree, the unit test of s b, the response prepared for EVERY
+//                        instance (exponents, bases) before the challenge bits exist
+//   read_back            the host learns sanity flags, unit flags and challenge bits; non-units redo the launch literally
+//   respond              the instances with challenge bit 1: gather what was prepared, one ladder (or the structure path, or the
+//                        reference's literal sequence), scatter E and F
+//   write_outputs        Alpha, E, F to the caller's buffers
+namespace {
+
+struct HostTrace {      // PGPU_HOST_TRACE=1 (measurements): when the HOST passed each stage of the call (ms from its start) -- where it waited for the device
+  bool on;
+  std::chrono::steady_clock::time_point t0 = std::chrono::steady_clock::now();
+  std::vector<std::pair<const char*, double>> log;
+  HostTrace() {
     static const bool host_trace = [] { const char* e = getenv("PGPU_HOST_TRACE"); return e && atoi(e) != 0; }();
-    const auto ht0 = std::chrono::steady_clock::now();
-    std::vector<std::pair<const char*, double>> ht_log;
-    auto HT = [&](const char* what) {
-      if (host_trace) ht_log.emplace_back(what, std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - ht0).count());
-    };
-    struct HtDump {
-      std::vector<std::pair<const char*, double>>& l;
-      ~HtDump() {
-        if (l.empty()) return;
-        fprintf(stderr, "[pgpu] prove host:");
-        for (auto& x : l) fprintf(stderr, " %s %.2f |", x.first, x.second);
-        fprintf(stderr, "\n");
-      }
-    } ht_dump{ht_log};
-    struct ExclusiveCall {
-      pgpu_ctx* c;
-      ExclusiveCall(pgpu_ctx* c_, bool on) : c(c_) { c->exclusive_call = on; }
-      ~ExclusiveCall() { c->exclusive_call = false; }
-    } exclusive_call(ctx, true);   // which of the call's launches take a CU per workgroup: plan::lds_share
+    on = host_trace;
+  }
+  void operator()(const char* what) {
+    if (on) log.emplace_back(what, std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count());
+  }
+  ~HostTrace() {
+    if (log.empty()) return;
+    fprintf(stderr, "[pgpu] prove host:");
+    for (auto& x : log) fprintf(stderr, " %s %.2f |", x.first, x.second);
+    fprintf(stderr, "\n");
+  }
+};
+
+struct ExclusiveCall {  // which of the call's launches take a CU per workgroup: plan::lds_share
+  pgpu_ctx* c;
+  explicit ExclusiveCall(pgpu_ctx* c_) : c(c_) { c->exclusive_call = true; }
+  ~ExclusiveCall() { c->exclusive_call = false; }
+};
+
+struct Background {     // side-lane ladders at wave priority 0 for the length of a scope (flag "background")
+  pgpu_ctx* c; bool on;
+  Background(pgpu_ctx* c_, bool on_) : c(c_), on(on_) { if (on) c->background_launch = true; }
+  ~Background() { if (on) c->background_launch = false; }
+};
+
+struct ProveCall {
+  // ---- the call
+  const pgpu_seckey* sk;
+  pgpu_ctx* ctx;
+  const pgpu_pubkey* pk;
+  const size_t S, secpar;
+  const uint8_t *ct1, *ct2, *a, *b, *x, *y;
+  const size_t ct_stride, n_stride;
+  uint8_t *alpha, *e_out, *f_out;
+  const size_t e_stride;
+  const int mem;
+  const ModCtx &mn, &mn2, &mn3;
+  const int W1, W2, W3;
+  const bool crt3;                                         // the prover holds the factorisation: exponentiations modulo n^3 go through p^3 and q^3 (pow_n3_crt)
+  const size_t batch, nbs, nb, nt;                         // instances; statements / instances padded to whole workgroups; numbers of the two-batch launches
+  const BigU &N, &N2;
+  HostTrace HT;
+  ExclusiveCall exclusive_call;
+  SideStream side;                                         // what depends on the statement only and on no ladder of the call
+  SideStream base_lane;                                    // (a lane of its own: s keeps the side stream, beside the same launch)
+  // ---- operands as limbs: per statement (row stride nbs) and per instance (row stride nb)
+  uint32_t *c1s = nullptr, *c2s = nullptr, *al = nullptr, *bl = nullptr, *xl = nullptr, *yl = nullptr;
+  uint32_t* d_stmt = nullptr;                              // instance -> its statement
+  uint32_t *c1 = nullptr, *c2 = nullptr;                   // ct1, ct2 per instance
+  // ---- values of the call
+  uint32_t *an = nullptr, *xn = nullptr;                   // a^n per statement, x^n per instance (W2 limbs)
+  uint32_t* qs = nullptr;                                  // s per statement (W1 limbs, stride nbs)
+  hipEvent_t inputs_ready = nullptr, an_ready = nullptr, residues_ready = nullptr, plaintext_ready = nullptr;
+  bool by_struct = false;
+  StructBase sbase;
+  int32_t *d_st_stmt = nullptr, *d_st_num = nullptr;
+  uint32_t *bn2 = nullptr, *t3 = nullptr, *san = nullptr, *alp = nullptr;
+  int32_t* d_ok = nullptr;
+  int32_t* chal = nullptr;
+  bool hash_early = false;
+  std::vector<int32_t> hok, hch, hst_stmt, hst_num;
+  // the response, prepared before the bits are known
+  uint32_t *qainv = nullptr, *qani = nullptr;
+  int32_t* d_badinv = nullptr;
+  bool any_badinv = false, sb_units = false, early = false, resp_struct = false, one_ladder = false;
+  const uint8_t* sb_root = nullptr;
+  RespBase rbase;
+  RespExps rexps;
+  uint32_t* en_all = nullptr;
+  int32_t* d_st_rstmt = nullptr;
+  uint32_t *ge_all = nullptr, *es_all[2] = {nullptr, nullptr}, *eb_all[2] = {nullptr, nullptr};
+  PreBases pre;
+  uint32_t *eo = nullptr, *fo = nullptr;                   // E, F of every instance
+
+  ProveCall(const pgpu_seckey* sk_, size_t S_, size_t secpar_, const uint8_t* ct1_, const uint8_t* ct2_, size_t ct_stride_, const uint8_t* a_,
+            const uint8_t* b_, const uint8_t* x_, const uint8_t* y_, size_t n_stride_, uint8_t* alpha_, uint8_t* e_out_, size_t e_stride_,
+            uint8_t* f_out_, int mem_)
+      : sk(sk_), ctx(sk_->ctx), pk(sk_->pk), S(S_), secpar(secpar_), ct1(ct1_), ct2(ct2_), a(a_), b(b_), x(x_), y(y_), ct_stride(ct_stride_),
+        n_stride(n_stride_), alpha(alpha_), e_out(e_out_), f_out(f_out_), e_stride(e_stride_), mem(mem_), mn(pk->mn), mn2(pk->mn2), mn3(*pk->mn3),
+        W1(mn.WT), W2(mn2.WT), W3(mn3.WT),
+        crt3(sk->has_crt2 && sk->c_p3invR >= 0 && 2 * sk->mp3.WT >= W3 && ctx->use_pair), batch(S * secpar), nbs(round_up(S, VM_BLOCK)),
+        nb(round_up(batch, VM_BLOCK)), nt(nbs + nb), N(pk->N), N2(mn2.N), exclusive_call(ctx), side(ctx), base_lane(ctx, 3) {}
+
+  void perlane3(const uint32_t* base, const uint32_t* exps, int we, size_t nbx, uint32_t* outp) {
+    if (crt3) pow_n3_crt(sk, base, W3, exps, we, nullptr, nbx, outp);
+    else perlane_pow(ctx, mn3, base, exps, we, nbx, outp);
+  }
+  void shared3(const uint32_t* base, int wb, const BigU& ex, size_t nbx, uint32_t* outp) {
+    if (crt3) pow_n3_crt(sk, base, wb, nullptr, 0, &ex, nbx, outp);
+    else shared_pow(ctx, mn3, base, wb, ex, nbx, outp);
+  }
+  uint32_t* up(const uint8_t* buf, size_t stride, int w, size_t count, size_t nbx) {
+    uint32_t* l = ctx->ws_t<uint32_t>((size_t)w * nbx);
+    unpack_operand(ctx, buf, stride, stride, count, mem, l, w, nbx);
+    return l;
+  }
+  uint32_t* expand(uint32_t* in, int w) {                  // a per-statement array repeated for the instances of its statement
+    if (secpar == 1) return in;
+    uint32_t* o = ctx->ws_t<uint32_t>((size_t)w * nb);
+    launch_gather(in, nbs, d_stmt, batch, o, nb, w, ctx->stream);
+    return o;
+  }
+
+  void unpack_inputs() {
     if (ct_stride != mn3.nbytes) api_throw(PGPU_ERR_INVALID, "ciphertext stride must be the byte length of n^3");
     if (n_stride * 8 > (size_t)LB * W1 + 7) api_throw(PGPU_ERR_INVALID, "a, b, x, y must fit the width of n");
-    auto up = [&](const uint8_t* buf, size_t stride, int w, size_t count, size_t nbx) {
-      uint32_t* l = ctx->ws_t<uint32_t>((size_t)w * nbx);
-      unpack_operand(ctx, buf, stride, stride, count, mem, l, w, nbx);
-      return l;
-    };
     // per statement (S numbers, row stride nbs) ...
-    uint32_t *c1s = up(ct1, ct_stride, W3, S, nbs), *c2s = up(ct2, ct_stride, W3, S, nbs);
-    uint32_t *al = up(a, n_stride, W1, S, nbs), *bl = up(b, n_stride, W1, S, nbs);
+    c1s = up(ct1, ct_stride, W3, S, nbs);
+    c2s = up(ct2, ct_stride, W3, S, nbs);
+    al = up(a, n_stride, W1, S, nbs);
+    bl = up(b, n_stride, W1, S, nbs);
     // ... and per instance (S * secpar numbers, row stride nb)
-    uint32_t *xl = up(x, n_stride, W1, batch, nb), *yl = up(y, n_stride, W1, batch, nb);
-    uint32_t* d_stmt = nullptr;                              // instance -> its statement
+    xl = up(x, n_stride, W1, batch, nb);
+    yl = up(y, n_stride, W1, batch, nb);
     if (secpar > 1) {
       std::vector<uint32_t> st(batch);
       for (size_t i = 0; i < batch; ++i) st[i] = (uint32_t)(i / secpar);
       d_stmt = ctx->upload_words(st);
     }
-    auto expand = [&](uint32_t* in, int w) {                 // a per-statement array repeated for the instances of its statement
-      if (secpar == 1) return in;
-      uint32_t* o = ctx->ws_t<uint32_t>((size_t)w * nb);
-      launch_gather(in, nbs, d_stmt, batch, o, nb, w, ctx->stream);
-      return o;
-    };
-    uint32_t *c1 = expand(c1s, W3), *c2 = expand(c2s, W3);
-    const BigU &N = pk->N, &N2 = mn2.N;
+    c1 = expand(c1s, W3);
+    c2 = expand(c2s, W3);
     // ---- what depends on the STATEMENT only and on no ladder of this call goes to the side stream, beside the big launches
     // (the GPU was busy, but with ~800 small launches in a row between the ladders: 30 of 188 ms per 16 384 instances):
     //   s = ExtractRandonness(ct1) (ddleq.go:103) for every statement -- a latency-bound launch beside the a^n | x^n
     //   launch, which fills half the chip; then, behind a^n, the inversion tree for a^-1 | (a^n)^-1 and the unit test of s b
     //   beside the Alpha ladders.  Which statements have an instance with challenge bit 1 is not known yet: all are done
     //   (the side work is bound by launch latencies, not by its width).
-    SideStream side(ctx);
+    inputs_ready = side.mark();
+  }
+
+  // ---- sanity check (ddleq.go:62-69): ct1^(a^n mod n^2) * b^(n^2) mod n^3 == ct2, else the reference panics -- once per
+  // statement.  Independent exponentiations of the same shape share a launch (the chip is filled better and, for the half-size
+  // batches of the response, a latency-bound launch is saved outright): a^n (S numbers) | x^n (S secpar numbers), then the
+  // sanity value and alpha -- ct1^(a^n) b^(n^2) | ct1^(x^n) y^(n^2) -- and further down s^(a^n) | s^(x^n).
+  void powers_of_n() {
+    an = ctx->ws_t<uint32_t>((size_t)W2 * nbs);
+    xn = ctx->ws_t<uint32_t>((size_t)W2 * nb);
+    uint32_t* ax = concat_ab(ctx, al, nbs, xl, nb, W1);
+    uint32_t* axn;
+    if (pow_n2_crt_usable(sk)) {
+      axn = pow_n2_crt(sk, ax, N, nbs + nb);               // the prover holds p and q
+    } else {
+      axn = ctx->ws_t<uint32_t>((size_t)W2 * (nbs + nb));
+      shared_pow(ctx, mn2, ax, W1, N, nbs + nb, axn);
+    }
+    split_ab(ctx, axn, nbs, nb, 0, W2, an);
+    split_ab(ctx, axn, nbs, nb, 1, W2, xn);
+    HT("a^n|x^n issued");
+  }
+
+  // The structure path's per-statement part (struct_pow_n3 below) -- the level-two plaintext of ct1 through p^3, q^3 and ct1 modulo
+  // the primes -- depends on the inputs only: it is issued beside the a^n | x^n launch on a lane of its own (s has the side
+  // stream), and runs where wave slots are free: beside that launch at 16 384 instances (one lane per number: one wave per SIMD),
+  // beside the ladders modulo the primes otherwise.
+  // (flag "background", measurements: the side lanes' ladders of a call that fills the chip at wave priority 0 -- a^n | x^n gates
+  // everything behind it, the plaintext of ct1 is needed after the lifts, s after the hash.  Measured with the main launch spread over
+  // the CUs (run_vm): 16 384 instances 130.4 ms without, 132.6 +- 4 with -- what a^n | x^n gains, the ladder modulo the primes and the
+  // lifts lose to the side launches that are still running beside them; secpar 40 the same within noise.  Off by default.)
+  void structure_base() {
+    by_struct = crt3 && struct_pow_usable(sk);
+    if (!by_struct) return;
+    Background bg(ctx, ctx->use_background);
+    d_st_stmt = ctx->ws_t<int32_t>(nbs);
+    d_st_num = ctx->ws_t<int32_t>(nt);
+    base_lane.enter(inputs_ready);
+    HIPCHK(hipMemsetAsync(d_st_stmt, 0, nbs * 4, ctx->stream));
+    HIPCHK(hipMemsetAsync(d_st_num, 0, nt * 4, ctx->stream));
+    struct_base_residues(sk, c1s, nbs, sbase);
+    if (base_lane.on) {
+      residues_ready = ctx->next_sync_ev();
+      HIPCHK(hipEventRecord(residues_ready, ctx->stream));
+    }
+    struct_base_plaintext(sk, c1s, nbs, S, d_st_stmt, sbase);
+    if (base_lane.on) {
+      plaintext_ready = ctx->next_sync_ev();
+      HIPCHK(hipEventRecord(plaintext_ready, ctx->stream));
+    }
+    base_lane.leave();
+  }
+
+  // s = ExtractRandonness(ct1) at level two (operations.go:75-91): z = G^(-v) ct1 mod n^3 with v = Decrypt(ct1)
+  // (operations.go:81-86) is only ever used modulo n (:88), and G^v = (1 + n)^v = 1 (mod n) whatever v is (the prover
+  // requires G = n + 1): z = ct1 (mod n).  No decryption, no G^v, no inversion modulo n^3 -- the same s.
+  void extract_randomness() {
     BigU ns_inv;
     if (!hostbig::modinv(N2 % sk->lambda, sk->lambda, ns_inv)) api_throw(PGPU_ERR_NOT_INVERTIBLE, "n^2 is not invertible mod lambda");
-    uint32_t* qs = nullptr;                                  // s per statement (W1 limbs, stride nbs)
-    hipEvent_t inputs_ready = side.mark();
-    // ---- sanity check (ddleq.go:62-69): ct1^(a^n mod n^2) * b^(n^2) mod n^3 == ct2, else the reference panics -- once per
-    // statement.  Independent exponentiations of the same shape share a launch (the chip is filled better and, for the half-size
-    // batches of the response, a latency-bound launch is saved outright): a^n (S numbers) | x^n (S secpar numbers), then the
-    // sanity value and alpha -- ct1^(a^n) b^(n^2) | ct1^(x^n) y^(n^2) -- and further down s^(a^n) | s^(x^n).
-    uint32_t* an = ctx->ws_t<uint32_t>((size_t)W2 * nbs);
-    uint32_t* xn = ctx->ws_t<uint32_t>((size_t)W2 * nb);
-    {
-      uint32_t* ax = concat_ab(ctx, al, nbs, xl, nb, W1);
-      uint32_t* axn;
-      if (pow_n2_crt_usable(sk)) {
-        axn = pow_n2_crt(sk, ax, N, nbs + nb);               // the prover holds p and q
-      } else {
-        axn = ctx->ws_t<uint32_t>((size_t)W2 * (nbs + nb));
-        shared_pow(ctx, mn2, ax, W1, N, nbs + nb, axn);
-      }
-      split_ab(ctx, axn, nbs, nb, 0, W2, an);
-      split_ab(ctx, axn, nbs, nb, 1, W2, xn);
-      HT("a^n|x^n issued");
-    }
     // Beside the a^n | x^n launch only where that launch leaves the second wave slot of the SIMDs free (one wave per SIMD or
     // less: 16 384 instances at secpar 1): a launch that fills both slots would lose one of them on half the chip to the side
     // launch for its whole length (measured at 32 768 instances: 48 -> 76 ms for 8 ms hidden).  Then s follows on the main stream.
     // (A side launch of a few dozen waves -- the statements of a secpar-40 call -- costs the big launch next to nothing.)
     const bool s_beside = plan::extract_beside(nbs, nb, plan::lanes_target(ctx->lanes_wanted, ctx->stream_cus));
-    // The structure path's per-statement part (struct_pow_n3 below) -- the level-two plaintext of ct1 through p^3, q^3 and ct1 modulo
-    // the primes -- depends on the inputs only: it is issued beside the a^n | x^n launch on a lane of its own (s has the side
-    // stream), and runs where wave slots are free: beside that launch at 16 384 instances (one lane per number: one wave per SIMD),
-    // beside the ladders modulo the primes otherwise.
-    const size_t nt = nbs + nb;
-    int32_t *d_st_stmt = nullptr, *d_st_num = nullptr;
-    const bool by_struct = crt3 && struct_pow_usable(sk);
-    StructBase sbase;
-    SideStream base_lane(ctx, 3);      // (a lane of its own: s keeps the side stream, beside the same launch)
-    hipEvent_t residues_ready = nullptr, plaintext_ready = nullptr;
-    // (flag "background", measurements: the side lanes' ladders of a call that fills the chip at wave priority 0 -- a^n | x^n gates
-    // everything behind it, the plaintext of ct1 is needed after the lifts, s after the hash.  Measured with the main launch spread over
-    // the CUs (run_vm): 16 384 instances 130.4 ms without, 132.6 +- 4 with -- what a^n | x^n gains, the ladder modulo the primes and the
-    // lifts lose to the side launches that are still running beside them; secpar 40 the same within noise.  Off by default.)
-    const bool side_yields = ctx->use_background;
-    struct Background {
-      pgpu_ctx* c; bool on;
-      Background(pgpu_ctx* c_, bool on_) : c(c_), on(on_) { if (on) c->background_launch = true; }
-      ~Background() { if (on) c->background_launch = false; }
-    };
-    if (by_struct) {
-      Background bg(ctx, side_yields);
-      d_st_stmt = ctx->ws_t<int32_t>(nbs);
-      d_st_num = ctx->ws_t<int32_t>(nt);
-      base_lane.enter(inputs_ready);
-      HIPCHK(hipMemsetAsync(d_st_stmt, 0, nbs * 4, ctx->stream));
-      HIPCHK(hipMemsetAsync(d_st_num, 0, nt * 4, ctx->stream));
-      struct_base_residues(sk, c1s, nbs, sbase);
-      if (base_lane.on) {
-        residues_ready = ctx->next_sync_ev();
-        HIPCHK(hipEventRecord(residues_ready, ctx->stream));
-      }
-      struct_base_plaintext(sk, c1s, nbs, S, d_st_stmt, sbase);
-      if (base_lane.on) {
-        plaintext_ready = ctx->next_sync_ev();
-        HIPCHK(hipEventRecord(plaintext_ready, ctx->stream));
-      }
-      base_lane.leave();
-    }
     if (s_beside) side.enter(inputs_ready);
     {
-      Background bg(ctx, side_yields && s_beside);
-      // s = ExtractRandonness(ct1) at level two (operations.go:75-91): z = G^(-v) ct1 mod n^3 with v = Decrypt(ct1)
-      // (operations.go:81-86) is only ever used modulo n (:88), and G^v = (1 + n)^v = 1 (mod n) whatever v is (the prover
-      // requires G = n + 1): z = ct1 (mod n).  No decryption, no G^v, no inversion modulo n^3 -- the same s.
+      Background bg(ctx, ctx->use_background && s_beside);
       uint32_t* z2 = ctx->ws_t<uint32_t>((size_t)W2 * nbs);
       reduce_mod(ctx, mn2, c1s, W3, z2, nbs);
       if (sk->has_crt && sk->mp.WT * 2 == W1) {                                // z^nsInv mod n through p and q
@@ -1425,25 +1488,37 @@ static void ddleq_prove_impl(const pgpu_seckey* sk, size_t S, size_t secpar, con
     }
     if (s_beside) side.leave();
     HT("s issued");
-    hipEvent_t an_ready = side.mark();
-    uint32_t* bn2 = ctx->ws_t<uint32_t>((size_t)W3 * nbs);
-    uint32_t* t3 = ctx->ws_t<uint32_t>((size_t)W3 * nb);
-    uint32_t* san = ctx->ws_t<uint32_t>((size_t)W3 * nbs);
-    uint32_t* alp = ctx->ws_t<uint32_t>((size_t)W3 * nb);
-    // ct1^(a^n) * b^(n^2) and ct1^(x^n) * y^(n^2), both batches (S statements | S secpar instances) in the same launches
-    auto literal_ladders = [&] {
-      // one interleaved ladder per number and CRT half on ct1 itself (pow_n3_crt: the p-adic split for batches that fill the chip)
-      uint32_t* cc2 = concat_ab(ctx, c1s, nbs, c1, nb, W3);
-      uint32_t* ee2 = concat_ab(ctx, an, nbs, xn, nb, W2);
-      uint32_t* by2 = concat_ab(ctx, bl, nbs, yl, nb, W1);
-      uint32_t* o2 = ctx->ws_t<uint32_t>((size_t)W3 * nt);
-      pow_n3_crt(sk, cc2, W3, ee2, W2, &N2, nt, o2, by2, W1);
-      split_ab(ctx, o2, nbs, nb, 0, W3, san);
-      split_ab(ctx, o2, nbs, nb, 1, W3, alp);
-    };
+    an_ready = side.mark();
+  }
+
+  // one interleaved ladder per number and CRT half on ct1 itself (pow_n3_crt: the p-adic split for batches that fill the chip)
+  void literal_ladders() {
+    uint32_t* cc2 = concat_ab(ctx, c1s, nbs, c1, nb, W3);
+    uint32_t* ee2 = concat_ab(ctx, an, nbs, xn, nb, W2);
+    uint32_t* by2 = concat_ab(ctx, bl, nbs, yl, nb, W1);
+    uint32_t* o2 = ctx->ws_t<uint32_t>((size_t)W3 * nt);
+    pow_n3_crt(sk, cc2, W3, ee2, W2, &N2, nt, o2, by2, W1);
+    split_ab(ctx, o2, nbs, nb, 0, W3, san);
+    split_ab(ctx, o2, nbs, nb, 1, W3, alp);
+  }
+
+  // ---- challenge bit = LSB SHA-256(ct2 || x || y || alpha)  (ddleq.go:91; ct1 is skipped: random_oracle.go:24-26)
+  void hash_bits() {
+    const uint32_t* parts[4] = {c2, xl, yl, alp};
+    const int widths[4] = {W3, W1, W1, W3};
+    HIPCHK(hipMemsetAsync(chal, 0, nb * 4, ctx->stream));
+    launch_sha256_transcript(parts, widths, 4, nb, batch, nullptr, chal, ctx->stream);
+  }
+
+  // ct1^(a^n) * b^(n^2) and ct1^(x^n) * y^(n^2), both batches (S statements | S secpar instances) in the same launches
+  void sanity_and_alpha() {
+    bn2 = ctx->ws_t<uint32_t>((size_t)W3 * nbs);
+    t3 = ctx->ws_t<uint32_t>((size_t)W3 * nb);
+    san = ctx->ws_t<uint32_t>((size_t)W3 * nbs);
+    alp = ctx->ws_t<uint32_t>((size_t)W3 * nb);
     // Through the structure of the unit group where the key serves it (struct_pow_n3): ct1's plaintext once per statement, then per
     // number a ladder modulo the primes and ONE lift modulo p^3, q^3.  Lanes that meet a non-unit are flagged; if a REAL lane is
-    // (never for honest inputs) the literal ladders redo the launch after the host has seen the flags (below).
+    // (never for honest inputs) the literal ladders redo the launch after the host has seen the flags (read_back).
     if (by_struct) {
       // the main stream waits for ct1 modulo the primes only; the decryption (a latency-bound launch when the statements are few) goes
       // on beside the ladders modulo the primes, and the lane of the closed form waits for it
@@ -1467,38 +1542,59 @@ static void ddleq_prove_impl(const pgpu_seckey* sk, size_t S, size_t secpar, con
       perlane3(c1s, an, W2, nbs, t3);
       modmul_arrays(ctx, mn3, t3, bn2, nbs, san);
     }
-    int32_t* d_ok = ctx->ws_t<int32_t>(nbs);
+    d_ok = ctx->ws_t<int32_t>(nbs);
     launch_equal(san, c2s, W3, nbs, S, d_ok, ctx->stream);
-    std::vector<int32_t> hok(S);
-    // ---- challenge bit = LSB SHA-256(ct2 || x || y || alpha)  (ddleq.go:91; ct1 is skipped: random_oracle.go:24-26).  With the CRT
-    // path Alpha is on the main stream by now: the hash follows it at once -- the host is about to wait inside the side section (the
-    // inversion tree inverts its root on the host) and would otherwise launch the hash only after that: 8 of 133 ms at 16 384 instances.
-    // The sanity flags are read together with the bits; a failed check discards them.
-    int32_t* chal = ctx->ws_t<int32_t>(nb);
-    const uint32_t* parts[4] = {c2, xl, yl, alp};
-    const int widths[4] = {W3, W1, W1, W3};
-    auto hash_bits = [&] {
-      HIPCHK(hipMemsetAsync(chal, 0, nb * 4, ctx->stream));
-      launch_sha256_transcript(parts, widths, 4, nb, batch, nullptr, chal, ctx->stream);
-    };
-    const bool hash_early = crt3;
+    hok.resize(S);
+    // With the CRT path Alpha is on the main stream by now: the hash follows it at once -- the host is about to wait inside the side
+    // section (the inversion tree inverts its root on the host) and would otherwise launch the hash only after that: 8 of 133 ms at
+    // 16 384 instances.  The sanity flags are read together with the bits; a failed check discards them.
+    chal = ctx->ws_t<int32_t>(nb);
+    hash_early = crt3;
     if (hash_early) hash_bits();
-    std::vector<int32_t> hch(batch);
-    // ---- side stream, behind a^n (the Alpha ladders above are in flight on the main stream): a^-1 and (a^n)^-1 modulo n^2 for
-    // every statement from ONE inversion tree (both batches side by side; a non-unit is flagged per lane and matters only if
-    // one of its instances draws challenge bit 1), and the unit test of s b for the one-ladder form of the response
-    uint32_t *qainv = ctx->ws_t<uint32_t>((size_t)W2 * nbs), *qani = ctx->ws_t<uint32_t>((size_t)W2 * nbs);
-    int32_t* d_badinv = ctx->ws_t<int32_t>(2 * nbs);
-    bool any_badinv = false, sb_units = false, early = false, resp_struct = false;
-    const uint8_t* sb_root = nullptr;
-    RespBase rbase;
-    RespExps rexps;
-    uint32_t* en_all = nullptr;
-    int32_t* d_st_rstmt = nullptr;
-    uint32_t *ge_all = nullptr, *es_all[2] = {nullptr, nullptr}, *eb_all[2] = {nullptr, nullptr};
-    PreBases pre;
-    const bool one_ladder = crt3 && ctx->use_lift && sk->eo_p.ok && sk->eo_q.ok && sk->eo_p.w == sk->eo_q.w &&
-                            W2 <= 2 * sk->eo_p.modd.WT && W2 <= 2 * sk->eo_q.modd.WT;
+    hch.resize(batch);
+  }
+
+  // the two exponents of the one-ladder response modulo the group orders of p^3 and q^3 (ord = 2^t m: the odd part through a Montgomery
+  // product modulo m, the 2-part from the lowest limbs, then the CRT lift) for `nbx` numbers: es = xn - an en, eb = -en
+  void response_exponents(const uint32_t* gxn, const uint32_t* gan, const uint32_t* en, size_t nbx, const uint32_t* es[2], const uint32_t* eb[2]) {
+    uint32_t* ls = ctx->ws_t<uint32_t>(nbx);
+    uint32_t* lb = ctx->ws_t<uint32_t>(nbx);
+    launch_exp_low_combine(gxn, gan, en, ls, lb, nbx, ctx->stream);
+    Fork fo_(ctx);                                                     // the exponents modulo the two group orders side by side
+    for (int half = 0; half < 2; ++half) {
+      fo_.chain(half);
+      const ExpOrder& eo_ = half ? sk->eo_q : sk->eo_p;
+      const ModCtx& mm = eo_.modd;
+      const size_t sm = (size_t)mm.WT * nbx;
+      uint32_t *am = ctx->ws_t<uint32_t>(sm), *em_ = ctx->ws_t<uint32_t>(sm), *xm = ctx->ws_t<uint32_t>(sm),
+               *pm = ctx->ws_t<uint32_t>(sm), *esm = ctx->ws_t<uint32_t>(sm), *ebm = ctx->ws_t<uint32_t>(sm),
+               *zero = ctx->ws_t<uint32_t>(sm);
+      HIPCHK(hipMemsetAsync(zero, 0, sm * 4, ctx->stream));
+      reduce_mod(ctx, mm, gan, W2, am, nbx);
+      reduce_mod(ctx, mm, en, W2, em_, nbx);
+      reduce_mod(ctx, mm, gxn, W2, xm, nbx);
+      modmul_arrays(ctx, mm, am, em_, nbx, pm);                                         // an en mod m
+      launch_sub_mod(xm, pm, mm.d_nmod, esm, mm.WT, nbx, ctx->stream);                   // xn - an en mod m
+      launch_sub_mod(zero, em_, mm.d_nmod, ebm, mm.WT, nbx, ctx->stream);                // -en mod m
+      uint32_t* e1 = ctx->ws_t<uint32_t>((size_t)eo_.w * nbx);
+      uint32_t* e2 = ctx->ws_t<uint32_t>((size_t)eo_.w * nbx);
+      launch_exp_order_lift(ls, 1, esm, mm.WT, eo_.m_limbs.d, eo_.t, eo_.minv, e1, eo_.w, nbx, ctx->stream);
+      launch_exp_order_lift(lb, 1, ebm, mm.WT, eo_.m_limbs.d, eo_.t, eo_.minv, e2, eo_.w, nbx, ctx->stream);
+      es[half] = e1;
+      eb[half] = e2;
+    }
+    fo_.join();
+  }
+
+  // ---- side stream, behind a^n (the Alpha ladders are in flight on the main stream): a^-1 and (a^n)^-1 modulo n^2 for
+  // every statement from ONE inversion tree (both batches side by side; a non-unit is flagged per lane and matters only if
+  // one of its instances draws challenge bit 1), and the unit test of s b for the one-ladder form of the response
+  void statement_side_work() {
+    qainv = ctx->ws_t<uint32_t>((size_t)W2 * nbs);
+    qani = ctx->ws_t<uint32_t>((size_t)W2 * nbs);
+    d_badinv = ctx->ws_t<int32_t>(2 * nbs);
+    one_ladder = crt3 && ctx->use_lift && sk->eo_p.ok && sk->eo_q.ok && sk->eo_p.w == sk->eo_q.w && W2 <= 2 * sk->eo_p.modd.WT &&
+                 W2 <= 2 * sk->eo_q.modd.WT;
     side.enter(an_ready);
     {
       uint32_t* a1 = ctx->ws_t<uint32_t>((size_t)W1 * nbs);
@@ -1517,7 +1613,7 @@ static void ddleq_prove_impl(const pgpu_seckey* sk, size_t S, size_t secpar, con
         // (no wait: the root of the product tree goes to pinned memory and is looked at once the hash is known -- the side lane
         // crawls beside the lifts, and a host that waits for it here issues the response's preparation 35 ms late)
         sb_root = all_units_begin(ctx, mn, sb, nbs, S);
-        sb_units = true;                                     // assumed; checked below, before anything uses the prepared response
+        sb_units = true;                                     // assumed; checked in read_back, before anything uses the prepared response
         HT("unit test");
       }
       // The response's per-statement bases (s, b: residues modulo p^3, q^3, p^2, q^2 and digit forms) and, for EVERY instance, its
@@ -1557,42 +1653,24 @@ static void ddleq_prove_impl(const pgpu_seckey* sk, size_t S, size_t secpar, con
           resp_exps(sk, xn, gan_a, en_a, nb, rexps);
           HT("resp_exps issued");
         } else {
-        uint32_t* ls = ctx->ws_t<uint32_t>(nb);
-        uint32_t* lb = ctx->ws_t<uint32_t>(nb);
-        launch_exp_low_combine(xn, gan_a, en_a, ls, lb, nb, ctx->stream);
-        Fork fo(ctx);
-        for (int half = 0; half < 2; ++half) {
-          fo.chain(half);
-          const ExpOrder& eo_ = half ? sk->eo_q : sk->eo_p;
-          const ModCtx& mm = eo_.modd;
-          const size_t sm = (size_t)mm.WT * nb;
-          uint32_t *am = ctx->ws_t<uint32_t>(sm), *em_ = ctx->ws_t<uint32_t>(sm), *xm = ctx->ws_t<uint32_t>(sm),
-                   *pm = ctx->ws_t<uint32_t>(sm), *esm = ctx->ws_t<uint32_t>(sm), *ebm = ctx->ws_t<uint32_t>(sm),
-                   *zero = ctx->ws_t<uint32_t>(sm);
-          HIPCHK(hipMemsetAsync(zero, 0, sm * 4, ctx->stream));
-          reduce_mod(ctx, mm, gan_a, W2, am, nb);
-          reduce_mod(ctx, mm, en_a, W2, em_, nb);
-          reduce_mod(ctx, mm, xn, W2, xm, nb);
-          modmul_arrays(ctx, mm, am, em_, nb, pm);                                         // an en mod m
-          launch_sub_mod(xm, pm, mm.d_nmod, esm, mm.WT, nb, ctx->stream);                   // xn - an en mod m
-          launch_sub_mod(zero, em_, mm.d_nmod, ebm, mm.WT, nb, ctx->stream);                // -en mod m
-          uint32_t* e1 = ctx->ws_t<uint32_t>((size_t)eo_.w * nb);
-          uint32_t* e2 = ctx->ws_t<uint32_t>((size_t)eo_.w * nb);
-          launch_exp_order_lift(ls, 1, esm, mm.WT, eo_.m_limbs.d, eo_.t, eo_.minv, e1, eo_.w, nb, ctx->stream);
-          launch_exp_order_lift(lb, 1, ebm, mm.WT, eo_.m_limbs.d, eo_.t, eo_.minv, e2, eo_.w, nb, ctx->stream);
-          es_all[half] = e1;
-          eb_all[half] = e2;
-        }
-        fo.join();
-        pre_bases(sk, zext(ctx, qs, W1, W3, nbs), zext(ctx, bl, W1, W3, nbs), nbs, pre);
+          const uint32_t *es[2], *eb[2];
+          response_exponents(xn, gan_a, en_a, nb, es, eb);
+          for (int half = 0; half < 2; ++half) {
+            es_all[half] = const_cast<uint32_t*>(es[half]);
+            eb_all[half] = const_cast<uint32_t*>(eb[half]);
+          }
+          pre_bases(sk, zext(ctx, qs, W1, W3, nbs), zext(ctx, bl, W1, W3, nbs), nbs, pre);
         }
       }
     }
     side.leave();
+  }
+
+  // the host learns the sanity flags, the unit flags of the structure path and the challenge bits
+  void read_back() {
     // (a device-to-host copy into pageable memory holds the host until the stream has got there: it comes after the side work
     // has been issued, not before)
     HIPCHK(hipMemcpyAsync(hok.data(), d_ok, S * 4, hipMemcpyDeviceToHost, ctx->stream));
-    std::vector<int32_t> hst_stmt, hst_num;
     if (by_struct) {
       hst_stmt.resize(S);
       hst_num.resize(nt);
@@ -1641,9 +1719,13 @@ static void ddleq_prove_impl(const pgpu_seckey* sk, size_t S, size_t secpar, con
       if (!sb_units) early = resp_struct = false;
     }
     HT("hash known");
+  }
+
+  // the instances with challenge bit 1 (ddleq.go:93-115): e = x a^-1, f = y c
+  void respond() {
     // default outputs: e = x, f = y (chalBit false)
-    uint32_t* eo = zext(ctx, xl, W1, W2, nb);
-    uint32_t* fo = zext(ctx, yl, W1, W3, nb);
+    eo = zext(ctx, xl, W1, W2, nb);
+    fo = zext(ctx, yl, W1, W3, nb);
     // instances with challenge bit 1 and the statement each belongs to
     std::vector<uint32_t> idx, sti;
     for (size_t i = 0; i < batch; ++i)
@@ -1651,159 +1733,122 @@ static void ddleq_prove_impl(const pgpu_seckey* sk, size_t S, size_t secpar, con
         idx.push_back((uint32_t)i);
         sti.push_back((uint32_t)(i / secpar));
       }
-    if (!idx.empty()) {
-      const size_t cnt = idx.size(), nbg = round_up(cnt, VM_BLOCK);
-      if (getenv("PGPU_PROFILE_DUMP")) fprintf(stderr, "[pgpu] prove: %zu of %zu instances drew challenge bit 1 (response batch %zu)\n", cnt, batch, nbg);
-      if (any_badinv) {      // ModInverse(a, n^2) of a non-unit a (ddleq.go:95) is undefined in the reference: refuse, as before
-        std::vector<int32_t> hb(2 * nbs);
-        HIPCHK(hipMemcpyAsync(hb.data(), d_badinv, 2 * nbs * 4, hipMemcpyDeviceToHost, ctx->stream));
-        HIPCHK(hipStreamSynchronize(ctx->stream));
-        for (uint32_t st : sti)
-          if (hb[st] || hb[nbs + st])
-            api_throw(PGPU_ERR_NOT_INVERTIBLE, "ModInverse: an element of the batch is not invertible modulo the modulus");
-      }
-      HT("bits sorted");
-      uint32_t* d_idx = ctx->upload_words(idx);
-      uint32_t* d_sti = ctx->upload_words(sti);
-      HT("idx uploaded");
-      auto gat = [&](const uint32_t* in, int w) {            // per-instance array -> the compacted instances
-        uint32_t* o = ctx->ws_t<uint32_t>((size_t)w * nbg);
-        launch_gather(in, nb, d_idx, cnt, o, nbg, w, ctx->stream);
-        return o;
-      };
-      auto per_inst = [&](const uint32_t* in, int w) {       // per-statement array -> one entry per compacted instance
-        uint32_t* o = ctx->ws_t<uint32_t>((size_t)w * nbg);
-        launch_gather(in, nbs, d_sti, cnt, o, nbg, w, ctx->stream);
-        return o;
-      };
-      bool done = false;
-      if (resp_struct) {
-        // through the structure of the unit group: gather the prepared exponents of the bit-1 instances; one ladder modulo the primes, one lift
-        uint32_t* ge = gat(ge_all, W2);
-        const uint32_t* e1p[2] = {gat(rexps.e1p[0], sk->eo1_p.w), gat(rexps.e1p[1], sk->eo1_q.w)};
-        const uint32_t* e2p[2] = {gat(rexps.e2p[0], sk->eo1_p.w), gat(rexps.e2p[1], sk->eo1_q.w)};
-        int32_t* d_st_r = ctx->ws_t<int32_t>(nbg);
-        HIPCHK(hipMemsetAsync(d_st_r, 0, nbg * 4, ctx->stream));
-        std::vector<uint32_t> sti_pad(sti);
-        sti_pad.resize(nbg, 0);                                            // (padding lanes: statement 0's bases)
-        uint32_t* c5 = ctx->ws_t<uint32_t>((size_t)W3 * nbg);
-        struct_response(sk, rbase, ctx->upload_words(sti_pad), gat(rexps.e1n, W2), gat(en_all, W2), e1p, e2p, nbg, c5, d_st_r);
-        HT("response issued");
-        std::vector<int32_t> hr(cnt), hs(S);
-        HIPCHK(hipMemcpyAsync(hr.data(), d_st_r, cnt * 4, hipMemcpyDeviceToHost, ctx->stream));
-        HIPCHK(hipMemcpyAsync(hs.data(), d_st_rstmt, S * 4, hipMemcpyDeviceToHost, ctx->stream));
-        HIPCHK(hipStreamSynchronize(ctx->stream));
-        bool nonunit = false;
-        for (size_t i = 0; i < cnt; ++i) nonunit = nonunit || hr[i] || hs[sti[i]];
-        if (!nonunit) {
-          uint32_t* y3 = zext(ctx, gat(yl, W1), W1, W3, nbg);
-          uint32_t* gf = ctx->ws_t<uint32_t>((size_t)W3 * nbg);
-          modmul_arrays(ctx, mn3, y3, c5, nbg, gf);                           // f = y c mod n^3 (ddleq.go:114)
-          launch_scatter(ge, nbg, d_idx, cnt, eo, nb, W2, ctx->stream);
-          launch_scatter(gf, nbg, d_idx, cnt, fo, nb, W3, ctx->stream);
-          done = true;
-        }
-      }
-      if (!done && early) {
-        done = true;
-        // everything but the ladder itself is at hand (side stream, above): gather it for the instances with bit 1
-        uint32_t* ge = gat(ge_all, W2);
-        const uint32_t* es[2] = {gat(es_all[0], sk->eo_p.w), gat(es_all[1], sk->eo_q.w)};
-        const uint32_t* eb[2] = {gat(eb_all[0], sk->eo_p.w), gat(eb_all[1], sk->eo_q.w)};
-        pre.sti = d_sti;
-        pre.cnt = cnt;
-        uint32_t* c5 = ctx->ws_t<uint32_t>((size_t)W3 * nbg);
-        HT("gathers issued");
-        if (!pow_n3_crt_two(sk, nullptr, es, nullptr, eb, nbg, c5, &pre)) api_throw(PGPU_ERR_UNSUPPORTED, "internal: the early response path lost its kernel");
-        HT("response issued");
-        uint32_t* y3 = zext(ctx, gat(yl, W1), W1, W3, nbg);
-        uint32_t* gf = ctx->ws_t<uint32_t>((size_t)W3 * nbg);
-        modmul_arrays(ctx, mn3, y3, c5, nbg, gf);                             // f = y c mod n^3 (ddleq.go:114)
-        launch_scatter(ge, nbg, d_idx, cnt, eo, nb, W2, ctx->stream);
-        launch_scatter(gf, nbg, d_idx, cnt, fo, nb, W3, ctx->stream);
-      }
-      if (!done) {
-      uint32_t *gx = gat(xl, W1), *gy = gat(yl, W1), *gxn = gat(xn, W2);
-      uint32_t *ainv = per_inst(qainv, W2), *ani = per_inst(qani, W2), *gan = per_inst(an, W2), *sres = per_inst(qs, W1),
-               *gb = per_inst(bl, W1);
-      // e = x * a^-1 mod n^2 (ddleq.go:94-99)
-      uint32_t* x2 = zext(ctx, gx, W1, W2, nbg);
-      uint32_t* ge = ctx->ws_t<uint32_t>((size_t)W2 * nbg);
-      modmul_arrays(ctx, mn2, x2, ainv, nbg, ge);
-      uint32_t* s3 = zext(ctx, sres, W1, W3, nbg);
-      // c = ((s^an * b)^en)^-1 * s^xn ; f = y * c mod n^3   (ddleq.go:103-114)
-      // en = e^n mod n^2 (ddleq.go:104) = (x a^-1)^n = x^n (a^n)^-1: both powers are at hand, so an inversion replaces the ladder
-      uint32_t* en = ctx->ws_t<uint32_t>((size_t)W2 * nbg);
-      modmul_arrays(ctx, mn2, gxn, ani, nbg, en);
-      uint32_t* c5 = nullptr;
-      if (one_ladder) {
-        // c = ((s^an b)^en)^-1 s^xn = s^(xn - an en) b^(-en)  (ddleq.go:107-112) whenever s and b are units: ONE interleaved
-        // ladder with two per-number exponents, computed modulo the group orders of p^3 and q^3 (ord = 2^t m: the odd part
-        // through a Montgomery product modulo m, the 2-part from the lowest limbs, then the CRT lift), instead of the ladders
-        // s^an | s^xn, (.)^en and a batch inversion modulo n^3.  A non-unit s or b (the reference's ModInverse is then
-        // undefined) keeps the literal sequence below and its error.  (The unit test ran per statement, on the side stream.)
-        if (sb_units) {
-          const uint32_t *es[2], *eb[2];
-          uint32_t* ls = ctx->ws_t<uint32_t>(nbg);
-          uint32_t* lb = ctx->ws_t<uint32_t>(nbg);
-          launch_exp_low_combine(gxn, gan, en, ls, lb, nbg, ctx->stream);
-          Fork fo(ctx);                                                  // the exponents modulo the two group orders side by side
-          for (int half = 0; half < 2; ++half) {
-            fo.chain(half);
-            const ExpOrder& eo_ = half ? sk->eo_q : sk->eo_p;
-            const ModCtx& mm = eo_.modd;
-            const size_t sm = (size_t)mm.WT * nbg;
-            uint32_t *am = ctx->ws_t<uint32_t>(sm), *em_ = ctx->ws_t<uint32_t>(sm), *xm = ctx->ws_t<uint32_t>(sm),
-                     *pm = ctx->ws_t<uint32_t>(sm), *esm = ctx->ws_t<uint32_t>(sm), *ebm = ctx->ws_t<uint32_t>(sm),
-                     *zero = ctx->ws_t<uint32_t>(sm);
-            HIPCHK(hipMemsetAsync(zero, 0, sm * 4, ctx->stream));
-            reduce_mod(ctx, mm, gan, W2, am, nbg);
-            reduce_mod(ctx, mm, en, W2, em_, nbg);
-            reduce_mod(ctx, mm, gxn, W2, xm, nbg);
-            modmul_arrays(ctx, mm, am, em_, nbg, pm);                                       // an en mod m
-            launch_sub_mod(xm, pm, mm.d_nmod, esm, mm.WT, nbg, ctx->stream);                 // xn - an en mod m
-            launch_sub_mod(zero, em_, mm.d_nmod, ebm, mm.WT, nbg, ctx->stream);              // -en mod m
-            uint32_t* e1 = ctx->ws_t<uint32_t>((size_t)eo_.w * nbg);
-            uint32_t* e2 = ctx->ws_t<uint32_t>((size_t)eo_.w * nbg);
-            launch_exp_order_lift(ls, 1, esm, mm.WT, eo_.m_limbs.d, eo_.t, eo_.minv, e1, eo_.w, nbg, ctx->stream);
-            launch_exp_order_lift(lb, 1, ebm, mm.WT, eo_.m_limbs.d, eo_.t, eo_.minv, e2, eo_.w, nbg, ctx->stream);
-            es[half] = e1;
-            eb[half] = e2;
-          }
-          fo.join();
-          uint32_t* b3n = zext(ctx, gb, W1, W3, nbg);
-          uint32_t* o = ctx->ws_t<uint32_t>((size_t)W3 * nbg);
-          if (pow_n3_crt_two(sk, s3, es, b3n, eb, nbg, o)) c5 = o;
-        }
-      }
-      uint32_t* cc = ctx->ws_t<uint32_t>((size_t)W3 * nbg);
-      uint32_t* sx = ctx->ws_t<uint32_t>((size_t)W3 * nbg);
-      if (!c5) {
-        // s^(a^n) and s^(x^n) (ddleq.go:107,112): same base, independent exponents -> one launch
-        uint32_t* ss2 = concat2(ctx, s3, s3, W3, nbg);
-        uint32_t* ee2 = concat2(ctx, gan, gxn, W2, nbg);
-        uint32_t* o2 = ctx->ws_t<uint32_t>((size_t)W3 * 2 * nbg);
-        perlane3(ss2, ee2, W2, 2 * nbg, o2);
-        split2(ctx, o2, 0, W3, nbg, cc);
-        split2(ctx, o2, 1, W3, nbg, sx);
-      }
-      if (!c5) {
-        uint32_t* b3 = zext(ctx, gb, W1, W3, nbg);
-        uint32_t* cb = ctx->ws_t<uint32_t>((size_t)W3 * nbg);
-        modmul_arrays(ctx, mn3, cc, b3, nbg, cb);
-        perlane3(cb, en, W2, nbg, cc);
-        launch_restride(cc, nbg, cnt, mn3.d_consts + (size_t)C_ONE * W3, cc, nbg, W3, ctx->stream);
-        uint32_t* ci = batch_inverse(ctx, mn3, cc, nbg, cnt);
-        c5 = ctx->ws_t<uint32_t>((size_t)W3 * nbg);
-        modmul_arrays(ctx, mn3, ci, sx, nbg, c5);
-      }
+    if (idx.empty()) return;
+    const size_t cnt = idx.size(), nbg = round_up(cnt, VM_BLOCK);
+    if (getenv("PGPU_PROFILE_DUMP")) fprintf(stderr, "[pgpu] prove: %zu of %zu instances drew challenge bit 1 (response batch %zu)\n", cnt, batch, nbg);
+    if (any_badinv) {      // ModInverse(a, n^2) of a non-unit a (ddleq.go:95) is undefined in the reference: refuse, as before
+      std::vector<int32_t> hb(2 * nbs);
+      HIPCHK(hipMemcpyAsync(hb.data(), d_badinv, 2 * nbs * 4, hipMemcpyDeviceToHost, ctx->stream));
+      HIPCHK(hipStreamSynchronize(ctx->stream));
+      for (uint32_t st : sti)
+        if (hb[st] || hb[nbs + st])
+          api_throw(PGPU_ERR_NOT_INVERTIBLE, "ModInverse: an element of the batch is not invertible modulo the modulus");
+    }
+    HT("bits sorted");
+    uint32_t* d_idx = ctx->upload_words(idx);
+    uint32_t* d_sti = ctx->upload_words(sti);
+    HT("idx uploaded");
+    auto gat = [&](const uint32_t* in, int w) {            // per-instance array -> the compacted instances
+      uint32_t* o = ctx->ws_t<uint32_t>((size_t)w * nbg);
+      launch_gather(in, nb, d_idx, cnt, o, nbg, w, ctx->stream);
+      return o;
+    };
+    auto per_inst = [&](const uint32_t* in, int w) {       // per-statement array -> one entry per compacted instance
+      uint32_t* o = ctx->ws_t<uint32_t>((size_t)w * nbg);
+      launch_gather(in, nbs, d_sti, cnt, o, nbg, w, ctx->stream);
+      return o;
+    };
+    auto finish = [&](uint32_t* ge, uint32_t* gy, uint32_t* c5) {       // f = y c mod n^3 (ddleq.go:114); E, F of the bit-1 instances into place
       uint32_t* y3 = zext(ctx, gy, W1, W3, nbg);
       uint32_t* gf = ctx->ws_t<uint32_t>((size_t)W3 * nbg);
       modmul_arrays(ctx, mn3, y3, c5, nbg, gf);
       launch_scatter(ge, nbg, d_idx, cnt, eo, nb, W2, ctx->stream);
       launch_scatter(gf, nbg, d_idx, cnt, fo, nb, W3, ctx->stream);
+    };
+    if (resp_struct) {
+      // through the structure of the unit group: gather the prepared exponents of the bit-1 instances; one ladder modulo the primes, one lift
+      uint32_t* ge = gat(ge_all, W2);
+      const uint32_t* e1p[2] = {gat(rexps.e1p[0], sk->eo1_p.w), gat(rexps.e1p[1], sk->eo1_q.w)};
+      const uint32_t* e2p[2] = {gat(rexps.e2p[0], sk->eo1_p.w), gat(rexps.e2p[1], sk->eo1_q.w)};
+      int32_t* d_st_r = ctx->ws_t<int32_t>(nbg);
+      HIPCHK(hipMemsetAsync(d_st_r, 0, nbg * 4, ctx->stream));
+      std::vector<uint32_t> sti_pad(sti);
+      sti_pad.resize(nbg, 0);                                            // (padding lanes: statement 0's bases)
+      uint32_t* c5 = ctx->ws_t<uint32_t>((size_t)W3 * nbg);
+      struct_response(sk, rbase, ctx->upload_words(sti_pad), gat(rexps.e1n, W2), gat(en_all, W2), e1p, e2p, nbg, c5, d_st_r);
+      HT("response issued");
+      std::vector<int32_t> hr(cnt), hs(S);
+      HIPCHK(hipMemcpyAsync(hr.data(), d_st_r, cnt * 4, hipMemcpyDeviceToHost, ctx->stream));
+      HIPCHK(hipMemcpyAsync(hs.data(), d_st_rstmt, S * 4, hipMemcpyDeviceToHost, ctx->stream));
+      HIPCHK(hipStreamSynchronize(ctx->stream));
+      bool nonunit = false;
+      for (size_t i = 0; i < cnt; ++i) nonunit = nonunit || hr[i] || hs[sti[i]];
+      if (!nonunit) {
+        finish(ge, gat(yl, W1), c5);
+        return;
       }
     }
+    if (early) {
+      // everything but the ladder itself is at hand (side stream, above): gather it for the instances with bit 1
+      uint32_t* ge = gat(ge_all, W2);
+      const uint32_t* es[2] = {gat(es_all[0], sk->eo_p.w), gat(es_all[1], sk->eo_q.w)};
+      const uint32_t* eb[2] = {gat(eb_all[0], sk->eo_p.w), gat(eb_all[1], sk->eo_q.w)};
+      pre.sti = d_sti;
+      pre.cnt = cnt;
+      uint32_t* c5 = ctx->ws_t<uint32_t>((size_t)W3 * nbg);
+      HT("gathers issued");
+      if (!pow_n3_crt_two(sk, nullptr, es, nullptr, eb, nbg, c5, &pre)) api_throw(PGPU_ERR_UNSUPPORTED, "internal: the early response path lost its kernel");
+      HT("response issued");
+      finish(ge, gat(yl, W1), c5);
+      return;
+    }
+    uint32_t *gx = gat(xl, W1), *gy = gat(yl, W1), *gxn = gat(xn, W2);
+    uint32_t *ainv = per_inst(qainv, W2), *ani = per_inst(qani, W2), *gan = per_inst(an, W2), *sres = per_inst(qs, W1),
+             *gb = per_inst(bl, W1);
+    // e = x * a^-1 mod n^2 (ddleq.go:94-99)
+    uint32_t* x2 = zext(ctx, gx, W1, W2, nbg);
+    uint32_t* ge = ctx->ws_t<uint32_t>((size_t)W2 * nbg);
+    modmul_arrays(ctx, mn2, x2, ainv, nbg, ge);
+    uint32_t* s3 = zext(ctx, sres, W1, W3, nbg);
+    // c = ((s^an * b)^en)^-1 * s^xn ; f = y * c mod n^3   (ddleq.go:103-114)
+    // en = e^n mod n^2 (ddleq.go:104) = (x a^-1)^n = x^n (a^n)^-1: both powers are at hand, so an inversion replaces the ladder
+    uint32_t* en = ctx->ws_t<uint32_t>((size_t)W2 * nbg);
+    modmul_arrays(ctx, mn2, gxn, ani, nbg, en);
+    uint32_t* c5 = nullptr;
+    if (one_ladder && sb_units) {
+      // c = ((s^an b)^en)^-1 s^xn = s^(xn - an en) b^(-en)  (ddleq.go:107-112) whenever s and b are units: ONE interleaved
+      // ladder with two per-number exponents, computed modulo the group orders of p^3 and q^3 (response_exponents), instead of the
+      // ladders s^an | s^xn, (.)^en and a batch inversion modulo n^3.  A non-unit s or b (the reference's ModInverse is then
+      // undefined) keeps the literal sequence below and its error.  (The unit test ran per statement, on the side stream.)
+      const uint32_t *es[2], *eb[2];
+      response_exponents(gxn, gan, en, nbg, es, eb);
+      uint32_t* b3n = zext(ctx, gb, W1, W3, nbg);
+      uint32_t* o = ctx->ws_t<uint32_t>((size_t)W3 * nbg);
+      if (pow_n3_crt_two(sk, s3, es, b3n, eb, nbg, o)) c5 = o;
+    }
+    uint32_t* cc = ctx->ws_t<uint32_t>((size_t)W3 * nbg);
+    uint32_t* sx = ctx->ws_t<uint32_t>((size_t)W3 * nbg);
+    if (!c5) {
+      // s^(a^n) and s^(x^n) (ddleq.go:107,112): same base, independent exponents -> one launch
+      uint32_t* ss2 = concat2(ctx, s3, s3, W3, nbg);
+      uint32_t* ee2 = concat2(ctx, gan, gxn, W2, nbg);
+      uint32_t* o2 = ctx->ws_t<uint32_t>((size_t)W3 * 2 * nbg);
+      perlane3(ss2, ee2, W2, 2 * nbg, o2);
+      split2(ctx, o2, 0, W3, nbg, cc);
+      split2(ctx, o2, 1, W3, nbg, sx);
+      uint32_t* b3 = zext(ctx, gb, W1, W3, nbg);
+      uint32_t* cb = ctx->ws_t<uint32_t>((size_t)W3 * nbg);
+      modmul_arrays(ctx, mn3, cc, b3, nbg, cb);
+      perlane3(cb, en, W2, nbg, cc);
+      launch_restride(cc, nbg, cnt, mn3.d_consts + (size_t)C_ONE * W3, cc, nbg, W3, ctx->stream);
+      uint32_t* ci = batch_inverse(ctx, mn3, cc, nbg, cnt);
+      c5 = ctx->ws_t<uint32_t>((size_t)W3 * nbg);
+      modmul_arrays(ctx, mn3, ci, sx, nbg, c5);
+    }
+    finish(ge, gy, c5);
+  }
+
+  void write_outputs() {
     pack_result(ctx, alp, W3, nb, batch, alpha, ct_stride, mn3.nbytes, mem);
     pack_result(ctx, eo, W2, nb, batch, e_out, e_stride, std::min(e_stride, mn2.nbytes), mem);
     pack_result(ctx, fo, W3, nb, batch, f_out, ct_stride, mn3.nbytes, mem);
@@ -1811,6 +1856,36 @@ static void ddleq_prove_impl(const pgpu_seckey* sk, size_t S, size_t secpar, con
     HIPCHK(hipStreamSynchronize(ctx->stream));
     HT("done");
   }
+
+  void run() {
+    unpack_inputs();
+    powers_of_n();
+    structure_base();
+    extract_randomness();
+    sanity_and_alpha();
+    statement_side_work();
+    read_back();
+    respond();
+    write_outputs();
+  }
+};
+
+}  // namespace
+
+extern "C" {
+
+static void ddleq_prove_impl(const pgpu_seckey* sk, size_t S, size_t secpar, const uint8_t* ct1, const uint8_t* ct2, size_t ct_stride,
+                             const uint8_t* a, const uint8_t* b, const uint8_t* x, const uint8_t* y, size_t n_stride, uint8_t* alpha,
+                             uint8_t* e_out, size_t e_stride, uint8_t* f_out, int mem) {
+  pgpu_ctx* ctx = sk->ctx;
+  const pgpu_pubkey* pk = sk->pk;
+  if (S == 0 || secpar == 0) api_throw(PGPU_ERR_INVALID, "empty batch");
+  if (!pk->mn3 || sk->c_mu2R < 0) api_throw(PGPU_ERR_UNSUPPORTED, "level two is not available for this key");
+  if (!pk->g_is_n_plus_1) api_throw(PGPU_ERR_UNSUPPORTED, "DDLEQ prover assumes G = N+1");
+  ctx->bind();
+  ctx->reset_ws();
+  ProveCall call(sk, S, secpar, ct1, ct2, ct_stride, a, b, x, y, n_stride, alpha, e_out, e_stride, f_out, mem);
+  call.run();
 }
 
 int pgpu_ddleq_prove(const pgpu_seckey* sk, size_t batch, const uint8_t* ct1, const uint8_t* ct2, size_t ct_stride,
