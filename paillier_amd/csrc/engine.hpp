@@ -771,6 +771,8 @@ uint32_t* pow_n2_crt(const pgpu_seckey* sk, const uint32_t* base, const BigU& e,
 uint32_t* L_times_const(pgpu_ctx* ctx, const pgpu_pubkey* pk, const uint32_t* u, size_t nb, size_t count, const ModCtx& mn,
                         int c_const, const uint32_t* neg_const);
 uint32_t* decrypt2_crt(const pgpu_seckey* sk, const uint32_t* c_limbs, size_t nb, size_t count, int32_t* d_status);
+bool struct_pow_usable(const pgpu_seckey* sk);
+void teichmueller_lift(const pgpu_seckey* sk, uint32_t* const t[2], size_t nb, int32_t* d_status, uint32_t* T);
 void gm2_from_reduced(pgpu_ctx* ctx, const pgpu_pubkey* pk, const uint32_t* mred, size_t nb, uint32_t* post);
 
 }  // namespace pgi

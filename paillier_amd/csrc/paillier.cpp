@@ -179,18 +179,24 @@ bool pow_n2_crt_usable(const pgpu_seckey* sk) {
 // -- a ladder modulo the PRIME (1 024 squarings of 1.5 H^2 on the generic one-lane kernel) and the ladder of the headline Decrypt with
 // the exponent pr, instead of 2 047 squarings in pair form: 8.6 M multiply-adds per number and half where the exponent n mod
 // pr (pr - 1) needs 12.2 M.  The same integers for EVERY x: a multiple of pr gives t = 0 and 0^pr = 0 = x^n modulo pr^2 (n >= 2).
-// Returns the canonical t per half (H limbs, stride nb), or false where the shortcut does not apply.
-static bool nth_power_residues(const pgpu_seckey* sk, const uint32_t* base, const BigU& e, size_t nb, uint32_t* t[2]) {
-  pgpu_ctx* ctx = sk->ctx;
-  if (!ctx->use_lift || !(e == sk->pk->N) || sk->mp.WT != sk->mq.WT) return false;
-  BigU r[2];
+// power_residues returns the canonical t per half (H limbs, stride nb), or false where the shortcut does not apply.
+// k = 1: the residues for x^n; k = 2: for x^(n^2) modulo pr^3 (= omega_3(x^(o^2) mod pr): the same argument one digit further).
+bool power_residues_usable(const pgpu_seckey* sk, int k, BigU r[2]) {
+  if (!sk->ctx->use_lift || !sk->has_crt || sk->mp.WT != sk->mq.WT) return false;
   for (int half = 0; half < 2; ++half) {
     const BigU &pr = half ? sk->q : sk->p, &o = half ? sk->p : sk->q;
     const BigU ord = pr - BigU(1);
     r[half] = o % ord;
+    if (k == 2) r[half] = (r[half] * r[half]) % ord;
     if (r[half].is_zero()) r[half] = ord;
     if (pr.bit_length() < 64 || r[half].bit_length() < 64) return false;       // (toy keys: the literal exponent)
   }
+  return true;
+}
+bool power_residues(const pgpu_seckey* sk, const uint32_t* base, int k, size_t nb, uint32_t* t[2]) {
+  pgpu_ctx* ctx = sk->ctx;
+  BigU r[2];
+  if (!power_residues_usable(sk, k, r)) return false;
   const ModCtx &mp = sk->mp, &mq = sk->mq;
   const int H = mp.WT, WN = sk->pk->mn.WT;
   const size_t S1 = (size_t)H * nb;
@@ -220,7 +226,7 @@ uint32_t* pow_n2_crt(const pgpu_seckey* sk, const uint32_t* base, const BigU& e,
   uint32_t* mem[2];
   Prog lad[2];
   uint32_t* tl[2] = {nullptr, nullptr};
-  const bool lifted = nth_power_residues(sk, base, e, nb, tl);      // e == n: t = x^(other prime) modulo each prime, then t^prime
+  const bool lifted = e == sk->pk->N && power_residues(sk, base, 1, nb, tl);      // e == n: t = x^(other prime) modulo each prime, then t^prime
   Fork in(ctx);                                                         // the q-half's entry chain beside the p-half's
   for (int half = 0; half < 2; ++half) {
     in.chain(half);
@@ -1108,6 +1114,44 @@ int pgpu_encrypt_with_r_sk(const pgpu_seckey* sk, int level, size_t batch, const
   if (!sk) return fail(PGPU_ERR_INVALID, "null key");
   pgpu_ctx* ctx = sk->ctx;
   const pgpu_pubkey* pk = sk->pk;
+  if (level == PGPU_LEVEL_TWO && pk->g_is_n_plus_1 && pk->mn3 && struct_pow_usable(sk)) {
+    // Level two for the key holder: r^(n^2) mod n^3 is the Teichmueller lift of r^(n^2) mod n, i.e. modulo p^3 the lift of
+    // t = (r mod p)^(q^2 mod (p - 1)) -- a ladder modulo the primes and ONE lift (1 023 squarings modulo p^3, q^3; the DDLEQ prover's
+    // teichmueller_lift): 33 M multiply-adds per ciphertext where the public path's (r^n mod n^2)^n mod n^3 needs 166 M.  The same
+    // integers for every unit r; an r that shares a factor with n has no lift (the lane is flagged) and the batch takes the public path.
+    BigU rr[2];
+    if (power_residues_usable(sk, 2, rr)) {
+      bool redo = false;
+      const int rc = guarded([&] {
+        check_batch_args(m, c, batch);
+        if (!r) api_throw(PGPU_ERR_INVALID, "null buffer");
+        ctx->bind();
+        ctx->reset_ws();
+        const ModCtx &mn = pk->mn, &mn3 = *pk->mn3;
+        const size_t nb = round_up(batch, VM_BLOCK);
+        uint32_t* gm = ctx->ws_t<uint32_t>((size_t)mn3.WT * nb);
+        build_gm(ctx, pk, level, m, m_stride, batch, mem, nb, gm);                     // 1 + m n + C(m, 2) n^2
+        uint32_t* rl = ctx->ws_t<uint32_t>((size_t)mn.WT * nb);
+        unpack_mod(ctx, mn, r, r_stride, batch, mem, rl, nb, true);                    // r^(n^2) mod n^3 depends on r mod n only
+        uint32_t* t[2];
+        if (!power_residues(sk, rl, 2, nb, t)) api_throw(PGPU_ERR_UNSUPPORTED, "internal: power_residues");
+        int32_t* d_status = ctx->ws_t<int32_t>(nb);
+        HIPCHK(hipMemsetAsync(d_status, 0, nb * 4, ctx->stream));
+        uint32_t* T = ctx->ws_t<uint32_t>((size_t)mn3.WT * nb);
+        teichmueller_lift(sk, t, nb, d_status, T);
+        uint32_t* out = ctx->ws_t<uint32_t>((size_t)mn3.WT * nb);
+        modmul_arrays(ctx, mn3, gm, T, nb, out);                                       // c = G^m r^(n^2) mod n^3
+        std::vector<int32_t> hst(batch);
+        HIPCHK(hipMemcpyAsync(hst.data(), d_status, batch * 4, hipMemcpyDeviceToHost, ctx->stream));
+        pack_result(ctx, out, mn3.WT, nb, batch, c, c_stride, mn3.nbytes, mem);
+        HIPCHK(hipStreamSynchronize(ctx->stream));
+        for (size_t i = 0; i < batch; ++i) redo = redo || hst[i] != 0;
+      });
+      if (rc != PGPU_OK) return rc;
+      if (!redo) return PGPU_OK;
+    }
+    return pgpu_encrypt_with_r(pk, level, batch, m, m_stride, r, r_stride, c, c_stride, mem);
+  }
   if (level != PGPU_LEVEL_ONE || !pk->g_is_n_plus_1 || !pow_n2_crt_usable(sk))
     return pgpu_encrypt_with_r(pk, level, batch, m, m_stride, r, r_stride, c, c_stride, mem);   // nothing to gain: the public path
   return guarded([&] {

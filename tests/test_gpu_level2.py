@@ -208,3 +208,42 @@ def test_per_ciphertext_constants_beyond_the_seven_bit_tables(ctx):
         assert got[i] == pow(cts[i], ks[i], n3), i
     h = B // 2
     assert pk.ConstMultBatch(cts[:h], ks[:h], level=ENC_LEVEL_TWO) + pk.ConstMultBatch(cts[h:], ks[h:], level=ENC_LEVEL_TWO) == got
+
+
+@pytest.mark.parametrize("bits", ["1024", "2048", "3072"])
+def test_key_holder_level_two_encrypt_by_the_lift(ctx, bits):
+    """sk.EncryptWithRAtLevel(m, r, 2) (SecretKey embeds PublicKey, paillier.go:59-62,206-218): the key holder computes r^(n^2) mod n^3
+    as the Teichmueller lift of (r mod p)^(q^2 mod (p - 1)) (and likewise modulo q^3) -- the same integers as the public path and
+    the oracle for every unit r, for r >= n and m >= n^2; a batch with an r that shares a factor with n takes the public path and
+    still gets the reference's integers; flag "lift" 0 is the public path outright."""
+    import paillier_amd as pa
+    from paillier_amd import ENC_LEVEL_TWO
+    k = json.load(open(os.path.join(G, "keys.json")))["paillier"][bits]
+    p, q = int(k["p"], 16), int(k["q"], 16)
+    n, lam = p * q, (p - 1) * (q - 1)
+    n2, n3 = n * n, n ** 3
+    sk_o = po.SecretKey(N=n, G=n + 1, Lambda=lam)
+    pk = pa.PublicKey(ctx, n, n + 1)
+    sk = pa.SecretKey(ctx, pk, lam)
+    rng = random.Random(int(bits) + 77)
+    ms = [0, 1, n - 1, n, n2 - 1, n2 + 5] + [rng.randrange(n2) for _ in range(270)]
+    rs = [1, n - 1, 2, n + 7, po.rand_unit(n, rng), po.rand_unit(n, rng)] + [po.rand_unit(n, rng) for _ in range(270)]
+    want = pk.EncryptWithRBatch(ms, rs, level=ENC_LEVEL_TWO)
+    got = sk.EncryptWithRBatch(ms, rs, level=ENC_LEVEL_TWO)
+    assert got == want
+    assert got[:8] == [pow(r, n2, n3) * pow(n + 1, m, n3) % n3 for m, r in zip(ms[:8], rs[:8])]
+    assert got[6:10] == [po.encrypt_with_r_at_level(sk_o, m, r, po.ENC_LEVEL_TWO).C for m, r in zip(ms[6:10], rs[6:10])]
+    launches_lift = ctx.last_vm_launches()
+    assert sk.DecryptBatch(got[:40], level=ENC_LEVEL_TWO) == [m % n2 for m in ms[:40]]
+    # non-units among the r: the reference's formula verbatim
+    rs2 = list(rs)
+    rs2[3], rs2[9] = p, 5 * q
+    got2 = sk.EncryptWithRBatch(ms, rs2, level=ENC_LEVEL_TWO)
+    assert got2 == pk.EncryptWithRBatch(ms, rs2, level=ENC_LEVEL_TWO)
+    assert got2[3] == pow(p, n2, n3) * pow(n + 1, ms[3], n3) % n3
+    ctx.set_flag("lift", 0)
+    try:
+        assert sk.EncryptWithRBatch(ms[:20], rs[:20], level=ENC_LEVEL_TWO) == want[:20]
+    finally:
+        ctx.set_flag("lift", 1)
+    assert launches_lift >= 2
