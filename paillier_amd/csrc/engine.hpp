@@ -436,7 +436,7 @@ struct Prog {
     if (o == VM_MULVT || o == VM_MULVT5) nm4 = true;
     if (o == VM_MULV7) mulv7 = true;
     if (o == VM_MULS) needs_muls = true;
-    if (o == VM_MULCV || o == VM_MULV5 || o == VM_MULV7 || o == VM_STORET || o == VM_MULVT || o == VM_MULVT5) wide_gathers = true;   // (kernels without these opcodes must not get the program)
+    if (o == VM_MULCV || o == VM_MULCV7 || o == VM_MULV5 || o == VM_MULV7 || o == VM_STORET || o == VM_MULVT || o == VM_MULVT5) wide_gathers = true;   // (kernels without these opcodes must not get the program)
     if (o == VM_MULV || o == VM_MULV5 || o == VM_MULV7 || o == VM_MULVT || o == VM_MULVT5) {
       has_mulv = true;
       gather_slots = std::max<uint32_t>(gather_slots, o == VM_MULV ? 17u : o == VM_MULVT ? 18u : o == VM_MULV5 ? 33u : o == VM_MULVT5 ? 49u : 129u);
@@ -444,7 +444,7 @@ struct Prog {
     if (aux >> 22) api_throw(PGPU_ERR_INVALID, "internal: table slot does not fit the instruction word");
     w.push_back(o | (aux << 8));
     w.push_back(arg);
-    if (o == VM_SQR || o == VM_MUL || o == VM_MULC || o == VM_MULV || o == VM_MULCV || o == VM_MULV5 || o == VM_MULV7 || o == VM_MULS || o == VM_MULVT || o == VM_MULVT5) montmuls += 1;
+    if (o == VM_SQR || o == VM_MUL || o == VM_MULC || o == VM_MULV || o == VM_MULCV || o == VM_MULCV7 || o == VM_MULV5 || o == VM_MULV7 || o == VM_MULS || o == VM_MULVT || o == VM_MULVT5) montmuls += 1;
     if (o == VM_SQR) sqrs += 1;
   }
   // Bits 30..31 of an instruction word: the priority the wave takes when it gets there -- 3, 2, 1, 0 over four stretches of a
@@ -468,7 +468,7 @@ struct Prog {
       const double f = done / montmuls;
       const uint32_t quarter = f < 0.80 ? 0u : f < 0.96 ? 1u : f < 0.992 ? 2u : 3u;
       w[i] = (w[i] & 0x3FFFFFFFu) | ((3u - quarter) << 30);
-      if (o == VM_SQR || o == VM_MUL || o == VM_MULC || o == VM_MULV || o == VM_MULCV || o == VM_MULV5 || o == VM_MULV7 || o == VM_MULS || o == VM_MULVT || o == VM_MULVT5) done += 1;
+      if (o == VM_SQR || o == VM_MUL || o == VM_MULC || o == VM_MULV || o == VM_MULCV || o == VM_MULCV7 || o == VM_MULV5 || o == VM_MULV7 || o == VM_MULS || o == VM_MULVT || o == VM_MULVT5) done += 1;
     }
   }
 };
@@ -553,9 +553,25 @@ struct pgpu_pubkey {
   DevLimbs n2_limbs;              // n^2 as mn2.WT limbs
   int c_inv2R = -1;               // 2^-1 * R mod n in mn.consts        (binomial of the level-two g^m)
   int c_ninv2R_2 = -1;            // n * 2^-1 * R mod n^2 in mn2.consts (Damgard-Jurik recovery, paillier.go:326-331)
-  struct AltTab { bool built = false; int base = 0; int nwin = 0; size_t kbits = 0; } alt[2];  // fixed-base comb tables of h_s
+  struct AltTab { bool built = false; BigU hs; size_t kbits = 0; } alt[2];  // the fixed base h_s of AltEncrypt (its comb table: comb7)
   struct FixedBase { BigU base; int idx; int nwin; };
   std::vector<FixedBase> fixed_bases;   // comb tables of other fixed bases mod n^2 (verification keys)
+  // 7-bit comb tables (VM_MULCV7) of fixed bases modulo n^2 / n^3, built on the device and kept there: entry 4 + 128 i + d =
+  // base^(d 128^i) in Montgomery form, entries 0 .. 3 = the modulus' standard constants (the programs' LOADC / MULC indices)
+  struct Comb7 {
+    BigU base;
+    int level = 0;
+    int nwin = 0;
+    uint32_t* d_table = nullptr;
+    size_t words = 0;
+    Comb7() = default;
+    Comb7(const Comb7&) = delete;
+    Comb7& operator=(const Comb7&) = delete;
+    ~Comb7() { if (d_table) { (void)hipMemset(d_table, 0, words * 4); (void)hipFree(d_table); } }
+  };
+  std::vector<std::unique_ptr<Comb7>> comb7;
+  struct CachedInverse { BigU x, inv; bool unit; };
+  std::vector<CachedInverse> inverse_cache;   // inverses modulo n^2 of per-key constants (verification keys), taken once on the host
   DevLimbs pairn_consts;          // n | Cadj | pad for the two-lane pair kernel (mn2.pairn points here)
   DevLimbs pairn_consts8, pairn_tconsts8;   // the same for the eight-lane pair kernel (76-limb digits) and its three constants
   DevLimbs triple_kconsts;        // n | (C1_i, C2_i) pairs | pad for the three-digit kernel (mn3->triple points here)
@@ -773,6 +789,9 @@ uint32_t* L_times_const(pgpu_ctx* ctx, const pgpu_pubkey* pk, const uint32_t* u,
 uint32_t* decrypt2_crt(const pgpu_seckey* sk, const uint32_t* c_limbs, size_t nb, size_t count, int32_t* d_status);
 bool struct_pow_usable(const pgpu_seckey* sk);
 void teichmueller_lift(const pgpu_seckey* sk, uint32_t* const t[2], size_t nb, int32_t* d_status, uint32_t* T);
+const pgpu_pubkey::Comb7& ensure_comb7(pgpu_pubkey* pk, int level, const BigU& base, size_t ebits);
+void emit_comb7(Prog& p, int we);
+constexpr uint32_t kComb7First = 4;   // first table entry of a Comb7 buffer (behind the standard constants)
 void gm2_from_reduced(pgpu_ctx* ctx, const pgpu_pubkey* pk, const uint32_t* mred, size_t nb, uint32_t* post);
 
 }  // namespace pgi

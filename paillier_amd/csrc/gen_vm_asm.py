@@ -34,7 +34,7 @@ LB = 28
 MASK = (1 << LB) - 1
 BLOCK = 256
 OPS = dict(END=0, LOAD=1, STORE=2, LOADC=3, SQR=4, MUL=5, MULC=6, MULV=7, ADD=8, SETOFF=9, MULCV=10, MULV5=11, MULV7=12, STORET=13, MULS=14,
-           MULVT=15, MULVT5=16)
+           MULVT=15, MULVT5=16, MULCV7=17)
 
 
 class Gen:
@@ -398,7 +398,7 @@ class Gen:
         # MULVT / MULVT5 / STORET (number-major tables with 4- / 5-bit windows): the pair kernels GenP (37-limb primes), GenQ, GenQ4
         nm4 = ("MULVT", "MULVT5", "STORET") if getattr(self, "nm4_tables", False) else ()
         muls = ("MULS",) if getattr(self, "has_muls", False) else ()
-        for nm in ("SQR", "MUL", "MULC", "MULV", "MULV5") + nm_tables + nm4 + muls + ("MULCV", "LOAD", "STORE", "LOADC", "ADD"):
+        for nm in ("SQR", "MUL", "MULC", "MULV", "MULV5") + nm_tables + nm4 + muls + ("MULCV", "MULCV7", "LOAD", "STORE", "LOADC", "ADD"):
             e(f"s_cmp_eq_u32 s18, {OPS[nm]}")
             e(f"s_cbranch_scc1 L_{nm.lower()}")
         self.end_of_program()  # END (and anything unsupported: the host never sends those)
@@ -490,37 +490,44 @@ class Gen:
         if nm4:
             self.number_major4_ops(St)
 
-        e("L_mulcv:")
-        # fixed-base comb: a <- consts[aux + 16*arg + digit], digit = 4-bit window `arg` of this number's exponent
-        e(f"s_mul_hi_u32 s{g.s_t1}, s17, {((1 << 32) + 6) // 7}")          # q = arg / 7
-        e(f"s_mul_i32 s98, s{g.s_t1}, 7")
-        e("s_sub_u32 s98, s17, s98")
-        e("s_lshl_b32 s98, s98, 2")                                        # shift = 4 (arg % 7)
-        e(f"s_mul_hi_u32 s{g.s_sbase + 1}, s{g.s_t1}, s3")
-        e(f"s_mul_i32 s{g.s_sbase}, s{g.s_t1}, s3")
-        e(f"s_add_u32 s{g.s_sbase}, s{g.s_sbase}, s12")
-        e(f"s_addc_u32 s{g.s_sbase + 1}, s{g.s_sbase + 1}, s13")
-        e(f"v_subrev_u32 v{g.v_t2}, {self.lds_a}, v{g.v_aread}")
-        e(f"s_mul_i32 s{g.s_t0}, s2, {self.NPB * 4}")
-        e(f"v_add_u32 v{g.v_t2}, s{g.s_t0}, v{g.v_t2}")                    # g*4
-        e(f"global_load_dword v{g.v_t3}, v{g.v_t2}, s[{g.s_sbase}:{g.s_sbase + 1}]")
-        e("s_waitcnt vmcnt(0)")
-        e(f"v_lshrrev_b32 v{g.v_t3}, s98, v{g.v_t3}")
-        e(f"v_and_b32 v{g.v_t3}, 15, v{g.v_t3}")                           # digit
-        e(f"v_mul_u32_u24 v{g.v_t3}, {self.WT * 4}, v{g.v_t3}")            # digit * entry bytes
-        e(f"v_add_u32 v{g.v_t3}, v{g.v_t3}, v{g.v_koff}")
-        e("s_bfe_u32 s98, s16, 0x160008")                                  # aux (bits 8..29)
-        e("s_lshl_b32 s17, s17, 4")                                        # 16*arg
-        e("s_add_u32 s17, s17, s98")
-        e(f"s_mul_hi_u32 s{g.s_sbase + 1}, s17, {self.WT * 4}")
-        e(f"s_mul_i32 s{g.s_sbase}, s17, {self.WT * 4}")
-        e(f"s_add_u32 s{g.s_sbase}, s{g.s_sbase}, s8")
-        e(f"s_addc_u32 s{g.s_sbase + 1}, s{g.s_sbase + 1}, s9")
-        for j in range(self.WL):
-            e(f"global_load_dword {St[j]}, v{g.v_t3}, s[{g.s_sbase}:{g.s_sbase + 1}] offset:{4 * j}")
-        e("s_waitcnt vmcnt(0)")
-        self.stage_to_lds(St)
-        e("s_branch L_montmul")
+        for lbl, per_word, wbits in (("L_mulcv", 7, 4), ("L_mulcv7", 4, 7)):
+            # fixed-base comb: a <- consts[aux + 2^wbits * arg + digit], digit = window `arg` of this number's exponent: 4 bits, 7 per
+            # 28-bit limb (MULCV), or 7 bits, 4 per limb (MULCV7: 128-entry tables, 1.75 x fewer products)
+            e(f"{lbl}:")
+            if per_word == 4:
+                e(f"s_lshr_b32 s{g.s_t1}, s17, 2")                              # q = arg / 4
+                e("s_and_b32 s98, s17, 3")
+                e("s_mul_i32 s98, s98, 7")                                      # shift = 7 (arg % 4)
+            else:
+                e(f"s_mul_hi_u32 s{g.s_t1}, s17, {((1 << 32) + 6) // 7}")       # q = arg / 7
+                e(f"s_mul_i32 s98, s{g.s_t1}, 7")
+                e("s_sub_u32 s98, s17, s98")
+                e("s_lshl_b32 s98, s98, 2")                                     # shift = 4 (arg % 7)
+            e(f"s_mul_hi_u32 s{g.s_sbase + 1}, s{g.s_t1}, s3")
+            e(f"s_mul_i32 s{g.s_sbase}, s{g.s_t1}, s3")
+            e(f"s_add_u32 s{g.s_sbase}, s{g.s_sbase}, s12")
+            e(f"s_addc_u32 s{g.s_sbase + 1}, s{g.s_sbase + 1}, s13")
+            e(f"v_subrev_u32 v{g.v_t2}, {self.lds_a}, v{g.v_aread}")
+            e(f"s_mul_i32 s{g.s_t0}, s2, {self.NPB * 4}")
+            e(f"v_add_u32 v{g.v_t2}, s{g.s_t0}, v{g.v_t2}")                    # g*4
+            e(f"global_load_dword v{g.v_t3}, v{g.v_t2}, s[{g.s_sbase}:{g.s_sbase + 1}]")
+            e("s_waitcnt vmcnt(0)")
+            e(f"v_lshrrev_b32 v{g.v_t3}, s98, v{g.v_t3}")
+            e(f"v_and_b32 v{g.v_t3}, {(1 << wbits) - 1}, v{g.v_t3}")           # digit
+            e(f"v_mul_u32_u24 v{g.v_t3}, {self.WT * 4}, v{g.v_t3}")            # digit * entry bytes
+            e(f"v_add_u32 v{g.v_t3}, v{g.v_t3}, v{g.v_koff}")
+            e("s_bfe_u32 s98, s16, 0x160008")                                  # aux (bits 8..29)
+            e(f"s_lshl_b32 s17, s17, {wbits}")                                 # 2^wbits * arg
+            e("s_add_u32 s17, s17, s98")
+            e(f"s_mul_hi_u32 s{g.s_sbase + 1}, s17, {self.WT * 4}")
+            e(f"s_mul_i32 s{g.s_sbase}, s17, {self.WT * 4}")
+            e(f"s_add_u32 s{g.s_sbase}, s{g.s_sbase}, s8")
+            e(f"s_addc_u32 s{g.s_sbase + 1}, s{g.s_sbase + 1}, s9")
+            for j in range(self.WL):
+                e(f"global_load_dword {St[j]}, v{g.v_t3}, s[{g.s_sbase}:{g.s_sbase + 1}] offset:{4 * j}")
+            e("s_waitcnt vmcnt(0)")
+            self.stage_to_lds(St)
+            e("s_branch L_montmul")
 
         e("L_mulc:")
         self.const_base()

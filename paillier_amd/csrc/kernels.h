@@ -26,6 +26,7 @@ enum VmOp : uint32_t {
   VM_MULVT = 15,  // VM_MULV (4-bit windows, 7 per exponent limb) on a table of NUMBER-major slots written by VM_STORET (the one-lane
                   // pair kernel for 37-limb primes and the two- and four-lane pair kernels)
   VM_MULVT5 = 16, // VM_MULV5 (5-bit windows of the repacked exponent) on a table of NUMBER-major slots; the same kernels
+  VM_MULCV7 = 17, // VM_MULCV with 7-bit windows (4 per exponent limb): x <- x*consts[aux + 128*arg + window]*R^-1 (the generic kernels)
 };
 
 struct VmSeg {
@@ -82,7 +83,10 @@ void launch_sha256_transcript(const uint32_t* const* parts, const int* widths, i
                               uint32_t* digest_out, int32_t* bit_out, hipStream_t st);
 void launch_equal(const uint32_t* a, const uint32_t* b, int w, size_t nb, size_t count, int32_t* ok, hipStream_t st);
 void launch_select(const int32_t* flags, const uint32_t* a, const uint32_t* b, uint32_t* out, int w, size_t nb, hipStream_t st);
-void launch_mul_plain(const uint32_t* a, int wa, const uint32_t* b, int wb, uint32_t* out, size_t nb, hipStream_t st);
+// comb table: entry (first + 128 i + d) of `table` ([entry][wt]) <- limbs of number i in slot 1 + d of `mem` ([slot][wt][nb]), i < nwin, d < 128
+void launch_comb7_transpose(const uint32_t* mem, size_t nb, int wt, int nwin, uint32_t first, uint32_t* table, hipStream_t st);
+void launch_mul_plain(const uint32_t* a, int wa, const uint32_t* b, int wb, uint32_t* out, size_t nb, uint32_t* scratch_lo, uint64_t* scratch_cy,
+                      hipStream_t st);
 void launch_digest_to_limbs(const uint32_t* dg, uint32_t* out, size_t nb, hipStream_t st);
 // slow path of batch_inverse: flags[g] = gcd(x[g], N) != 1 (binary GCD per lane; work = 2*w*nb words of scratch)
 void launch_unit_flags(const uint32_t* x, const uint32_t* nmod, int w, size_t nb, size_t count, uint32_t* work, int32_t* flags,

@@ -103,6 +103,12 @@ __global__ void __launch_bounds__(VM_BLOCK, (3 * WL + 24 <= 256) ? 2 : 1) vm_ker
       const uint32_t* p = sg.consts + ((size_t)((w0 >> 8) & 0x3FFFFFu) + 16u * arg + digit) * WT + (size_t)k * WL;
 #pragma unroll
       for (int j = 0; j < WL; ++j) col[j * NPB] = p[j];
+    } else if (op == VM_MULCV7) {
+      const uint32_t elimb = sg.digits[(size_t)(arg / 4u) * nb + g];
+      const uint32_t digit = (elimb >> (7u * (arg % 4u))) & 127u;
+      const uint32_t* p = sg.consts + ((size_t)((w0 >> 8) & 0x3FFFFFu) + 128u * arg + digit) * WT + (size_t)k * WL;
+#pragma unroll
+      for (int j = 0; j < WL; ++j) col[j * NPB] = p[j];
     } else {
       size_t slot = arg;
       if (op == VM_MULV) {
@@ -588,25 +594,70 @@ __global__ void k_mask_bits(uint32_t* __restrict__ x, int w, size_t nb, size_t b
 }
 
 // out[wa+wb] = a[wa] * b[wb] as plain integers (canonical limbs in, canonical limbs out); both operands per-number.
-// Used only for the unreduced c^4 and c_i^2 that feed the Fiat-Shamir hash (thresholdkey.go:241,248).
-__global__ void k_mul_plain(const uint32_t* __restrict__ a, int wa, const uint32_t* __restrict__ b, int wb,
-                            uint32_t* __restrict__ out, size_t nb) {
-  CHAIN_PRIORITY();
-  size_t g = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+// Used only for the unreduced c^4 and c_i^2 that feed the Fiat-Shamir hash (thresholdkey.go:241,248) -- 16 384-bit and 8 192-bit
+// integers.  Two steps: (1) one thread per (number, output column): the column's sum of limb products, flushed into (28-bit limb,
+// carry) every 64 terms so that nothing overflows 64 bits; a square (a == b) takes every pair once, doubled.  (2) one thread per
+// number walks the columns and resolves the carries.  (One thread per number for the whole product -- round 4 -- is 256 waves of
+// 586 x 586 dependent loads: 9 ms for the c^4 of 16 384 ciphertexts; this form: 1.3 ms.)
+__global__ void k_comb7_transpose(const uint32_t* __restrict__ mem, size_t nb, int wt, int nwin, uint32_t first, uint32_t* __restrict__ table) {
+  // one thread per (limb, window, digit): reads are coalesced over the windows' lanes only for small nwin -- a one-off per key
+  const size_t t = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const size_t total = (size_t)nwin * 128 * (size_t)wt;
+  if (t >= total) return;
+  const int l = (int)(t % (size_t)wt);
+  const size_t e = t / (size_t)wt;                 // 128 i + d
+  const size_t i = e >> 7, d = e & 127;
+  table[((size_t)first + e) * (size_t)wt + l] = mem[((1 + d) * (size_t)wt + (size_t)l) * nb + i];
+}
+
+__global__ void __launch_bounds__(256) k_mul_plain_cols(const uint32_t* __restrict__ a, int wa, const uint32_t* __restrict__ b, int wb, int sq,
+                                                        uint32_t* __restrict__ lo, uint64_t* __restrict__ cy, size_t nb) {
+  const size_t g = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const int c = (int)blockIdx.y;
   if (g >= nb) return;
-  uint64_t acc = 0, hi = 0;
-  const int wo = wa + wb;
-  for (int c = 0; c < wo; ++c) {
-    int i0 = c - (wb - 1) > 0 ? c - (wb - 1) : 0;
-    int i1 = c < wa - 1 ? c : wa - 1;
-    for (int i = i0; i <= i1; ++i) {
-      uint64_t p = (uint64_t)a[(size_t)i * nb + g] * b[(size_t)(c - i) * nb + g];
-      acc += p;
-      hi += acc < p;
+  const int i0 = c - (wb - 1) > 0 ? c - (wb - 1) : 0;
+  int i1 = c < wa - 1 ? c : wa - 1;
+  uint64_t acc = 0, carry = 0;
+  uint32_t low = 0;
+  int n = 0;
+  auto flush = [&] {
+    const uint64_t t = acc + low;
+    low = (uint32_t)t & LMASK;
+    carry += t >> LB;
+    acc = 0;
+    n = 0;
+  };
+  if (sq) {
+    const int ih = (c - 1) >> 1;                              // pairs (i, c - i) with i < c - i   (c = 0: none)
+    if (c > 0 && ih < i1) i1 = ih;
+    if (c > 0)
+      for (int i = i0; i <= i1; ++i) {
+        acc += 2ull * ((uint64_t)a[(size_t)i * nb + g] * a[(size_t)(c - i) * nb + g]);
+        if (++n == 64) flush();
+      }
+    if (!(c & 1) && (c >> 1) < wa) {
+      const uint64_t d = a[(size_t)(c >> 1) * nb + g];
+      acc += d * d;
     }
-    out[(size_t)c * nb + g] = (uint32_t)acc & LMASK;
-    acc = (acc >> LB) | (hi << (64 - LB));
-    hi >>= LB;
+  } else {
+    for (int i = i0; i <= i1; ++i) {
+      acc += (uint64_t)a[(size_t)i * nb + g] * b[(size_t)(c - i) * nb + g];
+      if (++n == 128) flush();
+    }
+  }
+  flush();
+  lo[(size_t)c * nb + g] = low;
+  cy[(size_t)c * nb + g] = carry;
+}
+__global__ void k_mul_plain_carry(const uint32_t* __restrict__ lo, const uint64_t* __restrict__ cy, int wo, uint32_t* __restrict__ out, size_t nb) {
+  CHAIN_PRIORITY();
+  const size_t g = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (g >= nb) return;
+  uint64_t carry = 0;
+  for (int c = 0; c < wo; ++c) {
+    const uint64_t t = carry + lo[(size_t)c * nb + g];
+    out[(size_t)c * nb + g] = (uint32_t)t & LMASK;
+    carry = (t >> LB) + cy[(size_t)c * nb + g];
   }
 }
 
@@ -1220,8 +1271,17 @@ void launch_equal(const uint32_t* a, const uint32_t* b, int w, size_t nb, size_t
 void launch_select(const int32_t* flags, const uint32_t* a, const uint32_t* b, uint32_t* out, int w, size_t nb, hipStream_t st) {
   hipLaunchKernelGGL(k_select, HELPER_GRID(nb), 0, st, flags, a, b, out, w, nb);
 }
-void launch_mul_plain(const uint32_t* a, int wa, const uint32_t* b, int wb, uint32_t* out, size_t nb, hipStream_t st) {
-  hipLaunchKernelGGL(k_mul_plain, HELPER_GRID(nb), 0, st, a, wa, b, wb, out, nb);
+void launch_comb7_transpose(const uint32_t* mem, size_t nb, int wt, int nwin, uint32_t first, uint32_t* table, hipStream_t st) {
+  const size_t total = (size_t)nwin * 128 * (size_t)wt;
+  hipLaunchKernelGGL(k_comb7_transpose, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, mem, nb, wt, nwin, first, table);
+}
+void launch_mul_plain(const uint32_t* a, int wa, const uint32_t* b, int wb, uint32_t* out, size_t nb, uint32_t* scratch_lo, uint64_t* scratch_cy,
+                      hipStream_t st) {
+  // scratch_lo: (wa + wb) * nb words, scratch_cy: (wa + wb) * nb 64-bit words
+  const int wo = wa + wb;
+  hipLaunchKernelGGL(k_mul_plain_cols, dim3((unsigned)((nb + 255) / 256), (unsigned)wo), dim3(256), 0, st, a, wa, b, wb, a == b && wa == wb ? 1 : 0,
+                     scratch_lo, scratch_cy, nb);
+  hipLaunchKernelGGL(k_mul_plain_carry, HELPER_GRID(nb), 0, st, scratch_lo, scratch_cy, wo, out, nb);
 }
 void launch_digest_to_limbs(const uint32_t* dg, uint32_t* out, size_t nb, hipStream_t st) {
   hipLaunchKernelGGL(k_digest_to_limbs, HELPER_GRID(nb), 0, st, dg, out, nb);

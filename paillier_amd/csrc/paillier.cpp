@@ -721,8 +721,8 @@ void build_gm(pgpu_ctx* ctx, const pgpu_pubkey* pk, int level, const uint8_t* m,
   gm2_from_reduced(ctx, pk, mred, nb, post);
 }
 
-// Fixed-base comb table of h_s for AltEncrypt (paillier.go:416-434: h_1 = (N-H)^N mod N^2, h_2 = (N^2-H)^(N^2) mod N^3):
-// entries h^(d 16^i) (Montgomery form), i < ceil(log2(K)/4), d < 16, appended to the ciphertext modulus' constants.
+// The fixed base h_s of AltEncrypt (paillier.go:416-434: h_1 = (N-H)^N mod N^2, h_2 = (N^2-H)^(N^2) mod N^3), computed once per key;
+// its comb table (7-bit windows, VM_MULCV7) is built on the device by ensure_comb7.
 void ensure_alt_table(pgpu_pubkey* pk, int level) {
   pgpu_pubkey::AltTab& t = pk->alt[level];
   if (t.built) return;
@@ -732,20 +732,8 @@ void ensure_alt_table(pgpu_pubkey* pk, int level) {
   ModCtx& mc = (level == PGPU_LEVEL_ONE) ? pk->mn2 : *pk->mn3;
   const BigU ns = (level == PGPU_LEVEL_ONE) ? pk->N : pk->mn2.N;
   if (hostbig::cmp(ns, pk->H) <= 0) api_throw(PGPU_ERR_INVALID, "H must be smaller than n^s");
-  BigU base = hostbig::powmod(ns - pk->H, ns, mc.N);
+  t.hs = hostbig::powmod(ns - pk->H, ns, mc.N);
   t.kbits = kbits;
-  t.nwin = (int)((kbits + 3) / 4);
-  t.base = (int)mc.consts.size();
-  const BigU rmod = mc.R % mc.N;
-  for (int i = 0; i < t.nwin; ++i) {
-    BigU cur(1);
-    for (int d = 0; d < 16; ++d) {
-      mc.consts.push_back(hostbig::mulmod(cur, rmod, mc.N));   // Montgomery form of base^d
-      cur = hostbig::mulmod(cur, base, mc.N);
-    }
-    base = cur;  // base^16
-  }
-  mc.upload();
   t.built = true;
 }
 
@@ -962,6 +950,7 @@ int pgpu_alt_encrypt_with_r(const pgpu_pubkey* pk, int level, size_t batch, cons
     ctx->bind();
     ensure_alt_table(const_cast<pgpu_pubkey*>(pk), level);
     const pgpu_pubkey::AltTab& t = pk->alt[level];
+    const pgpu_pubkey::Comb7& cb = ensure_comb7(const_cast<pgpu_pubkey*>(pk), level, t.hs, t.kbits);
     ctx->reset_ws();
     const size_t nb = round_up(batch, VM_BLOCK);
     const size_t sw = (size_t)mc.WT * nb;
@@ -984,11 +973,12 @@ int pgpu_alt_encrypt_with_r(const pgpu_pubkey* pk, int level, size_t batch, cons
     }
     Prog p;
     p.op(VM_LOADC, C_ONE_M);
-    for (int i = 0; i < t.nwin; ++i) p.op(VM_MULCV, (uint32_t)i, (uint32_t)t.base);
+    emit_comb7(p, std::max(we, 1));   // h_s^(r mod K): one table product per 7 bits
     p.op(VM_MUL, 0);      // * g^m (plain) -> leaves Montgomery form
     p.op(VM_STORE, 1);
     p.end();
     SegSpec sg{&mc, &p, memv, exps};
+    sg.tconsts = cb.d_table;
     run_vm(ctx, nb, sg, nullptr, true);
     launch_canon(memv + sw, mc.d_nmod, mc.WT, nb, ctx->stream);
     pack_result(ctx, memv + sw, mc.WT, nb, batch, c, c_stride, mc.nbytes, mem);

@@ -41,6 +41,19 @@ void emit_pow_small(Prog& p, const BigU& e, uint32_t base) {
   }
 }
 
+// x^-1 mod n^2 of a per-key constant (a verification key), computed once on the host and kept with the key; false: not a unit
+bool cached_inverse(pgpu_pubkey* pk, const BigU& x, BigU& inv) {
+  for (auto& e : pk->inverse_cache)
+    if (e.x == x) { inv = e.inv; return e.unit; }
+  pgpu_pubkey::CachedInverse e;
+  e.x = x;
+  e.unit = hostbig::modinv(x, pk->mn2.N, e.inv);
+  if (pk->inverse_cache.size() >= 64) pk->inverse_cache.erase(pk->inverse_cache.begin());      // (bounded: callers choose the keys)
+  pk->inverse_cache.push_back(e);
+  inv = e.inv;
+  return e.unit;
+}
+
 // fixed-base comb table of `base` modulo n^2 covering exponents of up to `ebits` bits; returns (first const index, windows)
 const pgpu_pubkey::FixedBase& ensure_fixed_base(pgpu_pubkey* pk, const BigU& base_in, size_t ebits) {
   ModCtx& mc = pk->mn2;
@@ -65,6 +78,83 @@ const pgpu_pubkey::FixedBase& ensure_fixed_base(pgpu_pubkey* pk, const BigU& bas
   mc.upload();
   pk->fixed_bases.push_back(f);
   return pk->fixed_bases.back();
+}
+
+// The 7-bit comb table of `base` modulo n^(level + 2) for exponents of up to `ebits` bits (4 windows per 28-bit limb: 1.75 x fewer
+// products than the 4-bit table).  82 000 entries for a 4 480-bit exponent: built on the DEVICE -- the host walks the chain
+// b_i = base^(128^i) (7 squarings per window), one lane per window multiplies its 127 entries up, a transpose puts them where
+// VM_MULCV7 reads them ([entry][WT], shared by the batch) -- and kept with the key.
+const pgpu_pubkey::Comb7& ensure_comb7(pgpu_pubkey* pk, int level, const BigU& base_in, size_t ebits) {
+  pgpu_ctx* ctx = pk->ctx;
+  ModCtx& mc = level == PGPU_LEVEL_TWO ? *pk->mn3 : pk->mn2;
+  const BigU base = base_in % mc.N;
+  const int nwin = (int)((ebits + LB - 1) / LB) * 4;
+  for (auto& c : pk->comb7)
+    if (c->level == level && c->base == base && c->nwin >= nwin) return *c;
+  std::unique_ptr<pgpu_pubkey::Comb7> c(new pgpu_pubkey::Comb7());
+  c->base = base;
+  c->level = level;
+  c->nwin = nwin;
+  const int WT = mc.WT;
+  const size_t nbw = round_up((size_t)nwin, VM_BLOCK);
+  // b_i in Montgomery form, limb-major [WT][nbw] (padding lanes: 1)
+  std::vector<uint32_t> bl((size_t)WT * nbw, 0);
+  {
+    const auto one = mc.to_mont(BigU(1)).to_limbs(LB, WT);
+    for (size_t i = (size_t)nwin; i < nbw; ++i)
+      for (int l = 0; l < WT; ++l) bl[(size_t)l * nbw + i] = one[(size_t)l];
+    BigU b = base;
+    for (int i = 0; i < nwin; ++i) {
+      const auto bm = mc.to_mont(b).to_limbs(LB, WT);
+      for (int l = 0; l < WT; ++l) bl[(size_t)l * nbw + (size_t)i] = bm[(size_t)l];
+      if (i + 1 < nwin)
+        for (int k = 0; k < 7; ++k) b = hostbig::mulmod(b, b, mc.N);
+    }
+  }
+  ctx->bind();
+  ctx->reset_ws();
+  const size_t sw = (size_t)WT * nbw;
+  uint32_t* mem = ctx->ws_t<uint32_t>(sw * 129);           // slots: 0 b_i, 1 + d: b_i^d
+  HIPCHK(hipMemcpyAsync(mem, bl.data(), sw * 4, hipMemcpyHostToDevice, ctx->stream));
+  {
+    Prog p;
+    p.op(VM_LOADC, C_ONE_M);
+    p.op(VM_STORE, 1);
+    for (uint32_t d = 1; d < 128; ++d) { p.op(VM_MUL, 0); p.op(VM_STORE, 1 + d); }
+    p.end();
+    SegSpec sg{&mc, &p, mem, nullptr};
+    run_vm(ctx, nbw, sg, nullptr, false);
+  }
+  for (uint32_t d = 0; d < 128; ++d) launch_canon(mem + (size_t)(1 + d) * sw, mc.d_nmod, WT, nbw, ctx->stream);
+  c->words = ((size_t)kComb7First + (size_t)nwin * 128) * (size_t)WT;
+  HIPCHK(hipMalloc((void**)&c->d_table, c->words * 4));
+  HIPCHK(hipMemcpyAsync(c->d_table, mc.d_consts, (size_t)kComb7First * WT * 4, hipMemcpyDeviceToDevice, ctx->stream));   // C_R2, C_R3, C_ONE_M, C_ONE
+  launch_comb7_transpose(mem, nbw, WT, nwin, kComb7First, c->d_table, ctx->stream);
+  HIPCHK(hipStreamSynchronize(ctx->stream));
+  if (pk->comb7.size() >= 16) pk->comb7.erase(pk->comb7.begin());     // (bounded: callers choose the bases)
+  pk->comb7.push_back(std::move(c));
+  return *pk->comb7.back();
+}
+// x <- x * base^(this number's exponent of `we` limbs): one table product per 7-bit window (the segment's tconsts = the Comb7 buffer)
+void emit_comb7(Prog& p, int we) {
+  for (int i = 0; i < we * 4; ++i) p.op(VM_MULCV7, (uint32_t)i, kComb7First);
+}
+// base^e mod n^2 through the 7-bit comb table; exps: limb-major [we][nb]; result canonical in `out`
+void comb_pow7(pgpu_ctx* ctx, const ModCtx& mc, const pgpu_pubkey::Comb7& cb, const uint32_t* exps, int we, size_t nb, uint32_t* out) {
+  if (we * 4 > cb.nwin) api_throw(PGPU_ERR_INVALID, "fixed-base table narrower than the exponent");
+  size_t sw = (size_t)mc.WT * nb;
+  uint32_t* memv = ctx->ws_t<uint32_t>(sw);
+  Prog p;
+  p.op(VM_LOADC, C_ONE_M);
+  emit_comb7(p, we);
+  p.op(VM_MULC, C_ONE);
+  p.op(VM_STORE, 0);
+  p.end();
+  SegSpec sg{&mc, &p, memv, exps};
+  sg.tconsts = cb.d_table;
+  run_vm(ctx, nb, sg, nullptr, true);
+  launch_canon(memv, mc.d_nmod, mc.WT, nb, ctx->stream);
+  HIPCHK(hipMemcpyAsync(out, memv, sw * 4, hipMemcpyDeviceToDevice, ctx->stream));
 }
 
 // x^e mod n^2 for a uniform base with a comb table and per-number exponents (limb-major [we][nb]); result canonical in `out`
@@ -93,9 +183,11 @@ uint32_t* zkp_hash(pgpu_ctx* ctx, int W2, const uint32_t* a, const uint32_t* b, 
   uint32_t* c2 = ctx->ws_t<uint32_t>((size_t)2 * W2 * nb);
   uint32_t* c4 = ctx->ws_t<uint32_t>((size_t)4 * W2 * nb);
   uint32_t* ci2 = ctx->ws_t<uint32_t>((size_t)2 * W2 * nb);
-  launch_mul_plain(c, W2, c, W2, c2, nb, ctx->stream);
-  launch_mul_plain(c2, 2 * W2, c2, 2 * W2, c4, nb, ctx->stream);
-  launch_mul_plain(ci, W2, ci, W2, ci2, nb, ctx->stream);
+  uint32_t* slo = ctx->ws_t<uint32_t>((size_t)4 * W2 * nb);                    // column sums of the widest product: limbs and carries
+  uint64_t* scy = ctx->ws_t<uint64_t>((size_t)4 * W2 * nb);
+  launch_mul_plain(c, W2, c, W2, c2, nb, slo, scy, ctx->stream);
+  launch_mul_plain(c2, 2 * W2, c2, 2 * W2, c4, nb, slo, scy, ctx->stream);
+  launch_mul_plain(ci, W2, ci, W2, ci2, nb, slo, scy, ctx->stream);
   const uint32_t* parts[4] = {a, b, c4, ci2};
   const int widths[4] = {W2, W2, 4 * W2, 2 * W2};
   uint32_t* dg = ctx->ws_t<uint32_t>(8 * nb);
@@ -599,8 +691,8 @@ int pgpu_share_zkp_prove(const pgpu_pubkey* pk, int total_servers, const uint8_t
     const int W2 = mc.WT;
     const BigU share = BigU::from_be(share_be, share_len), delta = factorial_big(total_servers);
     if (r_stride > mc.nbytes + 96) api_throw(PGPU_ERR_INVALID, "r stride larger than the byte length of n^2 plus 96 (r < n^2, thresholdkey.go:233)");
-    const pgpu_pubkey::FixedBase fb = ensure_fixed_base(const_cast<pgpu_pubkey*>(pk), BigU::from_be(vkey_be, vkey_len),
-                                                        std::max(mc.nbits + 384, r_stride * 8));
+    const pgpu_pubkey::Comb7& fb = ensure_comb7(const_cast<pgpu_pubkey*>(pk), PGPU_LEVEL_ONE, BigU::from_be(vkey_be, vkey_len),
+                                                std::max(mc.nbits + 384, r_stride * 8));
     ctx->reset_ws();
     const size_t nb = round_up(batch, VM_BLOCK);
     const size_t sw = (size_t)W2 * nb;
@@ -629,7 +721,7 @@ int pgpu_share_zkp_prove(const pgpu_pubkey* pk, int total_servers, const uint8_t
     uint32_t* a = ctx->ws_t<uint32_t>(sw);
     uint32_t* b = ctx->ws_t<uint32_t>(sw);
     perlane_pow(ctx, mc, c4m, rl, wr, nb, a);
-    comb_pow(ctx, mc, fb, rl, wr, nb, b);
+    comb_pow7(ctx, mc, fb, rl, wr, nb, b);                      // V^r: one table product per 7 bits of r
     uint32_t* dg = zkp_hash(ctx, W2, a, b, cl, pd.out(), nb, batch);
     // E and Z = r + E * delta * s_i (plain integers, thresholdkey.go:313-317)
     uint32_t* el = ctx->ws_t<uint32_t>(10 * nb);
@@ -666,8 +758,13 @@ int pgpu_share_zkp_verify(const pgpu_pubkey* pk, const uint8_t* vkey_be, size_t 
     // table that is kept with the key: bound it (an unbounded caller-chosen stride would grow the key without limit).
     if (z_stride > mc.nbytes + 96) api_throw(PGPU_ERR_INVALID, "z stride larger than the byte length of n^2 plus 96");
     const size_t zbits = std::max(z_stride * 8, mc.nbits + 384);
-    const pgpu_pubkey::FixedBase fbV = ensure_fixed_base(pkm, BigU::from_be(vkey_be, vkey_len), zbits);
-    const pgpu_pubkey::FixedBase fbI = ensure_fixed_base(pkm, BigU::from_be(vi_be, vi_len), 256);
+    const pgpu_pubkey::Comb7& fbV = ensure_comb7(pkm, PGPU_LEVEL_ONE, BigU::from_be(vkey_be, vkey_len), zbits);
+    // b = V^Z (v_i^E)^-1 = V^Z (v_i^-1)^E: the verification key v_i is fixed for the batch, so its inverse is taken ONCE, on the host
+    // (kept with the key), and the comb table is that of v_i^-1 -- no inversion tree for b.  A v_i that is not a unit has no inverse:
+    // mpz_invert leaves the reference's b undefined and every proof under that key is rejected.
+    BigU vi_inv;
+    const bool vi_unit = cached_inverse(pkm, BigU::from_be(vi_be, vi_len) % mc.N, vi_inv);
+    const pgpu_pubkey::FixedBase fbI = ensure_fixed_base(pkm, vi_unit ? vi_inv : BigU(1), 256);
     ctx->reset_ws();
     const size_t nb = round_up(batch, VM_BLOCK);
     const size_t sw = (size_t)W2 * nb;
@@ -706,25 +803,23 @@ int pgpu_share_zkp_verify(const pgpu_pubkey* pk, const uint8_t* vkey_be, size_t 
     uint32_t* b2 = ctx->ws_t<uint32_t>(sw);
     perlane_pow(ctx, mc, c4m, zl, wz, nb, a1);
     perlane_pow(ctx, mc, d2m, el, 10, nb, a2);
-    comb_pow(ctx, mc, fbV, zl, wz, nb, b1);
-    comb_pow(ctx, mc, fbI, el, 10, nb, b2);
-    // A proof whose Decryption (or v_i) is not a unit has no inverse: mpz_invert leaves the reference's a2 / b2 undefined
-    // and the hash comparison fails; here such a lane is rejected (ok = 0) without disturbing the other proofs.
+    comb_pow7(ctx, mc, fbV, zl, wz, nb, b1);
+    comb_pow(ctx, mc, fbI, el, 10, nb, b2);                     // (v_i^-1)^E
+    // A proof whose Decryption is not a unit has no inverse: mpz_invert leaves the reference's a2 undefined and the hash
+    // comparison fails; here such a lane is rejected (ok = 0) without disturbing the other proofs.
     int32_t* bad_a = ctx->ws_t<int32_t>(nb);
-    int32_t* bad_b = ctx->ws_t<int32_t>(nb);
     uint32_t* a2i = batch_inverse(ctx, mc, a2, nb, batch, bad_a);
     uint32_t* av = ctx->ws_t<uint32_t>(sw);
     modmul_arrays(ctx, mc, a1, a2i, nb, av);
-    uint32_t* b2i = batch_inverse(ctx, mc, b2, nb, batch, bad_b);
     uint32_t* bv = ctx->ws_t<uint32_t>(sw);
-    modmul_arrays(ctx, mc, b1, b2i, nb, bv);
+    modmul_arrays(ctx, mc, b1, b2, nb, bv);
     uint32_t* dg = zkp_hash(ctx, W2, av, bv, cl, dl, nb, batch);
     uint32_t* e2 = ctx->ws_t<uint32_t>(10 * nb);
     launch_digest_to_limbs(dg, e2, nb, ctx->stream);
     int32_t* d_ok = ctx->ws_t<int32_t>(nb);
     launch_equal(e2, el, 10, nb, batch, d_ok, ctx->stream);
     launch_clear_where(bad_a, batch, d_ok, ctx->stream);
-    launch_clear_where(bad_b, batch, d_ok, ctx->stream);
+    if (!vi_unit) HIPCHK(hipMemsetAsync(d_ok, 0, nb * 4, ctx->stream));
     HIPCHK(hipMemcpyAsync(ok, d_ok, batch * 4, hipMemcpyDeviceToHost, ctx->stream));
     HIPCHK(hipStreamSynchronize(ctx->stream));
   });

@@ -247,3 +247,28 @@ def test_key_holder_level_two_encrypt_by_the_lift(ctx, bits):
     finally:
         ctx.set_flag("lift", 1)
     assert launches_lift >= 2
+
+
+@pytest.mark.parametrize("level", [0, 1])
+def test_seven_bit_comb_asm_and_hipcc_kernels_agree(ctx, level):
+    """VM_MULCV7 (the fixed-base comb with 7-bit windows: AltEncrypt's h_s^r, the share ZKP's V^r / V^Z): the hand-assembled kernels
+    and the hipcc twin give the same ciphertexts (and the oracle's), at a batch that is re-sliced over more lanes and at one that is not."""
+    import paillier_amd as pa
+    sk_o, p, q = po.keygen_seeded(2048, 9)
+    n = sk_o.N
+    pk = pa.PublicKey(ctx, n, n + 1, H=sk_o.H, K=sk_o.K)
+    rng = random.Random(131 + level)
+    nsq = n if level == 0 else n * n
+    ms = [rng.randrange(nsq) for _ in range(300)]
+    rs = [0, 1, sk_o.K - 1, sk_o.K + 3] + [rng.getrandbits(1100) for _ in range(296)]
+    got = {}
+    for asm in (1, 0):
+        ctx.set_flag("asm", asm)
+        try:
+            got[asm] = pk.AltEncryptWithRBatch(ms, rs, level=level)
+            assert (ctx.last_vm_asm() > 0) == bool(asm)
+        finally:
+            ctx.set_flag("asm", 1)
+    assert got[1] == got[0]
+    want = [po.alt_encrypt_with_r_at_level(sk_o, m, r, level) for m, r in zip(ms[:6], rs[:6])]
+    assert got[1][0][:6] == [w[0].C for w in want] and got[1][1][:6] == [w[1] for w in want]

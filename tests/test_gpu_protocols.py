@@ -195,6 +195,12 @@ def test_share_zkp_device_resident(ctx, bits):
     assert got[:3] == [False, False, False] and all(got[3:])
     # wrong verification key (another server's): thresholdkey_test.go:294-327 expects rejection
     assert tk.VerifyProofBatch(v, vks[sid % total], cts, dec, es, zs) == [False] * B
+    # a verification key v_i that is not a unit modulo n^2 has no inverse (thresholdkey.go:308: mpz_invert undefined): every proof
+    # under it is rejected; and the engine's inverse of v_i (taken once, kept with the key) serves a second call
+    p_ = int(k["p"], 16) if "p" in k else None
+    if p_:
+        assert tk.VerifyProofBatch(v, p_ * 12345, cts, dec, es, zs) == [False] * B
+    assert tk.VerifyProofBatch(v, vks[sid - 1], cts, dec, es, zs) == [True] * B
 
 
 def test_ddleq_prove_on_device(ctx):
