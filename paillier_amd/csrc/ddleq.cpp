@@ -1,6 +1,7 @@
 // ddleq.cpp -- NestedRandomize (operations.go:96-118), the DDLEQ proofs (ddleq.go:27-153) and RandomOracleDigest
 // (random_oracle.go:10-32): interleaved ladders modulo n^3, the key holder's halves modulo p^3 / q^3, the prover.
 #include <chrono>
+#include <functional>
 #include "engine.hpp"
 
 extern "C" {
@@ -629,28 +630,20 @@ void struct_pow_n3(const pgpu_seckey* sk, const StructBase& sb, const uint32_t* 
 // and ONE lift -- where pow_n3_crt_two squares 3 071 times modulo p^3 (or 2 047 times modulo p^2 and 1 024 modulo p^3) on two
 // 128-entry tables.  Worth it from a few instances per statement (plan::response_by_structure).
 struct RespBase {
-  const uint32_t *mu_s = nullptr, *mu_b = nullptr;                 // mn2.WT limbs, stride nbs
+  const uint32_t* mu_b = nullptr;                                  // mn2.WT limbs, stride nbs
   const uint32_t *sp[2] = {nullptr, nullptr}, *bp[2] = {nullptr, nullptr};   // s, b modulo p and q: mp.WT limbs, stride nbs
   size_t nbs = 0;
 };
-// s, b: canonical residues modulo n (mn.WT limbs, stride nbs); d_status (nbs entries, zeroed) flags non-units among the first `count`
-void resp_base(const pgpu_seckey* sk, const uint32_t* s, const uint32_t* b, size_t nbs, size_t count, int32_t* d_status, RespBase& rb) {
+// s, b: canonical residues modulo n (mn.WT limbs, stride nbs); d_status (nbs entries, zeroed) flags non-units among the first `count`.
+// Only b's plaintext is taken (one CRT decryption per statement): E1 = xn - an en is a multiple of n^2 AS AN INTEGER -- en is made
+// as xn (an)^-1 mod n^2, so an en = xn + j n^2 -- and (1 + n)^(mu_s E1) = 1 whatever mu_s is: s enters through its residues modulo
+// the primes alone.  (Round 4 decrypted s as well and multiplied its plaintext by E1 mod n^2 = 0.)
+// (two steps, as struct_base_*: the residues feed the ladder modulo the primes, the plaintext only the closed form at the very end -- a
+// caller with a lane to spare lets the decryption run beside that ladder)
+void resp_base_residues(const pgpu_seckey* sk, const uint32_t* s, const uint32_t* b, size_t nbs, RespBase& rb) {
   pgpu_ctx* ctx = sk->ctx;
-  const int W1 = sk->pk->mn.WT, W = sk->mp3.WT, H = sk->mp.WT;
+  const int W1 = sk->pk->mn.WT, H = sk->mp.WT;
   rb.nbs = nbs;
-  // (both decryptions in one launch: 2 nbs numbers)
-  uint32_t* both = concat2(ctx, zext(ctx, s, W1, 2 * W, nbs), zext(ctx, b, W1, 2 * W, nbs), 2 * W, nbs);
-  int32_t* st2 = ctx->ws_t<int32_t>(2 * nbs);
-  HIPCHK(hipMemsetAsync(st2, 0, 2 * nbs * 4, ctx->stream));
-  const uint32_t* mu = decrypt2_crt(sk, both, 2 * nbs, 2 * nbs, st2);
-  const int W2 = sk->pk->mn2.WT;
-  uint32_t *ms = ctx->ws_t<uint32_t>((size_t)W2 * nbs), *mb = ctx->ws_t<uint32_t>((size_t)W2 * nbs);
-  split2(ctx, mu, 0, W2, nbs, ms);
-  split2(ctx, mu, 1, W2, nbs, mb);
-  rb.mu_s = ms;
-  rb.mu_b = mb;
-  launch_or_flags(st2, count, d_status, PGPU_LANE_NONUNIT, ctx->stream);
-  launch_or_flags(st2 + nbs, count, d_status, PGPU_LANE_NONUNIT, ctx->stream);
   for (int half = 0; half < 2; ++half) {
     const ModCtx& m1 = half ? sk->mq : sk->mp;
     uint32_t *x = ctx->ws_t<uint32_t>((size_t)H * nbs), *y = ctx->ws_t<uint32_t>((size_t)H * nbs);
@@ -660,10 +653,22 @@ void resp_base(const pgpu_seckey* sk, const uint32_t* s, const uint32_t* b, size
     rb.bp[half] = y;
   }
 }
-// per-instance exponents of the response, for EVERY instance (the challenge bits are not known yet): E1 mod n^2, and E1, E2 modulo
+void resp_base_plaintext(const pgpu_seckey* sk, const uint32_t* b, size_t nbs, size_t count, int32_t* d_status, RespBase& rb) {
+  pgpu_ctx* ctx = sk->ctx;
+  const int W1 = sk->pk->mn.WT, W = sk->mp3.WT;
+  rb.nbs = nbs;
+  int32_t* st = ctx->ws_t<int32_t>(nbs);
+  HIPCHK(hipMemsetAsync(st, 0, nbs * 4, ctx->stream));
+  rb.mu_b = decrypt2_crt(sk, zext(ctx, b, W1, 2 * W, nbs), nbs, nbs, st);
+  launch_or_flags(st, count, d_status, PGPU_LANE_NONUNIT, ctx->stream);
+}
+void resp_base(const pgpu_seckey* sk, const uint32_t* s, const uint32_t* b, size_t nbs, size_t count, int32_t* d_status, RespBase& rb) {
+  resp_base_residues(sk, s, b, nbs, rb);
+  resp_base_plaintext(sk, b, nbs, count, d_status, rb);
+}
+// per-instance exponents of the response, for EVERY instance (the challenge bits are not known yet): E1, E2 modulo
 // p - 1 and q - 1 (the odd part through a Montgomery product, the 2-part from the lowest limbs, then the CRT lift)
 struct RespExps {
-  uint32_t* e1n = nullptr;                                          // (xn - an en) mod n^2, mn2.WT limbs
   uint32_t* e1p[2] = {nullptr, nullptr};                            // E1 mod (pr - 1): eo1.w limbs
   uint32_t* e2p[2] = {nullptr, nullptr};                            // E2 mod (pr - 1)
 };
@@ -671,10 +676,6 @@ void resp_exps(const pgpu_seckey* sk, const uint32_t* xn, const uint32_t* an, co
   pgpu_ctx* ctx = sk->ctx;
   const ModCtx& mn2 = sk->pk->mn2;
   const int W2 = mn2.WT;
-  uint32_t* t = ctx->ws_t<uint32_t>((size_t)W2 * nb);
-  modmul_arrays(ctx, mn2, an, en, nb, t);
-  re.e1n = ctx->ws_t<uint32_t>((size_t)W2 * nb);
-  launch_sub_mod(xn, t, mn2.d_nmod, re.e1n, W2, nb, ctx->stream);
   uint32_t* ls = ctx->ws_t<uint32_t>(nb);
   uint32_t* lb = ctx->ws_t<uint32_t>(nb);
   launch_exp_low_combine(xn, an, en, ls, lb, nb, ctx->stream);
@@ -700,11 +701,19 @@ void resp_exps(const pgpu_seckey* sk, const uint32_t* xn, const uint32_t* an, co
   }
   fo.join();
 }
-// c[g] = s^(E1) b^(E2) mod n^3 for the `nb` (compacted) instances with challenge bit 1: sti[g] = statement of instance g (device,
-// nb entries), e1n / en: E1 and e^n modulo n^2 (mn2.WT limbs), e1p / e2p: the exponents modulo p - 1, q - 1 (eo1.w limbs); all stride
+// c[g] = s^(E1) b^(E2) mod n^3 for the `nb` (compacted) instances with challenge bit 1: sti[g] = row of instance g's statement in rb (device,
+// nb entries), en: e^n modulo n^2 (mn2.WT limbs), e1p / e2p: the exponents modulo p - 1, q - 1 (eo1.w limbs); all stride
 // nb.  out: WT(n^3) limbs.  d_status (nb entries, zeroed) is flagged where the lift met a non-unit.
-void struct_response(const pgpu_seckey* sk, const RespBase& rb, const uint32_t* sti, const uint32_t* e1n, const uint32_t* en,
-                     const uint32_t* const e1p[2], const uint32_t* const e2p[2], size_t nb, uint32_t* out, int32_t* d_status) {
+void struct_response(const pgpu_seckey* sk, const RespBase& rb, const uint32_t* sti, const uint32_t* en,
+                     const uint32_t* const e1p[2], const uint32_t* const e2p[2], size_t nb, uint32_t* out, int32_t* d_status,
+                     const std::function<hipEvent_t()>& plaintext_beside = nullptr) {
+  // plaintext_beside: rb.mu_b does not exist yet -- the callback issues its computation on another stream of the context and returns
+  // the event behind it.  It is called right BEHIND the launch of the ladder modulo the primes: that ladder is the critical path (the
+  // lift waits for it) and, inside a prover call, takes compute units of its own (plan::lds_share: 64 workgroups at 8 192 numbers);
+  // the decryption then fills the other CUs and has until the end of the lift.  Issued before the ladder it sits on every CU and the
+  // ladder's workgroups wait for empty ones (9 + 8 ms one after the other); with both launches sharing SIMDs each runs at half speed
+  // (15.5 and 12.8 ms side by side).  And issued before this function's own chains it ends up in a hardware queue in front of one of
+  // them (the runtime maps a process's streams onto four queues).  Only the lane of the closed form waits for the plaintext.
   pgpu_ctx* ctx = sk->ctx;
   const pgpu_pubkey* pk = sk->pk;
   const ModCtx &mn2 = pk->mn2, &mn3 = *pk->mn3;
@@ -715,18 +724,6 @@ void struct_response(const pgpu_seckey* sk, const RespBase& rb, const uint32_t* 
     launch_gather(in, rb.nbs, sti, nb, o, nb, w, ctx->stream);
     return o;
   };
-  // the <1 + n> coordinate on a lane of its own: k = mu_s E1 - mu_b en mod n^2, G = (1 + n)^k
-  uint32_t* G = ctx->ws_t<uint32_t>((size_t)W3 * nb);
-  SideStream g_lane(ctx, 2);
-  g_lane.enter(g_lane.mark());
-  {
-    uint32_t *k1 = ctx->ws_t<uint32_t>((size_t)W2 * nb), *k2 = ctx->ws_t<uint32_t>((size_t)W2 * nb), *kk = ctx->ws_t<uint32_t>((size_t)W2 * nb);
-    modmul_arrays(ctx, mn2, per_number(rb.mu_s, W2), e1n, nb, k1);
-    modmul_arrays(ctx, mn2, per_number(rb.mu_b, W2), en, nb, k2);
-    launch_sub_mod(k1, k2, mn2.d_nmod, kk, W2, nb, ctx->stream);
-    gm2_from_reduced(ctx, pk, kk, nb, G);
-  }
-  g_lane.leave();
   // c modulo the primes: (s mod pr)^(E1) (b mod pr)^(E2), one chain of squarings, two per-number window tables; both halves in one launch
   const int we = sk->eo1_p.w, wb = 4;
   const bool nm4 = ctx->use_nm4 && ctx->use_asm && H == 37 && plan::pair_nm4_fits(nb, H);
@@ -734,39 +731,60 @@ void struct_response(const pgpu_seckey* sk, const RespBase& rb, const uint32_t* 
   uint32_t* mem1[2];
   const uint32_t* dig[2];
   Prog lad[2];
-  Fork f1(ctx);
-  for (int half = 0; half < 2; ++half) {
-    f1.chain(half);
-    mem1[half] = ctx->ws_t<uint32_t>(S1 * (size_t)NS);             // slots (H limbs): 0 s, 1 b, 2 tmp, 3 out, TA.. / TB.. the tables
-    HIPCHK(hipMemcpyAsync(mem1[half], per_number(rb.sp[half], H), S1 * 4, hipMemcpyDeviceToDevice, ctx->stream));
-    HIPCHK(hipMemcpyAsync(mem1[half] + S1, per_number(rb.bp[half], H), S1 * 4, hipMemcpyDeviceToDevice, ctx->stream));
-    // the two exponents of a number one after the other in the rows of `digits`
-    uint32_t* d2 = ctx->ws_t<uint32_t>((size_t)2 * we * nb);
-    HIPCHK(hipMemcpyAsync(d2, e1p[half], (size_t)we * nb * 4, hipMemcpyDeviceToDevice, ctx->stream));
-    HIPCHK(hipMemcpyAsync(d2 + (size_t)we * nb, e2p[half], (size_t)we * nb * 4, hipMemcpyDeviceToDevice, ctx->stream));
-    dig[half] = d2;
-    Prog& pr = lad[half];
-    pr.op(VM_LOAD, 0); pr.op(VM_MULC, C_R2); pr.op(VM_STORE, 0);     // into Montgomery form (the generic kernel's working form)
-    pr.op(VM_LOAD, 1); pr.op(VM_MULC, C_R2); pr.op(VM_STORE, 1);
-    std::vector<PerNumberBase> pn;
-    pn.push_back(PerNumberBase{we, 0, TA, 0});
-    pn.push_back(PerNumberBase{we, 1, TB, (uint32_t)perlane_windows(we, wb)});
-    emit_modexp_multi(pr, pn, wb, {}, 2, 3, (uint32_t)C_ONE_M, nm4);
-    pr.op(VM_LOAD, 3); pr.op(VM_MULC, C_ONE); pr.op(VM_STORE, 3);    // and out of it
-    pr.end();
+  {
+    Fork f1(ctx);
+    for (int half = 0; half < 2; ++half) {
+      f1.chain(half);
+      mem1[half] = ctx->ws_t<uint32_t>(S1 * (size_t)NS);             // slots (H limbs): 0 s, 1 b, 2 tmp, 3 out, TA.. / TB.. the tables
+      HIPCHK(hipMemcpyAsync(mem1[half], per_number(rb.sp[half], H), S1 * 4, hipMemcpyDeviceToDevice, ctx->stream));
+      HIPCHK(hipMemcpyAsync(mem1[half] + S1, per_number(rb.bp[half], H), S1 * 4, hipMemcpyDeviceToDevice, ctx->stream));
+      // the two exponents of a number one after the other in the rows of `digits`
+      uint32_t* d2 = ctx->ws_t<uint32_t>((size_t)2 * we * nb);
+      HIPCHK(hipMemcpyAsync(d2, e1p[half], (size_t)we * nb * 4, hipMemcpyDeviceToDevice, ctx->stream));
+      HIPCHK(hipMemcpyAsync(d2 + (size_t)we * nb, e2p[half], (size_t)we * nb * 4, hipMemcpyDeviceToDevice, ctx->stream));
+      dig[half] = d2;
+      Prog& pr = lad[half];
+      pr.op(VM_LOAD, 0); pr.op(VM_MULC, C_R2); pr.op(VM_STORE, 0);     // into Montgomery form (the generic kernel's working form)
+      pr.op(VM_LOAD, 1); pr.op(VM_MULC, C_R2); pr.op(VM_STORE, 1);
+      std::vector<PerNumberBase> pn;
+      pn.push_back(PerNumberBase{we, 0, TA, 0});
+      pn.push_back(PerNumberBase{we, 1, TB, (uint32_t)perlane_windows(we, wb)});
+      emit_modexp_multi(pr, pn, wb, {}, 2, 3, (uint32_t)C_ONE_M, nm4);
+      pr.op(VM_LOAD, 3); pr.op(VM_MULC, C_ONE); pr.op(VM_STORE, 3);    // and out of it
+      pr.end();
+    }
+    f1.join();
   }
-  f1.join();
   {
     SegSpec sp{&sk->mp, &lad[0], mem1[0], dig[0]}, sq{&sk->mq, &lad[1], mem1[1], dig[1]};
     run_vm(ctx, nb, sp, &sq, true);
   }
+  const hipEvent_t plaintext_ready = plaintext_beside ? plaintext_beside() : nullptr;
+  // the <1 + n> coordinate on a lane of its own, beside the lift: k = - mu_b en mod n^2, G = (1 + n)^k
+  uint32_t* G = ctx->ws_t<uint32_t>((size_t)W3 * nb);
+  // (with the plaintext still in flight the closed form goes to the stream the decryption is on -- the side stream, which has a hardware
+  // queue of its own: on lane 2 it shares a queue with the lane the lift's chains fork to, and the lift would wait for the decryption)
+  SideStream g_lane(ctx, plaintext_beside ? 0 : 2);
+  g_lane.enter(g_lane.mark());
+  if (plaintext_ready) HIPCHK(hipStreamWaitEvent(ctx->stream, plaintext_ready, 0));
+  {
+    uint32_t *k1 = ctx->ws_t<uint32_t>((size_t)W2 * nb), *k2 = ctx->ws_t<uint32_t>((size_t)W2 * nb), *kk = ctx->ws_t<uint32_t>((size_t)W2 * nb);
+    HIPCHK(hipMemsetAsync(k1, 0, (size_t)W2 * nb * 4, ctx->stream));                  // (mu_s E1 = 0 modulo n^2: see resp_base)
+    modmul_arrays(ctx, mn2, per_number(rb.mu_b, W2), en, nb, k2);
+    launch_sub_mod(k1, k2, mn2.d_nmod, kk, W2, nb, ctx->stream);
+    gm2_from_reduced(ctx, pk, kk, nb, G);
+  }
+  g_lane.leave();
   uint32_t* tt[2];
   for (int half = 0; half < 2; ++half) {
     tt[half] = mem1[half] + 3 * S1;
     launch_canon(tt[half], (half ? sk->mq : sk->mp).d_nmod, H, nb, ctx->stream);
   }
   uint32_t* T = ctx->ws_t<uint32_t>((size_t)W3 * nb);
-  teichmueller_lift(sk, tt, nb, d_status, T);
+  {
+    ForceLds lift_lds(ctx, plaintext_beside ? plan::kLateLiftLds : -1);      // (beside the decryption that is still running: plan.hpp)
+    teichmueller_lift(sk, tt, nb, d_status, T);
+  }
   g_lane.join();
   modmul_arrays(ctx, mn3, G, T, nb, out);
 }
@@ -1345,7 +1363,7 @@ struct ProveCall {
   // the response, prepared before the bits are known
   uint32_t *qainv = nullptr, *qani = nullptr;
   int32_t* d_badinv = nullptr;
-  bool any_badinv = false, sb_units = false, early = false, resp_struct = false, one_ladder = false;
+  bool any_badinv = false, sb_units = false, early = false, resp_struct = false, resp_late = false, one_ladder = false;
   const uint8_t* sb_root = nullptr;
   RespBase rbase;
   RespExps rexps;
@@ -1625,11 +1643,17 @@ struct ProveCall {
       // From a few instances per statement on, the response goes through the structure of the unit group (struct_response): the
       // per-statement part -- the level-two "plaintexts" of s and b, s and b modulo the primes -- and every instance's exponents
       // are made here as well.
+      // With few instances per statement the per-statement part waits for the hash (resp_late): only the statements that HAVE an
+      // instance with challenge bit 1 -- half of them at secpar 1 -- get b's plaintext then, beside the ladder modulo the primes;
+      // the exponents of every instance are still made here.  One decryption, one ladder modulo the primes and one lift per bit-1
+      // instance: 64 M multiply-adds where the ladder on s and b themselves needs 103 M, and three latency-bound stages of ~9 ms
+      // (two of them side by side) where that ladder takes 32 ms at 8 192 numbers.
       resp_struct = by_struct && one_ladder && sb_units && plan::response_by_structure(S, batch, nb, plan::lanes_target(ctx->lanes_wanted, ctx->stream_cus));
-      const bool early_cond = one_ladder && sb_units && ctx->use_early && pre_bases_usable(sk) &&
+      resp_late = by_struct && one_ladder && sb_units && !resp_struct && ctx->use_late;
+      const bool early_cond = one_ladder && sb_units && ctx->use_early && pre_bases_usable(sk) && !resp_late &&
                               plan::early_response_ok(nb, sk->mp3.triple.root->WT);
-      if (resp_struct || early_cond) {
-        early = !resp_struct;
+      if (resp_struct || resp_late || early_cond) {
+        early = !resp_struct && !resp_late;
         std::vector<uint32_t> stall(nb, 0);
         for (size_t i = 0; i < batch; ++i) stall[i] = (uint32_t)(i / secpar);
         const uint32_t* d_stall = ctx->upload_words(stall);
@@ -1644,11 +1668,13 @@ struct ProveCall {
         modmul_arrays(ctx, mn2, x2a, ainv_a, nb, ge_all);                     // e = x a^-1 mod n^2 (ddleq.go:94-99)
         uint32_t* en_a = ctx->ws_t<uint32_t>((size_t)W2 * nb);
         modmul_arrays(ctx, mn2, xn, ani_a, nb, en_a);                         // e^n = x^n (a^n)^-1
-        if (resp_struct) {
-          d_st_rstmt = ctx->ws_t<int32_t>(nbs);
-          HIPCHK(hipMemsetAsync(d_st_rstmt, 0, nbs * 4, ctx->stream));
-          resp_base(sk, qs, bl, nbs, S, d_st_rstmt, rbase);
-          HT("resp_base issued");
+        if (resp_struct || resp_late) {
+          if (resp_struct) {
+            d_st_rstmt = ctx->ws_t<int32_t>(nbs);
+            HIPCHK(hipMemsetAsync(d_st_rstmt, 0, nbs * 4, ctx->stream));
+            resp_base(sk, qs, bl, nbs, S, d_st_rstmt, rbase);
+            HT("resp_base issued");
+          }
           en_all = en_a;
           resp_exps(sk, xn, gan_a, en_a, nb, rexps);
           HT("resp_exps issued");
@@ -1716,7 +1742,7 @@ struct ProveCall {
       // s b a unit for every statement?  (never false for honest inputs; if it is, what was prepared for the one-ladder response is dropped)
       HIPCHK(hipStreamSynchronize(ctx->stream));
       sb_units = all_units_end(mn, sb_root);
-      if (!sb_units) early = resp_struct = false;
+      if (!sb_units) early = resp_struct = resp_late = false;
     }
     HT("hash known");
   }
@@ -1765,24 +1791,78 @@ struct ProveCall {
       launch_scatter(ge, nbg, d_idx, cnt, eo, nb, W2, ctx->stream);
       launch_scatter(gf, nbg, d_idx, cnt, fo, nb, W3, ctx->stream);
     };
-    if (resp_struct) {
+    if (resp_struct || resp_late) {
       // through the structure of the unit group: gather the prepared exponents of the bit-1 instances; one ladder modulo the primes, one lift
       uint32_t* ge = gat(ge_all, W2);
       const uint32_t* e1p[2] = {gat(rexps.e1p[0], sk->eo1_p.w), gat(rexps.e1p[1], sk->eo1_q.w)};
       const uint32_t* e2p[2] = {gat(rexps.e2p[0], sk->eo1_p.w), gat(rexps.e2p[1], sk->eo1_q.w)};
       int32_t* d_st_r = ctx->ws_t<int32_t>(nbg);
       HIPCHK(hipMemsetAsync(d_st_r, 0, nbg * 4, ctx->stream));
-      std::vector<uint32_t> sti_pad(sti);
-      sti_pad.resize(nbg, 0);                                            // (padding lanes: statement 0's bases)
+      std::vector<uint32_t> row(sti);                                    // row of each instance's statement in rbase
+      size_t n_rows = S, nbu_late = 0;
+      const uint32_t* b_late = nullptr;
+      hipEvent_t late_inputs = nullptr;
+      // (late: the decryption of b runs on every compute unit the ladder modulo the primes leaves, until the lift is under way: a link of
+      // the main stream's chains that asked for an EMPTY compute unit would wait for its end -- 9 ms, measured)
+      struct NoShortExclusive {
+        pgpu_ctx* c; bool was;
+        NoShortExclusive(pgpu_ctx* c_, bool on) : c(c_), was(c_->use_exclusive_short) { if (on) c->use_exclusive_short = false; }
+        ~NoShortExclusive() { c->use_exclusive_short = was; }
+      } no_short(ctx, resp_late);
+      if (resp_late) {
+        // the statements that have an instance with bit 1, in order (sti is sorted): their s, b gathered, b decrypted NOW
+        std::vector<uint32_t> used;
+        for (size_t i = 0; i < cnt; ++i) {
+          if (used.empty() || used.back() != sti[i]) used.push_back(sti[i]);
+          row[i] = (uint32_t)(used.size() - 1);
+        }
+        n_rows = used.size();
+        const size_t nbu = round_up(n_rows, VM_BLOCK);
+        const uint32_t* d_used = ctx->upload_words(used);
+        uint32_t *s_u = ctx->ws_t<uint32_t>((size_t)W1 * nbu), *b_u = ctx->ws_t<uint32_t>((size_t)W1 * nbu);
+        launch_gather(qs, nbs, d_used, n_rows, s_u, nbu, W1, ctx->stream);
+        launch_gather(bl, nbs, d_used, n_rows, b_u, nbu, W1, ctx->stream);
+        // (padding rows: 1, a unit with plaintext 0)
+        launch_restride(s_u, nbu, n_rows, mn.d_consts + (size_t)C_ONE * W1, s_u, nbu, W1, ctx->stream);
+        launch_restride(b_u, nbu, n_rows, mn.d_consts + (size_t)C_ONE * W1, b_u, nbu, W1, ctx->stream);
+        d_st_rstmt = ctx->ws_t<int32_t>(nbu);
+        HIPCHK(hipMemsetAsync(d_st_rstmt, 0, nbu * 4, ctx->stream));
+        resp_base_residues(sk, s_u, b_u, nbu, rbase);
+        b_late = b_u;
+        nbu_late = nbu;
+        late_inputs = side.mark();                                       // b is gathered: all the decryption waits for
+        // b's plaintext on a lane of its own, beside the ladder modulo the primes of struct_response (which needs the residues only;
+        // its closed form waits for the plaintext)
+      }
+      row.resize(nbg, 0);                                                // (padding lanes: row 0's bases)
       uint32_t* c5 = ctx->ws_t<uint32_t>((size_t)W3 * nbg);
-      struct_response(sk, rbase, ctx->upload_words(sti_pad), gat(rexps.e1n, W2), gat(en_all, W2), e1p, e2p, nbg, c5, d_st_r);
+      std::function<hipEvent_t()> beside;
+      if (resp_late)
+        beside = [&]() -> hipEvent_t {
+          // b's plaintext on the side stream (idle since read_back joined it), beside the ladder modulo the primes
+          hipEvent_t ready = nullptr;
+          side.enter(late_inputs);
+          {
+            ForceLds one_per_cu(ctx, plan::kLateDecryptionLds);
+            resp_base_plaintext(sk, b_late, nbu_late, n_rows, d_st_rstmt, rbase);
+          }
+          if (side.on) {
+            ready = ctx->next_sync_ev();
+            HIPCHK(hipEventRecord(ready, ctx->stream));
+          }
+          side.leave();
+          HT("resp_base issued");
+          return ready;
+        };
+      struct_response(sk, rbase, ctx->upload_words(row), gat(en_all, W2), e1p, e2p, nbg, c5, d_st_r, beside);
+      side.join();
       HT("response issued");
-      std::vector<int32_t> hr(cnt), hs(S);
+      std::vector<int32_t> hr(cnt), hs(n_rows);
       HIPCHK(hipMemcpyAsync(hr.data(), d_st_r, cnt * 4, hipMemcpyDeviceToHost, ctx->stream));
-      HIPCHK(hipMemcpyAsync(hs.data(), d_st_rstmt, S * 4, hipMemcpyDeviceToHost, ctx->stream));
+      HIPCHK(hipMemcpyAsync(hs.data(), d_st_rstmt, n_rows * 4, hipMemcpyDeviceToHost, ctx->stream));
       HIPCHK(hipStreamSynchronize(ctx->stream));
       bool nonunit = false;
-      for (size_t i = 0; i < cnt; ++i) nonunit = nonunit || hr[i] || hs[sti[i]];
+      for (size_t i = 0; i < cnt; ++i) nonunit = nonunit || hr[i] || hs[row[i]];
       if (!nonunit) {
         finish(ge, gat(yl, W1), c5);
         return;

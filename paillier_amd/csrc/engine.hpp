@@ -98,11 +98,14 @@ struct pgpu_ctx {
   bool exclusive_call = false;   // set by a protocol function for the length of a call whose concurrent launches together fit the chip's compute units: every
                                  // workgroup then asks for the whole LDS of a CU, so the dispatcher cannot stack the side lanes' workgroups on the CUs the main
                                  // launch runs on (it starts every queue's workgroups from the same CUs: 17.5 -> 28 ms for a^n | x^n of 2 048 instances)
+  bool use_late = true;      // the DDLEQ prover's response for few instances per statement through the structure of the unit group AFTER the hash: b's plaintext for the statements with a bit-1 instance only (pgpu_ctx_set_flag("late", 0): the one-ladder response on s and b themselves)
   bool use_spread = true;    // a main-stream ladder of at most one workgroup per CU asks for just over half a CU's LDS (plan::lds_share; pgpu_ctx_set_flag("spread", 0): the dispatcher's placement)
   bool use_exclusive_short = true;    // short programs of a prover call take a CU per workgroup too (pgpu_ctx_set_flag("exclusive_short", 0): only ladders do; measured equal -- plan::lds_share)
   uint32_t stream_cus = plan::kChipCUs;   // compute units this context's stream may use (pgpu_ctx_set_flag("cu_partition", ...) narrows it)
   bool use_w74 = true;       // 74-limb two-slice moduli on the wave-sliced assembly kernel (pgpu_ctx_set_flag("w74", 0): four lanes of 37 limbs)
   bool use_exp_order = true; // the key holder's exponents modulo p^3, q^3 reduced modulo the group orders (pgpu_ctx_set_flag("exp_order", 0): as given)
+  int lds_force = -1;        // >= 0: the LDS request of the next assembly launches (set for the length of a scope by protocol code that places
+                             // launches against each other: plan::kLate*; otherwise plan::lds_share decides)
   bool use_background = false;   // the prover's side-lane ladders at wave priority 0 (pgpu_ctx_set_flag("background", 1): measured, no gain -- ddleq.cpp)
   bool background_launch = false; // set around side-lane ladders of a LARGE call (see run_vm): their long programs run at wave priority 0
   bool use_handover = true;  // a power modulo n^2 that is only needed modulo n^2 by the next ladder modulo n^3 stays in pair form: (a0, a1, 0) is its digit form (pgpu_ctx_set_flag("handover", 0): exit and re-entry)
@@ -220,6 +223,12 @@ namespace pgi {
 // inside side work (the root of an inversion tree goes through the host) waits for the side stream only: issue the main
 // stream's long launch BEFORE entering, and it runs meanwhile.  Disabled (ctx->use_side == false): everything stays on the one
 // stream, in program order -- the same results.
+struct ForceLds {            // ctx->lds_force for the length of a scope (value < 0: no change)
+  pgpu_ctx* c; int was;
+  ForceLds(pgpu_ctx* c_, int value) : c(c_), was(c_->lds_force) { if (value >= 0) c->lds_force = value; }
+  ~ForceLds() { c->lds_force = was; }
+};
+
 struct SideStream {
   pgpu_ctx* c;
   hipStream_t main_stream;

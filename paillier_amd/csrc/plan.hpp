@@ -182,6 +182,15 @@ inline int lds_share(uint32_t blocks, uint32_t stream_cus, bool on_side, bool in
   return 0;
 }
 
+// The late response of the prover (ddleq.cpp respond / struct_response): three latency-bound launches of one wave per SIMD or less --
+// the ladder modulo the primes on CUs of its own (lds_share above), b's decryption beside it, the lift behind the ladder while the
+// decryption is still running.  The decryption asks for just over half a CU's LDS: never two of its workgroups on a CU, so that EVERY
+// CU keeps a wave slot (183 VGPRs) for a workgroup of the lift, which keeps the kernel's own LDS size and fits beside it.  (With the
+// dispatcher's placement some CUs get two workgroups of the decryption and a quarter of the lift waits for them: 117 or 124 ms per
+// 16 384-instance call, call by call.)
+constexpr int kLateDecryptionLds = 2;
+constexpr int kLateLiftLds = 0;
+
 // ---- the generic kernels: lanes per number -------------------------------------------------------------------------------------
 // The same WT limbs can be sliced over more lanes (WL/2 limbs x 2K lanes).  The natural shape has the cheapest squarings (K == 1:
 // triangular rows; the wave-sliced two-slice kernels: every limb product once) and a single wave per SIMD already issues at ~88 % of

@@ -471,7 +471,7 @@ void run_vm(pgpu_ctx* ctx, size_t nb, const SegSpec& s0, const SegSpec* s1, bool
   // placement by LDS size (plan::lds_share): a CU per workgroup for the small launches of a call whose launches run beside each other, at
   // most one workgroup per CU for a main-stream ladder that fits the CUs its stream may use
   const bool on_side = ctx->stream == ctx->side || ctx->stream == ctx->side_l[0] || ctx->stream == ctx->side_l[1] || ctx->stream == ctx->side_l[2];
-  const int lds_share = !use_asm ? 0 : plan::lds_share(blocks, ctx->stream_cus, on_side, ctx->exclusive_call, montmuls, ctx->use_exclusive, ctx->use_spread, ctx->use_exclusive_short);
+  const int lds_share = !use_asm ? 0 : ctx->lds_force >= 0 ? ctx->lds_force : plan::lds_share(blocks, ctx->stream_cus, on_side, ctx->exclusive_call, montmuls, ctx->use_exclusive, ctx->use_spread, ctx->use_exclusive_short);
   hipError_t e = use_asm ? launch_vm_asm(WL, K, a, blocks, ctx->stream, lds_share) : launch_vm(WL, K, a, blocks, ctx->stream);
   if (use_asm) ctx->last_vm_asm++;
   ctx->last_vm_launches++;
