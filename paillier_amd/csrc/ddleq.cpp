@@ -569,19 +569,12 @@ void struct_pow_n3(const pgpu_seckey* sk, const StructBase& sb, const uint32_t* 
     launch_gather(in, sb.nbs, sti, nb, o, nb, w, ctx->stream);
     return o;
   };
-  // (1) the <1 + n> coordinate: k = m e mod n^2, G = (1 + n)^k = 1 + k n + C(k, 2) n^2 -- needed only at the very end: a chain of
-  // small kernels on a lane of its own, beside the ladders modulo the primes (one lane per number: a wave slot of every SIMD is free)
-  uint32_t* G = ctx->ws_t<uint32_t>((size_t)W3 * nb);
-  SideStream g_lane(ctx, 2);
-  g_lane.enter(g_lane.mark());
-  if (plaintext_ready) HIPCHK(hipStreamWaitEvent(ctx->stream, plaintext_ready, 0));
-  {
-    uint32_t* kk = ctx->ws_t<uint32_t>((size_t)W2 * nb);
-    modmul_arrays(ctx, mn2, per_number(sb.m, W2), e, nb, kk);
-    gm2_from_reduced(ctx, pk, kk, nb, G);
+  hipEvent_t ladder_inputs = nullptr;                      // "e and y are there": all the closed form needs of this stream
+  if (ctx->use_side) {
+    ladder_inputs = ctx->next_sync_ev();
+    HIPCHK(hipEventRecord(ladder_inputs, ctx->stream));
   }
-  g_lane.leave();
-  // (2) X modulo the primes: interleaved ladders with the exponents modulo p - 1, q - 1, both halves in one launch
+  // (1) X modulo the primes: interleaved ladders with the exponents modulo p - 1, q - 1, both halves in one launch
   // slots (H limbs): 0 ct mod pr, 1 y mod pr, 2 tmp, 3 out, 5 .. the windows of e (number-major where the kernel has VM_MULVT: a
   // limb-major gather reads one dword per 32-byte sector), then the 32 odd powers of y
   const bool nm4 = ctx->use_nm4 && ctx->use_asm && H == 37 && plan::pair_nm4_fits(nb, H);
@@ -609,7 +602,7 @@ void struct_pow_n3(const pgpu_seckey* sk, const StructBase& sb, const uint32_t* 
     SegSpec sp{&sk->mp, &lad[0], mem1[0], ex[0]}, sq{&sk->mq, &lad[1], mem1[1], ex[1]};
     run_vm(ctx, nb, sp, &sq, true);
   }
-  // (3) the lift of X mod n and (4) X = (1 + n)^k * omega(X mod n)
+  // (2) the lift of X mod n
   uint32_t* tt[2];
   for (int half = 0; half < 2; ++half) {
     tt[half] = mem1[half] + 3 * S1;
@@ -617,7 +610,24 @@ void struct_pow_n3(const pgpu_seckey* sk, const StructBase& sb, const uint32_t* 
   }
   uint32_t* T = ctx->ws_t<uint32_t>((size_t)W3 * nb);
   teichmueller_lift(sk, tt, nb, d_status, T);
+  // (3) the <1 + n> coordinate: k = m e mod n^2, G = (1 + n)^k = 1 + k n + C(k, 2) n^2 -- a chain of small kernels on a lane of its
+  // own that waits for the plaintext.  ISSUED here, behind everything the ladder and the lift fork to their lanes: the runtime maps a
+  // process's streams onto four hardware queues (this context has five streams), and a chain that waits for the decryption of ct1
+  // in front of a chain the ladder needs -- in the same queue, by whatever order the streams were created in -- held the ladder back
+  // until the decryption was over (X modulo the primes began 24 ms after a^n | x^n had ended; kernel trace, round 5).  It RUNS as soon
+  // as the plaintext is there, beside the lift.
+  uint32_t* G = ctx->ws_t<uint32_t>((size_t)W3 * nb);
+  SideStream g_lane(ctx, 2);
+  g_lane.enter(ladder_inputs);
+  if (plaintext_ready) HIPCHK(hipStreamWaitEvent(ctx->stream, plaintext_ready, 0));
+  {
+    uint32_t* kk = ctx->ws_t<uint32_t>((size_t)W2 * nb);
+    modmul_arrays(ctx, mn2, per_number(sb.m, W2), e, nb, kk);
+    gm2_from_reduced(ctx, pk, kk, nb, G);
+  }
+  g_lane.leave();
   g_lane.join();
+  // (4) X = (1 + n)^k * omega(X mod n)
   modmul_arrays(ctx, mn3, G, T, nb, out);
 }
 
@@ -1461,6 +1471,14 @@ struct ProveCall {
     by_struct = crt3 && struct_pow_usable(sk);
     if (!by_struct) return;
     Background bg(ctx, ctx->use_background);
+    // (flag "base_early": the links of this chain keep the kernels' own LDS size -- they run beside the a^n | x^n ladders at once
+    // instead of waiting for an EMPTY compute unit, which there is none of before those ladders end; the decryption of ct1 then shares
+    // the SIMDs with them: 246 + 183 VGPRs, a wave of each)
+    struct LinksBeside {
+      pgpu_ctx* c; bool was;
+      LinksBeside(pgpu_ctx* c_, bool on) : c(c_), was(c_->use_exclusive_short) { if (on) c->use_exclusive_short = false; }
+      ~LinksBeside() { c->use_exclusive_short = was; }
+    } links_beside(ctx, ctx->use_base_early);
     d_st_stmt = ctx->ws_t<int32_t>(nbs);
     d_st_num = ctx->ws_t<int32_t>(nt);
     base_lane.enter(inputs_ready);
