@@ -4,9 +4,15 @@
 set -e
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
 o=gpurun_out/r05; mkdir -p $o
-what=${@:-trace sweep floor launches}
+what=${@:-bench trace sweep floor launches}
 for w in $what; do
   case $w in
+    bench)
+      python3 bench.py --gpus 1 --steps 20 --warmup 5 > $o/bench_line.json 2> $o/bench_line.err
+      python3 tools/bench_summary.py $o/bench_line.json | tee $o/bench_summary.txt;;
+    kt) bash tools/prof_r05.sh kernel-trace > $o/prof_kt.txt 2>&1; cp gpurun_out/prof_r05/bench_kernel_stats.csv $o/ || true;;
+    headline) bash tools/prof_r05.sh headline > $o/prof_headline.txt 2>&1; cp gpurun_out/prof_r05/headline_kernel_stats.csv $o/ || true; tail -2 $o/prof_headline.txt | cut -c1-300;;
+    pmc) bash tools/prof_r05.sh pmc > $o/prof_pmc.txt 2>&1; cp gpurun_out/prof_r05/bench_pmc_summary.txt $o/ || true;;
     trace)
       rocprofv3 --kernel-trace --output-format csv -d $o/prove_kt -o t -- python3 tools/prove_only.py 16384 > $o/prove_kt.log 2>&1
       f=$(find $o/prove_kt -name '*kernel_trace.csv' | head -1)
