@@ -576,6 +576,15 @@ def main():
                             "encryptions/s", world * BL, dt, vms, mads, kern, "16384-lane level-two decrypt round trip on every rank"))
         if world == 1:
             checks["encrypt_l2_2048"] = (n2k, lm_h[:32], lr_h[:32], lc[:32].cpu().numpy())
+            # the same call on the SECRET key (SecretKey embeds PublicKey): r^(n^2) mod n^3 as the Teichmueller lift of
+            # (r mod p)^(q^2 mod (p - 1)) (and likewise modulo q^3) -- the same ciphertexts, a fifth of the multiplies
+            lc2 = torch.zeros((BL, 768), dtype=torch.uint8, device=dev)
+            dt_sk, vms_sk, mads_sk, kern_sk = timed(lambda: one_call(lambda: sk2.encrypt_with_r_raw(
+                BL, lm.data_ptr(), 512, lr.data_ptr(), 256, lc2.data_ptr(), 768, MEM_DEVICE, level=1)), ES)
+            assert torch.equal(lc2, lc), "[bench] key holder's level-two EncryptWithR differs from the public path"
+            extras[-1].update({"key_holder_encryptions_per_s": BL / dt_sk, "key_holder_kernel": kern_sk,
+                               "key_holder_executed_mad28_per_unit": mads_sk / BL})
+            del lc2
         del lm, lr, lc, lo
 
         # config 5: DDLEQ prove / verify, 2048-bit, 16384 (statement, instance) pairs IN TOTAL -- strong scaling: the pairs are
