@@ -204,6 +204,17 @@ struct pgpu_ctx {
     pinned_used += bytes;
     return ptr;
   }
+  // The context's four side streams, created TOGETHER and in this order the first time any of them is wanted: the runtime maps a
+  // process's streams onto four hardware queues in the order they are created, so that the fourth and fifth stream of a process share
+  // a queue -- and which two of a context's lanes that is must not depend on which entry point happened to be called first.  (Created
+  // lazily in call order, the verifier's x^(e0) ladder on lane 2 shared a queue with the entry chains on lane 1 whenever a prover call
+  // had come first: 118 ms instead of 75 for 2 048 instances.)  In this order lanes 2 and 3 share: the prover's closed form (lane 2)
+  // waits for the decryption on lane 3 anyway, and nothing else uses lane 3 beside a ladder on lane 2.
+  void ensure_side_streams() {
+    if (side) return;
+    HIPCHK(hipStreamCreateWithFlags(&side, hipStreamNonBlocking));
+    for (auto& l : side_l) HIPCHK(hipStreamCreateWithFlags(&l, hipStreamNonBlocking));
+  }
   ~pgpu_ctx() {
     if (pinned_base) (void)hipHostFree(pinned_base);
     wipe_ws();
@@ -239,7 +250,7 @@ struct SideStream {
   // CHAINS of small kernels -- the entry into digit form of the q-half next to the p-half's, of operand y next to x's; each such
   // kernel fills a fraction of the chip for tens of microseconds, chains side by side take about the time of one.
   explicit SideStream(pgpu_ctx* c_, int lane = 0) : c(c_), main_stream(c_->stream), s(lane ? c_->side_l[lane - 1] : c_->side), on(c_->use_side) {
-    if (on && !s) HIPCHK(hipStreamCreateWithFlags(&s, hipStreamNonBlocking));
+    if (on && !s) c->ensure_side_streams();
     if (on && s == main_stream) on = false;   // (nested use of a lane from inside itself: stay in line)
   }
   hipEvent_t mark() {                       // "everything issued to the main stream so far"
