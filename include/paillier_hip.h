@@ -154,8 +154,10 @@ int pgpu_seckey_has_crt(const pgpu_seckey* sk);
 int pgpu_encrypt_with_r(const pgpu_pubkey* pk, int level, size_t batch, const uint8_t* m, size_t m_stride,
                         const uint8_t* r, size_t r_stride, uint8_t* c, size_t c_stride, int mem);
 /* The same for the holder of the secret key (in the reference SecretKey embeds PublicKey, paillier.go:59-62: sk.EncryptWithR is
- * the same method): r^n mod n^2 through p^2 and q^2.  Identical ciphertexts, a third of the multiplies; level two and keys
- * without the factorisation take the public path. */
+ * the same method).  Level one: r^n mod n^2 through the primes -- t = (r mod p)^(q mod (p - 1)), then the Teichmueller lift t^p mod p^2
+ * (and likewise modulo q^2): a fifth of the public path's multiplies.  Level two: r^(n^2) mod n^3 as the lift modulo p^3, q^3 of
+ * (r mod p)^(q^2 mod (p - 1)): a fifth of the multiplies again; a batch with an r that shares a factor with n takes the public path.
+ * Identical ciphertexts for every input; keys without the factorisation take the public path. */
 int pgpu_encrypt_with_r_sk(const pgpu_seckey* sk, int level, size_t batch, const uint8_t* m, size_t m_stride,
                            const uint8_t* r, size_t r_stride, uint8_t* c, size_t c_stride, int mem);
 
