@@ -141,3 +141,44 @@ def test_generic_one_lane_kernel_number_major_windows(ctx):
     assert got[1] == got[0]
     assert got[1][0][:8] == [_alpha(n, rep(ct1)[i], xs[i], ys[i]) for i in range(8)]
     assert all(pk.VerifyDDLEQInstancesBatch(rep(ct1), rep(ct2), xs, ys, *got[1]))
+
+
+@pytest.mark.parametrize("bits,S,secpar", [(1024, 7, 1), (1024, 5, 2), (2048, 4, 3)])
+def test_late_response_through_the_structure(ctx, bits, S, secpar):
+    """Round 5: with fewer than four instances per statement and a batch that fills the chip the response goes through the structure of
+    the unit group AFTER the hash -- b's plaintext for the statements that have an instance with challenge bit 1 only (flag "late").
+    Small batches take the early form, so the occupancy target is set to one lane ("lanes_wanted" 1: every batch 'fills the chip') to
+    reach the late form here; the proofs must equal the one-ladder response's (late 0), the restatement of proveDDLEQInstance for EVERY
+    instance, and verify.  secpar 2 and 3: several instances share a statement (its s, b gathered once)."""
+    import paillier_amd as pa
+    sk_o, p, q = po.keygen_seeded(bits, bits + 77)
+    n = sk_o.N
+    pk = pa.PublicKey(ctx, n, n + 1)
+    sk = pa.SecretKey(ctx, pk, sk_o.Lambda)
+    rng = random.Random(bits + 7 * S + secpar)
+    ct1, ct2, a_s, b_s = _statements(sk_o, S, rng)
+    xs = [[po.rand_unit(n, rng) for _ in range(secpar)] for _ in range(S)]
+    ys = [[po.rand_unit(n, rng) for _ in range(secpar)] for _ in range(S)]
+    out, launches = {}, {}
+    ctx.set_flag("lanes_wanted", 1)
+    try:
+        for late in (1, 0):
+            ctx.set_flag("late", late)
+            out[late] = sk.ProveDDLEQBatch(secpar, ct1, ct2, a_s, b_s, xs, ys)
+            launches[late] = ctx.last_vm_launches()
+    finally:
+        ctx.set_flag("late", 1)
+        ctx.set_flag("lanes_wanted", 0)
+    assert out[1] == out[0]
+    assert launches[1] != launches[0], "the flag did not change the path: the late form was not reached"
+    al, es, fs = out[1]
+    bits_seen = set()
+    for j in range(S):
+        for k in range(secpar):
+            inst = po.prove_ddleq_instance_xy(sk_o, po.Ciphertext(ct1[j], 1), po.Ciphertext(ct2[j], 1), a_s[j], b_s[j], xs[j][k], ys[j][k])
+            assert (al[j][k], es[j][k], fs[j][k]) == (inst.Alpha, inst.E, inst.F), (j, k)
+            bits_seen.add(inst.E != xs[j][k])
+    assert bits_seen == {True, False}, "the draws must hit both challenge bits: change the seed"
+    flat = lambda v: [x for row in v for x in row]
+    rep = lambda v: [v[j] for j in range(S) for _ in range(secpar)]
+    assert all(pk.VerifyDDLEQInstancesBatch(rep(ct1), rep(ct2), flat(xs), flat(ys), flat(al), flat(es), flat(fs)))
