@@ -585,6 +585,36 @@ def main():
             extras[-1].update({"key_holder_encryptions_per_s": BL / dt_sk, "key_holder_kernel": kern_sk,
                                "key_holder_executed_mad28_per_unit": mads_sk / BL})
             del lc2
+        # level-two Decrypt (paillier.go:292-340 with s = 2: what NestedDecrypt runs first, :344-372) of the ciphertexts just made:
+        # CRT over p^3, q^3 on the three-digit kernel, the recovery algorithm's integers
+        dt, vms, mads, kern = timed(lambda: one_call(lambda: sk2.decrypt_raw(BL, lc.data_ptr(), 768, lo.data_ptr(), 512, MEM_DEVICE, level=1)), ES)
+        all_ranks_ok(torch.equal(lo, lm), "level-two Decrypt: Decrypt(Encrypt(m, r)) != m")
+        extras.append(entry("decrypt_l2_2048", "Batch 16384 level-two Decrypt per GPU, 2048-bit n (c^(p-1) mod p^3, c^(q-1) mod q^3, the "
+                            "Damgard-Jurik recovery, Garner)", "decryptions/s", world * BL, dt, vms, mads, kern,
+                            "16384-lane round trip on every rank"))
+        if world == 1:
+            checks["decrypt_l2_2048"] = (n2k, lam2, lc[:32].cpu().numpy(), lo[:32].cpu().numpy())
+        # NestedAdd (operations.go:121-127): a level-two ciphertext raised to a level-one ciphertext VALUE = ConstMult at level two
+        # with one 4096-bit k per ciphertext
+        nk_h = rand_below(n2k * n2k, BL, 512, np.random.default_rng(61 + 1000 * rank))
+        nk = torch.from_numpy(nk_h).to(dev)
+        no = torch.zeros((BL, 768), dtype=torch.uint8, device=dev)
+        dt, vms, mads, kern = timed(lambda: one_call(lambda: pk2.const_mult_raw(BL, lc.data_ptr(), 768, nk.data_ptr(), 512, 512, no.data_ptr(), 768,
+                                                                                 MEM_DEVICE, level=1)), ES)
+        # parity at full size: Decrypt_2(ct^k) = k * m mod n^2 -- checked through the group law as for ConstMult: ct^k * ct^(2^4096-1-k) == ct^(2^4096-1)
+        nkc = (255 - nk).contiguous()
+        no2 = torch.zeros((BL, 768), dtype=torch.uint8, device=dev)
+        pk2.const_mult_raw(BL, lc.data_ptr(), 768, nkc.data_ptr(), 512, 512, no2.data_ptr(), 768, MEM_DEVICE, level=1)
+        no3 = torch.zeros((BL, 768), dtype=torch.uint8, device=dev)
+        pk2.add_raw(BL, no.data_ptr(), 768, no2.data_ptr(), 768, no3.data_ptr(), 768, MEM_DEVICE, level=1)
+        pk2.const_mult_raw(BL, lc.data_ptr(), 768, np.full(512, 255, dtype=np.uint8), 512, 0, no2.data_ptr(), 768, MEM_DEVICE, level=1)
+        all_ranks_ok(torch.equal(no3, no2), "NestedAdd: ct^k * ct^(2^4096 - 1 - k) != ct^(2^4096 - 1)")
+        extras.append(entry("nested_add_2048", "Batch 16384 NestedAdd per GPU (operations.go:121-127): level-two ciphertext ^ (4096-bit value of a "
+                            "level-one ciphertext) mod n^3 = ConstMult at level two, one k per ciphertext", "ciphertexts/s", world * BL, dt, vms,
+                            mads, kern, "ct^k * ct^(2^4096 - 1 - k) == ct^(2^4096 - 1) on all 16384 lanes"))
+        if world == 1:
+            checks["nested_add_2048"] = (n2k, lc[:16].cpu().numpy(), nk_h[:16], no[:16].cpu().numpy())
+        del nk, nkc, no, no2, no3
         del lm, lr, lc, lo
 
         # config 5: DDLEQ prove / verify, 2048-bit, 16384 (statement, instance) pairs IN TOTAL -- strong scaling: the pairs are
@@ -958,6 +988,20 @@ def main():
             by["encrypt_l2_2048"].update({"parity": by["encrypt_l2_2048"]["parity"] + f"; {len(mh)} ciphertexts == libgmp oracle",
                                           "cpu_per_s": len(mh) / (time.perf_counter() - t), "cpu_threads": min(int(u), len(mh))})
             assert (want == ch).all(), "[bench] level-two Encrypt differs from the libgmp oracle"
+        if "decrypt_l2_2048" in checks:
+            nn, ll, ch, mh = checks["decrypt_l2_2048"]
+            t = time.perf_counter()
+            want, u = go.decrypt_l2_batch_raw(nn, ll, ch, 512, threads=threads)
+            by["decrypt_l2_2048"].update({"parity": by["decrypt_l2_2048"]["parity"] + f"; {len(ch)} plaintexts == libgmp oracle",
+                                          "cpu_per_s": len(ch) / (time.perf_counter() - t), "cpu_threads": min(int(u), len(ch))})
+            assert (want == mh).all(), "[bench] level-two Decrypt differs from the libgmp oracle"
+        if "nested_add_2048" in checks:
+            nn, ch, kh, oh = checks["nested_add_2048"]
+            t = time.perf_counter()
+            want, u = go.const_mult_batch_raw(nn ** 3, ch, kh, 768, threads=threads)
+            by["nested_add_2048"].update({"parity": by["nested_add_2048"]["parity"] + f"; {len(ch)} ciphertexts == libgmp oracle",
+                                          "cpu_per_s": len(ch) / (time.perf_counter() - t), "cpu_threads": min(int(u), len(ch))})
+            assert (want == oh).all(), "[bench] NestedAdd differs from the libgmp oracle"
         if "nested_randomize_2048" in checks:
             nn, (c1h, ah, bh, c2h) = checks["nested_randomize_2048"]
             t = time.perf_counter()

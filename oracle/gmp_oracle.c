@@ -799,4 +799,27 @@ int oracle_share_zkp_verify_batch(const uint8_t* n_be, size_t n_len, const uint8
   return used;
 }
 
+/* paillier.go:292-340 SecretKey.Decrypt at level two (what NestedDecrypt runs first, :344-372) for a batch: decrypt2 above, verbatim. */
+int oracle_decrypt_l2_batch(const uint8_t* n_be, size_t n_len, const uint8_t* lambda_be, size_t l_len, size_t batch, const uint8_t* c,
+                            size_t c_stride, uint8_t* m_out, size_t m_stride, int threads) {
+  mpz_t n, n2, n3, lambda;
+  mpz_inits(n, n2, n3, lambda, NULL);
+  imp(n, n_be, n_len); imp(lambda, lambda_be, l_len);
+  mpz_mul(n2, n, n); mpz_mul(n3, n2, n);
+  int used = 1;
+  ORACLE_PAR_BEGIN(threads, used)
+    mpz_t ci, mi;
+    mpz_inits(ci, mi, NULL);
+    ORACLE_FOR
+    for (long i = 0; i < (long)batch; ++i) {
+      imp(ci, c + (size_t)i * c_stride, c_stride);
+      decrypt2(mi, ci, n, n2, n3, lambda);
+      expo(mi, m_out + (size_t)i * m_stride, m_stride);
+    }
+    mpz_clears(ci, mi, NULL);
+  ORACLE_PAR_END
+  mpz_clears(n, n2, n3, lambda, NULL);
+  return used;
+}
+
 const char* oracle_gmp_version(void) { return gmp_version; }

@@ -21,7 +21,7 @@ def load():
         for name in ("oracle_decrypt_batch", "oracle_encrypt_batch", "oracle_modexp_batch", "oracle_decrypt_crt_batch",
                      "oracle_ddleq_verify_batch", "oracle_ddleq_prove_batch", "oracle_encrypt_l2_batch", "oracle_nested_randomize_batch",
                      "oracle_threshold_decrypt_batch", "oracle_add_sub_batch", "oracle_const_mult_batch", "oracle_alt_encrypt_batch",
-                     "oracle_share_zkp_prove_batch", "oracle_share_zkp_verify_batch"):
+                     "oracle_share_zkp_prove_batch", "oracle_share_zkp_verify_batch", "oracle_decrypt_l2_batch"):
             getattr(_lib, name).restype = C.c_int
     return _lib
 
@@ -241,3 +241,13 @@ def share_zkp_verify_batch_raw(n, vkey, vi, c_buf: np.ndarray, dec_buf: np.ndarr
                                              _p(c_buf), C.c_size_t(c_buf.shape[1]), _p(dec_buf), C.c_size_t(dec_buf.shape[1]), _p(e_buf),
                                              _p(z_buf), C.c_size_t(z_buf.shape[1]), _p(ok), _p(ab) if want_ab else None, threads)
     return (ok, used, ab) if want_ab else (ok, used)
+
+
+def decrypt_l2_batch_raw(n, lam, c_buf: np.ndarray, m_stride: int, threads: int = 1):
+    """paillier.go:292-340 at level two (the recovery algorithm for s = 2): c < n^3 -> m < n^2."""
+    lib = load()
+    nb, lb = _be(n), _be(lam)
+    out = np.zeros((c_buf.shape[0], m_stride), dtype=np.uint8)
+    used = lib.oracle_decrypt_l2_batch(nb, C.c_size_t(len(nb)), lb, C.c_size_t(len(lb)), C.c_size_t(c_buf.shape[0]), _p(c_buf),
+                                       C.c_size_t(c_buf.shape[1]), _p(out), C.c_size_t(m_stride), threads)
+    return out, used

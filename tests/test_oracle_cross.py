@@ -218,3 +218,20 @@ def test_share_zkp_restatement_fixtures_and_reference_kats():
     pd = po.partial_decryption_with_zkp_r(tsk, c1, r1)
     dec, eo, zo, _ = go.share_zkp_prove_batch_raw(n, int(t["total"]), shares[server - 1], v, _be_rows([c1], 512), _be_rows([r1], 512), zs_len)
     assert (_ints(dec), _ints(eo), _ints(zo)) == ([pd.Decryption], [pd.E], [pd.Z]) and po.verify_proof(pd)
+
+
+def test_level_two_decrypt_restatement():
+    """libgmp Decrypt at level two (bench.py's CPU figure beside decrypt_l2_2048) against the Python-int oracle and the committed
+    level-two fixtures, arbitrary elements of Z_{n^3} included (the reference's recovery algorithm on non-ciphertexts)."""
+    K, V, P = _golden()
+    k = K["paillier"]["2048"]
+    n, lam = int(k["n"], 16), int(k["lambda"], 16)
+    sk = po.SecretKey(N=n, G=n + 1, Lambda=lam)
+    l2 = P["level2"]
+    ms, cs = ([int(x, 16) for x in l2[key]] for key in ("m", "c"))
+    out, _ = go.decrypt_l2_batch_raw(n, lam, _be_rows(cs, 768), 512, threads=2)
+    assert _ints(out) == [m % (n * n) for m in ms]
+    rng = random.Random(12)
+    weird = [rng.randrange(n ** 3) for _ in range(3)] + [1, n ** 3 - 1]
+    out, _ = go.decrypt_l2_batch_raw(n, lam, _be_rows(weird, 768), 512)
+    assert _ints(out) == [po.decrypt(sk, po.Ciphertext(c, po.ENC_LEVEL_TWO)) for c in weird]
