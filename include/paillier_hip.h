@@ -98,9 +98,9 @@ int pgpu_ctx_last_profile(pgpu_ctx* ctx, double* vm_ms, int* vm_launches, double
  * ladders on ct1 itself; non-unit inputs always take those); "late" (default 1): with fewer than four instances per statement (and a batch that
  * fills the chip) the prover's response goes through the structure as well, AFTER the hash: the level-two plaintext of b for the statements
  * that have an instance with challenge bit 1 only, one ladder modulo the primes, one lift (0: one ladder of 3 071 squarings modulo p^3, q^3
- * on s and b themselves); "base_early" (default 1): the prover's per-statement structure chain (ct1 modulo the primes, its plaintext) is
- * issued with links that run beside the a^n | x^n ladders instead of waiting for an empty compute unit (0: behind those ladders; measured
- * equal on average, steadier call to call); "exclusive" (default 1): placement by LDS size -- the small concurrent launches
+ * on s and b themselves); "base_early" (default 1): the links of the prover's side chains -- the per-statement structure chain (ct1 modulo
+ * the primes, its plaintext) and the preparation of the response -- run beside the main stream's ladders instead of waiting for an empty
+ * compute unit (0: between those ladders; measured 1 % slower and less steady call to call); "exclusive" (default 1): placement by LDS size -- the small concurrent launches
  * of a prover call (up to 128 workgroups) ask for the whole LDS of a compute unit per workgroup, so that the side lanes' workgroups
  * land on idle CUs instead of the ones the main launch runs on, and a main-stream ladder of at most one workgroup per CU asks for more
  * than half of it, so that it spreads over all CUs (0: the dispatcher's placement); "exclusive_short" (default 1): the links between ladders -- programs of a few

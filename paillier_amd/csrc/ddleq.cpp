@@ -1375,6 +1375,7 @@ struct ProveCall {
   int32_t* d_badinv = nullptr;
   bool any_badinv = false, sb_units = false, early = false, resp_struct = false, resp_late = false, one_ladder = false;
   const uint8_t* sb_root = nullptr;
+  hipEvent_t root_ready = nullptr;
   RespBase rbase;
   RespExps rexps;
   uint32_t* en_all = nullptr;
@@ -1649,6 +1650,10 @@ struct ProveCall {
         // (no wait: the root of the product tree goes to pinned memory and is looked at once the hash is known -- the side lane
         // crawls beside the lifts, and a host that waits for it here issues the response's preparation 35 ms late)
         sb_root = all_units_begin(ctx, mn, sb, nbs, S);
+        if (side.on) {
+          root_ready = ctx->next_sync_ev();
+          HIPCHK(hipEventRecord(root_ready, ctx->stream));
+        }
         sb_units = true;                                     // assumed; checked in read_back, before anything uses the prepared response
         HT("unit test");
       }
@@ -1672,6 +1677,14 @@ struct ProveCall {
                               plan::early_response_ok(nb, sk->mp3.triple.root->WT);
       if (resp_struct || resp_late || early_cond) {
         early = !resp_struct && !resp_late;
+        // (flag "base_early": the links of this preparation run beside the Alpha ladders and the lifts instead of waiting for an EMPTY
+        // compute unit -- there is none while the lifts run, and the main stream then waited 4 ms for this lane after Alpha was known
+        // at secpar 40)
+        struct LinksBeside {
+          pgpu_ctx* c; bool was;
+          LinksBeside(pgpu_ctx* c_, bool on) : c(c_), was(c_->use_exclusive_short) { if (on) c->use_exclusive_short = false; }
+          ~LinksBeside() { c->use_exclusive_short = was; }
+        } links_beside(ctx, ctx->use_base_early);
         std::vector<uint32_t> stall(nb, 0);
         for (size_t i = 0; i < batch; ++i) stall[i] = (uint32_t)(i / secpar);
         const uint32_t* d_stall = ctx->upload_words(stall);
@@ -1710,20 +1723,44 @@ struct ProveCall {
     side.leave();
   }
 
+  // device int32 array -> the host vector, through the context's page-locked scratch where it fits (four copies into pageable memory
+  // are four round trips of ~0.15 ms between the lifts and the response; into pinned memory they are commands of the stream)
+  struct ReadBack { int32_t* pinned; std::vector<int32_t>* dst; size_t n; };
+  std::vector<ReadBack> pending;
+  void fetch(std::vector<int32_t>& dst, const int32_t* dev, size_t n) {
+    dst.resize(n);
+    int32_t* stage = nullptr;
+    if (ctx->pinned_used + n * 4 + 64 <= pgpu_ctx::kPinnedBytes) stage = (int32_t*)ctx->pinned(n * 4);
+    HIPCHK(hipMemcpyAsync(stage ? stage : dst.data(), dev, n * 4, hipMemcpyDeviceToHost, ctx->stream));
+    if (stage) pending.push_back({stage, &dst, n});
+  }
+  void fetched() {                                          // after the stream has been synchronised
+    for (auto& r : pending) memcpy(r.dst->data(), r.pinned, r.n * 4);
+    pending.clear();
+  }
+
   // the host learns the sanity flags, the unit flags of the structure path and the challenge bits
   void read_back() {
     // (a device-to-host copy into pageable memory holds the host until the stream has got there: it comes after the side work
     // has been issued, not before)
-    HIPCHK(hipMemcpyAsync(hok.data(), d_ok, S * 4, hipMemcpyDeviceToHost, ctx->stream));
+    fetch(hok, d_ok, S);
     if (by_struct) {
-      hst_stmt.resize(S);
-      hst_num.resize(nt);
-      HIPCHK(hipMemcpyAsync(hst_stmt.data(), d_st_stmt, S * 4, hipMemcpyDeviceToHost, ctx->stream));
-      HIPCHK(hipMemcpyAsync(hst_num.data(), d_st_num, nt * 4, hipMemcpyDeviceToHost, ctx->stream));
+      fetch(hst_stmt, d_st_stmt, S);
+      fetch(hst_num, d_st_num, nt);
     }
-    if (hash_early) HIPCHK(hipMemcpyAsync(hch.data(), chal, batch * 4, hipMemcpyDeviceToHost, ctx->stream));
+    if (hash_early) fetch(hch, chal, batch);
     HT("side issued");
+    // s b a unit for every statement?  The root of the product tree reaches pinned memory long before Alpha is known: its inversion on
+    // the host (0.4 ms) happens while the device is still in the lifts.  (Never false for honest inputs; if it is, what was prepared
+    // for the one-ladder response is dropped.)
+    bool root_checked = false;
+    if (sb_root && root_ready) {
+      HIPCHK(hipEventSynchronize(root_ready));
+      sb_units = all_units_end(mn, sb_root);
+      root_checked = true;
+    }
     HIPCHK(hipStreamSynchronize(ctx->stream));
+    fetched();
     HT("alpha known");
     if (by_struct) {
       bool nonunit = false;
@@ -1757,9 +1794,10 @@ struct ProveCall {
     HT("flags checked");
     side.join();                                             // the per-statement values are needed from here on
     if (sb_root) {
-      // s b a unit for every statement?  (never false for honest inputs; if it is, what was prepared for the one-ladder response is dropped)
-      HIPCHK(hipStreamSynchronize(ctx->stream));
-      sb_units = all_units_end(mn, sb_root);
+      if (!root_checked) {
+        HIPCHK(hipStreamSynchronize(ctx->stream));
+        sb_units = all_units_end(mn, sb_root);
+      }
       if (!sb_units) early = resp_struct = resp_late = false;
     }
     HT("hash known");

@@ -98,7 +98,7 @@ struct pgpu_ctx {
   bool exclusive_call = false;   // set by a protocol function for the length of a call whose concurrent launches together fit the chip's compute units: every
                                  // workgroup then asks for the whole LDS of a CU, so the dispatcher cannot stack the side lanes' workgroups on the CUs the main
                                  // launch runs on (it starts every queue's workgroups from the same CUs: 17.5 -> 28 ms for a^n | x^n of 2 048 instances)
-  bool use_base_early = true;  // the prover's per-statement structure chain (ct1 modulo the primes, its plaintext) starts beside the a^n | x^n ladders (pgpu_ctx_set_flag("base_early", 0): behind them)
+  bool use_base_early = true;  // the links of the prover's side chains (ct1's structure chain, the preparation of the response) run beside the main stream's ladders (pgpu_ctx_set_flag("base_early", 0): they wait for an empty compute unit, i.e. for the end of a ladder)
   bool use_late = true;      // the DDLEQ prover's response for few instances per statement through the structure of the unit group AFTER the hash: b's plaintext for the statements with a bit-1 instance only (pgpu_ctx_set_flag("late", 0): the one-ladder response on s and b themselves)
   bool use_spread = true;    // a main-stream ladder of at most one workgroup per CU asks for just over half a CU's LDS (plan::lds_share; pgpu_ctx_set_flag("spread", 0): the dispatcher's placement)
   bool use_exclusive_short = true;    // short programs of a prover call take a CU per workgroup too (pgpu_ctx_set_flag("exclusive_short", 0): only ladders do; measured equal -- plan::lds_share)
