@@ -175,7 +175,10 @@ constexpr uint32_t kExclusiveMaxBlocks = 128;
 inline int lds_share(uint32_t blocks, uint32_t stream_cus, bool on_side, bool in_exclusive_call, uint64_t products, bool enabled,
                      bool spread_enabled, bool exclusive_short = true) {
   if (!enabled) return 0;
-  if (in_exclusive_call && blocks <= kExclusiveMaxBlocks && blocks <= stream_cus && (products >= 256 || exclusive_short)) return 1;
+  // (a LINK of the MAIN stream never asks for an empty CU: while a side lane's ladder sits on every CU -- ct1's decryption beside the
+  // a^n | x^n ladders -- the main stream's chain between two of its ladders would wait for it: 9 ms between a^n | x^n and X modulo the
+  // primes instead of 2, kernel trace of round 5)
+  if (in_exclusive_call && blocks <= kExclusiveMaxBlocks && blocks <= stream_cus && (products >= 256 || (exclusive_short && on_side))) return 1;
   // (inside a CU partition the mask already keeps other contexts off these CUs, and the request only delays placement: eight contexts
   // on 32 CUs each, 1 024 / 2 048 ciphertexts per call: 39.4 / 62.1 ms without it, 45.7 / 65.7 ms with it)
   if (spread_enabled && !on_side && stream_cus == kChipCUs && blocks <= stream_cus && products >= 256) return 2;

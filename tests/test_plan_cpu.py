@@ -150,6 +150,8 @@ def test_placement_by_lds_size(q):
     # between ladders (a few products) included unless the flag "exclusive_short" is off
     assert q("lds_share", 64, 256, 1, 1, 12, 1, 1) == [1]
     assert q("lds_share", 64, 256, 1, 1, 12, 1, 1, 0) == [0]
+    assert q("lds_share", 64, 256, 0, 1, 12, 1, 1) == [2] or q("lds_share", 64, 256, 0, 1, 12, 1, 1) == [0]   # a link of the MAIN stream: never a whole CU
+    assert q("lds_share", 64, 256, 0, 1, 12, 1, 1) != [1]
     assert q("lds_share", 64, 256, 1, 1, 4000, 1, 1) == [1]
     assert q("lds_share", 128, 256, 0, 1, 4000, 1, 1) == [1]
     # wider: a main-stream ladder of at most one workgroup per CU spreads (just over half a CU's LDS); a side lane's keeps its size

@@ -49,7 +49,7 @@ for _ in range(int(os.environ.get("PROVE_REPS", "2"))):
         sk.ddleq_prove_raw(B, ct1.data_ptr(), ct2.data_ptr(), da.data_ptr(), db.data_ptr(), dx.data_ptr(), dy.data_ptr(), al.data_ptr(), pe.data_ptr(), pf.data_ptr(), MEM_DEVICE)
     else:
         sk.ddleq_prove_secpar_raw(B, SP, ct1.data_ptr(), ct2.data_ptr(), da.data_ptr(), db.data_ptr(), dx.data_ptr(), dy.data_ptr(), al.data_ptr(), pe.data_ptr(), pf.data_ptr(), MEM_DEVICE)
-    print("prove", B, "x", SP, (time.perf_counter() - t) * 1e3, "ms", ctx.last_profile(), flush=True)
+    print("prove", B, "x", SP, (time.perf_counter() - t) * 1e3, "ms", ctx.last_profile(), "all VM launches of the call:", ctx.last_vm_launches(), flush=True)
 if os.environ.get("PROVE_VERIFY"):
     # every instance against its statement (device-resident pgpu_ddleq_verify; statement rows repeated per instance)
     rep = lambda tns: tns.repeat_interleave(SP, dim=0).contiguous() if SP > 1 else tns
