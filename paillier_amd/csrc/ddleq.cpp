@@ -577,7 +577,11 @@ void struct_pow_n3(const pgpu_seckey* sk, const StructBase& sb, const uint32_t* 
   // (1) X modulo the primes: interleaved ladders with the exponents modulo p - 1, q - 1, both halves in one launch
   // slots (H limbs): 0 ct mod pr, 1 y mod pr, 2 tmp, 3 out, 5 .. the windows of e (number-major where the kernel has VM_MULVT: a
   // limb-major gather reads one dword per 32-byte sector), then the 32 odd powers of y
-  const bool nm4 = ctx->use_nm4 && ctx->use_asm && H == 37 && plan::pair_nm4_fits(nb, H);
+  // (a batch that leaves most SIMDs empty at one lane per number: the primes' four-lane twins, slots of Hs limbs -- PrimeShape; inside a
+  // prover call the decryption of ct1 is still running beside this ladder)
+  const PrimeShape ps = prime_shape(sk, nb, plaintext_ready ? 2 : 1);
+  const size_t Ss = (size_t)ps.Hs * nb;
+  const bool nm4 = ctx->use_nm4 && ctx->use_asm && H == 37 && plan::pair_nm4_fits(nb, ps.Hs);
   uint32_t* mem1[2];
   const uint32_t* ex[2];
   Prog lad[2];
@@ -585,27 +589,26 @@ void struct_pow_n3(const pgpu_seckey* sk, const StructBase& sb, const uint32_t* 
   for (int half = 0; half < 2; ++half) {
     f1.chain(half);
     const ExpOrder& eo = half ? sk->eo1_q : sk->eo1_p;
-    const ModCtx& m1 = half ? sk->mq : sk->mp;
-    mem1[half] = ctx->ws_t<uint32_t>(S1 * 54);
+    mem1[half] = ctx->ws_t<uint32_t>(Ss * 54);
     uint32_t* em = ctx->ws_t<uint32_t>((size_t)eo.modd.WT * nb);
     reduce_mod_wide(ctx, eo.modd, e, W2, em, nb);
     uint32_t* er = ctx->ws_t<uint32_t>((size_t)eo.w * nb);
     launch_exp_order_lift(e, W2, em, eo.modd.WT, eo.m_limbs.d, eo.t, eo.minv, er, eo.w, nb, ctx->stream);
     ex[half] = er;
-    HIPCHK(hipMemcpyAsync(mem1[half], per_number(sb.cpr[half], H), S1 * 4, hipMemcpyDeviceToDevice, ctx->stream));
-    reduce_mod(ctx, m1, y, W1, mem1[half] + S1, nb);
+    prime_slot_fill(ctx, ps, mem1[half], per_number(sb.cpr[half], H), nb);
+    reduce_mod(ctx, *ps.m[half], y, W1, mem1[half] + Ss, nb);
     emit_modexp_dual(lad[half], eo.w, half ? sk->n2_mod_q1 : sk->n2_mod_p1, 0, 1, 2, 3, 5, 5 + (uint32_t)perlane_table_slots(4, nm4), -1, 4, nm4);
     lad[half].end();
   }
   f1.join();
   {
-    SegSpec sp{&sk->mp, &lad[0], mem1[0], ex[0]}, sq{&sk->mq, &lad[1], mem1[1], ex[1]};
+    SegSpec sp{ps.m[0], &lad[0], mem1[0], ex[0]}, sq{ps.m[1], &lad[1], mem1[1], ex[1]};
     run_vm(ctx, nb, sp, &sq, true);
   }
   // (2) the lift of X mod n
   uint32_t* tt[2];
   for (int half = 0; half < 2; ++half) {
-    tt[half] = mem1[half] + 3 * S1;
+    tt[half] = mem1[half] + 3 * Ss;
     launch_canon(tt[half], (half ? sk->mq : sk->mp).d_nmod, H, nb, ctx->stream);
   }
   uint32_t* T = ctx->ws_t<uint32_t>((size_t)W3 * nb);
@@ -672,6 +675,26 @@ void resp_base_plaintext(const pgpu_seckey* sk, const uint32_t* b, size_t nbs, s
   rb.mu_b = decrypt2_crt(sk, zext(ctx, b, W1, 2 * W, nbs), nbs, nbs, st);
   launch_or_flags(st, count, d_status, PGPU_LANE_NONUNIT, ctx->stream);
 }
+// ct's and b's level-two plaintexts per statement in ONE decryption of 2 nbs numbers (a prover call that will take the response through
+// the structure whatever the challenge bits turn out to be: both are inputs of the call, and a second latency-bound launch of the
+// same kernel later -- behind s and the inversions on the side stream -- was the end of the critical path at 4 096 instances)
+void struct_and_resp_plaintexts(const pgpu_seckey* sk, const uint32_t* ct, const uint32_t* b, size_t nbs, size_t count, int32_t* d_status_ct,
+                                int32_t* d_status_b, StructBase& sb, RespBase& rb) {
+  pgpu_ctx* ctx = sk->ctx;
+  const int W1 = sk->pk->mn.WT, W2 = sk->pk->mn2.WT, W3 = sk->pk->mn3->WT, W = sk->mp3.WT;
+  sb.nbs = rb.nbs = nbs;
+  uint32_t* both = concat2(ctx, zext(ctx, ct, W3, 2 * W, nbs), zext(ctx, b, W1, 2 * W, nbs), 2 * W, nbs);
+  int32_t* st = ctx->ws_t<int32_t>(2 * nbs);
+  HIPCHK(hipMemsetAsync(st, 0, 2 * nbs * 4, ctx->stream));
+  const uint32_t* m2 = decrypt2_crt(sk, both, 2 * nbs, 2 * nbs, st);
+  uint32_t *m = ctx->ws_t<uint32_t>((size_t)W2 * nbs), *mu = ctx->ws_t<uint32_t>((size_t)W2 * nbs);
+  split2(ctx, m2, 0, W2, nbs, m);
+  split2(ctx, m2, 1, W2, nbs, mu);
+  sb.m = m;
+  rb.mu_b = mu;
+  launch_or_flags(st, count, d_status_ct, PGPU_LANE_NONUNIT, ctx->stream);
+  launch_or_flags(st + nbs, count, d_status_b, PGPU_LANE_NONUNIT, ctx->stream);
+}
 void resp_base(const pgpu_seckey* sk, const uint32_t* s, const uint32_t* b, size_t nbs, size_t count, int32_t* d_status, RespBase& rb) {
   resp_base_residues(sk, s, b, nbs, rb);
   resp_base_plaintext(sk, b, nbs, count, d_status, rb);
@@ -736,7 +759,9 @@ void struct_response(const pgpu_seckey* sk, const RespBase& rb, const uint32_t* 
   };
   // c modulo the primes: (s mod pr)^(E1) (b mod pr)^(E2), one chain of squarings, two per-number window tables; both halves in one launch
   const int we = sk->eo1_p.w, wb = 4;
-  const bool nm4 = ctx->use_nm4 && ctx->use_asm && H == 37 && plan::pair_nm4_fits(nb, H);
+  const PrimeShape ps = prime_shape(sk, nb);                          // (few numbers: four lanes per number, slots of Hs limbs)
+  const size_t Ss = (size_t)ps.Hs * nb;
+  const bool nm4 = ctx->use_nm4 && ctx->use_asm && H == 37 && plan::pair_nm4_fits(nb, ps.Hs);
   const uint32_t TA = 5, TB = TA + (uint32_t)perlane_table_slots(wb, nm4), NS = TB + (uint32_t)perlane_table_slots(wb, nm4);
   uint32_t* mem1[2];
   const uint32_t* dig[2];
@@ -745,9 +770,9 @@ void struct_response(const pgpu_seckey* sk, const RespBase& rb, const uint32_t* 
     Fork f1(ctx);
     for (int half = 0; half < 2; ++half) {
       f1.chain(half);
-      mem1[half] = ctx->ws_t<uint32_t>(S1 * (size_t)NS);             // slots (H limbs): 0 s, 1 b, 2 tmp, 3 out, TA.. / TB.. the tables
-      HIPCHK(hipMemcpyAsync(mem1[half], per_number(rb.sp[half], H), S1 * 4, hipMemcpyDeviceToDevice, ctx->stream));
-      HIPCHK(hipMemcpyAsync(mem1[half] + S1, per_number(rb.bp[half], H), S1 * 4, hipMemcpyDeviceToDevice, ctx->stream));
+      mem1[half] = ctx->ws_t<uint32_t>(Ss * (size_t)NS);             // slots (H limbs): 0 s, 1 b, 2 tmp, 3 out, TA.. / TB.. the tables
+      prime_slot_fill(ctx, ps, mem1[half], per_number(rb.sp[half], H), nb);
+      prime_slot_fill(ctx, ps, mem1[half] + Ss, per_number(rb.bp[half], H), nb);
       // the two exponents of a number one after the other in the rows of `digits`
       uint32_t* d2 = ctx->ws_t<uint32_t>((size_t)2 * we * nb);
       HIPCHK(hipMemcpyAsync(d2, e1p[half], (size_t)we * nb * 4, hipMemcpyDeviceToDevice, ctx->stream));
@@ -766,7 +791,7 @@ void struct_response(const pgpu_seckey* sk, const RespBase& rb, const uint32_t* 
     f1.join();
   }
   {
-    SegSpec sp{&sk->mp, &lad[0], mem1[0], dig[0]}, sq{&sk->mq, &lad[1], mem1[1], dig[1]};
+    SegSpec sp{ps.m[0], &lad[0], mem1[0], dig[0]}, sq{ps.m[1], &lad[1], mem1[1], dig[1]};
     run_vm(ctx, nb, sp, &sq, true);
   }
   const hipEvent_t plaintext_ready = plaintext_beside ? plaintext_beside() : nullptr;
@@ -787,7 +812,7 @@ void struct_response(const pgpu_seckey* sk, const RespBase& rb, const uint32_t* 
   g_lane.leave();
   uint32_t* tt[2];
   for (int half = 0; half < 2; ++half) {
-    tt[half] = mem1[half] + 3 * S1;
+    tt[half] = mem1[half] + 3 * Ss;
     launch_canon(tt[half], (half ? sk->mq : sk->mp).d_nmod, H, nb, ctx->stream);
   }
   uint32_t* T = ctx->ws_t<uint32_t>((size_t)W3 * nb);
@@ -1468,8 +1493,18 @@ struct ProveCall {
   // everything behind it, the plaintext of ct1 is needed after the lifts, s after the hash.  Measured with the main launch spread over
   // the CUs (run_vm): 16 384 instances 130.4 ms without, 132.6 +- 4 with -- what a^n | x^n gains, the ladder modulo the primes and the
   // lifts lose to the side launches that are still running beside them; secpar 40 the same within noise.  Off by default.)
+  // whether the response will go through the structure with its per-statement part made BEFORE the hash (plan::response_by_structure:
+  // from four instances per statement, and for small calls): decided here, before the structure chain of ct1, which then takes b's
+  // plaintext along in its decryption
+  void plan_response() {
+    one_ladder = crt3 && ctx->use_lift && sk->eo_p.ok && sk->eo_q.ok && sk->eo_p.w == sk->eo_q.w && W2 <= 2 * sk->eo_p.modd.WT &&
+                 W2 <= 2 * sk->eo_q.modd.WT;
+    resp_struct = by_struct && one_ladder && plan::response_by_structure(S, batch, nb, plan::lanes_target(ctx->lanes_wanted, ctx->stream_cus));
+  }
+
   void structure_base() {
     by_struct = crt3 && struct_pow_usable(sk);
+    plan_response();
     if (!by_struct) return;
     Background bg(ctx, ctx->use_background);
     // (flag "base_early": the links of this chain keep the kernels' own LDS size -- they run beside the a^n | x^n ladders at once
@@ -1490,7 +1525,13 @@ struct ProveCall {
       residues_ready = ctx->next_sync_ev();
       HIPCHK(hipEventRecord(residues_ready, ctx->stream));
     }
-    struct_base_plaintext(sk, c1s, nbs, S, d_st_stmt, sbase);
+    if (resp_struct) {
+      d_st_rstmt = ctx->ws_t<int32_t>(nbs);
+      HIPCHK(hipMemsetAsync(d_st_rstmt, 0, nbs * 4, ctx->stream));
+      struct_and_resp_plaintexts(sk, c1s, bl, nbs, S, d_st_stmt, d_st_rstmt, sbase, rbase);
+    } else {
+      struct_base_plaintext(sk, c1s, nbs, S, d_st_stmt, sbase);
+    }
     if (base_lane.on) {
       plaintext_ready = ctx->next_sync_ev();
       HIPCHK(hipEventRecord(plaintext_ready, ctx->stream));
@@ -1630,8 +1671,6 @@ struct ProveCall {
     qainv = ctx->ws_t<uint32_t>((size_t)W2 * nbs);
     qani = ctx->ws_t<uint32_t>((size_t)W2 * nbs);
     d_badinv = ctx->ws_t<int32_t>(2 * nbs);
-    one_ladder = crt3 && ctx->use_lift && sk->eo_p.ok && sk->eo_q.ok && sk->eo_p.w == sk->eo_q.w && W2 <= 2 * sk->eo_p.modd.WT &&
-                 W2 <= 2 * sk->eo_q.modd.WT;
     side.enter(an_ready);
     {
       uint32_t* a1 = ctx->ws_t<uint32_t>((size_t)W1 * nbs);
@@ -1671,7 +1710,7 @@ struct ProveCall {
       // the exponents of every instance are still made here.  One decryption, one ladder modulo the primes and one lift per bit-1
       // instance: 64 M multiply-adds where the ladder on s and b themselves needs 103 M, and three latency-bound stages of ~9 ms
       // (two of them side by side) where that ladder takes 32 ms at 8 192 numbers.
-      resp_struct = by_struct && one_ladder && sb_units && plan::response_by_structure(S, batch, nb, plan::lanes_target(ctx->lanes_wanted, ctx->stream_cus));
+      resp_struct = resp_struct && sb_units;          // (planned in plan_response; b's plaintext came with ct1's: structure_base)
       resp_late = by_struct && one_ladder && sb_units && !resp_struct && ctx->use_late;
       const bool early_cond = one_ladder && sb_units && ctx->use_early && pre_bases_usable(sk) && !resp_late &&
                               plan::early_response_ok(nb, sk->mp3.triple.root->WT);
@@ -1701,9 +1740,7 @@ struct ProveCall {
         modmul_arrays(ctx, mn2, xn, ani_a, nb, en_a);                         // e^n = x^n (a^n)^-1
         if (resp_struct || resp_late) {
           if (resp_struct) {
-            d_st_rstmt = ctx->ws_t<int32_t>(nbs);
-            HIPCHK(hipMemsetAsync(d_st_rstmt, 0, nbs * 4, ctx->stream));
-            resp_base(sk, qs, bl, nbs, S, d_st_rstmt, rbase);
+            resp_base_residues(sk, qs, bl, nbs, rbase);           // (the plaintext of b: structure_base, on ct1's lane)
             HT("resp_base issued");
           }
           en_all = en_a;

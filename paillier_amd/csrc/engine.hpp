@@ -99,6 +99,7 @@ struct pgpu_ctx {
                                  // workgroup then asks for the whole LDS of a CU, so the dispatcher cannot stack the side lanes' workgroups on the CUs the main
                                  // launch runs on (it starts every queue's workgroups from the same CUs: 17.5 -> 28 ms for a^n | x^n of 2 048 instances)
   bool use_base_early = true;  // the links of the prover's side chains (ct1's structure chain, the preparation of the response) run beside the main stream's ladders (pgpu_ctx_set_flag("base_early", 0): they wait for an empty compute unit, i.e. for the end of a ladder)
+  bool use_prime_lanes = true;   // ladders modulo the 37-limb primes of small batches on four lanes per number (pgpu_ctx_set_flag("prime_lanes", 0): one lane, the unrolled kernel)
   bool use_late = true;      // the DDLEQ prover's response for few instances per statement through the structure of the unit group AFTER the hash: b's plaintext for the statements with a bit-1 instance only (pgpu_ctx_set_flag("late", 0): the one-ladder response on s and b themselves)
   bool use_spread = true;    // a main-stream ladder of at most one workgroup per CU asks for just over half a CU's LDS (plan::lds_share; pgpu_ctx_set_flag("spread", 0): the dispatcher's placement)
   bool use_exclusive_short = true;    // short programs of a prover call take a CU per workgroup too (pgpu_ctx_set_flag("exclusive_short", 0): only ladders do; measured equal -- plan::lds_share)
@@ -373,13 +374,18 @@ struct ModCtx {
     return false;
   }
 
-  void init(pgpu_ctx* c, const BigU& n) {
+  // wl, k: a shape other than the narrowest that holds the modulus (the four-lane twins of the 37-limb primes, plan::prime_lanes)
+  void init(pgpu_ctx* c, const BigU& n, int wl = 0, int k = 0) {
     ctx = c;
     N = n;
     if (!N.is_odd() || N.bit_length() < 2) api_throw(PGPU_ERR_INVALID, "modulus must be odd and at least 3");
     nbits = N.bit_length();
     nbytes = (nbits + 7) / 8;
-    if (!pick_shape(nbits, WL, K)) api_throw(PGPU_ERR_UNSUPPORTED, "modulus wider than 9405 bits is not built");
+    if (wl) {
+      if (nbits + 3 > (size_t)LB * wl * k) api_throw(PGPU_ERR_INVALID, "internal: the modulus does not fit the shape asked for");
+      WL = wl;
+      K = k;
+    } else if (!pick_shape(nbits, WL, K)) api_throw(PGPU_ERR_UNSUPPORTED, "modulus wider than 9405 bits is not built");
     WT = WL * K;
     R = hostbig::shl(BigU(1), (size_t)LB * WT);
     uint32_t n0 = N.d[0], x = n0;  // Newton: x = n0^-1 mod 2^32
@@ -531,6 +537,17 @@ struct SegSpec {
   const uint32_t* tconsts = nullptr;
 };
 
+// The moduli the ladders modulo the primes of `nb` numbers run on (plan::prime_lanes): the key's p, q as they are -- one lane per number
+// -- or their four-lane twins, whose slots are Hs = 40 limbs wide.  A residue stays an H-limb array either way: the first H rows of a
+// twin's slot ARE that array (limb-major; a lazy value below 2 p has nothing in the rows above), and prime_slot_fill zeroes the rows
+// above a residue that goes in.
+struct PrimeShape {
+  const ModCtx* m[2] = {nullptr, nullptr};
+  int H = 0, Hs = 0;
+};
+PrimeShape prime_shape(const pgpu_seckey* sk, size_t nb, int beside = 1);     // beside: plan::prime_lanes
+void prime_slot_fill(pgpu_ctx* ctx, const PrimeShape& ps, uint32_t* slot, const uint32_t* src, size_t nb);
+
 // launch one VM kernel with 1 to 3 segments of `nb` numbers each (same modulus shape; s2 only together with s1)
 void run_vm(pgpu_ctx* ctx, size_t nb, const SegSpec& s0, const SegSpec* s1, bool profile, size_t launch_nb = 0,
             const SegSpec* s2 = nullptr);
@@ -637,6 +654,10 @@ struct pgpu_seckey {
   bool has_crt = false;
   BigU p, q;
   ModCtx mp, mq, mp2, mq2;       // moduli p, q, p^2, q^2
+  // the 37-limb primes of a 2048-bit key once more as 40-limb moduli in four lanes of 10 (the standard constants only): ladders
+  // modulo the primes of batches that leave most of the chip empty at one lane per number (plan::prime_lanes, PrimeShape)
+  bool has_sliced_primes = false;
+  ModCtx mp_s, mq_s;
   int c_hpR = -1, c_hqR = -1;    // constants: hp*R mod p in mp, hq*R mod q in mq
   int c_pinvR = -1;              // p^-1 * R mod q in mq
   DevLimbs pinv2k, qinv2k;       // p^-1 mod 2^(28 mp.WT), q^-1 mod 2^(28 mq.WT)

@@ -3837,7 +3837,7 @@ class GenQ3(LaneRows, Gen):
         return "\n".join(self.lines) + "\n"
 
 
-SHAPES = [(74, 1), (37, 1), (55, 1), (55, 2), (74, 2), (55, 4), (74, 4), (42, 8), (37, 2), (37, 4), (37, 16), (55, 16), (74, 32), (55, 32), (37, 32), (37, 64), (19, 96), (74, 48), (37, 48), (55, 48), (55, 112), (37, 112)]
+SHAPES = [(74, 1), (37, 1), (55, 1), (55, 2), (74, 2), (55, 4), (74, 4), (42, 8), (37, 2), (37, 4), (10, 4), (37, 16), (55, 16), (74, 32), (55, 32), (37, 32), (37, 64), (19, 96), (74, 48), (37, 48), (55, 48), (55, 112), (37, 112)]
 PAIR = {(37, 16), (55, 16)}  # (H, 16): the pair kernel for N = p^2 with H-limb p (GenP); 16 is a tag, not a lane count
 PAIR4 = {(37, 64)}          # (WL, 64): GenQ4, the two digits of GenQ(2 WL) sliced over two lanes each
 PAIR8 = {(19, 96)}          # (WL, 96): GenQ8, the two digits sliced over four lanes each (76-limb digits)
@@ -3870,6 +3870,13 @@ def make_gen(wl, k):
         # the one-lane 37-limb kernel runs the key holder's ladders modulo the primes of a 2048-bit key with per-number exponents
         # (struct_pow_n3): unrolled products, number-major window tables (a limb-major gather reads one dword per 32-byte sector)
         return GenM(wl)
+    if (wl, k) == (10, 4):
+        # the same 37-limb primes as 40-limb moduli in four lanes per number: ladders modulo the primes of batches too small to fill
+        # the chip with one lane per number (plan::prime_lanes) -- a product is 40 rows of 20 multiplies where the one-lane kernel
+        # has 2 053 - 2 738 in a row, and the ladder's latency is the run time there
+        g = Gen(wl, k)
+        g.nm4_tables = True
+        return g
     return Gen(wl, k)
 
 

@@ -162,6 +162,7 @@ hipError_t launch_vm(int wl, int k, const VmArgs& a, uint32_t blocks, hipStream_
   if (wl == 74 && k == 4) return launch_vm_t<74, 4>(a, blocks, st);
   if (wl == 37 && k == 2) return launch_vm_t<37, 2>(a, blocks, st);
   if (wl == 37 && k == 4) return launch_vm_t<37, 4>(a, blocks, st);
+  if (wl == 10 && k == 4) return launch_vm_t<10, 4>(a, blocks, st);   // 37-limb primes in four lanes per number (plan::prime_lanes)
   if (wl == 42 && k == 8) return launch_vm_t<42, 8>(a, blocks, st);   // n^3 of 3072-bit keys (9 216 bits): eight lanes per number
   return hipErrorInvalidValue;
 }

@@ -287,6 +287,13 @@ int pgpu_seckey_create(pgpu_ctx* ctx, const pgpu_pubkey* pk, const uint8_t* lamb
         sk->mq.upload();
         sk->mp2.upload();
         sk->mq2.upload();
+        if (sk->mp.WL == 37 && sk->mp.K == 1 && p.bit_length() + 3 <= (size_t)LB * 40) {
+          sk->mp_s.init(ctx, p, 10, 4);
+          sk->mq_s.init(ctx, q, 10, 4);
+          sk->mp_s.upload();
+          sk->mq_s.upload();
+          sk->has_sliced_primes = true;
+        }
         sk->pinv2k.set(inv_mod_pow2(p, (size_t)LB * sk->mp.WT), sk->mp.WT);
         sk->qinv2k.set(inv_mod_pow2(q, (size_t)LB * sk->mq.WT), sk->mq.WT);
         sk->p_limbs.set(p, sk->mp.WT);

@@ -123,15 +123,33 @@ uint32_t* decrypt1_crt(const pgpu_seckey* sk, const uint32_t* c_limbs, size_t nb
 
 // base^e mod n for a holder of the factorisation: ladders modulo p and q (half the width, exponents modulo p - 1 and
 // q - 1) in one two-segment launch, then Garner as in decrypt1_crt.  base: canonical, mn.WT limbs.  Returns mn.WT limbs.
+PrimeShape prime_shape(const pgpu_seckey* sk, size_t nb, int beside) {
+  pgpu_ctx* ctx = sk->ctx;
+  PrimeShape ps;
+  ps.H = sk->mp.WT;
+  const bool sliced = plan::prime_lanes(nb, plan::lanes_target(ctx->lanes_wanted, ctx->stream_cus), sk->has_sliced_primes, ctx->use_prime_lanes, beside) == 4;
+  ps.m[0] = sliced ? &sk->mp_s : &sk->mp;
+  ps.m[1] = sliced ? &sk->mq_s : &sk->mq;
+  ps.Hs = ps.m[0]->WT;
+  return ps;
+}
+void prime_slot_fill(pgpu_ctx* ctx, const PrimeShape& ps, uint32_t* slot, const uint32_t* src, size_t nb) {
+  HIPCHK(hipMemcpyAsync(slot, src, (size_t)ps.H * nb * 4, hipMemcpyDeviceToDevice, ctx->stream));
+  if (ps.Hs > ps.H) HIPCHK(hipMemsetAsync(slot + (size_t)ps.H * nb, 0, (size_t)(ps.Hs - ps.H) * nb * 4, ctx->stream));
+}
+
 uint32_t* pow_n_crt(const pgpu_seckey* sk, const uint32_t* base, const BigU& e, size_t nb) {
   pgpu_ctx* ctx = sk->ctx;
   const ModCtx &mp = sk->mp, &mq = sk->mq;
+  // (on a side lane -- s of the DDLEQ prover -- the ladder runs beside the main stream's and ct1's decryption)
+  const bool on_side = ctx->stream == ctx->side || ctx->stream == ctx->side_l[0] || ctx->stream == ctx->side_l[1] || ctx->stream == ctx->side_l[2];
+  const PrimeShape ps = prime_shape(sk, nb, on_side ? 4 : 1);
   const int W1 = mp.WT, WN = sk->pk->mn.WT;
-  const size_t S1 = (size_t)W1 * nb;
+  const size_t S1 = (size_t)W1 * nb, Ss = (size_t)ps.Hs * nb;
   // slots per half: 0 in, 2 tmp, 3 out, 5..36 table
-  uint32_t *memp = ctx->ws_t<uint32_t>(S1 * 37), *memq = ctx->ws_t<uint32_t>(S1 * 37);
-  reduce_mod(ctx, mp, base, WN, memp, nb);
-  reduce_mod(ctx, mq, base, WN, memq, nb);
+  uint32_t *memp = ctx->ws_t<uint32_t>(Ss * 37), *memq = ctx->ws_t<uint32_t>(Ss * 37);
+  reduce_mod(ctx, *ps.m[0], base, WN, memp, nb);
+  reduce_mod(ctx, *ps.m[1], base, WN, memq, nb);
   auto half_exp = [&](const BigU& pr) {
     const BigU ord = pr - BigU(1);
     BigU r = e % ord;
@@ -143,12 +161,12 @@ uint32_t* pow_n_crt(const pgpu_seckey* sk, const uint32_t* base, const BigU& e, 
   pp.end();
   emit_modexp_shared(pq, half_exp(sk->q), 0, NO_SLOT, 2, 3, 5, NO_SLOT, true);
   pq.end();
-  SegSpec sp{&mp, &pp, memp, nullptr}, sq{&mq, &pq, memq, nullptr};
+  SegSpec sp{ps.m[0], &pp, memp, nullptr}, sq{ps.m[1], &pq, memq, nullptr};
   run_vm(ctx, nb, sp, &sq, true);
   // small memory: 2 x_p, 3 x_q, 4 B, 5 A, 6 h
   uint32_t* m1 = ctx->ws_t<uint32_t>(S1 * 7);
-  HIPCHK(hipMemcpyAsync(m1 + 2 * S1, memp + 3 * S1, S1 * 4, hipMemcpyDeviceToDevice, ctx->stream));
-  HIPCHK(hipMemcpyAsync(m1 + 3 * S1, memq + 3 * S1, S1 * 4, hipMemcpyDeviceToDevice, ctx->stream));
+  HIPCHK(hipMemcpyAsync(m1 + 2 * S1, memp + 3 * Ss, S1 * 4, hipMemcpyDeviceToDevice, ctx->stream));
+  HIPCHK(hipMemcpyAsync(m1 + 3 * S1, memq + 3 * Ss, S1 * 4, hipMemcpyDeviceToDevice, ctx->stream));
   launch_canon(m1 + 2 * S1, mp.d_nmod, W1, nb, ctx->stream);     // one integer x_p in both places it is used
   launch_canon(m1 + 3 * S1, mq.d_nmod, W1, nb, ctx->stream);
   Prog c;
@@ -197,11 +215,14 @@ bool power_residues(const pgpu_seckey* sk, const uint32_t* base, int k, size_t n
   pgpu_ctx* ctx = sk->ctx;
   BigU r[2];
   if (!power_residues_usable(sk, k, r)) return false;
-  const ModCtx &mp = sk->mp, &mq = sk->mq;
-  const int H = mp.WT, WN = sk->pk->mn.WT;
-  const size_t S1 = (size_t)H * nb;
-  // slots per half (H limbs): 0 in, 2 tmp, 3 out, 5..36 the odd powers of the sliding windows
-  uint32_t *memp = ctx->ws_t<uint32_t>(S1 * 37), *memq = ctx->ws_t<uint32_t>(S1 * 37);
+  // (inside a prover call the structure chain of ct1 -- its decryption -- starts beside this ladder: 8 192 numbers on four lanes took
+  // 8.8 ms there, 4.5 alone, 5.8 on one lane)
+  const PrimeShape ps = prime_shape(sk, nb, ctx->exclusive_call ? 2 : 1);
+  const ModCtx &mp = *ps.m[0], &mq = *ps.m[1];
+  const int H = sk->mp.WT, WN = sk->pk->mn.WT;
+  const size_t Ss = (size_t)ps.Hs * nb;
+  // slots per half (H limbs; Hs on the four-lane twins): 0 in, 2 tmp, 3 out, 5..36 the odd powers of the sliding windows
+  uint32_t *memp = ctx->ws_t<uint32_t>(Ss * 37), *memq = ctx->ws_t<uint32_t>(Ss * 37);
   reduce_mod(ctx, mp, base, WN, memp, nb);
   reduce_mod(ctx, mq, base, WN, memq, nb);
   Prog pp, pq;
@@ -211,10 +232,10 @@ bool power_residues(const pgpu_seckey* sk, const uint32_t* base, int k, size_t n
   pq.end();
   SegSpec sp{&mp, &pp, memp, nullptr}, sq{&mq, &pq, memq, nullptr};
   run_vm(ctx, nb, sp, &sq, true);
-  t[0] = memp + 3 * S1;
-  t[1] = memq + 3 * S1;
-  launch_canon(t[0], mp.d_nmod, H, nb, ctx->stream);
-  launch_canon(t[1], mq.d_nmod, H, nb, ctx->stream);
+  t[0] = memp + 3 * Ss;                       // (the first H rows of the slot: PrimeShape)
+  t[1] = memq + 3 * Ss;
+  launch_canon(t[0], sk->mp.d_nmod, H, nb, ctx->stream);
+  launch_canon(t[1], sk->mq.d_nmod, H, nb, ctx->stream);
   return true;
 }
 

@@ -84,6 +84,16 @@ inline int crt_pair_lanes(int key_lanes, bool have_two_lane_variant, size_t nb, 
 // whether the CRT halves of Decrypt take the pair kernels at all at this batch size
 inline bool crt_pair_usable(int lanes_now, int prime_limbs, size_t nb, size_t lt) { return lanes_now == 1 || prime_limbs <= 55 || nb * 4 >= lt; }
 
+// ladders modulo the 37-limb PRIMES of a 2048-bit key (both halves in one launch: 2 nb numbers): one lane per number on the unrolled
+// kernel (2 053 multiplies in a row per squaring) -- or four lanes of 10 limbs (40 rows of 20) while that still leaves every wave a
+// SIMD of its own: what counts below a quarter of a wave per SIMD is the latency of one ladder (2 048 prover instances: 5.6 -> 4.3,
+// 7.3 -> 5.1, 7.7 -> 5.3 ms for the three ladders of the critical path).  Four lanes cost 2.4 x the issue slots of one, so a wave that
+// has to SHARE its SIMD loses more than it gained (X modulo the primes of 4 096 instances, 8 192 numbers beside ct1's decryption: 7.3 ->
+// 8.0 ms): `beside` = the launches that are known to run next to this one, the ladder included (1: alone).
+inline int prime_lanes(size_t nb, size_t lt, bool have_sliced, bool enabled, int beside = 1) {
+  return (have_sliced && enabled && nb * 2 * 4 * (size_t)beside <= lt) ? 4 : 1;
+}
+
 // three-digit kernel: two lanes per digit (GenQ6) for batches so small that eight lanes per number still leave every wave a SIMD
 inline bool triple_two_lanes_per_digit(size_t nb, size_t lt) { return nb * 8 <= lt; }
 // ... and x^(e0) W^n modulo n^3 (the verifier, NestedRandomize) as TWO such ladders side by side instead of one interleaved chain while

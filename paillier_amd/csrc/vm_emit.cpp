@@ -421,7 +421,7 @@ void run_vm(pgpu_ctx* ctx, size_t nb, const SegSpec& s0, const SegSpec* s1, bool
   // VM_STORET / VM_MULVT / VM_MULVT5: GenP for 37-limb primes, GenQ (two lanes), GenQ4 (four lanes)
   // (the three-digit kernel: VM_MULVT5 beside its VM_MULV7; the host never sends it 4-bit windows)
   // (and the generic one-lane kernel for 37-limb moduli: the ladders modulo the primes of struct_pow_n3)
-  const bool nm4_generic = !pair && WL == 37 && K == 1;
+  const bool nm4_generic = !pair && ((WL == 37 && K == 1) || (WL == 10 && K == 4));     // (and the primes' four-lane twins: PrimeShape)
   const bool nm4_kernel = nm4_generic || (pair && ((s0.pair_lanes == 1 && s0.pair_h == 37) || s0.pair_lanes == 2 || s0.pair_lanes == 4 || s0.pair_lanes == 3));
   const bool use_asm = ctx->use_asm && vm_asm_available(WL, K) && s0.prog->asm_ok && (!s1 || s1->prog->asm_ok) &&
                        (!s2 || s2->prog->asm_ok) && (!nm_tables || (nm4_generic ? !mulv7 : (pair && (mulv7 ? s0.pair_lanes == 3 : nm4 ? nm4_kernel : (s0.pair_lanes == 3 || nm4_kernel))))) &&

@@ -110,9 +110,10 @@ def test_asm_generator_model():
         text = g.generate()
         assert g.n_vgpr <= 256
         # number-major window tables: VM_STORET with VM_MULVT / VM_MULVT5 on the pair kernels that run per-number windows (the
-        # one-lane kernel for 37-limb primes, the two- and four-lane kernels), VM_MULV7 / VM_MULVT5 on the three-digit kernel
+        # one-lane kernel for 37-limb primes and its four-lane twin, the two- and four-lane kernels), VM_MULV7 / VM_MULVT5 on the
+        # three-digit kernel
         has = lambda lbl: f"\n{lbl}:" in text
-        if (wl, k) in ((37, 16), (74, 32), (55, 32), (37, 32), (37, 64), (37, 1)):
+        if (wl, k) in ((37, 16), (74, 32), (55, 32), (37, 32), (37, 64), (37, 1), (10, 4)):
             assert has("L_storet") and has("L_mulvt") and has("L_mulvt5") and not has("L_mulv7")
         elif (wl, k) in gen_vm_asm.TRIPLE:
             assert has("L_storet") and has("L_mulv7") and has("L_mulvt5") and not has("L_mulvt")

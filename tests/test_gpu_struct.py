@@ -119,7 +119,8 @@ def test_non_units_fall_back_to_the_literal_ladders(ctx):
 
 def test_generic_one_lane_kernel_number_major_windows(ctx):
     """The ladders modulo the primes run per-number 4-bit windows on NUMBER-major tables (VM_STORET / VM_MULVT) of the generic
-    one-lane kernel vm_asm_37_1; nm4 = 0 puts them back on limb-major tables: the same proofs."""
+    one-lane kernel vm_asm_37_1 ("prime_lanes" 0: a batch this small would take the four-lane twins, which the next test covers);
+    nm4 = 0 puts them back on limb-major tables: the same proofs."""
     import paillier_amd as pa
     sk_o, p, q = po.keygen_seeded(2048, 2080)
     n = sk_o.N
@@ -131,13 +132,15 @@ def test_generic_one_lane_kernel_number_major_windows(ctx):
     rep = lambda v: [v[i % 4] for i in range(S)]
     xs, ys = [po.rand_unit(n, rng) for _ in range(S)], [po.rand_unit(n, rng) for _ in range(S)]
     got = {}
-    for nm4 in (1, 0):
-        ctx.set_flag("nm4", nm4)
-        try:
+    ctx.set_flag("prime_lanes", 0)
+    try:
+        for nm4 in (1, 0):
+            ctx.set_flag("nm4", nm4)
             got[nm4] = sk.ProveDDLEQInstancesBatch(rep(ct1), rep(ct2), rep(a_s), rep(b_s), xs, ys)
             assert ctx.last_vm_asm() == ctx.last_vm_launches()
-        finally:
-            ctx.set_flag("nm4", 1)
+    finally:
+        ctx.set_flag("nm4", 1)
+        ctx.set_flag("prime_lanes", 1)
     assert got[1] == got[0]
     assert got[1][0][:8] == [_alpha(n, rep(ct1)[i], xs[i], ys[i]) for i in range(8)]
     assert all(pk.VerifyDDLEQInstancesBatch(rep(ct1), rep(ct2), xs, ys, *got[1]))
@@ -182,3 +185,59 @@ def test_late_response_through_the_structure(ctx, bits, S, secpar):
     flat = lambda v: [x for row in v for x in row]
     rep = lambda v: [v[j] for j in range(S) for _ in range(secpar)]
     assert all(pk.VerifyDDLEQInstancesBatch(rep(ct1), rep(ct2), flat(xs), flat(ys), flat(al), flat(es), flat(fs)))
+
+
+@pytest.mark.parametrize("bits", [2048, 1024])
+def test_ladders_modulo_the_primes_on_four_lanes(ctx, bits):
+    """Round 5: a batch that leaves most SIMDs empty at one lane per number runs the key holder's ladders modulo the primes (37 limbs)
+    on their four-lane twins -- p, q as 40-limb moduli in four lanes of 10, vm_asm_10_4 / vm_kernel<10, 4> (plan::prime_lanes, flag
+    "prime_lanes") --: x^n through the primes (key holder's Encrypt, both levels), the prover's X modulo the primes with per-number windows
+    on number-major AND limb-major tables, its response, s = ExtractRandonness.  Same integers as one lane per number (flag 0), as the
+    compiler-generated kernel (asm 0), as the oracle."""
+    import paillier_amd as pa
+    sk_o, p, q = po.keygen_seeded(bits, bits + 91)
+    n = sk_o.N
+    pk = pa.PublicKey(ctx, n, n + 1)
+    sk = pa.SecretKey(ctx, pk, sk_o.Lambda)
+    rng = random.Random(bits + 4)
+    S, secpar = 5, 2
+    ct1, ct2, a_s, b_s = _statements(sk_o, S, rng)
+    xs = [[po.rand_unit(n, rng) for _ in range(secpar)] for _ in range(S)]
+    ys = [[po.rand_unit(n, rng) for _ in range(secpar)] for _ in range(S)]
+    ms = [rng.randrange(n) for _ in range(70)] + [0, n - 1]
+    rs = [po.rand_unit(n, rng) for _ in ms]
+    rs[3], rs[4] = 1, n - 1
+    ms2 = [rng.randrange(n * n) for _ in range(9)]
+    got, mads = {}, {}
+    try:
+        for lanes, asm, nm4 in ((1, 1, 1), (0, 1, 1), (1, 0, 1), (1, 1, 0)):
+            ctx.set_flag("prime_lanes", lanes)
+            ctx.set_flag("asm", asm)
+            ctx.set_flag("nm4", nm4)
+            e1 = sk.EncryptWithRBatch(ms, rs)
+            mads[(lanes, asm, nm4)] = ctx.last_profile()["vm_mads"]
+            if asm:
+                assert ctx.last_vm_asm() == ctx.last_vm_launches()
+            e2 = sk.EncryptWithRBatch(ms2, rs[:len(ms2)], po.ENC_LEVEL_TWO)
+            pr = sk.ProveDDLEQBatch(secpar, ct1, ct2, a_s, b_s, xs, ys)
+            mads[(lanes, asm, nm4)] += ctx.last_profile()["vm_mads"]          # (a 1024-bit key's Encrypt has no ladder modulo the primes)
+            if asm:
+                assert ctx.last_vm_asm() == ctx.last_vm_launches()
+            got[(lanes, asm, nm4)] = (e1, e2, pr)
+    finally:
+        ctx.set_flag("prime_lanes", 1)
+        ctx.set_flag("asm", 1)
+        ctx.set_flag("nm4", 1)
+    ref = got[(1, 1, 1)]
+    assert all(v == ref for v in got.values())
+    assert mads[(1, 1, 1)] != mads[(0, 1, 1)], "the flag did not change the shape of the ladders modulo the primes"
+    assert ref[0] == [po.encrypt_with_r(sk_o, m, r).C for m, r in zip(ms, rs)]
+    assert ref[1] == [po.encrypt_with_r_at_level(sk_o, m, r, po.ENC_LEVEL_TWO).C for m, r in zip(ms2, rs)]
+    al, es, fs = ref[2]
+    bits_seen = set()
+    for j in range(S):
+        for k in range(secpar):
+            inst = po.prove_ddleq_instance_xy(sk_o, po.Ciphertext(ct1[j], 1), po.Ciphertext(ct2[j], 1), a_s[j], b_s[j], xs[j][k], ys[j][k])
+            assert (al[j][k], es[j][k], fs[j][k]) == (inst.Alpha, inst.E, inst.F), (j, k)
+            bits_seen.add(inst.E != xs[j][k])
+    assert bits_seen == {True, False}

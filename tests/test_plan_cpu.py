@@ -231,6 +231,21 @@ def test_crt_halves_lane_choice(q, nb, lanes, usable):
     assert q("crt_pair_lanes", 1, 1, nb, 0) == [lanes, usable]
 
 
+def test_ladders_modulo_the_primes_lane_choice(q):
+    """The key holder's ladders modulo the 37-limb primes (both halves in one launch): four lanes of 10 limbs per number while that
+    leaves every wave a SIMD of its own -- up to 8 192 numbers on the whole chip (the prover's response at 16 384 instances, every
+    ladder modulo the primes of a rank's 2 048 instances at N = 8) --, one lane on the unrolled kernel above; never without the twins
+    (other key sizes) or with the flag off; and a context confined to a CU partition counts its own compute units."""
+    assert q("prime_lanes", 8192, 0, 1, 1) == [4] and q("prime_lanes", 8448, 0, 1, 1) == [1]
+    assert q("prime_lanes", 256, 0, 1, 1) == [4] and q("prime_lanes", 32768, 0, 1, 1) == [1]
+    assert q("prime_lanes", 2048, 0, 0, 1) == [1] and q("prime_lanes", 2048, 0, 1, 0) == [1]
+    assert q("prime_lanes", 1024, 32 * 256, 1, 1) == [4] and q("prime_lanes", 2048, 32 * 256, 1, 1) == [1]
+    assert q("prime_lanes", 2048, 1, 1, 1) == [1]          # "lanes_wanted" 1: every batch 'fills the chip'
+    # beside other launches of the call (X modulo the primes next to ct1's decryption: 2; s on a side lane: 4) the bound shrinks
+    assert q("prime_lanes", 4096, 0, 1, 1, 2) == [4] and q("prime_lanes", 4352, 0, 1, 1, 2) == [1]
+    assert q("prime_lanes", 2048, 0, 1, 1, 4) == [4] and q("prime_lanes", 2304, 0, 1, 1, 4) == [1]
+
+
 def test_dual_ladder_windows_and_tables(q):
     W2 = 148
     assert q("dual_pair_window_bits", 16384, W2, 1) == [5] and q("dual_pair_window_bits", 61440, W2, 1) == [5]

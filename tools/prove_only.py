@@ -15,7 +15,7 @@ n = p * q
 dev = torch.device("cuda", 0)
 ctx = pa.Context(0, torch.cuda.current_stream().cuda_stream)
 pk = pa.PublicKey(ctx, n); sk = pa.SecretKey(ctx, pk, (p - 1) * (q - 1))
-for flag in ("early", "side", "nm4", "handover", "struct", "exclusive", "background", "exclusive_short", "spread", "lift", "late", "base_early"):                            # PROVE_EARLY=0 etc.: A/B runs of the prover's switches
+for flag in ("early", "side", "nm4", "handover", "struct", "exclusive", "background", "exclusive_short", "spread", "lift", "late", "base_early", "prime_lanes"):                            # PROVE_EARLY=0 etc.: A/B runs of the prover's switches
     if os.environ.get("PROVE_" + flag.upper()) is not None:
         ctx.set_flag(flag, int(os.environ["PROVE_" + flag.upper()]))
 SP = int(sys.argv[2]) if len(sys.argv) > 2 else 1
