@@ -3041,6 +3041,72 @@ class GenQ4(Gen):
         return "\n".join(self.lines) + "\n"
 
 
+class GenS4(GenQ4):
+    """ONE digit sliced over the four lanes of a quad: the 37-limb primes of a 2048-bit key as 40-limb moduli, four lanes of 10 limbs per
+    number -- the plain Montgomery contract of Gen(10, 4) (same slots, constants, opcodes, radix 2^(28 * 40)) on the rows of the
+    four-slice pair kernel GenQ8 without the second digit: the quotient digit of slice 0 and its broadcast interleaved with the first
+    multiplies of a row, a limb mask and the lane exchange that follows it in one instruction, multipliers read two rows at a time, the
+    carries of a slice taken sequentially in its own lane.  27 instructions a row (20 of them multiplies) where the generic four-lane
+    rows of Gen have 36: for ladders modulo the primes whose LATENCY is the run time (plan::prime_lanes)."""
+
+    def __init__(self, WL=10):
+        Gen.__init__(self, WL, 4)
+        assert self.n_vreg and not self.flush
+        self.H = 4 * WL
+        self.WTslot = self.WT
+        self.name = f"vm_asm_{WL}_4"
+        self.nm4_tables = True
+        self.sq_rows = True              # (the dispatcher's L_sqr stages x and branches to L_montsq)
+        self.sq_rows_k = False
+        self.lanes_per_number = 4
+        self.has_muls = False
+        self.alloc_row_regs()
+        assert self.n_vgpr <= 256, self.n_vgpr
+        # a paired read reaches up to six rows past the pointer: rows of padding behind the multiplier columns
+        self.lds_bytes = self.lds_a + (self.WT + 8) * self.NPB * 4
+        assert self.lds_bytes < 65536
+        self.dpp_bcast = "quad_perm:[0,0,0,0]"
+        self.dpp_next = "quad_perm:[1,2,3,3]"
+        self.dpp_prev = "quad_perm:[0,0,1,2]"
+        self._xb = self.vX
+
+    def prologue(self):
+        Gen.prologue(self)
+        self.init_row_regs()
+
+    def passes(self, tag, two_streams=False):
+        g, e = self, self.e
+        assert not two_streams
+        for j in range(self.WL):
+            e(f"v_mov_b64 {self.T(j)}, 0")
+        e(f"v_mov_b32 v{g.v_arow}, v{g.v_aread}")
+        self.read_pair(g.v_pa, g.v_arow, 0)
+        self.row_loop(tag, False, False)
+
+    def montsq(self):
+        # x <- x x R^-1: the multipliers are x's own limbs, staged by the dispatcher (no symmetry taken: every lane would idle for
+        # the half it skips)
+        self.e("L_montsq:")
+        self.passes("s")
+        self.normalize()
+        self.e("s_branch L_next")
+
+    def montmul(self, to_slot=False):
+        assert not to_slot
+        self.e("L_montmul:")
+        self.passes("m")
+        self.normalize()
+        self.e("s_branch L_next")
+
+    def generate(self):
+        self.prologue()
+        self.dispatcher()
+        self.montmul()
+        self.montsq()
+        self.epilogue()
+        return "\n".join(self.lines) + "\n"
+
+
 class GenQ8(GenQ4):
     """The pair kernel with every digit sliced over FOUR lanes: 8 lanes per number (lanes 0..3 = the 19-limb slices of a0, lanes
     4..7 = those of a1; a digit is 76 limbs -- the 74 limbs of a 2048-bit n padded: the host converts between the two radices
@@ -3874,9 +3940,11 @@ def make_gen(wl, k):
         # the same 37-limb primes as 40-limb moduli in four lanes per number: ladders modulo the primes of batches too small to fill
         # the chip with one lane per number (plan::prime_lanes) -- a product is 40 rows of 20 multiplies where the one-lane kernel
         # has 2 053 - 2 738 in a row, and the ladder's latency is the run time there
-        g = Gen(wl, k)
-        g.nm4_tables = True
-        return g
+        if os.environ.get("PGPU_GEN_GENERIC10", "0") == "1":       # A/B builds: the generic four-lane rows of Gen
+            g = Gen(wl, k)
+            g.nm4_tables = True
+            return g
+        return GenS4(wl)
     return Gen(wl, k)
 
 

@@ -215,9 +215,7 @@ bool power_residues(const pgpu_seckey* sk, const uint32_t* base, int k, size_t n
   pgpu_ctx* ctx = sk->ctx;
   BigU r[2];
   if (!power_residues_usable(sk, k, r)) return false;
-  // (inside a prover call the structure chain of ct1 -- its decryption -- starts beside this ladder: 8 192 numbers on four lanes took
-  // 8.8 ms there, 4.5 alone, 5.8 on one lane)
-  const PrimeShape ps = prime_shape(sk, nb, ctx->exclusive_call ? 2 : 1);
+  const PrimeShape ps = prime_shape(sk, nb);
   const ModCtx &mp = *ps.m[0], &mq = *ps.m[1];
   const int H = sk->mp.WT, WN = sk->pk->mn.WT;
   const size_t Ss = (size_t)ps.Hs * nb;

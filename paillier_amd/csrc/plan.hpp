@@ -85,11 +85,12 @@ inline int crt_pair_lanes(int key_lanes, bool have_two_lane_variant, size_t nb, 
 inline bool crt_pair_usable(int lanes_now, int prime_limbs, size_t nb, size_t lt) { return lanes_now == 1 || prime_limbs <= 55 || nb * 4 >= lt; }
 
 // ladders modulo the 37-limb PRIMES of a 2048-bit key (both halves in one launch: 2 nb numbers): one lane per number on the unrolled
-// kernel (2 053 multiplies in a row per squaring) -- or four lanes of 10 limbs (40 rows of 20) while that still leaves every wave a
-// SIMD of its own: what counts below a quarter of a wave per SIMD is the latency of one ladder (2 048 prover instances: 5.6 -> 4.3,
-// 7.3 -> 5.1, 7.7 -> 5.3 ms for the three ladders of the critical path).  Four lanes cost 2.4 x the issue slots of one, so a wave that
-// has to SHARE its SIMD loses more than it gained (X modulo the primes of 4 096 instances, 8 192 numbers beside ct1's decryption: 7.3 ->
-// 8.0 ms): `beside` = the launches that are known to run next to this one, the ladder included (1: alone).
+// kernel (2 053 multiplies in a row per squaring, ~2 300 issue slots) -- or four lanes of 10 limbs (vm_asm_10_4, GenS4: 40 rows of 27
+// instructions, ~1 100 slots per lane) while that still leaves every wave a SIMD of its own: what counts below a quarter of a wave per
+// SIMD is the latency of one ladder (2 048 prover instances: 5.6 -> 3.1, 7.3 -> 3.7, 7.7 -> 3.9 ms for the three ladders of the
+// critical path; 8 192 numbers of a^n | x^n at 4 096 instances: 6.0 -> 3.3).  Four lanes cost twice the issue slots of one, so a wave
+// that has to SHARE its SIMD gains nothing (X modulo the primes of 4 096 instances, 8 192 numbers beside ct1's decryption: 7.3 -> 9.7
+// ms): `beside` = the launches known to run next to this one, the ladder included (1: alone; s on a side lane: 4).
 inline int prime_lanes(size_t nb, size_t lt, bool have_sliced, bool enabled, int beside = 1) {
   return (have_sliced && enabled && nb * 2 * 4 * (size_t)beside <= lt) ? 4 : 1;
 }
