@@ -151,6 +151,16 @@ def test_asm_generator_model():
                 assert len([l for l in body.splitlines() if l.strip() and not l.strip().startswith(".")]) - 4 * per_row <= 4 * 11
             assert g.H == 4 * wl and g.lds_bytes * 2 <= 160 * 1024
             continue
+        if isinstance(g, gen_vm_asm.GenS4):
+            # one digit in the four lanes of a quad (the 37-limb primes as 40-limb moduli): four-row bodies of 2 WL multiplies per lane
+            # in a squaring and in a product alike, no quotient link, no s_nop, at most 7 other instructions a row
+            for lbl, where in (("L_qs", "L_montsq:"), ("L_qm", "L_montmul:")):
+                body = text.split(where)[1].split(lbl + ":")[1].split("s_cbranch_scc1 " + lbl)[0]
+                assert body.count("v_mad_u64_u32") == 4 * 2 * wl
+                assert body.count("v_mad_i64_i32") == 0 and body.count("s_nop") == 0
+                assert len([l for l in body.splitlines() if l.strip() and not l.strip().startswith(".")]) - 8 * wl <= 4 * 7
+            assert g.H == 4 * wl == g.WT and g.lds_bytes * 4 <= 160 * 1024
+            continue
         if (wl, k) in gen_vm_asm.PAIR4:
             # four-lane pair kernel: a squaring is one pass of four-row bodies of 2 WL multiplies per lane; a product is ONE pass
             # too, with two multiplier streams (3 WL multiplies a row); one quotient link per row; no s_nop inside a row, and at
