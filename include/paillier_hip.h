@@ -106,7 +106,7 @@ int pgpu_ctx_last_profile(pgpu_ctx* ctx, double* vm_ms, int* vm_launches, double
  * land on idle CUs instead of the ones the main launch runs on, and a main-stream ladder of at most one workgroup per CU asks for more
  * than half of it, so that it spreads over all CUs (0: the dispatcher's placement); "exclusive_short" (default 1): the links between ladders -- programs of a few
  * products -- ask for a whole CU as well (0: only ladders do and the links run beside the main stream's launches; measured equal); "spread" (default 1): the second of those two rules
- * alone (0: main-stream ladders keep the dispatcher's placement; both rules stop at the compute units the context's stream may use, so a
+ * alone -- which inside a prover call also holds for a side lane's ladder of 129 ... 256 workgroups -- (0: such ladders keep the dispatcher's placement; both rules stop at the compute units the context's stream may use, so a
  * context with a "cu_partition" narrower than its launch keeps the dispatcher's placement by itself); "w74" (default 1): moduli of two
  * 74-limb slices on the wave-sliced assembly kernel (0: four lanes of 37 limbs); "exp_order" (default 1): the key holder's exponents
  * modulo p^3, q^3 are reduced modulo the group orders on the device (0: used as given); "background" (default 0): the prover's side-lane

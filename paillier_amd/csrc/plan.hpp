@@ -192,7 +192,10 @@ inline int lds_share(uint32_t blocks, uint32_t stream_cus, bool on_side, bool in
   if (in_exclusive_call && blocks <= kExclusiveMaxBlocks && blocks <= stream_cus && (products >= 256 || (exclusive_short && on_side))) return 1;
   // (inside a CU partition the mask already keeps other contexts off these CUs, and the request only delays placement: eight contexts
   // on 32 CUs each, 1 024 / 2 048 ciphertexts per call: 39.4 / 62.1 ms without it, 45.7 / 65.7 ms with it)
-  if (spread_enabled && !on_side && stream_cus == kChipCUs && blocks <= stream_cus && products >= 256) return 2;
+  // (the same for a side lane's LADDER inside such a call -- ct1's decryption of 8 192 statements, 256 workgroups: with the dispatcher's
+  // placement some CUs get two of them and both wave slots of their SIMDs, and the main stream's links wait for a slot: 25.5 -> 13.3 ms
+  // for the launch, 78.6 -> 75.2 ms for the call)
+  if (spread_enabled && (!on_side || in_exclusive_call) && stream_cus == kChipCUs && blocks <= stream_cus && products >= 256) return 2;
   return 0;
 }
 

@@ -154,9 +154,14 @@ def test_placement_by_lds_size(q):
     assert q("lds_share", 64, 256, 0, 1, 12, 1, 1) != [1]
     assert q("lds_share", 64, 256, 1, 1, 4000, 1, 1) == [1]
     assert q("lds_share", 128, 256, 0, 1, 4000, 1, 1) == [1]
-    # wider: a main-stream ladder of at most one workgroup per CU spreads (just over half a CU's LDS); a side lane's keeps its size
+    # wider: a ladder of at most one workgroup per CU spreads (just over half a CU's LDS) -- the main stream's, and inside a prover call a
+    # side lane's as well (ct1's decryption of 8 192 statements: 256 workgroups; two on a CU take both wave slots of its SIMDs and the
+    # main stream's links wait for one); outside such a call a side lane's launch keeps its size, and so does every link
     assert q("lds_share", 256, 256, 0, 1, 4000, 1, 1) == [2]
-    assert q("lds_share", 256, 256, 1, 1, 4000, 1, 1) == [0]
+    assert q("lds_share", 256, 256, 1, 1, 4000, 1, 1) == [2]
+    assert q("lds_share", 256, 256, 1, 0, 4000, 1, 1) == [0]
+    assert q("lds_share", 256, 256, 1, 1, 12, 1, 1) == [0]
+    assert q("lds_share", 512, 256, 1, 1, 4000, 1, 1) == [0]
     assert q("lds_share", 257, 256, 0, 0, 4000, 1, 1) == [0]
     # outside a prover call: the spread rule alone, for ladders (>= 256 products), never for the links between them
     assert q("lds_share", 64, 256, 0, 0, 4000, 1, 1) == [2]
