@@ -1398,6 +1398,7 @@ struct ProveCall {
   // the response, prepared before the bits are known
   uint32_t *qainv = nullptr, *qani = nullptr;
   int32_t* d_badinv = nullptr;
+  hipEvent_t axn_done = nullptr;                            // a^n | x^n is through its eight-lane ladders (powers_of_n)
   bool any_badinv = false, sb_units = false, early = false, resp_struct = false, resp_late = false, one_ladder = false;
   const uint8_t* sb_root = nullptr;
   hipEvent_t root_ready = nullptr;
@@ -1476,6 +1477,12 @@ struct ProveCall {
     uint32_t* axn;
     if (pow_n2_crt_usable(sk)) {
       axn = pow_n2_crt(sk, ax, N, nbs + nb);               // the prover holds p and q
+      if (crt_pair8_usable(sk, nbs + nb) && ctx->use_side) {
+        // the second stage ran on eight lanes per number: up to a wave on EVERY SIMD for 3.6 ms.  ct1's decryption (a CU per workgroup on
+        // half the chip) beside it would make it two rounds of that; it has slack until the end of the lifts and starts behind this launch
+        axn_done = ctx->next_sync_ev();
+        HIPCHK(hipEventRecord(axn_done, ctx->stream));
+      }
     } else {
       axn = ctx->ws_t<uint32_t>((size_t)W2 * (nbs + nb));
       shared_pow(ctx, mn2, ax, W1, N, nbs + nb, axn);
@@ -1525,6 +1532,7 @@ struct ProveCall {
       residues_ready = ctx->next_sync_ev();
       HIPCHK(hipEventRecord(residues_ready, ctx->stream));
     }
+    if (axn_done) HIPCHK(hipStreamWaitEvent(ctx->stream, axn_done, 0));
     if (resp_struct) {
       d_st_rstmt = ctx->ws_t<int32_t>(nbs);
       HIPCHK(hipMemsetAsync(d_st_rstmt, 0, nbs * 4, ctx->stream));

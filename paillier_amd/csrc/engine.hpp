@@ -545,7 +545,11 @@ struct PrimeShape {
   const ModCtx* m[2] = {nullptr, nullptr};
   int H = 0, Hs = 0;
 };
-PrimeShape prime_shape(const pgpu_seckey* sk, size_t nb, int beside = 1);     // beside: plan::prime_lanes
+PrimeShape prime_shape(const pgpu_seckey* sk, size_t nb, int beside = 1);
+// x^(e[half]) in pair form modulo p^2 | q^2 on the eight-lane pair kernel, both halves in one launch (plan::crt_pair_lanes8): in[half] /
+// out[half] = pair digits (d0 | d1, 2 H limbs, stride nb) in the radix-R_H pair form of the one- and two-lane kernels
+bool crt_pair8_usable(const pgpu_seckey* sk, size_t nb);
+void crt_pair8_ladders(const pgpu_seckey* sk, const BigU e[2], const uint32_t* const in[2], uint32_t* const out[2], size_t nb);     // beside: plan::prime_lanes
 void prime_slot_fill(pgpu_ctx* ctx, const PrimeShape& ps, uint32_t* slot, const uint32_t* src, size_t nb);
 
 // launch one VM kernel with 1 to 3 segments of `nb` numbers each (same modulus shape; s2 only together with s1)
@@ -674,6 +678,11 @@ struct pgpu_seckey {
   bool pair_small2 = false;        // 37-limb primes: below one wave per SIMD the two-lane kernel fills the chip better
   int pair_lanes = 1;              // 1: GenP (both digits in one lane, 37-limb primes); 2: GenQ (one digit per lane: 55 / 74 limbs)
   DevLimbs pair_p, pair_q;
+  // the eight-lane pair kernel for the halves (digits of h8 = 40 limbs in four lanes of 10, Montgomery radix R_40): prime | Cadj, and the pair
+  // digits of R_40^2 R_H^-1 (a number enters with one product by it), of R_H (leaves), of R_40 -- CRT ladders of batches that leave most
+  // of the chip empty at two lanes per number (plan::crt_pair_lanes8)
+  int pair_h8 = 0;
+  DevLimbs pair8_p, pair8_q, pair8t_p, pair8t_q;
   int c_rh_p2 = -1, c_rh_q2 = -1;
   int c_pk_p2[4] = {-1, -1, -1, -1}, c_pk_q2[4] = {-1, -1, -1, -1};   // pair forms of R_H^(k+2): chunk k of c enters the ladder
   int c_onep_p2 = -1, c_onep_q2 = -1;                                 // pair form of 1 (normalises a lazy pair)
@@ -708,6 +717,7 @@ namespace pgi {
 // ---- keys.cpp / ctx.cpp --------------------------------------------------------------------------------------------------------
 BigU order_fixup(const BigU& e, const BigU& ord);
 std::vector<uint32_t> make_pair_consts(const BigU& pr, int H);
+bool make_pair8_consts(const BigU& root, const BigU& mod2, int H, int h8, std::vector<uint32_t>& c8, std::vector<uint32_t>& t8);
 std::vector<uint32_t> make_triple_kconsts(const BigU& n, int H);
 bool ctx_alive(pgpu_ctx* c);
 

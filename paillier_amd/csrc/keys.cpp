@@ -26,6 +26,26 @@ std::vector<uint32_t> make_pair_consts(const BigU& pr, int H) {
   return v;
 }
 
+// Constants of the eight-lane pair kernel for modulus mod2 = root^2, a root of H limbs in digits of h8 limbs (four slices): root | Cadj (+ one
+// word of padding), and the pair digits (d0 | d1, h8 limbs each) of R_h8^2 R_H^-1 (entry from the radix-R_H pair form), R_H (exit), R_h8 (= 1)
+bool make_pair8_consts(const BigU& root, const BigU& mod2, int H, int h8, std::vector<uint32_t>& c8, std::vector<uint32_t>& t8) {
+  c8 = make_pair_consts(root, h8);
+  c8.push_back(0);
+  const BigU rh = hostbig::shl(BigU(1), (size_t)LB * H) % mod2, r8 = hostbig::shl(BigU(1), (size_t)LB * h8) % mod2;
+  BigU rh_inv;
+  if (!hostbig::modinv(rh, mod2, rh_inv)) return false;
+  const BigU vals[3] = {hostbig::mulmod(hostbig::mulmod(r8, r8, mod2), rh_inv, mod2), rh, r8};
+  t8.clear();
+  for (const BigU& v : vals) {
+    BigU d1, d0;
+    hostbig::divmod(v, root, d1, d0);
+    auto l0 = d0.to_limbs(LB, (size_t)h8), l1 = d1.to_limbs(LB, (size_t)h8);
+    t8.insert(t8.end(), l0.begin(), l0.end());
+    t8.insert(t8.end(), l1.begin(), l1.end());
+  }
+  return true;
+}
+
 // Constants of the three-digit kernel for the root n (H limbs): n padded to an even number of words, then the pairs
 // (C1_i, C2_i), then two words of padding (the kernel prefetches one pair past the end).  C1 = k1 n is make_pair_consts'
 // Cadj (every limb in [2^28, 2^29)); C2 = -k1 (mod n) shifted into the same limb range: the -C1 n that the first link
@@ -174,23 +194,11 @@ int pgpu_pubkey_create(pgpu_ctx* ctx, const uint8_t* n_be, size_t n_len, const u
       // with one product by the pair digits of R_76^2 R_74^-1 and leaves with one by those of R_74
       const int h8 = (H + 3) / 4 * 4;
       if (H % 2 == 0 && vm_asm_available(h8 / 4, 96)) {
-        std::vector<uint32_t> pc8 = make_pair_consts(pk->N, h8);
-        pc8.push_back(0);
-        pk->pairn_consts8.w = (int)pc8.size();
-        HIPCHK(hipMalloc((void**)&pk->pairn_consts8.d, pc8.size() * 4));
-        HIPCHK(hipMemcpy(pk->pairn_consts8.d, pc8.data(), pc8.size() * 4, hipMemcpyHostToDevice));
-        const BigU r8 = hostbig::shl(BigU(1), (size_t)LB * h8) % n2;
-        BigU rh_inv;
-        if (hostbig::modinv(rh, n2, rh_inv)) {
-          const BigU vals[3] = {hostbig::mulmod(hostbig::mulmod(r8, r8, n2), rh_inv, n2), rh, r8};
-          std::vector<uint32_t> tc;
-          for (const BigU& v : vals) {
-            BigU d1, d0;
-            hostbig::divmod(v, pk->N, d1, d0);
-            auto l0 = d0.to_limbs(LB, (size_t)h8), l1 = d1.to_limbs(LB, (size_t)h8);
-            tc.insert(tc.end(), l0.begin(), l0.end());
-            tc.insert(tc.end(), l1.begin(), l1.end());
-          }
+        std::vector<uint32_t> pc8, tc;
+        if (make_pair8_consts(pk->N, n2, H, h8, pc8, tc)) {
+          pk->pairn_consts8.w = (int)pc8.size();
+          HIPCHK(hipMalloc((void**)&pk->pairn_consts8.d, pc8.size() * 4));
+          HIPCHK(hipMemcpy(pk->pairn_consts8.d, pc8.data(), pc8.size() * 4, hipMemcpyHostToDevice));
           pk->pairn_tconsts8.w = (int)tc.size();
           HIPCHK(hipMalloc((void**)&pk->pairn_tconsts8.d, tc.size() * 4));
           HIPCHK(hipMemcpy(pk->pairn_tconsts8.d, tc.data(), tc.size() * 4, hipMemcpyHostToDevice));
@@ -314,6 +322,16 @@ int pgpu_seckey_create(pgpu_ctx* ctx, const pgpu_pubkey* pk, const uint8_t* lamb
           };
           put(sk->pair_p, vp);
           put(sk->pair_q, vq);
+          {
+            const int h8 = (H + 3) / 4 * 4;
+            std::vector<uint32_t> c8p, t8p, c8q, t8q;
+            if (sk->pair_lanes == 1 && vm_asm_available(h8 / 4, 96) && make_pair8_consts(p, sk->mp2.N, H, h8, c8p, t8p) &&
+                make_pair8_consts(q, sk->mq2.N, H, h8, c8q, t8q)) {
+              put(sk->pair8_p, c8p); put(sk->pair8t_p, t8p);
+              put(sk->pair8_q, c8q); put(sk->pair8t_q, t8q);
+              sk->pair_h8 = h8;
+            }
+          }
           const BigU RH = hostbig::shl(BigU(1), (size_t)LB * H);
           sk->c_rh_p2 = sk->mp2.add_const(RH % sk->mp2.N);
           sk->c_rh_q2 = sk->mq2.add_const(RH % sk->mq2.N);

@@ -54,19 +54,42 @@ uint32_t* decrypt1_crt(const pgpu_seckey* sk, const uint32_t* c_limbs, size_t nb
           pr.op(VM_MULC, (uint32_t)onep); pr.op(VM_STORE, acc);
         }
       };
-      Prog pp, pq;
-      entry(pp, sk->c_pk_p2, sk->c_onep_p2, 2);
-      emit_modexp_shared(pp, sk->p - BigU(1), 2, NO_SLOT, 2, 3, 4, NO_SLOT, true, true);
-      pp.op(VM_LOAD, 3); pp.op(VM_MULC, C_ONE); pp.op(VM_STORE, 3);
-      pp.end();
-      entry(pq, sk->c_pk_q2, sk->c_onep_q2, 36);
-      emit_modexp_shared(pq, sk->q - BigU(1), 36, NO_SLOT, 36, 37, 38, NO_SLOT, true, true);
-      pq.op(VM_LOAD, 37); pq.op(VM_MULC, C_ONE); pq.op(VM_STORE, 37);
-      pq.end();
-      SegSpec sp{&mp2, &pp, mem, nullptr}, sq{&mq2, &pq, mem, nullptr};
-      sp.pair = sk->pair_p.d; sp.pair_n0inv = mp.n0inv; sp.pair_h = W1; sp.pair_lanes = pair_lanes_now;
-      sq.pair = sk->pair_q.d; sq.pair_n0inv = mq.n0inv; sq.pair_h = W1; sq.pair_lanes = pair_lanes_now;
-      run_vm(ctx, nb, sp, &sq, true);
+      auto run_halves = [&](const Prog& pp, const Prog& pq, bool profile) {
+        SegSpec sp{&mp2, &pp, mem, nullptr}, sq{&mq2, &pq, mem, nullptr};
+        sp.pair = sk->pair_p.d; sp.pair_n0inv = mp.n0inv; sp.pair_h = W1; sp.pair_lanes = pair_lanes_now;
+        sq.pair = sk->pair_q.d; sq.pair_n0inv = mq.n0inv; sq.pair_h = W1; sq.pair_lanes = pair_lanes_now;
+        run_vm(ctx, nb, sp, &sq, profile);
+      };
+      if (crt_pair8_usable(sk, nb)) {
+        // a batch that leaves most of the chip empty: entry and exit as they are (a handful of products on the two-lane kernel), the
+        // LADDERS on the eight-lane pair kernel (plan::crt_pair_lanes8) -- the latency of the ladder is the run time of the call
+        Prog pe, qe, px, qx;
+        entry(pe, sk->c_pk_p2, sk->c_onep_p2, 2);
+        pe.end();
+        entry(qe, sk->c_pk_q2, sk->c_onep_q2, 36);
+        qe.end();
+        run_halves(pe, qe, false);
+        const BigU es[2] = {sk->p - BigU(1), sk->q - BigU(1)};
+        const uint32_t* in8[2] = {mem + 2 * S2, mem + 36 * S2};
+        uint32_t* out8[2] = {mem + 3 * S2, mem + 37 * S2};
+        crt_pair8_ladders(sk, es, in8, out8, nb);
+        px.op(VM_LOAD, 3); px.op(VM_MULC, C_ONE); px.op(VM_STORE, 3);
+        px.end();
+        qx.op(VM_LOAD, 37); qx.op(VM_MULC, C_ONE); qx.op(VM_STORE, 37);
+        qx.end();
+        run_halves(px, qx, false);
+      } else {
+        Prog pp, pq;
+        entry(pp, sk->c_pk_p2, sk->c_onep_p2, 2);
+        emit_modexp_shared(pp, sk->p - BigU(1), 2, NO_SLOT, 2, 3, 4, NO_SLOT, true, true);
+        pp.op(VM_LOAD, 3); pp.op(VM_MULC, C_ONE); pp.op(VM_STORE, 3);
+        pp.end();
+        entry(pq, sk->c_pk_q2, sk->c_onep_q2, 36);
+        emit_modexp_shared(pq, sk->q - BigU(1), 36, NO_SLOT, 36, 37, 38, NO_SLOT, true, true);
+        pq.op(VM_LOAD, 37); pq.op(VM_MULC, C_ONE); pq.op(VM_STORE, 37);
+        pq.end();
+        run_halves(pp, pq, true);
+      }
     }
   } else {
     HIPCHK(hipMemcpyAsync(mem, c_limbs, S2 * 2 * 4, hipMemcpyDeviceToDevice, ctx->stream));
@@ -136,6 +159,40 @@ PrimeShape prime_shape(const pgpu_seckey* sk, size_t nb, int beside) {
 void prime_slot_fill(pgpu_ctx* ctx, const PrimeShape& ps, uint32_t* slot, const uint32_t* src, size_t nb) {
   HIPCHK(hipMemcpyAsync(slot, src, (size_t)ps.H * nb * 4, hipMemcpyDeviceToDevice, ctx->stream));
   if (ps.Hs > ps.H) HIPCHK(hipMemsetAsync(slot + (size_t)ps.H * nb, 0, (size_t)(ps.Hs - ps.H) * nb * 4, ctx->stream));
+}
+
+bool crt_pair8_usable(const pgpu_seckey* sk, size_t nb) {
+  pgpu_ctx* ctx = sk->ctx;
+  return sk->has_pair && ctx->use_asm && ctx->use_pair &&
+         plan::crt_pair_lanes8(nb, plan::lanes_target(ctx->lanes_wanted, ctx->stream_cus), sk->pair_h8 > 0, ctx->use_lanes8, ctx->exclusive_call ? 2 : 1);
+}
+void crt_pair8_ladders(const pgpu_seckey* sk, const BigU e[2], const uint32_t* const in[2], uint32_t* const out[2], size_t nb) {
+  pgpu_ctx* ctx = sk->ctx;
+  const int H = sk->mp.WT, H8 = sk->pair_h8;
+  const size_t S1 = (size_t)H * nb, SW8 = (size_t)2 * H8 * nb;
+  uint32_t* m8[2];
+  Prog lad[2];
+  for (int half = 0; half < 2; ++half) {
+    // pair slots of 2 x H8 limbs: 2 in, 3 out, 5.. the table; the digits zero-extended, radix R_H -> R_H8 with the first product of the
+    // program and back with its last
+    m8[half] = ctx->ws_t<uint32_t>(SW8 * (size_t)(5 + 32));
+    HIPCHK(hipMemsetAsync(m8[half] + 2 * SW8, 0, SW8 * 4, ctx->stream));
+    launch_restride(in[half], nb, nb, nullptr, m8[half] + 2 * SW8, nb, H, ctx->stream);
+    launch_restride(in[half] + S1, nb, nb, nullptr, m8[half] + 2 * SW8 + (size_t)H8 * nb, nb, H, ctx->stream);
+    Prog& p = lad[half];
+    p.op(VM_LOAD, 2); p.op(VM_MULC, 0); p.op(VM_STORE, 2);
+    emit_modexp_shared(p, e[half], 2, NO_SLOT, 2, 3, 5, NO_SLOT, true, true);
+    p.op(VM_LOAD, 3); p.op(VM_MULC, 1); p.op(VM_STORE, 3);
+    p.end();
+  }
+  SegSpec sp{&sk->mp2, &lad[0], m8[0], nullptr}, sq{&sk->mq2, &lad[1], m8[1], nullptr};
+  sp.pair = sk->pair8_p.d; sp.pair_n0inv = sk->mp.n0inv; sp.pair_h = H8; sp.pair_lanes = 8; sp.tconsts = sk->pair8t_p.d;
+  sq.pair = sk->pair8_q.d; sq.pair_n0inv = sk->mq.n0inv; sq.pair_h = H8; sq.pair_lanes = 8; sq.tconsts = sk->pair8t_q.d;
+  run_vm(ctx, nb, sp, &sq, true);
+  for (int half = 0; half < 2; ++half) {
+    launch_restride(m8[half] + 3 * SW8, nb, nb, nullptr, out[half], nb, H, ctx->stream);
+    launch_restride(m8[half] + 3 * SW8 + (size_t)H8 * nb, nb, nb, nullptr, out[half] + S1, nb, H, ctx->stream);
+  }
 }
 
 uint32_t* pow_n_crt(const pgpu_seckey* sk, const uint32_t* base, const BigU& e, size_t nb) {
@@ -244,6 +301,7 @@ uint32_t* pow_n2_crt(const pgpu_seckey* sk, const uint32_t* base, const BigU& e,
   uint32_t* xh[2];
   uint32_t* mem[2];
   Prog lad[2];
+  BigU ehs[2];
   uint32_t* tl[2] = {nullptr, nullptr};
   const bool lifted = e == sk->pk->N && power_residues(sk, base, 1, nb, tl);      // e == n: t = x^(other prime) modulo each prime, then t^prime
   Fork in(ctx);                                                         // the q-half's entry chain beside the p-half's
@@ -281,11 +339,17 @@ uint32_t* pow_n2_crt(const pgpu_seckey* sk, const uint32_t* base, const BigU& e,
       }
       if (eh.bit_length() < 64) eh = e;
     }
+    ehs[half] = eh;
     emit_modexp_shared(lad[half], eh, 2, NO_SLOT, 2, 3, 5, NO_SLOT, true, true);
     lad[half].end();
   }
   in.join();
-  {
+  if (crt_pair8_usable(sk, nb)) {
+    // (small batches: eight lanes per number -- the ladder's latency is the run time)
+    const uint32_t* in8[2] = {mem[0] + 2 * S2, mem[1] + 2 * S2};
+    uint32_t* out8[2] = {mem[0] + 3 * S2, mem[1] + 3 * S2};
+    crt_pair8_ladders(sk, ehs, in8, out8, nb);
+  } else {
     // (small batches on two lanes per number, as Decrypt chooses: a squaring is 37 rows of 74 multiplies instead of the one-lane
     // kernel's 4 810 in a row -- the ladder's latency is the run time there)
     const int lanes = plan::crt_pair_lanes(sk->pair_lanes, sk->pair_small2, nb, plan::lanes_target(ctx->lanes_wanted, ctx->stream_cus));

@@ -81,6 +81,15 @@ inline int pair_lanes_2or4(size_t numbers, size_t lt, bool have4) { return (numb
 inline int crt_pair_lanes(int key_lanes, bool have_two_lane_variant, size_t nb, size_t lt) {
   return (key_lanes == 1 && have_two_lane_variant && nb * 4 <= lt) ? 2 : key_lanes;
 }
+// ... and EIGHT lanes per number (vm_asm_10_96: the digits of 37-limb primes in four slices of 10 limbs, a squaring 40 rows of ~30
+// instructions where the two-lane kernel has 37 rows of ~84) while both halves fit two waves per SIMD: up to 8 192 numbers.  The latency
+// of the ladder is the run time there -- Decrypt-2048 of up to 4 096 ciphertexts 8.8 -> 4.0 ms per call, 8 192: 8.9 -> 6.3 (two waves per
+// SIMD), 12 288: 8.9 | 8.7; a rank's 2 048 prover instances: a^n | x^n's second stage 9.0 -> 4.9 ms.  Inside a call whose launches run
+// beside each other (`beside` 2: the DDLEQ prover) only while one wave per SIMD suffices: at 4 096 instances the launch took 6.2 instead
+// of 9.8 ms and the call 53.7 instead of 51.9 -- both wave slots of every SIMD were taken from ct1's decryption for that long
+inline bool crt_pair_lanes8(size_t nb, size_t lt, bool have8, bool enabled, int beside = 1) {
+  return have8 && enabled && nb * 2 * 8 * (size_t)beside <= 2 * lt;
+}
 // whether the CRT halves of Decrypt take the pair kernels at all at this batch size
 inline bool crt_pair_usable(int lanes_now, int prime_limbs, size_t nb, size_t lt) { return lanes_now == 1 || prime_limbs <= 55 || nb * 4 >= lt; }
 

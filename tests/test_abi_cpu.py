@@ -147,8 +147,10 @@ def test_asm_generator_model():
             for lbl, where, per_row in (("L_qs", "L_montsq:", 2 * wl), ("L_qm", "L_montmul:", 3 * wl)):
                 body = text.split(where)[1].split(lbl + ":")[1].split("s_cbranch_scc1 " + lbl)[0]
                 assert body.count("v_mad_u64_u32") == 4 * per_row
-                assert body.count("row_shr:4") == 4 and body.count("s_nop") == 0
-                assert len([l for l in body.splitlines() if l.strip() and not l.strip().startswith(".")]) - 4 * per_row <= 4 * 11
+                # (10-limb slices: a linked squaring row is too short to hide its chain between multiplies -- one wait state in front
+                # of each of its two DPP reads)
+                assert body.count("row_shr:4") == 4 and body.count("s_nop") == (8 if (wl == 10 and lbl == "L_qs") else 0)
+                assert len([l for l in body.splitlines() if l.strip() and not l.strip().startswith(".")]) - 4 * per_row <= 4 * (13 if wl == 10 else 11)
             assert g.H == 4 * wl and g.lds_bytes * 2 <= 160 * 1024
             continue
         if isinstance(g, gen_vm_asm.GenS4):

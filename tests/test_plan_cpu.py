@@ -251,6 +251,17 @@ def test_ladders_modulo_the_primes_lane_choice(q):
     assert q("prime_lanes", 2048, 0, 1, 1, 4) == [4] and q("prime_lanes", 2304, 0, 1, 1, 4) == [1]
 
 
+def test_crt_halves_on_eight_lanes(q):
+    """Both CRT halves of up to 8 192 numbers fit two waves per SIMD at eight lanes per number: the ladders of Decrypt and of the key
+    holder's x^n take vm_asm_10_96 there (a rank's 2 048 prover instances: 4 096 numbers); never without the constants or the flag."""
+    assert q("crt_pair_lanes8", 8192, 0, 1, 1) == [1] and q("crt_pair_lanes8", 8448, 0, 1, 1) == [0]
+    assert q("crt_pair_lanes8", 256, 0, 1, 1) == [1]
+    assert q("crt_pair_lanes8", 256, 0, 0, 1) == [0] and q("crt_pair_lanes8", 256, 0, 1, 0) == [0]
+    assert q("crt_pair_lanes8", 1024, 32 * 256, 1, 1) == [1] and q("crt_pair_lanes8", 1280, 32 * 256, 1, 1) == [0]
+    # inside a prover call (other launches beside it): one wave per SIMD at most
+    assert q("crt_pair_lanes8", 4096, 0, 1, 1, 2) == [1] and q("crt_pair_lanes8", 4352, 0, 1, 1, 2) == [0]
+
+
 def test_dual_ladder_windows_and_tables(q):
     W2 = 148
     assert q("dual_pair_window_bits", 16384, W2, 1) == [5] and q("dual_pair_window_bits", 61440, W2, 1) == [5]
