@@ -448,7 +448,7 @@ void garner_n3(const pgpu_seckey* sk, const uint32_t* xp, const uint32_t* xq, si
 // pr^3 the lift is t (t^(pr-1))^z, z = -(pr - 1)^-1 in Z_pr: w = t^(pr-1) on the digit kernel (the ladder of the level-two
 // decryption, both halves in one launch), a = (w - 1) / pr (exact for every unit t; a t that is 0 modulo the prime is flagged in d_status),
 // (1 + pr a)^z = 1 + pr (z a mod pr^2) + pr^2 (C(z,2) a^2 mod pr); then Garner.  T: WT(n^3) limbs, stride nb.
-void teichmueller_lift(const pgpu_seckey* sk, uint32_t* const t[2], size_t nb, int32_t* d_status, uint32_t* T) {
+void teichmueller_lift(const pgpu_seckey* sk, uint32_t* const t[2], size_t nb, int32_t* d_status, uint32_t* T, int beside) {
   pgpu_ctx* ctx = sk->ctx;
   const ModCtx &mp3 = sk->mp3, &mq3 = sk->mq3;
   const int H = sk->mp.WT, P2 = sk->mp2.WT, W = mp3.WT;
@@ -468,15 +468,8 @@ void teichmueller_lift(const pgpu_seckey* sk, uint32_t* const t[2], size_t nb, i
   }
   f2.join();
   {
-    Prog pp, pq;
-    emit_modexp_shared(pp, sk->p - BigU(1), 0, NO_SLOT, 2, 3, 5, NO_SLOT, true, true);
-    pp.end();
-    emit_modexp_shared(pq, sk->q - BigU(1), 0, NO_SLOT, 2, 3, 5, NO_SLOT, true, true);
-    pq.end();
-    SegSpec sp{&mp3, &pp, tp.mem, nullptr}, sq{&mq3, &pq, tq.mem, nullptr};
-    sp.pair = mp3.triple.kconsts; sp.pair_n0inv = sk->mp.n0inv; sp.pair_h = tp.H; sp.pair_lanes = 3; sp.tconsts = mp3.triple.tconsts;
-    sq.pair = mq3.triple.kconsts; sq.pair_n0inv = sk->mq.n0inv; sq.pair_h = tq.H; sq.pair_lanes = 3; sq.tconsts = mq3.triple.tconsts;
-    run_vm(ctx, nb, sp, &sq, true);
+    const BigU es[2] = {sk->p - BigU(1), sk->q - BigU(1)};
+    crt_triple_ladders(sk, es, tp, tq, nb, beside);        // (small batches: two lanes per digit)
   }
   // a = (w - 1) / pr (exact for every unit t), c = (1 + pr a)^z = 1 + pr (z a mod pr^2) + pr^2 (C(z,2) a^2 mod pr), tau = t c
   uint32_t* tau[2];
@@ -612,7 +605,8 @@ void struct_pow_n3(const pgpu_seckey* sk, const StructBase& sb, const uint32_t* 
     launch_canon(tt[half], (half ? sk->mq : sk->mp).d_nmod, H, nb, ctx->stream);
   }
   uint32_t* T = ctx->ws_t<uint32_t>((size_t)W3 * nb);
-  teichmueller_lift(sk, tt, nb, d_status, T);
+  // (ct1's decryption -- a CU per workgroup on half the chip -- may still be running: the lift then counts it as a launch beside itself)
+  teichmueller_lift(sk, tt, nb, d_status, T, plaintext_ready ? 2 : 1);
   // (3) the <1 + n> coordinate: k = m e mod n^2, G = (1 + n)^k = 1 + k n + C(k, 2) n^2 -- a chain of small kernels on a lane of its
   // own that waits for the plaintext.  ISSUED here, behind everything the ladder and the lift fork to their lanes: the runtime maps a
   // process's streams onto four hardware queues (this context has five streams), and a chain that waits for the decryption of ct1

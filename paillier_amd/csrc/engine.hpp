@@ -701,6 +701,11 @@ struct pgpu_seckey {
   DevLimbs q_limbs, p2_limbs;            // q as mq.WT limbs, p^2 as mp2.WT limbs
   DevLimbs q2_limbs;                     // q^2 as mq2.WT limbs
   DevLimbs tkc_p, ttc_p, tkc_q, ttc_q;   // three-digit kernel constants for the ladders modulo p^3 and q^3 (mp3 / mq3 .triple)
+  // the same ladders with TWO lanes per digit (GenQ6 on 19-limb slices: digits of h6 = 38 limbs, Montgomery radix R_38 per digit) for
+  // batches that leave most of the chip empty (plan::crt_triple_lanes6): kconsts for 38-limb digits, and the digit forms of
+  // R_38^2 R_H^-1 (entry from the radix-R_H digit form), R_H (exit), R_38 (= 1)
+  int triple_h6 = 0;
+  DevLimbs tkc6_p, ttc6_p, tkc6_q, ttc6_q;
   ExpOrder eo_p, eo_q;                   // exponent reduction modulo the orders of the units modulo p^3 / q^3
   // The key holder's powers modulo n^3 through the STRUCTURE of the unit group, Z*_{n^3} = <1 + n> x (Teichmueller lifts of Z*_n)
   // (ddleq.cpp struct_pow_n3): ladders modulo the primes with exponents modulo p - 1, q - 1, then the lift
@@ -741,6 +746,9 @@ struct TriplePlan {
   int H;
   uint32_t* slot(uint32_t i) const { return mem + (size_t)i * slot_words; }
 };
+// the ladders x^(e[half]) modulo p^3 | q^3 in digit form, both halves in one launch: slot 0 -> slot 3 of tp / tq (table from slot 5), on one
+// lane per digit or -- small batches -- two (plan::crt_triple_lanes6)
+void crt_triple_ladders(const pgpu_seckey* sk, const BigU e[2], const TriplePlan& tp, const TriplePlan& tq, size_t nb, int beside = 1);
 
 ModexpPlan modexp_alloc(pgpu_ctx* ctx, const ModCtx& mc, size_t nb, int table_slots);
 void reduce_mod(pgpu_ctx* ctx, const ModCtx& mc, const uint32_t* in, int w_in, uint32_t* out, size_t nb);
@@ -840,7 +848,7 @@ uint32_t* L_times_const(pgpu_ctx* ctx, const pgpu_pubkey* pk, const uint32_t* u,
                         int c_const, const uint32_t* neg_const);
 uint32_t* decrypt2_crt(const pgpu_seckey* sk, const uint32_t* c_limbs, size_t nb, size_t count, int32_t* d_status);
 bool struct_pow_usable(const pgpu_seckey* sk);
-void teichmueller_lift(const pgpu_seckey* sk, uint32_t* const t[2], size_t nb, int32_t* d_status, uint32_t* T);
+void teichmueller_lift(const pgpu_seckey* sk, uint32_t* const t[2], size_t nb, int32_t* d_status, uint32_t* T, int beside = 1);   // beside: plan::crt_triple_lanes6
 const pgpu_pubkey::Comb7& ensure_comb7(pgpu_pubkey* pk, int level, const BigU& base, size_t ebits);
 void emit_comb7(Prog& p, int we);
 constexpr uint32_t kComb7First = 4;   // first table entry of a Comb7 buffer (behind the standard constants)

@@ -3907,11 +3907,11 @@ class GenQ3(LaneRows, Gen):
         return "\n".join(self.lines) + "\n"
 
 
-SHAPES = [(74, 1), (37, 1), (55, 1), (55, 2), (74, 2), (55, 4), (74, 4), (42, 8), (37, 2), (37, 4), (10, 4), (37, 16), (55, 16), (74, 32), (55, 32), (37, 32), (37, 64), (19, 96), (10, 96), (74, 48), (37, 48), (55, 48), (55, 112), (37, 112)]
+SHAPES = [(74, 1), (37, 1), (55, 1), (55, 2), (74, 2), (55, 4), (74, 4), (42, 8), (37, 2), (37, 4), (10, 4), (37, 16), (55, 16), (74, 32), (55, 32), (37, 32), (37, 64), (19, 96), (10, 96), (74, 48), (37, 48), (55, 48), (55, 112), (37, 112), (19, 112)]
 PAIR = {(37, 16), (55, 16)}  # (H, 16): the pair kernel for N = p^2 with H-limb p (GenP); 16 is a tag, not a lane count
 PAIR4 = {(37, 64)}          # (WL, 64): GenQ4, the two digits of GenQ(2 WL) sliced over two lanes each
 PAIR8 = {(19, 96), (10, 96)}          # (WL, 96): GenQ8, the two digits sliced over four lanes each (76-limb digits)
-TRIPLE2 = {(55, 112), (37, 112)}   # (WL, 112): GenQ6, three digits of 2 WL limbs, two lanes each (+ two helper lanes)
+TRIPLE2 = {(55, 112), (37, 112), (19, 112)}   # (WL, 112): GenQ6, three digits of 2 WL limbs, two lanes each (+ two helper lanes)
 PAIR2 = {(74, 32), (55, 32), (37, 32)}          # (H, 32): the two-lane pair kernel for N = n^2 with H-limb n (GenQ)
 WAVE_SLICED = {(74, 2), (55, 2)}     # shapes whose slices live in different waves (GenW) instead of neighbouring lanes (Gen)
 TRIPLE = {(74, 48), (37, 48), (55, 48)}        # (H, 48): GenQ3, residues modulo n^3 as three base-n digits in the lanes of a quad

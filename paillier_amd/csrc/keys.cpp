@@ -399,6 +399,38 @@ int pgpu_seckey_create(pgpu_ctx* ctx, const pgpu_pubkey* pk, const uint8_t* lamb
                 (size_t)LB * sk->mp3.WT >= sk->mp3.nbits + 3 && (size_t)LB * sk->mq3.WT >= sk->mq3.nbits + 3) {
               setup_triple(sk->mp3, sk->mp, sk->mp2, sk->tkc_p, sk->ttc_p, sk->pinv2k.d, sk->pinv2k_2.d, sk->p_limbs.d, sk->p2_limbs.d);
               setup_triple(sk->mq3, sk->mq, sk->mq2, sk->tkc_q, sk->ttc_q, sk->qinv2k.d, sk->qinv2k_2.d, sk->q_limbs.d, sk->q2_limbs.d);
+              {
+                // two lanes per digit for small batches: digits of h6 = H + 1 limbs in two slices (GenQ6)
+                const int H = sk->mp.WT, h6 = (H + 1) / 2 * 2;
+                if (H % 2 == 1 && vm_asm_available(h6 / 2, 112)) {
+                  auto consts6 = [&](const BigU& pr, const BigU& pr3, DevLimbs& kc, DevLimbs& tc) {
+                    const std::vector<uint32_t> k6 = make_triple_kconsts(pr, h6);
+                    const BigU rh = hostbig::shl(BigU(1), (size_t)LB * H) % pr3, r6 = hostbig::shl(BigU(1), (size_t)LB * h6) % pr3;
+                    BigU rh_inv;
+                    if (!hostbig::modinv(rh, pr3, rh_inv)) return false;
+                    const BigU vals[3] = {hostbig::mulmod(hostbig::mulmod(r6, r6, pr3), rh_inv, pr3), rh, r6};
+                    std::vector<uint32_t> t6;
+                    for (const BigU& v : vals) {
+                      BigU q1, d0, d1, d2;
+                      hostbig::divmod(v, pr, q1, d0);
+                      hostbig::divmod(q1, pr, d2, d1);
+                      for (const BigU* dg : {&d0, &d1, &d2}) {
+                        auto l = dg->to_limbs(LB, (size_t)h6);
+                        t6.insert(t6.end(), l.begin(), l.end());
+                      }
+                    }
+                    auto put = [&](DevLimbs& d, const std::vector<uint32_t>& v) {
+                      d.w = (int)v.size();
+                      HIPCHK(hipMalloc((void**)&d.d, v.size() * 4));
+                      HIPCHK(hipMemcpy(d.d, v.data(), v.size() * 4, hipMemcpyHostToDevice));
+                    };
+                    put(kc, k6);
+                    put(tc, t6);
+                    return true;
+                  };
+                  if (consts6(p, sk->mp3.N, sk->tkc6_p, sk->ttc6_p) && consts6(q, sk->mq3.N, sk->tkc6_q, sk->ttc6_q)) sk->triple_h6 = h6;
+                }
+              }
               sk->eo_p.init(ctx, p);
               sk->eo_q.init(ctx, q);
               // the Teichmueller lift and the exponents modulo p - 1, q - 1 (struct_pow_n3)

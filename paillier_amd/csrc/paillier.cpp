@@ -161,6 +161,50 @@ void prime_slot_fill(pgpu_ctx* ctx, const PrimeShape& ps, uint32_t* slot, const 
   if (ps.Hs > ps.H) HIPCHK(hipMemsetAsync(slot + (size_t)ps.H * nb, 0, (size_t)(ps.Hs - ps.H) * nb * 4, ctx->stream));
 }
 
+void crt_triple_ladders(const pgpu_seckey* sk, const BigU e[2], const TriplePlan& tp, const TriplePlan& tq, size_t nb, int beside) {
+  pgpu_ctx* ctx = sk->ctx;
+  const ModCtx &mp3 = sk->mp3, &mq3 = sk->mq3;
+  const bool on_side = ctx->stream == ctx->side || ctx->stream == ctx->side_l[0] || ctx->stream == ctx->side_l[1] || ctx->stream == ctx->side_l[2];
+  const bool six = ctx->use_asm && plan::crt_triple_lanes6(nb, plan::lanes_target(ctx->lanes_wanted, ctx->stream_cus), sk->triple_h6 > 0, ctx->use_lanes8,
+                                                           std::max(beside, ctx->exclusive_call && on_side ? 2 : 1));
+  Prog lad[2];
+  if (!six) {
+    for (int half = 0; half < 2; ++half) {
+      emit_modexp_shared(lad[half], e[half], 0, NO_SLOT, 2, 3, 5, NO_SLOT, true, true);
+      lad[half].end();
+    }
+    SegSpec sp{&mp3, &lad[0], tp.mem, nullptr}, sq{&mq3, &lad[1], tq.mem, nullptr};
+    sp.pair = mp3.triple.kconsts; sp.pair_n0inv = sk->mp.n0inv; sp.pair_h = tp.H; sp.pair_lanes = 3; sp.tconsts = mp3.triple.tconsts;
+    sq.pair = mq3.triple.kconsts; sq.pair_n0inv = sk->mq.n0inv; sq.pair_h = tq.H; sq.pair_lanes = 3; sq.tconsts = mq3.triple.tconsts;
+    run_vm(ctx, nb, sp, &sq, true);
+    return;
+  }
+  // two lanes per digit: slots of 3 x h6 limbs of their own (0 in, 2 tmp, 3 out, 5.. the table); the digits zero-extended, radix R_H -> R_h6
+  // with the first product of the program and back with its last
+  const int H = tp.H, H6 = sk->triple_h6;
+  const size_t S1 = (size_t)H * nb, S6 = (size_t)H6 * nb, SW6 = 3 * S6;
+  uint32_t* m6[2];
+  for (int half = 0; half < 2; ++half) {
+    const TriplePlan& t = half ? tq : tp;
+    m6[half] = ctx->ws_t<uint32_t>(SW6 * (size_t)(5 + 32));
+    HIPCHK(hipMemsetAsync(m6[half], 0, SW6 * 4, ctx->stream));
+    for (int d = 0; d < 3; ++d) launch_restride(t.slot(0) + (size_t)d * S1, nb, nb, nullptr, m6[half] + (size_t)d * S6, nb, H, ctx->stream);
+    Prog& p = lad[half];
+    p.op(VM_LOAD, 0); p.op(VM_MULC, 0); p.op(VM_STORE, 0);
+    emit_modexp_shared(p, e[half], 0, NO_SLOT, 2, 3, 5, NO_SLOT, true, true);
+    p.op(VM_LOAD, 3); p.op(VM_MULC, 1); p.op(VM_STORE, 3);
+    p.end();
+  }
+  SegSpec sp{&mp3, &lad[0], m6[0], nullptr}, sq{&mq3, &lad[1], m6[1], nullptr};
+  sp.pair = sk->tkc6_p.d; sp.pair_n0inv = sk->mp.n0inv; sp.pair_h = H6; sp.pair_lanes = 6; sp.tconsts = sk->ttc6_p.d;
+  sq.pair = sk->tkc6_q.d; sq.pair_n0inv = sk->mq.n0inv; sq.pair_h = H6; sq.pair_lanes = 6; sq.tconsts = sk->ttc6_q.d;
+  run_vm(ctx, nb, sp, &sq, true);
+  for (int half = 0; half < 2; ++half) {
+    const TriplePlan& t = half ? tq : tp;
+    for (int d = 0; d < 3; ++d) launch_restride(m6[half] + 3 * SW6 + (size_t)d * S6, nb, nb, nullptr, t.slot(3) + (size_t)d * S1, nb, H, ctx->stream);
+  }
+}
+
 bool crt_pair8_usable(const pgpu_seckey* sk, size_t nb) {
   pgpu_ctx* ctx = sk->ctx;
   return sk->has_pair && ctx->use_asm && ctx->use_pair &&
@@ -534,15 +578,8 @@ uint32_t* decrypt2_crt(const pgpu_seckey* sk, const uint32_t* c_limbs, size_t nb
     triple_enter(ctx, mp3, g + 2 * S3, tp, 0);
     reduce_mod(ctx, mq3, c_limbs, 2 * W3, g + 2 * S3, nb);
     triple_enter(ctx, mq3, g + 2 * S3, tq, 0);
-    Prog pp, pq;
-    emit_modexp_shared(pp, sk->p - BigU(1), 0, NO_SLOT, 2, 3, 5, NO_SLOT, true, true);
-    pp.end();
-    emit_modexp_shared(pq, sk->q - BigU(1), 0, NO_SLOT, 2, 3, 5, NO_SLOT, true, true);
-    pq.end();
-    SegSpec sp{&mp3, &pp, tp.mem, nullptr}, sq{&mq3, &pq, tq.mem, nullptr};
-    sp.pair = mp3.triple.kconsts; sp.pair_n0inv = mp.n0inv; sp.pair_h = tp.H; sp.pair_lanes = 3; sp.tconsts = mp3.triple.tconsts;
-    sq.pair = mq3.triple.kconsts; sq.pair_n0inv = mq.n0inv; sq.pair_h = tq.H; sq.pair_lanes = 3; sq.tconsts = mq3.triple.tconsts;
-    run_vm(ctx, nb, sp, &sq, true);
+    const BigU es[2] = {sk->p - BigU(1), sk->q - BigU(1)};
+    crt_triple_ladders(sk, es, tp, tq, nb);
     up = g;
     uq = g + S3;
     triple_exit(ctx, mp3, tp, 3, up, nullptr);

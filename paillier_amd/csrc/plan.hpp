@@ -90,6 +90,12 @@ inline int crt_pair_lanes(int key_lanes, bool have_two_lane_variant, size_t nb, 
 inline bool crt_pair_lanes8(size_t nb, size_t lt, bool have8, bool enabled, int beside = 1) {
   return have8 && enabled && nb * 2 * 8 * (size_t)beside <= 2 * lt;
 }
+// ... and the ladders modulo p^3, q^3 (level-two Decrypt, the prover's lifts and plaintexts) with TWO lanes per digit (vm_asm_19_112: the
+// digits of 37-limb primes in two slices of 19 limbs; 38 rows of ~55 instructions where one lane per digit has 37 rows of ~93) while both
+// halves leave every wave a SIMD of its own: up to 4 096 numbers, counted with the launches known to run beside this one
+inline bool crt_triple_lanes6(size_t nb, size_t lt, bool have6, bool enabled, int beside = 1) {
+  return have6 && enabled && nb * 2 * 8 * (size_t)beside <= lt;
+}
 // whether the CRT halves of Decrypt take the pair kernels at all at this batch size
 inline bool crt_pair_usable(int lanes_now, int prime_limbs, size_t nb, size_t lt) { return lanes_now == 1 || prime_limbs <= 55 || nb * 4 >= lt; }
 

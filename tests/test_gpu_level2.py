@@ -272,3 +272,42 @@ def test_seven_bit_comb_asm_and_hipcc_kernels_agree(ctx, level):
     assert got[1] == got[0]
     want = [po.alt_encrypt_with_r_at_level(sk_o, m, r, level) for m, r in zip(ms[:6], rs[:6])]
     assert got[1][0][:6] == [w[0].C for w in want] and got[1][1][:6] == [w[1] for w in want]
+
+
+def test_crt_ladders_modulo_the_cubes_on_two_lanes_per_digit(ctx):
+    """Round 5: the ladders modulo p^3, q^3 of a small batch -- level-two Decrypt, the Teichmueller lifts and per-statement plaintexts of
+    the DDLEQ prover -- run on the three-digit kernel with TWO lanes per digit (vm_asm_19_112: the digits of the 37-limb primes in two
+    slices of 19 limbs, radix changed on the way in and out; plan::crt_triple_lanes6, flag "lanes8").  Same integers as one lane per
+    digit (lanes8 0), as the oracle, non-units included; the profile shows that the flag changed the kernel."""
+    import paillier_amd as pa
+    from paillier_amd import ENC_LEVEL_TWO
+    k = json.load(open(os.path.join(G, "keys.json")))["paillier"]["2048"]
+    p, q = int(k["p"], 16), int(k["q"], 16)
+    n, lam = p * q, (p - 1) * (q - 1)
+    n2, n3 = n * n, n ** 3
+    sk_o = po.SecretKey(N=n, G=n + 1, Lambda=lam)
+    pk = pa.PublicKey(ctx, n, n + 1)
+    sk = pa.SecretKey(ctx, pk, lam)
+    rng = random.Random(4242)
+    ms = [0, 1, n - 1, n, n2 - 1] + [rng.randrange(n2) for _ in range(35)]
+    rs = [po.rand_unit(n, rng) for _ in ms]
+    cts = pk.EncryptWithRBatch(ms, rs, level=ENC_LEVEL_TWO)
+    weird = [rng.randrange(n3) for _ in range(3)] + [n3 - 1, 1, p, n, n2, 0, 5 * n2, q * q]
+    ms1 = [rng.randrange(n) for _ in range(6)]
+    got, kern = {}, {}
+    try:
+        for lanes8 in (1, 0):
+            ctx.set_flag("lanes8", lanes8)
+            dec = sk.DecryptBatch(cts, level=ENC_LEVEL_TWO)
+            kern[lanes8] = ctx.last_profile()["kernel"]
+            assert ctx.last_vm_asm() == ctx.last_vm_launches()
+            w, st = sk.DecryptBatch(weird, level=ENC_LEVEL_TWO, return_status=True)
+            e2 = sk.EncryptWithRBatch(ms1, rs[:len(ms1)], ENC_LEVEL_TWO)          # the key holder's form: a lift modulo p^3, q^3
+            got[lanes8] = (dec, w, st.tolist(), e2)
+    finally:
+        ctx.set_flag("lanes8", 1)
+    assert got[1] == got[0]
+    assert kern[1] == "vm_asm_19_112" and kern[0] == "vm_asm_37_48", kern
+    assert got[1][0] == ms
+    assert got[1][1] == [po.decrypt(sk_o, po.Ciphertext(c, po.ENC_LEVEL_TWO)) for c in weird]
+    assert got[1][3] == [po.encrypt_with_r_at_level(sk_o, m, r, po.ENC_LEVEL_TWO).C for m, r in zip(ms1, rs)]

@@ -262,6 +262,14 @@ def test_crt_halves_on_eight_lanes(q):
     assert q("crt_pair_lanes8", 4096, 0, 1, 1, 2) == [1] and q("crt_pair_lanes8", 4352, 0, 1, 1, 2) == [0]
 
 
+def test_cube_ladders_on_two_lanes_per_digit(q):
+    """The ladders modulo p^3, q^3 of up to 4 096 numbers (both halves: a SIMD per wave at eight lanes per number) take two lanes per digit;
+    on a side lane of a prover call -- ct1's decryption beside the main stream's ladders -- up to 2 048."""
+    assert q("crt_triple_lanes6", 4096, 0, 1, 1) == [1] and q("crt_triple_lanes6", 4352, 0, 1, 1) == [0]
+    assert q("crt_triple_lanes6", 2048, 0, 1, 1, 2) == [1] and q("crt_triple_lanes6", 2304, 0, 1, 1, 2) == [0]
+    assert q("crt_triple_lanes6", 256, 0, 0, 1) == [0] and q("crt_triple_lanes6", 256, 0, 1, 0) == [0]
+
+
 def test_dual_ladder_windows_and_tables(q):
     W2 = 148
     assert q("dual_pair_window_bits", 16384, W2, 1) == [5] and q("dual_pair_window_bits", 61440, W2, 1) == [5]
