@@ -87,6 +87,7 @@ int pgpu_ctx_set_flag(pgpu_ctx* ctx, const char* name, int value) {
   if (strcmp(name, "exclusive_short") == 0) { ctx->use_exclusive_short = value != 0; return PGPU_OK; }
   if (strcmp(name, "base_early") == 0) { ctx->use_base_early = value != 0; return PGPU_OK; }
   if (strcmp(name, "late") == 0) { ctx->use_late = value != 0; return PGPU_OK; }
+  if (strcmp(name, "lanes16") == 0) { ctx->use_lanes16 = value != 0; return PGPU_OK; }
   if (strcmp(name, "prime_lanes") == 0) { ctx->use_prime_lanes = value != 0; return PGPU_OK; }
   if (strcmp(name, "spread") == 0) { ctx->use_spread = value != 0; return PGPU_OK; }
   if (strcmp(name, "w74") == 0) { ctx->use_w74 = value != 0; return PGPU_OK; }

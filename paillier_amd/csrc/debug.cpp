@@ -133,7 +133,7 @@ int pgpu_plan_query(const char* what, const uint64_t* a, int nargs, int64_t* out
     return 2;
   }
   if (w == "extract_beside" && need(3, 1)) { out[0] = plan::extract_beside((size_t)a[0], (size_t)a[1], lt(2)); return 1; }
-  if (w == "pair_lanes_shared" && need(4, 1)) { out[0] = plan::pair_lanes_shared((size_t)a[0], lt(1), a[2] != 0, a[3] != 0); return 1; }
+  if (w == "pair_lanes_shared" && need(4, 1)) { out[0] = plan::pair_lanes_shared((size_t)a[0], lt(1), a[2] != 0, a[3] != 0, nargs > 4 && a[4] != 0); return 1; }
   if (w == "pair_lanes_2or4" && need(3, 1)) { out[0] = plan::pair_lanes_2or4((size_t)a[0], lt(1), a[2] != 0); return 1; }
   if (w == "pair_kernel_serves" && need(3, 1)) { out[0] = plan::pair_kernel_serves((size_t)a[0], lt(1), a[2] != 0); return 1; }
   if (w == "crt_pair_lanes" && need(4, 2)) {

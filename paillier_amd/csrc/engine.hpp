@@ -99,6 +99,7 @@ struct pgpu_ctx {
                                  // workgroup then asks for the whole LDS of a CU, so the dispatcher cannot stack the side lanes' workgroups on the CUs the main
                                  // launch runs on (it starts every queue's workgroups from the same CUs: 17.5 -> 28 ms for a^n | x^n of 2 048 instances)
   bool use_base_early = true;  // the links of the prover's side chains (ct1's structure chain, the preparation of the response) run beside the main stream's ladders (pgpu_ctx_set_flag("base_early", 0): they wait for an empty compute unit, i.e. for the end of a ladder)
+  bool use_lanes16 = true;       // shared-exponent ladders modulo n^2 of up to 2 048 numbers on sixteen lanes per number (pgpu_ctx_set_flag("lanes16", 0): eight)
   bool use_prime_lanes = true;   // ladders modulo the 37-limb primes of small batches on four lanes per number (pgpu_ctx_set_flag("prime_lanes", 0): one lane, the unrolled kernel)
   bool use_late = true;      // the DDLEQ prover's response for few instances per statement through the structure of the unit group AFTER the hash: b's plaintext for the statements with a bit-1 instance only (pgpu_ctx_set_flag("late", 0): the one-ladder response on s and b themselves)
   bool use_spread = true;    // a main-stream ladder of at most one workgroup per CU asks for just over half a CU's LDS (plan::lds_share; pgpu_ctx_set_flag("spread", 0): the dispatcher's placement)
@@ -333,6 +334,10 @@ struct PairInfo {
   int h8 = 0;
   const uint32_t* consts8 = nullptr;  // device: n | Cadj, h8 limbs each, + one word of padding
   const uint32_t* tconsts8 = nullptr; // device: [3][2 h8] pair digits of R_h8^2 R_H^-1 (radix R_H -> R_h8), of R_H (back), of R_h8 (= 1)
+  // the sixteen-lane pair kernel (GenQ16: every digit in eight lanes of h16 / 8 limbs): the same constants for digits of h16 limbs
+  int h16 = 0;
+  const uint32_t* consts16 = nullptr;
+  const uint32_t* tconsts16 = nullptr;
 };
 
 // A modulus N = n^3 whose root n is known can run its ladders on the three-digit kernel (GenQ3): residues as
@@ -615,6 +620,7 @@ struct pgpu_pubkey {
   struct CachedInverse { BigU x, inv; bool unit; };
   std::vector<CachedInverse> inverse_cache;   // inverses modulo n^2 of per-key constants (verification keys), taken once on the host
   DevLimbs pairn_consts;          // n | Cadj | pad for the two-lane pair kernel (mn2.pairn points here)
+  DevLimbs pairn_consts16, pairn_tconsts16; // ... and for the sixteen-lane pair kernel (80-limb digits)
   DevLimbs pairn_consts8, pairn_tconsts8;   // the same for the eight-lane pair kernel (76-limb digits) and its three constants
   DevLimbs triple_kconsts;        // n | (C1_i, C2_i) pairs | pad for the three-digit kernel (mn3->triple points here)
   DevLimbs triple_tconsts;        // its constants in digit form

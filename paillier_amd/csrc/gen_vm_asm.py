@@ -2887,7 +2887,7 @@ class GenQ4(Gen):
             self.mad(self.T(j - 1), m, N(j), self.T(j))
             if j == 4:
                 e(f"v_lshl_add_u64 {self.T(0)}, {self.T(0)}, 0, {self.P(g.v_c)}")
-        e(f"v_and_b32_dpp v{g.v_in}, v{g.v_y0}, v{g.v_rxmask} {self.dpp_next} row_mask:0xf bank_mask:0xf")
+        e(f"v_and_b32_dpp v{g.v_in}, v{g.v_y0}, v{g.v_rxmask} {self.dpp_next} row_mask:0xf bank_mask:0xf{getattr(self, 'dpp_next_tail', '')}")
 
     def row_pair(self, cur, nxt, link, ahead, bump, cur2=None, nxt2=None, count=False):
         """two rows on the multiplier pair(s) cur; the pair(s) of the two rows `ahead` rows past the pointer are fetched into nxt;
@@ -3223,6 +3223,147 @@ class GenQ8(GenQ4):
             e(f"global_load_dword v{g.v_p0}, v{g.v_t3}, s[6:7] offset:{4 * self.H + 4 * WL * sgi}")
             e("s_waitcnt vmcnt(0)")
             e(f"ds_write_b64 v{g.v_t4}, {self.P(g.v_p0)} offset:{self.lds_c + 32 + 8 * sgi}")
+        e("s_waitcnt lgkmcnt(0)")
+        e("s_mov_b64 exec, s[96:97]")
+        e(f"v_mov_b32 v{g.v_p0}, 0")
+        e(f"ds_write_b32 v{g.v_t3}, v{g.v_p0} offset:{self.lds_z}")      # every thread zeroes one word of the zero rows
+        e("s_waitcnt lgkmcnt(0)")
+        e("s_barrier")
+        for j in range(WL):
+            e(f"ds_read_b32 v{g.v_N + j}, v{g.v_nbase} offset:{4 * j}")
+        e("s_waitcnt lgkmcnt(0)")
+        for j in range(WL):
+            e(f"v_mov_b32 {self.X(j)}, 0")
+        self.init_row_regs()
+
+
+class GenQ16(GenQ8):
+    """The pair kernel with every digit sliced over EIGHT lanes: 16 lanes per number -- one DPP row (lanes 0..7 = the 10-limb slices of
+    a0, lanes 8..15 = those of a1; a digit is 80 limbs: the 74 limbs of a 2048-bit n padded, radix R_80, the host changes radix with
+    one product on the way in and one on the way out as for GenQ8).  Rows, one-pass product and carries are GenQ4's with the exchanges
+    of a row: neighbours by row_shl:1 / row_shr:1 (what crosses a digit is masked, what comes from outside the row reads as zero), the
+    link and the copy of a0 by row_shr:8, the quotient digit's broadcast in two steps (its quad, then the quad above takes it from
+    four lanes down).  A squaring is 80 rows of 20 multiplies per lane where GenQ8 has 76 rows of 38: for shared-exponent ladders
+    modulo n^2 of at most 2 048 numbers (the verifier's E^n and y^n, small Encrypt batches), whose latency is the run time -- 6.4 us a
+    squaring against 7.4: the quotient chain of a row (six dependent steps, one multiply apart) is not hidden any more."""
+
+    def __init__(self, WL=10):
+        Gen.__init__(self, WL, 8)
+        assert self.n_vreg and not self.flush
+        self.H = 8 * WL
+        self.WTslot = 16 * WL
+        self.WT = self.WTslot
+        self.NPB = BLOCK // 16
+        self.name = f"vm_asm_{WL}_128"
+        self.sq_rows = True
+        self.sq_rows_k = False
+        self.lanes_per_number = 16
+        self.lds_a = (8 * self.WLp * 4 + 15) // 16 * 16
+        e = self.n_vgpr
+        self.v_sh, self.v_l2mask, self.v_l3mask = e, e + 1, e + 2      # l2mask: the link lane (k16 == 8); l3mask: digit one (k16 >= 8)
+        e += 3
+        e = (e + 1) // 2 * 2
+        self.v_d = e
+        e += 2
+        self.vR2 = e
+        e += WL
+        self.v_ai2, self.v_ain2, self.v_arow2, self.v_bump2 = e, e + 1, e + 2, e + 3
+        e += 4
+        self._xb = self.vX
+        self.v_caddr = e
+        e += 1
+        self.n_vgpr = e
+        self.alloc_row_regs()
+        assert self.n_vgpr <= 256, self.n_vgpr
+        self.lds_c = self.lds_a + (self.WTslot + 1) * self.NPB * 4
+        self.lds_z = self.lds_c + WL * 128
+        self.lds_bytes = self.lds_z + 1024
+        assert self.lds_bytes < 65536
+        self.has_muls = True
+        self.dpp_link = "row_shr:8"
+        self.dpp_bcast = None                     # two steps: chain_steps
+        self.dpp_next = "row_shl:1"
+        self.dpp_next_tail = " bound_ctrl:1"      # lane 15 reads past the row: zero, not its stale register
+        self.dpp_prev = "row_shr:1"
+        self.dpp_copy0 = "row_shr:8"
+        self.v_linkmask = self.v_l2mask
+        self.v_d1mask = self.v_l3mask
+
+    def chain_steps(self, link):
+        g = self
+        m = f"v{g.v_m}"
+        chain = [f"v_mul_lo_u32 {m}, {self.Tlo(0)}, s14"]
+        if link:
+            chain += [f"v_and_b32_dpp v{g.v_d}, {m}, v{g.v_mask28} {self.dpp_link} row_mask:0xf bank_mask:0xf",
+                      f"v_mad_i64_i32 {self.T(0)}, vcc, v{g.v_d}, v{g.v_linkmask}, {self.T(0)}",
+                      f"v_mul_lo_u32 {m}, {self.Tlo(0)}, s14"]
+        # slice 0 of the digit -> its quad, then the digit's upper quad (banks 1 and 3 of the row) takes it from four lanes down
+        chain.append(f"v_and_b32_dpp {m}, {m}, v{g.v_mask28} quad_perm:[0,0,0,0] row_mask:0xf bank_mask:0xf")
+        chain.append(f"v_mov_b32_dpp {m}, {m} row_shr:4 row_mask:0xf bank_mask:0xa")
+        return chain
+
+    def prologue(self):
+        g, e = self, self.e
+        WL, NPB = self.WL, self.NPB
+        e(f'.amdgcn_target "amdgcn-amd-amdhsa--gfx950"')
+        e(".text")
+        e(f".globl {self.name}")
+        e(".p2align 8")
+        e(f".type {self.name},@function")
+        e(f"{self.name}:")
+        self.select_segment()
+        e("s_load_dwordx8 s[4:11], s[0:1], 0x0")
+        e("s_load_dwordx4 s[12:15], s[0:1], 0x20")
+        e("s_waitcnt lgkmcnt(0)")
+        e("s_lshl_b32 s3, s15, 2")
+        e(f"v_and_b32 v{g.v_t1}, 15, v0")                 # k16 = 8 d + s
+        e(f"v_lshlrev_b32 v{g.v_caddr}, 3, v{g.v_t1}")    # this lane's column of the constants table: k16 * 8
+        e(f"v_lshrrev_b32 v{g.v_t2}, 4, v0")              # gl
+        e(f"s_mul_i32 s{g.s_t0}, s2, {NPB}")
+        e(f"v_add_u32 v{g.v_t3}, s{g.s_t0}, v{g.v_t2}")   # g
+        e(f"s_mul_i32 s{g.s_t1}, s15, {WL}")
+        e(f"v_mul_lo_u32 v{g.v_t4}, v{g.v_t1}, s{g.s_t1}")
+        e(f"v_add_lshl_u32 v{g.v_goff}, v{g.v_t4}, v{g.v_t3}, 2")
+        e(f"v_lshlrev_b32 v{g.v_aread}, 2, v{g.v_t2}")
+        e(f"v_add_u32 v{g.v_aread}, {self.lds_a}, v{g.v_aread}")
+        e(f"v_mul_u32_u24 v{g.v_t4}, {WL * NPB * 4}, v{g.v_t1}")
+        e(f"v_add_u32 v{g.v_awrite}, v{g.v_t4}, v{g.v_aread}")
+        e(f"v_mul_u32_u24 v{g.v_koff}, {WL * 4}, v{g.v_t1}")
+        e(f"v_and_b32 v{g.v_t4}, 7, v{g.v_t1}")           # s
+        e(f"v_mul_u32_u24 v{g.v_nbase}, {self.WLp * 4}, v{g.v_t4}")
+        e(f"v_lshrrev_b32 v{g.v_sh}, 3, v{g.v_t1}")       # d (kept; a squaring uses it as the multiplicand shift)
+        e(f"v_cmp_eq_u32 vcc, 0, v{g.v_t4}")
+        e("s_nop 1")
+        e(f"v_cndmask_b32 v{g.v_isfirst}, 0, -1, vcc")
+        e(f"v_cmp_ne_u32 vcc, 7, v{g.v_t4}")
+        e("s_nop 1")
+        e(f"v_cndmask_b32 v{g.v_notlast}, 0, -1, vcc")
+        e(f"v_cmp_eq_u32 vcc, 8, v{g.v_t1}")
+        e("s_nop 1")
+        e(f"v_cndmask_b32 v{g.v_l2mask}, 0, -1, vcc")
+        e(f"v_cmp_le_u32 vcc, 8, v{g.v_t1}")
+        e("s_nop 1")
+        e(f"v_cndmask_b32 v{g.v_l3mask}, 0, -1, vcc")
+        # modulus n (8 slices) -> LDS -> this lane's slice in VGPRs
+        e(f"v_lshlrev_b32 v{g.v_t3}, 2, v0")
+        e(f"v_cmp_gt_u32 vcc, {WL}, v0")
+        e("s_nop 1")
+        e("s_and_saveexec_b64 s[96:97], vcc")
+        for sgi in range(8):
+            e(f"global_load_dword v{g.v_p1}, v{g.v_t3}, s[6:7] offset:{sgi * WL * 4}")
+            e("s_waitcnt vmcnt(0)")
+            e(f"ds_write_b32 v{g.v_t3}, v{g.v_p1} offset:{sgi * self.WLp * 4}")
+        # constants table: thread t < WL writes row t = (eight zeros | Cadj_t, Cadj_(WL+t), ..., Cadj_(7 WL+t)), zero-extended to 64 bits
+        e(f"v_lshlrev_b32 v{g.v_t4}, 5, v{g.v_t3}")        # t * 128
+        e(f"v_mov_b32 v{g.v_y0}, 0")
+        e(f"v_mov_b32 v{g.v_y0 + 1}, 0")
+        e(f"v_mov_b32 v{g.v_p0 + 1}, 0")
+        for sgi in range(8):
+            e(f"ds_write_b64 v{g.v_t4}, {self.P(g.v_y0)} offset:{self.lds_c + 8 * sgi}")
+        for sgi in range(8):
+            e(f"global_load_dword v{g.v_p0}, v{g.v_t3}, s[6:7] offset:{4 * self.H + 4 * WL * sgi}")
+            e("s_waitcnt vmcnt(0)")
+            e(f"ds_write_b64 v{g.v_t4}, {self.P(g.v_p0)} offset:{self.lds_c + 64 + 8 * sgi}")
         e("s_waitcnt lgkmcnt(0)")
         e("s_mov_b64 exec, s[96:97]")
         e(f"v_mov_b32 v{g.v_p0}, 0")
@@ -3907,10 +4048,11 @@ class GenQ3(LaneRows, Gen):
         return "\n".join(self.lines) + "\n"
 
 
-SHAPES = [(74, 1), (37, 1), (55, 1), (55, 2), (74, 2), (55, 4), (74, 4), (42, 8), (37, 2), (37, 4), (10, 4), (37, 16), (55, 16), (74, 32), (55, 32), (37, 32), (37, 64), (19, 96), (10, 96), (74, 48), (37, 48), (55, 48), (55, 112), (37, 112), (19, 112)]
+SHAPES = [(74, 1), (37, 1), (55, 1), (55, 2), (74, 2), (55, 4), (74, 4), (42, 8), (37, 2), (37, 4), (10, 4), (37, 16), (55, 16), (74, 32), (55, 32), (37, 32), (37, 64), (19, 96), (10, 96), (10, 128), (74, 48), (37, 48), (55, 48), (55, 112), (37, 112), (19, 112)]
 PAIR = {(37, 16), (55, 16)}  # (H, 16): the pair kernel for N = p^2 with H-limb p (GenP); 16 is a tag, not a lane count
 PAIR4 = {(37, 64)}          # (WL, 64): GenQ4, the two digits of GenQ(2 WL) sliced over two lanes each
-PAIR8 = {(19, 96), (10, 96)}          # (WL, 96): GenQ8, the two digits sliced over four lanes each (76-limb digits)
+PAIR8 = {(19, 96), (10, 96)}
+PAIR16 = {(10, 128)}        # (WL, 128): GenQ16, the two digits sliced over eight lanes each (80-limb digits)          # (WL, 96): GenQ8, the two digits sliced over four lanes each (76-limb digits)
 TRIPLE2 = {(55, 112), (37, 112), (19, 112)}   # (WL, 112): GenQ6, three digits of 2 WL limbs, two lanes each (+ two helper lanes)
 PAIR2 = {(74, 32), (55, 32), (37, 32)}          # (H, 32): the two-lane pair kernel for N = n^2 with H-limb n (GenQ)
 WAVE_SLICED = {(74, 2), (55, 2)}     # shapes whose slices live in different waves (GenW) instead of neighbouring lanes (Gen)
@@ -3926,6 +4068,8 @@ def make_gen(wl, k):
         return GenQ4(wl)
     if (wl, k) in PAIR8:
         return GenQ8(wl)
+    if (wl, k) in PAIR16:
+        return GenQ16(wl)
     if (wl, k) in TRIPLE2:
         return GenQ6(wl)
     if (wl, k) in TRIPLE:

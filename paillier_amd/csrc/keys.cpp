@@ -207,6 +207,21 @@ int pgpu_pubkey_create(pgpu_ctx* ctx, const uint8_t* n_be, size_t n_len, const u
           pi.tconsts8 = pk->pairn_tconsts8.d;
         }
       }
+      const int h16 = (H + 7) / 8 * 8;
+      if (pi.h8 && vm_asm_available(h16 / 8, 128)) {
+        std::vector<uint32_t> pc16, tc;
+        if (make_pair8_consts(pk->N, n2, H, h16, pc16, tc)) {
+          pk->pairn_consts16.w = (int)pc16.size();
+          HIPCHK(hipMalloc((void**)&pk->pairn_consts16.d, pc16.size() * 4));
+          HIPCHK(hipMemcpy(pk->pairn_consts16.d, pc16.data(), pc16.size() * 4, hipMemcpyHostToDevice));
+          pk->pairn_tconsts16.w = (int)tc.size();
+          HIPCHK(hipMalloc((void**)&pk->pairn_tconsts16.d, tc.size() * 4));
+          HIPCHK(hipMemcpy(pk->pairn_tconsts16.d, tc.data(), tc.size() * 4, hipMemcpyHostToDevice));
+          pi.h16 = h16;
+          pi.consts16 = pk->pairn_consts16.d;
+          pi.tconsts16 = pk->pairn_tconsts16.d;
+        }
+      }
     }
     const bool one_lane_digit = pk->mn.K == 1 && vm_asm_available(pk->mn.WT, 48);
     const bool two_lane_digit = pk->mn.WT % 2 == 0 && vm_asm_available(pk->mn.WT / 2, 112);     // 3072-bit keys: digits of 110 limbs

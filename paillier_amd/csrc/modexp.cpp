@@ -44,10 +44,10 @@ void modexp_pair(pgpu_ctx* ctx, const ModCtx& mc, const ModexpPlan& pl, const Bi
     HIPCHK(hipMemcpyAsync(mem + 2 * SW, x0, S1 * 4, hipMemcpyDeviceToDevice, ctx->stream));
   }
   // (3) the ladder in pair form
-  if (lanes == 8 && !exps) {
-    // eight lanes per number (GenQ8, shared exponents only): slots of 2 x 76 limbs of their own; the digits are zero-extended,
-    // change radix R_74 -> R_76 with the first product of the program and come back with its last
-    const int H8 = pi.h8;
+  if ((lanes == 8 || lanes == 16) && !exps) {
+    // eight / sixteen lanes per number (GenQ8 / GenQ16, shared exponents only): slots of 2 x 76 / 2 x 80 limbs of their own; the digits
+    // are zero-extended, change radix R_74 -> R_76 / R_80 with the first product of the program and come back with its last
+    const int H8 = lanes == 16 ? pi.h16 : pi.h8;
     const size_t SW8 = (size_t)2 * H8 * nb;
     uint32_t* m8 = ctx->ws_t<uint32_t>(SW8 * (size_t)(5 + 32));        // pair slots: 2 in, 3 out, 5.. table
     HIPCHK(hipMemsetAsync(m8 + 2 * SW8, 0, SW8 * 4, ctx->stream));
@@ -59,7 +59,8 @@ void modexp_pair(pgpu_ctx* ctx, const ModCtx& mc, const ModexpPlan& pl, const Bi
     p.op(VM_LOAD, 3); p.op(VM_MULC, 1); p.op(VM_STORE, 3);
     p.end();
     SegSpec sp{&mc, &p, m8, nullptr};
-    sp.pair = pi.consts8; sp.pair_n0inv = mn.n0inv; sp.pair_h = H8; sp.pair_lanes = 8; sp.tconsts = pi.tconsts8;
+    sp.pair = lanes == 16 ? pi.consts16 : pi.consts8; sp.pair_n0inv = mn.n0inv; sp.pair_h = H8; sp.pair_lanes = lanes;
+    sp.tconsts = lanes == 16 ? pi.tconsts16 : pi.tconsts8;
     run_vm(ctx, nb, sp, nullptr, true);
     launch_restride(m8 + 3 * SW8, nb, nb, nullptr, mem + 3 * SW, nb, H, ctx->stream);
     launch_restride(m8 + 3 * SW8 + (size_t)H8 * nb, nb, nb, nullptr, mem + 3 * SW + S1, nb, H, ctx->stream);
@@ -70,7 +71,7 @@ void modexp_pair(pgpu_ctx* ctx, const ModCtx& mc, const ModexpPlan& pl, const Bi
     else emit_modexp_shared(p, *e, 2, NO_SLOT, 2, 3, 5, NO_SLOT, true, true);
     p.end();
     SegSpec sp{&mc, &p, mem, exps};
-    sp.pair = pi.consts; sp.pair_n0inv = mn.n0inv; sp.pair_h = H; sp.pair_lanes = lanes == 8 ? 4 : lanes;
+    sp.pair = pi.consts; sp.pair_n0inv = mn.n0inv; sp.pair_h = H; sp.pair_lanes = lanes >= 8 ? 4 : lanes;
     run_vm(ctx, nb, sp, nullptr, true);
   }
   if (raw_out) {
@@ -228,7 +229,8 @@ void modexp_shared_run(pgpu_ctx* ctx, const ModCtx& mc, const ModexpPlan& pl, co
   }
   if (pair_digits_in) api_throw(PGPU_ERR_UNSUPPORTED, "internal: pair digits handed to a ladder that is not on the digit kernel");
   const bool have4 = mc.pairn.root && mc.pairn.root->WT % 2 == 0 && vm_asm_available(mc.pairn.root->WT / 2, 64);
-  const int lanes = plan::pair_lanes_shared(pl.nb, plan::lanes_target(ctx->lanes_wanted, ctx->stream_cus), have4, have4 && mc.pairn.consts8 && ctx->use_lanes8);
+  const int lanes = plan::pair_lanes_shared(pl.nb, plan::lanes_target(ctx->lanes_wanted, ctx->stream_cus), have4, have4 && mc.pairn.consts8 && ctx->use_lanes8,
+                                            mc.pairn.consts16 && ctx->use_lanes16);
   if (mc.pairn.root && ctx->use_asm && ctx->use_pair && !wide && skip_zero && e.bit_length() >= 256 && plan::pair_kernel_serves(pl.nb, plan::lanes_target(ctx->lanes_wanted, ctx->stream_cus), have4)) {
     // (a batch that leaves SIMDs empty even at four lanes per number is bound by one ladder's latency: eight lanes, GenQ8)
     modexp_pair(ctx, mc, pl, &e, nullptr, 0, use_post, lanes, use_post ? nullptr : raw_pair_out);

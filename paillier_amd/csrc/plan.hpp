@@ -63,9 +63,14 @@ inline int dual_pair_window_bits(size_t nb, int w2, bool nm) {
 // Shared-exponent ladder modulo n^2 in pair form (GenQ 2 lanes / GenQ4 4 lanes / GenQ8 8 lanes per number).  `numbers` = all the
 // numbers of the launch (segments included).  Two lanes from one wave per SIMD upwards; below that four (a squaring is half as
 // long: the ladder's latency is the run time); eight while every wave still has a SIMD of its own.  0: no pair kernel fits.
-inline int pair_lanes_shared(size_t numbers, size_t lt, bool have4, bool have8) {
+// (round 5: sixteen -- GenQ16, a DPP row per number: a squaring is 80 rows of ~34 instructions where the eight-lane kernel has 76 rows of
+// 51, but the quotient chain of a row -- six dependent steps, one multiply apart -- is no longer hidden: 184 cycles a row measured, 6.4 us
+// a squaring against 7.4.  Up to 2 048 numbers: callers run TWO such ladders side by side (the verifier's E^n and y^n), and at 4 096
+// numbers each the pair took 25.9 ms where the eight-lane kernel takes 18)
+inline int pair_lanes_shared(size_t numbers, size_t lt, bool have4, bool have8, bool have16 = false) {
   if (numbers * 2 >= lt) return 2;
   if (!have4) return 2;
+  if (have8 && have16 && numbers * 16 * 2 <= lt) return 16;
   if (have8 && numbers * 8 <= lt) return 8;
   return 4;
 }

@@ -402,8 +402,8 @@ void run_vm(pgpu_ctx* ctx, size_t nb, const SegSpec& s0, const SegSpec* s1, bool
   if (s1 && pair != (s1->pair != nullptr)) api_throw(PGPU_ERR_INVALID, "segment kind mismatch");
   if (s2 && pair != (s2->pair != nullptr)) api_throw(PGPU_ERR_INVALID, "segment kind mismatch");
   if (pair) {
-    WL = s0.pair_lanes == 8 ? s0.pair_h / 4 : (s0.pair_lanes == 4 || s0.pair_lanes == 6) ? s0.pair_h / 2 : s0.pair_h;
-    K = s0.pair_lanes == 8 ? 96 : s0.pair_lanes == 6 ? 112 : s0.pair_lanes == 4 ? 64 : s0.pair_lanes == 3 ? 48 : s0.pair_lanes == 2 ? 32 : 16;   // tags of the pair kernels, not lane counts
+    WL = s0.pair_lanes == 16 ? s0.pair_h / 8 : s0.pair_lanes == 8 ? s0.pair_h / 4 : (s0.pair_lanes == 4 || s0.pair_lanes == 6) ? s0.pair_h / 2 : s0.pair_h;
+    K = s0.pair_lanes == 16 ? 128 : s0.pair_lanes == 8 ? 96 : s0.pair_lanes == 6 ? 112 : s0.pair_lanes == 4 ? 64 : s0.pair_lanes == 3 ? 48 : s0.pair_lanes == 2 ? 32 : 16;   // tags of the pair kernels, not lane counts
   } else {
     const plan::GenericShape gs = plan::generic_shape(WL, K, launch_nb, s2 ? 3 : s1 ? 2 : 1, plan::lanes_target(ctx->lanes_wanted, ctx->stream_cus),
                                                       ctx->use_w74 && ctx->use_asm);
@@ -440,7 +440,7 @@ void run_vm(pgpu_ctx* ctx, size_t nb, const SegSpec& s0, const SegSpec* s1, bool
       const double H = s0.pair_h;
       mulp = 12.0 * H * H;
       sq = 8.0 * H * H;
-    } else if (pair && (s0.pair_lanes == 4 || s0.pair_lanes == 8)) {   // GenQ4 / GenQ8: a squaring is one pass of H rows of 2 * H/2 multiplies in four lanes; a
+    } else if (pair && (s0.pair_lanes == 4 || s0.pair_lanes == 8 || s0.pair_lanes == 16)) {   // GenQ4 / GenQ8: a squaring is one pass of H rows of 2 * H/2 multiplies in four lanes; a
       const double H = s0.pair_h;              // product one pass with two multiplier streams (3 * H/2 multiplies a row)
       mulp = 6.0 * H * H;
       sq = 4.0 * H * H;
@@ -461,7 +461,7 @@ void run_vm(pgpu_ctx* ctx, size_t nb, const SegSpec& s0, const SegSpec* s1, bool
   }
   if (pair && !use_asm) api_throw(PGPU_ERR_UNSUPPORTED, "the pair kernel exists in assembly only");
   for (int i = 0; i < 3; ++i)
-    if (ss[i] && ss[i]->prog->needs_muls && !(pair && (s0.pair_lanes == 4 || s0.pair_lanes == 8)))
+    if (ss[i] && ss[i]->prog->needs_muls && !(pair && (s0.pair_lanes == 4 || s0.pair_lanes == 8 || s0.pair_lanes == 16)))
       api_throw(PGPU_ERR_UNSUPPORTED, "internal: VM_MULS on a kernel that does not implement it");
   if (pair && s0.pair_lanes == 1 && s0.pair_h > 37)
     for (int i = 0; i < 3; ++i)

@@ -163,6 +163,16 @@ def test_asm_generator_model():
                 assert len([l for l in body.splitlines() if l.strip() and not l.strip().startswith(".")]) - 8 * wl <= 4 * 7
             assert g.H == 4 * wl == g.WT and g.lds_bytes * 4 <= 160 * 1024
             continue
+        if (wl, k) in gen_vm_asm.PAIR16:
+            # sixteen-lane pair kernel: GenQ4's rows with eight slices per digit (a DPP row per number): the link by row_shr:8, the
+            # quotient digit's broadcast in two steps, neighbours by row_shl:1 with bound_ctrl (lane 15 reads zero)
+            for lbl, where, per_row in (("L_qs", "L_montsq:", 2 * wl), ("L_qm", "L_montmul:", 3 * wl)):
+                body = text.split(where)[1].split(lbl + ":")[1].split("s_cbranch_scc1 " + lbl)[0]
+                assert body.count("v_mad_u64_u32") == 4 * per_row
+                assert body.count("row_shr:8") == 4 and body.count("bank_mask:0xa") == 4 and body.count("bound_ctrl:1") == 4
+                assert len([l for l in body.splitlines() if l.strip() and not l.strip().startswith(".")]) - 4 * per_row <= 4 * 15
+            assert g.H == 8 * wl and g.NPB == 16 and g.lds_bytes * 4 <= 160 * 1024
+            continue
         if (wl, k) in gen_vm_asm.PAIR4:
             # four-lane pair kernel: a squaring is one pass of four-row bodies of 2 WL multiplies per lane; a product is ONE pass
             # too, with two multiplier streams (3 WL multiplies a row); one quotient link per row; no s_nop inside a row, and at

@@ -217,6 +217,10 @@ def test_pair_lanes_for_shared_exponents(q, numbers, have4, have8, lanes):
     assert q("pair_lanes_shared", numbers, 0, have4, have8) == [lanes]
     if not have8:
         assert q("pair_lanes_2or4", numbers, 0, have4) == [lanes]
+    # sixteen lanes (round 5) only where TWO such ladders side by side still leave every wave a SIMD of its own: up to 2 048 numbers, and
+    # only on top of eight
+    want16 = 16 if (have4 and have8 and numbers * 32 <= 65536) else lanes
+    assert q("pair_lanes_shared", numbers, 0, have4, have8, 1) == [want16]
 
 
 def test_pair_kernel_serves(q):
