@@ -567,12 +567,14 @@ uint32_t* dual_pow_pair(pgpu_ctx* ctx, const ModCtx& mc, const uint32_t* x, cons
   // A batch so small that eight lanes per number still leave every wave a SIMD of its own is bound by the ladder's latency: GenQ8
   // (76-limb digits over four lanes each; the radix changes R_74 <-> R_76 by one product on the way in and out, inside the program;
   // limb-major 5-bit tables -- the gathers of so few numbers are not what the launch waits for).  2 048 numbers: 36.6 -> 2x ms.
-  const bool eight = have4 && pi.consts8 && ctx->use_lanes8 &&
-                     plan::pair_lanes_shared(nb, plan::lanes_target(ctx->lanes_wanted, ctx->stream_cus), have4, true) == 8;
+  // (and sixteen -- GenQ16, 80-limb digits over eight lanes each -- for the smallest batches: plan::pair_lanes_shared)
+  const int wide = (have4 && pi.consts8 && ctx->use_lanes8)
+                       ? plan::pair_lanes_shared(nb, plan::lanes_target(ctx->lanes_wanted, ctx->stream_cus), have4, true, pi.consts16 && ctx->use_lanes16) : 0;
+  const bool eight = wide == 8 || wide == 16;
   // per-number window table number-major (VM_STORET / VM_MULVT5 / VM_MULVT): limb-major, the 16 384-number ladder of the DDLEQ
   // verifier fetched 98 GB of 32-byte sectors for its dword gathers in a 43 ms launch (profiles/r03_bench_traffic.txt)
   const bool nm4 = ctx->use_nm4 && !eight;
-  const int Hk = eight ? pi.h8 : H;                                        // limbs of a digit in the kernel's slots
+  const int Hk = wide == 16 ? pi.h16 : eight ? pi.h8 : H;                  // limbs of a digit in the kernel's slots
   const int wb = plan::dual_pair_window_bits(nb, 2 * Hk, nm4);             // gathers with 32-bit offsets
   if (!wb) return nullptr;
   const uint32_t tab2 = 5 + (uint32_t)perlane_table_slots(wb, nm4);
@@ -606,8 +608,8 @@ uint32_t* dual_pow_pair(pgpu_ctx* ctx, const ModCtx& mc, const uint32_t* x, cons
   if (eight) { pd.op(VM_MULC, 1); pd.op(VM_STORE, 3); }                                                      // radix R_76 -> R_74
   pd.end();
   SegSpec sp{&mc, &pd, pm, wb == 5 ? windows5_of(ctx, exps, we, nb) : exps};
-  sp.pair = eight ? pi.consts8 : pi.consts; sp.pair_n0inv = pi.root->n0inv; sp.pair_h = Hk; sp.pair_lanes = eight ? 8 : two ? 2 : 4;
-  if (eight) sp.tconsts = pi.tconsts8;
+  sp.pair = wide == 16 ? pi.consts16 : eight ? pi.consts8 : pi.consts; sp.pair_n0inv = pi.root->n0inv; sp.pair_h = Hk; sp.pair_lanes = eight ? wide : two ? 2 : 4;
+  if (eight) sp.tconsts = wide == 16 ? pi.tconsts16 : pi.tconsts8;
   run_vm(ctx, nb, sp, nullptr, true);
   if (eight) {
     uint32_t* back = ctx->ws_t<uint32_t>(SW * 4);                          // (pair_leave wants 74-limb digits and two scratch slots)
