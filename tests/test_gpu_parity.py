@@ -267,3 +267,42 @@ def test_wave_sliced_kernel(ctx, bits):
     finally:
         ctx.set_flag("asm", 1)
         ctx.set_flag("lanes_wanted", 0)
+
+
+@pytest.mark.parametrize("count", [1, 15, 17, 33, 2047, 2049, 4095, 4097, 8191, 8193])
+def test_batch_sizes_around_the_latency_kernels_limits(ctx, count):
+    """Round 5: 2048-bit keys pick their kernels by batch size -- sixteen lanes per number for r^n modulo n^2 up to 2 048 numbers, eight
+    for the CRT halves up to 8 192, four for the ladders modulo the primes, two lanes per digit modulo p^3, q^3 up to 4 096 (DESIGN.md
+    section 5) -- with blocks of 16 ... 64 numbers.  Counts that are no multiple of any block and counts on both sides of every limit:
+    Encrypt (public and key holder, both levels) -> Decrypt round trips, the first and last ciphertexts against the oracle, and the
+    same calls with the wide kernels switched off."""
+    import json, os
+    import paillier_amd as pa
+    from paillier_amd import ENC_LEVEL_TWO
+    k = json.load(open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "keys.json")))["paillier"]["2048"]
+    p, q = int(k["p"], 16), int(k["q"], 16)
+    n, lam = p * q, (p - 1) * (q - 1)
+    sk_o = po.SecretKey(N=n, G=n + 1, Lambda=lam)
+    pk = pa.PublicKey(ctx, n, n + 1)
+    sk = pa.SecretKey(ctx, pk, lam)
+    rng = random.Random(count)
+    ms = [rng.randrange(n) for _ in range(count)]
+    rs = [po.rand_unit(n, rng) for _ in range(count)]
+    cts = pk.EncryptWithRBatch(ms, rs)
+    for i in (0, count - 1):
+        assert cts[i] == po.encrypt_with_r(sk_o, ms[i], rs[i]).C
+    assert sk.EncryptWithRBatch(ms, rs) == cts                      # the key holder's form: through the primes and a lift
+    assert sk.DecryptBatch(cts) == ms
+    c2 = min(count, 4200)                                           # (level two: three times the bytes per number)
+    ct2 = sk.EncryptWithRBatch(cts[:c2], rs[:c2], ENC_LEVEL_TWO)
+    assert ct2[-1] == po.encrypt_with_r_at_level(sk_o, cts[c2 - 1], rs[c2 - 1], po.ENC_LEVEL_TWO).C
+    assert sk.DecryptBatch(ct2, level=ENC_LEVEL_TWO) == cts[:c2]
+    if count in (17, 2049, 4097):
+        try:
+            for flag in ("lanes8", "lanes16", "prime_lanes"):
+                ctx.set_flag(flag, 0)
+            assert pk.EncryptWithRBatch(ms, rs) == cts and sk.EncryptWithRBatch(ms, rs) == cts and sk.DecryptBatch(cts) == ms
+            assert sk.DecryptBatch(ct2, level=ENC_LEVEL_TWO) == cts[:c2]
+        finally:
+            for flag in ("lanes8", "lanes16", "prime_lanes"):
+                ctx.set_flag(flag, 1)
