@@ -130,14 +130,43 @@ uint32_t* dual_pow_n3(pgpu_ctx* ctx, const pgpu_pubkey* pk, const uint32_t* x, c
       ExclusiveScope excl(ctx, true);
       TriplePlan tx = triple_alloc(ctx, mn3, nb, 5 + perlane_table_slots(5, false));
       TriplePlan tw = triple_alloc(ctx, mn3, nb, 5 + 32);
+      // The smallest batches: FOUR lanes per digit (GenQ12, a DPP row per number; digits of h12 = 76 limbs in radix R_76).  The ladders run
+      // in slots of their own: the digit forms are zero-extended, change radix with the first product of their programs, and the product
+      // of the two results comes back to radix R_H with its last.
+      const TripleInfo& ti = mn3.triple;
+      const bool twelve = ctx->use_lanes16 && plan::triple_four_lanes_per_digit(nb, plan::lanes_target(ctx->lanes_wanted, ctx->stream_cus),
+                                                                                ti.h12 > 0 && vm_asm_available(ti.h12 / 4, 160), true);
+      auto plan12 = [&](int slots) {
+        TriplePlan t;
+        t.H = ti.h12; t.nb = nb; t.slot_words = (size_t)3 * ti.h12 * nb;
+        t.mem = ctx->ws_t<uint32_t>(t.slot_words * (size_t)slots);
+        return t;
+      };
+      TriplePlan tx12{}, tw12{};
+      if (twelve) { tx12 = plan12(5 + perlane_table_slots(5, false)); tw12 = plan12(5 + 32); }
+      auto widen = [&](const uint32_t* d74, uint32_t* d76) {          // digit form (3 x H limbs) -> 3 x h12 limbs, zero-extended
+        const size_t S74 = (size_t)H3 * nb, S76 = (size_t)ti.h12 * nb;
+        HIPCHK(hipMemsetAsync(d76, 0, 3 * S76 * 4, ctx->stream));
+        for (int d = 0; d < 3; ++d) launch_restride(d74 + (size_t)d * S74, nb, nb, nullptr, d76 + (size_t)d * S76, nb, H3, ctx->stream);
+      };
+      auto run12 = [&](const TriplePlan& t, const Prog& p, const uint32_t* exps) {
+        SegSpec sp{&mn3, &p, t.mem, exps};
+        sp.pair = ti.kconsts12; sp.pair_n0inv = ti.root->n0inv; sp.pair_h = ti.h12; sp.pair_lanes = 12; sp.tconsts = ti.tconsts12;
+        run_vm(ctx, nb, sp, nullptr, true);
+      };
       Fork ft(ctx, 3);
       ft.chain(2);
       triple_enter(ctx, mn3, pc.in(), tx, 0);
       {
         Prog px;
+        if (twelve) {
+          widen(tx.slot(0), tx12.slot(0));
+          px.op(VM_LOAD, 0); px.op(VM_MULC, 1); px.op(VM_STORE, 0);                     // radix R_H -> R_h12
+        }
         emit_modexp_perlane(px, W1, 0, NO_SLOT, 2, 3, 5, NO_SLOT, 0, 5, false);
         px.end();
-        triple_run(ctx, mn3, tx, px, triple_windows(ctx, e0, W1, nb, 5));
+        if (twelve) run12(tx12, px, triple_windows(ctx, e0, W1, nb, 5));
+        else triple_run(ctx, mn3, tx, px, triple_windows(ctx, e0, W1, nb, 5));
       }
       ft.chain(0);
       uint32_t* raw = nullptr;
@@ -150,14 +179,27 @@ uint32_t* dual_pow_n3(pgpu_ctx* ctx, const pgpu_pubkey* pk, const uint32_t* x, c
           triple_enter(ctx, mn3, pc.in() + pc.slot_words, tw, 0);
         }
         Prog pw;
+        if (twelve) {
+          widen(tw.slot(0), tw12.slot(0));
+          pw.op(VM_LOAD, 0); pw.op(VM_MULC, 1); pw.op(VM_STORE, 0);
+        }
         emit_modexp_shared(pw, pk->N, 0, NO_SLOT, 2, 3, 5, NO_SLOT, true, true);
         pw.end();
-        triple_run(ctx, mn3, tw, pw, nullptr);
+        if (twelve) run12(tw12, pw, nullptr);
+        else triple_run(ctx, mn3, tw, pw, nullptr);
         ft.join();
-        HIPCHK(hipMemcpyAsync(tw.slot(1), tx.slot(3), tw.slot_words * 4, hipMemcpyDeviceToDevice, ctx->stream));
         Prog pm;
-        pm.op(VM_LOAD, 3); pm.op(VM_MUL, 1); pm.op(VM_STORE, 3); pm.end();
-        triple_run(ctx, mn3, tw, pm, nullptr);
+        if (twelve) {
+          HIPCHK(hipMemcpyAsync(tw12.slot(1), tx12.slot(3), tw12.slot_words * 4, hipMemcpyDeviceToDevice, ctx->stream));
+          pm.op(VM_LOAD, 3); pm.op(VM_MUL, 1); pm.op(VM_MULC, 2); pm.op(VM_STORE, 3); pm.end();       // ... and back to radix R_H
+          run12(tw12, pm, nullptr);
+          const size_t S74 = (size_t)H3 * nb, S76 = (size_t)ti.h12 * nb;
+          for (int d = 0; d < 3; ++d) launch_restride(tw12.slot(3) + (size_t)d * S76, nb, nb, nullptr, tw.slot(3) + (size_t)d * S74, nb, H3, ctx->stream);
+        } else {
+          HIPCHK(hipMemcpyAsync(tw.slot(1), tx.slot(3), tw.slot_words * 4, hipMemcpyDeviceToDevice, ctx->stream));
+          pm.op(VM_LOAD, 3); pm.op(VM_MUL, 1); pm.op(VM_STORE, 3); pm.end();
+          triple_run(ctx, mn3, tw, pm, nullptr);
+        }
         triple_exit(ctx, mn3, tw, 3, pc.out(), nullptr);
         return pc.out();
       }

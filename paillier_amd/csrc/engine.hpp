@@ -353,6 +353,11 @@ struct TripleInfo {
   const uint32_t* dinv2 = nullptr;    // n^-1 mod 2^(28 WT(n^2))
   const uint32_t* n_limbs = nullptr;  // n   as WT(n) limbs
   const uint32_t* n2_limbs = nullptr; // n^2 as WT(n^2) limbs
+  // the sixteen-lane variant (GenQ12: four lanes per digit, digits of h12 limbs, radix R_h12): kconsts for h12-limb digits, and constants
+  // in digit form [3][3 h12]: 1 (= R_h12), R_h12^2 R_H^-1 (entry from the radix-R_H digit form), R_H (exit)
+  int h12 = 0;
+  const uint32_t* kconsts12 = nullptr;
+  const uint32_t* tconsts12 = nullptr;
   bool lanes6_only = false;           // the digit does not fit one lane (H > 74): only the two-lanes-per-digit kernel (GenQ6) serves it,
                                       // and that one runs shared-exponent and limb-major per-number programs only
 };
@@ -624,6 +629,7 @@ struct pgpu_pubkey {
   DevLimbs pairn_consts8, pairn_tconsts8;   // the same for the eight-lane pair kernel (76-limb digits) and its three constants
   DevLimbs triple_kconsts;        // n | (C1_i, C2_i) pairs | pad for the three-digit kernel (mn3->triple points here)
   DevLimbs triple_tconsts;        // its constants in digit form
+  DevLimbs triple_kconsts12, triple_tconsts12;   // the same for the sixteen-lane three-digit kernel (76-limb digits)
   std::vector<std::pair<int, int>> combine_consts;  // (total servers l, index of (4 (l!)^2)^-1 * R mod n in mn.consts)
 };
 

@@ -3661,6 +3661,223 @@ class GenQ6(GenQ4):
         return "\n".join(self.lines) + "\n"
 
 
+class GenQ12(GenQ6):
+    """The three-digit kernel with every digit sliced over FOUR lanes: 16 lanes per number -- one DPP row, a quad per digit:
+        quad 0 = the 19-limb slices of a0 | quad 1 = those of a2 | quad 2 = those of a1 | quad 3 = the helper digit
+    (digits of 76 limbs: the 74 limbs of a 2048-bit n padded, radix R_76 -- the host changes radix with one product on the way in and
+    one on the way out, as for GenQ8).  GenQ6's passes, products and carries with the exchanges of a quad per digit: quotient digit and
+    boundary column inside the quad, the links a0 -> a1 -> a2 by row_shr:8 and row_shl:4, the helper's copies by row_shr:4 / row_shr:12,
+    the sums of the partial products by row_shl:8 / row_shr:8 / row_shl:4.  A squaring is 76 rows of 38 multiplies per lane where GenQ6
+    has 74 rows of 74: for ladders modulo n^3 of at most 2 048 numbers (the verifier's W^n and x^(e0)), whose latency is the run time.
+    Shared-exponent programs and limb-major per-number windows only."""
+
+    def __init__(self, WL):
+        GenQ6.__init__(self, WL)
+        self.H = 4 * WL
+        self.WTslot = 12 * WL
+        self.WT = self.WTslot
+        self.NPB = BLOCK // 16
+        self.name = f"vm_asm_{WL}_160"
+        self.lanes_per_number = 16
+        self.lds_a = (4 * self.WLp * 4 + 15) // 16 * 16
+        self.v_park = self.n_vgpr                  # LDS address of this lane's parking rows (montmul)
+        self.n_vgpr += 1
+        assert self.n_vgpr <= 256
+        self.lds_c = self.lds_a + (self.WTslot + 1) * self.NPB * 4
+        self.lds_bytes = self.lds_c + WL * 128
+        assert self.lds_bytes < 65536
+        self.dpp_bcast = "quad_perm:[0,0,0,0]"
+        self.dpp_next = "quad_perm:[1,2,3,3]"
+        self.dpp_prev = "quad_perm:[0,0,1,2]"
+        self.npad = (self.H + 1) // 2 * 2
+
+    def set_exec16(self, mask16):
+        w = mask16 | (mask16 << 16)
+        self.e(f"s_mov_b32 exec_lo, {hex(w)}")
+        self.e(f"s_mov_b32 exec_hi, {hex(w)}")
+
+    def mask_digit_lanes(self, on):
+        if on:
+            self.set_exec16(0x0fff)
+        else:
+            self.e("s_mov_b64 exec, -1")
+
+    def prologue(self):
+        g, e = self, self.e
+        WL, NPB, H = self.WL, self.NPB, self.H
+        row = NPB * 4
+        e(f'.amdgcn_target "amdgcn-amd-amdhsa--gfx950"')
+        e(".text")
+        e(f".globl {self.name}")
+        e(".p2align 8")
+        e(f".type {self.name},@function")
+        e(f"{self.name}:")
+        self.select_segment()
+        e("s_load_dwordx8 s[4:11], s[0:1], 0x0")
+        e("s_load_dwordx4 s[12:15], s[0:1], 0x20")
+        e("s_waitcnt lgkmcnt(0)")
+        e("s_lshl_b32 s3, s15, 2")
+        e(f"v_and_b32 v{g.v_t1}, 15, v0")                 # k16
+        e(f"v_lshlrev_b32 v{g.v_caddr}, 3, v{g.v_t1}")    # this lane's column of the constants table
+        e(f"v_lshrrev_b32 v{g.v_t2}, 4, v0")              # gl
+        e(f"s_mul_i32 s{g.s_t0}, s2, {NPB}")
+        e(f"v_add_u32 v{g.v_t3}, s{g.s_t0}, v{g.v_t2}")   # g
+        # slot position of the lane: digit dd = (0, 2, 1, 2)[quad] (the helper aliases digit two; its stores are masked), slice s
+        e(f"v_lshrrev_b32 v{g.v_t4}, 2, v{g.v_t1}")       # q = k16 >> 2
+        e(f"v_and_b32 v{g.v_t5}, 1, v{g.v_t4}")           # t = q & 1
+        e(f"v_xor_b32 v{g.v_p0}, 1, v{g.v_t5}")           # t ^ 1
+        e(f"v_lshrrev_b32 v{g.v_p0 + 1}, 1, v{g.v_t4}")   # q >> 1
+        e(f"v_and_b32 v{g.v_p0}, v{g.v_p0}, v{g.v_p0 + 1}")
+        e(f"v_lshl_or_b32 v{g.v_t4}, v{g.v_t5}, 1, v{g.v_p0}")   # dd
+        e(f"v_and_b32 v{g.v_t5}, 3, v{g.v_t1}")           # s
+        e(f"v_lshl_or_b32 v{g.v_t4}, v{g.v_t4}, 2, v{g.v_t5}")   # kk = 4 dd + s
+        e(f"s_mul_i32 s{g.s_t1}, s15, {WL}")
+        e(f"v_mul_lo_u32 v{g.v_p0}, v{g.v_t4}, s{g.s_t1}")
+        e(f"v_add_lshl_u32 v{g.v_goff}, v{g.v_p0}, v{g.v_t3}, 2")
+        e(f"v_lshlrev_b32 v{g.v_aread}, 2, v{g.v_t2}")
+        e(f"v_add_u32 v{g.v_aread}, {self.lds_a}, v{g.v_aread}")
+        e(f"v_mul_u32_u24 v{g.v_p0}, {WL * NPB * 4}, v{g.v_t4}")
+        e(f"v_add_u32 v{g.v_awrite}, v{g.v_p0}, v{g.v_aread}")
+        e(f"v_mul_u32_u24 v{g.v_koff}, {WL * 4}, v{g.v_t4}")
+        e(f"v_mul_u32_u24 v{g.v_nbase}, {self.WLp * 4}, v{g.v_t5}")
+        # parking rows of a product's first pass: a0 in the rows of b0, a1 in those of b2, slice s at row s WL
+        e(f"v_mul_u32_u24 v{g.v_park}, {WL * row}, v{g.v_t5}")
+        e(f"v_add_u32 v{g.v_park}, v{g.v_park}, v{g.v_aread}")
+        e(f"v_lshrrev_b32 v{g.v_p0}, 3, v{g.v_t1}")        # 1 in quads 2, 3
+        e(f"v_mul_u32_u24 v{g.v_p0}, {2 * H * row}, v{g.v_p0}")
+        e(f"v_add_u32 v{g.v_park}, v{g.v_park}, v{g.v_p0}")
+        e(f"v_cmp_eq_u32 vcc, 0, v{g.v_t5}")
+        e("s_nop 1")
+        e(f"v_cndmask_b32 v{g.v_isfirst}, 0, -1, vcc")
+        e(f"v_cmp_ne_u32 vcc, 3, v{g.v_t5}")
+        e("s_nop 1")
+        e(f"v_cndmask_b32 v{g.v_notlast}, 0, -1, vcc")
+        for val, reg in ((8, g.v_l1mask), (4, g.v_l2mask)):
+            e(f"v_cmp_eq_u32 vcc, {val}, v{g.v_t1}")
+            e("s_nop 1")
+            e(f"v_cndmask_b32 v{reg}, 0, -1, vcc")
+        e(f"v_cmp_le_u32 vcc, 12, v{g.v_t1}")
+        e("s_nop 1")
+        e(f"v_cndmask_b32 v{g.v_hmask}, 0, -1, vcc")
+        e(f"v_add_u32 v{g.v_sh}, 4, v{g.v_t1}")
+        e(f"v_bfe_u32 v{g.v_sh}, v{g.v_sh}, 3, 1")         # 1 in the lanes of a2 and a1 (k16 = 4 .. 11): they double their multiplicand
+        # modulus n (4 slices) -> LDS -> this lane's slice in VGPRs
+        e(f"v_lshlrev_b32 v{g.v_t3}, 2, v0")
+        e(f"v_cmp_gt_u32 vcc, {WL}, v0")
+        e("s_nop 1")
+        e("s_and_saveexec_b64 s[96:97], vcc")
+        for sgi in range(4):
+            e(f"global_load_dword v{g.v_p1}, v{g.v_t3}, s[6:7] offset:{sgi * WL * 4}")
+            e("s_waitcnt vmcnt(0)")
+            e(f"ds_write_b32 v{g.v_t3}, v{g.v_p1} offset:{sgi * self.WLp * 4}")
+        # constants table: thread t < WL writes row t = (0 x 4 | C2 slices | C1 slices | 0 x 4), zero-extended to 64 bits
+        e(f"v_lshlrev_b32 v{g.v_t4}, 5, v{g.v_t3}")        # t * 128
+        e(f"v_lshlrev_b32 v{g.v_t5}, 1, v{g.v_t3}")        # t * 8: the pair (C1_t, C2_t)
+        e(f"v_mov_b32 v{g.v_y0}, 0")
+        e(f"v_mov_b32 v{g.v_y0 + 1}, 0")
+        for k in (0, 1, 2, 3, 12, 13, 14, 15):
+            e(f"ds_write_b64 v{g.v_t4}, {self.P(g.v_y0)} offset:{self.lds_c + 8 * k}")
+        for sgi in range(4):
+            e(f"global_load_dwordx2 {self.P(g.v_p0)}, v{g.v_t5}, s[6:7] offset:{4 * self.npad + 8 * WL * sgi}")
+            e("s_waitcnt vmcnt(0)")
+            e(f"v_mov_b32 v{g.v_y0}, v{g.v_p0 + 1}")       # (C2, 0)
+            e(f"v_mov_b32 v{g.v_p0 + 1}, 0")               # (C1, 0)
+            e(f"ds_write_b64 v{g.v_t4}, {self.P(g.v_p0)} offset:{self.lds_c + 8 * (8 + sgi)}")
+            e(f"ds_write_b64 v{g.v_t4}, {self.P(g.v_y0)} offset:{self.lds_c + 8 * (4 + sgi)}")
+        e("s_waitcnt lgkmcnt(0)")
+        e("s_mov_b64 exec, s[96:97]")
+        e("s_barrier")
+        for j in range(WL):
+            e(f"ds_read_b32 v{g.v_N + j}, v{g.v_nbase} offset:{4 * j}")
+        e("s_waitcnt lgkmcnt(0)")
+        for j in range(WL):
+            e(f"v_mov_b32 {self.X(j)}, 0")
+        self.init_row_regs()
+
+    def chain_steps(self, link2):
+        g = self
+        m = f"v{g.v_m}"
+        chain = [f"v_mul_lo_u32 {m}, {self.Tlo(0)}, s14"]
+        for ctrl, mask in [("row_shr:8", g.v_l1mask)] + ([("row_shl:4", g.v_l2mask)] if link2 else []):
+            chain += [f"v_and_b32_dpp v{g.v_d}, {m}, v{g.v_mask28} {ctrl} row_mask:0xf bank_mask:0xf",
+                      f"v_mad_i64_i32 {self.T(0)}, vcc, v{g.v_d}, v{mask}, {self.T(0)}",
+                      f"v_mul_lo_u32 {m}, {self.Tlo(0)}, s14"]
+        chain.append(f"v_and_b32_dpp {m}, {m}, v{g.v_mask28} {self.dpp_bcast} row_mask:0xf bank_mask:0xf")
+        return chain
+
+    def passes(self, tag, off_d, off_h, link2):
+        g, e = self, self.e
+        WL, H = self.WL, self.H
+        row = self.NPB * 4
+        for j in range(WL):                                      # accumulators <- (0 | C2 | C1 | 0) by quad
+            e(f"ds_read_b64 {self.T(j)}, v{g.v_caddr} offset:{self.lds_c + 128 * j}")
+        e(f"v_and_b32 v{g.v_t1}, {(off_h - off_d) * row}, v{g.v_hmask}")
+        e(f"v_add_u32 v{g.v_arow}, v{g.v_aread}, v{g.v_t1}")
+        if off_d:
+            e(f"v_add_u32 v{g.v_arow}, {off_d * row}, v{g.v_arow}")
+        self.read_pair(g.v_pa, g.v_arow, 0)
+        self.row_loop(tag, link2, False)
+
+    def montsq(self):
+        g, e = self, self.e
+        WL, H = self.WL, self.H
+        e("L_montsq:")
+        e("s_nop 1")
+        for j in range(WL):      # helper <- a1 (quad 3 takes quad 2's slices); a1, a2 double
+            e(f"v_mov_b32_dpp {self.X(j)}, {self.X(j)} row_shr:4 row_mask:0xf bank_mask:0x8")
+        for j in range(WL):
+            e(f"v_lshlrev_b32 {self.X(j)}, v{g.v_sh}, {self.X(j)}")
+        self.passes("s", 0, H, True)
+        self.normalize()
+        # a2 += a1 a1 R^-1 (helper): quad 1 += quad 3
+        self.set_exec16(0xf0f0)
+        e("s_nop 4")
+        for j in range(WL):
+            e(f"v_add_u32_dpp {self.X(j)}, {self.X(j)}, {self.X(j)} row_shl:8 row_mask:0xf bank_mask:0x2")
+        self.carry_X2()
+        e("s_mov_b64 exec, -1")
+        e("s_branch L_next")
+
+    def montmul(self):
+        g, e = self, self.e
+        WL, H = self.WL, self.H
+        row = self.NPB * 4
+        e("L_montmul:")
+        e("s_nop 1")
+        for j in range(WL):                                      # helper <- a0 (12 lanes down), every other lane keeps its digit
+            e(f"v_mov_b32_dpp {self.X(j)}, {self.X(j)} row_shr:12 row_mask:0xf bank_mask:0x8")
+        # pass 1: stream b0 in the digit lanes (a0 b0 -> a1 b0 -> a2 b0 chained), stream b2 in the helper lanes (a0 b2)
+        self.passes("m1", 0, 2 * H, True)
+        self.normalize(dst=self.Tlo)
+        # a0 and a1 still need their digits as multiplicands: park their results in the LDS rows of the finished streams
+        # (a0: rows of b0, a1: rows of b2); a2 and the helper are done: pass 2 runs with them masked off
+        self.set_exec16(0x0f0f)
+        for j in range(WL):
+            e(f"ds_write_b32 v{g.v_park}, {self.Tlo(j)} offset:{j * row}")
+        # pass 2: stream b1 in the lanes of a0, a1 (a0 b1 -> a1 b1 chained)
+        self.passes("m2", H, H, False)
+        self.normalize(dst=self.Tlo)
+        for j in range(WL):
+            e(f"ds_read_b32 {self.X(j)}, v{g.v_park} offset:{j * row}")    # lanes of a0, a1: the parked t00 / t10
+        e("s_waitcnt lgkmcnt(0)")
+        # c0 = t00 | c1 = t10 + t01 | c2 = t20 + t02 + t11
+        self.set_exec16(0xf0f0)
+        e("s_nop 4")
+        for j in range(WL):      # a2 <- t20 + t02 (helper, 8 lanes up)
+            e(f"v_add_u32_dpp {self.X(j)}, {self.Tlo(j)}, {self.Tlo(j)} row_shl:8 row_mask:0xf bank_mask:0x2")
+        self.set_exec16(0x0f0f)
+        e("s_nop 4")
+        for j in range(WL):      # a1 += t01 (pass two of a0, 8 lanes down)
+            e(f"v_add_u32_dpp {self.X(j)}, {self.Tlo(j)}, {self.X(j)} row_shr:8 row_mask:0xf bank_mask:0x4")
+        self.set_exec16(0x0ff0)
+        e("s_nop 4")
+        for j in range(WL):      # a2 += t11 (pass two of a1, 4 lanes up)
+            e(f"v_add_u32_dpp {self.X(j)}, {self.Tlo(j)}, {self.X(j)} row_shl:4 row_mask:0xf bank_mask:0x2")
+        self.carry_X2()
+        e("s_mov_b64 exec, -1")
+        e("s_branch L_next")
+
+
 class GenQ3(LaneRows, Gen):
     """Three-digit kernel for moduli N = n^3 with n PUBLIC (level-two Encrypt / ConstMult / NestedRandomize, the DDLEQ
     equations): the residue y R mod n^3 = a0 + a1 n + a2 n^2 (R = 2^(28 H), H = limbs of n, digits lazily reduced mod n)
@@ -4048,12 +4265,13 @@ class GenQ3(LaneRows, Gen):
         return "\n".join(self.lines) + "\n"
 
 
-SHAPES = [(74, 1), (37, 1), (55, 1), (55, 2), (74, 2), (55, 4), (74, 4), (42, 8), (37, 2), (37, 4), (10, 4), (37, 16), (55, 16), (74, 32), (55, 32), (37, 32), (37, 64), (19, 96), (10, 96), (10, 128), (74, 48), (37, 48), (55, 48), (55, 112), (37, 112), (19, 112)]
+SHAPES = [(74, 1), (37, 1), (55, 1), (55, 2), (74, 2), (55, 4), (74, 4), (42, 8), (37, 2), (37, 4), (10, 4), (37, 16), (55, 16), (74, 32), (55, 32), (37, 32), (37, 64), (19, 96), (10, 96), (10, 128), (74, 48), (37, 48), (55, 48), (55, 112), (37, 112), (19, 112), (19, 160)]
 PAIR = {(37, 16), (55, 16)}  # (H, 16): the pair kernel for N = p^2 with H-limb p (GenP); 16 is a tag, not a lane count
 PAIR4 = {(37, 64)}          # (WL, 64): GenQ4, the two digits of GenQ(2 WL) sliced over two lanes each
 PAIR8 = {(19, 96), (10, 96)}
 PAIR16 = {(10, 128)}        # (WL, 128): GenQ16, the two digits sliced over eight lanes each (80-limb digits)          # (WL, 96): GenQ8, the two digits sliced over four lanes each (76-limb digits)
-TRIPLE2 = {(55, 112), (37, 112), (19, 112)}   # (WL, 112): GenQ6, three digits of 2 WL limbs, two lanes each (+ two helper lanes)
+TRIPLE2 = {(55, 112), (37, 112), (19, 112)}
+TRIPLE4 = {(19, 160)}      # (WL, 160): GenQ12, three digits of 4 WL limbs, four lanes each (+ four helper lanes): a DPP row per number   # (WL, 112): GenQ6, three digits of 2 WL limbs, two lanes each (+ two helper lanes)
 PAIR2 = {(74, 32), (55, 32), (37, 32)}          # (H, 32): the two-lane pair kernel for N = n^2 with H-limb n (GenQ)
 WAVE_SLICED = {(74, 2), (55, 2)}     # shapes whose slices live in different waves (GenW) instead of neighbouring lanes (Gen)
 TRIPLE = {(74, 48), (37, 48), (55, 48)}        # (H, 48): GenQ3, residues modulo n^3 as three base-n digits in the lanes of a quad
@@ -4070,6 +4288,8 @@ def make_gen(wl, k):
         return GenQ8(wl)
     if (wl, k) in PAIR16:
         return GenQ16(wl)
+    if (wl, k) in TRIPLE4:
+        return GenQ12(wl)
     if (wl, k) in TRIPLE2:
         return GenQ6(wl)
     if (wl, k) in TRIPLE:

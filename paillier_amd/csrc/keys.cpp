@@ -229,6 +229,38 @@ int pgpu_pubkey_create(pgpu_ctx* ctx, const uint8_t* n_be, size_t n_len, const u
       setup_triple(*pk->mn3, pk->mn, pk->mn2, pk->triple_kconsts, pk->triple_tconsts, pk->ninv2k.d, pk->ninv2k_2.d, pk->n_limbs.d,
                    pk->n2_limbs.d);
       pk->mn3->triple.lanes6_only = !one_lane_digit;
+      {
+        // sixteen lanes per number (GenQ12): digits of h12 = H rounded up to four slices
+        const int H = pk->mn.WT, h12 = (H + 3) / 4 * 4;
+        if (one_lane_digit && two_lane_digit && vm_asm_available(h12 / 4, 160)) {
+          const std::vector<uint32_t> k12 = make_triple_kconsts(pk->N, h12);
+          const BigU rh = hostbig::shl(BigU(1), (size_t)LB * H) % n3, r12 = hostbig::shl(BigU(1), (size_t)LB * h12) % n3;
+          BigU rh_inv;
+          if (hostbig::modinv(rh, n3, rh_inv)) {
+            const BigU vals[3] = {r12, hostbig::mulmod(hostbig::mulmod(r12, r12, n3), rh_inv, n3), rh};
+            std::vector<uint32_t> t12;
+            for (const BigU& v : vals) {
+              BigU q1, d0, d1, d2;
+              hostbig::divmod(v, pk->N, q1, d0);
+              hostbig::divmod(q1, pk->N, d2, d1);
+              for (const BigU* dg : {&d0, &d1, &d2}) {
+                auto l = dg->to_limbs(LB, (size_t)h12);
+                t12.insert(t12.end(), l.begin(), l.end());
+              }
+            }
+            auto put = [&](DevLimbs& d, const std::vector<uint32_t>& v) {
+              d.w = (int)v.size();
+              HIPCHK(hipMalloc((void**)&d.d, v.size() * 4));
+              HIPCHK(hipMemcpy(d.d, v.data(), v.size() * 4, hipMemcpyHostToDevice));
+            };
+            put(pk->triple_kconsts12, k12);
+            put(pk->triple_tconsts12, t12);
+            pk->mn3->triple.h12 = h12;
+            pk->mn3->triple.kconsts12 = pk->triple_kconsts12.d;
+            pk->mn3->triple.tconsts12 = pk->triple_tconsts12.d;
+          }
+        }
+      }
     }
     pk->mn.upload();
     pk->mn2.upload();

@@ -117,6 +117,9 @@ inline int prime_lanes(size_t nb, size_t lt, bool have_sliced, bool enabled, int
 
 // three-digit kernel: two lanes per digit (GenQ6) for batches so small that eight lanes per number still leave every wave a SIMD
 inline bool triple_two_lanes_per_digit(size_t nb, size_t lt) { return nb * 8 <= lt; }
+// ... four lanes per digit (GenQ12, a DPP row per number) where the two ladders of dual_n3_two_ladders still find a SIMD per wave at sixteen
+// lanes per number each: up to 2 048 numbers
+inline bool triple_four_lanes_per_digit(size_t nb, size_t lt, bool have12, bool enabled) { return have12 && enabled && nb * 16 * 2 <= lt; }
 // ... and x^(e0) W^n modulo n^3 (the verifier, NestedRandomize) as TWO such ladders side by side instead of one interleaved chain while
 // both still find a SIMD per wave: up to 4 096 numbers
 inline bool dual_n3_two_ladders(size_t nb, size_t lt) { return nb * 8 * 2 <= lt; }

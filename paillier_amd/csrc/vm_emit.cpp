@@ -402,15 +402,15 @@ void run_vm(pgpu_ctx* ctx, size_t nb, const SegSpec& s0, const SegSpec* s1, bool
   if (s1 && pair != (s1->pair != nullptr)) api_throw(PGPU_ERR_INVALID, "segment kind mismatch");
   if (s2 && pair != (s2->pair != nullptr)) api_throw(PGPU_ERR_INVALID, "segment kind mismatch");
   if (pair) {
-    WL = s0.pair_lanes == 16 ? s0.pair_h / 8 : s0.pair_lanes == 8 ? s0.pair_h / 4 : (s0.pair_lanes == 4 || s0.pair_lanes == 6) ? s0.pair_h / 2 : s0.pair_h;
-    K = s0.pair_lanes == 16 ? 128 : s0.pair_lanes == 8 ? 96 : s0.pair_lanes == 6 ? 112 : s0.pair_lanes == 4 ? 64 : s0.pair_lanes == 3 ? 48 : s0.pair_lanes == 2 ? 32 : 16;   // tags of the pair kernels, not lane counts
+    WL = s0.pair_lanes == 16 ? s0.pair_h / 8 : (s0.pair_lanes == 8 || s0.pair_lanes == 12) ? s0.pair_h / 4 : (s0.pair_lanes == 4 || s0.pair_lanes == 6) ? s0.pair_h / 2 : s0.pair_h;
+    K = s0.pair_lanes == 16 ? 128 : s0.pair_lanes == 12 ? 160 : s0.pair_lanes == 8 ? 96 : s0.pair_lanes == 6 ? 112 : s0.pair_lanes == 4 ? 64 : s0.pair_lanes == 3 ? 48 : s0.pair_lanes == 2 ? 32 : 16;   // tags of the pair kernels, not lane counts
   } else {
     const plan::GenericShape gs = plan::generic_shape(WL, K, launch_nb, s2 ? 3 : s1 ? 2 : 1, plan::lanes_target(ctx->lanes_wanted, ctx->stream_cus),
                                                       ctx->use_w74 && ctx->use_asm);
     WL = gs.WL;
     K = gs.K;
   }
-  const uint32_t blocks_per_seg = (uint32_t)(launch_nb * (pair ? (s0.pair_lanes == 3 ? 4 : s0.pair_lanes == 6 ? 8 : s0.pair_lanes) : K) / VM_BLOCK);
+  const uint32_t blocks_per_seg = (uint32_t)(launch_nb * (pair ? (s0.pair_lanes == 3 ? 4 : s0.pair_lanes == 6 ? 8 : s0.pair_lanes == 12 ? 16 : s0.pair_lanes) : K) / VM_BLOCK);
   a.seg0_blocks = blocks_per_seg;
   a.seg1_blocks = blocks_per_seg;
   const uint32_t blocks = blocks_per_seg * (s2 ? 3 : s1 ? 2 : 1);
@@ -425,7 +425,7 @@ void run_vm(pgpu_ctx* ctx, size_t nb, const SegSpec& s0, const SegSpec* s1, bool
   const bool nm4_kernel = nm4_generic || (pair && ((s0.pair_lanes == 1 && s0.pair_h == 37) || s0.pair_lanes == 2 || s0.pair_lanes == 4 || s0.pair_lanes == 3));
   const bool use_asm = ctx->use_asm && vm_asm_available(WL, K) && s0.prog->asm_ok && (!s1 || s1->prog->asm_ok) &&
                        (!s2 || s2->prog->asm_ok) && (!nm_tables || (nm4_generic ? !mulv7 : (pair && (mulv7 ? s0.pair_lanes == 3 : nm4 ? nm4_kernel : (s0.pair_lanes == 3 || nm4_kernel))))) &&
-                       plan::gather_fits(nb, (s0.pair_lanes == 3 || s0.pair_lanes == 6) ? 3 * s0.pair_h : mc->WT,
+                       plan::gather_fits(nb, (s0.pair_lanes == 3 || s0.pair_lanes == 6 || s0.pair_lanes == 12) ? 3 * s0.pair_h : mc->WT,
                                          (int)std::max(s0.prog->gather_slots, std::max(s1 ? s1->prog->gather_slots : 1u, s2 ? s2->prog->gather_slots : 1u)));
   pgpu_ctx::Ev* ev = nullptr;
   if (profile) {
@@ -436,7 +436,7 @@ void run_vm(pgpu_ctx* ctx, size_t nb, const SegSpec& s0, const SegSpec* s1, bool
     // squaring rows: K == 1 triangular (WT^2 + WT(WT-1)/2 + WT); K == 2 slice-level symmetry (product part 1.5 WL^2 per lane)
     double sq = full;
     double mulp = full;
-    if (pair && (s0.pair_lanes == 3 || s0.pair_lanes == 6)) {   // GenQ3 / GenQ6: a squaring is one pass, a product 6 blocks (its second pass runs half the lanes)
+    if (pair && (s0.pair_lanes == 3 || s0.pair_lanes == 6 || s0.pair_lanes == 12)) {   // GenQ3 / GenQ6 / GenQ12: a squaring is one pass, a product 6 blocks (its second pass runs half the lanes)
       const double H = s0.pair_h;
       mulp = 12.0 * H * H;
       sq = 8.0 * H * H;

@@ -184,6 +184,16 @@ def test_asm_generator_model():
                 assert len([l for l in body.splitlines() if l.strip() and not l.strip().startswith(".")]) - 4 * per_row <= 4 * 11
             assert g.lds_bytes * 2 <= 160 * 1024
             continue
+        if (wl, k) in gen_vm_asm.TRIPLE4:
+            # three-digit kernel with four lanes per digit (a quad per digit, a DPP row per number): GenQ6's passes with the links by
+            # row_shr:8 / row_shl:4
+            for lbl, where, hops in (("L_qs", "L_montsq:", 2), ("L_qm1", "L_montmul:", 2), ("L_qm2", "L_montmul:", 1)):
+                body = text.split(where)[1].split(lbl + ":")[1].split("s_cbranch_scc1 " + lbl)[0]
+                assert body.count("v_mad_u64_u32") == 4 * 2 * wl
+                assert body.count("v_mad_i64_i32") == 4 * hops and body.count("s_nop") == 0
+                assert body.count("row_shr:8") == 4 and body.count("row_shl:4") == (4 if hops == 2 else 0)
+            assert g.H == 4 * wl and g.NPB == 16 and g.n_vgpr <= 256 and g.lds_bytes * 4 <= 160 * 1024
+            continue
         if (wl, k) in gen_vm_asm.TRIPLE2:
             # three-digit kernel with two lanes per digit: four-row bodies of 2 WL multiplies per lane in every pass (squaring: one
             # pass; product: two), both quotient links in the linked passes (row_shr:4, row_shl:2), one in pass two of a product

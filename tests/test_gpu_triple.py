@@ -145,21 +145,24 @@ def test_ddleq_verify_2048_on_and_off(ctx):
     wrong = [st[(i["s"] + 1) % 4]["ct2"] for i in ins]
     fs_bad = list(fs)
     fs_bad[3] ^= 1 << 4000
-    # (triple, lanes8): a batch this small takes two lanes per digit (vm_asm_37_112, limb-major 5-bit tables) unless lanes8 is off --
-    # then the one-lane digits with number-major 7-bit tables (vm_asm_74_48); triple off: the generic kernel
-    for flag, l8, suffix in ((1, 1, "_112"), (1, 0, "_48"), (0, 1, None)):
+    # (triple, lanes8, lanes16): a batch this small takes four lanes per digit (vm_asm_19_160, a DPP row per number: round 5) unless
+    # lanes16 is off -- then two lanes per digit (vm_asm_37_112, limb-major 5-bit tables) -- or lanes8 is off -- then the one-lane digits
+    # with number-major 7-bit tables (vm_asm_74_48); triple off: the generic kernel
+    for flag, l8, l16, suffix in ((1, 1, 1, "_160"), (1, 1, 0, "_112"), (1, 0, 1, "_48"), (0, 1, 1, None)):
         ctx.set_flag("triple", flag)
         ctx.set_flag("lanes8", l8)
+        ctx.set_flag("lanes16", l16)
         try:
             assert pk.VerifyDDLEQInstancesBatch(col("ct1"), col("ct2"), xs, ys, al, es, fs) == [True] * 16
             kern = ctx.last_profile()["kernel"]
-            assert kern.endswith(suffix) if suffix else not (kern.endswith("_48") or kern.endswith("_112")), kern
+            assert kern.endswith(suffix) if suffix else not (kern.endswith("_48") or kern.endswith("_112") or kern.endswith("_160")), kern
             assert pk.VerifyDDLEQInstancesBatch(col("ct1"), wrong, xs, ys, al, es, fs) == [bool(i["verify_wrong_ct2"]) for i in ins]
             got = pk.VerifyDDLEQInstancesBatch(col("ct1"), col("ct2"), xs, ys, al, es, fs_bad)
             assert got == [i != 3 for i in range(16)]
         finally:
             ctx.set_flag("triple", 1)
             ctx.set_flag("lanes8", 1)
+            ctx.set_flag("lanes16", 1)
 
 
 def test_split_through_n_squared_on_and_off(ctx):

@@ -274,6 +274,12 @@ def test_cube_ladders_on_two_lanes_per_digit(q):
     assert q("crt_triple_lanes6", 256, 0, 0, 1) == [0] and q("crt_triple_lanes6", 256, 0, 1, 0) == [0]
 
 
+def test_three_digit_kernel_on_four_lanes_per_digit(q):
+    """The verifier's two ladders modulo n^3 side by side at sixteen lanes per number each: up to 2 048 numbers."""
+    assert q("triple_four_lanes_per_digit", 2048, 0, 1, 1) == [1] and q("triple_four_lanes_per_digit", 2304, 0, 1, 1) == [0]
+    assert q("triple_four_lanes_per_digit", 256, 0, 0, 1) == [0] and q("triple_four_lanes_per_digit", 256, 0, 1, 0) == [0]
+
+
 def test_dual_ladder_windows_and_tables(q):
     W2 = 148
     assert q("dual_pair_window_bits", 16384, W2, 1) == [5] and q("dual_pair_window_bits", 61440, W2, 1) == [5]
