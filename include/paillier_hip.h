@@ -98,7 +98,7 @@ int pgpu_ctx_last_profile(pgpu_ctx* ctx, double* vm_ms, int* vm_launches, double
  * ladders on ct1 itself; non-unit inputs always take those); "late" (default 1): with fewer than four instances per statement (and a batch that
  * fills the chip) the prover's response goes through the structure as well, AFTER the hash: the level-two plaintext of b for the statements
  * that have an instance with challenge bit 1 only, one ladder modulo the primes, one lift (0: one ladder of 3 071 squarings modulo p^3, q^3
- * on s and b themselves); "lanes16" (default 1): shared-exponent ladders modulo n^2 of up to 2 048 numbers run on sixteen lanes per number
+ * on s and b themselves); "lanes16" (default 1): ladders modulo n^2 of up to 2 048 numbers -- and the verifier's two ladders modulo n^3 -- run on sixteen lanes per number
  * (0: eight); "prime_lanes" (default 1): the key holder's ladders modulo the primes of a 2048-bit key take four lanes of 10 limbs
  * per number while the batch (up to 8 192 numbers) leaves every wave a SIMD of its own (0: one lane per number throughout); "base_early" (default 1): the links of the prover's side chains -- the per-statement structure chain (ct1 modulo
  * the primes, its plaintext) and the preparation of the response -- run beside the main stream's ladders instead of waiting for an empty
