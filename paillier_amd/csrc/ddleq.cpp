@@ -133,27 +133,12 @@ uint32_t* dual_pow_n3(pgpu_ctx* ctx, const pgpu_pubkey* pk, const uint32_t* x, c
       // The smallest batches: FOUR lanes per digit (GenQ12, a DPP row per number; digits of h12 = 76 limbs in radix R_76).  The ladders run
       // in slots of their own: the digit forms are zero-extended, change radix with the first product of their programs, and the product
       // of the two results comes back to radix R_H with its last.
-      const TripleInfo& ti = mn3.triple;
-      const bool twelve = ctx->use_lanes16 && plan::triple_four_lanes_per_digit(nb, plan::lanes_target(ctx->lanes_wanted, ctx->stream_cus),
-                                                                                ti.h12 > 0 && vm_asm_available(ti.h12 / 4, 160), true);
-      auto plan12 = [&](int slots) {
-        TriplePlan t;
-        t.H = ti.h12; t.nb = nb; t.slot_words = (size_t)3 * ti.h12 * nb;
-        t.mem = ctx->ws_t<uint32_t>(t.slot_words * (size_t)slots);
-        return t;
-      };
+      const bool twelve = triple12_available(ctx, mn3) &&
+                          plan::triple_four_lanes_per_digit(nb, plan::lanes_target(ctx->lanes_wanted, ctx->stream_cus), true, true, 2);
       TriplePlan tx12{}, tw12{};
-      if (twelve) { tx12 = plan12(5 + perlane_table_slots(5, false)); tw12 = plan12(5 + 32); }
-      auto widen = [&](const uint32_t* d74, uint32_t* d76) {          // digit form (3 x H limbs) -> 3 x h12 limbs, zero-extended
-        const size_t S74 = (size_t)H3 * nb, S76 = (size_t)ti.h12 * nb;
-        HIPCHK(hipMemsetAsync(d76, 0, 3 * S76 * 4, ctx->stream));
-        for (int d = 0; d < 3; ++d) launch_restride(d74 + (size_t)d * S74, nb, nb, nullptr, d76 + (size_t)d * S76, nb, H3, ctx->stream);
-      };
-      auto run12 = [&](const TriplePlan& t, const Prog& p, const uint32_t* exps) {
-        SegSpec sp{&mn3, &p, t.mem, exps};
-        sp.pair = ti.kconsts12; sp.pair_n0inv = ti.root->n0inv; sp.pair_h = ti.h12; sp.pair_lanes = 12; sp.tconsts = ti.tconsts12;
-        run_vm(ctx, nb, sp, nullptr, true);
-      };
+      if (twelve) { tx12 = triple_alloc12(ctx, mn3, nb, 5 + perlane_table_slots(5, false)); tw12 = triple_alloc12(ctx, mn3, nb, 5 + 32); }
+      auto widen = [&](const uint32_t* d74, uint32_t* d76) { triple_widen12(ctx, mn3, d74, d76, nb); };
+      auto run12 = [&](const TriplePlan& t, const Prog& p, const uint32_t* exps) { triple_run12(ctx, mn3, t, p, exps); };
       Fork ft(ctx, 3);
       ft.chain(2);
       triple_enter(ctx, mn3, pc.in(), tx, 0);
@@ -193,8 +178,7 @@ uint32_t* dual_pow_n3(pgpu_ctx* ctx, const pgpu_pubkey* pk, const uint32_t* x, c
           HIPCHK(hipMemcpyAsync(tw12.slot(1), tx12.slot(3), tw12.slot_words * 4, hipMemcpyDeviceToDevice, ctx->stream));
           pm.op(VM_LOAD, 3); pm.op(VM_MUL, 1); pm.op(VM_MULC, 2); pm.op(VM_STORE, 3); pm.end();       // ... and back to radix R_H
           run12(tw12, pm, nullptr);
-          const size_t S74 = (size_t)H3 * nb, S76 = (size_t)ti.h12 * nb;
-          for (int d = 0; d < 3; ++d) launch_restride(tw12.slot(3) + (size_t)d * S76, nb, nb, nullptr, tw.slot(3) + (size_t)d * S74, nb, H3, ctx->stream);
+          triple_narrow12(ctx, mn3, tw12.slot(3), tw.slot(3), nb);
         } else {
           HIPCHK(hipMemcpyAsync(tw.slot(1), tx.slot(3), tw.slot_words * 4, hipMemcpyDeviceToDevice, ctx->stream));
           pm.op(VM_LOAD, 3); pm.op(VM_MUL, 1); pm.op(VM_STORE, 3); pm.end();

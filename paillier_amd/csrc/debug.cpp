@@ -144,7 +144,7 @@ int pgpu_plan_query(const char* what, const uint64_t* a, int nargs, int64_t* out
   if (w == "prime_lanes" && need(4, 1)) { out[0] = plan::prime_lanes((size_t)a[0], lt(1), a[2] != 0, a[3] != 0, nargs > 4 ? (int)a[4] : 1); return 1; }
   if (w == "crt_pair_lanes8" && need(4, 1)) { out[0] = plan::crt_pair_lanes8((size_t)a[0], lt(1), a[2] != 0, a[3] != 0, nargs > 4 ? (int)a[4] : 1); return 1; }
   if (w == "crt_triple_lanes6" && need(4, 1)) { out[0] = plan::crt_triple_lanes6((size_t)a[0], lt(1), a[2] != 0, a[3] != 0, nargs > 4 ? (int)a[4] : 1); return 1; }
-  if (w == "triple_four_lanes_per_digit" && need(4, 1)) { out[0] = plan::triple_four_lanes_per_digit((size_t)a[0], lt(1), a[2] != 0, a[3] != 0); return 1; }
+  if (w == "triple_four_lanes_per_digit" && need(4, 1)) { out[0] = plan::triple_four_lanes_per_digit((size_t)a[0], lt(1), a[2] != 0, a[3] != 0, nargs > 4 ? (int)a[4] : 2); return 1; }
   if (w == "dual_pair_window_bits" && need(3, 1)) { out[0] = plan::dual_pair_window_bits((size_t)a[0], (int)a[1], a[2] != 0); return 1; }
   if (w == "pair_nm4_fits" && need(2, 1)) { out[0] = plan::pair_nm4_fits((size_t)a[0], (int)a[1]); return 1; }
   if (w == "shared_chain_pays" && need(2, 1)) { out[0] = plan::shared_chain_pays((size_t)a[0], lt(1)); return 1; }

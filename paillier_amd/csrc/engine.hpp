@@ -760,6 +760,13 @@ struct TriplePlan {
 };
 // the ladders x^(e[half]) modulo p^3 | q^3 in digit form, both halves in one launch: slot 0 -> slot 3 of tp / tq (table from slot 5), on one
 // lane per digit or -- small batches -- two (plan::crt_triple_lanes6)
+// the three-digit kernel with four lanes per digit (GenQ12: slots of 3 x h12 limbs, radix R_h12; constants of mc.triple: 0 one, 1 entry from
+// the radix-R_H digit form, 2 exit): a plan of its own, digit forms zero-extended into it / cut back out of it, and the launch
+bool triple12_available(pgpu_ctx* ctx, const ModCtx& mc);
+TriplePlan triple_alloc12(pgpu_ctx* ctx, const ModCtx& mc, size_t nb, int slots);
+void triple_widen12(pgpu_ctx* ctx, const ModCtx& mc, const uint32_t* digits, uint32_t* digits12, size_t nb);
+void triple_narrow12(pgpu_ctx* ctx, const ModCtx& mc, const uint32_t* digits12, uint32_t* digits, size_t nb);
+void triple_run12(pgpu_ctx* ctx, const ModCtx& mc, const TriplePlan& t12, const Prog& p, const uint32_t* exps);
 void crt_triple_ladders(const pgpu_seckey* sk, const BigU e[2], const TriplePlan& tp, const TriplePlan& tq, size_t nb, int beside = 1);
 
 ModexpPlan modexp_alloc(pgpu_ctx* ctx, const ModCtx& mc, size_t nb, int table_slots);

@@ -177,6 +177,36 @@ void triple_exit(pgpu_ctx* ctx, const ModCtx& mc, const TriplePlan& tp, uint32_t
   HIPCHK(hipMemcpyAsync(out, gm + 2 * S3, S3 * 4, hipMemcpyDeviceToDevice, ctx->stream));
 }
 
+bool triple12_available(pgpu_ctx* ctx, const ModCtx& mc) {
+  const TripleInfo& ti = mc.triple;
+  return ti.h12 > 0 && ctx->use_asm && ctx->use_lanes8 && ctx->use_lanes16 && vm_asm_available(ti.h12 / 4, 160);
+}
+TriplePlan triple_alloc12(pgpu_ctx* ctx, const ModCtx& mc, size_t nb, int slots) {
+  TriplePlan t;
+  t.H = mc.triple.h12;
+  t.nb = nb;
+  t.slot_words = (size_t)3 * t.H * nb;
+  t.mem = ctx->ws_t<uint32_t>(t.slot_words * (size_t)slots);
+  return t;
+}
+void triple_widen12(pgpu_ctx* ctx, const ModCtx& mc, const uint32_t* digits, uint32_t* digits12, size_t nb) {
+  const int H = mc.triple.root->WT, H12 = mc.triple.h12;
+  const size_t S = (size_t)H * nb, S12 = (size_t)H12 * nb;
+  HIPCHK(hipMemsetAsync(digits12, 0, 3 * S12 * 4, ctx->stream));
+  for (int d = 0; d < 3; ++d) launch_restride(digits + (size_t)d * S, nb, nb, nullptr, digits12 + (size_t)d * S12, nb, H, ctx->stream);
+}
+void triple_narrow12(pgpu_ctx* ctx, const ModCtx& mc, const uint32_t* digits12, uint32_t* digits, size_t nb) {
+  const int H = mc.triple.root->WT, H12 = mc.triple.h12;
+  const size_t S = (size_t)H * nb, S12 = (size_t)H12 * nb;
+  for (int d = 0; d < 3; ++d) launch_restride(digits12 + (size_t)d * S12, nb, nb, nullptr, digits + (size_t)d * S, nb, H, ctx->stream);
+}
+void triple_run12(pgpu_ctx* ctx, const ModCtx& mc, const TriplePlan& t12, const Prog& p, const uint32_t* exps) {
+  const TripleInfo& ti = mc.triple;
+  SegSpec sp{&mc, &p, t12.mem, exps};
+  sp.pair = ti.kconsts12; sp.pair_n0inv = ti.root->n0inv; sp.pair_h = ti.h12; sp.pair_lanes = 12; sp.tconsts = ti.tconsts12;
+  run_vm(ctx, t12.nb, sp, nullptr, true);
+}
+
 void triple_run(pgpu_ctx* ctx, const ModCtx& mc, const TriplePlan& tp, const Prog& p, const uint32_t* exps) {
   const TripleInfo& ti = mc.triple;
   SegSpec sp{&mc, &p, tp.mem, exps};
@@ -205,6 +235,21 @@ void modexp_triple(pgpu_ctx* ctx, const ModCtx& mc, const ModexpPlan& pl, const 
   if (pair_digits) triple_from_pair(ctx, pair_digits, tp, 0);
   else triple_enter(ctx, mc, pl.in(), tp, 0);
   Prog p;
+  if (!exps && triple12_available(ctx, mc) &&
+      plan::triple_four_lanes_per_digit(pl.nb, plan::lanes_target(ctx->lanes_wanted, ctx->stream_cus), true, true, 1)) {
+    // a lone shared-exponent ladder of a batch that leaves most SIMDs empty (level-two Encrypt's (r^n)^n of up to 4 096 numbers): four
+    // lanes per digit -- slots of 3 x 76 limbs of their own, radix R_H -> R_76 with the first product of the program, back with its last
+    TriplePlan t12 = triple_alloc12(ctx, mc, pl.nb, 5 + 32);
+    triple_widen12(ctx, mc, tp.slot(0), t12.slot(0), pl.nb);
+    p.op(VM_LOAD, 0); p.op(VM_MULC, 1); p.op(VM_STORE, 0);
+    emit_modexp_shared(p, *e, 0, NO_SLOT, 2, 3, 5, NO_SLOT, true, true);
+    p.op(VM_LOAD, 3); p.op(VM_MULC, 2); p.op(VM_STORE, 3);
+    p.end();
+    triple_run12(ctx, mc, t12, p, nullptr);
+    triple_narrow12(ctx, mc, t12.slot(3), tp.slot(3), pl.nb);
+    triple_exit(ctx, mc, tp, 3, pl.out(), use_post ? pl.post() : nullptr);
+    return;
+  }
   if (exps) {
     emit_modexp_perlane(p, we, 0, NO_SLOT, 2, 3, 5, NO_SLOT, 0, wb, nm5);
     exps = triple_windows(ctx, exps, we, pl.nb, wb);

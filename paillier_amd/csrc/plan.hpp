@@ -119,7 +119,10 @@ inline int prime_lanes(size_t nb, size_t lt, bool have_sliced, bool enabled, int
 inline bool triple_two_lanes_per_digit(size_t nb, size_t lt) { return nb * 8 <= lt; }
 // ... four lanes per digit (GenQ12, a DPP row per number) where the two ladders of dual_n3_two_ladders still find a SIMD per wave at sixteen
 // lanes per number each: up to 2 048 numbers
-inline bool triple_four_lanes_per_digit(size_t nb, size_t lt, bool have12, bool enabled) { return have12 && enabled && nb * 16 * 2 <= lt; }
+// (`ladders`: how many such launches run side by side -- the verifier's two; a lone ladder, level-two Encrypt's (r^n)^n, up to 4 096)
+inline bool triple_four_lanes_per_digit(size_t nb, size_t lt, bool have12, bool enabled, int ladders = 2) {
+  return have12 && enabled && nb * 16 * (size_t)ladders <= lt;
+}
 // ... and x^(e0) W^n modulo n^3 (the verifier, NestedRandomize) as TWO such ladders side by side instead of one interleaved chain while
 // both still find a SIMD per wave: up to 4 096 numbers
 inline bool dual_n3_two_ladders(size_t nb, size_t lt) { return nb * 8 * 2 <= lt; }

@@ -278,6 +278,8 @@ def test_three_digit_kernel_on_four_lanes_per_digit(q):
     """The verifier's two ladders modulo n^3 side by side at sixteen lanes per number each: up to 2 048 numbers."""
     assert q("triple_four_lanes_per_digit", 2048, 0, 1, 1) == [1] and q("triple_four_lanes_per_digit", 2304, 0, 1, 1) == [0]
     assert q("triple_four_lanes_per_digit", 256, 0, 0, 1) == [0] and q("triple_four_lanes_per_digit", 256, 0, 1, 0) == [0]
+    # a lone ladder (level-two Encrypt's (r^n)^n): up to 4 096
+    assert q("triple_four_lanes_per_digit", 4096, 0, 1, 1, 1) == [1] and q("triple_four_lanes_per_digit", 4352, 0, 1, 1, 1) == [0]
 
 
 def test_dual_ladder_windows_and_tables(q):
