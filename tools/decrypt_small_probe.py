@@ -27,7 +27,7 @@ for B in [int(a) for a in sys.argv[1:]] or (256, 1024, 2048, 4096, 8192):
     c1 = torch.from_numpy(np.ascontiguousarray(raw[:, :512])).to(dev); c2 = torch.from_numpy(raw).to(dev)
     o1 = torch.zeros((B, 256), dtype=torch.uint8, device=dev); o2 = torch.zeros((B, 512), dtype=torch.uint8, device=dev)
     m = torch.from_numpy(np.ascontiguousarray(raw[:, 512:])).to(dev); r = torch.from_numpy(np.ascontiguousarray(raw[:, 256:512] | 1)).to(dev)
-    rows = {"decrypt": {}, "decrypt_l2": {}, "encrypt": {}}
+    rows = {"decrypt": {}, "decrypt_l2": {}, "encrypt": {}, "encrypt_l2": {}}
     for flag, on in (("lanes8", 1), ("lanes8", 0)):
         ctx.set_flag(flag, on)
         rows["decrypt"]["wide" if on else "narrow"] = best(lambda: sk.decrypt_raw(B, c1.data_ptr(), 512, o1.data_ptr(), 256, MEM_DEVICE))
@@ -36,6 +36,8 @@ for B in [int(a) for a in sys.argv[1:]] or (256, 1024, 2048, 4096, 8192):
     for on in (1, 0):
         ctx.set_flag("lanes16", on)
         rows["encrypt"]["wide" if on else "narrow"] = best(lambda: pk.encrypt_with_r_raw(B, m.data_ptr(), 256, r.data_ptr(), 256, c1.data_ptr(), 512, MEM_DEVICE))
+        # level two: (r^n mod n^2)^n mod n^3 -- sixteen lanes, then four lanes per digit (vm_asm_19_160) against eight and two (vm_asm_37_112)
+        rows["encrypt_l2"]["wide" if on else "narrow"] = best(lambda: pk.encrypt_with_r_raw(B, c1.data_ptr(), 512, r.data_ptr(), 256, c2.data_ptr(), 768, MEM_DEVICE, level=ENC_LEVEL_TWO))
     ctx.set_flag("lanes16", 1)
     for k, v in rows.items():
         print(json.dumps({"call": k, "batch": B, **v}), flush=True)
